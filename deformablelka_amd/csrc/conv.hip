@@ -1,0 +1,292 @@
+// General grouped N-d convolution (forward, data gradient, weight gradient) — the nn.Conv3d / nn.Conv2d calls
+// that sit on the D-LKA path: depthwise 5^3 and 7^3-dilation-3
+// (3D/d_lka_former/network_architecture/synapse/transformerblock.py:637-638), the dense offset-predict conv
+// C->81 (synapse/deform_conv.py:80-85), the 1x1x1 projections (transformerblock.py:641,659,662) and the 2-D
+// offset nets (2D/deformable_LKA/deformable_LKA.py:10-16).  In the reference these run in cuDNN.
+//
+// This file is the GENERAL direct path (any geometry).  One work-item per output voxel, COB output channels in
+// registers, weights wave-uniform through the scalar cache, lanes consecutive along W (coalesced).
+// Shape-specialised LDS-tiled / MFMA kernels for the hot shapes are in conv_tiled.hip.
+#include "dlka_kernels.h"
+
+namespace dlka {
+
+static int pick_pow2_upto32(int n)
+{
+    if (n >= 32) return 32;
+    int c = 1;
+    while (c < n) c <<= 1;
+    return c;
+}
+
+int conv_fwd_wt_floats(const Geom &g) { return g.group * g.K * g.Cg * round_up(g.Og, pick_pow2_upto32(g.Og)); }
+int conv_bwd_wb_floats(const Geom &g) { return g.group * g.K * g.Og * round_up(g.Cg, pick_pow2_upto32(g.Cg)); }
+
+// W[co][cg][tap] -> Wb[g][tap][o][CgP]  (for the data gradient: the Cg weights multiplying one grad_out value are contiguous)
+template <typename T>
+__global__ void relayout_weight_bwd_kernel(const T *__restrict__ w, float *__restrict__ wb, int group, int Og, int Cg, int K, int CgP)
+{
+    const int n = group * K * Og * CgP;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int cg = i % CgP, o = (i / CgP) % Og, tap = (i / CgP / Og) % K, g = i / CgP / Og / K;
+        wb[i] = (cg < Cg) ? ldf(w + ((long)(g * Og + o) * Cg + cg) * K + tap) : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: grid = (voxel tiles, group * OgP/COB, B)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int COB>
+__global__ __launch_bounds__(DLKA_THREADS) void conv_fwd_kernel(
+    const T *__restrict__ x, const float *__restrict__ wt, const T *__restrict__ bias, T *__restrict__ out, Geom g, int OgP)
+{
+    const int v = blockIdx.x * DLKA_THREADS + threadIdx.x;
+    const int chunks = OgP / COB;
+    const int gi = blockIdx.y / chunks, co0 = (blockIdx.y % chunks) * COB;
+    const int b = blockIdx.z;
+    if (v >= g.No) return;
+    const int ow = v % g.Wo, oh = (v / g.Wo) % g.Ho, od = v / (g.Wo * g.Ho);
+    const int bd = od * g.sd - g.pd, bh = oh * g.sh - g.ph, bw = ow * g.sw - g.pw;
+    float acc[COB];
+#pragma unroll
+    for (int j = 0; j < COB; ++j) acc[j] = 0.f;
+    const T *xg = x + (long)(b * g.C + gi * g.Cg) * g.Ni;
+    int tap = 0;
+    for (int i = 0; i < g.kd; ++i) {
+        const int zd = bd + i * g.dd;
+        for (int jx = 0; jx < g.kh; ++jx) {
+            const int zh = bh + jx * g.dh;
+            for (int k = 0; k < g.kw; ++k, ++tap) {
+                const int zw = bw + k * g.dw;
+                const bool ok = zd >= 0 && zd < g.D && zh >= 0 && zh < g.H && zw >= 0 && zw < g.W;
+                const int lin = ok ? (zd * g.H + zh) * g.W + zw : 0;
+                const float *wrow = wt + ((long)(gi * g.K + tap) * g.Cg) * OgP + co0;
+                for (int cg = 0; cg < g.Cg; ++cg) {
+                    const float xv = ok ? ldf(xg + (long)cg * g.Ni + lin) : 0.f;
+                    const float *wp = wrow + (long)cg * OgP;
+#pragma unroll
+                    for (int j = 0; j < COB; ++j) acc[j] = fmaf(xv, wp[j], acc[j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < COB; ++j) {
+        const int o = co0 + j;
+        if (o < g.Og) {
+            const int co = gi * g.Og + o;
+            stf(out + (long)(b * g.Cout + co) * g.No + v, acc[j] + (bias ? ldf(bias + co) : 0.f));
+        }
+    }
+}
+
+template <typename T>
+int launch_conv_fwd(const T *x, const T *w, const T *bias, T *out, float *wt, const Geom &g, hipStream_t st)
+{
+    const int cob = pick_pow2_upto32(g.Og);
+    const int OgP = round_up(g.Og, cob);
+    int rc = launch_relayout_weight<T>(w, wt, g.group, g.Og, g.Cg, g.K, OgP, st);
+    if (rc) return rc;
+    dim3 grid(cdiv(g.No, DLKA_THREADS), g.group * (OgP / cob), g.B), block(DLKA_THREADS);
+#define DLKA_L(COB)                                                                    \
+    {                                                                                  \
+        auto k = conv_fwd_kernel<T, COB>;                                              \
+        hipLaunchKernelGGL(k, grid, block, 0, st, x, (const float *)wt, bias, out, g, OgP); \
+    }
+    switch (cob) {
+        case 1: DLKA_L(1) break;
+        case 2: DLKA_L(2) break;
+        case 4: DLKA_L(4) break;
+        case 8: DLKA_L(8) break;
+        case 16: DLKA_L(16) break;
+        default: DLKA_L(32) break;
+    }
+#undef DLKA_L
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// data gradient (gather form, any stride): one work-item per input voxel, CIB input channels in registers
+//   gX[b][c][z] = sum_{o, tap : (z + p - tap*dil) % s == 0} gO[b][o][(z + p - tap*dil)/s] * W[o][c][tap]
+// grid = (input voxel tiles, group * CgP/CIB, B)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int CIB>
+__global__ __launch_bounds__(DLKA_THREADS) void conv_bwd_data_kernel(
+    const T *__restrict__ gout, const float *__restrict__ wb, T *__restrict__ gx, Geom g, int CgP)
+{
+    const int z = blockIdx.x * DLKA_THREADS + threadIdx.x;
+    const int chunks = CgP / CIB;
+    const int gi = blockIdx.y / chunks, ci0 = (blockIdx.y % chunks) * CIB;
+    const int b = blockIdx.z;
+    if (z >= g.Ni) return;
+    const int zw = z % g.W, zh = (z / g.W) % g.H, zd = z / (g.W * g.H);
+    float acc[CIB];
+#pragma unroll
+    for (int j = 0; j < CIB; ++j) acc[j] = 0.f;
+    const T *gg = gout + (long)(b * g.Cout + gi * g.Og) * g.No;
+    int tap = 0;
+    for (int i = 0; i < g.kd; ++i) {
+        const int nd = zd + g.pd - i * g.dd;
+        const int od = nd / g.sd;
+        const bool okd = nd >= 0 && (nd - od * g.sd) == 0 && od < g.Do;
+        for (int jx = 0; jx < g.kh; ++jx) {
+            const int nh = zh + g.ph - jx * g.dh;
+            const int oh = nh / g.sh;
+            const bool okh = nh >= 0 && (nh - oh * g.sh) == 0 && oh < g.Ho;
+            for (int k = 0; k < g.kw; ++k, ++tap) {
+                const int nw = zw + g.pw - k * g.dw;
+                const int ow = nw / g.sw;
+                const bool ok = okd && okh && nw >= 0 && (nw - ow * g.sw) == 0 && ow < g.Wo;
+                const int lin = ok ? (od * g.Ho + oh) * g.Wo + ow : 0;
+                const float *wrow = wb + ((long)(gi * g.K + tap) * g.Og) * CgP + ci0;
+                for (int o = 0; o < g.Og; ++o) {
+                    const float gv = ok ? ldf(gg + (long)o * g.No + lin) : 0.f;
+                    const float *wp = wrow + (long)o * CgP;
+#pragma unroll
+                    for (int j = 0; j < CIB; ++j) acc[j] = fmaf(gv, wp[j], acc[j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CIB; ++j) {
+        const int cg = ci0 + j;
+        if (cg < g.Cg) stf(gx + (long)(b * g.C + gi * g.Cg + cg) * g.Ni + z, acc[j]);
+    }
+}
+
+template <typename T>
+int launch_conv_bwd_data(const T *gout, const T *w, T *gx, float *wb, const Geom &g, hipStream_t st)
+{
+    const int cib = pick_pow2_upto32(g.Cg);
+    const int CgP = round_up(g.Cg, cib);
+    {
+        const int n = g.group * g.K * g.Og * CgP;
+        auto k = relayout_weight_bwd_kernel<T>;
+        hipLaunchKernelGGL(k, dim3(cdiv(n, 256)), dim3(256), 0, st, w, wb, g.group, g.Og, g.Cg, g.K, CgP);
+        DLKA_CHECK_LAUNCH();
+    }
+    dim3 grid(cdiv(g.Ni, DLKA_THREADS), g.group * (CgP / cib), g.B), block(DLKA_THREADS);
+#define DLKA_L(CIB)                                                               \
+    {                                                                             \
+        auto k = conv_bwd_data_kernel<T, CIB>;                                    \
+        hipLaunchKernelGGL(k, grid, block, 0, st, gout, (const float *)wb, gx, g, CgP); \
+    }
+    switch (cib) {
+        case 1: DLKA_L(1) break;
+        case 2: DLKA_L(2) break;
+        case 4: DLKA_L(4) break;
+        case 8: DLKA_L(8) break;
+        case 16: DLKA_L(16) break;
+        default: DLKA_L(32) break;
+    }
+#undef DLKA_L
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: gW[co][cg][tap] = sum_{b,v} gO[b][co][v] * x[b][c][v*s - p + tap*dil]
+// Same decomposition as deform_bwd_weight_kernel: block = (c, TPC taps, COB out-channels, voxel split).
+// grid = (C, tapchunks * cochunks, VS); gw32 is fp32, zero-initialised, accumulated with atomics.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int TPC, int COB>
+__global__ __launch_bounds__(DLKA_THREADS) void conv_bwd_weight_kernel(
+    const T *__restrict__ x, const T *__restrict__ gout, float *__restrict__ gw, Geom g, int cochunks)
+{
+    const int c = blockIdx.x;
+    const int tchunk = blockIdx.y / cochunks, cchunk = blockIdx.y % cochunks;
+    const int tap0 = tchunk * TPC, co0 = cchunk * COB;
+    const int gi = c / g.Cg, cg = c - gi * g.Cg;
+    const int VS = gridDim.z;
+    float acc[TPC][COB];
+#pragma unroll
+    for (int t = 0; t < TPC; ++t)
+#pragma unroll
+        for (int j = 0; j < COB; ++j) acc[t][j] = 0.f;
+    int ti[TPC], tj[TPC], tk[TPC];
+#pragma unroll
+    for (int t = 0; t < TPC; ++t) {
+        const int tap = tap0 + t;
+        tk[t] = (tap % g.kw) * g.dw; tj[t] = ((tap / g.kw) % g.kh) * g.dh; ti[t] = (tap / (g.kw * g.kh)) * g.dd;
+    }
+    const long total = (long)g.B * g.No;
+    for (long n = (long)blockIdx.z * DLKA_THREADS + threadIdx.x; n < total; n += (long)DLKA_THREADS * VS) {
+        const int b = (int)(n / g.No), v = (int)(n - (long)b * g.No);
+        const int ow = v % g.Wo, oh = (v / g.Wo) % g.Ho, od = v / (g.Wo * g.Ho);
+        const int bd = od * g.sd - g.pd, bh = oh * g.sh - g.ph, bw = ow * g.sw - g.pw;
+        float G[COB];
+#pragma unroll
+        for (int j = 0; j < COB; ++j)
+            G[j] = (co0 + j < g.Og) ? ldf(gout + (long)(b * g.Cout + gi * g.Og + co0 + j) * g.No + v) : 0.f;
+        const T *xp = x + (long)(b * g.C + c) * g.Ni;
+#pragma unroll
+        for (int t = 0; t < TPC; ++t) {
+            const int zd = bd + ti[t], zh = bh + tj[t], zw = bw + tk[t];
+            const bool ok = (tap0 + t < g.K) && zd >= 0 && zd < g.D && zh >= 0 && zh < g.H && zw >= 0 && zw < g.W;
+            const float xv = ok ? ldf(xp + (zd * g.H + zh) * g.W + zw) : 0.f;
+#pragma unroll
+            for (int j = 0; j < COB; ++j) acc[t][j] = fmaf(xv, G[j], acc[t][j]);
+        }
+    }
+    __shared__ float red[DLKA_THREADS / 64][TPC * COB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < TPC; ++t)
+#pragma unroll
+        for (int j = 0; j < COB; ++j) {
+            float a = acc[t][j];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
+            if (lane == 0) red[wave][t * COB + j] = a;
+        }
+    __syncthreads();
+    if (threadIdx.x < TPC * COB) {
+        const int t = threadIdx.x / COB, j = threadIdx.x % COB;
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < DLKA_THREADS / 64; ++w) a += red[w][threadIdx.x];
+        if (tap0 + t < g.K && co0 + j < g.Og)
+            atomicAdd(gw + ((long)(gi * g.Og + co0 + j) * g.Cg + cg) * g.K + tap0 + t, a);
+    }
+}
+
+template <typename T>
+int launch_conv_bwd_weight(const T *x, const T *gout, float *gw32, const Geom &g, hipStream_t st)
+{
+    constexpr int TPC = 4;
+    const int cob = g.Og >= 16 ? 16 : (g.Og >= 8 ? 8 : (g.Og >= 4 ? 4 : (g.Og >= 2 ? 2 : 1)));
+    const int cochunks = cdiv(g.Og, cob), tchunks = cdiv(g.K, TPC);
+    const long total = (long)g.B * g.No;
+    long want = 2048 / ((long)g.C * tchunks * cochunks) + 1;
+    long maxvs = cdivl(total, DLKA_THREADS);
+    int VS = (int)(want < 1 ? 1 : (want > maxvs ? maxvs : want));
+    if (VS > 64) VS = 64;
+    dim3 grid(g.C, tchunks * cochunks, VS), block(DLKA_THREADS);
+#define DLKA_L(COB)                                                    \
+    {                                                                  \
+        auto k = conv_bwd_weight_kernel<T, TPC, COB>;                  \
+        hipLaunchKernelGGL(k, grid, block, 0, st, x, gout, gw32, g, cochunks); \
+    }
+    switch (cob) {
+        case 1: DLKA_L(1) break;
+        case 2: DLKA_L(2) break;
+        case 4: DLKA_L(4) break;
+        case 8: DLKA_L(8) break;
+        default: DLKA_L(16) break;
+    }
+#undef DLKA_L
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+#define DLKA_INST(T)                                                                                        \
+    template int launch_conv_fwd<T>(const T *, const T *, const T *, T *, float *, const Geom &, hipStream_t); \
+    template int launch_conv_bwd_data<T>(const T *, const T *, T *, float *, const Geom &, hipStream_t);      \
+    template int launch_conv_bwd_weight<T>(const T *, const T *, float *, const Geom &, hipStream_t);
+DLKA_INST(float)
+DLKA_INST(bf16_t)
+#undef DLKA_INST
+
+}  // namespace dlka

@@ -1,0 +1,56 @@
+// Shared device/host helpers for the D-LKA HIP kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "dlka.h"
+#include "dlka_intrin.h"
+
+namespace dlka {
+
+// ---------------------------------------------------------------------------------------------
+// storage types: fp32, or bf16 storage with fp32 arithmetic
+// ---------------------------------------------------------------------------------------------
+struct bf16_t { uint16_t v; };
+
+__host__ __device__ __forceinline__ float ldf(const float *p) { return *p; }
+__host__ __device__ __forceinline__ float ldf(const bf16_t *p) {
+    uint32_t u = (uint32_t)p->v << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+__host__ __device__ __forceinline__ void stf(float *p, float x) { *p = x; }
+__host__ __device__ __forceinline__ void stf(bf16_t *p, float x) {  // round-to-nearest-even, NaN kept quiet
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) { p->v = (uint16_t)((u >> 16) | 0x40); return; }
+    u += 0x7fffu + ((u >> 16) & 1u);
+    p->v = (uint16_t)(u >> 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// geometry with the derived sizes every kernel needs
+// ---------------------------------------------------------------------------------------------
+struct Geom {
+    int B, C, D, H, W, Cout;
+    int kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw;
+    int group, dg;
+    int Do, Ho, Wo;
+    int K, Cg, Og, cpdg;  // taps, in-channels per group, out-channels per group, channels per deformable group
+    int No, Ni;           // output / input voxels per (b, channel) plane
+};
+
+__host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ __forceinline__ long cdivl(long a, long b) { return (a + b - 1) / b; }
+__host__ __device__ __forceinline__ int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+#define DLKA_THREADS 256
+
+#define DLKA_CHECK_LAUNCH()                                  \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return DLKA_ERR_LAUNCH; \
+    } while (0)
+
+}  // namespace dlka

@@ -1,0 +1,69 @@
+// Elementwise pieces of the D-LKA block: exact-erf GELU (nn.GELU() default,
+// 3D/d_lka_former/network_architecture/synapse/transformerblock.py:660), the u*attn gate (:652) and the
+// residual add (:671).  Pure HBM-bound streaming: 16-byte vector accesses, grid-stride.
+#include "dlka_kernels.h"
+
+namespace dlka {
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x)
+{
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+struct OpGelu { __device__ __forceinline__ float operator()(float x) const { return gelu_f(x); } };
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void eltwise_kernel(const T *a, const T *b, const T *c,
+                                                      T *o1, T *o2, long n)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (MODE == 0) {  // gelu fwd: o1 = gelu(a)
+            stf(o1 + i, gelu_f(ldf(a + i)));
+        } else if (MODE == 1) {  // gelu bwd: o1 = b * dgelu(a)
+            stf(o1 + i, ldf(b + i) * dgelu_f(ldf(a + i)));
+        } else if (MODE == 2) {  // mul fwd
+            stf(o1 + i, ldf(a + i) * ldf(b + i));
+        } else if (MODE == 3) {  // mul bwd: o1 = c*b ; o2 = c*a
+            const float gy = ldf(c + i);
+            const float av = ldf(a + i), bv = ldf(b + i);
+            if (o1) stf(o1 + i, gy * bv);
+            if (o2) stf(o2 + i, gy * av);
+        } else {  // add
+            stf(o1 + i, ldf(a + i) + ldf(b + i));
+        }
+    }
+}
+
+template <typename T, int MODE>
+static int launch_elt(const T *a, const T *b, const T *c, T *o1, T *o2, long n, hipStream_t st)
+{
+    if (n <= 0) return DLKA_OK;
+    long blocks = cdivl(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    auto k = eltwise_kernel<T, MODE>;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), 0, st, a, b, c, o1, o2, n);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+template <typename T> int launch_gelu_fwd(const T *x, T *y, long n, hipStream_t st) { return launch_elt<T, 0>(x, nullptr, nullptr, y, nullptr, n, st); }
+template <typename T> int launch_gelu_bwd(const T *x, const T *gy, T *gx, long n, hipStream_t st) { return launch_elt<T, 1>(x, gy, nullptr, gx, nullptr, n, st); }
+template <typename T> int launch_mul_fwd(const T *a, const T *b, T *y, long n, hipStream_t st) { return launch_elt<T, 2>(a, b, nullptr, y, nullptr, n, st); }
+template <typename T> int launch_mul_bwd(const T *a, const T *b, const T *gy, T *ga, T *gb, long n, hipStream_t st) { return launch_elt<T, 3>(a, b, gy, ga, gb, n, st); }
+template <typename T> int launch_add_fwd(const T *a, const T *b, T *y, long n, hipStream_t st) { return launch_elt<T, 4>(a, b, nullptr, y, nullptr, n, st); }
+
+#define DLKA_INST(T)                                                                    \
+    template int launch_gelu_fwd<T>(const T *, T *, long, hipStream_t);                  \
+    template int launch_gelu_bwd<T>(const T *, const T *, T *, long, hipStream_t);       \
+    template int launch_mul_fwd<T>(const T *, const T *, T *, long, hipStream_t);        \
+    template int launch_mul_bwd<T>(const T *, const T *, const T *, T *, T *, long, hipStream_t); \
+    template int launch_add_fwd<T>(const T *, const T *, T *, long, hipStream_t);
+DLKA_INST(float)
+DLKA_INST(bf16_t)
+#undef DLKA_INST
+
+}  // namespace dlka

@@ -1,0 +1,316 @@
+"""Tensor-level wrappers over the C-ABI.  PyTorch is used for device memory and streams only."""
+from __future__ import annotations
+
+from ctypes import byref
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+def _triple(v) -> Tuple[int, int, int]:
+    if isinstance(v, int):
+        return (v, v, v)
+    v = tuple(int(x) for x in v)
+    if len(v) != 3:
+        raise ValueError(f"expected an int or a 3-tuple, got {v}")
+    return v
+
+
+def _pair(v) -> Tuple[int, int]:
+    if isinstance(v, int):
+        return (v, v)
+    v = tuple(int(x) for x in v)
+    if len(v) != 2:
+        raise ValueError(f"expected an int or a 2-tuple, got {v}")
+    return v
+
+
+def _geom(x_shape, cout, k, s, p, d, group, dg=1, im2col_step=64) -> L.ConvGeom:
+    B, C, D, H, W = (int(v) for v in x_shape)
+    return L.ConvGeom(B, C, D, H, W, int(cout), *k, *s, *p, *d, int(group), int(dg), int(im2col_step))
+
+
+def _out_dims(g: L.ConvGeom):
+    f = L.get_lib().dlka_conv_out_size
+    return (f(g.D, g.pd, g.dd, g.kd, g.sd), f(g.H, g.ph, g.dh, g.kh, g.sh), f(g.W, g.pw, g.dw, g.kw, g.sw))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 3-D deformable conv
+# ------------------------------------------------------------------------------------------------------------
+def deform_conv3d_forward(input, weight, bias, offset, kernel_size, stride, padding, dilation, group, deformable_groups,
+                          im2col_step=64):
+    """``D3D.deform_conv_forward`` (3D/dcn/src/deform_conv.h:10-47)."""
+    # deform_conv_cuda.cu:41-47
+    if not input.is_contiguous():
+        raise RuntimeError("input tensor has to be contiguous")
+    if not weight.is_contiguous():
+        raise RuntimeError("weight tensor has to be contiguous")
+    L.require_device(input, weight, bias, offset)
+    k, s, p, d = _triple(kernel_size), _triple(stride), _triple(padding), _triple(dilation)
+    if tuple(weight.shape[2:5]) != k:  # deform_conv_cuda.cu:72-73
+        raise RuntimeError(f"Input shape and kernel shape wont match: ({k} vs {tuple(weight.shape[2:5])}).")
+    if input.shape[1] != weight.shape[1] * group:  # :75-76
+        raise RuntimeError(f"Input shape and kernel channels wont match: ({input.shape[1]} vs {weight.shape[1] * group}).")
+    offset = offset.contiguous()  # the reference does not check offset; a strided view would be misread
+    bias = bias.contiguous()
+    lib = L.get_lib()
+    g = _geom(input.shape, weight.shape[0], k, s, p, d, group, deformable_groups, im2col_step)
+    dt = L.dtype_code(input)
+    Do, Ho, Wo = _out_dims(g)
+    if min(Do, Ho, Wo) <= 0:
+        L.check(-4, "deform_conv_forward")
+    K = k[0] * k[1] * k[2]
+    if tuple(offset.shape) != (g.B, deformable_groups * 3 * K, Do, Ho, Wo):
+        raise RuntimeError(f"offset shape {tuple(offset.shape)} does not match {(g.B, deformable_groups * 3 * K, Do, Ho, Wo)}")
+    out = torch.empty((g.B, g.Cout, Do, Ho, Wo), dtype=input.dtype, device=input.device)
+    wsb = lib.dlka_deform_conv3d_forward_workspace(byref(g), dt)
+    ws = L.scratch(wsb, input)
+    rc = lib.dlka_deform_conv3d_forward(L.ptr(input), L.ptr(offset), L.ptr(weight), L.ptr(bias), L.ptr(out), L.ptr(ws), wsb,
+                                        byref(g), dt, L.stream_ptr(input))
+    L.check(rc, "deform_conv_forward")
+    return out
+
+
+def deform_conv3d_backward(input, weight, bias, offset, grad_output, kernel_size, stride, padding, dilation, group,
+                           deformable_groups, im2col_step=64, need=(True, True, True, True)):
+    """``D3D.deform_conv_backward`` (3D/dcn/src/deform_conv.h:49-91) -> (grad_input, grad_offset, grad_weight, grad_bias)."""
+    if not input.is_contiguous():
+        raise RuntimeError("input tensor has to be contiguous")
+    if not weight.is_contiguous():
+        raise RuntimeError("weight tensor has to be contiguous")
+    L.require_device(input, weight, bias, offset, grad_output)
+    k, s, p, d = _triple(kernel_size), _triple(stride), _triple(padding), _triple(dilation)
+    offset = offset.contiguous()
+    grad_output = grad_output.contiguous()  # reference: permute(...).contiguous() copies, deform_conv_cuda.cu:228
+    lib = L.get_lib()
+    g = _geom(input.shape, weight.shape[0], k, s, p, d, group, deformable_groups, im2col_step)
+    dt = L.dtype_code(input)
+    Do, Ho, Wo = _out_dims(g)
+    if tuple(grad_output.shape) != (g.B, g.Cout, Do, Ho, Wo):  # deform_conv_cuda.cu:193-200
+        raise RuntimeError(f"Input shape and grad_out shape wont match: ({(g.B, g.Cout, Do, Ho, Wo)} vs {tuple(grad_output.shape)}).")
+    gi = torch.empty_like(input) if need[0] else None
+    go = torch.empty_like(offset) if need[1] else None
+    gw = torch.empty_like(weight) if need[2] else None
+    gb = torch.empty_like(bias, memory_format=torch.contiguous_format) if need[3] else None
+    wsb = lib.dlka_deform_conv3d_backward_workspace(byref(g), dt)
+    ws = L.scratch(wsb, input)
+    rc = lib.dlka_deform_conv3d_backward(L.ptr(input), L.ptr(offset), L.ptr(weight), L.ptr(grad_output), L.ptr(gi), L.ptr(go),
+                                         L.ptr(gw), L.ptr(gb), L.ptr(ws), wsb, byref(g), dt, L.stream_ptr(input))
+    L.check(rc, "deform_conv_backward")
+    return gi, go, gw, gb
+
+
+def deform_conv3d_sample_index(offset, in_size: Sequence[int], kernel_size, stride, padding, dilation, deformable_groups=1):
+    """floor() indices [B,dg,K,Do,Ho,Wo,3] (int32) and guard mask [B,dg,K,Do,Ho,Wo] (uint8)."""
+    L.require_device(offset)
+    k, s, p, d = _triple(kernel_size), _triple(stride), _triple(padding), _triple(dilation)
+    offset = offset.contiguous()
+    B = offset.shape[0]
+    g = _geom((B, deformable_groups, *in_size), deformable_groups, k, s, p, d, 1, deformable_groups, 64)
+    Do, Ho, Wo = _out_dims(g)
+    K = k[0] * k[1] * k[2]
+    idx = torch.empty((B, deformable_groups, K, Do, Ho, Wo, 3), dtype=torch.int32, device=offset.device)
+    mask = torch.empty((B, deformable_groups, K, Do, Ho, Wo), dtype=torch.uint8, device=offset.device)
+    rc = L.get_lib().dlka_deform_conv3d_sample_index(L.ptr(offset), L.ptr(idx), L.ptr(mask), byref(g), L.dtype_code(offset),
+                                                     L.stream_ptr(offset))
+    L.check(rc, "deform_conv3d_sample_index")
+    return idx, mask
+
+
+# ------------------------------------------------------------------------------------------------------------
+# 2-D deformable conv (torchvision semantics)
+# ------------------------------------------------------------------------------------------------------------
+def _geom2d(x_shape, weight_shape, s, p, d, offset_channels):
+    B, C, H, W = (int(v) for v in x_shape)
+    Cout, Cg, kh, kw = (int(v) for v in weight_shape)
+    if C % Cg != 0:
+        raise RuntimeError("input channels must be divisible by weight.shape[1]")
+    og = offset_channels // (2 * kh * kw)
+    if og == 0 or offset_channels != og * 2 * kh * kw:
+        raise RuntimeError(f"offset.shape[1] = {offset_channels} is not a multiple of 2*kh*kw = {2 * kh * kw}")
+    return L.ConvGeom(B, C, 1, H, W, Cout, 1, kh, kw, 1, s[0], s[1], 0, p[0], p[1], 1, d[0], d[1], C // Cg, og, 64)
+
+
+def deform_conv2d_forward(input, offset, weight, bias=None, stride=1, padding=0, dilation=1):
+    L.require_device(input, offset, weight, bias)
+    s, p, d = _pair(stride), _pair(padding), _pair(dilation)
+    input, offset, weight = input.contiguous(), offset.contiguous(), weight.contiguous()
+    bias = None if bias is None else bias.contiguous()
+    g = _geom2d(input.shape, weight.shape, s, p, d, offset.shape[1])
+    lib = L.get_lib()
+    dt = L.dtype_code(input)
+    _, Ho, Wo = _out_dims(g)
+    if tuple(offset.shape[2:]) != (Ho, Wo):
+        raise RuntimeError(f"offset spatial size {tuple(offset.shape[2:])} does not match output {(Ho, Wo)}")
+    out = torch.empty((g.B, g.Cout, Ho, Wo), dtype=input.dtype, device=input.device)
+    wsb = lib.dlka_deform_conv2d_forward_workspace(byref(g), dt)
+    ws = L.scratch(wsb, input)
+    rc = lib.dlka_deform_conv2d_forward(L.ptr(input), L.ptr(offset), L.ptr(weight), L.ptr(bias), L.ptr(out), L.ptr(ws), wsb,
+                                        byref(g), dt, L.stream_ptr(input))
+    L.check(rc, "deform_conv2d")
+    return out
+
+
+def deform_conv2d_backward(input, offset, weight, grad_output, stride=1, padding=0, dilation=1, with_bias=False,
+                           need=(True, True, True)):
+    L.require_device(input, offset, weight, grad_output)
+    s, p, d = _pair(stride), _pair(padding), _pair(dilation)
+    input, offset, weight, grad_output = input.contiguous(), offset.contiguous(), weight.contiguous(), grad_output.contiguous()
+    g = _geom2d(input.shape, weight.shape, s, p, d, offset.shape[1])
+    lib = L.get_lib()
+    dt = L.dtype_code(input)
+    gi = torch.empty_like(input) if need[0] else None
+    go = torch.empty_like(offset) if need[1] else None
+    gw = torch.empty_like(weight) if need[2] else None
+    gb = torch.empty((g.Cout,), dtype=input.dtype, device=input.device) if with_bias else None
+    wsb = lib.dlka_deform_conv2d_backward_workspace(byref(g), dt)
+    ws = L.scratch(wsb, input)
+    rc = lib.dlka_deform_conv2d_backward(L.ptr(input), L.ptr(offset), L.ptr(weight), L.ptr(grad_output), L.ptr(gi), L.ptr(go),
+                                         L.ptr(gw), L.ptr(gb), L.ptr(ws), wsb, byref(g), dt, L.stream_ptr(input))
+    L.check(rc, "deform_conv2d backward")
+    return gi, go, gw, gb
+
+
+# ------------------------------------------------------------------------------------------------------------
+# plain conv
+# ------------------------------------------------------------------------------------------------------------
+def conv3d_forward(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    L.require_device(input, weight, bias)
+    s, p, d = _triple(stride), _triple(padding), _triple(dilation)
+    input, weight = input.contiguous(), weight.contiguous()
+    bias = None if bias is None else bias.contiguous()
+    g = _geom(input.shape, weight.shape[0], tuple(weight.shape[2:5]), s, p, d, groups)
+    lib = L.get_lib()
+    dt = L.dtype_code(input)
+    Do, Ho, Wo = _out_dims(g)
+    out = torch.empty((g.B, g.Cout, Do, Ho, Wo), dtype=input.dtype, device=input.device)
+    wsb = lib.dlka_conv3d_forward_workspace(byref(g), dt)
+    ws = L.scratch(wsb, input)
+    rc = lib.dlka_conv3d_forward(L.ptr(input), L.ptr(weight), L.ptr(bias), L.ptr(out), L.ptr(ws), wsb, byref(g), dt,
+                                 L.stream_ptr(input))
+    L.check(rc, "conv3d")
+    return out
+
+
+def conv3d_backward(input, weight, grad_output, stride=1, padding=0, dilation=1, groups=1, need=(True, True, True)):
+    L.require_device(input, weight, grad_output)
+    s, p, d = _triple(stride), _triple(padding), _triple(dilation)
+    input, weight, grad_output = input.contiguous(), weight.contiguous(), grad_output.contiguous()
+    g = _geom(input.shape, weight.shape[0], tuple(weight.shape[2:5]), s, p, d, groups)
+    lib = L.get_lib()
+    dt = L.dtype_code(input)
+    gi = torch.empty_like(input) if need[0] else None
+    gw = torch.empty_like(weight) if need[1] else None
+    gb = torch.empty((g.Cout,), dtype=input.dtype, device=input.device) if need[2] else None
+    wsb = lib.dlka_conv3d_backward_workspace(byref(g), dt)
+    ws = L.scratch(wsb, input)
+    rc = lib.dlka_conv3d_backward(L.ptr(input), L.ptr(weight), L.ptr(grad_output), L.ptr(gi), L.ptr(gw), L.ptr(gb), L.ptr(ws), wsb,
+                                  byref(g), dt, L.stream_ptr(input))
+    L.check(rc, "conv3d backward")
+    return gi, gw, gb
+
+
+def gelu_forward(x):
+    L.require_device(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    L.check(L.get_lib().dlka_gelu_forward(L.ptr(x), L.ptr(y), x.numel(), L.dtype_code(x), L.stream_ptr(x)), "gelu")
+    return y
+
+
+def gelu_backward(x, gy):
+    L.require_device(x, gy)
+    x, gy = x.contiguous(), gy.contiguous()
+    gx = torch.empty_like(x)
+    L.check(L.get_lib().dlka_gelu_backward(L.ptr(x), L.ptr(gy), L.ptr(gx), x.numel(), L.dtype_code(x), L.stream_ptr(x)), "gelu bwd")
+    return gx
+
+
+# ------------------------------------------------------------------------------------------------------------
+# whole blocks
+# ------------------------------------------------------------------------------------------------------------
+def _ptr_struct(cls, fields, tensors):
+    st = cls()
+    for n, t in zip(fields, tensors):
+        setattr(st, n, t.data_ptr())
+    return st
+
+
+def lka3d_attention_forward(x, params: Sequence[torch.Tensor]):
+    """x: [B,C,D,H,W]; params: the 14 tensors in ``_lib.LKA3D_FIELDS`` order. Returns (y, saved)."""
+    L.require_device(x, *params)
+    x = x.contiguous()
+    params = [t.contiguous() for t in params]
+    B, C, D, H, W = (int(v) for v in x.shape)
+    lib = L.get_lib()
+    dt = L.dtype_code(x)
+    sb, wb = lib.dlka_lka3d_saved_bytes(B, C, D, H, W, dt), lib.dlka_lka3d_workspace_bytes(B, C, D, H, W, dt)
+    if sb == 0:
+        L.check(-4, "lka3d_attention_forward")
+    saved, ws = L.scratch(sb, x), L.scratch(wb, x)
+    y = torch.empty_like(x)
+    ps = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, params)
+    rc = lib.dlka_lka3d_attention_forward(L.ptr(x), byref(ps), L.ptr(y), L.ptr(saved), sb, L.ptr(ws), wb, B, C, D, H, W, dt,
+                                          L.stream_ptr(x))
+    L.check(rc, "lka3d_attention_forward")
+    return y, saved
+
+
+def lka3d_attention_backward(x, params, grad_y, saved):
+    L.require_device(x, grad_y, saved, *params)
+    x, grad_y = x.contiguous(), grad_y.contiguous()
+    params = [t.contiguous() for t in params]
+    B, C, D, H, W = (int(v) for v in x.shape)
+    lib = L.get_lib()
+    dt = L.dtype_code(x)
+    wb = lib.dlka_lka3d_workspace_bytes(B, C, D, H, W, dt)
+    ws = L.scratch(wb, x)
+    gx = torch.empty_like(x)
+    grads = [torch.empty_like(t) for t in params]
+    ps = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, params)
+    gs = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, grads)
+    rc = lib.dlka_lka3d_attention_backward(L.ptr(x), byref(ps), L.ptr(grad_y), L.ptr(saved), saved.numel(), L.ptr(gx), byref(gs),
+                                           L.ptr(ws), wb, B, C, D, H, W, dt, L.stream_ptr(x))
+    L.check(rc, "lka3d_attention_backward")
+    return gx, grads
+
+
+def lka2d_attention_forward(x, params: Sequence[torch.Tensor]):
+    L.require_device(x, *params)
+    x = x.contiguous()
+    params = [t.contiguous() for t in params]
+    B, C, H, W = (int(v) for v in x.shape)
+    lib = L.get_lib()
+    dt = L.dtype_code(x)
+    sb, wb = lib.dlka_lka2d_saved_bytes(B, C, H, W, dt), lib.dlka_lka2d_workspace_bytes(B, C, H, W, dt)
+    if sb == 0:
+        L.check(-4, "lka2d_attention_forward")
+    saved, ws = L.scratch(sb, x), L.scratch(wb, x)
+    y = torch.empty_like(x)
+    ps = _ptr_struct(L.Lka2dPtrs, L.LKA2D_FIELDS, params)
+    rc = lib.dlka_lka2d_attention_forward(L.ptr(x), byref(ps), L.ptr(y), L.ptr(saved), sb, L.ptr(ws), wb, B, C, H, W, dt,
+                                          L.stream_ptr(x))
+    L.check(rc, "lka2d_attention_forward")
+    return y, saved
+
+
+def lka2d_attention_backward(x, params, grad_y, saved):
+    L.require_device(x, grad_y, saved, *params)
+    x, grad_y = x.contiguous(), grad_y.contiguous()
+    params = [t.contiguous() for t in params]
+    B, C, H, W = (int(v) for v in x.shape)
+    lib = L.get_lib()
+    dt = L.dtype_code(x)
+    wb = lib.dlka_lka2d_workspace_bytes(B, C, H, W, dt)
+    ws = L.scratch(wb, x)
+    gx = torch.empty_like(x)
+    grads = [torch.empty_like(t) for t in params]
+    ps = _ptr_struct(L.Lka2dPtrs, L.LKA2D_FIELDS, params)
+    gs = _ptr_struct(L.Lka2dPtrs, L.LKA2D_FIELDS, grads)
+    rc = lib.dlka_lka2d_attention_backward(L.ptr(x), byref(ps), L.ptr(grad_y), L.ptr(saved), saved.numel(), L.ptr(gx), byref(gs),
+                                           L.ptr(ws), wb, B, C, H, W, dt, L.stream_ptr(x))
+    L.check(rc, "lka2d_attention_backward")
+    return gx, grads

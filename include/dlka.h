@@ -1,0 +1,232 @@
+/*
+ * dlka.h — C-ABI of libdlka_hip.so: the MI355X (gfx950) implementation of the Deformable
+ * Large-Kernel-Attention hot path of xmindflow/deformableLKA.
+ *
+ * This is the drop-in boundary.  Every entry point takes plain device pointers, a geometry
+ * struct of ints and an opaque hipStream_t; no torch / ATen type crosses it.  Each declaration
+ * cites the reference interface it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - All tensor pointers are DEVICE pointers to dense, contiguous buffers in the layouts stated
+ *     per function (the reference asserts contiguity: 3D/dcn/src/cuda/deform_conv_cuda.cu:41-42).
+ *   - Inputs are borrowed and never written.  Outputs and workspaces are caller-allocated
+ *     (the reference allocates outputs itself with at::empty/zeros_like, deform_conv_cuda.cu:82,
+ *     202-205; here the host-language wrapper owns allocation so that the library stays ATen-free).
+ *   - Every call is asynchronous on `stream` (the reference uses the current CUDA stream,
+ *     deform_conv_cuda.cu:97) and is legal inside hipGraph capture: no allocation, no sync.
+ *   - Return value: DLKA_OK (0) or a negative dlka_status.  Nothing throws across this boundary.
+ *     dlka_status_string() gives the message the Python wrapper turns into RuntimeError, matching
+ *     the reference's AT_ASSERTM -> c10::Error -> RuntimeError behaviour.
+ *   - dtype: DLKA_F32 everywhere (the reference dispatches float/double only,
+ *     deform_conv_cuda.cu:96,233).  DLKA_BF16 = bf16 storage with fp32 accumulation (new capability).
+ */
+#ifndef DLKA_H_
+#define DLKA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLKA_ABI_VERSION 1
+
+typedef enum dlka_status {
+    DLKA_OK = 0,
+    DLKA_ERR_NULL = -1,         /* a required pointer is NULL                                          */
+    DLKA_ERR_GROUP = -2,        /* channels / out_channels not divisible by group (cu:65-66)           */
+    DLKA_ERR_DEFORM_GROUP = -3, /* channels not divisible by deformable_group                          */
+    DLKA_ERR_SHAPE = -4,        /* non-positive size or output size (cu:78-80)                         */
+    DLKA_ERR_IM2COL_STEP = -5,  /* batch % min(batch, im2col_step) != 0 (cu:61-63)                      */
+    DLKA_ERR_DTYPE = -6,        /* unsupported dtype                                                    */
+    DLKA_ERR_WORKSPACE = -7,    /* workspace too small / NULL                                           */
+    DLKA_ERR_UNSUPPORTED = -8,  /* parameter combination not implemented                                */
+    DLKA_ERR_LAUNCH = -9        /* hipGetLastError() != hipSuccess after a launch (reference only printf's, cuh:425-429) */
+} dlka_status;
+
+typedef enum dlka_dtype { DLKA_F32 = 0, DLKA_BF16 = 1 } dlka_dtype;
+
+/* Geometry of one (deformable or plain) N-d convolution.  2-D ops use D = kd = sd = dd = 1, pd = 0. */
+typedef struct dlka_conv_geom {
+    int32_t B, C, D, H, W;     /* input  [B][C][D][H][W]                                  */
+    int32_t Cout;              /* weight [Cout][C/group][kd][kh][kw]                      */
+    int32_t kd, kh, kw;
+    int32_t sd, sh, sw;        /* stride                                                  */
+    int32_t pd, ph, pw;        /* zero padding                                            */
+    int32_t dd, dh, dw;        /* dilation                                                */
+    int32_t group;             /* weight groups                                           */
+    int32_t deformable_group;  /* offset groups (deformable ops only; else ignored)       */
+    int32_t im2col_step;       /* accepted and validated for API parity only (cu:59-63);
+                                  no column buffer exists here, so it does not change the result */
+} dlka_conv_geom;
+
+int         dlka_abi_version(void);
+const char *dlka_status_string(int status);
+/* Output spatial size  (in + 2p - (d(k-1)+1))/s + 1   (deform_conv_cuda.cu:78-80). */
+int         dlka_conv_out_size(int in, int pad, int dil, int k, int stride);
+
+/* =======================================================================================
+ * 3-D deformable convolution — the D3D operator
+ * ======================================================================================= */
+
+/* Replaces  D3D.deform_conv_forward  (3D/dcn/src/vision.cpp:5, 3D/dcn/src/deform_conv.h:10-47)
+ *           = deform_conv_cuda_forward (3D/dcn/src/cuda/deform_conv_cuda.cu:18-126)
+ *           + deformable_im2col_gpu_kernel (3D/dcn/src/cuda/deform_im2col_cuda.cuh:192-265).
+ *   x      [B][C][D][H][W]
+ *   offset [B][dg*3*K][Do][Ho][Wo]   channel = dg_idx*3K + 3*tap + {0:d,1:h,2:w}, tap=(i*kh+j)*kw+k (cuh:237-239)
+ *   weight [Cout][C/group][kd][kh][kw]
+ *   bias   [Cout]                    always added, also when the module was built with bias=False
+ *   out    [B][Cout][Do][Ho][Wo]
+ *   workspace: dlka_deform_conv3d_forward_workspace(g, dtype) bytes (re-laid-out weights; no im2col columns). */
+size_t dlka_deform_conv3d_forward_workspace(const dlka_conv_geom *g, int dtype);
+int dlka_deform_conv3d_forward(const void *x, const void *offset, const void *weight, const void *bias,
+                               void *out, void *workspace, size_t workspace_bytes,
+                               const dlka_conv_geom *g, int dtype, void *stream);
+
+/* Replaces  D3D.deform_conv_backward (3D/dcn/src/vision.cpp:6, deform_conv.h:49-91)
+ *           = deform_conv_cuda_backward (deform_conv_cuda.cu:128-285)
+ *           + deformable_col2im_coord_gpu_kernel (cuh:336-405)  -> grad_offset
+ *           + deformable_col2im_gpu_kernel       (cuh:267-334)  -> grad_x   (fp32 atomics, order non-deterministic as in the reference)
+ *           + deformable_im2col_gpu_kernel again + addmm/addmv (cu:254-278) -> grad_weight, grad_bias.
+ *   All four gradients are fully overwritten (the reference returns fresh zeros_like tensors, cu:202-205).
+ *   Any of the grad_* pointers may be NULL to skip that gradient. */
+size_t dlka_deform_conv3d_backward_workspace(const dlka_conv_geom *g, int dtype);
+int dlka_deform_conv3d_backward(const void *x, const void *offset, const void *weight, const void *grad_out,
+                                void *grad_x, void *grad_offset, void *grad_weight, void *grad_bias,
+                                void *workspace, size_t workspace_bytes,
+                                const dlka_conv_geom *g, int dtype, void *stream);
+
+/* Debug/parity entry point: floor() sampling indices and the in-range guard of cuh:247 for every
+ * (b, dg, tap, out voxel).  idx int32 [B][dg][K][No][3], mask uint8 [B][dg][K][No].
+ * Backs the "integer sampling indices bit-exact" requirement of BASELINE.json. */
+int dlka_deform_conv3d_sample_index(const void *offset, int32_t *idx, uint8_t *mask,
+                                    const dlka_conv_geom *g, int dtype, void *stream);
+
+/* =======================================================================================
+ * 2-D deformable convolution — torchvision.ops.deform_conv2d(mask=None) semantics
+ * ======================================================================================= */
+
+/* Replaces  torchvision.ops.DeformConv2d.forward / deform_conv2d as called at
+ *           2D/deformable_LKA/deformable_LKA.py:18-30 (torchvision==0.12.0, 2D/requirements.txt:69).
+ *   x [B][C][H][W]; offset [B][og*2*K][Ho][Wo] with (dy,dx) per tap; weight [Cout][C/group][kh][kw];
+ *   bias [Cout] or NULL (the reference passes bias=False, deformable_LKA.py:25); out [B][Cout][Ho][Wo].
+ *   Geometry: D=kd=sd=dd=1, pd=0; deformable_group = offset groups. */
+size_t dlka_deform_conv2d_forward_workspace(const dlka_conv_geom *g, int dtype);
+int dlka_deform_conv2d_forward(const void *x, const void *offset, const void *weight, const void *bias,
+                               void *out, void *workspace, size_t workspace_bytes,
+                               const dlka_conv_geom *g, int dtype, void *stream);
+size_t dlka_deform_conv2d_backward_workspace(const dlka_conv_geom *g, int dtype);
+int dlka_deform_conv2d_backward(const void *x, const void *offset, const void *weight, const void *grad_out,
+                                void *grad_x, void *grad_offset, void *grad_weight, void *grad_bias,
+                                void *workspace, size_t workspace_bytes,
+                                const dlka_conv_geom *g, int dtype, void *stream);
+
+/* =======================================================================================
+ * Plain grouped N-d convolution — the nn.Conv3d / nn.Conv2d calls that sit on the path
+ * ======================================================================================= */
+
+/* Replaces the cuDNN-backed nn.Conv3d / nn.Conv2d modules inside the D-LKA block:
+ *   depthwise 5^3 pad 2 and 7^3 dil 3 pad 9   (3D/d_lka_former/network_architecture/synapse/transformerblock.py:637-638)
+ *   offset-predict conv C->81, 3^3 pad 1      (3D/d_lka_former/network_architecture/synapse/deform_conv.py:80-85)
+ *   1x1x1 convs proj_1 / conv1 / proj_2       (transformerblock.py:641,659,662)
+ *   2-D offset nets C->50 (5x5) / C->98 (7x7 dil 3) (2D/deformable_LKA/deformable_LKA.py:10-16)
+ *   x [B][C][D][H][W]; weight [Cout][C/group][kd][kh][kw]; bias [Cout] or NULL; out [B][Cout][Do][Ho][Wo]. */
+size_t dlka_conv3d_forward_workspace(const dlka_conv_geom *g, int dtype);
+int dlka_conv3d_forward(const void *x, const void *weight, const void *bias, void *out,
+                        void *workspace, size_t workspace_bytes,
+                        const dlka_conv_geom *g, int dtype, void *stream);
+/* grad_x / grad_weight / grad_bias may each be NULL to skip. All are fully overwritten. */
+size_t dlka_conv3d_backward_workspace(const dlka_conv_geom *g, int dtype);
+int dlka_conv3d_backward(const void *x, const void *weight, const void *grad_out,
+                         void *grad_x, void *grad_weight, void *grad_bias,
+                         void *workspace, size_t workspace_bytes,
+                         const dlka_conv_geom *g, int dtype, void *stream);
+
+/* =======================================================================================
+ * Elementwise pieces of the block (GELU, gate)
+ * ======================================================================================= */
+
+/* y = GELU_erf(x)  (nn.GELU() default, transformerblock.py:660);  n elements. */
+int dlka_gelu_forward(const void *x, void *y, int64_t n, int dtype, void *stream);
+/* gx = gy * dGELU(x) */
+int dlka_gelu_backward(const void *x, const void *gy, void *gx, int64_t n, int dtype, void *stream);
+/* y = a * b   (the "u * attn" gate, transformerblock.py:652; deformable_LKA.py:104) */
+int dlka_mul_forward(const void *a, const void *b, void *y, int64_t n, int dtype, void *stream);
+/* ga = gy * b ; gb = gy * a */
+int dlka_mul_backward(const void *a, const void *b, const void *gy, void *ga, void *gb, int64_t n, int dtype, void *stream);
+/* y = a + b */
+int dlka_add_forward(const void *a, const void *b, void *y, int64_t n, int dtype, void *stream);
+
+/* =======================================================================================
+ * Whole D-LKA attention blocks (fused launch sequences; one C call per block)
+ * ======================================================================================= */
+
+/* Parameters of LKA_Attention3d_deform (transformerblock.py:655-673) in state_dict order. All [..] dense. */
+typedef struct dlka_lka3d_params {
+    const void *proj_1_w, *proj_1_b;             /* [C][C][1][1][1], [C]              proj_1                         */
+    const void *conv0_w, *conv0_b;               /* [C][1][5][5][5], [C]              spatial_gating_unit.conv0       */
+    const void *conv_spatial_w, *conv_spatial_b; /* [C][1][7][7][7], [C]              spatial_gating_unit.conv_spatial */
+    const void *offset_w, *offset_b;             /* [81][C][3][3][3], [81]            ...deform_conv.conv_offset      */
+    const void *deform_w, *deform_b;             /* [C][C][3][3][3], [C]              ...deform_conv.{weight,bias}    */
+    const void *conv1_w, *conv1_b;               /* [C][C][1][1][1], [C]              spatial_gating_unit.conv1       */
+    const void *proj_2_w, *proj_2_b;             /* [C][C][1][1][1], [C]              proj_2                         */
+} dlka_lka3d_params;
+
+typedef struct dlka_lka3d_grads { /* same shapes as dlka_lka3d_params; all fully overwritten */
+    void *proj_1_w, *proj_1_b, *conv0_w, *conv0_b, *conv_spatial_w, *conv_spatial_b, *offset_w, *offset_b,
+         *deform_w, *deform_b, *conv1_w, *conv1_b, *proj_2_w, *proj_2_b;
+} dlka_lka3d_grads;
+
+/* Replaces  LKA_Attention3d_deform.forward(x, B, C, H, W, D)  (transformerblock.py:664-673) including
+ *           LKA3d_deform.forward (:644-652) and DeformConvPack.forward (synapse/deform_conv.py:93-105).
+ *   x, y: NCDHW volumes [B][C][D][H][W] (the (B,N,C)<->NCDHW permutes of :665,672 stay in the caller:
+ *   they are views/copies on the Python side exactly as in the reference).
+ *   saved: activations the backward needs; dlka_lka3d_saved_bytes(B,C,D,H,W,dtype) bytes, caller-owned,
+ *          must stay untouched until the matching backward call.
+ *   workspace: scratch, dlka_lka3d_workspace_bytes(...) bytes, may be reused right after the call. */
+size_t dlka_lka3d_saved_bytes(int B, int C, int D, int H, int W, int dtype);
+size_t dlka_lka3d_workspace_bytes(int B, int C, int D, int H, int W, int dtype);
+int dlka_lka3d_attention_forward(const void *x, const dlka_lka3d_params *p, void *y,
+                                 void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes,
+                                 int B, int C, int D, int H, int W, int dtype, void *stream);
+/* Backward of the above: grad_y -> grad_x and all 14 parameter gradients. */
+int dlka_lka3d_attention_backward(const void *x, const dlka_lka3d_params *p, const void *grad_y,
+                                  const void *saved, size_t saved_bytes,
+                                  void *grad_x, const dlka_lka3d_grads *grads,
+                                  void *workspace, size_t workspace_bytes,
+                                  int B, int C, int D, int H, int W, int dtype, void *stream);
+
+/* Parameters of the 2-D deformable_LKA_Attention (2D/deformable_LKA/deformable_LKA.py:124-140). */
+typedef struct dlka_lka2d_params {
+    const void *proj_1_w, *proj_1_b;             /* [C][C][1][1], [C]                                             */
+    const void *conv0_offset_w, *conv0_offset_b; /* [50][C][5][5], [50]   conv0.offset_net                         */
+    const void *conv0_w;                         /* [C][1][5][5]          conv0.deform_conv.weight (bias=False)    */
+    const void *conv_spatial_offset_w, *conv_spatial_offset_b; /* [98][C][7][7], [98]  conv_spatial.offset_net      */
+    const void *conv_spatial_w;                  /* [C][1][7][7]          conv_spatial.deform_conv.weight          */
+    const void *conv1_w, *conv1_b;               /* [C][C][1][1], [C]                                             */
+    const void *proj_2_w, *proj_2_b;             /* [C][C][1][1], [C]                                             */
+} dlka_lka2d_params;
+
+typedef struct dlka_lka2d_grads {
+    void *proj_1_w, *proj_1_b, *conv0_offset_w, *conv0_offset_b, *conv0_w,
+         *conv_spatial_offset_w, *conv_spatial_offset_b, *conv_spatial_w, *conv1_w, *conv1_b, *proj_2_w, *proj_2_b;
+} dlka_lka2d_grads;
+
+/* Replaces  deformable_LKA_Attention.forward (deformable_LKA.py:133-140) incl. deformable_LKA.forward (:98-104)
+ *           and DeformConv.forward (:27-30).  x, y: [B][C][H][W]. */
+size_t dlka_lka2d_saved_bytes(int B, int C, int H, int W, int dtype);
+size_t dlka_lka2d_workspace_bytes(int B, int C, int H, int W, int dtype);
+int dlka_lka2d_attention_forward(const void *x, const dlka_lka2d_params *p, void *y,
+                                 void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes,
+                                 int B, int C, int H, int W, int dtype, void *stream);
+int dlka_lka2d_attention_backward(const void *x, const dlka_lka2d_params *p, const void *grad_y,
+                                  const void *saved, size_t saved_bytes,
+                                  void *grad_x, const dlka_lka2d_grads *grads,
+                                  void *workspace, size_t workspace_bytes,
+                                  int B, int C, int H, int W, int dtype, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLKA_H_ */

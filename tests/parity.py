@@ -1,0 +1,140 @@
+"""Shared parity checks: the HIP path (through the C-ABI, via deformablelka_amd.ops) against the CPU oracle.
+Used by tests/test_parity_emu.py (host-compiled kernels on the wavefront emulator, tiny shapes, CPU-only
+container) and by tests/test_parity_gpu.py (-m gpu, real MI355X, reference-sized shapes)."""
+import torch
+import torch.nn.functional as F
+
+import oracle
+from deformablelka_amd import ops
+
+# tolerances (BASELINE.json north_star / SURVEY §8c): fwd fp32 <= 1e-4 abs vs oracle; bwd <= 1e-3 rel
+FWD_ATOL = 1e-4
+BWD_RTOL = 1e-3
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+
+
+def assert_close(name, got, ref, atol=None, rtol=None):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    if atol is not None:
+        err = (got - ref).abs().max().item()
+        assert err <= atol, f"{name}: max abs err {err:.3e} > {atol}"
+    if rtol is not None:
+        err = rel_err(got, ref)
+        assert err <= rtol, f"{name}: max rel err {err:.3e} > {rtol}"
+
+
+def make_deform3d(B, C, Cout, dims, k, s, p, d, g, dg, off_mode="normal", seed=0, scale=1.0):
+    gen = torch.Generator().manual_seed(seed)
+    k3 = (k,) * 3 if isinstance(k, int) else tuple(k)
+    s3 = (s,) * 3 if isinstance(s, int) else tuple(s)
+    p3 = (p,) * 3 if isinstance(p, int) else tuple(p)
+    d3 = (d,) * 3 if isinstance(d, int) else tuple(d)
+    D, H, W = dims
+    o = lambda i, kk, ss, pp, dd: (i + 2 * pp - (dd * (kk - 1) + 1)) // ss + 1
+    Do, Ho, Wo = (o(D, k3[0], s3[0], p3[0], d3[0]), o(H, k3[1], s3[1], p3[1], d3[1]), o(W, k3[2], s3[2], p3[2], d3[2]))
+    K = k3[0] * k3[1] * k3[2]
+    x = torch.randn(B, C, D, H, W, generator=gen)
+    w = torch.randn(Cout, C // g, *k3, generator=gen) * (1.0 / (C // g * K) ** 0.5)
+    b = torch.randn(Cout, generator=gen)
+    shp = (B, dg * 3 * K, Do, Ho, Wo)
+    if off_mode == "zero":
+        off = torch.zeros(shp)
+    elif off_mode == "uniform3":       # U(-3,3)
+        off = (torch.rand(shp, generator=gen) * 6 - 3)
+    elif off_mode == "wild":           # N(0,4^2): many out-of-bounds samples
+        off = torch.randn(shp, generator=gen) * 4
+    elif off_mode == "integer":        # exact integers incl. -1 and size
+        off = torch.randint(-2, 3, shp, generator=gen).float()
+    else:
+        off = torch.randn(shp, generator=gen) * scale
+    go = torch.randn(B, Cout, Do, Ho, Wo, generator=torch.Generator().manual_seed(seed + 1))
+    return x, off, w, b, go, (k3, s3, p3, d3)
+
+
+def check_deform3d(dev, B, C, Cout, dims, k, s, p, d, g, dg, off_mode="normal", seed=0, check_bwd=True, check_index=True):
+    x, off, w, b, go, (k3, s3, p3, d3) = make_deform3d(B, C, Cout, dims, k, s, p, d, g, dg, off_mode, seed)
+    ref = oracle.deform_conv3d_forward(x, w, b, off, s3, p3, d3, g, dg)
+    xd, od, wd, bd, god = (t.to(dev) for t in (x, off, w, b, go))
+    out = ops.deform_conv3d_forward(xd, wd, bd, od, k3, s3, p3, d3, g, dg, 64)
+    assert_close("deform3d fwd", out, ref, atol=FWD_ATOL)
+    if check_index:
+        idx, mask = ops.deform_conv3d_sample_index(od, dims, k3, s3, p3, d3, dg)
+        ridx, rmask = oracle.deform_conv3d_sample_index(off, dims, k3, s3, p3, d3, dg)
+        assert torch.equal(mask.cpu(), rmask), "guard mask not bit-exact"
+        assert torch.equal(idx.cpu(), ridx), "floor indices not bit-exact"
+    if check_bwd:
+        rgi, rgo, rgw, rgb = oracle.deform_conv3d_backward(x, w, b, off, go, s3, p3, d3, g, dg, q1_literal=False)
+        gi, goff, gw, gb = ops.deform_conv3d_backward(xd, wd, bd, od, god, k3, s3, p3, d3, g, dg, 64)
+        # integer-valued coordinates sit on the kink of the interpolant: the one-sided derivative is what both
+        # the reference and we compute, so it still has to match.
+        assert_close("deform3d grad_input", gi, rgi, rtol=BWD_RTOL)
+        assert_close("deform3d grad_offset", goff, rgo, rtol=BWD_RTOL)
+        assert_close("deform3d grad_weight", gw, rgw, rtol=BWD_RTOL)
+        assert_close("deform3d grad_bias", gb, rgb, rtol=BWD_RTOL)
+
+
+def make_deform2d(B, C, Cout, H, W, k, s, p, d, g, og, off_mode="normal", seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    kh, kw = k
+    o = lambda i, kk: (i + 2 * p - (d * (kk - 1) + 1)) // s + 1
+    Ho, Wo = o(H, kh), o(W, kw)
+    x = torch.randn(B, C, H, W, generator=gen)
+    w = torch.randn(Cout, C // g, kh, kw, generator=gen) * (1.0 / (C // g * kh * kw) ** 0.5)
+    shp = (B, og * 2 * kh * kw, Ho, Wo)
+    if off_mode == "zero":
+        off = torch.zeros(shp)
+    elif off_mode == "integer":
+        off = torch.randint(-2, 3, shp, generator=gen).float()
+    elif off_mode == "wild":
+        off = torch.randn(shp, generator=gen) * 4
+    else:
+        off = torch.randn(shp, generator=gen) * 1.5
+    go = torch.randn(B, Cout, Ho, Wo, generator=torch.Generator().manual_seed(seed + 1))
+    return x, off, w, go
+
+
+def check_deform2d(dev, B, C, Cout, H, W, k, s, p, d, g, og, off_mode="normal", seed=0, with_bias=False):
+    x, off, w, go = make_deform2d(B, C, Cout, H, W, k, s, p, d, g, og, off_mode, seed)
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(5)) if with_bias else None
+    ref = oracle.deform_conv2d_forward(x, off, w, bias, s, p, d)
+    xd, od, wd, god = (t.to(dev) for t in (x, off, w, go))
+    bd = None if bias is None else bias.to(dev)
+    out = ops.deform_conv2d_forward(xd, od, wd, bd, s, p, d)
+    assert_close("deform2d fwd", out, ref, atol=FWD_ATOL)
+    rgi, rgo, rgw, rgb = oracle.deform_conv2d_backward(x, off, w, go, s, p, d, with_bias=with_bias)
+    gi, goff, gw, gb = ops.deform_conv2d_backward(xd, od, wd, god, s, p, d, with_bias=with_bias)
+    assert_close("deform2d grad_input", gi, rgi, rtol=BWD_RTOL)
+    assert_close("deform2d grad_offset", goff, rgo, rtol=BWD_RTOL)
+    assert_close("deform2d grad_weight", gw, rgw, rtol=BWD_RTOL)
+    if with_bias:
+        assert_close("deform2d grad_bias", gb, rgb, rtol=BWD_RTOL)
+
+
+def check_conv3d(dev, B, C, Cout, dims, k, s, p, d, g, seed=0, use_aten_ref=True):
+    gen = torch.Generator().manual_seed(seed)
+    k3 = (k,) * 3 if isinstance(k, int) else tuple(k)
+    x = torch.randn(B, C, *dims, generator=gen)
+    w = torch.randn(Cout, C // g, *k3, generator=gen) * (1.0 / (C // g * k3[0] * k3[1] * k3[2]) ** 0.5)
+    b = torch.randn(Cout, generator=gen)
+    if use_aten_ref:   # the reference's own CPU path for these ops is ATen's conv (nn.Conv3d)
+        xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+        ref = F.conv3d(xr, wr, br, s, p, d, g)
+        go = torch.randn(ref.shape, generator=gen)
+        ref.backward(go.double())
+        rgi, rgw, rgb = xr.grad, wr.grad, br.grad
+        ref = ref.detach()
+    else:
+        ref = oracle.conv3d_forward(x, w, b, s, p, d, g)
+        go = torch.randn(ref.shape, generator=gen)
+        rgi, rgw, rgb = oracle.conv3d_backward(x, w, go, s, p, d, g)
+    out = ops.conv3d_forward(x.to(dev), w.to(dev), b.to(dev), s, p, d, g)
+    assert_close("conv3d fwd", out, ref, atol=FWD_ATOL)
+    gi, gw, gb = ops.conv3d_backward(x.to(dev), w.to(dev), go.to(dev), s, p, d, g)
+    assert_close("conv3d grad_input", gi, rgi, rtol=BWD_RTOL)
+    assert_close("conv3d grad_weight", gw, rgw, rtol=BWD_RTOL)
+    assert_close("conv3d grad_bias", gb, rgb, rtol=BWD_RTOL)
