@@ -1,0 +1,328 @@
+#!/usr/bin/env python
+"""bench.py — 3-D D-LKA fwd+bwd volumes/s on MI355X (BASELINE.json metric).
+
+One *step* = forward + backward through the 21 D-LKA attention blocks that one 64x128x128 Synapse patch traverses in
+D_LKA_Former (6x(C=32,32^3) + 6x(64,16^3) + 6x(128,8^3) + 3x(256,4^3)), batch 2 per GPU, plus the
+gradient all-reduce (N>1) and a plain SGD update of all block parameters.  Inputs are synthetic and already resident
+in HBM when the timed region starts.  `value` = volumes (patches) per second over all ranks.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see the driver contract), including
+  "roofline":     dominant kernel, algorithmic flops|bytes per launch / HIP-event duration, vs the MI355X peak
+  "cpu_baseline": the oracle block (ATen CPU convs + C deformable oracle) timed on the host cores, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PEAK_F32_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=2, help="volumes per GPU (BASELINE.json: b2)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample", default="stage", choices=["stage", "tiny"])
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# per-op HIP-event timing of the stage-0 block (C=32, 32^3, B): finds the dominant kernel and its roofline fraction
+# ----------------------------------------------------------------------------------------------------------------
+def op_table(B, C, N, dtype_bytes):
+    """(name, launches per step over the 21 blocks is derived separately) algorithmic flops / bytes for ONE launch at
+    stage (C, N^3, B).  Bytes follow SURVEY §8d's rule: unique input bytes + output bytes, intermediates on-chip = 0."""
+    n = N ** 3
+    E = B * C * n
+    Off = B * 81 * n
+    s = dtype_bytes
+    t = {}
+    t["pointwise_fwd"] = (2 * C * E, 2 * E * s)
+    t["dw5_fwd"] = (2 * 125 * E, 2 * E * s)
+    t["dw7_fwd"] = (2 * 343 * E, 2 * E * s)
+    t["offset_conv_fwd"] = (2 * 27 * C * 81 * B * n, (E + Off) * s)
+    t["deform_fwd"] = (2 * 27 * C * C * B * n + 27 * B * n * (15 * C + 30), (2 * E + Off) * s)
+    t["pointwise_bwd_data"] = (2 * C * E, 2 * E * s)
+    t["pointwise_bwd_weight"] = (2 * C * E, 2 * E * s)
+    t["dw5_bwd_data"] = (2 * 125 * E, 2 * E * s)
+    t["dw5_bwd_weight"] = (2 * 125 * E, 2 * E * s)
+    t["dw7_bwd_data"] = (2 * 343 * E, 2 * E * s)
+    t["dw7_bwd_weight"] = (2 * 343 * E, 2 * E * s)
+    t["offset_conv_bwd_data"] = (2 * 27 * C * 81 * B * n, (E + Off) * s)
+    t["offset_conv_bwd_weight"] = (2 * 27 * C * 81 * B * n, (E + Off) * s)
+    t["deform_bwd_input_offset"] = (2 * 27 * C * C * B * n + 27 * B * n * (45 * C + 60), (3 * E + 2 * Off) * s)
+    t["deform_bwd_weight"] = (2 * 27 * C * C * B * n + 27 * B * n * (15 * C + 30), (2 * E + Off) * s)
+    return t
+
+
+def time_ops(B, C, N, dtype, iters=10):
+    """HIP-event timing (torch.cuda.Event on the current stream == the stream the C-ABI launches on)."""
+    from ctypes import byref
+    from deformablelka_amd import _lib as L
+    lib = L.get_lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dt = L.DLKA_F32 if dtype == torch.float32 else L.DLKA_BF16
+    st = L.stream_ptr(torch.empty(1, device=dev))
+    g = torch.Generator().manual_seed(0)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev, dtype)
+    x, go = mk(B, C, N, N, N), mk(B, C, N, N, N)
+    off, goff = mk(B, 81, N, N, N), mk(B, 81, N, N, N)
+    out, out_off = torch.empty_like(x), torch.empty_like(off)
+    w_pw, w5, w7 = mk(C, C, 1, 1, 1), mk(C, 1, 5, 5, 5), mk(C, 1, 7, 7, 7)
+    w_off, w_dc = mk(81, C, 3, 3, 3) * 0.02, mk(C, C, 3, 3, 3) * 0.03
+    b_c, b_81 = mk(C), mk(81)
+    gw_pw, gw5, gw7, gw_off, gw_dc = (torch.empty_like(t) for t in (w_pw, w5, w7, w_off, w_dc))
+
+    def geom(cout, k, p, d, grp):
+        return L.ConvGeom(B, C, N, N, N, cout, k, k, k, 1, 1, 1, p, p, p, d, d, d, grp, 1, 64)
+
+    G = {"pw": geom(C, 1, 0, 1, 1), "dw5": geom(C, 5, 2, 1, C), "dw7": geom(C, 7, 9, 3, C), "off": geom(81, 3, 1, 1, 1),
+         "dcn": geom(C, 3, 1, 1, 1)}
+    wsb = max([lib.dlka_conv3d_forward_workspace(byref(v), dt) for v in G.values()] +
+              [lib.dlka_conv3d_backward_workspace(byref(v), dt) for v in G.values()] +
+              [lib.dlka_deform_conv3d_forward_workspace(byref(G["dcn"]), dt), lib.dlka_deform_conv3d_backward_workspace(byref(G["dcn"]), dt)])
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    P = L.ptr
+    N0 = None
+
+    def conv_fwd(key, w, b, inp, o):
+        return lambda: lib.dlka_conv3d_forward(P(inp), P(w), P(b), P(o), P(ws), wsb, byref(G[key]), dt, st)
+
+    def conv_bwd(key, w, inp, gout, gx, gw):
+        return lambda: lib.dlka_conv3d_backward(P(inp), P(w), P(gout), P(gx), P(gw), P(N0), P(ws), wsb, byref(G[key]), dt, st)
+
+    ops = {
+        "pointwise_fwd": conv_fwd("pw", w_pw, b_c, x, out),
+        "dw5_fwd": conv_fwd("dw5", w5, b_c, x, out),
+        "dw7_fwd": conv_fwd("dw7", w7, b_c, x, out),
+        "offset_conv_fwd": conv_fwd("off", w_off, b_81, x, out_off),
+        "deform_fwd": lambda: lib.dlka_deform_conv3d_forward(P(x), P(off), P(w_dc), P(b_c), P(out), P(ws), wsb, byref(G["dcn"]), dt, st),
+        "pointwise_bwd_data": conv_bwd("pw", w_pw, x, go, out, None),
+        "pointwise_bwd_weight": conv_bwd("pw", w_pw, x, go, None, gw_pw),
+        "dw5_bwd_data": conv_bwd("dw5", w5, x, go, out, None),
+        "dw5_bwd_weight": conv_bwd("dw5", w5, x, go, None, gw5),
+        "dw7_bwd_data": conv_bwd("dw7", w7, x, go, out, None),
+        "dw7_bwd_weight": conv_bwd("dw7", w7, x, go, None, gw7),
+        "offset_conv_bwd_data": conv_bwd("off", w_off, x, goff, out, None),
+        "offset_conv_bwd_weight": conv_bwd("off", w_off, x, goff, None, gw_off),
+        "deform_bwd_input_offset": lambda: lib.dlka_deform_conv3d_backward(P(x), P(off), P(w_dc), P(go), P(out), P(out_off), P(N0), P(N0), P(ws), wsb, byref(G["dcn"]), dt, st),
+        "deform_bwd_weight": lambda: lib.dlka_deform_conv3d_backward(P(x), P(off), P(w_dc), P(go), P(N0), P(N0), P(gw_dc), P(N0), P(ws), wsb, byref(G["dcn"]), dt, st),
+    }
+    res = {}
+    for name, fn in ops.items():
+        rc = fn()
+        if rc != 0:
+            raise RuntimeError(f"{name}: dlka status {rc}")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / iters  # ms per launch
+    return res
+
+
+# launches of each op per stage-block fwd+bwd (3 pointwise convs per block)
+OP_COUNT = {"pointwise_fwd": 3, "pointwise_bwd_data": 3, "pointwise_bwd_weight": 3}
+
+
+def roofline_report(B, dtype):
+    dbytes = 4 if dtype == torch.float32 else 2
+    C, N = 32, 32  # stage 0 carries ~70% of the step's FLOPs
+    ms = time_ops(B, C, N, dtype)
+    tab = op_table(B, C, N, dbytes)
+    peak_tf = PEAK_F32_TFLOPS if dtype == torch.float32 else PEAK_BF16_TFLOPS
+    ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+    rows = []
+    for name, t in ms.items():
+        fl, by = tab[name]
+        rows.append((t * OP_COUNT.get(name, 1), name, t, fl, by))
+    rows.sort(reverse=True)
+    log("per-op HIP-event timing, stage 0 (C=32, 32^3, B=%d), ms per launch:" % B)
+    for tot, name, t, fl, by in rows:
+        log(f"  {name:26s} {t:9.4f} ms  x{OP_COUNT.get(name, 1)}  {fl / t / 1e9:9.1f} GFLOP/s  {by / t / 1e6:9.1f} GB/s")
+    _, name, t, fl, by = rows[0]
+    ai = fl / by
+    if ai > ridge:
+        ach, peak, unit, bound = fl / (t * 1e-3) / 1e12, peak_tf, "TFLOP/s", "mfma"
+    else:
+        ach, peak, unit, bound = by / (t * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(name)
+        except Exception:
+            traffic = None
+    return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5),
+            "traffic": traffic, "kernel": name, "kernel_ms": round(t, 4), "algorithmic_flops": fl, "algorithmic_bytes": by,
+            "shape": f"C={C},{N}^3,B={B}", "per_op_ms": {k: round(v, 4) for k, v in ms.items()}}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle block on the host cores, bounded sample
+# ----------------------------------------------------------------------------------------------------------------
+def cpu_baseline(sample):
+    import oracle
+    from oracle import blocks
+    import deformablelka_amd as dk
+    oracle.build()
+    cores = torch.get_num_threads()
+    if sample == "tiny":
+        stages = [(32, (8, 8, 8), 6), (64, (4, 4, 4), 6)]
+        desc = "TINY shapes (debug only)"
+    else:
+        from deformablelka_amd.stack import SYNAPSE_STAGES
+        stages = SYNAPSE_STAGES
+        desc = ("one D-LKA block fwd+bwd per stage at B=1 (4 of the 21 blocks), fp32, ATen CPU convs + C deformable "
+                "oracle (OpenMP); per-volume time extrapolated as 6*t0+6*t1+6*t2+3*t3")
+    total = 0.0
+    per_stage = []
+    # untimed warm-up (thread pools, oneDNN primitive caches)
+    _m = dk.LKA_Attention3d_deform(8)
+    _P = {k: v.detach().clone().requires_grad_(True) for k, v in _m.state_dict().items()}
+    blocks.lka3d_attention_volume(torch.randn(1, 8, 6, 6, 6, requires_grad=True), _P).sum().backward()
+    for C, dims, nblk in stages:
+        torch.manual_seed(0)
+        m = dk.LKA_Attention3d_deform(C)
+        blocks.randomize_offsets_(m, std=0.02)
+        P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+        x = torch.randn(1, C, *dims, requires_grad=True)
+        gy = torch.randn(1, C, *dims)
+        t0 = time.perf_counter()
+        y = blocks.lka3d_attention_volume(x, P)
+        y.backward(gy)
+        dt = time.perf_counter() - t0
+        per_stage.append(round(dt, 3))
+        total += dt * nblk
+    return {"value": round(1.0 / total, 5), "unit": "volumes/s", "cores": cores, "kind": "port", "sample": desc,
+            "per_stage_block_s": per_stage}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm; ranks talk over xGMI
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from deformablelka_amd.stack import DLKABlockStack
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    stack = DLKABlockStack(args.batch, device=dev, dtype=dtype, seed=1234 + rank)
+    lr = 1e-3
+
+    def compute():
+        stack.forward_backward()
+
+    graph = None
+    # eager warm-up (also first-touch of every kernel), then capture
+    compute()
+    torch.cuda.synchronize()
+    if not args.no_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                compute()
+            torch.cuda.current_stream().wait_stream(s)
+            with torch.cuda.graph(graph):
+                compute()
+        except Exception as e:  # capture is an optimisation, not a requirement
+            log("hipGraph capture failed, running eagerly:", repr(e))
+            graph = None
+            torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            compute()
+        if world > 1:
+            dist.all_reduce(stack.flat_grads)           # one flat bucket: all 15.4M block parameters
+        stack.flat_params.add_(stack.flat_grads, alpha=-lr / world)   # SGD update
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = args.batch * world * args.steps / elapsed
+
+    if rank == 0:
+        out = {
+            "metric": "3D D-LKA fwd+bwd volumes/sec (64x128x128, b2)", "value": round(value, 3), "unit": "volumes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "3D D-LKA Former Synapse 64x128x128 patch: fwd+bwd of its 21 D-LKA attention blocks "
+                                   "(6x(32,32^3)+6x(64,16^3)+6x(128,8^3)+3x(256,4^3)) + grad all-reduce + SGD update",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "block_params": stack.num_params(), "hipgraph": graph is not None},
+        }
+        if not args.no_roofline:
+            try:
+                out["roofline"] = roofline_report(args.batch, dtype)
+            except Exception as e:
+                log("roofline timing failed:", repr(e))
+                out["roofline"] = None
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+            except Exception as e:
+                log("cpu baseline failed:", repr(e))
+                out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

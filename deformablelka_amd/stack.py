@@ -1,0 +1,130 @@
+"""Static-memory engine for a stack of 3-D D-LKA blocks (the 21 blocks one 64x128x128 patch traverses in
+D_LKA_Former, 3D/d_lka_former/network_architecture/synapse/model_components.py:33-39,127-131).
+
+MI355X-first layout: every parameter lives in ONE flat HBM buffer (``flat_params``), every gradient in one flat
+buffer of the same layout (``flat_grads``) — a single RCCL all-reduce per step with no bucketing copies —, saved
+activations of all blocks stay resident (288 GB HBM makes recomputation pointless at this size), and the whole
+fwd+bwd is a fixed sequence of C-ABI calls on one stream, so it can be captured in a hipGraph and replayed.
+"""
+from __future__ import annotations
+
+from ctypes import byref
+from typing import List, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+# (C, (H, W, D), number of blocks) for a 64x128x128 patch with the (2,4,4) stem — SURVEY.md §8 stage table
+SYNAPSE_STAGES: Tuple[Tuple[int, Tuple[int, int, int], int], ...] = (
+    (32, (32, 32, 32), 6), (64, (16, 16, 16), 6), (128, (8, 8, 8), 6), (256, (4, 4, 4), 3))
+CHAIN = 3  # blocks per stage instance are applied back to back (model_components.py:33-39)
+
+
+def _param_shapes(C: int):
+    return [(C, C, 1, 1, 1), (C,), (C, 1, 5, 5, 5), (C,), (C, 1, 7, 7, 7), (C,), (81, C, 3, 3, 3), (81,),
+            (C, C, 3, 3, 3), (C,), (C, C, 1, 1, 1), (C,), (C, C, 1, 1, 1), (C,)]
+
+
+class _Block:
+    __slots__ = ("C", "dims", "params", "grads", "pstruct", "gstruct", "saved", "x", "y", "gx", "gy", "saved_bytes")
+
+
+class DLKABlockStack:
+    def __init__(self, batch: int, stages: Sequence = SYNAPSE_STAGES, device="cuda:0", dtype=torch.float32, seed: int = 0,
+                 offset_std_voxels: float = 1.0):
+        self.B, self.device, self.dtype = batch, torch.device(device), dtype
+        self.lib = L.get_lib()
+        self.dt = L.DLKA_F32 if dtype == torch.float32 else L.DLKA_BF16
+        gen = torch.Generator().manual_seed(seed)
+        shapes_all = []
+        for C, dims, n in stages:
+            for _ in range(n):
+                shapes_all.append((C, dims, _param_shapes(C)))
+        total = sum(sum(int(torch.Size(s).numel()) for s in sh) for _, _, sh in shapes_all)
+        self.flat_params = torch.empty(total, dtype=dtype, device=self.device)
+        self.flat_grads = torch.zeros(total, dtype=dtype, device=self.device)
+        self.blocks: List[_Block] = []
+        self.chains: List[List[_Block]] = []
+        off = 0
+        ws_bytes = 0
+        for C, dims, shapes in shapes_all:
+            blk = _Block()
+            blk.C, blk.dims = C, dims
+            blk.params, blk.grads = [], []
+            for s in shapes:
+                n = int(torch.Size(s).numel())
+                blk.params.append(self.flat_params[off:off + n].view(s))
+                blk.grads.append(self.flat_grads[off:off + n].view(s))
+                off += n
+            self._init_block(blk, gen, offset_std_voxels)
+            blk.pstruct = L.Lka3dPtrs(*[p.data_ptr() for p in blk.params])
+            blk.gstruct = L.Lka3dPtrs(*[g.data_ptr() for g in blk.grads])
+            H, W, D = dims
+            blk.saved_bytes = self.lib.dlka_lka3d_saved_bytes(batch, C, H, W, D, self.dt)
+            blk.saved = torch.empty(blk.saved_bytes, dtype=torch.uint8, device=self.device)
+            ws_bytes = max(ws_bytes, self.lib.dlka_lka3d_workspace_bytes(batch, C, H, W, D, self.dt))
+            self.blocks.append(blk)
+        self.ws_bytes = ws_bytes
+        self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        # activations: blocks of one stage instance are chained x -> y -> ... ; each chain has a synthetic input and
+        # a synthetic grad_output (the layers between chains — down/up-sampling, UnetResBlock — are not D-LKA).
+        i = 0
+        for C, dims, n in stages:
+            for c0 in range(0, n, CHAIN):
+                chain = self.blocks[i + c0:i + min(c0 + CHAIN, n)]
+                shape = (batch, C) + tuple(dims)
+                acts = [torch.randn(shape, generator=gen).to(self.device, dtype)] + \
+                       [torch.empty(shape, dtype=dtype, device=self.device) for _ in chain]
+                gacts = [torch.empty(shape, dtype=dtype, device=self.device) for _ in chain] + \
+                        [torch.randn(shape, generator=gen).to(self.device, dtype)]
+                for j, blk in enumerate(chain):
+                    blk.x, blk.y = acts[j], acts[j + 1]
+                    blk.gx, blk.gy = gacts[j], gacts[j + 1]
+                self.chains.append(chain)
+            i += n
+
+    # reference initialisers: nn.Conv3d default (kaiming_uniform a=sqrt(5) + uniform bias), DeformConv weight/bias
+    # (3D/dcn/modules/deform_conv.py:44-50).  conv_offset would be zero (deform_conv.py:86-88) which makes every
+    # sample integer-aligned; for timing it is drawn so that predicted offsets have ~offset_std_voxels std.
+    def _init_block(self, blk, gen, offset_std):
+        import math
+        for idx in range(0, 14, 2):
+            w, b = blk.params[idx], blk.params[idx + 1]
+            fan_in = int(w[0].numel())
+            bound = 1.0 / math.sqrt(fan_in)
+            w.copy_(((torch.rand(w.shape, generator=gen) * 2 - 1) * bound).to(self.device, self.dtype))
+            b.copy_(((torch.rand(b.shape, generator=gen) * 2 - 1) * bound).to(self.device, self.dtype))
+        ow, ob = blk.params[6], blk.params[7]
+        fan_in = int(ow[0].numel())
+        # input to conv_offset has O(0.1-1) magnitude after the two depthwise convs; scale empirically fixed per C
+        ow.copy_((torch.randn(ow.shape, generator=gen) * (offset_std * 3.0 / math.sqrt(fan_in))).to(self.device, self.dtype))
+        ob.zero_()
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def forward(self):
+        st = self._stream()
+        for blk in self.blocks:
+            H, W, D = blk.dims
+            rc = self.lib.dlka_lka3d_attention_forward(L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.y), L.ptr(blk.saved),
+                                                       blk.saved_bytes, L.ptr(self.ws), self.ws_bytes, self.B, blk.C, H, W, D,
+                                                       self.dt, st)
+            L.check(rc, "lka3d_attention_forward")
+
+    def backward(self):
+        st = self._stream()
+        for blk in reversed(self.blocks):
+            H, W, D = blk.dims
+            rc = self.lib.dlka_lka3d_attention_backward(L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.gy), L.ptr(blk.saved),
+                                                        blk.saved_bytes, L.ptr(blk.gx), byref(blk.gstruct), L.ptr(self.ws),
+                                                        self.ws_bytes, self.B, blk.C, H, W, D, self.dt, st)
+            L.check(rc, "lka3d_attention_backward")
+
+    def forward_backward(self):
+        self.forward()
+        self.backward()
+
+    def num_params(self) -> int:
+        return int(self.flat_params.numel())

@@ -73,3 +73,14 @@ def test_gelu():
     xr = x.clone().requires_grad_(True)
     torch.nn.functional.gelu(xr).backward(gy)
     assert torch.allclose(ops.gelu_backward(x, gy), xr.grad, atol=1e-5)
+
+
+GOLDEN = ["DeformConvPack_k3", "DeformConvPack_k5_dw_zero", "DeformConv_g2_dg2_nobias", "DeformConvPack_d_TW",
+          "DeformConvPack_d_HW", "DeformConvPack_d_H", "DeformConvPack_Depth", "LKA3d_deform", "LKA_Attention3d_deform",
+          "DeformConv2d_k5_dw", "deformable_LKA_Attention"]
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_reference_module_golden(name):
+    from tests.golden_checks import replay
+    replay(name, "cpu")
