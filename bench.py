@@ -164,7 +164,7 @@ def roofline_report(B, dtype):
     rows.sort(reverse=True)
     log("per-op HIP-event timing, stage 0 (C=32, 32^3, B=%d), ms per launch:" % B)
     for tot, name, t, fl, by in rows:
-        log(f"  {name:26s} {t:9.4f} ms  x{OP_COUNT.get(name, 1)}  {fl / t / 1e9:9.1f} GFLOP/s  {by / t / 1e6:9.1f} GB/s")
+        log(f"  {name:26s} {t:9.4f} ms  x{OP_COUNT.get(name, 1)}  {fl / t / 1e9:9.2f} TFLOP/s  {by / t / 1e6:9.1f} GB/s")
     _, name, t, fl, by = rows[0]
     ai = fl / by
     if ai > ridge:
