@@ -78,7 +78,8 @@ def op_table(B, C, N, dtype_bytes):
 
 
 def time_ops(B, C, N, dtype, iters=10):
-    """HIP-event timing (torch.cuda.Event on the current stream == the stream the C-ABI launches on)."""
+    """HIP-event timing (torch.cuda.Event on the current stream == the stream the C-ABI launches on) of every
+    kernel-level op of one token-layout block, through the channels-last entry points the block itself uses."""
     from ctypes import byref
     from deformablelka_amd import _lib as L
     lib = L.get_lib()
@@ -87,8 +88,8 @@ def time_ops(B, C, N, dtype, iters=10):
     st = L.stream_ptr(torch.empty(1, device=dev))
     g = torch.Generator().manual_seed(0)
     mk = lambda *s: torch.randn(*s, generator=g).to(dev, dtype)
-    x, go = mk(B, C, N, N, N), mk(B, C, N, N, N)
-    off, goff = mk(B, 81, N, N, N), mk(B, 81, N, N, N)
+    x, go = mk(B, N, N, N, C), mk(B, N, N, N, C)                     # channels-last activations
+    off, goff = mk(B, 81, N, N, N), mk(B, 81, N, N, N)               # planar offsets
     out, out_off = torch.empty_like(x), torch.empty_like(off)
     w_pw, w5, w7 = mk(C, C, 1, 1, 1), mk(C, 1, 5, 5, 5), mk(C, 1, 7, 7, 7)
     w_off, w_dc = mk(81, C, 3, 3, 3) * 0.02, mk(C, C, 3, 3, 3) * 0.03
@@ -100,35 +101,34 @@ def time_ops(B, C, N, dtype, iters=10):
 
     G = {"pw": geom(C, 1, 0, 1, 1), "dw5": geom(C, 5, 2, 1, C), "dw7": geom(C, 7, 9, 3, C), "off": geom(81, 3, 1, 1, 1),
          "dcn": geom(C, 3, 1, 1, 1)}
-    wsb = max([lib.dlka_conv3d_forward_workspace(byref(v), dt) for v in G.values()] +
-              [lib.dlka_conv3d_backward_workspace(byref(v), dt) for v in G.values()] +
-              [lib.dlka_deform_conv3d_forward_workspace(byref(G["dcn"]), dt), lib.dlka_deform_conv3d_backward_workspace(byref(G["dcn"]), dt)])
+    wsb = max([lib.dlka_conv3d_cl_workspace(byref(v), dt, 1) for v in G.values()] +
+              [lib.dlka_deform_conv3d_cl_workspace(byref(G["dcn"]), dt, 1)])
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     P = L.ptr
     N0 = None
 
-    def conv_fwd(key, w, b, inp, o):
-        return lambda: lib.dlka_conv3d_forward(P(inp), P(w), P(b), P(o), P(ws), wsb, byref(G[key]), dt, st)
+    def conv_fwd(key, w, b, inp, o, planar=0):
+        return lambda: lib.dlka_conv3d_forward_cl(P(inp), P(w), P(b), P(o), planar, P(ws), wsb, byref(G[key]), dt, st)
 
-    def conv_bwd(key, w, inp, gout, gx, gw):
-        return lambda: lib.dlka_conv3d_backward(P(inp), P(w), P(gout), P(gx), P(gw), P(N0), P(ws), wsb, byref(G[key]), dt, st)
+    def conv_bwd(key, w, inp, gout, gx, gw, planar=0):
+        return lambda: lib.dlka_conv3d_backward_cl(P(inp), P(w), P(gout), planar, P(gx), P(gw), P(N0), P(ws), wsb, byref(G[key]), dt, st)
 
     ops = {
         "pointwise_fwd": conv_fwd("pw", w_pw, b_c, x, out),
         "dw5_fwd": conv_fwd("dw5", w5, b_c, x, out),
         "dw7_fwd": conv_fwd("dw7", w7, b_c, x, out),
-        "offset_conv_fwd": conv_fwd("off", w_off, b_81, x, out_off),
-        "deform_fwd": lambda: lib.dlka_deform_conv3d_forward(P(x), P(off), P(w_dc), P(b_c), P(out), P(ws), wsb, byref(G["dcn"]), dt, st),
+        "offset_conv_fwd": conv_fwd("off", w_off, b_81, x, out_off, 1),
+        "deform_fwd": lambda: lib.dlka_deform_conv3d_forward_cl(P(x), P(off), P(w_dc), P(b_c), P(out), P(ws), wsb, byref(G["dcn"]), dt, st),
         "pointwise_bwd_data": conv_bwd("pw", w_pw, x, go, out, None),
         "pointwise_bwd_weight": conv_bwd("pw", w_pw, x, go, None, gw_pw),
         "dw5_bwd_data": conv_bwd("dw5", w5, x, go, out, None),
         "dw5_bwd_weight": conv_bwd("dw5", w5, x, go, None, gw5),
         "dw7_bwd_data": conv_bwd("dw7", w7, x, go, out, None),
         "dw7_bwd_weight": conv_bwd("dw7", w7, x, go, None, gw7),
-        "offset_conv_bwd_data": conv_bwd("off", w_off, x, goff, out, None),
-        "offset_conv_bwd_weight": conv_bwd("off", w_off, x, goff, None, gw_off),
-        "deform_bwd_input_offset": lambda: lib.dlka_deform_conv3d_backward(P(x), P(off), P(w_dc), P(go), P(out), P(out_off), P(N0), P(N0), P(ws), wsb, byref(G["dcn"]), dt, st),
-        "deform_bwd_weight": lambda: lib.dlka_deform_conv3d_backward(P(x), P(off), P(w_dc), P(go), P(N0), P(N0), P(gw_dc), P(N0), P(ws), wsb, byref(G["dcn"]), dt, st),
+        "offset_conv_bwd_data": conv_bwd("off", w_off, x, goff, out, None, 1),
+        "offset_conv_bwd_weight": conv_bwd("off", w_off, x, goff, None, gw_off, 1),
+        "deform_bwd_input_offset": lambda: lib.dlka_deform_conv3d_backward_cl(P(x), P(off), P(w_dc), P(go), P(out), P(out_off), P(N0), P(N0), P(ws), wsb, byref(G["dcn"]), dt, st),
+        "deform_bwd_weight": lambda: lib.dlka_deform_conv3d_backward_cl(P(x), P(off), P(w_dc), P(go), P(N0), P(N0), P(gw_dc), P(N0), P(ws), wsb, byref(G["dcn"]), dt, st),
     }
     res = {}
     for name, fn in ops.items():

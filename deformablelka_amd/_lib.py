@@ -80,6 +80,21 @@ SIGNATURES = {
                                      + [c_int] * 5 + [c_void_p]),
     "dlka_lka2d_attention_backward": (c_int, [c_void_p, POINTER(Lka2dPtrs), c_void_p, c_void_p, c_size_t, c_void_p,
                                               POINTER(Lka2dPtrs), c_void_p, c_size_t] + [c_int] * 5 + [c_void_p]),
+    "dlka_conv3d_cl_workspace": (c_size_t, [_G, c_int, c_int]),
+    "dlka_conv3d_forward_cl": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_size_t, _G, c_int, c_void_p]),
+    "dlka_conv3d_backward_cl": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 4 + [c_size_t, _G, c_int, c_void_p]),
+    "dlka_deform_conv3d_cl_workspace": (c_size_t, [_G, c_int, c_int]),
+    "dlka_deform_conv3d_forward_cl": (c_int, [c_void_p] * 6 + [c_size_t, _G, c_int, c_void_p]),
+    "dlka_deform_conv3d_backward_cl": (c_int, [c_void_p] * 9 + [c_size_t, _G, c_int, c_void_p]),
+    "dlka_ncdhw_to_ndhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dlka_ndhwc_to_ncdhw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dlka_lka3d_tokens_supported": (c_int, [c_int] * 6),
+    "dlka_lka3d_tokens_saved_bytes": (c_size_t, [c_int] * 6),
+    "dlka_lka3d_tokens_workspace_bytes": (c_size_t, [c_int] * 6),
+    "dlka_lka3d_attention_tokens_forward": (c_int, [c_void_p, POINTER(Lka3dPtrs), c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]
+                                            + [c_int] * 6 + [c_void_p]),
+    "dlka_lka3d_attention_tokens_backward": (c_int, [c_void_p, POINTER(Lka3dPtrs), c_void_p, c_void_p, c_size_t, c_void_p,
+                                                     POINTER(Lka3dPtrs), c_void_p, c_size_t] + [c_int] * 6 + [c_void_p]),
 }
 
 

@@ -1,0 +1,65 @@
+// Argument blocks of the channels-last kernels (shared between the kernel files and the C-ABI sequencing code).
+#pragma once
+#include "dlka_common.h"
+
+namespace dlka {
+
+struct IgemmArgs {
+    const float *in;     // AMODE 0/1: [B][N][Cin] channels-last; AMODE 2: [B][CinReal][N] planar
+    const float *off;    // AMODE 1: [B][3K][N] planar offsets (reference layout)
+    const float *wp;     // [K][CinP][NP] prepared weights (zero padded)
+    const float *bias;   // [Cout] or null
+    const float *aux;    // epilogue operand (channels-last [M][Cout]) or null
+    float *out;          // OMODE 0: [M][Cout] channels-last; OMODE 1: [B][Cout][N] planar
+    float *out2;         // second epilogue output or null
+    int B, D, H, W, N, M;
+    int Cin, CinReal, CinP, Cout, NP;
+    int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
+    int units_per_split; // work units (tap, 32-channel chunk) per blockIdx.y; K * CinP/32 when gridDim.y == 1
+    int epi;             // 0: out = acc+bias | 1: out = acc+bias, out2 = gelu(out) | 2: out = acc+bias, out2 = aux*out | 3: out = acc+bias+aux
+};
+
+struct WgradArgs {
+    const float *g;
+    const float *in;    // [B][N][Cin] channels-last
+    const float *off;   // AMODE 1: planar offsets [B][3K][N]
+    float *part;        // [chunks][K][CoutP][Cin]
+    int B, D, H, W, N, M;
+    int Cin, Cout, CoutP;
+    int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
+    int rows_per_chunk;  // multiple of 32
+    int CT;              // Cin / 32
+};
+
+struct DwArgs {
+    const float *in;    // [B][D][H][W][C]
+    const float *wp;    // [K][C] prepared weights (tap-major, channel contiguous)
+    const float *bias;  // [C] or null
+    float *out;         // [B][D][H][W][C]
+    int B, D, H, W, C;
+    int kd, kh, pd, ph, pw, dd, dh;   // kw / dw are template parameters
+};
+
+struct DwWgradArgs {
+    const float *g;     // [B][D][H][W][C]
+    const float *in;    // [B][D][H][W][C]
+    float *gwp;         // [K][C] fp32, zero-initialised
+    int B, D, H, W, C;
+    int kd, kh, pd, ph, pw, dd, dh;
+    int rows_per_block;
+};
+
+struct DeformBwdArgs {
+    const float *in;    // [B][N][C] channels-last
+    const float *off;   // [B][3K][N] planar
+    const float *g;     // [M][Cout] channels-last grad_out
+    const float *wp;    // [K][CoutP][C]: wp[tap][co][ci] = W[co][ci][tap], rows co >= Cout are zero
+    float *gx;          // [B][N][C] fp32, zero-initialised (atomics)
+    float *goff;        // [B][3K][N] planar
+    int B, D, H, W, N, M;
+    int C, Cout, CoutP;
+    int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
+    int cc_per_block;   // 32-channel input chunks per blockIdx.z; grad_offset uses atomics when gridDim.z > 1
+};
+
+}  // namespace dlka

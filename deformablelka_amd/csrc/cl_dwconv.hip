@@ -1,0 +1,232 @@
+// Channels-last depthwise 3-D convolution (the large-kernel half of D-LKA): 5^3 pad 2 and 7^3 dilation 3 pad 9
+// (3D/d_lka_former/network_architecture/synapse/transformerblock.py:637-638; cuDNN in the reference).
+//
+// Depthwise = no contraction over channels, so this is a register-tiled vector kernel, not a GEMM: lanes run over
+// channels (every load / store is a contiguous 128-byte-per-32-lanes row piece of the [voxel][C] layout), each
+// work-item owns TW consecutive outputs along W and slides the KW taps over one input row segment held in registers
+// (TW + (KW-1)*DIL loads feed TW*KW FMAs).  Same kernel = forward and data gradient (flipped taps, no bias).
+#include "cl_args.h"
+#include "dlka_kernels.h"
+
+namespace dlka {
+
+template <int KW, int DIL, int TW>
+__global__ __launch_bounds__(256) void cl_dwconv_kernel(DwArgs p)
+{
+    constexpr int SEG = TW + (KW - 1) * DIL;
+    const int cpb = p.C < 256 ? p.C : 256;           // channels per block
+    const int rpb = 256 / cpb;                       // W-runs per block
+    const int c = blockIdx.z * cpb + threadIdx.x % cpb;
+    const int run = blockIdx.x * rpb + threadIdx.x / cpb;
+    const int runs_per_row = cdiv(p.W, TW);
+    const int rows = p.B * p.D * p.H;
+    if (run >= rows * runs_per_row || c >= p.C) return;
+    const int w0 = (run % runs_per_row) * TW;
+    const int row = run / runs_per_row;
+    const int h0 = row % p.H, d0 = (row / p.H) % p.D, b = row / (p.H * p.D);
+
+    float acc[TW];
+    const float bv = p.bias ? p.bias[c] : 0.f;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) acc[t] = bv;
+
+    for (int i = 0; i < p.kd; ++i) {
+        const int zd = d0 + i * p.dd - p.pd;
+        if (zd < 0 || zd >= p.D) continue;
+        for (int j = 0; j < p.kh; ++j) {
+            const int zh = h0 + j * p.dh - p.ph;
+            if (zh < 0 || zh >= p.H) continue;
+            const float *rowp = p.in + (((long)(b * p.D + zd) * p.H + zh) * p.W) * p.C + c;
+            float seg[SEG];
+#pragma unroll
+            for (int e = 0; e < SEG; ++e) {
+                const int zw = w0 - p.pw + e;
+                seg[e] = (zw >= 0 && zw < p.W) ? rowp[(long)zw * p.C] : 0.f;
+            }
+            const float *wrow = p.wp + (long)((i * p.kh + j) * KW) * p.C + c;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const float wv = wrow[(long)k * p.C];
+#pragma unroll
+                for (int t = 0; t < TW; ++t) acc[t] = fmaf(wv, seg[t + k * DIL], acc[t]);
+            }
+        }
+    }
+    float *op = p.out + (((long)(b * p.D + d0) * p.H + h0) * p.W + w0) * p.C + c;
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+        if (w0 + t < p.W) op[(long)t * p.C] = acc[t];
+}
+
+// reference layout W[c][1][kd][kh][kw] -> Wp[tap][c]; flip = 1 reverses the taps (data gradient)
+__global__ void cl_dw_prep_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int C, int K, int flip)
+{
+    const int n = C * K;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const int c = e % C, tap = e / C;
+        wp[e] = w[(long)c * K + (flip ? K - 1 - tap : tap)];
+    }
+}
+
+int launch_cl_dw_prep_weight(const float *w, float *wp, int C, int K, int flip, hipStream_t st)
+{
+    hipLaunchKernelGGL(cl_dw_prep_weight_kernel, dim3(cdiv(C * K, 256)), dim3(256), 0, st, w, wp, C, K, flip);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+// kw, dil_w select the instantiation; returns DLKA_ERR_UNSUPPORTED for other shapes (caller falls back to conv.hip)
+int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st)
+{
+    constexpr int TW = 8;
+    const int cpb = a.C < 256 ? a.C : 256, rpb = 256 / cpb;
+    const long runs = (long)a.B * a.D * a.H * cdiv(a.W, TW);
+    dim3 grid((unsigned)cdivl(runs, rpb), 1, cdiv(a.C, cpb)), block(256);
+    if (256 % cpb != 0) return DLKA_ERR_UNSUPPORTED;
+    if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_kernel<3, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_kernel<5, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_kernel<7, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else return DLKA_ERR_UNSUPPORTED;
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise weight gradient:  gW[c][tap] = sum_{b,d,h,w} G[b,d,h,w][c] * in[b, d+i*dd-pd, h+j*dh-ph, w+k*dw-pw][c]
+// grid.y = (i, j) tap rows; a work-item owns channel c and strides over (b, d, h, W-run); KW accumulators.
+// Work-items of a block that share c fold through LDS, then one fp32 atomic per (c, tap) per block into gWp[tap][c].
+// ---------------------------------------------------------------------------------------------
+template <int KW, int DIL, int TW>
+__global__ __launch_bounds__(256) void cl_dwconv_wgrad_kernel(DwWgradArgs p)
+{
+    constexpr int SEG = TW + (KW - 1) * DIL;
+    __shared__ float red[256 * KW];
+    const int cpb = p.C < 256 ? p.C : 256, rpb = 256 / cpb;
+    const int c = blockIdx.z * cpb + threadIdx.x % cpb;
+    const int rsub = threadIdx.x / cpb;
+    const int i = blockIdx.y / p.kh, j = blockIdx.y % p.kh;
+    const int runs_per_row = cdiv(p.W, TW);
+    const int rows = p.B * p.D * p.H;
+    const long run_lo = (long)blockIdx.x * p.rows_per_block * runs_per_row;
+    const long run_hi = min((long)rows * runs_per_row, run_lo + (long)p.rows_per_block * runs_per_row);
+    float acc[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) acc[k] = 0.f;
+    if (c < p.C) {
+        for (long run = run_lo + rsub; run < run_hi; run += rpb) {
+            const int w0 = (int)(run % runs_per_row) * TW;
+            const int row = (int)(run / runs_per_row);
+            const int h0 = row % p.H, d0 = (row / p.H) % p.D, b = row / (p.H * p.D);
+            const int zd = d0 + i * p.dd - p.pd, zh = h0 + j * p.dh - p.ph;
+            if (zd < 0 || zd >= p.D || zh < 0 || zh >= p.H) continue;
+            const float *gp = p.g + (((long)(b * p.D + d0) * p.H + h0) * p.W + w0) * p.C + c;
+            const float *rowp = p.in + (((long)(b * p.D + zd) * p.H + zh) * p.W) * p.C + c;
+            float gv[TW], seg[SEG];
+#pragma unroll
+            for (int t = 0; t < TW; ++t) gv[t] = (w0 + t < p.W) ? gp[(long)t * p.C] : 0.f;
+#pragma unroll
+            for (int e = 0; e < SEG; ++e) {
+                const int zw = w0 - p.pw + e;
+                seg[e] = (zw >= 0 && zw < p.W) ? rowp[(long)zw * p.C] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < KW; ++k)
+#pragma unroll
+                for (int t = 0; t < TW; ++t) acc[k] = fmaf(gv[t], seg[t + k * DIL], acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KW; ++k) red[k * 256 + threadIdx.x] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < cpb && c < p.C) {
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            float a = 0.f;
+            for (int r = 0; r < rpb; ++r) a += red[k * 256 + r * cpb + threadIdx.x];
+            atomicAdd(p.gwp + (long)((i * p.kh + j) * KW + k) * p.C + c, a);
+        }
+    }
+}
+
+int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st)
+{
+    constexpr int TW = 8;
+    const int cpb = a.C < 256 ? a.C : 256;
+    if (256 % cpb != 0) return DLKA_ERR_UNSUPPORTED;
+    const int rows = a.B * a.D * a.H;
+    int xb = rows < 64 ? rows : 64;                 // row-chunks: bounded atomics, enough blocks with grid.y = kd*kh
+    a.rows_per_block = cdiv(rows, xb);
+    xb = cdiv(rows, a.rows_per_block);
+    if (hipMemsetAsync(a.gwp, 0, (size_t)a.kd * a.kh * kw * a.C * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+    dim3 grid(xb, a.kd * a.kh, cdiv(a.C, cpb)), block(256);
+    if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_wgrad_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<3, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_wgrad_kernel<5, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<7, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else return DLKA_ERR_UNSUPPORTED;
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+// gWp[tap][c] -> reference layout gW[c][1][taps] in storage type T
+template <typename T>
+__global__ void cl_dw_unprep_kernel(const float *__restrict__ gwp, T *__restrict__ gw, int C, int K)
+{
+    const int n = C * K;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const int tap = e % K, c = e / K;
+        stf(gw + e, gwp[(long)tap * C + c]);
+    }
+}
+
+template <typename T>
+int launch_cl_dw_unprep(const float *gwp, T *gw, int C, int K, hipStream_t st)
+{
+    auto k = cl_dw_unprep_kernel<T>;
+    hipLaunchKernelGGL(k, dim3(cdiv(C * K, 256)), dim3(256), 0, st, gwp, gw, C, K);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+template int launch_cl_dw_unprep<float>(const float *, float *, int, int, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// layout changes between the reference's planar NCDHW and channels-last (used by the *_ndhwc test entry points and by
+// LKA_Attention3d_deform.forward_volume; the token entry point needs none).
+// ---------------------------------------------------------------------------------------------
+template <int TO_CL>
+__global__ __launch_bounds__(256) void cl_transpose_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int N)
+{
+    // tile 32 (voxels) x 32 (channels) through LDS; grid = (ceil(N/32), ceil(C/32), B)
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const float *s = src + (long)b * C * N;
+    float *d = dst + (long)b * C * N;
+    if (TO_CL) {  // src [C][N] -> dst [N][C]
+        for (int r = ty; r < 32; r += 8)
+            if (c0 + r < C && n0 + tx < N) tile[r][tx] = s[(long)(c0 + r) * N + n0 + tx];
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8)
+            if (n0 + r < N && c0 + tx < C) d[(long)(n0 + r) * C + c0 + tx] = tile[tx][r];
+    } else {      // src [N][C] -> dst [C][N]
+        for (int r = ty; r < 32; r += 8)
+            if (n0 + r < N && c0 + tx < C) tile[r][tx] = s[(long)(n0 + r) * C + c0 + tx];
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8)
+            if (c0 + r < C && n0 + tx < N) d[(long)(c0 + r) * N + n0 + tx] = tile[tx][r];
+    }
+}
+
+int launch_cl_transpose(const float *src, float *dst, int B, int C, int N, int to_cl, hipStream_t st)
+{
+    dim3 grid(cdiv(N, 32), cdiv(C, 32), B), block(256);
+    if (to_cl) { auto k = cl_transpose_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, src, dst, C, N); }
+    else { auto k = cl_transpose_kernel<0>; hipLaunchKernelGGL(k, grid, block, 0, st, src, dst, C, N); }
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+}  // namespace dlka

@@ -1,0 +1,261 @@
+// Channels-last implicit-GEMM convolution on the matrix cores (fp32-input MFMA, exact fp32).
+//
+// One kernel serves every dense contraction of the D-LKA block in token / NDHWC layout:
+//     out[m][n] = bias[n] + sum_{tap} sum_{c} A(m, tap, c) * Wp[tap][c][n]          m = (b, voxel), n = out channel
+//   AMODE 0  A = in[b][voxel + tap offset][c]                (zero padded)   1x1x1 projections, offset-predict conv
+//   AMODE 1  A = trilinear sample of in at voxel + tap + Delta(b, tap, voxel)     deformable conv (D3D semantics)
+//   AMODE 2  A = in_planar[b][c][voxel + tap offset]         (zero padded)   data-gradient of the offset conv
+// (AMODE 1 never materialises the 27*C-wide column matrix the reference writes to HBM,
+//  3D/dcn/src/cuda/deform_conv_cuda.cu:95 — samples go from registers straight into the MFMA A operand.)
+//
+// Mapping (gfx950, wave64): a wave owns a 32-row M tile and all N tiles (NT x 32 columns) -> NT accumulators of
+// v_mfma_f32_32x32x2_f32.  Lane l = (i = l & 31, h = l >> 5) feeds A[row i][k-slot h]; k-slot h of step s is
+// channel 16*h + s of the current 32-channel chunk, so every lane reads 16 CONTIGUOUS channels (four 16-byte loads)
+// of its row — the summation order over k is permuted, nothing else.  The 4 waves of a workgroup (128 rows) share
+// the 32 x NP weight chunk through LDS.  Small-spatial stages (C=256 at 4^3) are filled by splitting the taps over
+// blockIdx.y and accumulating with fp32 atomics.
+#include "deform_sample.h"
+#include "cl_args.h"
+#include "dlka_kernels.h"
+
+namespace dlka {
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+template <int AMODE, int OMODE, int NT>
+__global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float Bs[32 * NT * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int m = (blockIdx.x * 4 + wave) * 32 + i;      // this lane's A row
+    const bool row_ok = m < p.M;
+    const int b = row_ok ? m / p.N : 0;
+    const int v = row_ok ? m - b * p.N : 0;
+    const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / (p.W * p.H);
+    const int NPB = NT * 32;            // columns handled by this block
+    const int n0 = blockIdx.z * NPB;    // first column
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int nchunk = p.CinP / 32;
+    const int unit_lo = blockIdx.y * p.units_per_split;
+    const int unit_hi = min(p.K * nchunk, unit_lo + p.units_per_split);
+
+    int cur_tap = -1;
+    const float *rowp = nullptr;   // AMODE 0: neighbour row; AMODE 2: neighbour voxel in plane 0
+    TapSample<3> s;
+    for (int unit = unit_lo; unit < unit_hi; ++unit) {
+        const int tap = unit / nchunk, ck = unit - tap * nchunk;
+        if (tap != cur_tap) {   // uniform
+            cur_tap = tap;
+            const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
+            // ---- per-(row, tap) source description ----
+            if (AMODE == 0 || AMODE == 2) {
+                const int zd = d0 + ti * p.dd - p.pd, zh = h0 + tj * p.dh - p.ph, zw = w0 + tk * p.dw - p.pw;
+                const bool ok = row_ok && zd >= 0 && zd < p.D && zh >= 0 && zh < p.H && zw >= 0 && zw < p.W;
+                rowp = nullptr;
+                if (ok) {
+                    const long lin = (long)(zd * p.H + zh) * p.W + zw;
+                    rowp = (AMODE == 0) ? p.in + ((long)b * p.N + lin) * p.Cin : p.in + (long)b * p.CinReal * p.N + lin;
+                }
+            } else {
+                if (row_ok) {
+                    const float *offp = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
+                    setup_tap<3>(s, offp, p.N, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw, p.D, p.H, p.W);
+                } else {
+                    s.ok = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { s.idx[q] = 0; s.w[q] = 0.f; }
+                }
+            }
+        }
+        {
+
+            // ---- stage the 32 x NP weight chunk (shared by the 4 waves) ----
+            __syncthreads();   // previous chunk fully consumed
+            {
+                const float *src = p.wp + ((long)tap * p.CinP + ck * 32) * p.NP + n0;
+                float4 *dst = reinterpret_cast<float4 *>(Bs);
+                for (int e = tid; e < 32 * NPB / 4; e += 256) {
+                    const int rr = e / (NPB / 4), c4 = e - rr * (NPB / 4);
+                    dst[e] = reinterpret_cast<const float4 *>(src + (long)rr * p.NP)[c4];
+                }
+            }
+            // ---- this lane's 16 A values: channels ck*32 + 16*h + [0,16) of its row ----
+            float a[16];
+            const int c0 = ck * 32 + 16 * h;
+            if (AMODE == 0) {
+                if (rowp) {
+                    const float4 *r4 = reinterpret_cast<const float4 *>(rowp + c0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float4 t = r4[e];
+                        a[4 * e] = t.x; a[4 * e + 1] = t.y; a[4 * e + 2] = t.z; a[4 * e + 3] = t.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) a[e] = 0.f;
+                }
+            } else if (AMODE == 2) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) a[e] = (rowp && c0 + e < p.CinReal) ? rowp[(long)(c0 + e) * p.N] : 0.f;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) a[e] = 0.f;
+                const float *base = p.in + (long)b * p.N * p.Cin + c0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if ((s.ok >> q) & 1u) {   // corners outside the volume / samples outside the guard contribute 0
+                        const float4 *r4 = reinterpret_cast<const float4 *>(base + (long)s.idx[q] * p.Cin);
+                        const float wq = s.w[q];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float4 t = r4[e];
+                            a[4 * e] = fmaf(wq, t.x, a[4 * e]); a[4 * e + 1] = fmaf(wq, t.y, a[4 * e + 1]);
+                            a[4 * e + 2] = fmaf(wq, t.z, a[4 * e + 2]); a[4 * e + 3] = fmaf(wq, t.w, a[4 * e + 3]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();   // weights staged
+            // ---- 16 k-steps x NT MFMAs ----
+            const float *brow = Bs + (16 * h) * NPB + i;
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x2(a[st], brow[st * NPB + t * 32], acc[t]);
+            }
+        }
+    }
+
+    // ---- epilogue: D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
+    const int mbase = (blockIdx.x * 4 + wave) * 32;
+    const bool split = gridDim.y > 1;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + t * 32 + i;
+        if (n >= p.Cout) continue;
+        const float bv = (p.bias && blockIdx.y == 0) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = mbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (mr >= p.M) continue;
+            float val = acc[t][r] + bv;
+            long o;
+            if (OMODE == 0) {
+                o = (long)mr * p.Cout + n;
+            } else {
+                const int bb = mr / p.N, vv = mr - bb * p.N;
+                o = ((long)bb * p.Cout + n) * p.N + vv;
+            }
+            if (split) {
+                atomicAdd(p.out + o, val);
+            } else if (p.epi == 0) {
+                p.out[o] = val;
+            } else if (p.epi == 1) {
+                p.out[o] = val;
+                p.out2[o] = gelu_erf(val);
+            } else if (p.epi == 2) {
+                p.out[o] = val;
+                p.out2[o] = p.aux[o] * val;
+            } else {
+                p.out[o] = val + p.aux[o];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight preparation:  reference layout W[co][ci][tap]  ->  Wp[tap'][k][n]  (zero padded to CinP x NP)
+//   mode 0 (forward):        k = ci, n = co, tap' = tap
+//   mode 1 (data gradient):  k = co, n = ci, tap' = K-1-tap   (correlation with the flipped kernel)
+//   mode 2 (column matrix):  k = co, n = ci, tap' = tap       (Col = G * W[:, :, tap] in the deformable backward)
+// ---------------------------------------------------------------------------------------------
+__global__ void cl_prep_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int K, int KP, int NP, int mode)
+{
+    const long n_el = (long)K * KP * NP;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_el; e += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(e % NP), k = (int)((e / NP) % KP), tp = (int)(e / NP / KP);
+        float val = 0.f;
+        if (mode == 0) {
+            if (k < Cin && n < Cout) val = w[((long)n * Cin + k) * K + tp];
+        } else if (mode == 1) {
+            if (k < Cout && n < Cin) val = w[((long)k * Cin + n) * K + (K - 1 - tp)];
+        } else {
+            if (k < Cout && n < Cin) val = w[((long)k * Cin + n) * K + tp];
+        }
+        wp[e] = val;
+    }
+}
+
+int launch_cl_prep_weight(const float *w, float *wp, int Cout, int Cin, int K, int KP, int NP, int mode, hipStream_t st)
+{
+    const long n_el = (long)K * KP * NP;
+    long blocks = cdivl(n_el, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(cl_prep_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, wp, Cout, Cin, K, KP, NP, mode);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+template <int AMODE, int OMODE>
+static int launch_igemm_nt(const IgemmArgs &a, int splits, hipStream_t st)
+{
+    const int NT_total = a.NP / 32;
+    // column tiles per block: all of them when there are plenty of row blocks, fewer (-> gridDim.z) for small M
+    int NT = NT_total;
+    const int mblocks = cdiv(a.M, 128);
+    if (NT_total == 8 && mblocks * splits < 256) NT = (mblocks * splits * 2 < 256) ? 2 : 4;
+    else if (NT_total == 4 && mblocks * splits < 256) NT = (mblocks * splits * 2 < 256) ? 1 : 2;
+    else if (NT_total == 2 && mblocks * splits < 128) NT = 1;
+    dim3 grid(mblocks, splits, NT_total / NT), block(256);
+#define DLKA_IG(NTV)                                              \
+    {                                                             \
+        auto k = cl_igemm_kernel<AMODE, OMODE, NTV>;              \
+        hipLaunchKernelGGL(k, grid, block, 0, st, a);             \
+    }
+    switch (NT) {
+        case 1: DLKA_IG(1) break;
+        case 2: DLKA_IG(2) break;
+        case 3: DLKA_IG(3) break;
+        case 4: DLKA_IG(4) break;
+        case 8: DLKA_IG(8) break;
+        default: return DLKA_ERR_UNSUPPORTED;
+    }
+#undef DLKA_IG
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+// Picks the tap split so that small-spatial stages still fill the chip; returns the number of splits.
+int cl_igemm_pick_splits(int M, int units, int epi)
+{
+    if (epi != 0 || units == 1) return 1;
+    const int mblocks = cdiv(M, 128);
+    int splits = 1;
+    while (mblocks * splits < 512 && splits < units) ++splits;
+    const int ups = cdiv(units, splits);
+    return cdiv(units, ups);
+}
+
+int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t st)
+{
+    a.units_per_split = cdiv(a.K * (a.CinP / 32), splits);
+    splits = cdiv(a.K * (a.CinP / 32), a.units_per_split);
+    if (splits > 1) {
+        const long n = (long)a.M * a.Cout;
+        if (hipMemsetAsync(a.out, 0, (size_t)n * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+    }
+    if (amode == 0 && omode == 0) return launch_igemm_nt<0, 0>(a, splits, st);
+    if (amode == 0 && omode == 1) return launch_igemm_nt<0, 1>(a, splits, st);
+    if (amode == 1 && omode == 0) return launch_igemm_nt<1, 0>(a, splits, st);
+    if (amode == 2 && omode == 0) return launch_igemm_nt<2, 0>(a, splits, st);
+    return DLKA_ERR_UNSUPPORTED;
+}
+
+}  // namespace dlka

@@ -1,0 +1,470 @@
+// C-ABI entry points of the channels-last (NDHWC / token layout) fast path: stride-1 same-size convolutions on the
+// matrix cores, register-tiled depthwise convs, the fused deformable backward, and the token-layout D-LKA block.
+// Everything here is fp32; shapes the fast path does not cover return DLKA_ERR_UNSUPPORTED and the caller uses the
+// general NCDHW entry points (dlka_capi.hip) instead — still HIP, never a CPU fallback.
+#include "cl_args.h"
+#include "dlka_kernels.h"
+
+using namespace dlka;
+
+namespace {
+
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+struct Carver {
+    unsigned char *base;
+    size_t cap, used;
+    Carver(void *p, size_t n) : base((unsigned char *)p), cap(n), used(0) {}
+    void *take(size_t n)
+    {
+        n = align256(n);
+        if (!base || used + n > cap) { used = cap + 1; return nullptr; }
+        void *r = base + used;
+        used += n;
+        return r;
+    }
+    bool ok() const { return used <= cap; }
+};
+
+#define DLKA_TRY(expr)                  \
+    do {                                \
+        int rc_ = (expr);               \
+        if (rc_ != DLKA_OK) return rc_; \
+    } while (0)
+
+// a stride-1, same-size convolution in channels-last layout
+struct SameConv {
+    int B, D, H, W, N, M, Cin, Cout, group;
+    int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
+};
+
+int make_same_conv(const dlka_conv_geom *c, SameConv &s)
+{
+    if (!c) return DLKA_ERR_NULL;
+    if (c->B <= 0 || c->C <= 0 || c->D <= 0 || c->H <= 0 || c->W <= 0 || c->Cout <= 0) return DLKA_ERR_SHAPE;
+    if (c->kd <= 0 || c->kh <= 0 || c->kw <= 0 || c->dd <= 0 || c->dh <= 0 || c->dw <= 0) return DLKA_ERR_SHAPE;
+    if (c->group <= 0 || c->C % c->group || c->Cout % c->group) return DLKA_ERR_GROUP;
+    if (c->sd != 1 || c->sh != 1 || c->sw != 1) return DLKA_ERR_UNSUPPORTED;
+    if (dlka_conv_out_size(c->D, c->pd, c->dd, c->kd, 1) != c->D || dlka_conv_out_size(c->H, c->ph, c->dh, c->kh, 1) != c->H ||
+        dlka_conv_out_size(c->W, c->pw, c->dw, c->kw, 1) != c->W)
+        return DLKA_ERR_UNSUPPORTED;
+    const long N = (long)c->D * c->H * c->W;
+    if (N > (1l << 30) || (long)c->B * N > (1l << 30)) return DLKA_ERR_SHAPE;
+    s.B = c->B; s.D = c->D; s.H = c->H; s.W = c->W; s.N = (int)N; s.M = (int)(c->B * N);
+    s.Cin = c->C; s.Cout = c->Cout; s.group = c->group;
+    s.kd = c->kd; s.kh = c->kh; s.kw = c->kw; s.pd = c->pd; s.ph = c->ph; s.pw = c->pw;
+    s.dd = c->dd; s.dh = c->dh; s.dw = c->dw; s.K = c->kd * c->kh * c->kw;
+    return DLKA_OK;
+}
+
+bool nt_ok(int np) { const int nt = np / 32; return nt == 1 || nt == 2 || nt == 3 || nt == 4 || nt == 8; }
+bool is_depthwise(const SameConv &s) { return s.group == s.Cin && s.Cin == s.Cout; }
+bool dw_supported(const SameConv &s)
+{
+    const bool kshape = (s.kw == 5 && s.dw == 1) || (s.kw == 7 && s.dw == 3) || (s.kw == 3 && s.dw == 1) || (s.kw == 5 && s.dw == 3) ||
+                        (s.kw == 7 && s.dw == 1);
+    const int cpb = s.Cin < 256 ? s.Cin : 256;
+    return kshape && s.Cin % 32 == 0 && 256 % cpb == 0 && s.Cin % cpb == 0;
+}
+bool dense_fwd_supported(const SameConv &s) { return s.group == 1 && s.Cin % 32 == 0 && nt_ok(round_up(s.Cout, 32)); }
+
+void fill_igemm(IgemmArgs &a, const SameConv &s)
+{
+    memset(&a, 0, sizeof(a));
+    a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M;
+    a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
+}
+
+// ---- dense conv forward: out = conv(x) (+ epilogue) ---------------------------------------------------------------
+// wp must hold K * Cin * round_up(Cout,32) floats
+int dense_forward(const SameConv &s, const float *x, const float *w, const float *bias, float *out, int out_planar, float *wp,
+                  int epi, const float *aux, float *out2, hipStream_t st)
+{
+    const int NP = round_up(s.Cout, 32);
+    DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, NP, 0, st));
+    IgemmArgs a;
+    fill_igemm(a, s);
+    a.in = x; a.wp = wp; a.bias = bias; a.out = out; a.out2 = out2; a.aux = aux; a.epi = epi;
+    a.Cin = s.Cin; a.CinReal = s.Cin; a.CinP = s.Cin; a.Cout = s.Cout; a.NP = NP;
+    const int splits = cl_igemm_pick_splits(s.M, s.K * (s.Cin / 32), epi);
+    return launch_cl_igemm(0, out_planar ? 1 : 0, a, splits, st);
+}
+
+// ---- dense conv data gradient: gx = conv_transpose(gout) (+ epilogue) ---------------------------------------------
+// wp must hold K * round_up(Cout,32) * Cin floats.  gout channels-last needs Cout % 32 == 0; planar any Cout.
+int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, const float *w, float *gx, float *wp, int epi,
+                        const float *aux, hipStream_t st)
+{
+    const int KP = round_up(s.Cout, 32), NP = s.Cin;
+    if (!nt_ok(NP) || s.Cin % 32) return DLKA_ERR_UNSUPPORTED;
+    if (!gout_planar && s.Cout % 32) return DLKA_ERR_UNSUPPORTED;
+    DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, KP, NP, 1, st));
+    IgemmArgs a;
+    fill_igemm(a, s);
+    a.pd = s.dd * (s.kd - 1) - s.pd; a.ph = s.dh * (s.kh - 1) - s.ph; a.pw = s.dw * (s.kw - 1) - s.pw;
+    a.in = gout; a.wp = wp; a.bias = nullptr; a.out = gx; a.aux = aux; a.epi = epi;
+    a.Cin = s.Cout; a.CinReal = s.Cout; a.CinP = KP; a.Cout = s.Cin; a.NP = NP;
+    const int splits = cl_igemm_pick_splits(s.M, s.K * (KP / 32), epi);
+    return launch_cl_igemm(gout_planar ? 2 : 0, 0, a, splits, st);
+}
+
+size_t dense_wp_floats(const SameConv &s) { return (size_t)s.K * round_up(s.Cin, 32) * round_up(s.Cout, 32); }
+
+// ---- dense conv weight gradient -----------------------------------------------------------------------------------
+int dense_backward_weight(const SameConv &s, const float *x, const float *gout, int gout_planar, float *gw, float *part, hipStream_t st)
+{
+    if (s.Cin % 32) return DLKA_ERR_UNSUPPORTED;
+    if (s.K != 1 && s.K > 7 * 64) return DLKA_ERR_UNSUPPORTED;
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = gout; a.in = x; a.part = part;
+    a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.Cin = s.Cin; a.Cout = s.Cout;
+    a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
+    if (s.K == 1 && gout_planar) return DLKA_ERR_UNSUPPORTED;
+    return launch_cl_wgrad<float>(0, gout_planar ? 1 : 0, a, gw, st);
+}
+
+// ---- depthwise ------------------------------------------------------------------------------------------------------
+int dw_forward(const SameConv &s, const float *x, const float *w, const float *bias, float *out, float *wp, int flip, hipStream_t st)
+{
+    DLKA_TRY(launch_cl_dw_prep_weight(w, wp, s.Cin, s.K, flip, st));
+    DwArgs a;
+    a.in = x; a.wp = wp; a.bias = bias; a.out = out;
+    a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.C = s.Cin;
+    a.kd = s.kd; a.kh = s.kh; a.dd = s.dd; a.dh = s.dh;
+    if (flip) { a.pd = s.dd * (s.kd - 1) - s.pd; a.ph = s.dh * (s.kh - 1) - s.ph; a.pw = s.dw * (s.kw - 1) - s.pw; }
+    else { a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; }
+    return launch_cl_dwconv(a, s.kw, s.dw, st);
+}
+
+int dw_backward_weight(const SameConv &s, const float *x, const float *gout, float *gw, float *gwp, hipStream_t st)
+{
+    DwWgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = gout; a.in = x; a.gwp = gwp;
+    a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.C = s.Cin;
+    a.kd = s.kd; a.kh = s.kh; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh;
+    DLKA_TRY(launch_cl_dwconv_wgrad(a, s.kw, s.dw, st));
+    return launch_cl_dw_unprep<float>(gwp, gw, s.Cin, s.K, st);
+}
+
+// ---- deformable (groups = deformable_groups = 1) ---------------------------------------------------------------------
+bool deform_supported(const SameConv &s) { return s.group == 1 && s.Cin % 32 == 0 && s.Cout % 32 == 0 && nt_ok(s.Cout) && nt_ok(s.Cin); }
+
+int deform_forward(const SameConv &s, const float *x, const float *off, const float *w, const float *bias, float *out, float *wp, hipStream_t st)
+{
+    DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, s.Cout, 0, st));
+    IgemmArgs a;
+    fill_igemm(a, s);
+    a.in = x; a.off = off; a.wp = wp; a.bias = bias; a.out = out; a.epi = 0;
+    a.Cin = s.Cin; a.CinReal = s.Cin; a.CinP = s.Cin; a.Cout = s.Cout; a.NP = s.Cout;
+    const int splits = cl_igemm_pick_splits(s.M, s.K * (s.Cin / 32), 0);
+    return launch_cl_igemm(1, 0, a, splits, st);
+}
+
+int deform_backward(const SameConv &s, const float *x, const float *off, const float *w, const float *gout, float *gx, float *goff,
+                    float *gw, float *wp, float *part, hipStream_t st)
+{
+    if (gx || goff) {
+        DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cout, s.Cin, 2, st));
+        DeformBwdArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff;
+        a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.C = s.Cin; a.Cout = s.Cout; a.CoutP = s.Cout;
+        a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
+        DLKA_TRY(launch_cl_deform_bwd(a, st));
+    }
+    if (gw) {
+        WgradArgs a;
+        memset(&a, 0, sizeof(a));
+        a.g = gout; a.in = x; a.off = off; a.part = part;
+        a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.Cin = s.Cin; a.Cout = s.Cout;
+        a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
+        DLKA_TRY(launch_cl_wgrad<float>(1, 0, a, gw, st));
+    }
+    return DLKA_OK;
+}
+
+// ---- the token-layout 3-D block ----------------------------------------------------------------------------------------
+SameConv block_conv(int B, int C, int Cout, int D, int H, int W, int k, int pad, int dil, int group)
+{
+    SameConv s;
+    s.B = B; s.D = D; s.H = H; s.W = W; s.N = D * H * W; s.M = B * s.N; s.Cin = C; s.Cout = Cout; s.group = group;
+    s.kd = s.kh = s.kw = k; s.pd = s.ph = s.pw = pad; s.dd = s.dh = s.dw = dil; s.K = k * k * k;
+    return s;
+}
+
+struct TokGeoms {
+    SameConv pw, dw5, dw7, offc, dcn;
+    size_t E, Off;
+    TokGeoms(int B, int C, int D, int H, int W)
+    {
+        pw = block_conv(B, C, C, D, H, W, 1, 0, 1, 1);
+        dw5 = block_conv(B, C, C, D, H, W, 5, 2, 1, C);
+        dw7 = block_conv(B, C, C, D, H, W, 7, 9, 3, C);
+        offc = block_conv(B, C, 81, D, H, W, 3, 1, 1, 1);
+        dcn = block_conv(B, C, C, D, H, W, 3, 1, 1, 1);
+        E = (size_t)B * C * D * H * W;
+        Off = (size_t)B * 81 * D * H * W;
+    }
+    size_t wp_floats() const
+    {
+        size_t m = dense_wp_floats(offc);
+        if (dense_wp_floats(dcn) > m) m = dense_wp_floats(dcn);
+        if ((size_t)343 * dw7.Cin > m) m = (size_t)343 * dw7.Cin;
+        return m;
+    }
+    size_t part_floats() const
+    {
+        size_t m = cl_wgrad_part_floats(pw.M, 27, 81, pw.Cin);
+        const size_t d = cl_wgrad_part_floats(pw.M, 27, pw.Cin, pw.Cin);
+        return m > d ? m : d;
+    }
+};
+
+bool tokens_supported(int B, int C, int D, int H, int W)
+{
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return false;
+    if (!(C == 32 || C == 64 || C == 128 || C == 256)) return false;
+    if ((long)B * D * H * W > (1l << 28)) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- channels-last convolution ----------------------------------------------------------------------------------------
+size_t dlka_conv3d_cl_workspace(const dlka_conv_geom *c, int dtype, int backward)
+{
+    SameConv s;
+    if (dtype != DLKA_F32 || make_same_conv(c, s)) return 0;
+    if (is_depthwise(s)) return 2 * align256((size_t)s.K * s.Cin * 4);
+    size_t n = align256(dense_wp_floats(s) * 4);
+    if (backward) n += align256(cl_wgrad_part_floats(s.M, s.K, s.Cout, s.Cin) * 4);
+    return n;
+}
+
+int dlka_conv3d_forward_cl(const void *x, const void *weight, const void *bias, void *out, int out_planar, void *workspace,
+                           size_t workspace_bytes, const dlka_conv_geom *c, int dtype, void *stream)
+{
+    if (!x || !weight || !out) return DLKA_ERR_NULL;
+    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    SameConv s;
+    DLKA_TRY(make_same_conv(c, s));
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(workspace, workspace_bytes);
+    if (is_depthwise(s)) {
+        if (!dw_supported(s) || out_planar) return DLKA_ERR_UNSUPPORTED;
+        float *wp = (float *)cv.take((size_t)s.K * s.Cin * 4);
+        if (!cv.ok()) return DLKA_ERR_WORKSPACE;
+        return dw_forward(s, (const float *)x, (const float *)weight, (const float *)bias, (float *)out, wp, 0, st);
+    }
+    if (!dense_fwd_supported(s)) return DLKA_ERR_UNSUPPORTED;
+    float *wp = (float *)cv.take(dense_wp_floats(s) * 4);
+    if (!cv.ok()) return DLKA_ERR_WORKSPACE;
+    return dense_forward(s, (const float *)x, (const float *)weight, (const float *)bias, (float *)out, out_planar, wp, 0, nullptr, nullptr, st);
+}
+
+int dlka_conv3d_backward_cl(const void *x, const void *weight, const void *grad_out, int grad_out_planar, void *grad_x, void *grad_weight,
+                            void *grad_bias, void *workspace, size_t workspace_bytes, const dlka_conv_geom *c, int dtype, void *stream)
+{
+    if (!x || !weight || !grad_out) return DLKA_ERR_NULL;
+    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    SameConv s;
+    DLKA_TRY(make_same_conv(c, s));
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(workspace, workspace_bytes);
+    if (is_depthwise(s)) {
+        if (!dw_supported(s) || grad_out_planar) return DLKA_ERR_UNSUPPORTED;
+        float *wp = (float *)cv.take((size_t)s.K * s.Cin * 4), *gwp = (float *)cv.take((size_t)s.K * s.Cin * 4);
+        if (!cv.ok()) return DLKA_ERR_WORKSPACE;
+        if (grad_x) DLKA_TRY(dw_forward(s, (const float *)grad_out, (const float *)weight, nullptr, (float *)grad_x, wp, 1, st));
+        if (grad_weight) DLKA_TRY(dw_backward_weight(s, (const float *)x, (const float *)grad_out, (float *)grad_weight, gwp, st));
+        if (grad_bias) DLKA_TRY(launch_cl_colsum((const float *)grad_out, (float *)grad_bias, s.M, s.Cout, st));
+        return DLKA_OK;
+    }
+    if (s.group != 1) return DLKA_ERR_UNSUPPORTED;
+    float *wp = (float *)cv.take(dense_wp_floats(s) * 4);
+    float *part = (float *)cv.take(cl_wgrad_part_floats(s.M, s.K, s.Cout, s.Cin) * 4);
+    if (!cv.ok()) return DLKA_ERR_WORKSPACE;
+    if (grad_x) DLKA_TRY(dense_backward_data(s, (const float *)grad_out, grad_out_planar, (const float *)weight, (float *)grad_x, wp, 0, nullptr, st));
+    if (grad_weight) DLKA_TRY(dense_backward_weight(s, (const float *)x, (const float *)grad_out, grad_out_planar, (float *)grad_weight, part, st));
+    if (grad_bias) {
+        if (grad_out_planar) DLKA_TRY(launch_bias_grad<float>((const float *)grad_out, (float *)grad_bias, s.B, s.Cout, s.N, st));
+        else DLKA_TRY(launch_cl_colsum((const float *)grad_out, (float *)grad_bias, s.M, s.Cout, st));
+    }
+    return DLKA_OK;
+}
+
+// ---- channels-last deformable conv (x, out channels-last; offsets planar as in the reference) ---------------------------
+size_t dlka_deform_conv3d_cl_workspace(const dlka_conv_geom *c, int dtype, int backward)
+{
+    SameConv s;
+    if (dtype != DLKA_F32 || make_same_conv(c, s)) return 0;
+    size_t n = align256(dense_wp_floats(s) * 4);
+    if (backward) n += align256(cl_wgrad_part_floats(s.M, s.K, s.Cout, s.Cin) * 4);
+    return n;
+}
+
+int dlka_deform_conv3d_forward_cl(const void *x, const void *offset, const void *weight, const void *bias, void *out, void *workspace,
+                                  size_t workspace_bytes, const dlka_conv_geom *c, int dtype, void *stream)
+{
+    if (!x || !offset || !weight || !bias || !out) return DLKA_ERR_NULL;
+    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    SameConv s;
+    DLKA_TRY(make_same_conv(c, s));
+    if (c->deformable_group != 1 || !deform_supported(s)) return DLKA_ERR_UNSUPPORTED;
+    Carver cv(workspace, workspace_bytes);
+    float *wp = (float *)cv.take(dense_wp_floats(s) * 4);
+    if (!cv.ok()) return DLKA_ERR_WORKSPACE;
+    return deform_forward(s, (const float *)x, (const float *)offset, (const float *)weight, (const float *)bias, (float *)out, wp, (hipStream_t)stream);
+}
+
+int dlka_deform_conv3d_backward_cl(const void *x, const void *offset, const void *weight, const void *grad_out, void *grad_x, void *grad_offset,
+                                   void *grad_weight, void *grad_bias, void *workspace, size_t workspace_bytes, const dlka_conv_geom *c,
+                                   int dtype, void *stream)
+{
+    if (!x || !offset || !weight || !grad_out) return DLKA_ERR_NULL;
+    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    SameConv s;
+    DLKA_TRY(make_same_conv(c, s));
+    if (c->deformable_group != 1 || !deform_supported(s)) return DLKA_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(workspace, workspace_bytes);
+    float *wp = (float *)cv.take(dense_wp_floats(s) * 4);
+    float *part = (float *)cv.take(cl_wgrad_part_floats(s.M, s.K, s.Cout, s.Cin) * 4);
+    if (!cv.ok()) return DLKA_ERR_WORKSPACE;
+    DLKA_TRY(deform_backward(s, (const float *)x, (const float *)offset, (const float *)weight, (const float *)grad_out, (float *)grad_x,
+                             (float *)grad_offset, (float *)grad_weight, wp, part, st));
+    if (grad_bias) DLKA_TRY(launch_cl_colsum((const float *)grad_out, (float *)grad_bias, s.M, s.Cout, st));
+    return DLKA_OK;
+}
+
+// ---- layout helpers -------------------------------------------------------------------------------------------------------
+int dlka_ncdhw_to_ndhwc(const void *src, void *dst, int B, int C, int N, int dtype, void *stream)
+{
+    if (!src || !dst) return DLKA_ERR_NULL;
+    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    return launch_cl_transpose((const float *)src, (float *)dst, B, C, N, 1, (hipStream_t)stream);
+}
+int dlka_ndhwc_to_ncdhw(const void *src, void *dst, int B, int C, int N, int dtype, void *stream)
+{
+    if (!src || !dst) return DLKA_ERR_NULL;
+    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    return launch_cl_transpose((const float *)src, (float *)dst, B, C, N, 0, (hipStream_t)stream);
+}
+
+// ---- token-layout D-LKA block ------------------------------------------------------------------------------------------------
+int dlka_lka3d_tokens_supported(int B, int C, int D, int H, int W, int dtype) { return (dtype == DLKA_F32 && tokens_supported(B, C, D, H, W)) ? 1 : 0; }
+
+size_t dlka_lka3d_tokens_saved_bytes(int B, int C, int D, int H, int W, int dtype)
+{
+    if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return 0;
+    TokGeoms G(B, C, D, H, W);
+    return 6 * align256(G.E * 4) + align256(G.Off * 4);
+}
+
+size_t dlka_lka3d_tokens_workspace_bytes(int B, int C, int D, int H, int W, int dtype)
+{
+    if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return 0;
+    TokGeoms G(B, C, D, H, W);
+    return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 4 * align256(G.E * 4) + align256(G.Off * 4) + align256(4096);
+}
+
+int dlka_lka3d_attention_tokens_forward(const void *x_, const dlka_lka3d_params *p, void *y_, void *saved, size_t saved_bytes,
+                                        void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, void *stream)
+{
+    if (!x_ || !p || !y_ || !saved || !workspace) return DLKA_ERR_NULL;
+    const void *const *pp = (const void *const *)p;
+    for (size_t k = 0; k < sizeof(*p) / sizeof(void *); ++k) if (!pp[k]) return DLKA_ERR_NULL;
+    if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return DLKA_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    TokGeoms G(B, C, D, H, W);
+    Carver sv(saved, saved_bytes), cv(workspace, workspace_bytes);
+    float *h = (float *)sv.take(G.E * 4), *a = (float *)sv.take(G.E * 4), *t1 = (float *)sv.take(G.E * 4), *t = (float *)sv.take(G.E * 4);
+    float *off = (float *)sv.take(G.Off * 4), *f = (float *)sv.take(G.E * 4), *g1 = (float *)sv.take(G.E * 4);
+    float *wp = (float *)cv.take(G.wp_floats() * 4);
+    (void)cv.take(G.part_floats() * 4);
+    float *m = (float *)cv.take(G.E * 4);
+    if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
+    const float *x = (const float *)x_;
+    float *y = (float *)y_;
+    // proj_1 + GELU (transformerblock.py:667-668): h kept for the GELU gradient, a = GELU(h)
+    DLKA_TRY(dense_forward(G.pw, x, (const float *)p->proj_1_w, (const float *)p->proj_1_b, h, 0, wp, 1, nullptr, a, st));
+    // depthwise 5^3 then 7^3 dilation 3 (:646-647)
+    DLKA_TRY(dw_forward(G.dw5, a, (const float *)p->conv0_w, (const float *)p->conv0_b, t1, wp, 0, st));
+    DLKA_TRY(dw_forward(G.dw7, t1, (const float *)p->conv_spatial_w, (const float *)p->conv_spatial_b, t, wp, 0, st));
+    // offset-predict conv C -> 81 (synapse/deform_conv.py:94); offsets stay in the reference's planar layout
+    DLKA_TRY(dense_forward(G.offc, t, (const float *)p->offset_w, (const float *)p->offset_b, off, 1, wp, 0, nullptr, nullptr, st));
+    // deformable 3^3 conv (deform_conv.py:95-105)
+    DLKA_TRY(deform_forward(G.dcn, t, off, (const float *)p->deform_w, (const float *)p->deform_b, f, wp, st));
+    // conv1 + gate u*attn (:650-652): g1 kept, m = a * g1
+    DLKA_TRY(dense_forward(G.pw, f, (const float *)p->conv1_w, (const float *)p->conv1_b, g1, 0, wp, 2, a, m, st));
+    // proj_2 + shortcut (:670-671)
+    DLKA_TRY(dense_forward(G.pw, m, (const float *)p->proj_2_w, (const float *)p->proj_2_b, y, 0, wp, 3, x, nullptr, st));
+    return DLKA_OK;
+}
+
+int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params *p, const void *gy_, const void *saved, size_t saved_bytes,
+                                         void *gx_, const dlka_lka3d_grads *gr, void *workspace, size_t workspace_bytes, int B, int C,
+                                         int D, int H, int W, int dtype, void *stream)
+{
+    if (!x_ || !p || !gy_ || !saved || !gx_ || !gr || !workspace) return DLKA_ERR_NULL;
+    const void *const *pp = (const void *const *)p;
+    for (size_t k = 0; k < sizeof(*p) / sizeof(void *); ++k) if (!pp[k]) return DLKA_ERR_NULL;
+    void *const *gp = (void *const *)gr;
+    for (size_t k = 0; k < sizeof(*gr) / sizeof(void *); ++k) if (!gp[k]) return DLKA_ERR_NULL;
+    if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return DLKA_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    TokGeoms G(B, C, D, H, W);
+    Carver sv((void *)saved, saved_bytes), cv(workspace, workspace_bytes);
+    const float *h = (float *)sv.take(G.E * 4), *a = (float *)sv.take(G.E * 4), *t1 = (float *)sv.take(G.E * 4), *t = (float *)sv.take(G.E * 4);
+    const float *off = (float *)sv.take(G.Off * 4), *f = (float *)sv.take(G.E * 4), *g1 = (float *)sv.take(G.E * 4);
+    float *wp = (float *)cv.take(G.wp_floats() * 4);
+    float *part = (float *)cv.take(G.part_floats() * 4);
+    float *bA = (float *)cv.take(G.E * 4), *bB = (float *)cv.take(G.E * 4), *bC = (float *)cv.take(G.E * 4), *bD = (float *)cv.take(G.E * 4);
+    float *bO = (float *)cv.take(G.Off * 4);
+    if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
+    const float *x = (const float *)x_, *gy = (const float *)gy_;
+    float *gx = (float *)gx_;
+    const long E = (long)G.E;
+    float *gwp = part;  // depthwise weight-gradient staging ([K][C] fp32) reuses the partial-sum area
+
+    // proj_2:  y = P2 m + x
+    DLKA_TRY(launch_mul_fwd<float>(a, g1, bA, E, st));                                                             // bA = m (recomputed)
+    DLKA_TRY(dense_backward_data(G.pw, gy, 0, (const float *)p->proj_2_w, bB, wp, 0, nullptr, st));                // bB = gm
+    DLKA_TRY(dense_backward_weight(G.pw, bA, gy, 0, (float *)gr->proj_2_w, part, st));
+    DLKA_TRY(launch_cl_colsum(gy, (float *)gr->proj_2_b, G.pw.M, C, st));
+    // gate:  m = a * g1
+    DLKA_TRY(launch_mul_bwd<float>(a, g1, bB, bC, bD, E, st));                                                     // bC = ga1 = gm*g1, bD = gg1 = gm*a
+    // conv1:  g1 = P0 f
+    DLKA_TRY(dense_backward_data(G.pw, bD, 0, (const float *)p->conv1_w, bB, wp, 0, nullptr, st));                 // bB = gf
+    DLKA_TRY(dense_backward_weight(G.pw, f, bD, 0, (float *)gr->conv1_w, part, st));
+    DLKA_TRY(launch_cl_colsum(bD, (float *)gr->conv1_b, G.pw.M, C, st));
+    // deformable conv:  f = DCN(t, off)
+    DLKA_TRY(deform_backward(G.dcn, t, off, (const float *)p->deform_w, bB, bA, bO, (float *)gr->deform_w, wp, part, st));  // bA = gt_a, bO = goff
+    DLKA_TRY(launch_cl_colsum(bB, (float *)gr->deform_b, G.pw.M, C, st));
+    // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
+    DLKA_TRY(dense_backward_weight(G.offc, t, bO, 1, (float *)gr->offset_w, part, st));
+    DLKA_TRY(launch_bias_grad<float>(bO, (float *)gr->offset_b, B, 81, G.pw.N, st));
+    DLKA_TRY(dense_backward_data(G.offc, bO, 1, (const float *)p->offset_w, bD, wp, 3, bA, st));                   // bD = gt
+    // depthwise 7^3 dil 3:  t = DW7 t1
+    DLKA_TRY(dw_forward(G.dw7, bD, (const float *)p->conv_spatial_w, nullptr, bB, wp, 1, st));                     // bB = gt1
+    DLKA_TRY(dw_backward_weight(G.dw7, t1, bD, (float *)gr->conv_spatial_w, gwp, st));
+    DLKA_TRY(launch_cl_colsum(bD, (float *)gr->conv_spatial_b, G.pw.M, C, st));
+    // depthwise 5^3:  t1 = DW5 a
+    DLKA_TRY(dw_forward(G.dw5, bB, (const float *)p->conv0_w, nullptr, bA, wp, 1, st));                            // bA = ga2
+    DLKA_TRY(dw_backward_weight(G.dw5, a, bB, (float *)gr->conv0_w, gwp, st));
+    DLKA_TRY(launch_cl_colsum(bB, (float *)gr->conv0_b, G.pw.M, C, st));
+    // GELU:  a = GELU(h)
+    DLKA_TRY(launch_add_fwd<float>(bC, bA, bC, E, st));                                                            // bC = ga
+    DLKA_TRY(launch_gelu_bwd<float>(h, bC, bA, E, st));                                                            // bA = gh
+    // proj_1:  h = P1 x ;  gx = P1^T gh + gy (shortcut)
+    DLKA_TRY(dense_backward_weight(G.pw, x, bA, 0, (float *)gr->proj_1_w, part, st));
+    DLKA_TRY(launch_cl_colsum(bA, (float *)gr->proj_1_b, G.pw.M, C, st));
+    DLKA_TRY(dense_backward_data(G.pw, bA, 0, (const float *)p->proj_1_w, gx, wp, 3, gy, st));
+    return DLKA_OK;
+}
+
+}  // extern "C"

@@ -314,3 +314,130 @@ def lka2d_attention_backward(x, params, grad_y, saved):
                                            L.ptr(ws), wb, B, C, H, W, dt, L.stream_ptr(x))
     L.check(rc, "lka2d_attention_backward")
     return gx, grads
+
+
+# ------------------------------------------------------------------------------------------------------------
+# channels-last fast path (fp32): x [B, D, H, W, C]
+# ------------------------------------------------------------------------------------------------------------
+def _geom_cl(x_shape, cout, k, p, d, group, dg=1):
+    B, D, H, W, C = (int(v) for v in x_shape)
+    return L.ConvGeom(B, C, D, H, W, int(cout), *k, 1, 1, 1, *p, *d, int(group), int(dg), 64)
+
+
+def conv3d_forward_cl(x, weight, bias=None, padding=0, dilation=1, groups=1, out_planar=False):
+    L.require_device(x, weight, bias)
+    p, d = _triple(padding), _triple(dilation)
+    x, weight = x.contiguous(), weight.contiguous()
+    bias = None if bias is None else bias.contiguous()
+    g = _geom_cl(x.shape, weight.shape[0], tuple(weight.shape[2:5]), p, d, groups)
+    lib = L.get_lib()
+    dt = L.dtype_code(x)
+    B, D, H, W, _ = x.shape
+    shape = (B, g.Cout, D, H, W) if out_planar else (B, D, H, W, g.Cout)
+    out = torch.empty(shape, dtype=x.dtype, device=x.device)
+    wsb = lib.dlka_conv3d_cl_workspace(byref(g), dt, 0)
+    ws = L.scratch(wsb, x)
+    rc = lib.dlka_conv3d_forward_cl(L.ptr(x), L.ptr(weight), L.ptr(bias), L.ptr(out), int(out_planar), L.ptr(ws), wsb, byref(g), dt,
+                                    L.stream_ptr(x))
+    L.check(rc, "conv3d_forward_cl")
+    return out
+
+
+def conv3d_backward_cl(x, weight, grad_out, padding=0, dilation=1, groups=1, grad_out_planar=False):
+    L.require_device(x, weight, grad_out)
+    p, d = _triple(padding), _triple(dilation)
+    x, weight, grad_out = x.contiguous(), weight.contiguous(), grad_out.contiguous()
+    g = _geom_cl(x.shape, weight.shape[0], tuple(weight.shape[2:5]), p, d, groups)
+    lib = L.get_lib()
+    dt = L.dtype_code(x)
+    gi, gw = torch.empty_like(x), torch.empty_like(weight)
+    gb = torch.empty((g.Cout,), dtype=x.dtype, device=x.device)
+    wsb = lib.dlka_conv3d_cl_workspace(byref(g), dt, 1)
+    ws = L.scratch(wsb, x)
+    rc = lib.dlka_conv3d_backward_cl(L.ptr(x), L.ptr(weight), L.ptr(grad_out), int(grad_out_planar), L.ptr(gi), L.ptr(gw), L.ptr(gb),
+                                     L.ptr(ws), wsb, byref(g), dt, L.stream_ptr(x))
+    L.check(rc, "conv3d_backward_cl")
+    return gi, gw, gb
+
+
+def deform_conv3d_forward_cl(x, offset, weight, bias, padding=1, dilation=1):
+    """x [B,D,H,W,C] channels-last, offset [B,3K,D,H,W] planar -> out [B,D,H,W,Cout]."""
+    L.require_device(x, offset, weight, bias)
+    p, d = _triple(padding), _triple(dilation)
+    x, offset, weight, bias = x.contiguous(), offset.contiguous(), weight.contiguous(), bias.contiguous()
+    g = _geom_cl(x.shape, weight.shape[0], tuple(weight.shape[2:5]), p, d, 1)
+    lib = L.get_lib()
+    dt = L.dtype_code(x)
+    B, D, H, W, _ = x.shape
+    out = torch.empty((B, D, H, W, g.Cout), dtype=x.dtype, device=x.device)
+    wsb = lib.dlka_deform_conv3d_cl_workspace(byref(g), dt, 0)
+    ws = L.scratch(wsb, x)
+    rc = lib.dlka_deform_conv3d_forward_cl(L.ptr(x), L.ptr(offset), L.ptr(weight), L.ptr(bias), L.ptr(out), L.ptr(ws), wsb, byref(g), dt,
+                                           L.stream_ptr(x))
+    L.check(rc, "deform_conv3d_forward_cl")
+    return out
+
+
+def deform_conv3d_backward_cl(x, offset, weight, grad_out, padding=1, dilation=1):
+    L.require_device(x, offset, weight, grad_out)
+    p, d = _triple(padding), _triple(dilation)
+    x, offset, weight, grad_out = x.contiguous(), offset.contiguous(), weight.contiguous(), grad_out.contiguous()
+    g = _geom_cl(x.shape, weight.shape[0], tuple(weight.shape[2:5]), p, d, 1)
+    lib = L.get_lib()
+    dt = L.dtype_code(x)
+    gi, go, gw = torch.empty_like(x), torch.empty_like(offset), torch.empty_like(weight)
+    gb = torch.empty((g.Cout,), dtype=x.dtype, device=x.device)
+    wsb = lib.dlka_deform_conv3d_cl_workspace(byref(g), dt, 1)
+    ws = L.scratch(wsb, x)
+    rc = lib.dlka_deform_conv3d_backward_cl(L.ptr(x), L.ptr(offset), L.ptr(weight), L.ptr(grad_out), L.ptr(gi), L.ptr(go), L.ptr(gw),
+                                            L.ptr(gb), L.ptr(ws), wsb, byref(g), dt, L.stream_ptr(x))
+    L.check(rc, "deform_conv3d_backward_cl")
+    return gi, go, gw, gb
+
+
+def lka3d_tokens_supported(x, B, C, D, H, W) -> bool:
+    if x.dtype != torch.float32:
+        return False
+    return bool(L.get_lib().dlka_lka3d_tokens_supported(B, C, D, H, W, L.DLKA_F32))
+
+
+def lka3d_attention_tokens_forward(x, params, dims):
+    """x: [B, N, C] tokens, dims = (D, H, W) spatial extents (the reference's H, W, D). Returns (y, saved)."""
+    L.require_device(x, *params)
+    x = x.contiguous()
+    params = [t.contiguous() for t in params]
+    B, N, C = (int(v) for v in x.shape)
+    D, H, W = (int(v) for v in dims)
+    assert N == D * H * W
+    lib = L.get_lib()
+    dt = L.dtype_code(x)
+    sb, wb = lib.dlka_lka3d_tokens_saved_bytes(B, C, D, H, W, dt), lib.dlka_lka3d_tokens_workspace_bytes(B, C, D, H, W, dt)
+    if sb == 0:
+        L.check(-8, "lka3d_attention_tokens_forward")
+    saved, ws = L.scratch(sb, x), L.scratch(wb, x)
+    y = torch.empty_like(x)
+    ps = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, params)
+    rc = lib.dlka_lka3d_attention_tokens_forward(L.ptr(x), byref(ps), L.ptr(y), L.ptr(saved), sb, L.ptr(ws), wb, B, C, D, H, W, dt,
+                                                 L.stream_ptr(x))
+    L.check(rc, "lka3d_attention_tokens_forward")
+    return y, saved
+
+
+def lka3d_attention_tokens_backward(x, params, grad_y, saved, dims):
+    L.require_device(x, grad_y, saved, *params)
+    x, grad_y = x.contiguous(), grad_y.contiguous()
+    params = [t.contiguous() for t in params]
+    B, N, C = (int(v) for v in x.shape)
+    D, H, W = (int(v) for v in dims)
+    lib = L.get_lib()
+    dt = L.dtype_code(x)
+    wb = lib.dlka_lka3d_tokens_workspace_bytes(B, C, D, H, W, dt)
+    ws = L.scratch(wb, x)
+    gx = torch.empty_like(x)
+    grads = [torch.empty_like(t) for t in params]
+    ps = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, params)
+    gs = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, grads)
+    rc = lib.dlka_lka3d_attention_tokens_backward(L.ptr(x), byref(ps), L.ptr(grad_y), L.ptr(saved), saved.numel(), L.ptr(gx), byref(gs),
+                                                  L.ptr(ws), wb, B, C, D, H, W, dt, L.stream_ptr(x))
+    L.check(rc, "lka3d_attention_tokens_backward")
+    return gx, grads

@@ -61,9 +61,11 @@ class DLKABlockStack:
             blk.pstruct = L.Lka3dPtrs(*[p.data_ptr() for p in blk.params])
             blk.gstruct = L.Lka3dPtrs(*[g.data_ptr() for g in blk.grads])
             H, W, D = dims
-            blk.saved_bytes = self.lib.dlka_lka3d_saved_bytes(batch, C, H, W, D, self.dt)
+            if not self.lib.dlka_lka3d_tokens_supported(batch, C, H, W, D, self.dt):
+                raise RuntimeError(f"token-layout D-LKA block does not support C={C}, dtype={dtype}")
+            blk.saved_bytes = self.lib.dlka_lka3d_tokens_saved_bytes(batch, C, H, W, D, self.dt)
             blk.saved = torch.empty(blk.saved_bytes, dtype=torch.uint8, device=self.device)
-            ws_bytes = max(ws_bytes, self.lib.dlka_lka3d_workspace_bytes(batch, C, H, W, D, self.dt))
+            ws_bytes = max(ws_bytes, self.lib.dlka_lka3d_tokens_workspace_bytes(batch, C, H, W, D, self.dt))
             self.blocks.append(blk)
         self.ws_bytes = ws_bytes
         self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
@@ -73,7 +75,7 @@ class DLKABlockStack:
         for C, dims, n in stages:
             for c0 in range(0, n, CHAIN):
                 chain = self.blocks[i + c0:i + min(c0 + CHAIN, n)]
-                shape = (batch, C) + tuple(dims)
+                shape = (batch, dims[0] * dims[1] * dims[2], C)   # token layout [B, N, C]
                 acts = [torch.randn(shape, generator=gen).to(self.device, dtype)] + \
                        [torch.empty(shape, dtype=dtype, device=self.device) for _ in chain]
                 gacts = [torch.empty(shape, dtype=dtype, device=self.device) for _ in chain] + \
@@ -108,19 +110,19 @@ class DLKABlockStack:
         st = self._stream()
         for blk in self.blocks:
             H, W, D = blk.dims
-            rc = self.lib.dlka_lka3d_attention_forward(L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.y), L.ptr(blk.saved),
+            rc = self.lib.dlka_lka3d_attention_tokens_forward(L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.y), L.ptr(blk.saved),
                                                        blk.saved_bytes, L.ptr(self.ws), self.ws_bytes, self.B, blk.C, H, W, D,
                                                        self.dt, st)
-            L.check(rc, "lka3d_attention_forward")
+            L.check(rc, "lka3d_attention_tokens_forward")
 
     def backward(self):
         st = self._stream()
         for blk in reversed(self.blocks):
             H, W, D = blk.dims
-            rc = self.lib.dlka_lka3d_attention_backward(L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.gy), L.ptr(blk.saved),
+            rc = self.lib.dlka_lka3d_attention_tokens_backward(L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.gy), L.ptr(blk.saved),
                                                         blk.saved_bytes, L.ptr(blk.gx), byref(blk.gstruct), L.ptr(self.ws),
                                                         self.ws_bytes, self.B, blk.C, H, W, D, self.dt, st)
-            L.check(rc, "lka3d_attention_backward")
+            L.check(rc, "lka3d_attention_tokens_backward")
 
     def forward_backward(self):
         self.forward()

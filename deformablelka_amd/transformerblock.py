@@ -50,6 +50,24 @@ class _LKA3dAttentionFn(Function):
         return (gx, *grads)
 
 
+class _LKA3dTokensFn(Function):
+    """Whole block on the token tensor [B, N, C] (channels-last end to end, no permutes)."""
+
+    @staticmethod
+    def forward(ctx, x, dims, *params):
+        y, saved = ops.lka3d_attention_tokens_forward(x, params, dims)
+        ctx.dims = dims
+        ctx.save_for_backward(x, saved, *params)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, saved, *params = ctx.saved_tensors
+        gx, grads = ops.lka3d_attention_tokens_backward(x, params, gy, saved, ctx.dims)
+        return (gx, None, *grads)
+
+
 class LKA_Attention3d_deform(nn.Module):
     """transformerblock.py:655-673."""
 
@@ -73,6 +91,10 @@ class LKA_Attention3d_deform(nn.Module):
         return _LKA3dAttentionFn.apply(x, *self.block_params())
 
     def forward(self, x, B, C, H, W, D):
+        # Fast path: the token tensor IS the channels-last volume; run the block on it directly.
+        if ops.lka3d_tokens_supported(x, B, C, H, W, D):
+            return _LKA3dTokensFn.apply(x, (H, W, D), *self.block_params())
+        # General path (any C / dtype): the reference's own data movement around the NCDHW block.
         x = x.permute(0, 2, 1).reshape(B, C, H, W, D)  # B N C --> B C N --> B C H W D   (:665)
         x = self.forward_volume(x)
         x = x.reshape(B, C, H * W * D).permute(0, 2, 1)  # (:672)

@@ -226,6 +226,55 @@ int dlka_lka2d_attention_backward(const void *x, const dlka_lka2d_params *p, con
                                   void *workspace, size_t workspace_bytes,
                                   int B, int C, int H, int W, int dtype, void *stream);
 
+
+/* =======================================================================================
+ * Channels-last (NDHWC / token layout) fast path — fp32, stride 1, same-size output
+ * ======================================================================================= *
+ * The D-LKA block's real interface is the token tensor (B, N, C) (transformerblock.py:664-673): the reference permutes
+ * it to NCDHW (a copy), runs the block, and permutes back (another copy).  On MI355X the whole block runs directly in
+ * token = channels-last layout: dense contractions (1x1x1 projections, offset-predict conv, deformable conv and their
+ * gradients) are implicit GEMMs on the fp32-input matrix cores, depthwise convs are register-tiled vector kernels.
+ * Offsets keep the reference's planar layout [B][3K][N].  Functions return DLKA_ERR_UNSUPPORTED for shapes outside
+ * the fast path (caller then uses the general NCDHW entry points above).                                              */
+
+/* x [B][D][H][W][C]; weight/bias in the reference layout; out [B][D][H][W][Cout], or planar [B][Cout][N] if out_planar.
+ * Depthwise (group == C == Cout, kw/dilation in {5/1, 7/3, 3/1, 5/3, 7/1}) or dense (group == 1, C % 32 == 0). */
+size_t dlka_conv3d_cl_workspace(const dlka_conv_geom *g, int dtype, int backward);
+int dlka_conv3d_forward_cl(const void *x, const void *weight, const void *bias, void *out, int out_planar,
+                           void *workspace, size_t workspace_bytes, const dlka_conv_geom *g, int dtype, void *stream);
+int dlka_conv3d_backward_cl(const void *x, const void *weight, const void *grad_out, int grad_out_planar,
+                            void *grad_x, void *grad_weight, void *grad_bias,
+                            void *workspace, size_t workspace_bytes, const dlka_conv_geom *g, int dtype, void *stream);
+
+/* Deformable conv with x / out / grad_x channels-last and offset / grad_offset planar (reference layout).
+ * group == deformable_group == 1, C and Cout in {32, 64, 96, 128, 256}.  Same semantics as dlka_deform_conv3d_*. */
+size_t dlka_deform_conv3d_cl_workspace(const dlka_conv_geom *g, int dtype, int backward);
+int dlka_deform_conv3d_forward_cl(const void *x, const void *offset, const void *weight, const void *bias, void *out,
+                                  void *workspace, size_t workspace_bytes, const dlka_conv_geom *g, int dtype, void *stream);
+int dlka_deform_conv3d_backward_cl(const void *x, const void *offset, const void *weight, const void *grad_out,
+                                   void *grad_x, void *grad_offset, void *grad_weight, void *grad_bias,
+                                   void *workspace, size_t workspace_bytes, const dlka_conv_geom *g, int dtype, void *stream);
+
+/* [B][C][N] <-> [B][N][C] */
+int dlka_ncdhw_to_ndhwc(const void *src, void *dst, int B, int C, int N, int dtype, void *stream);
+int dlka_ndhwc_to_ncdhw(const void *src, void *dst, int B, int C, int N, int dtype, void *stream);
+
+/* Replaces  LKA_Attention3d_deform.forward(x, B, C, H, W, D)  (transformerblock.py:664-673) on the TOKEN tensor itself:
+ *   x, y, grad_x, grad_y: [B][N][C] with N = D*H*W voxels in (d,h,w) order of the reference's reshape(B,C,H,W,D)
+ *   (its "H,W,D" are just the three spatial extents).  No permute/copy on either side.
+ *   Supported: fp32, C in {32, 64, 128, 256} (the four D_LKA_Former stage widths). */
+int    dlka_lka3d_tokens_supported(int B, int C, int D, int H, int W, int dtype);
+size_t dlka_lka3d_tokens_saved_bytes(int B, int C, int D, int H, int W, int dtype);
+size_t dlka_lka3d_tokens_workspace_bytes(int B, int C, int D, int H, int W, int dtype);
+int dlka_lka3d_attention_tokens_forward(const void *x, const dlka_lka3d_params *p, void *y,
+                                        void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes,
+                                        int B, int C, int D, int H, int W, int dtype, void *stream);
+int dlka_lka3d_attention_tokens_backward(const void *x, const dlka_lka3d_params *p, const void *grad_y,
+                                         const void *saved, size_t saved_bytes,
+                                         void *grad_x, const dlka_lka3d_grads *grads,
+                                         void *workspace, size_t workspace_bytes,
+                                         int B, int C, int D, int H, int W, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

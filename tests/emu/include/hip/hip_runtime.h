@@ -39,6 +39,15 @@ struct dim3 {
 };
 struct uint3 { unsigned x, y, z; };
 
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) float2 { float x, y; };
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
+inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
+using std::max;
+using std::min;
+
 typedef void *hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
@@ -151,22 +160,6 @@ inline void run_block(Block &b) {
 
 // ---- collectives -----------------------------------------------------------------------------
 inline void barrier() { F().state = BARRIER; yield_to_sched(); }
-
-// deposit `bytes` from this lane, rendezvous with the wave, return pointer to the wave's 64 slots
-inline Slot *wave_exchange(const void *mine, size_t bytes) {
-    Block &b = B();
-    Fiber &f = F();
-    const int w = f.lin / WAVE;
-    const int par = b.waveop_count[w] & 1;  // all lanes of a wave see the same count at the same collective
-    memcpy(b.xchg[par][f.lin].b, mine, bytes);
-    f.state = WAVEOP;
-    yield_to_sched();
-    // the LAST lane to resume bumps the counter: do it lazily — each lane keeps a private count instead
-    return &b.xchg[par][w * WAVE];
-}
-
-// private per-fiber op counter keeps parity consistent without a second rendezvous
-struct OpCount { int v = 0; };
 
 template <typename Kernel, typename... Args>
 void launch(Kernel k, dim3 grid, dim3 block, size_t shmem, Args... args) {

@@ -138,3 +138,71 @@ def check_conv3d(dev, B, C, Cout, dims, k, s, p, d, g, seed=0, use_aten_ref=True
     assert_close("conv3d grad_input", gi, rgi, rtol=BWD_RTOL)
     assert_close("conv3d grad_weight", gw, rgw, rtol=BWD_RTOL)
     assert_close("conv3d grad_bias", gb, rgb, rtol=BWD_RTOL)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# channels-last fast path
+# ------------------------------------------------------------------------------------------------------------
+def to_cl(t):   # [B,C,D,H,W] -> [B,D,H,W,C]
+    return t.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def from_cl(t):
+    return t.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def check_conv3d_cl(dev, B, C, Cout, dims, k, p, d, g, planar=False, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, *dims, generator=gen)
+    w = torch.randn(Cout, C // g, k, k, k, generator=gen) * (1.0 / (C // g * k ** 3) ** 0.5)
+    b = torch.randn(Cout, generator=gen)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    ref = F.conv3d(xr, wr, br, 1, p, d, g)
+    go = torch.randn(ref.shape, generator=gen)
+    ref.backward(go.double())
+    out = ops.conv3d_forward_cl(to_cl(x).to(dev), w.to(dev), b.to(dev), p, d, g, out_planar=planar)
+    assert_close("conv3d_cl fwd", out if planar else from_cl(out), ref.detach(), atol=FWD_ATOL)
+    gi, gw, gb = ops.conv3d_backward_cl(to_cl(x).to(dev), w.to(dev), (go if planar else to_cl(go)).to(dev), p, d, g, grad_out_planar=planar)
+    assert_close("conv3d_cl grad_input", from_cl(gi), xr.grad, rtol=BWD_RTOL)
+    assert_close("conv3d_cl grad_weight", gw, wr.grad, rtol=BWD_RTOL)
+    assert_close("conv3d_cl grad_bias", gb, br.grad, rtol=BWD_RTOL)
+
+
+def check_deform3d_cl(dev, B, C, Cout, dims, off_mode="normal", seed=0):
+    x, off, w, b, go, (k3, s3, p3, d3) = make_deform3d(B, C, Cout, dims, 3, 1, 1, 1, 1, 1, off_mode, seed)
+    ref = oracle.deform_conv3d_forward(x, w, b, off, 1, 1, 1, 1, 1)
+    out = ops.deform_conv3d_forward_cl(to_cl(x).to(dev), off.to(dev), w.to(dev), b.to(dev), 1, 1)
+    assert_close("deform3d_cl fwd", from_cl(out), ref, atol=FWD_ATOL)
+    rgi, rgo, rgw, rgb = oracle.deform_conv3d_backward(x, w, b, off, go, 1, 1, 1, 1, 1, q1_literal=False)
+    gi, goff, gw, gb = ops.deform_conv3d_backward_cl(to_cl(x).to(dev), off.to(dev), w.to(dev), to_cl(go).to(dev), 1, 1)
+    assert_close("deform3d_cl grad_input", from_cl(gi), rgi, rtol=BWD_RTOL)
+    assert_close("deform3d_cl grad_offset", goff, rgo, rtol=BWD_RTOL)
+    assert_close("deform3d_cl grad_weight", gw, rgw, rtol=BWD_RTOL)
+    assert_close("deform3d_cl grad_bias", gb, rgb, rtol=BWD_RTOL)
+
+
+def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=2e-4, rtol=2e-3):
+    """Token-layout fused block vs the oracle block (oracle/blocks.py)."""
+    import deformablelka_amd as dk
+    from oracle import blocks
+    torch.manual_seed(seed)
+    H, W, D = dims
+    N = H * W * D
+    m = dk.LKA_Attention3d_deform(C)
+    blocks.randomize_offsets_(m, std=offset_std)
+    x = torch.randn(B, N, C)
+    gy = torch.randn(B, N, C)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    yr = blocks.lka3d_attention_tokens(xr, P, B, C, H, W, D)
+    yr.backward(gy)
+    m = m.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    y = m(xd, B, C, H, W, D)
+    y.backward(gy.to(dev))
+    assert_close("tokens y", y, yr.detach(), atol=atol)
+    assert_close("tokens gx", xd.grad, xr.grad, rtol=rtol)
+    for k, p in m.named_parameters():
+        g = P[k].grad
+        if g is not None and g.abs().max() > 0:
+            assert_close("tokens grad " + k, p.grad, g, rtol=rtol)

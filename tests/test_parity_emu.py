@@ -84,3 +84,31 @@ GOLDEN = ["DeformConvPack_k3", "DeformConvPack_k5_dw_zero", "DeformConv_g2_dg2_n
 def test_reference_module_golden(name):
     from tests.golden_checks import replay
     replay(name, "cpu")
+
+
+# ---- channels-last fast path (MFMA implicit GEMM, register-tiled depthwise) on the emulator ----------------
+CL_CONV = [
+    # B, C, Cout, dims, k, p, d, g, planar
+    (1, 32, 32, (3, 4, 5), 1, 0, 1, 1, False),      # pointwise
+    (2, 32, 81, (3, 4, 6), 3, 1, 1, 1, True),       # offset-predict conv, planar output
+    (1, 64, 32, (2, 3, 5), 3, 1, 1, 1, False),      # two input chunks
+    (1, 32, 32, (5, 6, 9), 5, 2, 1, 32, False),     # depthwise 5^3
+    (1, 32, 32, (7, 5, 10), 7, 9, 3, 32, False),    # depthwise 7^3 dil 3
+]
+
+
+@pytest.mark.parametrize("case", CL_CONV)
+def test_conv3d_cl(case):
+    *cfg, planar = case
+    parity.check_conv3d_cl("cpu", *cfg, planar=planar)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, (3, 4, 5), "normal"), (1, 32, 64, (4, 3, 6), "wild"), (1, 64, 32, (3, 3, 4), "integer")])
+def test_deform3d_cl(case):
+    B, C, Cout, dims, mode = case
+    parity.check_deform3d_cl("cpu", B, C, Cout, dims, off_mode=mode)
+
+
+def test_lka3d_tokens_block():
+    """Token-layout fused block (MFMA igemm + dw + fused deformable backward), one C-ABI call per direction."""
+    parity.check_lka3d_tokens("cpu", 1, 32, (3, 4, 5))

@@ -169,3 +169,65 @@ def test_error_behaviour():
     m = dk.DeformConv(4, 4, 3, 1, 1).to(DEV)
     with pytest.raises(AssertionError):
         m(x, off[:, :80])
+
+
+# ---- channels-last fast path (MFMA implicit GEMM etc.) -------------------------------------------------------
+CL_CONV = [
+    (2, 32, 32, (12, 12, 12), 1, 0, 1, 1, False),
+    (2, 32, 81, (10, 10, 10), 3, 1, 1, 1, True),      # offset-predict conv (planar offsets)
+    (2, 64, 81, (8, 8, 8), 3, 1, 1, 1, True),
+    (2, 256, 81, (4, 4, 4), 3, 1, 1, 1, True),        # stage-3, real size (split-K path)
+    (2, 128, 128, (8, 8, 8), 1, 0, 1, 1, False),      # stage-2 pointwise, real size
+    (2, 256, 256, (4, 4, 4), 1, 0, 1, 1, False),      # stage-3 pointwise, real size
+    (2, 32, 32, (12, 12, 12), 5, 2, 1, 32, False),
+    (2, 32, 32, (12, 12, 12), 7, 9, 3, 32, False),
+    (2, 128, 128, (8, 8, 8), 7, 9, 3, 128, False),    # stage-2 dw7, real size
+    (2, 256, 256, (4, 4, 4), 5, 2, 1, 256, False),    # stage-3 dw5, real size
+]
+
+
+@pytest.mark.parametrize("case", CL_CONV)
+def test_conv3d_cl(case):
+    *cfg, planar = case
+    parity.check_conv3d_cl(DEV, *cfg, planar=planar)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, (12, 12, 12), "normal"), (2, 64, 64, (8, 8, 8), "uniform3"),
+                                  (2, 128, 128, (8, 8, 8), "wild"), (2, 256, 256, (4, 4, 4), "normal"),
+                                  (1, 32, 32, (9, 9, 9), "integer"), (1, 32, 32, (5, 6, 7), "zero")])
+def test_deform3d_cl(case):
+    B, C, Cout, dims, mode = case
+    parity.check_deform3d_cl(DEV, B, C, Cout, dims, off_mode=mode)
+
+
+@pytest.mark.parametrize("C,dims", [(32, (16, 16, 16)), (64, (8, 8, 8)), (128, (8, 8, 8)), (256, (4, 4, 4)), (32, (5, 6, 7))])
+def test_lka3d_tokens_block_vs_oracle(C, dims):
+    parity.check_lka3d_tokens(DEV, 2, C, dims)
+
+
+def test_tokens_full_size_stage0_matches_general_path():
+    """BASELINE.json full size (C=32, 32^3, B=2): the token-layout fast path against our own general NCDHW path
+    (which is pinned to the oracle above) — forward and all gradients."""
+    import deformablelka_amd as dk
+    from oracle import blocks
+    torch.manual_seed(0)
+    B, C, n = 2, 32, 32
+    m = dk.LKA_Attention3d_deform(C)
+    blocks.randomize_offsets_(m, std=0.02)
+    m = m.to(DEV)
+    x = torch.randn(B, n * n * n, C, device=DEV)
+    gy = torch.randn(B, n * n * n, C, device=DEV)
+    xa = x.clone().requires_grad_(True)
+    ya = m(xa, B, C, n, n, n)                      # token fast path
+    ya.backward(gy)
+    ga = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for p in m.parameters():
+        p.grad = None
+    xb = x.clone().requires_grad_(True)
+    vb = xb.permute(0, 2, 1).reshape(B, C, n, n, n)
+    yb = m.forward_volume(vb).reshape(B, C, n * n * n).permute(0, 2, 1)   # general NCDHW path
+    yb.backward(gy)
+    parity.assert_close("y", ya, yb.detach(), atol=2e-4)
+    parity.assert_close("gx", xa.grad, xb.grad, rtol=2e-3)
+    for k, p in m.named_parameters():
+        parity.assert_close("grad " + k, ga[k], p.grad, rtol=2e-3)
