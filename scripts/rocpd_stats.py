@@ -7,7 +7,7 @@ import sys
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
 w = csv.writer(open(sys.argv[2], "w", newline=""))
-w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
 for r in rows:
-    w.writerow([r[0], r[1], int(r[2]), round(r[3], 1), round(r[4], 4)])
+    w.writerow([r[0], r[1], round(r[2], 1), round(r[3], 1), round(r[4], 4)])
 print(f"wrote {len(rows)} kernels to {sys.argv[2]}")
