@@ -23,7 +23,8 @@ struct WgradArgs {
     const float *g;
     const float *in;    // [B][N][Cin] channels-last
     const float *off;   // AMODE 1: planar offsets [B][3K][N]
-    float *part;        // [chunks][K][CoutP][Cin]
+    float *part;        // [chunks][K][CoutP][Cin] partial weight-gradient tiles, followed by [chunks][CoutP] partial bias sums
+    float *bpart;       // = part + chunks*K*CoutP*Cin when the bias gradient is wanted, else null (set by the launcher)
     int B, D, H, W, N, M;
     int Cin, Cout, CoutP;
     int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
@@ -44,6 +45,7 @@ struct DwWgradArgs {
     const float *g;     // [B][D][H][W][C]
     const float *in;    // [B][D][H][W][C]
     float *gwp;         // [K][C] fp32, zero-initialised
+    float *gb;          // [C] fp32, zero-initialised bias gradient (column sums of g) or null
     int B, D, H, W, C;
     int kd, kh, pd, ph, pw, dd, dh;
     int rows_per_block;

@@ -114,18 +114,26 @@ __global__ __launch_bounds__(256) void cl_dwconv_wgrad_kernel(DwWgradArgs p)
     float acc[KW];
 #pragma unroll
     for (int k = 0; k < KW; ++k) acc[k] = 0.f;
+    float bsum = 0.f;
+    const bool want_bias = p.gb && blockIdx.y == 0;   // one (i, j) slice also folds the column sums of g
     if (c < p.C) {
         for (long run = run_lo + rsub; run < run_hi; run += rpb) {
             const int w0 = (int)(run % runs_per_row) * TW;
             const int row = (int)(run / runs_per_row);
             const int h0 = row % p.H, d0 = (row / p.H) % p.D, b = row / (p.H * p.D);
             const int zd = d0 + i * p.dd - p.pd, zh = h0 + j * p.dh - p.ph;
-            if (zd < 0 || zd >= p.D || zh < 0 || zh >= p.H) continue;
+            const bool rows_ok = !(zd < 0 || zd >= p.D || zh < 0 || zh >= p.H);
+            if (!rows_ok && !want_bias) continue;
             const float *gp = p.g + (((long)(b * p.D + d0) * p.H + h0) * p.W + w0) * p.C + c;
-            const float *rowp = p.in + (((long)(b * p.D + zd) * p.H + zh) * p.W) * p.C + c;
             float gv[TW], seg[SEG];
 #pragma unroll
             for (int t = 0; t < TW; ++t) gv[t] = (w0 + t < p.W) ? gp[(long)t * p.C] : 0.f;
+            if (want_bias) {
+#pragma unroll
+                for (int t = 0; t < TW; ++t) bsum += gv[t];
+            }
+            if (!rows_ok) continue;
+            const float *rowp = p.in + (((long)(b * p.D + zd) * p.H + zh) * p.W) * p.C + c;
 #pragma unroll
             for (int e = 0; e < SEG; ++e) {
                 const int zw = w0 - p.pw + e;
@@ -140,6 +148,27 @@ __global__ __launch_bounds__(256) void cl_dwconv_wgrad_kernel(DwWgradArgs p)
 #pragma unroll
     for (int k = 0; k < KW; ++k) red[k * 256 + threadIdx.x] = acc[k];
     __syncthreads();
+    if (want_bias) {   // uniform per block; reuses the k = 0 slice after the weight sums are read below
+        float a0 = 0.f;
+        if (threadIdx.x < cpb && c < p.C)
+            for (int r = 0; r < rpb; ++r) a0 += red[r * cpb + threadIdx.x];
+        __syncthreads();
+        red[threadIdx.x] = bsum;
+        __syncthreads();
+        if (threadIdx.x < cpb && c < p.C) {
+            float bs = 0.f;
+            for (int r = 0; r < rpb; ++r) bs += red[r * cpb + threadIdx.x];
+            atomicAdd(p.gb + c, bs);
+            atomicAdd(p.gwp + (long)((i * p.kh + j) * KW) * p.C + c, a0);
+#pragma unroll
+            for (int k = 1; k < KW; ++k) {
+                float a = 0.f;
+                for (int r = 0; r < rpb; ++r) a += red[k * 256 + r * cpb + threadIdx.x];
+                atomicAdd(p.gwp + (long)((i * p.kh + j) * KW + k) * p.C + c, a);
+            }
+        }
+        return;
+    }
     if (threadIdx.x < cpb && c < p.C) {
 #pragma unroll
         for (int k = 0; k < KW; ++k) {
@@ -160,6 +189,7 @@ int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st)
     a.rows_per_block = cdiv(rows, xb);
     xb = cdiv(rows, a.rows_per_block);
     if (hipMemsetAsync(a.gwp, 0, (size_t)a.kd * a.kh * kw * a.C * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+    if (a.gb && hipMemsetAsync(a.gb, 0, (size_t)a.C * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
     dim3 grid(xb, a.kd * a.kh, cdiv(a.C, cpb)), block(256);
     if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
     else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_wgrad_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }

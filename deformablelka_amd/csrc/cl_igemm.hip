@@ -22,39 +22,19 @@ namespace dlka {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
-template <int AMODE, int OMODE, int NT>
-__global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
-{
-    __shared__ __attribute__((aligned(16))) float Bs[32 * NT * 32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 31, h = lane >> 5;
-    const int m = (blockIdx.x * 4 + wave) * 32 + i;      // this lane's A row
-    const bool row_ok = m < p.M;
-    const int b = row_ok ? m / p.N : 0;
-    const int v = row_ok ? m - b * p.N : 0;
-    const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / (p.W * p.H);
-    const int NPB = NT * 32;            // columns handled by this block
-    const int n0 = blockIdx.z * NPB;    // first column
+// Fetches this lane's 16 A values (channels ck*32 + 16*h + [0,16) of row m) for one (tap, chunk) unit.
+template <int AMODE>
+struct ARow {
+    int cur_tap;
+    const float *rowp;   // AMODE 0: neighbour row; AMODE 2: neighbour voxel in plane 0
+    TapSample<3> s;      // AMODE 1
+    __device__ __forceinline__ ARow() : cur_tap(-1), rowp(nullptr) {}
 
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    const int nchunk = p.CinP / 32;
-    const int unit_lo = blockIdx.y * p.units_per_split;
-    const int unit_hi = min(p.K * nchunk, unit_lo + p.units_per_split);
-
-    int cur_tap = -1;
-    const float *rowp = nullptr;   // AMODE 0: neighbour row; AMODE 2: neighbour voxel in plane 0
-    TapSample<3> s;
-    for (int unit = unit_lo; unit < unit_hi; ++unit) {
-        const int tap = unit / nchunk, ck = unit - tap * nchunk;
-        if (tap != cur_tap) {   // uniform
+    __device__ __forceinline__ void fetch(const IgemmArgs &p, int tap, int ck, int h, bool row_ok, int b, int v, int d0, int h0, int w0, float *a)
+    {
+        if (tap != cur_tap) {   // wave-uniform
             cur_tap = tap;
             const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
-            // ---- per-(row, tap) source description ----
             if (AMODE == 0 || AMODE == 2) {
                 const int zd = d0 + ti * p.dd - p.pd, zh = h0 + tj * p.dh - p.ph, zw = w0 + tk * p.dw - p.pw;
                 const bool ok = row_ok && zd >= 0 && zd < p.D && zh >= 0 && zh < p.H && zw >= 0 && zw < p.W;
@@ -74,65 +54,108 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
                 }
             }
         }
-        {
-
-            // ---- stage the 32 x NP weight chunk (shared by the 4 waves) ----
-            __syncthreads();   // previous chunk fully consumed
-            {
-                const float *src = p.wp + ((long)tap * p.CinP + ck * 32) * p.NP + n0;
-                float4 *dst = reinterpret_cast<float4 *>(Bs);
-                for (int e = tid; e < 32 * NPB / 4; e += 256) {
-                    const int rr = e / (NPB / 4), c4 = e - rr * (NPB / 4);
-                    dst[e] = reinterpret_cast<const float4 *>(src + (long)rr * p.NP)[c4];
+        const int c0 = ck * 32 + 16 * h;
+        if (AMODE == 0) {
+            if (rowp) {
+                const float4 *r4 = reinterpret_cast<const float4 *>(rowp + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float4 t = r4[e];
+                    a[4 * e] = t.x; a[4 * e + 1] = t.y; a[4 * e + 2] = t.z; a[4 * e + 3] = t.w;
                 }
-            }
-            // ---- this lane's 16 A values: channels ck*32 + 16*h + [0,16) of its row ----
-            float a[16];
-            const int c0 = ck * 32 + 16 * h;
-            if (AMODE == 0) {
-                if (rowp) {
-                    const float4 *r4 = reinterpret_cast<const float4 *>(rowp + c0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float4 t = r4[e];
-                        a[4 * e] = t.x; a[4 * e + 1] = t.y; a[4 * e + 2] = t.z; a[4 * e + 3] = t.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) a[e] = 0.f;
-                }
-            } else if (AMODE == 2) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) a[e] = (rowp && c0 + e < p.CinReal) ? rowp[(long)(c0 + e) * p.N] : 0.f;
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) a[e] = 0.f;
-                const float *base = p.in + (long)b * p.N * p.Cin + c0;
+            }
+        } else if (AMODE == 2) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    if ((s.ok >> q) & 1u) {   // corners outside the volume / samples outside the guard contribute 0
-                        const float4 *r4 = reinterpret_cast<const float4 *>(base + (long)s.idx[q] * p.Cin);
-                        const float wq = s.w[q];
+            for (int e = 0; e < 16; ++e) a[e] = (rowp && c0 + e < p.CinReal) ? rowp[(long)(c0 + e) * p.N] : 0.f;
+        } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float4 t = r4[e];
-                            a[4 * e] = fmaf(wq, t.x, a[4 * e]); a[4 * e + 1] = fmaf(wq, t.y, a[4 * e + 1]);
-                            a[4 * e + 2] = fmaf(wq, t.z, a[4 * e + 2]); a[4 * e + 3] = fmaf(wq, t.w, a[4 * e + 3]);
-                        }
+            for (int e = 0; e < 16; ++e) a[e] = 0.f;
+            const float *base = p.in + (long)b * p.N * p.Cin + c0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if ((s.ok >> q) & 1u) {   // corners outside the volume / samples outside the guard contribute 0
+                    const float4 *r4 = reinterpret_cast<const float4 *>(base + (long)s.idx[q] * p.Cin);
+                    const float wq = s.w[q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float4 t = r4[e];
+                        a[4 * e] = fmaf(wq, t.x, a[4 * e]); a[4 * e + 1] = fmaf(wq, t.y, a[4 * e + 1]);
+                        a[4 * e + 2] = fmaf(wq, t.z, a[4 * e + 2]); a[4 * e + 3] = fmaf(wq, t.w, a[4 * e + 3]);
                     }
                 }
             }
-            __syncthreads();   // weights staged
-            // ---- 16 k-steps x NT MFMAs ----
-            const float *brow = Bs + (16 * h) * NPB + i;
+        }
+    }
+};
+
+template <int AMODE, int OMODE, int NT>
+__global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
+{
+    constexpr int NPB = NT * 32;                 // columns handled by this block
+    constexpr int BV = NT;                       // float4 of the 32 x NPB weight chunk each of the 256 threads stages
+    __shared__ __attribute__((aligned(16))) float Bs[2][32 * NPB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int m = (blockIdx.x * 4 + wave) * 32 + i;      // this lane's A row
+    const bool row_ok = m < p.M;
+    const int b = row_ok ? m / p.N : 0;
+    const int v = row_ok ? m - b * p.N : 0;
+    const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / (p.W * p.H);
+    const int n0 = blockIdx.z * NPB;    // first column
+
+    f32x16 acc[NT];
 #pragma unroll
-            for (int st = 0; st < 16; ++st) {
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x2(a[st], brow[st * NPB + t * 32], acc[t]);
-            }
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int nchunk = p.CinP / 32;
+    const int unit_lo = blockIdx.y * p.units_per_split;
+    const int unit_hi = min(p.K * nchunk, unit_lo + p.units_per_split);
+
+    // software pipeline: while the MFMAs of unit u run, the weight chunk and the A values of unit u+1 are in flight
+    ARow<AMODE> arow;
+    f32x4 breg[BV];   // ext_vector_type: stays in registers across iterations (HIP's float4 struct did not)
+    float a_cur[16], a_nxt[16];
+#define DLKA_LOAD_B(unit_)                                                                         \
+    {                                                                                              \
+        const int tap_ = (unit_) / nchunk, ck_ = (unit_) - tap_ * nchunk;                          \
+        const float *src_ = p.wp + ((long)tap_ * p.CinP + ck_ * 32) * p.NP + n0;                   \
+        _Pragma("unroll") for (int e = 0; e < BV; ++e) {                                           \
+            const int idx_ = tid + e * 256;                                                        \
+            const int rr_ = idx_ / (NPB / 4), c4_ = idx_ - rr_ * (NPB / 4);                        \
+            breg[e] = reinterpret_cast<const f32x4 *>(src_ + (long)rr_ * p.NP)[c4_];              \
+        }                                                                                          \
+    }
+    if (unit_lo < unit_hi) {
+        DLKA_LOAD_B(unit_lo)
+        const int tap = unit_lo / nchunk;
+        arow.fetch(p, tap, unit_lo - tap * nchunk, h, row_ok, b, v, d0, h0, w0, a_nxt);
+    }
+    int buf = 0;
+    for (int unit = unit_lo; unit < unit_hi; ++unit, buf ^= 1) {
+#pragma unroll
+        for (int e = 0; e < BV; ++e) reinterpret_cast<f32x4 *>(Bs[buf])[tid + e * 256] = breg[e];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a_cur[e] = a_nxt[e];
+        __syncthreads();   // Bs[buf] staged; Bs[buf^1] (read two iterations ago) is free again
+        if (unit + 1 < unit_hi) {
+            DLKA_LOAD_B(unit + 1)
+            const int tap = (unit + 1) / nchunk;
+            arow.fetch(p, tap, unit + 1 - tap * nchunk, h, row_ok, b, v, d0, h0, w0, a_nxt);
+        }
+        const float *brow = Bs[buf] + (16 * h) * NPB + i;
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x2(a_cur[st], brow[st * NPB + t * 32], acc[t]);
         }
     }
 
+#undef DLKA_LOAD_B
     // ---- epilogue: D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
     const int mbase = (blockIdx.x * 4 + wave) * 32;
     const bool split = gridDim.y > 1;

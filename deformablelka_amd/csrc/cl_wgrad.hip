@@ -27,31 +27,64 @@ __global__ __launch_bounds__(64) void cl_wgrad_kernel(WgradArgs p)
     const int tap0 = blockIdx.z * TPW;
     const int co = ot * 32 + i;      // A-operand row (as lane i)
     const int ci = ct * 32 + i;      // B-operand column (as lane j = i)
+    const bool want_bias = p.bpart && ct == 0 && blockIdx.z == 0;
 
     f32x16 acc[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+
+    // tap offsets of this wave (uniform): neighbour = voxel + (od, oh, ow)
+    int od[TPW], oh[TPW], ow[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tap = tap0 + t;
+        od[t] = (tap / (p.kw * p.kh)) * p.dd - p.pd;
+        oh[t] = ((tap / p.kw) % p.kh) * p.dh - p.ph;
+        ow[t] = (tap % p.kw) * p.dw - p.pw;
+    }
 
     const int m_lo = chunk * p.rows_per_chunk;
     const int m_hi = min(p.M, m_lo + p.rows_per_chunk);
     for (int mbase = m_lo; mbase < m_hi; mbase += 32) {
-        // ---- A operand: G[m = mbase + 16h + s][co], s = 0..15 ----
+        // ---- rows this lane touches in the MFMA k dimension: m = mbase + 16h + s ----
+        const int mrow0 = mbase + 16 * h;
+        const int b0 = mrow0 / p.N, v0 = mrow0 - b0 * p.N;
+        // ---- A operand: G[m][co], s = 0..15 ----
         float ga[16];
+        if (GMODE == 0) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int m = mbase + 16 * h + s;
-            float val = 0.f;
-            if (m < m_hi && co < p.Cout) {
-                if (GMODE == 0) {
-                    val = p.g[(long)m * p.Cout + co];
-                } else {
-                    const int b = m / p.N, v = m - b * p.N;
-                    val = p.g[((long)b * p.Cout + co) * p.N + v];
+            for (int s = 0; s < 16; ++s) {
+                const int m = mrow0 + s;
+                ga[s] = (m < m_hi && co < p.Cout) ? p.g[(long)m * p.Cout + co] : 0.f;
+            }
+        } else {
+            const bool contiguous = (v0 + 15 < p.N) && (mrow0 + 15 < m_hi) && ((p.N & 3) == 0) && ((v0 & 3) == 0);
+            if (contiguous && co < p.Cout) {   // 16 consecutive voxels of one plane: four 16-byte loads
+                const f32x4 *g4 = reinterpret_cast<const f32x4 *>(p.g + ((long)b0 * p.Cout + co) * p.N + v0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 t4 = g4[e];
+                    ga[4 * e] = t4[0]; ga[4 * e + 1] = t4[1]; ga[4 * e + 2] = t4[2]; ga[4 * e + 3] = t4[3];
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int m = mrow0 + s;
+                    float val = 0.f;
+                    if (m < m_hi && co < p.Cout) {
+                        const int b = m / p.N, v = m - b * p.N;
+                        val = p.g[((long)b * p.Cout + co) * p.N + v];
+                    }
+                    ga[s] = val;
                 }
             }
-            ga[s] = val;
+        }
+        if (want_bias) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) bsum += ga[s];
         }
         if (AMODE == 1) {
             // ---- phase 1: sample tile S[t][row][32 ch] for this wave's TPW taps (lane = (row i, channel half h)) ----
@@ -68,27 +101,30 @@ __global__ __launch_bounds__(64) void cl_wgrad_kernel(WgradArgs p)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) a[e] = 0.f;
                 if (tap < p.K && row_ok) {
-                    const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
                     TapSample<3> s;
                     const float *offp = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
-                    setup_tap<3>(s, offp, p.N, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw, p.D, p.H, p.W);
+                    setup_tap<3>(s, offp, p.N, d0 + od[t], h0 + oh[t], w0 + ow[t], p.D, p.H, p.W);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         if ((s.ok >> q) & 1u) {
-                            const float4 *r4 = reinterpret_cast<const float4 *>(base + (long)s.idx[q] * p.Cin);
+                            const f32x4 *r4 = reinterpret_cast<const f32x4 *>(base + (long)s.idx[q] * p.Cin);
                             const float wq = s.w[q];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float4 x4 = r4[e];
-                                a[4 * e] = fmaf(wq, x4.x, a[4 * e]); a[4 * e + 1] = fmaf(wq, x4.y, a[4 * e + 1]);
-                                a[4 * e + 2] = fmaf(wq, x4.z, a[4 * e + 2]); a[4 * e + 3] = fmaf(wq, x4.w, a[4 * e + 3]);
+                                const f32x4 x4 = r4[e];
+                                a[4 * e] = fmaf(wq, x4[0], a[4 * e]); a[4 * e + 1] = fmaf(wq, x4[1], a[4 * e + 1]);
+                                a[4 * e + 2] = fmaf(wq, x4[2], a[4 * e + 2]); a[4 * e + 3] = fmaf(wq, x4[3], a[4 * e + 3]);
                             }
                         }
                     }
                 }
-                float4 *dst = reinterpret_cast<float4 *>(S + (t * 32 + i) * SROW + 16 * h);
+                f32x4 *dst = reinterpret_cast<f32x4 *>(S + (t * 32 + i) * SROW + 16 * h);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dst[e] = make_float4(a[4 * e], a[4 * e + 1], a[4 * e + 2], a[4 * e + 3]);
+                for (int e = 0; e < 4; ++e) {
+                    f32x4 o4;
+                    o4[0] = a[4 * e]; o4[1] = a[4 * e + 1]; o4[2] = a[4 * e + 2]; o4[3] = a[4 * e + 3];
+                    dst[e] = o4;
+                }
             }
             __syncthreads();
 #pragma unroll
@@ -98,25 +134,30 @@ __global__ __launch_bounds__(64) void cl_wgrad_kernel(WgradArgs p)
                 for (int s = 0; s < 16; ++s) acc[t] = mfma_32x32x2(ga[s], srow[s * SROW], acc[t]);
             }
         } else {
-            // ---- B operand straight from global: in[neighbour(m = mbase + 16h + s)][ci] ----
+            // ---- B operand straight from global: in[neighbour(m = mrow0 + s)][ci] ----
+            // voxel coordinates of the 16 rows, decoded once per tile (packed d:10 | h:10 | w:10, b in the row offset)
+            int crd[16];
+            int rowoff[16];   // element offset of in[b][v][ci] (fits int: B*N*Cin < 2^31 checked by the launcher)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                int v = v0 + s, b = b0;
+                if (v >= p.N) { v -= p.N; b += 1; }   // a tile spans at most two batch items when N >= 32; else general:
+                if (v >= p.N) { b = (mrow0 + s) / p.N; v = (mrow0 + s) - b * p.N; }
+                const int w_ = v % p.W, hh = (v / p.W) % p.H, d_ = v / (p.W * p.H);
+                crd[s] = (mrow0 + s < m_hi) ? ((d_ << 20) | (hh << 10) | w_) : -1;
+                rowoff[s] = (b * p.N + v) * p.Cin + ci;
+            }
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
-                const int tap = tap0 + t;
-                if (tap >= p.K) continue;  // uniform
-                const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
+                if (tap0 + t >= p.K) continue;  // uniform
+                const int doff = ((od[t] * p.H + oh[t]) * p.W + ow[t]) * p.Cin;
                 float bv[16];
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
-                    const int m = mbase + 16 * h + s;
-                    float val = 0.f;
-                    if (m < m_hi) {
-                        const int b = m / p.N, v = m - b * p.N;
-                        const int zw = v % p.W + tk * p.dw - p.pw, zh = (v / p.W) % p.H + tj * p.dh - p.ph,
-                                  zd = v / (p.W * p.H) + ti * p.dd - p.pd;
-                        if (zd >= 0 && zd < p.D && zh >= 0 && zh < p.H && zw >= 0 && zw < p.W)
-                            val = p.in[((long)b * p.N + (long)(zd * p.H + zh) * p.W + zw) * p.Cin + ci];
-                    }
-                    bv[s] = val;
+                    const int c_ = crd[s];
+                    const int zd = (c_ >> 20) + od[t], zh = ((c_ >> 10) & 1023) + oh[t], zw = (c_ & 1023) + ow[t];
+                    const bool ok = c_ >= 0 && zd >= 0 && zd < p.D && zh >= 0 && zh < p.H && zw >= 0 && zw < p.W;
+                    bv[s] = ok ? p.in[rowoff[s] + doff] : 0.f;
                 }
 #pragma unroll
                 for (int s = 0; s < 16; ++s) acc[t] = mfma_32x32x2(ga[s], bv[s], acc[t]);
@@ -134,18 +175,37 @@ __global__ __launch_bounds__(64) void cl_wgrad_kernel(WgradArgs p)
             p.part[(((long)chunk * p.K + tap) * p.CoutP + ot * 32 + row) * p.Cin + ci] = acc[t][r];
         }
     }
+    if (want_bias) {
+        bsum += __shfl_xor(bsum, 32);   // the two halves hold the same co for different rows
+        if (h == 0) p.bpart[(long)chunk * p.CoutP + co] = bsum;
+    }
 }
 
-// gW[co][ci][tap] (reference layout, storage type T) = sum_chunk part[chunk][tap][co][ci]
+// gW[co][ci][tap] (reference layout, storage type T) = sum_chunk part[chunk][tap][co][ci];  gb[co] = sum_chunk bpart[chunk][co]
 template <typename T>
-__global__ void cl_wgrad_reduce_kernel(const float *__restrict__ part, T *__restrict__ gw, int chunks, int K, int CoutP, int Cout, int Cin)
+__global__ void cl_wgrad_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bpart, T *__restrict__ gw, T *__restrict__ gb,
+                                       int chunks, int K, int CoutP, int Cout, int Cin)
 {
     const long n = (long)K * Cout * Cin;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-        const int ci = (int)(e % Cin), co = (int)((e / Cin) % Cout), tap = (int)(e / Cin / Cout);
-        float a = 0.f;
-        for (int c = 0; c < chunks; ++c) a += part[(((long)c * K + tap) * CoutP + co) * Cin + ci];
-        stf(gw + ((long)co * Cin + ci) * K + tap, a);
+    const long stride = (long)K * CoutP * Cin;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n + (gb ? Cout : 0); e += (long)gridDim.x * blockDim.x) {
+        if (e < n) {
+            const int ci = (int)(e % Cin), co = (int)((e / Cin) % Cout), tap = (int)(e / Cin / Cout);
+            const float *src = part + ((long)tap * CoutP + co) * Cin + ci;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int c = 0;
+            for (; c + 4 <= chunks; c += 4) {   // independent loads in flight
+                a0 += src[(long)c * stride]; a1 += src[(long)(c + 1) * stride];
+                a2 += src[(long)(c + 2) * stride]; a3 += src[(long)(c + 3) * stride];
+            }
+            for (; c < chunks; ++c) a0 += src[(long)c * stride];
+            stf(gw + ((long)co * Cin + ci) * K + tap, (a0 + a1) + (a2 + a3));
+        } else {
+            const int co = (int)(e - n);
+            float a = 0.f;
+            for (int c = 0; c < chunks; ++c) a += bpart[(long)c * CoutP + co];
+            stf(gb + co, a);
+        }
     }
 }
 
@@ -158,11 +218,11 @@ int cl_wgrad_pick_chunks(int M)
 
 size_t cl_wgrad_part_floats(int M, int K, int Cout, int Cin)
 {
-    return (size_t)cl_wgrad_pick_chunks(M) * K * round_up(Cout, 32) * Cin;
+    return (size_t)cl_wgrad_pick_chunks(M) * ((size_t)K * round_up(Cout, 32) * Cin + round_up(Cout, 32));
 }
 
 template <typename T>
-int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, hipStream_t st)
+int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t st)
 {
     const int chunks = cl_wgrad_pick_chunks(a.M);
     const int tiles = cdiv(a.M, 32);
@@ -171,15 +231,17 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, hipStream_t st)
     a.CoutP = round_up(a.Cout, 32);
     a.CT = a.Cin / 32;
     const int OT = a.CoutP / 32;
+    if ((long)a.B * a.N * a.Cin >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;
+    a.bpart = gb ? a.part + (size_t)nchunks * a.K * a.CoutP * a.Cin : nullptr;
     if (a.K == 1) {
         dim3 grid(nchunks, OT * a.CT, 1), block(64);
         if (amode == 0 && gmode == 0) { auto k = cl_wgrad_kernel<0, 0, 1>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
         else return DLKA_ERR_UNSUPPORTED;
     } else {
-        constexpr int TPW = 7;
-        dim3 grid(nchunks, OT * a.CT, cdiv(a.K, TPW)), block(64);
-        if (amode == 0 && gmode == 1) { auto k = cl_wgrad_kernel<0, 1, TPW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-        else if (amode == 0 && gmode == 0) { auto k = cl_wgrad_kernel<0, 0, TPW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        constexpr int TPW = 7, TPW0 = 4;   // plain-neighbour variant: fewer taps per wave -> 2 waves/SIMD
+        dim3 grid(nchunks, OT * a.CT, cdiv(a.K, TPW)), grid0(nchunks, OT * a.CT, cdiv(a.K, TPW0)), block(64);
+        if (amode == 0 && gmode == 1) { auto k = cl_wgrad_kernel<0, 1, TPW0>; hipLaunchKernelGGL(k, grid0, block, 0, st, a); }
+        else if (amode == 0 && gmode == 0) { auto k = cl_wgrad_kernel<0, 0, TPW0>; hipLaunchKernelGGL(k, grid0, block, 0, st, a); }
         else if (amode == 1 && gmode == 0) { auto k = cl_wgrad_kernel<1, 0, TPW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
         else return DLKA_ERR_UNSUPPORTED;
     }
@@ -188,12 +250,12 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, hipStream_t st)
     long blocks = cdivl(n, 256);
     if (blocks > 2048) blocks = 2048;
     auto rk = cl_wgrad_reduce_kernel<T>;
-    hipLaunchKernelGGL(rk, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)a.part, gw, nchunks, a.K, a.CoutP, a.Cout, a.Cin);
+    hipLaunchKernelGGL(rk, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)a.part, (const float *)a.bpart, gw, gb, nchunks, a.K, a.CoutP, a.Cout, a.Cin);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
 
-template int launch_cl_wgrad<float>(int, int, WgradArgs, float *, hipStream_t);
+template int launch_cl_wgrad<float>(int, int, WgradArgs, float *, float *, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------
 // column sums of a channels-last matrix:  gb[n] = sum_m G[m][n]     (bias gradients)

@@ -2,6 +2,8 @@
 // matrix cores, register-tiled depthwise convs, the fused deformable backward, and the token-layout D-LKA block.
 // Everything here is fp32; shapes the fast path does not cover return DLKA_ERR_UNSUPPORTED and the caller uses the
 // general NCDHW entry points (dlka_capi.hip) instead — still HIP, never a CPU fallback.
+#include <stdlib.h>
+
 #include "cl_args.h"
 #include "dlka_kernels.h"
 
@@ -111,7 +113,7 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
 size_t dense_wp_floats(const SameConv &s) { return (size_t)s.K * round_up(s.Cin, 32) * round_up(s.Cout, 32); }
 
 // ---- dense conv weight gradient -----------------------------------------------------------------------------------
-int dense_backward_weight(const SameConv &s, const float *x, const float *gout, int gout_planar, float *gw, float *part, hipStream_t st)
+int dense_backward_weight(const SameConv &s, const float *x, const float *gout, int gout_planar, float *gw, float *gb, float *part, hipStream_t st)
 {
     if (s.Cin % 32) return DLKA_ERR_UNSUPPORTED;
     if (s.K != 1 && s.K > 7 * 64) return DLKA_ERR_UNSUPPORTED;
@@ -121,7 +123,7 @@ int dense_backward_weight(const SameConv &s, const float *x, const float *gout, 
     a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.Cin = s.Cin; a.Cout = s.Cout;
     a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
     if (s.K == 1 && gout_planar) return DLKA_ERR_UNSUPPORTED;
-    return launch_cl_wgrad<float>(0, gout_planar ? 1 : 0, a, gw, st);
+    return launch_cl_wgrad<float>(0, gout_planar ? 1 : 0, a, gw, gb, st);
 }
 
 // ---- depthwise ------------------------------------------------------------------------------------------------------
@@ -137,11 +139,11 @@ int dw_forward(const SameConv &s, const float *x, const float *w, const float *b
     return launch_cl_dwconv(a, s.kw, s.dw, st);
 }
 
-int dw_backward_weight(const SameConv &s, const float *x, const float *gout, float *gw, float *gwp, hipStream_t st)
+int dw_backward_weight(const SameConv &s, const float *x, const float *gout, float *gw, float *gb, float *gwp, hipStream_t st)
 {
     DwWgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.g = gout; a.in = x; a.gwp = gwp;
+    a.g = gout; a.in = x; a.gwp = gwp; a.gb = gb;
     a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.C = s.Cin;
     a.kd = s.kd; a.kh = s.kh; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh;
     DLKA_TRY(launch_cl_dwconv_wgrad(a, s.kw, s.dw, st));
@@ -163,7 +165,7 @@ int deform_forward(const SameConv &s, const float *x, const float *off, const fl
 }
 
 int deform_backward(const SameConv &s, const float *x, const float *off, const float *w, const float *gout, float *gx, float *goff,
-                    float *gw, float *wp, float *part, hipStream_t st)
+                    float *gw, float *gb, float *wp, float *part, hipStream_t st)
 {
     if (gx || goff) {
         DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cout, s.Cin, 2, st));
@@ -172,7 +174,9 @@ int deform_backward(const SameConv &s, const float *x, const float *off, const f
         a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff;
         a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.C = s.Cin; a.Cout = s.Cout; a.CoutP = s.Cout;
         a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
-        DLKA_TRY(launch_cl_deform_bwd(a, st));
+        // LDS-window scatter for volumes with enough bricks to fill the chip; global-atomic variant for tiny ones
+        if (s.N >= 512 && !getenv("DLKA_DEFORM_BWD_GLOBAL")) DLKA_TRY(launch_cl_deform_bwd_lds(a, st));
+        else DLKA_TRY(launch_cl_deform_bwd(a, st));
     }
     if (gw) {
         WgradArgs a;
@@ -180,7 +184,9 @@ int deform_backward(const SameConv &s, const float *x, const float *off, const f
         a.g = gout; a.in = x; a.off = off; a.part = part;
         a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.Cin = s.Cin; a.Cout = s.Cout;
         a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
-        DLKA_TRY(launch_cl_wgrad<float>(1, 0, a, gw, st));
+        DLKA_TRY(launch_cl_wgrad<float>(1, 0, a, gw, gb, st));
+    } else if (gb) {
+        DLKA_TRY(launch_cl_colsum(gout, gb, s.M, s.Cout, st));
     }
     return DLKA_OK;
 }
@@ -280,8 +286,8 @@ int dlka_conv3d_backward_cl(const void *x, const void *weight, const void *grad_
         float *wp = (float *)cv.take((size_t)s.K * s.Cin * 4), *gwp = (float *)cv.take((size_t)s.K * s.Cin * 4);
         if (!cv.ok()) return DLKA_ERR_WORKSPACE;
         if (grad_x) DLKA_TRY(dw_forward(s, (const float *)grad_out, (const float *)weight, nullptr, (float *)grad_x, wp, 1, st));
-        if (grad_weight) DLKA_TRY(dw_backward_weight(s, (const float *)x, (const float *)grad_out, (float *)grad_weight, gwp, st));
-        if (grad_bias) DLKA_TRY(launch_cl_colsum((const float *)grad_out, (float *)grad_bias, s.M, s.Cout, st));
+        if (grad_weight) DLKA_TRY(dw_backward_weight(s, (const float *)x, (const float *)grad_out, (float *)grad_weight, (float *)grad_bias, gwp, st));
+        else if (grad_bias) DLKA_TRY(launch_cl_colsum((const float *)grad_out, (float *)grad_bias, s.M, s.Cout, st));
         return DLKA_OK;
     }
     if (s.group != 1) return DLKA_ERR_UNSUPPORTED;
@@ -289,8 +295,8 @@ int dlka_conv3d_backward_cl(const void *x, const void *weight, const void *grad_
     float *part = (float *)cv.take(cl_wgrad_part_floats(s.M, s.K, s.Cout, s.Cin) * 4);
     if (!cv.ok()) return DLKA_ERR_WORKSPACE;
     if (grad_x) DLKA_TRY(dense_backward_data(s, (const float *)grad_out, grad_out_planar, (const float *)weight, (float *)grad_x, wp, 0, nullptr, st));
-    if (grad_weight) DLKA_TRY(dense_backward_weight(s, (const float *)x, (const float *)grad_out, grad_out_planar, (float *)grad_weight, part, st));
-    if (grad_bias) {
+    if (grad_weight) DLKA_TRY(dense_backward_weight(s, (const float *)x, (const float *)grad_out, grad_out_planar, (float *)grad_weight, (float *)grad_bias, part, st));
+    else if (grad_bias) {
         if (grad_out_planar) DLKA_TRY(launch_bias_grad<float>((const float *)grad_out, (float *)grad_bias, s.B, s.Cout, s.N, st));
         else DLKA_TRY(launch_cl_colsum((const float *)grad_out, (float *)grad_bias, s.M, s.Cout, st));
     }
@@ -336,8 +342,7 @@ int dlka_deform_conv3d_backward_cl(const void *x, const void *offset, const void
     float *part = (float *)cv.take(cl_wgrad_part_floats(s.M, s.K, s.Cout, s.Cin) * 4);
     if (!cv.ok()) return DLKA_ERR_WORKSPACE;
     DLKA_TRY(deform_backward(s, (const float *)x, (const float *)offset, (const float *)weight, (const float *)grad_out, (float *)grad_x,
-                             (float *)grad_offset, (float *)grad_weight, wp, part, st));
-    if (grad_bias) DLKA_TRY(launch_cl_colsum((const float *)grad_out, (float *)grad_bias, s.M, s.Cout, st));
+                             (float *)grad_offset, (float *)grad_weight, (float *)grad_bias, wp, part, st));
     return DLKA_OK;
 }
 
@@ -434,35 +439,28 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     // proj_2:  y = P2 m + x
     DLKA_TRY(launch_mul_fwd<float>(a, g1, bA, E, st));                                                             // bA = m (recomputed)
     DLKA_TRY(dense_backward_data(G.pw, gy, 0, (const float *)p->proj_2_w, bB, wp, 0, nullptr, st));                // bB = gm
-    DLKA_TRY(dense_backward_weight(G.pw, bA, gy, 0, (float *)gr->proj_2_w, part, st));
-    DLKA_TRY(launch_cl_colsum(gy, (float *)gr->proj_2_b, G.pw.M, C, st));
+    DLKA_TRY(dense_backward_weight(G.pw, bA, gy, 0, (float *)gr->proj_2_w, (float *)gr->proj_2_b, part, st));
     // gate:  m = a * g1
     DLKA_TRY(launch_mul_bwd<float>(a, g1, bB, bC, bD, E, st));                                                     // bC = ga1 = gm*g1, bD = gg1 = gm*a
     // conv1:  g1 = P0 f
     DLKA_TRY(dense_backward_data(G.pw, bD, 0, (const float *)p->conv1_w, bB, wp, 0, nullptr, st));                 // bB = gf
-    DLKA_TRY(dense_backward_weight(G.pw, f, bD, 0, (float *)gr->conv1_w, part, st));
-    DLKA_TRY(launch_cl_colsum(bD, (float *)gr->conv1_b, G.pw.M, C, st));
+    DLKA_TRY(dense_backward_weight(G.pw, f, bD, 0, (float *)gr->conv1_w, (float *)gr->conv1_b, part, st));
     // deformable conv:  f = DCN(t, off)
-    DLKA_TRY(deform_backward(G.dcn, t, off, (const float *)p->deform_w, bB, bA, bO, (float *)gr->deform_w, wp, part, st));  // bA = gt_a, bO = goff
-    DLKA_TRY(launch_cl_colsum(bB, (float *)gr->deform_b, G.pw.M, C, st));
+    DLKA_TRY(deform_backward(G.dcn, t, off, (const float *)p->deform_w, bB, bA, bO, (float *)gr->deform_w, (float *)gr->deform_b, wp, part, st));  // bA = gt_a, bO = goff
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
-    DLKA_TRY(dense_backward_weight(G.offc, t, bO, 1, (float *)gr->offset_w, part, st));
-    DLKA_TRY(launch_bias_grad<float>(bO, (float *)gr->offset_b, B, 81, G.pw.N, st));
+    DLKA_TRY(dense_backward_weight(G.offc, t, bO, 1, (float *)gr->offset_w, (float *)gr->offset_b, part, st));
     DLKA_TRY(dense_backward_data(G.offc, bO, 1, (const float *)p->offset_w, bD, wp, 3, bA, st));                   // bD = gt
     // depthwise 7^3 dil 3:  t = DW7 t1
     DLKA_TRY(dw_forward(G.dw7, bD, (const float *)p->conv_spatial_w, nullptr, bB, wp, 1, st));                     // bB = gt1
-    DLKA_TRY(dw_backward_weight(G.dw7, t1, bD, (float *)gr->conv_spatial_w, gwp, st));
-    DLKA_TRY(launch_cl_colsum(bD, (float *)gr->conv_spatial_b, G.pw.M, C, st));
+    DLKA_TRY(dw_backward_weight(G.dw7, t1, bD, (float *)gr->conv_spatial_w, (float *)gr->conv_spatial_b, gwp, st));
     // depthwise 5^3:  t1 = DW5 a
     DLKA_TRY(dw_forward(G.dw5, bB, (const float *)p->conv0_w, nullptr, bA, wp, 1, st));                            // bA = ga2
-    DLKA_TRY(dw_backward_weight(G.dw5, a, bB, (float *)gr->conv0_w, gwp, st));
-    DLKA_TRY(launch_cl_colsum(bB, (float *)gr->conv0_b, G.pw.M, C, st));
+    DLKA_TRY(dw_backward_weight(G.dw5, a, bB, (float *)gr->conv0_w, (float *)gr->conv0_b, gwp, st));
     // GELU:  a = GELU(h)
     DLKA_TRY(launch_add_fwd<float>(bC, bA, bC, E, st));                                                            // bC = ga
     DLKA_TRY(launch_gelu_bwd<float>(h, bC, bA, E, st));                                                            // bA = gh
     // proj_1:  h = P1 x ;  gx = P1^T gh + gy (shortcut)
-    DLKA_TRY(dense_backward_weight(G.pw, x, bA, 0, (float *)gr->proj_1_w, part, st));
-    DLKA_TRY(launch_cl_colsum(bA, (float *)gr->proj_1_b, G.pw.M, C, st));
+    DLKA_TRY(dense_backward_weight(G.pw, x, bA, 0, (float *)gr->proj_1_w, (float *)gr->proj_1_b, part, st));
     DLKA_TRY(dense_backward_data(G.pw, bA, 0, (const float *)p->proj_1_w, gx, wp, 3, gy, st));
     return DLKA_OK;
 }

@@ -47,7 +47,7 @@ int cl_igemm_pick_splits(int M, int units, int epi);
 int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t st);
 int cl_wgrad_pick_chunks(int M);
 size_t cl_wgrad_part_floats(int M, int K, int Cout, int Cin);
-template <typename T> int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, hipStream_t st);
+template <typename T> int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t st);
 int launch_cl_colsum(const float *g, float *gb32, int M, int Cout, hipStream_t st);
 int launch_cl_dw_prep_weight(const float *w, float *wp, int C, int K, int flip, hipStream_t st);
 int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st);
@@ -55,5 +55,6 @@ int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st);
 template <typename T> int launch_cl_dw_unprep(const float *gwp, T *gw, int C, int K, hipStream_t st);
 int launch_cl_transpose(const float *src, float *dst, int B, int C, int N, int to_cl, hipStream_t st);
 int launch_cl_deform_bwd(const DeformBwdArgs &a, hipStream_t st);
+int launch_cl_deform_bwd_lds(const DeformBwdArgs &a, hipStream_t st);
 
 }  // namespace dlka

@@ -112,3 +112,10 @@ def test_deform3d_cl(case):
 def test_lka3d_tokens_block():
     """Token-layout fused block (MFMA igemm + dw + fused deformable backward), one C-ABI call per direction."""
     parity.check_lka3d_tokens("cpu", 1, 32, (3, 4, 5))
+
+
+@pytest.mark.parametrize("case", [(1, 32, 32, (8, 8, 8), "normal"), (2, 32, 32, (9, 8, 10), "wild"), (1, 32, 32, (8, 9, 8), "integer")])
+def test_deform3d_cl_lds_window(case):
+    """N >= 512 selects the LDS-window backward (bricks, halo overflow to global atomics, partial bricks)."""
+    B, C, Cout, dims, mode = case
+    parity.check_deform3d_cl("cpu", B, C, Cout, dims, off_mode=mode)
