@@ -1,0 +1,425 @@
+// Channels-last backward of the 3-D deformable convolution w.r.t. offsets and input — third generation.
+//
+// What the reference does (3D/dcn/src/cuda/deform_conv_cuda.cu:226-251): columns = W^T * grad_out (at::mm into a
+// 27*C x B*N buffer in HBM), deformable_col2im_coord_gpu_kernel (grad_offset, deform_im2col_cuda.cuh:336-405) and
+// deformable_col2im_gpu_kernel (grad_input, cuh:267-334: one global fp32 atomicAdd per column element and corner).
+//
+// Measured on MI355X (profiles/r01d_accum_ubench.txt): global fp32 atomics top out at ~3.3e11 lane-atomics/s whatever
+// the locality (1.0-1.6 ms for the 4.5e8 corner updates of one C=32, 32^3, B=2 call), LDS *fp32* atomics (ds_add_f32)
+// are no faster (0.33 lanes/clk/CU), but LDS *fp64* atomics (ds_add_f64) run at 6.7 lanes/clk/CU — 20x.  Hence:
+//
+//   cl_deform_goff_kernel   grad_offset only: a pure gather, no atomics.  MFMA orientation D[channel][voxel]
+//                           (A = W_tap^T from LDS, B = grad_out rows kept in registers for all 27 taps), so a lane owns
+//                           ONE voxel: its sampling description is lane-local and the channel reduction of
+//                           Col * d(sample)/d(q) is 16 in-register FMAs per corner plus one cross-half add.
+//   cl_deform_gx_kernel     grad_input: a workgroup owns a brick of OUTPUT voxels and a 4-channel slice; the scatter
+//                           accumulates in an fp64 LDS window (brick + 3-voxel halo) with ds_add_f64 — the sum is exact
+//                           to fp64 and independent of the order —; MFMA rows = 8 taps x 4 channels, columns = voxels.
+//                           Corners beyond the halo (|tap + offset| > ~2 voxels outside the brick) fall back to global atomics.
+//   cl_deform_gx_gather_kernel   every input voxel sums the <= few windows that cover it (plain loads, fixed order) and
+//                           adds the result to grad_input: no flush atomics.
+#include "cl_args.h"
+#include "dlka_kernels.h"
+
+namespace dlka {
+
+namespace {
+
+constexpr int HALO = 3;
+constexpr int CS = 4;     // channels per grad_input slice
+constexpr int TG = 8;     // taps per MFMA row group (TG * CS = 32 MFMA rows)
+
+struct LaneTap {
+    int zd, zh, zw;        // floor corner (may be -1)
+    float ld, lh, lw;      // fractions
+    unsigned okm;          // bit q set <=> corner q is inside the volume and the sample passes the guard
+};
+
+// Sampling rule of deform_im2col_cuda.cuh:244-259 for one (voxel, tap); identical to setup_tap<3> (deform_sample.h).
+__device__ __forceinline__ void lane_tap(LaneTap &s, const float *__restrict__ off, long N, int bd, int bh, int bw, int D, int H, int W)
+{
+    const float qd = (float)bd + off[0];
+    const float qh = (float)bh + off[N];
+    const float qw = (float)bw + off[2 * N];
+    s.okm = 0;
+    s.zd = s.zh = s.zw = 0;
+    s.ld = s.lh = s.lw = 0.f;
+    const bool inside = qd > -1.f && qh > -1.f && qw > -1.f && qd < (float)D && qh < (float)H && qw < (float)W;
+    if (inside) {  // floor in [-1, size-1]
+        const float fd_ = floorf(qd), fh_ = floorf(qh), fw_ = floorf(qw);
+        s.zd = (int)fd_; s.zh = (int)fh_; s.zw = (int)fw_;
+        s.ld = qd - fd_; s.lh = qh - fh_; s.lw = qw - fw_;
+        unsigned okm = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
+            const bool ok = (cd ? s.zd + 1 <= D - 1 : s.zd >= 0) && (ch ? s.zh + 1 <= H - 1 : s.zh >= 0) && (cw ? s.zw + 1 <= W - 1 : s.zw >= 0);
+            okm |= (ok ? 1u : 0u) << q;
+        }
+        s.okm = okm;
+    }
+}
+
+}  // namespace
+
+// =====================================================================================================================
+// grad_offset
+// =====================================================================================================================
+// grid: (ceil(M / 128), tap groups); block 256 = 4 waves x 32 voxels.  Lane (j = lane & 31, h = lane >> 5): voxel j of the
+// wave; MFMA D regs r <-> channel (r & 3) + 8 * (r >> 2) + 4 * h of the current 32-channel chunk.
+template <int NKC_REG>   // grad_out chunks (32 channels each) kept in registers across taps; 0 = reload per use
+__global__ __launch_bounds__(256) void cl_deform_goff_kernel(DeformBwdArgs p, int taps_per_block)
+{
+    __shared__ __attribute__((aligned(16))) float Bs[32 * 32];          // W[tap][co chunk][ci chunk]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int m = (blockIdx.x * 4 + wave) * 32 + j;
+    const bool row_ok = m < p.M;
+    const int b = row_ok ? m / p.N : 0;
+    const int v = row_ok ? m - b * p.N : 0;
+    const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / (p.W * p.H);
+    const int HW = p.H * p.W;
+    const int ncc = p.C / 32, nkc = p.CoutP / 32;
+    const int tap_lo = blockIdx.y * taps_per_block, tap_hi = min(p.K, tap_lo + taps_per_block);
+
+    // B operand: grad_out[m][kc*32 + 16h + s]
+    float greg[NKC_REG > 0 ? NKC_REG : 1][16];
+    if (NKC_REG > 0) {
+#pragma unroll
+        for (int kc = 0; kc < NKC_REG; ++kc) {
+            if (row_ok && kc < nkc && kc * 32 + 16 * h < p.Cout) {
+                const f32x4 *g4 = reinterpret_cast<const f32x4 *>(p.g + (long)m * p.Cout + kc * 32 + 16 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 t = g4[e];
+                    greg[kc][4 * e] = t[0]; greg[kc][4 * e + 1] = t[1]; greg[kc][4 * e + 2] = t[2]; greg[kc][4 * e + 3] = t[3];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) greg[kc][e] = 0.f;
+            }
+        }
+    }
+
+    for (int tap = tap_lo; tap < tap_hi; ++tap) {
+        const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
+        LaneTap s;
+        s.okm = 0; s.zd = s.zh = s.zw = 0; s.ld = s.lh = s.lw = 0.f;
+        if (row_ok)
+            lane_tap(s, p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v, p.N, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw,
+                     p.D, p.H, p.W);
+        float S[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) S[q] = 0.f;
+        const long cbase = ((long)b * p.N + (long)(s.zd * p.H + s.zh) * p.W + s.zw) * p.C + 4 * h;
+
+        for (int cc = 0; cc < ncc; ++cc) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 1
+            for (int kc = 0; kc < nkc; ++kc) {
+                __syncthreads();   // Bs consumed
+                {
+                    const int rr = tid >> 3, c4 = tid & 7;   // 32 rows (co) x 32 floats (ci): 256 float4
+                    reinterpret_cast<f32x4 *>(Bs)[rr * 8 + c4] =
+                        *(reinterpret_cast<const f32x4 *>(p.wp + ((long)tap * p.CoutP + kc * 32 + rr) * p.C + cc * 32) + c4);
+                }
+                float gl[16];
+                if (NKC_REG == 0) {
+                    if (row_ok && kc * 32 + 16 * h < p.Cout) {
+                        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(p.g + (long)m * p.Cout + kc * 32 + 16 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const f32x4 t = g4[e];
+                            gl[4 * e] = t[0]; gl[4 * e + 1] = t[1]; gl[4 * e + 2] = t[2]; gl[4 * e + 3] = t[3];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) gl[e] = 0.f;
+                    }
+                }
+                __syncthreads();
+                const float *arow = Bs + (16 * h) * 32 + j;   // A[i = channel j][k = co 16h + st]
+                if (NKC_REG == 1) {
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], greg[0][st], acc);
+                } else if (NKC_REG == 2) {
+                    if (kc == 0) {
+#pragma unroll
+                        for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], greg[0][st], acc);
+                    } else {
+#pragma unroll
+                        for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], greg[NKC_REG > 1 ? 1 : 0][st], acc);
+                    }
+                } else {
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], gl[st], acc);
+                }
+            }
+            // acc[r] = Col[voxel j][ci = cc*32 + (r&3) + 8*(r>>2) + 4h]
+            if (s.okm) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if ((s.okm >> q) & 1u) {
+                        const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
+                        const float *xp = p.in + cbase + (long)(cd * HW + ch * p.W + cw) * p.C + cc * 32;
+                        float sq = S[q];
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xp + 8 * g4);
+                            sq = fmaf(acc[4 * g4], x4[0], sq); sq = fmaf(acc[4 * g4 + 1], x4[1], sq);
+                            sq = fmaf(acc[4 * g4 + 2], x4[2], sq); sq = fmaf(acc[4 * g4 + 3], x4[3], sq);
+                        }
+                        S[q] = sq;
+                    }
+                }
+            }
+        }
+        // d(sample)/d(q_axis) = sum_q sign_axis(q) * (product of the other two axis weights) * x_q   (cuh:111-190)
+        const float fd[2] = {1.f - s.ld, s.ld}, fh[2] = {1.f - s.lh, s.lh}, fw[2] = {1.f - s.lw, s.lw};
+        float gd = 0.f, gh = 0.f, gw = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
+            gd = fmaf((cd ? 1.f : -1.f) * fh[ch] * fw[cw], S[q], gd);
+            gh = fmaf((ch ? 1.f : -1.f) * fd[cd] * fw[cw], S[q], gh);
+            gw = fmaf((cw ? 1.f : -1.f) * fd[cd] * fh[ch], S[q], gw);
+        }
+        gd += __shfl_xor(gd, 32);   // the two halves hold complementary channel sets of the same voxel
+        gh += __shfl_xor(gh, 32);
+        gw += __shfl_xor(gw, 32);
+        if (h == 0 && row_ok) {
+            float *dst = p.goff + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
+            dst[0] = gd; dst[p.N] = gh; dst[2 * (long)p.N] = gw;
+        }
+    }
+}
+
+// =====================================================================================================================
+// grad_input: brick scatter into an fp64 LDS window
+// =====================================================================================================================
+struct GxGeom {
+    int bd, bh, bw;         // brick of output voxels
+    int nbd, nbh, nbw;      // bricks per axis
+    int wvox_max;           // (bd + 2 HALO)(bh + 2 HALO)(bw + 2 HALO), each factor clipped to the volume
+    int nslices;            // C / CS
+    int ngroups;            // ceil(K / TG)
+};
+
+__device__ __host__ __forceinline__ void gx_window(int b0, int bsz, int size, int &lo, int &len)
+{
+    lo = b0 - HALO < 0 ? 0 : b0 - HALO;
+    int hi = b0 + bsz + HALO;
+    if (hi > size) hi = size;
+    len = hi - lo;
+}
+
+__global__ __launch_bounds__(256) void cl_deform_gx_kernel(DeformBwdArgs p, GxGeom gg, float *__restrict__ scratch)
+{
+    DLKA_DYN_SMEM(unsigned char, smem);
+    double *Win = reinterpret_cast<double *>(smem);                                        // [CS][wvox]
+    float *Bs = reinterpret_cast<float *>(smem + (size_t)gg.wvox_max * CS * sizeof(double));   // [CoutP][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    int bid = blockIdx.x;
+    const int bw_i = bid % gg.nbw; bid /= gg.nbw;
+    const int bh_i = bid % gg.nbh; bid /= gg.nbh;
+    const int bd_i = bid % gg.nbd; const int b = bid / gg.nbd;
+    const int slice = blockIdx.y;
+    const int bd0 = bd_i * gg.bd, bh0 = bh_i * gg.bh, bw0 = bw_i * gg.bw;
+    int wd0, wh0, ww0, WD, WH, WW;
+    gx_window(bd0, gg.bd, p.D, wd0, WD);
+    gx_window(bh0, gg.bh, p.H, wh0, WH);
+    gx_window(bw0, gg.bw, p.W, ww0, WW);
+    const int wvox = WD * WH * WW;
+    const int R = gg.bd * gg.bh * gg.bw, ntiles = cdiv(R, 32);
+    const int nkc = p.CoutP / 32;
+
+    for (int e = tid; e < wvox * CS; e += blockDim.x) Win[e] = 0.0;
+
+    for (int grp = 0; grp < gg.ngroups; ++grp) {
+        __syncthreads();   // Bs consumed by every wave (first pass: window zeroed)
+        // A operand tile: Bs[co][t8*4 + c4] = W[co][slice*4 + c4][tap = grp*8 + t8]   (wp[tap][co][ci], zero beyond K)
+        for (int e = tid; e < p.CoutP * TG; e += blockDim.x) {
+            const int co = e / TG, t8 = e - co * TG, tap = grp * TG + t8;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (tap < p.K) val = *reinterpret_cast<const f32x4 *>(p.wp + ((long)tap * p.CoutP + co) * p.C + slice * CS);
+            reinterpret_cast<f32x4 *>(Bs)[e] = val;
+        }
+        __syncthreads();
+        for (int tile = wave; tile < ntiles; tile += nwaves) {
+            const int row = tile * 32 + j;
+            const int rw = row % gg.bw, rh = (row / gg.bw) % gg.bh, rd = row / (gg.bw * gg.bh);
+            const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
+            const bool ok = row < R && vd < p.D && vh < p.H && vw < p.W;
+            const int v = ok ? (vd * p.H + vh) * p.W + vw : 0;
+            const long m = (long)b * p.N + v;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int kc = 0; kc < nkc; ++kc) {
+                float gl[16];
+                if (ok && kc * 32 + 16 * h < p.Cout) {
+                    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(p.g + m * p.Cout + kc * 32 + 16 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x4 t = g4[e];
+                        gl[4 * e] = t[0]; gl[4 * e + 1] = t[1]; gl[4 * e + 2] = t[2]; gl[4 * e + 3] = t[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) gl[e] = 0.f;
+                }
+                const float *arow = Bs + (kc * 32 + 16 * h) * 32 + j;   // A[i = (t8, c4) = j][k = co]
+#pragma unroll
+                for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], gl[st], acc);
+            }
+            // acc[r]: MFMA row (r&3) + 8*(r>>2) + 4h  ->  c4 = r & 3, t8 = 2*(r>>2) + h;   column = voxel j
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int tap = grp * TG + 2 * r4 + h;
+                if (!ok || tap >= p.K) continue;
+                const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
+                LaneTap s;
+                lane_tap(s, p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v, p.N, vd + ti * p.dd - p.pd, vh + tj * p.dh - p.ph, vw + tk * p.dw - p.pw,
+                         p.D, p.H, p.W);
+                if (!s.okm) continue;
+                const float fd[2] = {1.f - s.ld, s.ld}, fh[2] = {1.f - s.lh, s.lh}, fw[2] = {1.f - s.lw, s.lw};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (!((s.okm >> q) & 1u)) continue;
+                    const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
+                    const float wq = fd[cd] * fh[ch] * fw[cw];
+                    const int zd = s.zd + cd, zh = s.zh + ch, zw = s.zw + cw;       // inside the volume (okm)
+                    const int xd = zd - wd0, xh = zh - wh0, xw = zw - ww0;
+                    if ((unsigned)xd < (unsigned)WD && (unsigned)xh < (unsigned)WH && (unsigned)xw < (unsigned)WW) {
+                        double *cell = Win + (xd * WH + xh) * WW + xw;
+#pragma unroll
+                        for (int c = 0; c < CS; ++c) atomicAdd(cell + c * wvox, (double)(acc[4 * r4 + c] * wq));
+                    } else {
+                        float *dst = p.gx + ((long)b * p.N + (long)(zd * p.H + zh) * p.W + zw) * p.C + slice * CS;
+#pragma unroll
+                        for (int c = 0; c < CS; ++c) atomicAdd(dst + c, acc[4 * r4 + c] * wq);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // flush: scratch[brick][slice][cell] as float4 (the four channels of the slice)
+    f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + ((long)blockIdx.x * gg.nslices + slice) * gg.wvox_max;
+    for (int e = tid; e < wvox; e += blockDim.x) {
+        f32x4 o;
+        o[0] = (float)Win[e]; o[1] = (float)Win[wvox + e]; o[2] = (float)Win[2 * wvox + e]; o[3] = (float)Win[3 * wvox + e];
+        dst[e] = o;
+    }
+}
+
+// grad_input[b][voxel][slice*4 .. +3] += sum over the bricks whose window covers the voxel (ascending brick order).
+__global__ __launch_bounds__(256) void cl_deform_gx_gather_kernel(DeformBwdArgs p, GxGeom gg, const float *__restrict__ scratch)
+{
+    const long total = (long)p.B * p.N * gg.nslices;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int v = (int)(e % p.N);
+        const int slice = (int)((e / p.N) % gg.nslices);
+        const int b = (int)(e / p.N / gg.nslices);
+        const int w = v % p.W, hh = (v / p.W) % p.H, d = v / (p.W * p.H);
+        // brick i covers [i*bs - HALO, i*bs + bs + HALO): smallest such i satisfies i*bs > x - HALO - bs
+        const int td = d - HALO - gg.bd + 1, th = hh - HALO - gg.bh + 1, tw = w - HALO - gg.bw + 1;
+        const int id_lo = td > 0 ? cdiv(td, gg.bd) : 0, ih_lo = th > 0 ? cdiv(th, gg.bh) : 0, iw_lo = tw > 0 ? cdiv(tw, gg.bw) : 0;
+        const int id_hi = min(gg.nbd - 1, (d + HALO) / gg.bd), ih_hi = min(gg.nbh - 1, (hh + HALO) / gg.bh), iw_hi = min(gg.nbw - 1, (w + HALO) / gg.bw);
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int id = id_lo; id <= id_hi; ++id) {
+            int wd0, WD;
+            gx_window(id * gg.bd, gg.bd, p.D, wd0, WD);
+            for (int ih = ih_lo; ih <= ih_hi; ++ih) {
+                int wh0, WH;
+                gx_window(ih * gg.bh, gg.bh, p.H, wh0, WH);
+                for (int iw = iw_lo; iw <= iw_hi; ++iw) {
+                    int ww0, WW;
+                    gx_window(iw * gg.bw, gg.bw, p.W, ww0, WW);
+                    const long brick = (((long)b * gg.nbd + id) * gg.nbh + ih) * gg.nbw + iw;
+                    const int cell = ((d - wd0) * WH + (hh - wh0)) * WW + (w - ww0);
+                    const f32x4 t = reinterpret_cast<const f32x4 *>(scratch)[(brick * gg.nslices + slice) * gg.wvox_max + cell];
+                    sum[0] += t[0]; sum[1] += t[1]; sum[2] += t[2]; sum[3] += t[3];
+                }
+            }
+        }
+        f32x4 *dst = reinterpret_cast<f32x4 *>(p.gx + ((long)b * p.N + v) * p.C + slice * CS);
+        f32x4 o = *dst;
+        o[0] += sum[0]; o[1] += sum[1]; o[2] += sum[2]; o[3] += sum[3];
+        *dst = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+static GxGeom pick_gx_geom(const DeformBwdArgs &a)
+{
+    GxGeom g;
+    g.bd = a.D < 8 ? a.D : 8; g.bh = a.H < 8 ? a.H : 8; g.bw = a.W < 8 ? a.W : 8;
+    g.nslices = a.C / CS;
+    g.ngroups = cdiv(a.K, TG);
+    auto blocks = [&]() { return (long)a.B * cdiv(a.D, g.bd) * cdiv(a.H, g.bh) * cdiv(a.W, g.bw) * g.nslices; };
+    // enough workgroups to cover the 256 CUs; keep at least one 32-row tile per brick
+    while (blocks() < 256 && g.bd * g.bh * g.bw > 32) {
+        if (g.bd >= g.bh && g.bd >= g.bw && g.bd > 1) g.bd = cdiv(g.bd, 2);
+        else if (g.bh >= g.bw && g.bh > 1) g.bh = cdiv(g.bh, 2);
+        else g.bw = cdiv(g.bw, 2);
+    }
+    g.nbd = cdiv(a.D, g.bd); g.nbh = cdiv(a.H, g.bh); g.nbw = cdiv(a.W, g.bw);
+    auto ext = [](int bs, int size) { int e = bs + 2 * HALO; return e > size ? size : e; };
+    g.wvox_max = ext(g.bd, a.D) * ext(g.bh, a.H) * ext(g.bw, a.W);
+    return g;
+}
+
+size_t cl_deform_bwd2_scratch_floats(const DeformBwdArgs &a)
+{
+    if (a.C % CS) return 0;
+    const GxGeom g = pick_gx_geom(a);
+    return (size_t)a.B * g.nbd * g.nbh * g.nbw * g.nslices * g.wvox_max * CS;
+}
+
+int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st)
+{
+    if (a.C % 32 || a.CoutP % 32) return DLKA_ERR_UNSUPPORTED;
+    if (a.goff) {
+        const int mblocks = cdiv(a.M, 128);
+        int tsplit = 1;
+        while (mblocks * tsplit < 512 && tsplit < a.K) ++tsplit;
+        const int tpb = cdiv(a.K, tsplit);
+        tsplit = cdiv(a.K, tpb);
+        dim3 grid(mblocks, tsplit), block(256);
+        const int nkc = a.CoutP / 32;
+        if (nkc == 1) { auto k = cl_deform_goff_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
+        else if (nkc == 2) { auto k = cl_deform_goff_kernel<2>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
+        else { auto k = cl_deform_goff_kernel<0>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
+        DLKA_CHECK_LAUNCH();
+    }
+    if (a.gx) {
+        if (!scratch) return DLKA_ERR_WORKSPACE;
+        const GxGeom g = pick_gx_geom(a);
+        if (hipMemsetAsync(a.gx, 0, (size_t)a.B * a.N * a.C * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+        const size_t lds = (size_t)g.wvox_max * CS * sizeof(double) + (size_t)a.CoutP * 32 * sizeof(float);
+        if (lds > 160 * 1024) return DLKA_ERR_UNSUPPORTED;
+#if !defined(HIPEMU)
+        static bool attr_done = false;   // dynamic LDS above 64 KB has to be enabled once per function
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(cl_deform_gx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return DLKA_ERR_LAUNCH;
+            attr_done = true;
+        }
+#endif
+        const int bricks = a.B * g.nbd * g.nbh * g.nbw;
+        hipLaunchKernelGGL(cl_deform_gx_kernel, dim3(bricks, g.nslices), dim3(256), lds, st, a, g, scratch);
+        DLKA_CHECK_LAUNCH();
+        const long total = (long)a.B * a.N * g.nslices;
+        long gb = cdivl(total, 256);
+        if (gb > 4096) gb = 4096;
+        hipLaunchKernelGGL(cl_deform_gx_gather_kernel, dim3((unsigned)gb), dim3(256), 0, st, a, g, (const float *)scratch);
+        DLKA_CHECK_LAUNCH();
+    }
+    return DLKA_OK;
+}
+
+}  // namespace dlka

@@ -164,18 +164,45 @@ int deform_forward(const SameConv &s, const float *x, const float *off, const fl
     return launch_cl_igemm(1, 0, a, splits, st);
 }
 
+void fill_deform_bwd(DeformBwdArgs &a, const SameConv &s)
+{
+    memset(&a, 0, sizeof(a));
+    a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.C = s.Cin; a.Cout = s.Cout; a.CoutP = s.Cout;
+    a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
+}
+
+// scratch floats of the brick windows the grad_input scatter flushes (cl_deform_bwd2.hip)
+size_t deform_scratch_floats(const SameConv &s)
+{
+    DeformBwdArgs a;
+    fill_deform_bwd(a, s);
+    return cl_deform_bwd2_scratch_floats(a);
+}
+
+// variant: 0 = gather/LDS-fp64-window kernels (default), 1 = one fused kernel with global fp32 atomics,
+//          2 = LDS fp32-atomic window (kept for A/B measurements; DLKA_DEFORM_BWD selects)
+int deform_bwd_variant()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("DLKA_DEFORM_BWD");
+        v = e ? atoi(e) : 0;
+        if (v < 0 || v > 2) v = 0;
+    }
+    return v;
+}
+
 int deform_backward(const SameConv &s, const float *x, const float *off, const float *w, const float *gout, float *gx, float *goff,
-                    float *gw, float *gb, float *wp, float *part, hipStream_t st)
+                    float *gw, float *gb, float *wp, float *part, float *scratch, hipStream_t st)
 {
     if (gx || goff) {
         DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cout, s.Cin, 2, st));
         DeformBwdArgs a;
-        memset(&a, 0, sizeof(a));
+        fill_deform_bwd(a, s);
         a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff;
-        a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.C = s.Cin; a.Cout = s.Cout; a.CoutP = s.Cout;
-        a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
-        // LDS-window scatter for volumes with enough bricks to fill the chip; global-atomic variant for tiny ones
-        if (s.N >= 512 && !getenv("DLKA_DEFORM_BWD_GLOBAL")) DLKA_TRY(launch_cl_deform_bwd_lds(a, st));
+        const int variant = deform_bwd_variant();
+        if (variant == 0) DLKA_TRY(launch_cl_deform_bwd2(a, scratch, st));
+        else if (variant == 2 && s.N >= 512) DLKA_TRY(launch_cl_deform_bwd_lds(a, st));
         else DLKA_TRY(launch_cl_deform_bwd(a, st));
     }
     if (gw) {
@@ -220,6 +247,7 @@ struct TokGeoms {
         if ((size_t)343 * dw7.Cin > m) m = (size_t)343 * dw7.Cin;
         return m;
     }
+    size_t scratch_floats() const { return deform_scratch_floats(dcn); }
     size_t part_floats() const
     {
         size_t m = cl_wgrad_part_floats(pw.M, 27, 81, pw.Cin);
@@ -309,7 +337,7 @@ size_t dlka_deform_conv3d_cl_workspace(const dlka_conv_geom *c, int dtype, int b
     SameConv s;
     if (dtype != DLKA_F32 || make_same_conv(c, s)) return 0;
     size_t n = align256(dense_wp_floats(s) * 4);
-    if (backward) n += align256(cl_wgrad_part_floats(s.M, s.K, s.Cout, s.Cin) * 4);
+    if (backward) n += align256(cl_wgrad_part_floats(s.M, s.K, s.Cout, s.Cin) * 4) + align256(deform_scratch_floats(s) * 4);
     return n;
 }
 
@@ -340,9 +368,10 @@ int dlka_deform_conv3d_backward_cl(const void *x, const void *offset, const void
     Carver cv(workspace, workspace_bytes);
     float *wp = (float *)cv.take(dense_wp_floats(s) * 4);
     float *part = (float *)cv.take(cl_wgrad_part_floats(s.M, s.K, s.Cout, s.Cin) * 4);
+    float *scratch = (float *)cv.take(deform_scratch_floats(s) * 4);
     if (!cv.ok()) return DLKA_ERR_WORKSPACE;
     DLKA_TRY(deform_backward(s, (const float *)x, (const float *)offset, (const float *)weight, (const float *)grad_out, (float *)grad_x,
-                             (float *)grad_offset, (float *)grad_weight, (float *)grad_bias, wp, part, st));
+                             (float *)grad_offset, (float *)grad_weight, (float *)grad_bias, wp, part, scratch, st));
     return DLKA_OK;
 }
 
@@ -374,7 +403,8 @@ size_t dlka_lka3d_tokens_workspace_bytes(int B, int C, int D, int H, int W, int 
 {
     if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return 0;
     TokGeoms G(B, C, D, H, W);
-    return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 4 * align256(G.E * 4) + align256(G.Off * 4) + align256(4096);
+    return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 4 * align256(G.E * 4) + align256(G.Off * 4) +
+           align256(G.scratch_floats() * 4) + align256(4096);
 }
 
 int dlka_lka3d_attention_tokens_forward(const void *x_, const dlka_lka3d_params *p, void *y_, void *saved, size_t saved_bytes,
@@ -430,6 +460,7 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     float *part = (float *)cv.take(G.part_floats() * 4);
     float *bA = (float *)cv.take(G.E * 4), *bB = (float *)cv.take(G.E * 4), *bC = (float *)cv.take(G.E * 4), *bD = (float *)cv.take(G.E * 4);
     float *bO = (float *)cv.take(G.Off * 4);
+    float *scratch = (float *)cv.take(G.scratch_floats() * 4);
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const float *x = (const float *)x_, *gy = (const float *)gy_;
     float *gx = (float *)gx_;
@@ -446,7 +477,7 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     DLKA_TRY(dense_backward_data(G.pw, bD, 0, (const float *)p->conv1_w, bB, wp, 0, nullptr, st));                 // bB = gf
     DLKA_TRY(dense_backward_weight(G.pw, f, bD, 0, (float *)gr->conv1_w, (float *)gr->conv1_b, part, st));
     // deformable conv:  f = DCN(t, off)
-    DLKA_TRY(deform_backward(G.dcn, t, off, (const float *)p->deform_w, bB, bA, bO, (float *)gr->deform_w, (float *)gr->deform_b, wp, part, st));  // bA = gt_a, bO = goff
+    DLKA_TRY(deform_backward(G.dcn, t, off, (const float *)p->deform_w, bB, bA, bO, (float *)gr->deform_w, (float *)gr->deform_b, wp, part, scratch, st));  // bA = gt_a, bO = goff
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
     DLKA_TRY(dense_backward_weight(G.offc, t, bO, 1, (float *)gr->offset_w, (float *)gr->offset_b, part, st));
     DLKA_TRY(dense_backward_data(G.offc, bO, 1, (const float *)p->offset_w, bD, wp, 3, bA, st));                   // bD = gt

@@ -227,6 +227,18 @@ inline float atomicAdd(float *addr, float v) {
     memcpy(&f, &old, 4);
     return f;
 }
+inline double atomicAdd(double *addr, double v) {
+    auto *a = reinterpret_cast<std::atomic<uint64_t> *>(addr);
+    uint64_t old = a->load(std::memory_order_relaxed), nw;
+    double f;
+    do {
+        memcpy(&f, &old, 8);
+        f += v;
+        memcpy(&nw, &f, 8);
+    } while (!a->compare_exchange_weak(old, nw, std::memory_order_relaxed));
+    memcpy(&f, &old, 8);
+    return f;
+}
 inline int atomicAdd(int *addr, int v) { return reinterpret_cast<std::atomic<int> *>(addr)->fetch_add(v); }
 
 // ---- wave collectives ---------------------------------------------------------------------------
