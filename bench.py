@@ -77,7 +77,7 @@ def op_table(B, C, N, dtype_bytes):
     return t
 
 
-def time_ops(B, C, N, dtype, iters=10):
+def time_ops(B, C, N, dtype, iters=10, only=None):
     """HIP-event timing (torch.cuda.Event on the current stream == the stream the C-ABI launches on) of every
     kernel-level op of one token-layout block, through the channels-last entry points the block itself uses."""
     from ctypes import byref
@@ -132,6 +132,8 @@ def time_ops(B, C, N, dtype, iters=10):
     }
     res = {}
     for name, fn in ops.items():
+        if only is not None and name not in only:
+            continue
         rc = fn()
         if rc != 0:
             raise RuntimeError(f"{name}: dlka status {rc}")
