@@ -51,6 +51,19 @@ struct DwWgradArgs {
     int rows_per_block;
 };
 
+struct PrepJob {
+    const float *src;   // weight in the reference layout
+    float *dst;         // prepared layout
+    int Cout, Cin, K, KP, NP;
+    int mode;           // 0 fwd, 1 data-grad (flipped), 2 column matrix; 3 depthwise, 4 depthwise flipped
+    long n;             // elements of dst
+};
+struct PrepBatch {
+    PrepJob j[16];
+    int njobs;
+    long total;
+};
+
 struct DeformBwdArgs {
     const float *in;    // [B][N][C] channels-last
     const float *off;   // [B][3K][N] planar

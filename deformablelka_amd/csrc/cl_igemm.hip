@@ -14,6 +14,8 @@
 // of its row — the summation order over k is permuted, nothing else.  The 4 waves of a workgroup (128 rows) share
 // the 32 x NP weight chunk through LDS.  Small-spatial stages (C=256 at 4^3) are filled by splitting the taps over
 // blockIdx.y and accumulating with fp32 atomics.
+#include <stdlib.h>
+
 #include "deform_sample.h"
 #include "cl_args.h"
 #include "dlka_kernels.h"
@@ -226,6 +228,44 @@ int launch_cl_prep_weight(const float *w, float *wp, int Cout, int Cin, int K, i
     return DLKA_OK;
 }
 
+// All weight re-layouts of one D-LKA block in ONE launch (the per-conv prep launches were ~17 x 5 us per block).
+// job.mode 0/1/2: cl_prep_weight_kernel's modes; 3: depthwise W[c][tap] -> Wp[tap][c]; 4: the same with flipped taps.
+__global__ __launch_bounds__(256) void cl_prep_batch_kernel(PrepBatch b)
+{
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < b.total; e += (long)gridDim.x * blockDim.x) {
+        int ji = 0;
+        long lo = 0;
+        while (ji + 1 < b.njobs && e >= lo + b.j[ji].n) { lo += b.j[ji].n; ++ji; }
+        const PrepJob &j = b.j[ji];
+        const long l = e - lo;
+        float val = 0.f;
+        if (j.mode >= 3) {
+            const int c = (int)(l % j.Cin), tap = (int)(l / j.Cin);
+            val = j.src[(long)c * j.K + (j.mode == 4 ? j.K - 1 - tap : tap)];
+        } else {
+            const int n = (int)(l % j.NP), k = (int)((l / j.NP) % j.KP), tp = (int)(l / j.NP / j.KP);
+            if (j.mode == 0) {
+                if (k < j.Cin && n < j.Cout) val = j.src[((long)n * j.Cin + k) * j.K + tp];
+            } else if (j.mode == 1) {
+                if (k < j.Cout && n < j.Cin) val = j.src[((long)k * j.Cin + n) * j.K + (j.K - 1 - tp)];
+            } else {
+                if (k < j.Cout && n < j.Cin) val = j.src[((long)k * j.Cin + n) * j.K + tp];
+            }
+        }
+        j.dst[l] = val;
+    }
+}
+
+int launch_cl_prep_batch(const PrepBatch &b, hipStream_t st)
+{
+    if (b.njobs <= 0) return DLKA_OK;
+    long blocks = cdivl(b.total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cl_prep_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
 template <int AMODE, int OMODE>
 static int launch_igemm_nt(const IgemmArgs &a, int splits, hipStream_t st)
 {
@@ -260,8 +300,13 @@ int cl_igemm_pick_splits(int M, int units, int epi)
 {
     if (epi != 0 || units == 1) return 1;
     const int mblocks = cdiv(M, 128);
+    // Split partial sums meet in global fp32 atomics on the SAME addresses: measured on MI355X (profiles/r01e), 216-way
+    // splits of the C=256 / 4^3 offset conv cost 130 us, almost all of it same-address serialisation in L2.  Bound the
+    // contention instead of chasing block count.
+    static int cap = -1;
+    if (cap < 0) { const char *e = getenv("DLKA_IGEMM_MAX_SPLITS"); cap = e ? atoi(e) : 32; if (cap < 1) cap = 1; }
     int splits = 1;
-    while (mblocks * splits < 512 && splits < units) ++splits;
+    while (mblocks * splits < 512 && splits < units && splits < cap) ++splits;
     const int ups = cdiv(units, splits);
     return cdiv(units, ups);
 }

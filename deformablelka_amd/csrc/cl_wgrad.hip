@@ -182,30 +182,39 @@ __global__ __launch_bounds__(64) void cl_wgrad_kernel(WgradArgs p)
 }
 
 // gW[co][ci][tap] (reference layout, storage type T) = sum_chunk part[chunk][tap][co][ci];  gb[co] = sum_chunk bpart[chunk][co]
+// A workgroup folds 32 consecutive outputs: thread (e = tid & 31, cl = tid >> 5) sums chunks cl, cl+8, ... (coalesced
+// 128-byte reads per chunk), the 8 partial sums meet in LDS.  (The first version gave one thread all 128 chunks of an
+// output: 40 us for the 1024 outputs of a pointwise conv, pure dependent-load latency; profiles/r01e.)
 template <typename T>
-__global__ void cl_wgrad_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bpart, T *__restrict__ gw, T *__restrict__ gb,
-                                       int chunks, int K, int CoutP, int Cout, int Cin)
+__global__ __launch_bounds__(256) void cl_wgrad_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bpart, T *__restrict__ gw, T *__restrict__ gb,
+                                                              int chunks, int K, int CoutP, int Cout, int Cin)
 {
-    const long n = (long)K * Cout * Cin;
+    __shared__ float red[8][33];
+    const long n = (long)K * Cout * Cin, ntot = n + (gb ? Cout : 0);
     const long stride = (long)K * CoutP * Cin;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n + (gb ? Cout : 0); e += (long)gridDim.x * blockDim.x) {
+    const int el = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    for (long base = (long)blockIdx.x * 32; base < ntot; base += (long)gridDim.x * 32) {
+        const long e = base + el;
+        float a0 = 0.f, a1 = 0.f;
+        int ci = 0, co = 0, tap = 0;
         if (e < n) {
-            const int ci = (int)(e % Cin), co = (int)((e / Cin) % Cout), tap = (int)(e / Cin / Cout);
+            ci = (int)(e % Cin); co = (int)((e / Cin) % Cout); tap = (int)(e / Cin / Cout);
             const float *src = part + ((long)tap * CoutP + co) * Cin + ci;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            int c = 0;
-            for (; c + 4 <= chunks; c += 4) {   // independent loads in flight
-                a0 += src[(long)c * stride]; a1 += src[(long)(c + 1) * stride];
-                a2 += src[(long)(c + 2) * stride]; a3 += src[(long)(c + 3) * stride];
-            }
-            for (; c < chunks; ++c) a0 += src[(long)c * stride];
-            stf(gw + ((long)co * Cin + ci) * K + tap, (a0 + a1) + (a2 + a3));
-        } else {
-            const int co = (int)(e - n);
-            float a = 0.f;
-            for (int c = 0; c < chunks; ++c) a += bpart[(long)c * CoutP + co];
-            stf(gb + co, a);
+            int c = cl;
+            for (; c + 8 < chunks; c += 16) { a0 += src[(long)c * stride]; a1 += src[(long)(c + 8) * stride]; }
+            if (c < chunks) a0 += src[(long)c * stride];
+        } else if (e < ntot) {
+            co = (int)(e - n);
+            for (int c = cl; c < chunks; c += 8) a0 += bpart[(long)c * CoutP + co];
         }
+        red[cl][el] = a0 + a1;
+        __syncthreads();
+        if (cl == 0 && e < ntot) {
+            const float t = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+            if (e < n) stf(gw + ((long)co * Cin + ci) * K + tap, t);
+            else stf(gb + co, t);
+        }
+        __syncthreads();
     }
 }
 
@@ -246,9 +255,9 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
         else return DLKA_ERR_UNSUPPORTED;
     }
     DLKA_CHECK_LAUNCH();
-    const long n = (long)a.K * a.Cout * a.Cin;
-    long blocks = cdivl(n, 256);
-    if (blocks > 2048) blocks = 2048;
+    const long n = (long)a.K * a.Cout * a.Cin + (gb ? a.Cout : 0);
+    long blocks = cdivl(n, 32);
+    if (blocks > 4096) blocks = 4096;
     auto rk = cl_wgrad_reduce_kernel<T>;
     hipLaunchKernelGGL(rk, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)a.part, (const float *)a.bpart, gw, gb, nchunks, a.K, a.CoutP, a.Cout, a.Cin);
     DLKA_CHECK_LAUNCH();

@@ -83,7 +83,7 @@ int dense_forward(const SameConv &s, const float *x, const float *w, const float
                   int epi, const float *aux, float *out2, hipStream_t st)
 {
     const int NP = round_up(s.Cout, 32);
-    DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, NP, 0, st));
+    if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, NP, 0, st));   // w == null: wp already prepared
     IgemmArgs a;
     fill_igemm(a, s);
     a.in = x; a.wp = wp; a.bias = bias; a.out = out; a.out2 = out2; a.aux = aux; a.epi = epi;
@@ -100,7 +100,7 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
     const int KP = round_up(s.Cout, 32), NP = s.Cin;
     if (!nt_ok(NP) || s.Cin % 32) return DLKA_ERR_UNSUPPORTED;
     if (!gout_planar && s.Cout % 32) return DLKA_ERR_UNSUPPORTED;
-    DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, KP, NP, 1, st));
+    if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, KP, NP, 1, st));
     IgemmArgs a;
     fill_igemm(a, s);
     a.pd = s.dd * (s.kd - 1) - s.pd; a.ph = s.dh * (s.kh - 1) - s.ph; a.pw = s.dw * (s.kw - 1) - s.pw;
@@ -129,7 +129,7 @@ int dense_backward_weight(const SameConv &s, const float *x, const float *gout, 
 // ---- depthwise ------------------------------------------------------------------------------------------------------
 int dw_forward(const SameConv &s, const float *x, const float *w, const float *bias, float *out, float *wp, int flip, hipStream_t st)
 {
-    DLKA_TRY(launch_cl_dw_prep_weight(w, wp, s.Cin, s.K, flip, st));
+    if (w) DLKA_TRY(launch_cl_dw_prep_weight(w, wp, s.Cin, s.K, flip, st));
     DwArgs a;
     a.in = x; a.wp = wp; a.bias = bias; a.out = out;
     a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.C = s.Cin;
@@ -155,7 +155,7 @@ bool deform_supported(const SameConv &s) { return s.group == 1 && s.Cin % 32 == 
 
 int deform_forward(const SameConv &s, const float *x, const float *off, const float *w, const float *bias, float *out, float *wp, hipStream_t st)
 {
-    DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, s.Cout, 0, st));
+    if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, s.Cout, 0, st));
     IgemmArgs a;
     fill_igemm(a, s);
     a.in = x; a.off = off; a.wp = wp; a.bias = bias; a.out = out; a.epi = 0;
@@ -196,7 +196,7 @@ int deform_backward(const SameConv &s, const float *x, const float *off, const f
                     float *gw, float *gb, float *wp, float *part, float *scratch, hipStream_t st)
 {
     if (gx || goff) {
-        DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cout, s.Cin, 2, st));
+        if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cout, s.Cin, 2, st));
         DeformBwdArgs a;
         fill_deform_bwd(a, s);
         a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff;
@@ -248,6 +248,13 @@ struct TokGeoms {
         return m;
     }
     size_t scratch_floats() const { return deform_scratch_floats(dcn); }
+    // prepared weights, kept in `saved` from the forward to the backward call (floats)
+    size_t pw_floats() const { return (size_t)pw.Cin * pw.Cin; }
+    size_t offc_floats() const { return dense_wp_floats(offc); }
+    size_t dcn_floats() const { return dense_wp_floats(dcn); }
+    size_t dw5_floats() const { return (size_t)125 * dw5.Cin; }
+    size_t dw7_floats() const { return (size_t)343 * dw7.Cin; }
+    size_t prep_floats() const { return 6 * pw_floats() + 2 * offc_floats() + 2 * dcn_floats() + 2 * dw5_floats() + 2 * dw7_floats() + 16 * 64; }
     size_t part_floats() const
     {
         size_t m = cl_wgrad_part_floats(pw.M, 27, 81, pw.Cin);
@@ -255,6 +262,49 @@ struct TokGeoms {
         return m > d ? m : d;
     }
 };
+
+// carve + (forward only) fill the prepared-weight area
+struct TokPrep {
+    float *pw_f[3], *pw_b[3];   // proj_1, conv1, proj_2: forward (mode 0) / data-gradient (mode 1) layouts
+    float *off_f, *off_b, *dcn_f, *dcn_b, *dw5_f, *dw5_b, *dw7_f, *dw7_b;
+};
+
+void add_job(PrepBatch &pb, const void *src, float *dst, int Cout, int Cin, int K, int KP, int NP, int mode)
+{
+    PrepJob &j = pb.j[pb.njobs++];
+    j.src = (const float *)src; j.dst = dst; j.Cout = Cout; j.Cin = Cin; j.K = K; j.KP = KP; j.NP = NP; j.mode = mode;
+    j.n = mode >= 3 ? (long)Cin * K : (long)K * KP * NP;
+    pb.total += j.n;
+}
+
+int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_params *p, hipStream_t st, bool fill)
+{
+    float *q = base;
+    auto take = [&](size_t n) { float *r = q; q += (n + 63) & ~(size_t)63; return r; };
+    for (int k = 0; k < 3; ++k) { t.pw_f[k] = take(G.pw_floats()); t.pw_b[k] = take(G.pw_floats()); }
+    t.off_f = take(G.offc_floats()); t.off_b = take(G.offc_floats());
+    t.dcn_f = take(G.dcn_floats()); t.dcn_b = take(G.dcn_floats());
+    t.dw5_f = take(G.dw5_floats()); t.dw5_b = take(G.dw5_floats());
+    t.dw7_f = take(G.dw7_floats()); t.dw7_b = take(G.dw7_floats());
+    if (!fill) return DLKA_OK;
+    PrepBatch pb;
+    memset(&pb, 0, sizeof(pb));
+    const int C = G.pw.Cin;
+    const void *pw_w[3] = {p->proj_1_w, p->conv1_w, p->proj_2_w};
+    for (int k = 0; k < 3; ++k) {
+        add_job(pb, pw_w[k], t.pw_f[k], C, C, 1, C, C, 0);
+        add_job(pb, pw_w[k], t.pw_b[k], C, C, 1, C, C, 1);
+    }
+    add_job(pb, p->offset_w, t.off_f, 81, C, 27, C, 96, 0);
+    add_job(pb, p->offset_w, t.off_b, 81, C, 27, 96, C, 1);
+    add_job(pb, p->deform_w, t.dcn_f, C, C, 27, C, C, 0);
+    add_job(pb, p->deform_w, t.dcn_b, C, C, 27, C, C, 2);
+    add_job(pb, p->conv0_w, t.dw5_f, C, C, 125, 0, 0, 3);
+    add_job(pb, p->conv0_w, t.dw5_b, C, C, 125, 0, 0, 4);
+    add_job(pb, p->conv_spatial_w, t.dw7_f, C, C, 343, 0, 0, 3);
+    add_job(pb, p->conv_spatial_w, t.dw7_b, C, C, 343, 0, 0, 4);
+    return launch_cl_prep_batch(pb, st);
+}
 
 bool tokens_supported(int B, int C, int D, int H, int W)
 {
@@ -396,7 +446,7 @@ size_t dlka_lka3d_tokens_saved_bytes(int B, int C, int D, int H, int W, int dtyp
 {
     if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return 0;
     TokGeoms G(B, C, D, H, W);
-    return 6 * align256(G.E * 4) + align256(G.Off * 4);
+    return 6 * align256(G.E * 4) + align256(G.Off * 4) + align256(G.prep_floats() * 4);
 }
 
 size_t dlka_lka3d_tokens_workspace_bytes(int B, int C, int D, int H, int W, int dtype)
@@ -419,25 +469,28 @@ int dlka_lka3d_attention_tokens_forward(const void *x_, const dlka_lka3d_params 
     Carver sv(saved, saved_bytes), cv(workspace, workspace_bytes);
     float *h = (float *)sv.take(G.E * 4), *a = (float *)sv.take(G.E * 4), *t1 = (float *)sv.take(G.E * 4), *t = (float *)sv.take(G.E * 4);
     float *off = (float *)sv.take(G.Off * 4), *f = (float *)sv.take(G.E * 4), *g1 = (float *)sv.take(G.E * 4);
-    float *wp = (float *)cv.take(G.wp_floats() * 4);
-    (void)cv.take(G.part_floats() * 4);
+    float *prep = (float *)sv.take(G.prep_floats() * 4);
     float *m = (float *)cv.take(G.E * 4);
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const float *x = (const float *)x_;
     float *y = (float *)y_;
+    const float *N0 = nullptr;
+    // every weight re-layout of the block (forward and backward forms) in one launch; the backward call reuses them
+    TokPrep PW;
+    DLKA_TRY(carve_prep(G, prep, PW, p, st, true));
     // proj_1 + GELU (transformerblock.py:667-668): h kept for the GELU gradient, a = GELU(h)
-    DLKA_TRY(dense_forward(G.pw, x, (const float *)p->proj_1_w, (const float *)p->proj_1_b, h, 0, wp, 1, nullptr, a, st));
+    DLKA_TRY(dense_forward(G.pw, x, N0, (const float *)p->proj_1_b, h, 0, PW.pw_f[0], 1, nullptr, a, st));
     // depthwise 5^3 then 7^3 dilation 3 (:646-647)
-    DLKA_TRY(dw_forward(G.dw5, a, (const float *)p->conv0_w, (const float *)p->conv0_b, t1, wp, 0, st));
-    DLKA_TRY(dw_forward(G.dw7, t1, (const float *)p->conv_spatial_w, (const float *)p->conv_spatial_b, t, wp, 0, st));
+    DLKA_TRY(dw_forward(G.dw5, a, N0, (const float *)p->conv0_b, t1, PW.dw5_f, 0, st));
+    DLKA_TRY(dw_forward(G.dw7, t1, N0, (const float *)p->conv_spatial_b, t, PW.dw7_f, 0, st));
     // offset-predict conv C -> 81 (synapse/deform_conv.py:94); offsets stay in the reference's planar layout
-    DLKA_TRY(dense_forward(G.offc, t, (const float *)p->offset_w, (const float *)p->offset_b, off, 1, wp, 0, nullptr, nullptr, st));
+    DLKA_TRY(dense_forward(G.offc, t, N0, (const float *)p->offset_b, off, 1, PW.off_f, 0, nullptr, nullptr, st));
     // deformable 3^3 conv (deform_conv.py:95-105)
-    DLKA_TRY(deform_forward(G.dcn, t, off, (const float *)p->deform_w, (const float *)p->deform_b, f, wp, st));
+    DLKA_TRY(deform_forward(G.dcn, t, off, N0, (const float *)p->deform_b, f, PW.dcn_f, st));
     // conv1 + gate u*attn (:650-652): g1 kept, m = a * g1
-    DLKA_TRY(dense_forward(G.pw, f, (const float *)p->conv1_w, (const float *)p->conv1_b, g1, 0, wp, 2, a, m, st));
+    DLKA_TRY(dense_forward(G.pw, f, N0, (const float *)p->conv1_b, g1, 0, PW.pw_f[1], 2, a, m, st));
     // proj_2 + shortcut (:670-671)
-    DLKA_TRY(dense_forward(G.pw, m, (const float *)p->proj_2_w, (const float *)p->proj_2_b, y, 0, wp, 3, x, nullptr, st));
+    DLKA_TRY(dense_forward(G.pw, m, N0, (const float *)p->proj_2_b, y, 0, PW.pw_f[2], 3, x, nullptr, st));
     return DLKA_OK;
 }
 
@@ -456,7 +509,8 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     Carver sv((void *)saved, saved_bytes), cv(workspace, workspace_bytes);
     const float *h = (float *)sv.take(G.E * 4), *a = (float *)sv.take(G.E * 4), *t1 = (float *)sv.take(G.E * 4), *t = (float *)sv.take(G.E * 4);
     const float *off = (float *)sv.take(G.Off * 4), *f = (float *)sv.take(G.E * 4), *g1 = (float *)sv.take(G.E * 4);
-    float *wp = (float *)cv.take(G.wp_floats() * 4);
+    float *prep = (float *)sv.take(G.prep_floats() * 4);   // written by the matching forward call
+    (void)cv.take(G.wp_floats() * 4);
     float *part = (float *)cv.take(G.part_floats() * 4);
     float *bA = (float *)cv.take(G.E * 4), *bB = (float *)cv.take(G.E * 4), *bC = (float *)cv.take(G.E * 4), *bD = (float *)cv.take(G.E * 4);
     float *bO = (float *)cv.take(G.Off * 4);
@@ -466,33 +520,36 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     float *gx = (float *)gx_;
     const long E = (long)G.E;
     float *gwp = part;  // depthwise weight-gradient staging ([K][C] fp32) reuses the partial-sum area
+    const float *N0 = nullptr;
+    TokPrep PW;
+    DLKA_TRY(carve_prep(G, prep, PW, p, st, false));
 
     // proj_2:  y = P2 m + x
     DLKA_TRY(launch_mul_fwd<float>(a, g1, bA, E, st));                                                             // bA = m (recomputed)
-    DLKA_TRY(dense_backward_data(G.pw, gy, 0, (const float *)p->proj_2_w, bB, wp, 0, nullptr, st));                // bB = gm
+    DLKA_TRY(dense_backward_data(G.pw, gy, 0, N0, bB, PW.pw_b[2], 0, nullptr, st));                // bB = gm
     DLKA_TRY(dense_backward_weight(G.pw, bA, gy, 0, (float *)gr->proj_2_w, (float *)gr->proj_2_b, part, st));
     // gate:  m = a * g1
     DLKA_TRY(launch_mul_bwd<float>(a, g1, bB, bC, bD, E, st));                                                     // bC = ga1 = gm*g1, bD = gg1 = gm*a
     // conv1:  g1 = P0 f
-    DLKA_TRY(dense_backward_data(G.pw, bD, 0, (const float *)p->conv1_w, bB, wp, 0, nullptr, st));                 // bB = gf
+    DLKA_TRY(dense_backward_data(G.pw, bD, 0, N0, bB, PW.pw_b[1], 0, nullptr, st));                 // bB = gf
     DLKA_TRY(dense_backward_weight(G.pw, f, bD, 0, (float *)gr->conv1_w, (float *)gr->conv1_b, part, st));
     // deformable conv:  f = DCN(t, off)
-    DLKA_TRY(deform_backward(G.dcn, t, off, (const float *)p->deform_w, bB, bA, bO, (float *)gr->deform_w, (float *)gr->deform_b, wp, part, scratch, st));  // bA = gt_a, bO = goff
+    DLKA_TRY(deform_backward(G.dcn, t, off, N0, bB, bA, bO, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part, scratch, st));  // bA = gt_a, bO = goff
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
     DLKA_TRY(dense_backward_weight(G.offc, t, bO, 1, (float *)gr->offset_w, (float *)gr->offset_b, part, st));
-    DLKA_TRY(dense_backward_data(G.offc, bO, 1, (const float *)p->offset_w, bD, wp, 3, bA, st));                   // bD = gt
+    DLKA_TRY(dense_backward_data(G.offc, bO, 1, N0, bD, PW.off_b, 3, bA, st));                   // bD = gt
     // depthwise 7^3 dil 3:  t = DW7 t1
-    DLKA_TRY(dw_forward(G.dw7, bD, (const float *)p->conv_spatial_w, nullptr, bB, wp, 1, st));                     // bB = gt1
+    DLKA_TRY(dw_forward(G.dw7, bD, N0, nullptr, bB, PW.dw7_b, 1, st));                     // bB = gt1
     DLKA_TRY(dw_backward_weight(G.dw7, t1, bD, (float *)gr->conv_spatial_w, (float *)gr->conv_spatial_b, gwp, st));
     // depthwise 5^3:  t1 = DW5 a
-    DLKA_TRY(dw_forward(G.dw5, bB, (const float *)p->conv0_w, nullptr, bA, wp, 1, st));                            // bA = ga2
+    DLKA_TRY(dw_forward(G.dw5, bB, N0, nullptr, bA, PW.dw5_b, 1, st));                            // bA = ga2
     DLKA_TRY(dw_backward_weight(G.dw5, a, bB, (float *)gr->conv0_w, (float *)gr->conv0_b, gwp, st));
     // GELU:  a = GELU(h)
     DLKA_TRY(launch_add_fwd<float>(bC, bA, bC, E, st));                                                            // bC = ga
     DLKA_TRY(launch_gelu_bwd<float>(h, bC, bA, E, st));                                                            // bA = gh
     // proj_1:  h = P1 x ;  gx = P1^T gh + gy (shortcut)
     DLKA_TRY(dense_backward_weight(G.pw, x, bA, 0, (float *)gr->proj_1_w, (float *)gr->proj_1_b, part, st));
-    DLKA_TRY(dense_backward_data(G.pw, bA, 0, (const float *)p->proj_1_w, gx, wp, 3, gy, st));
+    DLKA_TRY(dense_backward_data(G.pw, bA, 0, N0, gx, PW.pw_b[0], 3, gy, st));
     return DLKA_OK;
 }
 

@@ -43,6 +43,7 @@ template <typename T> int launch_add_fwd(const T *a, const T *b, T *y, long n, h
 
 // ---- channels-last fast path (cl_*.hip) --------------------------------------------------------------------------
 int launch_cl_prep_weight(const float *w, float *wp, int Cout, int Cin, int K, int KP, int NP, int mode, hipStream_t st);
+int launch_cl_prep_batch(const PrepBatch &b, hipStream_t st);
 int cl_igemm_pick_splits(int M, int units, int epi);
 int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t st);
 int cl_wgrad_pick_chunks(int M);
