@@ -273,9 +273,7 @@ def main():
             graph.replay()
         else:
             compute()
-        if world > 1:
-            dist.all_reduce(stack.flat_grads)           # one flat bucket: all 15.4M block parameters
-        stack.flat_params.add_(stack.flat_grads, alpha=-lr / world)   # SGD update
+        stack.reduce_and_update(lr, world, dist)        # one flat all-reduce (15.4M block parameters) + SGD update
 
     for _ in range(args.warmup):
         step()

@@ -104,6 +104,8 @@ class DLKABlockStack:
         ob.zero_()
 
     def _stream(self):
+        if self.device.type != "cuda":   # only reachable through the CPU test backend (tests/emu)
+            return None
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def forward(self):
@@ -127,6 +129,14 @@ class DLKABlockStack:
     def forward_backward(self):
         self.forward()
         self.backward()
+
+    def reduce_and_update(self, lr: float, world: int = 1, dist=None):
+        """Data-parallel tail of a step: ONE all-reduce of the flat gradient buffer (RCCL over xGMI when the process
+        group is ``nccl``; the batch shards across ranks with no other collective), then plain SGD on the
+        flat parameter buffer with the gradient averaged over ranks."""
+        if world > 1:
+            dist.all_reduce(self.flat_grads)
+        self.flat_params.add_(self.flat_grads, alpha=-lr / world)
 
     def num_params(self) -> int:
         return int(self.flat_params.numel())

@@ -1,0 +1,77 @@
+"""N>1 logic of the data-parallel path on CPU: two `gloo` ranks, each with its own batch shard, run the block stack
+through the emulator build of the real kernels, all-reduce the flat gradient buffer and take the SGD step
+(`DLKABlockStack.reduce_and_update`, the code bench.py runs over RCCL).  The result must equal one process that sees
+both shards."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+STAGES = ((32, (2, 2, 3), 2),)   # two chained C=32 blocks on a 2x2x3 volume (the emulator runs every lane as a fiber)
+LR = 0.1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_stack(data_seed):
+    from deformablelka_amd import _lib
+    from deformablelka_amd.stack import DLKABlockStack
+    from tests import emu
+    _lib._set_backend_for_tests(emu.load())
+    st = DLKABlockStack(1, stages=STAGES, device="cpu", seed=7)            # same parameters on every rank
+    g = torch.Generator().manual_seed(1000 + data_seed)                    # rank-specific inputs / grad_outputs
+    for chain in st.chains:
+        chain[0].x.copy_(torch.randn(chain[0].x.shape, generator=g))
+        chain[-1].gy.copy_(torch.randn(chain[-1].gy.shape, generator=g))
+    return st
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIPEMU_THREADS="2")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    st = _make_stack(rank)
+    st.forward_backward()
+    st.reduce_and_update(LR, world, dist)
+    if rank == 0:
+        torch.save({"params": st.flat_params.clone(), "grads": st.flat_grads.clone()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_data_parallel_step_matches_single_process(tmp_path):
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    # single process: both shards, gradients summed by hand
+    gsum, p0 = None, None
+    for r in range(2):
+        st = _make_stack(r)
+        p0 = st.flat_params.clone()
+        st.forward_backward()
+        gsum = st.flat_grads.clone() if gsum is None else gsum + st.flat_grads
+    from deformablelka_amd import _lib
+    _lib._set_backend_for_tests(None)
+    assert gsum.abs().max() > 0
+    assert torch.allclose(got["grads"], gsum, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(got["params"], p0 - LR / 2 * gsum, rtol=1e-5, atol=1e-6)
+
+
+def test_single_rank_update_needs_no_process_group():
+    st = _make_stack(0)
+    p0 = st.flat_params.clone()
+    st.forward_backward()
+    st.reduce_and_update(LR, 1, None)
+    from deformablelka_amd import _lib
+    _lib._set_backend_for_tests(None)
+    assert torch.allclose(st.flat_params, p0 - LR * st.flat_grads)
