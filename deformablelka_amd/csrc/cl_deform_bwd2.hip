@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void cl_deform_goff_kernel(DeformBwdArgs p, in
     const int HW = p.H * p.W;
     const int ncc = p.C / 32, nkc = p.CoutP / 32;
     const int tap_lo = blockIdx.y * taps_per_block, tap_hi = min(p.K, tap_lo + taps_per_block);
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.C * 4);
 
     // B operand: grad_out[m][kc*32 + 16h + s]
     float greg[NKC_REG > 0 ? NKC_REG : 1][16];
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void cl_deform_goff_kernel(DeformBwdArgs p, in
         float S[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) S[q] = 0.f;
-        const long cbase = ((long)b * p.N + (long)(s.zd * p.H + s.zh) * p.W + s.zw) * p.C + 4 * h;
+        const unsigned cbase = (unsigned)(((b * p.N + (s.zd * p.H + s.zh) * p.W + s.zw) * p.C + 4 * h) * 4);   // bytes; only used where okm is set
 
         for (int cc = 0; cc < ncc; ++cc) {
             f32x16 acc;
@@ -157,23 +158,19 @@ __global__ __launch_bounds__(256) void cl_deform_goff_kernel(DeformBwdArgs p, in
                     for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], gl[st], acc);
                 }
             }
-            // acc[r] = Col[voxel j][ci = cc*32 + (r&3) + 8*(r>>2) + 4h]
-            if (s.okm) {
+            // acc[r] = Col[voxel j][ci = cc*32 + (r&3) + 8*(r>>2) + 4h];  unconditional buffer loads, dropped corners -> 0
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    if ((s.okm >> q) & 1u) {
-                        const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
-                        const float *xp = p.in + cbase + (long)(cd * HW + ch * p.W + cw) * p.C + cc * 32;
-                        float sq = S[q];
+            for (int q = 0; q < 8; ++q) {
+                const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
+                const unsigned off = ((s.okm >> q) & 1u) ? cbase + (unsigned)((cd * HW + ch * p.W + cw) * p.C + cc * 32) * 4u : DLKA_OOB;
+                float sq = S[q];
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xp + 8 * g4);
-                            sq = fmaf(acc[4 * g4], x4[0], sq); sq = fmaf(acc[4 * g4 + 1], x4[1], sq);
-                            sq = fmaf(acc[4 * g4 + 2], x4[2], sq); sq = fmaf(acc[4 * g4 + 3], x4[3], sq);
-                        }
-                        S[q] = sq;
-                    }
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 x4 = buf_load_f32x4(rin, off + 32u * g4);
+                    sq = fmaf(acc[4 * g4], x4[0], sq); sq = fmaf(acc[4 * g4 + 1], x4[1], sq);
+                    sq = fmaf(acc[4 * g4 + 2], x4[2], sq); sq = fmaf(acc[4 * g4 + 3], x4[3], sq);
                 }
+                S[q] = sq;
             }
         }
         // d(sample)/d(q_axis) = sum_q sign_axis(q) * (product of the other two axis weights) * x_q   (cuh:111-190)
@@ -383,6 +380,7 @@ size_t cl_deform_bwd2_scratch_floats(const DeformBwdArgs &a)
 int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st)
 {
     if (a.C % 32 || a.CoutP % 32) return DLKA_ERR_UNSUPPORTED;
+    if ((long)a.M * a.C * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     if (a.goff) {
         const int mblocks = cdiv(a.M, 128);
         int tsplit = 1;

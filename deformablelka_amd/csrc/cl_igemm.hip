@@ -25,27 +25,29 @@ namespace dlka {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
 // Fetches this lane's 16 A values (channels ck*32 + 16*h + [0,16) of row m) for one (tap, chunk) unit.
+// Every load is an unconditional buffer load: zero padding, rows beyond M and corners outside the volume read offset
+// DLKA_OOB and come back as 0, so there is no branch around a load and the loads of unit u+1 stay in flight under
+// the MFMAs of unit u.
 template <int AMODE>
 struct ARow {
     int cur_tap;
-    const float *rowp;   // AMODE 0: neighbour row; AMODE 2: neighbour voxel in plane 0
-    TapSample<3> s;      // AMODE 1
-    __device__ __forceinline__ ARow() : cur_tap(-1), rowp(nullptr) {}
+    unsigned rowoff;     // AMODE 0: byte offset of the neighbour row; AMODE 2: of the neighbour voxel in plane 0; DLKA_OOB if padded
+    unsigned coff[8];    // AMODE 1: byte offsets of the 8 corner rows (DLKA_OOB for dropped corners)
+    float cw[8];         // AMODE 1: corner weights
+    __device__ __forceinline__ ARow() : cur_tap(-1), rowoff(DLKA_OOB) {}
 
-    __device__ __forceinline__ void fetch(const IgemmArgs &p, int tap, int ck, int h, bool row_ok, int b, int v, int d0, int h0, int w0, float *a)
+    __device__ __forceinline__ void fetch(const IgemmArgs &p, const BufRsrc &rin, int tap, int ck, int h, bool row_ok, int b, int v, int d0, int h0, int w0, float *a)
     {
         if (tap != cur_tap) {   // wave-uniform
             cur_tap = tap;
             const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
             if (AMODE == 0 || AMODE == 2) {
                 const int zd = d0 + ti * p.dd - p.pd, zh = h0 + tj * p.dh - p.ph, zw = w0 + tk * p.dw - p.pw;
-                const bool ok = row_ok && zd >= 0 && zd < p.D && zh >= 0 && zh < p.H && zw >= 0 && zw < p.W;
-                rowp = nullptr;
-                if (ok) {
-                    const long lin = (long)(zd * p.H + zh) * p.W + zw;
-                    rowp = (AMODE == 0) ? p.in + ((long)b * p.N + lin) * p.Cin : p.in + (long)b * p.CinReal * p.N + lin;
-                }
+                const bool ok = row_ok & ((unsigned)zd < (unsigned)p.D) & ((unsigned)zh < (unsigned)p.H) & ((unsigned)zw < (unsigned)p.W);
+                const int lin = (zd * p.H + zh) * p.W + zw;
+                rowoff = !ok ? DLKA_OOB : (AMODE == 0 ? (unsigned)((b * p.N + lin) * p.Cin) * 4u : (unsigned)(b * p.CinReal * p.N + lin) * 4u);
             } else {
+                TapSample<3> s;
                 if (row_ok) {
                     const float *offp = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
                     setup_tap<3>(s, offp, p.N, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw, p.D, p.H, p.W);
@@ -54,39 +56,35 @@ struct ARow {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) { s.idx[q] = 0; s.w[q] = 0.f; }
                 }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    coff[q] = ((s.ok >> q) & 1u) ? (unsigned)((b * p.N + s.idx[q]) * p.Cin) * 4u : DLKA_OOB;
+                    cw[q] = s.w[q];
+                }
             }
         }
         const int c0 = ck * 32 + 16 * h;
         if (AMODE == 0) {
-            if (rowp) {
-                const float4 *r4 = reinterpret_cast<const float4 *>(rowp + c0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float4 t = r4[e];
-                    a[4 * e] = t.x; a[4 * e + 1] = t.y; a[4 * e + 2] = t.z; a[4 * e + 3] = t.w;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) a[e] = 0.f;
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 t = buf_load_f32x4(rin, rowoff + (unsigned)(c0 + 4 * e) * 4u);
+                a[4 * e] = t[0]; a[4 * e + 1] = t[1]; a[4 * e + 2] = t[2]; a[4 * e + 3] = t[3];
             }
         } else if (AMODE == 2) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) a[e] = (rowp && c0 + e < p.CinReal) ? rowp[(long)(c0 + e) * p.N] : 0.f;
+            for (int e = 0; e < 16; ++e)
+                a[e] = buf_load_f32(rin, (c0 + e < p.CinReal) ? rowoff + (unsigned)((c0 + e) * p.N) * 4u : DLKA_OOB);
         } else {
 #pragma unroll
             for (int e = 0; e < 16; ++e) a[e] = 0.f;
-            const float *base = p.in + (long)b * p.N * p.Cin + c0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if ((s.ok >> q) & 1u) {   // corners outside the volume / samples outside the guard contribute 0
-                    const float4 *r4 = reinterpret_cast<const float4 *>(base + (long)s.idx[q] * p.Cin);
-                    const float wq = s.w[q];
+            for (int q = 0; q < 8; ++q) {   // dropped corners (outside the volume / the guard) read 0 with weight 0
+                const float wq = cw[q];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float4 t = r4[e];
-                        a[4 * e] = fmaf(wq, t.x, a[4 * e]); a[4 * e + 1] = fmaf(wq, t.y, a[4 * e + 1]);
-                        a[4 * e + 2] = fmaf(wq, t.z, a[4 * e + 2]); a[4 * e + 3] = fmaf(wq, t.w, a[4 * e + 3]);
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 t = buf_load_f32x4(rin, coff[q] + (unsigned)(c0 + 4 * e) * 4u);
+                    a[4 * e] = fmaf(wq, t[0], a[4 * e]); a[4 * e + 1] = fmaf(wq, t[1], a[4 * e + 1]);
+                    a[4 * e + 2] = fmaf(wq, t[2], a[4 * e + 2]); a[4 * e + 3] = fmaf(wq, t[3], a[4 * e + 3]);
                 }
             }
         }
@@ -119,6 +117,7 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
     const int unit_hi = min(p.K * nchunk, unit_lo + p.units_per_split);
 
     // software pipeline: while the MFMAs of unit u run, the weight chunk and the A values of unit u+1 are in flight
+    const BufRsrc rin = make_rsrc(p.in, AMODE == 2 ? (size_t)p.B * p.CinReal * p.N * 4 : (size_t)p.M * p.Cin * 4);
     ARow<AMODE> arow;
     f32x4 breg[BV];   // ext_vector_type: stays in registers across iterations (HIP's float4 struct did not)
     float a_cur[16], a_nxt[16];
@@ -135,7 +134,7 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
     if (unit_lo < unit_hi) {
         DLKA_LOAD_B(unit_lo)
         const int tap = unit_lo / nchunk;
-        arow.fetch(p, tap, unit_lo - tap * nchunk, h, row_ok, b, v, d0, h0, w0, a_nxt);
+        arow.fetch(p, rin, tap, unit_lo - tap * nchunk, h, row_ok, b, v, d0, h0, w0, a_nxt);
     }
     int buf = 0;
     for (int unit = unit_lo; unit < unit_hi; ++unit, buf ^= 1) {
@@ -147,7 +146,7 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
         if (unit + 1 < unit_hi) {
             DLKA_LOAD_B(unit + 1)
             const int tap = (unit + 1) / nchunk;
-            arow.fetch(p, tap, unit + 1 - tap * nchunk, h, row_ok, b, v, d0, h0, w0, a_nxt);
+            arow.fetch(p, rin, tap, unit + 1 - tap * nchunk, h, row_ok, b, v, d0, h0, w0, a_nxt);
         }
         const float *brow = Bs[buf] + (16 * h) * NPB + i;
 #pragma unroll
@@ -313,6 +312,7 @@ int cl_igemm_pick_splits(int M, int units, int epi)
 
 int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t st)
 {
+    if ((long)a.M * (amode == 2 ? a.CinReal : a.Cin) * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     a.units_per_split = cdiv(a.K * (a.CinP / 32), splits);
     splits = cdiv(a.K * (a.CinP / 32), a.units_per_split);
     if (splits > 1) {

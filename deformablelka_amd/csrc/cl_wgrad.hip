@@ -10,6 +10,8 @@
 // One wave (64-thread workgroup) owns one 32(co) x 32(ci) output tile for TPW taps and walks a chunk of rows, 32 at a
 // time: MFMA A operand = G^T (lane i = co), B operand = A(m,tap,ci) (lane j = ci), k = 32 rows per step pair.
 // Partial sums per row-chunk go to a workspace and are folded by cl_wgrad_reduce_kernel (no same-address atomics).
+#include <stdlib.h>
+
 #include "deform_sample.h"
 #include "cl_args.h"
 #include "dlka_kernels.h"
@@ -28,6 +30,7 @@ __global__ __launch_bounds__(64) void cl_wgrad_kernel(WgradArgs p)
     const int co = ot * 32 + i;      // A-operand row (as lane i)
     const int ci = ct * 32 + i;      // B-operand column (as lane j = i)
     const bool want_bias = p.bpart && ct == 0 && blockIdx.z == 0;
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * 4);
 
     f32x16 acc[TPW];
 #pragma unroll
@@ -93,28 +96,32 @@ __global__ __launch_bounds__(64) void cl_wgrad_kernel(WgradArgs p)
             const bool row_ok = m < m_hi;
             const int b = row_ok ? m / p.N : 0, v = row_ok ? m - b * p.N : 0;
             const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / (p.W * p.H);
-            const float *base = p.in + (long)b * p.N * p.Cin + ct * 32 + 16 * h;
+            const unsigned cbyte = (unsigned)(ct * 32 + 16 * h) * 4u;
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const int tap = tap0 + t;
                 float a[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) a[e] = 0.f;
-                if (tap < p.K && row_ok) {
+                if (tap < p.K) {   // uniform
                     TapSample<3> s;
-                    const float *offp = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
-                    setup_tap<3>(s, offp, p.N, d0 + od[t], h0 + oh[t], w0 + ow[t], p.D, p.H, p.W);
+                    if (row_ok) {
+                        const float *offp = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
+                        setup_tap<3>(s, offp, p.N, d0 + od[t], h0 + oh[t], w0 + ow[t], p.D, p.H, p.W);
+                    } else {
+                        s.ok = 0;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        if ((s.ok >> q) & 1u) {
-                            const f32x4 *r4 = reinterpret_cast<const f32x4 *>(base + (long)s.idx[q] * p.Cin);
-                            const float wq = s.w[q];
+                        for (int q = 0; q < 8; ++q) { s.idx[q] = 0; s.w[q] = 0.f; }
+                    }
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const f32x4 x4 = r4[e];
-                                a[4 * e] = fmaf(wq, x4[0], a[4 * e]); a[4 * e + 1] = fmaf(wq, x4[1], a[4 * e + 1]);
-                                a[4 * e + 2] = fmaf(wq, x4[2], a[4 * e + 2]); a[4 * e + 3] = fmaf(wq, x4[3], a[4 * e + 3]);
-                            }
+                    for (int q = 0; q < 8; ++q) {   // unconditional buffer loads: dropped corners read DLKA_OOB -> 0
+                        const unsigned off = ((s.ok >> q) & 1u) ? (unsigned)((b * p.N + s.idx[q]) * p.Cin) * 4u + cbyte : DLKA_OOB;
+                        const float wq = s.w[q];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const f32x4 x4 = buf_load_f32x4(rin, off + 16u * e);
+                            a[4 * e] = fmaf(wq, x4[0], a[4 * e]); a[4 * e + 1] = fmaf(wq, x4[1], a[4 * e + 1]);
+                            a[4 * e + 2] = fmaf(wq, x4[2], a[4 * e + 2]); a[4 * e + 3] = fmaf(wq, x4[3], a[4 * e + 3]);
                         }
                     }
                 }
@@ -181,6 +188,174 @@ __global__ __launch_bounds__(64) void cl_wgrad_kernel(WgradArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Dense (plain-neighbour) weight gradient, second generation.  One wave owns COT co-tiles x TPW taps x one 32-channel
+// ci-tile: the B operand (input rows of a tap) is loaded once and feeds COT MFMA chains, the A operand (grad_out rows of
+// a co-tile) once and feeds TPW chains -> (COT + TPW) * 16 loads per COT * TPW * 16 MFMAs per 32-row step (3x3: 96 / 144
+// instead of the first version's 80 / 64).  The next step's operands are in flight while the current step's MFMAs issue.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int GMODE, int COT, int TPW, bool N16>   // N16: N % 16 == 0 (the 16 rows of a half-wave never straddle two volumes)
+__global__ __launch_bounds__(64) void cl_wgrad_dense_kernel(WgradArgs p)
+{
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int chunk = blockIdx.x;
+    const int OTG = cdiv(p.CoutP / 32, COT);                  // co-tile groups
+    const int otg = blockIdx.y / p.CT, ct = blockIdx.y % p.CT;
+    const int tap0 = blockIdx.z * TPW;
+    const int ci = ct * 32 + i;
+    const bool want_bias = p.bpart && ct == 0 && blockIdx.z == 0;
+    (void)OTG;
+
+    f32x16 acc[COT][TPW];
+#pragma unroll
+    for (int c = 0; c < COT; ++c)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+    float bsum[COT];
+#pragma unroll
+    for (int c = 0; c < COT; ++c) bsum[c] = 0.f;
+
+    int od[TPW], oh[TPW], ow[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tap = tap0 + t;
+        od[t] = (tap / (p.kw * p.kh)) * p.dd - p.pd;
+        oh[t] = ((tap / p.kw) % p.kh) * p.dh - p.ph;
+        ow[t] = (tap % p.kw) * p.dw - p.pw;
+    }
+    const int m_lo = chunk * p.rows_per_chunk;
+    const int m_hi = min(p.M, m_lo + p.rows_per_chunk);
+
+    float ga_n[COT][16], bv_n[TPW][16];
+    const BufRsrc rg = make_rsrc(p.g, (size_t)p.M * p.Cout * 4), rx = make_rsrc(p.in, (size_t)p.M * p.Cin * 4);
+    // operands of the 32-row step starting at mbase: rows m = mbase + 16h + s.  Every load is an unconditional buffer
+    // load; rows beyond the chunk, channels beyond Cout and zero-padded neighbours read offset DLKA_OOB -> 0.
+    auto load_step = [&](int mbase) {
+        const int mrow0 = mbase + 16 * h;
+        const int b0 = mrow0 / p.N, v0 = mrow0 - b0 * p.N;
+#pragma unroll
+        for (int c = 0; c < COT; ++c) {
+            const int co = (otg * COT + c) * 32 + i;
+            if (GMODE == 0) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int m = mrow0 + s;
+                    ga_n[c][s] = buf_load_f32(rg, (m < m_hi && co < p.Cout) ? (unsigned)(m * p.Cout + co) * 4u : DLKA_OOB);
+                }
+            } else if (N16) {   // 16 consecutive voxels of one plane, 64-byte aligned: four 16-byte loads
+                const unsigned off = (mrow0 < m_hi && co < p.Cout) ? (unsigned)((b0 * p.Cout + co) * p.N + v0) * 4u : DLKA_OOB;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 t4 = buf_load_f32x4(rg, off + 16u * e);
+                    ga_n[c][4 * e] = t4[0]; ga_n[c][4 * e + 1] = t4[1]; ga_n[c][4 * e + 2] = t4[2]; ga_n[c][4 * e + 3] = t4[3];
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int m = mrow0 + s;
+                    const int b = m / p.N, v = m - b * p.N;
+                    ga_n[c][s] = buf_load_f32(rg, (m < m_hi && co < p.Cout) ? (unsigned)((b * p.Cout + co) * p.N + v) * 4u : DLKA_OOB);
+                }
+            }
+        }
+        if (p.K == 1) {   // pointwise: the B rows are the A rows
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int m = mrow0 + s;
+                bv_n[0][s] = buf_load_f32(rx, (m < m_hi) ? (unsigned)(m * p.Cin + ci) * 4u : DLKA_OOB);
+            }
+        } else {
+            int crd[16];
+            unsigned rowoff[16];
+            if (N16) {
+                // 16 consecutive voxels of one volume: decode the first (three runtime divisions, ~60 VALU instructions),
+                // walk the rest with carries — the per-row div/mod chain was most of this kernel's VALU time
+                int w_ = v0 % p.W, hh = (v0 / p.W) % p.H, d_ = v0 / (p.W * p.H);
+                const unsigned base = (unsigned)((b0 * p.N + v0) * p.Cin + ci) * 4u;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    crd[s] = (mrow0 + s < m_hi) ? ((d_ << 20) | (hh << 10) | w_) : -1;
+                    rowoff[s] = base + (unsigned)(s * p.Cin) * 4u;
+                    ++w_;
+                    if (w_ == p.W) { w_ = 0; ++hh; if (hh == p.H) { hh = 0; ++d_; } }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    int v = v0 + s, b = b0;
+                    if (v >= p.N) { v -= p.N; b += 1; }
+                    if (v >= p.N) { b = (mrow0 + s) / p.N; v = (mrow0 + s) - b * p.N; }
+                    const int w_ = v % p.W, hh = (v / p.W) % p.H, d_ = v / (p.W * p.H);
+                    crd[s] = (mrow0 + s < m_hi) ? ((d_ << 20) | (hh << 10) | w_) : -1;
+                    rowoff[s] = (unsigned)((b * p.N + v) * p.Cin + ci) * 4u;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const bool tap_ok = tap0 + t < p.K;  // uniform
+                const int doff = ((od[t] * p.H + oh[t]) * p.W + ow[t]) * p.Cin * 4;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int c_ = crd[s];
+                    const int zd = (c_ >> 20) + od[t], zh = ((c_ >> 10) & 1023) + oh[t], zw = (c_ & 1023) + ow[t];
+                    // bitwise, not short-circuit: the compiler turns && chains into a branch per element
+                    const bool ok = tap_ok & (c_ >= 0) & ((unsigned)zd < (unsigned)p.D) & ((unsigned)zh < (unsigned)p.H) & ((unsigned)zw < (unsigned)p.W);
+                    bv_n[t][s] = buf_load_f32(rx, ok ? rowoff[s] + (unsigned)doff : DLKA_OOB);
+                }
+            }
+        }
+    };
+
+    if (m_lo < m_hi) load_step(m_lo);
+    for (int mbase = m_lo; mbase < m_hi; mbase += 32) {
+        float ga[COT][16], bv[TPW][16];
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) ga[c][s] = ga_n[c][s];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) bv[t][s] = bv_n[t][s];
+        if (mbase + 32 < m_hi) load_step(mbase + 32);   // in flight under the MFMAs below
+        if (want_bias) {
+#pragma unroll
+            for (int c = 0; c < COT; ++c)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) bsum[c] += ga[c][s];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int c = 0; c < COT; ++c)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) acc[c][t] = mfma_32x32x2(ga[c][s], bv[t][s], acc[c][t]);
+    }
+    // ---- partial tiles out: D row = co_local, col = ci_local ----
+#pragma unroll
+    for (int c = 0; c < COT; ++c) {
+        const int ot = otg * COT + c;
+        if (ot * 32 >= p.CoutP) continue;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int tap = tap0 + t;
+            if (tap >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                p.part[(((long)chunk * p.K + tap) * p.CoutP + ot * 32 + row) * p.Cin + ci] = acc[c][t][r];
+            }
+        }
+        if (want_bias) {
+            float bs = bsum[c];
+            bs += __shfl_xor(bs, 32);   // the two halves hold the same co for different rows
+            if (h == 0) p.bpart[(long)chunk * p.CoutP + ot * 32 + i] = bs;
+        }
+    }
+}
+
 // gW[co][ci][tap] (reference layout, storage type T) = sum_chunk part[chunk][tap][co][ci];  gb[co] = sum_chunk bpart[chunk][co]
 // A workgroup folds 32 consecutive outputs: thread (e = tid & 31, cl = tid >> 5) sums chunks cl, cl+8, ... (coalesced
 // 128-byte reads per chunk), the 8 partial sums meet in LDS.  (The first version gave one thread all 128 chunks of an
@@ -218,41 +393,76 @@ __global__ __launch_bounds__(256) void cl_wgrad_reduce_kernel(const float *__res
     }
 }
 
-int cl_wgrad_pick_chunks(int M)
+// Work decomposition.  Waves = chunks x (co-tile groups x ci-tiles) x tap groups; aim at ~2 waves per SIMD over the chip
+// so that small outputs (a 32x32 pointwise gradient is ONE tile) still get their parallelism from the row dimension.
+struct WgradPlan { int chunks, tpw, cot; };
+
+static WgradPlan wgrad_plan(int M, int K, int Cout, int Cin, int amode)
 {
+    WgradPlan pl;
+    const int OT = round_up(Cout, 32) / 32, CT = Cin / 32;
+    if (amode == 1) { pl.tpw = 7; pl.cot = 1; }
+    else if (K == 1) { pl.tpw = 1; pl.cot = (OT % 2 == 0) ? 2 : 1; }
+    else {
+        static int tpw_env = -1;
+        if (tpw_env < 0) { const char *e = getenv("DLKA_WGRAD_TPW"); tpw_env = e ? atoi(e) : 3; if (tpw_env < 1 || tpw_env > 3) tpw_env = 3; }
+        pl.tpw = tpw_env; pl.cot = (OT % 3 == 0) ? 3 : ((OT % 2 == 0) ? 2 : 1);
+    }
+    const int groups = cdiv(OT, pl.cot) * CT * cdiv(K, pl.tpw);
     const int tiles = cdiv(M, 32);
-    int chunks = tiles < 128 ? tiles : 128;
-    return chunks < 1 ? 1 : chunks;
+    // register-heavy variants run one wave per SIMD (1024 slots): fill them once rather than 2.004 times
+    const int slots = (amode == 0 && K > 1 && pl.cot * pl.tpw >= 6) ? 1024 : 2048;   // <=2 waves/SIMD for the rest
+    int chunks = slots / groups;
+    if (chunks > tiles) chunks = tiles;
+    if (chunks > 1024) chunks = 1024;
+    if (chunks < 1) chunks = 1;
+    pl.chunks = chunks;
+    return pl;
 }
+
+int cl_wgrad_pick_chunks(int M, int K, int Cout, int Cin, int amode) { return wgrad_plan(M, K, Cout, Cin, amode).chunks; }
 
 size_t cl_wgrad_part_floats(int M, int K, int Cout, int Cin)
 {
-    return (size_t)cl_wgrad_pick_chunks(M) * ((size_t)K * round_up(Cout, 32) * Cin + round_up(Cout, 32));
+    const int c0 = wgrad_plan(M, K, Cout, Cin, 0).chunks, c1 = wgrad_plan(M, K, Cout, Cin, 1).chunks;
+    return (size_t)(c0 > c1 ? c0 : c1) * ((size_t)K * round_up(Cout, 32) * Cin + round_up(Cout, 32));
 }
 
 template <typename T>
 int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t st)
 {
-    const int chunks = cl_wgrad_pick_chunks(a.M);
+    const WgradPlan pl = wgrad_plan(a.M, a.K, a.Cout, a.Cin, amode);
     const int tiles = cdiv(a.M, 32);
-    a.rows_per_chunk = cdiv(tiles, chunks) * 32;
+    a.rows_per_chunk = cdiv(tiles, pl.chunks) * 32;
     const int nchunks = cdiv(a.M, a.rows_per_chunk);
     a.CoutP = round_up(a.Cout, 32);
     a.CT = a.Cin / 32;
     const int OT = a.CoutP / 32;
-    if ((long)a.B * a.N * a.Cin >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;
+    if ((long)a.M * a.Cin * 4 >= (1l << 31) || (long)a.M * a.Cout * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     a.bpart = gb ? a.part + (size_t)nchunks * a.K * a.CoutP * a.Cin : nullptr;
-    if (a.K == 1) {
-        dim3 grid(nchunks, OT * a.CT, 1), block(64);
-        if (amode == 0 && gmode == 0) { auto k = cl_wgrad_kernel<0, 0, 1>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-        else return DLKA_ERR_UNSUPPORTED;
+    dim3 block(64);
+    if (amode == 1) {
+        if (gmode != 0 || a.K == 1) return DLKA_ERR_UNSUPPORTED;
+        dim3 grid(nchunks, OT * a.CT, cdiv(a.K, 7));
+        auto k = cl_wgrad_kernel<1, 0, 7>;
+        hipLaunchKernelGGL(k, grid, block, 0, st, a);
     } else {
-        constexpr int TPW = 7, TPW0 = 4;   // plain-neighbour variant: fewer taps per wave -> 2 waves/SIMD
-        dim3 grid(nchunks, OT * a.CT, cdiv(a.K, TPW)), grid0(nchunks, OT * a.CT, cdiv(a.K, TPW0)), block(64);
-        if (amode == 0 && gmode == 1) { auto k = cl_wgrad_kernel<0, 1, TPW0>; hipLaunchKernelGGL(k, grid0, block, 0, st, a); }
-        else if (amode == 0 && gmode == 0) { auto k = cl_wgrad_kernel<0, 0, TPW0>; hipLaunchKernelGGL(k, grid0, block, 0, st, a); }
-        else if (amode == 1 && gmode == 0) { auto k = cl_wgrad_kernel<1, 0, TPW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-        else return DLKA_ERR_UNSUPPORTED;
+        dim3 grid(nchunks, cdiv(OT, pl.cot) * a.CT, cdiv(a.K, pl.tpw));
+#define DLKA_WG(GM, CO, TP)                                                                                      \
+    {                                                                                                            \
+        if ((a.N & 15) == 0) { auto k = cl_wgrad_dense_kernel<GM, CO, TP, true>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }  \
+        else { auto k = cl_wgrad_dense_kernel<GM, CO, TP, false>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }              \
+    }
+        if (a.K == 1) {
+            if (gmode != 0) return DLKA_ERR_UNSUPPORTED;
+            if (pl.cot == 2) DLKA_WG(0, 2, 1) else DLKA_WG(0, 1, 1)
+        } else if (gmode == 1) {
+            if (pl.cot == 3 && pl.tpw == 1) DLKA_WG(1, 3, 1) else if (pl.cot == 3 && pl.tpw == 2) DLKA_WG(1, 3, 2)
+            else if (pl.cot == 3) DLKA_WG(1, 3, 3) else if (pl.cot == 2) DLKA_WG(1, 2, 3) else DLKA_WG(1, 1, 3)
+        } else {
+            if (pl.cot == 3) DLKA_WG(0, 3, 3) else if (pl.cot == 2) DLKA_WG(0, 2, 3) else DLKA_WG(0, 1, 3)
+        }
+#undef DLKA_WG
     }
     DLKA_CHECK_LAUNCH();
     const long n = (long)a.K * a.Cout * a.Cin + (gb ? a.Cout : 0);

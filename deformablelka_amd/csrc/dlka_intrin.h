@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 namespace dlka {
+#define DLKA_OOB 0x80000000u   // byte offset beyond any buffer the gather kernels accept (< 2 GB)
 #if defined(HIPEMU)
 typedef hipemu_f32x4 f32x4;
 typedef hipemu_f32x16 f32x16;
@@ -12,6 +13,21 @@ __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) { ret
 __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) { return hipemu::mfma_f32_16x16x4f32(a, b, c); }
 __device__ __forceinline__ int readfirstlane(int v) { return hipemu::readfirstlane(v); }
 #define DLKA_DYN_SMEM(type, name) type *name = reinterpret_cast<type *>(hipemu::dyn_smem())
+// buffer resource: loads at a byte offset >= the buffer size return 0 (the hardware range check of buffer_load)
+struct BufRsrc { const unsigned char *base; unsigned bytes; };
+__device__ __forceinline__ BufRsrc make_rsrc(const void *p, size_t bytes) { return BufRsrc{(const unsigned char *)p, (unsigned)bytes}; }
+__device__ __forceinline__ float buf_load_f32(BufRsrc r, unsigned off)
+{
+    float v = 0.f;
+    if (off < r.bytes && off + 4 <= r.bytes) memcpy(&v, r.base + off, 4);
+    return v;
+}
+__device__ __forceinline__ f32x4 buf_load_f32x4(BufRsrc r, unsigned off)
+{
+    f32x4 v;
+    for (int e = 0; e < 4; ++e) v[e] = buf_load_f32(r, off + 4u * e);
+    return v;
+}
 #else
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -21,6 +37,18 @@ __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) { ret
 // v_mfma_f32_16x16x4_f32 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D: col = l&15, row = (l>>4)*4 + r.
 __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ int readfirstlane(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Buffer loads (buffer_load_dword / _dwordx4 ... offen): 32-bit byte offsets against a wave-uniform descriptor, and the
+// hardware range check returns 0 for offsets >= the buffer size.  The gather kernels use that for zero padding and for
+// corners outside the volume: the offset of a dropped element is DLKA_OOB, so every load is unconditional — no branch
+// around it, no select after it, and the loads of the next tile stay in flight under the MFMAs of the current one
+// (a conditional load compiles to s_cbranch + s_waitcnt vmcnt(0) per element; measured in profiles/r01g).
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc make_rsrc(const void *p, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load_f32(BufRsrc r, unsigned off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); }
+__device__ __forceinline__ f32x4 buf_load_f32x4(BufRsrc r, unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); }
 #define DLKA_DYN_SMEM(type, name)                                             \
     extern __shared__ __attribute__((aligned(16))) unsigned char dlka_dyn_lds[]; \
     type *name = reinterpret_cast<type *>(dlka_dyn_lds)
