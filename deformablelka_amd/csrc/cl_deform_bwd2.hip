@@ -18,7 +18,10 @@
 //                           Corners beyond the halo (|tap + offset| > ~2 voxels outside the brick) fall back to global atomics.
 //   cl_deform_gx_gather_kernel   every input voxel sums the <= few windows that cover it (plain loads, fixed order) and
 //                           adds the result to grad_input: no flush atomics.
+#include <stdlib.h>
+
 #include "cl_args.h"
+#include "cl_gather.h"
 #include "dlka_kernels.h"
 
 namespace dlka {
@@ -190,6 +193,189 @@ __global__ __launch_bounds__(256) void cl_deform_goff_kernel(DeformBwdArgs p, in
             float *dst = p.goff + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
             dst[0] = gd; dst[p.N] = gh; dst[2 * (long)p.N] = gw;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// grad_offset with the line-friendly gather of cl_gather.h.
+//   goff_axis[m, tap] = sum_c Col[m, tap, c] * Dax[m, tap, c],   Dax = sum_q dcoef_axis(q) * x_q   (cuh:111-190)
+// Per (32-voxel tile, tap, 32-channel chunk) a wave
+//   1. runs the Col chunk on the matrix cores (orientation D[channel][voxel] as above; the corner loads issued one unit
+//      earlier land meanwhile),
+//   2. in the gather layout (lane = (row of 8, 16-byte piece of 8): every load covers 8 whole 128-byte rows) turns the
+//      8 corner pieces of each of its 4 rows into the three derivative samples and writes them to wave-private LDS tiles,
+//   3. back in the MFMA layout (lane = voxel, 16 channels in registers) reads its 16 channels of the three tiles and
+//      dots them with Col: 48 FMAs and one cross-half add per axis — no cross-lane reduction tree, no atomics.
+// (An intermediate version kept Col in the gather layout and reduced 8-lane groups with DPP; it needed 435 registers,
+//  ran one wave per SIMD and was no faster than the first kernel.)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NKC_REG>
+__global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p, int taps_per_block)
+{
+    constexpr int SROW = 36;
+    __shared__ __attribute__((aligned(16))) float Bs2[2][32 * 32];          // W[tap][co chunk][ci chunk], double buffered
+    __shared__ __attribute__((aligned(16))) float Tsm[4][3][32 * SROW];     // per wave: derivative-sample tiles (d, h, w)
+    __shared__ __attribute__((aligned(16))) float Dsm[4][32 * GATHER_DESC_WORDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int gr = lane >> 3, gp = lane & 7;
+    const int mbase = (blockIdx.x * 4 + wave) * 32;
+    const int m = mbase + j;
+    const bool row_ok = m < p.M;
+    const int b = row_ok ? m / p.N : 0;
+    const int v = row_ok ? m - b * p.N : 0;
+    const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / (p.W * p.H);
+    const int HW = p.H * p.W, rowbytes = p.C * 4;
+    const int ncc = p.C / 32, nkc = p.CoutP / 32;
+    const int tap_lo = blockIdx.y * taps_per_block, tap_hi = min(p.K, tap_lo + taps_per_block);
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.C * 4);
+    float *Tt = &Tsm[wave][0][0], *Dt = Dsm[wave];
+
+    float greg[NKC_REG > 0 ? NKC_REG : 1][16];
+    if (NKC_REG > 0) {
+#pragma unroll
+        for (int kc = 0; kc < NKC_REG; ++kc) {
+            const bool okg = row_ok && kc < nkc && kc * 32 + 16 * h < p.Cout;
+            const f32x4 *g4 = reinterpret_cast<const f32x4 *>(p.g + (okg ? (long)m * p.Cout + kc * 32 + 16 * h : 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 t = g4[e];
+                greg[kc][4 * e] = okg ? t[0] : 0.f; greg[kc][4 * e + 1] = okg ? t[1] : 0.f;
+                greg[kc][4 * e + 2] = okg ? t[2] : 0.f; greg[kc][4 * e + 3] = okg ? t[3] : 0.f;
+            }
+        }
+    }
+
+    f32x4 xr[4][8];   // corner pieces of the unit in flight
+    RowDesc rd[4];
+    float onx[3] = {0.f, 0.f, 0.f};   // offsets of the next tap to describe, loaded a whole tap ahead
+    auto load_offsets = [&](int tap) {
+        const float *op = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
+        onx[0] = op[0]; onx[1] = op[p.N]; onx[2] = op[2 * (long)p.N];
+    };
+    auto describe = [&](int tap) {
+        const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
+        wave_sync();
+        if (h == 0) {
+            RowDesc r;
+            r.base = 0; r.okm = 0; r.ld = r.lh = r.lw = 0.f;
+            if (row_ok) r = gather_describe3(onx[0], onx[1], onx[2], p.N, b, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw, p.D, p.H, p.W);
+            gather_publish(Dt, j, r);
+        }
+        wave_sync();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rd[g] = gather_lookup(Dt, 8 * g + gr);
+    };
+    auto issue = [&](int cc) {
+        const unsigned cbyte = (unsigned)(cc * 32 + 4 * gp) * 4u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xr[g][q] = buf_load_f32x4(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
+    };
+
+    // weight tile of stage s = (tap, cc, kc) in flight in a register while the previous stage computes
+    const int nstage = (tap_hi - tap_lo) * ncc * nkc;
+    f32x4 wreg;
+    auto load_w = [&](int s) {
+        const int kc = s % nkc, cc = (s / nkc) % ncc, tap = tap_lo + s / (nkc * ncc);
+        const int rr = tid >> 3, c4 = tid & 7;
+        wreg = *(reinterpret_cast<const f32x4 *>(p.wp + ((long)tap * p.CoutP + kc * 32 + rr) * p.C + cc * 32) + c4);
+    };
+    int stage = 0;
+    if (tap_lo < tap_hi) {
+        load_w(0);
+        load_offsets(tap_lo);
+        describe(tap_lo);
+        issue(0);
+        if (tap_lo + 1 < tap_hi) load_offsets(tap_lo + 1);
+    }
+    for (int tap = tap_lo; tap < tap_hi; ++tap) {
+        float gd = 0.f, gh = 0.f, gw = 0.f;
+        for (int cc = 0; cc < ncc; ++cc) {
+            // ---- 1. Col chunk on the matrix cores ----
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 1
+            for (int kc = 0; kc < nkc; ++kc) {
+                float *Bs = Bs2[stage & 1];
+                reinterpret_cast<f32x4 *>(Bs)[tid] = wreg;
+                ++stage;
+                if (stage < nstage) load_w(stage);
+                float gl[16];
+                if (NKC_REG == 0) {
+                    const bool okg = row_ok && kc * 32 + 16 * h < p.Cout;
+                    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(p.g + (okg ? (long)m * p.Cout + kc * 32 + 16 * h : 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x4 t = g4[e];
+                        gl[4 * e] = okg ? t[0] : 0.f; gl[4 * e + 1] = okg ? t[1] : 0.f; gl[4 * e + 2] = okg ? t[2] : 0.f; gl[4 * e + 3] = okg ? t[3] : 0.f;
+                    }
+                }
+                __syncthreads();   // this stage's tile staged; the other buffer (read one stage ago) is free for the next
+                const float *arow = Bs + (16 * h) * 32 + j;
+                if (NKC_REG == 1) {
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], greg[0][st], acc);
+                } else if (NKC_REG == 2) {
+                    if (kc == 0) {
+#pragma unroll
+                        for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], greg[0][st], acc);
+                    } else {
+#pragma unroll
+                        for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], greg[NKC_REG > 1 ? 1 : 0][st], acc);
+                    }
+                } else {
+#pragma unroll
+                    for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], gl[st], acc);
+                }
+            }
+            // ---- 2. derivative samples of this lane's 4 gather rows -> LDS tiles ----
+            wave_sync();   // previous tiles consumed
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float fd[2] = {1.f - rd[g].ld, rd[g].ld}, fh[2] = {1.f - rd[g].lh, rd[g].lh}, fw[2] = {1.f - rd[g].lw, rd[g].lw};
+                f32x4 dd = {0.f, 0.f, 0.f, 0.f}, dh = {0.f, 0.f, 0.f, 0.f}, dw = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
+                    const float kd_ = (cd ? 1.f : -1.f) * fh[ch] * fw[cw], kh_ = (ch ? 1.f : -1.f) * fd[cd] * fw[cw], kw_ = (cw ? 1.f : -1.f) * fd[cd] * fh[ch];
+                    const f32x4 x4 = xr[g][q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dd[e] = fmaf(kd_, x4[e], dd[e]); dh[e] = fmaf(kh_, x4[e], dh[e]); dw[e] = fmaf(kw_, x4[e], dw[e]);
+                    }
+                }
+                float *dst = Tt + (8 * g + gr) * SROW + 4 * gp;
+                *reinterpret_cast<f32x4 *>(dst) = dd;
+                *reinterpret_cast<f32x4 *>(dst + 32 * SROW) = dh;
+                *reinterpret_cast<f32x4 *>(dst + 2 * 32 * SROW) = dw;
+            }
+            // the next unit's corner loads go out now: in flight under the dots below, the next staging and the next MFMAs
+            if (cc + 1 < ncc) issue(cc + 1);
+            else if (tap + 1 < tap_hi) { describe(tap + 1); issue(0); }
+            wave_sync();
+            // ---- 3. dot with Col in the MFMA layout: acc[r] = Col[voxel j][channel (r&3) + 8*(r>>2) + 4h] ----
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float *src = Tt + j * SROW + 8 * g4 + 4 * h;
+                const f32x4 td = *reinterpret_cast<const f32x4 *>(src), th = *reinterpret_cast<const f32x4 *>(src + 32 * SROW),
+                            tw = *reinterpret_cast<const f32x4 *>(src + 2 * 32 * SROW);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gd = fmaf(acc[4 * g4 + e], td[e], gd); gh = fmaf(acc[4 * g4 + e], th[e], gh); gw = fmaf(acc[4 * g4 + e], tw[e], gw);
+                }
+            }
+        }
+        gd += __shfl_xor(gd, 32);   // the two halves hold complementary channel sets of the same voxel
+        gh += __shfl_xor(gh, 32);
+        gw += __shfl_xor(gw, 32);
+        if (h == 0 && row_ok) {
+            float *dst = p.goff + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
+            dst[0] = gd; dst[p.N] = gh; dst[2 * (long)p.N] = gw;
+        }
+        if (tap + 2 < tap_hi) load_offsets(tap + 2);
     }
 }
 
@@ -389,9 +575,16 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         tsplit = cdiv(a.K, tpb);
         dim3 grid(mblocks, tsplit), block(256);
         const int nkc = a.CoutP / 32;
-        if (nkc == 1) { auto k = cl_deform_goff_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
-        else if (nkc == 2) { auto k = cl_deform_goff_kernel<2>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
-        else { auto k = cl_deform_goff_kernel<0>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
+        static const bool v1 = getenv("DLKA_GOFF_V1") != nullptr;   // A/B switch: first "lane = voxel" gather
+        if (v1) {
+            if (nkc == 1) { auto k = cl_deform_goff_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
+            else if (nkc == 2) { auto k = cl_deform_goff_kernel<2>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
+            else { auto k = cl_deform_goff_kernel<0>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
+        } else {
+            if (nkc == 1) { auto k = cl_deform_goff2_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
+            else if (nkc == 2) { auto k = cl_deform_goff2_kernel<2>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
+            else { auto k = cl_deform_goff2_kernel<0>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
+        }
         DLKA_CHECK_LAUNCH();
     }
     if (a.gx) {

@@ -1,0 +1,88 @@
+// Trilinear gather of channels-last volumes with a line-friendly lane layout.
+//
+// Measured (profiles/r01g_gather_layout_ubench.txt): the vector-memory front end charges per cache line touched per
+// instruction.  A wave that loads "lane = (row i of 32, half h): 64 bytes of row i" touches 32 rows per instruction and
+// gathers at 9.6 TB/s; "lane = (row r of 8, piece p of 8): 16 bytes" covers 8 WHOLE 128-byte rows per instruction and
+// gathers at 33 TB/s.  The deformable kernels therefore gather in the second layout and transpose through LDS into
+// whatever layout their MFMA operand needs.
+//
+// Per (32-row tile, tap): lanes 0..31 compute the sampling description of row `lane` (deform_im2col_cuda.cuh:244-259)
+// and publish it in a wave-private LDS table; lane (r = lane >> 3, p = lane & 7) then serves rows 8g + r, g = 0..3:
+// 8 corner loads of 16 bytes (channels 4p .. 4p+3 of the current 32-channel chunk) per row.
+#pragma once
+#include "dlka_common.h"
+
+namespace dlka {
+
+struct RowDesc {
+    int base;        // b*N + linear index of corner 000 (coordinates may be -1: only corners flagged in okm are addressed)
+    unsigned okm;    // bit q: corner q inside the volume and the sample inside the guard
+    float ld, lh, lw;
+};
+
+constexpr int GATHER_DESC_WORDS = 8;   // LDS words per row in the description table
+
+// Sampling rule for one (row, tap); q = base + offset.  Returns okm == 0 when the sample is outside the guard.
+__device__ __forceinline__ RowDesc gather_describe3(float od, float oh, float ow, long N, int b, int bd, int bh, int bw, int D, int H, int W)
+{
+    RowDesc r;
+    r.base = 0; r.okm = 0; r.ld = r.lh = r.lw = 0.f;
+    const float qd = (float)bd + od;
+    const float qh = (float)bh + oh;
+    const float qw = (float)bw + ow;
+    const bool inside = (qd > -1.f) & (qh > -1.f) & (qw > -1.f) & (qd < (float)D) & (qh < (float)H) & (qw < (float)W);
+    if (inside) {  // floor in [-1, size-1]
+        const float fd_ = floorf(qd), fh_ = floorf(qh), fw_ = floorf(qw);
+        const int zd = (int)fd_, zh = (int)fh_, zw = (int)fw_;
+        r.ld = qd - fd_; r.lh = qh - fh_; r.lw = qw - fw_;
+        r.base = b * (int)N + (zd * H + zh) * W + zw;
+        const unsigned vd0 = zd >= 0, vd1 = zd + 1 <= D - 1, vh0 = zh >= 0, vh1 = zh + 1 <= H - 1, vw0 = zw >= 0, vw1 = zw + 1 <= W - 1;
+        unsigned okm = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const unsigned ok = (((q >> 2) & 1) ? vd1 : vd0) & (((q >> 1) & 1) ? vh1 : vh0) & ((q & 1) ? vw1 : vw0);
+            okm |= ok << q;
+        }
+        r.okm = okm;
+    }
+    return r;
+}
+
+__device__ __forceinline__ RowDesc gather_describe(const float *__restrict__ off, long N, int b, int bd, int bh, int bw, int D, int H, int W)
+{
+    return gather_describe3(off[0], off[N], off[2 * N], N, b, bd, bh, bw, D, H, W);
+}
+
+__device__ __forceinline__ void gather_publish(float *tab, int row, const RowDesc &r)
+{
+    f32x4 a, b;
+    a[0] = __int_as_float(r.base); a[1] = __int_as_float((int)r.okm); a[2] = r.ld; a[3] = r.lh;
+    b[0] = r.lw; b[1] = 0.f; b[2] = 0.f; b[3] = 0.f;
+    reinterpret_cast<f32x4 *>(tab + row * GATHER_DESC_WORDS)[0] = a;
+    reinterpret_cast<f32x4 *>(tab + row * GATHER_DESC_WORDS)[1] = b;
+}
+
+__device__ __forceinline__ RowDesc gather_lookup(const float *tab, int row)
+{
+    const f32x4 a = reinterpret_cast<const f32x4 *>(tab + row * GATHER_DESC_WORDS)[0];
+    RowDesc r;
+    r.base = __float_as_int(a[0]); r.okm = (unsigned)__float_as_int(a[1]); r.ld = a[2]; r.lh = a[3];
+    r.lw = tab[row * GATHER_DESC_WORDS + 4];
+    return r;
+}
+
+// byte offset of corner q of a described row, channel byte offset cbyte; DLKA_OOB (-> loads 0) for dropped corners
+__device__ __forceinline__ unsigned gather_offset(const RowDesc &r, int q, int HW, int W, int rowbytes, unsigned cbyte)
+{
+    const int idx = r.base + ((q >> 2) & 1) * HW + ((q >> 1) & 1) * W + (q & 1);
+    return ((r.okm >> q) & 1u) ? (unsigned)idx * (unsigned)rowbytes + cbyte : DLKA_OOB;
+}
+
+__device__ __forceinline__ void gather_weights(const RowDesc &r, float w[8])
+{
+    const float fd[2] = {1.f - r.ld, r.ld}, fh[2] = {1.f - r.lh, r.lh}, fw[2] = {1.f - r.lw, r.lw};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w[q] = fd[(q >> 2) & 1] * fh[(q >> 1) & 1] * fw[q & 1];
+}
+
+}  // namespace dlka

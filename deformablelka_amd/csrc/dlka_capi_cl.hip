@@ -161,6 +161,11 @@ int deform_forward(const SameConv &s, const float *x, const float *off, const fl
     a.in = x; a.off = off; a.wp = wp; a.bias = bias; a.out = out; a.epi = 0;
     a.Cin = s.Cin; a.CinReal = s.Cin; a.CinP = s.Cin; a.Cout = s.Cout; a.NP = s.Cout;
     const int splits = cl_igemm_pick_splits(s.M, s.K * (s.Cin / 32), 0);
+    static const bool old_path = getenv("DLKA_DEFORM_FWD_IGEMM") != nullptr;   // A/B switch: first-generation "lane = row" gather
+    if (!old_path) {
+        const int rc = launch_cl_deform_fwd(a, splits, st);
+        if (rc != DLKA_ERR_UNSUPPORTED) return rc;
+    }
     return launch_cl_igemm(1, 0, a, splits, st);
 }
 

@@ -13,6 +13,17 @@ __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) { ret
 __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) { return hipemu::mfma_f32_16x16x4f32(a, b, c); }
 __device__ __forceinline__ int readfirstlane(int v) { return hipemu::readfirstlane(v); }
 #define DLKA_DYN_SMEM(type, name) type *name = reinterpret_cast<type *>(hipemu::dyn_smem())
+// lanes of one wave exchange data through LDS without a workgroup barrier: on the GPU the wave executes in lockstep and
+// LDS operations retire in program order; the emulator runs lanes as fibers and needs a rendezvous
+__device__ __forceinline__ void wave_sync() { (void)hipemu::shfl_any(0, 0); }
+// sum over the 8 lanes that share lane >> 3 (result in all 8)
+__device__ __forceinline__ float sum8(float x)
+{
+    x += hipemu::shfl_any(x, (hipemu::F().lin & 63) ^ 1);
+    x += hipemu::shfl_any(x, (hipemu::F().lin & 63) ^ 2);
+    x += hipemu::shfl_any(x, (hipemu::F().lin & 63) ^ 4);
+    return x;
+}
 // buffer resource: loads at a byte offset >= the buffer size return 0 (the hardware range check of buffer_load)
 struct BufRsrc { const unsigned char *base; unsigned bytes; };
 __device__ __forceinline__ BufRsrc make_rsrc(const void *p, size_t bytes) { return BufRsrc{(const unsigned char *)p, (unsigned)bytes}; }
@@ -42,6 +53,16 @@ __device__ __forceinline__ int readfirstlane(int v) { return __builtin_amdgcn_re
 // corners outside the volume: the offset of a dropped element is DLKA_OOB, so every load is unconditional — no branch
 // around it, no select after it, and the loads of the next tile stay in flight under the MFMAs of the current one
 // (a conditional load compiles to s_cbranch + s_waitcnt vmcnt(0) per element; measured in profiles/r01g).
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// sum over the 8 lanes that share lane >> 3 (result in all 8): three DPP adds, no LDS traffic
+// quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141 (lane k <-> 7-k inside each 8)
+__device__ __forceinline__ float sum8(float x)
+{
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false));
+    return x;
+}
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 __device__ __forceinline__ BufRsrc make_rsrc(const void *p, size_t bytes)
 {
