@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
 {
     constexpr int NPB = NT * 32;                 // columns handled by this block
     constexpr int BV = NT;                       // float4 of the 32 x NPB weight chunk each of the 256 threads stages
-    __shared__ __attribute__((aligned(16))) float Bs[2][32 * NPB];
+    constexpr int BSZ = (OMODE == 1 && 32 * NPB < 2 * 32 * 33) ? 2 * 32 * 33 : 32 * NPB;   // OMODE 1 reuses Bs for 4 transpose tiles
+    __shared__ __attribute__((aligned(16))) float Bs[2][BSZ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int m = (blockIdx.x * 4 + wave) * 32 + i;      // this lane's A row
@@ -160,6 +161,35 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
     // ---- epilogue: D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
     const int mbase = (blockIdx.x * 4 + wave) * 32;
     const bool split = gridDim.y > 1;
+    if (OMODE == 1) {
+        // Planar output [B][Cout][N]: in the D layout a store instruction would scatter 32 lanes over 32 planes (4 bytes
+        // per cache line).  Transpose each 32 x 32 tile through LDS so that lanes run over voxels: every store / atomic
+        // then covers 128 contiguous bytes of one plane.  (The weight buffers are free once the main loop is done.)
+        __syncthreads();
+        float *T = &Bs[0][0] + wave * (32 * 33);
+        const int mr = mbase + i;
+        const bool rok = mr < p.M;
+        const int bb = rok ? mr / p.N : 0, vv = rok ? mr - bb * p.N : 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + i] = acc[t][r];
+            wave_sync();
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) {
+                const int col = 2 * cc + h, n = n0 + t * 32 + col;
+                if (n >= p.Cout) continue;   // uniform per half-wave
+                float val = T[i * 33 + col];
+                if (p.bias && blockIdx.y == 0) val += p.bias[n];
+                if (!rok) continue;
+                float *dst = p.out + ((long)bb * p.Cout + n) * p.N + vv;
+                if (split) atomicAdd(dst, val);
+                else *dst = val;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = n0 + t * 32 + i;
@@ -170,13 +200,7 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
             const int mr = mbase + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (mr >= p.M) continue;
             float val = acc[t][r] + bv;
-            long o;
-            if (OMODE == 0) {
-                o = (long)mr * p.Cout + n;
-            } else {
-                const int bb = mr / p.N, vv = mr - bb * p.N;
-                o = ((long)bb * p.Cout + n) * p.N + vv;
-            }
+            const long o = (long)mr * p.Cout + n;
             if (split) {
                 atomicAdd(p.out + o, val);
             } else if (p.epi == 0) {

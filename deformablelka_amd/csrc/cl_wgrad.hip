@@ -14,6 +14,7 @@
 
 #include "deform_sample.h"
 #include "cl_args.h"
+#include "cl_gather.h"
 #include "dlka_kernels.h"
 
 namespace dlka {
@@ -184,6 +185,118 @@ __global__ __launch_bounds__(64) void cl_wgrad_kernel(WgradArgs p)
     }
     if (want_bias) {
         bsum += __shfl_xor(bsum, 32);   // the two halves hold the same co for different rows
+        if (h == 0) p.bpart[(long)chunk * p.CoutP + co] = bsum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Deformable weight gradient, second generation: the sample tile of each tap is gathered in the line-friendly layout of
+// cl_gather.h (8 whole 128-byte rows per load instruction), interpolated, and written to a wave-private LDS tile from
+// which the MFMA B operand is read; the corner loads of tap t+1 are in flight under the MFMAs of tap t.
+//     gW[co][ci][tap] = sum_m G[m][co] * S(m, tap, ci)
+// One wave = one 32(co) x 32(ci) tile x TPW taps over a chunk of rows.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TPW>
+__global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
+{
+    constexpr int SROW = 36;
+    __shared__ __attribute__((aligned(16))) float Ssm[2][32 * SROW];
+    __shared__ __attribute__((aligned(16))) float Dt[32 * GATHER_DESC_WORDS];
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int gr = lane >> 3, gp = lane & 7;
+    const int chunk = blockIdx.x;
+    const int ot = blockIdx.y / p.CT, ct = blockIdx.y % p.CT;
+    const int tap0 = blockIdx.z * TPW;
+    const int ntap = min(TPW, p.K - tap0);
+    const int co = ot * 32 + i;
+    const bool want_bias = p.bpart && ct == 0 && blockIdx.z == 0;
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * 4), rg = make_rsrc(p.g, (size_t)p.M * p.Cout * 4);
+    const int HW = p.H * p.W, rowbytes = p.Cin * 4;
+    const unsigned cbyte = (unsigned)(ct * 32 + 4 * gp) * 4u;
+
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+
+    const int m_lo = chunk * p.rows_per_chunk;
+    const int m_hi = min(p.M, m_lo + p.rows_per_chunk);
+    f32x4 xr[4][8];
+    RowDesc rd[4];
+    for (int mbase = m_lo; mbase < m_hi; mbase += 32) {
+        // A operand: G[m = mbase + 16h + s][co]
+        float ga[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int mm = mbase + 16 * h + s;
+            ga[s] = buf_load_f32(rg, (mm < m_hi && co < p.Cout) ? (unsigned)(mm * p.Cout + co) * 4u : DLKA_OOB);
+        }
+        // describing lane: row m = mbase + i
+        const int m = mbase + i;
+        const bool row_ok = m < m_hi;
+        const int b = row_ok ? m / p.N : 0, v = row_ok ? m - b * p.N : 0;
+        const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / (p.W * p.H);
+        auto describe_issue = [&](int t) {
+            const int tap = tap0 + t;
+            const int od = (tap / (p.kw * p.kh)) * p.dd - p.pd, oh = ((tap / p.kw) % p.kh) * p.dh - p.ph, ow = (tap % p.kw) * p.dw - p.pw;
+            wave_sync();
+            if (h == 0) {
+                RowDesc r;
+                r.base = 0; r.okm = 0; r.ld = r.lh = r.lw = 0.f;
+                if (row_ok) r = gather_describe(p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v, p.N, b, d0 + od, h0 + oh, w0 + ow, p.D, p.H, p.W);
+                gather_publish(Dt, i, r);
+            }
+            wave_sync();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                rd[g] = gather_lookup(Dt, 8 * g + gr);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xr[g][q] = buf_load_f32x4(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
+            }
+        };
+        describe_issue(0);
+        if (want_bias) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) bsum += ga[s];
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            if (t >= ntap) break;   // uniform
+            float *S = Ssm[t & 1];
+            // interpolate tap t and put its tile into LDS (the tile read two taps ago is free: LDS ops retire in order)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float wq[8];
+                gather_weights(rd[g], wq);
+                f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    s4[0] = fmaf(wq[q], xr[g][q][0], s4[0]); s4[1] = fmaf(wq[q], xr[g][q][1], s4[1]);
+                    s4[2] = fmaf(wq[q], xr[g][q][2], s4[2]); s4[3] = fmaf(wq[q], xr[g][q][3], s4[3]);
+                }
+                *reinterpret_cast<f32x4 *>(S + (8 * g + gr) * SROW + 4 * gp) = s4;
+            }
+            if (t + 1 < ntap) describe_issue(t + 1);   // its corner loads fly under the MFMAs below
+            else wave_sync();
+            const float *srow = S + (16 * h) * SROW + i;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc[t] = mfma_32x32x2(ga[s], srow[s * SROW], acc[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tap = tap0 + t;
+        if (tap >= p.K) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            p.part[(((long)chunk * p.K + tap) * p.CoutP + ot * 32 + row) * p.Cin + ct * 32 + i] = acc[t][r];
+        }
+    }
+    if (want_bias) {
+        bsum += __shfl_xor(bsum, 32);
         if (h == 0) p.bpart[(long)chunk * p.CoutP + co] = bsum;
     }
 }
@@ -401,7 +514,11 @@ static WgradPlan wgrad_plan(int M, int K, int Cout, int Cin, int amode)
 {
     WgradPlan pl;
     const int OT = round_up(Cout, 32) / 32, CT = Cin / 32;
-    if (amode == 1) { pl.tpw = 7; pl.cot = 1; }
+    if (amode == 1) {
+        static int tpw_d = -1;
+        if (tpw_d < 0) { const char *e = getenv("DLKA_WGRAD_DEFORM_TPW"); tpw_d = e ? atoi(e) : 3; if (tpw_d != 3 && tpw_d != 4 && tpw_d != 7 && tpw_d != 0) tpw_d = 3; }
+        pl.tpw = tpw_d == 0 ? 7 : tpw_d; pl.cot = 1;   // 0 selects the first-generation kernel (TPW 7)
+    }
     else if (K == 1) { pl.tpw = 1; pl.cot = (OT % 2 == 0) ? 2 : 1; }
     else {
         static int tpw_env = -1;
@@ -443,9 +560,12 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
     dim3 block(64);
     if (amode == 1) {
         if (gmode != 0 || a.K == 1) return DLKA_ERR_UNSUPPORTED;
-        dim3 grid(nchunks, OT * a.CT, cdiv(a.K, 7));
-        auto k = cl_wgrad_kernel<1, 0, 7>;
-        hipLaunchKernelGGL(k, grid, block, 0, st, a);
+        static const bool v1 = getenv("DLKA_WGRAD_DEFORM_TPW") && atoi(getenv("DLKA_WGRAD_DEFORM_TPW")) == 0;
+        dim3 grid(nchunks, OT * a.CT, cdiv(a.K, pl.tpw));
+        if (v1) { auto k = cl_wgrad_kernel<1, 0, 7>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else if (pl.tpw == 3) { auto k = cl_wgrad_deform_kernel<3>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else if (pl.tpw == 4) { auto k = cl_wgrad_deform_kernel<4>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else { auto k = cl_wgrad_deform_kernel<7>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
     } else {
         dim3 grid(nchunks, cdiv(OT, pl.cot) * a.CT, cdiv(a.K, pl.tpw));
 #define DLKA_WG(GM, CO, TP)                                                                                      \
