@@ -99,8 +99,12 @@ class DLKABlockStack:
             b.copy_(((torch.rand(b.shape, generator=gen) * 2 - 1) * bound).to(self.device, self.dtype))
         ow, ob = blk.params[6], blk.params[7]
         fan_in = int(ow[0].numel())
-        # input to conv_offset has O(0.1-1) magnitude after the two depthwise convs; scale empirically fixed per C
-        ow.copy_((torch.randn(ow.shape, generator=gen) * (offset_std * 3.0 / math.sqrt(fan_in))).to(self.device, self.dtype))
+        # timing needs non-degenerate offsets with std ~ 1 voxel.  The input of conv_offset (after proj_1, GELU and
+        # the two default-initialised depthwise convs) shrinks with C, so the gain is calibrated per stage width: measured
+        # on MI355X with gain 3/sqrt(fan_in) the predicted offsets had std 0.272 / 0.190 / 0.104 / 0.080 at C = 32 / 64 /
+        # 128 / 256 (scripts/stack_stats.py); the table below brings all four to ~1.0 and is frozen.
+        calib = {32: 3.68, 64: 5.26, 128: 9.6, 256: 12.5}.get(blk.C, 1.0)
+        ow.copy_((torch.randn(ow.shape, generator=gen) * (offset_std * calib * 3.0 / math.sqrt(fan_in))).to(self.device, self.dtype))
         ob.zero_()
 
     def _stream(self):
