@@ -10,6 +10,7 @@ struct IgemmArgs {
     const float *wp;     // [K][CinP][NP] prepared weights (zero padded)
     const float *bias;   // [Cout] or null
     const float *aux;    // epilogue operand (channels-last [M][Cout]) or null
+    const float *aux2;   // second epilogue operand (epi 4)
     float *out;          // OMODE 0: [M][Cout] channels-last; OMODE 1: [B][Cout][N] planar
     float *out2;         // second epilogue output or null
     int B, D, H, W, N, M;
@@ -17,6 +18,7 @@ struct IgemmArgs {
     int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
     int units_per_split; // work units (tap, 32-channel chunk) per blockIdx.y; K * CinP/32 when gridDim.y == 1
     int epi;             // 0: out = acc+bias | 1: out = acc+bias, out2 = gelu(out) | 2: out = acc+bias, out2 = aux*out | 3: out = acc+bias+aux
+                         // 4: out = (acc+bias)*aux, out2 = (acc+bias)*aux2   (gate backward fused into proj_2's data gradient)
 };
 
 struct WgradArgs {
@@ -62,6 +64,22 @@ struct PrepBatch {
     PrepJob j[16];
     int njobs;
     long total;
+};
+
+// one weight-gradient finalisation: fold the row-chunk partials (kind 0) or re-lay a depthwise [tap][c] buffer (kind 1)
+struct FinalizeJob {
+    const float *part;   // kind 0: [chunks][K][CoutP][Cin] partial tiles; kind 1: gwp [K][C]
+    const float *bpart;  // kind 0: [chunks][CoutP] partial bias sums or null
+    float *gw, *gb;      // outputs in the reference layout
+    int chunks, K, CoutP, Cout, Cin;
+    int kind;
+    long n;              // outputs (weights + bias entries)
+    long block0;         // first workgroup of this job
+};
+struct FinalizeBatch {
+    FinalizeJob j[8];
+    int njobs;
+    long nblocks;
 };
 
 struct DeformBwdArgs {

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void cl_dwconv_wgrad_kernel(DwWgradArgs p)
     }
 }
 
-int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st)
+int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st, bool zero_init)
 {
     constexpr int TW = 8;
     const int cpb = a.C < 256 ? a.C : 256;
@@ -188,8 +188,10 @@ int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st)
     int xb = rows < 64 ? rows : 64;                 // row-chunks: bounded atomics, enough blocks with grid.y = kd*kh
     a.rows_per_block = cdiv(rows, xb);
     xb = cdiv(rows, a.rows_per_block);
-    if (hipMemsetAsync(a.gwp, 0, (size_t)a.kd * a.kh * kw * a.C * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
-    if (a.gb && hipMemsetAsync(a.gb, 0, (size_t)a.C * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+    if (zero_init) {   // (the fused block zeroes all of its accumulation targets with one memset)
+        if (hipMemsetAsync(a.gwp, 0, (size_t)a.kd * a.kh * kw * a.C * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+        if (a.gb && hipMemsetAsync(a.gb, 0, (size_t)a.C * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+    }
     dim3 grid(xb, a.kd * a.kh, cdiv(a.C, cpb)), block(256);
     if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
     else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_wgrad_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }

@@ -211,8 +211,11 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
             } else if (p.epi == 2) {
                 p.out[o] = val;
                 p.out2[o] = p.aux[o] * val;
-            } else {
+            } else if (p.epi == 3) {
                 p.out[o] = val + p.aux[o];
+            } else {
+                p.out[o] = val * p.aux[o];
+                p.out2[o] = val * p.aux2[o];
             }
         }
     }

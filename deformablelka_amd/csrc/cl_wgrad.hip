@@ -539,6 +539,11 @@ static WgradPlan wgrad_plan(int M, int K, int Cout, int Cin, int amode)
 
 int cl_wgrad_pick_chunks(int M, int K, int Cout, int Cin, int amode) { return wgrad_plan(M, K, Cout, Cin, amode).chunks; }
 
+size_t cl_wgrad_part_floats_mode(int M, int K, int Cout, int Cin, int amode)
+{
+    return (size_t)wgrad_plan(M, K, Cout, Cin, amode).chunks * ((size_t)K * round_up(Cout, 32) * Cin + round_up(Cout, 32));
+}
+
 size_t cl_wgrad_part_floats(int M, int K, int Cout, int Cin)
 {
     const int c0 = wgrad_plan(M, K, Cout, Cin, 0).chunks, c1 = wgrad_plan(M, K, Cout, Cin, 1).chunks;
@@ -546,7 +551,7 @@ size_t cl_wgrad_part_floats(int M, int K, int Cout, int Cin)
 }
 
 template <typename T>
-int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t st)
+int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t st, FinalizeJob *defer)
 {
     const WgradPlan pl = wgrad_plan(a.M, a.K, a.Cout, a.Cin, amode);
     const int tiles = cdiv(a.M, 32);
@@ -586,6 +591,11 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
     }
     DLKA_CHECK_LAUNCH();
     const long n = (long)a.K * a.Cout * a.Cin + (gb ? a.Cout : 0);
+    if (defer) {   // the caller folds the partials of several gradients in one launch (launch_cl_wgrad_finalize)
+        defer->part = a.part; defer->bpart = a.bpart; defer->gw = (float *)gw; defer->gb = (float *)gb;
+        defer->chunks = nchunks; defer->K = a.K; defer->CoutP = a.CoutP; defer->Cout = a.Cout; defer->Cin = a.Cin; defer->kind = 0; defer->n = n;
+        return DLKA_OK;
+    }
     long blocks = cdivl(n, 32);
     if (blocks > 4096) blocks = 4096;
     auto rk = cl_wgrad_reduce_kernel<T>;
@@ -594,7 +604,64 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
     return DLKA_OK;
 }
 
-template int launch_cl_wgrad<float>(int, int, WgradArgs, float *, float *, hipStream_t);
+template int launch_cl_wgrad<float>(int, int, WgradArgs, float *, float *, hipStream_t, FinalizeJob *);
+
+// All weight-gradient finalisations of one D-LKA block in ONE launch: the five partial-sum folds (3 pointwise, offset
+// conv, deformable conv) and the two depthwise [tap][c] -> [c][tap] re-layouts were seven ~5-10 us launches per block.
+__global__ __launch_bounds__(256) void cl_wgrad_finalize_kernel(FinalizeBatch b)
+{
+    __shared__ float red[8][33];
+    int ji = 0;
+    while (ji + 1 < b.njobs && (long)blockIdx.x >= b.j[ji + 1].block0) ++ji;
+    const FinalizeJob &jb = b.j[ji];
+    const long e = ((long)blockIdx.x - jb.block0) * 32 + (threadIdx.x & 31);
+    const int el = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    if (jb.kind == 1) {   // depthwise staging [K + 1][C] (row K = bias sums): gw[c][tap] = gwp[tap][c], gb[c] = gwp[K][c]
+        if (cl == 0 && e < jb.n) {
+            const long nw = (long)jb.K * jb.Cin;
+            if (e < nw) {
+                const int tap = (int)(e % jb.K), c = (int)(e / jb.K);
+                jb.gw[e] = jb.part[(long)tap * jb.Cin + c];
+            } else {
+                jb.gb[e - nw] = jb.part[nw + (e - nw)];
+            }
+        }
+        return;
+    }
+    const long n = (long)jb.K * jb.Cout * jb.Cin;
+    const long stride = (long)jb.K * jb.CoutP * jb.Cin;
+    float a0 = 0.f, a1 = 0.f;
+    int ci = 0, co = 0, tap = 0;
+    if (e < n) {
+        ci = (int)(e % jb.Cin); co = (int)((e / jb.Cin) % jb.Cout); tap = (int)(e / jb.Cin / jb.Cout);
+        const float *src = jb.part + ((long)tap * jb.CoutP + co) * jb.Cin + ci;
+        int c = cl;
+        for (; c + 8 < jb.chunks; c += 16) { a0 += src[(long)c * stride]; a1 += src[(long)(c + 8) * stride]; }
+        if (c < jb.chunks) a0 += src[(long)c * stride];
+    } else if (e < jb.n) {
+        co = (int)(e - n);
+        for (int c = cl; c < jb.chunks; c += 8) a0 += jb.bpart[(long)c * jb.CoutP + co];
+    }
+    red[cl][el] = a0 + a1;
+    __syncthreads();
+    if (cl == 0 && e < jb.n) {
+        const float t = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+        if (e < n) jb.gw[((long)co * jb.Cin + ci) * jb.K + tap] = t;
+        else jb.gb[co] = t;
+    }
+}
+
+int launch_cl_wgrad_finalize(FinalizeBatch &b, hipStream_t st)
+{
+    if (b.njobs <= 0) return DLKA_OK;
+    long blk = 0;
+    for (int k = 0; k < b.njobs; ++k) { b.j[k].block0 = blk; blk += cdivl(b.j[k].n, 32); }
+    b.nblocks = blk;
+    if (blk > 0x7fffffffL) return DLKA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(cl_wgrad_finalize_kernel, dim3((unsigned)blk), dim3(256), 0, st, b);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // column sums of a channels-last matrix:  gb[n] = sum_m G[m][n]     (bias gradients)

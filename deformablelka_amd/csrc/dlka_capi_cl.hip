@@ -95,7 +95,7 @@ int dense_forward(const SameConv &s, const float *x, const float *w, const float
 // ---- dense conv data gradient: gx = conv_transpose(gout) (+ epilogue) ---------------------------------------------
 // wp must hold K * round_up(Cout,32) * Cin floats.  gout channels-last needs Cout % 32 == 0; planar any Cout.
 int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, const float *w, float *gx, float *wp, int epi,
-                        const float *aux, hipStream_t st)
+                        const float *aux, hipStream_t st, const float *aux2 = nullptr, float *out2 = nullptr)
 {
     const int KP = round_up(s.Cout, 32), NP = s.Cin;
     if (!nt_ok(NP) || s.Cin % 32) return DLKA_ERR_UNSUPPORTED;
@@ -104,7 +104,7 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
     IgemmArgs a;
     fill_igemm(a, s);
     a.pd = s.dd * (s.kd - 1) - s.pd; a.ph = s.dh * (s.kh - 1) - s.ph; a.pw = s.dw * (s.kw - 1) - s.pw;
-    a.in = gout; a.wp = wp; a.bias = nullptr; a.out = gx; a.aux = aux; a.epi = epi;
+    a.in = gout; a.wp = wp; a.bias = nullptr; a.out = gx; a.aux = aux; a.aux2 = aux2; a.out2 = out2; a.epi = epi;
     a.Cin = s.Cout; a.CinReal = s.Cout; a.CinP = KP; a.Cout = s.Cin; a.NP = NP;
     const int splits = cl_igemm_pick_splits(s.M, s.K * (KP / 32), epi);
     return launch_cl_igemm(gout_planar ? 2 : 0, 0, a, splits, st);
@@ -113,7 +113,8 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
 size_t dense_wp_floats(const SameConv &s) { return (size_t)s.K * round_up(s.Cin, 32) * round_up(s.Cout, 32); }
 
 // ---- dense conv weight gradient -----------------------------------------------------------------------------------
-int dense_backward_weight(const SameConv &s, const float *x, const float *gout, int gout_planar, float *gw, float *gb, float *part, hipStream_t st)
+int dense_backward_weight(const SameConv &s, const float *x, const float *gout, int gout_planar, float *gw, float *gb, float *part, hipStream_t st,
+                          FinalizeJob *defer = nullptr)
 {
     if (s.Cin % 32) return DLKA_ERR_UNSUPPORTED;
     if (s.K != 1 && s.K > 7 * 64) return DLKA_ERR_UNSUPPORTED;
@@ -123,7 +124,7 @@ int dense_backward_weight(const SameConv &s, const float *x, const float *gout, 
     a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.Cin = s.Cin; a.Cout = s.Cout;
     a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
     if (s.K == 1 && gout_planar) return DLKA_ERR_UNSUPPORTED;
-    return launch_cl_wgrad<float>(0, gout_planar ? 1 : 0, a, gw, gb, st);
+    return launch_cl_wgrad<float>(0, gout_planar ? 1 : 0, a, gw, gb, st, defer);
 }
 
 // ---- depthwise ------------------------------------------------------------------------------------------------------
@@ -139,13 +140,22 @@ int dw_forward(const SameConv &s, const float *x, const float *w, const float *b
     return launch_cl_dwconv(a, s.kw, s.dw, st);
 }
 
-int dw_backward_weight(const SameConv &s, const float *x, const float *gout, float *gw, float *gb, float *gwp, hipStream_t st)
+// defer != null: gwp is a zeroed [K + 1][C] staging area (row K collects the bias sums) that the caller's fused
+// finalisation kernel re-lays into gw / gb
+int dw_backward_weight(const SameConv &s, const float *x, const float *gout, float *gw, float *gb, float *gwp, hipStream_t st, FinalizeJob *defer = nullptr)
 {
     DwWgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.g = gout; a.in = x; a.gwp = gwp; a.gb = gb;
+    a.g = gout; a.in = x; a.gwp = gwp; a.gb = defer ? gwp + (size_t)s.K * s.Cin : gb;
     a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.C = s.Cin;
     a.kd = s.kd; a.kh = s.kh; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh;
+    if (defer) {
+        DLKA_TRY(launch_cl_dwconv_wgrad(a, s.kw, s.dw, st, false));
+        memset(defer, 0, sizeof(*defer));
+        defer->part = gwp; defer->gw = gw; defer->gb = gb; defer->K = s.K; defer->Cin = s.Cin; defer->kind = 1; defer->chunks = 1;
+        defer->n = (long)s.K * s.Cin + s.Cin;
+        return DLKA_OK;
+    }
     DLKA_TRY(launch_cl_dwconv_wgrad(a, s.kw, s.dw, st));
     return launch_cl_dw_unprep<float>(gwp, gw, s.Cin, s.K, st);
 }
@@ -198,7 +208,7 @@ int deform_bwd_variant()
 }
 
 int deform_backward(const SameConv &s, const float *x, const float *off, const float *w, const float *gout, float *gx, float *goff,
-                    float *gw, float *gb, float *wp, float *part, float *scratch, hipStream_t st)
+                    float *gw, float *gb, float *wp, float *part, float *scratch, hipStream_t st, FinalizeJob *defer = nullptr)
 {
     if (gx || goff) {
         if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cout, s.Cin, 2, st));
@@ -216,7 +226,7 @@ int deform_backward(const SameConv &s, const float *x, const float *off, const f
         a.g = gout; a.in = x; a.off = off; a.part = part;
         a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.Cin = s.Cin; a.Cout = s.Cout;
         a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
-        DLKA_TRY(launch_cl_wgrad<float>(1, 0, a, gw, gb, st));
+        DLKA_TRY(launch_cl_wgrad<float>(1, 0, a, gw, gb, st, defer));
     } else if (gb) {
         DLKA_TRY(launch_cl_colsum(gout, gb, s.M, s.Cout, st));
     }
@@ -260,12 +270,12 @@ struct TokGeoms {
     size_t dw5_floats() const { return (size_t)125 * dw5.Cin; }
     size_t dw7_floats() const { return (size_t)343 * dw7.Cin; }
     size_t prep_floats() const { return 6 * pw_floats() + 2 * offc_floats() + 2 * dcn_floats() + 2 * dw5_floats() + 2 * dw7_floats() + 16 * 64; }
-    size_t part_floats() const
-    {
-        size_t m = cl_wgrad_part_floats(pw.M, 27, 81, pw.Cin);
-        const size_t d = cl_wgrad_part_floats(pw.M, 27, pw.Cin, pw.Cin);
-        return m > d ? m : d;
-    }
+    // weight-gradient partials: every gradient of the block has its own area (folded by one fused launch at the end)
+    size_t part_pw() const { return (cl_wgrad_part_floats_mode(pw.M, 1, pw.Cin, pw.Cin, 0) + 63) & ~(size_t)63; }
+    size_t part_off() const { return (cl_wgrad_part_floats_mode(pw.M, 27, 81, pw.Cin, 0) + 63) & ~(size_t)63; }
+    size_t part_dcn() const { return (cl_wgrad_part_floats_mode(pw.M, 27, pw.Cin, pw.Cin, 1) + 63) & ~(size_t)63; }
+    size_t stage_dw() const { return (size_t)(125 + 1 + 343 + 1) * pw.Cin; }   // dw5 [126][C] then dw7 [344][C]
+    size_t part_floats() const { return 3 * part_pw() + part_off() + part_dcn() + ((stage_dw() + 63) & ~(size_t)63); }
 };
 
 // carve + (forward only) fill the prepared-weight area
@@ -451,7 +461,7 @@ size_t dlka_lka3d_tokens_saved_bytes(int B, int C, int D, int H, int W, int dtyp
 {
     if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return 0;
     TokGeoms G(B, C, D, H, W);
-    return 6 * align256(G.E * 4) + align256(G.Off * 4) + align256(G.prep_floats() * 4);
+    return 7 * align256(G.E * 4) + align256(G.Off * 4) + align256(G.prep_floats() * 4);
 }
 
 size_t dlka_lka3d_tokens_workspace_bytes(int B, int C, int D, int H, int W, int dtype)
@@ -475,7 +485,7 @@ int dlka_lka3d_attention_tokens_forward(const void *x_, const dlka_lka3d_params 
     float *h = (float *)sv.take(G.E * 4), *a = (float *)sv.take(G.E * 4), *t1 = (float *)sv.take(G.E * 4), *t = (float *)sv.take(G.E * 4);
     float *off = (float *)sv.take(G.Off * 4), *f = (float *)sv.take(G.E * 4), *g1 = (float *)sv.take(G.E * 4);
     float *prep = (float *)sv.take(G.prep_floats() * 4);
-    float *m = (float *)cv.take(G.E * 4);
+    float *m = (float *)sv.take(G.E * 4);   // gate output, kept: proj_2's weight gradient needs it
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const float *x = (const float *)x_;
     float *y = (float *)y_;
@@ -515,6 +525,7 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     const float *h = (float *)sv.take(G.E * 4), *a = (float *)sv.take(G.E * 4), *t1 = (float *)sv.take(G.E * 4), *t = (float *)sv.take(G.E * 4);
     const float *off = (float *)sv.take(G.Off * 4), *f = (float *)sv.take(G.E * 4), *g1 = (float *)sv.take(G.E * 4);
     float *prep = (float *)sv.take(G.prep_floats() * 4);   // written by the matching forward call
+    const float *m = (const float *)sv.take(G.E * 4);
     (void)cv.take(G.wp_floats() * 4);
     float *part = (float *)cv.take(G.part_floats() * 4);
     float *bA = (float *)cv.take(G.E * 4), *bB = (float *)cv.take(G.E * 4), *bC = (float *)cv.take(G.E * 4), *bD = (float *)cv.take(G.E * 4);
@@ -524,37 +535,41 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     const float *x = (const float *)x_, *gy = (const float *)gy_;
     float *gx = (float *)gx_;
     const long E = (long)G.E;
-    float *gwp = part;  // depthwise weight-gradient staging ([K][C] fp32) reuses the partial-sum area
     const float *N0 = nullptr;
     TokPrep PW;
     DLKA_TRY(carve_prep(G, prep, PW, p, st, false));
+    // partial-sum areas, one per weight gradient; folded by ONE launch at the end
+    float *part_p2 = part, *part_c1 = part_p2 + G.part_pw(), *part_p1 = part_c1 + G.part_pw(), *part_off = part_p1 + G.part_pw();
+    float *part_dcn = part_off + G.part_off(), *stage5 = part_dcn + G.part_dcn(), *stage7 = stage5 + (size_t)126 * C;
+    if (hipMemsetAsync(stage5, 0, G.stage_dw() * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;   // the depthwise kernels accumulate with atomics
+    FinalizeBatch fb;
+    memset(&fb, 0, sizeof(fb));
 
-    // proj_2:  y = P2 m + x
-    DLKA_TRY(launch_mul_fwd<float>(a, g1, bA, E, st));                                                             // bA = m (recomputed)
-    DLKA_TRY(dense_backward_data(G.pw, gy, 0, N0, bB, PW.pw_b[2], 0, nullptr, st));                // bB = gm
-    DLKA_TRY(dense_backward_weight(G.pw, bA, gy, 0, (float *)gr->proj_2_w, (float *)gr->proj_2_b, part, st));
-    // gate:  m = a * g1
-    DLKA_TRY(launch_mul_bwd<float>(a, g1, bB, bC, bD, E, st));                                                     // bC = ga1 = gm*g1, bD = gg1 = gm*a
+    // proj_2:  y = P2 m + x.   Its data gradient gm = P2^T gy feeds only the gate  m = a * g1, whose backward is fused into
+    // the epilogue:  bD = gg1 = gm * a,  bC = ga1 = gm * g1
+    DLKA_TRY(dense_backward_data(G.pw, gy, 0, N0, bD, PW.pw_b[2], 4, a, st, g1, bC));
+    DLKA_TRY(dense_backward_weight(G.pw, m, gy, 0, (float *)gr->proj_2_w, (float *)gr->proj_2_b, part_p2, st, &fb.j[fb.njobs++]));
     // conv1:  g1 = P0 f
     DLKA_TRY(dense_backward_data(G.pw, bD, 0, N0, bB, PW.pw_b[1], 0, nullptr, st));                 // bB = gf
-    DLKA_TRY(dense_backward_weight(G.pw, f, bD, 0, (float *)gr->conv1_w, (float *)gr->conv1_b, part, st));
+    DLKA_TRY(dense_backward_weight(G.pw, f, bD, 0, (float *)gr->conv1_w, (float *)gr->conv1_b, part_c1, st, &fb.j[fb.njobs++]));
     // deformable conv:  f = DCN(t, off)
-    DLKA_TRY(deform_backward(G.dcn, t, off, N0, bB, bA, bO, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part, scratch, st));  // bA = gt_a, bO = goff
+    DLKA_TRY(deform_backward(G.dcn, t, off, N0, bB, bA, bO, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, st,
+                             &fb.j[fb.njobs++]));                                                   // bA = gt_a, bO = goff
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
-    DLKA_TRY(dense_backward_weight(G.offc, t, bO, 1, (float *)gr->offset_w, (float *)gr->offset_b, part, st));
-    DLKA_TRY(dense_backward_data(G.offc, bO, 1, N0, bD, PW.off_b, 3, bA, st));                   // bD = gt
+    DLKA_TRY(dense_backward_weight(G.offc, t, bO, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, st, &fb.j[fb.njobs++]));
+    DLKA_TRY(dense_backward_data(G.offc, bO, 1, N0, bD, PW.off_b, 3, bA, st));                      // bD = gt
     // depthwise 7^3 dil 3:  t = DW7 t1
-    DLKA_TRY(dw_forward(G.dw7, bD, N0, nullptr, bB, PW.dw7_b, 1, st));                     // bB = gt1
-    DLKA_TRY(dw_backward_weight(G.dw7, t1, bD, (float *)gr->conv_spatial_w, (float *)gr->conv_spatial_b, gwp, st));
+    DLKA_TRY(dw_forward(G.dw7, bD, N0, nullptr, bB, PW.dw7_b, 1, st));                              // bB = gt1
+    DLKA_TRY(dw_backward_weight(G.dw7, t1, bD, (float *)gr->conv_spatial_w, (float *)gr->conv_spatial_b, stage7, st, &fb.j[fb.njobs++]));
     // depthwise 5^3:  t1 = DW5 a
-    DLKA_TRY(dw_forward(G.dw5, bB, N0, nullptr, bA, PW.dw5_b, 1, st));                            // bA = ga2
-    DLKA_TRY(dw_backward_weight(G.dw5, a, bB, (float *)gr->conv0_w, (float *)gr->conv0_b, gwp, st));
-    // GELU:  a = GELU(h)
-    DLKA_TRY(launch_add_fwd<float>(bC, bA, bC, E, st));                                                            // bC = ga
-    DLKA_TRY(launch_gelu_bwd<float>(h, bC, bA, E, st));                                                            // bA = gh
+    DLKA_TRY(dw_forward(G.dw5, bB, N0, nullptr, bA, PW.dw5_b, 1, st));                              // bA = ga2
+    DLKA_TRY(dw_backward_weight(G.dw5, a, bB, (float *)gr->conv0_w, (float *)gr->conv0_b, stage5, st, &fb.j[fb.njobs++]));
+    // GELU:  a = GELU(h);  ga = ga1 + ga2
+    DLKA_TRY(launch_gelu_bwd_sum<float>(h, bC, bA, bB, E, st));                                     // bB = gh
     // proj_1:  h = P1 x ;  gx = P1^T gh + gy (shortcut)
-    DLKA_TRY(dense_backward_weight(G.pw, x, bA, 0, (float *)gr->proj_1_w, (float *)gr->proj_1_b, part, st));
-    DLKA_TRY(dense_backward_data(G.pw, bA, 0, N0, gx, PW.pw_b[0], 3, gy, st));
+    DLKA_TRY(dense_backward_weight(G.pw, x, bB, 0, (float *)gr->proj_1_w, (float *)gr->proj_1_b, part_p1, st, &fb.j[fb.njobs++]));
+    DLKA_TRY(dense_backward_data(G.pw, bB, 0, N0, gx, PW.pw_b[0], 3, gy, st));
+    DLKA_TRY(launch_cl_wgrad_finalize(fb, st));
     return DLKA_OK;
 }
 

@@ -40,6 +40,7 @@ template <typename T> int launch_gelu_bwd(const T *x, const T *gy, T *gx, long n
 template <typename T> int launch_mul_fwd(const T *a, const T *b, T *y, long n, hipStream_t st);
 template <typename T> int launch_mul_bwd(const T *a, const T *b, const T *gy, T *ga, T *gb, long n, hipStream_t st);
 template <typename T> int launch_add_fwd(const T *a, const T *b, T *y, long n, hipStream_t st);
+template <typename T> int launch_gelu_bwd_sum(const T *x, const T *g1, const T *g2, T *gx, long n, hipStream_t st);
 
 // ---- channels-last fast path (cl_*.hip) --------------------------------------------------------------------------
 int launch_cl_prep_weight(const float *w, float *wp, int Cout, int Cin, int K, int KP, int NP, int mode, hipStream_t st);
@@ -49,11 +50,13 @@ int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t s
 int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st);
 int cl_wgrad_pick_chunks(int M, int K, int Cout, int Cin, int amode);
 size_t cl_wgrad_part_floats(int M, int K, int Cout, int Cin);
-template <typename T> int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t st);
+template <typename T> int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t st, FinalizeJob *defer = nullptr);
+size_t cl_wgrad_part_floats_mode(int M, int K, int Cout, int Cin, int amode);
+int launch_cl_wgrad_finalize(FinalizeBatch &b, hipStream_t st);
 int launch_cl_colsum(const float *g, float *gb32, int M, int Cout, hipStream_t st);
 int launch_cl_dw_prep_weight(const float *w, float *wp, int C, int K, int flip, hipStream_t st);
 int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st);
-int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st);
+int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st, bool zero_init = true);
 template <typename T> int launch_cl_dw_unprep(const float *gwp, T *gw, int C, int K, hipStream_t st);
 int launch_cl_transpose(const float *src, float *dst, int B, int C, int N, int to_cl, hipStream_t st);
 int launch_cl_deform_bwd(const DeformBwdArgs &a, hipStream_t st);

@@ -32,8 +32,10 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const T *a, const T *b, co
             const float av = ldf(a + i), bv = ldf(b + i);
             if (o1) stf(o1 + i, gy * bv);
             if (o2) stf(o2 + i, gy * av);
-        } else {  // add
+        } else if (MODE == 4) {  // add
             stf(o1 + i, ldf(a + i) + ldf(b + i));
+        } else {  // gelu bwd of a sum: o1 = (b + c) * dgelu(a)
+            stf(o1 + i, (ldf(b + i) + ldf(c + i)) * dgelu_f(ldf(a + i)));
         }
     }
 }
@@ -55,13 +57,15 @@ template <typename T> int launch_gelu_bwd(const T *x, const T *gy, T *gx, long n
 template <typename T> int launch_mul_fwd(const T *a, const T *b, T *y, long n, hipStream_t st) { return launch_elt<T, 2>(a, b, nullptr, y, nullptr, n, st); }
 template <typename T> int launch_mul_bwd(const T *a, const T *b, const T *gy, T *ga, T *gb, long n, hipStream_t st) { return launch_elt<T, 3>(a, b, gy, ga, gb, n, st); }
 template <typename T> int launch_add_fwd(const T *a, const T *b, T *y, long n, hipStream_t st) { return launch_elt<T, 4>(a, b, nullptr, y, nullptr, n, st); }
+template <typename T> int launch_gelu_bwd_sum(const T *x, const T *g1, const T *g2, T *gx, long n, hipStream_t st) { return launch_elt<T, 5>(x, g1, g2, gx, nullptr, n, st); }
 
 #define DLKA_INST(T)                                                                    \
     template int launch_gelu_fwd<T>(const T *, T *, long, hipStream_t);                  \
     template int launch_gelu_bwd<T>(const T *, const T *, T *, long, hipStream_t);       \
     template int launch_mul_fwd<T>(const T *, const T *, T *, long, hipStream_t);        \
     template int launch_mul_bwd<T>(const T *, const T *, const T *, T *, T *, long, hipStream_t); \
-    template int launch_add_fwd<T>(const T *, const T *, T *, long, hipStream_t);
+    template int launch_add_fwd<T>(const T *, const T *, T *, long, hipStream_t);         \
+    template int launch_gelu_bwd_sum<T>(const T *, const T *, const T *, T *, long, hipStream_t);
 DLKA_INST(float)
 DLKA_INST(bf16_t)
 #undef DLKA_INST
