@@ -321,6 +321,30 @@ int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_para
     return launch_cl_prep_batch(pb, st);
 }
 
+// ---- fork / join of the backward pass ------------------------------------------------------------------------------------
+// The weight gradients of a block only READ what the data-gradient chain produces; they run on an internal side stream,
+// forked and joined with events, so that the two chains overlap (also under hipGraph capture, where the event pattern
+// becomes a fork / join in the graph).  Opt-in with DLKA_SIDE_STREAM=1.
+struct SideCtx {
+    hipStream_t side;
+    hipEvent_t ev[8];
+    bool ok;
+};
+
+SideCtx &side_ctx()
+{
+    static SideCtx c = [] {
+        SideCtx x;
+        memset(&x, 0, sizeof(x));
+        x.ok = getenv("DLKA_SIDE_STREAM") != nullptr;   // opt-in: measured slower on MI355X (20.4 vs 19.0 ms/step), see DESIGN.md
+        if (x.ok && hipStreamCreateWithFlags(&x.side, hipStreamNonBlocking) != hipSuccess) x.ok = false;
+        for (int k = 0; k < 8 && x.ok; ++k)
+            if (hipEventCreateWithFlags(&x.ev[k], hipEventDisableTiming) != hipSuccess) x.ok = false;
+        return x;
+    }();
+    return c;
+}
+
 bool tokens_supported(int B, int C, int D, int H, int W)
 {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return false;
@@ -468,7 +492,7 @@ size_t dlka_lka3d_tokens_workspace_bytes(int B, int C, int D, int H, int W, int 
 {
     if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return 0;
     TokGeoms G(B, C, D, H, W);
-    return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 4 * align256(G.E * 4) + align256(G.Off * 4) +
+    return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 8 * align256(G.E * 4) + align256(G.Off * 4) +
            align256(G.scratch_floats() * 4) + align256(4096);
 }
 
@@ -528,8 +552,10 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     const float *m = (const float *)sv.take(G.E * 4);
     (void)cv.take(G.wp_floats() * 4);
     float *part = (float *)cv.take(G.part_floats() * 4);
-    float *bA = (float *)cv.take(G.E * 4), *bB = (float *)cv.take(G.E * 4), *bC = (float *)cv.take(G.E * 4), *bD = (float *)cv.take(G.E * 4);
-    float *bO = (float *)cv.take(G.Off * 4);
+    // every intermediate gradient has its own buffer: the weight-gradient stream reads them while the data-gradient chain moves on
+    float *gg1 = (float *)cv.take(G.E * 4), *ga1 = (float *)cv.take(G.E * 4), *gf = (float *)cv.take(G.E * 4), *gta = (float *)cv.take(G.E * 4);
+    float *gt = (float *)cv.take(G.E * 4), *gt1 = (float *)cv.take(G.E * 4), *ga2 = (float *)cv.take(G.E * 4), *gh = (float *)cv.take(G.E * 4);
+    float *goff = (float *)cv.take(G.Off * 4);
     float *scratch = (float *)cv.take(G.scratch_floats() * 4);
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const float *x = (const float *)x_, *gy = (const float *)gy_;
@@ -541,35 +567,59 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     // partial-sum areas, one per weight gradient; folded by ONE launch at the end
     float *part_p2 = part, *part_c1 = part_p2 + G.part_pw(), *part_p1 = part_c1 + G.part_pw(), *part_off = part_p1 + G.part_pw();
     float *part_dcn = part_off + G.part_off(), *stage5 = part_dcn + G.part_dcn(), *stage7 = stage5 + (size_t)126 * C;
-    if (hipMemsetAsync(stage5, 0, G.stage_dw() * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;   // the depthwise kernels accumulate with atomics
     FinalizeBatch fb;
     memset(&fb, 0, sizeof(fb));
 
+    SideCtx &sc = side_ctx();
+    const bool fork = sc.ok;
+    hipStream_t ws_ = fork ? sc.side : st;   // stream of the weight gradients
+    int nev = 0;
+    // `ws_` may use what the main stream has produced so far
+    auto publish = [&]() -> int {
+        if (!fork) return DLKA_OK;
+        if (hipEventRecord(sc.ev[nev], st) != hipSuccess || hipStreamWaitEvent(ws_, sc.ev[nev], 0) != hipSuccess) return DLKA_ERR_LAUNCH;
+        ++nev;
+        return DLKA_OK;
+    };
+    DLKA_TRY(publish());   // fork: everything issued before this call (gy, saved activations, the previous block's use of the workspace)
+    if (hipMemsetAsync(stage5, 0, G.stage_dw() * 4, ws_) != hipSuccess) return DLKA_ERR_LAUNCH;   // the depthwise kernels accumulate with atomics
+
     // proj_2:  y = P2 m + x.   Its data gradient gm = P2^T gy feeds only the gate  m = a * g1, whose backward is fused into
-    // the epilogue:  bD = gg1 = gm * a,  bC = ga1 = gm * g1
-    DLKA_TRY(dense_backward_data(G.pw, gy, 0, N0, bD, PW.pw_b[2], 4, a, st, g1, bC));
-    DLKA_TRY(dense_backward_weight(G.pw, m, gy, 0, (float *)gr->proj_2_w, (float *)gr->proj_2_b, part_p2, st, &fb.j[fb.njobs++]));
+    // the epilogue:  gg1 = gm * a,  ga1 = gm * g1
+    DLKA_TRY(dense_backward_weight(G.pw, m, gy, 0, (float *)gr->proj_2_w, (float *)gr->proj_2_b, part_p2, ws_, &fb.j[fb.njobs++]));
+    DLKA_TRY(dense_backward_data(G.pw, gy, 0, N0, gg1, PW.pw_b[2], 4, a, st, g1, ga1));
+    DLKA_TRY(publish());
     // conv1:  g1 = P0 f
-    DLKA_TRY(dense_backward_data(G.pw, bD, 0, N0, bB, PW.pw_b[1], 0, nullptr, st));                 // bB = gf
-    DLKA_TRY(dense_backward_weight(G.pw, f, bD, 0, (float *)gr->conv1_w, (float *)gr->conv1_b, part_c1, st, &fb.j[fb.njobs++]));
-    // deformable conv:  f = DCN(t, off)
-    DLKA_TRY(deform_backward(G.dcn, t, off, N0, bB, bA, bO, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, st,
-                             &fb.j[fb.njobs++]));                                                   // bA = gt_a, bO = goff
+    DLKA_TRY(dense_backward_weight(G.pw, f, gg1, 0, (float *)gr->conv1_w, (float *)gr->conv1_b, part_c1, ws_, &fb.j[fb.njobs++]));
+    DLKA_TRY(dense_backward_data(G.pw, gg1, 0, N0, gf, PW.pw_b[1], 0, nullptr, st));
+    DLKA_TRY(publish());
+    // deformable conv:  f = DCN(t, off):  weight gradient on the side stream, grad_offset and grad_input on the main one
+    DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
+                             &fb.j[fb.njobs++]));
+    DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, goff, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st));
+    DLKA_TRY(publish());
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
-    DLKA_TRY(dense_backward_weight(G.offc, t, bO, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, st, &fb.j[fb.njobs++]));
-    DLKA_TRY(dense_backward_data(G.offc, bO, 1, N0, bD, PW.off_b, 3, bA, st));                      // bD = gt
+    DLKA_TRY(dense_backward_weight(G.offc, t, goff, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, ws_, &fb.j[fb.njobs++]));
+    DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st));
+    DLKA_TRY(dense_backward_data(G.offc, goff, 1, N0, gt, PW.off_b, 3, gta, st));
+    DLKA_TRY(publish());
     // depthwise 7^3 dil 3:  t = DW7 t1
-    DLKA_TRY(dw_forward(G.dw7, bD, N0, nullptr, bB, PW.dw7_b, 1, st));                              // bB = gt1
-    DLKA_TRY(dw_backward_weight(G.dw7, t1, bD, (float *)gr->conv_spatial_w, (float *)gr->conv_spatial_b, stage7, st, &fb.j[fb.njobs++]));
+    DLKA_TRY(dw_backward_weight(G.dw7, t1, gt, (float *)gr->conv_spatial_w, (float *)gr->conv_spatial_b, stage7, ws_, &fb.j[fb.njobs++]));
+    DLKA_TRY(dw_forward(G.dw7, gt, N0, nullptr, gt1, PW.dw7_b, 1, st));
+    DLKA_TRY(publish());
     // depthwise 5^3:  t1 = DW5 a
-    DLKA_TRY(dw_forward(G.dw5, bB, N0, nullptr, bA, PW.dw5_b, 1, st));                              // bA = ga2
-    DLKA_TRY(dw_backward_weight(G.dw5, a, bB, (float *)gr->conv0_w, (float *)gr->conv0_b, stage5, st, &fb.j[fb.njobs++]));
+    DLKA_TRY(dw_backward_weight(G.dw5, a, gt1, (float *)gr->conv0_w, (float *)gr->conv0_b, stage5, ws_, &fb.j[fb.njobs++]));
+    DLKA_TRY(dw_forward(G.dw5, gt1, N0, nullptr, ga2, PW.dw5_b, 1, st));
     // GELU:  a = GELU(h);  ga = ga1 + ga2
-    DLKA_TRY(launch_gelu_bwd_sum<float>(h, bC, bA, bB, E, st));                                     // bB = gh
+    DLKA_TRY(launch_gelu_bwd_sum<float>(h, ga1, ga2, gh, E, st));
+    DLKA_TRY(publish());
     // proj_1:  h = P1 x ;  gx = P1^T gh + gy (shortcut)
-    DLKA_TRY(dense_backward_weight(G.pw, x, bB, 0, (float *)gr->proj_1_w, (float *)gr->proj_1_b, part_p1, st, &fb.j[fb.njobs++]));
-    DLKA_TRY(dense_backward_data(G.pw, bB, 0, N0, gx, PW.pw_b[0], 3, gy, st));
-    DLKA_TRY(launch_cl_wgrad_finalize(fb, st));
+    DLKA_TRY(dense_backward_weight(G.pw, x, gh, 0, (float *)gr->proj_1_w, (float *)gr->proj_1_b, part_p1, ws_, &fb.j[fb.njobs++]));
+    DLKA_TRY(launch_cl_wgrad_finalize(fb, ws_));
+    DLKA_TRY(dense_backward_data(G.pw, gh, 0, N0, gx, PW.pw_b[0], 3, gy, st));
+    if (fork) {   // join
+        if (hipEventRecord(sc.ev[nev], ws_) != hipSuccess || hipStreamWaitEvent(st, sc.ev[nev], 0) != hipSuccess) return DLKA_ERR_LAUNCH;
+    }
     return DLKA_OK;
 }
 

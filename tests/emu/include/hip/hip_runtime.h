@@ -55,6 +55,14 @@ inline hipError_t hipGetLastError() { return 0; }
 inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 enum hipMemcpyKind { hipMemcpyDeviceToDevice = 3 };
+// streams / events: everything is synchronous in the emulator
+typedef void *hipEvent_t;
+#define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return 0; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
 
 namespace hipemu {
