@@ -244,7 +244,11 @@ def main():
     from deformablelka_amd.stack import DLKABlockStack
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
     stack = DLKABlockStack(args.batch, device=dev, dtype=dtype, seed=1234 + rank)
-    lr = 1e-3
+    # Synthetic grad_outputs (N(0,1), no loss behind them) make the block gradients huge; a training-sized step would blow
+    # the parameters up within a few iterations (offsets -> inf/NaN, every sample dropped, kernels get FASTER: observed,
+    # profiles/r01i).  The SGD update is executed in full but with a step small enough that the data distribution the
+    # kernels see (offset std ~ 1 voxel) is the same in the last timed step as in the first; checked after the run.
+    lr = 1e-12
 
     def compute():
         stack.forward_backward()
@@ -295,6 +299,9 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = args.batch * world * args.steps / elapsed
+    health = stack.health()   # finite parameters / gradients and the offset statistics of the LAST executed step
+    if not health["finite"]:
+        raise SystemExit(f"bench invalid: non-finite parameters or gradients after the timed steps: {health}")
 
     if rank == 0:
         out = {
@@ -304,7 +311,8 @@ def main():
             "config": {"workload": "3D D-LKA Former Synapse 64x128x128 patch: fwd+bwd of its 21 D-LKA attention blocks "
                                    "(6x(32,32^3)+6x(64,16^3)+6x(128,8^3)+3x(256,4^3)) + grad all-reduce + SGD update",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "block_params": stack.num_params(), "hipgraph": graph is not None},
+                       "block_params": stack.num_params(), "hipgraph": graph is not None,
+                       "offset_std_voxels_stage0": health["offset_std"][0], "offset_std_voxels_by_stage": health["offset_std"]},
         }
         if not args.no_roofline:
             try:

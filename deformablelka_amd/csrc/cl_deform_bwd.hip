@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void cl_deform_bwd_kernel(DeformBwdArgs p)
 int launch_cl_deform_bwd(const DeformBwdArgs &a, hipStream_t st)
 {
     if (a.gx) {
-        if (hipMemsetAsync(a.gx, 0, (size_t)a.B * a.N * a.C * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+        if (launch_zero(a.gx, (size_t)a.B * a.N * a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
     }
     DeformBwdArgs b = a;
     const int ncc = a.C / 32, mblocks = cdiv(a.M, 128);
@@ -176,7 +176,7 @@ int launch_cl_deform_bwd(const DeformBwdArgs &a, hipStream_t st)
     b.cc_per_block = cdiv(ncc, zsplit);
     zsplit = cdiv(ncc, b.cc_per_block);
     if (zsplit > 1 && a.goff) {
-        if (hipMemsetAsync(a.goff, 0, (size_t)a.B * 3 * a.K * a.N * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+        if (launch_zero(a.goff, (size_t)a.B * 3 * a.K * a.N * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(cl_deform_bwd_kernel, dim3(mblocks, a.K, zsplit), dim3(256), 0, st, b);
     DLKA_CHECK_LAUNCH();

@@ -590,7 +590,7 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
     if (a.gx) {
         if (!scratch) return DLKA_ERR_WORKSPACE;
         const GxGeom g = pick_gx_geom(a);
-        if (hipMemsetAsync(a.gx, 0, (size_t)a.B * a.N * a.C * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+        if (launch_zero(a.gx, (size_t)a.B * a.N * a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         const size_t lds = (size_t)g.wvox_max * CS * sizeof(double) + (size_t)a.CoutP * 32 * sizeof(float);
         if (lds > 160 * 1024) return DLKA_ERR_UNSUPPORTED;
 #if !defined(HIPEMU)

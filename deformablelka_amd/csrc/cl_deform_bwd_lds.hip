@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256) void cl_deform_bwd_lds_kernel(DeformBwdArgs p,
 int launch_cl_deform_bwd_lds(const DeformBwdArgs &a, hipStream_t st)
 {
     if (a.C % CS) return DLKA_ERR_UNSUPPORTED;
-    if (a.gx && hipMemsetAsync(a.gx, 0, (size_t)a.B * a.N * a.C * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
-    if (a.goff && hipMemsetAsync(a.goff, 0, (size_t)a.B * 3 * a.K * a.N * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+    if (a.gx && launch_zero(a.gx, (size_t)a.B * a.N * a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
+    if (a.goff && launch_zero(a.goff, (size_t)a.B * 3 * a.K * a.N * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
     const int nbw = cdiv(a.W, BW), nbh = cdiv(a.H, BH), nbd = cdiv(a.D, BD);
     const int bricks = nbw * nbh * nbd * a.B, slices = a.C / CS;
     int groups = 1;

@@ -158,7 +158,7 @@ int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
     a.units_per_split = cdiv(a.K * (a.CinP / 32), splits);
     splits = cdiv(a.K * (a.CinP / 32), a.units_per_split);
     if (splits > 1) {
-        if (hipMemsetAsync(a.out, 0, (size_t)a.M * a.Cout * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+        if (launch_zero(a.out, (size_t)a.M * a.Cout * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
     }
     const int NT_total = a.NP / 32;
     const int mblocks = cdiv(a.M, 128);

@@ -189,8 +189,8 @@ int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st, boo
     a.rows_per_block = cdiv(rows, xb);
     xb = cdiv(rows, a.rows_per_block);
     if (zero_init) {   // (the fused block zeroes all of its accumulation targets with one memset)
-        if (hipMemsetAsync(a.gwp, 0, (size_t)a.kd * a.kh * kw * a.C * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
-        if (a.gb && hipMemsetAsync(a.gb, 0, (size_t)a.C * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+        if (launch_zero(a.gwp, (size_t)a.kd * a.kh * kw * a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
+        if (a.gb && launch_zero(a.gb, (size_t)a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
     }
     dim3 grid(xb, a.kd * a.kh, cdiv(a.C, cpb)), block(256);
     if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }

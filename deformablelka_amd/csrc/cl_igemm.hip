@@ -344,7 +344,7 @@ int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t s
     splits = cdiv(a.K * (a.CinP / 32), a.units_per_split);
     if (splits > 1) {
         const long n = (long)a.M * a.Cout;
-        if (hipMemsetAsync(a.out, 0, (size_t)n * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+        if (launch_zero(a.out, (size_t)n * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
     }
     if (amode == 0 && omode == 0) return launch_igemm_nt<0, 0>(a, splits, st);
     if (amode == 0 && omode == 1) return launch_igemm_nt<0, 1>(a, splits, st);

@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void cl_colsum_kernel(const float *__restrict_
 
 int launch_cl_colsum(const float *g, float *gb32, int M, int Cout, hipStream_t st)
 {
-    if (hipMemsetAsync(gb32, 0, (size_t)Cout * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+    if (launch_zero(gb32, (size_t)Cout * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
     int blocks = cdiv(M, 256);
     if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;

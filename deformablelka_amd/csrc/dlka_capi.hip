@@ -115,12 +115,12 @@ int deform_backward_t(const void *x, const void *off, const void *w, const void 
     if (!cv.ok() || !wt) return DLKA_ERR_WORKSPACE;
     if (gx || goff) {
         DLKA_TRY(launch_relayout_weight<T>((const T *)w, wt, g.group, g.Og, g.Cg, g.K, OgP, st));
-        if (gx32) { if (hipMemsetAsync(gx32, 0, nx * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH; }
+        if (gx32) { if (launch_zero(gx32, nx * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH; }
         DLKA_TRY((launch_deform_bwd_input_offset<T, NOFF>((const T *)x, (const T *)off, wt, OgP, (const T *)gout, gx32, (T *)goff, g, st)));
         if (gx && dtype != DLKA_F32) DLKA_TRY(launch_cast_from_f32<T>(gx32, (T *)gx, (long)nx, st));
     }
     if (gw) {
-        if (hipMemsetAsync(gw32, 0, nw * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+        if (launch_zero(gw32, nw * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         DLKA_TRY((launch_deform_bwd_weight<T, NOFF>((const T *)x, (const T *)off, (const T *)gout, gw32, g, st)));
         if (dtype != DLKA_F32) DLKA_TRY(launch_cast_from_f32<T>(gw32, (T *)gw, (long)nw, st));
     }
@@ -157,7 +157,7 @@ int conv_backward_t(const void *x, const void *w, const void *gout, void *gx, vo
     if (!cv.ok() || !wb) return DLKA_ERR_WORKSPACE;
     if (gx) DLKA_TRY(launch_conv_bwd_data<T>((const T *)gout, (const T *)w, (T *)gx, wb, g, st));
     if (gw) {
-        if (hipMemsetAsync(gw32, 0, nw * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+        if (launch_zero(gw32, nw * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         DLKA_TRY(launch_conv_bwd_weight<T>((const T *)x, (const T *)gout, gw32, g, st));
         if (dtype != DLKA_F32) DLKA_TRY(launch_cast_from_f32<T>(gw32, (T *)gw, (long)nw, st));
     }
@@ -250,7 +250,7 @@ int conv_bwd_all(const T *xin, const T *w, const T *gout, T *gx, void *gw, void 
     if (gx) DLKA_TRY(launch_conv_bwd_data<T>(gout, w, gx, scratch, g, st));
     if (gw) {
         float *gw32 = (dtype == DLKA_F32) ? (float *)gw : gw32buf;
-        if (hipMemsetAsync(gw32, 0, nw * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+        if (launch_zero(gw32, nw * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         DLKA_TRY(launch_conv_bwd_weight<T>(xin, gout, gw32, g, st));
         if (dtype != DLKA_F32) DLKA_TRY(launch_cast_from_f32<T>(gw32, (T *)gw, (long)nw, st));
     }
@@ -294,10 +294,10 @@ int lka3d_backward_t(const void *x_, const dlka_lka3d_params *p, const void *gy_
         float *gxa = (dtype == DLKA_F32) ? (float *)bA : gx32;
         float *gwa = (dtype == DLKA_F32) ? (float *)gr->deform_w : gw32;
         DLKA_TRY(launch_relayout_weight<T>((const T *)p->deform_w, scr, g.group, g.Og, g.Cg, g.K, OgP, st));
-        if (hipMemsetAsync(gxa, 0, nx * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+        if (launch_zero(gxa, nx * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         DLKA_TRY((launch_deform_bwd_input_offset<T, 3>(t, off, scr, OgP, bB, gxa, bO, g, st)));   // bA = gt_a, bO = goff
         if (dtype != DLKA_F32) DLKA_TRY(launch_cast_from_f32<T>(gxa, bA, (long)nx, st));
-        if (hipMemsetAsync(gwa, 0, nw * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+        if (launch_zero(gwa, nw * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         DLKA_TRY((launch_deform_bwd_weight<T, 3>(t, off, bB, gwa, g, st)));
         if (dtype != DLKA_F32) DLKA_TRY(launch_cast_from_f32<T>(gwa, (T *)gr->deform_w, (long)nw, st));
         DLKA_TRY(launch_bias_grad<T>(bB, (T *)gr->deform_b, g.B, g.Cout, g.No, st));
@@ -392,10 +392,10 @@ int deform2d_bwd_all(const T *xin, const T *off, const T *w, const T *go, T *gxi
     float *gxa = (dtype == DLKA_F32) ? (float *)gxin : gx32;
     float *gwa = (dtype == DLKA_F32) ? (float *)gw : gw32buf;
     DLKA_TRY(launch_relayout_weight<T>(w, scr, g.group, g.Og, g.Cg, g.K, OgP, st));
-    if (hipMemsetAsync(gxa, 0, nx * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+    if (launch_zero(gxa, nx * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
     DLKA_TRY((launch_deform_bwd_input_offset<T, 2>(xin, off, scr, OgP, go, gxa, goff, g, st)));
     if (dtype != DLKA_F32) DLKA_TRY(launch_cast_from_f32<T>(gxa, gxin, (long)nx, st));
-    if (hipMemsetAsync(gwa, 0, nw * 4, st) != hipSuccess) return DLKA_ERR_LAUNCH;
+    if (launch_zero(gwa, nw * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
     DLKA_TRY((launch_deform_bwd_weight<T, 2>(xin, off, go, gwa, g, st)));
     if (dtype != DLKA_F32) DLKA_TRY(launch_cast_from_f32<T>(gwa, (T *)gw, (long)nw, st));
     return DLKA_OK;

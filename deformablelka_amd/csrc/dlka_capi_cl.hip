@@ -582,7 +582,7 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
         return DLKA_OK;
     };
     DLKA_TRY(publish());   // fork: everything issued before this call (gy, saved activations, the previous block's use of the workspace)
-    if (hipMemsetAsync(stage5, 0, G.stage_dw() * 4, ws_) != hipSuccess) return DLKA_ERR_LAUNCH;   // the depthwise kernels accumulate with atomics
+    if (launch_zero(stage5, G.stage_dw() * 4, ws_) != DLKA_OK) return DLKA_ERR_LAUNCH;   // the depthwise kernels accumulate with atomics
 
     // proj_2:  y = P2 m + x.   Its data gradient gm = P2^T gy feeds only the gate  m = a * g1, whose backward is fused into
     // the epilogue:  gg1 = gm * a,  ga1 = gm * g1

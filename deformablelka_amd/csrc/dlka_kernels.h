@@ -35,6 +35,7 @@ template <typename T>
 int launch_conv_bwd_weight(const T *x, const T *gout, float *gw32, const Geom &g, hipStream_t st);
 
 // ---- eltwise.hip -------------------------------------------------------------------------------------------
+int launch_zero(void *ptr, size_t bytes, hipStream_t st);   // zero fill by kernel (graph-replay safe)
 template <typename T> int launch_gelu_fwd(const T *x, T *y, long n, hipStream_t st);
 template <typename T> int launch_gelu_bwd(const T *x, const T *gy, T *gx, long n, hipStream_t st);
 template <typename T> int launch_mul_fwd(const T *a, const T *b, T *y, long n, hipStream_t st);

@@ -59,6 +59,28 @@ template <typename T> int launch_mul_bwd(const T *a, const T *b, const T *gy, T 
 template <typename T> int launch_add_fwd(const T *a, const T *b, T *y, long n, hipStream_t st) { return launch_elt<T, 4>(a, b, nullptr, y, nullptr, n, st); }
 template <typename T> int launch_gelu_bwd_sum(const T *x, const T *g1, const T *g2, T *gx, long n, hipStream_t st) { return launch_elt<T, 5>(x, g1, g2, gx, nullptr, n, st); }
 
+// Zero fill as an ordinary kernel.  (hipMemsetAsync nodes captured into a hipGraph did not reproduce the eager result on
+// ROCm 7.2 / MI355X: from the second replay on, buffers zeroed this way held garbage — scripts/debug_graph.py.)
+__global__ __launch_bounds__(256) void zero_fill_kernel(float *__restrict__ p, long n4, long n)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) reinterpret_cast<f32x4 *>(p)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+}
+
+int launch_zero(void *ptr, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return DLKA_OK;
+    if (((uintptr_t)ptr & 15) || (bytes & 3)) return hipMemsetAsync(ptr, 0, bytes, st) == hipSuccess ? DLKA_OK : DLKA_ERR_LAUNCH;
+    const long n = (long)(bytes / 4), n4 = n / 4;
+    long blocks = cdivl(n4 > 0 ? n4 : n, 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (float *)ptr, n4, n);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
 #define DLKA_INST(T)                                                                    \
     template int launch_gelu_fwd<T>(const T *, T *, long, hipStream_t);                  \
     template int launch_gelu_bwd<T>(const T *, const T *, T *, long, hipStream_t);       \

@@ -142,5 +142,23 @@ class DLKABlockStack:
             dist.all_reduce(self.flat_grads)
         self.flat_params.add_(self.flat_grads, alpha=-lr / world)
 
+    def health(self) -> dict:
+        """Finite-ness of parameters / gradients and the std of the predicted offsets (voxels) of the first block of each
+        stage, read from the activations the last forward pass saved."""
+        finite = bool(torch.isfinite(self.flat_params).all().item() and torch.isfinite(self.flat_grads).all().item())
+        stds, seen = [], set()
+        a256 = lambda n: (n + 255) & ~255
+        for blk in self.blocks:
+            if blk.C in seen:
+                continue
+            seen.add(blk.C)
+            H, W, D = blk.dims
+            N = H * W * D
+            E, Off = self.B * blk.C * N, self.B * 81 * N
+            o = 4 * a256(E * 4)   # saved = h, a, t1, t, off, ...
+            off = blk.saved[o:o + Off * 4].view(torch.float32)
+            stds.append(round(float(off.std().item()), 3))
+        return {"finite": finite, "offset_std": stds}
+
     def num_params(self) -> int:
         return int(self.flat_params.numel())

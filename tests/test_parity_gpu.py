@@ -231,3 +231,30 @@ def test_tokens_full_size_stage0_matches_general_path():
     parity.assert_close("gx", xa.grad, xb.grad, rtol=2e-3)
     for k, p in m.named_parameters():
         parity.assert_close("grad " + k, ga[k], p.grad, rtol=2e-3)
+
+
+def test_hipgraph_replay_reproduces_eager():
+    """bench.py replays the 21-block step from a hipGraph: every replay must reproduce the eager result (a graph whose
+    zero-fills were hipMemsetAsync nodes did not, from the second replay on — scripts/debug_graph.py)."""
+    from deformablelka_amd.stack import DLKABlockStack
+    st = DLKABlockStack(2, stages=((32, (8, 8, 8), 1), (64, (8, 8, 8), 1), (256, (4, 4, 4), 1)), device="cuda:0", seed=3)
+    st.forward_backward()
+    torch.cuda.synchronize()
+    ref = [g.clone() for b in st.blocks for g in b.grads] + [b.gx.clone() for b in st.blocks] + [b.y.clone() for b in st.blocks]
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        st.forward_backward()
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        st.forward_backward()
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        cur = [g_.clone() for b in st.blocks for g_ in b.grads] + [b.gx.clone() for b in st.blocks] + [b.y.clone() for b in st.blocks]
+        for a, c in zip(ref, cur):
+            assert torch.isfinite(c).all()
+            scale = max(float(a.abs().max()), 1e-6)
+            assert float((a - c).abs().max()) <= 2e-3 * scale   # atomics order only
+    assert st.health()["finite"]
