@@ -398,7 +398,7 @@ __device__ __host__ __forceinline__ void gx_window(int b0, int bsz, int size, in
     len = hi - lo;
 }
 
-__global__ __launch_bounds__(256) void cl_deform_gx_kernel(DeformBwdArgs p, GxGeom gg, float *__restrict__ scratch)
+__global__ __launch_bounds__(1024) void cl_deform_gx_kernel(DeformBwdArgs p, GxGeom gg, float *__restrict__ scratch)
 {
     DLKA_DYN_SMEM(unsigned char, smem);
     double *Win = reinterpret_cast<double *>(smem);                                        // [CS][wvox]
@@ -602,7 +602,9 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         }
 #endif
         const int bricks = a.B * g.nbd * g.nbh * g.nbw;
-        hipLaunchKernelGGL(cl_deform_gx_kernel, dim3(bricks, g.nslices), dim3(256), lds, st, a, g, scratch);
+        static int gx_threads = 0;
+        if (!gx_threads) { const char *e = getenv("DLKA_GX_THREADS"); gx_threads = e ? atoi(e) : 512; if (gx_threads != 256 && gx_threads != 512 && gx_threads != 1024) gx_threads = 512; }
+        hipLaunchKernelGGL(cl_deform_gx_kernel, dim3(bricks, g.nslices), dim3(gx_threads), lds, st, a, g, scratch);
         DLKA_CHECK_LAUNCH();
         const long total = (long)a.B * a.N * g.nslices;
         long gb = cdivl(total, 256);

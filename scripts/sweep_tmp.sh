@@ -1,1 +1,1 @@
-for t in 0 3 4 7; do for st in "32 32" "64 16"; do set -- $st; echo -n "deform wgrad TPW=$t C=$1: "; DLKA_WGRAD_DEFORM_TPW=$t python scripts/prof_op.py --C $1 --N $2 --iters 20 --ops deform_bwd_weight | tr '\n' ' '; echo; done; done
+for t in 256 512 1024; do echo -n "gx threads=$t: "; DLKA_GX_THREADS=$t python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c60-180; done
