@@ -388,6 +388,7 @@ struct GxGeom {
     int wvox_max;           // (bd + 2 HALO)(bh + 2 HALO)(bw + 2 HALO), each factor clipped to the volume
     int nslices;            // C / CS
     int ngroups;            // ceil(K / TG)
+    int resident;           // all tap groups' weight tiles fit in LDS next to the window
 };
 
 __device__ __host__ __forceinline__ void gx_window(int b0, int bsz, int size, int &lo, int &len)
@@ -398,7 +399,7 @@ __device__ __host__ __forceinline__ void gx_window(int b0, int bsz, int size, in
     len = hi - lo;
 }
 
-__global__ __launch_bounds__(1024) void cl_deform_gx_kernel(DeformBwdArgs p, GxGeom gg, float *__restrict__ scratch)
+__global__ __launch_bounds__(512) void cl_deform_gx_kernel(DeformBwdArgs p, GxGeom gg, float *__restrict__ scratch)
 {
     DLKA_DYN_SMEM(unsigned char, smem);
     double *Win = reinterpret_cast<double *>(smem);                                        // [CS][wvox]
@@ -421,71 +422,108 @@ __global__ __launch_bounds__(1024) void cl_deform_gx_kernel(DeformBwdArgs p, GxG
 
     for (int e = tid; e < wvox * CS; e += blockDim.x) Win[e] = 0.0;
 
-    for (int grp = 0; grp < gg.ngroups; ++grp) {
-        __syncthreads();   // Bs consumed by every wave (first pass: window zeroed)
-        // A operand tile: Bs[co][t8*4 + c4] = W[co][slice*4 + c4][tap = grp*8 + t8]   (wp[tap][co][ci], zero beyond K)
+    // A operand tile of group grp: Bs[co][t8*4 + c4] = W[co][slice*4 + c4][tap = grp*8 + t8]   (wp[tap][co][ci], zero beyond K)
+    auto stage_weights = [&](int grp, float *dstB) {
         for (int e = tid; e < p.CoutP * TG; e += blockDim.x) {
             const int co = e / TG, t8 = e - co * TG, tap = grp * TG + t8;
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
             if (tap < p.K) val = *reinterpret_cast<const f32x4 *>(p.wp + ((long)tap * p.CoutP + co) * p.C + slice * CS);
-            reinterpret_cast<f32x4 *>(Bs)[e] = val;
+            reinterpret_cast<f32x4 *>(dstB)[e] = val;
         }
-        __syncthreads();
-        for (int tile = wave; tile < ntiles; tile += nwaves) {
-            const int row = tile * 32 + j;
-            const int rw = row % gg.bw, rh = (row / gg.bw) % gg.bh, rd = row / (gg.bw * gg.bh);
-            const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
-            const bool ok = row < R && vd < p.D && vh < p.H && vw < p.W;
-            const int v = ok ? (vd * p.H + vh) * p.W + vw : 0;
-            const long m = (long)b * p.N + v;
-            f32x16 acc;
+    };
+    auto load_g = [&](int tile, int kc, float *gl) {
+        const int row = tile * 32 + j;
+        const int rw = row % gg.bw, rh = (row / gg.bw) % gg.bh, rd = row / (gg.bw * gg.bh);
+        const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
+        const bool ok = row < R && vd < p.D && vh < p.H && vw < p.W && kc * 32 + 16 * h < p.Cout;
+        const long m = (long)b * p.N + (ok ? (vd * p.H + vh) * p.W + vw : 0);
+        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(p.g + (ok ? m * p.Cout + kc * 32 + 16 * h : 0));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            for (int kc = 0; kc < nkc; ++kc) {
-                float gl[16];
-                if (ok && kc * 32 + 16 * h < p.Cout) {
-                    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(p.g + m * p.Cout + kc * 32 + 16 * h);
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 t = g4[e];
+            gl[4 * e] = ok ? t[0] : 0.f; gl[4 * e + 1] = ok ? t[1] : 0.f; gl[4 * e + 2] = ok ? t[2] : 0.f; gl[4 * e + 3] = ok ? t[3] : 0.f;
+        }
+    };
+
+    // one (32-voxel tile, 8-tap group): Col on the matrix cores, then the scatter
+    auto tile_group = [&](int tile, int grp, const float *Bg, const float (*gl)[16], bool reload) {
+        const int row = tile * 32 + j;
+        const int rw = row % gg.bw, rh = (row / gg.bw) % gg.bh, rd = row / (gg.bw * gg.bh);
+        const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
+        const bool ok = row < R && vd < p.D && vh < p.H && vw < p.W;
+        const int v = ok ? (vd * p.H + vh) * p.W + vw : 0;
+        f32x16 acc;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const f32x4 t = g4[e];
-                        gl[4 * e] = t[0]; gl[4 * e + 1] = t[1]; gl[4 * e + 2] = t[2]; gl[4 * e + 3] = t[3];
-                    }
-                } else {
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (!reload) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) gl[e] = 0.f;
-                }
-                const float *arow = Bs + (kc * 32 + 16 * h) * 32 + j;   // A[i = (t8, c4) = j][k = co]
+            for (int kc = 0; kc < 4; ++kc) {   // static indices keep gl in registers
+                if (kc >= nkc) break;
+                const float *arow = Bg + (kc * 32 + 16 * h) * 32 + j;   // A[i = (t8, c4) = j][k = co]
 #pragma unroll
-                for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], gl[st], acc);
+                for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], gl[kc][st], acc);
             }
+        } else {
+            for (int kc = 0; kc < nkc; ++kc) {
+                float g1[16];
+                load_g(tile, kc, g1);
+                const float *arow = Bg + (kc * 32 + 16 * h) * 32 + j;
+#pragma unroll
+                for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], g1[st], acc);
+            }
+        }
+        {
             // acc[r]: MFMA row (r&3) + 8*(r>>2) + 4h  ->  c4 = r & 3, t8 = 2*(r>>2) + h;   column = voxel j
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int tap = grp * TG + 2 * r4 + h;
-                if (!ok || tap >= p.K) continue;
-                const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
-                LaneTap s;
-                lane_tap(s, p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v, p.N, vd + ti * p.dd - p.pd, vh + tj * p.dh - p.ph, vw + tk * p.dw - p.pw,
-                         p.D, p.H, p.W);
-                if (!s.okm) continue;
-                const float fd[2] = {1.f - s.ld, s.ld}, fh[2] = {1.f - s.lh, s.lh}, fw[2] = {1.f - s.lw, s.lw};
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int tap = grp * TG + 2 * r4 + h;
+            if (!ok || tap >= p.K) continue;
+            const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
+            LaneTap s;
+            lane_tap(s, p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v, p.N, vd + ti * p.dd - p.pd, vh + tj * p.dh - p.ph, vw + tk * p.dw - p.pw,
+                     p.D, p.H, p.W);
+            if (!s.okm) continue;
+            const float fd[2] = {1.f - s.ld, s.ld}, fh[2] = {1.f - s.lh, s.lh}, fw[2] = {1.f - s.lw, s.lw};
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    if (!((s.okm >> q) & 1u)) continue;
-                    const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
-                    const float wq = fd[cd] * fh[ch] * fw[cw];
-                    const int zd = s.zd + cd, zh = s.zh + ch, zw = s.zw + cw;       // inside the volume (okm)
-                    const int xd = zd - wd0, xh = zh - wh0, xw = zw - ww0;
-                    if ((unsigned)xd < (unsigned)WD && (unsigned)xh < (unsigned)WH && (unsigned)xw < (unsigned)WW) {
-                        double *cell = Win + (xd * WH + xh) * WW + xw;
+            for (int q = 0; q < 8; ++q) {
+                if (!((s.okm >> q) & 1u)) continue;
+                const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
+                const float wq = fd[cd] * fh[ch] * fw[cw];
+                const int zd = s.zd + cd, zh = s.zh + ch, zw = s.zw + cw;       // inside the volume (okm)
+                const int xd = zd - wd0, xh = zh - wh0, xw = zw - ww0;
+                if ((unsigned)xd < (unsigned)WD && (unsigned)xh < (unsigned)WH && (unsigned)xw < (unsigned)WW) {
+                    double *cell = Win + (xd * WH + xh) * WW + xw;
 #pragma unroll
-                        for (int c = 0; c < CS; ++c) atomicAdd(cell + c * wvox, (double)(acc[4 * r4 + c] * wq));
-                    } else {
-                        float *dst = p.gx + ((long)b * p.N + (long)(zd * p.H + zh) * p.W + zw) * p.C + slice * CS;
+                    for (int c = 0; c < CS; ++c) atomicAdd(cell + c * wvox, (double)(acc[4 * r4 + c] * wq));
+                } else {
+                    float *dst = p.gx + ((long)b * p.N + (long)(zd * p.H + zh) * p.W + zw) * p.C + slice * CS;
 #pragma unroll
-                        for (int c = 0; c < CS; ++c) atomicAdd(dst + c, acc[4 * r4 + c] * wq);
-                    }
+                    for (int c = 0; c < CS; ++c) atomicAdd(dst + c, acc[4 * r4 + c] * wq);
                 }
+            }
+        }
+        }
+    };
+    if (gg.resident) {
+        // all tap groups' weights stay in LDS: a tile's grad_out rows are loaded ONCE (registers) for its 4 groups and the
+        // main loop has no workgroup barrier.  (Measured before: grad_out re-read per group and slice = 377 MB of L2->HBM
+        // traffic against 8 MB of data, profiles/r01j_pmc.)
+        for (int grp = 0; grp < gg.ngroups; ++grp) stage_weights(grp, Bs + (size_t)grp * p.CoutP * 32);
+        __syncthreads();   // also: window zeroed
+        for (int tile = wave; tile < ntiles; tile += nwaves) {
+            float gl[4][16];
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc)
+                if (kc < nkc) load_g(tile, kc, gl[kc]);
+            for (int grp = 0; grp < gg.ngroups; ++grp) tile_group(tile, grp, Bs + (size_t)grp * p.CoutP * 32, gl, false);
+        }
+    } else {
+        for (int grp = 0; grp < gg.ngroups; ++grp) {
+            __syncthreads();   // Bs consumed by every wave (first pass: window zeroed)
+            stage_weights(grp, Bs);
+            __syncthreads();
+            for (int tile = wave; tile < ntiles; tile += nwaves) {
+                tile_group(tile, grp, Bs, nullptr, true);
             }
         }
     }
@@ -591,7 +629,10 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         if (!scratch) return DLKA_ERR_WORKSPACE;
         const GxGeom g = pick_gx_geom(a);
         if (launch_zero(a.gx, (size_t)a.B * a.N * a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
-        const size_t lds = (size_t)g.wvox_max * CS * sizeof(double) + (size_t)a.CoutP * 32 * sizeof(float);
+        GxGeom gl_ = g;
+        const size_t lds_all = (size_t)g.wvox_max * CS * sizeof(double) + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
+        gl_.resident = (lds_all <= 150 * 1024 && a.CoutP <= 128) ? 1 : 0;
+        const size_t lds = gl_.resident ? lds_all : (size_t)g.wvox_max * CS * sizeof(double) + (size_t)a.CoutP * 32 * sizeof(float);
         if (lds > 160 * 1024) return DLKA_ERR_UNSUPPORTED;
 #if !defined(HIPEMU)
         static bool attr_done = false;   // dynamic LDS above 64 KB has to be enabled once per function
@@ -603,8 +644,8 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
 #endif
         const int bricks = a.B * g.nbd * g.nbh * g.nbw;
         static int gx_threads = 0;
-        if (!gx_threads) { const char *e = getenv("DLKA_GX_THREADS"); gx_threads = e ? atoi(e) : 512; if (gx_threads != 256 && gx_threads != 512 && gx_threads != 1024) gx_threads = 512; }
-        hipLaunchKernelGGL(cl_deform_gx_kernel, dim3(bricks, g.nslices), dim3(gx_threads), lds, st, a, g, scratch);
+        if (!gx_threads) { const char *e = getenv("DLKA_GX_THREADS"); gx_threads = e ? atoi(e) : 512; if (gx_threads != 256 && gx_threads != 512) gx_threads = 512; }
+        hipLaunchKernelGGL(cl_deform_gx_kernel, dim3(bricks, g.nslices), dim3(gx_threads), lds, st, a, gl_, scratch);
         DLKA_CHECK_LAUNCH();
         const long total = (long)a.B * a.N * g.nslices;
         long gb = cdivl(total, 256);
