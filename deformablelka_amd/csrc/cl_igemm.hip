@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
             float val = acc[t][r] + bv;
             const long o = (long)mr * p.Cout + n;
             if (split) {
+                if (p.epi == 3 && blockIdx.y == 0) val += p.aux[o];   // the residual / fan-in term enters once
                 atomicAdd(p.out + o, val);
             } else if (p.epi == 0) {
                 p.out[o] = val;
@@ -324,7 +325,7 @@ static int launch_igemm_nt(const IgemmArgs &a, int splits, hipStream_t st)
 // Picks the tap split so that small-spatial stages still fill the chip; returns the number of splits.
 int cl_igemm_pick_splits(int M, int units, int epi)
 {
-    if (epi != 0 || units == 1) return 1;
+    if ((epi != 0 && epi != 3) || units == 1) return 1;   // epilogues 0 and 3 are linear in the accumulator: splittable
     const int mblocks = cdiv(M, 128);
     // Split partial sums meet in global fp32 atomics on the SAME addresses: measured on MI355X (profiles/r01e), 216-way
     // splits of the C=256 / 4^3 offset conv cost 130 us, almost all of it same-address serialisation in L2.  Bound the
