@@ -72,7 +72,11 @@ def op_table(B, C, N, dtype_bytes):
     t["dw7_bwd_weight"] = (2 * 343 * E, 2 * E * s)
     t["offset_conv_bwd_data"] = (2 * 27 * C * 81 * B * n, (E + Off) * s)
     t["offset_conv_bwd_weight"] = (2 * 27 * C * 81 * B * n, (E + Off) * s)
-    t["deform_bwd_input_offset"] = (2 * 27 * C * C * B * n + 27 * B * n * (45 * C + 60), (3 * E + 2 * Off) * s)
+    # grad_input (brick scatter): Col = G W_tap^T on the matrix cores + 8 corners x C multiply-adds per (voxel, tap);
+    # reads grad_out, offsets, writes grad_input.   grad_offset (gather): Col again + 8 x C dot products + 3 x 8 blends;
+    # reads x, grad_out, offsets, writes grad_offset.
+    t["deform_bwd_input"] = (2 * 27 * C * C * B * n + 27 * B * n * (16 * C), (2 * E + Off) * s)
+    t["deform_bwd_offset"] = (2 * 27 * C * C * B * n + 27 * B * n * (16 * C + 48), (2 * E + 2 * Off) * s)
     t["deform_bwd_weight"] = (2 * 27 * C * C * B * n + 27 * B * n * (15 * C + 30), (2 * E + Off) * s)
     return t
 
@@ -127,7 +131,8 @@ def time_ops(B, C, N, dtype, iters=10, only=None):
         "dw7_bwd_weight": conv_bwd("dw7", w7, x, go, None, gw7),
         "offset_conv_bwd_data": conv_bwd("off", w_off, x, goff, out, None, 1),
         "offset_conv_bwd_weight": conv_bwd("off", w_off, x, goff, None, gw_off, 1),
-        "deform_bwd_input_offset": lambda: lib.dlka_deform_conv3d_backward_cl(P(x), P(off), P(w_dc), P(go), P(out), P(out_off), P(N0), P(N0), P(ws), wsb, byref(G["dcn"]), dt, st),
+        "deform_bwd_input": lambda: lib.dlka_deform_conv3d_backward_cl(P(x), P(off), P(w_dc), P(go), P(out), P(N0), P(N0), P(N0), P(ws), wsb, byref(G["dcn"]), dt, st),
+        "deform_bwd_offset": lambda: lib.dlka_deform_conv3d_backward_cl(P(x), P(off), P(w_dc), P(go), P(N0), P(out_off), P(N0), P(N0), P(ws), wsb, byref(G["dcn"]), dt, st),
         "deform_bwd_weight": lambda: lib.dlka_deform_conv3d_backward_cl(P(x), P(off), P(w_dc), P(go), P(N0), P(N0), P(gw_dc), P(N0), P(ws), wsb, byref(G["dcn"]), dt, st),
     }
     res = {}
@@ -150,6 +155,19 @@ def time_ops(B, C, N, dtype, iters=10, only=None):
 
 # launches of each op per stage-block fwd+bwd (3 pointwise convs per block)
 OP_COUNT = {"pointwise_fwd": 3, "pointwise_bwd_data": 3, "pointwise_bwd_weight": 3}
+# the HIP kernel that carries each op (rocprofv3 --kernel-trace name) and what else the op launches
+OP_KERNEL = {
+    "deform_bwd_input": ("dlka::cl_deform_gx_kernel", "+ cl_prep_weight (5 us) + zero_fill (5 us) + cl_deform_gx_gather_kernel (13 us)"),
+    "deform_bwd_offset": ("dlka::cl_deform_goff2_kernel<1>", "+ cl_prep_weight (5 us)"),
+    "deform_fwd": ("dlka::cl_deform_fwd_kernel<1>", "+ cl_prep_weight (5 us)"),
+    "deform_bwd_weight": ("dlka::cl_wgrad_deform_kernel<3>", "+ cl_wgrad_reduce_kernel (13 us)"),
+    "offset_conv_fwd": ("dlka::cl_igemm_kernel<0, 1, 3>", "+ cl_prep_weight (5 us)"),
+    "offset_conv_bwd_data": ("dlka::cl_igemm_kernel<2, 0, 1>", "+ cl_prep_weight (5 us)"),
+    "offset_conv_bwd_weight": ("dlka::cl_wgrad_dense_kernel<1, 3, 3, true>", "+ cl_wgrad_reduce_kernel (9 us)"),
+    "dw7_fwd": ("dlka::cl_dwconv_kernel<7, 3, 8>", "+ cl_dw_prep_weight (5 us)"),
+    "dw7_bwd_data": ("dlka::cl_dwconv_kernel<7, 3, 8>", "+ cl_dw_prep_weight (5 us)"),
+    "dw7_bwd_weight": ("dlka::cl_dwconv_wgrad_kernel<7, 3, 8>", "+ zero_fill + cl_dw_unprep"),
+}
 
 
 def roofline_report(B, dtype):
@@ -174,14 +192,16 @@ def roofline_report(B, dtype):
     else:
         ach, peak, unit, bound = by / (t * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/pmc_traffic.sh)
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(name)
+            traffic = json.load(open(pmc)).get(name, {}).get("traffic_bytes_per_launch")
         except Exception:
             traffic = None
+    kern, extra = OP_KERNEL.get(name, (name, ""))
     return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5),
-            "traffic": traffic, "kernel": name, "kernel_ms": round(t, 4), "algorithmic_flops": fl, "algorithmic_bytes": by,
+            "traffic": traffic, "kernel": kern, "op": name, "op_also_launches": extra,
+            "kernel_ms": round(t, 4), "algorithmic_flops": fl, "algorithmic_bytes": by,
             "shape": f"C={C},{N}^3,B={B}", "per_op_ms": {k: round(v, 4) for k, v in ms.items()}}
 
 

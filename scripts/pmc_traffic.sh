@@ -8,7 +8,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-OPS=${OPS:-deform_bwd_input_offset,deform_fwd,offset_conv_fwd,offset_conv_bwd_data,offset_conv_bwd_weight,deform_bwd_weight,dw7_fwd,dw7_bwd_weight,pointwise_fwd}
+OPS=${OPS:-deform_bwd_input,deform_bwd_offset,deform_fwd,offset_conv_fwd,offset_conv_bwd_data,offset_conv_bwd_weight,deform_bwd_weight,dw7_fwd,dw7_bwd_weight,pointwise_fwd}
 for op in ${OPS//,/ }; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/$op/$ctr -o t -- python $R/scripts/prof_op.py --C 32 --N 32 --iters 3 --ops $op > $O/$op.$ctr.log 2>&1

@@ -6,7 +6,7 @@ TAG=$1; shift
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
-OPS=${OPS:-deform_bwd_input_offset,deform_bwd_weight,offset_conv_bwd_weight,deform_fwd,offset_conv_fwd}
+OPS=${OPS:-deform_bwd_input,deform_bwd_offset,deform_bwd_weight,offset_conv_bwd_weight,deform_fwd,offset_conv_fwd}
 cd /tmp
 for st in "$@"; do
   set -- $st
