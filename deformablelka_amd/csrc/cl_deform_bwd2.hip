@@ -578,14 +578,27 @@ __global__ __launch_bounds__(256) void cl_deform_gx_gather_kernel(DeformBwdArgs 
 static GxGeom pick_gx_geom(const DeformBwdArgs &a)
 {
     GxGeom g;
-    g.bd = a.D < 8 ? a.D : 8; g.bh = a.H < 8 ? a.H : 8; g.bw = a.W < 8 ? a.W : 8;
+    // Bricks are long along W: the 32 voxels of a wave tile are then consecutive in w, and with spatially smooth offsets
+    // their corner cells are consecutive fp64 cells of the window — distinct LDS banks (a cubic 8x8x8 brick puts 4 short
+    // w-rows in a tile, whose cells collide).  DLKA_GX_BRICK=cube restores the cubic shape for A/B runs.
+    static const bool cube = getenv("DLKA_GX_BRICK") != nullptr;
+    if (cube) {
+        g.bd = a.D < 8 ? a.D : 8; g.bh = a.H < 8 ? a.H : 8; g.bw = a.W < 8 ? a.W : 8;
+    } else {
+        g.bw = a.W < 32 ? a.W : 32;
+        g.bh = a.H < 4 ? a.H : 4;
+        int rest = 512 / (g.bw * g.bh);
+        if (rest < 1) rest = 1;
+        g.bd = a.D < rest ? a.D : rest;
+        if (g.bd > 8) g.bd = 8;
+    }
     g.nslices = a.C / CS;
     g.ngroups = cdiv(a.K, TG);
     auto blocks = [&]() { return (long)a.B * cdiv(a.D, g.bd) * cdiv(a.H, g.bh) * cdiv(a.W, g.bw) * g.nslices; };
     // enough workgroups to cover the 256 CUs; keep at least one 32-row tile per brick
     while (blocks() < 256 && g.bd * g.bh * g.bw > 32) {
-        if (g.bd >= g.bh && g.bd >= g.bw && g.bd > 1) g.bd = cdiv(g.bd, 2);
-        else if (g.bh >= g.bw && g.bh > 1) g.bh = cdiv(g.bh, 2);
+        if (g.bd >= g.bh && g.bd > 1) g.bd = cdiv(g.bd, 2);
+        else if (g.bh > 1) g.bh = cdiv(g.bh, 2);
         else g.bw = cdiv(g.bw, 2);
     }
     g.nbd = cdiv(a.D, g.bd); g.nbh = cdiv(a.H, g.bh); g.nbw = cdiv(a.W, g.bw);

@@ -5,6 +5,8 @@
 // channels (every load / store is a contiguous 128-byte-per-32-lanes row piece of the [voxel][C] layout), each
 // work-item owns TW consecutive outputs along W and slides the KW taps over one input row segment held in registers
 // (TW + (KW-1)*DIL loads feed TW*KW FMAs).  Same kernel = forward and data gradient (flipped taps, no bias).
+#include <stdlib.h>
+
 #include "cl_args.h"
 #include "dlka_kernels.h"
 
@@ -185,7 +187,9 @@ int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st, boo
     const int cpb = a.C < 256 ? a.C : 256;
     if (256 % cpb != 0) return DLKA_ERR_UNSUPPORTED;
     const int rows = a.B * a.D * a.H;
-    int xb = rows < 64 ? rows : 64;                 // row-chunks: bounded atomics, enough blocks with grid.y = kd*kh
+    static int xb_env = 0;
+    if (!xb_env) { const char *e = getenv("DLKA_DWW_XB"); xb_env = e ? atoi(e) : 64; if (xb_env < 1) xb_env = 64; }
+    int xb = rows < xb_env ? rows : xb_env;         // row-chunks: bounded atomics, enough blocks with grid.y = kd*kh
     a.rows_per_block = cdiv(rows, xb);
     xb = cdiv(rows, a.rows_per_block);
     if (zero_init) {   // (the fused block zeroes all of its accumulation targets with one memset)

@@ -1,1 +1,3 @@
-for v in 0 1; do for st in "32 32" "64 16" "128 8" "256 4"; do set -- $st; echo -n "dwconv v1=$v C=$1: "; if [ $v = 1 ]; then export DLKA_DWCONV_V1=1; else unset DLKA_DWCONV_V1; fi; python scripts/prof_op.py --C $1 --N $2 --iters 20 --ops dw5_fwd,dw7_fwd,dw7_bwd_data | tr '\n' ' '; echo; done; done
+echo -n "long bricks: "; python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c60-180
+echo -n "cubic bricks: "; DLKA_GX_BRICK=cube python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c60-180
+python scripts/prof_op.py --C 32 --N 32 --iters 20 --ops deform_bwd_input
