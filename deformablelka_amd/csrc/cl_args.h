@@ -17,6 +17,7 @@ struct IgemmArgs {
     int Cin, CinReal, CinP, Cout, NP;
     int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
     int units_per_split; // work units (tap, 32-channel chunk) per blockIdx.y; K * CinP/32 when gridDim.y == 1
+    int split_bf16;      // 1: contraction on the bf16 matrix cores with two-term split operands (weights prepared with mode | 8)
     int epi;             // 0: out = acc+bias | 1: out = acc+bias, out2 = gelu(out) | 2: out = acc+bias, out2 = aux*out | 3: out = acc+bias+aux
                          // 4: out = (acc+bias)*aux, out2 = (acc+bias)*aux2   (gate backward fused into proj_2's data gradient)
 };
@@ -57,7 +58,7 @@ struct PrepJob {
     const float *src;   // weight in the reference layout
     float *dst;         // prepared layout
     int Cout, Cin, K, KP, NP;
-    int mode;           // 0 fwd, 1 data-grad (flipped), 2 column matrix; 3 depthwise, 4 depthwise flipped
+    int mode;           // 0 fwd, 1 data-grad (flipped), 2 column matrix (| 8: bf16 split layout); 3 depthwise, 4 depthwise flipped
     long n;             // elements of dst
 };
 struct PrepBatch {

@@ -12,7 +12,7 @@
 
 namespace dlka {
 
-template <int KW, int DIL, int TW>
+template <int KW, int DIL, int TW, int ABL = 0>   // ABL: ablation for profiling only (1 = no input loads, 2 = no FMAs)
 __global__ __launch_bounds__(256) void cl_dwconv_kernel(DwArgs p)
 {
     constexpr int SEG = TW + (KW - 1) * DIL;
@@ -43,9 +43,16 @@ __global__ __launch_bounds__(256) void cl_dwconv_kernel(DwArgs p)
 #pragma unroll
             for (int e = 0; e < SEG; ++e) {
                 const int zw = w0 - p.pw + e;
-                seg[e] = (zw >= 0 && zw < p.W) ? rowp[(long)zw * p.C] : 0.f;
+                seg[e] = (ABL == 1) ? (float)(e + zh) : ((zw >= 0 && zw < p.W) ? rowp[(long)zw * p.C] : 0.f);
             }
             const float *wrow = p.wp + (long)((i * p.kh + j) * KW) * p.C + c;
+            if (ABL == 2) {
+#pragma unroll
+                for (int e = 0; e < SEG; ++e) acc[e % TW] += seg[e];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) acc[k % TW] += wrow[(long)k * p.C];
+                continue;
+            }
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
                 const float wv = wrow[(long)k * p.C];
@@ -86,7 +93,12 @@ int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st)
     dim3 grid((unsigned)cdivl(runs, rpb), 1, cdiv(a.C, cpb)), block(256);
     if (256 % cpb != 0) return DLKA_ERR_UNSUPPORTED;
     if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-    else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else if (kw == 7 && dil_w == 3) {
+        static const int abl = getenv("DLKA_DW_ABL") ? atoi(getenv("DLKA_DW_ABL")) : 0;   // profiling ablation only
+        if (abl == 1) { auto k = cl_dwconv_kernel<7, 3, TW, 1>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else if (abl == 2) { auto k = cl_dwconv_kernel<7, 3, TW, 2>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else { auto k = cl_dwconv_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    }
     else if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_kernel<3, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
     else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_kernel<5, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
     else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_kernel<7, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }

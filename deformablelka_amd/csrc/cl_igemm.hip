@@ -91,7 +91,10 @@ struct ARow {
     }
 };
 
-template <int AMODE, int OMODE, int NT>
+// SPLIT: the contraction runs on the bf16 matrix cores with two-term split operands (dlka_intrin.h: hi*hi + hi*lo + lo*hi,
+// fp32 accumulation, ~1e-5 relative) instead of the exact fp32-input MFMA: 6 x 32 cycles per 32-channel unit and column tile
+// instead of 16 x 64.  The prepared weights then hold, per unit, the blocks [hi|lo][k half mf][lane half h][NP][8 bf16].
+template <int AMODE, int OMODE, int NT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
 {
     constexpr int NPB = NT * 32;                 // columns handled by this block
@@ -125,11 +128,16 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
 #define DLKA_LOAD_B(unit_)                                                                         \
     {                                                                                              \
         const int tap_ = (unit_) / nchunk, ck_ = (unit_) - tap_ * nchunk;                          \
-        const float *src_ = p.wp + ((long)tap_ * p.CinP + ck_ * 32) * p.NP + n0;                   \
+        const float *src_ = p.wp + ((long)tap_ * p.CinP + ck_ * 32) * p.NP + (SPLIT ? 0 : n0);     \
         _Pragma("unroll") for (int e = 0; e < BV; ++e) {                                           \
             const int idx_ = tid + e * 256;                                                        \
-            const int rr_ = idx_ / (NPB / 4), c4_ = idx_ - rr_ * (NPB / 4);                        \
-            breg[e] = reinterpret_cast<const f32x4 *>(src_ + (long)rr_ * p.NP)[c4_];              \
+            if (SPLIT) {   /* 8 segments (part, mf, h) of NPB 16-byte column records */            \
+                const int seg_ = idx_ / NPB, col_ = idx_ - seg_ * NPB;                              \
+                breg[e] = reinterpret_cast<const f32x4 *>(src_)[(long)seg_ * p.NP + n0 + col_];    \
+            } else {                                                                               \
+                const int rr_ = idx_ / (NPB / 4), c4_ = idx_ - rr_ * (NPB / 4);                    \
+                breg[e] = reinterpret_cast<const f32x4 *>(src_ + (long)rr_ * p.NP)[c4_];          \
+            }                                                                                      \
         }                                                                                          \
     }
     if (unit_lo < unit_hi) {
@@ -149,11 +157,27 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
             const int tap = (unit + 1) / nchunk;
             arow.fetch(p, rin, tap, unit + 1 - tap * nchunk, h, row_ok, b, v, d0, h0, w0, a_nxt);
         }
-        const float *brow = Bs[buf] + (16 * h) * NPB + i;
+        if (SPLIT) {
+            const bf16x8 *B16 = reinterpret_cast<const bf16x8 *>(Bs[buf]);   // [(part*2 + mf)*2 + h][NPB] records of 8 bf16
 #pragma unroll
-        for (int st = 0; st < 16; ++st) {
+            for (int mf = 0; mf < 2; ++mf) {
+                bf16x8 ahi, alo;
+                split_bf16x8(a_cur + 8 * mf, ahi, alo);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x2(a_cur[st], brow[st * NPB + t * 32], acc[t]);
+                for (int t = 0; t < NT; ++t) {
+                    const bf16x8 bhi = B16[((0 * 2 + mf) * 2 + h) * NPB + t * 32 + i], blo = B16[((1 * 2 + mf) * 2 + h) * NPB + t * 32 + i];
+                    acc[t] = mfma_32x32x16_bf16(alo, bhi, acc[t]);   // small terms first
+                    acc[t] = mfma_32x32x16_bf16(ahi, blo, acc[t]);
+                    acc[t] = mfma_32x32x16_bf16(ahi, bhi, acc[t]);
+                }
+            }
+        } else {
+            const float *brow = Bs[buf] + (16 * h) * NPB + i;
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x2(a_cur[st], brow[st * NPB + t * 32], acc[t]);
+            }
         }
     }
 
@@ -228,20 +252,33 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
 //   mode 1 (data gradient):  k = co, n = ci, tap' = K-1-tap   (correlation with the flipped kernel)
 //   mode 2 (column matrix):  k = co, n = ci, tap' = tap       (Col = G * W[:, :, tap] in the deformable backward)
 // ---------------------------------------------------------------------------------------------
+// prepared value of element (tap' tp, k, n); mode & 8 selects the bf16 split layout (see prep_store)
+__device__ __forceinline__ float prep_value(const float *__restrict__ w, int Cout, int Cin, int K, int mode, int tp, int k, int n)
+{
+    const int m = mode & 7;
+    if (m == 0) return (k < Cin && n < Cout) ? w[((long)n * Cin + k) * K + tp] : 0.f;
+    if (m == 1) return (k < Cout && n < Cin) ? w[((long)k * Cin + n) * K + (K - 1 - tp)] : 0.f;
+    return (k < Cout && n < Cin) ? w[((long)k * Cin + n) * K + tp] : 0.f;
+}
+
+// plain: wp[(tp*KP + k)*NP + n] = val.   split (mode & 8): unit = (tp, k / 32) of 32*NP floats holds bf16 records
+// [(part*2 + mf)*2 + h][NP][8] with k % 32 = 16h + 8mf + e, part 0 = hi, 1 = lo.
+__device__ __forceinline__ void prep_store(float *__restrict__ wp, int KP, int NP, int mode, int tp, int k, int n, float val)
+{
+    if (!(mode & 8)) { wp[((long)tp * KP + k) * NP + n] = val; return; }
+    const int kk = k & 31, h = kk >> 4, mf = (kk >> 3) & 1, e = kk & 7;
+    unsigned short *u = reinterpret_cast<unsigned short *>(wp + ((long)tp * KP + (k & ~31)) * NP);
+    const unsigned short hi = bf16_bits(val), lo = bf16_bits(val - bf16_value(hi));
+    u[((long)((0 * 2 + mf) * 2 + h) * NP + n) * 8 + e] = hi;
+    u[((long)((1 * 2 + mf) * 2 + h) * NP + n) * 8 + e] = lo;
+}
+
 __global__ void cl_prep_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int Cout, int Cin, int K, int KP, int NP, int mode)
 {
     const long n_el = (long)K * KP * NP;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_el; e += (long)gridDim.x * blockDim.x) {
         const int n = (int)(e % NP), k = (int)((e / NP) % KP), tp = (int)(e / NP / KP);
-        float val = 0.f;
-        if (mode == 0) {
-            if (k < Cin && n < Cout) val = w[((long)n * Cin + k) * K + tp];
-        } else if (mode == 1) {
-            if (k < Cout && n < Cin) val = w[((long)k * Cin + n) * K + (K - 1 - tp)];
-        } else {
-            if (k < Cout && n < Cin) val = w[((long)k * Cin + n) * K + tp];
-        }
-        wp[e] = val;
+        prep_store(wp, KP, NP, mode, tp, k, n, prep_value(w, Cout, Cin, K, mode, tp, k, n));
     }
 }
 
@@ -266,18 +303,13 @@ __global__ __launch_bounds__(256) void cl_prep_batch_kernel(PrepBatch b)
         const PrepJob &j = b.j[ji];
         const long l = e - lo;
         float val = 0.f;
-        if (j.mode >= 3) {
+        if (j.mode == 3 || j.mode == 4) {
             const int c = (int)(l % j.Cin), tap = (int)(l / j.Cin);
             val = j.src[(long)c * j.K + (j.mode == 4 ? j.K - 1 - tap : tap)];
         } else {
             const int n = (int)(l % j.NP), k = (int)((l / j.NP) % j.KP), tp = (int)(l / j.NP / j.KP);
-            if (j.mode == 0) {
-                if (k < j.Cin && n < j.Cout) val = j.src[((long)n * j.Cin + k) * j.K + tp];
-            } else if (j.mode == 1) {
-                if (k < j.Cout && n < j.Cin) val = j.src[((long)k * j.Cin + n) * j.K + (j.K - 1 - tp)];
-            } else {
-                if (k < j.Cout && n < j.Cin) val = j.src[((long)k * j.Cin + n) * j.K + tp];
-            }
+            prep_store(j.dst, j.KP, j.NP, j.mode, tp, k, n, prep_value(j.src, j.Cout, j.Cin, j.K, j.mode, tp, k, n));
+            continue;
         }
         j.dst[l] = val;
     }
@@ -293,7 +325,7 @@ int launch_cl_prep_batch(const PrepBatch &b, hipStream_t st)
     return DLKA_OK;
 }
 
-template <int AMODE, int OMODE>
+template <int AMODE, int OMODE, bool SPLIT = false>
 static int launch_igemm_nt(const IgemmArgs &a, int splits, hipStream_t st)
 {
     const int NT_total = a.NP / 32;
@@ -306,7 +338,7 @@ static int launch_igemm_nt(const IgemmArgs &a, int splits, hipStream_t st)
     dim3 grid(mblocks, splits, NT_total / NT), block(256);
 #define DLKA_IG(NTV)                                              \
     {                                                             \
-        auto k = cl_igemm_kernel<AMODE, OMODE, NTV>;              \
+        auto k = cl_igemm_kernel<AMODE, OMODE, NTV, SPLIT>;       \
         hipLaunchKernelGGL(k, grid, block, 0, st, a);             \
     }
     switch (NT) {
@@ -346,6 +378,12 @@ int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t s
     if (splits > 1) {
         const long n = (long)a.M * a.Cout;
         if (launch_zero(a.out, (size_t)n * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
+    }
+    if (a.split_bf16) {   // bf16 x3 split contraction (the prepared weights must be in the split layout)
+        if (amode == 0 && omode == 0) return launch_igemm_nt<0, 0, true>(a, splits, st);
+        if (amode == 0 && omode == 1) return launch_igemm_nt<0, 1, true>(a, splits, st);
+        if (amode == 2 && omode == 0) return launch_igemm_nt<2, 0, true>(a, splits, st);
+        return DLKA_ERR_UNSUPPORTED;
     }
     if (amode == 0 && omode == 0) return launch_igemm_nt<0, 0>(a, splits, st);
     if (amode == 0 && omode == 1) return launch_igemm_nt<0, 1>(a, splits, st);

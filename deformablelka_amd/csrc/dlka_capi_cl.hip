@@ -70,6 +70,14 @@ bool dw_supported(const SameConv &s)
 }
 bool dense_fwd_supported(const SameConv &s) { return s.group == 1 && s.Cin % 32 == 0 && nt_ok(round_up(s.Cout, 32)); }
 
+// Contractions with K > 1 taps (the offset-predict conv: 52 % of the block's FLOPs) are MFMA-bound in fp32; they run on the
+// bf16 matrix cores with two-term split operands (fp32 accumulation, ~1e-5 relative; cl_igemm.hip) unless DLKA_EXACT_FP32=1.
+bool use_split(const SameConv &s)
+{
+    static const bool exact = getenv("DLKA_EXACT_FP32") != nullptr;
+    return !exact && s.K > 1;
+}
+
 void fill_igemm(IgemmArgs &a, const SameConv &s)
 {
     memset(&a, 0, sizeof(a));
@@ -83,9 +91,11 @@ int dense_forward(const SameConv &s, const float *x, const float *w, const float
                   int epi, const float *aux, float *out2, hipStream_t st)
 {
     const int NP = round_up(s.Cout, 32);
-    if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, NP, 0, st));   // w == null: wp already prepared
+    const bool split = use_split(s);
+    if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, NP, split ? 8 : 0, st));   // w == null: wp already prepared
     IgemmArgs a;
     fill_igemm(a, s);
+    a.split_bf16 = split ? 1 : 0;
     a.in = x; a.wp = wp; a.bias = bias; a.out = out; a.out2 = out2; a.aux = aux; a.epi = epi;
     a.Cin = s.Cin; a.CinReal = s.Cin; a.CinP = s.Cin; a.Cout = s.Cout; a.NP = NP;
     const int splits = cl_igemm_pick_splits(s.M, s.K * (s.Cin / 32), epi);
@@ -100,9 +110,11 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
     const int KP = round_up(s.Cout, 32), NP = s.Cin;
     if (!nt_ok(NP) || s.Cin % 32) return DLKA_ERR_UNSUPPORTED;
     if (!gout_planar && s.Cout % 32) return DLKA_ERR_UNSUPPORTED;
-    if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, KP, NP, 1, st));
+    const bool split = use_split(s);
+    if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, KP, NP, split ? 9 : 1, st));
     IgemmArgs a;
     fill_igemm(a, s);
+    a.split_bf16 = split ? 1 : 0;
     a.pd = s.dd * (s.kd - 1) - s.pd; a.ph = s.dh * (s.kh - 1) - s.ph; a.pw = s.dw * (s.kw - 1) - s.pw;
     a.in = gout; a.wp = wp; a.bias = nullptr; a.out = gx; a.aux = aux; a.aux2 = aux2; a.out2 = out2; a.epi = epi;
     a.Cin = s.Cout; a.CinReal = s.Cout; a.CinP = KP; a.Cout = s.Cin; a.NP = NP;
@@ -288,7 +300,7 @@ void add_job(PrepBatch &pb, const void *src, float *dst, int Cout, int Cin, int 
 {
     PrepJob &j = pb.j[pb.njobs++];
     j.src = (const float *)src; j.dst = dst; j.Cout = Cout; j.Cin = Cin; j.K = K; j.KP = KP; j.NP = NP; j.mode = mode;
-    j.n = mode >= 3 ? (long)Cin * K : (long)K * KP * NP;
+    j.n = (mode == 3 || mode == 4) ? (long)Cin * K : (long)K * KP * NP;
     pb.total += j.n;
 }
 
@@ -310,8 +322,8 @@ int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_para
         add_job(pb, pw_w[k], t.pw_f[k], C, C, 1, C, C, 0);
         add_job(pb, pw_w[k], t.pw_b[k], C, C, 1, C, C, 1);
     }
-    add_job(pb, p->offset_w, t.off_f, 81, C, 27, C, 96, 0);
-    add_job(pb, p->offset_w, t.off_b, 81, C, 27, 96, C, 1);
+    add_job(pb, p->offset_w, t.off_f, 81, C, 27, C, 96, use_split(G.offc) ? 8 : 0);
+    add_job(pb, p->offset_w, t.off_b, 81, C, 27, 96, C, use_split(G.offc) ? 9 : 1);
     add_job(pb, p->deform_w, t.dcn_f, C, C, 27, C, C, 0);
     add_job(pb, p->deform_w, t.dcn_b, C, C, 27, C, C, 2);
     add_job(pb, p->conv0_w, t.dw5_f, C, C, 125, 0, 0, 3);

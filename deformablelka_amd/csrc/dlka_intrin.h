@@ -12,6 +12,18 @@ typedef hipemu_f32x16 f32x16;
 __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) { return hipemu::mfma_f32_32x32x2f32(a, b, c); }
 __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) { return hipemu::mfma_f32_16x16x4f32(a, b, c); }
 __device__ __forceinline__ int readfirstlane(int v) { return hipemu::readfirstlane(v); }
+typedef hipemu::hipemu_bf16x8 bf16x8;
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return hipemu::mfma_f32_32x32x16bf16(a, b, c); }
+// a[e] = hi[e] + lo[e] + O(2^-18 |a[e]|): two-term bf16 split of 8 fp32 values
+__device__ __forceinline__ void split_bf16x8(const float *a, bf16x8 &hi, bf16x8 &lo)
+{
+    for (int e = 0; e < 8; ++e) {
+        hi.v[e] = hipemu::hipemu_f32_to_bf16(a[e]);
+        lo.v[e] = hipemu::hipemu_f32_to_bf16(a[e] - hipemu::hipemu_bf16_to_f32(hi.v[e]));
+    }
+}
+__device__ __forceinline__ unsigned short bf16_bits(float x) { return hipemu::hipemu_f32_to_bf16(x); }
+__device__ __forceinline__ float bf16_value(unsigned short h) { return hipemu::hipemu_bf16_to_f32(h); }
 #define DLKA_DYN_SMEM(type, name) type *name = reinterpret_cast<type *>(hipemu::dyn_smem())
 // lanes of one wave exchange data through LDS without a workgroup barrier: on the GPU the wave executes in lockstep and
 // LDS operations retire in program order; the emulator runs lanes as fibers and needs a rendezvous
@@ -48,6 +60,22 @@ __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) { ret
 // v_mfma_f32_16x16x4_f32 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D: col = l&15, row = (l>>4)*4 + r.
 __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ int readfirstlane(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// v_mfma_f32_32x32x16_bf16 (32 cycles/SIMD, 16x the fp32-input rate): lane (i = l&31, g = l>>5) holds A[i][8g..8g+7] and
+// B[8g..8g+7][j = l&31]; D as above.  bf16 x bf16 products are exact in fp32 and the accumulation is fp32, so a two-term
+// split  a = a_hi + a_lo  (a_lo = bf16(a - a_hi)) with the three products hi*hi + hi*lo + lo*hi reproduces an fp32 product
+// to ~3 * 2^-18 relative (1.1e-5 worst case) at 3/16 of the fp32-input MFMA cost.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void split_bf16x8(const float *a, bf16x8 &hi, bf16x8 &lo)
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hi[e] = (__bf16)a[e];
+        lo[e] = (__bf16)(a[e] - (float)hi[e]);
+    }
+}
+__device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float bf16_value(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 // Buffer loads (buffer_load_dword / _dwordx4 ... offen): 32-bit byte offsets against a wave-uniform descriptor, and the
 // hardware range check returns 0 for offsets >= the buffer size.  The gather kernels use that for zero padding and for
 // corners outside the volume: the offset of a dropped element is DLKA_OOB, so every load is unconditional — no branch

@@ -337,6 +337,39 @@ inline hipemu_f32x16 mfma_f32_32x32x2f32(float a, float bv, hipemu_f32x16 c) {
     return d;
 }
 
+// v_mfma_f32_32x32x16_bf16: lane (i = l&31, g = l>>5) holds A[i][8g..8g+7] and B[8g..8g+7][j = l&31] as bf16 (raw 16-bit patterns
+// here); D as 32x32x2.  Products of bf16 values are exact in fp32; accumulation in fp32.
+struct hipemu_bf16x8 { unsigned short v[8]; };
+inline float hipemu_bf16_to_f32(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+inline unsigned short hipemu_f32_to_bf16(float x) {   // round to nearest even
+    unsigned u; memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+inline hipemu_f32x16 mfma_f32_32x32x16bf16(hipemu_bf16x8 a, hipemu_bf16x8 bv, hipemu_f32x16 c) {
+    Fiber &f = F(); Block &b = B();
+    const int w0 = (f.lin / WAVE) * WAVE, l = f.lin - w0;
+    unsigned short ab[16];
+    memcpy(ab, a.v, 16); memcpy(ab + 8, bv.v, 16);
+    memcpy(b.xchg[0][f.lin].b, ab, sizeof(ab));
+    f.state = WAVEOP; yield_to_sched();
+    hipemu_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float acc = c[r];
+        for (int g = 0; g < 2; ++g) {
+            unsigned short A[16], Bm[16];
+            memcpy(A, b.xchg[0][w0 + row + 32 * g].b, sizeof(A));
+            memcpy(Bm, b.xchg[0][w0 + col + 32 * g].b, sizeof(Bm));
+            for (int e = 0; e < 8; ++e) acc += hipemu_bf16_to_f32(A[e]) * hipemu_bf16_to_f32(Bm[8 + e]);
+        }
+        d[r] = acc;
+    }
+    f.state = WAVEOP; yield_to_sched();
+    return d;
+}
+
 // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D: col=l&15, row=(l>>4)*4+r
 inline hipemu_f32x4 mfma_f32_16x16x4f32(float a, float bv, hipemu_f32x4 c) {
     Fiber &f = F(); Block &b = B();
