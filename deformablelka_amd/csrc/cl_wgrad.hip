@@ -307,7 +307,9 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
 // a co-tile) once and feeds TPW chains -> (COT + TPW) * 16 loads per COT * TPW * 16 MFMAs per 32-row step (3x3: 96 / 144
 // instead of the first version's 80 / 64).  The next step's operands are in flight while the current step's MFMAs issue.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int GMODE, int COT, int TPW, bool N16>   // N16: N % 16 == 0 (the 16 rows of a half-wave never straddle two volumes)
+// SPLIT: bf16 x3-split contraction (dlka_intrin.h) instead of the exact fp32-input MFMA: 54 x 32 cycles per 32-row step instead
+// of 144 x 64 for the 3 x 3 blocking.
+template <int GMODE, int COT, int TPW, bool N16, bool SPLIT = false>   // N16: N % 16 == 0 (the 16 rows of a half-wave never straddle two volumes)
 __global__ __launch_bounds__(64) void cl_wgrad_dense_kernel(WgradArgs p)
 {
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
@@ -439,12 +441,31 @@ __global__ __launch_bounds__(64) void cl_wgrad_dense_kernel(WgradArgs p)
 #pragma unroll
                 for (int s = 0; s < 16; ++s) bsum[c] += ga[c][s];
         }
+        if (SPLIT) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+            for (int mf = 0; mf < 2; ++mf) {   // k = rows 16h + 8mf + e
+                bf16x8 ahi[COT], alo[COT], bhi[TPW], blo[TPW];
 #pragma unroll
-            for (int c = 0; c < COT; ++c)
+                for (int c = 0; c < COT; ++c) split_bf16x8(ga[c] + 8 * mf, ahi[c], alo[c]);
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) acc[c][t] = mfma_32x32x2(ga[c][s], bv[t][s], acc[c][t]);
+                for (int t = 0; t < TPW; ++t) split_bf16x8(bv[t] + 8 * mf, bhi[t], blo[t]);
+#pragma unroll
+                for (int c = 0; c < COT; ++c)
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) {
+                        acc[c][t] = mfma_32x32x16_bf16(alo[c], bhi[t], acc[c][t]);
+                        acc[c][t] = mfma_32x32x16_bf16(ahi[c], blo[t], acc[c][t]);
+                        acc[c][t] = mfma_32x32x16_bf16(ahi[c], bhi[t], acc[c][t]);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int c = 0; c < COT; ++c)
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) acc[c][t] = mfma_32x32x2(ga[c][s], bv[t][s], acc[c][t]);
+        }
     }
     // ---- partial tiles out: D row = co_local, col = ci_local ----
 #pragma unroll
@@ -573,9 +594,12 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
         else { auto k = cl_wgrad_deform_kernel<7>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
     } else {
         dim3 grid(nchunks, cdiv(OT, pl.cot) * a.CT, cdiv(a.K, pl.tpw));
+        static const bool exact = getenv("DLKA_EXACT_FP32") != nullptr;
+        const bool split = !exact && a.K > 1;   // MFMA-bound contractions: bf16 x3 split (see cl_igemm.hip)
 #define DLKA_WG(GM, CO, TP)                                                                                      \
     {                                                                                                            \
-        if ((a.N & 15) == 0) { auto k = cl_wgrad_dense_kernel<GM, CO, TP, true>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }  \
+        if ((a.N & 15) == 0 && split) { auto k = cl_wgrad_dense_kernel<GM, CO, TP, true, true>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }  \
+        else if ((a.N & 15) == 0) { auto k = cl_wgrad_dense_kernel<GM, CO, TP, true>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }  \
         else { auto k = cl_wgrad_dense_kernel<GM, CO, TP, false>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }              \
     }
         if (a.K == 1) {

@@ -70,12 +70,17 @@ bool dw_supported(const SameConv &s)
 }
 bool dense_fwd_supported(const SameConv &s) { return s.group == 1 && s.Cin % 32 == 0 && nt_ok(round_up(s.Cout, 32)); }
 
-// Contractions with K > 1 taps (the offset-predict conv: 52 % of the block's FLOPs) are MFMA-bound in fp32; they run on the
-// bf16 matrix cores with two-term split operands (fp32 accumulation, ~1e-5 relative; cl_igemm.hip) unless DLKA_EXACT_FP32=1.
-bool use_split(const SameConv &s)
+// Gradient contractions with K > 1 taps (data and weight gradient of the offset-predict conv) are MFMA-bound in fp32; they
+// run on the bf16 matrix cores with two-term split operands (fp32 accumulation, ~1e-5 relative; cl_igemm.hip) unless
+// DLKA_EXACT_FP32=1.  The FORWARD offset conv stays on the exact fp32-input MFMA: its output decides floor() of every
+// sampling position, and a 1e-5 perturbation flips the cell of the samples that sit within 1e-5 of an integer — harmless
+// for training, but each flip changes that sample's grad_offset by O(1), which showed as a 1.5e-2 relative difference of
+// conv_offset.weight.grad against the oracle when the offsets are concentrated near 0 (tests/test_parity_gpu.py).
+bool use_split(const SameConv &s, bool forward)
 {
     static const bool exact = getenv("DLKA_EXACT_FP32") != nullptr;
-    return !exact && s.K > 1;
+    static const bool all = getenv("DLKA_SPLIT_FORWARD") != nullptr;   // A/B: also split the forward conv (118 -> 56 us at stage 0)
+    return !exact && s.K > 1 && (!forward || all);
 }
 
 void fill_igemm(IgemmArgs &a, const SameConv &s)
@@ -91,7 +96,7 @@ int dense_forward(const SameConv &s, const float *x, const float *w, const float
                   int epi, const float *aux, float *out2, hipStream_t st)
 {
     const int NP = round_up(s.Cout, 32);
-    const bool split = use_split(s);
+    const bool split = use_split(s, true);
     if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, NP, split ? 8 : 0, st));   // w == null: wp already prepared
     IgemmArgs a;
     fill_igemm(a, s);
@@ -110,7 +115,7 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
     const int KP = round_up(s.Cout, 32), NP = s.Cin;
     if (!nt_ok(NP) || s.Cin % 32) return DLKA_ERR_UNSUPPORTED;
     if (!gout_planar && s.Cout % 32) return DLKA_ERR_UNSUPPORTED;
-    const bool split = use_split(s);
+    const bool split = use_split(s, false);
     if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, KP, NP, split ? 9 : 1, st));
     IgemmArgs a;
     fill_igemm(a, s);
@@ -322,8 +327,8 @@ int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_para
         add_job(pb, pw_w[k], t.pw_f[k], C, C, 1, C, C, 0);
         add_job(pb, pw_w[k], t.pw_b[k], C, C, 1, C, C, 1);
     }
-    add_job(pb, p->offset_w, t.off_f, 81, C, 27, C, 96, use_split(G.offc) ? 8 : 0);
-    add_job(pb, p->offset_w, t.off_b, 81, C, 27, 96, C, use_split(G.offc) ? 9 : 1);
+    add_job(pb, p->offset_w, t.off_f, 81, C, 27, C, 96, use_split(G.offc, true) ? 8 : 0);
+    add_job(pb, p->offset_w, t.off_b, 81, C, 27, 96, C, use_split(G.offc, false) ? 9 : 1);
     add_job(pb, p->deform_w, t.dcn_f, C, C, 27, C, C, 0);
     add_job(pb, p->deform_w, t.dcn_b, C, C, 27, C, C, 2);
     add_job(pb, p->conv0_w, t.dw5_f, C, C, 125, 0, 0, 3);
