@@ -389,6 +389,7 @@ struct GxGeom {
     int nslices;            // C / CS
     int ngroups;            // ceil(K / TG)
     int resident;           // all tap groups' weight tiles fit in LDS next to the window
+    int ablate;             // profiling only (DLKA_GX_ABL): 1 = no LDS atomics, 2 = no sampling description / scatter at all
 };
 
 __device__ __host__ __forceinline__ void gx_window(int b0, int bsz, int size, int &lo, int &len)
@@ -472,6 +473,13 @@ __global__ __launch_bounds__(512) void cl_deform_gx_kernel(DeformBwdArgs p, GxGe
                 for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], g1[st], acc);
             }
         }
+        if (gg.ablate == 2) {   // profiling: keep the MFMA results alive, skip the scatter
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[r];
+            if (sum == 12345.678f) p.gx[0] = sum;
+            return;
+        }
         {
             // acc[r]: MFMA row (r&3) + 8*(r>>2) + 4h  ->  c4 = r & 3, t8 = 2*(r>>2) + h;   column = voxel j
 #pragma unroll
@@ -493,6 +501,11 @@ __global__ __launch_bounds__(512) void cl_deform_gx_kernel(DeformBwdArgs p, GxGe
                 const int xd = zd - wd0, xh = zh - wh0, xw = zw - ww0;
                 if ((unsigned)xd < (unsigned)WD && (unsigned)xh < (unsigned)WH && (unsigned)xw < (unsigned)WW) {
                     double *cell = Win + (xd * WH + xh) * WW + xw;
+                    if (gg.ablate == 1) {   // profiling: plain (racy) stores instead of atomics
+#pragma unroll
+                        for (int c = 0; c < CS; ++c) cell[c * wvox] = (double)(acc[4 * r4 + c] * wq);
+                        continue;
+                    }
 #pragma unroll
                     for (int c = 0; c < CS; ++c) atomicAdd(cell + c * wvox, (double)(acc[4 * r4 + c] * wq));
                 } else {
@@ -645,6 +658,8 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         GxGeom gl_ = g;
         const size_t lds_all = (size_t)g.wvox_max * CS * sizeof(double) + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
         gl_.resident = (lds_all <= 150 * 1024 && a.CoutP <= 128) ? 1 : 0;
+        static const int abl = getenv("DLKA_GX_ABL") ? atoi(getenv("DLKA_GX_ABL")) : 0;
+        gl_.ablate = abl;
         const size_t lds = gl_.resident ? lds_all : (size_t)g.wvox_max * CS * sizeof(double) + (size_t)a.CoutP * 32 * sizeof(float);
         if (lds > 160 * 1024) return DLKA_ERR_UNSUPPORTED;
 #if !defined(HIPEMU)
