@@ -12,11 +12,12 @@ from .deformable_LKA import deformable_LKA, deformable_LKA_Attention  # noqa: F4
 from .functions.deform_conv_func import DeformConvFunction  # noqa: F401
 from .modules.deform_conv import (DeformConv, DeformConv_d, DeformConvPack, DeformConvPack_d,  # noqa: F401
                                   DeformConvPack_Depth, DeformConvPack_experimental)
-from .transformerblock import LKA3d_deform, LKA_Attention3d_deform  # noqa: F401
+from .dynunet_block import UnetResBlock  # noqa: F401
+from .transformerblock import LKA3d_deform, LKA_Attention3d_deform, TransformerBlock_3D_single_deform_LKA  # noqa: F401
 from .tv_ops import DeformConv2d, deform_conv2d  # noqa: F401
 
 __all__ = ["DeformConv", "DeformConvPack", "DeformConvPack_experimental", "DeformConvPack_Depth", "DeformConv_d",
-           "DeformConvPack_d", "DeformConvFunction", "LKA3d_deform", "LKA_Attention3d_deform", "DeformConv2dPack",
+           "DeformConvPack_d", "DeformConvFunction", "LKA3d_deform", "LKA_Attention3d_deform", "TransformerBlock_3D_single_deform_LKA", "UnetResBlock", "DeformConv2dPack",
            "deformable_LKA", "deformable_LKA_Attention", "DeformConv2d", "deform_conv2d", "install_reference_aliases"]
 
 

@@ -39,6 +39,15 @@ class Lka3dPtrs(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in LKA3D_FIELDS]
 
 
+TBLOCK3D_FIELDS = ("norm_w", "norm_b", "gamma", "pos_embed", "conv51_conv1_w", "conv51_conv2_w", "conv51_norm1_w", "conv51_norm1_b",
+                   "conv51_norm2_w", "conv51_norm2_b", "conv8_w", "conv8_b")
+
+
+class TBlock3dPtrs(ctypes.Structure):
+    """``dlka_tblock3d_params`` / ``dlka_tblock3d_grads``."""
+    _fields_ = [(n, c_void_p) for n in TBLOCK3D_FIELDS]
+
+
 class Lka2dPtrs(ctypes.Structure):
     """``dlka_lka2d_params`` / ``dlka_lka2d_grads``."""
     _fields_ = [(n, c_void_p) for n in LKA2D_FIELDS]
@@ -95,6 +104,20 @@ SIGNATURES = {
                                             + [c_int] * 6 + [c_void_p]),
     "dlka_lka3d_attention_tokens_backward": (c_int, [c_void_p, POINTER(Lka3dPtrs), c_void_p, c_void_p, c_size_t, c_void_p,
                                                      POINTER(Lka3dPtrs), c_void_p, c_size_t] + [c_int] * 6 + [c_void_p]),
+    "dlka_layernorm_tokens_forward": (c_int, [c_void_p, c_int] + [c_void_p] * 6 + [c_int] * 3 + [ctypes.c_float, c_int, c_void_p]),
+    "dlka_layernorm_tokens_backward": (c_int, [c_void_p] * 9 + [c_int] * 4 + [c_void_p]),
+    "dlka_scale_residual_forward": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p]),
+    "dlka_scale_residual_backward": (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p]),
+    "dlka_batchnorm_cl_forward": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 2 + [c_int64, c_int, ctypes.c_float, ctypes.c_float, c_int, c_void_p]),
+    "dlka_batchnorm_cl_backward": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 5 + [c_int64, c_int, ctypes.c_float, c_int, c_void_p]),
+    "dlka_channel_scale": (c_int, [c_void_p] * 3 + [c_int, c_int64, c_int, c_int, c_void_p]),
+    "dlka_tblock3d_supported": (c_int, [c_int] * 6),
+    "dlka_tblock3d_saved_bytes": (c_size_t, [c_int] * 6),
+    "dlka_tblock3d_workspace_bytes": (c_size_t, [c_int] * 6),
+    "dlka_tblock3d_forward": (c_int, [c_void_p, c_int, POINTER(TBlock3dPtrs), POINTER(Lka3dPtrs), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                                      c_void_p, c_size_t] + [c_int] * 5 + [ctypes.c_float, ctypes.c_float, c_int, c_void_p]),
+    "dlka_tblock3d_backward": (c_int, [POINTER(TBlock3dPtrs), POINTER(Lka3dPtrs), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                       POINTER(TBlock3dPtrs), POINTER(Lka3dPtrs), c_void_p, c_size_t] + [c_int] * 6 + [c_void_p]),
 }
 
 

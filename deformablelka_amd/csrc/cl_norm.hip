@@ -1,0 +1,352 @@
+// The non-convolutional pieces of TransformerBlock_3D_single_deform_LKA (3D/d_lka_former/network_architecture/synapse/
+// transformerblock.py:570-630) around the D-LKA block, in token / channels-last layout [M = B*N][C], fp32:
+//   tokens + pos_embed + LayerNorm (:620-624)            cl_layernorm_fwd_kernel / cl_layernorm_bwd_kernel
+//   x + gamma * epa_block(...) (:624)                    cl_scale_residual_fwd_kernel / _bwd_kernel
+//   BatchNorm3d (+ residual) + LeakyReLU of UnetResBlock (dynunet_block.py:66-79)   cl_bn_* kernels
+//   Dropout3d's per-(sample, channel) mask (:611)        cl_channel_scale_kernel
+// All of them are HBM-bound streaming / reduction kernels: lanes run over channels (contiguous 128-byte row pieces), rows
+// are strided over the grid; per-channel reductions fold in LDS and finish with one fp32 atomic per channel and workgroup.
+#include "dlka_kernels.h"
+
+namespace dlka {
+
+#define DLKA_TRY_LAUNCH(expr)           \
+    do {                                \
+        int rc_ = (expr);               \
+        if (rc_ != DLKA_OK) return rc_; \
+    } while (0)
+
+namespace {
+constexpr int NT = 256;
+constexpr int KMAX = 4;   // channels per lane: C <= 256 (the D-LKA stage widths are 32 .. 256)
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+}  // namespace
+
+// One wave per token row: x (planar [B][C][N] — the NCDHW tensor the block receives — or channels-last [M][C]) (+ pos[N][C])
+// -> xt[M][C]; xn = (xt - mean) * rstd * w + b; stats[m] = {mean, rstd}.   Biased variance, eps inside the sqrt (nn.LayerNorm).
+__global__ __launch_bounds__(NT) void cl_layernorm_fwd_kernel(const float *__restrict__ x, int x_planar, const float *__restrict__ pos,
+                                                              const float *__restrict__ w, const float *__restrict__ b, float *__restrict__ xt,
+                                                              float *__restrict__ xn, float *__restrict__ stats, int B, int N, int C, float eps)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long M = (long)B * N;
+    for (long m = (long)blockIdx.x * (NT / 64) + wave; m < M; m += (long)gridDim.x * (NT / 64)) {
+        const int bb = (int)(m / N), v = (int)(m - (long)bb * N);
+        float s = 0.f, s2 = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            float val = x_planar ? x[((long)bb * C + c) * N + v] : x[m * C + c];
+            if (pos) val += pos[(long)v * C + c];
+            xt[m * C + c] = val;
+            s += val;
+            s2 = fmaf(val, val, s2);
+        }
+        s = wave_sum(s);
+        s2 = wave_sum(s2);
+        const float mean = s / C;
+        const float var = fmaxf(s2 / C - mean * mean, 0.f);
+        const float rstd = 1.f / sqrtf(var + eps);
+        for (int c = lane; c < C; c += 64) xn[m * C + c] = (xt[m * C + c] - mean) * rstd * w[c] + b[c];
+        if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
+    }
+}
+
+// gxt[m][c] = (g_res ? g_res : 0) + rstd * (dxhat - mean_c(dxhat) - xhat * mean_c(dxhat * xhat)),  dxhat = g * w
+// gw[c] += sum_m g * xhat, gb[c] += sum_m g   (zero-initialised; one atomic per channel and workgroup)
+// gpos[v][c] += gxt[m][c]                     (zero-initialised; optional)
+__global__ __launch_bounds__(NT) void cl_layernorm_bwd_kernel(const float *__restrict__ g, const float *__restrict__ g_res, const float *__restrict__ xt,
+                                                              const float *__restrict__ stats, const float *__restrict__ w, float *__restrict__ gxt,
+                                                              float *__restrict__ gw, float *__restrict__ gb, float *__restrict__ gpos, int B, int N, int C)
+{
+    DLKA_DYN_SMEM(float, red);   // [waves][2][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long M = (long)B * N;
+    float aw[KMAX], ab[KMAX];   // this lane's channels lane + 64k: partial sums over the rows of this wave (registers, no LDS atomics)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { aw[k] = 0.f; ab[k] = 0.f; }
+    for (long m = (long)blockIdx.x * (NT / 64) + wave; m < M; m += (long)gridDim.x * (NT / 64)) {
+        const float mean = stats[2 * m], rstd = stats[2 * m + 1];
+        float s1 = 0.f, s2 = 0.f, xh[KMAX], dxh[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int c = lane + 64 * k;
+            xh[k] = 0.f; dxh[k] = 0.f;
+            if (c < C) {
+                const float gv = g[m * C + c];
+                xh[k] = (xt[m * C + c] - mean) * rstd;
+                dxh[k] = gv * w[c];
+                s1 += dxh[k];
+                s2 = fmaf(dxh[k], xh[k], s2);
+                aw[k] = fmaf(gv, xh[k], aw[k]);
+                ab[k] += gv;
+            }
+        }
+        s1 = wave_sum(s1) / C;
+        s2 = wave_sum(s2) / C;
+        const int v = (int)(m % N);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) {
+                float val = rstd * (dxh[k] - s1 - xh[k] * s2);
+                if (g_res) val += g_res[m * C + c];
+                gxt[m * C + c] = val;
+                if (gpos) atomicAdd(gpos + (long)v * C + c, val);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) { red[(wave * 2 + 0) * C + c] = aw[k]; red[(wave * 2 + 1) * C + c] = ab[k]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += NT) {
+        float sw = 0.f, sb = 0.f;
+        for (int wv = 0; wv < NT / 64; ++wv) { sw += red[(wv * 2 + 0) * C + c]; sb += red[(wv * 2 + 1) * C + c]; }
+        atomicAdd(gw + c, sw);
+        atomicAdd(gb + c, sb);
+    }
+}
+
+// out = xt + gamma[c] * e
+__global__ __launch_bounds__(NT) void cl_scale_residual_fwd_kernel(const float *__restrict__ xt, const float *__restrict__ e, const float *__restrict__ gamma,
+                                                                   float *__restrict__ out, long M, int C)
+{
+    const long n = M * C;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) out[i] = fmaf(gamma[i % C], e[i], xt[i]);
+}
+
+// ge = gamma[c] * g;  ggamma[c] += sum_m g * e   (zero-initialised)
+__global__ __launch_bounds__(NT) void cl_scale_residual_bwd_kernel(const float *__restrict__ g, const float *__restrict__ e, const float *__restrict__ gamma,
+                                                                   float *__restrict__ ge, float *__restrict__ ggamma, long M, int C)
+{
+    DLKA_DYN_SMEM(float, red);   // [C]
+    for (int c = threadIdx.x; c < C; c += NT) red[c] = 0.f;
+    __syncthreads();
+    const int cpb = C < NT ? C : NT, rpb = NT / cpb;   // C is a multiple of 32 and <= 1024; rows in flight per pass
+    const int c_in = threadIdx.x % cpb, r_in = threadIdx.x / cpb;
+    for (int cb = 0; cb < C; cb += cpb) {
+        const int c = cb + c_in;
+        float acc = 0.f;
+        if (r_in < rpb && c < C) {
+            const float gm = gamma[c];
+            for (long m = (long)blockIdx.x * rpb + r_in; m < M; m += (long)gridDim.x * rpb) {
+                const float gv = g[m * C + c];
+                ge[m * C + c] = gm * gv;
+                acc = fmaf(gv, e[m * C + c], acc);
+            }
+            atomicAdd(&red[c], acc);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += NT) atomicAdd(ggamma + c, red[c]);
+}
+
+// sums[c] += sum_m x[m][c], sums[C + c] += sum_m x[m][c]^2     (zero-initialised)
+__global__ __launch_bounds__(NT) void cl_bn_stats_kernel(const float *__restrict__ x, float *__restrict__ sums, long M, int C)
+{
+    DLKA_DYN_SMEM(float, red);   // [2][C]
+    for (int c = threadIdx.x; c < 2 * C; c += NT) red[c] = 0.f;
+    __syncthreads();
+    const int cpb = C < NT ? C : NT, rpb = NT / cpb;
+    const int c_in = threadIdx.x % cpb, r_in = threadIdx.x / cpb;
+    for (int cb = 0; cb < C; cb += cpb) {
+        const int c = cb + c_in;
+        if (r_in < rpb && c < C) {
+            float s = 0.f, s2 = 0.f;
+            for (long m = (long)blockIdx.x * rpb + r_in; m < M; m += (long)gridDim.x * rpb) {
+                const float v = x[m * C + c];
+                s += v;
+                s2 = fmaf(v, v, s2);
+            }
+            atomicAdd(&red[c], s);
+            atomicAdd(&red[C + c], s2);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += NT) atomicAdd(sums + c, red[c]);
+}
+
+// stats[c] = mean, stats[C + c] = rstd, stats[2C + c] = unbiased variance (for the running estimate)
+__global__ void cl_bn_finish_stats_kernel(const float *__restrict__ sums, float *__restrict__ stats, long M, int C, float eps)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = sums[c] / (float)M;
+    const float var = fmaxf(sums[C + c] / (float)M - mean * mean, 0.f);
+    stats[c] = mean;
+    stats[C + c] = 1.f / sqrtf(var + eps);
+    stats[2 * C + c] = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+}
+
+// y = lrelu((x - mean) * rstd * w + b (+ res))
+__global__ __launch_bounds__(NT) void cl_bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ w,
+                                                         const float *__restrict__ b, const float *__restrict__ stats, const float *__restrict__ mask,
+                                                         float *__restrict__ y, long M, long N, int C, float slope)
+{
+    const long n = M * C;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        float v = (x[i] - stats[c]) * stats[C + c] * w[c] + b[c];
+        if (res) v += res[i];
+        v = v > 0.f ? v : slope * v;
+        if (mask) v *= mask[(i / (N * C)) * C + c];   // Dropout3d of the block output, folded in (mask >= 0: the sign survives where it matters)
+        y[i] = v;
+    }
+}
+
+// gpre = g * lrelu'(y);  sums[c] += sum_m gpre, sums[C + c] += sum_m gpre * xhat   (zero-initialised);  gres = gpre (optional)
+__global__ __launch_bounds__(NT) void cl_bn_bwd_reduce_kernel(const float *__restrict__ g, const float *__restrict__ gmask, const float *__restrict__ x,
+                                                              const float *__restrict__ y, const float *__restrict__ stats, float *__restrict__ sums,
+                                                              float *__restrict__ gres, const float *__restrict__ gres_add, long M, long N, int C, float slope)
+{
+    DLKA_DYN_SMEM(float, red);   // [2][C]
+    for (int c = threadIdx.x; c < 2 * C; c += NT) red[c] = 0.f;
+    __syncthreads();
+    const int cpb = C < NT ? C : NT, rpb = NT / cpb;
+    const int c_in = threadIdx.x % cpb, r_in = threadIdx.x / cpb;
+    for (int cb = 0; cb < C; cb += cpb) {
+        const int c = cb + c_in;
+        if (r_in < rpb && c < C) {
+            const float mean = stats[c], rstd = stats[C + c];
+            float s = 0.f, s2 = 0.f;
+            for (long m = (long)blockIdx.x * rpb + r_in; m < M; m += (long)gridDim.x * rpb) {
+                const long i = m * C + c;
+                float gp = g[i] * (y[i] > 0.f ? 1.f : slope);
+                if (gmask) gp *= gmask[(m / N) * C + c];
+                if (gres) gres[i] = gres_add ? gp + gres_add[i] : gp;
+                s += gp;
+                s2 = fmaf(gp, (x[i] - mean) * rstd, s2);
+            }
+            atomicAdd(&red[c], s);
+            atomicAdd(&red[C + c], s2);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += NT) atomicAdd(sums + c, red[c]);
+}
+
+// training: gx = rstd * w * (gpre - sums[c]/M - xhat * sums[C+c]/M);  eval (running statistics): gx = rstd * w * gpre
+// gw[c] = sums[C + c], gb[c] = sums[c]   (written by workgroup 0)
+__global__ __launch_bounds__(NT) void cl_bn_bwd_apply_kernel(const float *__restrict__ g, const float *__restrict__ gmask, const float *__restrict__ x,
+                                                             const float *__restrict__ y, const float *__restrict__ w, const float *__restrict__ stats,
+                                                             const float *__restrict__ sums, float *__restrict__ gx, float *__restrict__ gw, float *__restrict__ gb,
+                                                             long M, long N, int C, float slope, int training)
+{
+    const long n = M * C;
+    const float invM = 1.f / (float)M;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        const float rstd = stats[C + c];
+        float gp = g[i] * (y[i] > 0.f ? 1.f : slope);
+        if (gmask) gp *= gmask[(i / (N * C)) * C + c];
+        float v = gp;
+        if (training) v -= sums[c] * invM + (x[i] - stats[c]) * rstd * sums[C + c] * invM;
+        gx[i] = rstd * w[c] * v;
+    }
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += NT) { gw[c] = sums[C + c]; gb[c] = sums[c]; }
+}
+
+// y[m][c] = x[m][c] * mask[b][c]
+__global__ __launch_bounds__(NT) void cl_channel_scale_kernel(const float *__restrict__ x, const float *__restrict__ mask, float *__restrict__ y, int B, long N,
+                                                              int C)
+{
+    const long n = (long)B * N * C;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % C), b = (int)(i / ((long)N * C));
+        y[i] = x[i] * mask[(long)b * C + c];
+    }
+}
+
+static unsigned grid_for(long work_items, long per_block, long cap = 2048)
+{
+    long g = cdivl(work_items, per_block);
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+int launch_cl_layernorm_fwd(const float *x, int x_planar, const float *pos, const float *w, const float *b, float *xt, float *xn, float *stats, int B, int N,
+                            int C, float eps, hipStream_t st)
+{
+    if (C > 64 * KMAX) return DLKA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(cl_layernorm_fwd_kernel, dim3(grid_for((long)B * N, NT / 64, 4096)), dim3(NT), 0, st, x, x_planar, pos, w, b, xt, xn, stats, B, N, C, eps);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+int launch_cl_layernorm_bwd(const float *g, const float *g_res, const float *xt, const float *stats, const float *w, float *gxt, float *gw, float *gb,
+                            float *gpos, int B, int N, int C, hipStream_t st)
+{
+    if (C > 64 * KMAX) return DLKA_ERR_UNSUPPORTED;
+    DLKA_TRY_LAUNCH(launch_zero(gw, (size_t)C * 4, st));
+    DLKA_TRY_LAUNCH(launch_zero(gb, (size_t)C * 4, st));
+    if (gpos) DLKA_TRY_LAUNCH(launch_zero(gpos, (size_t)N * C * 4, st));
+    hipLaunchKernelGGL(cl_layernorm_bwd_kernel, dim3(grid_for((long)B * N, NT / 64, 1024)), dim3(NT), (NT / 64) * 2 * C * sizeof(float), st, g, g_res, xt, stats, w, gxt, gw, gb,
+                       gpos, B, N, C);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+int launch_cl_scale_residual_fwd(const float *xt, const float *e, const float *gamma, float *out, long M, int C, hipStream_t st)
+{
+    hipLaunchKernelGGL(cl_scale_residual_fwd_kernel, dim3(grid_for(M * C, NT)), dim3(NT), 0, st, xt, e, gamma, out, M, C);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+int launch_cl_scale_residual_bwd(const float *g, const float *e, const float *gamma, float *ge, float *ggamma, long M, int C, hipStream_t st)
+{
+    DLKA_TRY_LAUNCH(launch_zero(ggamma, (size_t)C * 4, st));
+    const int rpb = NT / (C < NT ? C : NT);
+    hipLaunchKernelGGL(cl_scale_residual_bwd_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), C * sizeof(float), st, g, e, gamma, ge, ggamma, M, C);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+// sums: 2C floats of scratch; stats: 3C floats {mean, rstd, unbiased var}
+int launch_cl_bn_stats(const float *x, float *sums, float *stats, long M, int C, float eps, hipStream_t st)
+{
+    DLKA_TRY_LAUNCH(launch_zero(sums, (size_t)2 * C * 4, st));
+    const int rpb = NT / (C < NT ? C : NT);
+    hipLaunchKernelGGL(cl_bn_stats_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), 2 * C * sizeof(float), st, x, sums, M, C);
+    DLKA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(cl_bn_finish_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float *)sums, stats, M, C, eps);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+int launch_cl_bn_apply(const float *x, const float *res, const float *w, const float *b, const float *stats, const float *mask, float *y, long M, long N, int C,
+                       float slope, hipStream_t st)
+{
+    hipLaunchKernelGGL(cl_bn_apply_kernel, dim3(grid_for(M * C, NT)), dim3(NT), 0, st, x, res, w, b, stats, mask, y, M, N, C, slope);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+int launch_cl_bn_bwd(const float *g, const float *gmask, const float *x, const float *y, const float *w, const float *stats, float *sums, float *gx, float *gres,
+                     const float *gres_add, float *gw, float *gb, long M, long N, int C, float slope, int training, hipStream_t st)
+{
+    DLKA_TRY_LAUNCH(launch_zero(sums, (size_t)2 * C * 4, st));
+    const int rpb = NT / (C < NT ? C : NT);
+    hipLaunchKernelGGL(cl_bn_bwd_reduce_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), 2 * C * sizeof(float), st, g, gmask, x, y, stats, sums, gres, gres_add, M, N, C, slope);
+    DLKA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(cl_bn_bwd_apply_kernel, dim3(grid_for(M * C, NT)), dim3(NT), 0, st, g, gmask, x, y, w, stats, (const float *)sums, gx, gw, gb, M, N, C, slope, training);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+int launch_cl_channel_scale(const float *x, const float *mask, float *y, int B, long N, int C, hipStream_t st)
+{
+    hipLaunchKernelGGL(cl_channel_scale_kernel, dim3(grid_for((long)B * N * C, NT)), dim3(NT), 0, st, x, mask, y, B, N, C);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+}  // namespace dlka

@@ -640,4 +640,233 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     return DLKA_OK;
 }
 
+// ---- the wrapper block's non-convolutional pieces (cl_norm.hip) ------------------------------------------------------------
+int dlka_layernorm_tokens_forward(const void *x, int x_planar, const void *pos, const void *w, const void *b, void *xt, void *xn, void *stats, int B,
+                                  int N, int C, float eps, int dtype, void *stream)
+{
+    if (!x || !w || !b || !xt || !xn || !stats) return DLKA_ERR_NULL;
+    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    if (B <= 0 || N <= 0 || C <= 0) return DLKA_ERR_SHAPE;
+    return launch_cl_layernorm_fwd((const float *)x, x_planar, (const float *)pos, (const float *)w, (const float *)b, (float *)xt, (float *)xn,
+                                   (float *)stats, B, N, C, eps, (hipStream_t)stream);
+}
+
+int dlka_layernorm_tokens_backward(const void *g_xn, const void *g_res, const void *xt, const void *stats, const void *w, void *gxt, void *gw,
+                                   void *gb, void *gpos, int B, int N, int C, int dtype, void *stream)
+{
+    if (!g_xn || !xt || !stats || !w || !gxt || !gw || !gb) return DLKA_ERR_NULL;
+    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    if (B <= 0 || N <= 0 || C <= 0) return DLKA_ERR_SHAPE;
+    return launch_cl_layernorm_bwd((const float *)g_xn, (const float *)g_res, (const float *)xt, (const float *)stats, (const float *)w, (float *)gxt,
+                                   (float *)gw, (float *)gb, (float *)gpos, B, N, C, (hipStream_t)stream);
+}
+
+int dlka_scale_residual_forward(const void *xt, const void *e, const void *gamma, void *out, int64_t M, int C, int dtype, void *stream)
+{
+    if (!xt || !e || !gamma || !out) return DLKA_ERR_NULL;
+    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    if (M <= 0 || C <= 0) return DLKA_ERR_SHAPE;
+    return launch_cl_scale_residual_fwd((const float *)xt, (const float *)e, (const float *)gamma, (float *)out, (long)M, C, (hipStream_t)stream);
+}
+
+int dlka_scale_residual_backward(const void *g, const void *e, const void *gamma, void *ge, void *ggamma, int64_t M, int C, int dtype, void *stream)
+{
+    if (!g || !e || !gamma || !ge || !ggamma) return DLKA_ERR_NULL;
+    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    if (M <= 0 || C <= 0 || C > 1024 || C % 32) return DLKA_ERR_SHAPE;
+    return launch_cl_scale_residual_bwd((const float *)g, (const float *)e, (const float *)gamma, (float *)ge, (float *)ggamma, (long)M, C, (hipStream_t)stream);
+}
+
+int dlka_batchnorm_cl_forward(const void *x, const void *res, const void *w, const void *b, void *stats, int training, void *y, void *scratch, int64_t M,
+                              int C, float eps, float slope, int dtype, void *stream)
+{
+    if (!x || !w || !b || !stats || !y || !scratch) return DLKA_ERR_NULL;
+    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    if (M <= 0 || C <= 0 || C > 1024 || C % 32) return DLKA_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (training) DLKA_TRY(launch_cl_bn_stats((const float *)x, (float *)scratch, (float *)stats, (long)M, C, eps, st));
+    return launch_cl_bn_apply((const float *)x, (const float *)res, (const float *)w, (const float *)b, (const float *)stats, nullptr, (float *)y, (long)M, (long)M, C, slope, st);
+}
+
+int dlka_batchnorm_cl_backward(const void *g, const void *x, const void *y, const void *w, const void *stats, int training, void *gx, void *gres,
+                               void *gw, void *gb, void *scratch, int64_t M, int C, float slope, int dtype, void *stream)
+{
+    if (!g || !x || !y || !w || !stats || !gx || !gw || !gb || !scratch) return DLKA_ERR_NULL;
+    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    if (M <= 0 || C <= 0 || C > 1024 || C % 32) return DLKA_ERR_SHAPE;
+    return launch_cl_bn_bwd((const float *)g, nullptr, (const float *)x, (const float *)y, (const float *)w, (const float *)stats, (float *)scratch, (float *)gx,
+                            (float *)gres, nullptr, (float *)gw, (float *)gb, (long)M, (long)M, C, slope, training, (hipStream_t)stream);
+}
+
+int dlka_channel_scale(const void *x, const void *mask, void *y, int B, int64_t N, int C, int dtype, void *stream)
+{
+    if (!x || !mask || !y) return DLKA_ERR_NULL;
+    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    if (B <= 0 || N <= 0 || C <= 0) return DLKA_ERR_SHAPE;
+    return launch_cl_channel_scale((const float *)x, (const float *)mask, (float *)y, B, (long)N, C, (hipStream_t)stream);
+}
+
+
+// ---- TransformerBlock_3D_single_deform_LKA, one call per direction -----------------------------------------------------------
+// Reference: 3D/d_lka_former/network_architecture/synapse/transformerblock.py:617-630 (forward), dynunet_block.py:66-80
+// (UnetResBlock.forward).  Everything stays in token layout [M][C]; the only strided access is the read of an NCDHW input.
+namespace {
+
+struct TBlockGeoms {
+    SameConv c3, pw;   // the 3^3 dense convs of UnetResBlock, the 1x1x1 conv of conv8
+    size_t E, M;
+    TBlockGeoms(int B, int C, int D, int H, int W)
+    {
+        dlka_conv_geom g;
+        memset(&g, 0, sizeof(g));
+        g.B = B; g.C = C; g.D = D; g.H = H; g.W = W; g.Cout = C;
+        g.kd = g.kh = g.kw = 3; g.sd = g.sh = g.sw = 1; g.pd = g.ph = g.pw = 1; g.dd = g.dh = g.dw = 1; g.group = 1; g.deformable_group = 1; g.im2col_step = 64;
+        make_same_conv(&g, c3);
+        g.kd = g.kh = g.kw = 1; g.pd = g.ph = g.pw = 0;
+        make_same_conv(&g, pw);
+        M = (size_t)c3.M;
+        E = M * C;
+    }
+    size_t wp_floats() const { return dense_wp_floats(c3); }
+    size_t part_floats() const { return cl_wgrad_part_floats(c3.M, c3.K, c3.Cout, c3.Cin); }
+};
+
+bool tblock_supported(int B, int C, int D, int H, int W) { return tokens_supported(B, C, D, H, W) && (long)D * H * W < (1l << 31); }
+
+struct TBlockSaved {
+    float *xt, *xn, *e, *attn, *c1, *a1, *c2, *rd, *lnstats;
+    void *lka;
+    size_t lka_bytes;
+};
+
+bool carve_tblock_saved(Carver &sv, const TBlockGeoms &G, int B, int C, int D, int H, int W, TBlockSaved &S)
+{
+    S.xt = (float *)sv.take(G.E * 4); S.xn = (float *)sv.take(G.E * 4); S.e = (float *)sv.take(G.E * 4); S.attn = (float *)sv.take(G.E * 4);
+    S.c1 = (float *)sv.take(G.E * 4); S.a1 = (float *)sv.take(G.E * 4); S.c2 = (float *)sv.take(G.E * 4); S.rd = (float *)sv.take(G.E * 4);
+    S.lnstats = (float *)sv.take(G.M * 2 * 4);
+    S.lka_bytes = dlka_lka3d_tokens_saved_bytes(B, C, D, H, W, DLKA_F32);
+    S.lka = sv.take(S.lka_bytes);
+    return sv.ok();
+}
+
+}  // namespace
+
+int dlka_tblock3d_supported(int B, int C, int D, int H, int W, int dtype) { return (dtype == DLKA_F32 && tblock_supported(B, C, D, H, W)) ? 1 : 0; }
+
+size_t dlka_tblock3d_saved_bytes(int B, int C, int D, int H, int W, int dtype)
+{
+    if (!dlka_tblock3d_supported(B, C, D, H, W, dtype)) return 0;
+    TBlockGeoms G(B, C, D, H, W);
+    return 8 * align256(G.E * 4) + align256(G.M * 2 * 4) + align256(dlka_lka3d_tokens_saved_bytes(B, C, D, H, W, dtype));
+}
+
+size_t dlka_tblock3d_workspace_bytes(int B, int C, int D, int H, int W, int dtype)
+{
+    if (!dlka_tblock3d_supported(B, C, D, H, W, dtype)) return 0;
+    TBlockGeoms G(B, C, D, H, W);
+    return align256(dlka_lka3d_tokens_workspace_bytes(B, C, D, H, W, dtype)) + align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) +
+           6 * align256(G.E * 4) + align256(4096);
+}
+
+int dlka_tblock3d_forward(const void *x, int x_planar, const dlka_tblock3d_params *p, const dlka_lka3d_params *lka, const void *drop_mask, int training,
+                          void *bn_stats, void *y, void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W,
+                          float ln_eps, float bn_eps, int dtype, void *stream)
+{
+    if (!x || !p || !lka || !bn_stats || !y || !saved || !workspace) return DLKA_ERR_NULL;
+    if (!p->norm_w || !p->norm_b || !p->gamma || !p->conv51_conv1_w || !p->conv51_conv2_w || !p->conv51_norm1_w || !p->conv51_norm1_b ||
+        !p->conv51_norm2_w || !p->conv51_norm2_b || !p->conv8_w || !p->conv8_b)
+        return DLKA_ERR_NULL;
+    if (!dlka_tblock3d_supported(B, C, D, H, W, dtype)) return DLKA_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    TBlockGeoms G(B, C, D, H, W);
+    Carver sv(saved, saved_bytes), cv(workspace, workspace_bytes);
+    TBlockSaved S;
+    if (!carve_tblock_saved(sv, G, B, C, D, H, W, S)) return DLKA_ERR_WORKSPACE;
+    const size_t lka_ws_bytes = dlka_lka3d_tokens_workspace_bytes(B, C, D, H, W, dtype);
+    void *lka_ws = cv.take(lka_ws_bytes);
+    float *wp = (float *)cv.take(G.wp_floats() * 4);
+    float *sums = (float *)cv.take(4096);
+    if (!cv.ok()) return DLKA_ERR_WORKSPACE;
+    const long M = (long)G.M, N = G.c3.N;
+    float *st1 = (float *)bn_stats, *st2 = st1 + 3 * C;
+    const float slope = 0.01f;   // UnetResBlock's act_name default (dynunet_block.py:41)
+    // tokens (+ pos_embed) and LayerNorm (:620-624)
+    DLKA_TRY(launch_cl_layernorm_fwd((const float *)x, x_planar, (const float *)p->pos_embed, (const float *)p->norm_w, (const float *)p->norm_b, S.xt, S.xn,
+                                     S.lnstats, B, (int)N, C, ln_eps, st));
+    // epa_block = the D-LKA block (:624)
+    DLKA_TRY(dlka_lka3d_attention_tokens_forward(S.xn, lka, S.e, S.lka, S.lka_bytes, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, stream));
+    // attn = x + gamma * epa (:624); attn IS attn_skip in channels-last memory (:626 is a view here)
+    DLKA_TRY(launch_cl_scale_residual_fwd(S.xt, S.e, (const float *)p->gamma, S.attn, M, C, st));
+    // conv51 = UnetResBlock (dynunet_block.py:66-80)
+    DLKA_TRY(dense_forward(G.c3, S.attn, (const float *)p->conv51_conv1_w, nullptr, S.c1, 0, wp, 0, nullptr, nullptr, st));
+    if (training) DLKA_TRY(launch_cl_bn_stats(S.c1, sums, st1, M, C, bn_eps, st));
+    DLKA_TRY(launch_cl_bn_apply(S.c1, nullptr, (const float *)p->conv51_norm1_w, (const float *)p->conv51_norm1_b, st1, nullptr, S.a1, M, N, C, slope, st));
+    DLKA_TRY(dense_forward(G.c3, S.a1, (const float *)p->conv51_conv2_w, nullptr, S.c2, 0, wp, 0, nullptr, nullptr, st));
+    if (training) DLKA_TRY(launch_cl_bn_stats(S.c2, sums, st2, M, C, bn_eps, st));
+    // ... + residual, LeakyReLU, and conv8[0] = Dropout3d folded into the same pass (:611)
+    DLKA_TRY(launch_cl_bn_apply(S.c2, S.attn, (const float *)p->conv51_norm2_w, (const float *)p->conv51_norm2_b, st2, (const float *)drop_mask, S.rd, M, N, C, slope, st));
+    // x = attn_skip + conv8(attn) (:628)
+    DLKA_TRY(dense_forward(G.pw, S.rd, (const float *)p->conv8_w, (const float *)p->conv8_b, (float *)y, 0, wp, 3, S.attn, nullptr, st));
+    return DLKA_OK;
+}
+
+int dlka_tblock3d_backward(const dlka_tblock3d_params *p, const dlka_lka3d_params *lka, const void *drop_mask, int training, const void *bn_stats,
+                           const void *grad_y, const void *saved, size_t saved_bytes, void *grad_x, const dlka_tblock3d_grads *gr,
+                           const dlka_lka3d_grads *glka, void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, void *stream)
+{
+    if (!p || !lka || !bn_stats || !grad_y || !saved || !grad_x || !gr || !glka || !workspace) return DLKA_ERR_NULL;
+    if (!gr->norm_w || !gr->norm_b || !gr->gamma || !gr->conv51_conv1_w || !gr->conv51_conv2_w || !gr->conv51_norm1_w || !gr->conv51_norm1_b ||
+        !gr->conv51_norm2_w || !gr->conv51_norm2_b || !gr->conv8_w || !gr->conv8_b)
+        return DLKA_ERR_NULL;
+    if ((p->pos_embed != nullptr) != (gr->pos_embed != nullptr)) return DLKA_ERR_NULL;
+    if (!dlka_tblock3d_supported(B, C, D, H, W, dtype)) return DLKA_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    TBlockGeoms G(B, C, D, H, W);
+    Carver sv((void *)saved, saved_bytes), cv(workspace, workspace_bytes);
+    TBlockSaved S;
+    if (!carve_tblock_saved(sv, G, B, C, D, H, W, S)) return DLKA_ERR_WORKSPACE;
+    const size_t lka_ws_bytes = dlka_lka3d_tokens_workspace_bytes(B, C, D, H, W, dtype);
+    void *lka_ws = cv.take(lka_ws_bytes);
+    float *wp = (float *)cv.take(G.wp_floats() * 4);
+    float *part = (float *)cv.take(G.part_floats() * 4);
+    float *b0 = (float *)cv.take(G.E * 4), *b1 = (float *)cv.take(G.E * 4), *b2 = (float *)cv.take(G.E * 4), *b3 = (float *)cv.take(G.E * 4);
+    float *b4 = (float *)cv.take(G.E * 4), *b5 = (float *)cv.take(G.E * 4);
+    float *sums = (float *)cv.take(4096);
+    if (!cv.ok()) return DLKA_ERR_WORKSPACE;
+    const long M = (long)G.M, N = G.c3.N;
+    const float *st1 = (const float *)bn_stats, *st2 = st1 + 3 * C;
+    const float *gy = (const float *)grad_y, *mask = (const float *)drop_mask;
+    const float slope = 0.01f;
+    // conv8[1]:  y = W8 rd + b8 + attn
+    float *g_rd = b0;
+    DLKA_TRY(dense_backward_weight(G.pw, S.rd, gy, 0, (float *)gr->conv8_w, (float *)gr->conv8_b, part, st));
+    DLKA_TRY(dense_backward_data(G.pw, gy, 0, (const float *)p->conv8_w, g_rd, wp, 0, nullptr, st));
+    // Dropout3d + LeakyReLU + (BN2(c2) + attn):  g_c2, and everything that flows into attn so far:  g_skip = gy + g_pre
+    float *g_c2 = b1, *g_skip = b2;
+    DLKA_TRY(launch_cl_bn_bwd(g_rd, mask, S.c2, S.rd, (const float *)p->conv51_norm2_w, st2, sums, g_c2, g_skip, gy, (float *)gr->conv51_norm2_w,
+                              (float *)gr->conv51_norm2_b, M, N, C, slope, training, st));
+    // conv2
+    float *g_a1 = b0;
+    DLKA_TRY(dense_backward_weight(G.c3, S.a1, g_c2, 0, (float *)gr->conv51_conv2_w, nullptr, part, st));
+    DLKA_TRY(dense_backward_data(G.c3, g_c2, 0, (const float *)p->conv51_conv2_w, g_a1, wp, 0, nullptr, st));
+    // LeakyReLU + BN1
+    float *g_c1 = b1;
+    DLKA_TRY(launch_cl_bn_bwd(g_a1, nullptr, S.c1, S.a1, (const float *)p->conv51_norm1_w, st1, sums + 512, g_c1, nullptr, nullptr, (float *)gr->conv51_norm1_w,
+                              (float *)gr->conv51_norm1_b, M, N, C, slope, training, st));
+    // conv1:  g_attn = W1^T g_c1 + g_skip
+    float *g_attn = b3;
+    DLKA_TRY(dense_backward_weight(G.c3, S.attn, g_c1, 0, (float *)gr->conv51_conv1_w, nullptr, part, st));
+    DLKA_TRY(dense_backward_data(G.c3, g_c1, 0, (const float *)p->conv51_conv1_w, g_attn, wp, 3, g_skip, st));
+    // attn = xt + gamma * e
+    float *g_e = b4;
+    DLKA_TRY(launch_cl_scale_residual_bwd(g_attn, S.e, (const float *)p->gamma, g_e, (float *)gr->gamma, M, C, st));
+    // epa_block
+    float *g_xn = b5;
+    DLKA_TRY(dlka_lka3d_attention_tokens_backward(S.xn, lka, g_e, S.lka, S.lka_bytes, g_xn, glka, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, stream));
+    // LayerNorm (+ the residual branch g_attn), pos_embed
+    DLKA_TRY(launch_cl_layernorm_bwd(g_xn, g_attn, S.xt, S.lnstats, (const float *)p->norm_w, (float *)grad_x, (float *)gr->norm_w, (float *)gr->norm_b,
+                                     (float *)gr->pos_embed, B, (int)N, C, st));
+    return DLKA_OK;
+}
+
 }  // extern "C"

@@ -441,3 +441,184 @@ def lka3d_attention_tokens_backward(x, params, grad_y, saved, dims):
                                                   L.ptr(ws), wb, B, C, D, H, W, dt, L.stream_ptr(x))
     L.check(rc, "lka3d_attention_tokens_backward")
     return gx, grads
+
+
+# ------------------------------------------------------------------------------------------------------------
+# TransformerBlock_3D_single_deform_LKA (transformerblock.py:570-630): the wrapper around the D-LKA block
+# ------------------------------------------------------------------------------------------------------------
+def tblock3d_supported(x, B, C, D, H, W) -> bool:
+    if x.dtype != torch.float32:
+        return False
+    return bool(L.get_lib().dlka_tblock3d_supported(B, C, D, H, W, L.DLKA_F32))
+
+
+def _opt_ptr_struct(cls, fields, tensors):
+    st = cls()
+    for f, t in zip(fields, tensors):
+        setattr(st, f, None if t is None else L.ptr(t))
+    return st
+
+
+def tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_stats, dims, ln_eps=1e-5, bn_eps=1e-5):
+    """x: [B, C, N...] contiguous NCDHW (x_planar) or [B, N, C] tokens; dims = the reference's (H, W, D).
+    Returns (y tokens [B, N, C], saved).  bn_stats [6*C] is written (training) or read (eval)."""
+    L.require_device(x, bn_stats, drop_mask, *[t for t in tparams if t is not None], *lka_params)
+    assert x.is_contiguous() and bn_stats.is_contiguous()
+    tparams = [None if t is None else t.contiguous() for t in tparams]
+    lka_params = [t.contiguous() for t in lka_params]
+    D, H, W = (int(v) for v in dims)
+    N = D * H * W
+    B = int(x.shape[0])
+    C = int(x.shape[1] if x_planar else x.shape[-1])
+    assert x.numel() == B * N * C
+    lib = L.get_lib()
+    dt = L.dtype_code(x)
+    sb, wb = lib.dlka_tblock3d_saved_bytes(B, C, D, H, W, dt), lib.dlka_tblock3d_workspace_bytes(B, C, D, H, W, dt)
+    if sb == 0:
+        L.check(-8, "tblock3d_forward")
+    saved, ws = L.scratch(sb, x), L.scratch(wb, x)
+    y = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
+    ps = _opt_ptr_struct(L.TBlock3dPtrs, L.TBLOCK3D_FIELDS, tparams)
+    lk = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, lka_params)
+    rc = lib.dlka_tblock3d_forward(L.ptr(x), int(bool(x_planar)), byref(ps), byref(lk), L.ptr(drop_mask), int(bool(training)), L.ptr(bn_stats),
+                                   L.ptr(y), L.ptr(saved), sb, L.ptr(ws), wb, B, C, D, H, W, float(ln_eps), float(bn_eps), dt, L.stream_ptr(x))
+    L.check(rc, "tblock3d_forward")
+    return y, saved
+
+
+def tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, grad_y, saved, dims):
+    """Returns (grad_x tokens [B, N, C], grads of tparams (None where the parameter is None), grads of lka_params)."""
+    L.require_device(grad_y, saved, bn_stats)
+    grad_y = grad_y.contiguous()
+    tparams = [None if t is None else t.contiguous() for t in tparams]
+    lka_params = [t.contiguous() for t in lka_params]
+    B, N, C = (int(v) for v in grad_y.shape)
+    D, H, W = (int(v) for v in dims)
+    lib = L.get_lib()
+    dt = L.dtype_code(grad_y)
+    wb = lib.dlka_tblock3d_workspace_bytes(B, C, D, H, W, dt)
+    ws = L.scratch(wb, grad_y)
+    gx = torch.empty_like(grad_y)
+    tg = [None if t is None else torch.empty_like(t) for t in tparams]
+    lg = [torch.empty_like(t) for t in lka_params]
+    ps = _opt_ptr_struct(L.TBlock3dPtrs, L.TBLOCK3D_FIELDS, tparams)
+    lk = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, lka_params)
+    gs = _opt_ptr_struct(L.TBlock3dPtrs, L.TBLOCK3D_FIELDS, tg)
+    gl = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, lg)
+    rc = lib.dlka_tblock3d_backward(byref(ps), byref(lk), L.ptr(drop_mask), int(bool(training)), L.ptr(bn_stats), L.ptr(grad_y), L.ptr(saved),
+                                    saved.numel(), L.ptr(gx), byref(gs), byref(gl), L.ptr(ws), wb, B, C, D, H, W, dt, L.stream_ptr(grad_y))
+    L.check(rc, "tblock3d_backward")
+    return gx, tg, lg
+
+
+# ---- the wrapper's pieces, one by one (used by UnetResBlock standalone and by the parity tests) ---------------------------
+def layernorm_tokens_forward(x, x_planar, pos, weight, bias, eps=1e-5):
+    """x: NCDHW-contiguous [B, C, ...] (x_planar) or tokens [B, N, C].  Returns (xt, xn, stats[M, 2])."""
+    L.require_device(x, pos, weight, bias)
+    x = x.contiguous()
+    B = int(x.shape[0])
+    C = int(x.shape[1] if x_planar else x.shape[-1])
+    N = x.numel() // (B * C)
+    xt = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
+    xn = torch.empty_like(xt)
+    stats = torch.empty((B * N, 2), dtype=torch.float32, device=x.device)
+    rc = L.get_lib().dlka_layernorm_tokens_forward(L.ptr(x), int(bool(x_planar)), L.ptr(None if pos is None else pos.contiguous()), L.ptr(weight.contiguous()),
+                                                   L.ptr(bias.contiguous()), L.ptr(xt), L.ptr(xn), L.ptr(stats), B, N, C, float(eps), L.dtype_code(x),
+                                                   L.stream_ptr(x))
+    L.check(rc, "layernorm_tokens_forward")
+    return xt, xn, stats
+
+
+def layernorm_tokens_backward(g_xn, g_res, xt, stats, weight, with_pos=False):
+    L.require_device(g_xn, g_res, xt, stats, weight)
+    B, N, C = (int(v) for v in xt.shape)
+    g_xn = g_xn.contiguous()
+    g_res = None if g_res is None else g_res.contiguous()
+    gxt = torch.empty_like(xt)
+    gw, gb = torch.empty_like(weight), torch.empty_like(weight)
+    gpos = torch.empty((1, N, C), dtype=xt.dtype, device=xt.device) if with_pos else None
+    rc = L.get_lib().dlka_layernorm_tokens_backward(L.ptr(g_xn), L.ptr(g_res), L.ptr(xt), L.ptr(stats), L.ptr(weight.contiguous()), L.ptr(gxt), L.ptr(gw),
+                                                    L.ptr(gb), L.ptr(gpos), B, N, C, L.dtype_code(xt), L.stream_ptr(xt))
+    L.check(rc, "layernorm_tokens_backward")
+    return gxt, gw, gb, gpos
+
+
+def scale_residual_forward(xt, e, gamma):
+    L.require_device(xt, e, gamma)
+    xt, e = xt.contiguous(), e.contiguous()
+    out = torch.empty_like(xt)
+    C = int(xt.shape[-1])
+    rc = L.get_lib().dlka_scale_residual_forward(L.ptr(xt), L.ptr(e), L.ptr(gamma.contiguous()), L.ptr(out), xt.numel() // C, C, L.dtype_code(xt),
+                                                 L.stream_ptr(xt))
+    L.check(rc, "scale_residual_forward")
+    return out
+
+
+def scale_residual_backward(g, e, gamma):
+    L.require_device(g, e, gamma)
+    g, e = g.contiguous(), e.contiguous()
+    ge, gg = torch.empty_like(e), torch.empty_like(gamma)
+    C = int(e.shape[-1])
+    rc = L.get_lib().dlka_scale_residual_backward(L.ptr(g), L.ptr(e), L.ptr(gamma.contiguous()), L.ptr(ge), L.ptr(gg), e.numel() // C, C, L.dtype_code(e),
+                                                  L.stream_ptr(e))
+    L.check(rc, "scale_residual_backward")
+    return ge, gg
+
+
+def batchnorm_cl_forward(x, res, weight, bias, stats, training, eps=1e-5, slope=0.01):
+    """x: channels-last [..., C].  y = LeakyReLU(BN(x) (+ res)).  stats [3*C] written (training) or read (eval: {mean, rstd})."""
+    L.require_device(x, res, weight, bias, stats)
+    x = x.contiguous()
+    res = None if res is None else res.contiguous()
+    C = int(x.shape[-1])
+    y = torch.empty_like(x)
+    scr = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    rc = L.get_lib().dlka_batchnorm_cl_forward(L.ptr(x), L.ptr(res), L.ptr(weight.contiguous()), L.ptr(bias.contiguous()), L.ptr(stats), int(bool(training)),
+                                               L.ptr(y), L.ptr(scr), x.numel() // C, C, float(eps), float(slope), L.dtype_code(x), L.stream_ptr(x))
+    L.check(rc, "batchnorm_cl_forward")
+    return y
+
+
+def batchnorm_cl_backward(g, x, y, weight, stats, training, with_res=False, slope=0.01):
+    L.require_device(g, x, y, weight, stats)
+    g, x, y = g.contiguous(), x.contiguous(), y.contiguous()
+    C = int(x.shape[-1])
+    gx = torch.empty_like(x)
+    gres = torch.empty_like(x) if with_res else None
+    gw, gb = torch.empty_like(weight), torch.empty_like(weight)
+    scr = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    rc = L.get_lib().dlka_batchnorm_cl_backward(L.ptr(g), L.ptr(x), L.ptr(y), L.ptr(weight.contiguous()), L.ptr(stats), int(bool(training)), L.ptr(gx),
+                                                L.ptr(gres), L.ptr(gw), L.ptr(gb), L.ptr(scr), x.numel() // C, C, float(slope), L.dtype_code(x),
+                                                L.stream_ptr(x))
+    L.check(rc, "batchnorm_cl_backward")
+    return gx, gres, gw, gb
+
+
+def channel_scale(x, mask):
+    """x [B, ..., C] channels-last, mask [B, C]."""
+    L.require_device(x, mask)
+    x, mask = x.contiguous(), mask.contiguous()
+    B, C = int(x.shape[0]), int(x.shape[-1])
+    y = torch.empty_like(x)
+    rc = L.get_lib().dlka_channel_scale(L.ptr(x), L.ptr(mask), L.ptr(y), B, x.numel() // (B * C), C, L.dtype_code(x), L.stream_ptr(x))
+    L.check(rc, "channel_scale")
+    return y
+
+
+def ncdhw_to_ndhwc(x):
+    """[B, C, *S] contiguous -> [B, *S, C] contiguous (HIP transpose)."""
+    L.require_device(x)
+    x = x.contiguous()
+    B, C = int(x.shape[0]), int(x.shape[1])
+    out = torch.empty((B, *x.shape[2:], C), dtype=x.dtype, device=x.device)
+    L.check(L.get_lib().dlka_ncdhw_to_ndhwc(L.ptr(x), L.ptr(out), B, C, x.numel() // (B * C), L.dtype_code(x), L.stream_ptr(x)), "ncdhw_to_ndhwc")
+    return out
+
+
+def ndhwc_to_ncdhw(x):
+    L.require_device(x)
+    x = x.contiguous()
+    B, C = int(x.shape[0]), int(x.shape[-1])
+    out = torch.empty((B, C, *x.shape[1:-1]), dtype=x.dtype, device=x.device)
+    L.check(L.get_lib().dlka_ndhwc_to_ncdhw(L.ptr(x), L.ptr(out), B, C, x.numel() // (B * C), L.dtype_code(x), L.stream_ptr(x)), "ndhwc_to_ncdhw")
+    return out

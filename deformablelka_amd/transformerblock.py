@@ -1,5 +1,6 @@
-"""3-D D-LKA modules — ``LKA3d_deform`` and ``LKA_Attention3d_deform`` with the constructor / forward signatures and
-``state_dict`` keys of 3D/d_lka_former/network_architecture/synapse/transformerblock.py:634-673.
+"""3-D D-LKA modules — ``TransformerBlock_3D_single_deform_LKA``, ``LKA3d_deform`` and ``LKA_Attention3d_deform`` with the
+constructor / forward signatures and ``state_dict`` keys of
+3D/d_lka_former/network_architecture/synapse/transformerblock.py:570-673.
 
 ``LKA_Attention3d_deform.forward(x, B, C, H, W, D)`` runs the whole block (proj_1, GELU, dw 5^3, dw 7^3 dil 3,
 offset-predict conv, deformable 3^3 conv, conv1, gate, proj_2, residual) as ONE C-ABI call per direction
@@ -11,6 +12,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import nn_ops, ops
+from .dynunet_block import UnetResBlock, bn_eval_stats, bn_update_running
 from .modules.deform_conv import DeformConvPack
 
 
@@ -99,3 +101,88 @@ class LKA_Attention3d_deform(nn.Module):
         x = self.forward_volume(x)
         x = x.reshape(B, C, H * W * D).permute(0, 2, 1)  # (:672)
         return x
+
+
+class _TBlock3dFn(Function):
+    """The whole wrapper block: one C-ABI call per direction (``dlka_tblock3d_forward/backward``)."""
+
+    @staticmethod
+    def forward(ctx, x, x_planar, dims, drop_mask, training, bn_stats, eps, *params):
+        tparams, lka_params = params[:12], params[12:]
+        y, saved = ops.tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_stats, dims, eps[0], eps[1])
+        ctx.cfg = (x_planar, dims, training, tuple(x.shape), [p is not None for p in tparams])
+        ctx.save_for_backward(saved, bn_stats, drop_mask, *[p for p in params if p is not None])
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x_planar, dims, training, xshape, present = ctx.cfg
+        saved, bn_stats, drop_mask, *ps = ctx.saved_tensors
+        it = iter(ps)
+        tparams = [next(it) if here else None for here in present]
+        lka_params = list(it)
+        gx, tg, lg = ops.tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, gy, saved, dims)
+        if x_planar:   # gradient w.r.t. the NCDHW input = the permuted view of the token gradient
+            B, C = xshape[0], xshape[1]
+            gx = gx.view(B, *xshape[2:], C).permute(0, 4, 1, 2, 3)
+        else:
+            gx = gx.view(xshape)
+        return (gx, None, None, None, None, None, None, *tg, *lg)
+
+
+class TransformerBlock_3D_single_deform_LKA(nn.Module):
+    """transformerblock.py:570-630.  ``forward(x)`` takes the (B, C, H, W, D) volume and returns a (B, C, H, W, D) tensor that is
+    the permuted view of channels-last memory — the reference's own ``attn_skip`` is such a view too (:626).  A following block
+    recognises that layout and reads the tokens without a copy."""
+
+    def __init__(self, input_size: int, hidden_size: int, proj_size: int, num_heads: int, dropout_rate: float = 0.0, pos_embed=False) -> None:
+        super().__init__()
+        if not (0 <= dropout_rate <= 1):
+            raise ValueError("dropout_rate should be between 0 and 1.")
+        if hidden_size % num_heads != 0:
+            raise ValueError("hidden_size should be divisible by num_heads.")
+        self.norm = nn.LayerNorm(hidden_size)
+        self.gamma = nn.Parameter(1e-6 * torch.ones(hidden_size), requires_grad=True)
+        self.epa_block = LKA_Attention3d_deform(d_model=hidden_size)
+        self.conv51 = UnetResBlock(3, hidden_size, hidden_size, kernel_size=3, stride=1, norm_name="batch")
+        self.conv8 = nn.Sequential(nn.Dropout3d(0.1, False), nn.Conv3d(hidden_size, hidden_size, 1))
+        self.pos_embed = None
+        if pos_embed:
+            self.pos_embed = nn.Parameter(torch.zeros(1, input_size, hidden_size))
+
+    def _draw_drop_mask(self, B, C, dtype, device):
+        """conv8[0] = Dropout3d: the same draw F.dropout3d makes for its (B, C, 1, 1, 1) noise tensor, bernoulli(1 - p) / (1 - p),
+        from the device's generator.  The kernels only consume the [B, C] multipliers."""
+        return torch.nn.functional.dropout3d(torch.ones(B, C, 1, 1, 1, dtype=dtype, device=device), self.conv8[0].p, True).view(B, C)
+
+    def wrapper_params(self):
+        """The 12 tensors in ``dlka_tblock3d_params`` order (include/dlka.h)."""
+        c = self.conv51
+        return (self.norm.weight, self.norm.bias, self.gamma, self.pos_embed, c.conv1.conv.weight, c.conv2.conv.weight, c.norm1.weight, c.norm1.bias,
+                c.norm2.weight, c.norm2.bias, self.conv8[1].weight, self.conv8[1].bias)
+
+    def forward(self, x):
+        B, C, H, W, D = x.shape
+        if not ops.tblock3d_supported(x, B, C, H, W, D):
+            raise NotImplementedError(f"TransformerBlock_3D_single_deform_LKA on the HIP path needs float32 and hidden_size in {{32, 64, 128, 256}}; "
+                                      f"got {x.dtype}, C={C}")
+        tokens = x.permute(0, 2, 3, 4, 1)
+        if tokens.is_contiguous():       # e.g. the previous block's output: already [B][N][C] in memory
+            xin, planar = tokens, False
+        else:
+            xin, planar = x.contiguous(), True
+        drop = self.conv8[0]
+        mask = self._draw_drop_mask(B, C, x.dtype, x.device) if drop.training and drop.p > 0 else None
+        c = self.conv51
+        training = c.norm1.training
+        if training:
+            stats = torch.empty(6 * C, dtype=torch.float32, device=x.device)
+        else:
+            stats = torch.cat([bn_eval_stats(c.norm1), bn_eval_stats(c.norm2)])
+        y = _TBlock3dFn.apply(xin, planar, (H, W, D), mask, training, stats, (self.norm.eps, c.norm1.eps), *self.wrapper_params(),
+                              *self.epa_block.block_params())
+        if training:
+            bn_update_running(c.norm1, stats[:3 * C])
+            bn_update_running(c.norm2, stats[3 * C:])
+        return y.view(B, H, W, D, C).permute(0, 4, 1, 2, 3)

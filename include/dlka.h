@@ -275,6 +275,77 @@ int dlka_lka3d_attention_tokens_backward(const void *x, const dlka_lka3d_params 
                                          void *workspace, size_t workspace_bytes,
                                          int B, int C, int D, int H, int W, int dtype, void *stream);
 
+/* =======================================================================================
+ * TransformerBlock_3D_single_deform_LKA: what surrounds the D-LKA block
+ * ======================================================================================= *
+ * The reference wrapper (3D/d_lka_former/network_architecture/synapse/transformerblock.py:617-630) reshapes the NCDHW
+ * volume to tokens (a permute copy), adds pos_embed, applies nn.LayerNorm, computes x + gamma * epa_block(...), permutes
+ * back (another copy) and runs UnetResBlock (two 3^3 convs, BatchNorm3d, LeakyReLU 0.01; dynunet_block.py:12-80) and
+ * Dropout3d + 1x1x1 conv.  Here everything stays in token / channels-last layout [M = B*N][C], fp32, C <= 256; the
+ * convolutions go through dlka_conv3d_*_cl, the rest through the entry points below.                                  */
+
+/* xt = tokens(x) (+ pos[N][C]);  xn = LayerNorm(xt) * w + b (biased variance, eps inside the sqrt: nn.LayerNorm, :609,:624);
+ * stats[m] = {mean, rstd}.  x is the block input either as the NCDHW tensor itself (x_planar = 1: [B][C][N], read strided —
+ * replaces the reshape/permute copy of :620) or already as tokens (x_planar = 0). */
+int dlka_layernorm_tokens_forward(const void *x, int x_planar, const void *pos, const void *w, const void *b, void *xt, void *xn,
+                                  void *stats, int B, int N, int C, float eps, int dtype, void *stream);
+/* gxt = (g_res ? g_res : 0) + LayerNorm backward of g_xn;  gw, gb, gpos ([N][C], optional) fully overwritten. */
+int dlka_layernorm_tokens_backward(const void *g_xn, const void *g_res, const void *xt, const void *stats, const void *w, void *gxt,
+                                   void *gw, void *gb, void *gpos, int B, int N, int C, int dtype, void *stream);
+/* out = xt + gamma[c] * e   (:624, gamma = 1e-6 * ones at construction, :610) */
+int dlka_scale_residual_forward(const void *xt, const void *e, const void *gamma, void *out, int64_t M, int C, int dtype, void *stream);
+/* ge = gamma[c] * g;  ggamma[c] = sum_m g * e */
+int dlka_scale_residual_backward(const void *g, const void *e, const void *gamma, void *ge, void *ggamma, int64_t M, int C, int dtype,
+                                 void *stream);
+/* y = LeakyReLU(BatchNorm(x) (+ res))   (dynunet_block.py:68-79; nn.BatchNorm3d over (B, spatial) per channel).
+ * training = 1: batch statistics are computed and written to stats = {mean[C], rstd[C], unbiased var[C]};
+ * training = 0: stats[0..2C) = {running_mean, 1/sqrt(running_var + eps)} supplied by the caller.  scratch: 2*C floats. */
+int dlka_batchnorm_cl_forward(const void *x, const void *res, const void *w, const void *b, void *stats, int training, void *y,
+                              void *scratch, int64_t M, int C, float eps, float slope, int dtype, void *stream);
+/* gx, gw, gb fully overwritten; gres (optional) = gradient of the residual input.  scratch: 2*C floats. */
+int dlka_batchnorm_cl_backward(const void *g, const void *x, const void *y, const void *w, const void *stats, int training, void *gx,
+                               void *gres, void *gw, void *gb, void *scratch, int64_t M, int C, float slope, int dtype, void *stream);
+/* y[b][n][c] = x[b][n][c] * mask[b][c]   (nn.Dropout3d drops whole channels per sample, :611; the mask comes from the caller's RNG) */
+int dlka_channel_scale(const void *x, const void *mask, void *y, int B, int64_t N, int C, int dtype, void *stream);
+
+/* ---- the whole wrapper block, one call per direction --------------------------------------------------------------- */
+/* Parameters of TransformerBlock_3D_single_deform_LKA other than epa_block's (those travel as dlka_lka3d_params):
+ * state_dict keys norm.*, gamma, pos_embed, conv51.conv{1,2}.conv.weight, conv51.norm{1,2}.*, conv8.1.* (:609-616). */
+typedef struct dlka_tblock3d_params {
+    const void *norm_w, *norm_b;                         /* [C]             nn.LayerNorm                                   */
+    const void *gamma;                                   /* [C]                                                           */
+    const void *pos_embed;                               /* [N][C] or NULL  (pos_embed=False)                             */
+    const void *conv51_conv1_w, *conv51_conv2_w;         /* [C][C][3][3][3] UnetResBlock convs, no bias                   */
+    const void *conv51_norm1_w, *conv51_norm1_b;         /* [C]             BatchNorm3d affine                            */
+    const void *conv51_norm2_w, *conv51_norm2_b;         /* [C]                                                           */
+    const void *conv8_w, *conv8_b;                       /* [C][C][1][1][1], [C]   conv8[1]                               */
+} dlka_tblock3d_params;
+
+typedef struct dlka_tblock3d_grads { /* same shapes; all fully overwritten; pos_embed NULL iff the parameter is */
+    void *norm_w, *norm_b, *gamma, *pos_embed, *conv51_conv1_w, *conv51_conv2_w, *conv51_norm1_w, *conv51_norm1_b,
+         *conv51_norm2_w, *conv51_norm2_b, *conv8_w, *conv8_b;
+} dlka_tblock3d_grads;
+
+int dlka_tblock3d_supported(int B, int C, int D, int H, int W, int dtype);   /* fp32, C in {32,64,128,256} */
+size_t dlka_tblock3d_saved_bytes(int B, int C, int D, int H, int W, int dtype);
+size_t dlka_tblock3d_workspace_bytes(int B, int C, int D, int H, int W, int dtype);
+/* Replaces TransformerBlock_3D_single_deform_LKA.forward (transformerblock.py:617-630).
+ *   x: the block input, NCDHW [B][C][N] (x_planar = 1) or already tokens [B][N][C] (x_planar = 0, e.g. the previous block's y);
+ *   y: tokens [B][N][C] — the reference's (B, C, H, W, D) result is the permuted VIEW of this memory;
+ *   drop_mask: [B][C] multipliers of conv8[0] = Dropout3d(0.1) drawn by the caller's RNG ({0, 1/(1-p)}), NULL = no dropout (eval);
+ *   bn_stats: 6*C floats {mean1, rstd1, var1, mean2, rstd2, var2}: written in training mode (var = unbiased batch variance, for the
+ *             caller's running-statistics update), read in eval mode (mean = running_mean, rstd = 1/sqrt(running_var + eps));
+ *             must be handed unchanged to the matching backward call, like `saved`. */
+int dlka_tblock3d_forward(const void *x, int x_planar, const dlka_tblock3d_params *p, const dlka_lka3d_params *lka,
+                          const void *drop_mask, int training, void *bn_stats, void *y,
+                          void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes,
+                          int B, int C, int D, int H, int W, float ln_eps, float bn_eps, int dtype, void *stream);
+/* grad_y, grad_x: tokens [B][N][C] (grad wrt the NCDHW input is the permuted view of grad_x). */
+int dlka_tblock3d_backward(const dlka_tblock3d_params *p, const dlka_lka3d_params *lka, const void *drop_mask, int training,
+                           const void *bn_stats, const void *grad_y, const void *saved, size_t saved_bytes, void *grad_x,
+                           const dlka_tblock3d_grads *grads, const dlka_lka3d_grads *lka_grads,
+                           void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

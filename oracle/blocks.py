@@ -37,6 +37,39 @@ def lka3d_attention_tokens(x, P, B, C, H, W, D):
     return v.reshape(B, C, H * W * D).permute(0, 2, 1)
 
 
+def unet_res_block(x, P, prefix, training, stats_out=None):
+    """UnetResBlock(3, C, C, kernel_size=3, stride=1, norm_name="batch").forward — dynunet_block.py:66-80 with MONAI 0.8's
+    factories resolved (Convolution conv_only -> Conv3d bias=False padding 1; "batch" -> BatchNorm3d; LeakyReLU 0.01).
+    Running statistics are NOT updated in place (the caller's dict stays intact); in training mode batch statistics are used."""
+    def bn(v, n):
+        rm, rv = P[prefix + n + ".running_mean"], P[prefix + n + ".running_var"]
+        if training:
+            return F.batch_norm(v, None, None, P[prefix + n + ".weight"], P[prefix + n + ".bias"], True, 0.1, 1e-5)
+        return F.batch_norm(v, rm, rv, P[prefix + n + ".weight"], P[prefix + n + ".bias"], False, 0.1, 1e-5)
+    out = F.conv3d(x, P[prefix + "conv1.conv.weight"], None, padding=1)          # :68
+    out = F.leaky_relu(bn(out, "norm1"), 0.01)                                   # :69-70
+    out = F.conv3d(out, P[prefix + "conv2.conv.weight"], None, padding=1)        # :71
+    out = bn(out, "norm2")                                                       # :72
+    return F.leaky_relu(out + x, 0.01)                                           # :77-79
+
+
+def transformer_block_3d(x, P, training=False, drop_mask=None):
+    """TransformerBlock_3D_single_deform_LKA.forward — transformerblock.py:617-630.  drop_mask: the (B, C) multipliers of
+    conv8[0] = Dropout3d(0.1) (None = eval / no dropout)."""
+    B, C, H, W, D = x.shape
+    t = x.reshape(B, C, H * W * D).permute(0, 2, 1)                              # :620
+    if "pos_embed" in P and P["pos_embed"] is not None:
+        t = t + P["pos_embed"]                                                   # :622-623
+    n = F.layer_norm(t, (C,), P["norm.weight"], P["norm.bias"], 1e-5)
+    lka = {k[len("epa_block."):]: v for k, v in P.items() if k.startswith("epa_block.")}
+    attn = t + P["gamma"] * lka3d_attention_tokens(n, lka, B, C, H, W, D)        # :624
+    skip = attn.reshape(B, H, W, D, C).permute(0, 4, 1, 2, 3)                    # :626
+    a = unet_res_block(skip, P, "conv51.", training)                             # :627
+    if drop_mask is not None:
+        a = a * drop_mask.view(B, C, 1, 1, 1)
+    return skip + F.conv3d(a, P["conv8.1.weight"], P["conv8.1.bias"])            # :628
+
+
 def deform_conv_2d_pack(x, P, prefix, k, pad, dil, groups):
     """2-D ``DeformConv.forward`` — 2D/deformable_LKA/deformable_LKA.py:27-30."""
     off = F.conv2d(x, P[prefix + "offset_net.weight"], P[prefix + "offset_net.bias"], padding=pad, dilation=dil)

@@ -71,18 +71,42 @@ def _install_stubs():
     sys.modules["fvcore"] = fv
     sys.modules["fvcore.nn"] = fvnn
 
-    # monai is only needed by UnetResBlock (wrapper, out of scope); stub the names dynunet_block.py imports
+    # MONAI (the reference pins monai==0.8.1 in its requirements; not installed here, not vendored) supplies the three factories
+    # UnetResBlock is built from (dynunet_block.py:7-9).  Their published behaviour for the arguments the reference passes:
+    #   Convolution(3, cin, cout, strides, kernel_size, bias=False, conv_only=True, padding=p) -> nn.Sequential with ONE child
+    #       "conv" = nn.Conv3d(cin, cout, kernel_size, strides, p, bias=False)      (state_dict key "<name>.conv.weight")
+    #   get_norm_layer("batch", 3, C)  -> nn.BatchNorm3d(C)  (torch defaults: eps 1e-5, momentum 0.1, affine, running stats)
+    #   get_act_layer(("leakyrelu", {"inplace": True, "negative_slope": 0.01})) -> nn.LeakyReLU(0.01, inplace=True)
     for name in ("monai", "monai.networks", "monai.networks.blocks", "monai.networks.blocks.convolutions",
                  "monai.networks.layers", "monai.networks.layers.factories", "monai.networks.layers.utils"):
         sys.modules[name] = types.ModuleType(name)
-    sys.modules["monai.networks.blocks.convolutions"].Convolution = object
+
+    class Convolution(nn.Sequential):
+        def __init__(self, spatial_dims, in_channels, out_channels, strides=1, kernel_size=3, act=None, norm=None, dropout=None, bias=True,
+                     conv_only=False, is_transposed=False, padding=None, output_padding=None):
+            super().__init__()
+            assert spatial_dims == 3 and conv_only and not is_transposed and dropout is None
+            self.add_module("conv", nn.Conv3d(in_channels, out_channels, kernel_size, strides, padding, bias=bias))
+
+    sys.modules["monai.networks.blocks.convolutions"].Convolution = Convolution
+
     class _AnyAttr:
         def __getattr__(self, n):
             return n
     sys.modules["monai.networks.layers.factories"].Act = _AnyAttr()
     sys.modules["monai.networks.layers.factories"].Norm = _AnyAttr()
-    sys.modules["monai.networks.layers.utils"].get_act_layer = lambda *a, **k: None
-    sys.modules["monai.networks.layers.utils"].get_norm_layer = lambda *a, **k: None
+
+    def get_act_layer(name):
+        kind, kw = name
+        assert kind.lower() == "leakyrelu"
+        return nn.LeakyReLU(**kw)
+
+    def get_norm_layer(name, spatial_dims, channels):
+        assert name == "batch" and spatial_dims == 3
+        return nn.BatchNorm3d(channels)
+
+    sys.modules["monai.networks.layers.utils"].get_act_layer = get_act_layer
+    sys.modules["monai.networks.layers.utils"].get_norm_layer = get_norm_layer
 
 
 def _import_reference():
@@ -104,14 +128,20 @@ def _import_reference():
     return tb, dc, dcn_mod, lka2d
 
 
-def _run(module, inputs, seed):
-    """forward + backward with a fixed grad_output; returns everything needed to replay on another implementation."""
+def _run(module, inputs, seed, rng_seed=None):
+    """forward + backward with a fixed grad_output; returns everything needed to replay on another implementation.
+    rng_seed: torch.manual_seed right before the forward (modules that draw dropout noise)."""
     xs = [t.clone().requires_grad_(True) if torch.is_tensor(t) and t.is_floating_point() else t for t in inputs]
+    state_before = {k: v.detach().clone() for k, v in module.state_dict().items()}
+    if rng_seed is not None:
+        torch.manual_seed(rng_seed)
     y = module(*xs)
     gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(seed))
     y.backward(gy)
     return {
-        "state_dict": {k: v.detach().clone() for k, v in module.state_dict().items()},
+        "state_dict": state_before, "rng_seed": rng_seed,
+        # what the forward itself changed (BatchNorm running statistics in training mode)
+        "state_after": {k: v.detach().clone() for k, v in module.state_dict().items() if not torch.equal(v, state_before[k])},
         "inputs": [t.detach().clone() if torch.is_tensor(t) else t for t in inputs],
         "output": y.detach().clone(), "grad_output": gy,
         "grad_inputs": [t.grad.detach().clone() if torch.is_tensor(t) and t.grad is not None else None for t in xs],
@@ -183,6 +213,46 @@ def main():
     m = lka2d.deformable_LKA_Attention(6)
     randomize_offsets_(m, std=0.03)
     gold["deformable_LKA_Attention"] = _run(m, [torch.randn(2, 6, 12, 11)], 19)
+
+    # (8) the wrapper block TransformerBlock_3D_single_deform_LKA (transformerblock.py:570-630) and its UnetResBlock
+    def _liven(m):   # the constructor's gamma = 1e-6 / pos_embed = 0 / BN = identity would hide most of the block
+        with torch.no_grad():
+            m.gamma.normal_(0.5, 0.2)
+            if m.pos_embed is not None:
+                m.pos_embed.normal_(0, 0.5)
+            m.norm.weight.normal_(1.0, 0.2)
+            m.norm.bias.normal_(0, 0.2)
+            for bn in (m.conv51.norm1, m.conv51.norm2):
+                bn.weight.normal_(1.0, 0.2)
+                bn.bias.normal_(0, 0.2)
+                bn.running_mean.normal_(0, 0.3)
+                bn.running_var.uniform_(0.5, 1.5)
+        randomize_offsets_(m, std=0.05)
+
+    B, C, H, W, D = 2, 32, 4, 5, 6
+    torch.manual_seed(20)
+    m = tb.TransformerBlock_3D_single_deform_LKA(input_size=H * W * D, hidden_size=C, proj_size=32, num_heads=4, dropout_rate=0.1, pos_embed=True)
+    _liven(m)
+    m.train()
+    gold["TransformerBlock_3D_single_deform_LKA_train"] = _run(m, [torch.randn(B, C, H, W, D)], 30, rng_seed=1234)
+    gold["TransformerBlock_3D_single_deform_LKA_train"]["ctor"] = dict(input_size=H * W * D, hidden_size=C, proj_size=32, num_heads=4,
+                                                                       dropout_rate=0.1, pos_embed=True)
+    torch.manual_seed(21)
+    m = tb.TransformerBlock_3D_single_deform_LKA(input_size=H * W * D, hidden_size=C, proj_size=32, num_heads=4, dropout_rate=0.1, pos_embed=False)
+    _liven(m)
+    m.eval()
+    gold["TransformerBlock_3D_single_deform_LKA_eval"] = _run(m, [torch.randn(1, C, H, W, D)], 31)
+    gold["TransformerBlock_3D_single_deform_LKA_eval"]["ctor"] = dict(input_size=H * W * D, hidden_size=C, proj_size=32, num_heads=4,
+                                                                      dropout_rate=0.1, pos_embed=False)
+    torch.manual_seed(22)
+    from d_lka_former.network_architecture.dynunet_block import UnetResBlock
+    m = UnetResBlock(3, C, C, kernel_size=3, stride=1, norm_name="batch")
+    with torch.no_grad():
+        for bn in (m.norm1, m.norm2):
+            bn.weight.normal_(1.0, 0.2)
+            bn.bias.normal_(0, 0.2)
+    m.train()
+    gold["UnetResBlock_train"] = _run(m, [torch.randn(2, C, 5, 4, 6)], 32)
 
     path = os.path.join(OUT, "reference_modules.pt")
     torch.save(gold, path)

@@ -31,6 +31,11 @@ def build(name, case):
         return dk.LKA3d_deform(case["inputs"][0].shape[1])
     if name == "LKA_Attention3d_deform":
         return dk.LKA_Attention3d_deform(case["inputs"][2])
+    if name.startswith("TransformerBlock_3D_single_deform_LKA"):
+        return dk.TransformerBlock_3D_single_deform_LKA(**case["ctor"])
+    if name.startswith("UnetResBlock"):
+        C = case["inputs"][0].shape[1]
+        return dk.UnetResBlock(3, C, C, kernel_size=3, stride=1, norm_name="batch")
     if name == "DeformConv2d_k5_dw":
         return dk.DeformConv2dPack(6, kernel_size=(5, 5), padding=2, groups=6)
     if name == "deformable_LKA_Attention":
@@ -43,9 +48,20 @@ def replay(name, dev, fwd_atol=1e-4, bwd_rtol=1e-3):
     m = build(name, case)
     m.load_state_dict(case["state_dict"], strict=True)
     m = m.to(dev)
+    m.train(not name.endswith("_eval"))
     xs = [t.to(dev).clone().requires_grad_(True) if torch.is_tensor(t) and t.is_floating_point() else t for t in case["inputs"]]
+    if case.get("rng_seed") is not None:   # dropout noise: the reference run drew it from the CPU generator; draw there on any device
+        torch.manual_seed(case["rng_seed"])
+        draw = m._draw_drop_mask
+        m._draw_drop_mask = lambda B, C, dtype, device: draw(B, C, dtype, "cpu").to(device)
     y = m(*xs)
     assert_close(name + " output", y, case["output"], atol=fwd_atol)
+    for k, v in case.get("state_after", {}).items():
+        got = m.state_dict()[k]
+        if v.is_floating_point():
+            assert_close(f"{name} buffer {k}", got, v, rtol=1e-4)
+        else:
+            assert torch.equal(got.cpu(), v), k
     y.backward(case["grad_output"].to(dev))
     for i, (x, g) in enumerate(zip(xs, case["grad_inputs"])):
         if g is not None:

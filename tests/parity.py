@@ -206,3 +206,122 @@ def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=2e-4, rtol
         g = P[k].grad
         if g is not None and g.abs().max() > 0:
             assert_close("tokens grad " + k, p.grad, g, rtol=rtol)
+
+
+# ---- the wrapper block (TransformerBlock_3D_single_deform_LKA) and its pieces ------------------------------------------------
+def check_layernorm_tokens(dev, B, C, N, planar, pos, seed=0):
+    from deformablelka_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, N, generator=g) * 2 + 0.5 if planar else torch.randn(B, N, C, generator=g) * 2 + 0.5
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    pe = torch.randn(1, N, C, generator=g) if pos else None
+    gxn, gres = torch.randn(B, N, C, generator=g), torch.randn(B, N, C, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    per = pe.clone().requires_grad_(True) if pos else None
+    t = xr.permute(0, 2, 1) if planar else xr
+    if pos:
+        t = t + per
+    n = F.layer_norm(t, (C,), wr, br, 1e-5)
+    (n * gxn).sum().backward(retain_graph=True)
+    (t * gres).sum().backward()
+    xt, xn, stats = ops.layernorm_tokens_forward(x.to(dev), planar, None if pe is None else pe.to(dev), w.to(dev), b.to(dev))
+    assert_close("ln xt", xt, t.detach(), atol=1e-6)
+    assert_close("ln xn", xn, n.detach(), atol=2e-5)
+    gxt, gw, gb, gpos = ops.layernorm_tokens_backward(gxn.to(dev), gres.to(dev), xt, stats, w.to(dev), with_pos=pos)
+    ref_gx = xr.grad.permute(0, 2, 1) if planar else xr.grad
+    assert_close("ln gx", gxt, ref_gx, rtol=1e-4)
+    assert_close("ln gw", gw, wr.grad, rtol=1e-4)
+    assert_close("ln gb", gb, br.grad, rtol=1e-4)
+    if pos:
+        assert_close("ln gpos", gpos, per.grad, rtol=1e-4)
+
+
+def check_batchnorm_cl(dev, M, C, training, with_res, seed=0):
+    from deformablelka_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, C, generator=g) * 1.5 + 0.3
+    res = torch.randn(M, C, generator=g) if with_res else None
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5
+    gy = torch.randn(M, C, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if with_res else None
+    v = F.batch_norm(xr, None if training else rm, None if training else rv, wr, br, training, 0.1, 1e-5)
+    if with_res:
+        v = v + rr
+    y_ref = F.leaky_relu(v, 0.01)
+    y_ref.backward(gy)
+    if training:
+        stats = torch.empty(3 * C).to(dev)
+    else:
+        stats = torch.cat([rm, torch.rsqrt(rv + 1e-5), rv]).to(dev)
+    y = ops.batchnorm_cl_forward(x.to(dev), None if res is None else res.to(dev), w.to(dev), b.to(dev), stats, training)
+    assert_close("bn y", y, y_ref.detach(), atol=2e-5)
+    if training:
+        assert_close("bn mean", stats[:C], x.mean(0), atol=1e-5)
+        assert_close("bn var", stats[2 * C:], x.var(0, unbiased=True), rtol=1e-4)
+    gx, gres, gw, gb = ops.batchnorm_cl_backward(gy.to(dev), x.to(dev), y, w.to(dev), stats, training, with_res=with_res)
+    assert_close("bn gx", gx, xr.grad, rtol=2e-4)
+    assert_close("bn gw", gw, wr.grad, rtol=2e-4)
+    assert_close("bn gb", gb, br.grad, rtol=2e-4)
+    if with_res:
+        assert_close("bn gres", gres, rr.grad, rtol=1e-5)
+
+
+def check_scale_residual(dev, M, C, seed=0):
+    from deformablelka_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    xt, e, gm, gy = torch.randn(M, C, generator=g), torch.randn(M, C, generator=g), torch.randn(C, generator=g), torch.randn(M, C, generator=g)
+    out = ops.scale_residual_forward(xt.to(dev), e.to(dev), gm.to(dev))
+    assert_close("sr out", out, xt + gm * e, atol=1e-6)
+    ge, gg = ops.scale_residual_backward(gy.to(dev), e.to(dev), gm.to(dev))
+    assert_close("sr ge", ge, gy * gm, atol=1e-6)
+    assert_close("sr ggamma", gg, (gy * e).sum(0), rtol=1e-4)
+    B = 3
+    x3, mask = torch.randn(B, 7, C, generator=g), torch.rand(B, C, generator=g)
+    assert_close("channel scale", ops.channel_scale(x3.to(dev), mask.to(dev)), x3 * mask[:, None, :], atol=1e-6)
+
+
+def check_tblock3d(dev, B, C, dims, training, pos, seed=0, offset_std=0.02, atol=3e-4, rtol=3e-3, chain=False):
+    """The fused wrapper block vs the oracle composition (oracle/blocks.py transformer_block_3d)."""
+    import deformablelka_amd as dk
+    from oracle import blocks
+    torch.manual_seed(seed)
+    H, W, D = dims
+    N = H * W * D
+    m = dk.TransformerBlock_3D_single_deform_LKA(N, C, C, 4, dropout_rate=0.1, pos_embed=pos)
+    blocks.randomize_offsets_(m, std=offset_std)
+    with torch.no_grad():
+        m.gamma.normal_(0.5, 0.2)
+        if pos:
+            m.pos_embed.normal_(0, 0.5)
+        for bn in (m.conv51.norm1, m.conv51.norm2):
+            bn.weight.normal_(1.0, 0.2)
+            bn.bias.normal_(0, 0.2)
+            bn.running_mean.normal_(0, 0.3)
+            bn.running_var.uniform_(0.5, 1.5)
+    m.train(training)
+    x = torch.randn(B, C, H, W, D)
+    gy = torch.randn(B, C, H, W, D)
+    mask = torch.nn.functional.dropout3d(torch.ones(B, C, 1, 1, 1), 0.1, True).view(B, C) if training else None
+    P = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.detach().clone())
+         for k, v in m.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    yr = blocks.transformer_block_3d(xr, P, training, mask)
+    if chain:
+        yr = blocks.transformer_block_3d(yr, P, training, mask)
+    yr.backward(gy)
+    m = m.to(dev)
+    m._draw_drop_mask = lambda B_, C_, dtype, device: mask.to(device)
+    xd = x.to(dev).requires_grad_(True)
+    y = m(xd)
+    assert y.permute(0, 2, 3, 4, 1).is_contiguous()   # the result is the permuted view of token memory
+    if chain:
+        y = m(y)                                      # second application reads the tokens in place (x_planar = 0)
+    y.backward(gy.to(dev))
+    assert_close("tblock y", y, yr.detach(), atol=atol)
+    assert_close("tblock gx", xd.grad, xr.grad, rtol=rtol)
+    for k, p in m.named_parameters():
+        g = P[k].grad
+        if g is not None and g.abs().max() > 0:
+            assert_close("tblock grad " + k, p.grad, g, rtol=rtol)

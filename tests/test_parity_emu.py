@@ -77,7 +77,8 @@ def test_gelu():
 
 GOLDEN = ["DeformConvPack_k3", "DeformConvPack_k5_dw_zero", "DeformConv_g2_dg2_nobias", "DeformConvPack_d_TW",
           "DeformConvPack_d_HW", "DeformConvPack_d_H", "DeformConvPack_Depth", "LKA3d_deform", "LKA_Attention3d_deform",
-          "DeformConv2d_k5_dw", "deformable_LKA_Attention"]
+          "DeformConv2d_k5_dw", "deformable_LKA_Attention", "TransformerBlock_3D_single_deform_LKA_train",
+          "TransformerBlock_3D_single_deform_LKA_eval", "UnetResBlock_train"]
 
 
 @pytest.mark.parametrize("name", GOLDEN)
@@ -119,3 +120,24 @@ def test_deform3d_cl_lds_window(case):
     """N >= 512 selects the LDS-window backward (bricks, halo overflow to global atomics, partial bricks)."""
     B, C, Cout, dims, mode = case
     parity.check_deform3d_cl("cpu", B, C, Cout, dims, off_mode=mode)
+
+
+# ---- the wrapper block TransformerBlock_3D_single_deform_LKA ----------------------------------------------------------------
+@pytest.mark.parametrize("case", [(2, 32, 37, True, True), (1, 64, 50, False, False), (3, 128, 9, True, False), (1, 256, 21, False, True)])
+def test_layernorm_tokens(case):
+    B, C, N, planar, pos = case
+    parity.check_layernorm_tokens("cpu", B, C, N, planar, pos)
+
+
+@pytest.mark.parametrize("case", [(300, 32, True, True), (77, 64, True, False), (130, 256, False, True), (64, 128, False, False)])
+def test_batchnorm_cl(case):
+    parity.check_batchnorm_cl("cpu", *case)
+
+
+def test_scale_residual_and_channel_scale():
+    parity.check_scale_residual("cpu", 203, 64)
+
+
+def test_tblock3d_chain():
+    """Two applications back to back: the second reads the first's channels-last output in place; gradients accumulate."""
+    parity.check_tblock3d("cpu", 1, 32, (3, 4, 5), True, True, chain=True)

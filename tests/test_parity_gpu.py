@@ -77,7 +77,8 @@ def test_conv3d_vs_aten_cpu(case):
 
 GOLDEN = ["DeformConvPack_k3", "DeformConvPack_k5_dw_zero", "DeformConv_g2_dg2_nobias", "DeformConvPack_d_TW",
           "DeformConvPack_d_HW", "DeformConvPack_d_H", "DeformConvPack_Depth", "LKA3d_deform", "LKA_Attention3d_deform",
-          "DeformConv2d_k5_dw", "deformable_LKA_Attention"]
+          "DeformConv2d_k5_dw", "deformable_LKA_Attention", "TransformerBlock_3D_single_deform_LKA_train",
+          "TransformerBlock_3D_single_deform_LKA_eval", "UnetResBlock_train"]
 
 
 @pytest.mark.parametrize("name", GOLDEN)
@@ -258,3 +259,29 @@ def test_hipgraph_replay_reproduces_eager():
             scale = max(float(a.abs().max()), 1e-6)
             assert float((a - c).abs().max()) <= 2e-3 * scale   # atomics order only
     assert st.health()["finite"]
+
+
+# ---- the wrapper block TransformerBlock_3D_single_deform_LKA -----------------------------------------------
+@pytest.mark.parametrize("case", [(2, 32, 4099, True, True), (1, 64, 5000, False, False), (3, 128, 999, True, False), (1, 256, 2100, False, True)])
+def test_layernorm_tokens(case):
+    B, C, N, planar, pos = case
+    parity.check_layernorm_tokens(DEV, B, C, N, planar, pos)
+
+
+@pytest.mark.parametrize("case", [(30011, 32, True, True), (7777, 64, True, False), (13000, 256, False, True), (6400, 128, False, False)])
+def test_batchnorm_cl(case):
+    parity.check_batchnorm_cl(DEV, *case)
+
+
+def test_scale_residual_and_channel_scale():
+    parity.check_scale_residual(DEV, 20003, 64)
+
+
+@pytest.mark.parametrize("C,dims,training,pos", [(32, (16, 16, 16), True, True), (64, (8, 8, 8), False, False), (128, (6, 5, 7), True, False),
+                                                  (256, (4, 4, 4), True, True)])
+def test_tblock3d_vs_oracle(C, dims, training, pos):
+    parity.check_tblock3d(DEV, 2, C, dims, training, pos)
+
+
+def test_tblock3d_chain():
+    parity.check_tblock3d(DEV, 1, 32, (6, 8, 10), True, True, chain=True)
