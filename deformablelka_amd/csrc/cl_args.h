@@ -18,6 +18,7 @@ struct IgemmArgs {
     int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
     int units_per_split; // work units (tap, 32-channel chunk) per blockIdx.y; K * CinP/32 when gridDim.y == 1
     int split_bf16;      // 1: contraction on the bf16 matrix cores with two-term split operands (weights prepared with mode | 8)
+    int out_zeroed;      // 1: the caller has already zero-filled `out` (split partial sums meet there in atomics)
     int epi;             // 0: out = acc+bias | 1: out = acc+bias, out2 = gelu(out) | 2: out = acc+bias, out2 = aux*out | 3: out = acc+bias+aux
                          // 4: out = (acc+bias)*aux, out2 = (acc+bias)*aux2   (gate backward fused into proj_2's data gradient)
 };
@@ -40,6 +41,8 @@ struct DwArgs {
     const float *wp;    // [K][C] prepared weights (tap-major, channel contiguous)
     const float *bias;  // [C] or null
     float *out;         // [B][D][H][W][C]
+    const float *gelu_x;   // optional fused epilogue (data gradient of dw 5^3 inside the D-LKA block): out = (acc + gelu_add) * gelu'(gelu_x)
+    const float *gelu_add;
     int B, D, H, W, C;
     int kd, kh, pd, ph, pw, dd, dh;   // kw / dw are template parameters
 };
@@ -94,6 +97,17 @@ struct DeformBwdArgs {
     int C, Cout, CoutP;
     int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
     int cc_per_block;   // 32-channel input chunks per blockIdx.z; grad_offset uses atomics when gridDim.z > 1
+    int gx_zeroed;      // 1: the caller has already zero-filled gx
+};
+
+// Several zero fills in one launch (every dependent kernel node costs ~4.5 us of dispatch latency inside a hipGraph on
+// MI355X, profiles/r01n): regions are 16-byte aligned float arrays.
+struct ZeroBatch {
+    int n;
+    float *p[8];
+    long cnt[8];          // floats
+    unsigned block0[9];   // first workgroup of each region (set by the launcher)
+    void add(float *ptr, size_t floats) { if (ptr && floats && n < 8) { p[n] = ptr; cnt[n] = (long)floats; ++n; } }
 };
 
 }  // namespace dlka

@@ -654,7 +654,7 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
     if (a.gx) {
         if (!scratch) return DLKA_ERR_WORKSPACE;
         const GxGeom g = pick_gx_geom(a);
-        if (launch_zero(a.gx, (size_t)a.B * a.N * a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
+        if (!a.gx_zeroed && launch_zero(a.gx, (size_t)a.B * a.N * a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         GxGeom gl_ = g;
         const size_t lds_all = (size_t)g.wvox_max * CS * sizeof(double) + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
         gl_.resident = (lds_all <= 150 * 1024 && a.CoutP <= 128) ? 1 : 0;

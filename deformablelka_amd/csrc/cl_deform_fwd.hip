@@ -157,7 +157,7 @@ int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
     if ((long)a.M * a.Cin * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     a.units_per_split = cdiv(a.K * (a.CinP / 32), splits);
     splits = cdiv(a.K * (a.CinP / 32), a.units_per_split);
-    if (splits > 1) {
+    if (splits > 1 && !a.out_zeroed) {
         if (launch_zero(a.out, (size_t)a.M * a.Cout * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
     }
     const int NT_total = a.NP / 32;

@@ -5,6 +5,9 @@
 // channels (every load / store is a contiguous 128-byte-per-32-lanes row piece of the [voxel][C] layout), each
 // work-item owns TW consecutive outputs along W and slides the KW taps over one input row segment held in registers
 // (TW + (KW-1)*DIL loads feed TW*KW FMAs).  Same kernel = forward and data gradient (flipped taps, no bias).
+// (A row-tiled variant — TH output rows spaced DIL apart per work-item, 5 FMA per load instead of 2.15 — was measured SLOWER
+// (72.9 vs 65.5 us at C=32 / 32^3, profiles/r01o_dw_variants.txt): the kernel is bound by instruction issue with too few waves to
+// hide latency, not by the L1 request rate, and bigger per-thread tiles leave ~1 wave per SIMD.)
 #include <stdlib.h>
 
 #include "cl_args.h"
@@ -61,7 +64,14 @@ __global__ __launch_bounds__(256) void cl_dwconv_kernel(DwArgs p)
             }
         }
     }
-    float *op = p.out + (((long)(b * p.D + d0) * p.H + h0) * p.W + w0) * p.C + c;
+    const long obase = (((long)(b * p.D + d0) * p.H + h0) * p.W + w0) * p.C + c;
+    float *op = p.out + obase;
+    if (p.gelu_x) {   // uniform: a = GELU(h) feeds dw 5^3 and the gate, so gh = (ga_gate + ga_dw5) * gelu'(h) closes here
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+            if (w0 + t < p.W) op[(long)t * p.C] = (acc[t] + p.gelu_add[obase + (long)t * p.C]) * dgelu_f(p.gelu_x[obase + (long)t * p.C]);
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TW; ++t)
         if (w0 + t < p.W) op[(long)t * p.C] = acc[t];
@@ -193,6 +203,98 @@ __global__ __launch_bounds__(256) void cl_dwconv_wgrad_kernel(DwWgradArgs p)
     }
 }
 
+// Second generation: the INPUT row segment is the stationary operand.  A work-item owns (channel c, W-run, kd index i) and walks
+// over input rows (b, zd, zh); the row segment it loads (SEG values) meets the KH grad_output rows (zd - i*dd + pd, zh - j*dh + ph)
+// that pair with it, KH*KW accumulators in registers: SEG + KH*TW loads feed KH*KW*TW FMAs (4.8 FMA per load for 7^3 dil 3, against
+// 1.65 in the first version, which re-read the input segment for every (i, j) — that kernel was bound by the L1 request rate:
+// 177 us at C=32 / 32^3, profiles/r01n).  grid.y = kd.  The bias gradient rides on the (i, j) = centre-tap pairing, which visits every
+// grad_output element exactly once.
+template <int KW, int DIL, int TW>
+__global__ __launch_bounds__(256) void cl_dwconv_wgrad2_kernel(DwWgradArgs p)
+{
+    constexpr int KH = KW;
+    constexpr int SEG = TW + (KW - 1) * DIL;
+    __shared__ float red[256 * KW];
+    const int cpb = p.C < 256 ? p.C : 256, rpb = 256 / cpb;
+    const int c = blockIdx.z * cpb + threadIdx.x % cpb;
+    const int rsub = threadIdx.x / cpb;
+    const int i = blockIdx.y;
+    const int runs_per_row = cdiv(p.W, TW);
+    const int rows = p.B * p.D * p.H;
+    const long run_lo = (long)blockIdx.x * p.rows_per_block * runs_per_row;
+    const long run_hi = min((long)rows * runs_per_row, run_lo + (long)p.rows_per_block * runs_per_row);
+    float acc[KH][KW];
+#pragma unroll
+    for (int j = 0; j < KH; ++j)
+#pragma unroll
+        for (int k = 0; k < KW; ++k) acc[j][k] = 0.f;
+    float bsum = 0.f;
+    const int doff = i * p.dd - p.pd;
+    const bool bias_slice = p.gb && doff == 0;   // uniform per block
+    if (c < p.C) {
+        for (long run = run_lo + rsub; run < run_hi; run += rpb) {
+            const int w0 = (int)(run % runs_per_row) * TW;
+            const int row = (int)(run / runs_per_row);
+            const int zh = row % p.H, zd = (row / p.H) % p.D, b = row / (p.H * p.D);
+            const int d0 = zd - doff;
+            if (d0 < 0 || d0 >= p.D) continue;
+            const float *rowp = p.in + (((long)(b * p.D + zd) * p.H + zh) * p.W) * p.C + c;
+            float seg[SEG];
+#pragma unroll
+            for (int e = 0; e < SEG; ++e) {
+                const int zw = w0 - p.pw + e;
+                seg[e] = (zw >= 0 && zw < p.W) ? rowp[(long)zw * p.C] : 0.f;
+            }
+            const float *gplane = p.g + ((long)(b * p.D + d0) * p.H * p.W + w0) * p.C + c;
+#pragma unroll
+            for (int j = 0; j < KH; ++j) {
+                const int hoff = j * p.dh - p.ph;
+                const int h0 = zh - hoff;
+                if (h0 < 0 || h0 >= p.H) continue;
+                const float *gp = gplane + (long)h0 * p.W * p.C;
+                float gv[TW];
+#pragma unroll
+                for (int t = 0; t < TW; ++t) gv[t] = (w0 + t < p.W) ? gp[(long)t * p.C] : 0.f;
+                if (bias_slice && hoff == 0) {
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) bsum += gv[t];
+                }
+#pragma unroll
+                for (int k = 0; k < KW; ++k)
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) acc[j][k] = fmaf(gv[t], seg[t + k * DIL], acc[j][k]);
+            }
+        }
+    }
+    // work-items of the block that share c fold through LDS; one fp32 atomic per (c, tap) per block
+#pragma unroll
+    for (int j = 0; j < KH; ++j) {
+#pragma unroll
+        for (int k = 0; k < KW; ++k) red[k * 256 + threadIdx.x] = acc[j][k];
+        __syncthreads();
+        if (threadIdx.x < cpb && c < p.C) {
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                float a = 0.f;
+                for (int r = 0; r < rpb; ++r) a += red[k * 256 + r * cpb + threadIdx.x];
+                atomicAdd(p.gwp + (long)((i * KH + j) * KW + k) * p.C + c, a);
+            }
+        }
+        __syncthreads();
+    }
+    if (bias_slice) {
+        red[threadIdx.x] = bsum;
+        __syncthreads();
+        if (threadIdx.x < cpb && c < p.C) {
+            float bs = 0.f;
+            for (int r = 0; r < rpb; ++r) bs += red[r * cpb + threadIdx.x];
+            atomicAdd(p.gb + c, bs);
+        }
+    }
+}
+
+static inline dim3 block256() { return dim3(256); }
+
 int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st, bool zero_init)
 {
     constexpr int TW = 8;
@@ -207,6 +309,22 @@ int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st, boo
     if (zero_init) {   // (the fused block zeroes all of its accumulation targets with one memset)
         if (launch_zero(a.gwp, (size_t)a.kd * a.kh * kw * a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         if (a.gb && launch_zero(a.gb, (size_t)a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
+    }
+    static const bool v1 = getenv("DLKA_DWW_V1") != nullptr;   // A/B switch: first generation (grid.y = kd*kh, input re-read per tap row)
+    // the centre tap row must exist for the bias ride-along (odd kernels with "same" padding: always)
+    const bool centre = (a.pd % a.dd == 0) && (a.ph % a.dh == 0) && a.pd / a.dd < a.kd && a.ph / a.dh < a.kh;
+    // measured (profiles/r01o_dw_variants.txt): 7^3 dil 3 178 -> 103 us at 32^3, 38 -> 36 us at 16^3; 5^3 72 -> 66 us at 32^3 but 23.5 -> 26 us at 16^3
+    const bool pays = kw >= 7 || rows >= 1024;
+    if (!v1 && pays && a.kd == kw && a.kh == kw && a.dd == dil_w && a.dh == dil_w && (centre || !a.gb)) {
+        dim3 grid2(xb, a.kd, cdiv(a.C, cpb));
+        if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
+        else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_wgrad2_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
+        else if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<3, 1, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
+        else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_wgrad2_kernel<5, 3, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
+        else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<7, 1, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
+        else return DLKA_ERR_UNSUPPORTED;
+        DLKA_CHECK_LAUNCH();
+        return DLKA_OK;
     }
     dim3 grid(xb, a.kd * a.kh, cdiv(a.C, cpb)), block(256);
     if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }

@@ -309,16 +309,16 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
 // ---------------------------------------------------------------------------------------------------------------------
 // SPLIT: bf16 x3-split contraction (dlka_intrin.h) instead of the exact fp32-input MFMA: 54 x 32 cycles per 32-row step instead
 // of 144 x 64 for the 3 x 3 blocking.
-template <int GMODE, int COT, int TPW, bool N16, bool SPLIT = false>   // N16: N % 16 == 0 (the 16 rows of a half-wave never straddle two volumes)
-__global__ __launch_bounds__(64) void cl_wgrad_dense_kernel(WgradArgs p)
+template <int GMODE, int COT, int TPW, bool N16, bool SPLIT>   // N16: N % 16 == 0 (the 16 rows of a half-wave never straddle two volumes)
+__device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int bz)
 {
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
     const int chunk = blockIdx.x;
     const int OTG = cdiv(p.CoutP / 32, COT);                  // co-tile groups
     const int otg = blockIdx.y / p.CT, ct = blockIdx.y % p.CT;
-    const int tap0 = blockIdx.z * TPW;
+    const int tap0 = bz * TPW;
     const int ci = ct * 32 + i;
-    const bool want_bias = p.bpart && ct == 0 && blockIdx.z == 0;
+    const bool want_bias = p.bpart && ct == 0 && bz == 0;
     (void)OTG;
 
     f32x16 acc[COT][TPW];
@@ -490,6 +490,21 @@ __global__ __launch_bounds__(64) void cl_wgrad_dense_kernel(WgradArgs p)
     }
 }
 
+template <int GMODE, int COT, int TPW, bool N16, bool SPLIT = false>
+__global__ __launch_bounds__(64) void cl_wgrad_dense_kernel(WgradArgs p)
+{
+    wgrad_dense_body<GMODE, COT, TPW, N16, SPLIT>(p, blockIdx.z);
+}
+
+// The three pointwise weight gradients of a D-LKA block (proj_2, conv1, proj_1: same geometry, different operands) in ONE
+// launch, blockIdx.z = job: every dependent kernel node costs ~4.5 us inside the graph, and each of these is a ~1 us kernel.
+struct WgradArgs3 { WgradArgs a[3]; };
+template <int COT, bool N16>
+__global__ __launch_bounds__(64) void cl_wgrad_pw3_kernel(WgradArgs3 b)
+{
+    wgrad_dense_body<0, COT, 1, N16, false>(b.a[blockIdx.z], 0);
+}
+
 // gW[co][ci][tap] (reference layout, storage type T) = sum_chunk part[chunk][tap][co][ci];  gb[co] = sum_chunk bpart[chunk][co]
 // A workgroup folds 32 consecutive outputs: thread (e = tid & 31, cl = tid >> 5) sums chunks cl, cl+8, ... (coalesced
 // 128-byte reads per chunk), the 8 partial sums meet in LDS.  (The first version gave one thread all 128 chunks of an
@@ -551,6 +566,11 @@ static WgradPlan wgrad_plan(int M, int K, int Cout, int Cin, int amode)
     // register-heavy variants run one wave per SIMD (1024 slots): fill them once rather than 2.004 times
     const int slots = (amode == 0 && K > 1 && pl.cot * pl.tpw >= 6) ? 1024 : 2048;   // <=2 waves/SIMD for the rest
     int chunks = slots / groups;
+    if (K == 1) {   // pointwise: every partial is re-read by the fold; past a few hundred the fold costs more than the extra waves buy
+        static int pw_cap = -1;
+        if (pw_cap < 0) { const char *e = getenv("DLKA_WGRAD_PW_CHUNKS"); pw_cap = e ? atoi(e) : 512; if (pw_cap < 1) pw_cap = 512; }
+        if (chunks > pw_cap) chunks = pw_cap;
+    }
     if (chunks > tiles) chunks = tiles;
     if (chunks > 1024) chunks = 1024;
     if (chunks < 1) chunks = 1;
@@ -628,6 +648,38 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
     return DLKA_OK;
 }
 
+// three pointwise (K = 1) weight gradients with identical geometry; always deferred to the caller's fused finalisation
+int launch_cl_wgrad_pw3(const WgradArgs *jobs, float *const *gw, float *const *gb, hipStream_t st, FinalizeJob *defer)
+{
+    WgradArgs3 b;
+    const WgradArgs &a0 = jobs[0];
+    if (a0.K != 1) return DLKA_ERR_UNSUPPORTED;
+    const WgradPlan pl = wgrad_plan(a0.M, 1, a0.Cout, a0.Cin, 0);
+    const int tiles = cdiv(a0.M, 32);
+    const int rpc = cdiv(tiles, pl.chunks) * 32;
+    const int nchunks = cdiv(a0.M, rpc);
+    const int CoutP = round_up(a0.Cout, 32), CT = a0.Cin / 32, OT = CoutP / 32;
+    if ((long)a0.M * a0.Cin * 4 >= (1l << 31) || (long)a0.M * a0.Cout * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;
+    for (int k = 0; k < 3; ++k) {
+        b.a[k] = jobs[k];
+        WgradArgs &a = b.a[k];
+        a.rows_per_chunk = rpc; a.CoutP = CoutP; a.CT = CT;
+        a.bpart = gb[k] ? a.part + (size_t)nchunks * CoutP * a.Cin : nullptr;
+        FinalizeJob &d = defer[k];
+        memset(&d, 0, sizeof(d));
+        d.part = a.part; d.bpart = a.bpart; d.gw = gw[k]; d.gb = gb[k];
+        d.chunks = nchunks; d.K = 1; d.CoutP = CoutP; d.Cout = a.Cout; d.Cin = a.Cin; d.kind = 0; d.n = (long)a.Cout * a.Cin + (gb[k] ? a.Cout : 0);
+    }
+    dim3 grid(nchunks, cdiv(OT, pl.cot) * CT, 3), block(64);
+    const bool n16 = (a0.N & 15) == 0;
+    if (pl.cot == 2 && n16) { auto k = cl_wgrad_pw3_kernel<2, true>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
+    else if (pl.cot == 2) { auto k = cl_wgrad_pw3_kernel<2, false>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
+    else if (n16) { auto k = cl_wgrad_pw3_kernel<1, true>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
+    else { auto k = cl_wgrad_pw3_kernel<1, false>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
 template int launch_cl_wgrad<float>(int, int, WgradArgs, float *, float *, hipStream_t, FinalizeJob *);
 
 // All weight-gradient finalisations of one D-LKA block in ONE launch: the five partial-sum folds (3 pointwise, offset
@@ -660,8 +712,15 @@ __global__ __launch_bounds__(256) void cl_wgrad_finalize_kernel(FinalizeBatch b)
         ci = (int)(e % jb.Cin); co = (int)((e / jb.Cin) % jb.Cout); tap = (int)(e / jb.Cin / jb.Cout);
         const float *src = jb.part + ((long)tap * jb.CoutP + co) * jb.Cin + ci;
         int c = cl;
-        for (; c + 8 < jb.chunks; c += 16) { a0 += src[(long)c * stride]; a1 += src[(long)(c + 8) * stride]; }
-        if (c < jb.chunks) a0 += src[(long)c * stride];
+        // 8 independent loads in flight per work-item: with 2048 partials per output (pointwise convs at 32^3) the fold is a
+        // chain of dependent-latency loads otherwise (133 us for the stage-0 batch with two chains, profiles/r01n)
+        float a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+        for (; c + 56 < jb.chunks; c += 64) {
+            a0 += src[(long)c * stride]; a1 += src[(long)(c + 8) * stride]; a2 += src[(long)(c + 16) * stride]; a3 += src[(long)(c + 24) * stride];
+            a4 += src[(long)(c + 32) * stride]; a5 += src[(long)(c + 40) * stride]; a6 += src[(long)(c + 48) * stride]; a7 += src[(long)(c + 56) * stride];
+        }
+        for (; c < jb.chunks; c += 8) a0 += src[(long)c * stride];
+        a0 = ((a0 + a2) + (a4 + a6)); a1 = ((a1 + a3) + (a5 + a7));
     } else if (e < jb.n) {
         co = (int)(e - n);
         for (int c = cl; c < jb.chunks; c += 8) a0 += jb.bpart[(long)c * jb.CoutP + co];

@@ -92,8 +92,12 @@ void fill_igemm(IgemmArgs &a, const SameConv &s)
 
 // ---- dense conv forward: out = conv(x) (+ epilogue) ---------------------------------------------------------------
 // wp must hold K * Cin * round_up(Cout,32) floats
+int dense_forward_splits(const SameConv &s, int epi) { return cl_igemm_pick_splits(s.M, s.K * (s.Cin / 32), epi, s.K); }
+int dense_backward_data_splits(const SameConv &s, int epi) { return cl_igemm_pick_splits(s.M, s.K * (round_up(s.Cout, 32) / 32), epi, s.K); }
+
+// zeroed: the caller has zero-filled `out` (needed when the tap split is > 1; one batched fill per block instead of one per conv)
 int dense_forward(const SameConv &s, const float *x, const float *w, const float *bias, float *out, int out_planar, float *wp,
-                  int epi, const float *aux, float *out2, hipStream_t st)
+                  int epi, const float *aux, float *out2, hipStream_t st, bool zeroed = false)
 {
     const int NP = round_up(s.Cout, 32);
     const bool split = use_split(s, true);
@@ -101,16 +105,16 @@ int dense_forward(const SameConv &s, const float *x, const float *w, const float
     IgemmArgs a;
     fill_igemm(a, s);
     a.split_bf16 = split ? 1 : 0;
-    a.in = x; a.wp = wp; a.bias = bias; a.out = out; a.out2 = out2; a.aux = aux; a.epi = epi;
+    a.in = x; a.wp = wp; a.bias = bias; a.out = out; a.out2 = out2; a.aux = aux; a.epi = epi; a.out_zeroed = zeroed ? 1 : 0;
     a.Cin = s.Cin; a.CinReal = s.Cin; a.CinP = s.Cin; a.Cout = s.Cout; a.NP = NP;
-    const int splits = cl_igemm_pick_splits(s.M, s.K * (s.Cin / 32), epi);
+    const int splits = dense_forward_splits(s, epi);
     return launch_cl_igemm(0, out_planar ? 1 : 0, a, splits, st);
 }
 
 // ---- dense conv data gradient: gx = conv_transpose(gout) (+ epilogue) ---------------------------------------------
 // wp must hold K * round_up(Cout,32) * Cin floats.  gout channels-last needs Cout % 32 == 0; planar any Cout.
 int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, const float *w, float *gx, float *wp, int epi,
-                        const float *aux, hipStream_t st, const float *aux2 = nullptr, float *out2 = nullptr)
+                        const float *aux, hipStream_t st, const float *aux2 = nullptr, float *out2 = nullptr, bool zeroed = false)
 {
     const int KP = round_up(s.Cout, 32), NP = s.Cin;
     if (!nt_ok(NP) || s.Cin % 32) return DLKA_ERR_UNSUPPORTED;
@@ -121,9 +125,9 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
     fill_igemm(a, s);
     a.split_bf16 = split ? 1 : 0;
     a.pd = s.dd * (s.kd - 1) - s.pd; a.ph = s.dh * (s.kh - 1) - s.ph; a.pw = s.dw * (s.kw - 1) - s.pw;
-    a.in = gout; a.wp = wp; a.bias = nullptr; a.out = gx; a.aux = aux; a.aux2 = aux2; a.out2 = out2; a.epi = epi;
+    a.in = gout; a.wp = wp; a.bias = nullptr; a.out = gx; a.aux = aux; a.aux2 = aux2; a.out2 = out2; a.epi = epi; a.out_zeroed = zeroed ? 1 : 0;
     a.Cin = s.Cout; a.CinReal = s.Cout; a.CinP = KP; a.Cout = s.Cin; a.NP = NP;
-    const int splits = cl_igemm_pick_splits(s.M, s.K * (KP / 32), epi);
+    const int splits = dense_backward_data_splits(s, epi);
     return launch_cl_igemm(gout_planar ? 2 : 0, 0, a, splits, st);
 }
 
@@ -144,12 +148,21 @@ int dense_backward_weight(const SameConv &s, const float *x, const float *gout, 
     return launch_cl_wgrad<float>(0, gout_planar ? 1 : 0, a, gw, gb, st, defer);
 }
 
+void fill_pw_wgrad(WgradArgs &a, const SameConv &s, const float *x, const float *gout, float *part)
+{
+    memset(&a, 0, sizeof(a));
+    a.g = gout; a.in = x; a.part = part;
+    a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.Cin = s.Cin; a.Cout = s.Cout;
+    a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
+}
+
 // ---- depthwise ------------------------------------------------------------------------------------------------------
-int dw_forward(const SameConv &s, const float *x, const float *w, const float *bias, float *out, float *wp, int flip, hipStream_t st)
+int dw_forward(const SameConv &s, const float *x, const float *w, const float *bias, float *out, float *wp, int flip, hipStream_t st,
+               const float *gelu_x = nullptr, const float *gelu_add = nullptr)
 {
     if (w) DLKA_TRY(launch_cl_dw_prep_weight(w, wp, s.Cin, s.K, flip, st));
     DwArgs a;
-    a.in = x; a.wp = wp; a.bias = bias; a.out = out;
+    a.in = x; a.wp = wp; a.bias = bias; a.out = out; a.gelu_x = gelu_x; a.gelu_add = gelu_add;
     a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.C = s.Cin;
     a.kd = s.kd; a.kh = s.kh; a.dd = s.dd; a.dh = s.dh;
     if (flip) { a.pd = s.dd * (s.kd - 1) - s.pd; a.ph = s.dh * (s.kh - 1) - s.ph; a.pw = s.dw * (s.kw - 1) - s.pw; }
@@ -180,14 +193,15 @@ int dw_backward_weight(const SameConv &s, const float *x, const float *gout, flo
 // ---- deformable (groups = deformable_groups = 1) ---------------------------------------------------------------------
 bool deform_supported(const SameConv &s) { return s.group == 1 && s.Cin % 32 == 0 && s.Cout % 32 == 0 && nt_ok(s.Cout) && nt_ok(s.Cin); }
 
-int deform_forward(const SameConv &s, const float *x, const float *off, const float *w, const float *bias, float *out, float *wp, hipStream_t st)
+int deform_forward(const SameConv &s, const float *x, const float *off, const float *w, const float *bias, float *out, float *wp, hipStream_t st,
+                   bool zeroed = false)
 {
     if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, s.Cout, 0, st));
     IgemmArgs a;
     fill_igemm(a, s);
-    a.in = x; a.off = off; a.wp = wp; a.bias = bias; a.out = out; a.epi = 0;
+    a.in = x; a.off = off; a.wp = wp; a.bias = bias; a.out = out; a.epi = 0; a.out_zeroed = zeroed ? 1 : 0;
     a.Cin = s.Cin; a.CinReal = s.Cin; a.CinP = s.Cin; a.Cout = s.Cout; a.NP = s.Cout;
-    const int splits = cl_igemm_pick_splits(s.M, s.K * (s.Cin / 32), 0);
+    const int splits = dense_forward_splits(s, 0);
     static const bool old_path = getenv("DLKA_DEFORM_FWD_IGEMM") != nullptr;   // A/B switch: first-generation "lane = row" gather
     if (!old_path) {
         const int rc = launch_cl_deform_fwd(a, splits, st);
@@ -225,13 +239,13 @@ int deform_bwd_variant()
 }
 
 int deform_backward(const SameConv &s, const float *x, const float *off, const float *w, const float *gout, float *gx, float *goff,
-                    float *gw, float *gb, float *wp, float *part, float *scratch, hipStream_t st, FinalizeJob *defer = nullptr)
+                    float *gw, float *gb, float *wp, float *part, float *scratch, hipStream_t st, FinalizeJob *defer = nullptr, bool gx_zeroed = false)
 {
     if (gx || goff) {
         if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cout, s.Cin, 2, st));
         DeformBwdArgs a;
         fill_deform_bwd(a, s);
-        a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff;
+        a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff; a.gx_zeroed = gx_zeroed ? 1 : 0;
         const int variant = deform_bwd_variant();
         if (variant == 0) DLKA_TRY(launch_cl_deform_bwd2(a, scratch, st));
         else if (variant == 2 && s.N >= 512) DLKA_TRY(launch_cl_deform_bwd_lds(a, st));
@@ -534,19 +548,26 @@ int dlka_lka3d_attention_tokens_forward(const void *x_, const dlka_lka3d_params 
     // every weight re-layout of the block (forward and backward forms) in one launch; the backward call reuses them
     TokPrep PW;
     DLKA_TRY(carve_prep(G, prep, PW, p, st, true));
+    // outputs of tap-split convs (small stages) collect partial sums with atomics: ONE zero fill for all of them
+    ZeroBatch zb;
+    memset(&zb, 0, sizeof(zb));
+    if (dense_forward_splits(G.offc, 0) > 1) zb.add(off, G.Off);
+    if (dense_forward_splits(G.dcn, 0) > 1) zb.add(f, G.E);
+    if (dense_forward_splits(G.pw, 3) > 1) zb.add(y, G.E);
+    DLKA_TRY(launch_zero_batch(zb, st));
     // proj_1 + GELU (transformerblock.py:667-668): h kept for the GELU gradient, a = GELU(h)
     DLKA_TRY(dense_forward(G.pw, x, N0, (const float *)p->proj_1_b, h, 0, PW.pw_f[0], 1, nullptr, a, st));
     // depthwise 5^3 then 7^3 dilation 3 (:646-647)
     DLKA_TRY(dw_forward(G.dw5, a, N0, (const float *)p->conv0_b, t1, PW.dw5_f, 0, st));
     DLKA_TRY(dw_forward(G.dw7, t1, N0, (const float *)p->conv_spatial_b, t, PW.dw7_f, 0, st));
     // offset-predict conv C -> 81 (synapse/deform_conv.py:94); offsets stay in the reference's planar layout
-    DLKA_TRY(dense_forward(G.offc, t, N0, (const float *)p->offset_b, off, 1, PW.off_f, 0, nullptr, nullptr, st));
+    DLKA_TRY(dense_forward(G.offc, t, N0, (const float *)p->offset_b, off, 1, PW.off_f, 0, nullptr, nullptr, st, true));
     // deformable 3^3 conv (deform_conv.py:95-105)
-    DLKA_TRY(deform_forward(G.dcn, t, off, N0, (const float *)p->deform_b, f, PW.dcn_f, st));
+    DLKA_TRY(deform_forward(G.dcn, t, off, N0, (const float *)p->deform_b, f, PW.dcn_f, st, true));
     // conv1 + gate u*attn (:650-652): g1 kept, m = a * g1
     DLKA_TRY(dense_forward(G.pw, f, N0, (const float *)p->conv1_b, g1, 0, PW.pw_f[1], 2, a, m, st));
     // proj_2 + shortcut (:670-671)
-    DLKA_TRY(dense_forward(G.pw, m, N0, (const float *)p->proj_2_b, y, 0, PW.pw_f[2], 3, x, nullptr, st));
+    DLKA_TRY(dense_forward(G.pw, m, N0, (const float *)p->proj_2_b, y, 0, PW.pw_f[2], 3, x, nullptr, st, true));
     return DLKA_OK;
 }
 
@@ -598,17 +619,25 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
         ++nev;
         return DLKA_OK;
     };
+    // everything that is accumulated into with atomics, zero-filled by ONE launch: the depthwise weight-gradient staging, the
+    // deformable conv's grad_input (halo overflow of the LDS windows) and the outputs of tap-split data gradients
+    ZeroBatch zb;
+    memset(&zb, 0, sizeof(zb));
+    zb.add(stage5, G.stage_dw());
+    zb.add(gta, G.E);
+    if (dense_backward_data_splits(G.pw, 0) > 1) zb.add(gf, G.E);
+    if (dense_backward_data_splits(G.offc, 3) > 1) zb.add(gt, G.E);
+    if (dense_backward_data_splits(G.pw, 3) > 1) zb.add(gx, G.E);
+    DLKA_TRY(launch_zero_batch(zb, st));
     DLKA_TRY(publish());   // fork: everything issued before this call (gy, saved activations, the previous block's use of the workspace)
-    if (launch_zero(stage5, G.stage_dw() * 4, ws_) != DLKA_OK) return DLKA_ERR_LAUNCH;   // the depthwise kernels accumulate with atomics
 
     // proj_2:  y = P2 m + x.   Its data gradient gm = P2^T gy feeds only the gate  m = a * g1, whose backward is fused into
     // the epilogue:  gg1 = gm * a,  ga1 = gm * g1
-    DLKA_TRY(dense_backward_weight(G.pw, m, gy, 0, (float *)gr->proj_2_w, (float *)gr->proj_2_b, part_p2, ws_, &fb.j[fb.njobs++]));
+    // (the three pointwise weight gradients run as ONE launch at the end: their operands m/gy, f/gg1, x/gh all stay live)
     DLKA_TRY(dense_backward_data(G.pw, gy, 0, N0, gg1, PW.pw_b[2], 4, a, st, g1, ga1));
     DLKA_TRY(publish());
     // conv1:  g1 = P0 f
-    DLKA_TRY(dense_backward_weight(G.pw, f, gg1, 0, (float *)gr->conv1_w, (float *)gr->conv1_b, part_c1, ws_, &fb.j[fb.njobs++]));
-    DLKA_TRY(dense_backward_data(G.pw, gg1, 0, N0, gf, PW.pw_b[1], 0, nullptr, st));
+    DLKA_TRY(dense_backward_data(G.pw, gg1, 0, N0, gf, PW.pw_b[1], 0, nullptr, st, nullptr, nullptr, true));
     DLKA_TRY(publish());
     // deformable conv:  f = DCN(t, off):  weight gradient on the side stream, grad_offset and grad_input on the main one
     DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
@@ -617,8 +646,8 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     DLKA_TRY(publish());
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
     DLKA_TRY(dense_backward_weight(G.offc, t, goff, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, ws_, &fb.j[fb.njobs++]));
-    DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st));
-    DLKA_TRY(dense_backward_data(G.offc, goff, 1, N0, gt, PW.off_b, 3, gta, st));
+    DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, true));
+    DLKA_TRY(dense_backward_data(G.offc, goff, 1, N0, gt, PW.off_b, 3, gta, st, nullptr, nullptr, true));
     DLKA_TRY(publish());
     // depthwise 7^3 dil 3:  t = DW7 t1
     DLKA_TRY(dw_backward_weight(G.dw7, t1, gt, (float *)gr->conv_spatial_w, (float *)gr->conv_spatial_b, stage7, ws_, &fb.j[fb.njobs++]));
@@ -626,14 +655,23 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     DLKA_TRY(publish());
     // depthwise 5^3:  t1 = DW5 a
     DLKA_TRY(dw_backward_weight(G.dw5, a, gt1, (float *)gr->conv0_w, (float *)gr->conv0_b, stage5, ws_, &fb.j[fb.njobs++]));
-    DLKA_TRY(dw_forward(G.dw5, gt1, N0, nullptr, ga2, PW.dw5_b, 1, st));
-    // GELU:  a = GELU(h);  ga = ga1 + ga2
-    DLKA_TRY(launch_gelu_bwd_sum<float>(h, ga1, ga2, gh, E, st));
+    // ... with the GELU backward in its epilogue:  a = GELU(h),  gh = (ga1 + DW5^T gt1) * gelu'(h)
+    (void)ga2; (void)E;
+    DLKA_TRY(dw_forward(G.dw5, gt1, N0, nullptr, gh, PW.dw5_b, 1, st, h, ga1));
     DLKA_TRY(publish());
     // proj_1:  h = P1 x ;  gx = P1^T gh + gy (shortcut)
-    DLKA_TRY(dense_backward_weight(G.pw, x, gh, 0, (float *)gr->proj_1_w, (float *)gr->proj_1_b, part_p1, ws_, &fb.j[fb.njobs++]));
+    {
+        WgradArgs jobs[3];
+        fill_pw_wgrad(jobs[0], G.pw, m, gy, part_p2);
+        fill_pw_wgrad(jobs[1], G.pw, f, gg1, part_c1);
+        fill_pw_wgrad(jobs[2], G.pw, x, gh, part_p1);
+        float *const gws[3] = {(float *)gr->proj_2_w, (float *)gr->conv1_w, (float *)gr->proj_1_w};
+        float *const gbs[3] = {(float *)gr->proj_2_b, (float *)gr->conv1_b, (float *)gr->proj_1_b};
+        DLKA_TRY(launch_cl_wgrad_pw3(jobs, gws, gbs, ws_, &fb.j[fb.njobs]));
+        fb.njobs += 3;
+    }
     DLKA_TRY(launch_cl_wgrad_finalize(fb, ws_));
-    DLKA_TRY(dense_backward_data(G.pw, gh, 0, N0, gx, PW.pw_b[0], 3, gy, st));
+    DLKA_TRY(dense_backward_data(G.pw, gh, 0, N0, gx, PW.pw_b[0], 3, gy, st, nullptr, nullptr, true));
     if (fork) {   // join
         if (hipEventRecord(sc.ev[nev], ws_) != hipSuccess || hipStreamWaitEvent(st, sc.ev[nev], 0) != hipSuccess) return DLKA_ERR_LAUNCH;
     }

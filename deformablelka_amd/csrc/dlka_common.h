@@ -46,6 +46,15 @@ __host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) 
 __host__ __device__ __forceinline__ long cdivl(long a, long b) { return (a + b - 1) / b; }
 __host__ __device__ __forceinline__ int round_up(int a, int b) { return cdiv(a, b) * b; }
 
+// exact (erf) GELU and its derivative, as nn.GELU() in the reference block (transformerblock.py:660)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x)
+{
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
 #define DLKA_THREADS 256
 
 #define DLKA_CHECK_LAUNCH()                                  \

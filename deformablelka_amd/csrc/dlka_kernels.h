@@ -35,7 +35,9 @@ template <typename T>
 int launch_conv_bwd_weight(const T *x, const T *gout, float *gw32, const Geom &g, hipStream_t st);
 
 // ---- eltwise.hip -------------------------------------------------------------------------------------------
-int launch_zero(void *ptr, size_t bytes, hipStream_t st);   // zero fill by kernel (graph-replay safe)
+int launch_zero(void *ptr, size_t bytes, hipStream_t st);
+struct ZeroBatch;
+int launch_zero_batch(ZeroBatch &b, hipStream_t st);   // zero fill by kernel (graph-replay safe)
 template <typename T> int launch_gelu_fwd(const T *x, T *y, long n, hipStream_t st);
 template <typename T> int launch_gelu_bwd(const T *x, const T *gy, T *gx, long n, hipStream_t st);
 template <typename T> int launch_mul_fwd(const T *a, const T *b, T *y, long n, hipStream_t st);
@@ -46,7 +48,7 @@ template <typename T> int launch_gelu_bwd_sum(const T *x, const T *g1, const T *
 // ---- channels-last fast path (cl_*.hip) --------------------------------------------------------------------------
 int launch_cl_prep_weight(const float *w, float *wp, int Cout, int Cin, int K, int KP, int NP, int mode, hipStream_t st);
 int launch_cl_prep_batch(const PrepBatch &b, hipStream_t st);
-int cl_igemm_pick_splits(int M, int units, int epi);
+int cl_igemm_pick_splits(int M, int units, int epi, int K);
 int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t st);
 int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st);
 int cl_wgrad_pick_chunks(int M, int K, int Cout, int Cin, int amode);
@@ -54,6 +56,7 @@ size_t cl_wgrad_part_floats(int M, int K, int Cout, int Cin);
 template <typename T> int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t st, FinalizeJob *defer = nullptr);
 size_t cl_wgrad_part_floats_mode(int M, int K, int Cout, int Cin, int amode);
 int launch_cl_wgrad_finalize(FinalizeBatch &b, hipStream_t st);
+int launch_cl_wgrad_pw3(const WgradArgs *jobs, float *const *gw, float *const *gb, hipStream_t st, FinalizeJob *defer);
 int launch_cl_colsum(const float *g, float *gb32, int M, int Cout, hipStream_t st);
 int launch_cl_dw_prep_weight(const float *w, float *wp, int C, int K, int flip, hipStream_t st);
 int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st);

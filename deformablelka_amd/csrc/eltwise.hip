@@ -1,17 +1,11 @@
 // Elementwise pieces of the D-LKA block: exact-erf GELU (nn.GELU() default,
 // 3D/d_lka_former/network_architecture/synapse/transformerblock.py:660), the u*attn gate (:652) and the
 // residual add (:671).  Pure HBM-bound streaming: 16-byte vector accesses, grid-stride.
+#include "cl_args.h"
 #include "dlka_kernels.h"
 
 namespace dlka {
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float dgelu_f(float x)
-{
-    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-    return cdf + x * pdf;
-}
 
 struct OpGelu { __device__ __forceinline__ float operator()(float x) const { return gelu_f(x); } };
 
@@ -77,6 +71,36 @@ int launch_zero(void *ptr, size_t bytes, hipStream_t st)
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (float *)ptr, n4, n);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+// one workgroup clears 4096 floats of one region
+__global__ __launch_bounds__(256) void zero_batch_kernel(ZeroBatch b)
+{
+    int r = 0;
+    while (r + 1 < b.n && blockIdx.x >= b.block0[r + 1]) ++r;
+    float *p = b.p[r];
+    const long n = b.cnt[r], base = (long)(blockIdx.x - b.block0[r]) * 4096;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long i = base + (long)(k * 256 + threadIdx.x) * 4;
+        if (i + 3 < n) *reinterpret_cast<f32x4 *>(p + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+        else for (long j = i; j < n; ++j) p[j] = 0.f;
+    }
+}
+
+int launch_zero_batch(ZeroBatch &b, hipStream_t st)
+{
+    if (b.n <= 0) return DLKA_OK;
+    unsigned blk = 0;
+    for (int r = 0; r < b.n; ++r) {
+        if ((uintptr_t)b.p[r] & 15) return DLKA_ERR_UNSUPPORTED;
+        b.block0[r] = blk;
+        blk += (unsigned)cdivl(b.cnt[r], 4096);
+    }
+    b.block0[b.n] = blk;
+    hipLaunchKernelGGL(zero_batch_kernel, dim3(blk), dim3(256), 0, st, b);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
