@@ -301,9 +301,12 @@ int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st, boo
     const int cpb = a.C < 256 ? a.C : 256;
     if (256 % cpb != 0) return DLKA_ERR_UNSUPPORTED;
     const int rows = a.B * a.D * a.H;
-    static int xb_env = 0;
-    if (!xb_env) { const char *e = getenv("DLKA_DWW_XB"); xb_env = e ? atoi(e) : 64; if (xb_env < 1) xb_env = 64; }
-    int xb = rows < xb_env ? rows : xb_env;         // row-chunks: bounded atomics, enough blocks with grid.y = kd*kh
+    static int xb_env = -1;
+    if (xb_env < 0) { const char *e = getenv("DLKA_DWW_XB"); xb_env = e ? atoi(e) : 0; if (xb_env < 0) xb_env = 0; }
+    // row-chunks: bounded atomics, enough waves to hide latency.  64 chunks, 128 for the large volumes (measured on the block graph:
+    // 1.515 -> 1.462 ms at 32^3 with 128, no change at 16^3, 256 worse at 16^3; profiles/r01p)
+    const int xb_want = xb_env ? xb_env : (rows >= 1024 ? 128 : 64);
+    int xb = rows < xb_want ? rows : xb_want;
     a.rows_per_block = cdiv(rows, xb);
     xb = cdiv(rows, a.rows_per_block);
     if (zero_init) {   // (the fused block zeroes all of its accumulation targets with one memset)

@@ -49,6 +49,7 @@ template <typename T> int launch_gelu_bwd_sum(const T *x, const T *g1, const T *
 int launch_cl_prep_weight(const float *w, float *wp, int Cout, int Cin, int K, int KP, int NP, int mode, hipStream_t st);
 int launch_cl_prep_batch(const PrepBatch &b, hipStream_t st);
 int cl_igemm_pick_splits(int M, int units, int epi, int K);
+int launch_cl_pointwise(const IgemmArgs &a, hipStream_t st);
 int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t st);
 int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st);
 int cl_wgrad_pick_chunks(int M, int K, int Cout, int Cin, int amode);
