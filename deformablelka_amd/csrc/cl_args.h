@@ -17,7 +17,7 @@ struct IgemmArgs {
     int Cin, CinReal, CinP, Cout, NP;
     int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
     int units_per_split; // work units (tap, 32-channel chunk) per blockIdx.y; K * CinP/32 when gridDim.y == 1
-    int split_bf16;      // 1: contraction on the bf16 matrix cores with two-term split operands (weights prepared with mode | 8)
+    int split_bf16;      // 2 / 3: contraction on the bf16 matrix cores with two- / three-term split operands (weights prepared with mode | 8 / | 16)
     int out_zeroed;      // 1: the caller has already zero-filled `out` (split partial sums meet there in atomics)
     int epi;             // 0: out = acc+bias | 1: out = acc+bias, out2 = gelu(out) | 2: out = acc+bias, out2 = aux*out | 3: out = acc+bias+aux
                          // 4: out = (acc+bias)*aux, out2 = (acc+bias)*aux2   (gate backward fused into proj_2's data gradient)
@@ -77,6 +77,7 @@ struct FinalizeJob {
     float *gw, *gb;      // outputs in the reference layout
     int chunks, K, CoutP, Cout, Cin;
     int kind;
+    int tr;              // kind 0: 1 = "transposing" fold (set by the launcher: few partials, many outputs), see cl_wgrad_finalize_kernel
     long n;              // outputs (weights + bias entries)
     long block0;         // first workgroup of this job
 };
@@ -98,6 +99,7 @@ struct DeformBwdArgs {
     int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
     int cc_per_block;   // 32-channel input chunks per blockIdx.z; grad_offset uses atomics when gridDim.z > 1
     int gx_zeroed;      // 1: the caller has already zero-filled gx
+    int goff_zeroed;    // 1: the caller has already zero-filled goff (needed when cl_deform_goff_ccsplit() > 1)
 };
 
 // Several zero fills in one launch (every dependent kernel node costs ~4.5 us of dispatch latency inside a hipGraph on

@@ -228,6 +228,8 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
     const int HW = p.H * p.W, rowbytes = p.C * 4;
     const int ncc = p.C / 32, nkc = p.CoutP / 32;
     const int tap_lo = blockIdx.y * taps_per_block, tap_hi = min(p.K, tap_lo + taps_per_block);
+    // blockIdx.z: slice of the 32-channel input chunks (tiny volumes only: the partial dots then meet in atomics on a zeroed goff)
+    const int cc_lo = blockIdx.z * p.cc_per_block, cc_hi = min(ncc, cc_lo + p.cc_per_block), ncb = cc_hi - cc_lo;
     const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.C * 4);
     float *Tt = &Tsm[wave][0][0], *Dt = Dsm[wave];
 
@@ -275,10 +277,10 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
     };
 
     // weight tile of stage s = (tap, cc, kc) in flight in a register while the previous stage computes
-    const int nstage = (tap_hi - tap_lo) * ncc * nkc;
+    const int nstage = (tap_hi - tap_lo) * ncb * nkc;
     f32x4 wreg;
     auto load_w = [&](int s) {
-        const int kc = s % nkc, cc = (s / nkc) % ncc, tap = tap_lo + s / (nkc * ncc);
+        const int kc = s % nkc, cc = cc_lo + (s / nkc) % ncb, tap = tap_lo + s / (nkc * ncb);
         const int rr = tid >> 3, c4 = tid & 7;
         wreg = *(reinterpret_cast<const f32x4 *>(p.wp + ((long)tap * p.CoutP + kc * 32 + rr) * p.C + cc * 32) + c4);
     };
@@ -287,12 +289,12 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
         load_w(0);
         load_offsets(tap_lo);
         describe(tap_lo);
-        issue(0);
+        issue(cc_lo);
         if (tap_lo + 1 < tap_hi) load_offsets(tap_lo + 1);
     }
     for (int tap = tap_lo; tap < tap_hi; ++tap) {
         float gd = 0.f, gh = 0.f, gw = 0.f;
-        for (int cc = 0; cc < ncc; ++cc) {
+        for (int cc = cc_lo; cc < cc_hi; ++cc) {
             // ---- 1. Col chunk on the matrix cores ----
             f32x16 acc;
 #pragma unroll
@@ -353,8 +355,8 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
                 *reinterpret_cast<f32x4 *>(dst + 2 * 32 * SROW) = dw;
             }
             // the next unit's corner loads go out now: in flight under the dots below, the next staging and the next MFMAs
-            if (cc + 1 < ncc) issue(cc + 1);
-            else if (tap + 1 < tap_hi) { describe(tap + 1); issue(0); }
+            if (cc + 1 < cc_hi) issue(cc + 1);
+            else if (tap + 1 < tap_hi) { describe(tap + 1); issue(cc_lo); }
             wave_sync();
             // ---- 3. dot with Col in the MFMA layout: acc[r] = Col[voxel j][channel (r&3) + 8*(r>>2) + 4h] ----
 #pragma unroll
@@ -373,7 +375,8 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
         gw += __shfl_xor(gw, 32);
         if (h == 0 && row_ok) {
             float *dst = p.goff + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
-            dst[0] = gd; dst[p.N] = gh; dst[2 * (long)p.N] = gw;
+            if (gridDim.z > 1) { atomicAdd(dst, gd); atomicAdd(dst + p.N, gh); atomicAdd(dst + 2 * (long)p.N, gw); }
+            else { dst[0] = gd; dst[p.N] = gh; dst[2 * (long)p.N] = gw; }
         }
         if (tap + 2 < tap_hi) load_offsets(tap + 2);
     }
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(512) void cl_deform_gx_kernel(DeformBwdArgs p, GxGe
 {
     DLKA_DYN_SMEM(unsigned char, smem);
     double *Win = reinterpret_cast<double *>(smem);                                        // [CS][wvox]
-    float *Bs = reinterpret_cast<float *>(smem + (size_t)gg.wvox_max * CS * sizeof(double));   // [CoutP][32]
+    float *Bs = reinterpret_cast<float *>(smem + (size_t)(gg.wvox_max + 64) * CS * sizeof(double));   // [CoutP][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     int bid = blockIdx.x;
@@ -417,11 +420,13 @@ __global__ __launch_bounds__(512) void cl_deform_gx_kernel(DeformBwdArgs p, GxGe
     gx_window(bd0, gg.bd, p.D, wd0, WD);
     gx_window(bh0, gg.bh, p.H, wh0, WH);
     gx_window(bw0, gg.bw, p.W, ww0, WW);
-    const int wvox = WD * WH * WW;
+    const int wvox = WD * WH * WW, WHW = WH * WW;
+    const int wstride = wvox + 64;     // channel plane stride: the window cells, then one trash cell per lane
+    const int trash = wvox + lane;
     const int R = gg.bd * gg.bh * gg.bw, ntiles = cdiv(R, 32);
     const int nkc = p.CoutP / 32;
 
-    for (int e = tid; e < wvox * CS; e += blockDim.x) Win[e] = 0.0;
+    for (int e = tid; e < wstride * CS; e += blockDim.x) Win[e] = 0.0;
 
     // A operand tile of group grp: Bs[co][t8*4 + c4] = W[co][slice*4 + c4][tap = grp*8 + t8]   (wp[tap][co][ci], zero beyond K)
     auto stage_weights = [&](int grp, float *dstB) {
@@ -482,34 +487,53 @@ __global__ __launch_bounds__(512) void cl_deform_gx_kernel(DeformBwdArgs p, GxGe
         }
         {
             // acc[r]: MFMA row (r&3) + 8*(r>>2) + 4h  ->  c4 = r & 3, t8 = 2*(r>>2) + h;   column = voxel j
+            // The window part of the scatter is branch-free: a corner outside the window keeps its 4 atomics but they add 0.0 to
+            // this lane's private trash cell (index wvox + lane), so the 32 ds_add_f64 of a tap issue back to back with no exec-mask
+            // juggling per corner.  Corners inside the volume but outside the window (rare: |offset| > HALO) take global atomics.
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             const int tap = grp * TG + 2 * r4 + h;
             if (!ok || tap >= p.K) continue;
-            const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
+            int ti, tj, tk;
+            if (p.kw == 3 && p.kh == 3) { ti = tap / 9; const int rr = tap - 9 * ti; tj = rr / 3; tk = rr - 3 * tj; }   // uniform
+            else { tk = tap % p.kw; tj = (tap / p.kw) % p.kh; ti = tap / (p.kw * p.kh); }
             LaneTap s;
             lane_tap(s, p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v, p.N, vd + ti * p.dd - p.pd, vh + tj * p.dh - p.ph, vw + tk * p.dw - p.pw,
                      p.D, p.H, p.W);
             if (!s.okm) continue;
             const float fd[2] = {1.f - s.ld, s.ld}, fh[2] = {1.f - s.lh, s.lh}, fw[2] = {1.f - s.lw, s.lw};
+            const int xd = s.zd - wd0, xh = s.zh - wh0, xw = s.zw - ww0;
+            // the window lies inside the volume: in-window implies in-volume
+            const bool ad[2] = {(unsigned)xd < (unsigned)WD, (unsigned)(xd + 1) < (unsigned)WD};
+            const bool ah[2] = {(unsigned)xh < (unsigned)WH, (unsigned)(xh + 1) < (unsigned)WH};
+            const bool aw[2] = {(unsigned)xw < (unsigned)WW, (unsigned)(xw + 1) < (unsigned)WW};
+            const int base = (xd * WH + xh) * WW + xw;
+            const float wdh[4] = {fd[0] * fh[0], fd[0] * fh[1], fd[1] * fh[0], fd[1] * fh[1]};
+            unsigned glb = 0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                if (!((s.okm >> q) & 1u)) continue;
                 const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
-                const float wq = fd[cd] * fh[ch] * fw[cw];
-                const int zd = s.zd + cd, zh = s.zh + ch, zw = s.zw + cw;       // inside the volume (okm)
-                const int xd = zd - wd0, xh = zh - wh0, xw = zw - ww0;
-                if ((unsigned)xd < (unsigned)WD && (unsigned)xh < (unsigned)WH && (unsigned)xw < (unsigned)WW) {
-                    double *cell = Win + (xd * WH + xh) * WW + xw;
-                    if (gg.ablate == 1) {   // profiling: plain (racy) stores instead of atomics
+                const bool inwin = ad[cd] & ah[ch] & aw[cw];
+                const float wq = wdh[2 * cd + ch] * fw[cw];
+                glb |= ((!inwin) & ((s.okm >> q) & 1u)) << q;
+                const int idx = inwin ? base + cd * WHW + ch * WW + cw : trash;
+                const float wv = inwin ? wq : 0.f;
+                double *cell = Win + idx;
+                if (gg.ablate == 1) {   // profiling: plain (racy) stores instead of atomics
 #pragma unroll
-                        for (int c = 0; c < CS; ++c) cell[c * wvox] = (double)(acc[4 * r4 + c] * wq);
-                        continue;
-                    }
+                    for (int c = 0; c < CS; ++c) cell[c * wstride] = (double)(acc[4 * r4 + c] * wv);
+                    continue;
+                }
 #pragma unroll
-                    for (int c = 0; c < CS; ++c) atomicAdd(cell + c * wvox, (double)(acc[4 * r4 + c] * wq));
-                } else {
-                    float *dst = p.gx + ((long)b * p.N + (long)(zd * p.H + zh) * p.W + zw) * p.C + slice * CS;
+                for (int c = 0; c < CS; ++c) atomicAdd(cell + c * wstride, (double)(acc[4 * r4 + c] * wv));
+            }
+            if (glb) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (!((glb >> q) & 1u)) continue;
+                    const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
+                    const float wq = wdh[2 * cd + ch] * fw[cw];
+                    float *dst = p.gx + ((long)b * p.N + (long)((s.zd + cd) * p.H + s.zh + ch) * p.W + s.zw + cw) * p.C + slice * CS;
 #pragma unroll
                     for (int c = 0; c < CS; ++c) atomicAdd(dst + c, acc[4 * r4 + c] * wq);
                 }
@@ -545,7 +569,7 @@ __global__ __launch_bounds__(512) void cl_deform_gx_kernel(DeformBwdArgs p, GxGe
     f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + ((long)blockIdx.x * gg.nslices + slice) * gg.wvox_max;
     for (int e = tid; e < wvox; e += blockDim.x) {
         f32x4 o;
-        o[0] = (float)Win[e]; o[1] = (float)Win[wvox + e]; o[2] = (float)Win[2 * wvox + e]; o[3] = (float)Win[3 * wvox + e];
+        o[0] = (float)Win[e]; o[1] = (float)Win[wstride + e]; o[2] = (float)Win[2 * wstride + e]; o[3] = (float)Win[3 * wstride + e];
         dst[e] = o;
     }
 }
@@ -627,6 +651,20 @@ size_t cl_deform_bwd2_scratch_floats(const DeformBwdArgs &a)
     return (size_t)a.B * g.nbd * g.nbh * g.nbw * g.nslices * g.wvox_max * CS;
 }
 
+// Slices of the input-channel chunks for grad_offset.  At C = 256 / 4^3 the (voxel-block, tap) grid is 27 workgroups, each
+// running 64 chunk GEMMs in sequence (82 us, profiles/r01n); slicing the channel chunks brings it to ~216 workgroups.
+int cl_deform_goff_ccsplit(const DeformBwdArgs &a)
+{
+    const int mblocks = cdiv(a.M, 128);
+    int tsplit = 1;
+    while (mblocks * tsplit < 512 && tsplit < a.K) ++tsplit;
+    tsplit = cdiv(a.K, cdiv(a.K, tsplit));
+    const int ncc = a.C / 32;
+    int split = 1;
+    while (mblocks * tsplit * split * 2 <= 256 && split * 2 <= ncc) split *= 2;
+    return cdiv(ncc, cdiv(ncc, split));
+}
+
 int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st)
 {
     if (a.C % 32 || a.CoutP % 32) return DLKA_ERR_UNSUPPORTED;
@@ -637,17 +675,21 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         while (mblocks * tsplit < 512 && tsplit < a.K) ++tsplit;
         const int tpb = cdiv(a.K, tsplit);
         tsplit = cdiv(a.K, tpb);
-        dim3 grid(mblocks, tsplit), block(256);
         const int nkc = a.CoutP / 32;
         static const bool v1 = getenv("DLKA_GOFF_V1") != nullptr;   // A/B switch: first "lane = voxel" gather
+        const int ccsplit = v1 ? 1 : cl_deform_goff_ccsplit(a);
+        DeformBwdArgs ag = a;
+        ag.cc_per_block = cdiv(a.C / 32, ccsplit);
+        if (ccsplit > 1 && !a.goff_zeroed && launch_zero(a.goff, (size_t)a.B * 3 * a.K * a.N * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
+        dim3 grid(mblocks, tsplit, ccsplit), block(256);
         if (v1) {
             if (nkc == 1) { auto k = cl_deform_goff_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
             else if (nkc == 2) { auto k = cl_deform_goff_kernel<2>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
             else { auto k = cl_deform_goff_kernel<0>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
         } else {
-            if (nkc == 1) { auto k = cl_deform_goff2_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
-            else if (nkc == 2) { auto k = cl_deform_goff2_kernel<2>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
-            else { auto k = cl_deform_goff2_kernel<0>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
+            if (nkc == 1) { auto k = cl_deform_goff2_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
+            else if (nkc == 2) { auto k = cl_deform_goff2_kernel<2>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
+            else { auto k = cl_deform_goff2_kernel<0>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
         }
         DLKA_CHECK_LAUNCH();
     }
@@ -656,11 +698,12 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const GxGeom g = pick_gx_geom(a);
         if (!a.gx_zeroed && launch_zero(a.gx, (size_t)a.B * a.N * a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         GxGeom gl_ = g;
-        const size_t lds_all = (size_t)g.wvox_max * CS * sizeof(double) + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
+        const size_t lds_win = (size_t)(g.wvox_max + 64) * CS * sizeof(double);   // window + one trash cell per lane and channel plane
+        const size_t lds_all = lds_win + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
         gl_.resident = (lds_all <= 150 * 1024 && a.CoutP <= 128) ? 1 : 0;
         static const int abl = getenv("DLKA_GX_ABL") ? atoi(getenv("DLKA_GX_ABL")) : 0;
         gl_.ablate = abl;
-        const size_t lds = gl_.resident ? lds_all : (size_t)g.wvox_max * CS * sizeof(double) + (size_t)a.CoutP * 32 * sizeof(float);
+        const size_t lds = gl_.resident ? lds_all : lds_win + (size_t)a.CoutP * 32 * sizeof(float);
         if (lds > 160 * 1024) return DLKA_ERR_UNSUPPORTED;
 #if !defined(HIPEMU)
         static bool attr_done = false;   // dynamic LDS above 64 KB has to be enabled once per function

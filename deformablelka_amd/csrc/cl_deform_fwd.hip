@@ -7,6 +7,8 @@
 // covers 8 whole 128-byte rows — 3.5x the gather rate of the first version's "lane = row" loads), transposes it through
 // a wave-private LDS tile into the MFMA A layout, and feeds v_mfma_f32_32x32x2_f32.  The gather loads of unit u+1 are in
 // flight under the MFMAs of unit u; the 4 waves of a workgroup share the 32 x NP weight chunk through LDS.
+#include <stdlib.h>
+
 #include "cl_args.h"
 #include "cl_gather.h"
 #include "dlka_kernels.h"
@@ -166,6 +168,12 @@ int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
     int NT = NT_total;
     if (NT_total == 8) NT = 4;
     else if (NT_total == 3 || NT_total > 4) return DLKA_ERR_UNSUPPORTED;
+    // small volumes: fewer column tiles per workgroup (-> more workgroups) beats not repeating the gather
+    // (C=256 / 4^3: 57.8 -> 36.0 us with NT = 1; C=128 / 8^3: 47.6 -> 41.0 us with NT = 2; profiles/r01s_dfwd_tuning.txt)
+    if (a.M <= 256) NT = 1;
+    else if (a.M <= 2048 && NT_total == 4) NT = 2;
+    static const int nt_env = getenv("DLKA_DFWD_NT") ? atoi(getenv("DLKA_DFWD_NT")) : 0;   // tuning knob
+    if (nt_env == 1 || nt_env == 2 || nt_env == 4) { if (NT_total % nt_env == 0 && nt_env <= NT_total) NT = nt_env; }
     dim3 grid(mblocks, splits, NT_total / NT), block(256);
     switch (NT) {
         case 1: { auto k = cl_deform_fwd_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;

@@ -94,12 +94,16 @@ struct ARow {
 // SPLIT: the contraction runs on the bf16 matrix cores with two-term split operands (dlka_intrin.h: hi*hi + hi*lo + lo*hi,
 // fp32 accumulation, ~1e-5 relative) instead of the exact fp32-input MFMA: 6 x 32 cycles per 32-channel unit and column tile
 // instead of 16 x 64.  The prepared weights then hold, per unit, the blocks [hi|lo][k half mf][lane half h][NP][8 bf16].
-template <int AMODE, int OMODE, int NT, bool SPLIT = false>
+// SPLIT = 3: three-term operands and the six products above 2^-24 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid): fp32-equivalent
+// (the dropped terms are below fp32's own rounding), 12 x 32 cycles per unit and tile — 2.7x the fp32-input MFMA.  Used for the FORWARD
+// offset conv, whose output decides floor() of the sampling positions and must not move by 1e-5; records [(part*2+mf)*2+h], part 0..2.
+template <int AMODE, int OMODE, int NT, int SPLIT = 0>
 __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
 {
     constexpr int NPB = NT * 32;                 // columns handled by this block
-    constexpr int BV = NT;                       // float4 of the 32 x NPB weight chunk each of the 256 threads stages
-    constexpr int BSZ = (OMODE == 1 && 32 * NPB < 2 * 32 * 33) ? 2 * 32 * 33 : 32 * NPB;   // OMODE 1 reuses Bs for 4 transpose tiles
+    constexpr int UF = SPLIT == 3 ? 48 : 32;     // floats of prepared weights per unit and column
+    constexpr int BV = (UF * NPB / 4 + 255) / 256;   // float4 of the weight chunk each of the 256 threads stages
+    constexpr int BSZ = (OMODE == 1 && UF * NPB < 2 * 32 * 33) ? 2 * 32 * 33 : UF * NPB;   // OMODE 1 reuses Bs for 4 transpose tiles
     __shared__ __attribute__((aligned(16))) float Bs[2][BSZ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
@@ -128,12 +132,12 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
 #define DLKA_LOAD_B(unit_)                                                                         \
     {                                                                                              \
         const int tap_ = (unit_) / nchunk, ck_ = (unit_) - tap_ * nchunk;                          \
-        const float *src_ = p.wp + ((long)tap_ * p.CinP + ck_ * 32) * p.NP + (SPLIT ? 0 : n0);     \
+        const float *src_ = p.wp + ((long)tap_ * nchunk + ck_) * UF * p.NP + (SPLIT ? 0 : n0);      \
         _Pragma("unroll") for (int e = 0; e < BV; ++e) {                                           \
             const int idx_ = tid + e * 256;                                                        \
-            if (SPLIT) {   /* 8 segments (part, mf, h) of NPB 16-byte column records */            \
+            if (SPLIT) {   /* 4 * SPLIT segments (part, mf, h) of NPB 16-byte column records */     \
                 const int seg_ = idx_ / NPB, col_ = idx_ - seg_ * NPB;                              \
-                breg[e] = reinterpret_cast<const f32x4 *>(src_)[(long)seg_ * p.NP + n0 + col_];    \
+                if (idx_ < UF * NPB / 4) breg[e] = reinterpret_cast<const f32x4 *>(src_)[(long)seg_ * p.NP + n0 + col_]; \
             } else {                                                                               \
                 const int rr_ = idx_ / (NPB / 4), c4_ = idx_ - rr_ * (NPB / 4);                    \
                 breg[e] = reinterpret_cast<const f32x4 *>(src_ + (long)rr_ * p.NP)[c4_];          \
@@ -148,7 +152,8 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
     int buf = 0;
     for (int unit = unit_lo; unit < unit_hi; ++unit, buf ^= 1) {
 #pragma unroll
-        for (int e = 0; e < BV; ++e) reinterpret_cast<f32x4 *>(Bs[buf])[tid + e * 256] = breg[e];
+        for (int e = 0; e < BV; ++e)
+            if (tid + e * 256 < UF * NPB / 4) reinterpret_cast<f32x4 *>(Bs[buf])[tid + e * 256] = breg[e];
 #pragma unroll
         for (int e = 0; e < 16; ++e) a_cur[e] = a_nxt[e];
         __syncthreads();   // Bs[buf] staged; Bs[buf^1] (read two iterations ago) is free again
@@ -157,7 +162,25 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
             const int tap = (unit + 1) / nchunk;
             arow.fetch(p, rin, tap, unit + 1 - tap * nchunk, h, row_ok, b, v, d0, h0, w0, a_nxt);
         }
-        if (SPLIT) {
+        if (SPLIT == 3) {
+            const bf16x8 *B16 = reinterpret_cast<const bf16x8 *>(Bs[buf]);   // [(part*2 + mf)*2 + h][NPB] records of 8 bf16, part = hi, mid, lo
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                bf16x8 ahi, amid, alo;
+                split3_bf16x8(a_cur + 8 * mf, ahi, amid, alo);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bf16x8 bhi = B16[((0 * 2 + mf) * 2 + h) * NPB + t * 32 + i], bmid = B16[((1 * 2 + mf) * 2 + h) * NPB + t * 32 + i],
+                                 blo = B16[((2 * 2 + mf) * 2 + h) * NPB + t * 32 + i];
+                    acc[t] = mfma_32x32x16_bf16(alo, bhi, acc[t]);   // small terms first
+                    acc[t] = mfma_32x32x16_bf16(ahi, blo, acc[t]);
+                    acc[t] = mfma_32x32x16_bf16(amid, bmid, acc[t]);
+                    acc[t] = mfma_32x32x16_bf16(amid, bhi, acc[t]);
+                    acc[t] = mfma_32x32x16_bf16(ahi, bmid, acc[t]);
+                    acc[t] = mfma_32x32x16_bf16(ahi, bhi, acc[t]);
+                }
+            }
+        } else if (SPLIT) {
             const bf16x8 *B16 = reinterpret_cast<const bf16x8 *>(Bs[buf]);   // [(part*2 + mf)*2 + h][NPB] records of 8 bf16
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) {
@@ -265,8 +288,18 @@ __device__ __forceinline__ float prep_value(const float *__restrict__ w, int Cou
 // [(part*2 + mf)*2 + h][NP][8] with k % 32 = 16h + 8mf + e, part 0 = hi, 1 = lo.
 __device__ __forceinline__ void prep_store(float *__restrict__ wp, int KP, int NP, int mode, int tp, int k, int n, float val)
 {
-    if (!(mode & 8)) { wp[((long)tp * KP + k) * NP + n] = val; return; }
+    if (!(mode & 24)) { wp[((long)tp * KP + k) * NP + n] = val; return; }
     const int kk = k & 31, h = kk >> 4, mf = (kk >> 3) & 1, e = kk & 7;
+    if (mode & 16) {   // three-term records: a unit takes 48 * NP floats
+        unsigned short *u = reinterpret_cast<unsigned short *>(wp + ((long)tp * (KP / 32) + (k >> 5)) * 48 * NP);
+        const unsigned short hi = bf16_bits(val);
+        const float r1 = val - bf16_value(hi);
+        const unsigned short mid = bf16_bits(r1), lo = bf16_bits(r1 - bf16_value(mid));
+        u[((long)((0 * 2 + mf) * 2 + h) * NP + n) * 8 + e] = hi;
+        u[((long)((1 * 2 + mf) * 2 + h) * NP + n) * 8 + e] = mid;
+        u[((long)((2 * 2 + mf) * 2 + h) * NP + n) * 8 + e] = lo;
+        return;
+    }
     unsigned short *u = reinterpret_cast<unsigned short *>(wp + ((long)tp * KP + (k & ~31)) * NP);
     const unsigned short hi = bf16_bits(val), lo = bf16_bits(val - bf16_value(hi));
     u[((long)((0 * 2 + mf) * 2 + h) * NP + n) * 8 + e] = hi;
@@ -325,7 +358,7 @@ int launch_cl_prep_batch(const PrepBatch &b, hipStream_t st)
     return DLKA_OK;
 }
 
-template <int AMODE, int OMODE, bool SPLIT = false>
+template <int AMODE, int OMODE, int SPLIT = 0>
 static int launch_igemm_nt(const IgemmArgs &a, int splits, hipStream_t st)
 {
     const int NT_total = a.NP / 32;
@@ -390,9 +423,14 @@ int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t s
         if (launch_zero(a.out, (size_t)n * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
     }
     if (a.split_bf16) {   // bf16 x3 split contraction (the prepared weights must be in the split layout)
-        if (amode == 0 && omode == 0) return launch_igemm_nt<0, 0, true>(a, splits, st);
-        if (amode == 0 && omode == 1) return launch_igemm_nt<0, 1, true>(a, splits, st);
-        if (amode == 2 && omode == 0) return launch_igemm_nt<2, 0, true>(a, splits, st);
+        if (a.split_bf16 == 3) {
+            if (amode == 0 && omode == 1) return launch_igemm_nt<0, 1, 3>(a, splits, st);
+            if (amode == 0 && omode == 0) return launch_igemm_nt<0, 0, 3>(a, splits, st);
+            return DLKA_ERR_UNSUPPORTED;
+        }
+        if (amode == 0 && omode == 0) return launch_igemm_nt<0, 0, 2>(a, splits, st);
+        if (amode == 0 && omode == 1) return launch_igemm_nt<0, 1, 2>(a, splits, st);
+        if (amode == 2 && omode == 0) return launch_igemm_nt<2, 0, 2>(a, splits, st);
         return DLKA_ERR_UNSUPPORTED;
     }
     if (amode == 0 && omode == 0) return launch_igemm_nt<0, 0>(a, splits, st);

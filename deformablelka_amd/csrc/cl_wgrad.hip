@@ -706,6 +706,40 @@ __global__ __launch_bounds__(256) void cl_wgrad_finalize_kernel(FinalizeBatch b)
     }
     const long n = (long)jb.K * jb.Cout * jb.Cin;
     const long stride = (long)jb.K * jb.CoutP * jb.Cin;
+    if (jb.tr) {
+        // Few partials, many outputs (the small stages: 27 x 256 x 256 weights, 3 partials): a workgroup owns (co, 32 ci, all K taps).
+        // Reads stay 128-byte rows of the [tap][co][ci] partial tiles; the K x 32 results are re-laid through LDS and leave as ONE
+        // contiguous run of 32*K floats of gW[co][ci][tap] — the element-per-lane version wrote 4-byte pieces K*4 bytes apart
+        // (67 us for the C = 256 block, profiles/r01n).
+        __shared__ float tile[32 * 28];   // [ci][tap], K <= 27 (+1 padding)
+        const long blk = (long)blockIdx.x - jb.block0;
+        const int cblocks = jb.Cin / 32;
+        const long wblocks = (long)jb.Cout * cblocks;
+        if (blk < wblocks) {
+            const int co = (int)(blk / cblocks), ci0 = (int)(blk % cblocks) * 32;
+            for (int tp = cl; tp < jb.K; tp += 8) {
+                const float *src = jb.part + ((long)tp * jb.CoutP + co) * jb.Cin + ci0 + el;
+                float s0 = 0.f, s1 = 0.f;
+                int c = 0;
+                for (; c + 1 < jb.chunks; c += 2) { s0 += src[(long)c * stride]; s1 += src[(long)(c + 1) * stride]; }
+                if (c < jb.chunks) s0 += src[(long)c * stride];
+                tile[el * 28 + tp] = s0 + s1;
+            }
+            __syncthreads();
+            float *dst = jb.gw + ((long)co * jb.Cin + ci0) * jb.K;
+            for (int l = threadIdx.x; l < 32 * jb.K; l += 256) dst[l] = tile[(l / jb.K) * 28 + l % jb.K];
+        } else if (jb.gb) {
+            const int co = (int)(blk - wblocks) * 32 + el;
+            float s0 = 0.f;
+            if (co < jb.Cout)
+                for (int c = cl; c < jb.chunks; c += 8) s0 += jb.bpart[(long)c * jb.CoutP + co];
+            red[cl][el] = s0;
+            __syncthreads();
+            if (cl == 0 && co < jb.Cout)
+                jb.gb[co] = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+        }
+        return;
+    }
     float a0 = 0.f, a1 = 0.f;
     int ci = 0, co = 0, tap = 0;
     if (e < n) {
@@ -738,7 +772,13 @@ int launch_cl_wgrad_finalize(FinalizeBatch &b, hipStream_t st)
 {
     if (b.njobs <= 0) return DLKA_OK;
     long blk = 0;
-    for (int k = 0; k < b.njobs; ++k) { b.j[k].block0 = blk; blk += cdivl(b.j[k].n, 32); }
+    static const bool no_tr = getenv("DLKA_FINALIZE_V1") != nullptr;   // A/B switch
+    for (int k = 0; k < b.njobs; ++k) {
+        FinalizeJob &j = b.j[k];
+        j.block0 = blk;
+        j.tr = (!no_tr && j.kind == 0 && j.K > 1 && j.K <= 27 && j.chunks <= 16 && j.Cin % 32 == 0 && (long)j.Cout * j.Cin >= 1024) ? 1 : 0;
+        blk += j.tr ? (long)j.Cout * (j.Cin / 32) + (j.gb ? cdiv(j.Cout, 32) : 0) : cdivl(j.n, 32);
+    }
     b.nblocks = blk;
     if (blk > 0x7fffffffL) return DLKA_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(cl_wgrad_finalize_kernel, dim3((unsigned)blk), dim3(256), 0, st, b);

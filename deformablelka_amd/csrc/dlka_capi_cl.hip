@@ -76,12 +76,17 @@ bool dense_fwd_supported(const SameConv &s) { return s.group == 1 && s.Cin % 32 
 // sampling position, and a 1e-5 perturbation flips the cell of the samples that sit within 1e-5 of an integer — harmless
 // for training, but each flip changes that sample's grad_offset by O(1), which showed as a 1.5e-2 relative difference of
 // conv_offset.weight.grad against the oracle when the offsets are concentrated near 0 (tests/test_parity_gpu.py).
-bool use_split(const SameConv &s, bool forward)
+// Returns the number of bf16 terms per operand (0 = exact fp32-input MFMA).  Gradient contractions: 2 (three products, ~1e-5).
+// Forward: 3 (six products, fp32-equivalent) — see cl_igemm.hip; DLKA_SPLIT_FORWARD=2 forces the two-term split there for A/B runs.
+int use_split(const SameConv &s, bool forward)
 {
     static const bool exact = getenv("DLKA_EXACT_FP32") != nullptr;
-    static const bool all = getenv("DLKA_SPLIT_FORWARD") != nullptr;   // A/B: also split the forward conv (118 -> 56 us at stage 0)
-    return !exact && s.K > 1 && (!forward || all);
+    static const int fwd = getenv("DLKA_SPLIT_FORWARD") ? atoi(getenv("DLKA_SPLIT_FORWARD")) : 3;
+    if (exact || s.K <= 1) return 0;
+    if (!forward) return 2;
+    return (fwd == 2 || fwd == 3) ? fwd : 0;
 }
+inline int split_mode_flag(int terms) { return terms == 3 ? 16 : (terms == 2 ? 8 : 0); }
 
 void fill_igemm(IgemmArgs &a, const SameConv &s)
 {
@@ -100,11 +105,11 @@ int dense_forward(const SameConv &s, const float *x, const float *w, const float
                   int epi, const float *aux, float *out2, hipStream_t st, bool zeroed = false)
 {
     const int NP = round_up(s.Cout, 32);
-    const bool split = use_split(s, true);
-    if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, NP, split ? 8 : 0, st));   // w == null: wp already prepared
+    const int split = use_split(s, true);
+    if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, NP, split_mode_flag(split), st));   // w == null: wp already prepared
     IgemmArgs a;
     fill_igemm(a, s);
-    a.split_bf16 = split ? 1 : 0;
+    a.split_bf16 = split;
     a.in = x; a.wp = wp; a.bias = bias; a.out = out; a.out2 = out2; a.aux = aux; a.epi = epi; a.out_zeroed = zeroed ? 1 : 0;
     a.Cin = s.Cin; a.CinReal = s.Cin; a.CinP = s.Cin; a.Cout = s.Cout; a.NP = NP;
     const int splits = dense_forward_splits(s, epi);
@@ -119,11 +124,11 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
     const int KP = round_up(s.Cout, 32), NP = s.Cin;
     if (!nt_ok(NP) || s.Cin % 32) return DLKA_ERR_UNSUPPORTED;
     if (!gout_planar && s.Cout % 32) return DLKA_ERR_UNSUPPORTED;
-    const bool split = use_split(s, false);
-    if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, KP, NP, split ? 9 : 1, st));
+    const int split = use_split(s, false);
+    if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, KP, NP, 1 | split_mode_flag(split), st));
     IgemmArgs a;
     fill_igemm(a, s);
-    a.split_bf16 = split ? 1 : 0;
+    a.split_bf16 = split;
     a.pd = s.dd * (s.kd - 1) - s.pd; a.ph = s.dh * (s.kh - 1) - s.ph; a.pw = s.dw * (s.kw - 1) - s.pw;
     a.in = gout; a.wp = wp; a.bias = nullptr; a.out = gx; a.aux = aux; a.aux2 = aux2; a.out2 = out2; a.epi = epi; a.out_zeroed = zeroed ? 1 : 0;
     a.Cin = s.Cout; a.CinReal = s.Cout; a.CinP = KP; a.Cout = s.Cin; a.NP = NP;
@@ -131,7 +136,8 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
     return launch_cl_igemm(gout_planar ? 2 : 0, 0, a, splits, st);
 }
 
-size_t dense_wp_floats(const SameConv &s) { return (size_t)s.K * round_up(s.Cin, 32) * round_up(s.Cout, 32); }
+// (x 3/2 for K > 1: the three-term bf16 layout of the forward weights takes 48 instead of 32 floats per unit and column)
+size_t dense_wp_floats(const SameConv &s) { return (size_t)s.K * round_up(s.Cin, 32) * round_up(s.Cout, 32) * (s.K > 1 ? 3 : 2) / 2; }
 
 // ---- dense conv weight gradient -----------------------------------------------------------------------------------
 int dense_backward_weight(const SameConv &s, const float *x, const float *gout, int gout_planar, float *gw, float *gb, float *part, hipStream_t st,
@@ -239,13 +245,14 @@ int deform_bwd_variant()
 }
 
 int deform_backward(const SameConv &s, const float *x, const float *off, const float *w, const float *gout, float *gx, float *goff,
-                    float *gw, float *gb, float *wp, float *part, float *scratch, hipStream_t st, FinalizeJob *defer = nullptr, bool gx_zeroed = false)
+                    float *gw, float *gb, float *wp, float *part, float *scratch, hipStream_t st, FinalizeJob *defer = nullptr, bool gx_zeroed = false,
+                    bool goff_zeroed = false)
 {
     if (gx || goff) {
         if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cout, s.Cin, 2, st));
         DeformBwdArgs a;
         fill_deform_bwd(a, s);
-        a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff; a.gx_zeroed = gx_zeroed ? 1 : 0;
+        a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff; a.gx_zeroed = gx_zeroed ? 1 : 0; a.goff_zeroed = goff_zeroed ? 1 : 0;
         const int variant = deform_bwd_variant();
         if (variant == 0) DLKA_TRY(launch_cl_deform_bwd2(a, scratch, st));
         else if (variant == 2 && s.N >= 512) DLKA_TRY(launch_cl_deform_bwd_lds(a, st));
@@ -341,7 +348,7 @@ int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_para
         add_job(pb, pw_w[k], t.pw_f[k], C, C, 1, C, C, 0);
         add_job(pb, pw_w[k], t.pw_b[k], C, C, 1, C, C, 1);
     }
-    add_job(pb, p->offset_w, t.off_f, 81, C, 27, C, 96, use_split(G.offc, true) ? 8 : 0);
+    add_job(pb, p->offset_w, t.off_f, 81, C, 27, C, 96, split_mode_flag(use_split(G.offc, true)));
     add_job(pb, p->offset_w, t.off_b, 81, C, 27, 96, C, use_split(G.offc, false) ? 9 : 1);
     add_job(pb, p->deform_w, t.dcn_f, C, C, 27, C, C, 0);
     add_job(pb, p->deform_w, t.dcn_b, C, C, 27, C, C, 2);
@@ -625,6 +632,11 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     memset(&zb, 0, sizeof(zb));
     zb.add(stage5, G.stage_dw());
     zb.add(gta, G.E);
+    {
+        DeformBwdArgs da;
+        fill_deform_bwd(da, G.dcn);
+        if (deform_bwd_variant() == 0 && cl_deform_goff_ccsplit(da) > 1) zb.add(goff, G.Off);
+    }
     if (dense_backward_data_splits(G.pw, 0) > 1) zb.add(gf, G.E);
     if (dense_backward_data_splits(G.offc, 3) > 1) zb.add(gt, G.E);
     if (dense_backward_data_splits(G.pw, 3) > 1) zb.add(gx, G.E);
@@ -642,7 +654,7 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     // deformable conv:  f = DCN(t, off):  weight gradient on the side stream, grad_offset and grad_input on the main one
     DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
                              &fb.j[fb.njobs++]));
-    DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, goff, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st));
+    DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, goff, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, false, true));
     DLKA_TRY(publish());
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
     DLKA_TRY(dense_backward_weight(G.offc, t, goff, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, ws_, &fb.j[fb.njobs++]));

@@ -22,6 +22,16 @@ __device__ __forceinline__ void split_bf16x8(const float *a, bf16x8 &hi, bf16x8 
         lo.v[e] = hipemu::hipemu_f32_to_bf16(a[e] - hipemu::hipemu_bf16_to_f32(hi.v[e]));
     }
 }
+// a[e] = hi[e] + mid[e] + lo[e] up to fp32 rounding: three bf16 terms carry the 24-bit significand
+__device__ __forceinline__ void split3_bf16x8(const float *a, bf16x8 &hi, bf16x8 &mid, bf16x8 &lo)
+{
+    for (int e = 0; e < 8; ++e) {
+        hi.v[e] = hipemu::hipemu_f32_to_bf16(a[e]);
+        const float r1 = a[e] - hipemu::hipemu_bf16_to_f32(hi.v[e]);
+        mid.v[e] = hipemu::hipemu_f32_to_bf16(r1);
+        lo.v[e] = hipemu::hipemu_f32_to_bf16(r1 - hipemu::hipemu_bf16_to_f32(mid.v[e]));
+    }
+}
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return hipemu::hipemu_f32_to_bf16(x); }
 __device__ __forceinline__ float bf16_value(unsigned short h) { return hipemu::hipemu_bf16_to_f32(h); }
 #define DLKA_DYN_SMEM(type, name) type *name = reinterpret_cast<type *>(hipemu::dyn_smem())
@@ -72,6 +82,16 @@ __device__ __forceinline__ void split_bf16x8(const float *a, bf16x8 &hi, bf16x8 
     for (int e = 0; e < 8; ++e) {
         hi[e] = (__bf16)a[e];
         lo[e] = (__bf16)(a[e] - (float)hi[e]);
+    }
+}
+__device__ __forceinline__ void split3_bf16x8(const float *a, bf16x8 &hi, bf16x8 &mid, bf16x8 &lo)
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hi[e] = (__bf16)a[e];
+        const float r1 = a[e] - (float)hi[e];   // exact in fp32
+        mid[e] = (__bf16)r1;
+        lo[e] = (__bf16)(r1 - (float)mid[e]);
     }
 }
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }

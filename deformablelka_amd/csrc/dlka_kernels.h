@@ -68,6 +68,7 @@ int launch_cl_deform_bwd(const DeformBwdArgs &a, hipStream_t st);
 int launch_cl_deform_bwd_lds(const DeformBwdArgs &a, hipStream_t st);
 size_t cl_deform_bwd2_scratch_floats(const DeformBwdArgs &a);
 int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st);
+int cl_deform_goff_ccsplit(const DeformBwdArgs &a);
 
 // ---- cl_norm.hip: the non-convolutional pieces of TransformerBlock_3D_single_deform_LKA ---------------------------------
 int launch_cl_layernorm_fwd(const float *x, int x_planar, const float *pos, const float *w, const float *b, float *xt, float *xn, float *stats, int B, int N,
