@@ -19,6 +19,7 @@ struct IgemmArgs {
     int units_per_split; // work units (tap, 32-channel chunk) per blockIdx.y; K * CinP/32 when gridDim.y == 1
     int split_bf16;      // 2 / 3: contraction on the bf16 matrix cores with two- / three-term split operands (weights prepared with mode | 8 / | 16)
     int out_zeroed;      // 1: the caller has already zero-filled `out` (split partial sums meet there in atomics)
+    int a_packed;        // AMODE 2 + split_bf16 == 2: `in` holds pack_split2() words (CinReal = CinP channel planes per batch, zero padded)
     int epi;             // 0: out = acc+bias | 1: out = acc+bias, out2 = gelu(out) | 2: out = acc+bias, out2 = aux*out | 3: out = acc+bias+aux
                          // 4: out = (acc+bias)*aux, out2 = (acc+bias)*aux2   (gate backward fused into proj_2's data gradient)
 };
@@ -34,6 +35,7 @@ struct WgradArgs {
     int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
     int rows_per_chunk;  // multiple of 32
     int CT;              // Cin / 32
+    int g_cpad;          // GMODE 1 only, > 0: g holds pack_split2() words with g_cpad channel planes per batch (see DeformBwdArgs::goff_cpad)
 };
 
 struct DwArgs {
@@ -100,6 +102,8 @@ struct DeformBwdArgs {
     int cc_per_block;   // 32-channel input chunks per blockIdx.z; grad_offset uses atomics when gridDim.z > 1
     int gx_zeroed;      // 1: the caller has already zero-filled gx
     int goff_zeroed;    // 1: the caller has already zero-filled goff (needed when cl_deform_goff_ccsplit() > 1)
+    int goff_cpad;      // > 0: goff is written as pack_split2() words with goff_cpad channel planes per batch (planes >= 3K zero) for the
+                        //      split-MFMA consumers (offset-conv data / weight gradient); 0: plain fp32 [B][3K][N]
 };
 
 // Several zero fills in one launch (every dependent kernel node costs ~4.5 us of dispatch latency inside a hipGraph on

@@ -233,6 +233,10 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
     const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.C * 4);
     float *Tt = &Tsm[wave][0][0], *Dt = Dsm[wave];
 
+    if (p.goff_cpad && blockIdx.y == 0 && blockIdx.z == 0 && h == 0 && row_ok) {   // the zero planes 3K .. goff_cpad-1 of the packed layout
+        float *dst = p.goff + ((long)b * p.goff_cpad + 3 * p.K) * p.N + v;
+        for (int c = 3 * p.K; c < p.goff_cpad; ++c, dst += p.N) *dst = 0.f;
+    }
     float greg[NKC_REG > 0 ? NKC_REG : 1][16];
     if (NKC_REG > 0) {
 #pragma unroll
@@ -374,8 +378,9 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
         gh += __shfl_xor(gh, 32);
         gw += __shfl_xor(gw, 32);
         if (h == 0 && row_ok) {
-            float *dst = p.goff + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
+            float *dst = p.goff + ((long)b * (p.goff_cpad ? p.goff_cpad : 3 * p.K) + 3 * tap) * p.N + v;
             if (gridDim.z > 1) { atomicAdd(dst, gd); atomicAdd(dst + p.N, gh); atomicAdd(dst + 2 * (long)p.N, gw); }
+            else if (p.goff_cpad) { dst[0] = pack_split2(gd); dst[p.N] = pack_split2(gh); dst[2 * (long)p.N] = pack_split2(gw); }
             else { dst[0] = gd; dst[p.N] = gh; dst[2 * (long)p.N] = gw; }
         }
         if (tap + 2 < tap_hi) load_offsets(tap + 2);
@@ -680,6 +685,7 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const int ccsplit = v1 ? 1 : cl_deform_goff_ccsplit(a);
         DeformBwdArgs ag = a;
         ag.cc_per_block = cdiv(a.C / 32, ccsplit);
+        if (a.goff_cpad && (ccsplit > 1 || v1)) return DLKA_ERR_UNSUPPORTED;   // the packed layout needs the single-writer path
         if (ccsplit > 1 && !a.goff_zeroed && launch_zero(a.goff, (size_t)a.B * 3 * a.K * a.N * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         dim3 grid(mblocks, tsplit, ccsplit), block(256);
         if (v1) {

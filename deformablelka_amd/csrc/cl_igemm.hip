@@ -71,9 +71,16 @@ struct ARow {
                 a[4 * e] = t[0]; a[4 * e + 1] = t[1]; a[4 * e + 2] = t[2]; a[4 * e + 3] = t[3];
             }
         } else if (AMODE == 2) {
+            if (p.a_packed) {   // uniform: all CinP planes exist (zero padded): one per-lane offset, the plane stride rides in the scalar offset
+                const unsigned vo = rowoff == DLKA_OOB ? DLKA_OOB : rowoff + (unsigned)(16 * h * p.N) * 4u;
+                const unsigned so = (unsigned)(ck * 32 * p.N) * 4u, ps = (unsigned)p.N * 4u;
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                a[e] = buf_load_f32(rin, (c0 + e < p.CinReal) ? rowoff + (unsigned)((c0 + e) * p.N) * 4u : DLKA_OOB);
+                for (int e = 0; e < 16; ++e) a[e] = buf_load_f32_s(rin, vo, so + (unsigned)e * ps);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    a[e] = buf_load_f32(rin, (c0 + e < p.CinReal) ? rowoff + (unsigned)((c0 + e) * p.N) * 4u : DLKA_OOB);
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 16; ++e) a[e] = 0.f;
@@ -185,7 +192,8 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) {
                 bf16x8 ahi, alo;
-                split_bf16x8(a_cur + 8 * mf, ahi, alo);
+                if (AMODE == 2 && p.a_packed) unpack_split2x8(a_cur + 8 * mf, ahi, alo);   // split once by the producer (cl_deform_goff2_kernel)
+                else split_bf16x8(a_cur + 8 * mf, ahi, alo);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const bf16x8 bhi = B16[((0 * 2 + mf) * 2 + h) * NPB + t * 32 + i], blo = B16[((1 * 2 + mf) * 2 + h) * NPB + t * 32 + i];

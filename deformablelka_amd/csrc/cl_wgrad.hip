@@ -344,7 +344,8 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
     const int m_hi = min(p.M, m_lo + p.rows_per_chunk);
 
     float ga_n[COT][16], bv_n[TPW][16];
-    const BufRsrc rg = make_rsrc(p.g, (size_t)p.M * p.Cout * 4), rx = make_rsrc(p.in, (size_t)p.M * p.Cin * 4);
+    const int gcp = (GMODE == 1 && p.g_cpad) ? p.g_cpad : p.Cout;   // channel planes per batch of a planar g
+    const BufRsrc rg = make_rsrc(p.g, (size_t)p.B * p.N * gcp * 4), rx = make_rsrc(p.in, (size_t)p.M * p.Cin * 4);
     // operands of the 32-row step starting at mbase: rows m = mbase + 16h + s.  Every load is an unconditional buffer
     // load; rows beyond the chunk, channels beyond Cout and zero-padded neighbours read offset DLKA_OOB -> 0.
     auto load_step = [&](int mbase) {
@@ -360,7 +361,7 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
                     ga_n[c][s] = buf_load_f32(rg, (m < m_hi && co < p.Cout) ? (unsigned)(m * p.Cout + co) * 4u : DLKA_OOB);
                 }
             } else if (N16) {   // 16 consecutive voxels of one plane, 64-byte aligned: four 16-byte loads
-                const unsigned off = (mrow0 < m_hi && co < p.Cout) ? (unsigned)((b0 * p.Cout + co) * p.N + v0) * 4u : DLKA_OOB;
+                const unsigned off = (mrow0 < m_hi && co < p.Cout) ? (unsigned)((b0 * gcp + co) * p.N + v0) * 4u : DLKA_OOB;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const f32x4 t4 = buf_load_f32x4(rg, off + 16u * e);
@@ -371,7 +372,7 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
                 for (int s = 0; s < 16; ++s) {
                     const int m = mrow0 + s;
                     const int b = m / p.N, v = m - b * p.N;
-                    ga_n[c][s] = buf_load_f32(rg, (m < m_hi && co < p.Cout) ? (unsigned)((b * p.Cout + co) * p.N + v) * 4u : DLKA_OOB);
+                    ga_n[c][s] = buf_load_f32(rg, (m < m_hi && co < p.Cout) ? (unsigned)((b * gcp + co) * p.N + v) * 4u : DLKA_OOB);
                 }
             }
         }
@@ -435,18 +436,27 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
 #pragma unroll
             for (int s = 0; s < 16; ++s) bv[t][s] = bv_n[t][s];
         if (mbase + 32 < m_hi) load_step(mbase + 32);   // in flight under the MFMAs below
+        const bool gpk = GMODE == 1 && SPLIT && p.g_cpad;   // uniform: g arrives as pack_split2() words
         if (want_bias) {
 #pragma unroll
             for (int c = 0; c < COT; ++c)
 #pragma unroll
-                for (int s = 0; s < 16; ++s) bsum[c] += ga[c][s];
+                for (int s = 0; s < 16; ++s) {
+                    if (gpk) {
+                        const unsigned u = __builtin_bit_cast(unsigned, ga[c][s]);
+                        bsum[c] += __builtin_bit_cast(float, u & 0xffff0000u) + __builtin_bit_cast(float, u << 16);
+                    } else bsum[c] += ga[c][s];
+                }
         }
         if (SPLIT) {
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) {   // k = rows 16h + 8mf + e
                 bf16x8 ahi[COT], alo[COT], bhi[TPW], blo[TPW];
 #pragma unroll
-                for (int c = 0; c < COT; ++c) split_bf16x8(ga[c] + 8 * mf, ahi[c], alo[c]);
+                for (int c = 0; c < COT; ++c) {
+                    if (gpk) unpack_split2x8(ga[c] + 8 * mf, ahi[c], alo[c]);
+                    else split_bf16x8(ga[c] + 8 * mf, ahi[c], alo[c]);
+                }
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) split_bf16x8(bv[t] + 8 * mf, bhi[t], blo[t]);
 #pragma unroll
@@ -616,6 +626,7 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
         dim3 grid(nchunks, cdiv(OT, pl.cot) * a.CT, cdiv(a.K, pl.tpw));
         static const bool exact = getenv("DLKA_EXACT_FP32") != nullptr;
         const bool split = !exact && a.K > 1;   // MFMA-bound contractions: bf16 x3 split (see cl_igemm.hip)
+        if (a.g_cpad && !((a.N & 15) == 0 && split && gmode == 1)) return DLKA_ERR_UNSUPPORTED;   // packed g: split + N16 variant only
 #define DLKA_WG(GM, CO, TP)                                                                                      \
     {                                                                                                            \
         if ((a.N & 15) == 0 && split) { auto k = cl_wgrad_dense_kernel<GM, CO, TP, true, true>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }  \

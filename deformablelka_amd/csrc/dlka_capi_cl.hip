@@ -119,7 +119,7 @@ int dense_forward(const SameConv &s, const float *x, const float *w, const float
 // ---- dense conv data gradient: gx = conv_transpose(gout) (+ epilogue) ---------------------------------------------
 // wp must hold K * round_up(Cout,32) * Cin floats.  gout channels-last needs Cout % 32 == 0; planar any Cout.
 int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, const float *w, float *gx, float *wp, int epi,
-                        const float *aux, hipStream_t st, const float *aux2 = nullptr, float *out2 = nullptr, bool zeroed = false)
+                        const float *aux, hipStream_t st, const float *aux2 = nullptr, float *out2 = nullptr, bool zeroed = false, bool g_packed = false)
 {
     const int KP = round_up(s.Cout, 32), NP = s.Cin;
     if (!nt_ok(NP) || s.Cin % 32) return DLKA_ERR_UNSUPPORTED;
@@ -132,6 +132,10 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
     a.pd = s.dd * (s.kd - 1) - s.pd; a.ph = s.dh * (s.kh - 1) - s.ph; a.pw = s.dw * (s.kw - 1) - s.pw;
     a.in = gout; a.wp = wp; a.bias = nullptr; a.out = gx; a.aux = aux; a.aux2 = aux2; a.out2 = out2; a.epi = epi; a.out_zeroed = zeroed ? 1 : 0;
     a.Cin = s.Cout; a.CinReal = s.Cout; a.CinP = KP; a.Cout = s.Cin; a.NP = NP;
+    if (g_packed) {   // gout = pack_split2() words, KP zero-padded channel planes per batch (DeformBwdArgs::goff_cpad)
+        if (!gout_planar || split != 2) return DLKA_ERR_UNSUPPORTED;
+        a.a_packed = 1; a.CinReal = KP;
+    }
     const int splits = dense_backward_data_splits(s, epi);
     return launch_cl_igemm(gout_planar ? 2 : 0, 0, a, splits, st);
 }
@@ -141,7 +145,7 @@ size_t dense_wp_floats(const SameConv &s) { return (size_t)s.K * round_up(s.Cin,
 
 // ---- dense conv weight gradient -----------------------------------------------------------------------------------
 int dense_backward_weight(const SameConv &s, const float *x, const float *gout, int gout_planar, float *gw, float *gb, float *part, hipStream_t st,
-                          FinalizeJob *defer = nullptr)
+                          FinalizeJob *defer = nullptr, int g_cpad = 0)
 {
     if (s.Cin % 32) return DLKA_ERR_UNSUPPORTED;
     if (s.K != 1 && s.K > 7 * 64) return DLKA_ERR_UNSUPPORTED;
@@ -151,6 +155,8 @@ int dense_backward_weight(const SameConv &s, const float *x, const float *gout, 
     a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.Cin = s.Cin; a.Cout = s.Cout;
     a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
     if (s.K == 1 && gout_planar) return DLKA_ERR_UNSUPPORTED;
+    if (g_cpad && (!gout_planar || s.K == 1)) return DLKA_ERR_UNSUPPORTED;
+    a.g_cpad = g_cpad;
     return launch_cl_wgrad<float>(0, gout_planar ? 1 : 0, a, gw, gb, st, defer);
 }
 
@@ -246,13 +252,13 @@ int deform_bwd_variant()
 
 int deform_backward(const SameConv &s, const float *x, const float *off, const float *w, const float *gout, float *gx, float *goff,
                     float *gw, float *gb, float *wp, float *part, float *scratch, hipStream_t st, FinalizeJob *defer = nullptr, bool gx_zeroed = false,
-                    bool goff_zeroed = false)
+                    bool goff_zeroed = false, int goff_cpad = 0)
 {
     if (gx || goff) {
         if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cout, s.Cin, 2, st));
         DeformBwdArgs a;
         fill_deform_bwd(a, s);
-        a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff; a.gx_zeroed = gx_zeroed ? 1 : 0; a.goff_zeroed = goff_zeroed ? 1 : 0;
+        a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff; a.gx_zeroed = gx_zeroed ? 1 : 0; a.goff_zeroed = goff_zeroed ? 1 : 0; a.goff_cpad = goff_cpad;
         const int variant = deform_bwd_variant();
         if (variant == 0) DLKA_TRY(launch_cl_deform_bwd2(a, scratch, st));
         else if (variant == 2 && s.N >= 512) DLKA_TRY(launch_cl_deform_bwd_lds(a, st));
@@ -282,7 +288,7 @@ SameConv block_conv(int B, int C, int Cout, int D, int H, int W, int k, int pad,
 
 struct TokGeoms {
     SameConv pw, dw5, dw7, offc, dcn;
-    size_t E, Off;
+    size_t E, Off, GOff;   // GOff: the backward's internal grad_offset buffer, 96 channel planes per batch (packed layout, DeformBwdArgs::goff_cpad)
     TokGeoms(int B, int C, int D, int H, int W)
     {
         pw = block_conv(B, C, C, D, H, W, 1, 0, 1, 1);
@@ -292,6 +298,7 @@ struct TokGeoms {
         dcn = block_conv(B, C, C, D, H, W, 3, 1, 1, 1);
         E = (size_t)B * C * D * H * W;
         Off = (size_t)B * 81 * D * H * W;
+        GOff = (size_t)B * 96 * D * H * W;
     }
     size_t wp_floats() const
     {
@@ -530,7 +537,7 @@ size_t dlka_lka3d_tokens_workspace_bytes(int B, int C, int D, int H, int W, int 
 {
     if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return 0;
     TokGeoms G(B, C, D, H, W);
-    return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 8 * align256(G.E * 4) + align256(G.Off * 4) +
+    return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 8 * align256(G.E * 4) + align256(G.GOff * 4) +
            align256(G.scratch_floats() * 4) + align256(4096);
 }
 
@@ -600,7 +607,7 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     // every intermediate gradient has its own buffer: the weight-gradient stream reads them while the data-gradient chain moves on
     float *gg1 = (float *)cv.take(G.E * 4), *ga1 = (float *)cv.take(G.E * 4), *gf = (float *)cv.take(G.E * 4), *gta = (float *)cv.take(G.E * 4);
     float *gt = (float *)cv.take(G.E * 4), *gt1 = (float *)cv.take(G.E * 4), *ga2 = (float *)cv.take(G.E * 4), *gh = (float *)cv.take(G.E * 4);
-    float *goff = (float *)cv.take(G.Off * 4);
+    float *goff = (float *)cv.take(G.GOff * 4);
     float *scratch = (float *)cv.take(G.scratch_floats() * 4);
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const float *x = (const float *)x_, *gy = (const float *)gy_;
@@ -632,10 +639,20 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     memset(&zb, 0, sizeof(zb));
     zb.add(stage5, G.stage_dw());
     zb.add(gta, G.E);
+    // grad_offset has ONE producer and two 27-tap consumers that contract it on the bf16 matrix cores (offset conv data / weight gradient):
+    // the producer stores it already split (pack_split2 words, 96 channel planes) unless its channel-sliced variant needs fp32 atomics
+    int goff_cpad = 0;
     {
         DeformBwdArgs da;
         fill_deform_bwd(da, G.dcn);
-        if (deform_bwd_variant() == 0 && cl_deform_goff_ccsplit(da) > 1) zb.add(goff, G.Off);
+        // Measured with the workgroup-tiled consumers (profiles/r01v): no gain — they are bound by per-unit latency (barrier + staging per
+        // 192 MFMA cycles), not by the split arithmetic (grad_offset +14 us, weight gradient +18 us, data gradient unchanged at 32^3) — so the
+        // packed hand-over is opt-in (DLKA_GOFF_PACKED=1) until the consumers are wave-granular.
+        const bool fp32_goff = getenv("DLKA_GOFF_PACKED") == nullptr;   // (not cached: tests toggle it)
+        const bool sliced = deform_bwd_variant() == 0 && cl_deform_goff_ccsplit(da) > 1;
+        if (sliced) zb.add(goff, G.Off);
+        // (N % 16: the weight-gradient kernel's split variant exists for 16-voxel-aligned volumes only, cl_wgrad.hip)
+        else if (!fp32_goff && deform_bwd_variant() == 0 && use_split(G.offc, false) == 2 && (G.offc.N & 15) == 0) goff_cpad = 96;
     }
     if (dense_backward_data_splits(G.pw, 0) > 1) zb.add(gf, G.E);
     if (dense_backward_data_splits(G.offc, 3) > 1) zb.add(gt, G.E);
@@ -654,12 +671,12 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     // deformable conv:  f = DCN(t, off):  weight gradient on the side stream, grad_offset and grad_input on the main one
     DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
                              &fb.j[fb.njobs++]));
-    DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, goff, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, false, true));
+    DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, goff, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, false, true, goff_cpad));
     DLKA_TRY(publish());
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
-    DLKA_TRY(dense_backward_weight(G.offc, t, goff, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, ws_, &fb.j[fb.njobs++]));
+    DLKA_TRY(dense_backward_weight(G.offc, t, goff, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, ws_, &fb.j[fb.njobs++], goff_cpad));
     DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, true));
-    DLKA_TRY(dense_backward_data(G.offc, goff, 1, N0, gt, PW.off_b, 3, gta, st, nullptr, nullptr, true));
+    DLKA_TRY(dense_backward_data(G.offc, goff, 1, N0, gt, PW.off_b, 3, gta, st, nullptr, nullptr, true, goff_cpad != 0));
     DLKA_TRY(publish());
     // depthwise 7^3 dil 3:  t = DW7 t1
     DLKA_TRY(dw_backward_weight(G.dw7, t1, gt, (float *)gr->conv_spatial_w, (float *)gr->conv_spatial_b, stage7, ws_, &fb.j[fb.njobs++]));

@@ -61,6 +61,24 @@ __device__ __forceinline__ f32x4 buf_load_f32x4(BufRsrc r, unsigned off)
     for (int e = 0; e < 4; ++e) v[e] = buf_load_f32(r, off + 4u * e);
     return v;
 }
+// voff: per-lane byte offset (range-checked: DLKA_OOB -> 0); soff: wave-uniform byte offset added on top (NOT range-checked by the
+// hardware, so voff + soff must stay inside the buffer by construction)
+__device__ __forceinline__ float buf_load_f32_s(BufRsrc r, unsigned voff, unsigned soff)
+{
+    if (!(voff < r.bytes)) return 0.f;
+    return buf_load_f32(r, voff + soff);
+}
+// two-term bf16 split packed in one word: hi << 16 | lo
+__device__ __forceinline__ float pack_split2(float x)
+{
+    const unsigned short hi = hipemu::hipemu_f32_to_bf16(x), lo = hipemu::hipemu_f32_to_bf16(x - hipemu::hipemu_bf16_to_f32(hi));
+    const unsigned u = ((unsigned)hi << 16) | lo;
+    float f; memcpy(&f, &u, 4); return f;
+}
+__device__ __forceinline__ void unpack_split2x8(const float *w, bf16x8 &hi, bf16x8 &lo)
+{
+    for (int e = 0; e < 8; ++e) { unsigned u; memcpy(&u, w + e, 4); hi.v[e] = (unsigned short)(u >> 16); lo.v[e] = (unsigned short)(u & 0xffffu); }
+}
 #else
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -118,6 +136,33 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void *p, size_t bytes)
 }
 __device__ __forceinline__ float buf_load_f32(BufRsrc r, unsigned off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); }
 __device__ __forceinline__ f32x4 buf_load_f32x4(BufRsrc r, unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); }
+// voff: per-lane byte offset (range-checked: DLKA_OOB -> 0); soff: wave-uniform byte offset (SGPR) added on top — not part of the hardware
+// range check, so voff + soff must stay inside the buffer by construction.  Saves the per-load VALU address add.
+__device__ __forceinline__ float buf_load_f32_s(BufRsrc r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+// two-term bf16 split packed in one word (hi << 16 | lo): the producer splits ONCE, consumers that contract the value many times (27 taps)
+// rebuild their MFMA operands with one v_perm per pair instead of ~5 VALU instructions per value per use
+__device__ __forceinline__ float pack_split2(float x)
+{
+    const __bf16 hi = (__bf16)x;
+    const __bf16 lo = (__bf16)(x - (float)hi);
+    return __builtin_bit_cast(float, ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16) | (unsigned)__builtin_bit_cast(unsigned short, lo));
+}
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void unpack_split2x8(const float *w, bf16x8 &hi, bf16x8 &lo)
+{
+    u32x4_t h4, l4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned w0 = __builtin_bit_cast(unsigned, w[2 * q]), w1 = __builtin_bit_cast(unsigned, w[2 * q + 1]);
+        h4[q] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);   // {w1.hi16, w0.hi16}
+        l4[q] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);   // {w1.lo16, w0.lo16}
+    }
+    hi = __builtin_bit_cast(bf16x8, h4);
+    lo = __builtin_bit_cast(bf16x8, l4);
+}
 #define DLKA_DYN_SMEM(type, name)                                             \
     extern __shared__ __attribute__((aligned(16))) unsigned char dlka_dyn_lds[]; \
     type *name = reinterpret_cast<type *>(dlka_dyn_lds)

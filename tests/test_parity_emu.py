@@ -115,6 +115,17 @@ def test_lka3d_tokens_block():
     parity.check_lka3d_tokens("cpu", 1, 32, (3, 4, 5))
 
 
+def test_lka3d_tokens_block_n16():
+    """N % 16 == 0 selects the pre-split (packed bf16 hi|lo) grad_offset hand-over between the deformable backward and the
+    offset conv's data / weight gradients."""
+    import os
+    os.environ["DLKA_GOFF_PACKED"] = "1"
+    try:
+        parity.check_lka3d_tokens("cpu", 1, 32, (4, 4, 4))
+    finally:
+        del os.environ["DLKA_GOFF_PACKED"]
+
+
 @pytest.mark.parametrize("case", [(1, 32, 32, (8, 8, 8), "normal"), (2, 32, 32, (9, 8, 10), "wild"), (1, 32, 32, (8, 9, 8), "integer")])
 def test_deform3d_cl_lds_window(case):
     """N >= 512 selects the LDS-window backward (bricks, halo overflow to global atomics, partial bricks)."""
