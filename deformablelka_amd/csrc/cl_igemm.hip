@@ -16,87 +16,12 @@
 // blockIdx.y and accumulating with fp32 atomics.
 #include <stdlib.h>
 
-#include "deform_sample.h"
-#include "cl_args.h"
+#include "cl_arow.h"
 #include "dlka_kernels.h"
 
 namespace dlka {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-
-// Fetches this lane's 16 A values (channels ck*32 + 16*h + [0,16) of row m) for one (tap, chunk) unit.
-// Every load is an unconditional buffer load: zero padding, rows beyond M and corners outside the volume read offset
-// DLKA_OOB and come back as 0, so there is no branch around a load and the loads of unit u+1 stay in flight under
-// the MFMAs of unit u.
-template <int AMODE>
-struct ARow {
-    int cur_tap;
-    unsigned rowoff;     // AMODE 0: byte offset of the neighbour row; AMODE 2: of the neighbour voxel in plane 0; DLKA_OOB if padded
-    unsigned coff[8];    // AMODE 1: byte offsets of the 8 corner rows (DLKA_OOB for dropped corners)
-    float cw[8];         // AMODE 1: corner weights
-    __device__ __forceinline__ ARow() : cur_tap(-1), rowoff(DLKA_OOB) {}
-
-    __device__ __forceinline__ void fetch(const IgemmArgs &p, const BufRsrc &rin, int tap, int ck, int h, bool row_ok, int b, int v, int d0, int h0, int w0, float *a)
-    {
-        if (tap != cur_tap) {   // wave-uniform
-            cur_tap = tap;
-            const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
-            if (AMODE == 0 || AMODE == 2) {
-                const int zd = d0 + ti * p.dd - p.pd, zh = h0 + tj * p.dh - p.ph, zw = w0 + tk * p.dw - p.pw;
-                const bool ok = row_ok & ((unsigned)zd < (unsigned)p.D) & ((unsigned)zh < (unsigned)p.H) & ((unsigned)zw < (unsigned)p.W);
-                const int lin = (zd * p.H + zh) * p.W + zw;
-                rowoff = !ok ? DLKA_OOB : (AMODE == 0 ? (unsigned)((b * p.N + lin) * p.Cin) * 4u : (unsigned)(b * p.CinReal * p.N + lin) * 4u);
-            } else {
-                TapSample<3> s;
-                if (row_ok) {
-                    const float *offp = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
-                    setup_tap<3>(s, offp, p.N, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw, p.D, p.H, p.W);
-                } else {
-                    s.ok = 0;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { s.idx[q] = 0; s.w[q] = 0.f; }
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    coff[q] = ((s.ok >> q) & 1u) ? (unsigned)((b * p.N + s.idx[q]) * p.Cin) * 4u : DLKA_OOB;
-                    cw[q] = s.w[q];
-                }
-            }
-        }
-        const int c0 = ck * 32 + 16 * h;
-        if (AMODE == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x4 t = buf_load_f32x4(rin, rowoff + (unsigned)(c0 + 4 * e) * 4u);
-                a[4 * e] = t[0]; a[4 * e + 1] = t[1]; a[4 * e + 2] = t[2]; a[4 * e + 3] = t[3];
-            }
-        } else if (AMODE == 2) {
-            if (p.a_packed) {   // uniform: all CinP planes exist (zero padded): one per-lane offset, the plane stride rides in the scalar offset
-                const unsigned vo = rowoff == DLKA_OOB ? DLKA_OOB : rowoff + (unsigned)(16 * h * p.N) * 4u;
-                const unsigned so = (unsigned)(ck * 32 * p.N) * 4u, ps = (unsigned)p.N * 4u;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) a[e] = buf_load_f32_s(rin, vo, so + (unsigned)e * ps);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    a[e] = buf_load_f32(rin, (c0 + e < p.CinReal) ? rowoff + (unsigned)((c0 + e) * p.N) * 4u : DLKA_OOB);
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) a[e] = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {   // dropped corners (outside the volume / the guard) read 0 with weight 0
-                const float wq = cw[q];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const f32x4 t = buf_load_f32x4(rin, coff[q] + (unsigned)(c0 + 4 * e) * 4u);
-                    a[4 * e] = fmaf(wq, t[0], a[4 * e]); a[4 * e + 1] = fmaf(wq, t[1], a[4 * e + 1]);
-                    a[4 * e + 2] = fmaf(wq, t[2], a[4 * e + 2]); a[4 * e + 3] = fmaf(wq, t[3], a[4 * e + 3]);
-                }
-            }
-        }
-    }
-};
 
 // SPLIT: the contraction runs on the bf16 matrix cores with two-term split operands (dlka_intrin.h: hi*hi + hi*lo + lo*hi,
 // fp32 accumulation, ~1e-5 relative) instead of the exact fp32-input MFMA: 6 x 32 cycles per 32-channel unit and column tile
@@ -431,6 +356,10 @@ int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t s
         if (launch_zero(a.out, (size_t)n * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
     }
     if (a.split_bf16) {   // bf16 x3 split contraction (the prepared weights must be in the split layout)
+        {   // wave-granular variant first (no LDS staging, no barriers); the zero fill for split partial sums was done above
+            const int rc = launch_cl_conv_wave(amode, omode, a, splits, st);
+            if (rc != DLKA_ERR_UNSUPPORTED) return rc;
+        }
         if (a.split_bf16 == 3) {
             if (amode == 0 && omode == 1) return launch_igemm_nt<0, 1, 3>(a, splits, st);
             if (amode == 0 && omode == 0) return launch_igemm_nt<0, 0, 3>(a, splits, st);

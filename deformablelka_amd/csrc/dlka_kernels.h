@@ -50,6 +50,7 @@ int launch_cl_prep_weight(const float *w, float *wp, int Cout, int Cin, int K, i
 int launch_cl_prep_batch(const PrepBatch &b, hipStream_t st);
 int cl_igemm_pick_splits(int M, int units, int epi, int K);
 int launch_cl_pointwise(const IgemmArgs &a, hipStream_t st);
+int launch_cl_conv_wave(int amode, int omode, const IgemmArgs &a, int splits, hipStream_t st);
 int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t st);
 int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st);
 int cl_wgrad_pick_chunks(int M, int K, int Cout, int Cin, int amode);
