@@ -397,8 +397,19 @@ struct GxGeom {
     int nslices;            // C / CS
     int ngroups;            // ceil(K / TG)
     int resident;           // all tap groups' weight tiles fit in LDS next to the window
+    int tap_far;            // 1: half-waves take taps 16 apart (K <= 32 = 4 groups of 8), see gx_tap()
     int ablate;             // profiling only (DLKA_GX_ABL): 1 = no LDS atomics, 2 = no sampling description / scatter at all
 };
+
+// MFMA row t8 of tap group grp <-> tap.  The two half-waves scatter rows t8 = 2*r4 and 2*r4 + 1 in the same instruction; with consecutive
+// taps there (tk, tk + 1) lane (j, 1) and lane (j + 1, 0) aim at the SAME window cell whenever their offsets floor alike — the
+// "consecutive + 0/1 jitter" pattern that costs 21 instead of 9.4 cycles per ds_add_f64 in isolation (profiles/r01e_lds_f64_patterns.txt).
+// tap_far pairs tap x with tap x + 16 instead (another d-plane of the window).  In the real kernel it did NOT pay (390 vs 370 us at 32^3):
+// the LDS unit serves the half-waves in separate passes, and neighbouring taps share offset / window cache lines.  Kept as an A/B knob.
+__device__ __host__ __forceinline__ int gx_tap(int grp, int t8, int tap_far)
+{
+    return tap_far ? (t8 & 1) * 16 + grp * 4 + (t8 >> 1) : grp * TG + t8;
+}
 
 __device__ __host__ __forceinline__ void gx_window(int b0, int bsz, int size, int &lo, int &len)
 {
@@ -436,7 +447,7 @@ __global__ __launch_bounds__(512) void cl_deform_gx_kernel(DeformBwdArgs p, GxGe
     // A operand tile of group grp: Bs[co][t8*4 + c4] = W[co][slice*4 + c4][tap = grp*8 + t8]   (wp[tap][co][ci], zero beyond K)
     auto stage_weights = [&](int grp, float *dstB) {
         for (int e = tid; e < p.CoutP * TG; e += blockDim.x) {
-            const int co = e / TG, t8 = e - co * TG, tap = grp * TG + t8;
+            const int co = e / TG, t8 = e - co * TG, tap = gx_tap(grp, t8, gg.tap_far);
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
             if (tap < p.K) val = *reinterpret_cast<const f32x4 *>(p.wp + ((long)tap * p.CoutP + co) * p.C + slice * CS);
             reinterpret_cast<f32x4 *>(dstB)[e] = val;
@@ -497,7 +508,7 @@ __global__ __launch_bounds__(512) void cl_deform_gx_kernel(DeformBwdArgs p, GxGe
             // juggling per corner.  Corners inside the volume but outside the window (rare: |offset| > HALO) take global atomics.
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            const int tap = grp * TG + 2 * r4 + h;
+            const int tap = gx_tap(grp, 2 * r4 + h, gg.tap_far);
             if (!ok || tap >= p.K) continue;
             int ti, tj, tk;
             if (p.kw == 3 && p.kh == 3) { ti = tap / 9; const int rr = tap - 9 * ti; tj = rr / 3; tk = rr - 3 * tj; }   // uniform
@@ -709,6 +720,8 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         gl_.resident = (lds_all <= 150 * 1024 && a.CoutP <= 128) ? 1 : 0;
         static const int abl = getenv("DLKA_GX_ABL") ? atoi(getenv("DLKA_GX_ABL")) : 0;
         gl_.ablate = abl;
+        static const bool far_taps = getenv("DLKA_GX_TAP_FAR") != nullptr;   // A/B switch (measured: 390 vs 370 us at 32^3 — slower, stays off)
+        gl_.tap_far = (far_taps && g.ngroups == 4) ? 1 : 0;
         const size_t lds = gl_.resident ? lds_all : lds_win + (size_t)a.CoutP * 32 * sizeof(float);
         if (lds > 160 * 1024) return DLKA_ERR_UNSUPPORTED;
 #if !defined(HIPEMU)
