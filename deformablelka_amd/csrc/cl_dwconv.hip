@@ -77,6 +77,152 @@ __global__ __launch_bounds__(256) void cl_dwconv_kernel(DwArgs p)
         if (w0 + t < p.W) op[(long)t * p.C] = acc[t];
 }
 
+// Second generation of the forward / data-gradient kernel.  Same tiling; what changes is how the input row segment is read.  The first
+// version's `(zw >= 0 && zw < W) ? row[zw * C] : 0` compiled to a branch, a 64-bit address computation and a wait PER LOAD (~14
+// instructions for each of the 26 loads of a 7-tap dil-3 row, against 56 FMAs).  Here the (b, d, h) of a wave's outputs is wave-uniform
+// (the launcher checks it), so every input row gets its own buffer descriptor built by the scalar unit: base = the row, size = W*C*4
+// bytes.  The per-lane offset ((w0 - pw + e)*C + c)*4 then needs no bounds code at all — left of the row it is "negative" (huge as
+// unsigned), right of it >= the size, and the hardware range check returns 0 for both.  One v_add + one buffer_load per element; rows
+// outside the volume are skipped by scalar branches; the tap weights come through the scalar offset.
+template <int KW, int DIL, int TW>
+__global__ __launch_bounds__(256) void cl_dwconv_rows_kernel(DwArgs p)
+{
+    constexpr int SEG = TW + (KW - 1) * DIL;
+    const int cpb = p.C < 256 ? p.C : 256;
+    const int rpb = 256 / cpb;
+    const int c = blockIdx.z * cpb + threadIdx.x % cpb;
+    const int run = blockIdx.x * rpb + threadIdx.x / cpb;
+    const int runs_per_row = cdiv(p.W, TW);
+    const int rows = p.B * p.D * p.H;
+    if (run >= rows * runs_per_row || c >= p.C) return;
+    const int w0 = (run % runs_per_row) * TW;
+    const int row = wave_uniform(run / runs_per_row);
+    const int h0 = row % p.H, d0 = (row / p.H) % p.D, b = row / (p.H * p.D);
+
+    float acc[TW];
+    const float bv = p.bias ? p.bias[c] : 0.f;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) acc[t] = bv;
+
+    const int cb = p.C * 4;                                  // bytes per voxel
+    const unsigned rowbytes = (unsigned)(p.W * cb);
+    const int vbase = (w0 - p.pw) * cb + c * 4;              // byte offset of segment element 0 inside the row (may be negative)
+    const BufRsrc rwt = make_rsrc(p.wp, (size_t)p.kd * p.kh * KW * cb);
+    const unsigned cv = (unsigned)c * 4u;
+    for (int i = 0; i < p.kd; ++i) {
+        const int zd = d0 + i * p.dd - p.pd;
+        if (zd < 0 || zd >= p.D) continue;                   // scalar
+        for (int j = 0; j < p.kh; ++j) {
+            const int zh = h0 + j * p.dh - p.ph;
+            if (zh < 0 || zh >= p.H) continue;               // scalar
+            const BufRsrc rr = make_rsrc(p.in + ((long)(b * p.D + zd) * p.H + zh) * p.W * p.C, rowbytes);
+            float seg[SEG];
+#pragma unroll
+            for (int e = 0; e < SEG; ++e) seg[e] = buf_load_f32(rr, (unsigned)(vbase + e * cb));
+            const unsigned ws = (unsigned)((i * p.kh + j) * KW) * (unsigned)cb;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const float wv = buf_load_f32_s(rwt, cv, ws + (unsigned)(k * cb));
+#pragma unroll
+                for (int t = 0; t < TW; ++t) acc[t] = fmaf(wv, seg[t + k * DIL], acc[t]);
+            }
+        }
+    }
+    const long obase = (((long)(b * p.D + d0) * p.H + h0) * p.W + w0) * p.C + c;
+    float *op = p.out + obase;
+    if (p.gelu_x) {   // uniform: a = GELU(h) feeds dw 5^3 and the gate, so gh = (ga_gate + ga_dw5) * gelu'(h) closes here
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+            if (w0 + t < p.W) op[(long)t * p.C] = (acc[t] + p.gelu_add[obase + (long)t * p.C]) * dgelu_f(p.gelu_x[obase + (long)t * p.C]);
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+        if (w0 + t < p.W) op[(long)t * p.C] = acc[t];
+}
+
+// ... and with TWO output rows per work-item, h0 and h0 + DIL: with the loads lean, the kernel sits on the L1 return path (one 256-byte
+// wave load per segment element: 1.7 GB per launch at 32^3 for 7^3 dil 3), and output rows DIL apart share KH - 1 of their KH input
+// rows — KH + 1 segment loads per tap plane feed 2 KH row products.  The tap plane's KH*KW weights sit in registers for both.
+template <int KW, int DIL, int TW>
+__global__ __launch_bounds__(256) void cl_dwconv_rows2_kernel(DwArgs p)
+{
+    constexpr int KH = KW;
+    constexpr int SEG = TW + (KW - 1) * DIL;
+    const int cpb = p.C < 256 ? p.C : 256;
+    const int rpb = 256 / cpb;
+    const int c = blockIdx.z * cpb + threadIdx.x % cpb;
+    const int run = blockIdx.x * rpb + threadIdx.x / cpb;
+    const int runs_per_row = cdiv(p.W, TW);
+    const int groups = DIL * cdiv(p.H, 2 * DIL);             // row pairs per (b, d) plane: h0 = r + 2*DIL*q, r < DIL
+    const long total = (long)p.B * p.D * groups * runs_per_row;
+    if (run >= total || c >= p.C) return;
+    const int w0 = (run % runs_per_row) * TW;
+    const int gidx = wave_uniform(run / runs_per_row);
+    const int grp = gidx % groups, d0 = (gidx / groups) % p.D, b = gidx / (groups * p.D);
+    const int h0 = (grp % DIL) + (grp / DIL) * 2 * DIL;
+    if (h0 >= p.H) return;                                   // scalar
+    const bool two = h0 + DIL < p.H;                         // scalar: the second output row exists
+
+    float acc0[TW], acc1[TW];
+    const float bv = p.bias ? p.bias[c] : 0.f;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) { acc0[t] = bv; acc1[t] = bv; }
+
+    const int cb = p.C * 4;
+    const unsigned rowbytes = (unsigned)(p.W * cb);
+    const int vbase = (w0 - p.pw) * cb + c * 4;
+    const BufRsrc rwt = make_rsrc(p.wp, (size_t)p.kd * KH * KW * cb);
+    const unsigned cv = (unsigned)c * 4u;
+    for (int i = 0; i < p.kd; ++i) {
+        const int zd = d0 + i * p.dd - p.pd;
+        if (zd < 0 || zd >= p.D) continue;                   // scalar
+        float wv[KH][KW];
+#pragma unroll
+        for (int j = 0; j < KH; ++j)
+#pragma unroll
+            for (int k = 0; k < KW; ++k) wv[j][k] = buf_load_f32_s(rwt, cv, (unsigned)(((i * KH + j) * KW + k) * cb));
+        const float *plane = p.in + ((long)(b * p.D + zd) * p.H) * p.W * p.C;
+#pragma unroll
+        for (int r = 0; r <= KH; ++r) {                      // input row h0 - ph + r*DIL: tap row r of output 0, r - 1 of output 1
+            const int zh = h0 - p.ph + r * DIL;
+            if (zh < 0 || zh >= p.H) continue;               // scalar
+            const BufRsrc rr = make_rsrc(plane + (long)zh * p.W * p.C, rowbytes);
+            float seg[SEG];
+#pragma unroll
+            for (int e = 0; e < SEG; ++e) seg[e] = buf_load_f32(rr, (unsigned)(vbase + e * cb));
+            if (r < KH) {
+#pragma unroll
+                for (int k = 0; k < KW; ++k)
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) acc0[t] = fmaf(wv[r][k], seg[t + k * DIL], acc0[t]);
+            }
+            if (r >= 1) {
+#pragma unroll
+                for (int k = 0; k < KW; ++k)
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) acc1[t] = fmaf(wv[r - 1][k], seg[t + k * DIL], acc1[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        if (o == 1 && !two) break;
+        const long obase = (((long)(b * p.D + d0) * p.H + h0 + o * DIL) * p.W + w0) * p.C + c;
+        float *op = p.out + obase;
+        const float *acc = o ? acc1 : acc0;
+        if (p.gelu_x) {
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+                if (w0 + t < p.W) op[(long)t * p.C] = (acc[t] + p.gelu_add[obase + (long)t * p.C]) * dgelu_f(p.gelu_x[obase + (long)t * p.C]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+                if (w0 + t < p.W) op[(long)t * p.C] = acc[t];
+        }
+    }
+}
+
 // reference layout W[c][1][kd][kh][kw] -> Wp[tap][c]; flip = 1 reverses the taps (data gradient)
 __global__ void cl_dw_prep_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int C, int K, int flip)
 {
@@ -102,6 +248,31 @@ int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st)
     const long runs = (long)a.B * a.D * a.H * cdiv(a.W, TW);
     dim3 grid((unsigned)cdivl(runs, rpb), 1, cdiv(a.C, cpb)), block(256);
     if (256 % cpb != 0) return DLKA_ERR_UNSUPPORTED;
+    static const bool v1 = getenv("DLKA_DW_V1") != nullptr;   // A/B switch: first generation (conditional global loads)
+    static const int abl0 = getenv("DLKA_DW_ABL") ? atoi(getenv("DLKA_DW_ABL")) : 0;
+    // the rows kernel needs (b, d, h) uniform per wave: the 64 / cpb runs of a wave must not straddle two rows
+    const int wpr = cpb < 64 ? 64 / cpb : 1;
+    if (!v1 && !abl0 && cdiv(a.W, TW) % wpr == 0 && (long)a.W * a.C * 4 < (1l << 31)) {
+        static const int th_env = getenv("DLKA_DW_TH") ? atoi(getenv("DLKA_DW_TH")) : 0;   // tuning knob: 1 / 2 output rows per work-item
+        const bool cubic = a.kd == kw && a.kh == kw && a.dd == dil_w && a.dh == dil_w;
+        const int th = th_env ? th_env : 2;
+        if (th == 2 && cubic && a.H >= 2 * dil_w && ((kw == 7 && dil_w == 3) || (kw == 5 && dil_w == 1))) {
+            const long runs2 = (long)a.B * a.D * dil_w * cdiv(a.H, 2 * dil_w) * cdiv(a.W, TW);
+            dim3 grid2((unsigned)cdivl(runs2, rpb), 1, cdiv(a.C, cpb));
+            if (kw == 7) { auto k = cl_dwconv_rows2_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid2, block, 0, st, a); }
+            else { auto k = cl_dwconv_rows2_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid2, block, 0, st, a); }
+            DLKA_CHECK_LAUNCH();
+            return DLKA_OK;
+        }
+        bool done = true;
+        if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_rows_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<3, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_rows_kernel<5, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<7, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else done = false;
+        if (done) { DLKA_CHECK_LAUNCH(); return DLKA_OK; }
+    }
     if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
     else if (kw == 7 && dil_w == 3) {
         static const int abl = getenv("DLKA_DW_ABL") ? atoi(getenv("DLKA_DW_ABL")) : 0;   // profiling ablation only
@@ -232,29 +403,32 @@ __global__ __launch_bounds__(256) void cl_dwconv_wgrad2_kernel(DwWgradArgs p)
     const int doff = i * p.dd - p.pd;
     const bool bias_slice = p.gb && doff == 0;   // uniform per block
     if (c < p.C) {
+        // every load is a buffer load against a descriptor of ONE row (built by the scalar unit: the rows of a wave's runs are
+        // wave-uniform, the launcher checks it): no bounds code per element, see cl_dwconv_rows_kernel
+        const int cb = p.C * 4;
+        const unsigned rowbytes = (unsigned)(p.W * cb);
         for (long run = run_lo + rsub; run < run_hi; run += rpb) {
             const int w0 = (int)(run % runs_per_row) * TW;
-            const int row = (int)(run / runs_per_row);
+            const int row = wave_uniform((int)(run / runs_per_row));
             const int zh = row % p.H, zd = (row / p.H) % p.D, b = row / (p.H * p.D);
             const int d0 = zd - doff;
-            if (d0 < 0 || d0 >= p.D) continue;
-            const float *rowp = p.in + (((long)(b * p.D + zd) * p.H + zh) * p.W) * p.C + c;
+            if (d0 < 0 || d0 >= p.D) continue;   // scalar
+            const BufRsrc rx = make_rsrc(p.in + (((long)(b * p.D + zd) * p.H + zh) * p.W) * p.C, rowbytes);
+            const int vbase = (w0 - p.pw) * cb + c * 4;
             float seg[SEG];
 #pragma unroll
-            for (int e = 0; e < SEG; ++e) {
-                const int zw = w0 - p.pw + e;
-                seg[e] = (zw >= 0 && zw < p.W) ? rowp[(long)zw * p.C] : 0.f;
-            }
-            const float *gplane = p.g + ((long)(b * p.D + d0) * p.H * p.W + w0) * p.C + c;
+            for (int e = 0; e < SEG; ++e) seg[e] = buf_load_f32(rx, (unsigned)(vbase + e * cb));
+            const float *gplane = p.g + ((long)(b * p.D + d0) * p.H * p.W) * p.C;
+            const unsigned gbase = (unsigned)(w0 * cb + c * 4);
 #pragma unroll
             for (int j = 0; j < KH; ++j) {
                 const int hoff = j * p.dh - p.ph;
                 const int h0 = zh - hoff;
-                if (h0 < 0 || h0 >= p.H) continue;
-                const float *gp = gplane + (long)h0 * p.W * p.C;
+                if (h0 < 0 || h0 >= p.H) continue;   // scalar
+                const BufRsrc rg = make_rsrc(gplane + (long)h0 * p.W * p.C, rowbytes);
                 float gv[TW];
 #pragma unroll
-                for (int t = 0; t < TW; ++t) gv[t] = (w0 + t < p.W) ? gp[(long)t * p.C] : 0.f;
+                for (int t = 0; t < TW; ++t) gv[t] = buf_load_f32(rg, gbase + (unsigned)(t * cb));   // w0 + t >= W: beyond the row -> 0
                 if (bias_slice && hoff == 0) {
 #pragma unroll
                     for (int t = 0; t < TW; ++t) bsum += gv[t];
@@ -317,8 +491,12 @@ int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st, boo
     // the centre tap row must exist for the bias ride-along (odd kernels with "same" padding: always)
     const bool centre = (a.pd % a.dd == 0) && (a.ph % a.dh == 0) && a.pd / a.dd < a.kd && a.ph / a.dh < a.kh;
     // measured (profiles/r01o_dw_variants.txt): 7^3 dil 3 178 -> 103 us at 32^3, 38 -> 36 us at 16^3; 5^3 72 -> 66 us at 32^3 but 23.5 -> 26 us at 16^3
-    const bool pays = kw >= 7 || rows >= 1024;
-    if (!v1 && pays && a.kd == kw && a.kh == kw && a.dd == dil_w && a.dh == dil_w && (centre || !a.gb)) {
+    // with row descriptors (profiles/r01y_dww_rows.txt, us, new vs first generation): 7^3 dil 3: 55 vs 188 at 32^3, 31 vs 39 at 16^3, 22 vs 18 at 8^3;
+    // 5^3: 38 vs 69 at 32^3, equal below
+    const bool pays = kw >= 7 ? rows >= 512 : rows >= 1024;
+    const int wpr = cpb < 64 ? 64 / cpb : 1;                       // runs per wave: must not straddle rows (row descriptors)
+    const bool uniform = cdiv(a.W, TW) % wpr == 0 && (long)a.W * a.C * 4 < (1l << 31);
+    if (!v1 && pays && uniform && a.kd == kw && a.kh == kw && a.dd == dil_w && a.dh == dil_w && (centre || !a.gb)) {
         dim3 grid2(xb, a.kd, cdiv(a.C, cpb));
         if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
         else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_wgrad2_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }

@@ -38,6 +38,8 @@ __device__ __forceinline__ float bf16_value(unsigned short h) { return hipemu::h
 // lanes of one wave exchange data through LDS without a workgroup barrier: on the GPU the wave executes in lockstep and
 // LDS operations retire in program order; the emulator runs lanes as fibers and needs a rendezvous
 __device__ __forceinline__ void wave_sync() { (void)hipemu::shfl_any(0, 0); }
+// a value the caller guarantees to be equal in all active lanes of the wave (moves it to a scalar register on the GPU)
+__device__ __forceinline__ int wave_uniform(int x) { return x; }
 // sum over the 8 lanes that share lane >> 3 (result in all 8)
 __device__ __forceinline__ float sum8(float x)
 {
@@ -120,6 +122,9 @@ __device__ __forceinline__ float bf16_value(unsigned short h) { return __builtin
 // around it, no select after it, and the loads of the next tile stay in flight under the MFMAs of the current one
 // (a conditional load compiles to s_cbranch + s_waitcnt vmcnt(0) per element; measured in profiles/r01g).
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// a value the caller guarantees to be equal in all active lanes of the wave: into a scalar register, so that pointers / buffer
+// descriptors derived from it are built by the scalar unit
+__device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 // sum over the 8 lanes that share lane >> 3 (result in all 8): three DPP adds, no LDS traffic
 // quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141 (lane k <-> 7-k inside each 8)
 __device__ __forceinline__ float sum8(float x)
