@@ -35,6 +35,7 @@ struct WgradArgs {
     int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
     int rows_per_chunk;  // multiple of 32
     int CT;              // Cin / 32
+    int w16;             // set by the launcher: W % 16 == 0 (fast row addressing in cl_wgrad_dense_kernel)
     int g_cpad;          // GMODE 1 only, > 0: g holds pack_split2() words with g_cpad channel planes per batch (see DeformBwdArgs::goff_cpad)
 };
 

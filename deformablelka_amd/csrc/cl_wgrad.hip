@@ -382,6 +382,29 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
                 const int m = mrow0 + s;
                 bv_n[0][s] = buf_load_f32(rx, (m < m_hi) ? (unsigned)(m * p.Cin + ci) * 4u : DLKA_OOB);
             }
+        } else if (N16 && p.w16 && p.kw == 3 && p.dw == 1) {
+            // Fast addressing (W % 16 == 0, 3-wide taps): the 16 voxels of a half-wave are one aligned run of a W-row, so (d, h) — and with
+            // them the whole tap's validity in d and h — are common to the 16 rows, only w = w_ + s moves, and only s = 0 / s = 15 can
+            // step over the row's ends.  One select per tap, two edge selects and one add per row instead of ~12 VALU instructions per
+            // (tap, row).  (The general decode below was half of this kernel's VALU time,
+            // and the kernel is VALU-bound: matrix cores 17 % busy, profiles/r01u_pmc_offc.txt.)
+            const int w_ = v0 % p.W, hh = (v0 / p.W) % p.H, d_ = v0 / (p.W * p.H);
+            const unsigned base = (mrow0 < m_hi) ? (unsigned)((b0 * p.N + v0) * p.Cin + ci) * 4u : DLKA_OOB;
+            const unsigned rs = (unsigned)p.Cin * 4u;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int zd = d_ + od[t], zh = hh + oh[t];
+                const bool ok = (tap0 + t < p.K) & (base != DLKA_OOB) & ((unsigned)zd < (unsigned)p.D) & ((unsigned)zh < (unsigned)p.H);
+                const int doff = ((od[t] * p.H + oh[t]) * p.W + ow[t]) * p.Cin * 4;
+                const unsigned tb = ok ? base + (unsigned)doff : DLKA_OOB;
+                const unsigned tb0 = (w_ + ow[t] >= 0) ? tb : DLKA_OOB, tb15 = (w_ + 15 + ow[t] < p.W) ? tb : DLKA_OOB;
+                // (the row stride is added in the vector offset, not the scalar one: the hardware range-checks the vector offset alone, and
+                //  tb itself can lie one element before the buffer when the run starts the tensor and the tap looks left)
+                bv_n[t][0] = buf_load_f32(rx, tb0);
+#pragma unroll
+                for (int s = 1; s < 15; ++s) bv_n[t][s] = buf_load_f32(rx, tb + (unsigned)s * rs);
+                bv_n[t][15] = buf_load_f32(rx, tb15 + 15u * rs);
+            }
         } else {
             int crd[16];
             unsigned rowoff[16];
@@ -610,6 +633,8 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
     const int nchunks = cdiv(a.M, a.rows_per_chunk);
     a.CoutP = round_up(a.Cout, 32);
     a.CT = a.Cin / 32;
+    static const bool slow_addr = getenv("DLKA_WGRAD_SLOW_ADDR") != nullptr;   // A/B switch
+    a.w16 = (!slow_addr && (a.W & 15) == 0) ? 1 : 0;
     const int OT = a.CoutP / 32;
     if ((long)a.M * a.Cin * 4 >= (1l << 31) || (long)a.M * a.Cout * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     a.bpart = gb ? a.part + (size_t)nchunks * a.K * a.CoutP * a.Cin : nullptr;

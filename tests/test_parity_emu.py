@@ -93,6 +93,8 @@ CL_CONV = [
     (1, 32, 32, (3, 4, 5), 1, 0, 1, 1, False),      # pointwise
     (2, 32, 81, (3, 4, 6), 3, 1, 1, 1, True),       # offset-predict conv, planar output
     (1, 64, 32, (2, 3, 5), 3, 1, 1, 1, False),      # two input chunks
+    (1, 32, 32, (2, 3, 16), 3, 1, 1, 1, False),     # W % 16 == 0: the weight gradient's fast row addressing
+    (2, 32, 81, (2, 2, 16), 3, 1, 1, 1, True),      # the same with a planar grad_out (offset conv)
     (1, 32, 32, (5, 6, 9), 5, 2, 1, 32, False),     # depthwise 5^3
     (1, 32, 32, (7, 5, 10), 7, 9, 3, 32, False),    # depthwise 7^3 dil 3
 ]
