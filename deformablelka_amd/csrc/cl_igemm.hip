@@ -335,8 +335,10 @@ int cl_igemm_pick_splits(int M, int units, int epi, int K)
     // contention instead of chasing block count.
     static int cap = -1;
     if (cap < 0) { const char *e = getenv("DLKA_IGEMM_MAX_SPLITS"); cap = e ? atoi(e) : 32; if (cap < 1) cap = 1; }
+    static int want = -1;   // workgroups to aim for (tuning knob)
+    if (want < 0) { const char *e = getenv("DLKA_IGEMM_WANT_WGS"); want = e ? atoi(e) : 512; if (want < 1) want = 512; }
     int splits = 1;
-    while (mblocks * splits < 512 && splits < units && splits < cap) ++splits;
+    while (mblocks * splits < want && splits < units && splits < cap) ++splits;
     const int ups = cdiv(units, splits);
     return cdiv(units, ups);
 }
