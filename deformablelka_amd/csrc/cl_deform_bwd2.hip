@@ -419,10 +419,20 @@ __device__ __host__ __forceinline__ void gx_window(int b0, int bsz, int size, in
     len = hi - lo;
 }
 
+// FX: the window holds 64-bit INTEGER cells, two channels per cell as 32-bit fixed-point fields (value = hi * 2^32 + lo in signed
+// arithmetic, so the sum of packed words is the packed word of the two sums as long as each stays below 2^31).  One ds_add_u64 then
+// carries two channels: half the LDS atomic instructions of the fp64 window (the kernel's bound), integer adds are
+// exact and order-independent, and ds_add_u64 is the faster instruction (8.2 vs 6.8 lanes/clk/CU).  The price is a per-(brick, slice) scale:
+// 2^k with |contribution| * 2^k < 2^20 from the bound max_rows ||grad_out row||_1 * max |W| — 20 bits of resolution for the largest
+// contribution (error per add <= 2^-21 of it) and 2^11 same-sign maximal contributions of headroom per cell before the field overflows.
+template <bool FX>
 __global__ __launch_bounds__(512) void cl_deform_gx_kernel(DeformBwdArgs p, GxGeom gg, float *__restrict__ scratch)
 {
-    DLKA_DYN_SMEM(unsigned char, smem);
+    DLKA_DYN_SMEM(unsigned char, smem0);
+    unsigned *smax = reinterpret_cast<unsigned *>(smem0);   // 16 bytes of scalars first (static LDS next to a 160 KB dynamic limit is refused)
+    unsigned char *smem = smem0 + 16;
     double *Win = reinterpret_cast<double *>(smem);                                        // [CS][wvox]
+    unsigned long long *WinI = reinterpret_cast<unsigned long long *>(smem);               // FX: [CS / 2][wvox]
     float *Bs = reinterpret_cast<float *>(smem + (size_t)(gg.wvox_max + 64) * CS * sizeof(double));   // [CoutP][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -442,7 +452,40 @@ __global__ __launch_bounds__(512) void cl_deform_gx_kernel(DeformBwdArgs p, GxGe
     const int R = gg.bd * gg.bh * gg.bw, ntiles = cdiv(R, 32);
     const int nkc = p.CoutP / 32;
 
-    for (int e = tid; e < wstride * CS; e += blockDim.x) Win[e] = 0.0;
+    for (int e = tid; e < wstride * (FX ? CS / 2 : CS); e += blockDim.x) Win[e] = 0.0;   // (0.0 and integer 0 share the bit pattern)
+    float fx_scale = 1.f, fx_inv = 1.f;
+    if (FX) {
+        if (tid < 2) smax[tid] = 0u;
+        __syncthreads();
+        // bound of |Col| over the brick: max |W| of this slice (all taps) x max L1 norm of a grad_out row
+        float wm = 0.f;
+        for (int e = tid; e < p.K * p.CoutP; e += blockDim.x) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(p.wp + (long)e * p.C + slice * CS);
+            wm = fmaxf(fmaxf(wm, fmaxf(fabsf(w4[0]), fabsf(w4[1]))), fmaxf(fabsf(w4[2]), fabsf(w4[3])));
+        }
+        float gm = 0.f;
+        for (int row = tid; row < R; row += blockDim.x) {
+            const int rw = row % gg.bw, rh = (row / gg.bw) % gg.bh, rd = row / (gg.bw * gg.bh);
+            const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
+            if (vd < p.D && vh < p.H && vw < p.W) {
+                const float *gp = p.g + ((long)b * p.N + (vd * p.H + vh) * p.W + vw) * p.Cout;
+                float l1 = 0.f;
+                for (int co = 0; co < p.Cout; co += 4) {
+                    const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gp + co);
+                    l1 += (fabsf(g4[0]) + fabsf(g4[1])) + (fabsf(g4[2]) + fabsf(g4[3]));
+                }
+                gm = fmaxf(gm, l1);
+            }
+        }
+        atomicMax(&smax[0], __float_as_uint(wm));   // non-negative floats order like their bit patterns
+        atomicMax(&smax[1], __float_as_uint(gm));
+        __syncthreads();
+        const float vmax = __uint_as_float(smax[0]) * __uint_as_float(smax[1]);
+        int ex = 0;
+        if (vmax > 0.f && vmax < 3.0e38f) (void)frexpf(vmax, &ex);   // vmax < 2^ex
+        fx_scale = ldexpf(1.f, 20 - ex);
+        fx_inv = ldexpf(1.f, ex - 20);
+    }
 
     // A operand tile of group grp: Bs[co][t8*4 + c4] = W[co][slice*4 + c4][tap = grp*8 + t8]   (wp[tap][co][ci], zero beyond K)
     auto stage_weights = [&](int grp, float *dstB) {
@@ -540,6 +583,17 @@ __global__ __launch_bounds__(512) void cl_deform_gx_kernel(DeformBwdArgs p, GxGe
                     for (int c = 0; c < CS; ++c) cell[c * wstride] = (double)(acc[4 * r4 + c] * wv);
                     continue;
                 }
+                if (FX) {
+                    const float ws = wv * fx_scale;
+#pragma unroll
+                    for (int pr = 0; pr < CS / 2; ++pr) {
+                        const int i0 = rint_i32(acc[4 * r4 + 2 * pr] * ws), i1 = rint_i32(acc[4 * r4 + 2 * pr + 1] * ws);
+                        // packed = (int64)i1 * 2^32 + (int64)i0: low word i0, high word i1 - 1 if i0 < 0
+                        const unsigned long long pk = ((unsigned long long)(unsigned)(i1 + (i0 >> 31)) << 32) | (unsigned long long)(unsigned)i0;
+                        atomicAdd(WinI + idx + pr * wstride, pk);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int c = 0; c < CS; ++c) atomicAdd(cell + c * wstride, (double)(acc[4 * r4 + c] * wv));
             }
@@ -585,7 +639,18 @@ __global__ __launch_bounds__(512) void cl_deform_gx_kernel(DeformBwdArgs p, GxGe
     f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + ((long)blockIdx.x * gg.nslices + slice) * gg.wvox_max;
     for (int e = tid; e < wvox; e += blockDim.x) {
         f32x4 o;
+        if (FX) {
+#pragma unroll
+            for (int pr = 0; pr < CS / 2; ++pr) {
+                const long long sv = (long long)WinI[pr * wstride + e];
+                const int lo = (int)(unsigned)(sv & 0xffffffffll);          // sum of the low fields (sign carried by the two's complement)
+                const long long hi = (sv - (long long)lo) >> 32;            // sum of the high fields
+                o[2 * pr] = (float)lo * fx_inv;
+                o[2 * pr + 1] = (float)hi * fx_inv;
+            }
+        } else {
         o[0] = (float)Win[e]; o[1] = (float)Win[wstride + e]; o[2] = (float)Win[2 * wstride + e]; o[3] = (float)Win[3 * wstride + e];
+        }
         dst[e] = o;
     }
 }
@@ -715,7 +780,7 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const GxGeom g = pick_gx_geom(a);
         if (!a.gx_zeroed && launch_zero(a.gx, (size_t)a.B * a.N * a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         GxGeom gl_ = g;
-        const size_t lds_win = (size_t)(g.wvox_max + 64) * CS * sizeof(double);   // window + one trash cell per lane and channel plane
+        const size_t lds_win = 16 + (size_t)(g.wvox_max + 64) * CS * sizeof(double);   // scalars, window + one trash cell per lane and channel plane
         const size_t lds_all = lds_win + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
         gl_.resident = (lds_all <= 150 * 1024 && a.CoutP <= 128) ? 1 : 0;
         static const int abl = getenv("DLKA_GX_ABL") ? atoi(getenv("DLKA_GX_ABL")) : 0;
@@ -727,7 +792,8 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
 #if !defined(HIPEMU)
         static bool attr_done = false;   // dynamic LDS above 64 KB has to be enabled once per function
         if (!attr_done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(cl_deform_gx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(cl_deform_gx_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(cl_deform_gx_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return DLKA_ERR_LAUNCH;
             attr_done = true;
         }
@@ -735,7 +801,10 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const int bricks = a.B * g.nbd * g.nbh * g.nbw;
         static int gx_threads = 0;
         if (!gx_threads) { const char *e = getenv("DLKA_GX_THREADS"); gx_threads = e ? atoi(e) : 512; if (gx_threads != 256 && gx_threads != 512) gx_threads = 512; }
-        hipLaunchKernelGGL(cl_deform_gx_kernel, dim3(bricks, g.nslices), dim3(gx_threads), lds, st, a, gl_, scratch);
+        // fixed-point window (see cl_deform_gx_kernel): opt-in, DLKA_GX_FIXED=1 (not cached: tests toggle it)
+        const bool fixed = getenv("DLKA_GX_FIXED") != nullptr && !abl;
+        if (fixed) { auto k = cl_deform_gx_kernel<true>; hipLaunchKernelGGL(k, dim3(bricks, g.nslices), dim3(gx_threads), lds, st, a, gl_, scratch); }
+        else { auto k = cl_deform_gx_kernel<false>; hipLaunchKernelGGL(k, dim3(bricks, g.nslices), dim3(gx_threads), lds, st, a, gl_, scratch); }
         DLKA_CHECK_LAUNCH();
         const long total = (long)a.B * a.N * g.nslices;
         long gb = cdivl(total, 256);

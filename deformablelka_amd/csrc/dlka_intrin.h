@@ -40,6 +40,9 @@ __device__ __forceinline__ float bf16_value(unsigned short h) { return hipemu::h
 __device__ __forceinline__ void wave_sync() { (void)hipemu::shfl_any(0, 0); }
 // a value the caller guarantees to be equal in all active lanes of the wave (moves it to a scalar register on the GPU)
 __device__ __forceinline__ int wave_uniform(int x) { return x; }
+__device__ __forceinline__ int rint_i32(float x) { return (int)lrintf(x); }
+__device__ __forceinline__ unsigned __float_as_uint(float f) { unsigned v; memcpy(&v, &f, 4); return v; }
+__device__ __forceinline__ float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 // sum over the 8 lanes that share lane >> 3 (result in all 8)
 __device__ __forceinline__ float sum8(float x)
 {
@@ -125,6 +128,7 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // a value the caller guarantees to be equal in all active lanes of the wave: into a scalar register, so that pointers / buffer
 // descriptors derived from it are built by the scalar unit
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ int rint_i32(float x) { return __float2int_rn(x); }
 // sum over the 8 lanes that share lane >> 3 (result in all 8): three DPP adds, no LDS traffic
 // quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141 (lane k <-> 7-k inside each 8)
 __device__ __forceinline__ float sum8(float x)

@@ -248,6 +248,15 @@ inline double atomicAdd(double *addr, double v) {
     return f;
 }
 inline int atomicAdd(int *addr, int v) { return reinterpret_cast<std::atomic<int> *>(addr)->fetch_add(v); }
+inline unsigned long long atomicAdd(unsigned long long *addr, unsigned long long v) {
+    return reinterpret_cast<std::atomic<unsigned long long> *>(addr)->fetch_add(v);
+}
+inline unsigned atomicMax(unsigned *addr, unsigned v) {
+    auto *a = reinterpret_cast<std::atomic<unsigned> *>(addr);
+    unsigned old = a->load(std::memory_order_relaxed);
+    while (old < v && !a->compare_exchange_weak(old, v, std::memory_order_relaxed)) {}
+    return old;
+}
 
 // ---- wave collectives ---------------------------------------------------------------------------
 namespace hipemu {

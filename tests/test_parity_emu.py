@@ -154,3 +154,15 @@ def test_scale_residual_and_channel_scale():
 def test_tblock3d_chain():
     """Two applications back to back: the second reads the first's channels-last output in place; gradients accumulate."""
     parity.check_tblock3d("cpu", 1, 32, (3, 4, 5), True, True, chain=True)
+
+
+@pytest.mark.parametrize("case", [(1, 32, 32, (8, 8, 8), "normal"), (2, 32, 32, (9, 8, 10), "wild")])
+def test_deform3d_cl_fixed_point_window(case):
+    """DLKA_GX_FIXED=1: grad_input scattered into a 64-bit integer LDS window, two 32-bit fixed-point channels per cell."""
+    import os
+    B, C, Cout, dims, mode = case
+    os.environ["DLKA_GX_FIXED"] = "1"
+    try:
+        parity.check_deform3d_cl("cpu", B, C, Cout, dims, off_mode=mode)
+    finally:
+        del os.environ["DLKA_GX_FIXED"]
