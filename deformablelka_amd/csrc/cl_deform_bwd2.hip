@@ -426,14 +426,14 @@ __device__ __host__ __forceinline__ void gx_window(int b0, int bsz, int size, in
 // 2^k with |contribution| * 2^k < 2^20 from the bound max_rows ||grad_out row||_1 * max |W| — 20 bits of resolution for the largest
 // contribution (error per add <= 2^-21 of it) and 2^11 same-sign maximal contributions of headroom per cell before the field overflows.
 template <bool FX>
-__global__ __launch_bounds__(512) void cl_deform_gx_kernel(DeformBwdArgs p, GxGeom gg, float *__restrict__ scratch)
+__global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwdArgs p, GxGeom gg, float *__restrict__ scratch)
 {
     DLKA_DYN_SMEM(unsigned char, smem0);
     unsigned *smax = reinterpret_cast<unsigned *>(smem0);   // 16 bytes of scalars first (static LDS next to a 160 KB dynamic limit is refused)
     unsigned char *smem = smem0 + 16;
     double *Win = reinterpret_cast<double *>(smem);                                        // [CS][wvox]
     unsigned long long *WinI = reinterpret_cast<unsigned long long *>(smem);               // FX: [CS / 2][wvox]
-    float *Bs = reinterpret_cast<float *>(smem + (size_t)(gg.wvox_max + 64) * CS * sizeof(double));   // [CoutP][32]
+    float *Bs = reinterpret_cast<float *>(smem + (size_t)(gg.wvox_max + 64) * (FX ? CS / 2 : CS) * sizeof(double));   // [CoutP][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     int bid = blockIdx.x;
@@ -780,7 +780,9 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const GxGeom g = pick_gx_geom(a);
         if (!a.gx_zeroed && launch_zero(a.gx, (size_t)a.B * a.N * a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         GxGeom gl_ = g;
-        const size_t lds_win = 16 + (size_t)(g.wvox_max + 64) * CS * sizeof(double);   // scalars, window + one trash cell per lane and channel plane
+        const bool fixed = getenv("DLKA_GX_FIXED") != nullptr && !(getenv("DLKA_GX_ABL") && atoi(getenv("DLKA_GX_ABL")));   // opt-in, not cached: tests toggle it
+        // scalars, window + one trash cell per lane and channel plane (the fixed-point window packs two channels per cell)
+        const size_t lds_win = 16 + (size_t)(g.wvox_max + 64) * (fixed ? CS / 2 : CS) * sizeof(double);
         const size_t lds_all = lds_win + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
         gl_.resident = (lds_all <= 150 * 1024 && a.CoutP <= 128) ? 1 : 0;
         static const int abl = getenv("DLKA_GX_ABL") ? atoi(getenv("DLKA_GX_ABL")) : 0;
@@ -801,8 +803,6 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const int bricks = a.B * g.nbd * g.nbh * g.nbw;
         static int gx_threads = 0;
         if (!gx_threads) { const char *e = getenv("DLKA_GX_THREADS"); gx_threads = e ? atoi(e) : 512; if (gx_threads != 256 && gx_threads != 512) gx_threads = 512; }
-        // fixed-point window (see cl_deform_gx_kernel): opt-in, DLKA_GX_FIXED=1 (not cached: tests toggle it)
-        const bool fixed = getenv("DLKA_GX_FIXED") != nullptr && !abl;
         if (fixed) { auto k = cl_deform_gx_kernel<true>; hipLaunchKernelGGL(k, dim3(bricks, g.nslices), dim3(gx_threads), lds, st, a, gl_, scratch); }
         else { auto k = cl_deform_gx_kernel<false>; hipLaunchKernelGGL(k, dim3(bricks, g.nslices), dim3(gx_threads), lds, st, a, gl_, scratch); }
         DLKA_CHECK_LAUNCH();
