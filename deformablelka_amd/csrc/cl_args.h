@@ -36,6 +36,7 @@ struct WgradArgs {
     int rows_per_chunk;  // multiple of 32
     int CT;              // Cin / 32
     int w16;             // set by the launcher: W % 16 == 0 (fast row addressing in cl_wgrad_dense_kernel)
+    int xcd_ny, xcd_nz, xcd_total;   // set by the launcher: > 0 = 1-D XCD-swizzled grid over (chunk, y, z) work items, see xcd_item()
     int g_cpad;          // GMODE 1 only, > 0: g holds pack_split2() words with g_cpad channel planes per batch (see DeformBwdArgs::goff_cpad)
 };
 

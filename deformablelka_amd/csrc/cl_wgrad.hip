@@ -204,12 +204,17 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
     __shared__ __attribute__((aligned(16))) float Dt[32 * GATHER_DESC_WORDS];
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
     const int gr = lane >> 3, gp = lane & 7;
-    const int chunk = blockIdx.x;
-    const int ot = blockIdx.y / p.CT, ct = blockIdx.y % p.CT;
-    const int tap0 = blockIdx.z * TPW;
+    int chunk = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_total) {   // XCD-swizzled 1-D grid: an XCD owns a contiguous range of row chunks (with all their tiles and tap groups)
+        const int r = xcd_item(blockIdx.x, p.xcd_total);
+        if (r < 0) return;
+        chunk = r / (p.xcd_ny * p.xcd_nz); by = (r / p.xcd_nz) % p.xcd_ny; bz = r % p.xcd_nz;
+    }
+    const int ot = by / p.CT, ct = by % p.CT;
+    const int tap0 = bz * TPW;
     const int ntap = min(TPW, p.K - tap0);
     const int co = ot * 32 + i;
-    const bool want_bias = p.bpart && ct == 0 && blockIdx.z == 0;
+    const bool want_bias = p.bpart && ct == 0 && bz == 0;
     const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * 4), rg = make_rsrc(p.g, (size_t)p.M * p.Cout * 4);
     const int HW = p.H * p.W, rowbytes = p.Cin * 4;
     const unsigned cbyte = (unsigned)(ct * 32 + 4 * gp) * 4u;
@@ -310,12 +315,17 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
 // SPLIT: bf16 x3-split contraction (dlka_intrin.h) instead of the exact fp32-input MFMA: 54 x 32 cycles per 32-row step instead
 // of 144 x 64 for the 3 x 3 blocking.
 template <int GMODE, int COT, int TPW, bool N16, bool SPLIT>   // N16: N % 16 == 0 (the 16 rows of a half-wave never straddle two volumes)
-__device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int bz)
+__device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int bz_in)
 {
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
-    const int chunk = blockIdx.x;
+    int chunk = blockIdx.x, by = blockIdx.y, bz = bz_in;
+    if (p.xcd_total) {   // XCD-swizzled 1-D grid (see cl_wgrad_deform_kernel)
+        const int r = xcd_item(blockIdx.x, p.xcd_total);
+        if (r < 0) return;
+        chunk = r / (p.xcd_ny * p.xcd_nz); by = (r / p.xcd_nz) % p.xcd_ny; bz = r % p.xcd_nz;
+    }
     const int OTG = cdiv(p.CoutP / 32, COT);                  // co-tile groups
-    const int otg = blockIdx.y / p.CT, ct = blockIdx.y % p.CT;
+    const int otg = by / p.CT, ct = by % p.CT;
     const int tap0 = bz * TPW;
     const int ci = ct * 32 + i;
     const bool want_bias = p.bpart && ct == 0 && bz == 0;
@@ -643,12 +653,22 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
         if (gmode != 0 || a.K == 1) return DLKA_ERR_UNSUPPORTED;
         static const bool v1 = getenv("DLKA_WGRAD_DEFORM_TPW") && atoi(getenv("DLKA_WGRAD_DEFORM_TPW")) == 0;
         dim3 grid(nchunks, OT * a.CT, cdiv(a.K, pl.tpw));
+        static const bool no_xcd = getenv("DLKA_NO_XCD_SWIZZLE") != nullptr;   // A/B switch
+        if (!v1 && !no_xcd && nchunks >= 16) {
+            a.xcd_ny = grid.y; a.xcd_nz = grid.z; a.xcd_total = (int)(grid.x * grid.y * grid.z);
+            grid = dim3(xcd_grid(a.xcd_total), 1, 1);
+        }
         if (v1) { auto k = cl_wgrad_kernel<1, 0, 7>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
         else if (pl.tpw == 3) { auto k = cl_wgrad_deform_kernel<3>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
         else if (pl.tpw == 4) { auto k = cl_wgrad_deform_kernel<4>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
         else { auto k = cl_wgrad_deform_kernel<7>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
     } else {
         dim3 grid(nchunks, cdiv(OT, pl.cot) * a.CT, cdiv(a.K, pl.tpw));
+        static const bool no_xcd2 = getenv("DLKA_NO_XCD_SWIZZLE") != nullptr;
+        if (!no_xcd2 && a.K > 1 && nchunks >= 16) {
+            a.xcd_ny = grid.y; a.xcd_nz = grid.z; a.xcd_total = (int)(grid.x * grid.y * grid.z);
+            grid = dim3(xcd_grid(a.xcd_total), 1, 1);
+        }
         static const bool exact = getenv("DLKA_EXACT_FP32") != nullptr;
         const bool split = !exact && a.K > 1;   // MFMA-bound contractions: bf16 x3 split (see cl_igemm.hip)
         if (a.g_cpad && !((a.N & 15) == 0 && split && gmode == 1)) return DLKA_ERR_UNSUPPORTED;   // packed g: split + N16 variant only

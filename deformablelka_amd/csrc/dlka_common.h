@@ -55,6 +55,18 @@ __device__ __forceinline__ float dgelu_f(float x)
     return cdf + x * pdf;
 }
 
+// Workgroup b of a launch runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md: used for speed only, never for correctness), and
+// each XCD has its own 4 MB L2.  A launch whose work items are ordered so that neighbours share data (row chunks of a volume) therefore
+// wants item ranges, not item stripes, per XCD: block b -> item (b % 8) * ceil(total / 8) + b / 8.  The grid is 8 * ceil(total / 8)
+// blocks; the few blocks beyond `total` return -1.
+__host__ __device__ __forceinline__ int xcd_item(int block, int total)
+{
+    const int per = (total + 7) / 8;
+    const int r = (block % 8) * per + block / 8;
+    return r < total ? r : -1;
+}
+__host__ __device__ __forceinline__ int xcd_grid(int total) { return 8 * ((total + 7) / 8); }
+
 #define DLKA_THREADS 256
 
 #define DLKA_CHECK_LAUNCH()                                  \
