@@ -42,10 +42,14 @@ def main():
         tok = torch.randn(a.batch, H * W * D, C, device=dev, requires_grad=True)
         gtok = torch.randn_like(tok)
 
-        def full():
+        def full():   # (grads dropped each time: autograd's `.grad +=` accumulation is not part of the block)
+            m.zero_grad(set_to_none=True)
+            x.grad = None
             m(x).backward(gy)
 
         def lka():
+            m.zero_grad(set_to_none=True)
+            tok.grad = None
             inner(tok, a.batch, C, H, W, D).backward(gtok)
 
         def fwd():
