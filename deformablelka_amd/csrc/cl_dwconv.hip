@@ -141,33 +141,35 @@ __global__ __launch_bounds__(256) void cl_dwconv_rows_kernel(DwArgs p)
         if (w0 + t < p.W) op[(long)t * p.C] = acc[t];
 }
 
-// ... and with TWO output rows per work-item, h0 and h0 + DIL: with the loads lean, the kernel sits on the L1 return path (one 256-byte
+// ... and with TH output rows per work-item, h0, h0 + DIL, ...: with the loads lean, the kernel sits on the L1 return path (one 256-byte
 // wave load per segment element: 1.7 GB per launch at 32^3 for 7^3 dil 3), and output rows DIL apart share KH - 1 of their KH input
-// rows — KH + 1 segment loads per tap plane feed 2 KH row products.  The tap plane's KH*KW weights sit in registers for both.
-template <int KW, int DIL, int TW>
-__global__ __launch_bounds__(256) void cl_dwconv_rows2_kernel(DwArgs p)
+// rows — KH + TH - 1 segment loads per tap plane feed TH * KH row products.  The tap plane's KH*KW weights sit in registers for all.
+template <int KW, int DIL, int TW, int TH>
+__global__ __launch_bounds__(256) void cl_dwconv_rowsN_kernel(DwArgs p)
 {
     constexpr int KH = KW;
     constexpr int SEG = TW + (KW - 1) * DIL;
+    constexpr int NR = KH + TH - 1;                          // input rows per tap plane
     const int cpb = p.C < 256 ? p.C : 256;
     const int rpb = 256 / cpb;
     const int c = blockIdx.z * cpb + threadIdx.x % cpb;
     const int run = blockIdx.x * rpb + threadIdx.x / cpb;
     const int runs_per_row = cdiv(p.W, TW);
-    const int groups = DIL * cdiv(p.H, 2 * DIL);             // row pairs per (b, d) plane: h0 = r + 2*DIL*q, r < DIL
+    const int groups = DIL * cdiv(p.H, TH * DIL);            // row groups per (b, d) plane: h0 = r + TH*DIL*q, r < DIL
     const long total = (long)p.B * p.D * groups * runs_per_row;
     if (run >= total || c >= p.C) return;
     const int w0 = (run % runs_per_row) * TW;
     const int gidx = wave_uniform(run / runs_per_row);
     const int grp = gidx % groups, d0 = (gidx / groups) % p.D, b = gidx / (groups * p.D);
-    const int h0 = (grp % DIL) + (grp / DIL) * 2 * DIL;
+    const int h0 = (grp % DIL) + (grp / DIL) * TH * DIL;
     if (h0 >= p.H) return;                                   // scalar
-    const bool two = h0 + DIL < p.H;                         // scalar: the second output row exists
 
-    float acc0[TW], acc1[TW];
+    float acc[TH][TW];
     const float bv = p.bias ? p.bias[c] : 0.f;
 #pragma unroll
-    for (int t = 0; t < TW; ++t) { acc0[t] = bv; acc1[t] = bv; }
+    for (int o = 0; o < TH; ++o)
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[o][t] = bv;
 
     const int cb = p.C * 4;
     const unsigned rowbytes = (unsigned)(p.W * cb);
@@ -184,41 +186,36 @@ __global__ __launch_bounds__(256) void cl_dwconv_rows2_kernel(DwArgs p)
             for (int k = 0; k < KW; ++k) wv[j][k] = buf_load_f32_s(rwt, cv, (unsigned)(((i * KH + j) * KW + k) * cb));
         const float *plane = p.in + ((long)(b * p.D + zd) * p.H) * p.W * p.C;
 #pragma unroll
-        for (int r = 0; r <= KH; ++r) {                      // input row h0 - ph + r*DIL: tap row r of output 0, r - 1 of output 1
+        for (int r = 0; r < NR; ++r) {                       // input row h0 - ph + r*DIL: tap row r - o of output row o
             const int zh = h0 - p.ph + r * DIL;
             if (zh < 0 || zh >= p.H) continue;               // scalar
             const BufRsrc rr = make_rsrc(plane + (long)zh * p.W * p.C, rowbytes);
             float seg[SEG];
 #pragma unroll
             for (int e = 0; e < SEG; ++e) seg[e] = buf_load_f32(rr, (unsigned)(vbase + e * cb));
-            if (r < KH) {
+#pragma unroll
+            for (int o = 0; o < TH; ++o) {
+                if (r - o < 0 || r - o >= KH) continue;      // compile time
 #pragma unroll
                 for (int k = 0; k < KW; ++k)
 #pragma unroll
-                    for (int t = 0; t < TW; ++t) acc0[t] = fmaf(wv[r][k], seg[t + k * DIL], acc0[t]);
-            }
-            if (r >= 1) {
-#pragma unroll
-                for (int k = 0; k < KW; ++k)
-#pragma unroll
-                    for (int t = 0; t < TW; ++t) acc1[t] = fmaf(wv[r - 1][k], seg[t + k * DIL], acc1[t]);
+                    for (int t = 0; t < TW; ++t) acc[o][t] = fmaf(wv[r - o][k], seg[t + k * DIL], acc[o][t]);
             }
         }
     }
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        if (o == 1 && !two) break;
+    for (int o = 0; o < TH; ++o) {
+        if (h0 + o * DIL >= p.H) break;                      // scalar
         const long obase = (((long)(b * p.D + d0) * p.H + h0 + o * DIL) * p.W + w0) * p.C + c;
         float *op = p.out + obase;
-        const float *acc = o ? acc1 : acc0;
         if (p.gelu_x) {
 #pragma unroll
             for (int t = 0; t < TW; ++t)
-                if (w0 + t < p.W) op[(long)t * p.C] = (acc[t] + p.gelu_add[obase + (long)t * p.C]) * dgelu_f(p.gelu_x[obase + (long)t * p.C]);
+                if (w0 + t < p.W) op[(long)t * p.C] = (acc[o][t] + p.gelu_add[obase + (long)t * p.C]) * dgelu_f(p.gelu_x[obase + (long)t * p.C]);
         } else {
 #pragma unroll
             for (int t = 0; t < TW; ++t)
-                if (w0 + t < p.W) op[(long)t * p.C] = acc[t];
+                if (w0 + t < p.W) op[(long)t * p.C] = acc[o][t];
         }
     }
 }
@@ -256,11 +253,13 @@ int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st)
         static const int th_env = getenv("DLKA_DW_TH") ? atoi(getenv("DLKA_DW_TH")) : 0;   // tuning knob: 1 / 2 output rows per work-item
         const bool cubic = a.kd == kw && a.kh == kw && a.dd == dil_w && a.dh == dil_w;
         const int th = th_env ? th_env : 2;
-        if (th == 2 && cubic && a.H >= 2 * dil_w && ((kw == 7 && dil_w == 3) || (kw == 5 && dil_w == 1))) {
-            const long runs2 = (long)a.B * a.D * dil_w * cdiv(a.H, 2 * dil_w) * cdiv(a.W, TW);
+        if ((th == 2 || th == 3) && cubic && a.H >= th * dil_w && ((kw == 7 && dil_w == 3) || (kw == 5 && dil_w == 1))) {
+            const long runs2 = (long)a.B * a.D * dil_w * cdiv(a.H, th * dil_w) * cdiv(a.W, TW);
             dim3 grid2((unsigned)cdivl(runs2, rpb), 1, cdiv(a.C, cpb));
-            if (kw == 7) { auto k = cl_dwconv_rows2_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid2, block, 0, st, a); }
-            else { auto k = cl_dwconv_rows2_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid2, block, 0, st, a); }
+            if (kw == 7 && th == 2) { auto k = cl_dwconv_rowsN_kernel<7, 3, TW, 2>; hipLaunchKernelGGL(k, grid2, block, 0, st, a); }
+            else if (kw == 7) { auto k = cl_dwconv_rowsN_kernel<7, 3, TW, 3>; hipLaunchKernelGGL(k, grid2, block, 0, st, a); }
+            else if (th == 2) { auto k = cl_dwconv_rowsN_kernel<5, 1, TW, 2>; hipLaunchKernelGGL(k, grid2, block, 0, st, a); }
+            else { auto k = cl_dwconv_rowsN_kernel<5, 1, TW, 3>; hipLaunchKernelGGL(k, grid2, block, 0, st, a); }
             DLKA_CHECK_LAUNCH();
             return DLKA_OK;
         }
