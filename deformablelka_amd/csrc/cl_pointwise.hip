@@ -13,7 +13,7 @@
 namespace dlka {
 
 template <int UNUSED = 0>
-__global__ __launch_bounds__(64) void cl_pointwise_kernel(IgemmArgs p)
+__global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
 {
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
     const int mbase = blockIdx.x * 32, n0 = blockIdx.y * 32;
@@ -27,6 +27,19 @@ __global__ __launch_bounds__(64) void cl_pointwise_kernel(IgemmArgs p)
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // epilogue operands (residual / gate tensors) are requested FIRST: their addresses are known now, and a wave's timeline is otherwise
+    // load latency -> MFMAs -> a second load latency for them
+    float auxv[16], aux2v[16];
+    const bool n_ok = n < p.Cout;
+    if (p.epi >= 2) {   // uniform
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = mbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool ok = n_ok && mr < p.M;
+            auxv[r] = ok ? p.aux[(long)mr * p.Cout + n] : 0.f;
+            aux2v[r] = (ok && p.epi == 4) ? p.aux2[(long)mr * p.Cout + n] : 0.f;
+        }
+    }
     const int nchunk = p.CinP / 32;
     for (int c0 = 0; c0 < nchunk; c0 += 4) {
         f32x4 a[4][4];
@@ -64,12 +77,12 @@ __global__ __launch_bounds__(64) void cl_pointwise_kernel(IgemmArgs p)
             p.out2[o] = gelu_f(val);
         } else if (p.epi == 2) {
             p.out[o] = val;
-            p.out2[o] = p.aux[o] * val;
+            p.out2[o] = auxv[r] * val;
         } else if (p.epi == 3) {
-            p.out[o] = val + p.aux[o];
+            p.out[o] = val + auxv[r];
         } else {
-            p.out[o] = val * p.aux[o];
-            p.out2[o] = val * p.aux2[o];
+            p.out[o] = val * auxv[r];
+            p.out2[o] = val * aux2v[r];
         }
     }
 }
