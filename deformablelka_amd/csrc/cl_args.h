@@ -65,7 +65,7 @@ struct PrepJob {
     const float *src;   // weight in the reference layout
     float *dst;         // prepared layout
     int Cout, Cin, K, KP, NP;
-    int mode;           // 0 fwd, 1 data-grad (flipped), 2 column matrix (| 8: bf16 split layout); 3 depthwise, 4 depthwise flipped
+    int mode;           // 0 fwd, 1 data-grad (flipped), 2 column matrix (| 8 / | 16: bf16 split layouts); 3 depthwise, 4 depthwise flipped; 5 zero fill of dst
     long n;             // elements of dst
 };
 struct PrepBatch {

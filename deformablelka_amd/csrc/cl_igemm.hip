@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256) void cl_prep_batch_kernel(PrepBatch b)
         const PrepJob &j = b.j[ji];
         const long l = e - lo;
         float val = 0.f;
+        if (j.mode == 5) { j.dst[l] = 0.f; continue; }   // a zero fill riding along (split outputs of the forward pass)
         if (j.mode == 3 || j.mode == 4) {
             const int c = (int)(l % j.Cin), tap = (int)(l / j.Cin);
             val = j.src[(long)c * j.K + (j.mode == 4 ? j.K - 1 - tap : tap)];

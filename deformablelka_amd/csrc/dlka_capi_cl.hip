@@ -337,7 +337,7 @@ void add_job(PrepBatch &pb, const void *src, float *dst, int Cout, int Cin, int 
     pb.total += j.n;
 }
 
-int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_params *p, hipStream_t st, bool fill)
+int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_params *p, hipStream_t st, bool fill, const ZeroBatch *zb = nullptr)
 {
     float *q = base;
     auto take = [&](size_t n) { float *r = q; q += (n + 63) & ~(size_t)63; return r; };
@@ -363,6 +363,13 @@ int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_para
     add_job(pb, p->conv0_w, t.dw5_b, C, C, 125, 0, 0, 4);
     add_job(pb, p->conv_spatial_w, t.dw7_f, C, C, 343, 0, 0, 3);
     add_job(pb, p->conv_spatial_w, t.dw7_b, C, C, 343, 0, 0, 4);
+    if (zb)   // the forward pass's zero fills ride along (one launch less per block)
+        for (int r = 0; r < zb->n && pb.njobs < 16; ++r) {
+            PrepJob &j = pb.j[pb.njobs++];
+            memset(&j, 0, sizeof(j));
+            j.dst = zb->p[r]; j.n = zb->cnt[r]; j.mode = 5;
+            pb.total += j.n;
+        }
     return launch_cl_prep_batch(pb, st);
 }
 
@@ -560,15 +567,14 @@ int dlka_lka3d_attention_tokens_forward(const void *x_, const dlka_lka3d_params 
     float *y = (float *)y_;
     const float *N0 = nullptr;
     // every weight re-layout of the block (forward and backward forms) in one launch; the backward call reuses them
-    TokPrep PW;
-    DLKA_TRY(carve_prep(G, prep, PW, p, st, true));
-    // outputs of tap-split convs (small stages) collect partial sums with atomics: ONE zero fill for all of them
+    // outputs of tap-split convs (small stages) collect partial sums with atomics: their zero fills ride in the weight-preparation launch
     ZeroBatch zb;
     memset(&zb, 0, sizeof(zb));
     if (dense_forward_splits(G.offc, 0) > 1) zb.add(off, G.Off);
     if (dense_forward_splits(G.dcn, 0) > 1) zb.add(f, G.E);
     if (dense_forward_splits(G.pw, 3) > 1) zb.add(y, G.E);
-    DLKA_TRY(launch_zero_batch(zb, st));
+    TokPrep PW;
+    DLKA_TRY(carve_prep(G, prep, PW, p, st, true, &zb));
     // proj_1 + GELU (transformerblock.py:667-668): h kept for the GELU gradient, a = GELU(h)
     DLKA_TRY(dense_forward(G.pw, x, N0, (const float *)p->proj_1_b, h, 0, PW.pw_f[0], 1, nullptr, a, st));
     // depthwise 5^3 then 7^3 dilation 3 (:646-647)
