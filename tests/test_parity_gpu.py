@@ -201,7 +201,7 @@ def test_deform3d_cl(case):
     parity.check_deform3d_cl(DEV, B, C, Cout, dims, off_mode=mode)
 
 
-@pytest.mark.parametrize("C,dims", [(32, (16, 16, 16)), (64, (8, 8, 8)), (128, (8, 8, 8)), (256, (4, 4, 4)), (32, (5, 6, 7))])
+@pytest.mark.parametrize("C,dims", [(32, (16, 16, 16)), (64, (8, 8, 8)), (64, (16, 16, 16)), (128, (8, 8, 8)), (256, (4, 4, 4)), (32, (5, 6, 7))])
 def test_lka3d_tokens_block_vs_oracle(C, dims):
     parity.check_lka3d_tokens(DEV, 2, C, dims)
 
