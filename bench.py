@@ -263,7 +263,8 @@ def main():
 
     from deformablelka_amd.stack import DLKABlockStack
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
-    stack = DLKABlockStack(args.batch, device=dev, dtype=dtype, seed=1234 + rank)
+    # replicas start from the same parameters (seed); every rank gets its own shard of synthetic volumes (data_seed)
+    stack = DLKABlockStack(args.batch, device=dev, dtype=dtype, seed=1234, data_seed=4321 + rank)
     # Synthetic grad_outputs (N(0,1), no loss behind them) make the block gradients huge; a training-sized step would blow
     # the parameters up within a few iterations (offsets -> inf/NaN, every sample dropped, kernels get FASTER: observed,
     # profiles/r01i).  The SGD update is executed in full but with a step small enough that the data distribution the

@@ -32,7 +32,9 @@ class _Block:
 
 class DLKABlockStack:
     def __init__(self, batch: int, stages: Sequence = SYNAPSE_STAGES, device="cuda:0", dtype=torch.float32, seed: int = 0,
-                 offset_std_voxels: float = 1.0):
+                 offset_std_voxels: float = 1.0, data_seed=None):
+        """seed: parameters (identical on every data-parallel rank); data_seed: the synthetic inputs / grad_outputs of THIS rank's
+        batch shard (None: drawn from the parameter generator, single-process use)."""
         self.B, self.device, self.dtype = batch, torch.device(device), dtype
         self.lib = L.get_lib()
         self.dt = L.DLKA_F32 if dtype == torch.float32 else L.DLKA_BF16
@@ -71,6 +73,8 @@ class DLKABlockStack:
         self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
         # activations: blocks of one stage instance are chained x -> y -> ... ; each chain has a synthetic input and
         # a synthetic grad_output (the layers between chains — down/up-sampling, UnetResBlock — are not D-LKA).
+        if data_seed is not None:
+            gen = torch.Generator().manual_seed(int(data_seed))
         i = 0
         for C, dims, n in stages:
             for c0 in range(0, n, CHAIN):
