@@ -18,6 +18,7 @@ struct IgemmArgs {
     int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
     int units_per_split; // work units (tap, 32-channel chunk) per blockIdx.y; K * CinP/32 when gridDim.y == 1
     int split_bf16;      // 2 / 3: contraction on the bf16 matrix cores with two- / three-term split operands (weights prepared with mode | 8 / | 16)
+    int xcd_nx;          // set by the launcher: > 0 = gridDim.x is xcd_grid(xcd_nx) and blockIdx.x is mapped through xcd_item() (dlka_common.h)
     int out_zeroed;      // 1: the caller has already zero-filled `out` (split partial sums meet there in atomics)
     int a_packed;        // AMODE 2 + split_bf16 == 2: `in` holds pack_split2() words (CinReal = CinP channel planes per batch, zero padded)
     int epi;             // 0: out = acc+bias | 1: out = acc+bias, out2 = gelu(out) | 2: out = acc+bias, out2 = aux*out | 3: out = acc+bias+aux
@@ -45,6 +46,7 @@ struct DwArgs {
     const float *wp;    // [K][C] prepared weights (tap-major, channel contiguous)
     const float *bias;  // [C] or null
     float *out;         // [B][D][H][W][C]
+    int xcd_nx;            // set by the launcher: > 0 = blockIdx.x is mapped through xcd_item()
     const float *gelu_x;   // optional fused epilogue (data gradient of dw 5^3 inside the D-LKA block): out = (acc + gelu_add) * gelu'(gelu_x)
     const float *gelu_add;
     int B, D, H, W, C;
@@ -59,6 +61,7 @@ struct DwWgradArgs {
     int B, D, H, W, C;
     int kd, kh, pd, ph, pw, dd, dh;
     int rows_per_block;
+    int xcd_nx;         // set by the launcher: > 0 = blockIdx.x is mapped through xcd_item()
 };
 
 struct PrepJob {
@@ -102,6 +105,7 @@ struct DeformBwdArgs {
     int C, Cout, CoutP;
     int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
     int cc_per_block;   // 32-channel input chunks per blockIdx.z; grad_offset uses atomics when gridDim.z > 1
+    int xcd_nx;         // set by the launchers (per kernel): > 0 = blockIdx.x is mapped through xcd_item()
     int gx_zeroed;      // 1: the caller has already zero-filled gx
     int goff_zeroed;    // 1: the caller has already zero-filled goff (needed when cl_deform_goff_ccsplit() > 1)
     int goff_cpad;      // > 0: goff is written as pack_split2() words with goff_cpad channel planes per batch (planes >= 3K zero) for the

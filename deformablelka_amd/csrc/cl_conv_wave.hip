@@ -24,7 +24,9 @@ __global__ __launch_bounds__(256) void cl_conv_wave_kernel(IgemmArgs p)
     __shared__ float Tsm[OMODE == 1 ? 4 * 32 * 33 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int mbase = (blockIdx.x * 4 + wave) * 32;
+    const int bx = DLKA_XCD_BX(p.xcd_nx);
+    if (bx < 0) return;
+    const int mbase = (bx * 4 + wave) * 32;
     const int m = mbase + i;
     const bool row_ok = m < p.M;
     const int b = row_ok ? m / p.N : 0;
@@ -178,10 +180,13 @@ int launch_cl_conv_wave(int amode, int omode, const IgemmArgs &a, int splits, hi
     }
     if (NT < 1 || NT > 3 || NT_total % NT || (DEPTH != 2 && DEPTH != 3)) return DLKA_ERR_UNSUPPORTED;
     dim3 grid(cdiv(a.M, 128), splits, NT_total / NT), block(256);
+    IgemmArgs ax = a;
+    ax.xcd_nx = 0;
+    if (xcd_swizzle_enabled() && grid.x >= (unsigned)xcd_min_blocks()) { ax.xcd_nx = (int)grid.x; grid.x = xcd_grid(ax.xcd_nx); }
 #define DLKA_CW(AM, OM, NTV, SP, DP)                                        \
     {                                                                       \
         auto k = cl_conv_wave_kernel<AM, OM, NTV, SP, DP>;                  \
-        hipLaunchKernelGGL(k, grid, block, 0, st, a);                       \
+        hipLaunchKernelGGL(k, grid, block, 0, st, ax);                      \
     }
 #define DLKA_CW_NT(AM, OM, SP)                                              \
     {                                                                       \

@@ -27,7 +27,9 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;      // MFMA roles
     const int gr = lane >> 3, gp = lane & 7;     // gather roles: row gr of each group of 8, 16-byte piece gp
-    const int mbase = (blockIdx.x * 4 + wave) * 32;
+    const int bx = DLKA_XCD_BX(p.xcd_nx);
+    if (bx < 0) return;
+    const int mbase = (bx * 4 + wave) * 32;
     const int m = mbase + i;
     const bool row_ok = m < p.M;
     const int b = row_ok ? m / p.N : 0;
@@ -175,6 +177,8 @@ int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
     static const int nt_env = getenv("DLKA_DFWD_NT") ? atoi(getenv("DLKA_DFWD_NT")) : 0;   // tuning knob
     if (nt_env == 1 || nt_env == 2 || nt_env == 4) { if (NT_total % nt_env == 0 && nt_env <= NT_total) NT = nt_env; }
     dim3 grid(mblocks, splits, NT_total / NT), block(256);
+    a.xcd_nx = 0;
+    if (xcd_swizzle_enabled() && mblocks >= (unsigned)xcd_min_blocks()) { a.xcd_nx = mblocks; grid.x = xcd_grid(mblocks); }
     switch (NT) {
         case 1: { auto k = cl_deform_fwd_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
         case 2: { auto k = cl_deform_fwd_kernel<2>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;

@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256) void cl_dwconv_rows_kernel(DwArgs p)
     const int cpb = p.C < 256 ? p.C : 256;
     const int rpb = 256 / cpb;
     const int c = blockIdx.z * cpb + threadIdx.x % cpb;
-    const int run = blockIdx.x * rpb + threadIdx.x / cpb;
+    const int bx = DLKA_XCD_BX(p.xcd_nx);   // XCD-aware: an XCD owns a contiguous slab of rows (neighbouring rows share their input rows)
+    if (bx < 0) return;
+    const int run = bx * rpb + threadIdx.x / cpb;
     const int runs_per_row = cdiv(p.W, TW);
     const int rows = p.B * p.D * p.H;
     if (run >= rows * runs_per_row || c >= p.C) return;
@@ -153,7 +155,9 @@ __global__ __launch_bounds__(256) void cl_dwconv_rowsN_kernel(DwArgs p)
     const int cpb = p.C < 256 ? p.C : 256;
     const int rpb = 256 / cpb;
     const int c = blockIdx.z * cpb + threadIdx.x % cpb;
-    const int run = blockIdx.x * rpb + threadIdx.x / cpb;
+    const int bx = DLKA_XCD_BX(p.xcd_nx);   // XCD-aware: an XCD owns a contiguous slab of rows (neighbouring rows share their input rows)
+    if (bx < 0) return;
+    const int run = bx * rpb + threadIdx.x / cpb;
     const int runs_per_row = cdiv(p.W, TW);
     const int groups = DIL * cdiv(p.H, TH * DIL);            // row groups per (b, d) plane: h0 = r + TH*DIL*q, r < DIL
     const long total = (long)p.B * p.D * groups * runs_per_row;
@@ -250,25 +254,31 @@ int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st)
     // the rows kernel needs (b, d, h) uniform per wave: the 64 / cpb runs of a wave must not straddle two rows
     const int wpr = cpb < 64 ? 64 / cpb : 1;
     if (!v1 && !abl0 && cdiv(a.W, TW) % wpr == 0 && (long)a.W * a.C * 4 < (1l << 31)) {
+        DwArgs ax = a;
+        ax.xcd_nx = 0;
+        auto swz = [&](dim3 &g) { if (xcd_swizzle_enabled() && g.x >= (unsigned)xcd_min_blocks()) { ax.xcd_nx = (int)g.x; g.x = xcd_grid(ax.xcd_nx); } };
         static const int th_env = getenv("DLKA_DW_TH") ? atoi(getenv("DLKA_DW_TH")) : 0;   // tuning knob: 1 / 2 output rows per work-item
         const bool cubic = a.kd == kw && a.kh == kw && a.dd == dil_w && a.dh == dil_w;
         const int th = th_env ? th_env : 2;
         if ((th == 2 || th == 3) && cubic && a.H >= th * dil_w && ((kw == 7 && dil_w == 3) || (kw == 5 && dil_w == 1))) {
             const long runs2 = (long)a.B * a.D * dil_w * cdiv(a.H, th * dil_w) * cdiv(a.W, TW);
             dim3 grid2((unsigned)cdivl(runs2, rpb), 1, cdiv(a.C, cpb));
-            if (kw == 7 && th == 2) { auto k = cl_dwconv_rowsN_kernel<7, 3, TW, 2>; hipLaunchKernelGGL(k, grid2, block, 0, st, a); }
-            else if (kw == 7) { auto k = cl_dwconv_rowsN_kernel<7, 3, TW, 3>; hipLaunchKernelGGL(k, grid2, block, 0, st, a); }
-            else if (th == 2) { auto k = cl_dwconv_rowsN_kernel<5, 1, TW, 2>; hipLaunchKernelGGL(k, grid2, block, 0, st, a); }
-            else { auto k = cl_dwconv_rowsN_kernel<5, 1, TW, 3>; hipLaunchKernelGGL(k, grid2, block, 0, st, a); }
+            swz(grid2);
+            if (kw == 7 && th == 2) { auto k = cl_dwconv_rowsN_kernel<7, 3, TW, 2>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
+            else if (kw == 7) { auto k = cl_dwconv_rowsN_kernel<7, 3, TW, 3>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
+            else if (th == 2) { auto k = cl_dwconv_rowsN_kernel<5, 1, TW, 2>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
+            else { auto k = cl_dwconv_rowsN_kernel<5, 1, TW, 3>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
             DLKA_CHECK_LAUNCH();
             return DLKA_OK;
         }
         bool done = true;
-        if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-        else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_rows_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-        else if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<3, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-        else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_rows_kernel<5, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-        else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<7, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        dim3 grid1 = grid;
+        swz(grid1);
+        if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
+        else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_rows_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
+        else if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<3, 1, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
+        else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_rows_kernel<5, 3, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
+        else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<7, 1, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
         else done = false;
         if (done) { DLKA_CHECK_LAUNCH(); return DLKA_OK; }
     }
@@ -391,7 +401,9 @@ __global__ __launch_bounds__(256) void cl_dwconv_wgrad2_kernel(DwWgradArgs p)
     const int i = blockIdx.y;
     const int runs_per_row = cdiv(p.W, TW);
     const int rows = p.B * p.D * p.H;
-    const long run_lo = (long)blockIdx.x * p.rows_per_block * runs_per_row;
+    const int bx = DLKA_XCD_BX(p.xcd_nx);   // XCD-aware: an XCD owns a contiguous range of row chunks
+    if (bx < 0) return;
+    const long run_lo = (long)bx * p.rows_per_block * runs_per_row;
     const long run_hi = min((long)rows * runs_per_row, run_lo + (long)p.rows_per_block * runs_per_row);
     float acc[KH][KW];
 #pragma unroll
@@ -497,6 +509,8 @@ int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st, boo
     const bool uniform = cdiv(a.W, TW) % wpr == 0 && (long)a.W * a.C * 4 < (1l << 31);
     if (!v1 && pays && uniform && a.kd == kw && a.kh == kw && a.dd == dil_w && a.dh == dil_w && (centre || !a.gb)) {
         dim3 grid2(xb, a.kd, cdiv(a.C, cpb));
+        a.xcd_nx = 0;
+        if (xcd_swizzle_enabled() && xb >= (unsigned)xcd_min_blocks()) { a.xcd_nx = xb; grid2.x = xcd_grid(xb); }
         if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
         else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_wgrad2_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
         else if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<3, 1, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }

@@ -39,7 +39,9 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
     __shared__ __attribute__((aligned(16))) float Bs[2][BSZ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int m = (blockIdx.x * 4 + wave) * 32 + i;      // this lane's A row
+    const int bx = DLKA_XCD_BX(p.xcd_nx);                // XCD-aware tile order: an XCD owns a contiguous range of row blocks
+    if (bx < 0) return;
+    const int m = (bx * 4 + wave) * 32 + i;              // this lane's A row
     const bool row_ok = m < p.M;
     const int b = row_ok ? m / p.N : 0;
     const int v = row_ok ? m - b * p.N : 0;
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
 
 #undef DLKA_LOAD_B
     // ---- epilogue: D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
-    const int mbase = (blockIdx.x * 4 + wave) * 32;
+    const int mbase = (bx * 4 + wave) * 32;
     const bool split = gridDim.y > 1;
     if (OMODE == 1) {
         // Planar output [B][Cout][N]: in the D layout a store instruction would scatter 32 lanes over 32 planes (4 bytes
@@ -303,10 +305,13 @@ static int launch_igemm_nt(const IgemmArgs &a, int splits, hipStream_t st)
     else if (NT_total == 4 && mblocks * splits < 256) NT = (mblocks * splits * 2 < 256) ? 1 : 2;
     else if (NT_total == 2 && mblocks * splits < 128) NT = 1;
     dim3 grid(mblocks, splits, NT_total / NT), block(256);
+    IgemmArgs ax = a;
+    ax.xcd_nx = 0;
+    if (xcd_swizzle_enabled() && a.K > 1 && mblocks >= (unsigned)xcd_min_blocks()) { ax.xcd_nx = mblocks; grid.x = xcd_grid(mblocks); }
 #define DLKA_IG(NTV)                                              \
     {                                                             \
         auto k = cl_igemm_kernel<AMODE, OMODE, NTV, SPLIT>;       \
-        hipLaunchKernelGGL(k, grid, block, 0, st, a);             \
+        hipLaunchKernelGGL(k, grid, block, 0, st, ax);            \
     }
     switch (NT) {
         case 1: DLKA_IG(1) break;

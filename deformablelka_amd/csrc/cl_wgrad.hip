@@ -654,7 +654,7 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
         static const bool v1 = getenv("DLKA_WGRAD_DEFORM_TPW") && atoi(getenv("DLKA_WGRAD_DEFORM_TPW")) == 0;
         dim3 grid(nchunks, OT * a.CT, cdiv(a.K, pl.tpw));
         static const bool no_xcd = getenv("DLKA_NO_XCD_SWIZZLE") != nullptr;   // A/B switch
-        if (!v1 && !no_xcd && nchunks >= 16) {
+        if (!v1 && !no_xcd && nchunks >= xcd_min_blocks()) {
             a.xcd_ny = grid.y; a.xcd_nz = grid.z; a.xcd_total = (int)(grid.x * grid.y * grid.z);
             grid = dim3(xcd_grid(a.xcd_total), 1, 1);
         }
@@ -665,7 +665,7 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
     } else {
         dim3 grid(nchunks, cdiv(OT, pl.cot) * a.CT, cdiv(a.K, pl.tpw));
         static const bool no_xcd2 = getenv("DLKA_NO_XCD_SWIZZLE") != nullptr;
-        if (!no_xcd2 && a.K > 1 && nchunks >= 16) {
+        if (!no_xcd2 && a.K > 1 && nchunks >= xcd_min_blocks()) {
             a.xcd_ny = grid.y; a.xcd_nz = grid.z; a.xcd_total = (int)(grid.x * grid.y * grid.z);
             grid = dim3(xcd_grid(a.xcd_total), 1, 1);
         }

@@ -1,5 +1,6 @@
 // Shared device/host helpers for the D-LKA HIP kernels (gfx950).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -66,6 +67,21 @@ __host__ __device__ __forceinline__ int xcd_item(int block, int total)
     return r < total ? r : -1;
 }
 __host__ __device__ __forceinline__ int xcd_grid(int total) { return 8 * ((total + 7) / 8); }
+// blockIdx.x of a launch whose x dimension enumerates spatial tiles: nx > 0 = swizzled (gridDim.x == xcd_grid(nx); since that is a multiple
+// of 8, the XCD of a block is blockIdx.x % 8 whatever blockIdx.y / z are), -1 for the padding blocks; nx == 0 = plain.
+#define DLKA_XCD_BX(nx) ((nx) > 0 ? xcd_item((int)blockIdx.x, (nx)) : (int)blockIdx.x)
+inline bool xcd_swizzle_enabled()
+{
+    static const bool on = getenv("DLKA_NO_XCD_SWIZZLE") == nullptr;
+    return on;
+}
+// launches with fewer tiles than this keep the plain order (nothing to gain); DLKA_XCD_MIN lowers it so that small test shapes take the
+// swizzled path too (not cached: tests toggle it)
+inline int xcd_min_blocks()
+{
+    const char *e = getenv("DLKA_XCD_MIN");
+    return e ? atoi(e) : 16;
+}
 
 #define DLKA_THREADS 256
 

@@ -166,3 +166,17 @@ def test_deform3d_cl_fixed_point_window(case):
         parity.check_deform3d_cl("cpu", B, C, Cout, dims, off_mode=mode)
     finally:
         del os.environ["DLKA_GX_FIXED"]
+
+
+def test_xcd_swizzled_tile_order():
+    """DLKA_XCD_MIN=1 sends these small shapes through the XCD-aware block -> tile mapping every spatially tiled kernel uses at full size
+    (contiguous tile ranges per XCD, padding blocks that exit): same results."""
+    import os
+    os.environ["DLKA_XCD_MIN"] = "1"
+    try:
+        parity.check_lka3d_tokens("cpu", 1, 32, (3, 4, 5))
+        parity.check_deform3d_cl("cpu", 2, 32, 32, (9, 8, 10), off_mode="wild")
+        parity.check_conv3d_cl("cpu", 1, 64, 32, (2, 3, 5), 3, 1, 1, 1, planar=False)
+        parity.check_conv3d_cl("cpu", 1, 32, 32, (7, 5, 10), 7, 9, 3, 32, planar=False)
+    finally:
+        del os.environ["DLKA_XCD_MIN"]
