@@ -400,6 +400,7 @@ struct GxGeom {
     int ngroups;            // ceil(K / TG)
     int resident;           // all tap groups' weight tiles fit in LDS next to the window
     int xcd_nx;             // > 0: blockIdx.x is mapped through xcd_item() (set by the launcher)
+    int item_grid;          // 1: 1-D grid over (brick, slice) items; 0: x = brick, y = slice
     int tap_far;            // 1: half-waves take taps 16 apart (K <= 32 = 4 groups of 8), see gx_tap()
     int ablate;             // profiling only (DLKA_GX_ABL): 1 = no LDS atomics, 2 = no sampling description / scatter at all
 };
@@ -441,10 +442,14 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
     float *Bs = reinterpret_cast<float *>(smem + (size_t)(gg.wvox_max + 64) * (FX ? CS / 2 : CS) * sizeof(double));   // [CoutP][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    // 1-D grid over (brick, slice) items, slices of a brick adjacent and an XCD owning a contiguous item range: the nslices workgroups of a
-    // brick read the same grad_out rows and offsets, and run next to each other in that XCD's L2 (fabric traffic 504 -> 199 MB per launch at
-    // 32^3, same time)
-    const int item = gg.xcd_nx > 0 ? xcd_item((int)blockIdx.x, gg.xcd_nx) : (int)blockIdx.x;
+    // XCD-aware order: an XCD owns a contiguous range of bricks (they share halo rows of grad_out / offsets); optionally (item_grid) a 1-D grid
+    // over (brick, slice) items with the slices of a brick adjacent
+    int item;
+    if (gg.item_grid) item = gg.xcd_nx > 0 ? xcd_item((int)blockIdx.x, gg.xcd_nx) : (int)blockIdx.x;
+    else {   // brick-major 2-D grid (x = brick, XCD-swizzled; y = slice)
+        const int bk = DLKA_XCD_BX(gg.xcd_nx);
+        item = bk < 0 ? -1 : bk * gg.nslices + (int)blockIdx.y;
+    }
     if (item < 0) return;
     const int brick = item / gg.nslices;
     int bid = brick;
@@ -815,12 +820,17 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
 #endif
         const int bricks = a.B * g.nbd * g.nbh * g.nbw;
         const int items = bricks * g.nslices;
-        gl_.xcd_nx = (xcd_swizzle_enabled() && items >= xcd_min_blocks()) ? items : 0;
-        const int gx_grid = gl_.xcd_nx ? xcd_grid(items) : items;
+        // A/B switch.  The item order (slices of a brick adjacent) cuts the fabric traffic further, 279 -> 199 MB per launch at 32^3, but costs
+        // 1 % of the whole step (15.6 vs 15.44 ms, two runs each): the eight slices of a brick then hit the same L2 channels at once.  Off.
+        const bool item_grid = getenv("DLKA_GX_ITEM_ORDER") ? atoi(getenv("DLKA_GX_ITEM_ORDER")) != 0 : false;
+        gl_.item_grid = item_grid ? 1 : 0;
+        const int nx = item_grid ? items : bricks;
+        gl_.xcd_nx = (xcd_swizzle_enabled() && nx >= xcd_min_blocks()) ? nx : 0;
+        const dim3 gx_grid(gl_.xcd_nx ? xcd_grid(nx) : nx, item_grid ? 1 : g.nslices);
         static int gx_threads = 0;
         if (!gx_threads) { const char *e = getenv("DLKA_GX_THREADS"); gx_threads = e ? atoi(e) : 512; if (gx_threads != 256 && gx_threads != 512) gx_threads = 512; }
-        if (fixed) { auto k = cl_deform_gx_kernel<true>; hipLaunchKernelGGL(k, dim3(gx_grid), dim3(gx_threads), lds, st, a, gl_, scratch); }
-        else { auto k = cl_deform_gx_kernel<false>; hipLaunchKernelGGL(k, dim3(gx_grid), dim3(gx_threads), lds, st, a, gl_, scratch); }
+        if (fixed) { auto k = cl_deform_gx_kernel<true>; hipLaunchKernelGGL(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
+        else { auto k = cl_deform_gx_kernel<false>; hipLaunchKernelGGL(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
         DLKA_CHECK_LAUNCH();
         const long total = (long)a.B * a.N * g.nslices;
         long gb = cdivl(total, 256);
