@@ -282,12 +282,14 @@ int launch_cl_layernorm_fwd(const float *x, int x_planar, const float *pos, cons
 }
 
 int launch_cl_layernorm_bwd(const float *g, const float *g_res, const float *xt, const float *stats, const float *w, float *gxt, float *gw, float *gb,
-                            float *gpos, int B, int N, int C, hipStream_t st)
+                            float *gpos, int B, int N, int C, hipStream_t st, bool zeroed)
 {
     if (C > 64 * KMAX) return DLKA_ERR_UNSUPPORTED;
-    DLKA_TRY_LAUNCH(launch_zero(gw, (size_t)C * 4, st));
-    DLKA_TRY_LAUNCH(launch_zero(gb, (size_t)C * 4, st));
-    if (gpos) DLKA_TRY_LAUNCH(launch_zero(gpos, (size_t)N * C * 4, st));
+    if (!zeroed) {   // (the fused block zero-fills every accumulation target of a direction with one launch)
+        DLKA_TRY_LAUNCH(launch_zero(gw, (size_t)C * 4, st));
+        DLKA_TRY_LAUNCH(launch_zero(gb, (size_t)C * 4, st));
+        if (gpos) DLKA_TRY_LAUNCH(launch_zero(gpos, (size_t)N * C * 4, st));
+    }
     hipLaunchKernelGGL(cl_layernorm_bwd_kernel, dim3(grid_for((long)B * N, NT / 64, 1024)), dim3(NT), (NT / 64) * 2 * C * sizeof(float), st, g, g_res, xt, stats, w, gxt, gw, gb,
                        gpos, B, N, C);
     DLKA_CHECK_LAUNCH();
@@ -301,9 +303,9 @@ int launch_cl_scale_residual_fwd(const float *xt, const float *e, const float *g
     return DLKA_OK;
 }
 
-int launch_cl_scale_residual_bwd(const float *g, const float *e, const float *gamma, float *ge, float *ggamma, long M, int C, hipStream_t st)
+int launch_cl_scale_residual_bwd(const float *g, const float *e, const float *gamma, float *ge, float *ggamma, long M, int C, hipStream_t st, bool zeroed)
 {
-    DLKA_TRY_LAUNCH(launch_zero(ggamma, (size_t)C * 4, st));
+    if (!zeroed) DLKA_TRY_LAUNCH(launch_zero(ggamma, (size_t)C * 4, st));
     const int rpb = NT / (C < NT ? C : NT);
     hipLaunchKernelGGL(cl_scale_residual_bwd_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), C * sizeof(float), st, g, e, gamma, ge, ggamma, M, C);
     DLKA_CHECK_LAUNCH();
@@ -311,9 +313,9 @@ int launch_cl_scale_residual_bwd(const float *g, const float *e, const float *ga
 }
 
 // sums: 2C floats of scratch; stats: 3C floats {mean, rstd, unbiased var}
-int launch_cl_bn_stats(const float *x, float *sums, float *stats, long M, int C, float eps, hipStream_t st)
+int launch_cl_bn_stats(const float *x, float *sums, float *stats, long M, int C, float eps, hipStream_t st, bool zeroed)
 {
-    DLKA_TRY_LAUNCH(launch_zero(sums, (size_t)2 * C * 4, st));
+    if (!zeroed) DLKA_TRY_LAUNCH(launch_zero(sums, (size_t)2 * C * 4, st));
     const int rpb = NT / (C < NT ? C : NT);
     hipLaunchKernelGGL(cl_bn_stats_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), 2 * C * sizeof(float), st, x, sums, M, C);
     DLKA_CHECK_LAUNCH();
@@ -331,9 +333,9 @@ int launch_cl_bn_apply(const float *x, const float *res, const float *w, const f
 }
 
 int launch_cl_bn_bwd(const float *g, const float *gmask, const float *x, const float *y, const float *w, const float *stats, float *sums, float *gx, float *gres,
-                     const float *gres_add, float *gw, float *gb, long M, long N, int C, float slope, int training, hipStream_t st)
+                     const float *gres_add, float *gw, float *gb, long M, long N, int C, float slope, int training, hipStream_t st, bool zeroed)
 {
-    DLKA_TRY_LAUNCH(launch_zero(sums, (size_t)2 * C * 4, st));
+    if (!zeroed) DLKA_TRY_LAUNCH(launch_zero(sums, (size_t)2 * C * 4, st));
     const int rpb = NT / (C < NT ? C : NT);
     hipLaunchKernelGGL(cl_bn_bwd_reduce_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), 2 * C * sizeof(float), st, g, gmask, x, y, stats, sums, gres, gres_add, M, N, C, slope);
     DLKA_CHECK_LAUNCH();

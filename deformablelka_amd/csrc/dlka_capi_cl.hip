@@ -808,6 +808,7 @@ bool tblock_supported(int B, int C, int D, int H, int W) { return tokens_support
 
 struct TBlockSaved {
     float *xt, *xn, *e, *attn, *c1, *a1, *c2, *rd, *lnstats;
+    float *w1_f, *w1_b, *w2_f, *w2_b, *w8_f, *w8_b;   // prepared weights (forward / data-gradient forms), written by ONE launch in forward
     void *lka;
     size_t lka_bytes;
 };
@@ -817,6 +818,9 @@ bool carve_tblock_saved(Carver &sv, const TBlockGeoms &G, int B, int C, int D, i
     S.xt = (float *)sv.take(G.E * 4); S.xn = (float *)sv.take(G.E * 4); S.e = (float *)sv.take(G.E * 4); S.attn = (float *)sv.take(G.E * 4);
     S.c1 = (float *)sv.take(G.E * 4); S.a1 = (float *)sv.take(G.E * 4); S.c2 = (float *)sv.take(G.E * 4); S.rd = (float *)sv.take(G.E * 4);
     S.lnstats = (float *)sv.take(G.M * 2 * 4);
+    S.w1_f = (float *)sv.take(dense_wp_floats(G.c3) * 4); S.w1_b = (float *)sv.take(dense_wp_floats(G.c3) * 4);
+    S.w2_f = (float *)sv.take(dense_wp_floats(G.c3) * 4); S.w2_b = (float *)sv.take(dense_wp_floats(G.c3) * 4);
+    S.w8_f = (float *)sv.take(dense_wp_floats(G.pw) * 4); S.w8_b = (float *)sv.take(dense_wp_floats(G.pw) * 4);
     S.lka_bytes = dlka_lka3d_tokens_saved_bytes(B, C, D, H, W, DLKA_F32);
     S.lka = sv.take(S.lka_bytes);
     return sv.ok();
@@ -830,15 +834,16 @@ size_t dlka_tblock3d_saved_bytes(int B, int C, int D, int H, int W, int dtype)
 {
     if (!dlka_tblock3d_supported(B, C, D, H, W, dtype)) return 0;
     TBlockGeoms G(B, C, D, H, W);
-    return 8 * align256(G.E * 4) + align256(G.M * 2 * 4) + align256(dlka_lka3d_tokens_saved_bytes(B, C, D, H, W, dtype));
+    return 8 * align256(G.E * 4) + align256(G.M * 2 * 4) + 4 * align256(dense_wp_floats(G.c3) * 4) + 2 * align256(dense_wp_floats(G.pw) * 4) +
+           align256(dlka_lka3d_tokens_saved_bytes(B, C, D, H, W, dtype));
 }
 
 size_t dlka_tblock3d_workspace_bytes(int B, int C, int D, int H, int W, int dtype)
 {
     if (!dlka_tblock3d_supported(B, C, D, H, W, dtype)) return 0;
     TBlockGeoms G(B, C, D, H, W);
-    return align256(dlka_lka3d_tokens_workspace_bytes(B, C, D, H, W, dtype)) + align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) +
-           6 * align256(G.E * 4) + align256(4096);
+    return align256(dlka_lka3d_tokens_workspace_bytes(B, C, D, H, W, dtype)) + align256(G.wp_floats() * 4) + 2 * align256(G.part_floats() * 4) +
+           align256(cl_wgrad_part_floats(G.pw.M, 1, G.pw.Cout, G.pw.Cin) * 4) + 6 * align256(G.E * 4) + align256(4096);
 }
 
 int dlka_tblock3d_forward(const void *x, int x_planar, const dlka_tblock3d_params *p, const dlka_lka3d_params *lka, const void *drop_mask, int training,
@@ -863,6 +868,25 @@ int dlka_tblock3d_forward(const void *x, int x_planar, const dlka_tblock3d_param
     const long M = (long)G.M, N = G.c3.N;
     float *st1 = (float *)bn_stats, *st2 = st1 + 3 * C;
     const float slope = 0.01f;   // UnetResBlock's act_name default (dynunet_block.py:41)
+    (void)wp;
+    // ONE launch prepares the wrapper's six weight forms (kept in `saved` for the backward call) and zero-fills what this direction accumulates
+    // into with atomics (BatchNorm sums, tap-split conv outputs)
+    {
+        PrepBatch pb;
+        memset(&pb, 0, sizeof(pb));
+        const int f3 = split_mode_flag(use_split(G.c3, true)), b3 = 1 | split_mode_flag(use_split(G.c3, false));
+        add_job(pb, p->conv51_conv1_w, S.w1_f, C, C, 27, C, C, f3);
+        add_job(pb, p->conv51_conv1_w, S.w1_b, C, C, 27, C, C, b3);
+        add_job(pb, p->conv51_conv2_w, S.w2_f, C, C, 27, C, C, f3);
+        add_job(pb, p->conv51_conv2_w, S.w2_b, C, C, 27, C, C, b3);
+        add_job(pb, p->conv8_w, S.w8_f, C, C, 1, C, C, 0);
+        add_job(pb, p->conv8_w, S.w8_b, C, C, 1, C, C, 1);
+        auto add_zero = [&](float *ptr, size_t n) { PrepJob &j = pb.j[pb.njobs++]; memset(&j, 0, sizeof(j)); j.dst = ptr; j.n = (long)n; j.mode = 5; pb.total += j.n; };
+        add_zero(sums, 1024);
+        if (dense_forward_splits(G.c3, 0) > 1) { add_zero(S.c1, G.E); add_zero(S.c2, G.E); }
+        if (dense_forward_splits(G.pw, 3) > 1) add_zero((float *)y, G.E);
+        DLKA_TRY(launch_cl_prep_batch(pb, st));
+    }
     // tokens (+ pos_embed) and LayerNorm (:620-624)
     DLKA_TRY(launch_cl_layernorm_fwd((const float *)x, x_planar, (const float *)p->pos_embed, (const float *)p->norm_w, (const float *)p->norm_b, S.xt, S.xn,
                                      S.lnstats, B, (int)N, C, ln_eps, st));
@@ -871,15 +895,15 @@ int dlka_tblock3d_forward(const void *x, int x_planar, const dlka_tblock3d_param
     // attn = x + gamma * epa (:624); attn IS attn_skip in channels-last memory (:626 is a view here)
     DLKA_TRY(launch_cl_scale_residual_fwd(S.xt, S.e, (const float *)p->gamma, S.attn, M, C, st));
     // conv51 = UnetResBlock (dynunet_block.py:66-80)
-    DLKA_TRY(dense_forward(G.c3, S.attn, (const float *)p->conv51_conv1_w, nullptr, S.c1, 0, wp, 0, nullptr, nullptr, st));
-    if (training) DLKA_TRY(launch_cl_bn_stats(S.c1, sums, st1, M, C, bn_eps, st));
+    DLKA_TRY(dense_forward(G.c3, S.attn, nullptr, nullptr, S.c1, 0, S.w1_f, 0, nullptr, nullptr, st, true));
+    if (training) DLKA_TRY(launch_cl_bn_stats(S.c1, sums, st1, M, C, bn_eps, st, true));
     DLKA_TRY(launch_cl_bn_apply(S.c1, nullptr, (const float *)p->conv51_norm1_w, (const float *)p->conv51_norm1_b, st1, nullptr, S.a1, M, N, C, slope, st));
-    DLKA_TRY(dense_forward(G.c3, S.a1, (const float *)p->conv51_conv2_w, nullptr, S.c2, 0, wp, 0, nullptr, nullptr, st));
-    if (training) DLKA_TRY(launch_cl_bn_stats(S.c2, sums, st2, M, C, bn_eps, st));
+    DLKA_TRY(dense_forward(G.c3, S.a1, nullptr, nullptr, S.c2, 0, S.w2_f, 0, nullptr, nullptr, st, true));
+    if (training) DLKA_TRY(launch_cl_bn_stats(S.c2, sums + 512, st2, M, C, bn_eps, st, true));
     // ... + residual, LeakyReLU, and conv8[0] = Dropout3d folded into the same pass (:611)
     DLKA_TRY(launch_cl_bn_apply(S.c2, S.attn, (const float *)p->conv51_norm2_w, (const float *)p->conv51_norm2_b, st2, (const float *)drop_mask, S.rd, M, N, C, slope, st));
     // x = attn_skip + conv8(attn) (:628)
-    DLKA_TRY(dense_forward(G.pw, S.rd, (const float *)p->conv8_w, (const float *)p->conv8_b, (float *)y, 0, wp, 3, S.attn, nullptr, st));
+    DLKA_TRY(dense_forward(G.pw, S.rd, nullptr, (const float *)p->conv8_b, (float *)y, 0, S.w8_f, 3, S.attn, nullptr, st, true));
     return DLKA_OK;
 }
 
@@ -900,8 +924,9 @@ int dlka_tblock3d_backward(const dlka_tblock3d_params *p, const dlka_lka3d_param
     if (!carve_tblock_saved(sv, G, B, C, D, H, W, S)) return DLKA_ERR_WORKSPACE;
     const size_t lka_ws_bytes = dlka_lka3d_tokens_workspace_bytes(B, C, D, H, W, dtype);
     void *lka_ws = cv.take(lka_ws_bytes);
-    float *wp = (float *)cv.take(G.wp_floats() * 4);
-    float *part = (float *)cv.take(G.part_floats() * 4);
+    (void)cv.take(G.wp_floats() * 4);   // (layout kept: the forward call carves the same region)
+    float *part1 = (float *)cv.take(G.part_floats() * 4), *part2 = (float *)cv.take(G.part_floats() * 4);
+    float *part8 = (float *)cv.take(cl_wgrad_part_floats(G.pw.M, 1, G.pw.Cout, G.pw.Cin) * 4);
     float *b0 = (float *)cv.take(G.E * 4), *b1 = (float *)cv.take(G.E * 4), *b2 = (float *)cv.take(G.E * 4), *b3 = (float *)cv.take(G.E * 4);
     float *b4 = (float *)cv.take(G.E * 4), *b5 = (float *)cv.take(G.E * 4);
     float *sums = (float *)cv.take(4096);
@@ -910,35 +935,46 @@ int dlka_tblock3d_backward(const dlka_tblock3d_params *p, const dlka_lka3d_param
     const float *st1 = (const float *)bn_stats, *st2 = st1 + 3 * C;
     const float *gy = (const float *)grad_y, *mask = (const float *)drop_mask;
     const float slope = 0.01f;
+    float *g_rd = b0, *g_c2 = b1, *g_skip = b2, *g_attn = b3, *g_a1 = b4, *g_c1 = b1, *g_e = b4, *g_xn = b5;
+    // everything this direction accumulates into with atomics, zero-filled by ONE launch; the weight re-layouts were done by the forward call;
+    // the three weight-gradient folds are ONE launch
+    {
+        ZeroBatch zb;
+        memset(&zb, 0, sizeof(zb));
+        zb.add(sums, 1024);
+        zb.add((float *)gr->gamma, C);
+        zb.add((float *)gr->norm_w, C);
+        zb.add((float *)gr->norm_b, C);
+        if (gr->pos_embed) zb.add((float *)gr->pos_embed, (size_t)N * C);
+        if (dense_backward_data_splits(G.c3, 0) > 1) zb.add(g_a1, G.E);
+        if (dense_backward_data_splits(G.c3, 3) > 1) zb.add(g_attn, G.E);
+        DLKA_TRY(launch_zero_batch(zb, st));
+    }
+    FinalizeBatch fb;
+    memset(&fb, 0, sizeof(fb));
     // conv8[1]:  y = W8 rd + b8 + attn
-    float *g_rd = b0;
-    DLKA_TRY(dense_backward_weight(G.pw, S.rd, gy, 0, (float *)gr->conv8_w, (float *)gr->conv8_b, part, st));
-    DLKA_TRY(dense_backward_data(G.pw, gy, 0, (const float *)p->conv8_w, g_rd, wp, 0, nullptr, st));
+    DLKA_TRY(dense_backward_weight(G.pw, S.rd, gy, 0, (float *)gr->conv8_w, (float *)gr->conv8_b, part8, st, &fb.j[fb.njobs++]));
+    DLKA_TRY(dense_backward_data(G.pw, gy, 0, nullptr, g_rd, S.w8_b, 0, nullptr, st, nullptr, nullptr, true));
     // Dropout3d + LeakyReLU + (BN2(c2) + attn):  g_c2, and everything that flows into attn so far:  g_skip = gy + g_pre
-    float *g_c2 = b1, *g_skip = b2;
     DLKA_TRY(launch_cl_bn_bwd(g_rd, mask, S.c2, S.rd, (const float *)p->conv51_norm2_w, st2, sums, g_c2, g_skip, gy, (float *)gr->conv51_norm2_w,
-                              (float *)gr->conv51_norm2_b, M, N, C, slope, training, st));
+                              (float *)gr->conv51_norm2_b, M, N, C, slope, training, st, true));
     // conv2
-    float *g_a1 = b0;
-    DLKA_TRY(dense_backward_weight(G.c3, S.a1, g_c2, 0, (float *)gr->conv51_conv2_w, nullptr, part, st));
-    DLKA_TRY(dense_backward_data(G.c3, g_c2, 0, (const float *)p->conv51_conv2_w, g_a1, wp, 0, nullptr, st));
+    DLKA_TRY(dense_backward_weight(G.c3, S.a1, g_c2, 0, (float *)gr->conv51_conv2_w, nullptr, part2, st, &fb.j[fb.njobs++]));
+    DLKA_TRY(dense_backward_data(G.c3, g_c2, 0, nullptr, g_a1, S.w2_b, 0, nullptr, st, nullptr, nullptr, true));
     // LeakyReLU + BN1
-    float *g_c1 = b1;
     DLKA_TRY(launch_cl_bn_bwd(g_a1, nullptr, S.c1, S.a1, (const float *)p->conv51_norm1_w, st1, sums + 512, g_c1, nullptr, nullptr, (float *)gr->conv51_norm1_w,
-                              (float *)gr->conv51_norm1_b, M, N, C, slope, training, st));
+                              (float *)gr->conv51_norm1_b, M, N, C, slope, training, st, true));
     // conv1:  g_attn = W1^T g_c1 + g_skip
-    float *g_attn = b3;
-    DLKA_TRY(dense_backward_weight(G.c3, S.attn, g_c1, 0, (float *)gr->conv51_conv1_w, nullptr, part, st));
-    DLKA_TRY(dense_backward_data(G.c3, g_c1, 0, (const float *)p->conv51_conv1_w, g_attn, wp, 3, g_skip, st));
+    DLKA_TRY(dense_backward_weight(G.c3, S.attn, g_c1, 0, (float *)gr->conv51_conv1_w, nullptr, part1, st, &fb.j[fb.njobs++]));
+    DLKA_TRY(launch_cl_wgrad_finalize(fb, st));
+    DLKA_TRY(dense_backward_data(G.c3, g_c1, 0, nullptr, g_attn, S.w1_b, 3, g_skip, st, nullptr, nullptr, true));
     // attn = xt + gamma * e
-    float *g_e = b4;
-    DLKA_TRY(launch_cl_scale_residual_bwd(g_attn, S.e, (const float *)p->gamma, g_e, (float *)gr->gamma, M, C, st));
+    DLKA_TRY(launch_cl_scale_residual_bwd(g_attn, S.e, (const float *)p->gamma, g_e, (float *)gr->gamma, M, C, st, true));
     // epa_block
-    float *g_xn = b5;
     DLKA_TRY(dlka_lka3d_attention_tokens_backward(S.xn, lka, g_e, S.lka, S.lka_bytes, g_xn, glka, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, stream));
     // LayerNorm (+ the residual branch g_attn), pos_embed
     DLKA_TRY(launch_cl_layernorm_bwd(g_xn, g_attn, S.xt, S.lnstats, (const float *)p->norm_w, (float *)grad_x, (float *)gr->norm_w, (float *)gr->norm_b,
-                                     (float *)gr->pos_embed, B, (int)N, C, st));
+                                     (float *)gr->pos_embed, B, (int)N, C, st, true));
     return DLKA_OK;
 }
 

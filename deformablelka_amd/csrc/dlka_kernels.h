@@ -75,14 +75,14 @@ int cl_deform_goff_ccsplit(const DeformBwdArgs &a);
 int launch_cl_layernorm_fwd(const float *x, int x_planar, const float *pos, const float *w, const float *b, float *xt, float *xn, float *stats, int B, int N,
                             int C, float eps, hipStream_t st);
 int launch_cl_layernorm_bwd(const float *g, const float *g_res, const float *xt, const float *stats, const float *w, float *gxt, float *gw, float *gb,
-                            float *gpos, int B, int N, int C, hipStream_t st);
+                            float *gpos, int B, int N, int C, hipStream_t st, bool zeroed = false);
 int launch_cl_scale_residual_fwd(const float *xt, const float *e, const float *gamma, float *out, long M, int C, hipStream_t st);
-int launch_cl_scale_residual_bwd(const float *g, const float *e, const float *gamma, float *ge, float *ggamma, long M, int C, hipStream_t st);
-int launch_cl_bn_stats(const float *x, float *sums, float *stats, long M, int C, float eps, hipStream_t st);
+int launch_cl_scale_residual_bwd(const float *g, const float *e, const float *gamma, float *ge, float *ggamma, long M, int C, hipStream_t st, bool zeroed = false);
+int launch_cl_bn_stats(const float *x, float *sums, float *stats, long M, int C, float eps, hipStream_t st, bool zeroed = false);
 int launch_cl_bn_apply(const float *x, const float *res, const float *w, const float *b, const float *stats, const float *mask, float *y, long M, long N, int C,
                        float slope, hipStream_t st);
 int launch_cl_bn_bwd(const float *g, const float *gmask, const float *x, const float *y, const float *w, const float *stats, float *sums, float *gx, float *gres,
-                     const float *gres_add, float *gw, float *gb, long M, long N, int C, float slope, int training, hipStream_t st);
+                     const float *gres_add, float *gw, float *gb, long M, long N, int C, float slope, int training, hipStream_t st, bool zeroed = false);
 int launch_cl_channel_scale(const float *x, const float *mask, float *y, int B, long N, int C, hipStream_t st);
 
 }  // namespace dlka
