@@ -25,6 +25,13 @@ __device__ __forceinline__ float wave_sum(float v)
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// sum over the 32-lane half this lane belongs to (C <= 32: a wave carries two token rows)
+__device__ __forceinline__ float half_sum(float v)
+{
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 }  // namespace
 
 // One wave per token row: x (planar [B][C][N] — the NCDHW tensor the block receives — or channels-last [M][C]) (+ pos[N][C])
@@ -35,6 +42,28 @@ __global__ __launch_bounds__(NT) void cl_layernorm_fwd_kernel(const float *__res
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long M = (long)B * N;
+    if (C <= 32) {   // two token rows per wave: lanes 0-31 / 32-63 (a 32-channel row would leave half the wave idle)
+        const int c = lane & 31, hh = lane >> 5;
+        for (long m0 = ((long)blockIdx.x * (NT / 64) + wave) * 2; m0 < M; m0 += (long)gridDim.x * (NT / 64) * 2) {
+            const long m = m0 + hh;
+            const bool ok = m < M && c < C;
+            const int bb = ok ? (int)(m / N) : 0, v = ok ? (int)(m - (long)bb * N) : 0;
+            float val = 0.f;
+            if (ok) {
+                val = x_planar ? x[((long)bb * C + c) * N + v] : x[m * C + c];
+                if (pos) val += pos[(long)v * C + c];
+                xt[m * C + c] = val;
+            }
+            const float mean = half_sum(val) / C;
+            const float var = fmaxf(half_sum(val * val) / C - mean * mean, 0.f);
+            const float rstd = 1.f / sqrtf(var + eps);
+            if (ok) {
+                xn[m * C + c] = (val - mean) * rstd * w[c] + b[c];
+                if (c == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
+            }
+        }
+        return;
+    }
     for (long m = (long)blockIdx.x * (NT / 64) + wave; m < M; m += (long)gridDim.x * (NT / 64)) {
         const int bb = (int)(m / N), v = (int)(m - (long)bb * N);
         float s = 0.f, s2 = 0.f;
@@ -68,6 +97,41 @@ __global__ __launch_bounds__(NT) void cl_layernorm_bwd_kernel(const float *__res
     float aw[KMAX], ab[KMAX];   // this lane's channels lane + 64k: partial sums over the rows of this wave (registers, no LDS atomics)
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) { aw[k] = 0.f; ab[k] = 0.f; }
+    if (C <= 32) {   // two token rows per wave (see the forward kernel); the two halves' channel sums meet in LDS below
+        const int c = lane & 31, hh = lane >> 5;
+        float a_w = 0.f, a_b = 0.f;
+        for (long m0 = ((long)blockIdx.x * (NT / 64) + wave) * 2; m0 < M; m0 += (long)gridDim.x * (NT / 64) * 2) {
+            const long m = m0 + hh;
+            const bool ok = m < M && c < C;
+            float xh = 0.f, dxh = 0.f, rstd = 0.f;
+            if (ok) {
+                const float gv = g[m * C + c];
+                rstd = stats[2 * m + 1];
+                xh = (xt[m * C + c] - stats[2 * m]) * rstd;
+                dxh = gv * w[c];
+                a_w = fmaf(gv, xh, a_w);
+                a_b += gv;
+            }
+            const float s1 = half_sum(dxh) / C, s2 = half_sum(dxh * xh) / C;
+            if (ok) {
+                float val = rstd * (dxh - s1 - xh * s2);
+                if (g_res) val += g_res[m * C + c];
+                gxt[m * C + c] = val;
+                if (gpos) atomicAdd(gpos + (long)(m % N) * C + c, val);
+            }
+        }
+        a_w += __shfl_xor(a_w, 32);
+        a_b += __shfl_xor(a_b, 32);
+        if (lane < 32 && c < C) { red[(wave * 2 + 0) * C + c] = a_w; red[(wave * 2 + 1) * C + c] = a_b; }
+        __syncthreads();
+        for (int cc = threadIdx.x; cc < C; cc += NT) {
+            float sw = 0.f, sb = 0.f;
+            for (int wv = 0; wv < NT / 64; ++wv) { sw += red[(wv * 2 + 0) * C + cc]; sb += red[(wv * 2 + 1) * C + cc]; }
+            atomicAdd(gw + cc, sw);
+            atomicAdd(gb + cc, sb);
+        }
+        return;
+    }
     for (long m = (long)blockIdx.x * (NT / 64) + wave; m < M; m += (long)gridDim.x * (NT / 64)) {
         const float mean = stats[2 * m], rstd = stats[2 * m + 1];
         float s1 = 0.f, s2 = 0.f, xh[KMAX], dxh[KMAX];
@@ -159,7 +223,14 @@ __global__ __launch_bounds__(NT) void cl_bn_stats_kernel(const float *__restrict
         const int c = cb + c_in;
         if (r_in < rpb && c < C) {
             float s = 0.f, s2 = 0.f;
-            for (long m = (long)blockIdx.x * rpb + r_in; m < M; m += (long)gridDim.x * rpb) {
+            const long step = (long)gridDim.x * rpb;
+            long m = (long)blockIdx.x * rpb + r_in;
+            for (; m + 3 * step < M; m += 4 * step) {   // four rows in flight per work-item (the loop is pure load latency otherwise)
+                const float v0 = x[m * C + c], v1 = x[(m + step) * C + c], v2 = x[(m + 2 * step) * C + c], v3 = x[(m + 3 * step) * C + c];
+                s += (v0 + v1) + (v2 + v3);
+                s2 = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, s2))));
+            }
+            for (; m < M; m += step) {
                 const float v = x[m * C + c];
                 s += v;
                 s2 = fmaf(v, v, s2);
@@ -215,7 +286,21 @@ __global__ __launch_bounds__(NT) void cl_bn_bwd_reduce_kernel(const float *__res
         if (r_in < rpb && c < C) {
             const float mean = stats[c], rstd = stats[C + c];
             float s = 0.f, s2 = 0.f;
-            for (long m = (long)blockIdx.x * rpb + r_in; m < M; m += (long)gridDim.x * rpb) {
+            const long step = (long)gridDim.x * rpb;
+            long m = (long)blockIdx.x * rpb + r_in;
+            for (; m + step < M; m += 2 * step) {   // two rows (six to eight loads) in flight per work-item
+                const long i0 = m * C + c, i1 = (m + step) * C + c;
+                const float g0 = g[i0], g1 = g[i1], y0 = y[i0], y1 = y[i1], x0 = x[i0], x1 = x[i1];
+                float gp0 = g0 * (y0 > 0.f ? 1.f : slope), gp1 = g1 * (y1 > 0.f ? 1.f : slope);
+                if (gmask) { gp0 *= gmask[(m / N) * C + c]; gp1 *= gmask[((m + step) / N) * C + c]; }
+                if (gres) {
+                    gres[i0] = gres_add ? gp0 + gres_add[i0] : gp0;
+                    gres[i1] = gres_add ? gp1 + gres_add[i1] : gp1;
+                }
+                s += gp0 + gp1;
+                s2 = fmaf(gp0, (x0 - mean) * rstd, fmaf(gp1, (x1 - mean) * rstd, s2));
+            }
+            for (; m < M; m += step) {
                 const long i = m * C + c;
                 float gp = g[i] * (y[i] > 0.f ? 1.f : slope);
                 if (gmask) gp *= gmask[(m / N) * C + c];
