@@ -22,12 +22,15 @@ def _free_port():
     return p
 
 
-def _make_stack(data_seed):
+STAGES2 = ((32, (2, 2, 3), 1), (64, (2, 2, 2), 1))   # two stages: the overlapped schedule cuts the backward pass between them
+
+
+def _make_stack(data_seed, stages=STAGES):
     from deformablelka_amd import _lib
     from deformablelka_amd.stack import DLKABlockStack
     from tests import emu
     _lib._set_backend_for_tests(emu.load())
-    st = DLKABlockStack(1, stages=STAGES, device="cpu", seed=7)            # same parameters on every rank
+    st = DLKABlockStack(1, stages=stages, device="cpu", seed=7)            # same parameters on every rank
     g = torch.Generator().manual_seed(1000 + data_seed)                    # rank-specific inputs / grad_outputs
     for chain in st.chains:
         chain[0].x.copy_(torch.randn(chain[0].x.shape, generator=g))
@@ -75,3 +78,44 @@ def test_single_rank_update_needs_no_process_group():
     from deformablelka_amd import _lib
     _lib._set_backend_for_tests(None)
     assert torch.allclose(st.flat_params, p0 - LR * st.flat_grads)
+
+
+def _worker_overlapped(rank, world, port, out):
+    """The schedule bench.py runs for N > 1: backward of the late (parameter-heavy) blocks, their all-reduce asynchronously, the rest of
+    the backward pass, the second all-reduce, both waits, then the update."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIPEMU_THREADS="2")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    st = _make_stack(rank, STAGES2)
+    split = st.split_index(0.5)   # the C = 64 block holds 72 % of the gradient bytes of this two-stage stack
+    cut = st.grad_offset_of(split)
+    assert 0 < split < len(st.blocks) and 0 < cut < st.flat_grads.numel()
+    st.forward()
+    st.backward(split, None)
+    w1 = dist.all_reduce(st.flat_grads[cut:], async_op=True)
+    st.backward(0, split)
+    w2 = dist.all_reduce(st.flat_grads[:cut], async_op=True)
+    w1.wait()
+    w2.wait()
+    st.flat_params.add_(st.flat_grads, alpha=-LR / world)
+    if rank == 0:
+        torch.save({"params": st.flat_params.clone(), "grads": st.flat_grads.clone()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_overlapped_allreduce_schedule_matches_single_process(tmp_path):
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_worker_overlapped, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    gsum, p0 = None, None
+    for r in range(2):
+        st = _make_stack(r, STAGES2)
+        p0 = st.flat_params.clone()
+        st.forward_backward()
+        gsum = st.flat_grads.clone() if gsum is None else gsum + st.flat_grads
+    from deformablelka_amd import _lib
+    _lib._set_backend_for_tests(None)
+    assert torch.allclose(got["grads"], gsum, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(got["params"], p0 - LR / 2 * gsum, rtol=1e-5, atol=1e-6)
