@@ -64,6 +64,7 @@ SIGNATURES = {
     "dlka_deform_conv3d_backward_workspace": (c_size_t, [_G, c_int]),
     "dlka_deform_conv3d_backward": (c_int, [c_void_p] * 9 + [c_size_t, _G, c_int, c_void_p]),
     "dlka_deform_conv3d_sample_index": (c_int, [c_void_p] * 3 + [_G, c_int, c_void_p]),
+    "dlka_deform_conv3d_sample_index_path": (c_int, [c_void_p] * 3 + [_G, c_int, c_int, c_void_p]),
     "dlka_deform_conv2d_forward_workspace": (c_size_t, [_G, c_int]),
     "dlka_deform_conv2d_forward": (c_int, [c_void_p] * 6 + [c_size_t, _G, c_int, c_void_p]),
     "dlka_deform_conv2d_backward_workspace": (c_size_t, [_G, c_int]),

@@ -20,6 +20,7 @@
 //                           adds the result to grad_input: no flush atomics.
 #include <stdlib.h>
 
+#include <atomic>
 #include "cl_args.h"
 #include "cl_gather.h"
 #include "dlka_kernels.h"
@@ -810,12 +811,17 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const size_t lds = gl_.resident ? lds_all : lds_win + (size_t)a.CoutP * 32 * sizeof(float);
         if (lds > 160 * 1024) return DLKA_ERR_UNSUPPORTED;
 #if !defined(HIPEMU)
-        static bool attr_done = false;   // dynamic LDS above 64 KB has to be enabled once per function
-        if (!attr_done) {
+        // dynamic LDS above 64 KB has to be enabled per function AND per device (a process may drive several GPUs,
+        // e.g. nn.DataParallel in the reference trainers); one bit per device, set after the attribute call succeeded
+        static std::atomic<uint64_t> attr_done{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return DLKA_ERR_LAUNCH;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(attr_done.load(std::memory_order_acquire) & bit)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(cl_deform_gx_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void *>(cl_deform_gx_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return DLKA_ERR_LAUNCH;
-            attr_done = true;
+            attr_done.fetch_or(bit, std::memory_order_release);
         }
 #endif
         const int bricks = a.B * g.nbd * g.nbh * g.nbw;

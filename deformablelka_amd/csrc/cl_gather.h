@@ -18,6 +18,7 @@ struct RowDesc {
     int base;        // b*N + linear index of corner 000 (coordinates may be -1: only corners flagged in okm are addressed)
     unsigned okm;    // bit q: corner q inside the volume and the sample inside the guard
     float ld, lh, lw;
+    int zd, zh, zw;  // floor cell (read by the index-parity debug entry only; dead in the hot kernels)
 };
 
 constexpr int GATHER_DESC_WORDS = 8;   // LDS words per row in the description table
@@ -27,6 +28,7 @@ __device__ __forceinline__ RowDesc gather_describe3(float od, float oh, float ow
 {
     RowDesc r;
     r.base = 0; r.okm = 0; r.ld = r.lh = r.lw = 0.f;
+    r.zd = r.zh = r.zw = 0;
     const float qd = (float)bd + od;
     const float qh = (float)bh + oh;
     const float qw = (float)bw + ow;
@@ -35,6 +37,7 @@ __device__ __forceinline__ RowDesc gather_describe3(float od, float oh, float ow
         const float fd_ = floorf(qd), fh_ = floorf(qh), fw_ = floorf(qw);
         const int zd = (int)fd_, zh = (int)fh_, zw = (int)fw_;
         r.ld = qd - fd_; r.lh = qh - fh_; r.lw = qw - fw_;
+        r.zd = zd; r.zh = zh; r.zw = zw;
         r.base = b * (int)N + (zd * H + zh) * W + zw;
         const unsigned vd0 = zd >= 0, vd1 = zd + 1 <= D - 1, vh0 = zh >= 0, vh1 = zh + 1 <= H - 1, vw0 = zw >= 0, vw1 = zw + 1 <= W - 1;
         unsigned okm = 0;

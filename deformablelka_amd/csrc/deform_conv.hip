@@ -12,6 +12,7 @@
 // deformable groups).  Faster shape-specialised kernels for the D-LKA hot configuration live in
 // deform_conv_tiled.hip and are chosen by the dispatcher in dlka_capi.hip.
 #include "deform_sample.h"
+#include "cl_gather.h"
 #include "dlka_kernels.h"
 
 namespace dlka {
@@ -396,7 +397,10 @@ int launch_cast_from_f32(const float *src, T *dst, long n, hipStream_t st)
 // ---------------------------------------------------------------------------------------------
 // debug: floor indices + guard mask (bit-exact index parity)
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+// path 0: the rule written out on its own; path 1: through setup_tap<3> (what every general-path kernel calls);
+// path 2: through gather_describe3 (what every channels-last fast-path kernel calls).  Paths 1/2 report the cell only where
+// the guard holds (outside it the hot kernels never form an address).
+template <typename T, int PATH>
 __global__ void sample_index_kernel(const T *__restrict__ off, int32_t *__restrict__ idx, uint8_t *__restrict__ mask, Geom g)
 {
     const long n = (long)g.B * g.dg * g.K * g.No;
@@ -406,24 +410,42 @@ __global__ void sample_index_kernel(const T *__restrict__ off, int32_t *__restri
         const int ow = v % g.Wo, oh = (v / g.Wo) % g.Ho, od = v / (g.Wo * g.Ho);
         const int k = tap % g.kw, j = (tap / g.kw) % g.kh, i = tap / (g.kw * g.kh);
         const T *offp = off + (bg * 3 * g.K + 3 * tap) * g.No + v;
-        const float qd = (float)(od * g.sd - g.pd + i * g.dd) + ldf(offp);
-        const float qh = (float)(oh * g.sh - g.ph + j * g.dh) + ldf(offp + g.No);
-        const float qw = (float)(ow * g.sw - g.pw + k * g.dw) + ldf(offp + 2 * (long)g.No);
-        idx[e * 3 + 0] = (int32_t)floorf(qd);
-        idx[e * 3 + 1] = (int32_t)floorf(qh);
-        idx[e * 3 + 2] = (int32_t)floorf(qw);
-        mask[e] = (qd > -1.f && qh > -1.f && qw > -1.f && qd < (float)g.D && qh < (float)g.H && qw < (float)g.W) ? 1 : 0;
+        const int bd = od * g.sd - g.pd + i * g.dd, bh = oh * g.sh - g.ph + j * g.dh, bw = ow * g.sw - g.pw + k * g.dw;
+        if (PATH == 0) {
+            const float qd = (float)bd + ldf(offp);
+            const float qh = (float)bh + ldf(offp + g.No);
+            const float qw = (float)bw + ldf(offp + 2 * (long)g.No);
+            idx[e * 3 + 0] = (int32_t)floorf(qd);
+            idx[e * 3 + 1] = (int32_t)floorf(qh);
+            idx[e * 3 + 2] = (int32_t)floorf(qw);
+            mask[e] = (qd > -1.f && qh > -1.f && qw > -1.f && qd < (float)g.D && qh < (float)g.H && qw < (float)g.W) ? 1 : 0;
+        } else if (PATH == 1) {
+            TapSample<3> s;
+            setup_tap<3, T>(s, offp, g.No, bd, bh, bw, g.D, g.H, g.W);
+            idx[e * 3 + 0] = s.inside ? s.z0[0] : 0;
+            idx[e * 3 + 1] = s.inside ? s.z0[1] : 0;
+            idx[e * 3 + 2] = s.inside ? s.z0[2] : 0;
+            mask[e] = s.inside ? 1 : 0;
+        } else {
+            const RowDesc r = gather_describe3(ldf(offp), ldf(offp + g.No), ldf(offp + 2 * (long)g.No), (long)g.Ni, 0, bd, bh, bw, g.D, g.H, g.W);
+            idx[e * 3 + 0] = r.zd;
+            idx[e * 3 + 1] = r.zh;
+            idx[e * 3 + 2] = r.zw;
+            mask[e] = r.okm ? 1 : 0;   // inside the guard <=> at least one corner contributes
+        }
     }
 }
 
 template <typename T>
-int launch_sample_index(const T *off, int32_t *idx, uint8_t *mask, const Geom &g, hipStream_t st)
+int launch_sample_index(const T *off, int32_t *idx, uint8_t *mask, const Geom &g, int path, hipStream_t st)
 {
     const long n = (long)g.B * g.dg * g.K * g.No;
     long blocks = cdivl(n, 256);
     if (blocks > 8192) blocks = 8192;
-    auto k = sample_index_kernel<T>;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), 0, st, off, idx, mask, g);
+    if (path == 0) hipLaunchKernelGGL((sample_index_kernel<T, 0>), dim3((unsigned)blocks), dim3(256), 0, st, off, idx, mask, g);
+    else if (path == 1) hipLaunchKernelGGL((sample_index_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, off, idx, mask, g);
+    else if (path == 2) hipLaunchKernelGGL((sample_index_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), 0, st, off, idx, mask, g);
+    else return DLKA_ERR_UNSUPPORTED;
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -439,7 +461,7 @@ int launch_sample_index(const T *off, int32_t *idx, uint8_t *mask, const Geom &g
     template int launch_deform_bwd_weight<T, 2>(const T *, const T *, const T *, float *, const Geom &, hipStream_t);          \
     template int launch_bias_grad<T>(const T *, T *, int, int, int, hipStream_t);                                              \
     template int launch_cast_from_f32<T>(const float *, T *, long, hipStream_t);                                               \
-    template int launch_sample_index<T>(const T *, int32_t *, uint8_t *, const Geom &, hipStream_t);
+    template int launch_sample_index<T>(const T *, int32_t *, uint8_t *, const Geom &, int, hipStream_t);
 DLKA_INST(float)
 DLKA_INST(bf16_t)
 #undef DLKA_INST

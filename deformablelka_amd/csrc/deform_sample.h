@@ -22,6 +22,7 @@ struct TapSample {
     unsigned cok;     // bit q set <=> corner q is inside the volume (ignores the guard) — torchvision's coord weight
     float fd[2], fh[2], fw[2];  // per-axis weights of the low / high corner
     bool inside;
+    int z0[3];        // floor cell (d,h,w), clamped to [-2, size]; read by the index-parity debug entry only
 };
 
 // offp points at offset channel (NOFF*tap) of this (b, dg) at output voxel v; consecutive channels are No apart.
@@ -47,6 +48,7 @@ __device__ __forceinline__ void setup_tap(TapSample<NOFF> &s, const T *__restric
     const int h0 = (int)fminf(fmaxf(fl_h, -2.f), (float)H);
     const int w0 = (int)fminf(fmaxf(fl_w, -2.f), (float)W);
     const float ld = qd - fl_d, lh = qh - fl_h, lw = qw - fl_w;
+    s.z0[0] = d0; s.z0[1] = h0; s.z0[2] = w0;
     s.fd[0] = 1.f - ld; s.fd[1] = ld;
     s.fh[0] = 1.f - lh; s.fh[1] = lh;
     s.fw[0] = 1.f - lw; s.fw[1] = lw;

@@ -517,14 +517,19 @@ int dlka_deform_conv3d_backward(const void *x, const void *offset, const void *w
                          (deform_backward_t<bf16_t, 3>(x, offset, weight, grad_out, grad_x, grad_offset, grad_weight, grad_bias, workspace, workspace_bytes, g, dtype, st)));
 }
 
-int dlka_deform_conv3d_sample_index(const void *offset, int32_t *idx, uint8_t *mask, const dlka_conv_geom *c, int dtype, void *stream)
+int dlka_deform_conv3d_sample_index_path(const void *offset, int32_t *idx, uint8_t *mask, const dlka_conv_geom *c, int dtype, int path, void *stream)
 {
     if (!offset || !idx || !mask) return DLKA_ERR_NULL;
     Geom g;
     DLKA_TRY(make_geom(c, true, g));
     hipStream_t st = (hipStream_t)stream;
-    return DLKA_DISPATCH(dtype, launch_sample_index<float>((const float *)offset, idx, mask, g, st),
-                         launch_sample_index<bf16_t>((const bf16_t *)offset, idx, mask, g, st));
+    return DLKA_DISPATCH(dtype, launch_sample_index<float>((const float *)offset, idx, mask, g, path, st),
+                         launch_sample_index<bf16_t>((const bf16_t *)offset, idx, mask, g, path, st));
+}
+
+int dlka_deform_conv3d_sample_index(const void *offset, int32_t *idx, uint8_t *mask, const dlka_conv_geom *c, int dtype, void *stream)
+{
+    return dlka_deform_conv3d_sample_index_path(offset, idx, mask, c, dtype, 0, stream);
 }
 
 // ---- 2-D deformable -------------------------------------------------------------------------------------------

@@ -22,7 +22,7 @@ int launch_bias_grad(const T *gout, T *gb, int B, int Cout, int No, hipStream_t 
 template <typename T>
 int launch_cast_from_f32(const float *src, T *dst, long n, hipStream_t st);
 template <typename T>
-int launch_sample_index(const T *off, int32_t *idx, uint8_t *mask, const Geom &g, hipStream_t st);
+int launch_sample_index(const T *off, int32_t *idx, uint8_t *mask, const Geom &g, int path, hipStream_t st);
 
 // ---- conv.hip (general grouped convolution: depthwise, dense, pointwise) -----------------------------------
 int conv_fwd_wt_floats(const Geom &g);

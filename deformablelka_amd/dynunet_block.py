@@ -89,14 +89,19 @@ class UnetResBlock(nn.Module):
 
     def forward(self, inp):
         C = self.norm1.num_features
-        if self.training:
+        # nn.BatchNorm3d keys on ITS OWN .training (the "freeze BN" pattern calls bn.eval() inside a module left in train mode);
+        # TransformerBlock_3D_single_deform_LKA does the same.  One fused Function serves both norms, so they must agree.
+        training = self.norm1.training
+        if self.norm2.training != training:
+            raise NotImplementedError("UnetResBlock: norm1 and norm2 must be in the same mode (both .train() or both .eval())")
+        if training:
             st1 = torch.empty(3 * C, dtype=torch.float32, device=inp.device)
             st2 = torch.empty_like(st1)
         else:
             st1, st2 = bn_eval_stats(self.norm1), bn_eval_stats(self.norm2)
-        out = _UnetResBlockFn.apply(inp, self.training, st1, st2, (self.norm1.eps, self.norm2.eps), self.conv1.conv.weight, self.norm1.weight,
+        out = _UnetResBlockFn.apply(inp, training, st1, st2, (self.norm1.eps, self.norm2.eps), self.conv1.conv.weight, self.norm1.weight,
                                     self.norm1.bias, self.conv2.conv.weight, self.norm2.weight, self.norm2.bias)
-        if self.training:
+        if training:
             bn_update_running(self.norm1, st1)
             bn_update_running(self.norm2, st2)
         return out

@@ -103,8 +103,10 @@ def deform_conv3d_backward(input, weight, bias, offset, grad_output, kernel_size
     return gi, go, gw, gb
 
 
-def deform_conv3d_sample_index(offset, in_size: Sequence[int], kernel_size, stride, padding, dilation, deformable_groups=1):
-    """floor() indices [B,dg,K,Do,Ho,Wo,3] (int32) and guard mask [B,dg,K,Do,Ho,Wo] (uint8)."""
+def deform_conv3d_sample_index(offset, in_size: Sequence[int], kernel_size, stride, padding, dilation, deformable_groups=1, path=0):
+    """floor() indices [B,dg,K,Do,Ho,Wo,3] (int32) and guard mask [B,dg,K,Do,Ho,Wo] (uint8).
+    ``path``: 0 = standalone rule, 1 = through ``setup_tap`` (general kernels), 2 = through ``gather_describe3``
+    (channels-last fast path); 1/2 report idx = 0 where the mask is 0."""
     L.require_device(offset)
     k, s, p, d = _triple(kernel_size), _triple(stride), _triple(padding), _triple(dilation)
     offset = offset.contiguous()
@@ -114,8 +116,8 @@ def deform_conv3d_sample_index(offset, in_size: Sequence[int], kernel_size, stri
     K = k[0] * k[1] * k[2]
     idx = torch.empty((B, deformable_groups, K, Do, Ho, Wo, 3), dtype=torch.int32, device=offset.device)
     mask = torch.empty((B, deformable_groups, K, Do, Ho, Wo), dtype=torch.uint8, device=offset.device)
-    rc = L.get_lib().dlka_deform_conv3d_sample_index(L.ptr(offset), L.ptr(idx), L.ptr(mask), byref(g), L.dtype_code(offset),
-                                                     L.stream_ptr(offset))
+    rc = L.get_lib().dlka_deform_conv3d_sample_index_path(L.ptr(offset), L.ptr(idx), L.ptr(mask), byref(g), L.dtype_code(offset),
+                                                          int(path), L.stream_ptr(offset))
     L.check(rc, "deform_conv3d_sample_index")
     return idx, mask
 

@@ -132,9 +132,14 @@ class _TBlock3dFn(Function):
 
 
 class TransformerBlock_3D_single_deform_LKA(nn.Module):
-    """transformerblock.py:570-630.  ``forward(x)`` takes the (B, C, H, W, D) volume and returns a (B, C, H, W, D) tensor that is
-    the permuted view of channels-last memory — the reference's own ``attn_skip`` is such a view too (:626).  A following block
-    recognises that layout and reads the tokens without a copy."""
+    """transformerblock.py:570-630.  ``forward(x)`` takes the (B, C, H, W, D) volume and returns a contiguous (B, C, H, W, D)
+    tensor, as the reference does (:626-630), so that any consumer's ``.view()`` keeps working.
+
+    ``keep_channels_last = True`` (an attribute, not a constructor argument: the constructor is the reference's) skips that final
+    layout copy and returns the ``torch.channels_last_3d`` view of the token memory the kernels wrote; a following block recognises
+    the layout and reads the tokens in place.  ``deformablelka_amd.network`` sets it on the blocks it chains."""
+
+    keep_channels_last = False
 
     def __init__(self, input_size: int, hidden_size: int, proj_size: int, num_heads: int, dropout_rate: float = 0.0, pos_embed=False) -> None:
         super().__init__()
@@ -185,4 +190,5 @@ class TransformerBlock_3D_single_deform_LKA(nn.Module):
         if training:
             bn_update_running(c.norm1, stats[:3 * C])
             bn_update_running(c.norm2, stats[3 * C:])
-        return y.view(B, H, W, D, C).permute(0, 4, 1, 2, 3)
+        y = y.view(B, H, W, D, C).permute(0, 4, 1, 2, 3)
+        return y if self.keep_channels_last else y.contiguous()

@@ -102,6 +102,12 @@ int dlka_deform_conv3d_backward(const void *x, const void *offset, const void *w
  * Backs the "integer sampling indices bit-exact" requirement of BASELINE.json. */
 int dlka_deform_conv3d_sample_index(const void *offset, int32_t *idx, uint8_t *mask,
                                     const dlka_conv_geom *g, int dtype, void *stream);
+/* Same outputs, computed by the very device functions the hot kernels call, so that the bit-exact index claim covers
+ * the code that runs:  path 0 = the rule on its own (as above); path 1 = setup_tap<3> (deform_sample.h — every
+ * general NCDHW kernel); path 2 = gather_describe3 (cl_gather.h — every channels-last fast-path kernel).  Paths 1/2
+ * report idx = 0 where mask == 0 (outside the guard of cuh:247 the kernels never form a cell). */
+int dlka_deform_conv3d_sample_index_path(const void *offset, int32_t *idx, uint8_t *mask,
+                                         const dlka_conv_geom *g, int dtype, int path, void *stream);
 
 /* =======================================================================================
  * 2-D deformable convolution — torchvision.ops.deform_conv2d(mask=None) semantics

@@ -7,9 +7,13 @@ torch-level compositions that restate the reference's Python modules.
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
 package.  ``deformablelka_amd`` never does (tests/test_no_oracle_in_product.py enforces it).
 
-Parity status: **unpinned by the reference's own tests** (it has none for this path and its native op
-is CUDA-only); pinned by derived known-answer properties and by golden vectors generated through the
-reference's Python modules (tests/golden/make_golden.py).
+Parity status (3-D, D3D): **pinned to the reference's own arithmetic**.  The reference has no golden vectors for this
+path, but its native op builds for gfx950 (``oracle/ref.mk`` -> ``oracle/_ref/D3D.so``, sources unmodified): the C oracle is
+checked against its recorded outputs on CPU (tests/golden/d3d_reference_vectors.pt, tests/test_oracle_vs_reference_vectors.py)
+and against the op itself on the MI355X (tests/test_ref_d3d_gpu.py), besides derived known-answer properties and the golden
+vectors generated through the reference's Python modules (tests/golden/make_golden.py).
+Parity status (2-D, torchvision 0.12 deform_conv2d): **unpinned** — torchvision is neither vendored by the reference nor
+installed here; the restatement follows its published algorithm and is anchored on the reference's call sites only.
 """
 from __future__ import annotations
 

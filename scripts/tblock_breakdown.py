@@ -36,6 +36,7 @@ def main():
     for C, (H, W, D), n in SYNAPSE_STAGES:
         torch.manual_seed(0)
         m = dk.TransformerBlock_3D_single_deform_LKA(H * W * D, C, C, 4, dropout_rate=0.1, pos_embed=True).to(dev)
+        m.keep_channels_last = True
         inner = m.epa_block
         x = torch.randn(a.batch, C, H, W, D, device=dev).permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3).requires_grad_(True)
         gy = torch.randn(a.batch, H, W, D, C, device=dev).permute(0, 4, 1, 2, 3)

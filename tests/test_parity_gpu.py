@@ -206,6 +206,23 @@ def test_lka3d_tokens_block_vs_oracle(C, dims):
     parity.check_lka3d_tokens(DEV, 2, C, dims)
 
 
+# offset_std = std of conv_offset.weight that makes the PREDICTED offsets ~1 voxel at that stage width — the regime bench.py times
+# (deformablelka_amd/stack.py:_init_block calibration: 3 * calib / sqrt(27 C))
+HEADLINE = [(32, (32, 32, 32), 0.376), (64, (16, 16, 16), 0.380), (128, (8, 8, 8), 0.490), (256, (4, 4, 4), 0.451)]
+
+
+@pytest.mark.parametrize("C,dims,wstd", HEADLINE)
+def test_lka3d_tokens_block_headline_shapes_vs_oracle(C, dims, wstd):
+    """BASELINE.json config 3 at FULL size (B=2; stage 0 = C 32, 32^3 dominates the metric), offsets ~1 voxel: the token fast
+    path against the oracle block, forward and every gradient."""
+    parity.check_lka3d_tokens(DEV, 2, C, dims, offset_std=wstd, report_offsets=True)
+
+
+def test_deform3d_cl_headline_shape_vs_oracle():
+    """The deformable conv of the headline shape (C=32, 32^3, B=2, offsets N(0,1)): forward + all four gradients vs the oracle."""
+    parity.check_deform3d_cl(DEV, 2, 32, 32, (32, 32, 32), off_mode="normal")
+
+
 def test_tokens_full_size_stage0_matches_general_path():
     """BASELINE.json full size (C=32, 32^3, B=2): the token-layout fast path against our own general NCDHW path
     (which is pinned to the oracle above) — forward and all gradients."""
@@ -271,6 +288,12 @@ def test_layernorm_tokens(case):
 @pytest.mark.parametrize("case", [(30011, 32, True, True), (7777, 64, True, False), (13000, 256, False, True), (6400, 128, False, False)])
 def test_batchnorm_cl(case):
     parity.check_batchnorm_cl(DEV, *case)
+
+
+@pytest.mark.parametrize("ratio", [20.0, 500.0])
+def test_batchnorm_cl_large_mean(ratio):
+    """|mean| >> std: the one-pass E[x^2] - mean^2 form would lose the variance (24 % off at ratio 500); the pivoted sums must not."""
+    parity.check_batchnorm_cl(DEV, 30011, 32, True, True, mean_over_std=ratio)
 
 
 def test_scale_residual_and_channel_scale():
