@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-tblock", action="store_true", help="skip the second metric (wrapper-block stack through nn.Module/autograd)")
     ap.add_argument("--cpu-sample", default="stage", choices=["stage", "tiny"])
     return ap.parse_args()
 
@@ -191,16 +192,18 @@ def roofline_report(B, dtype):
         ach, peak, unit, bound = fl / (t * 1e-3) / 1e12, peak_tf, "TFLOP/s", "mfma"
     else:
         ach, peak, unit, bound = by / (t * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
-    traffic = None
+    traffic = traffic_source = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/pmc_traffic.sh)
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(name, {}).get("traffic_bytes_per_launch")
+            blob = json.load(open(pmc))
+            traffic = blob.get(name, {}).get("traffic_bytes_per_launch")
+            traffic_source = "profiles/pmc_traffic.json (%s): committed rocprofv3 --pmc passes, NOT measured by this run" % blob.get("_meta", {}).get("round", "r02f")
         except Exception:
             traffic = None
     kern, extra = OP_KERNEL.get(name, (name, ""))
     return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5),
-            "traffic": traffic, "kernel": kern, "op": name, "op_also_launches": extra,
+            "traffic": traffic, "traffic_source": traffic_source, "kernel": kern, "op": name, "op_also_launches": extra,
             "kernel_ms": round(t, 4), "algorithmic_flops": fl, "algorithmic_bytes": by,
             "shape": f"C={C},{N}^3,B={B}", "per_op_ms": {k: round(v, 4) for k, v in ms.items()}}
 
@@ -208,41 +211,140 @@ def roofline_report(B, dtype):
 # ----------------------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle block on the host cores, bounded sample
 # ----------------------------------------------------------------------------------------------------------------
-def cpu_baseline(sample):
+def cpu_baseline(sample, batch, budget_s=40.0):
+    """the oracle block (ATen CPU convs = the reference's own CPU path for nn.Conv3d/GELU, C oracle for the deformable conv,
+    autograd backward) on the host cores — B = `batch`, fp32, offsets ~1 voxel, every one of the four stage shapes timed (no
+    extrapolation between stages; the 21-block time is 6*t0 + 6*t1 + 6*t2 + 3*t3 of MEASURED per-stage medians).  Protocol per stage:
+    warm-up + timed repetitions, median; BOUNDED: the plan's 3 warm + 10 timed shrink to what fits the time budget and the counts
+    actually run are reported.  All host threads, then one thread (per-core figure) on the stages that still fit the budget."""
+    import statistics
     import oracle
     from oracle import blocks
     import deformablelka_amd as dk
+    from deformablelka_amd.stack import _offset_std_for
     oracle.build()
     cores = torch.get_num_threads()
     if sample == "tiny":
         stages = [(32, (8, 8, 8), 6), (64, (4, 4, 4), 6)]
-        desc = "TINY shapes (debug only)"
     else:
         from deformablelka_amd.stack import SYNAPSE_STAGES
         stages = SYNAPSE_STAGES
-        desc = ("one D-LKA block fwd+bwd per stage at B=1 (4 of the 21 blocks), fp32, ATen CPU convs + C deformable "
-                "oracle (OpenMP); per-volume time extrapolated as 6*t0+6*t1+6*t2+3*t3")
-    total = 0.0
-    per_stage = []
     # untimed warm-up (thread pools, oneDNN primitive caches)
     _m = dk.LKA_Attention3d_deform(8)
     _P = {k: v.detach().clone().requires_grad_(True) for k, v in _m.state_dict().items()}
     blocks.lka3d_attention_volume(torch.randn(1, 8, 6, 6, 6, requires_grad=True), _P).sum().backward()
-    for C, dims, nblk in stages:
+
+    def make(C, dims):
         torch.manual_seed(0)
         m = dk.LKA_Attention3d_deform(C)
-        blocks.randomize_offsets_(m, std=0.02)
+        blocks.randomize_offsets_(m, std=_offset_std_for(C))
         P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
-        x = torch.randn(1, C, *dims, requires_grad=True)
-        gy = torch.randn(1, C, *dims)
+        return P, torch.randn(batch, C, *dims, requires_grad=True), torch.randn(batch, C, *dims)
+
+    def once(P, x, gy):
         t0 = time.perf_counter()
-        y = blocks.lka3d_attention_volume(x, P)
-        y.backward(gy)
-        dt = time.perf_counter() - t0
-        per_stage.append(round(dt, 3))
-        total += dt * nblk
-    return {"value": round(1.0 / total, 5), "unit": "volumes/s", "cores": cores, "kind": "port", "sample": desc,
-            "per_stage_block_s": per_stage}
+        blocks.lka3d_attention_volume(x, P).backward(gy)
+        return time.perf_counter() - t0
+
+    t_start = time.perf_counter()
+    per_stage, reps = [], []
+    share = budget_s * 0.7 / len(stages)
+    for C, dims, nblk in reversed(list(stages)):        # small stages first: they always get their full repetitions
+        P, x, gy = make(C, dims)
+        t_stage = time.perf_counter()
+        warm = 0
+        while warm < 3 and (warm == 0 or time.perf_counter() - t_stage < share * 0.3):
+            once(P, x, gy)
+            warm += 1
+        ts = []
+        while len(ts) < 10 and (len(ts) < 1 or time.perf_counter() - t_stage < share):
+            ts.append(once(P, x, gy))
+        per_stage.insert(0, statistics.median(ts))
+        reps.insert(0, (warm, len(ts)))
+    total = sum(t * n for t, (_, _, n) in zip(per_stage, stages))
+    # one thread
+    one = {}
+    torch.set_num_threads(1)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    try:
+        import ctypes
+        try:
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)    # the C oracle's OpenMP team
+        except OSError:
+            pass
+        for (C, dims, nblk), t_all in reversed(list(zip(stages, per_stage))):
+            if time.perf_counter() - t_start + t_all * cores * 0.5 > budget_s:   # would not fit: say so instead of extrapolating
+                one[f"C{C}"] = None
+                continue
+            P, x, gy = make(C, dims)
+            once(P, x, gy)
+            one[f"C{C}"] = round(once(P, x, gy), 4)
+    finally:
+        torch.set_num_threads(cores)
+        try:
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+        except Exception:
+            pass
+    return {"value": round(batch / total, 5), "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": (f"oracle D-LKA block fwd+bwd at B={batch}, fp32, offsets ~1 voxel, one block of EACH of the 4 stage shapes timed "
+                       f"(warm-up, timed repetitions per stage C=32/64/128/256: {reps}; median), 21-block time = 6*t0+6*t1+6*t2+3*t3; "
+                       f"bounded to ~{budget_s:.0f} s (BASELINE.md §3 asks 3 warm + 10 timed)" if sample != "tiny" else "TINY shapes (debug only)"),
+            "per_stage_block_s": [round(t, 4) for t in per_stage], "one_thread_block_s": one, "torch": torch.__version__,
+            "wall_s": round(time.perf_counter() - t_start, 1)}
+
+
+def step_work(batch, dbytes):
+    """Algorithmic FLOPs and bytes of ONE step (fwd+bwd of the 21 blocks at B = batch), SURVEY.md §8d: bytes fwd+bwd = 43 E + 5 Off
+    words per block (activations in the run's storage type, offsets always fp32), FLOPs = 3 x forward."""
+    from deformablelka_amd.stack import SYNAPSE_STAGES
+    fl = by = 0
+    for C, (H, W, D), n in SYNAPSE_STAGES:
+        N = H * W * D
+        E, Off = batch * C * N, batch * 81 * N
+        fwd = 6 * C * E + 936 * E + 2 * 27 * C * 81 * batch * N + 2 * 27 * C * C * batch * N + 27 * batch * N * (15 * C + 30)
+        fl += n * 3 * fwd
+        by += n * (43 * E * dbytes + 5 * Off * 4)
+    return fl, by
+
+
+def tblock_metric(batch, steps, warmup, dev):
+    """Second reported metric: the same 21 blocks INSIDE their wrapper (TransformerBlock_3D_single_deform_LKA: LayerNorm, gamma residual,
+    UnetResBlock, conv8 — SURVEY.md §8 rows a1/f1), fwd+bwd through the nn.Module / autograd path, chained per stage instance."""
+    import deformablelka_amd as dk
+    from deformablelka_amd.stack import SYNAPSE_STAGES, CHAIN, _offset_std_for
+    torch.manual_seed(0)
+    chains = []
+    for C, (H, W, D), n in SYNAPSE_STAGES:
+        for c0 in range(0, n, CHAIN):
+            mods = []
+            for _ in range(min(CHAIN, n - c0)):
+                m = dk.TransformerBlock_3D_single_deform_LKA(H * W * D, C, C, 4, dropout_rate=0.1, pos_embed=True)
+                with torch.no_grad():
+                    m.epa_block.spatial_gating_unit.deform_conv.conv_offset.weight.normal_(0, _offset_std_for(C))
+                m.keep_channels_last = True
+                mods.append(m.to(dev))
+            x = torch.randn(batch, H, W, D, C, device=dev).permute(0, 4, 1, 2, 3).requires_grad_(True)
+            gy = torch.randn(batch, H, W, D, C, device=dev).permute(0, 4, 1, 2, 3)
+            chains.append((mods, x, gy))
+
+    def step():
+        for mods, x, gy in chains:
+            y = x
+            for m in mods:
+                y = m(y)
+            y.backward(gy)
+
+    for _ in range(max(warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"metric": "3D D-LKA transformer-block (wrapper + D-LKA) fwd+bwd volumes/sec (64x128x128)", "value": round(batch / dt, 3),
+            "unit": "volumes/s", "ms_per_step": round(dt * 1e3, 3), "path": "nn.Module + autograd, eager (no hipGraph), training mode",
+            "blocks": sum(len(c[0]) for c in chains)}
 
 
 def main():
@@ -291,6 +393,8 @@ def main():
     def compute_b():
         stack.backward(0, split)
 
+    from deformablelka_amd import dp
+
     graph = None
     graph_a = graph_b = None
     # eager warm-up (also first-touch of every kernel), then capture
@@ -310,45 +414,56 @@ def main():
             log("hipGraph capture failed, running eagerly:", repr(e))
             graph = None
             torch.cuda.synchronize()
-        if overlap and graph is not None:
-            try:
-                graph_a, graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_a):
-                    compute_a()
-                with torch.cuda.graph(graph_b):
-                    compute_b()
-            except Exception as e:
-                log("split capture failed, using the single graph + one all-reduce:", repr(e))
-                graph_a = graph_b = None
-                overlap = False
-                torch.cuda.synchronize()
+        if not dp.all_ranks_agree(graph is not None, dist, world, dev):   # every rank replays a graph, or none does
+            graph = None
+
+    def prepare_overlap():
+        nonlocal graph_a, graph_b
+        if args.no_graph or graph is None:
+            return True            # eager halves need no preparation
+        try:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                compute_a()
+            with torch.cuda.graph(gb):
+                compute_b()
+            graph_a, graph_b = ga, gb
+            return True
+        except Exception as e:
+            log("split capture failed:", repr(e))
+            torch.cuda.synchronize()
+            return False
+
+    def run_a():
+        (graph_a.replay() if graph_a is not None else compute_a())
+
+    def run_b():
+        (graph_b.replay() if graph_b is not None else compute_b())
+
+    def trial_overlap():   # the two compute halves WITHOUT collectives
+        try:
+            run_a()
+            run_b()
+            torch.cuda.synchronize()
+            return True
+        except Exception as e:
+            log("overlapped trial failed:", repr(e))
+            torch.cuda.synchronize()
+            return False
+
+    # the ADVICE-r1 finding: every local decision is reduced over the ranks before anyone acts on it (deformablelka_amd/dp.py,
+    # tests/test_dist_gloo.py::test_all_ranks_take_the_same_allreduce_schedule)
+    schedule = dp.choose_schedule(overlap, prepare_overlap, trial_overlap, dist, world, dev)
+    if schedule != "overlap":
+        graph_a = graph_b = None
 
     def step_simple():
-        if graph is not None:
-            graph.replay()
-        else:
-            compute()
-        stack.reduce_and_update(lr, world, dist)        # one flat all-reduce (15.4M block parameters) + SGD update
+        dp.step_single(stack, lr, world, dist, graph.replay if graph is not None else compute)   # one flat all-reduce + SGD update
 
     def step_overlapped():
-        (graph_a.replay() if graph_a is not None else compute_a())
-        w1 = dist.all_reduce(stack.flat_grads[cut:], async_op=True) if world > 1 else None   # gradients of blocks[split:], final now
-        (graph_b.replay() if graph_b is not None else compute_b())
-        w2 = dist.all_reduce(stack.flat_grads[:cut], async_op=True) if world > 1 else None
-        if w1 is not None:
-            w1.wait()
-            w2.wait()
-        stack.flat_params.add_(stack.flat_grads, alpha=-lr / world)
+        dp.step_overlap(stack, lr, world, dist, run_a, run_b, cut)
 
-    step = step_simple
-    if overlap:
-        try:   # one trial step of the overlapped schedule; any failure falls back to the simple one
-            step_overlapped()
-            torch.cuda.synchronize()
-            step = step_overlapped
-        except Exception as e:
-            log("overlapped step failed, using the single all-reduce:", repr(e))
-            torch.cuda.synchronize()
+    step = step_overlapped if schedule == "overlap" else step_simple
 
     for _ in range(args.warmup):
         step()
@@ -389,15 +504,28 @@ def main():
         if not args.no_roofline:
             try:
                 out["roofline"] = roofline_report(args.batch, dtype)
+                fl, by = step_work(args.batch, 4 if dtype == torch.float32 else 2)
+                t_step = ms_per_step * 1e-3
+                out["roofline"]["step"] = {   # the WHOLE step against both roofs (north_star: achieved-HBM-bandwidth fraction)
+                    "algorithmic_flops": fl, "algorithmic_bytes": by,
+                    "hbm_frac": round(by / t_step / (PEAK_HBM_GBS * 1e9), 5), "achieved_GBps": round(by / t_step / 1e9, 1),
+                    "fp32_frac": round(fl / t_step / (PEAK_F32_TFLOPS * 1e12), 5), "achieved_TFLOPs": round(fl / t_step / 1e12, 2),
+                    "floor_ms_hbm": round(by / (PEAK_HBM_GBS * 1e9) * 1e3, 3), "floor_ms_fp32": round(fl / (PEAK_F32_TFLOPS * 1e12) * 1e3, 3)}
             except Exception as e:
                 log("roofline timing failed:", repr(e))
                 out["roofline"] = None
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+                out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.batch)
             except Exception as e:
                 log("cpu baseline failed:", repr(e))
                 out["cpu_baseline"] = None
+        if not args.no_tblock and world == 1 and dtype == torch.float32:
+            try:
+                out["tblock"] = tblock_metric(args.batch, max(3, args.steps // 2), 2, dev)
+            except Exception as e:
+                log("tblock metric failed:", repr(e))
+                out["tblock"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

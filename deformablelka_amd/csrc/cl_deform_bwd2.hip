@@ -18,6 +18,7 @@
 //                           Corners beyond the halo (|tap + offset| > ~2 voxels outside the brick) fall back to global atomics.
 //   cl_deform_gx_gather_kernel   every input voxel sums the <= few windows that cover it (plain loads, fixed order) and
 //                           adds the result to grad_input: no flush atomics.
+#include <math.h>
 #include <stdlib.h>
 
 #include <atomic>
@@ -404,6 +405,8 @@ struct GxGeom {
     int item_grid;          // 1: 1-D grid over (brick, slice) items; 0: x = brick, y = slice
     int tap_far;            // 1: half-waves take taps 16 apart (K <= 32 = 4 groups of 8), see gx_tap()
     int ablate;             // profiling only (DLKA_GX_ABL): 1 = no LDS atomics, 2 = no sampling description / scatter at all
+    float fx_lim;           // fixed-point window: largest scaled magnitude of one contribution, R*K * (fx_lim + 1/2) < 2^31 (R = rows of a
+                            // brick, K = taps), see the kernel
 };
 
 // MFMA row t8 of tap group grp <-> tap.  The two half-waves scatter rows t8 = 2*r4 and 2*r4 + 1 in the same instruction; with consecutive
@@ -427,11 +430,10 @@ __device__ __host__ __forceinline__ void gx_window(int b0, int bsz, int size, in
 // FX: the window holds 64-bit INTEGER cells, two channels per cell as 32-bit fixed-point fields (value = hi * 2^32 + lo in signed
 // arithmetic, so the sum of packed words is the packed word of the two sums as long as each stays below 2^31).  One ds_add_u64 then
 // carries two channels: half the LDS atomic instructions of the fp64 window (the kernel's bound), integer adds are
-// exact and order-independent, and ds_add_u64 is the faster instruction (8.2 vs 6.8 lanes/clk/CU).  The price is a per-(brick, slice) scale:
-// 2^k with |contribution| * 2^k < 2^20 from the bound max_rows ||grad_out row||_1 * max |W| — 20 bits of resolution for the largest
-// contribution (error per add <= 2^-21 of it) and 2^11 same-sign maximal contributions of headroom per cell before the field overflows.
-// (Sixteen waves on ONE fp64 window — 1024 threads, 128 registers — measured 371 vs 374 us: the fp64 window is bound by its LDS atomics, more
-// waves do not help it; the packed window halves that work AND fits twice per CU.)
+// exact and order-independent, ds_add_u64 is the faster instruction (8.2 vs 6.8 lanes/clk/CU), and the 61 KB window fits TWICE per CU
+// (the fp64 one is 122 KB).  The price is a per-(brick, slice) power-of-two scale; it is chosen from a Cauchy-Schwarz bound of |Col| so
+// that overflow is impossible for ANY offsets (see the kernel): 2^31 / (R*K) - 1 = 155 343 levels (17.2 bits) for the largest possible contribution
+// at the default brick (R*K = 512 * 27), i.e. an error <= 3.2e-6 of that bound per add; measured 1.9e-4 of max|grad_input| at 32^3.  Default where it is faster (C <= 64, resident weights).
 template <bool FX>
 __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwdArgs p, GxGeom gg, float *__restrict__ scratch)
 {
@@ -471,39 +473,6 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
 
     for (int e = tid; e < wstride * (FX ? CS / 2 : CS); e += blockDim.x) Win[e] = 0.0;   // (0.0 and integer 0 share the bit pattern)
     float fx_scale = 1.f, fx_inv = 1.f;
-    if (FX) {
-        if (tid < 2) smax[tid] = 0u;
-        __syncthreads();
-        // bound of |Col| over the brick: max |W| of this slice (all taps) x max L1 norm of a grad_out row
-        float wm = 0.f;
-        for (int e = tid; e < p.K * p.CoutP; e += blockDim.x) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(p.wp + (long)e * p.C + slice * CS);
-            wm = fmaxf(fmaxf(wm, fmaxf(fabsf(w4[0]), fabsf(w4[1]))), fmaxf(fabsf(w4[2]), fabsf(w4[3])));
-        }
-        float gm = 0.f;
-        for (int row = tid; row < R; row += blockDim.x) {
-            const int rw = row % gg.bw, rh = (row / gg.bw) % gg.bh, rd = row / (gg.bw * gg.bh);
-            const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
-            if (vd < p.D && vh < p.H && vw < p.W) {
-                const float *gp = p.g + ((long)b * p.N + (vd * p.H + vh) * p.W + vw) * p.Cout;
-                float l1 = 0.f;
-                for (int co = 0; co < p.Cout; co += 4) {
-                    const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gp + co);
-                    l1 += (fabsf(g4[0]) + fabsf(g4[1])) + (fabsf(g4[2]) + fabsf(g4[3]));
-                }
-                gm = fmaxf(gm, l1);
-            }
-        }
-        atomicMax(&smax[0], __float_as_uint(wm));   // non-negative floats order like their bit patterns
-        atomicMax(&smax[1], __float_as_uint(gm));
-        __syncthreads();
-        const float vmax = __uint_as_float(smax[0]) * __uint_as_float(smax[1]);
-        int ex = 0;
-        if (vmax > 0.f && vmax < 3.0e38f) (void)frexpf(vmax, &ex);   // vmax < 2^ex
-        fx_scale = ldexpf(1.f, 20 - ex);
-        fx_inv = ldexpf(1.f, ex - 20);
-    }
-
     // A operand tile of group grp: Bs[co][t8*4 + c4] = W[co][slice*4 + c4][tap = grp*8 + t8]   (wp[tap][co][ci], zero beyond K)
     auto stage_weights = [&](int grp, float *dstB) {
         for (int e = tid; e < p.CoutP * TG; e += blockDim.x) {
@@ -633,7 +602,48 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
         // main loop has no workgroup barrier.  (Measured before: grad_out re-read per group and slice = 377 MB of L2->HBM
         // traffic against 8 MB of data, profiles/r01j_pmc.)
         for (int grp = 0; grp < gg.ngroups; ++grp) stage_weights(grp, Bs + (size_t)grp * p.CoutP * 32);
+        if (FX && tid < 2) smax[tid] = 0u;
         __syncthreads();   // also: window zeroed
+        if (FX) {
+            // Power-of-two scale with a PROVABLE overflow bound.  Every contribution is Col * wq with 0 <= wq <= 1 and
+            //   |Col(c, tap, o)| = |sum_co W[co][c][tap] G[o][co]| <= ||W[:, c, tap]||_2 * ||G[o, :]||_2      (Cauchy-Schwarz)
+            //                    <= vmax := max over this slice's (c, tap) columns  x  max over this brick's rows,
+            // and one cell receives at most ONE corner from each (row, tap) pair of the brick, i.e. <= R*K contributions.  With
+            // |rint(Col * wq * scale)| <= vmax * scale + 1/2 <= fx_lim + 1/2 and the host's fx_lim (R*K * (fx_lim + 1/2) < 2^31), no 32-bit
+            // field can overflow whatever the offsets are.  (The column norms come from the weight tiles just staged in LDS.)
+            float wm = 0.f;
+            if (tid < gg.ngroups * 32) {
+                const float *col = Bs + (size_t)(tid >> 5) * p.CoutP * 32 + (tid & 31);
+                float ss = 0.f;
+                for (int co = 0; co < p.CoutP; ++co) ss = fmaf(col[co * 32], col[co * 32], ss);
+                wm = sqrtf(ss);
+            }
+            float gm = 0.f;
+            for (int row = tid; row < R; row += blockDim.x) {
+                const int rw = row % gg.bw, rh = (row / gg.bw) % gg.bh, rd = row / (gg.bw * gg.bh);
+                const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
+                if (vd < p.D && vh < p.H && vw < p.W) {
+                    const float *gp = p.g + ((long)b * p.N + (vd * p.H + vh) * p.W + vw) * p.Cout;
+                    float ss = 0.f;
+                    for (int co = 0; co < p.Cout; co += 4) {
+                        const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gp + co);
+                        ss = fmaf(g4[0], g4[0], fmaf(g4[1], g4[1], fmaf(g4[2], g4[2], fmaf(g4[3], g4[3], ss))));
+                    }
+                    gm = fmaxf(gm, sqrtf(ss));
+                }
+            }
+            atomicMax(&smax[0], __float_as_uint(wm));   // non-negative floats order like their bit patterns
+            atomicMax(&smax[1], __float_as_uint(gm));
+            __syncthreads();
+            // 1.0001: the fp32 rounding of the two norms and of the MFMA's own sum (each < 1e-5 relative)
+            const float vmax = __uint_as_float(smax[0]) * __uint_as_float(smax[1]) * 1.0001f;
+            // |Col * wq * scale| <= vmax * scale <= fx_lim,  R*K * (fx_lim + 1/2) < 2^31  (fx_lim from the host); the scale need not be a
+            // power of two: the window holds integers, only the final read-back multiplies by 1/scale
+            if (vmax > 1e-30f && vmax < 3.0e38f) {
+                fx_scale = gg.fx_lim / vmax * 0.999999f;
+                fx_inv = 1.f / fx_scale;
+            }
+        }
         for (int tile = wave; tile < ntiles; tile += nwaves) {
             float gl[4][16];
 #pragma unroll
@@ -799,7 +809,19 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const GxGeom g = pick_gx_geom(a);
         if (!a.gx_zeroed && launch_zero(a.gx, (size_t)a.B * a.N * a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         GxGeom gl_ = g;
-        const bool fixed = getenv("DLKA_GX_FIXED") != nullptr && !(getenv("DLKA_GX_ABL") && atoi(getenv("DLKA_GX_ABL")));   // opt-in, not cached: tests toggle it
+        // fixed-point window (two channels per 64-bit integer cell): default where it measured faster — C <= 64 with all weight tiles
+        // resident in LDS (252 vs 362 us at C=32 / 32^3; at C >= 128 the scale pre-pass costs more than the atomics it saves).
+        // DLKA_GX_FIXED=0 forces the fp64 window, =1 the fixed-point one wherever it is possible (A/B runs; not cached: tests toggle it).
+        const char *fx_env = getenv("DLKA_GX_FIXED");
+        const bool abl_on = getenv("DLKA_GX_ABL") && atoi(getenv("DLKA_GX_ABL"));
+        const long rk = (long)g.bd * g.bh * g.bw * a.K;
+        const double fx_lim = 2147483648.0 / (double)rk - 1.0;   // rk * (fx_lim + 1/2) = 2^31 - rk/2 < 2^31
+        const int fx_bits = fx_lim > 1.0 ? (int)floor(log2(fx_lim)) : 0;
+        const size_t lds_win_fx = 16 + (size_t)(g.wvox_max + 64) * (CS / 2) * sizeof(double);
+        const bool fx_possible = lds_win_fx + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float) <= 150 * 1024 && a.CoutP <= 128 && g.ngroups * 32 <= 512 &&
+                                 fx_bits >= 12 && !abl_on;
+        const bool fixed = fx_possible && (fx_env ? atoi(fx_env) != 0 : a.C <= 64);
+        gl_.fx_lim = (float)fx_lim;
         // scalars, window + one trash cell per lane and channel plane (the fixed-point window packs two channels per cell)
         const size_t lds_win = 16 + (size_t)(g.wvox_max + 64) * (fixed ? CS / 2 : CS) * sizeof(double);
         const size_t lds_all = lds_win + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);

@@ -26,6 +26,16 @@ def _param_shapes(C: int):
             (C, C, 3, 3, 3), (C,), (C, C, 1, 1, 1), (C,), (C, C, 1, 1, 1), (C,)]
 
 
+def _offset_std_for(C: int, offset_std_voxels: float = 1.0) -> float:
+    """std of conv_offset.weight ~ N(0, .) that makes the PREDICTED offsets ~offset_std_voxels at stage width C.  The input of conv_offset
+    (after proj_1, GELU and the two default-initialised depthwise convs) shrinks with C, so the gain is calibrated per stage width:
+    measured on MI355X with gain 3/sqrt(fan_in) the predicted offsets had std 0.272 / 0.190 / 0.104 / 0.080 at C = 32 / 64 / 128 / 256
+    (scripts/stack_stats.py); the table brings all four to ~1.0 and is frozen."""
+    import math
+    calib = {32: 3.68, 64: 5.26, 128: 9.6, 256: 12.5}.get(C, 1.0)
+    return offset_std_voxels * calib * 3.0 / math.sqrt(C * 27)
+
+
 class _Block:
     __slots__ = ("C", "dims", "params", "grads", "pstruct", "gstruct", "saved", "x", "y", "gx", "gy", "saved_bytes")
 
@@ -102,13 +112,7 @@ class DLKABlockStack:
             w.copy_(((torch.rand(w.shape, generator=gen) * 2 - 1) * bound).to(self.device, self.dtype))
             b.copy_(((torch.rand(b.shape, generator=gen) * 2 - 1) * bound).to(self.device, self.dtype))
         ow, ob = blk.params[6], blk.params[7]
-        fan_in = int(ow[0].numel())
-        # timing needs non-degenerate offsets with std ~ 1 voxel.  The input of conv_offset (after proj_1, GELU and
-        # the two default-initialised depthwise convs) shrinks with C, so the gain is calibrated per stage width: measured
-        # on MI355X with gain 3/sqrt(fan_in) the predicted offsets had std 0.272 / 0.190 / 0.104 / 0.080 at C = 32 / 64 /
-        # 128 / 256 (scripts/stack_stats.py); the table below brings all four to ~1.0 and is frozen.
-        calib = {32: 3.68, 64: 5.26, 128: 9.6, 256: 12.5}.get(blk.C, 1.0)
-        ow.copy_((torch.randn(ow.shape, generator=gen) * (offset_std * calib * 3.0 / math.sqrt(fan_in))).to(self.device, self.dtype))
+        ow.copy_((torch.randn(ow.shape, generator=gen) * _offset_std_for(blk.C, offset_std)).to(self.device, self.dtype))
         ob.zero_()
 
     def _stream(self):

@@ -185,6 +185,55 @@ def check_deform3d_cl(dev, B, C, Cout, dims, off_mode="normal", seed=0):
     assert_close("deform3d_cl grad_bias", gb, rgb, rtol=BWD_RTOL)
 
 
+def check_deform3d_cl_gx_worst_case(dev, C, dims, B=1):
+    """Adversarial input for the fixed-point grad_input window (cl_deform_gx_kernel<true>): grad_out = +1 everywhere, W = +1 everywhere and
+    EVERY (voxel, tap) sample aimed exactly at ONE input voxel (integer position -> corner weight 1), so that the cell of that voxel
+    receives, from each brick whose window covers it, R*K contributions of the same sign at the Cauchy-Schwarz maximum |Col| = Cout —
+    precisely the case the overflow bound is built for.  (Bricks farther away reach the voxel through the global-atomic path.)"""
+    D, H, W = dims
+    K = 27
+    tgt = (D // 2, H // 2, W // 2)
+    x = torch.randn(B, C, D, H, W, generator=torch.Generator().manual_seed(0))
+    w = torch.ones(C, C, 3, 3, 3)
+    b = torch.zeros(C)
+    go = torch.ones(B, C, D, H, W)
+    zd, zh, zw = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing="ij")
+    off = torch.zeros(B, K, 3, D, H, W)
+    for t in range(K):
+        ti, tj, tk = t // 9, (t // 3) % 3, t % 3
+        off[:, t, 0] = (tgt[0] - (zd + ti - 1)).float()
+        off[:, t, 1] = (tgt[1] - (zh + tj - 1)).float()
+        off[:, t, 2] = (tgt[2] - (zw + tk - 1)).float()
+    off = off.reshape(B, 3 * K, D, H, W)
+    rgi, _, _, _ = oracle.deform_conv3d_backward(x, w, b, off, go, 1, 1, 1, 1, 1, q1_literal=False)
+    assert abs(rgi[0, 0, tgt[0], tgt[1], tgt[2]].item() - C * K * D * H * W) < 1e-3 * C * K * D * H * W   # everything lands on the target
+    gi, _, _, _ = ops.deform_conv3d_backward_cl(to_cl(x).to(dev), off.to(dev), w.to(dev), to_cl(go).to(dev), 1, 1)
+    assert_close("gx worst case", from_cl(gi), rgi, rtol=1e-5)
+
+
+def check_deform3d_cl_gx_fixed_vs_fp64(dev, B, C, dims, max_rel=4e-4):
+    """The fixed-point window against the fp64 window (DLKA_GX_FIXED=0) on the same inputs: its quantisation error, relative to
+    max|grad_input|.  The provable headroom (R*K contributions per cell) leaves ~17 bits for the largest possible contribution; measured on
+    the MI355X 1.9e-4 (C=32, 32^3) / 2.4e-4 (C=64, 16^3) with a power-of-two scale — bounded here at 4e-4, against the 1e-3 contract."""
+    x, off, w, b, go, _ = make_deform3d(B, C, C, dims, 3, 1, 1, 1, 1, 1, "normal", 0)
+    args = (to_cl(x).to(dev), off.to(dev), w.to(dev), to_cl(go).to(dev), 1, 1)
+    old = os.environ.get("DLKA_GX_FIXED")
+    try:
+        os.environ["DLKA_GX_FIXED"] = "1"
+        g_fx = ops.deform_conv3d_backward_cl(*args)[0].cpu()
+        os.environ["DLKA_GX_FIXED"] = "0"
+        g_64 = ops.deform_conv3d_backward_cl(*args)[0].cpu()
+    finally:
+        if old is None:
+            os.environ.pop("DLKA_GX_FIXED", None)
+        else:
+            os.environ["DLKA_GX_FIXED"] = old
+    err = rel_err(g_fx, g_64)
+    print(f"[gx fixed-point vs fp64 window, C={C} dims={dims}] max rel err {err:.3e}")
+    assert 0 < err <= max_rel, err      # > 0: the two variants really are different kernels
+    return err
+
+
 def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=2e-4, rtol=2e-3, report_offsets=False):
     """Token-layout fused block vs the oracle block (oracle/blocks.py)."""
     import deformablelka_amd as dk
@@ -275,6 +324,11 @@ def check_batchnorm_cl(dev, M, C, training, with_res, seed=0, mean_over_std=0.2)
         assert_close("bn mean", stats[:C], x.double().mean(0), atol=max(1e-5, 2e-7 * 1.5 * mean_over_std))   # one fp32 ulp of |mean|
         assert_close("bn var", stats[2 * C:], x.double().var(0, unbiased=True), rtol=1e-4)
     gx, gres, gw, gb = ops.batchnorm_cl_backward(gy.to(dev), x.to(dev), y, w.to(dev), stats, training, with_res=with_res)
+    # LeakyReLU has a kink at 0: where the pre-activation is within rounding of 0 the two implementations may sit on different sides
+    # of it (slope 1 vs 0.01) — those elements are compared through the parameter gradients only
+    away = (v.detach().abs() > 1e-5).to(gx.device)
+    gx = gx * away
+    xr.grad.mul_(away.cpu())
     assert_close("bn gx", gx, xr.grad, rtol=max(2e-4, 2e-6 * mean_over_std))
     assert_close("bn gw", gw, wr.grad, rtol=max(2e-4, 2e-6 * mean_over_std))
     assert_close("bn gb", gb, br.grad, rtol=2e-4)

@@ -119,3 +119,55 @@ def test_overlapped_allreduce_schedule_matches_single_process(tmp_path):
     _lib._set_backend_for_tests(None)
     assert torch.allclose(got["grads"], gsum, rtol=1e-5, atol=1e-6)
     assert torch.allclose(got["params"], p0 - LR / 2 * gsum, rtol=1e-5, atol=1e-6)
+
+
+def _worker_schedule(rank, world, port, out, failing_rank, fail_at):
+    """Unhappy path of the schedule choice: one rank's split capture (or trial step) fails -> EVERY rank must fall back to the single
+    all-reduce; the step then still produces the single-process result (mismatched collectives would hang or corrupt instead)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIPEMU_THREADS="2")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deformablelka_amd import dp
+    st = _make_stack(rank, STAGES2)
+    split = st.split_index(0.5)
+    cut = st.grad_offset_of(split)
+
+    def prepare():
+        if rank == failing_rank and fail_at == "prepare":
+            raise RuntimeError("simulated capture failure")
+        return True
+
+    def trial():
+        if rank == failing_rank and fail_at == "trial":
+            return False
+        st.forward(); st.backward(split, None); st.backward(0, split)
+        return True
+
+    sched = dp.choose_schedule(True, prepare, trial, dist, world, "cpu")
+    if sched == "overlap":
+        dp.step_overlap(st, LR, world, dist, lambda: (st.forward(), st.backward(split, None)), lambda: st.backward(0, split), cut)
+    else:
+        dp.step_single(st, LR, world, dist, st.forward_backward)
+    torch.save({"params": st.flat_params.clone(), "grads": st.flat_grads.clone(), "sched": sched}, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("failing_rank,fail_at,expect", [(1, "prepare", "single"), (0, "trial", "single"), (-1, "", "overlap")])
+def test_all_ranks_take_the_same_allreduce_schedule(tmp_path, failing_rank, fail_at, expect):
+    out = str(tmp_path / "rank")
+    mp.spawn(_worker_schedule, args=(2, _free_port(), out, failing_rank, fail_at), nprocs=2, join=True)
+    got = [torch.load(out + f".{r}") for r in range(2)]
+    assert got[0]["sched"] == got[1]["sched"] == expect
+    gsum, p0 = None, None
+    for r in range(2):
+        st = _make_stack(r, STAGES2)
+        p0 = st.flat_params.clone()
+        st.forward_backward()
+        gsum = st.flat_grads.clone() if gsum is None else gsum + st.flat_grads
+    from deformablelka_amd import _lib
+    _lib._set_backend_for_tests(None)
+    for g in got:
+        assert torch.allclose(g["grads"], gsum, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(g["params"], p0 - LR / 2 * gsum, rtol=1e-5, atol=1e-6)

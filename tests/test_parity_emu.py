@@ -186,3 +186,10 @@ def test_xcd_swizzled_tile_order():
         parity.check_conv3d_cl("cpu", 1, 32, 32, (7, 5, 10), 7, 9, 3, 32, planar=False)
     finally:
         del os.environ["DLKA_XCD_MIN"]
+
+
+def test_gx_fixed_point_window_worst_case_and_error():
+    """cl_deform_gx_kernel<true> (default at C <= 64): no overflow on the adversarial input its bound is built for, and its
+    quantisation error against the fp64 window."""
+    parity.check_deform3d_cl_gx_worst_case("cpu", 32, (6, 5, 9))
+    parity.check_deform3d_cl_gx_fixed_vs_fp64("cpu", 1, 32, (6, 5, 7))

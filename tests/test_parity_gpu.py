@@ -223,6 +223,17 @@ def test_deform3d_cl_headline_shape_vs_oracle():
     parity.check_deform3d_cl(DEV, 2, 32, 32, (32, 32, 32), off_mode="normal")
 
 
+@pytest.mark.parametrize("C,dims", [(32, (32, 32, 32)), (64, (16, 16, 16)), (32, (9, 7, 11))])
+def test_gx_fixed_point_window_worst_case(C, dims):
+    """Provable overflow bound of the fixed-point grad_input window at the full stage sizes: R*K same-sign maximal contributions per cell."""
+    parity.check_deform3d_cl_gx_worst_case(DEV, C, dims, B=2 if dims[0] > 9 else 1)
+
+
+@pytest.mark.parametrize("C,dims", [(32, (32, 32, 32)), (64, (16, 16, 16))])
+def test_gx_fixed_point_window_error_vs_fp64_window(C, dims):
+    parity.check_deform3d_cl_gx_fixed_vs_fp64(DEV, 2, C, dims)
+
+
 def test_tokens_full_size_stage0_matches_general_path():
     """BASELINE.json full size (C=32, 32^3, B=2): the token-layout fast path against our own general NCDHW path
     (which is pinned to the oracle above) — forward and all gradients."""
