@@ -27,7 +27,7 @@ import torch  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
-PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA (not the roof of the bf16 run: its contractions other than the offset conv stay on fp32 MFMA)
 
 
 def log(*a):
@@ -92,13 +92,17 @@ def time_ops(B, C, N, dtype, iters=10, only=None):
     dt = L.DLKA_F32 if dtype == torch.float32 else L.DLKA_BF16
     st = L.stream_ptr(torch.empty(1, device=dev))
     g = torch.Generator().manual_seed(0)
-    mk = lambda *s: torch.randn(*s, generator=g).to(dev, dtype)
+    bf16 = dtype == torch.bfloat16
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev, dtype)              # activations in the run's storage type
+    mkf = lambda *s: torch.randn(*s, generator=g).to(dev, torch.float32)     # offsets, parameters: always fp32
     x, go = mk(B, N, N, N, C), mk(B, N, N, N, C)                     # channels-last activations
-    off, goff = mk(B, 81, N, N, N), mk(B, 81, N, N, N)               # planar offsets
-    out, out_off = torch.empty_like(x), torch.empty_like(off)
-    w_pw, w5, w7 = mk(C, C, 1, 1, 1), mk(C, 1, 5, 5, 5), mk(C, 1, 7, 7, 7)
-    w_off, w_dc = mk(81, C, 3, 3, 3) * 0.02, mk(C, C, 3, 3, 3) * 0.03
-    b_c, b_81 = mk(C), mk(81)
+    off, goff = mkf(B, 81, N, N, N), mkf(B, 81, N, N, N)             # planar offsets
+    out, out_off = torch.empty(B, N, N, N, C, dtype=torch.float32, device=dev), torch.empty_like(off)   # (fp32-sized: also serves as fp32 grad_x)
+    w_pw, w5, w7 = mkf(C, C, 1, 1, 1), mkf(C, 1, 5, 5, 5), mkf(C, 1, 7, 7, 7)
+    w_off, w_dc = mkf(81, C, 3, 3, 3) * 0.02, mkf(C, C, 3, 3, 3) * 0.03
+    b_c, b_81 = mkf(C), mkf(81)
+    if bf16 and only is None:   # the per-op entry points carry bf16 activations for the deformable conv only (the dominant ops)
+        only = ("deform_fwd", "deform_bwd_input", "deform_bwd_offset", "deform_bwd_weight")
     gw_pw, gw5, gw7, gw_off, gw_dc = (torch.empty_like(t) for t in (w_pw, w5, w7, w_off, w_dc))
 
     def geom(cout, k, p, d, grp):
@@ -176,7 +180,7 @@ def roofline_report(B, dtype):
     C, N = 32, 32  # stage 0 carries ~70% of the step's FLOPs
     ms = time_ops(B, C, N, dtype)
     tab = op_table(B, C, N, dbytes)
-    peak_tf = PEAK_F32_TFLOPS if dtype == torch.float32 else PEAK_BF16_TFLOPS
+    peak_tf = PEAK_F32_TFLOPS   # the deformable conv's contractions run on the fp32-input MFMA in both storage modes
     ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
     rows = []
     for name, t in ms.items():
@@ -520,6 +524,9 @@ def main():
             except Exception as e:
                 log("cpu baseline failed:", repr(e))
                 out["cpu_baseline"] = None
+        if dtype == torch.bfloat16:
+            out["config"]["bf16"] = ("bf16 STORAGE of every activation tensor (x, y, saved, intermediate gradients); fp32 parameters, offsets, "
+                                     "grad_offset and accumulation; offset-predict conv on single bf16 MFMA products, the other contractions on fp32 MFMA")
         if not args.no_tblock and world == 1 and dtype == torch.float32:
             try:
                 out["tblock"] = tblock_metric(args.batch, max(3, args.steps // 2), 2, dev)

@@ -21,6 +21,9 @@ struct IgemmArgs {
     int xcd_nx;          // set by the launcher: > 0 = gridDim.x is xcd_grid(xcd_nx) and blockIdx.x is mapped through xcd_item() (dlka_common.h)
     int out_zeroed;      // 1: the caller has already zero-filled `out` (split partial sums meet there in atomics)
     int a_packed;        // AMODE 2 + split_bf16 == 2: `in` holds pack_split2() words (CinReal = CinP channel planes per batch, zero padded)
+    int act_bf16;        // 1: the activation tensors (in, aux, aux2, out, out2 — whatever is channels-last) are bf16 storage (DLKA_BF16 token path;
+                         //    fp32 arithmetic, fp32 weights / bias); planar tensors (offsets, grad_offset) are always fp32
+    int aux_f32;         // act_bf16 only: `aux` is fp32 all the same (the grad_input accumulation target of the deformable conv)
     int epi;             // 0: out = acc+bias | 1: out = acc+bias, out2 = gelu(out) | 2: out = acc+bias, out2 = aux*out | 3: out = acc+bias+aux
                          // 4: out = (acc+bias)*aux, out2 = (acc+bias)*aux2   (gate backward fused into proj_2's data gradient)
 };
@@ -35,6 +38,7 @@ struct WgradArgs {
     int Cin, Cout, CoutP;
     int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
     int rows_per_chunk;  // multiple of 32
+    int act_bf16;        // 1: `in` (and a channels-last `g`) are bf16 storage; a planar `g` (grad_offset) stays fp32
     int CT;              // Cin / 32
     int w16;             // set by the launcher: W % 16 == 0 (fast row addressing in cl_wgrad_dense_kernel)
     int xcd_ny, xcd_nz, xcd_total;   // set by the launcher: > 0 = 1-D XCD-swizzled grid over (chunk, y, z) work items, see xcd_item()
@@ -50,6 +54,7 @@ struct DwArgs {
     const float *gelu_x;   // optional fused epilogue (data gradient of dw 5^3 inside the D-LKA block): out = (acc + gelu_add) * gelu'(gelu_x)
     const float *gelu_add;
     int B, D, H, W, C;
+    int act_bf16;          // 1: in / out / gelu_x / gelu_add are bf16 storage
     int kd, kh, pd, ph, pw, dd, dh;   // kw / dw are template parameters
 };
 
@@ -61,6 +66,7 @@ struct DwWgradArgs {
     int B, D, H, W, C;
     int kd, kh, pd, ph, pw, dd, dh;
     int rows_per_block;
+    int act_bf16;       // 1: g / in are bf16 storage (the staging buffer gwp stays fp32)
     int xcd_nx;         // set by the launcher: > 0 = blockIdx.x is mapped through xcd_item()
 };
 
@@ -108,6 +114,7 @@ struct DeformBwdArgs {
     int xcd_nx;         // set by the launchers (per kernel): > 0 = blockIdx.x is mapped through xcd_item()
     int gx_zeroed;      // 1: the caller has already zero-filled gx
     int goff_zeroed;    // 1: the caller has already zero-filled goff (needed when cl_deform_goff_ccsplit() > 1)
+    int act_bf16;       // 1: in / g are bf16 storage (gx, goff stay fp32: atomics / planar)
     int goff_cpad;      // > 0: goff is written as pack_split2() words with goff_cpad channel planes per batch (planes >= 3K zero) for the
                         //      split-MFMA consumers (offset-conv data / weight gradient); 0: plain fp32 [B][3K][N]
 };

@@ -9,7 +9,7 @@ namespace dlka {
 // Every load is an unconditional buffer load: zero padding, rows beyond M and corners outside the volume read offset
 // DLKA_OOB and come back as 0, so there is no branch around a load and the loads of unit u+1 stay in flight under
 // the MFMAs of unit u.
-template <int AMODE>
+template <int AMODE, typename T = float>   // T: storage of a channels-last `in` (AMODE 0); planar inputs (AMODE 2) are always fp32
 struct ARow {
     int cur_tap;
     unsigned rowoff;     // AMODE 0: byte offset of the neighbour row; AMODE 2: of the neighbour voxel in plane 0; DLKA_OOB if padded
@@ -26,7 +26,7 @@ struct ARow {
                 const int zd = d0 + ti * p.dd - p.pd, zh = h0 + tj * p.dh - p.ph, zw = w0 + tk * p.dw - p.pw;
                 const bool ok = row_ok & ((unsigned)zd < (unsigned)p.D) & ((unsigned)zh < (unsigned)p.H) & ((unsigned)zw < (unsigned)p.W);
                 const int lin = (zd * p.H + zh) * p.W + zw;
-                rowoff = !ok ? DLKA_OOB : (AMODE == 0 ? (unsigned)((b * p.N + lin) * p.Cin) * 4u : (unsigned)(b * p.CinReal * p.N + lin) * 4u);
+                rowoff = !ok ? DLKA_OOB : (AMODE == 0 ? (unsigned)((b * p.N + lin) * p.Cin) * (unsigned)sizeof(T) : (unsigned)(b * p.CinReal * p.N + lin) * 4u);
             } else {
                 TapSample<3> s;
                 if (row_ok) {
@@ -48,7 +48,7 @@ struct ARow {
         if (AMODE == 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const f32x4 t = buf_load_f32x4(rin, rowoff + (unsigned)(c0 + 4 * e) * 4u);
+                const f32x4 t = act_buf_load4<T>(rin, rowoff + (unsigned)(c0 + 4 * e) * (unsigned)sizeof(T));
                 a[4 * e] = t[0]; a[4 * e + 1] = t[1]; a[4 * e + 2] = t[2]; a[4 * e + 3] = t[3];
             }
         } else if (AMODE == 2) {

@@ -211,9 +211,11 @@ __global__ __launch_bounds__(256) void cl_deform_goff_kernel(DeformBwdArgs p, in
 // (An intermediate version kept Col in the gather layout and reduced 8-lane groups with DPP; it needed 435 registers,
 //  ran one wave per SIMD and was no faster than the first kernel.)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NKC_REG>
+template <int NKC_REG, typename T = float>   // T: storage of `in` and `g` (channels-last); offsets / grad_offset are fp32 planar
 __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p, int taps_per_block)
 {
+    constexpr unsigned XB = sizeof(T);
+    const T *gin = reinterpret_cast<const T *>(p.g);
     constexpr int SROW = 36;
     __shared__ __attribute__((aligned(16))) float Bs2[2][32 * 32];          // W[tap][co chunk][ci chunk], double buffered
     __shared__ __attribute__((aligned(16))) float Tsm[4][3][32 * SROW];     // per wave: derivative-sample tiles (d, h, w)
@@ -229,12 +231,12 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
     const int b = row_ok ? m / p.N : 0;
     const int v = row_ok ? m - b * p.N : 0;
     const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / (p.W * p.H);
-    const int HW = p.H * p.W, rowbytes = p.C * 4;
+    const int HW = p.H * p.W, rowbytes = p.C * XB;
     const int ncc = p.C / 32, nkc = p.CoutP / 32;
     const int tap_lo = blockIdx.y * taps_per_block, tap_hi = min(p.K, tap_lo + taps_per_block);
     // blockIdx.z: slice of the 32-channel input chunks (tiny volumes only: the partial dots then meet in atomics on a zeroed goff)
     const int cc_lo = blockIdx.z * p.cc_per_block, cc_hi = min(ncc, cc_lo + p.cc_per_block), ncb = cc_hi - cc_lo;
-    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.C * 4);
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.C * XB);
     float *Tt = &Tsm[wave][0][0], *Dt = Dsm[wave];
 
     if (p.goff_cpad && blockIdx.y == 0 && blockIdx.z == 0 && h == 0 && row_ok) {   // the zero planes 3K .. goff_cpad-1 of the packed layout
@@ -246,10 +248,10 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
 #pragma unroll
         for (int kc = 0; kc < NKC_REG; ++kc) {
             const bool okg = row_ok && kc < nkc && kc * 32 + 16 * h < p.Cout;
-            const f32x4 *g4 = reinterpret_cast<const f32x4 *>(p.g + (okg ? (long)m * p.Cout + kc * 32 + 16 * h : 0));
+            const long gi = okg ? (long)m * p.Cout + kc * 32 + 16 * h : 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const f32x4 t = g4[e];
+                const f32x4 t = act_load4(gin, gi + 4 * e);
                 greg[kc][4 * e] = okg ? t[0] : 0.f; greg[kc][4 * e + 1] = okg ? t[1] : 0.f;
                 greg[kc][4 * e + 2] = okg ? t[2] : 0.f; greg[kc][4 * e + 3] = okg ? t[3] : 0.f;
             }
@@ -277,11 +279,11 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
         for (int g = 0; g < 4; ++g) rd[g] = gather_lookup(Dt, 8 * g + gr);
     };
     auto issue = [&](int cc) {
-        const unsigned cbyte = (unsigned)(cc * 32 + 4 * gp) * 4u;
+        const unsigned cbyte = (unsigned)(cc * 32 + 4 * gp) * XB;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) xr[g][q] = buf_load_f32x4(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
+            for (int q = 0; q < 8; ++q) xr[g][q] = act_buf_load4<T>(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
     };
 
     // weight tile of stage s = (tap, cc, kc) in flight in a register while the previous stage computes
@@ -316,10 +318,10 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
                 float gl[16];
                 if (NKC_REG == 0) {
                     const bool okg = row_ok && kc * 32 + 16 * h < p.Cout;
-                    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(p.g + (okg ? (long)m * p.Cout + kc * 32 + 16 * h : 0));
+                    const long gi = okg ? (long)m * p.Cout + kc * 32 + 16 * h : 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const f32x4 t = g4[e];
+                        const f32x4 t = act_load4(gin, gi + 4 * e);
                         gl[4 * e] = okg ? t[0] : 0.f; gl[4 * e + 1] = okg ? t[1] : 0.f; gl[4 * e + 2] = okg ? t[2] : 0.f; gl[4 * e + 3] = okg ? t[3] : 0.f;
                     }
                 }
@@ -434,9 +436,10 @@ __device__ __host__ __forceinline__ void gx_window(int b0, int bsz, int size, in
 // (the fp64 one is 122 KB).  The price is a per-(brick, slice) power-of-two scale; it is chosen from a Cauchy-Schwarz bound of |Col| so
 // that overflow is impossible for ANY offsets (see the kernel): 2^31 / (R*K) - 1 = 155 343 levels (17.2 bits) for the largest possible contribution
 // at the default brick (R*K = 512 * 27), i.e. an error <= 3.2e-6 of that bound per add; measured 1.9e-4 of max|grad_input| at 32^3.  Default where it is faster (C <= 64, resident weights).
-template <bool FX>
+template <bool FX, typename T = float>   // T: storage of grad_out `g` (channels-last); the windows, their scratch slabs and grad_input stay fp32
 __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwdArgs p, GxGeom gg, float *__restrict__ scratch)
 {
+    const T *gin = reinterpret_cast<const T *>(p.g);
     DLKA_DYN_SMEM(unsigned char, smem0);
     unsigned *smax = reinterpret_cast<unsigned *>(smem0);   // 16 bytes of scalars first (static LDS next to a 160 KB dynamic limit is refused)
     unsigned char *smem = smem0 + 16;
@@ -488,10 +491,10 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
         const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
         const bool ok = row < R && vd < p.D && vh < p.H && vw < p.W && kc * 32 + 16 * h < p.Cout;
         const long m = (long)b * p.N + (ok ? (vd * p.H + vh) * p.W + vw : 0);
-        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(p.g + (ok ? m * p.Cout + kc * 32 + 16 * h : 0));
+        const long gi = ok ? m * p.Cout + kc * 32 + 16 * h : 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const f32x4 t = g4[e];
+            const f32x4 t = act_load4(gin, gi + 4 * e);
             gl[4 * e] = ok ? t[0] : 0.f; gl[4 * e + 1] = ok ? t[1] : 0.f; gl[4 * e + 2] = ok ? t[2] : 0.f; gl[4 * e + 3] = ok ? t[3] : 0.f;
         }
     };
@@ -623,10 +626,10 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
                 const int rw = row % gg.bw, rh = (row / gg.bw) % gg.bh, rd = row / (gg.bw * gg.bh);
                 const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
                 if (vd < p.D && vh < p.H && vw < p.W) {
-                    const float *gp = p.g + ((long)b * p.N + (vd * p.H + vh) * p.W + vw) * p.Cout;
+                    const long gi = ((long)b * p.N + (vd * p.H + vh) * p.W + vw) * p.Cout;
                     float ss = 0.f;
                     for (int co = 0; co < p.Cout; co += 4) {
-                        const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gp + co);
+                        const f32x4 g4 = act_load4(gin, gi + co);
                         ss = fmaf(g4[0], g4[0], fmaf(g4[1], g4[1], fmaf(g4[2], g4[2], fmaf(g4[3], g4[3], ss))));
                     }
                     gm = fmaxf(gm, sqrtf(ss));
@@ -793,12 +796,18 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         dim3 grid(mblocks, tsplit, ccsplit), block(256);
         ag.xcd_nx = 0;
         if (!v1 && xcd_swizzle_enabled() && mblocks >= xcd_min_blocks()) { ag.xcd_nx = mblocks; grid.x = xcd_grid(mblocks); }
+        if (v1 && a.act_bf16) return DLKA_ERR_UNSUPPORTED;
         if (v1) {
             if (nkc == 1) { auto k = cl_deform_goff_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
             else if (nkc == 2) { auto k = cl_deform_goff_kernel<2>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
             else { auto k = cl_deform_goff_kernel<0>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
         } else {
-            if (nkc == 1) { auto k = cl_deform_goff2_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
+            if (a.act_bf16) {
+                if (nkc == 1) { auto k = cl_deform_goff2_kernel<1, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
+                else if (nkc == 2) { auto k = cl_deform_goff2_kernel<2, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
+                else { auto k = cl_deform_goff2_kernel<0, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
+            }
+            else if (nkc == 1) { auto k = cl_deform_goff2_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
             else if (nkc == 2) { auto k = cl_deform_goff2_kernel<2>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
             else { auto k = cl_deform_goff2_kernel<0>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
         }
@@ -840,9 +849,10 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         if (hipGetDevice(&dev) != hipSuccess) return DLKA_ERR_LAUNCH;
         const uint64_t bit = 1ull << (dev & 63);
         if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(cl_deform_gx_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void *>(cl_deform_gx_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return DLKA_ERR_LAUNCH;
+            const void *fns[4] = {reinterpret_cast<const void *>(cl_deform_gx_kernel<false>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true>),
+                                  reinterpret_cast<const void *>(cl_deform_gx_kernel<false, bf16_t>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true, bf16_t>)};
+            for (int f = 0; f < 4; ++f)
+                if (hipFuncSetAttribute(fns[f], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DLKA_ERR_LAUNCH;
             attr_done.fetch_or(bit, std::memory_order_release);
         }
 #endif
@@ -857,7 +867,11 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const dim3 gx_grid(gl_.xcd_nx ? xcd_grid(nx) : nx, item_grid ? 1 : g.nslices);
         static int gx_threads = 0;
         if (!gx_threads) { const char *e = getenv("DLKA_GX_THREADS"); gx_threads = e ? atoi(e) : 512; if (gx_threads != 256 && gx_threads != 512) gx_threads = 512; }
-        if (fixed) { auto k = cl_deform_gx_kernel<true>; hipLaunchKernelGGL(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
+        if (a.act_bf16) {
+            if (fixed) { auto k = cl_deform_gx_kernel<true, bf16_t>; hipLaunchKernelGGL(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
+            else { auto k = cl_deform_gx_kernel<false, bf16_t>; hipLaunchKernelGGL(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
+        }
+        else if (fixed) { auto k = cl_deform_gx_kernel<true>; hipLaunchKernelGGL(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
         else { auto k = cl_deform_gx_kernel<false>; hipLaunchKernelGGL(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
         DLKA_CHECK_LAUNCH();
         const long total = (long)a.B * a.N * g.nslices;

@@ -15,9 +15,10 @@
 
 namespace dlka {
 
-template <int NT>
+template <typename T, int NT>   // T: activation storage of `in` / `out` (float | bf16_t); split partial sums (gridDim.y > 1) always land in fp32
 __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
 {
+    constexpr unsigned SB = sizeof(T);
     constexpr int NPB = NT * 32;
     constexpr int BV = NT;
     constexpr int SROW = 36;   // padded sample-tile row (floats): 16-byte aligned, conflict-free b128 rows
@@ -36,8 +37,8 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
     const int v = row_ok ? m - b * p.N : 0;
     const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / (p.W * p.H);
     const int n0 = blockIdx.z * NPB;
-    const int HW = p.H * p.W, rowbytes = p.Cin * 4;
-    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * 4);
+    const int HW = p.H * p.W, rowbytes = p.Cin * SB;
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * SB);
     float *S = Ssm[wave], *Dt = Dsm[wave];
 
     f32x16 acc[NT];
@@ -84,11 +85,11 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
 #pragma unroll
             for (int g = 0; g < 4; ++g) rd[g] = gather_lookup(Dt, 8 * g + gr);
         }
-        const unsigned cbyte = (unsigned)(ck * 32 + 4 * gp) * 4u;
+        const unsigned cbyte = (unsigned)(ck * 32 + 4 * gp) * SB;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) xr[g][q] = buf_load_f32x4(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
+            for (int q = 0; q < 8; ++q) xr[g][q] = act_buf_load4<T>(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
     };
     // interpolate, transpose through the wave-private tile, return the MFMA A values of this lane
     auto finish = [&](float *a) {
@@ -149,9 +150,8 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
             const int mr = mbase + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (mr >= p.M) continue;
             const float val = acc[t][r] + bv;
-            float *dst = p.out + (long)mr * p.Cout + n;
-            if (split) atomicAdd(dst, val);
-            else *dst = val;
+            if (split) atomicAdd(p.out + (long)mr * p.Cout + n, val);   // fp32 accumulation buffer (the launcher's caller casts it for bf16)
+            else act_store1(reinterpret_cast<T *>(p.out), (long)mr * p.Cout + n, val);
         }
     }
 }
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
 int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
 {
     if ((long)a.M * a.Cin * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+    // act_bf16 with splits > 1: a.out must be an fp32 [M][Cout] accumulation buffer (the caller converts it afterwards)
     a.units_per_split = cdiv(a.K * (a.CinP / 32), splits);
     splits = cdiv(a.K * (a.CinP / 32), a.units_per_split);
     if (splits > 1 && !a.out_zeroed) {
@@ -179,11 +180,20 @@ int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
     dim3 grid(mblocks, splits, NT_total / NT), block(256);
     a.xcd_nx = 0;
     if (xcd_swizzle_enabled() && mblocks >= (unsigned)xcd_min_blocks()) { a.xcd_nx = mblocks; grid.x = xcd_grid(mblocks); }
-    switch (NT) {
-        case 1: { auto k = cl_deform_fwd_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
-        case 2: { auto k = cl_deform_fwd_kernel<2>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
-        case 4: { auto k = cl_deform_fwd_kernel<4>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
-        default: return DLKA_ERR_UNSUPPORTED;
+    if (a.act_bf16) {
+        switch (NT) {
+            case 1: { auto k = cl_deform_fwd_kernel<bf16_t, 1>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
+            case 2: { auto k = cl_deform_fwd_kernel<bf16_t, 2>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
+            case 4: { auto k = cl_deform_fwd_kernel<bf16_t, 4>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
+            default: return DLKA_ERR_UNSUPPORTED;
+        }
+    } else {
+        switch (NT) {
+            case 1: { auto k = cl_deform_fwd_kernel<float, 1>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
+            case 2: { auto k = cl_deform_fwd_kernel<float, 2>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
+            case 4: { auto k = cl_deform_fwd_kernel<float, 4>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
+            default: return DLKA_ERR_UNSUPPORTED;
+        }
     }
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;

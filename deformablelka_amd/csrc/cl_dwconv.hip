@@ -15,10 +15,13 @@
 
 namespace dlka {
 
-template <int KW, int DIL, int TW, int ABL = 0>   // ABL: ablation for profiling only (1 = no input loads, 2 = no FMAs)
+// T: activation storage (float, or bf16_t with fp32 arithmetic — DLKA_BF16 token path); weights / bias are fp32
+template <typename T, int KW, int DIL, int TW, int ABL = 0>   // ABL: ablation for profiling only (1 = no input loads, 2 = no FMAs)
 __global__ __launch_bounds__(256) void cl_dwconv_kernel(DwArgs p)
 {
     constexpr int SEG = TW + (KW - 1) * DIL;
+    const T *inp = reinterpret_cast<const T *>(p.in), *gxp = reinterpret_cast<const T *>(p.gelu_x), *gap = reinterpret_cast<const T *>(p.gelu_add);
+    T *outp = reinterpret_cast<T *>(p.out);
     const int cpb = p.C < 256 ? p.C : 256;           // channels per block
     const int rpb = 256 / cpb;                       // W-runs per block
     const int c = blockIdx.z * cpb + threadIdx.x % cpb;
@@ -41,12 +44,12 @@ __global__ __launch_bounds__(256) void cl_dwconv_kernel(DwArgs p)
         for (int j = 0; j < p.kh; ++j) {
             const int zh = h0 + j * p.dh - p.ph;
             if (zh < 0 || zh >= p.H) continue;
-            const float *rowp = p.in + (((long)(b * p.D + zd) * p.H + zh) * p.W) * p.C + c;
+            const T *rowp = inp + (((long)(b * p.D + zd) * p.H + zh) * p.W) * p.C + c;
             float seg[SEG];
 #pragma unroll
             for (int e = 0; e < SEG; ++e) {
                 const int zw = w0 - p.pw + e;
-                seg[e] = (ABL == 1) ? (float)(e + zh) : ((zw >= 0 && zw < p.W) ? rowp[(long)zw * p.C] : 0.f);
+                seg[e] = (ABL == 1) ? (float)(e + zh) : ((zw >= 0 && zw < p.W) ? act_load1(rowp, (long)zw * p.C) : 0.f);
             }
             const float *wrow = p.wp + (long)((i * p.kh + j) * KW) * p.C + c;
             if (ABL == 2) {
@@ -65,16 +68,15 @@ __global__ __launch_bounds__(256) void cl_dwconv_kernel(DwArgs p)
         }
     }
     const long obase = (((long)(b * p.D + d0) * p.H + h0) * p.W + w0) * p.C + c;
-    float *op = p.out + obase;
     if (p.gelu_x) {   // uniform: a = GELU(h) feeds dw 5^3 and the gate, so gh = (ga_gate + ga_dw5) * gelu'(h) closes here
 #pragma unroll
         for (int t = 0; t < TW; ++t)
-            if (w0 + t < p.W) op[(long)t * p.C] = (acc[t] + p.gelu_add[obase + (long)t * p.C]) * dgelu_f(p.gelu_x[obase + (long)t * p.C]);
+            if (w0 + t < p.W) act_store1(outp, obase + (long)t * p.C, (acc[t] + act_load1(gap, obase + (long)t * p.C)) * dgelu_f(act_load1(gxp, obase + (long)t * p.C)));
         return;
     }
 #pragma unroll
     for (int t = 0; t < TW; ++t)
-        if (w0 + t < p.W) op[(long)t * p.C] = acc[t];
+        if (w0 + t < p.W) act_store1(outp, obase + (long)t * p.C, acc[t]);
 }
 
 // Second generation of the forward / data-gradient kernel.  Same tiling; what changes is how the input row segment is read.  The first
@@ -84,10 +86,13 @@ __global__ __launch_bounds__(256) void cl_dwconv_kernel(DwArgs p)
 // bytes.  The per-lane offset ((w0 - pw + e)*C + c)*4 then needs no bounds code at all — left of the row it is "negative" (huge as
 // unsigned), right of it >= the size, and the hardware range check returns 0 for both.  One v_add + one buffer_load per element; rows
 // outside the volume are skipped by scalar branches; the tap weights come through the scalar offset.
-template <int KW, int DIL, int TW>
+template <typename T, int KW, int DIL, int TW>
 __global__ __launch_bounds__(256) void cl_dwconv_rows_kernel(DwArgs p)
 {
     constexpr int SEG = TW + (KW - 1) * DIL;
+    constexpr int SB = sizeof(T);
+    const T *inp = reinterpret_cast<const T *>(p.in), *gxp = reinterpret_cast<const T *>(p.gelu_x), *gap = reinterpret_cast<const T *>(p.gelu_add);
+    T *outp = reinterpret_cast<T *>(p.out);
     const int cpb = p.C < 256 ? p.C : 256;
     const int rpb = 256 / cpb;
     const int c = blockIdx.z * cpb + threadIdx.x % cpb;
@@ -106,10 +111,10 @@ __global__ __launch_bounds__(256) void cl_dwconv_rows_kernel(DwArgs p)
 #pragma unroll
     for (int t = 0; t < TW; ++t) acc[t] = bv;
 
-    const int cb = p.C * 4;                                  // bytes per voxel
+    const int cb = p.C * SB, cbw = p.C * 4;                  // bytes per voxel: activations / fp32 tap weights
     const unsigned rowbytes = (unsigned)(p.W * cb);
-    const int vbase = (w0 - p.pw) * cb + c * 4;              // byte offset of segment element 0 inside the row (may be negative)
-    const BufRsrc rwt = make_rsrc(p.wp, (size_t)p.kd * p.kh * KW * cb);
+    const int vbase = (w0 - p.pw) * cb + c * SB;             // byte offset of segment element 0 inside the row (may be negative)
+    const BufRsrc rwt = make_rsrc(p.wp, (size_t)p.kd * p.kh * KW * cbw);
     const unsigned cv = (unsigned)c * 4u;
     for (int i = 0; i < p.kd; ++i) {
         const int zd = d0 + i * p.dd - p.pd;
@@ -117,39 +122,41 @@ __global__ __launch_bounds__(256) void cl_dwconv_rows_kernel(DwArgs p)
         for (int j = 0; j < p.kh; ++j) {
             const int zh = h0 + j * p.dh - p.ph;
             if (zh < 0 || zh >= p.H) continue;               // scalar
-            const BufRsrc rr = make_rsrc(p.in + ((long)(b * p.D + zd) * p.H + zh) * p.W * p.C, rowbytes);
+            const BufRsrc rr = make_rsrc(inp + ((long)(b * p.D + zd) * p.H + zh) * p.W * p.C, rowbytes);
             float seg[SEG];
 #pragma unroll
-            for (int e = 0; e < SEG; ++e) seg[e] = buf_load_f32(rr, (unsigned)(vbase + e * cb));
-            const unsigned ws = (unsigned)((i * p.kh + j) * KW) * (unsigned)cb;
+            for (int e = 0; e < SEG; ++e) seg[e] = act_buf_load1<T>(rr, (unsigned)(vbase + e * cb));
+            const unsigned ws = (unsigned)((i * p.kh + j) * KW) * (unsigned)cbw;
 #pragma unroll
             for (int k = 0; k < KW; ++k) {
-                const float wv = buf_load_f32_s(rwt, cv, ws + (unsigned)(k * cb));
+                const float wv = buf_load_f32_s(rwt, cv, ws + (unsigned)(k * cbw));
 #pragma unroll
                 for (int t = 0; t < TW; ++t) acc[t] = fmaf(wv, seg[t + k * DIL], acc[t]);
             }
         }
     }
     const long obase = (((long)(b * p.D + d0) * p.H + h0) * p.W + w0) * p.C + c;
-    float *op = p.out + obase;
     if (p.gelu_x) {   // uniform: a = GELU(h) feeds dw 5^3 and the gate, so gh = (ga_gate + ga_dw5) * gelu'(h) closes here
 #pragma unroll
         for (int t = 0; t < TW; ++t)
-            if (w0 + t < p.W) op[(long)t * p.C] = (acc[t] + p.gelu_add[obase + (long)t * p.C]) * dgelu_f(p.gelu_x[obase + (long)t * p.C]);
+            if (w0 + t < p.W) act_store1(outp, obase + (long)t * p.C, (acc[t] + act_load1(gap, obase + (long)t * p.C)) * dgelu_f(act_load1(gxp, obase + (long)t * p.C)));
         return;
     }
 #pragma unroll
     for (int t = 0; t < TW; ++t)
-        if (w0 + t < p.W) op[(long)t * p.C] = acc[t];
+        if (w0 + t < p.W) act_store1(outp, obase + (long)t * p.C, acc[t]);
 }
 
 // ... and with TH output rows per work-item, h0, h0 + DIL, ...: with the loads lean, the kernel sits on the L1 return path (one 256-byte
 // wave load per segment element: 1.7 GB per launch at 32^3 for 7^3 dil 3), and output rows DIL apart share KH - 1 of their KH input
 // rows — KH + TH - 1 segment loads per tap plane feed TH * KH row products.  The tap plane's KH*KW weights sit in registers for all.
-template <int KW, int DIL, int TW, int TH>
+template <typename T, int KW, int DIL, int TW, int TH>
 __global__ __launch_bounds__(256) void cl_dwconv_rowsN_kernel(DwArgs p)
 {
     constexpr int KH = KW;
+    constexpr int SB = sizeof(T);
+    const T *inp = reinterpret_cast<const T *>(p.in), *gxp = reinterpret_cast<const T *>(p.gelu_x), *gap = reinterpret_cast<const T *>(p.gelu_add);
+    T *outp = reinterpret_cast<T *>(p.out);
     constexpr int SEG = TW + (KW - 1) * DIL;
     constexpr int NR = KH + TH - 1;                          // input rows per tap plane
     const int cpb = p.C < 256 ? p.C : 256;
@@ -175,10 +182,10 @@ __global__ __launch_bounds__(256) void cl_dwconv_rowsN_kernel(DwArgs p)
 #pragma unroll
         for (int t = 0; t < TW; ++t) acc[o][t] = bv;
 
-    const int cb = p.C * 4;
+    const int cb = p.C * SB, cbw = p.C * 4;
     const unsigned rowbytes = (unsigned)(p.W * cb);
-    const int vbase = (w0 - p.pw) * cb + c * 4;
-    const BufRsrc rwt = make_rsrc(p.wp, (size_t)p.kd * KH * KW * cb);
+    const int vbase = (w0 - p.pw) * cb + c * SB;
+    const BufRsrc rwt = make_rsrc(p.wp, (size_t)p.kd * KH * KW * cbw);
     const unsigned cv = (unsigned)c * 4u;
     for (int i = 0; i < p.kd; ++i) {
         const int zd = d0 + i * p.dd - p.pd;
@@ -187,8 +194,8 @@ __global__ __launch_bounds__(256) void cl_dwconv_rowsN_kernel(DwArgs p)
 #pragma unroll
         for (int j = 0; j < KH; ++j)
 #pragma unroll
-            for (int k = 0; k < KW; ++k) wv[j][k] = buf_load_f32_s(rwt, cv, (unsigned)(((i * KH + j) * KW + k) * cb));
-        const float *plane = p.in + ((long)(b * p.D + zd) * p.H) * p.W * p.C;
+            for (int k = 0; k < KW; ++k) wv[j][k] = buf_load_f32_s(rwt, cv, (unsigned)(((i * KH + j) * KW + k) * cbw));
+        const T *plane = inp + ((long)(b * p.D + zd) * p.H) * p.W * p.C;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {                       // input row h0 - ph + r*DIL: tap row r - o of output row o
             const int zh = h0 - p.ph + r * DIL;
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(256) void cl_dwconv_rowsN_kernel(DwArgs p)
             const BufRsrc rr = make_rsrc(plane + (long)zh * p.W * p.C, rowbytes);
             float seg[SEG];
 #pragma unroll
-            for (int e = 0; e < SEG; ++e) seg[e] = buf_load_f32(rr, (unsigned)(vbase + e * cb));
+            for (int e = 0; e < SEG; ++e) seg[e] = act_buf_load1<T>(rr, (unsigned)(vbase + e * cb));
 #pragma unroll
             for (int o = 0; o < TH; ++o) {
                 if (r - o < 0 || r - o >= KH) continue;      // compile time
@@ -211,15 +218,14 @@ __global__ __launch_bounds__(256) void cl_dwconv_rowsN_kernel(DwArgs p)
     for (int o = 0; o < TH; ++o) {
         if (h0 + o * DIL >= p.H) break;                      // scalar
         const long obase = (((long)(b * p.D + d0) * p.H + h0 + o * DIL) * p.W + w0) * p.C + c;
-        float *op = p.out + obase;
         if (p.gelu_x) {
 #pragma unroll
             for (int t = 0; t < TW; ++t)
-                if (w0 + t < p.W) op[(long)t * p.C] = (acc[o][t] + p.gelu_add[obase + (long)t * p.C]) * dgelu_f(p.gelu_x[obase + (long)t * p.C]);
+                if (w0 + t < p.W) act_store1(outp, obase + (long)t * p.C, (acc[o][t] + act_load1(gap, obase + (long)t * p.C)) * dgelu_f(act_load1(gxp, obase + (long)t * p.C)));
         } else {
 #pragma unroll
             for (int t = 0; t < TW; ++t)
-                if (w0 + t < p.W) op[(long)t * p.C] = acc[o][t];
+                if (w0 + t < p.W) act_store1(outp, obase + (long)t * p.C, acc[o][t]);
         }
     }
 }
@@ -242,13 +248,16 @@ int launch_cl_dw_prep_weight(const float *w, float *wp, int C, int K, int flip, 
 }
 
 // kw, dil_w select the instantiation; returns DLKA_ERR_UNSUPPORTED for other shapes (caller falls back to conv.hip)
-int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st)
+template <typename T>
+static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st)
 {
     constexpr int TW = 8;
+    constexpr bool F32 = sizeof(T) == 4;   // the bf16 storage path is instantiated for the two D-LKA shapes only (5^3, 7^3 dil 3)
     const int cpb = a.C < 256 ? a.C : 256, rpb = 256 / cpb;
     const long runs = (long)a.B * a.D * a.H * cdiv(a.W, TW);
     dim3 grid((unsigned)cdivl(runs, rpb), 1, cdiv(a.C, cpb)), block(256);
     if (256 % cpb != 0) return DLKA_ERR_UNSUPPORTED;
+    if (!F32 && !((kw == 5 && dil_w == 1) || (kw == 7 && dil_w == 3))) return DLKA_ERR_UNSUPPORTED;
     static const bool v1 = getenv("DLKA_DW_V1") != nullptr;   // A/B switch: first generation (conditional global loads)
     static const int abl0 = getenv("DLKA_DW_ABL") ? atoi(getenv("DLKA_DW_ABL")) : 0;
     // the rows kernel needs (b, d, h) uniform per wave: the 64 / cpb runs of a wave must not straddle two rows
@@ -260,41 +269,53 @@ int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st)
         static const int th_env = getenv("DLKA_DW_TH") ? atoi(getenv("DLKA_DW_TH")) : 0;   // tuning knob: 1 / 2 output rows per work-item
         const bool cubic = a.kd == kw && a.kh == kw && a.dd == dil_w && a.dh == dil_w;
         const int th = th_env ? th_env : 2;
-        if ((th == 2 || th == 3) && cubic && a.H >= th * dil_w && ((kw == 7 && dil_w == 3) || (kw == 5 && dil_w == 1))) {
+        if ((th == 2 || (th == 3 && F32)) && cubic && a.H >= th * dil_w && ((kw == 7 && dil_w == 3) || (kw == 5 && dil_w == 1))) {
             const long runs2 = (long)a.B * a.D * dil_w * cdiv(a.H, th * dil_w) * cdiv(a.W, TW);
             dim3 grid2((unsigned)cdivl(runs2, rpb), 1, cdiv(a.C, cpb));
             swz(grid2);
-            if (kw == 7 && th == 2) { auto k = cl_dwconv_rowsN_kernel<7, 3, TW, 2>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
-            else if (kw == 7) { auto k = cl_dwconv_rowsN_kernel<7, 3, TW, 3>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
-            else if (th == 2) { auto k = cl_dwconv_rowsN_kernel<5, 1, TW, 2>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
-            else { auto k = cl_dwconv_rowsN_kernel<5, 1, TW, 3>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
+            if (kw == 7 && th == 2) { auto k = cl_dwconv_rowsN_kernel<T, 7, 3, TW, 2>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
+            else if (kw == 5 && th == 2) { auto k = cl_dwconv_rowsN_kernel<T, 5, 1, TW, 2>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
+            else if constexpr (F32) {
+                if (kw == 7) { auto k = cl_dwconv_rowsN_kernel<float, 7, 3, TW, 3>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
+                else { auto k = cl_dwconv_rowsN_kernel<float, 5, 1, TW, 3>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
+            }
             DLKA_CHECK_LAUNCH();
             return DLKA_OK;
         }
         bool done = true;
         dim3 grid1 = grid;
         swz(grid1);
-        if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
-        else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_rows_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
-        else if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<3, 1, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
-        else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_rows_kernel<5, 3, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
-        else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<7, 1, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
-        else done = false;
+        if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<T, 5, 1, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
+        else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_rows_kernel<T, 7, 3, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
+        else if constexpr (F32) {
+            if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<float, 3, 1, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
+            else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_rows_kernel<float, 5, 3, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
+            else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<float, 7, 1, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
+            else done = false;
+        } else done = false;
         if (done) { DLKA_CHECK_LAUNCH(); return DLKA_OK; }
     }
-    if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_kernel<T, 5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
     else if (kw == 7 && dil_w == 3) {
         static const int abl = getenv("DLKA_DW_ABL") ? atoi(getenv("DLKA_DW_ABL")) : 0;   // profiling ablation only
-        if (abl == 1) { auto k = cl_dwconv_kernel<7, 3, TW, 1>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-        else if (abl == 2) { auto k = cl_dwconv_kernel<7, 3, TW, 2>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-        else { auto k = cl_dwconv_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        if (F32 && abl == 1) { auto k = cl_dwconv_kernel<float, 7, 3, TW, 1>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else if (F32 && abl == 2) { auto k = cl_dwconv_kernel<float, 7, 3, TW, 2>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else { auto k = cl_dwconv_kernel<T, 7, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
     }
-    else if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_kernel<3, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-    else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_kernel<5, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-    else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_kernel<7, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else if constexpr (F32) {
+        if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_kernel<float, 3, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_kernel<float, 5, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_kernel<float, 7, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else return DLKA_ERR_UNSUPPORTED;
+    }
     else return DLKA_ERR_UNSUPPORTED;
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
+}
+
+int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st)
+{
+    return a.act_bf16 ? launch_cl_dwconv_t<bf16_t>(a, kw, dil_w, st) : launch_cl_dwconv_t<float>(a, kw, dil_w, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -302,10 +323,11 @@ int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st)
 // grid.y = (i, j) tap rows; a work-item owns channel c and strides over (b, d, h, W-run); KW accumulators.
 // Work-items of a block that share c fold through LDS, then one fp32 atomic per (c, tap) per block into gWp[tap][c].
 // ---------------------------------------------------------------------------------------------
-template <int KW, int DIL, int TW>
+template <typename T, int KW, int DIL, int TW>
 __global__ __launch_bounds__(256) void cl_dwconv_wgrad_kernel(DwWgradArgs p)
 {
     constexpr int SEG = TW + (KW - 1) * DIL;
+    const T *inp = reinterpret_cast<const T *>(p.in), *gin = reinterpret_cast<const T *>(p.g);
     __shared__ float red[256 * KW];
     const int cpb = p.C < 256 ? p.C : 256, rpb = 256 / cpb;
     const int c = blockIdx.z * cpb + threadIdx.x % cpb;
@@ -328,20 +350,20 @@ __global__ __launch_bounds__(256) void cl_dwconv_wgrad_kernel(DwWgradArgs p)
             const int zd = d0 + i * p.dd - p.pd, zh = h0 + j * p.dh - p.ph;
             const bool rows_ok = !(zd < 0 || zd >= p.D || zh < 0 || zh >= p.H);
             if (!rows_ok && !want_bias) continue;
-            const float *gp = p.g + (((long)(b * p.D + d0) * p.H + h0) * p.W + w0) * p.C + c;
+            const T *gp = gin + (((long)(b * p.D + d0) * p.H + h0) * p.W + w0) * p.C + c;
             float gv[TW], seg[SEG];
 #pragma unroll
-            for (int t = 0; t < TW; ++t) gv[t] = (w0 + t < p.W) ? gp[(long)t * p.C] : 0.f;
+            for (int t = 0; t < TW; ++t) gv[t] = (w0 + t < p.W) ? act_load1(gp, (long)t * p.C) : 0.f;
             if (want_bias) {
 #pragma unroll
                 for (int t = 0; t < TW; ++t) bsum += gv[t];
             }
             if (!rows_ok) continue;
-            const float *rowp = p.in + (((long)(b * p.D + zd) * p.H + zh) * p.W) * p.C + c;
+            const T *rowp = inp + (((long)(b * p.D + zd) * p.H + zh) * p.W) * p.C + c;
 #pragma unroll
             for (int e = 0; e < SEG; ++e) {
                 const int zw = w0 - p.pw + e;
-                seg[e] = (zw >= 0 && zw < p.W) ? rowp[(long)zw * p.C] : 0.f;
+                seg[e] = (zw >= 0 && zw < p.W) ? act_load1(rowp, (long)zw * p.C) : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < KW; ++k)
@@ -389,10 +411,12 @@ __global__ __launch_bounds__(256) void cl_dwconv_wgrad_kernel(DwWgradArgs p)
 // 1.65 in the first version, which re-read the input segment for every (i, j) — that kernel was bound by the L1 request rate:
 // 177 us at C=32 / 32^3, profiles/r01n).  grid.y = kd.  The bias gradient rides on the (i, j) = centre-tap pairing, which visits every
 // grad_output element exactly once.
-template <int KW, int DIL, int TW>
+template <typename T, int KW, int DIL, int TW>
 __global__ __launch_bounds__(256) void cl_dwconv_wgrad2_kernel(DwWgradArgs p)
 {
     constexpr int KH = KW;
+    constexpr int SB = sizeof(T);
+    const T *inp = reinterpret_cast<const T *>(p.in), *gin = reinterpret_cast<const T *>(p.g);
     constexpr int SEG = TW + (KW - 1) * DIL;
     __shared__ float red[256 * KW];
     const int cpb = p.C < 256 ? p.C : 256, rpb = 256 / cpb;
@@ -416,7 +440,7 @@ __global__ __launch_bounds__(256) void cl_dwconv_wgrad2_kernel(DwWgradArgs p)
     if (c < p.C) {
         // every load is a buffer load against a descriptor of ONE row (built by the scalar unit: the rows of a wave's runs are
         // wave-uniform, the launcher checks it): no bounds code per element, see cl_dwconv_rows_kernel
-        const int cb = p.C * 4;
+        const int cb = p.C * SB;
         const unsigned rowbytes = (unsigned)(p.W * cb);
         for (long run = run_lo + rsub; run < run_hi; run += rpb) {
             const int w0 = (int)(run % runs_per_row) * TW;
@@ -424,13 +448,13 @@ __global__ __launch_bounds__(256) void cl_dwconv_wgrad2_kernel(DwWgradArgs p)
             const int zh = row % p.H, zd = (row / p.H) % p.D, b = row / (p.H * p.D);
             const int d0 = zd - doff;
             if (d0 < 0 || d0 >= p.D) continue;   // scalar
-            const BufRsrc rx = make_rsrc(p.in + (((long)(b * p.D + zd) * p.H + zh) * p.W) * p.C, rowbytes);
-            const int vbase = (w0 - p.pw) * cb + c * 4;
+            const BufRsrc rx = make_rsrc(inp + (((long)(b * p.D + zd) * p.H + zh) * p.W) * p.C, rowbytes);
+            const int vbase = (w0 - p.pw) * cb + c * SB;
             float seg[SEG];
 #pragma unroll
-            for (int e = 0; e < SEG; ++e) seg[e] = buf_load_f32(rx, (unsigned)(vbase + e * cb));
-            const float *gplane = p.g + ((long)(b * p.D + d0) * p.H * p.W) * p.C;
-            const unsigned gbase = (unsigned)(w0 * cb + c * 4);
+            for (int e = 0; e < SEG; ++e) seg[e] = act_buf_load1<T>(rx, (unsigned)(vbase + e * cb));
+            const T *gplane = gin + ((long)(b * p.D + d0) * p.H * p.W) * p.C;
+            const unsigned gbase = (unsigned)(w0 * cb + c * SB);
 #pragma unroll
             for (int j = 0; j < KH; ++j) {
                 const int hoff = j * p.dh - p.ph;
@@ -439,7 +463,7 @@ __global__ __launch_bounds__(256) void cl_dwconv_wgrad2_kernel(DwWgradArgs p)
                 const BufRsrc rg = make_rsrc(gplane + (long)h0 * p.W * p.C, rowbytes);
                 float gv[TW];
 #pragma unroll
-                for (int t = 0; t < TW; ++t) gv[t] = buf_load_f32(rg, gbase + (unsigned)(t * cb));   // w0 + t >= W: beyond the row -> 0
+                for (int t = 0; t < TW; ++t) gv[t] = act_buf_load1<T>(rg, gbase + (unsigned)(t * cb));   // w0 + t >= W: beyond the row -> 0
                 if (bias_slice && hoff == 0) {
 #pragma unroll
                     for (int t = 0; t < TW; ++t) bsum += gv[t];
@@ -480,9 +504,12 @@ __global__ __launch_bounds__(256) void cl_dwconv_wgrad2_kernel(DwWgradArgs p)
 
 static inline dim3 block256() { return dim3(256); }
 
-int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st, bool zero_init)
+template <typename T>
+static int launch_cl_dwconv_wgrad_t(DwWgradArgs a, int kw, int dil_w, hipStream_t st, bool zero_init)
 {
     constexpr int TW = 8;
+    constexpr bool F32 = sizeof(T) == 4;   // bf16 storage: the two D-LKA shapes only
+    if (!F32 && !((kw == 5 && dil_w == 1) || (kw == 7 && dil_w == 3))) return DLKA_ERR_UNSUPPORTED;
     const int cpb = a.C < 256 ? a.C : 256;
     if (256 % cpb != 0) return DLKA_ERR_UNSUPPORTED;
     const int rows = a.B * a.D * a.H;
@@ -511,24 +538,29 @@ int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st, boo
         dim3 grid2(xb, a.kd, cdiv(a.C, cpb));
         a.xcd_nx = 0;
         if (xcd_swizzle_enabled() && xb >= (unsigned)xcd_min_blocks()) { a.xcd_nx = xb; grid2.x = xcd_grid(xb); }
-        if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
-        else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_wgrad2_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
-        else if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<3, 1, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
-        else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_wgrad2_kernel<5, 3, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
-        else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<7, 1, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
+        if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<T, 5, 1, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
+        else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_wgrad2_kernel<T, 7, 3, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
+        else if (F32 && kw == 3 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<float, 3, 1, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
+        else if (F32 && kw == 5 && dil_w == 3) { auto k = cl_dwconv_wgrad2_kernel<float, 5, 3, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
+        else if (F32 && kw == 7 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<float, 7, 1, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
         else return DLKA_ERR_UNSUPPORTED;
         DLKA_CHECK_LAUNCH();
         return DLKA_OK;
     }
     dim3 grid(xb, a.kd * a.kh, cdiv(a.C, cpb)), block(256);
-    if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-    else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_wgrad_kernel<7, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-    else if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<3, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-    else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_wgrad_kernel<5, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-    else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<7, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<T, 5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_wgrad_kernel<T, 7, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else if (F32 && kw == 3 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<float, 3, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else if (F32 && kw == 5 && dil_w == 3) { auto k = cl_dwconv_wgrad_kernel<float, 5, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else if (F32 && kw == 7 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<float, 7, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
     else return DLKA_ERR_UNSUPPORTED;
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
+}
+
+int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st, bool zero_init)
+{
+    return a.act_bf16 ? launch_cl_dwconv_wgrad_t<bf16_t>(a, kw, dil_w, st, zero_init) : launch_cl_dwconv_wgrad_t<float>(a, kw, dil_w, st, zero_init);
 }
 
 // gWp[tap][c] -> reference layout gW[c][1][taps] in storage type T

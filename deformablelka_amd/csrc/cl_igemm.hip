@@ -29,9 +29,12 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 // SPLIT = 3: three-term operands and the six products above 2^-24 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid): fp32-equivalent
 // (the dropped terms are below fp32's own rounding), 12 x 32 cycles per unit and tile — 2.7x the fp32-input MFMA.  Used for the FORWARD
 // offset conv, whose output decides floor() of the sampling positions and must not move by 1e-5; records [(part*2+mf)*2+h], part 0..2.
-template <int AMODE, int OMODE, int NT, int SPLIT = 0>
+// T: storage of the channels-last activation tensors (AMODE 0 `in`; OMODE 0 `out` / `out2` / `aux` / `aux2`): float, or bf16_t (DLKA_BF16
+// token path).  A bf16 A operand is its own high term, so the split contraction drops the a_lo products.  Planar tensors stay fp32.
+template <int AMODE, int OMODE, int NT, int SPLIT = 0, typename T = float>
 __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
 {
+    constexpr bool A16 = AMODE == 0 && sizeof(T) == 2;   // A values are exact bf16
     constexpr int NPB = NT * 32;                 // columns handled by this block
     constexpr int UF = SPLIT == 3 ? 48 : 32;     // floats of prepared weights per unit and column
     constexpr int BV = (UF * NPB / 4 + 255) / 256;   // float4 of the weight chunk each of the 256 threads stages
@@ -59,8 +62,8 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
     const int unit_hi = min(p.K * nchunk, unit_lo + p.units_per_split);
 
     // software pipeline: while the MFMAs of unit u run, the weight chunk and the A values of unit u+1 are in flight
-    const BufRsrc rin = make_rsrc(p.in, AMODE == 2 ? (size_t)p.B * p.CinReal * p.N * 4 : (size_t)p.M * p.Cin * 4);
-    ARow<AMODE> arow;
+    const BufRsrc rin = make_rsrc(p.in, AMODE == 2 ? (size_t)p.B * p.CinReal * p.N * 4 : (size_t)p.M * p.Cin * sizeof(T));
+    ARow<AMODE, T> arow;
     f32x4 breg[BV];   // ext_vector_type: stays in registers across iterations (HIP's float4 struct did not)
     float a_cur[16], a_nxt[16];
 #define DLKA_LOAD_B(unit_)                                                                         \
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const bf16x8 bhi = B16[((0 * 2 + mf) * 2 + h) * NPB + t * 32 + i], blo = B16[((1 * 2 + mf) * 2 + h) * NPB + t * 32 + i];
-                    acc[t] = mfma_32x32x16_bf16(alo, bhi, acc[t]);   // small terms first
+                    if (!A16) acc[t] = mfma_32x32x16_bf16(alo, bhi, acc[t]);   // small terms first (a bf16 A has no low term)
                     acc[t] = mfma_32x32x16_bf16(ahi, blo, acc[t]);
                     acc[t] = mfma_32x32x16_bf16(ahi, bhi, acc[t]);
                 }
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
         // per cache line).  Transpose each 32 x 32 tile through LDS so that lanes run over voxels: every store / atomic
         // then covers 128 contiguous bytes of one plane.  (The weight buffers are free once the main loop is done.)
         __syncthreads();
-        float *T = &Bs[0][0] + wave * (32 * 33);
+        float *Tt = &Bs[0][0] + wave * (32 * 33);
         const int mr = mbase + i;
         const bool rok = mr < p.M;
         const int bb = rok ? mr / p.N : 0, vv = rok ? mr - bb * p.N : 0;
@@ -156,13 +159,13 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
         for (int t = 0; t < NT; ++t) {
             wave_sync();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + i] = acc[t][r];
+            for (int r = 0; r < 16; ++r) Tt[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + i] = acc[t][r];
             wave_sync();
 #pragma unroll
             for (int cc = 0; cc < 16; ++cc) {
                 const int col = 2 * cc + h, n = n0 + t * 32 + col;
                 if (n >= p.Cout) continue;   // uniform per half-wave
-                float val = T[i * 33 + col];
+                float val = Tt[i * 33 + col];
                 if (p.bias && blockIdx.y == 0) val += p.bias[n];
                 if (!rok) continue;
                 float *dst = p.out + ((long)bb * p.Cout + n) * p.N + vv;
@@ -183,22 +186,25 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
             if (mr >= p.M) continue;
             float val = acc[t][r] + bv;
             const long o = (long)mr * p.Cout + n;
-            if (split) {
-                if (p.epi == 3 && blockIdx.y == 0) val += p.aux[o];   // the residual / fan-in term enters once
+            T *outp = reinterpret_cast<T *>(p.out), *out2p = reinterpret_cast<T *>(p.out2);
+            const T *auxp = reinterpret_cast<const T *>(p.aux), *aux2p = reinterpret_cast<const T *>(p.aux2);
+            const float auxv = (p.epi >= 2 && !(split && blockIdx.y != 0)) ? ((sizeof(T) == 2 && p.aux_f32) ? p.aux[o] : act_load1(auxp, o)) : 0.f;
+            if (split) {   // partial sums meet in an fp32 buffer (for bf16 storage the caller converts it afterwards)
+                if (p.epi == 3 && blockIdx.y == 0) val += auxv;   // the residual / fan-in term enters once
                 atomicAdd(p.out + o, val);
             } else if (p.epi == 0) {
-                p.out[o] = val;
+                act_store1(outp, o, val);
             } else if (p.epi == 1) {
-                p.out[o] = val;
-                p.out2[o] = gelu_erf(val);
+                act_store1(outp, o, val);
+                act_store1(out2p, o, gelu_erf(val));
             } else if (p.epi == 2) {
-                p.out[o] = val;
-                p.out2[o] = p.aux[o] * val;
+                act_store1(outp, o, val);
+                act_store1(out2p, o, auxv * val);
             } else if (p.epi == 3) {
-                p.out[o] = val + p.aux[o];
+                act_store1(outp, o, val + auxv);
             } else {
-                p.out[o] = val * p.aux[o];
-                p.out2[o] = val * p.aux2[o];
+                act_store1(outp, o, val * auxv);
+                act_store1(out2p, o, val * act_load1(aux2p, o));
             }
         }
     }
@@ -294,7 +300,7 @@ int launch_cl_prep_batch(const PrepBatch &b, hipStream_t st)
     return DLKA_OK;
 }
 
-template <int AMODE, int OMODE, int SPLIT = 0>
+template <int AMODE, int OMODE, int SPLIT = 0, typename T = float>
 static int launch_igemm_nt(const IgemmArgs &a, int splits, hipStream_t st)
 {
     const int NT_total = a.NP / 32;
@@ -310,7 +316,7 @@ static int launch_igemm_nt(const IgemmArgs &a, int splits, hipStream_t st)
     if (xcd_swizzle_enabled() && a.K > 1 && mblocks >= (unsigned)xcd_min_blocks()) { ax.xcd_nx = mblocks; grid.x = xcd_grid(mblocks); }
 #define DLKA_IG(NTV)                                              \
     {                                                             \
-        auto k = cl_igemm_kernel<AMODE, OMODE, NTV, SPLIT>;       \
+        auto k = cl_igemm_kernel<AMODE, OMODE, NTV, SPLIT, T>;    \
         hipLaunchKernelGGL(k, grid, block, 0, st, ax);            \
     }
     switch (NT) {
@@ -362,6 +368,12 @@ int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t s
     if (splits > 1 && !a.out_zeroed) {
         const long n = (long)a.M * a.Cout;
         if (launch_zero(a.out, (size_t)n * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
+    }
+    if (a.act_bf16) {   // bf16 activation storage (DLKA_BF16 token path): the two 27-tap convs of the block, two-term weight layout
+        if (a.split_bf16 != 2) return DLKA_ERR_UNSUPPORTED;
+        if (amode == 0 && omode == 1) return launch_igemm_nt<0, 1, 2, bf16_t>(a, splits, st);   // offset-predict conv forward (fp32 planar out)
+        if (amode == 2 && omode == 0) return launch_igemm_nt<2, 0, 2, bf16_t>(a, splits, st);   // its data gradient (fp32 planar in, bf16 out)
+        return DLKA_ERR_UNSUPPORTED;
     }
     if (a.split_bf16) {   // bf16 x3 split contraction (the prepared weights must be in the split layout)
         {   // wave-granular variant first (no LDS staging, no barriers); the zero fill for split partial sums was done above

@@ -12,16 +12,19 @@
 
 namespace dlka {
 
-template <int UNUSED = 0>
+template <typename T>   // activation storage: float, or bf16_t (fp32 arithmetic either way; weights / bias are fp32)
 __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
 {
+    constexpr unsigned SB = sizeof(T);
+    const T *auxp = reinterpret_cast<const T *>(p.aux), *aux2p = reinterpret_cast<const T *>(p.aux2);
+    T *outp = reinterpret_cast<T *>(p.out), *out2p = reinterpret_cast<T *>(p.out2);
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
     const int mbase = blockIdx.x * 32, n0 = blockIdx.y * 32;
     const int m = mbase + i, n = n0 + i;
-    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * 4);
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * SB);
     const BufRsrc rw = make_rsrc(p.wp, (size_t)p.CinP * p.NP * 4);
     // MFMA k order within a 32-channel chunk: step s contracts channels s (lanes 0-31) and 16 + s (lanes 32-63) — the same on both operands
-    const unsigned abase = m < p.M ? (unsigned)m * (unsigned)p.Cin * 4u + 64u * h : DLKA_OOB;
+    const unsigned abase = m < p.M ? (unsigned)m * (unsigned)p.Cin * SB + 16u * SB * h : DLKA_OOB;
     const unsigned bbase = ((unsigned)(16 * h) * (unsigned)p.NP + (unsigned)n) * 4u;
     const unsigned bstep = (unsigned)p.NP * 4u;
     f32x16 acc;
@@ -36,8 +39,8 @@ __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
         for (int r = 0; r < 16; ++r) {
             const int mr = mbase + (r & 3) + 8 * (r >> 2) + 4 * h;
             const bool ok = n_ok && mr < p.M;
-            auxv[r] = ok ? p.aux[(long)mr * p.Cout + n] : 0.f;
-            aux2v[r] = (ok && p.epi == 4) ? p.aux2[(long)mr * p.Cout + n] : 0.f;
+            auxv[r] = ok ? act_load1(auxp, (long)mr * p.Cout + n) : 0.f;
+            aux2v[r] = (ok && p.epi == 4) ? act_load1(aux2p, (long)mr * p.Cout + n) : 0.f;
         }
     }
     const int nchunk = p.CinP / 32;
@@ -47,10 +50,10 @@ __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (c0 + u >= nchunk) break;   // uniform
-            const unsigned ao = abase + (unsigned)(c0 + u) * 128u;
+            const unsigned ao = abase + (unsigned)(c0 + u) * 32u * SB;
             const unsigned bo = bbase + (unsigned)(c0 + u) * 32u * bstep;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[u][e] = buf_load_f32x4(rin, ao + 16u * e);
+            for (int e = 0; e < 4; ++e) a[u][e] = act_buf_load4<T>(rin, ao + 4u * SB * e);
 #pragma unroll
             for (int s = 0; s < 16; ++s) b[u][s] = buf_load_f32(rw, bo + (unsigned)s * bstep);
         }
@@ -71,18 +74,18 @@ __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
         const float val = acc[r] + bv;
         const long o = (long)mr * p.Cout + n;
         if (p.epi == 0) {
-            p.out[o] = val;
+            act_store1(outp, o, val);
         } else if (p.epi == 1) {
-            p.out[o] = val;
-            p.out2[o] = gelu_f(val);
+            act_store1(outp, o, val);
+            act_store1(out2p, o, gelu_f(val));
         } else if (p.epi == 2) {
-            p.out[o] = val;
-            p.out2[o] = auxv[r] * val;
+            act_store1(outp, o, val);
+            act_store1(out2p, o, auxv[r] * val);
         } else if (p.epi == 3) {
-            p.out[o] = val + auxv[r];
+            act_store1(outp, o, val + auxv[r]);
         } else {
-            p.out[o] = val * auxv[r];
-            p.out2[o] = val * aux2v[r];
+            act_store1(outp, o, val * auxv[r]);
+            act_store1(out2p, o, val * aux2v[r]);
         }
     }
 }
@@ -93,8 +96,8 @@ int launch_cl_pointwise(const IgemmArgs &a, hipStream_t st)
     if (a.K != 1 || a.split_bf16 || a.Cin % 32 || a.CinP != a.Cin || a.NP % 32) return DLKA_ERR_UNSUPPORTED;
     if ((long)a.M * a.Cin * 4 >= (1l << 31) || (long)a.CinP * a.NP * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     dim3 grid(cdiv(a.M, 32), a.NP / 32), block(64);
-    auto k = cl_pointwise_kernel<0>;
-    hipLaunchKernelGGL(k, grid, block, 0, st, a);
+    if (a.act_bf16) { auto k = cl_pointwise_kernel<bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    else { auto k = cl_pointwise_kernel<float>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }

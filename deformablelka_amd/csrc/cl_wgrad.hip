@@ -196,9 +196,10 @@ __global__ __launch_bounds__(64) void cl_wgrad_kernel(WgradArgs p)
 //     gW[co][ci][tap] = sum_m G[m][co] * S(m, tap, ci)
 // One wave = one 32(co) x 32(ci) tile x TPW taps over a chunk of rows.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TPW>
+template <int TPW, typename T = float>   // T: storage of `in` and `g` (both channels-last)
 __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
 {
+    constexpr unsigned XB = sizeof(T);
     constexpr int SROW = 36;
     __shared__ __attribute__((aligned(16))) float Ssm[2][32 * SROW];
     __shared__ __attribute__((aligned(16))) float Dt[32 * GATHER_DESC_WORDS];
@@ -215,9 +216,9 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
     const int ntap = min(TPW, p.K - tap0);
     const int co = ot * 32 + i;
     const bool want_bias = p.bpart && ct == 0 && bz == 0;
-    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * 4), rg = make_rsrc(p.g, (size_t)p.M * p.Cout * 4);
-    const int HW = p.H * p.W, rowbytes = p.Cin * 4;
-    const unsigned cbyte = (unsigned)(ct * 32 + 4 * gp) * 4u;
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * XB), rg = make_rsrc(p.g, (size_t)p.M * p.Cout * XB);
+    const int HW = p.H * p.W, rowbytes = p.Cin * XB;
+    const unsigned cbyte = (unsigned)(ct * 32 + 4 * gp) * XB;
 
     f32x16 acc[TPW];
 #pragma unroll
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int mm = mbase + 16 * h + s;
-            ga[s] = buf_load_f32(rg, (mm < m_hi && co < p.Cout) ? (unsigned)(mm * p.Cout + co) * 4u : DLKA_OOB);
+            ga[s] = act_buf_load1<T>(rg, (mm < m_hi && co < p.Cout) ? (unsigned)(mm * p.Cout + co) * XB : DLKA_OOB);
         }
         // describing lane: row m = mbase + i
         const int m = mbase + i;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
             for (int g = 0; g < 4; ++g) {
                 rd[g] = gather_lookup(Dt, 8 * g + gr);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) xr[g][q] = buf_load_f32x4(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
+                for (int q = 0; q < 8; ++q) xr[g][q] = act_buf_load4<T>(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
             }
         };
         describe_issue(0);
@@ -314,9 +315,13 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
 // ---------------------------------------------------------------------------------------------------------------------
 // SPLIT: bf16 x3-split contraction (dlka_intrin.h) instead of the exact fp32-input MFMA: 54 x 32 cycles per 32-row step instead
 // of 144 x 64 for the 3 x 3 blocking.
-template <int GMODE, int COT, int TPW, bool N16, bool SPLIT>   // N16: N % 16 == 0 (the 16 rows of a half-wave never straddle two volumes)
+// T: storage of `in` and of a channels-last `g` (GMODE 0); a planar `g` (GMODE 1: grad_offset) is always fp32.  A bf16 `in` is its own high
+// term, so the split contraction drops the b_lo product.
+template <int GMODE, int COT, int TPW, bool N16, bool SPLIT, typename T>   // N16: N % 16 == 0 (the 16 rows of a half-wave never straddle two volumes)
 __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int bz_in)
 {
+    constexpr unsigned XB = sizeof(T), GB = GMODE == 0 ? sizeof(T) : 4u;
+    constexpr bool B16 = sizeof(T) == 2;
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
     int chunk = blockIdx.x, by = blockIdx.y, bz = bz_in;
     if (p.xcd_total) {   // XCD-swizzled 1-D grid (see cl_wgrad_deform_kernel)
@@ -355,7 +360,7 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
 
     float ga_n[COT][16], bv_n[TPW][16];
     const int gcp = (GMODE == 1 && p.g_cpad) ? p.g_cpad : p.Cout;   // channel planes per batch of a planar g
-    const BufRsrc rg = make_rsrc(p.g, (size_t)p.B * p.N * gcp * 4), rx = make_rsrc(p.in, (size_t)p.M * p.Cin * 4);
+    const BufRsrc rg = make_rsrc(p.g, (size_t)p.B * p.N * gcp * GB), rx = make_rsrc(p.in, (size_t)p.M * p.Cin * XB);
     // operands of the 32-row step starting at mbase: rows m = mbase + 16h + s.  Every load is an unconditional buffer
     // load; rows beyond the chunk, channels beyond Cout and zero-padded neighbours read offset DLKA_OOB -> 0.
     auto load_step = [&](int mbase) {
@@ -368,7 +373,7 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const int m = mrow0 + s;
-                    ga_n[c][s] = buf_load_f32(rg, (m < m_hi && co < p.Cout) ? (unsigned)(m * p.Cout + co) * 4u : DLKA_OOB);
+                    ga_n[c][s] = act_buf_load1<T>(rg, (m < m_hi && co < p.Cout) ? (unsigned)(m * p.Cout + co) * XB : DLKA_OOB);
                 }
             } else if (N16) {   // 16 consecutive voxels of one plane, 64-byte aligned: four 16-byte loads
                 const unsigned off = (mrow0 < m_hi && co < p.Cout) ? (unsigned)((b0 * gcp + co) * p.N + v0) * 4u : DLKA_OOB;
@@ -390,7 +395,7 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int m = mrow0 + s;
-                bv_n[0][s] = buf_load_f32(rx, (m < m_hi) ? (unsigned)(m * p.Cin + ci) * 4u : DLKA_OOB);
+                bv_n[0][s] = act_buf_load1<T>(rx, (m < m_hi) ? (unsigned)(m * p.Cin + ci) * XB : DLKA_OOB);
             }
         } else if (N16 && p.w16 && p.kw == 3 && p.dw == 1) {
             // Fast addressing (W % 16 == 0, 3-wide taps): the 16 voxels of a half-wave are one aligned run of a W-row, so (d, h) — and with
@@ -399,21 +404,21 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
             // (tap, row).  (The general decode below was half of this kernel's VALU time,
             // and the kernel is VALU-bound: matrix cores 17 % busy, profiles/r01u_pmc_offc.txt.)
             const int w_ = v0 % p.W, hh = (v0 / p.W) % p.H, d_ = v0 / (p.W * p.H);
-            const unsigned base = (mrow0 < m_hi) ? (unsigned)((b0 * p.N + v0) * p.Cin + ci) * 4u : DLKA_OOB;
-            const unsigned rs = (unsigned)p.Cin * 4u;
+            const unsigned base = (mrow0 < m_hi) ? (unsigned)((b0 * p.N + v0) * p.Cin + ci) * XB : DLKA_OOB;
+            const unsigned rs = (unsigned)p.Cin * XB;
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const int zd = d_ + od[t], zh = hh + oh[t];
                 const bool ok = (tap0 + t < p.K) & (base != DLKA_OOB) & ((unsigned)zd < (unsigned)p.D) & ((unsigned)zh < (unsigned)p.H);
-                const int doff = ((od[t] * p.H + oh[t]) * p.W + ow[t]) * p.Cin * 4;
+                const int doff = ((od[t] * p.H + oh[t]) * p.W + ow[t]) * p.Cin * (int)XB;
                 const unsigned tb = ok ? base + (unsigned)doff : DLKA_OOB;
                 const unsigned tb0 = (w_ + ow[t] >= 0) ? tb : DLKA_OOB, tb15 = (w_ + 15 + ow[t] < p.W) ? tb : DLKA_OOB;
                 // (the row stride is added in the vector offset, not the scalar one: the hardware range-checks the vector offset alone, and
                 //  tb itself can lie one element before the buffer when the run starts the tensor and the tap looks left)
-                bv_n[t][0] = buf_load_f32(rx, tb0);
+                bv_n[t][0] = act_buf_load1<T>(rx, tb0);
 #pragma unroll
-                for (int s = 1; s < 15; ++s) bv_n[t][s] = buf_load_f32(rx, tb + (unsigned)s * rs);
-                bv_n[t][15] = buf_load_f32(rx, tb15 + 15u * rs);
+                for (int s = 1; s < 15; ++s) bv_n[t][s] = act_buf_load1<T>(rx, tb + (unsigned)s * rs);
+                bv_n[t][15] = act_buf_load1<T>(rx, tb15 + 15u * rs);
             }
         } else {
             int crd[16];
@@ -422,11 +427,11 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
                 // 16 consecutive voxels of one volume: decode the first (three runtime divisions, ~60 VALU instructions),
                 // walk the rest with carries — the per-row div/mod chain was most of this kernel's VALU time
                 int w_ = v0 % p.W, hh = (v0 / p.W) % p.H, d_ = v0 / (p.W * p.H);
-                const unsigned base = (unsigned)((b0 * p.N + v0) * p.Cin + ci) * 4u;
+                const unsigned base = (unsigned)((b0 * p.N + v0) * p.Cin + ci) * XB;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     crd[s] = (mrow0 + s < m_hi) ? ((d_ << 20) | (hh << 10) | w_) : -1;
-                    rowoff[s] = base + (unsigned)(s * p.Cin) * 4u;
+                    rowoff[s] = base + (unsigned)(s * p.Cin) * XB;
                     ++w_;
                     if (w_ == p.W) { w_ = 0; ++hh; if (hh == p.H) { hh = 0; ++d_; } }
                 }
@@ -438,20 +443,20 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
                     if (v >= p.N) { b = (mrow0 + s) / p.N; v = (mrow0 + s) - b * p.N; }
                     const int w_ = v % p.W, hh = (v / p.W) % p.H, d_ = v / (p.W * p.H);
                     crd[s] = (mrow0 + s < m_hi) ? ((d_ << 20) | (hh << 10) | w_) : -1;
-                    rowoff[s] = (unsigned)((b * p.N + v) * p.Cin + ci) * 4u;
+                    rowoff[s] = (unsigned)((b * p.N + v) * p.Cin + ci) * XB;
                 }
             }
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const bool tap_ok = tap0 + t < p.K;  // uniform
-                const int doff = ((od[t] * p.H + oh[t]) * p.W + ow[t]) * p.Cin * 4;
+                const int doff = ((od[t] * p.H + oh[t]) * p.W + ow[t]) * p.Cin * (int)XB;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const int c_ = crd[s];
                     const int zd = (c_ >> 20) + od[t], zh = ((c_ >> 10) & 1023) + oh[t], zw = (c_ & 1023) + ow[t];
                     // bitwise, not short-circuit: the compiler turns && chains into a branch per element
                     const bool ok = tap_ok & (c_ >= 0) & ((unsigned)zd < (unsigned)p.D) & ((unsigned)zh < (unsigned)p.H) & ((unsigned)zw < (unsigned)p.W);
-                    bv_n[t][s] = buf_load_f32(rx, ok ? rowoff[s] + (unsigned)doff : DLKA_OOB);
+                    bv_n[t][s] = act_buf_load1<T>(rx, ok ? rowoff[s] + (unsigned)doff : DLKA_OOB);
                 }
             }
         }
@@ -497,7 +502,7 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
 #pragma unroll
                     for (int t = 0; t < TPW; ++t) {
                         acc[c][t] = mfma_32x32x16_bf16(alo[c], bhi[t], acc[c][t]);
-                        acc[c][t] = mfma_32x32x16_bf16(ahi[c], blo[t], acc[c][t]);
+                        if (!B16) acc[c][t] = mfma_32x32x16_bf16(ahi[c], blo[t], acc[c][t]);   // a bf16 `in` has no low term
                         acc[c][t] = mfma_32x32x16_bf16(ahi[c], bhi[t], acc[c][t]);
                     }
             }
@@ -533,19 +538,19 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
     }
 }
 
-template <int GMODE, int COT, int TPW, bool N16, bool SPLIT = false>
+template <int GMODE, int COT, int TPW, bool N16, bool SPLIT = false, typename T = float>
 __global__ __launch_bounds__(64) void cl_wgrad_dense_kernel(WgradArgs p)
 {
-    wgrad_dense_body<GMODE, COT, TPW, N16, SPLIT>(p, blockIdx.z);
+    wgrad_dense_body<GMODE, COT, TPW, N16, SPLIT, T>(p, blockIdx.z);
 }
 
 // The three pointwise weight gradients of a D-LKA block (proj_2, conv1, proj_1: same geometry, different operands) in ONE
 // launch, blockIdx.z = job: every dependent kernel node costs ~4.5 us inside the graph, and each of these is a ~1 us kernel.
 struct WgradArgs3 { WgradArgs a[3]; };
-template <int COT, bool N16>
+template <int COT, bool N16, typename T = float>
 __global__ __launch_bounds__(64) void cl_wgrad_pw3_kernel(WgradArgs3 b)
 {
-    wgrad_dense_body<0, COT, 1, N16, false>(b.a[blockIdx.z], 0);
+    wgrad_dense_body<0, COT, 1, N16, false, T>(b.a[blockIdx.z], 0);
 }
 
 // gW[co][ci][tap] (reference layout, storage type T) = sum_chunk part[chunk][tap][co][ci];  gb[co] = sum_chunk bpart[chunk][co]
@@ -658,7 +663,11 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
             a.xcd_ny = grid.y; a.xcd_nz = grid.z; a.xcd_total = (int)(grid.x * grid.y * grid.z);
             grid = dim3(xcd_grid(a.xcd_total), 1, 1);
         }
-        if (v1) { auto k = cl_wgrad_kernel<1, 0, 7>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        if (a.act_bf16) {
+            if (v1 || pl.tpw != 3) return DLKA_ERR_UNSUPPORTED;
+            auto k = cl_wgrad_deform_kernel<3, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, a);
+        }
+        else if (v1) { auto k = cl_wgrad_kernel<1, 0, 7>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
         else if (pl.tpw == 3) { auto k = cl_wgrad_deform_kernel<3>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
         else if (pl.tpw == 4) { auto k = cl_wgrad_deform_kernel<4>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
         else { auto k = cl_wgrad_deform_kernel<7>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
@@ -678,7 +687,16 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
         else if ((a.N & 15) == 0) { auto k = cl_wgrad_dense_kernel<GM, CO, TP, true>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }  \
         else { auto k = cl_wgrad_dense_kernel<GM, CO, TP, false>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }              \
     }
-        if (a.K == 1) {
+        if (a.act_bf16) {   // DLKA_BF16 token path: only the offset-predict conv's weight gradient comes through here (planar fp32 g, bf16 in)
+            if (a.K == 1 || gmode != 1 || !split || a.g_cpad || pl.tpw != 3) return DLKA_ERR_UNSUPPORTED;
+#define DLKA_WGB(CO)                                                                                                                           \
+    {                                                                                                                                          \
+        if ((a.N & 15) == 0) { auto k = cl_wgrad_dense_kernel<1, CO, 3, true, true, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }    \
+        else { auto k = cl_wgrad_dense_kernel<1, CO, 3, false, true, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }                   \
+    }
+            if (pl.cot == 3) DLKA_WGB(3) else if (pl.cot == 2) DLKA_WGB(2) else DLKA_WGB(1)
+#undef DLKA_WGB
+        } else if (a.K == 1) {
             if (gmode != 0) return DLKA_ERR_UNSUPPORTED;
             if (pl.cot == 2) DLKA_WG(0, 2, 1) else DLKA_WG(0, 1, 1)
         } else if (gmode == 1) {
@@ -728,7 +746,13 @@ int launch_cl_wgrad_pw3(const WgradArgs *jobs, float *const *gw, float *const *g
     }
     dim3 grid(nchunks, cdiv(OT, pl.cot) * CT, 3), block(64);
     const bool n16 = (a0.N & 15) == 0;
-    if (pl.cot == 2 && n16) { auto k = cl_wgrad_pw3_kernel<2, true>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
+    if (a0.act_bf16) {
+        if (pl.cot == 2 && n16) { auto k = cl_wgrad_pw3_kernel<2, true, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
+        else if (pl.cot == 2) { auto k = cl_wgrad_pw3_kernel<2, false, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
+        else if (n16) { auto k = cl_wgrad_pw3_kernel<1, true, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
+        else { auto k = cl_wgrad_pw3_kernel<1, false, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
+    }
+    else if (pl.cot == 2 && n16) { auto k = cl_wgrad_pw3_kernel<2, true>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
     else if (pl.cot == 2) { auto k = cl_wgrad_pw3_kernel<2, false>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
     else if (n16) { auto k = cl_wgrad_pw3_kernel<1, true>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
     else { auto k = cl_wgrad_pw3_kernel<1, false>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }

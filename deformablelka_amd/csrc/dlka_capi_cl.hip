@@ -38,6 +38,7 @@ struct Carver {
 struct SameConv {
     int B, D, H, W, N, M, Cin, Cout, group;
     int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
+    int act_bf16;   // 1: channels-last activation tensors are bf16 storage (DLKA_BF16 token path); planar offsets / grad_offset stay fp32
 };
 
 int make_same_conv(const dlka_conv_geom *c, SameConv &s)
@@ -56,6 +57,7 @@ int make_same_conv(const dlka_conv_geom *c, SameConv &s)
     s.Cin = c->C; s.Cout = c->Cout; s.group = c->group;
     s.kd = c->kd; s.kh = c->kh; s.kw = c->kw; s.pd = c->pd; s.ph = c->ph; s.pw = c->pw;
     s.dd = c->dd; s.dh = c->dh; s.dw = c->dw; s.K = c->kd * c->kh * c->kw;
+    s.act_bf16 = 0;
     return DLKA_OK;
 }
 
@@ -82,6 +84,7 @@ int use_split(const SameConv &s, bool forward)
 {
     static const bool exact = getenv("DLKA_EXACT_FP32") != nullptr;
     static const int fwd = getenv("DLKA_SPLIT_FORWARD") ? atoi(getenv("DLKA_SPLIT_FORWARD")) : 3;
+    if (s.act_bf16) return s.K > 1 ? 2 : 0;   // bf16 activations are their own high term: two-term weights, no a_lo products (cl_igemm.hip)
     if (exact || s.K <= 1) return 0;
     if (!forward) return 2;
     return (fwd == 2 || fwd == 3) ? fwd : 0;
@@ -93,6 +96,7 @@ void fill_igemm(IgemmArgs &a, const SameConv &s)
     memset(&a, 0, sizeof(a));
     a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M;
     a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
+    a.act_bf16 = s.act_bf16;
 }
 
 // ---- dense conv forward: out = conv(x) (+ epilogue) ---------------------------------------------------------------
@@ -118,8 +122,11 @@ int dense_forward(const SameConv &s, const float *x, const float *w, const float
 
 // ---- dense conv data gradient: gx = conv_transpose(gout) (+ epilogue) ---------------------------------------------
 // wp must hold K * round_up(Cout,32) * Cin floats.  gout channels-last needs Cout % 32 == 0; planar any Cout.
+// bf16 storage: `aux_f32` says the epilogue operand is fp32 all the same; `acc32` (fp32 [M][Cin], ZEROED by the caller) receives split
+// partial sums and is converted into gx afterwards
 int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, const float *w, float *gx, float *wp, int epi,
-                        const float *aux, hipStream_t st, const float *aux2 = nullptr, float *out2 = nullptr, bool zeroed = false, bool g_packed = false)
+                        const float *aux, hipStream_t st, const float *aux2 = nullptr, float *out2 = nullptr, bool zeroed = false, bool g_packed = false,
+                        bool aux_f32 = false, float *acc32 = nullptr)
 {
     const int KP = round_up(s.Cout, 32), NP = s.Cin;
     if (!nt_ok(NP) || s.Cin % 32) return DLKA_ERR_UNSUPPORTED;
@@ -136,7 +143,14 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
         if (!gout_planar || split != 2) return DLKA_ERR_UNSUPPORTED;
         a.a_packed = 1; a.CinReal = KP;
     }
+    a.aux_f32 = aux_f32 ? 1 : 0;
     const int splits = dense_backward_data_splits(s, epi);
+    if (s.act_bf16 && splits > 1) {
+        if (!acc32) return DLKA_ERR_WORKSPACE;
+        a.out = acc32; a.out_zeroed = 1;
+        DLKA_TRY(launch_cl_igemm(gout_planar ? 2 : 0, 0, a, splits, st));
+        return launch_cast_from_f32<bf16_t>(acc32, reinterpret_cast<bf16_t *>(gx), (long)s.M * s.Cin, st);
+    }
     return launch_cl_igemm(gout_planar ? 2 : 0, 0, a, splits, st);
 }
 
@@ -157,6 +171,7 @@ int dense_backward_weight(const SameConv &s, const float *x, const float *gout, 
     if (s.K == 1 && gout_planar) return DLKA_ERR_UNSUPPORTED;
     if (g_cpad && (!gout_planar || s.K == 1)) return DLKA_ERR_UNSUPPORTED;
     a.g_cpad = g_cpad;
+    a.act_bf16 = s.act_bf16;
     return launch_cl_wgrad<float>(0, gout_planar ? 1 : 0, a, gw, gb, st, defer);
 }
 
@@ -166,6 +181,7 @@ void fill_pw_wgrad(WgradArgs &a, const SameConv &s, const float *x, const float 
     a.g = gout; a.in = x; a.part = part;
     a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.Cin = s.Cin; a.Cout = s.Cout;
     a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
+    a.act_bf16 = s.act_bf16;
 }
 
 // ---- depthwise ------------------------------------------------------------------------------------------------------
@@ -176,6 +192,7 @@ int dw_forward(const SameConv &s, const float *x, const float *w, const float *b
     DwArgs a;
     a.in = x; a.wp = wp; a.bias = bias; a.out = out; a.gelu_x = gelu_x; a.gelu_add = gelu_add;
     a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.C = s.Cin;
+    a.act_bf16 = s.act_bf16; a.xcd_nx = 0;
     a.kd = s.kd; a.kh = s.kh; a.dd = s.dd; a.dh = s.dh;
     if (flip) { a.pd = s.dd * (s.kd - 1) - s.pd; a.ph = s.dh * (s.kh - 1) - s.ph; a.pw = s.dw * (s.kw - 1) - s.pw; }
     else { a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; }
@@ -191,6 +208,7 @@ int dw_backward_weight(const SameConv &s, const float *x, const float *gout, flo
     a.g = gout; a.in = x; a.gwp = gwp; a.gb = defer ? gwp + (size_t)s.K * s.Cin : gb;
     a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.C = s.Cin;
     a.kd = s.kd; a.kh = s.kh; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh;
+    a.act_bf16 = s.act_bf16;
     if (defer) {
         DLKA_TRY(launch_cl_dwconv_wgrad(a, s.kw, s.dw, st, false));
         memset(defer, 0, sizeof(*defer));
@@ -205,8 +223,9 @@ int dw_backward_weight(const SameConv &s, const float *x, const float *gout, flo
 // ---- deformable (groups = deformable_groups = 1) ---------------------------------------------------------------------
 bool deform_supported(const SameConv &s) { return s.group == 1 && s.Cin % 32 == 0 && s.Cout % 32 == 0 && nt_ok(s.Cout) && nt_ok(s.Cin); }
 
+// bf16 storage with a tap split: `acc32` (fp32 [M][Cout], ZEROED by the caller) receives the partial sums and is converted into `out`
 int deform_forward(const SameConv &s, const float *x, const float *off, const float *w, const float *bias, float *out, float *wp, hipStream_t st,
-                   bool zeroed = false)
+                   bool zeroed = false, float *acc32 = nullptr)
 {
     if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, s.Cout, 0, st));
     IgemmArgs a;
@@ -214,6 +233,15 @@ int deform_forward(const SameConv &s, const float *x, const float *off, const fl
     a.in = x; a.off = off; a.wp = wp; a.bias = bias; a.out = out; a.epi = 0; a.out_zeroed = zeroed ? 1 : 0;
     a.Cin = s.Cin; a.CinReal = s.Cin; a.CinP = s.Cin; a.Cout = s.Cout; a.NP = s.Cout;
     const int splits = dense_forward_splits(s, 0);
+    if (s.act_bf16) {
+        if (splits > 1) {
+            if (!acc32) return DLKA_ERR_WORKSPACE;
+            a.out = acc32; a.out_zeroed = 1;
+            DLKA_TRY(launch_cl_deform_fwd(a, splits, st));
+            return launch_cast_from_f32<bf16_t>(acc32, reinterpret_cast<bf16_t *>(out), (long)s.M * s.Cout, st);
+        }
+        return launch_cl_deform_fwd(a, splits, st);
+    }
     static const bool old_path = getenv("DLKA_DEFORM_FWD_IGEMM") != nullptr;   // A/B switch: first-generation "lane = row" gather
     if (!old_path) {
         const int rc = launch_cl_deform_fwd(a, splits, st);
@@ -227,6 +255,7 @@ void fill_deform_bwd(DeformBwdArgs &a, const SameConv &s)
     memset(&a, 0, sizeof(a));
     a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.C = s.Cin; a.Cout = s.Cout; a.CoutP = s.Cout;
     a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
+    a.act_bf16 = s.act_bf16;
 }
 
 // scratch floats of the brick windows the grad_input scatter flushes (cl_deform_bwd2.hip)
@@ -259,7 +288,7 @@ int deform_backward(const SameConv &s, const float *x, const float *off, const f
         DeformBwdArgs a;
         fill_deform_bwd(a, s);
         a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff; a.gx_zeroed = gx_zeroed ? 1 : 0; a.goff_zeroed = goff_zeroed ? 1 : 0; a.goff_cpad = goff_cpad;
-        const int variant = deform_bwd_variant();
+        const int variant = s.act_bf16 ? 0 : deform_bwd_variant();
         if (variant == 0) DLKA_TRY(launch_cl_deform_bwd2(a, scratch, st));
         else if (variant == 2 && s.N >= 512) DLKA_TRY(launch_cl_deform_bwd_lds(a, st));
         else DLKA_TRY(launch_cl_deform_bwd(a, st));
@@ -270,17 +299,20 @@ int deform_backward(const SameConv &s, const float *x, const float *off, const f
         a.g = gout; a.in = x; a.off = off; a.part = part;
         a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.Cin = s.Cin; a.Cout = s.Cout;
         a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
+        a.act_bf16 = s.act_bf16;
         DLKA_TRY(launch_cl_wgrad<float>(1, 0, a, gw, gb, st, defer));
     } else if (gb) {
+        if (s.act_bf16) return DLKA_ERR_UNSUPPORTED;
         DLKA_TRY(launch_cl_colsum(gout, gb, s.M, s.Cout, st));
     }
     return DLKA_OK;
 }
 
 // ---- the token-layout 3-D block ----------------------------------------------------------------------------------------
-SameConv block_conv(int B, int C, int Cout, int D, int H, int W, int k, int pad, int dil, int group)
+SameConv block_conv(int B, int C, int Cout, int D, int H, int W, int k, int pad, int dil, int group, int act_bf16 = 0)
 {
     SameConv s;
+    s.act_bf16 = act_bf16;
     s.B = B; s.D = D; s.H = H; s.W = W; s.N = D * H * W; s.M = B * s.N; s.Cin = C; s.Cout = Cout; s.group = group;
     s.kd = s.kh = s.kw = k; s.pd = s.ph = s.pw = pad; s.dd = s.dh = s.dw = dil; s.K = k * k * k;
     return s;
@@ -289,13 +321,16 @@ SameConv block_conv(int B, int C, int Cout, int D, int H, int W, int k, int pad,
 struct TokGeoms {
     SameConv pw, dw5, dw7, offc, dcn;
     size_t E, Off, GOff;   // GOff: the backward's internal grad_offset buffer, 96 channel planes per batch (packed layout, DeformBwdArgs::goff_cpad)
-    TokGeoms(int B, int C, int D, int H, int W)
+    size_t SB;             // bytes per activation element (4, or 2 on the DLKA_BF16 path)
+    TokGeoms(int B, int C, int D, int H, int W, int dtype = DLKA_F32)
     {
-        pw = block_conv(B, C, C, D, H, W, 1, 0, 1, 1);
-        dw5 = block_conv(B, C, C, D, H, W, 5, 2, 1, C);
-        dw7 = block_conv(B, C, C, D, H, W, 7, 9, 3, C);
-        offc = block_conv(B, C, 81, D, H, W, 3, 1, 1, 1);
-        dcn = block_conv(B, C, C, D, H, W, 3, 1, 1, 1);
+        const int bf = dtype == DLKA_BF16 ? 1 : 0;
+        SB = bf ? 2 : 4;
+        pw = block_conv(B, C, C, D, H, W, 1, 0, 1, 1, bf);
+        dw5 = block_conv(B, C, C, D, H, W, 5, 2, 1, C, bf);
+        dw7 = block_conv(B, C, C, D, H, W, 7, 9, 3, C, bf);
+        offc = block_conv(B, C, 81, D, H, W, 3, 1, 1, 1, bf);
+        dcn = block_conv(B, C, C, D, H, W, 3, 1, 1, 1, bf);
         E = (size_t)B * C * D * H * W;
         Off = (size_t)B * 81 * D * H * W;
         GOff = (size_t)B * 96 * D * H * W;
@@ -476,7 +511,7 @@ int dlka_conv3d_backward_cl(const void *x, const void *weight, const void *grad_
 size_t dlka_deform_conv3d_cl_workspace(const dlka_conv_geom *c, int dtype, int backward)
 {
     SameConv s;
-    if (dtype != DLKA_F32 || make_same_conv(c, s)) return 0;
+    if ((dtype != DLKA_F32 && dtype != DLKA_BF16) || make_same_conv(c, s)) return 0;
     size_t n = align256(dense_wp_floats(s) * 4);
     if (backward) n += align256(cl_wgrad_part_floats(s.M, s.K, s.Cout, s.Cin) * 4) + align256(deform_scratch_floats(s) * 4);
     return n;
@@ -486,10 +521,12 @@ int dlka_deform_conv3d_forward_cl(const void *x, const void *offset, const void 
                                   size_t workspace_bytes, const dlka_conv_geom *c, int dtype, void *stream)
 {
     if (!x || !offset || !weight || !bias || !out) return DLKA_ERR_NULL;
-    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    if (dtype != DLKA_F32 && dtype != DLKA_BF16) return DLKA_ERR_UNSUPPORTED;
     SameConv s;
     DLKA_TRY(make_same_conv(c, s));
     if (c->deformable_group != 1 || !deform_supported(s)) return DLKA_ERR_UNSUPPORTED;
+    s.act_bf16 = dtype == DLKA_BF16;   // x / out bf16 storage; offsets, weight and bias stay fp32
+    if (s.act_bf16 && dense_forward_splits(s, 0) > 1) return DLKA_ERR_UNSUPPORTED;   // (tap-split stages: token entry points only)
     Carver cv(workspace, workspace_bytes);
     float *wp = (float *)cv.take(dense_wp_floats(s) * 4);
     if (!cv.ok()) return DLKA_ERR_WORKSPACE;
@@ -501,10 +538,14 @@ int dlka_deform_conv3d_backward_cl(const void *x, const void *offset, const void
                                    int dtype, void *stream)
 {
     if (!x || !offset || !weight || !grad_out) return DLKA_ERR_NULL;
-    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    if (dtype != DLKA_F32 && dtype != DLKA_BF16) return DLKA_ERR_UNSUPPORTED;
     SameConv s;
     DLKA_TRY(make_same_conv(c, s));
     if (c->deformable_group != 1 || !deform_supported(s)) return DLKA_ERR_UNSUPPORTED;
+    // DLKA_BF16: x / grad_out bf16 storage; offsets, weight and ALL FOUR gradients fp32 (grad_x is the fp32 accumulation target the token
+    // block also uses; grad_offset is planar; the parameter gradients are fp32 masters)
+    s.act_bf16 = dtype == DLKA_BF16;
+    if (s.act_bf16 && grad_bias && !grad_weight) return DLKA_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
     float *wp = (float *)cv.take(dense_wp_floats(s) * 4);
@@ -531,19 +572,19 @@ int dlka_ndhwc_to_ncdhw(const void *src, void *dst, int B, int C, int N, int dty
 }
 
 // ---- token-layout D-LKA block ------------------------------------------------------------------------------------------------
-int dlka_lka3d_tokens_supported(int B, int C, int D, int H, int W, int dtype) { return (dtype == DLKA_F32 && tokens_supported(B, C, D, H, W)) ? 1 : 0; }
+int dlka_lka3d_tokens_supported(int B, int C, int D, int H, int W, int dtype) { return ((dtype == DLKA_F32 || dtype == DLKA_BF16) && tokens_supported(B, C, D, H, W)) ? 1 : 0; }
 
 size_t dlka_lka3d_tokens_saved_bytes(int B, int C, int D, int H, int W, int dtype)
 {
     if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return 0;
-    TokGeoms G(B, C, D, H, W);
-    return 7 * align256(G.E * 4) + align256(G.Off * 4) + align256(G.prep_floats() * 4);
+    TokGeoms G(B, C, D, H, W, dtype);
+    return 7 * align256(G.E * G.SB) + align256(G.Off * 4) + align256(G.prep_floats() * 4);
 }
 
 size_t dlka_lka3d_tokens_workspace_bytes(int B, int C, int D, int H, int W, int dtype)
 {
     if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return 0;
-    TokGeoms G(B, C, D, H, W);
+    TokGeoms G(B, C, D, H, W, dtype);   // (the eight gradient buffers keep their fp32 size on the bf16 path: gta and the split scratch ARE fp32)
     return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 8 * align256(G.E * 4) + align256(G.GOff * 4) +
            align256(G.scratch_floats() * 4) + align256(4096);
 }
@@ -556,13 +597,20 @@ int dlka_lka3d_attention_tokens_forward(const void *x_, const dlka_lka3d_params 
     for (size_t k = 0; k < sizeof(*p) / sizeof(void *); ++k) if (!pp[k]) return DLKA_ERR_NULL;
     if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return DLKA_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    TokGeoms G(B, C, D, H, W);
+    // DLKA_BF16: x, y and every saved activation are bf16 storage (`float *` below is then just an address: the kernels reinterpret it);
+    // offsets, prepared weights, parameters and all accumulators are fp32
+    TokGeoms G(B, C, D, H, W, dtype);
+    const size_t SB = G.SB;
     Carver sv(saved, saved_bytes), cv(workspace, workspace_bytes);
-    float *h = (float *)sv.take(G.E * 4), *a = (float *)sv.take(G.E * 4), *t1 = (float *)sv.take(G.E * 4), *t = (float *)sv.take(G.E * 4);
-    float *off = (float *)sv.take(G.Off * 4), *f = (float *)sv.take(G.E * 4), *g1 = (float *)sv.take(G.E * 4);
+    float *h = (float *)sv.take(G.E * SB), *a = (float *)sv.take(G.E * SB), *t1 = (float *)sv.take(G.E * SB), *t = (float *)sv.take(G.E * SB);
+    float *off = (float *)sv.take(G.Off * 4), *f = (float *)sv.take(G.E * SB), *g1 = (float *)sv.take(G.E * SB);
     float *prep = (float *)sv.take(G.prep_floats() * 4);
-    float *m = (float *)sv.take(G.E * 4);   // gate output, kept: proj_2's weight gradient needs it
+    float *m = (float *)sv.take(G.E * SB);   // gate output, kept: proj_2's weight gradient needs it
+    (void)cv.take(G.wp_floats() * 4);
+    (void)cv.take(G.part_floats() * 4);
+    float *acc32 = (float *)cv.take(G.E * 4);   // bf16 path: fp32 landing zone of a tap-split deformable conv (small stages)
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
+    const bool bf = dtype == DLKA_BF16;
     const float *x = (const float *)x_;
     float *y = (float *)y_;
     const float *N0 = nullptr;
@@ -571,7 +619,7 @@ int dlka_lka3d_attention_tokens_forward(const void *x_, const dlka_lka3d_params 
     ZeroBatch zb;
     memset(&zb, 0, sizeof(zb));
     if (dense_forward_splits(G.offc, 0) > 1) zb.add(off, G.Off);
-    if (dense_forward_splits(G.dcn, 0) > 1) zb.add(f, G.E);
+    if (dense_forward_splits(G.dcn, 0) > 1) zb.add(bf ? acc32 : f, G.E);
     if (dense_forward_splits(G.pw, 3) > 1) zb.add(y, G.E);
     TokPrep PW;
     DLKA_TRY(carve_prep(G, prep, PW, p, st, true, &zb));
@@ -583,7 +631,7 @@ int dlka_lka3d_attention_tokens_forward(const void *x_, const dlka_lka3d_params 
     // offset-predict conv C -> 81 (synapse/deform_conv.py:94); offsets stay in the reference's planar layout
     DLKA_TRY(dense_forward(G.offc, t, N0, (const float *)p->offset_b, off, 1, PW.off_f, 0, nullptr, nullptr, st, true));
     // deformable 3^3 conv (deform_conv.py:95-105)
-    DLKA_TRY(deform_forward(G.dcn, t, off, N0, (const float *)p->deform_b, f, PW.dcn_f, st, true));
+    DLKA_TRY(deform_forward(G.dcn, t, off, N0, (const float *)p->deform_b, f, PW.dcn_f, st, true, acc32));
     // conv1 + gate u*attn (:650-652): g1 kept, m = a * g1
     DLKA_TRY(dense_forward(G.pw, f, N0, (const float *)p->conv1_b, g1, 0, PW.pw_f[1], 2, a, m, st));
     // proj_2 + shortcut (:670-671)
@@ -602,12 +650,16 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     for (size_t k = 0; k < sizeof(*gr) / sizeof(void *); ++k) if (!gp[k]) return DLKA_ERR_NULL;
     if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return DLKA_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    TokGeoms G(B, C, D, H, W);
+    // DLKA_BF16: x, gy, gx, the saved activations and the intermediate gradients gg1, ga1, gf, gt, gt1, gh are bf16 storage; grad_offset, the
+    // deformable conv's grad_input accumulator gta (atomics), the weight-gradient partials and the parameter gradients are fp32
+    TokGeoms G(B, C, D, H, W, dtype);
+    const size_t SB = G.SB;
+    const bool bf = dtype == DLKA_BF16;
     Carver sv((void *)saved, saved_bytes), cv(workspace, workspace_bytes);
-    const float *h = (float *)sv.take(G.E * 4), *a = (float *)sv.take(G.E * 4), *t1 = (float *)sv.take(G.E * 4), *t = (float *)sv.take(G.E * 4);
-    const float *off = (float *)sv.take(G.Off * 4), *f = (float *)sv.take(G.E * 4), *g1 = (float *)sv.take(G.E * 4);
+    const float *h = (float *)sv.take(G.E * SB), *a = (float *)sv.take(G.E * SB), *t1 = (float *)sv.take(G.E * SB), *t = (float *)sv.take(G.E * SB);
+    const float *off = (float *)sv.take(G.Off * 4), *f = (float *)sv.take(G.E * SB), *g1 = (float *)sv.take(G.E * SB);
     float *prep = (float *)sv.take(G.prep_floats() * 4);   // written by the matching forward call
-    const float *m = (const float *)sv.take(G.E * 4);
+    const float *m = (const float *)sv.take(G.E * SB);
     (void)cv.take(G.wp_floats() * 4);
     float *part = (float *)cv.take(G.part_floats() * 4);
     // every intermediate gradient has its own buffer: the weight-gradient stream reads them while the data-gradient chain moves on
@@ -654,14 +706,14 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
         // Measured with the workgroup-tiled consumers (profiles/r01v): no gain — they are bound by per-unit latency (barrier + staging per
         // 192 MFMA cycles), not by the split arithmetic (grad_offset +14 us, weight gradient +18 us, data gradient unchanged at 32^3) — so the
         // packed hand-over is opt-in (DLKA_GOFF_PACKED=1) until the consumers are wave-granular.
-        const bool fp32_goff = getenv("DLKA_GOFF_PACKED") == nullptr;   // (not cached: tests toggle it)
-        const bool sliced = deform_bwd_variant() == 0 && cl_deform_goff_ccsplit(da) > 1;
+        const bool fp32_goff = bf || getenv("DLKA_GOFF_PACKED") == nullptr;   // (not cached: tests toggle it)
+        const bool sliced = (bf || deform_bwd_variant() == 0) && cl_deform_goff_ccsplit(da) > 1;
         if (sliced) zb.add(goff, G.Off);
         // (N % 16: the weight-gradient kernel's split variant exists for 16-voxel-aligned volumes only, cl_wgrad.hip)
         else if (!fp32_goff && deform_bwd_variant() == 0 && use_split(G.offc, false) == 2 && (G.offc.N & 15) == 0) goff_cpad = 96;
     }
     if (dense_backward_data_splits(G.pw, 0) > 1) zb.add(gf, G.E);
-    if (dense_backward_data_splits(G.offc, 3) > 1) zb.add(gt, G.E);
+    if (dense_backward_data_splits(G.offc, 3) > 1) zb.add(bf ? ga2 : gt, G.E);   // bf16: split partial sums land in the fp32 scratch ga2
     if (dense_backward_data_splits(G.pw, 3) > 1) zb.add(gx, G.E);
     DLKA_TRY(launch_zero_batch(zb, st));
     DLKA_TRY(publish());   // fork: everything issued before this call (gy, saved activations, the previous block's use of the workspace)
@@ -682,7 +734,7 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
     DLKA_TRY(dense_backward_weight(G.offc, t, goff, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, ws_, &fb.j[fb.njobs++], goff_cpad));
     DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, true));
-    DLKA_TRY(dense_backward_data(G.offc, goff, 1, N0, gt, PW.off_b, 3, gta, st, nullptr, nullptr, true, goff_cpad != 0));
+    DLKA_TRY(dense_backward_data(G.offc, goff, 1, N0, gt, PW.off_b, 3, gta, st, nullptr, nullptr, true, goff_cpad != 0, true, ga2));
     DLKA_TRY(publish());
     // depthwise 7^3 dil 3:  t = DW7 t1
     DLKA_TRY(dw_backward_weight(G.dw7, t1, gt, (float *)gr->conv_spatial_w, (float *)gr->conv_spatial_b, stage7, ws_, &fb.j[fb.njobs++]));
@@ -691,7 +743,7 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     // depthwise 5^3:  t1 = DW5 a
     DLKA_TRY(dw_backward_weight(G.dw5, a, gt1, (float *)gr->conv0_w, (float *)gr->conv0_b, stage5, ws_, &fb.j[fb.njobs++]));
     // ... with the GELU backward in its epilogue:  a = GELU(h),  gh = (ga1 + DW5^T gt1) * gelu'(h)
-    (void)ga2; (void)E;
+    (void)E;
     DLKA_TRY(dw_forward(G.dw5, gt1, N0, nullptr, gh, PW.dw5_b, 1, st, h, ga1));
     DLKA_TRY(publish());
     // proj_1:  h = P1 x ;  gx = P1^T gh + gy (shortcut)

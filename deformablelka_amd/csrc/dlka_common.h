@@ -31,6 +31,39 @@ __host__ __device__ __forceinline__ void stf(bf16_t *p, float x) {  // round-to-
     p->v = (uint16_t)(u >> 16);
 }
 
+
+// ---- activation storage type of the channels-last kernels: float, or bf16_t (DLKA_BF16: half the bytes, fp32 arithmetic) ----
+// Kernels keep their `const float *` argument blocks and reinterpret them; byte offsets scale with sizeof(T).
+template <typename T> __device__ __forceinline__ f32x4 act_buf_load4(BufRsrc r, unsigned byteoff);   // 4 consecutive elements
+template <> __device__ __forceinline__ f32x4 act_buf_load4<float>(BufRsrc r, unsigned byteoff) { return buf_load_f32x4(r, byteoff); }
+template <> __device__ __forceinline__ f32x4 act_buf_load4<bf16_t>(BufRsrc r, unsigned byteoff) { return buf_load_bf16x4(r, byteoff); }
+template <typename T> __device__ __forceinline__ float act_buf_load1(BufRsrc r, unsigned byteoff);
+template <> __device__ __forceinline__ float act_buf_load1<float>(BufRsrc r, unsigned byteoff) { return buf_load_f32(r, byteoff); }
+template <> __device__ __forceinline__ float act_buf_load1<bf16_t>(BufRsrc r, unsigned byteoff) { return buf_load_bf16(r, byteoff); }
+// pointer flavours: element index, 4 consecutive elements (aligned to 4 elements)
+struct alignas(8) ActU2 { unsigned x, y; };
+__device__ __forceinline__ f32x4 act_load4(const float *p, long i) { return *reinterpret_cast<const f32x4 *>(p + i); }
+__device__ __forceinline__ f32x4 act_load4(const bf16_t *p, long i)
+{
+    const ActU2 w = *reinterpret_cast<const ActU2 *>(p + i);
+    f32x4 v;
+    v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xffff0000u);
+    v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xffff0000u);
+    return v;
+}
+__device__ __forceinline__ void act_store4(float *p, long i, f32x4 v) { *reinterpret_cast<f32x4 *>(p + i) = v; }
+__device__ __forceinline__ void act_store4(bf16_t *p, long i, f32x4 v)
+{
+    ActU2 w;
+    w.x = (unsigned)bf16_bits(v[0]) | ((unsigned)bf16_bits(v[1]) << 16);
+    w.y = (unsigned)bf16_bits(v[2]) | ((unsigned)bf16_bits(v[3]) << 16);
+    *reinterpret_cast<ActU2 *>(p + i) = w;
+}
+__device__ __forceinline__ float act_load1(const float *p, long i) { return p[i]; }
+__device__ __forceinline__ float act_load1(const bf16_t *p, long i) { return __uint_as_float((unsigned)p[i].v << 16); }
+__device__ __forceinline__ void act_store1(float *p, long i, float v) { p[i] = v; }
+__device__ __forceinline__ void act_store1(bf16_t *p, long i, float v) { p[i].v = bf16_bits(v); }
+
 // ---------------------------------------------------------------------------------------------
 // geometry with the derived sizes every kernel needs
 // ---------------------------------------------------------------------------------------------

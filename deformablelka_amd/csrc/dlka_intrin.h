@@ -73,6 +73,23 @@ __device__ __forceinline__ float buf_load_f32_s(BufRsrc r, unsigned voff, unsign
     if (!(voff < r.bytes)) return 0.f;
     return buf_load_f32(r, voff + soff);
 }
+// ---- bf16 activation storage (DLKA_BF16 token path): 4 consecutive bf16 -> 4 floats, one 8-byte buffer load ----
+__device__ __forceinline__ f32x4 buf_load_bf16x4(BufRsrc r, unsigned off)
+{
+    f32x4 v;
+    for (int e = 0; e < 4; ++e) {
+        unsigned short h = 0;
+        if (off < r.bytes && off + 2u * e + 2 <= r.bytes) memcpy(&h, r.base + off + 2u * e, 2);
+        v[e] = hipemu::hipemu_bf16_to_f32(h);
+    }
+    return v;
+}
+__device__ __forceinline__ float buf_load_bf16(BufRsrc r, unsigned off)
+{
+    unsigned short h = 0;
+    if (off < r.bytes && off + 2 <= r.bytes) memcpy(&h, r.base + off, 2);
+    return hipemu::hipemu_bf16_to_f32(h);
+}
 // two-term bf16 split packed in one word: hi << 16 | lo
 __device__ __forceinline__ float pack_split2(float x)
 {
@@ -150,6 +167,20 @@ __device__ __forceinline__ f32x4 buf_load_f32x4(BufRsrc r, unsigned off) { retur
 __device__ __forceinline__ float buf_load_f32_s(BufRsrc r, unsigned voff, unsigned soff)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+// ---- bf16 activation storage (DLKA_BF16 token path): 4 consecutive bf16 -> 4 floats, one 8-byte buffer load ----
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 buf_load_bf16x4(BufRsrc r, unsigned off)
+{
+    const u32x2_t w = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    f32x4 v;
+    v[0] = __builtin_bit_cast(float, w[0] << 16); v[1] = __builtin_bit_cast(float, w[0] & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, w[1] << 16); v[3] = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+    return v;
+}
+__device__ __forceinline__ float buf_load_bf16(BufRsrc r, unsigned off)
+{
+    return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0) << 16);
 }
 // two-term bf16 split packed in one word (hi << 16 | lo): the producer splits ONCE, consumers that contract the value many times (27 taps)
 // rebuild their MFMA operands with one v_perm per pair instead of ~5 VALU instructions per value per use

@@ -398,16 +398,36 @@ def deform_conv3d_backward_cl(x, offset, weight, grad_out, padding=1, dilation=1
 
 
 def lka3d_tokens_supported(x, B, C, D, H, W) -> bool:
-    if x.dtype != torch.float32:
+    """float32, or bfloat16 activations (DLKA_BF16: bf16 storage of x / y / saved activations, fp32 parameters, offsets and accumulation)."""
+    if x.dtype not in (torch.float32, torch.bfloat16):
         return False
-    return bool(L.get_lib().dlka_lka3d_tokens_supported(B, C, D, H, W, L.DLKA_F32))
+    return bool(L.get_lib().dlka_lka3d_tokens_supported(B, C, D, H, W, L.dtype_code(x)))
+
+
+def autocast_activation_dtype(x):
+    """The autocast policy of the token-layout D-LKA block (the reference registers none): inside ``torch.autocast(dtype=
+    torch.bfloat16)`` the block runs on bf16 activations with fp32 parameters / accumulation; anything else keeps x's dtype."""
+    try:
+        on = torch.is_autocast_enabled(x.device.type)
+        dt = torch.get_autocast_dtype(x.device.type) if on else None
+    except (TypeError, RuntimeError):
+        return x.dtype
+    return torch.bfloat16 if (on and dt == torch.bfloat16 and x.dtype in (torch.float32, torch.bfloat16)) else x.dtype
+
+
+
+def _fp32_param(t):
+    """Parameters of the token-layout block are fp32 masters whatever the activation dtype is."""
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"the token-layout D-LKA block keeps its parameters in float32 (bf16 is an ACTIVATION dtype); got {t.dtype}")
+    return t.contiguous()
 
 
 def lka3d_attention_tokens_forward(x, params, dims):
     """x: [B, N, C] tokens, dims = (D, H, W) spatial extents (the reference's H, W, D). Returns (y, saved)."""
     L.require_device(x, *params)
     x = x.contiguous()
-    params = [t.contiguous() for t in params]
+    params = [_fp32_param(t) for t in params]
     B, N, C = (int(v) for v in x.shape)
     D, H, W = (int(v) for v in dims)
     assert N == D * H * W
@@ -427,8 +447,8 @@ def lka3d_attention_tokens_forward(x, params, dims):
 
 def lka3d_attention_tokens_backward(x, params, grad_y, saved, dims):
     L.require_device(x, grad_y, saved, *params)
-    x, grad_y = x.contiguous(), grad_y.contiguous()
-    params = [t.contiguous() for t in params]
+    x, grad_y = x.contiguous(), grad_y.to(x.dtype).contiguous()
+    params = [_fp32_param(t) for t in params]
     B, N, C = (int(v) for v in x.shape)
     D, H, W = (int(v) for v in dims)
     lib = L.get_lib()

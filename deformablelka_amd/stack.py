@@ -54,8 +54,9 @@ class DLKABlockStack:
             for _ in range(n):
                 shapes_all.append((C, dims, _param_shapes(C)))
         total = sum(sum(int(torch.Size(s).numel()) for s in sh) for _, _, sh in shapes_all)
-        self.flat_params = torch.empty(total, dtype=dtype, device=self.device)
-        self.flat_grads = torch.zeros(total, dtype=dtype, device=self.device)
+        # dtype is the ACTIVATION storage type (float32, or bfloat16 = DLKA_BF16); parameters and gradients are fp32 masters either way
+        self.flat_params = torch.empty(total, dtype=torch.float32, device=self.device)
+        self.flat_grads = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.blocks: List[_Block] = []
         self.chains: List[List[_Block]] = []
         off = 0
@@ -109,10 +110,10 @@ class DLKABlockStack:
             w, b = blk.params[idx], blk.params[idx + 1]
             fan_in = int(w[0].numel())
             bound = 1.0 / math.sqrt(fan_in)
-            w.copy_(((torch.rand(w.shape, generator=gen) * 2 - 1) * bound).to(self.device, self.dtype))
-            b.copy_(((torch.rand(b.shape, generator=gen) * 2 - 1) * bound).to(self.device, self.dtype))
+            w.copy_(((torch.rand(w.shape, generator=gen) * 2 - 1) * bound).to(self.device))
+            b.copy_(((torch.rand(b.shape, generator=gen) * 2 - 1) * bound).to(self.device))
         ow, ob = blk.params[6], blk.params[7]
-        ow.copy_((torch.randn(ow.shape, generator=gen) * _offset_std_for(blk.C, offset_std)).to(self.device, self.dtype))
+        ow.copy_((torch.randn(ow.shape, generator=gen) * _offset_std_for(blk.C, offset_std)).to(self.device))
         ob.zero_()
 
     def _stream(self):
@@ -183,7 +184,7 @@ class DLKABlockStack:
             H, W, D = blk.dims
             N = H * W * D
             E, Off = self.B * blk.C * N, self.B * 81 * N
-            o = 4 * a256(E * 4)   # saved = h, a, t1, t, off, ...
+            o = 4 * a256(E * (4 if self.dtype == torch.float32 else 2))   # saved = h, a, t1, t, off, ...  (activations in the run's storage type)
             off = blk.saved[o:o + Off * 4].view(torch.float32)
             stds.append(round(float(off.std().item()), 3))
         return {"finite": finite, "offset_std": stds}

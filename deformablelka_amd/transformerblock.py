@@ -94,7 +94,12 @@ class LKA_Attention3d_deform(nn.Module):
 
     def forward(self, x, B, C, H, W, D):
         # Fast path: the token tensor IS the channels-last volume; run the block on it directly.
-        if ops.lka3d_tokens_supported(x, B, C, H, W, D):
+        # Autocast policy (the reference has none — its op would raise on half inputs, deform_conv_cuda.cu:96): inside
+        # torch.autocast(dtype=torch.bfloat16) the block takes bf16 activations with fp32 parameters and accumulation.
+        act = ops.autocast_activation_dtype(x)
+        if act != x.dtype and self.proj_1.weight.dtype == torch.float32 and ops.lka3d_tokens_supported(x.to(act), B, C, H, W, D):
+            x = x.to(act)
+        if self.proj_1.weight.dtype == torch.float32 and ops.lka3d_tokens_supported(x, B, C, H, W, D):
             return _LKA3dTokensFn.apply(x, (H, W, D), *self.block_params())
         # General path (any C / dtype): the reference's own data movement around the NCDHW block.
         x = x.permute(0, 2, 1).reshape(B, C, H, W, D)  # B N C --> B C N --> B C H W D   (:665)

@@ -268,7 +268,12 @@ int dlka_ndhwc_to_ncdhw(const void *src, void *dst, int B, int C, int N, int dty
 /* Replaces  LKA_Attention3d_deform.forward(x, B, C, H, W, D)  (transformerblock.py:664-673) on the TOKEN tensor itself:
  *   x, y, grad_x, grad_y: [B][N][C] with N = D*H*W voxels in (d,h,w) order of the reference's reshape(B,C,H,W,D)
  *   (its "H,W,D" are just the three spatial extents).  No permute/copy on either side.
- *   Supported: fp32, C in {32, 64, 128, 256} (the four D_LKA_Former stage widths). */
+ *   Supported: C in {32, 64, 128, 256} (the four D_LKA_Former stage widths); dtype
+ *     DLKA_F32   everything fp32 (the parity path: 1e-4 against the reference);
+ *     DLKA_BF16  x, y, grad_y, grad_x and every saved / intermediate activation are bf16 STORAGE; parameters (dlka_lka3d_params), their
+ *                gradients, the predicted offsets, grad_offset and all accumulation are fp32.  The offset-predict conv runs single bf16
+ *                MFMA products against two-term (fp32-exact) weights.  The reference registers no autocast policy and would raise on half
+ *                inputs (deform_conv_cuda.cu:96); this is the policy the Python modules apply inside torch.autocast(dtype=bfloat16). */
 int    dlka_lka3d_tokens_supported(int B, int C, int D, int H, int W, int dtype);
 size_t dlka_lka3d_tokens_saved_bytes(int B, int C, int D, int H, int W, int dtype);
 size_t dlka_lka3d_tokens_workspace_bytes(int B, int C, int D, int H, int W, int dtype);

@@ -11,29 +11,38 @@ import torch.nn.functional as F
 import oracle
 
 
-def lka3d_attention_volume(x, P):
+def bf16_storage(t):
+    """Straight-through bf16 rounding: the value a tensor has after being STORED as bf16 (what the DLKA_BF16 path does to every activation
+    it writes), with the identity as its derivative."""
+    return t + (t.bfloat16().float() - t).detach()
+
+
+def lka3d_attention_volume(x, P, store=None):
     """LKA_Attention3d_deform on an NCDHW volume — 3D/d_lka_former/network_architecture/synapse/transformerblock.py:664-673
-    (minus the token permutes), LKA3d_deform.forward :644-652, DeformConvPack.forward synapse/deform_conv.py:93-105."""
+    (minus the token permutes), LKA3d_deform.forward :644-652, DeformConvPack.forward synapse/deform_conv.py:93-105.
+    store: None = the reference's fp32 block; ``bf16_storage`` = the same arithmetic with every activation the DLKA_BF16 path writes to HBM
+    rounded to bf16 where it is written (offsets stay fp32) — the model of "bf16 activations, fp32 parameters and accumulation"."""
+    st = store if store is not None else (lambda t: t)
     C = x.shape[1]
     shortcut = x.clone()                                                         # :666
-    a = F.gelu(F.conv3d(x, P["proj_1.weight"], P["proj_1.bias"]))                # :667-668
+    a = st(F.gelu(F.conv3d(x, P["proj_1.weight"], P["proj_1.bias"])))            # :667-668
     u = a.clone()                                                                # :645
     s = "spatial_gating_unit."
-    attn = F.conv3d(a, P[s + "conv0.weight"], P[s + "conv0.bias"], padding=2, groups=C)                             # :646
-    attn = F.conv3d(attn, P[s + "conv_spatial.weight"], P[s + "conv_spatial.bias"], padding=9, dilation=3, groups=C)  # :647
+    attn = st(F.conv3d(a, P[s + "conv0.weight"], P[s + "conv0.bias"], padding=2, groups=C))                             # :646
+    attn = st(F.conv3d(attn, P[s + "conv_spatial.weight"], P[s + "conv_spatial.bias"], padding=9, dilation=3, groups=C))  # :647
     attn = attn.contiguous()                                                     # :648
     off = F.conv3d(attn, P[s + "deform_conv.conv_offset.weight"], P[s + "deform_conv.conv_offset.bias"], stride=1, padding=1)
-    attn = oracle.DeformConv3dFunction.apply(attn, off, P[s + "deform_conv.weight"], P[s + "deform_conv.bias"],
-                                             1, 1, 1, 1, 1, 64)                  # deform_conv.py:95-105
-    attn = F.conv3d(attn, P[s + "conv1.weight"], P[s + "conv1.bias"])            # :650
-    y = F.conv3d(u * attn, P["proj_2.weight"], P["proj_2.bias"])                 # :652, :670
-    return y + shortcut                                                          # :671
+    attn = st(oracle.DeformConv3dFunction.apply(attn, off, P[s + "deform_conv.weight"], P[s + "deform_conv.bias"],
+                                                1, 1, 1, 1, 1, 64))              # deform_conv.py:95-105
+    attn = F.conv3d(attn, P[s + "conv1.weight"], P[s + "conv1.bias"])            # :650  (the gate consumes conv1's fp32 value in the fused epilogue)
+    y = F.conv3d(st(u * attn), P["proj_2.weight"], P["proj_2.bias"])             # :652, :670
+    return st(y + shortcut)                                                      # :671
 
 
-def lka3d_attention_tokens(x, P, B, C, H, W, D):
+def lka3d_attention_tokens(x, P, B, C, H, W, D, store=None):
     """The full forward(x, B, C, H, W, D) on (B, N, C) tokens, :664-673."""
     v = x.permute(0, 2, 1).reshape(B, C, H, W, D)
-    v = lka3d_attention_volume(v, P)
+    v = lka3d_attention_volume(v, P, store)
     return v.reshape(B, C, H * W * D).permute(0, 2, 1)
 
 

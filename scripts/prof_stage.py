@@ -15,10 +15,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--stage", type=int, default=3)
 ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
 a = ap.parse_args()
 torch.cuda.set_device(0)
 C, dims, n = SYNAPSE_STAGES[a.stage]
-st = DLKABlockStack(a.batch, stages=((C, dims, 1),), device="cuda:0")
+st = DLKABlockStack(a.batch, stages=((C, dims, 1),), device="cuda:0", dtype=torch.float32 if a.dtype == "f32" else torch.bfloat16)
 s = torch.cuda.Stream()
 s.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(s):

@@ -270,6 +270,75 @@ def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=2e-4, rtol
             assert_close("tokens grad " + k, p.grad, g, rtol=4 * rtol if "conv_offset" in k else rtol)
 
 
+BF16_RTOL = 2e-2   # bf16 path vs the fp32 oracle <= 2e-2 rel (of max |reference|)
+
+
+def check_lka3d_tokens_bf16(dev, B, C, dims, seed=0, offset_std=0.38, rtol=BF16_RTOL, via_autocast=False, report=False):
+    """DLKA_BF16 token path: bf16 activations (x, y, every saved tensor, the intermediate gradients), fp32 parameters / offsets /
+    accumulation — against the fp32 oracle block fed the SAME bf16-rounded input.  via_autocast: fp32 tensors inside torch.autocast(bf16)
+    (the block's autocast policy) instead of explicit bf16 tensors."""
+    import deformablelka_amd as dk
+    from oracle import blocks
+    torch.manual_seed(seed)
+    H, W, D = dims
+    N = H * W * D
+    m = dk.LKA_Attention3d_deform(C)
+    blocks.randomize_offsets_(m, std=offset_std)
+    x = torch.randn(B, N, C).bfloat16()
+    gy = torch.randn(B, N, C).bfloat16()
+    def run_oracle(store):
+        P = {k: v.detach().clone().requires_grad_(True) for k, v in m0.items()}
+        xr = x.float().requires_grad_(True)
+        yr = blocks.lka3d_attention_tokens(xr, P, B, C, H, W, D, store=store)
+        yr.backward(gy.float())
+        return yr.detach(), xr.grad, {k: v.grad for k, v in P.items()}
+
+    m0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    y32, gx32, g32 = run_oracle(None)                      # the reference's fp32 block
+    y16, gx16, g16 = run_oracle(blocks.bf16_storage)       # the same arithmetic with bf16-STORED activations: the model of the DLKA_BF16 path
+    m = m.to(dev)
+    if via_autocast:
+        xd = x.float().to(dev).requires_grad_(True)
+        with torch.autocast(torch.device(dev).type, dtype=torch.bfloat16):
+            y = m(xd, B, C, H, W, D)
+    else:
+        xd = x.to(dev).requires_grad_(True)
+        y = m(xd, B, C, H, W, D)
+    assert y.dtype == torch.bfloat16, y.dtype
+    y.backward(gy.to(dev))
+    errs = {"y": rel_err(y, y32), "gx": rel_err(xd.grad, gx32)}
+    errs16 = {"y": rel_err(y, y16), "gx": rel_err(xd.grad, gx16)}
+    for k, p in m.named_parameters():
+        assert p.grad.dtype == torch.float32
+        if g32[k] is not None and g32[k].abs().max() > 0:
+            errs[k] = rel_err(p.grad, g32[k])
+            errs16[k] = rel_err(p.grad, g16[k])
+    if report or os.environ.get("DLKA_PARITY_VERBOSE"):
+        short = lambda k: ".".join(k.split(".")[-2:])
+        print(f"[bf16 tokens C={C} dims={dims}] vs fp32 oracle: " + " ".join(f"{short(k)}={v:.1e}" for k, v in errs.items()))
+        print(f"[bf16 tokens C={C} dims={dims}] vs bf16-storage oracle: " + " ".join(f"{short(k)}={v:.1e}" for k, v in errs16.items()))
+    # grad_offset is DISCONTINUOUS where a sampling coordinate crosses an integer.  Rounding the offset conv's input to bf16 moves the
+    # predicted offsets by ~0.4 % and flips the cell of the samples that sit that close to a boundary; each flip changes that sample's
+    # grad_offset by O(1).  conv_offset.{weight,bias}.grad sum grad_offset with random signs, so they move by ~2*sqrt(flip rate) = O(10 %), and
+    # through grad_t everything UPSTREAM of the deformable conv in the backward pass (conv_spatial, conv0, proj_1) moves by a few percent —
+    # for ANY implementation with bf16 activations: the bf16-storage oracle sits at the same distance from the fp32 one (printed above).
+    # Even two bf16 implementations differ there, because a last-bit difference in an fp32 sum occasionally rounds to the other bf16
+    # neighbour.  Measured on the MI355X at the four full stage shapes (vs bf16-storage / vs fp32): conv_offset <= 8.6e-2 / 1.8e-1,
+    # conv0 / conv_spatial <= 4.4e-2 / 1.1e-1, proj_1 <= 1.0e-2 / 3.5e-2; everything else (y, gx, deform_conv, conv1, proj_2) <= 8e-3.
+    def limits(k):
+        if "conv_offset" in k:
+            return 1.5e-1, None                   # (vs bf16-storage oracle, vs fp32 oracle: reported only)
+        if any(t in k for t in ("conv0.", "conv_spatial.", "proj_1.")):
+            return 3 * rtol, 1.5e-1
+        return rtol, rtol                         # y, gx and every gradient not exposed to the discontinuity: the SURVEY §8c bar, 2e-2
+    for k in errs:
+        l16, l32 = limits(k)
+        assert errs16[k] <= l16, f"bf16 tokens {k}: rel err vs bf16-storage oracle {errs16[k]:.3e} > {l16}"
+        if l32 is not None:
+            assert errs[k] <= l32, f"bf16 tokens {k}: rel err vs fp32 oracle {errs[k]:.3e} > {l32}"
+    return errs
+
+
 # ---- the wrapper block (TransformerBlock_3D_single_deform_LKA) and its pieces ------------------------------------------------
 def check_layernorm_tokens(dev, B, C, N, planar, pos, seed=0):
     from deformablelka_amd import ops

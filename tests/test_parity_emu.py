@@ -193,3 +193,9 @@ def test_gx_fixed_point_window_worst_case_and_error():
     quantisation error against the fp64 window."""
     parity.check_deform3d_cl_gx_worst_case("cpu", 32, (6, 5, 9))
     parity.check_deform3d_cl_gx_fixed_vs_fp64("cpu", 1, 32, (6, 5, 7))
+
+
+@pytest.mark.parametrize("C,dims,autocast", [(32, (4, 4, 8), False), (64, (3, 4, 5), False), (32, (5, 6, 7), True)])
+def test_lka3d_tokens_bf16(C, dims, autocast):
+    """DLKA_BF16 token path (bf16 activations, fp32 parameters / accumulation) vs the fp32 oracle at 2e-2."""
+    parity.check_lka3d_tokens_bf16("cpu", 1, C, dims, via_autocast=autocast, report=True)

@@ -218,6 +218,19 @@ def test_lka3d_tokens_block_headline_shapes_vs_oracle(C, dims, wstd):
     parity.check_lka3d_tokens(DEV, 2, C, dims, offset_std=wstd, report_offsets=True)
 
 
+@pytest.mark.parametrize("C,dims,wstd", HEADLINE)
+def test_lka3d_tokens_bf16_headline_shapes_vs_oracle(C, dims, wstd):
+    """The north_star dtype: bf16 activations (fp32 parameters / offsets / accumulation) on the token fast path at the FULL stage sizes
+    (B=2, offsets ~1 voxel) — every output and gradient within 2e-2 of the bf16-storage oracle, and of the fp32 oracle wherever the
+    quantity is not exposed to grad_offset's discontinuity (tests/parity.py:check_lka3d_tokens_bf16)."""
+    parity.check_lka3d_tokens_bf16(DEV, 2, C, dims, offset_std=wstd, report=True)
+
+
+def test_lka3d_tokens_bf16_autocast_policy():
+    """fp32 tensors inside torch.autocast(dtype=bfloat16): the block's policy moves the activations to bf16, parameters stay fp32."""
+    parity.check_lka3d_tokens_bf16(DEV, 2, 64, (8, 8, 8), via_autocast=True, report=True)
+
+
 def test_deform3d_cl_headline_shape_vs_oracle():
     """The deformable conv of the headline shape (C=32, 32^3, B=2, offsets N(0,1)): forward + all four gradients vs the oracle."""
     parity.check_deform3d_cl(DEV, 2, 32, 32, (32, 32, 32), off_mode="normal")
