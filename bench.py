@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--extras", action="store_true", help="also report the full-net training iteration, the 2-D block images/s and the sliding-window tiles/s "
+                    "(SURVEY §8d secondary metrics; ~1 min)")
     ap.add_argument("--no-tblock", action="store_true", help="skip the second metric (wrapper-block stack through nn.Module/autograd)")
     ap.add_argument("--cpu-sample", default="stage", choices=["stage", "tiny"])
     return ap.parse_args()
@@ -351,6 +353,98 @@ def tblock_metric(batch, steps, warmup, dev):
             "blocks": sum(len(c[0]) for c in chains)}
 
 
+def fullnet_metric(batch, steps, dev, bf16=False):
+    """Third metric (SURVEY §8d iii / §8f-2): the WHOLE D_LKA_Former (42.35 M parameters; its 21 D-LKA transformer blocks on this repo's kernels,
+    the conv / norm plumbing around them on stock torch layers), one trainer iteration per step — forward, deep-supervision loss, backward,
+    clip_grad_norm_(12), SGD(momentum 0.99, nesterov) — on a synthetic 64x128x128 patch batch (d_lka_former_trainer_synapse.py:259-309)."""
+    from deformablelka_amd import training
+    from deformablelka_amd.stack import _offset_std_for
+    torch.manual_seed(0)
+    net = training.initialize_network(1, 14, (64, 128, 128), device=dev)
+    with torch.no_grad():
+        for blk in net.dlka_blocks():
+            w = blk.epa_block.spatial_gating_unit.deform_conv.conv_offset.weight
+            w.normal_(0, _offset_std_for(w.shape[1]))
+    opt = training.initialize_optimizer(net, initial_lr=1e-6)
+    x = torch.randn(batch, 1, 64, 128, 128, device=dev)
+    tgt = torch.randint(0, 14, (batch, 64, 128, 128), device=dev)
+    net.train()
+    for _ in range(2):
+        training.run_iteration(net, opt, x, tgt, bf16_autocast=bf16)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = training.run_iteration(net, opt, x, tgt, bf16_autocast=bf16)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    if not bool(torch.isfinite(loss)):
+        raise RuntimeError("full-net loss is not finite")
+    return {"metric": "3D D-LKA Former full-net training iteration volumes/sec (64x128x128)", "value": round(batch / dt, 3), "unit": "volumes/s",
+            "ms_per_step": round(dt * 1e3, 2), "params": sum(p.numel() for p in net.parameters()), "loss": round(float(loss), 4),
+            "path": "nn.Module + autograd, eager; D-LKA blocks = HIP kernels, plumbing = torch/MIOpen" + ("; bf16 autocast policy" if bf16 else "")}
+
+
+def lka2d_metric(steps, dev):
+    """Secondary metric of SURVEY §8d: the 2-D D-LKA attention block fwd+bwd at B=24 on the three decoder shapes of the 224^2 net
+    (2D/networks/MaxViT_deform_LKA.py:643-679), two blocks each — images/s through deformable_LKA_Attention."""
+    import deformablelka_amd as dk
+    from deformablelka_amd.init_utils import randomize_offset_nets
+    shapes = [(384, 14), (192, 28), (96, 56)]
+    torch.manual_seed(0)
+    mods, xs, gys = [], [], []
+    for C, n in shapes:
+        for _ in range(2):
+            m = dk.deformable_LKA_Attention(C).to(dev)
+            randomize_offset_nets(m, 0.02)
+            mods.append(m)
+            xs.append(torch.randn(24, C, n, n, device=dev, requires_grad=True))
+            gys.append(torch.randn(24, C, n, n, device=dev))
+
+    def step():
+        for m, x, gy in zip(mods, xs, gys):
+            m(x).backward(gy)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    per = []
+    for m, x, gy in zip(mods[::2], xs[::2], gys[::2]):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            m(x).backward(gy)
+        e1.record()
+        torch.cuda.synchronize()
+        per.append(round(e0.elapsed_time(e1) / steps, 3))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"metric": "2D D-LKA attention blocks fwd+bwd images/sec (224x224 net, B=24: 2x(384,14^2)+2x(192,28^2)+2x(96,56^2))", "value": round(24 / dt, 2),
+            "unit": "images/s", "ms_per_step": round(dt * 1e3, 2), "ms_per_block_fwd_bwd": dict(zip(["384x14^2", "192x28^2", "96x56^2"], per))}
+
+
+def inference_metric(dev):
+    """BASELINE.json config 5: pancreas-style sliding-window inference, 96^3 tiles, stride 16, on a synthetic (240, 240, 160) volume =
+    10 x 10 x 5 = 500 tiles (test_util.py:73-75), the volume, score map and counts resident in HBM; tiles/s, forward only."""
+    from deformablelka_amd import inference, training
+    torch.manual_seed(0)
+    net = training.initialize_network(1, 2, (96, 96, 96), device=dev, patch_size=(2, 2, 2)).eval()
+    net.do_ds = False
+    vol = torch.randn(240, 240, 160, device=dev)
+    small = vol[:112, :112, :96].contiguous()          # warm-up: 2 x 2 x 1 tiles
+    inference.predict_single_case(net, small, 16, 16, (96, 96, 96), num_classes=2, tile_batch=4)
+    torch.cuda.synchronize()
+    n = inference.num_tiles(vol.shape, (96, 96, 96), 16, 16)
+    t0 = time.perf_counter()
+    lab, score = inference.predict_single_case(net, vol, 16, 16, (96, 96, 96), num_classes=2, tile_batch=4)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert lab.shape == vol.shape and bool(torch.isfinite(score).all())
+    return {"metric": "3D D-LKA Former sliding-window inference tiles/sec (96^3 tiles, stride 16, 240x240x160 volume resident in HBM)",
+            "value": round(n / dt, 2), "unit": "tiles/s", "tiles": n, "seconds_per_volume": round(dt, 2), "tile_batch": 4}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -533,6 +627,17 @@ def main():
             except Exception as e:
                 log("tblock metric failed:", repr(e))
                 out["tblock"] = None
+        if args.extras and world == 1:
+            for key, fn in (("fullnet", lambda: fullnet_metric(args.batch, 5, dev, bf16=(dtype == torch.bfloat16))),
+                            ("lka2d", lambda: lka2d_metric(5, dev)), ("inference", lambda: inference_metric(dev))):
+                if dtype == torch.bfloat16 and key != "fullnet":
+                    continue
+                try:
+                    out[key] = fn()
+                except Exception as e:
+                    log(f"{key} metric failed:", repr(e))
+                    out[key] = None
+                torch.cuda.empty_cache()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

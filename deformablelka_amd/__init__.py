@@ -15,10 +15,14 @@ from .modules.deform_conv import (DeformConv, DeformConv_d, DeformConvPack, Defo
 from .dynunet_block import UnetResBlock  # noqa: F401
 from .transformerblock import LKA3d_deform, LKA_Attention3d_deform, TransformerBlock_3D_single_deform_LKA  # noqa: F401
 from .tv_ops import DeformConv2d, deform_conv2d  # noqa: F401
+from .network import D_LKA_Former, D_LKA_Former_Encoder, D_LKA_FormerUpBlock, UnetOutBlock  # noqa: F401
+from .decoder2d import deformableLKABlock, MyDecoderLayer  # noqa: F401
+from . import inference, training, dp  # noqa: F401
 
 __all__ = ["DeformConv", "DeformConvPack", "DeformConvPack_experimental", "DeformConvPack_Depth", "DeformConv_d",
            "DeformConvPack_d", "DeformConvFunction", "LKA3d_deform", "LKA_Attention3d_deform", "TransformerBlock_3D_single_deform_LKA", "UnetResBlock", "DeformConv2dPack",
-           "deformable_LKA", "deformable_LKA_Attention", "DeformConv2d", "deform_conv2d", "install_reference_aliases"]
+           "deformable_LKA", "deformable_LKA_Attention", "DeformConv2d", "deform_conv2d", "install_reference_aliases", "D_LKA_Former",
+           "D_LKA_Former_Encoder", "D_LKA_FormerUpBlock", "UnetOutBlock", "deformableLKABlock", "MyDecoderLayer", "inference", "training", "dp"]
 
 
 def install_reference_aliases(names=("D3D", "functions.deform_conv_func", "modules.deform_conv")):

@@ -1,0 +1,83 @@
+"""The trainer-side hooks of the 3-D net: what ``d_lka_former_trainer_synapse.py`` does around the network —
+``initialize_network`` (:158-198), ``initialize_optimizer_and_scheduler`` (:200-205) and ``run_iteration`` (:259-309) — plus the
+data-parallel wrapper the reference leaves to ``nn.DataParallel`` (``run_training.py``): one process per GPU, ``torch.distributed``
+(backend ``nccl`` = RCCL over xGMI), gradients averaged with bucketed all-reduces that overlap the backward pass
+(``DistributedDataParallel``), batch sharded by rank with no other collective."""
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+import torch
+import torch.nn as nn
+
+from .network import D_LKA_Former
+from .transformerblock import TransformerBlock_3D_single_deform_LKA
+
+
+def initialize_network(input_channels: int = 1, num_classes: int = 14, crop_size: Sequence[int] = (64, 128, 128), depths=(3, 3, 3, 3),
+                       skip_connections=(True, True, True, True), trans_block=TransformerBlock_3D_single_deform_LKA, device=None,
+                       patch_size=(2, 4, 4)) -> D_LKA_Former:
+    """d_lka_former_trainer_synapse.py:158-185 (the fvcore FLOP count of :186-193 is logging only)."""
+    net = D_LKA_Former(in_channels=input_channels, out_channels=num_classes, img_size=crop_size, feature_size=16, num_heads=4, depths=list(depths),
+                       dims=[32, 64, 128, 256], do_ds=True, trans_block=trans_block, skip_connections=list(skip_connections), patch_size=patch_size)
+    if device is not None:
+        net = net.to(device)
+    net.inference_apply_nonlin = lambda x: torch.softmax(x, 1)
+    return net
+
+
+def initialize_optimizer(net: nn.Module, initial_lr: float = 1e-2, weight_decay: float = 3e-5):
+    """:200-205: SGD, momentum 0.99, Nesterov; the reference drives the learning rate with nnU-Net's poly schedule."""
+    return torch.optim.SGD(net.parameters(), initial_lr, weight_decay=weight_decay, momentum=0.99, nesterov=True)
+
+
+def wrap_data_parallel(net: nn.Module, device, find_unused_parameters: bool = False, bucket_cap_mb: int = 25) -> nn.Module:
+    """One replica per process / GPU.  ``find_unused_parameters`` is needed for the 2-D net only (its ``decoder_3`` owns two D-LKA blocks
+    that never run).  ``gradient_as_bucket_view`` lets RCCL reduce in place.  Without an initialised process group (single
+    GPU) the network is returned as is."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return net
+    dev = torch.device(device)
+    ids = [dev.index] if dev.type == "cuda" else None
+    return nn.parallel.DistributedDataParallel(net, device_ids=ids, find_unused_parameters=find_unused_parameters, bucket_cap_mb=bucket_cap_mb,
+                                               gradient_as_bucket_view=True)
+
+
+def deep_supervision_loss(outputs, target, weights=None, base_loss: Callable = None):
+    """The trainer weights the deep-supervision heads 1, 1/2, 1/4, ... (normalised; nnU-Net's ``MultipleOutputLoss2``).  ``base_loss``
+    defaults to cross-entropy (the reference adds a soft-Dice term from nnU-Net, outside the hot path).  target: the list of label volumes at
+    the heads' resolutions, or one full-resolution volume that is nearest-neighbour down-sampled here."""
+    base_loss = base_loss or nn.functional.cross_entropy
+    if not isinstance(outputs, (list, tuple)):
+        return base_loss(outputs, target)
+    n = len(outputs)
+    weights = weights or [1.0 / (2 ** i) for i in range(n)]
+    s = sum(weights)
+    total = 0.0
+    for i, out in enumerate(outputs):
+        tgt = target[i] if isinstance(target, (list, tuple)) else target
+        if tgt.shape[-3:] != out.shape[-3:]:
+            tgt = nn.functional.interpolate(tgt[:, None].float(), size=out.shape[-3:], mode="nearest")[:, 0].long()
+        total = total + (weights[i] / s) * base_loss(out, tgt)
+    return total
+
+
+def run_iteration(net: nn.Module, optimizer, data: torch.Tensor, target, loss_fn: Callable = deep_supervision_loss, do_backprop: bool = True,
+                  clip_norm: float = 12.0, bf16_autocast: bool = False, forward: Callable = None):
+    """:259-309: zero_grad, forward, loss, backward, clip_grad_norm_(12), step.  ``bf16_autocast`` runs the D-LKA blocks on bf16 activations
+    (their autocast policy; bf16 needs no gradient scaler — the reference's fp16 branch does, :281-290)."""
+    fwd = forward if forward is not None else net      # (modules whose forward takes more than the data tensor)
+    optimizer.zero_grad()
+    if bf16_autocast:
+        with torch.autocast(data.device.type, dtype=torch.bfloat16):
+            output = fwd(data)
+            loss = loss_fn(output, target)
+    else:
+        output = fwd(data)
+        loss = loss_fn(output, target)
+    if do_backprop:
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), clip_norm)
+        optimizer.step()
+    return loss.detach()

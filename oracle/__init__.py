@@ -121,8 +121,8 @@ def deform_conv3d_backward(input, weight, bias, offset, grad_output, stride=1, p
     s, p, d = _triple(stride), _triple(padding), _triple(dilation)
     B, C, D, H, W = input.shape
     Cout, _, kd, kh, kw = weight.shape
-    gi, go = torch.empty_like(input), torch.empty_like(offset)
-    gw, gb = torch.empty_like(weight), torch.empty_like(bias)
+    gi, go = torch.empty_like(input, memory_format=torch.contiguous_format), torch.empty_like(offset, memory_format=torch.contiguous_format)
+    gw, gb = torch.empty_like(weight, memory_format=torch.contiguous_format), torch.empty_like(bias, memory_format=torch.contiguous_format)
     _p = _Args()
     fn = getattr(lib(), "dlka_oracle_deform_conv3d_backward" + _sfx(input))
     rc = fn(_p(input), _p(weight), _p(bias), _p(offset),
@@ -191,7 +191,7 @@ def deform_conv2d_backward(input, offset, weight, grad_output, stride=1, padding
     Cout, Cg, kh, kw = weight.shape
     group = C // Cg
     og = offset.shape[1] // (2 * kh * kw)
-    gi, go, gw = torch.empty_like(input), torch.empty_like(offset), torch.empty_like(weight)
+    gi, go, gw = torch.empty_like(input, memory_format=torch.contiguous_format), torch.empty_like(offset, memory_format=torch.contiguous_format), torch.empty_like(weight, memory_format=torch.contiguous_format)
     gb = torch.empty((Cout,), dtype=input.dtype) if with_bias else None
     _p = _Args()
     fn = getattr(lib(), "dlka_oracle_deform_conv2d_backward" + _sfx(input))
@@ -239,7 +239,7 @@ def conv3d_backward(input, weight, grad_output, stride=1, padding=0, dilation=1,
     s, p, d = _triple(stride), _triple(padding), _triple(dilation)
     B, C, D, H, W = input.shape
     Cout, _, kd, kh, kw = weight.shape
-    gi, gw = torch.empty_like(input), torch.empty_like(weight)
+    gi, gw = torch.empty_like(input, memory_format=torch.contiguous_format), torch.empty_like(weight, memory_format=torch.contiguous_format)
     gb = torch.empty((Cout,), dtype=input.dtype) if with_bias else None
     _p = _Args()
     fn = getattr(lib(), "dlka_oracle_conv3d_backward" + _sfx(input))

@@ -9,13 +9,21 @@ import deformablelka_amd as dk
 from tests.parity import assert_close
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_modules.pt")
+GOLD_NETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_nets.pt")   # tests/golden/make_golden_nets.py
 _cache = {}
 
 
 def gold():
     if "g" not in _cache:
         _cache["g"] = torch.load(GOLD, weights_only=False)
+        _cache["g"].update({k: v for k, v in gold_nets().items() if isinstance(v, dict) and "state_dict" in v and "inputs" in v})
     return _cache["g"]
+
+
+def gold_nets():
+    if "n" not in _cache:
+        _cache["n"] = torch.load(GOLD_NETS, weights_only=False)
+    return _cache["n"]
 
 
 def build(name, case):
@@ -40,6 +48,10 @@ def build(name, case):
         return dk.DeformConv2dPack(6, kernel_size=(5, 5), padding=2, groups=6)
     if name == "deformable_LKA_Attention":
         return dk.deformable_LKA_Attention(case["inputs"][0].shape[1])
+    if name == "deformableLKABlock":
+        return dk.deformableLKABlock(**case["ctor"])
+    if name.startswith("MyDecoderLayer"):
+        return dk.MyDecoderLayer(**case["ctor"])
     raise KeyError(name)
 
 

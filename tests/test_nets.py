@@ -1,0 +1,202 @@
+"""SURVEY.md §8f rows 2-4 on the CPU: the full 3-D net assembly against the reference's own class (keys / shapes of the real assembly, the
+plumbing around the D-LKA blocks at the full 64x128x128 patch), the 2-D decoder pieces against the reference's classes (kernel sources on
+the emulator), the sliding-window predictor, and the data-parallel trainer hook (2 gloo ranks)."""
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import golden_checks
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+
+
+# ---- D_LKA_Former ---------------------------------------------------------------------------------------------------------------------
+def test_d_lka_former_state_dict_matches_the_reference_class():
+    """Every key and shape of the reference's D_LKA_Former(trans_block=TransformerBlock_3D_single_deform_LKA) — 699 entries, 42.35 M
+    parameters — so that a reference checkpoint loads with strict=True."""
+    import deformablelka_amd as dk
+    g = golden_checks.gold_nets()
+    net = dk.D_LKA_Former(in_channels=1, out_channels=14, img_size=[64, 128, 128], feature_size=16, num_heads=4, depths=[3, 3, 3, 3],
+                          dims=[32, 64, 128, 256], do_ds=True)
+    mine = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert mine == g["D_LKA_Former_keys"]
+    assert sum(p.numel() for p in net.parameters()) == g["D_LKA_Former_params"] == 42353327
+    assert len(net.dlka_blocks()) == 21
+
+
+def test_d_lka_former_plumbing_matches_the_reference_at_full_size():
+    """Everything AROUND the transformer blocks — stem, down-sampling + GroupNorm, token reshapes, transposed convs, skip additions,
+    encoder1 / decoder2 (InstanceNorm conv blocks), deep-supervision heads — against the reference's class at the full patch, with the same
+    cheap block plugged into both (``trans_block`` is a constructor argument of both)."""
+    import deformablelka_amd as dk
+    from make_golden_nets import LiteBlock
+    case = golden_checks.gold_nets()["D_LKA_Former_plumbing"]
+    net = dk.D_LKA_Former(trans_block=LiteBlock, **case["ctor"])
+    net.load_state_dict(case["state_dict"], strict=True)
+    net.eval()
+    x = torch.randn(1, 1, 64, 128, 128, generator=torch.Generator().manual_seed(case["input_seed"]))
+    with torch.no_grad():
+        outs = net(x)
+    assert [tuple(o.shape) for o in outs] == case["out_shapes"]
+    for o, sub, mean, amean in zip(outs, case["out_sub"], case["out_mean"], case["out_abs_mean"]):
+        assert (o[..., ::8, ::8, ::8] - sub).abs().max().item() < 2e-5
+        assert abs(float(o.double().mean()) - mean) < 1e-6 and abs(float(o.double().abs().mean()) - amean) < 1e-6
+
+
+# ---- 2-D decoder ----------------------------------------------------------------------------------------------------------------------
+@pytest.fixture()
+def emu_backend():
+    from deformablelka_amd import _lib
+    from tests import emu
+    _lib._set_backend_for_tests(emu.load())
+    yield
+    _lib._set_backend_for_tests(None)
+
+
+@pytest.mark.parametrize("name", ["deformableLKABlock", "MyDecoderLayer", "MyDecoderLayer_last", "MyDecoderLayer_noskip"])
+def test_decoder2d_golden_on_emulator(name, emu_backend):
+    golden_checks.replay(name, "cpu")
+
+
+# ---- sliding-window inference -----------------------------------------------------------------------------------------------------------
+def test_sliding_window_steps():
+    from deformablelka_amd.inference import compute_steps_for_sliding_window as steps, num_tiles
+    assert steps((64,), (110,), 0.5) == [[0, 23, 46]]                  # the example in neural_network.py:270-271
+    assert steps((64, 128, 128), (64, 128, 128), 0.5) == [[0], [0], [0]]
+    assert steps((96, 96, 96), (240, 240, 160), 0.5) == [[0, 48, 96, 144], [0, 48, 96, 144], [0, 32, 64]]
+    assert num_tiles((240, 240, 160), (96, 96, 96), 16, 16) == 10 * 10 * 5   # SURVEY §8d cfg 5
+
+
+def test_gaussian_importance_map_matches_scipy():
+    """neural_network.py:250-263 uses scipy.ndimage.gaussian_filter on a unit impulse; the separable closed form must agree."""
+    from scipy.ndimage import gaussian_filter
+    from deformablelka_amd.inference import gaussian_importance_map
+    for ps in [(8, 12, 10), (16, 16, 16), (5, 24, 24)]:
+        tmp = np.zeros(ps)
+        tmp[tuple(i // 2 for i in ps)] = 1
+        ref = gaussian_filter(tmp, [i / 8 for i in ps], 0, mode="constant", cval=0)
+        ref = (ref / ref.max()).astype(np.float32)
+        ref[ref == 0] = ref[ref != 0].min()
+        got = gaussian_importance_map(ps).numpy()
+        assert np.abs(got - ref).max() < 1e-6 and got.min() > 0 and got.max() == 1.0
+
+
+class _PointwiseNet(torch.nn.Module):
+    """Per-voxel network: its tiled prediction must equal its whole-volume prediction whatever the blending weights are."""
+
+    def __init__(self, k=3):
+        super().__init__()
+        self.c = torch.nn.Conv3d(1, k, 1)
+
+    def forward(self, x):
+        return [self.c(x), self.c(x)[..., ::2, ::2, ::2]]   # deep-supervision list: the predictor takes the first head
+
+
+def test_tiled_prediction_equals_whole_volume_for_a_pointwise_net():
+    from deformablelka_amd import inference as inf
+    torch.manual_seed(0)
+    net = _PointwiseNet()
+    x = torch.randn(1, 21, 30, 19)
+    whole = torch.softmax(net(x[None])[0], 1)[0]
+    for gauss in (True, False):
+        seg, probs = inf.predict_3d_tiled(net, x, (8, 16, 8), step_size=0.5, use_gaussian=gauss, tile_batch=3)
+        assert probs.shape == whole.shape and (probs - whole).abs().max().item() < 1e-5
+        assert torch.equal(seg, whole.argmax(0))
+    # smaller than the patch in one axis: symmetric zero padding, cropped again
+    seg, probs = inf.predict_3d_tiled(net, x[:, :5], (8, 16, 8), step_size=0.5)
+    assert probs.shape == (3, 5, 30, 19) and (probs - torch.softmax(net(x[None, :, :5])[0], 1)[0]).abs().max().item() < 1e-5
+    # pancreas procedure (test_util.py:45-111)
+    lab, score = inf.predict_single_case(net, x[0], stride_xy=6, stride_z=5, patch_size=(8, 16, 8), num_classes=3, tile_batch=2)
+    assert (score - whole).abs().max().item() < 1e-5 and torch.equal(lab, whole.argmax(0))
+
+
+def test_predict_single_case_matches_the_reference_loop():
+    """A network whose output depends on the tile CONTENT AND POSITION-in-tile (3^3 conv with zero padding): the restated numpy loop of
+    test_util.py:73-106 must give the same blended score map."""
+    from deformablelka_amd import inference as inf
+    torch.manual_seed(1)
+    net = torch.nn.Conv3d(1, 2, 3, padding=1)
+    image = torch.randn(13, 17, 11)
+    ps, sxy, sz = (8, 8, 8), 4, 3
+    lab, score = inf.predict_single_case(net, image, sxy, sz, ps, num_classes=2, tile_batch=5)
+    img = image.numpy()
+    ww, hh, dd = img.shape
+    nx, ny, nz = math.ceil((ww - ps[0]) / sxy) + 1, math.ceil((hh - ps[1]) / sxy) + 1, math.ceil((dd - ps[2]) / sz) + 1
+    sm, cnt = np.zeros((2,) + img.shape, np.float32), np.zeros(img.shape, np.float32)
+    for a in range(nx):
+        xs = min(sxy * a, ww - ps[0])
+        for b in range(ny):
+            ys = min(sxy * b, hh - ps[1])
+            for c in range(nz):
+                zs = min(sz * c, dd - ps[2])
+                t = torch.from_numpy(img[xs:xs + 8, ys:ys + 8, zs:zs + 8])[None, None]
+                y = torch.softmax(net(t), 1)[0].detach().numpy()
+                sm[:, xs:xs + 8, ys:ys + 8, zs:zs + 8] += y
+                cnt[xs:xs + 8, ys:ys + 8, zs:zs + 8] += 1
+    sm = sm / cnt[None]
+    assert np.abs(score.numpy() - sm).max() < 1e-5 and np.array_equal(lab.numpy(), sm.argmax(0))
+
+
+# ---- trainer hook: DistributedDataParallel over two gloo ranks ------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_block():
+    import deformablelka_amd as dk
+    from oracle.blocks import randomize_offsets_
+    torch.manual_seed(5)
+    m = dk.deformableLKABlock(dim=8)
+    randomize_offsets_(m, std=0.05)
+    return m
+
+
+def _ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIPEMU_THREADS="2")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deformablelka_amd import _lib, training
+    from tests import emu
+    _lib._set_backend_for_tests(emu.load())
+    net = training.wrap_data_parallel(_make_block(), "cpu")
+    assert isinstance(net, torch.nn.parallel.DistributedDataParallel)
+    g = torch.Generator().manual_seed(100 + rank)                      # this rank's shard of the batch
+    x, tgt = torch.randn(1, 20, 8, generator=g), torch.randn(1, 20, 8, generator=g)
+    opt = torch.optim.SGD(net.parameters(), 0.1)
+    loss = training.run_iteration(net, opt, x, tgt, loss_fn=lambda o, t: ((o - t) ** 2).mean(), clip_norm=1e9, forward=lambda t: net(t, 4, 5))
+    if rank == 0:
+        torch.save({"params": {k: v.detach().clone() for k, v in net.module.state_dict().items()}, "loss": loss}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_ddp_trainer_hook_two_ranks_equals_one_process_on_both_shards(tmp_path, emu_backend):
+    """wrap_data_parallel + run_iteration on 2 gloo ranks (1 sample each) == one process that sees both samples (mean loss)."""
+    from deformablelka_amd import training
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_ddp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    from deformablelka_amd import _lib
+    from tests import emu
+    _lib._set_backend_for_tests(emu.load())
+    net = _make_block()
+    xs, ts = [], []
+    for r in range(2):
+        g = torch.Generator().manual_seed(100 + r)
+        xs.append(torch.randn(1, 20, 8, generator=g)); ts.append(torch.randn(1, 20, 8, generator=g))
+    opt = torch.optim.SGD(net.parameters(), 0.1)
+    training.run_iteration(net, opt, torch.cat(xs), torch.cat(ts), loss_fn=lambda o, t: ((o - t) ** 2).mean(), clip_norm=1e9, forward=lambda t: net(t, 4, 5))
+    for k, v in net.state_dict().items():
+        assert torch.allclose(got["params"][k], v, rtol=1e-4, atol=1e-6), k
