@@ -58,6 +58,19 @@ struct DwArgs {
     int kd, kh, pd, ph, pw, dd, dh;   // kw / dw are template parameters
 };
 
+// channels-last 2-D depthwise deformable conv (cl_ddw2d.hip): forward uses in / off / wp / out; backward in / off / wp / g / gx / goff / part
+struct DwArgs2d {
+    const float *in;     // [B][H][W][C]
+    const float *off;    // [B][2 kh kw][H][W] planar (dy, dx) per tap
+    const float *wp;     // [kh kw][C] prepared tap weights (launch_cl_dw_prep_weight, unflipped)
+    const float *g;      // [B][H][W][C] grad_out
+    float *out;          // [B][H][W][C]
+    float *gx;           // [B][H][W][C], zero-filled by the caller
+    float *goff;         // [B][2 kh kw][H][W]
+    float *part;         // cl_ddw2d_part_floats() floats of weight-gradient partials
+    int B, H, W, C, kh, kw, ph, pw, dh, dw;
+};
+
 struct DwWgradArgs {
     const float *g;     // [B][D][H][W][C]
     const float *in;    // [B][D][H][W][C]

@@ -1,0 +1,409 @@
+// Channels-last 2-D DEPTHWISE deformable convolution — the two large-kernel convs of the 2-D D-LKA block
+// (2D/deformable_LKA/deformable_LKA.py:93-94: 5x5 pad 2 and 7x7 dilation 3 pad 9, groups = C, ONE offset field shared by all
+// channels, bias-free), torchvision 0.12 `deform_conv2d` semantics (offset channels (dy, dx) per tap, guard
+// q <= -1 || q >= size -> 0, per-corner zeroing; un-vendored, restated in oracle/dlka_oracle_impl.h).
+//
+//     out[m][c] = sum_tap w[c][tap] * S(m, tap, c),   S = bilinear sample of in[b][:, :, c] at  base(m, tap) + offset[b][2 tap .. +1][m]
+//
+// The reference goes through torchvision: an im2col buffer of C*K x B*H*W floats (722 MB / 1.4 GB at C = 96, 56^2, B = 24) and C
+// separate 1 x K GEMMs.  Depthwise = no contraction over channels, and the sampling positions are the SAME for every channel, so in
+// channels-last layout one (pixel, tap) costs one sampling description and four whole-row gathers: lane (r = lane >> 3, p = lane & 7)
+// serves pixel r of the wave's 8 pixels and channels 4p .. 4p+3 of the current 32-channel chunk — every load instruction covers 8 whole
+// 128-byte rows, the access pattern that gathers at L1 speed (cl_gather.h) — and all C/32 chunks of a pixel reuse the description.
+// The matrix cores have nothing to do here (north_star: "depthwise / gather-bound, not a dense contraction").
+//
+//   cl_ddw2d_fwd_kernel      forward
+//   cl_ddw2d_bwd_kernel      one traversal for grad_offset (channel reduction in registers + one DPP sum over the 8 lanes of a pixel, no
+//                            atomics) and the weight-gradient partials (tap-outer loop: 4 accumulators per chunk and lane, folded across
+//                            the pixel lanes with shuffles and across waves through LDS)
+//   cl_ddw2d_gx_kernel       grad_input: tile scatter into an fp64 LDS window, see there
+//   cl_ddw2d_fold_kernel     sums the per-block weight-gradient partials into the reference layout [C][1][kh][kw]
+#include <stdlib.h>
+
+#include <atomic>
+#include "cl_args.h"
+#include "dlka_kernels.h"
+
+namespace dlka {
+
+namespace {
+
+struct Tap2 {
+    unsigned off[4];   // byte offsets of the 4 corner ROWS (pixel * C * 4); DLKA_OOB (-> loads 0) for corners outside the image
+    float wt[4];       // bilinear weights; 0 for corners outside the image AND for samples outside the guard
+    float ly, lx;
+    unsigned okm;      // corners that contribute to the sample / receive grad_input (inside the image and the guard)
+};
+
+// torchvision bilinear_interpolate / get_coordinate_weight (deform_conv2d_kernel.cpp): corners (y0,x0) (y0,x1) (y1,x0) (y1,x1).
+// The SAMPLE (forward, weight gradient, grad_input) is guarded: 0 unless -1 < q < size.  The coordinate weight (grad_offset) has no guard,
+// only the per-corner bounds — the two differ exactly at q == -1, where the high corner is inside the image: its row offset stays valid
+// here (the loads feed the derivative) while its bilinear weight and okm bit are cleared.
+__device__ __forceinline__ void describe2(Tap2 &s, float oy, float ox, int b, int by, int bx, int H, int W, int N, int rowbytes)
+{
+    const float qy = (float)by + oy, qx = (float)bx + ox;
+    s.okm = 0;
+    s.ly = s.lx = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s.off[q] = DLKA_OOB; s.wt[q] = 0.f; }
+    const bool reach = (qy >= -1.f) & (qx >= -1.f) & (qy < (float)H) & (qx < (float)W);   // some corner can lie inside the image
+    if (reach) {
+        const bool inside = (qy > -1.f) & (qx > -1.f);
+        const float fy = floorf(qy), fx = floorf(qx);
+        const int y0 = (int)fy, x0 = (int)fx;
+        const float ly = qy - fy, lx = qx - fx, hy = 1.f - ly, hx = 1.f - lx;
+        s.ly = ly; s.lx = lx;
+        const bool vy0 = y0 >= 0, vy1 = y0 + 1 <= H - 1, vx0 = x0 >= 0, vx1 = x0 + 1 <= W - 1;
+        const bool ok[4] = {vy0 && vx0, vy0 && vx1, vy1 && vx0, vy1 && vx1};
+        const float w4[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
+        const int base = b * N + y0 * W + x0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (ok[q]) {
+                s.off[q] = (unsigned)(base + (q >> 1) * W + (q & 1)) * (unsigned)rowbytes;
+                if (inside) { s.wt[q] = w4[q]; s.okm |= 1u << q; }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+struct Ddw2dArgs {
+    const float *in;     // [B][N][C] channels-last
+    const float *off;    // [B][2K][N] planar (dy, dx) per tap
+    const float *wp;     // [K][C] prepared tap weights
+    const float *g;      // [B][N][C] grad_out (backward)
+    float *out;          // forward: [B][N][C]
+    float *gx;           // backward: [B][N][C], ZERO-FILLED by the caller (atomics)
+    float *goff;         // backward: [B][2K][N]
+    float *part;         // backward: [nblocks][K][C] weight-gradient partials
+    int B, H, W, N, M, C, K, kh, kw, ph, pw, dh, dw;
+    int px_per_block;    // backward: pixels per workgroup (multiple of 32)
+};
+
+// grid (ceil(M / 32), C / (32 * NCH)); block 256 = 4 waves x 8 pixels.  NCH channel chunks of 32 per block.
+template <int NCH>
+__global__ __launch_bounds__(256) void cl_ddw2d_fwd_kernel(Ddw2dArgs p)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane >> 3, pp = lane & 7;
+    const int m = blockIdx.x * 32 + wave * 8 + r;
+    const bool ok = m < p.M;
+    const int b = ok ? m / p.N : 0, n = ok ? m - b * p.N : 0;
+    const int x0 = n % p.W, y0 = n / p.W;
+    const int c0 = blockIdx.y * NCH * 32 + 4 * pp;
+    const int rowbytes = p.C * 4;
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.C * 4), rw = make_rsrc(p.wp, (size_t)p.K * p.C * 4);
+    f32x4 acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *offp = p.off + (long)b * 2 * p.K * p.N + n;
+    for (int tap = 0; tap < p.K; ++tap) {
+        const int ti = tap / p.kw, tj = tap - ti * p.kw;
+        Tap2 s;
+        const float oy = ok ? offp[(long)(2 * tap) * p.N] : 0.f, ox = ok ? offp[(long)(2 * tap + 1) * p.N] : 0.f;
+        describe2(s, oy, ox, b, y0 - p.ph + ti * p.dh, x0 - p.pw + tj * p.dw, p.H, p.W, p.N, rowbytes);
+        if (!ok) s.off[0] = s.off[1] = s.off[2] = s.off[3] = DLKA_OOB;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const unsigned cb = (unsigned)(c0 + 32 * c) * 4u;
+            f32x4 x4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x4[q] = buf_load_f32x4(rin, s.off[q] == DLKA_OOB ? DLKA_OOB : s.off[q] + cb);
+            const f32x4 w4 = buf_load_f32x4(rw, (unsigned)(tap * p.C) * 4u + cb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sv = s.wt[0] * x4[0][e];
+                sv = fmaf(s.wt[1], x4[1][e], sv); sv = fmaf(s.wt[2], x4[2][e], sv); sv = fmaf(s.wt[3], x4[3][e], sv);
+                acc[c][e] = fmaf(w4[e], sv, acc[c][e]);
+            }
+        }
+    }
+    if (!ok) return;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) *reinterpret_cast<f32x4 *>(p.out + (long)m * p.C + c0 + 32 * c) = acc[c];
+}
+
+// grid (ceil(M / px_per_block)); block 256 = 4 waves; a wave walks its share of the block's pixels 8 at a time, for ONE tap at a time
+// (tap-outer), all NCH chunks of the row per (pixel, tap).
+template <int NCH>
+__global__ __launch_bounds__(256) void cl_ddw2d_bwd_kernel(Ddw2dArgs p)
+{
+    __shared__ float red[4][NCH * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane >> 3, pp = lane & 7;
+    const int rowbytes = p.C * 4;
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.C * 4), rg = make_rsrc(p.g, (size_t)p.M * p.C * 4), rw = make_rsrc(p.wp, (size_t)p.K * p.C * 4);
+    const int m_lo = blockIdx.x * p.px_per_block, m_hi = min(p.M, m_lo + p.px_per_block);
+    for (int tap = 0; tap < p.K; ++tap) {
+        const int ti = tap / p.kw, tj = tap - ti * p.kw;
+        f32x4 gwacc[NCH], w4[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            gwacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            w4[c] = buf_load_f32x4(rw, (unsigned)(tap * p.C + 32 * c + 4 * pp) * 4u);
+        }
+        for (int mb = m_lo + wave * 8; mb < m_hi; mb += 32) {
+            const int m = mb + r;
+            const bool ok = m < m_hi;
+            const int b = ok ? m / p.N : 0, n = ok ? m - b * p.N : 0;
+            const int x0 = n % p.W, y0 = n / p.W;
+            const float *offp = p.off + ((long)b * 2 * p.K + 2 * tap) * p.N + n;
+            Tap2 s;
+            describe2(s, ok ? offp[0] : 0.f, ok ? offp[p.N] : 0.f, b, y0 - p.ph + ti * p.dh, x0 - p.pw + tj * p.dw, p.H, p.W, p.N, rowbytes);
+            if (!ok) { s.off[0] = s.off[1] = s.off[2] = s.off[3] = DLKA_OOB; s.okm = 0; s.wt[0] = s.wt[1] = s.wt[2] = s.wt[3] = 0.f; }
+            // d(sample)/dy = (1-lx) (x10 - x00) + lx (x11 - x01), d/dx = (1-ly) (x01 - x00) + ly (x11 - x10); corners outside the image read 0
+            // (torchvision get_coordinate_weight: per-corner bounds only, no guard)
+            const float hy = 1.f - s.ly, hx = 1.f - s.lx;
+            const float dyw[4] = {-hx, -s.lx, hx, s.lx}, dxw[4] = {-hy, hy, -s.ly, s.ly};
+            float goy = 0.f, gox = 0.f;
+            const unsigned gb = ok ? (unsigned)m * (unsigned)rowbytes : DLKA_OOB;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const unsigned cb = (unsigned)(32 * c + 4 * pp) * 4u;
+                f32x4 x4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x4[q] = buf_load_f32x4(rin, s.off[q] == DLKA_OOB ? DLKA_OOB : s.off[q] + cb);
+                const f32x4 g4 = buf_load_f32x4(rg, gb == DLKA_OOB ? DLKA_OOB : gb + cb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float sv = s.wt[0] * x4[0][e];
+                    sv = fmaf(s.wt[1], x4[1][e], sv); sv = fmaf(s.wt[2], x4[2][e], sv); sv = fmaf(s.wt[3], x4[3][e], sv);
+                    gwacc[c][e] = fmaf(g4[e], sv, gwacc[c][e]);
+                    const float col = g4[e] * w4[c][e];                       // d loss / d sample
+                    float dy = 0.f, dx = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { dy = fmaf(dyw[q], x4[q][e], dy); dx = fmaf(dxw[q], x4[q][e], dx); }
+                    goy = fmaf(col, dy, goy); gox = fmaf(col, dx, gox);
+                }
+            }
+            goy = sum8(goy);   // over the 8 channel pieces of the pixel
+            gox = sum8(gox);
+            if (ok && pp == 0) {
+                float *gop = p.goff + ((long)b * 2 * p.K + 2 * tap) * p.N + n;
+                gop[0] = goy;
+                gop[p.N] = gox;
+            }
+        }
+        // fold the weight gradient of this tap: over the 8 pixel lanes (DPP-free path: shuffles), then over the 4 waves (LDS)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = gwacc[c][e];
+                v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+                gwacc[c][e] = v;
+            }
+        __syncthreads();   // red free
+        if (r == 0) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wave][32 * c + 4 * pp + e] = gwacc[c][e];
+        }
+        __syncthreads();
+        for (int e = tid; e < NCH * 32; e += 256)
+            p.part[((long)blockIdx.x * p.K + tap) * p.C + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    }
+}
+
+// grad_input of the depthwise deformable conv:  gx[b][v][c] = sum over (pixel o, tap) whose sample touches v of  G[o][c] w[c][tap] wt_v.
+// The reference (torchvision deformable_col2im) issues one global fp32 atomicAdd per (pixel, tap, channel, corner); measured here the same
+// scheme in channels-last layout costs 12 ms at C = 96 / 56^2 / B = 24 (1.4e9 atomics on heavily shared rows, profiles/r03e).  As in the
+// 3-D block (cl_deform_bwd2.hip) the scatter therefore goes into an LDS window first: a workgroup owns a tile of OUTPUT pixels and a
+// 4-channel slice, its window = the tile plus the kernel reach plus a 3-pixel offset margin, clipped to the image, in fp64 cells —
+// ds_add_f64 is the fast LDS atomic on gfx950 (6.8 lanes/clk/CU against 0.33 for ds_add_f32, profiles/r01e) and makes the sum
+// order-independent.  Corners beyond the window (|offset| > 3 pixels outside the reach) go straight to global atomics; the window is
+// flushed with one fp32 atomic per non-zero (cell, channel).
+constexpr int GX2_CS = 4;        // channels per slice
+constexpr int GX2_MARGIN = 3;    // offset margin of the window beyond the kernel reach
+
+template <int DUMMY>
+__global__ __launch_bounds__(256) void cl_ddw2d_gx_kernel(Ddw2dArgs p, int TH, int TW, int ntx, int nty, int reach_y, int reach_x)
+{
+    DLKA_DYN_SMEM(unsigned char, smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    int t = blockIdx.x;
+    const int tx = t % ntx; t /= ntx;
+    const int ty = t % nty; const int b = t / nty;
+    const int slice = blockIdx.y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int wy0 = max(0, oy0 - reach_y - GX2_MARGIN), wy1 = min(p.H, oy0 + TH + reach_y + GX2_MARGIN);
+    const int wx0 = max(0, ox0 - reach_x - GX2_MARGIN), wx1 = min(p.W, ox0 + TW + reach_x + GX2_MARGIN);
+    const int WH = wy1 - wy0, WW = wx1 - wx0, wcells = WH * WW;
+    const int wstride = wcells + 64;          // per channel plane: the window, then one trash cell per lane
+    double *Win = reinterpret_cast<double *>(smem);                                  // [CS][wstride]
+    float *Ws = reinterpret_cast<float *>(smem + (size_t)GX2_CS * wstride * 8);      // [K][CS] tap weights of this slice
+    for (int e = tid; e < GX2_CS * wstride; e += 256) Win[e] = 0.0;
+    for (int e = tid; e < p.K * GX2_CS; e += 256) Ws[e] = p.wp[(long)(e / GX2_CS) * p.C + slice * GX2_CS + (e % GX2_CS)];
+    __syncthreads();
+    const int npx = TH * TW;
+    const int trash = wcells + lane;
+    for (int px = tid; px < npx; px += 256) {
+        const int oy = oy0 + px / TW, ox = ox0 + px % TW;
+        if (oy >= p.H || ox >= p.W) continue;
+        const int n = oy * p.W + ox;
+        const f32x4 g4 = *reinterpret_cast<const f32x4 *>(p.g + ((long)b * p.N + n) * p.C + slice * GX2_CS);
+        const float *offp = p.off + (long)b * 2 * p.K * p.N + n;
+        for (int tap = 0; tap < p.K; ++tap) {
+            const int ti = tap / p.kw, tj = tap - ti * p.kw;
+            const float qy = (float)(oy - p.ph + ti * p.dh) + offp[(long)(2 * tap) * p.N];
+            const float qx = (float)(ox - p.pw + tj * p.dw) + offp[(long)(2 * tap + 1) * p.N];
+            if (!((qy > -1.f) & (qx > -1.f) & (qy < (float)p.H) & (qx < (float)p.W))) continue;   // the sample's guard
+            const float fy = floorf(qy), fx = floorf(qx);
+            const int y0 = (int)fy, x0 = (int)fx;
+            const float ly = qy - fy, lx = qx - fx;
+            const float wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
+            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(Ws + tap * GX2_CS);
+            const float col[4] = {g4[0] * w4[0], g4[1] * w4[1], g4[2] * w4[2], g4[3] * w4[3]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int yy = y0 + (q >> 1), xx = x0 + (q & 1);
+                const bool inimg = ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
+                const bool inwin = inimg & (yy >= wy0) & (yy < wy1) & (xx >= wx0) & (xx < wx1);
+                const float wq = wy[q >> 1] * wx[q & 1];
+                // branch-free window part: a corner outside the window adds 0.0 to this lane's trash cell
+                const int idx = inwin ? (yy - wy0) * WW + (xx - wx0) : trash;
+                const float wv = inwin ? wq : 0.f;
+#pragma unroll
+                for (int c = 0; c < GX2_CS; ++c) atomicAdd(Win + c * wstride + idx, (double)(col[c] * wv));
+                if (inimg & !inwin) {   // rare: beyond the offset margin
+                    float *dst = p.gx + ((long)b * p.N + yy * p.W + xx) * p.C + slice * GX2_CS;
+#pragma unroll
+                    for (int c = 0; c < GX2_CS; ++c) atomicAdd(dst + c, col[c] * wq);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < wcells; e += 256) {
+        const int yy = wy0 + e / WW, xx = wx0 + e % WW;
+        float *dst = p.gx + ((long)b * p.N + yy * p.W + xx) * p.C + slice * GX2_CS;
+#pragma unroll
+        for (int c = 0; c < GX2_CS; ++c) {
+            const float v = (float)Win[c * wstride + e];
+            if (v != 0.f) atomicAdd(dst + c, v);
+        }
+    }
+}
+
+// gw[c][tap] (reference layout [C][1][kh][kw]) = sum_blocks part[block][tap][c]
+__global__ __launch_bounds__(256) void cl_ddw2d_fold_kernel(const float *__restrict__ part, float *__restrict__ gw, int nblocks, int K, int C)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;   // (tap, c)
+    if (e >= K * C) return;
+    float a0 = 0.f, a1 = 0.f;
+    int bk = 0;
+    for (; bk + 1 < nblocks; bk += 2) { a0 += part[(long)bk * K * C + e]; a1 += part[(long)(bk + 1) * K * C + e]; }
+    if (bk < nblocks) a0 += part[(long)bk * K * C + e];
+    const int tap = e / C, c = e - tap * C;
+    gw[(long)c * K + tap] = a0 + a1;
+}
+
+static int ddw2d_nch(int C)
+{
+    const int n = C / 32;
+    return (C % 32 == 0 && (n == 1 || n == 2 || n == 3 || n == 4 || n == 6 || n == 8 || n == 12)) ? n : 0;
+}
+
+int cl_ddw2d_supported(int C) { return ddw2d_nch(C) != 0; }
+
+int cl_ddw2d_bwd_px_per_block(int M)
+{
+    // ~1024 workgroups when the tensor is large enough; at least one 32-pixel pass per wave group
+    int px = ((M / 1024) + 31) / 32 * 32;
+    if (px < 32) px = 32;
+    return px;
+}
+
+size_t cl_ddw2d_part_floats(int M, int K, int C) { return (size_t)cdiv(M, cl_ddw2d_bwd_px_per_block(M)) * K * C; }
+
+static void fill_ddw(Ddw2dArgs &a, const DwArgs2d &d)
+{
+    memset(&a, 0, sizeof(a));
+    a.in = d.in; a.off = d.off; a.wp = d.wp; a.g = d.g; a.out = d.out; a.gx = d.gx; a.goff = d.goff; a.part = d.part;
+    a.B = d.B; a.H = d.H; a.W = d.W; a.N = d.H * d.W; a.M = d.B * d.H * d.W; a.C = d.C; a.K = d.kh * d.kw; a.kh = d.kh; a.kw = d.kw;
+    a.ph = d.ph; a.pw = d.pw; a.dh = d.dh; a.dw = d.dw;
+}
+
+int launch_cl_ddw2d_fwd(const DwArgs2d &d, hipStream_t st)
+{
+    const int nch = ddw2d_nch(d.C);
+    if (!nch) return DLKA_ERR_UNSUPPORTED;
+    Ddw2dArgs a;
+    fill_ddw(a, d);
+    if ((long)a.M * a.C * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+    const int mblocks = cdiv(a.M, 32);
+    // few pixels (14^2 stages): split the channel chunks over gridDim.y so that the chip still fills
+    int per = nch;
+    while (per > 1 && mblocks * (nch / per) < 1024 && per % 2 == 0) per /= 2;
+    if (per == 3 && mblocks * (nch / 3) < 512) per = 1;
+    dim3 grid(mblocks, nch / per), block(256);
+#define DLKA_DDW_F(N_) case N_: { auto k = cl_ddw2d_fwd_kernel<N_>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
+    switch (per) {
+        DLKA_DDW_F(1) DLKA_DDW_F(2) DLKA_DDW_F(3) DLKA_DDW_F(4) DLKA_DDW_F(6) DLKA_DDW_F(8) DLKA_DDW_F(12)
+        default: return DLKA_ERR_UNSUPPORTED;
+    }
+#undef DLKA_DDW_F
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+// gx must be zero-filled by the caller; gw receives the folded weight gradient in the reference layout
+int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st)
+{
+    const int nch = ddw2d_nch(d.C);
+    if (!nch) return DLKA_ERR_UNSUPPORTED;
+    Ddw2dArgs a;
+    fill_ddw(a, d);
+    if ((long)a.M * a.C * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;
+    a.px_per_block = cl_ddw2d_bwd_px_per_block(a.M);
+    const int nblocks = cdiv(a.M, a.px_per_block);
+    dim3 grid(nblocks), block(256);
+#define DLKA_DDW_B(N_) case N_: { auto k = cl_ddw2d_bwd_kernel<N_>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
+    switch (nch) {
+        DLKA_DDW_B(1) DLKA_DDW_B(2) DLKA_DDW_B(3) DLKA_DDW_B(4) DLKA_DDW_B(6) DLKA_DDW_B(8) DLKA_DDW_B(12)
+        default: return DLKA_ERR_UNSUPPORTED;
+    }
+#undef DLKA_DDW_B
+    DLKA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(cl_ddw2d_fold_kernel, dim3(cdiv(a.K * a.C, 256)), dim3(256), 0, st, (const float *)a.part, gw, nblocks, a.K, a.C);
+    DLKA_CHECK_LAUNCH();
+    {   // grad_input: LDS-window scatter
+        const int reach_y = a.ph > (a.kh - 1) * a.dh - a.ph ? a.ph : (a.kh - 1) * a.dh - a.ph;   // |base - output pixel| <= reach
+        const int reach_x = a.pw > (a.kw - 1) * a.dw - a.pw ? a.pw : (a.kw - 1) * a.dw - a.pw;
+        int TH = a.H < 16 ? a.H : 16, TW = a.W < 32 ? a.W : 32;
+        auto cells = [&](int th, int tw) {
+            const int wh = th + 2 * (reach_y + GX2_MARGIN) < a.H ? th + 2 * (reach_y + GX2_MARGIN) : a.H;
+            const int ww = tw + 2 * (reach_x + GX2_MARGIN) < a.W ? tw + 2 * (reach_x + GX2_MARGIN) : a.W;
+            return (size_t)wh * ww;
+        };
+        auto lds_bytes = [&](int th, int tw) { return (size_t)GX2_CS * (cells(th, tw) + 64) * 8 + (size_t)a.K * GX2_CS * 4; };
+        // enough workgroups for the chip, and two of them per CU (<= 76 KB each)
+        while ((lds_bytes(TH, TW) > 76 * 1024 || (long)a.B * cdiv(a.H, TH) * cdiv(a.W, TW) * (a.C / GX2_CS) < 1024) && TH * TW > 64) {
+            if (TW >= 2 * TH && TW > 8) TW = cdiv(TW, 2); else TH = cdiv(TH, 2);
+        }
+        const size_t lds = lds_bytes(TH, TW);
+        if (lds > 150 * 1024) return DLKA_ERR_UNSUPPORTED;
+#if !defined(HIPEMU)
+        static std::atomic<uint64_t> attr_done{0};   // dynamic LDS above 64 KB: per function and per device
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return DLKA_ERR_LAUNCH;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(cl_ddw2d_gx_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return DLKA_ERR_LAUNCH;
+            attr_done.fetch_or(bit, std::memory_order_release);
+        }
+#endif
+        const int ntx = cdiv(a.W, TW), nty = cdiv(a.H, TH);
+        dim3 ggrid(a.B * nty * ntx, a.C / GX2_CS);
+        auto k = cl_ddw2d_gx_kernel<0>;
+        hipLaunchKernelGGL(k, ggrid, dim3(256), lds, st, a, TH, TW, ntx, nty, reach_y, reach_x);
+        DLKA_CHECK_LAUNCH();
+    }
+    return DLKA_OK;
+}
+
+}  // namespace dlka

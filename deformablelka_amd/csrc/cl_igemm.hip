@@ -307,7 +307,9 @@ static int launch_igemm_nt(const IgemmArgs &a, int splits, hipStream_t st)
     // column tiles per block: all of them when there are plenty of row blocks, fewer (-> gridDim.z) for small M
     int NT = NT_total;
     const int mblocks = cdiv(a.M, 128);
-    if (NT_total == 8 && mblocks * splits < 256) NT = (mblocks * splits * 2 < 256) ? 2 : 4;
+    if (NT_total == 6) NT = 3;          // 192 / 384 columns (the 2-D block's offset-net data gradients): 3 / 4 tiles per workgroup
+    else if (NT_total == 12) NT = 4;
+    else if (NT_total == 8 && mblocks * splits < 256) NT = (mblocks * splits * 2 < 256) ? 2 : 4;
     else if (NT_total == 4 && mblocks * splits < 256) NT = (mblocks * splits * 2 < 256) ? 1 : 2;
     else if (NT_total == 2 && mblocks * splits < 128) NT = 1;
     dim3 grid(mblocks, splits, NT_total / NT), block(256);

@@ -711,6 +711,7 @@ int dlka_lka3d_attention_backward(const void *x, const dlka_lka3d_params *p, con
 size_t dlka_lka2d_saved_bytes(int B, int C, int H, int W, int dtype)
 {
     if (check_block(B, C, 1, H, W)) return 0;
+    if (lka2d_cl_supported(B, C, H, W, dtype)) return lka2d_cl_saved_bytes(B, C, H, W);   // channels-last fast path (dlka_capi_cl.hip)
     Lka2dGeoms G(B, C, H, W);
     return 5 * align256(G.E * esz(dtype)) + align256(G.Off5 * esz(dtype)) + align256(G.Off7 * esz(dtype));
 }
@@ -718,6 +719,7 @@ size_t dlka_lka2d_saved_bytes(int B, int C, int H, int W, int dtype)
 size_t dlka_lka2d_workspace_bytes(int B, int C, int H, int W, int dtype)
 {
     if (check_block(B, C, 1, H, W)) return 0;
+    if (lka2d_cl_supported(B, C, H, W, dtype)) return lka2d_cl_workspace_bytes(B, C, H, W);
     Lka2dGeoms G(B, C, H, W);
     size_t n = align256(G.scratch_floats() * 4) + 4 * align256(G.E * esz(dtype)) + align256(G.Off7 * esz(dtype));
     if (dtype != DLKA_F32) n += align256(G.max_weight_elems() * 4) + align256(G.E * 4);
@@ -732,6 +734,10 @@ int dlka_lka2d_attention_forward(const void *x, const dlka_lka2d_params *p, void
     for (size_t i = 0; i < sizeof(*p) / sizeof(void *); ++i) if (!pp[i]) return DLKA_ERR_NULL;
     DLKA_TRY(check_block(B, C, 1, H, W));
     hipStream_t st = (hipStream_t)stream;
+    // channels-last fast path (MFMA offset nets, gather-layout depthwise deformable convs) wherever the width allows; DLKA_LKA2D_GENERAL=1
+    // forces the general NCHW kernels (A/B runs and the parity test of one path against the other)
+    if (lka2d_cl_supported(B, C, H, W, dtype) && !getenv("DLKA_LKA2D_GENERAL"))
+        return lka2d_cl_forward(x, p, y, saved, saved_bytes, workspace, workspace_bytes, B, C, H, W, st);
     return DLKA_DISPATCH(dtype, lka2d_forward_t<float>(x, p, y, saved, saved_bytes, workspace, workspace_bytes, B, C, H, W, st),
                          lka2d_forward_t<bf16_t>(x, p, y, saved, saved_bytes, workspace, workspace_bytes, B, C, H, W, st));
 }
@@ -747,6 +753,8 @@ int dlka_lka2d_attention_backward(const void *x, const dlka_lka2d_params *p, con
     for (size_t i = 0; i < sizeof(*grads) / sizeof(void *); ++i) if (!gp[i]) return DLKA_ERR_NULL;
     DLKA_TRY(check_block(B, C, 1, H, W));
     hipStream_t st = (hipStream_t)stream;
+    if (lka2d_cl_supported(B, C, H, W, dtype) && !getenv("DLKA_LKA2D_GENERAL"))
+        return lka2d_cl_backward(x, p, grad_y, saved, saved_bytes, grad_x, grads, workspace, workspace_bytes, B, C, H, W, st);
     return DLKA_DISPATCH(dtype,
                          lka2d_backward_t<float>(x, p, grad_y, saved, saved_bytes, grad_x, grads, workspace, workspace_bytes, B, C, H, W, dtype, st),
                          lka2d_backward_t<bf16_t>(x, p, grad_y, saved, saved_bytes, grad_x, grads, workspace, workspace_bytes, B, C, H, W, dtype, st));

@@ -129,7 +129,7 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
                         bool aux_f32 = false, float *acc32 = nullptr)
 {
     const int KP = round_up(s.Cout, 32), NP = s.Cin;
-    if (!nt_ok(NP) || s.Cin % 32) return DLKA_ERR_UNSUPPORTED;
+    if (!(nt_ok(NP) || NP == 192 || NP == 384) || s.Cin % 32) return DLKA_ERR_UNSUPPORTED;   // (192 / 384: the 2-D block's widths, 3 / 4 column tiles per workgroup)
     if (!gout_planar && s.Cout % 32) return DLKA_ERR_UNSUPPORTED;
     const int split = use_split(s, false);
     if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, KP, NP, 1 | split_mode_flag(split), st));
@@ -441,6 +441,204 @@ bool tokens_supported(int B, int C, int D, int H, int W)
 }
 
 }  // namespace
+
+// =========================================================================================================================
+// The 2-D D-LKA block (deformable_LKA_Attention, 2D/deformable_LKA/deformable_LKA.py:124-140) on the channels-last kernels.
+// x / y arrive in the reference's NCHW layout; the block transposes once on the way in and once on the way out (two passes of E
+// floats against ~100 E of work) and runs entirely in [B][H][W][C]:
+//   1x1 projections (+GELU / gate / residual epilogues)      cl_pointwise_kernel
+//   offset nets C -> 50 (5x5) and C -> 98 (7x7 dil 3)        cl_igemm_kernel (3-D kernel with D = kd = 1), planar offsets as torchvision wants them;
+//                                                            split-bf16 MFMA as in the 3-D block (forward fp32-equivalent three-term)
+//   the two depthwise deformable convs                       cl_ddw2d.hip
+// Supported: fp32, C / 32 in {1, 2, 3, 4, 6, 8, 12} (the net's 96 / 192 / 384 / 768 -> the first three; 768 never runs).
+// =========================================================================================================================
+namespace dlka {
+
+namespace {
+
+SameConv block_conv2d(int B, int C, int Cout, int H, int W, int k, int pad, int dil)
+{
+    SameConv s;
+    s.act_bf16 = 0;
+    s.B = B; s.D = 1; s.H = H; s.W = W; s.N = H * W; s.M = B * s.N; s.Cin = C; s.Cout = Cout; s.group = 1;
+    s.kd = 1; s.kh = s.kw = k; s.pd = 0; s.ph = s.pw = pad; s.dd = 1; s.dh = s.dw = dil; s.K = k * k;
+    return s;
+}
+
+struct Lka2dCl {
+    SameConv pw, off5, off7;
+    size_t E, O5, O7;
+    int B, C, H, W;
+    Lka2dCl(int B_, int C_, int H_, int W_) : B(B_), C(C_), H(H_), W(W_)
+    {
+        pw = block_conv2d(B, C, C, H, W, 1, 0, 1);
+        off5 = block_conv2d(B, C, 50, H, W, 5, 2, 1);
+        off7 = block_conv2d(B, C, 98, H, W, 7, 9, 3);
+        E = (size_t)B * C * H * W; O5 = (size_t)B * 50 * H * W; O7 = (size_t)B * 98 * H * W;
+    }
+    size_t pw_floats() const { return (size_t)C * C; }
+    size_t off5_floats() const { return dense_wp_floats(off5); }
+    size_t off7_floats() const { return dense_wp_floats(off7); }
+    size_t prep_floats() const { return 6 * (pw_floats() + 64) + 2 * (off5_floats() + 64) + 2 * (off7_floats() + 64) + (size_t)(25 + 49) * C + 256; }
+    size_t part_pw() const { return (cl_wgrad_part_floats_mode(pw.M, 1, C, C, 0) + 63) & ~(size_t)63; }
+    size_t part_o5() const { return (cl_wgrad_part_floats_mode(pw.M, 25, 50, C, 0) + 63) & ~(size_t)63; }
+    size_t part_o7() const { return (cl_wgrad_part_floats_mode(pw.M, 49, 98, C, 0) + 63) & ~(size_t)63; }
+    size_t part_dw() const { return (cl_ddw2d_part_floats(pw.M, 49, C) + 63) & ~(size_t)63; }
+    size_t part_floats() const { return 3 * part_pw() + part_o5() + part_o7() + part_dw(); }
+};
+
+struct Prep2d { float *pw_f[3], *pw_b[3], *o5_f, *o5_b, *o7_f, *o7_b, *dw5, *dw7; };
+
+int carve_prep2d(const Lka2dCl &G, float *base, Prep2d &t, const dlka_lka2d_params *p, hipStream_t st, bool fill)
+{
+    float *q = base;
+    auto take = [&](size_t n) { float *r = q; q += (n + 63) & ~(size_t)63; return r; };
+    for (int k = 0; k < 3; ++k) { t.pw_f[k] = take(G.pw_floats()); t.pw_b[k] = take(G.pw_floats()); }
+    t.o5_f = take(G.off5_floats()); t.o5_b = take(G.off5_floats());
+    t.o7_f = take(G.off7_floats()); t.o7_b = take(G.off7_floats());
+    t.dw5 = take((size_t)25 * G.C); t.dw7 = take((size_t)49 * G.C);
+    if (!fill) return DLKA_OK;
+    PrepBatch pb;
+    memset(&pb, 0, sizeof(pb));
+    const int C = G.C;
+    const void *pw_w[3] = {p->proj_1_w, p->conv1_w, p->proj_2_w};
+    for (int k = 0; k < 3; ++k) {
+        add_job(pb, pw_w[k], t.pw_f[k], C, C, 1, C, C, 0);
+        add_job(pb, pw_w[k], t.pw_b[k], C, C, 1, C, C, 1);
+    }
+    add_job(pb, p->conv0_offset_w, t.o5_f, 50, C, 25, C, 64, split_mode_flag(use_split(G.off5, true)));
+    add_job(pb, p->conv0_offset_w, t.o5_b, 50, C, 25, 64, C, use_split(G.off5, false) ? 9 : 1);
+    add_job(pb, p->conv_spatial_offset_w, t.o7_f, 98, C, 49, C, 128, split_mode_flag(use_split(G.off7, true)));
+    add_job(pb, p->conv_spatial_offset_w, t.o7_b, 98, C, 49, 128, C, use_split(G.off7, false) ? 9 : 1);
+    add_job(pb, p->conv0_w, t.dw5, C, C, 25, 0, 0, 3);
+    add_job(pb, p->conv_spatial_w, t.dw7, C, C, 49, 0, 0, 3);
+    return launch_cl_prep_batch(pb, st);
+}
+
+void fill_ddw(DwArgs2d &d, const Lka2dCl &G, int k, int pad, int dil)
+{
+    memset(&d, 0, sizeof(d));
+    d.B = G.B; d.H = G.H; d.W = G.W; d.C = G.C; d.kh = d.kw = k; d.ph = d.pw = pad; d.dh = d.dw = dil;
+}
+
+}  // namespace
+
+int lka2d_cl_supported(int B, int C, int H, int W, int dtype)
+{
+    if (dtype != DLKA_F32 || B <= 0 || H <= 0 || W <= 0 || !cl_ddw2d_supported(C)) return 0;
+    if (!(nt_ok(C) || C == 192 || C == 384)) return 0;   // the offset nets' data gradient has C columns: the igemm launcher's tile menu
+    if ((long)B * H * W * C >= (1l << 29)) return 0;
+    return dense_fwd_supported(block_conv2d(B, C, 50, H, W, 5, 2, 1)) ? 1 : 0;
+}
+
+size_t lka2d_cl_saved_bytes(int B, int C, int H, int W)
+{
+    Lka2dCl G(B, C, H, W);
+    return 8 * align256(G.E * 4) + align256(G.O5 * 4) + align256(G.O7 * 4) + align256(G.prep_floats() * 4);
+}
+
+size_t lka2d_cl_workspace_bytes(int B, int C, int H, int W)
+{
+    Lka2dCl G(B, C, H, W);
+    return 9 * align256(G.E * 4) + align256(G.O7 * 4) + align256(G.part_floats() * 4) + align256(4096);
+}
+
+int lka2d_cl_forward(const void *x_, const dlka_lka2d_params *p, void *y_, void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes, int B,
+                     int C, int H, int W, hipStream_t st)
+{
+    Lka2dCl G(B, C, H, W);
+    Carver sv(saved, saved_bytes), cv(workspace, workspace_bytes);
+    float *xt = (float *)sv.take(G.E * 4), *h = (float *)sv.take(G.E * 4), *a = (float *)sv.take(G.E * 4), *t1 = (float *)sv.take(G.E * 4);
+    float *t2 = (float *)sv.take(G.E * 4), *g1 = (float *)sv.take(G.E * 4), *m = (float *)sv.take(G.E * 4), *spare = (float *)sv.take(G.E * 4);
+    float *o5 = (float *)sv.take(G.O5 * 4), *o7 = (float *)sv.take(G.O7 * 4);
+    float *prep = (float *)sv.take(G.prep_floats() * 4);
+    float *yt = (float *)cv.take(G.E * 4);
+    (void)spare;
+    if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
+    const float *N0 = nullptr;
+    Prep2d PW;
+    DLKA_TRY(carve_prep2d(G, prep, PW, p, st, true));
+    DLKA_TRY(launch_cl_transpose((const float *)x_, xt, B, C, G.pw.N, 1, st));                                               // NCHW -> NHWC
+    DLKA_TRY(dense_forward(G.pw, xt, N0, (const float *)p->proj_1_b, h, 0, PW.pw_f[0], 1, nullptr, a, st));                    // :135-136 (+GELU)
+    DLKA_TRY(dense_forward(G.off5, a, N0, (const float *)p->conv0_offset_b, o5, 1, PW.o5_f, 0, nullptr, nullptr, st));         // :28 offset_net
+    DwArgs2d d;
+    fill_ddw(d, G, 5, 2, 1);
+    d.in = a; d.off = o5; d.wp = PW.dw5; d.out = t1;
+    DLKA_TRY(launch_cl_ddw2d_fwd(d, st));                                                                                     // :29
+    DLKA_TRY(dense_forward(G.off7, t1, N0, (const float *)p->conv_spatial_offset_b, o7, 1, PW.o7_f, 0, nullptr, nullptr, st));
+    fill_ddw(d, G, 7, 9, 3);
+    d.in = t1; d.off = o7; d.wp = PW.dw7; d.out = t2;
+    DLKA_TRY(launch_cl_ddw2d_fwd(d, st));
+    DLKA_TRY(dense_forward(G.pw, t2, N0, (const float *)p->conv1_b, g1, 0, PW.pw_f[1], 2, a, m, st));                          // :102-104 conv1 + gate
+    DLKA_TRY(dense_forward(G.pw, m, N0, (const float *)p->proj_2_b, yt, 0, PW.pw_f[2], 3, xt, nullptr, st));                   // :138-139 proj_2 + shortcut
+    return launch_cl_transpose(yt, (float *)y_, B, C, G.pw.N, 0, st);
+}
+
+int lka2d_cl_backward(const void *x_, const dlka_lka2d_params *p, const void *gy_, const void *saved, size_t saved_bytes, void *gx_, const dlka_lka2d_grads *gr,
+                      void *workspace, size_t workspace_bytes, int B, int C, int H, int W, hipStream_t st)
+{
+    (void)x_;
+    Lka2dCl G(B, C, H, W);
+    Carver sv((void *)saved, saved_bytes), cv(workspace, workspace_bytes);
+    const float *xt = (float *)sv.take(G.E * 4), *h = (float *)sv.take(G.E * 4), *a = (float *)sv.take(G.E * 4), *t1 = (float *)sv.take(G.E * 4);
+    const float *t2 = (float *)sv.take(G.E * 4), *g1 = (float *)sv.take(G.E * 4), *m = (float *)sv.take(G.E * 4);
+    (void)sv.take(G.E * 4);
+    const float *o5 = (float *)sv.take(G.O5 * 4), *o7 = (float *)sv.take(G.O7 * 4);
+    float *prep = (float *)sv.take(G.prep_floats() * 4);
+    float *gyt = (float *)cv.take(G.E * 4), *gg1 = (float *)cv.take(G.E * 4), *ga1 = (float *)cv.take(G.E * 4), *gt2 = (float *)cv.take(G.E * 4);
+    float *gta = (float *)cv.take(G.E * 4), *gt1 = (float *)cv.take(G.E * 4), *gaa = (float *)cv.take(G.E * 4), *gab = (float *)cv.take(G.E * 4);
+    float *gh = (float *)cv.take(G.E * 4);
+    float *goff = (float *)cv.take(G.O7 * 4);
+    float *part = (float *)cv.take(G.part_floats() * 4);
+    if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
+    const float *N0 = nullptr;
+    Prep2d PW;
+    DLKA_TRY(carve_prep2d(G, prep, PW, p, st, false));
+    float *part_p2 = part, *part_c1 = part_p2 + G.part_pw(), *part_p1 = part_c1 + G.part_pw(), *part_o5 = part_p1 + G.part_pw();
+    float *part_o7 = part_o5 + G.part_o5(), *part_dw = part_o7 + G.part_o7();
+    FinalizeBatch fb;
+    memset(&fb, 0, sizeof(fb));
+    ZeroBatch zb;
+    memset(&zb, 0, sizeof(zb));
+    zb.add(gta, G.E);   // grad_input targets of the two depthwise deformable convs (fp32 atomics)
+    zb.add(gaa, G.E);
+    DLKA_TRY(launch_zero_batch(zb, st));
+    float *gxt = gt2;   // (gt2 is dead by the time the last projection's data gradient is written)
+    DLKA_TRY(launch_cl_transpose((const float *)gy_, gyt, B, C, G.pw.N, 1, st));
+    // proj_2 data gradient with the gate's backward in the epilogue: gg1 = gm * a, ga1 = gm * g1
+    DLKA_TRY(dense_backward_data(G.pw, gyt, 0, N0, gg1, PW.pw_b[2], 4, a, st, g1, ga1));
+    DLKA_TRY(dense_backward_data(G.pw, gg1, 0, N0, gt2, PW.pw_b[1], 0, nullptr, st));                                           // conv1
+    // conv_spatial = DeformConv(7x7 dil 3): t2 = DDW7(t1, o7 = offnet7(t1))
+    DwArgs2d d;
+    fill_ddw(d, G, 7, 9, 3);
+    d.in = t1; d.off = o7; d.wp = PW.dw7; d.g = gt2; d.gx = gta; d.goff = goff; d.part = part_dw;
+    DLKA_TRY(launch_cl_ddw2d_bwd(d, (float *)gr->conv_spatial_w, st));
+    DLKA_TRY(dense_backward_weight(G.off7, t1, goff, 1, (float *)gr->conv_spatial_offset_w, (float *)gr->conv_spatial_offset_b, part_o7, st, &fb.j[fb.njobs++]));
+    DLKA_TRY(dense_backward_data(G.off7, goff, 1, N0, gt1, PW.o7_b, 3, gta, st));                                               // gt1 = gta + offnet7^T goff
+    // conv0 = DeformConv(5x5): t1 = DDW5(a, o5 = offnet5(a))
+    fill_ddw(d, G, 5, 2, 1);
+    d.in = a; d.off = o5; d.wp = PW.dw5; d.g = gt1; d.gx = gaa; d.goff = goff; d.part = part_dw;
+    DLKA_TRY(launch_cl_ddw2d_bwd(d, (float *)gr->conv0_w, st));
+    DLKA_TRY(dense_backward_weight(G.off5, a, goff, 1, (float *)gr->conv0_offset_w, (float *)gr->conv0_offset_b, part_o5, st, &fb.j[fb.njobs++]));
+    DLKA_TRY(dense_backward_data(G.off5, goff, 1, N0, gab, PW.o5_b, 3, gaa, st));                                               // gab = gaa + offnet5^T goff
+    // a = GELU(h) feeds the gate and conv0: gh = (ga1 + gab) * gelu'(h)
+    DLKA_TRY(launch_gelu_bwd_sum<float>(h, ga1, gab, gh, (long)G.E, st));
+    {
+        WgradArgs jobs[3];
+        fill_pw_wgrad(jobs[0], G.pw, m, gyt, part_p2);
+        fill_pw_wgrad(jobs[1], G.pw, t2, gg1, part_c1);
+        fill_pw_wgrad(jobs[2], G.pw, xt, gh, part_p1);
+        float *const gws[3] = {(float *)gr->proj_2_w, (float *)gr->conv1_w, (float *)gr->proj_1_w};
+        float *const gbs[3] = {(float *)gr->proj_2_b, (float *)gr->conv1_b, (float *)gr->proj_1_b};
+        DLKA_TRY(launch_cl_wgrad_pw3(jobs, gws, gbs, st, &fb.j[fb.njobs]));
+        fb.njobs += 3;
+    }
+    DLKA_TRY(launch_cl_wgrad_finalize(fb, st));
+    DLKA_TRY(dense_backward_data(G.pw, gh, 0, N0, gxt, PW.pw_b[0], 3, gyt, st));                                                // gx = P1^T gh + gy
+    return launch_cl_transpose(gxt, (float *)gx_, B, C, G.pw.N, 0, st);
+}
+
+}  // namespace dlka
 
 extern "C" {
 

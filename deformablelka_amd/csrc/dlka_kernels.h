@@ -71,6 +71,20 @@ size_t cl_deform_bwd2_scratch_floats(const DeformBwdArgs &a);
 int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st);
 int cl_deform_goff_ccsplit(const DeformBwdArgs &a);
 
+// ---- cl_ddw2d.hip: channels-last 2-D depthwise deformable conv (the 2-D D-LKA block's large-kernel convs) ------------------------------
+int cl_ddw2d_supported(int C);
+size_t cl_ddw2d_part_floats(int M, int K, int C);
+int launch_cl_ddw2d_fwd(const DwArgs2d &d, hipStream_t st);
+int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st);
+// the 2-D D-LKA block on the channels-last kernels (dlka_capi_cl.hip); NCHW in / out, transposed inside
+int lka2d_cl_supported(int B, int C, int H, int W, int dtype);
+size_t lka2d_cl_saved_bytes(int B, int C, int H, int W);
+size_t lka2d_cl_workspace_bytes(int B, int C, int H, int W);
+int lka2d_cl_forward(const void *x, const dlka_lka2d_params *p, void *y, void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes, int B,
+                     int C, int H, int W, hipStream_t st);
+int lka2d_cl_backward(const void *x, const dlka_lka2d_params *p, const void *gy, const void *saved, size_t saved_bytes, void *gx, const dlka_lka2d_grads *gr,
+                      void *workspace, size_t workspace_bytes, int B, int C, int H, int W, hipStream_t st);
+
 // ---- cl_norm.hip: the non-convolutional pieces of TransformerBlock_3D_single_deform_LKA ---------------------------------
 int launch_cl_layernorm_fwd(const float *x, int x_planar, const float *pos, const float *w, const float *b, float *xt, float *xn, float *stats, int B, int N,
                             int C, float eps, hipStream_t st);

@@ -47,7 +47,17 @@ def get_output_padding(kernel_size, stride, padding):
 
 
 class Convolution(nn.Sequential):
-    """``monai.networks.blocks.Convolution(..., conv_only=True)``: a Sequential with ONE child named ``conv``."""
+    """``monai.networks.blocks.Convolution(..., conv_only=True)``: a Sequential with ONE child named ``conv`` (the parameters live there, so
+    the ``state_dict`` keys are the reference's).
+
+    On the GPU in fp32 the forward does not call MIOpen: measured on the MI355X (scripts/probe_miopen_conv3d.py, profiles/r03f) its fp32 3-D
+    paths cost 320 ms for ONE 3x3x3 16 -> 16 conv fwd+bwd at 2 x 64x128x128 (weight gradient) and 10 ms for the (2,4,4) transposed conv — a
+    1.03 s training step of which the 21 D-LKA blocks are 24 ms.  The four shapes the net uses are instead computed as
+      * kernel == stride, no padding (stem, down-sampling):       patchify + one GEMM,
+      * transposed, kernel == stride (up-sampling):               one GEMM + depth-to-space,
+      * 1x1x1 (output heads):                                     one GEMM over the channel axis,
+      * 3x3x3 stride 1 (encoder1 / decoder2 conv blocks):         this repo's general HIP conv kernels (``nn_ops.conv3d``),
+    all exact re-expressions of the same convolution (fp32; the GEMMs are rocBLAS through ``torch.matmul``, autograd included)."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride, bias=False, is_transposed=False):
         super().__init__()
@@ -57,6 +67,37 @@ class Convolution(nn.Sequential):
         else:
             conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride, pad, bias=bias)
         self.add_module("conv", conv)
+        self.gemm_path = True   # set False to force the stock torch / MIOpen layer
+
+    def forward(self, x):
+        c = self.conv
+        if not (self.gemm_path and x.is_cuda and x.dtype == torch.float32 and c.weight.dtype == torch.float32 and not torch.is_autocast_enabled()):
+            return c(x)
+        k, s, p = tuple(c.kernel_size), tuple(c.stride), tuple(c.padding)
+        B, Cin = x.shape[:2]
+        if isinstance(c, nn.ConvTranspose3d):
+            if k == s and p == (0, 0, 0) and tuple(c.output_padding) == (0, 0, 0) and c.groups == 1:
+                D, H, W = x.shape[2:]
+                Cout = c.weight.shape[1]
+                y = torch.matmul(x.permute(0, 2, 3, 4, 1).reshape(-1, Cin), c.weight.reshape(Cin, -1))            # (B D H W, Cout kd kh kw)
+                y = y.reshape(B, D, H, W, Cout, *k).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(B, Cout, D * k[0], H * k[1], W * k[2])
+                return y if c.bias is None else y + c.bias.view(1, -1, 1, 1, 1)
+            return c(x)
+        if c.groups != 1 or tuple(c.dilation) != (1, 1, 1):
+            return c(x)
+        Cout = c.weight.shape[0]
+        if k == (1, 1, 1) and s == (1, 1, 1) and p == (0, 0, 0):
+            y = torch.matmul(c.weight.reshape(Cout, Cin), x.reshape(B, Cin, -1)).reshape(B, Cout, *x.shape[2:])
+            return y if c.bias is None else y + c.bias.view(1, -1, 1, 1, 1)
+        if k == s and p == (0, 0, 0) and all(n % kk == 0 for n, kk in zip(x.shape[2:], k)):
+            D, H, W = (n // kk for n, kk in zip(x.shape[2:], k))
+            cols = x.reshape(B, Cin, D, k[0], H, k[1], W, k[2]).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * D * H * W, -1)   # patches
+            y = torch.matmul(cols, c.weight.reshape(Cout, -1).t()).reshape(B, D, H, W, Cout).permute(0, 4, 1, 2, 3).contiguous()
+            return y if c.bias is None else y + c.bias.view(1, -1, 1, 1, 1)
+        if s == (1, 1, 1):
+            from . import nn_ops
+            return nn_ops.conv3d(x.contiguous(), c.weight, c.bias, s, p, (1, 1, 1), 1)
+        return c(x)
 
 
 def get_conv_layer(spatial_dims, in_channels, out_channels, kernel_size=3, stride=1, dropout=None, bias=False, conv_only=True,

@@ -128,9 +128,11 @@ class _TBlock3dFn(Function):
         tparams = [next(it) if here else None for here in present]
         lka_params = list(it)
         gx, tg, lg = ops.tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, gy, saved, dims)
-        if x_planar:   # gradient w.r.t. the NCDHW input = the permuted view of the token gradient
+        if x_planar:   # gradient w.r.t. the NCDHW input: tokens -> NCDHW.  A contiguous tensor, not the permuted view: the producer of x is a
+            # torch layer whose backward (MIOpen) falls to its naive "nonpacked" kernels on a strided grad_output (profiles/r03e: 61 % of a
+            # full-net step)
             B, C = xshape[0], xshape[1]
-            gx = gx.view(B, *xshape[2:], C).permute(0, 4, 1, 2, 3)
+            gx = ops.ndhwc_to_ncdhw(gx.view(B, *xshape[2:], C))
         else:
             gx = gx.view(xshape)
         return (gx, None, None, None, None, None, None, *tg, *lg)

@@ -270,6 +270,39 @@ def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=2e-4, rtol
             assert_close("tokens grad " + k, p.grad, g, rtol=4 * rtol if "conv_offset" in k else rtol)
 
 
+def check_lka2d_attention(dev, B, C, H, W, seed=0, offset_std=0.03, atol=2e-4, rtol=2e-3, report=False):
+    """deformable_LKA_Attention (2D/deformable_LKA/deformable_LKA.py:124-140) vs the oracle block; widths with C % 32 == 0 take the
+    channels-last fast path (MFMA offset nets + cl_ddw2d.hip), the rest the general NCHW kernels."""
+    import deformablelka_amd as dk
+    from oracle import blocks
+    torch.manual_seed(seed)
+    m = dk.deformable_LKA_Attention(C)
+    blocks.randomize_offsets_(m, std=offset_std)
+    x = torch.randn(B, C, H, W)
+    gy = torch.randn(B, C, H, W)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    yr = blocks.lka2d_attention(xr, P)
+    yr.backward(gy)
+    m = m.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    y = m(xd)
+    y.backward(gy.to(dev))
+    errs = {"y_abs": (y.detach().cpu() - yr.detach()).abs().max().item(), "gx": rel_err(xd.grad, xr.grad)}
+    for k, p in m.named_parameters():
+        if P[k].grad is not None and P[k].grad.abs().max() > 0:
+            errs[k] = rel_err(p.grad, P[k].grad)
+    if report or os.environ.get("DLKA_PARITY_VERBOSE"):
+        print(f"[lka2d C={C} {H}x{W} B={B}] " + " ".join(f"{'.'.join(k.split('.')[-2:])}={v:.1e}" for k, v in errs.items()))
+    assert errs["y_abs"] <= atol, errs
+    for k, v in errs.items():
+        if k == "y_abs":
+            continue
+        # offset_net.{weight,bias}.grad sum grad_offset, which is discontinuous at integer sampling coordinates (see check_lka3d_tokens)
+        assert v <= (4 * rtol if "offset_net" in k else rtol), f"lka2d {k}: rel err {v:.3e}"
+    return errs
+
+
 BF16_RTOL = 2e-2   # SURVEY §8c: bf16 path vs the fp32 oracle <= 2e-2 rel (of max |reference|)
 
 

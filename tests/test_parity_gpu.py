@@ -231,6 +231,43 @@ def test_lka3d_tokens_bf16_autocast_policy():
     parity.check_lka3d_tokens_bf16(DEV, 2, 64, (8, 8, 8), via_autocast=True, report=True)
 
 
+@pytest.mark.parametrize("C,hw", [(96, 56), (192, 28), (384, 14)])
+def test_lka2d_attention_real_shapes_vs_oracle(C, hw):
+    """The three decoder shapes of the 224^2 2-D net (B = 2 here, 24 in training): the channels-last 2-D block — MFMA offset nets,
+    gather-layout depthwise deformable convs (cl_ddw2d.hip) — forward and every gradient against the oracle block."""
+    parity.check_lka2d_attention(DEV, 2, C, hw, hw, report=True)
+
+
+def test_lka2d_attention_fast_path_equals_general_path():
+    """Same inputs through the channels-last fast path and (DLKA_LKA2D_GENERAL=1) the general NCHW kernels."""
+    import os
+    import deformablelka_amd as dk
+    from oracle import blocks
+    torch.manual_seed(0)
+    m = dk.deformable_LKA_Attention(96).to(DEV)
+    blocks.randomize_offsets_(m, std=0.03)
+    x = torch.randn(3, 96, 20, 17, device=DEV)
+    gy = torch.randn_like(x)
+
+    def run():
+        xs = x.clone().requires_grad_(True)
+        for p in m.parameters():
+            p.grad = None
+        y = m(xs)
+        y.backward(gy)
+        return [y.detach(), xs.grad] + [p.grad.clone() for p in m.parameters()]
+    fast = run()
+    os.environ["DLKA_LKA2D_GENERAL"] = "1"
+    try:
+        gen = run()
+    finally:
+        os.environ.pop("DLKA_LKA2D_GENERAL", None)
+    assert not torch.equal(fast[0], gen[0])
+    parity.assert_close("y", fast[0], gen[0], atol=2e-4)
+    for i, (a, b) in enumerate(zip(fast[1:], gen[1:])):
+        parity.assert_close(f"grad {i}", a, b, rtol=8e-3)
+
+
 def test_deform3d_cl_headline_shape_vs_oracle():
     """The deformable conv of the headline shape (C=32, 32^3, B=2, offsets N(0,1)): forward + all four gradients vs the oracle."""
     parity.check_deform3d_cl(DEV, 2, 32, 32, (32, 32, 32), off_mode="normal")
