@@ -355,7 +355,7 @@ def tblock_metric(batch, steps, warmup, dev):
 
 def fullnet_metric(batch, steps, dev, bf16=False):
     """Third metric (SURVEY §8d iii / §8f-2): the WHOLE D_LKA_Former (42.35 M parameters; its 21 D-LKA transformer blocks on this repo's kernels,
-    the conv / norm plumbing around them on stock torch layers), one trainer iteration per step — forward, deep-supervision loss, backward,
+    the conv / norm plumbing around them as GEMM re-expressions, HIP 3^3 convs and torch norms), one trainer iteration per step — forward, deep-supervision loss, backward,
     clip_grad_norm_(12), SGD(momentum 0.99, nesterov) — on a synthetic 64x128x128 patch batch (d_lka_former_trainer_synapse.py:259-309)."""
     from deformablelka_amd import training
     from deformablelka_amd.stack import _offset_std_for
@@ -381,7 +381,7 @@ def fullnet_metric(batch, steps, dev, bf16=False):
         raise RuntimeError("full-net loss is not finite")
     return {"metric": "3D D-LKA Former full-net training iteration volumes/sec (64x128x128)", "value": round(batch / dt, 3), "unit": "volumes/s",
             "ms_per_step": round(dt * 1e3, 2), "params": sum(p.numel() for p in net.parameters()), "loss": round(float(loss), 4),
-            "path": "nn.Module + autograd, eager; D-LKA blocks = HIP kernels, plumbing = torch/MIOpen" + ("; bf16 autocast policy" if bf16 else "")}
+            "path": "nn.Module + autograd, eager; D-LKA blocks = HIP kernels; plumbing convs = GEMM re-expressions (rocBLAS) / HIP 3^3 convs, norms = torch" + ("; bf16 autocast policy" if bf16 else "")}
 
 
 def lka2d_metric(steps, dev):

@@ -8,10 +8,11 @@ What runs where:
   * the 21 ``TransformerBlock_3D_single_deform_LKA`` (encoder stages 0-3, decoders 5/4/3) — this repo's HIP kernels, chained in the
     channels-last layout (``keep_channels_last``) so that no block boundary costs a layout copy;
   * the plumbing around them — stem / down-sampling convs + GroupNorm, transposed convs, ``encoder1`` / ``decoder2`` conv blocks with
-    InstanceNorm, the 1x1x1 output heads — stock ``torch.nn`` layers (MIOpen on the MI355X).  They are local stand-ins for the MONAI
-    0.8.1 factories the reference builds them from (``get_conv_layer`` -> ``Convolution(conv_only=True)`` = a Sequential whose child
-    ``conv`` is the torch conv; ``get_norm_layer`` -> GroupNorm / InstanceNorm3d / BatchNorm3d; dynunet_block.py:226-270), not part
-    of the hot path ("MaxViT encoder / nnU-Net plumbing stay stock PyTorch").
+    InstanceNorm, the 1x1x1 output heads — ``torch.nn`` parameter containers (local stand-ins for the MONAI 0.8.1 factories the
+    reference builds them from: ``get_conv_layer`` -> ``Convolution(conv_only=True)`` = a Sequential whose child ``conv`` is the torch
+    conv; ``get_norm_layer`` -> GroupNorm / InstanceNorm3d / BatchNorm3d; dynunet_block.py:226-270).  Norms run as stock torch ops; the
+    convs are computed as GEMMs / by this repo's HIP conv kernels on the GPU in fp32, because MIOpen's fp32 3-D paths are pathologically
+    slow on this stack (see ``Convolution``).  None of this is hot-path code; it exists so that the full net trains.
 The reference hard-codes the token counts of the Synapse patch (model_components.py:14, d_lka_former_synapse.py:97-132); here they
 follow from ``img_size`` and ``patch_size`` (defaults = the reference's), which also covers the pancreas variant (96^3, stem (2,2,2)).
 """
