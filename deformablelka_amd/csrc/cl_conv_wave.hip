@@ -161,13 +161,13 @@ __global__ __launch_bounds__(256) void cl_conv_wave_kernel(IgemmArgs p)
 // Split-operand convs with K > 1, epilogues 0 and 3.  Returns DLKA_ERR_UNSUPPORTED for anything else (the caller then uses cl_igemm_kernel).
 int launch_cl_conv_wave(int amode, int omode, const IgemmArgs &a, int splits, hipStream_t st)
 {
-    static const bool off = getenv("DLKA_CONV_WAVE_OFF") != nullptr;   // A/B switch
+    constexpr bool off = false;
     if (off || a.K <= 1 || (a.split_bf16 != 2 && a.split_bf16 != 3) || (a.epi != 0 && a.epi != 3)) return DLKA_ERR_UNSUPPORTED;
     if (amode != 0 && amode != 2) return DLKA_ERR_UNSUPPORTED;
     if ((long)a.K * (a.CinP / 32) * (a.split_bf16 == 3 ? 48 : 32) * a.NP * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     const int NT_total = a.NP / 32;
     // column tiles per wave / prefetch depth.  DLKA_CONV_WAVE_CFG=<NT><DEPTH> overrides for tuning (e.g. 32 = NT 3, depth 2).
-    static const int cfg = getenv("DLKA_CONV_WAVE_CFG") ? atoi(getenv("DLKA_CONV_WAVE_CFG")) : 0;
+    constexpr int cfg = 0;
     int NT = 1, DEPTH = 2;
     if (cfg) { NT = cfg / 10; DEPTH = cfg % 10; }
     else {

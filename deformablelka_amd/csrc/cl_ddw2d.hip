@@ -1,7 +1,7 @@
 // Channels-last 2-D DEPTHWISE deformable convolution — the two large-kernel convs of the 2-D D-LKA block
 // (2D/deformable_LKA/deformable_LKA.py:93-94: 5x5 pad 2 and 7x7 dilation 3 pad 9, groups = C, ONE offset field shared by all
 // channels, bias-free), torchvision 0.12 `deform_conv2d` semantics (offset channels (dy, dx) per tap, guard
-// q <= -1 || q >= size -> 0, per-corner zeroing; un-vendored, restated in oracle/dlka_oracle_impl.h).
+// q <= -1 || q >= size -> 0, per-corner zeroing; torchvision is un-vendored: the rule is restated from its published kernel, include/dlka.h).
 //
 //     out[m][c] = sum_tap w[c][tap] * S(m, tap, c),   S = bilinear sample of in[b][:, :, c] at  base(m, tap) + offset[b][2 tap .. +1][m]
 //

@@ -729,7 +729,7 @@ static GxGeom pick_gx_geom(const DeformBwdArgs &a)
     // Bricks are long along W: the 32 voxels of a wave tile are then consecutive in w, and with spatially smooth offsets
     // their corner cells are consecutive fp64 cells of the window — distinct LDS banks (a cubic 8x8x8 brick puts 4 short
     // w-rows in a tile, whose cells collide).  DLKA_GX_BRICK=cube restores the cubic shape for A/B runs.
-    static const bool cube = getenv("DLKA_GX_BRICK") != nullptr;
+    constexpr bool cube = false;
     if (cube) {
         g.bd = a.D < 8 ? a.D : 8; g.bh = a.H < 8 ? a.H : 8; g.bw = a.W < 8 ? a.W : 8;
     } else {
@@ -787,7 +787,7 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const int tpb = cdiv(a.K, tsplit);
         tsplit = cdiv(a.K, tpb);
         const int nkc = a.CoutP / 32;
-        static const bool v1 = getenv("DLKA_GOFF_V1") != nullptr;   // A/B switch: first "lane = voxel" gather
+        constexpr bool v1 = false;   // (first "lane = voxel" gather, cl_deform_goff_kernel: superseded, 225-250 us against 150)
         const int ccsplit = v1 ? 1 : cl_deform_goff_ccsplit(a);
         DeformBwdArgs ag = a;
         ag.cc_per_block = cdiv(a.C / 32, ccsplit);
@@ -822,7 +822,7 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         // resident in LDS (252 vs 362 us at C=32 / 32^3; at C >= 128 the scale pre-pass costs more than the atomics it saves).
         // DLKA_GX_FIXED=0 forces the fp64 window, =1 the fixed-point one wherever it is possible (A/B runs; not cached: tests toggle it).
         const char *fx_env = getenv("DLKA_GX_FIXED");
-        const bool abl_on = getenv("DLKA_GX_ABL") && atoi(getenv("DLKA_GX_ABL"));
+        constexpr bool abl_on = false;
         const long rk = (long)g.bd * g.bh * g.bw * a.K;
         const double fx_lim = 2147483648.0 / (double)rk - 1.0;   // rk * (fx_lim + 1/2) = 2^31 - rk/2 < 2^31
         const int fx_bits = fx_lim > 1.0 ? (int)floor(log2(fx_lim)) : 0;
@@ -835,9 +835,9 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const size_t lds_win = 16 + (size_t)(g.wvox_max + 64) * (fixed ? CS / 2 : CS) * sizeof(double);
         const size_t lds_all = lds_win + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
         gl_.resident = (lds_all <= 150 * 1024 && a.CoutP <= 128) ? 1 : 0;
-        static const int abl = getenv("DLKA_GX_ABL") ? atoi(getenv("DLKA_GX_ABL")) : 0;
+        constexpr int abl = 0;
         gl_.ablate = abl;
-        static const bool far_taps = getenv("DLKA_GX_TAP_FAR") != nullptr;   // A/B switch (measured: 390 vs 370 us at 32^3 — slower, stays off)
+        constexpr bool far_taps = false;   // (measured: 390 vs 370 us at 32^3 — slower)
         gl_.tap_far = (far_taps && g.ngroups == 4) ? 1 : 0;
         const size_t lds = gl_.resident ? lds_all : lds_win + (size_t)a.CoutP * 32 * sizeof(float);
         if (lds > 160 * 1024) return DLKA_ERR_UNSUPPORTED;
@@ -860,13 +860,13 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const int items = bricks * g.nslices;
         // A/B switch.  The item order (slices of a brick adjacent) cuts the fabric traffic further, 279 -> 199 MB per launch at 32^3, but costs
         // 1 % of the whole step (15.6 vs 15.44 ms, two runs each): the eight slices of a brick then hit the same L2 channels at once.  Off.
-        const bool item_grid = getenv("DLKA_GX_ITEM_ORDER") ? atoi(getenv("DLKA_GX_ITEM_ORDER")) != 0 : false;
+        constexpr bool item_grid = false;
         gl_.item_grid = item_grid ? 1 : 0;
         const int nx = item_grid ? items : bricks;
         gl_.xcd_nx = (xcd_swizzle_enabled() && nx >= xcd_min_blocks()) ? nx : 0;
         const dim3 gx_grid(gl_.xcd_nx ? xcd_grid(nx) : nx, item_grid ? 1 : g.nslices);
         static int gx_threads = 0;
-        if (!gx_threads) { const char *e = getenv("DLKA_GX_THREADS"); gx_threads = e ? atoi(e) : 512; if (gx_threads != 256 && gx_threads != 512) gx_threads = 512; }
+        if (!gx_threads) gx_threads = 512;
         if (a.act_bf16) {
             if (fixed) { auto k = cl_deform_gx_kernel<true, bf16_t>; hipLaunchKernelGGL(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
             else { auto k = cl_deform_gx_kernel<false, bf16_t>; hipLaunchKernelGGL(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }

@@ -175,7 +175,7 @@ int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
     // (C=256 / 4^3: 57.8 -> 36.0 us with NT = 1; C=128 / 8^3: 47.6 -> 41.0 us with NT = 2; profiles/r01s_dfwd_tuning.txt)
     if (a.M <= 256) NT = 1;
     else if (a.M <= 2048 && NT_total == 4) NT = 2;
-    static const int nt_env = getenv("DLKA_DFWD_NT") ? atoi(getenv("DLKA_DFWD_NT")) : 0;   // tuning knob
+    constexpr int nt_env = 0;
     if (nt_env == 1 || nt_env == 2 || nt_env == 4) { if (NT_total % nt_env == 0 && nt_env <= NT_total) NT = nt_env; }
     dim3 grid(mblocks, splits, NT_total / NT), block(256);
     a.xcd_nx = 0;

@@ -258,15 +258,15 @@ static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st
     dim3 grid((unsigned)cdivl(runs, rpb), 1, cdiv(a.C, cpb)), block(256);
     if (256 % cpb != 0) return DLKA_ERR_UNSUPPORTED;
     if (!F32 && !((kw == 5 && dil_w == 1) || (kw == 7 && dil_w == 3))) return DLKA_ERR_UNSUPPORTED;
-    static const bool v1 = getenv("DLKA_DW_V1") != nullptr;   // A/B switch: first generation (conditional global loads)
-    static const int abl0 = getenv("DLKA_DW_ABL") ? atoi(getenv("DLKA_DW_ABL")) : 0;
+    constexpr bool v1 = false;
+    constexpr int abl0 = 0;
     // the rows kernel needs (b, d, h) uniform per wave: the 64 / cpb runs of a wave must not straddle two rows
     const int wpr = cpb < 64 ? 64 / cpb : 1;
     if (!v1 && !abl0 && cdiv(a.W, TW) % wpr == 0 && (long)a.W * a.C * 4 < (1l << 31)) {
         DwArgs ax = a;
         ax.xcd_nx = 0;
         auto swz = [&](dim3 &g) { if (xcd_swizzle_enabled() && g.x >= (unsigned)xcd_min_blocks()) { ax.xcd_nx = (int)g.x; g.x = xcd_grid(ax.xcd_nx); } };
-        static const int th_env = getenv("DLKA_DW_TH") ? atoi(getenv("DLKA_DW_TH")) : 0;   // tuning knob: 1 / 2 output rows per work-item
+        constexpr int th_env = 0;
         const bool cubic = a.kd == kw && a.kh == kw && a.dd == dil_w && a.dh == dil_w;
         const int th = th_env ? th_env : 2;
         if ((th == 2 || (th == 3 && F32)) && cubic && a.H >= th * dil_w && ((kw == 7 && dil_w == 3) || (kw == 5 && dil_w == 1))) {
@@ -297,7 +297,7 @@ static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st
     }
     if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_kernel<T, 5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
     else if (kw == 7 && dil_w == 3) {
-        static const int abl = getenv("DLKA_DW_ABL") ? atoi(getenv("DLKA_DW_ABL")) : 0;   // profiling ablation only
+        constexpr int abl = 0;
         if (F32 && abl == 1) { auto k = cl_dwconv_kernel<float, 7, 3, TW, 1>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
         else if (F32 && abl == 2) { auto k = cl_dwconv_kernel<float, 7, 3, TW, 2>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
         else { auto k = cl_dwconv_kernel<T, 7, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
@@ -514,7 +514,7 @@ static int launch_cl_dwconv_wgrad_t(DwWgradArgs a, int kw, int dil_w, hipStream_
     if (256 % cpb != 0) return DLKA_ERR_UNSUPPORTED;
     const int rows = a.B * a.D * a.H;
     static int xb_env = -1;
-    if (xb_env < 0) { const char *e = getenv("DLKA_DWW_XB"); xb_env = e ? atoi(e) : 0; if (xb_env < 0) xb_env = 0; }
+    if (xb_env < 0) xb_env = 0;
     // row-chunks: bounded atomics, enough waves to hide latency.  64 chunks, 128 for the large volumes (measured on the block graph:
     // 1.515 -> 1.462 ms at 32^3 with 128, no change at 16^3, 256 worse at 16^3; profiles/r01p)
     const int xb_want = xb_env ? xb_env : (rows >= 1024 ? 128 : 64);
@@ -525,7 +525,7 @@ static int launch_cl_dwconv_wgrad_t(DwWgradArgs a, int kw, int dil_w, hipStream_
         if (launch_zero(a.gwp, (size_t)a.kd * a.kh * kw * a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         if (a.gb && launch_zero(a.gb, (size_t)a.C * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
     }
-    static const bool v1 = getenv("DLKA_DWW_V1") != nullptr;   // A/B switch: first generation (grid.y = kd*kh, input re-read per tap row)
+    constexpr bool v1 = false;
     // the centre tap row must exist for the bias ride-along (odd kernels with "same" padding: always)
     const bool centre = (a.pd % a.dd == 0) && (a.ph % a.dh == 0) && a.pd / a.dd < a.kd && a.ph / a.dh < a.kh;
     // measured (profiles/r01o_dw_variants.txt): 7^3 dil 3 178 -> 103 us at 32^3, 38 -> 36 us at 16^3; 5^3 72 -> 66 us at 32^3 but 23.5 -> 26 us at 16^3

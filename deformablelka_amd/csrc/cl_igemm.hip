@@ -341,16 +341,16 @@ int cl_igemm_pick_splits(int M, int units, int epi, int K)
     // pointwise convs (K = 1) have C/32 <= 8 units: splitting 2 or 4 ways buys nothing that pays for the zero fill + atomics
     // (C = 64 / 16^3: 24.6 us split vs 11.8 us unsplit for the same GEMM, profiles/r01n); they run unsplit on cl_pointwise.hip
     static int pw_min = -1;
-    if (pw_min < 0) { const char *e = getenv("DLKA_PW_SPLIT_MIN_UNITS"); pw_min = e ? atoi(e) : 99; }
+    if (pw_min < 0) pw_min = 99;
     if (K == 1 && units < pw_min) return 1;
     const int mblocks = cdiv(M, 128);
     // Split partial sums meet in global fp32 atomics on the SAME addresses: measured on MI355X (profiles/r01e), 216-way
     // splits of the C=256 / 4^3 offset conv cost 130 us, almost all of it same-address serialisation in L2.  Bound the
     // contention instead of chasing block count.
     static int cap = -1;
-    if (cap < 0) { const char *e = getenv("DLKA_IGEMM_MAX_SPLITS"); cap = e ? atoi(e) : 32; if (cap < 1) cap = 1; }
+    if (cap < 0) cap = 32;
     static int want = -1;   // workgroups to aim for (tuning knob)
-    if (want < 0) { const char *e = getenv("DLKA_IGEMM_WANT_WGS"); want = e ? atoi(e) : 512; if (want < 1) want = 512; }
+    if (want < 0) want = 512;
     int splits = 1;
     while (mblocks * splits < want && splits < units && splits < cap) ++splits;
     const int ups = cdiv(units, splits);
@@ -362,7 +362,7 @@ int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t s
     if ((long)a.M * (amode == 2 ? a.CinReal : a.Cin) * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     a.units_per_split = cdiv(a.K * (a.CinP / 32), splits);
     splits = cdiv(a.K * (a.CinP / 32), a.units_per_split);
-    static const bool pw_v1 = getenv("DLKA_PW_V1") != nullptr;   // A/B switch: pointwise convs through this kernel
+    constexpr bool pw_v1 = false;
     if (!pw_v1 && amode == 0 && omode == 0 && a.K == 1 && splits == 1 && !a.split_bf16) {
         const int rc = launch_cl_pointwise(a, st);
         if (rc != DLKA_ERR_UNSUPPORTED) return rc;

@@ -600,13 +600,13 @@ static WgradPlan wgrad_plan(int M, int K, int Cout, int Cin, int amode)
     const int OT = round_up(Cout, 32) / 32, CT = Cin / 32;
     if (amode == 1) {
         static int tpw_d = -1;
-        if (tpw_d < 0) { const char *e = getenv("DLKA_WGRAD_DEFORM_TPW"); tpw_d = e ? atoi(e) : 3; if (tpw_d != 3 && tpw_d != 4 && tpw_d != 7 && tpw_d != 0) tpw_d = 3; }
+        if (tpw_d < 0) tpw_d = 3;   // measured best (4 and 7 taps per wave: more registers, fewer waves)
         pl.tpw = tpw_d == 0 ? 7 : tpw_d; pl.cot = 1;   // 0 selects the first-generation kernel (TPW 7)
     }
     else if (K == 1) { pl.tpw = 1; pl.cot = (OT % 2 == 0) ? 2 : 1; }
     else {
         static int tpw_env = -1;
-        if (tpw_env < 0) { const char *e = getenv("DLKA_WGRAD_TPW"); tpw_env = e ? atoi(e) : 3; if (tpw_env < 1 || tpw_env > 3) tpw_env = 3; }
+        if (tpw_env < 0) tpw_env = 3;
         pl.tpw = tpw_env; pl.cot = (OT % 3 == 0) ? 3 : ((OT % 2 == 0) ? 2 : 1);
     }
     const int groups = cdiv(OT, pl.cot) * CT * cdiv(K, pl.tpw);
@@ -616,7 +616,7 @@ static WgradPlan wgrad_plan(int M, int K, int Cout, int Cin, int amode)
     int chunks = slots / groups;
     if (K == 1) {   // pointwise: every partial is re-read by the fold; past a few hundred the fold costs more than the extra waves buy
         static int pw_cap = -1;
-        if (pw_cap < 0) { const char *e = getenv("DLKA_WGRAD_PW_CHUNKS"); pw_cap = e ? atoi(e) : 512; if (pw_cap < 1) pw_cap = 512; }
+        if (pw_cap < 0) pw_cap = 512;
         if (chunks > pw_cap) chunks = pw_cap;
     }
     if (chunks > tiles) chunks = tiles;
@@ -648,7 +648,7 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
     const int nchunks = cdiv(a.M, a.rows_per_chunk);
     a.CoutP = round_up(a.Cout, 32);
     a.CT = a.Cin / 32;
-    static const bool slow_addr = getenv("DLKA_WGRAD_SLOW_ADDR") != nullptr;   // A/B switch
+    constexpr bool slow_addr = false;
     a.w16 = (!slow_addr && (a.W & 15) == 0) ? 1 : 0;
     const int OT = a.CoutP / 32;
     if ((long)a.M * a.Cin * 4 >= (1l << 31) || (long)a.M * a.Cout * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
@@ -656,7 +656,7 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
     dim3 block(64);
     if (amode == 1) {
         if (gmode != 0 || a.K == 1) return DLKA_ERR_UNSUPPORTED;
-        static const bool v1 = getenv("DLKA_WGRAD_DEFORM_TPW") && atoi(getenv("DLKA_WGRAD_DEFORM_TPW")) == 0;
+        constexpr bool v1 = false;   // (first-generation kernel cl_wgrad_kernel<1, 0, 7>: kept for the general igemm fallback only)
         dim3 grid(nchunks, OT * a.CT, cdiv(a.K, pl.tpw));
         static const bool no_xcd = getenv("DLKA_NO_XCD_SWIZZLE") != nullptr;   // A/B switch
         if (!v1 && !no_xcd && nchunks >= xcd_min_blocks()) {
@@ -852,7 +852,7 @@ int launch_cl_wgrad_finalize(FinalizeBatch &b, hipStream_t st)
 {
     if (b.njobs <= 0) return DLKA_OK;
     long blk = 0;
-    static const bool no_tr = getenv("DLKA_FINALIZE_V1") != nullptr;   // A/B switch
+    constexpr bool no_tr = false;
     for (int k = 0; k < b.njobs; ++k) {
         FinalizeJob &j = b.j[k];
         j.block0 = blk;

@@ -9,8 +9,8 @@
 // same or adjacent cache lines.
 //
 // Kernels in this file are the GENERAL path (any kernel size / stride / pad / dilation / groups /
-// deformable groups).  Faster shape-specialised kernels for the D-LKA hot configuration live in
-// deform_conv_tiled.hip and are chosen by the dispatcher in dlka_capi.hip.
+// deformable groups).  The shape-specialised kernels of the D-LKA hot configuration are the channels-last ones
+// (cl_*.hip), entered through dlka_capi_cl.hip.
 #include "deform_sample.h"
 #include "cl_gather.h"
 #include "dlka_kernels.h"

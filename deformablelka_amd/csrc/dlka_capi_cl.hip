@@ -242,7 +242,7 @@ int deform_forward(const SameConv &s, const float *x, const float *off, const fl
         }
         return launch_cl_deform_fwd(a, splits, st);
     }
-    static const bool old_path = getenv("DLKA_DEFORM_FWD_IGEMM") != nullptr;   // A/B switch: first-generation "lane = row" gather
+    constexpr bool old_path = false;
     if (!old_path) {
         const int rc = launch_cl_deform_fwd(a, splits, st);
         if (rc != DLKA_ERR_UNSUPPORTED) return rc;
@@ -266,18 +266,7 @@ size_t deform_scratch_floats(const SameConv &s)
     return cl_deform_bwd2_scratch_floats(a);
 }
 
-// variant: 0 = gather/LDS-fp64-window kernels (default), 1 = one fused kernel with global fp32 atomics,
-//          2 = LDS fp32-atomic window (kept for A/B measurements; DLKA_DEFORM_BWD selects)
-int deform_bwd_variant()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("DLKA_DEFORM_BWD");
-        v = e ? atoi(e) : 0;
-        if (v < 0 || v > 2) v = 0;
-    }
-    return v;
-}
+int deform_bwd_variant() { return 0; }   // (two earlier generations — one fused kernel with global atomics, an fp32 LDS window — were removed in round 2)
 
 int deform_backward(const SameConv &s, const float *x, const float *off, const float *w, const float *gout, float *gx, float *goff,
                     float *gw, float *gb, float *wp, float *part, float *scratch, hipStream_t st, FinalizeJob *defer = nullptr, bool gx_zeroed = false,
@@ -288,10 +277,7 @@ int deform_backward(const SameConv &s, const float *x, const float *off, const f
         DeformBwdArgs a;
         fill_deform_bwd(a, s);
         a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff; a.gx_zeroed = gx_zeroed ? 1 : 0; a.goff_zeroed = goff_zeroed ? 1 : 0; a.goff_cpad = goff_cpad;
-        const int variant = s.act_bf16 ? 0 : deform_bwd_variant();
-        if (variant == 0) DLKA_TRY(launch_cl_deform_bwd2(a, scratch, st));
-        else if (variant == 2 && s.N >= 512) DLKA_TRY(launch_cl_deform_bwd_lds(a, st));
-        else DLKA_TRY(launch_cl_deform_bwd(a, st));
+        DLKA_TRY(launch_cl_deform_bwd2(a, scratch, st));
     }
     if (gw) {
         WgradArgs a;
@@ -423,7 +409,7 @@ SideCtx &side_ctx()
     static SideCtx c = [] {
         SideCtx x;
         memset(&x, 0, sizeof(x));
-        x.ok = getenv("DLKA_SIDE_STREAM") != nullptr;   // opt-in: measured slower on MI355X (20.4 vs 19.0 ms/step), see DESIGN.md
+        x.ok = false;   // a side stream for the weight gradients measured slower on MI355X (20.4 vs 19.0 ms/step eager, 1.70 vs 1.61 ms per block under graph replay)
         if (x.ok && hipStreamCreateWithFlags(&x.side, hipStreamNonBlocking) != hipSuccess) x.ok = false;
         for (int k = 0; k < 8 && x.ok; ++k)
             if (hipEventCreateWithFlags(&x.ev[k], hipEventDisableTiming) != hipSuccess) x.ok = false;

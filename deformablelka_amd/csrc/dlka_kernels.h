@@ -65,8 +65,6 @@ int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st);
 int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st, bool zero_init = true);
 template <typename T> int launch_cl_dw_unprep(const float *gwp, T *gw, int C, int K, hipStream_t st);
 int launch_cl_transpose(const float *src, float *dst, int B, int C, int N, int to_cl, hipStream_t st);
-int launch_cl_deform_bwd(const DeformBwdArgs &a, hipStream_t st);
-int launch_cl_deform_bwd_lds(const DeformBwdArgs &a, hipStream_t st);
 size_t cl_deform_bwd2_scratch_floats(const DeformBwdArgs &a);
 int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st);
 int cl_deform_goff_ccsplit(const DeformBwdArgs &a);
