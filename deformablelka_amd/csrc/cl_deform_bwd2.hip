@@ -222,7 +222,8 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
     __shared__ __attribute__((aligned(16))) float Dsm[4][32 * GATHER_DESC_WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int gr = lane >> 3, gp = lane & 7;
+    using GG = GatherGeom<T>;
+    const int gr = lane >> GG::PSHIFT, gp = lane & ((1 << GG::PSHIFT) - 1);
     const int bx = DLKA_XCD_BX(p.xcd_nx);
     if (bx < 0) return;
     const int mbase = (bx * 4 + wave) * 32;
@@ -258,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
         }
     }
 
-    f32x4 xr[4][8];   // corner pieces of the unit in flight
-    RowDesc rd[4];
+    GatherPiece<T> xr[GG::NG][8];   // corner pieces of the unit in flight
+    RowDesc rd[GG::NG];
     float onx[3] = {0.f, 0.f, 0.f};   // offsets of the next tap to describe, loaded a whole tap ahead
     auto load_offsets = [&](int tap) {
         const float *op = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
@@ -276,14 +277,14 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
         }
         wave_sync();
 #pragma unroll
-        for (int g = 0; g < 4; ++g) rd[g] = gather_lookup(Dt, 8 * g + gr);
+        for (int g = 0; g < GG::NG; ++g) rd[g] = gather_lookup(Dt, GG::RPI * g + gr);
     };
     auto issue = [&](int cc) {
-        const unsigned cbyte = (unsigned)(cc * 32 + 4 * gp) * XB;
+        const unsigned cbyte = (unsigned)(cc * 32 + GG::PE * gp) * XB;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < GG::NG; ++g)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) xr[g][q] = act_buf_load4<T>(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
+            for (int q = 0; q < 8; ++q) xr[g][q] = gather_load<T>(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
     };
 
     // weight tile of stage s = (tap, cc, kc) in flight in a register while the previous stage computes
@@ -346,23 +347,26 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
             // ---- 2. derivative samples of this lane's 4 gather rows -> LDS tiles ----
             wave_sync();   // previous tiles consumed
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < GG::NG; ++g) {
                 const float fd[2] = {1.f - rd[g].ld, rd[g].ld}, fh[2] = {1.f - rd[g].lh, rd[g].lh}, fw[2] = {1.f - rd[g].lw, rd[g].lw};
-                f32x4 dd = {0.f, 0.f, 0.f, 0.f}, dh = {0.f, 0.f, 0.f, 0.f}, dw = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
-                    const float kd_ = (cd ? 1.f : -1.f) * fh[ch] * fw[cw], kh_ = (ch ? 1.f : -1.f) * fd[cd] * fw[cw], kw_ = (cw ? 1.f : -1.f) * fd[cd] * fh[ch];
-                    const f32x4 x4 = xr[g][q];
+                for (int v = 0; v < GG::PE / 4; ++v) {
+                    f32x4 dd = {0.f, 0.f, 0.f, 0.f}, dh = {0.f, 0.f, 0.f, 0.f}, dw = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        dd[e] = fmaf(kd_, x4[e], dd[e]); dh[e] = fmaf(kh_, x4[e], dh[e]); dw[e] = fmaf(kw_, x4[e], dw[e]);
+                    for (int q = 0; q < 8; ++q) {
+                        const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
+                        const float kd_ = (cd ? 1.f : -1.f) * fh[ch] * fw[cw], kh_ = (ch ? 1.f : -1.f) * fd[cd] * fw[cw], kw_ = (cw ? 1.f : -1.f) * fd[cd] * fh[ch];
+                        const f32x4 x4 = xr[g][q].v[v];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            dd[e] = fmaf(kd_, x4[e], dd[e]); dh[e] = fmaf(kh_, x4[e], dh[e]); dw[e] = fmaf(kw_, x4[e], dw[e]);
+                        }
                     }
+                    float *dst = Tt + (GG::RPI * g + gr) * SROW + GG::PE * gp + 4 * v;
+                    *reinterpret_cast<f32x4 *>(dst) = dd;
+                    *reinterpret_cast<f32x4 *>(dst + 32 * SROW) = dh;
+                    *reinterpret_cast<f32x4 *>(dst + 2 * 32 * SROW) = dw;
                 }
-                float *dst = Tt + (8 * g + gr) * SROW + 4 * gp;
-                *reinterpret_cast<f32x4 *>(dst) = dd;
-                *reinterpret_cast<f32x4 *>(dst + 32 * SROW) = dh;
-                *reinterpret_cast<f32x4 *>(dst + 2 * 32 * SROW) = dw;
             }
             // the next unit's corner loads go out now: in flight under the dots below, the next staging and the next MFMAs
             if (cc + 1 < cc_hi) issue(cc + 1);

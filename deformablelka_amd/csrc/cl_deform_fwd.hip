@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
     __shared__ __attribute__((aligned(16))) float Dsm[4][32 * GATHER_DESC_WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;      // MFMA roles
-    const int gr = lane >> 3, gp = lane & 7;     // gather roles: row gr of each group of 8, 16-byte piece gp
+    using GG = GatherGeom<T>;
+    const int gr = lane >> GG::PSHIFT, gp = lane & ((1 << GG::PSHIFT) - 1);   // gather roles: row gr of each group of RPI, 16-byte piece gp
     const int bx = DLKA_XCD_BX(p.xcd_nx);
     if (bx < 0) return;
     const int mbase = (bx * 4 + wave) * 32;
@@ -52,8 +53,8 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
     const int unit_hi = min(p.K * nchunk, unit_lo + p.units_per_split);
 
     f32x4 breg[BV];
-    f32x4 xr[4][8];          // gathered corner pieces of the next unit, in flight
-    RowDesc rd[4];           // descriptions of this lane's 4 gather rows (current tap)
+    GatherPiece<T> xr[GG::NG][8];   // gathered corner pieces of the next unit, in flight
+    RowDesc rd[GG::NG];             // descriptions of this lane's gather rows (current tap)
     int cur_tap = -1;
 
 #define DLKA_LOAD_B(unit_)                                                                         \
@@ -83,28 +84,31 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
             }
             wave_sync();
 #pragma unroll
-            for (int g = 0; g < 4; ++g) rd[g] = gather_lookup(Dt, 8 * g + gr);
+            for (int g = 0; g < GG::NG; ++g) rd[g] = gather_lookup(Dt, GG::RPI * g + gr);
         }
-        const unsigned cbyte = (unsigned)(ck * 32 + 4 * gp) * SB;
+        const unsigned cbyte = (unsigned)(ck * 32 + GG::PE * gp) * SB;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < GG::NG; ++g)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) xr[g][q] = act_buf_load4<T>(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
+            for (int q = 0; q < 8; ++q) xr[g][q] = gather_load<T>(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
     };
     // interpolate, transpose through the wave-private tile, return the MFMA A values of this lane
     auto finish = [&](float *a) {
         wave_sync();   // previous tile consumed
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < GG::NG; ++g) {
             float wq[8];
             gather_weights(rd[g], wq);
-            f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                s4[0] = fmaf(wq[q], xr[g][q][0], s4[0]); s4[1] = fmaf(wq[q], xr[g][q][1], s4[1]);
-                s4[2] = fmaf(wq[q], xr[g][q][2], s4[2]); s4[3] = fmaf(wq[q], xr[g][q][3], s4[3]);
+            for (int v = 0; v < GG::PE / 4; ++v) {
+                f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    s4[0] = fmaf(wq[q], xr[g][q].v[v][0], s4[0]); s4[1] = fmaf(wq[q], xr[g][q].v[v][1], s4[1]);
+                    s4[2] = fmaf(wq[q], xr[g][q].v[v][2], s4[2]); s4[3] = fmaf(wq[q], xr[g][q].v[v][3], s4[3]);
+                }
+                *reinterpret_cast<f32x4 *>(S + (GG::RPI * g + gr) * SROW + GG::PE * gp + 4 * v) = s4;
             }
-            *reinterpret_cast<f32x4 *>(S + (8 * g + gr) * SROW + 4 * gp) = s4;
         }
         wave_sync();
 #pragma unroll

@@ -81,6 +81,27 @@ __device__ __forceinline__ unsigned gather_offset(const RowDesc &r, int q, int H
     return ((r.okm >> q) & 1u) ? (unsigned)idx * (unsigned)rowbytes + cbyte : DLKA_OOB;
 }
 
+// Lane layout of the gather, by activation storage type.  fp32: a 32-channel chunk of a row is 128 bytes — lane = (row of 8, 16-byte piece
+// of 8), four row groups cover a 32-row tile.  bf16: the chunk is 64 bytes — lane = (row of 16, 16-byte piece of 4), two row groups; the
+// per-lane load is still 16 bytes (8 channels), so a 32-row tile takes HALF the load instructions (8-byte loads in the fp32 layout were
+// measured slower than fp32 itself: 117 vs 102 us for the stage-0 forward, profiles/r03c).
+template <typename T> struct GatherGeom { static constexpr int NG = 4, RPI = 8, PE = 4, PSHIFT = 3; };
+template <> struct GatherGeom<bf16_t> { static constexpr int NG = 2, RPI = 16, PE = 8, PSHIFT = 2; };
+template <typename T> struct GatherPiece { f32x4 v[GatherGeom<T>::PE / 4]; };
+template <typename T> __device__ __forceinline__ GatherPiece<T> gather_load(BufRsrc r, unsigned byteoff);
+template <> __device__ __forceinline__ GatherPiece<float> gather_load<float>(BufRsrc r, unsigned byteoff)
+{
+    GatherPiece<float> p;
+    p.v[0] = buf_load_f32x4(r, byteoff);
+    return p;
+}
+template <> __device__ __forceinline__ GatherPiece<bf16_t> gather_load<bf16_t>(BufRsrc r, unsigned byteoff)
+{
+    GatherPiece<bf16_t> p;
+    buf_load_bf16x8(r, byteoff, p.v[0], p.v[1]);
+    return p;
+}
+
 __device__ __forceinline__ void gather_weights(const RowDesc &r, float w[8])
 {
     const float fd[2] = {1.f - r.ld, r.ld}, fh[2] = {1.f - r.lh, r.lh}, fw[2] = {1.f - r.lw, r.lw};

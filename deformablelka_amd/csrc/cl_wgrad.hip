@@ -204,7 +204,8 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
     __shared__ __attribute__((aligned(16))) float Ssm[2][32 * SROW];
     __shared__ __attribute__((aligned(16))) float Dt[32 * GATHER_DESC_WORDS];
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
-    const int gr = lane >> 3, gp = lane & 7;
+    using GG = GatherGeom<T>;
+    const int gr = lane >> GG::PSHIFT, gp = lane & ((1 << GG::PSHIFT) - 1);
     int chunk = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (p.xcd_total) {   // XCD-swizzled 1-D grid: an XCD owns a contiguous range of row chunks (with all their tiles and tap groups)
         const int r = xcd_item(blockIdx.x, p.xcd_total);
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
     const bool want_bias = p.bpart && ct == 0 && bz == 0;
     const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * XB), rg = make_rsrc(p.g, (size_t)p.M * p.Cout * XB);
     const int HW = p.H * p.W, rowbytes = p.Cin * XB;
-    const unsigned cbyte = (unsigned)(ct * 32 + 4 * gp) * XB;
+    const unsigned cbyte = (unsigned)(ct * 32 + GG::PE * gp) * XB;
 
     f32x16 acc[TPW];
 #pragma unroll
@@ -229,8 +230,8 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
 
     const int m_lo = chunk * p.rows_per_chunk;
     const int m_hi = min(p.M, m_lo + p.rows_per_chunk);
-    f32x4 xr[4][8];
-    RowDesc rd[4];
+    GatherPiece<T> xr[GG::NG][8];
+    RowDesc rd[GG::NG];
     for (int mbase = m_lo; mbase < m_hi; mbase += 32) {
         // A operand: G[m = mbase + 16h + s][co]
         float ga[16];
@@ -256,10 +257,10 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
             }
             wave_sync();
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                rd[g] = gather_lookup(Dt, 8 * g + gr);
+            for (int g = 0; g < GG::NG; ++g) {
+                rd[g] = gather_lookup(Dt, GG::RPI * g + gr);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) xr[g][q] = act_buf_load4<T>(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
+                for (int q = 0; q < 8; ++q) xr[g][q] = gather_load<T>(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
             }
         };
         describe_issue(0);
@@ -273,16 +274,19 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
             float *S = Ssm[t & 1];
             // interpolate tap t and put its tile into LDS (the tile read two taps ago is free: LDS ops retire in order)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < GG::NG; ++g) {
                 float wq[8];
                 gather_weights(rd[g], wq);
-                f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    s4[0] = fmaf(wq[q], xr[g][q][0], s4[0]); s4[1] = fmaf(wq[q], xr[g][q][1], s4[1]);
-                    s4[2] = fmaf(wq[q], xr[g][q][2], s4[2]); s4[3] = fmaf(wq[q], xr[g][q][3], s4[3]);
+                for (int v = 0; v < GG::PE / 4; ++v) {
+                    f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        s4[0] = fmaf(wq[q], xr[g][q].v[v][0], s4[0]); s4[1] = fmaf(wq[q], xr[g][q].v[v][1], s4[1]);
+                        s4[2] = fmaf(wq[q], xr[g][q].v[v][2], s4[2]); s4[3] = fmaf(wq[q], xr[g][q].v[v][3], s4[3]);
+                    }
+                    *reinterpret_cast<f32x4 *>(S + (GG::RPI * g + gr) * SROW + GG::PE * gp + 4 * v) = s4;
                 }
-                *reinterpret_cast<f32x4 *>(S + (8 * g + gr) * SROW + 4 * gp) = s4;
             }
             if (t + 1 < ntap) describe_issue(t + 1);   // its corner loads fly under the MFMAs below
             else wave_sync();

@@ -90,6 +90,12 @@ __device__ __forceinline__ float buf_load_bf16(BufRsrc r, unsigned off)
     if (off < r.bytes && off + 2 <= r.bytes) memcpy(&h, r.base + off, 2);
     return hipemu::hipemu_bf16_to_f32(h);
 }
+// 8 consecutive bf16 (one 16-byte load) -> lo = elements 0..3, hi = 4..7
+__device__ __forceinline__ void buf_load_bf16x8(BufRsrc r, unsigned off, f32x4 &lo, f32x4 &hi)
+{
+    lo = buf_load_bf16x4(r, off);
+    hi = buf_load_bf16x4(r, off == DLKA_OOB ? DLKA_OOB : off + 8u);
+}
 // two-term bf16 split packed in one word: hi << 16 | lo
 __device__ __forceinline__ float pack_split2(float x)
 {
@@ -170,6 +176,7 @@ __device__ __forceinline__ float buf_load_f32_s(BufRsrc r, unsigned voff, unsign
 }
 // ---- bf16 activation storage (DLKA_BF16 token path): 4 consecutive bf16 -> 4 floats, one 8-byte buffer load ----
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 buf_load_bf16x4(BufRsrc r, unsigned off)
 {
     const u32x2_t w = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
@@ -182,6 +189,15 @@ __device__ __forceinline__ float buf_load_bf16(BufRsrc r, unsigned off)
 {
     return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0) << 16);
 }
+// 8 consecutive bf16 (one 16-byte load) -> lo = elements 0..3, hi = 4..7
+__device__ __forceinline__ void buf_load_bf16x8(BufRsrc r, unsigned off, f32x4 &lo, f32x4 &hi)
+{
+    const u32x4_t w = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    lo[0] = __builtin_bit_cast(float, w[0] << 16); lo[1] = __builtin_bit_cast(float, w[0] & 0xffff0000u);
+    lo[2] = __builtin_bit_cast(float, w[1] << 16); lo[3] = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+    hi[0] = __builtin_bit_cast(float, w[2] << 16); hi[1] = __builtin_bit_cast(float, w[2] & 0xffff0000u);
+    hi[2] = __builtin_bit_cast(float, w[3] << 16); hi[3] = __builtin_bit_cast(float, w[3] & 0xffff0000u);
+}
 // two-term bf16 split packed in one word (hi << 16 | lo): the producer splits ONCE, consumers that contract the value many times (27 taps)
 // rebuild their MFMA operands with one v_perm per pair instead of ~5 VALU instructions per value per use
 __device__ __forceinline__ float pack_split2(float x)
@@ -190,7 +206,6 @@ __device__ __forceinline__ float pack_split2(float x)
     const __bf16 lo = (__bf16)(x - (float)hi);
     return __builtin_bit_cast(float, ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16) | (unsigned)__builtin_bit_cast(unsigned short, lo));
 }
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void unpack_split2x8(const float *w, bf16x8 &hi, bf16x8 &lo)
 {
     u32x4_t h4, l4;
