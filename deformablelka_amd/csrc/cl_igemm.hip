@@ -290,6 +290,39 @@ __global__ __launch_bounds__(256) void cl_prep_batch_kernel(PrepBatch b)
     }
 }
 
+// The same re-layouts for MANY blocks in one launch: the job table lives in device memory (built once per model, the pointers do not
+// change), `first[j]` = first workgroup of job j; a workgroup finds its job by bisection and covers PREP_TABLE_CHUNK elements of it.
+constexpr int PREP_TABLE_CHUNK = 2048;
+__global__ __launch_bounds__(256) void cl_prep_table_kernel(const PrepJob *__restrict__ jobs, const int *__restrict__ first, int njobs)
+{
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {   // last job whose first workgroup is <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PrepJob j = jobs[lo];
+    const long l0 = (long)((int)blockIdx.x - first[lo]) * PREP_TABLE_CHUNK;
+    for (long l = l0 + threadIdx.x; l < l0 + PREP_TABLE_CHUNK && l < j.n; l += 256) {
+        if (j.mode == 3 || j.mode == 4) {
+            const int c = (int)(l % j.Cin), tap = (int)(l / j.Cin);
+            j.dst[l] = j.src[(long)c * j.K + (j.mode == 4 ? j.K - 1 - tap : tap)];
+        } else {
+            const int n = (int)(l % j.NP), k = (int)((l / j.NP) % j.KP), tp = (int)(l / j.NP / j.KP);
+            prep_store(j.dst, j.KP, j.NP, j.mode, tp, k, n, prep_value(j.src, j.Cout, j.Cin, j.K, j.mode, tp, k, n));
+        }
+    }
+}
+
+int cl_prep_table_blocks(long n) { return (int)cdivl(n, PREP_TABLE_CHUNK); }
+
+int launch_cl_prep_table(const PrepJob *jobs_dev, const int *first_dev, int njobs, int nblocks, hipStream_t st)
+{
+    if (njobs <= 0) return DLKA_OK;
+    hipLaunchKernelGGL(cl_prep_table_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, jobs_dev, first_dev, njobs);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
 int launch_cl_prep_batch(const PrepBatch &b, hipStream_t st)
 {
     if (b.njobs <= 0) return DLKA_OK;

@@ -358,7 +358,8 @@ void add_job(PrepBatch &pb, const void *src, float *dst, int Cout, int Cin, int 
     pb.total += j.n;
 }
 
-int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_params *p, hipStream_t st, bool fill, const ZeroBatch *zb = nullptr)
+int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_params *p, hipStream_t st, bool fill, const ZeroBatch *zb = nullptr,
+               PrepBatch *collect = nullptr)
 {
     float *q = base;
     auto take = [&](size_t n) { float *r = q; q += (n + 63) & ~(size_t)63; return r; };
@@ -391,6 +392,7 @@ int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_para
             j.dst = zb->p[r]; j.n = zb->cnt[r]; j.mode = 5;
             pb.total += j.n;
         }
+    if (collect) { *collect = pb; return DLKA_OK; }   // dlka_lka3d_tokens_prepare_plan: the jobs go into a table instead of a launch
     return launch_cl_prep_batch(pb, st);
 }
 
@@ -409,7 +411,8 @@ SideCtx &side_ctx()
     static SideCtx c = [] {
         SideCtx x;
         memset(&x, 0, sizeof(x));
-        x.ok = false;   // a side stream for the weight gradients measured slower on MI355X (20.4 vs 19.0 ms/step eager, 1.70 vs 1.61 ms per block under graph replay)
+        x.ok = false;   // a side stream for the weight gradients measured slower under graph replay at EVERY stage (fork / join cost): 1.70 vs 1.61 ms
+                        // per block at stage 0 (r01), 0.479 vs 0.414 ms at stage 2 and 0.433 vs 0.381 ms at stage 3 (r03); the code path stays for reference
         if (x.ok && hipStreamCreateWithFlags(&x.side, hipStreamNonBlocking) != hipSuccess) x.ok = false;
         for (int k = 0; k < 8 && x.ok; ++k)
             if (hipEventCreateWithFlags(&x.ev[k], hipEventDisableTiming) != hipSuccess) x.ok = false;
@@ -773,8 +776,8 @@ size_t dlka_lka3d_tokens_workspace_bytes(int B, int C, int D, int H, int W, int 
            align256(G.scratch_floats() * 4) + align256(4096);
 }
 
-int dlka_lka3d_attention_tokens_forward(const void *x_, const dlka_lka3d_params *p, void *y_, void *saved, size_t saved_bytes,
-                                        void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, void *stream)
+static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void *y_, void *saved, size_t saved_bytes, void *workspace,
+                               size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, void *stream, bool prepared)
 {
     if (!x_ || !p || !y_ || !saved || !workspace) return DLKA_ERR_NULL;
     const void *const *pp = (const void *const *)p;
@@ -806,7 +809,12 @@ int dlka_lka3d_attention_tokens_forward(const void *x_, const dlka_lka3d_params 
     if (dense_forward_splits(G.dcn, 0) > 1) zb.add(bf ? acc32 : f, G.E);
     if (dense_forward_splits(G.pw, 3) > 1) zb.add(y, G.E);
     TokPrep PW;
-    DLKA_TRY(carve_prep(G, prep, PW, p, st, true, &zb));
+    if (prepared) {   // the prepared weights are already in `saved` (dlka_lka3d_tokens_prepare_run): only the zero fills remain
+        DLKA_TRY(carve_prep(G, prep, PW, p, st, false));
+        if (zb.n) DLKA_TRY(launch_zero_batch(zb, st));
+    } else {
+        DLKA_TRY(carve_prep(G, prep, PW, p, st, true, &zb));
+    }
     // proj_1 + GELU (transformerblock.py:667-668): h kept for the GELU gradient, a = GELU(h)
     DLKA_TRY(dense_forward(G.pw, x, N0, (const float *)p->proj_1_b, h, 0, PW.pw_f[0], 1, nullptr, a, st));
     // depthwise 5^3 then 7^3 dilation 3 (:646-647)
@@ -821,6 +829,77 @@ int dlka_lka3d_attention_tokens_forward(const void *x_, const dlka_lka3d_params 
     // proj_2 + shortcut (:670-671)
     DLKA_TRY(dense_forward(G.pw, m, N0, (const float *)p->proj_2_b, y, 0, PW.pw_f[2], 3, x, nullptr, st, true));
     return DLKA_OK;
+}
+
+int dlka_lka3d_attention_tokens_forward(const void *x, const dlka_lka3d_params *p, void *y, void *saved, size_t saved_bytes, void *workspace,
+                                        size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, void *stream)
+{
+    return tokens_forward_impl(x, p, y, saved, saved_bytes, workspace, workspace_bytes, B, C, D, H, W, dtype, stream, false);
+}
+
+int dlka_lka3d_attention_tokens_forward_prepared(const void *x, const dlka_lka3d_params *p, void *y, void *saved, size_t saved_bytes, void *workspace,
+                                                 size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, void *stream)
+{
+    return tokens_forward_impl(x, p, y, saved, saved_bytes, workspace, workspace_bytes, B, C, D, H, W, dtype, stream, true);
+}
+
+// ---- weight preparation of MANY blocks in one launch --------------------------------------------------------------------------------
+// plan (host, then copied to the device by the caller): [int njobs][int nblocks][int first[MAXJ]][PrepJob jobs[MAXJ]]
+namespace {
+constexpr int PLAN_JOBS_PER_BLOCK = 16;   // (14 today: 6 pointwise, 2 offset conv, 2 deformable, 4 depthwise forms)
+struct PlanHeader { int njobs, nblocks, pad0, pad1; };
+size_t plan_first_off() { return sizeof(PlanHeader); }
+size_t plan_jobs_off(int nb) { return align256(sizeof(PlanHeader) + (size_t)nb * PLAN_JOBS_PER_BLOCK * sizeof(int)); }
+}  // namespace
+
+size_t dlka_lka3d_tokens_prepare_plan_bytes(int nblocks)
+{
+    if (nblocks <= 0) return 0;
+    return plan_jobs_off(nblocks) + (size_t)nblocks * PLAN_JOBS_PER_BLOCK * sizeof(PrepJob);
+}
+
+int dlka_lka3d_tokens_prepare_plan(int nblocks, const dlka_lka3d_params *params, void *const *saved, const size_t *saved_bytes, const int *dims5,
+                                   int dtype, void *plan_host, size_t plan_bytes)
+{
+    if (!params || !saved || !saved_bytes || !dims5 || !plan_host) return DLKA_ERR_NULL;
+    if (nblocks <= 0 || plan_bytes < dlka_lka3d_tokens_prepare_plan_bytes(nblocks)) return DLKA_ERR_WORKSPACE;
+    unsigned char *base = (unsigned char *)plan_host;
+    PlanHeader *hd = (PlanHeader *)base;
+    int *first = (int *)(base + plan_first_off());
+    PrepJob *jobs = (PrepJob *)(base + plan_jobs_off(nblocks));
+    int nj = 0, nb = 0;
+    for (int k = 0; k < nblocks; ++k) {
+        const int B = dims5[5 * k], C = dims5[5 * k + 1], D = dims5[5 * k + 2], H = dims5[5 * k + 3], W = dims5[5 * k + 4];
+        if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return DLKA_ERR_UNSUPPORTED;
+        TokGeoms G(B, C, D, H, W, dtype);
+        Carver sv(saved[k], saved_bytes[k]);
+        for (int e = 0; e < 4; ++e) (void)sv.take(G.E * G.SB);   // h, a, t1, t
+        (void)sv.take(G.Off * 4);
+        (void)sv.take(G.E * G.SB); (void)sv.take(G.E * G.SB);     // f, g1
+        float *prep = (float *)sv.take(G.prep_floats() * 4);
+        if (!sv.ok()) return DLKA_ERR_WORKSPACE;
+        TokPrep PW;
+        PrepBatch pb;
+        DLKA_TRY(carve_prep(G, prep, PW, &params[k], nullptr, true, nullptr, &pb));
+        if (pb.njobs > PLAN_JOBS_PER_BLOCK) return DLKA_ERR_UNSUPPORTED;
+        for (int j = 0; j < pb.njobs; ++j) {
+            first[nj] = nb;
+            jobs[nj] = pb.j[j];
+            nb += cl_prep_table_blocks(pb.j[j].n);
+            ++nj;
+        }
+    }
+    hd->njobs = nj; hd->nblocks = nb; hd->pad0 = hd->pad1 = 0;
+    return DLKA_OK;
+}
+
+int dlka_lka3d_tokens_prepare_run(const void *plan_device, const void *plan_host, int nblocks, void *stream)
+{
+    if (!plan_device || !plan_host) return DLKA_ERR_NULL;
+    const PlanHeader *hd = (const PlanHeader *)plan_host;   // (the counts are read from the host copy: no device round trip)
+    const unsigned char *dev = (const unsigned char *)plan_device;
+    return launch_cl_prep_table((const PrepJob *)(dev + plan_jobs_off(nblocks)), (const int *)(dev + plan_first_off()), hd->njobs, hd->nblocks,
+                                (hipStream_t)stream);
 }
 
 int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params *p, const void *gy_, const void *saved, size_t saved_bytes,

@@ -82,6 +82,7 @@ class DLKABlockStack:
             self.blocks.append(blk)
         self.ws_bytes = ws_bytes
         self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        self._build_prepare_plan()
         # activations: blocks of one stage instance are chained x -> y -> ... ; each chain has a synthetic input and
         # a synthetic grad_output (the layers between chains — down/up-sampling, UnetResBlock — are not D-LKA).
         if data_seed is not None:
@@ -116,6 +117,27 @@ class DLKABlockStack:
         ow.copy_((torch.randn(ow.shape, generator=gen) * _offset_std_for(blk.C, offset_std)).to(self.device))
         ob.zero_()
 
+    def _build_prepare_plan(self):
+        """The prepared (MFMA-operand-order) weight forms of ALL blocks are produced by ONE launch per step (``prepare()``), not by one launch
+        inside every block's forward call: the job table is built here once — parameter and ``saved`` addresses never change — and lives on
+        the device (include/dlka.h: dlka_lka3d_tokens_prepare_*)."""
+        import ctypes
+        n = len(self.blocks)
+        nbytes = self.lib.dlka_lka3d_tokens_prepare_plan_bytes(n)
+        params = (L.Lka3dPtrs * n)(*[b.pstruct for b in self.blocks])
+        saved = (ctypes.c_void_p * n)(*[b.saved.data_ptr() for b in self.blocks])
+        sbytes = (ctypes.c_size_t * n)(*[b.saved_bytes for b in self.blocks])
+        dims = (ctypes.c_int * (5 * n))(*[v for b in self.blocks for v in (self.B, b.C, *b.dims)])
+        self._plan_host = torch.zeros(nbytes, dtype=torch.uint8)
+        rc = self.lib.dlka_lka3d_tokens_prepare_plan(n, params, saved, sbytes, dims, self.dt, ctypes.c_void_p(self._plan_host.data_ptr()), nbytes)
+        L.check(rc, "lka3d_tokens_prepare_plan")
+        self._plan_dev = self._plan_host.to(self.device) if self.device.type == "cuda" else self._plan_host
+
+    def prepare(self):
+        """Re-lay the weights of all blocks (after every parameter update): one launch."""
+        rc = self.lib.dlka_lka3d_tokens_prepare_run(L.ptr(self._plan_dev), L.ptr(self._plan_host), len(self.blocks), self._stream())
+        L.check(rc, "lka3d_tokens_prepare_run")
+
     def _stream(self):
         if self.device.type != "cuda":   # only reachable through the CPU test backend (tests/emu)
             return None
@@ -123,12 +145,13 @@ class DLKABlockStack:
 
     def forward(self):
         st = self._stream()
+        self.prepare()
         for blk in self.blocks:
             H, W, D = blk.dims
-            rc = self.lib.dlka_lka3d_attention_tokens_forward(L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.y), L.ptr(blk.saved),
-                                                       blk.saved_bytes, L.ptr(self.ws), self.ws_bytes, self.B, blk.C, H, W, D,
-                                                       self.dt, st)
-            L.check(rc, "lka3d_attention_tokens_forward")
+            rc = self.lib.dlka_lka3d_attention_tokens_forward_prepared(L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.y), L.ptr(blk.saved),
+                                                                blk.saved_bytes, L.ptr(self.ws), self.ws_bytes, self.B, blk.C, H, W, D,
+                                                                self.dt, st)
+            L.check(rc, "lka3d_attention_tokens_forward_prepared")
 
     def backward(self, lo: int = 0, hi: int = None):
         """Backward pass of blocks[lo:hi] in reverse order (default: all)."""

@@ -280,6 +280,20 @@ size_t dlka_lka3d_tokens_workspace_bytes(int B, int C, int D, int H, int W, int 
 int dlka_lka3d_attention_tokens_forward(const void *x, const dlka_lka3d_params *p, void *y,
                                         void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes,
                                         int B, int C, int D, int H, int W, int dtype, void *stream);
+/* Weight preparation of MANY blocks in ONE launch.  The forward call above re-lays the block's weights into MFMA operand order (12 small
+ * jobs, one launch per block; inside a hipGraph every dependent node costs ~4.5 us, and at C = 256 the launch itself is 41 us).  The prepared
+ * forms depend on the parameters only, so a model that steps all its blocks (the 21 blocks of a D_LKA_Former patch) prepares them together,
+ * once per optimizer step:
+ *   plan_bytes  size of the job table;  _prepare_plan fills a HOST buffer (pointers of every block's parameters and `saved` area; they must stay
+ *   put); the caller copies it to the device once;  _prepare_run(plan_device, plan_host, n) = one launch;  _forward_prepared = the forward call
+ *   without its preparation launch.  params: array of n structs; dims5: n x (B, C, D, H, W). */
+size_t dlka_lka3d_tokens_prepare_plan_bytes(int nblocks);
+int dlka_lka3d_tokens_prepare_plan(int nblocks, const dlka_lka3d_params *params, void *const *saved, const size_t *saved_bytes,
+                                   const int *dims5, int dtype, void *plan_host, size_t plan_bytes);
+int dlka_lka3d_tokens_prepare_run(const void *plan_device, const void *plan_host, int nblocks, void *stream);
+int dlka_lka3d_attention_tokens_forward_prepared(const void *x, const dlka_lka3d_params *p, void *y,
+                                                 void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes,
+                                                 int B, int C, int D, int H, int W, int dtype, void *stream);
 int dlka_lka3d_attention_tokens_backward(const void *x, const dlka_lka3d_params *p, const void *grad_y,
                                          const void *saved, size_t saved_bytes,
                                          void *grad_x, const dlka_lka3d_grads *grads,

@@ -214,3 +214,24 @@ def test_lka2d_attention_tiled_windows_and_far_offsets():
     # within fp32 rounding of a cell boundary turns up in roughly every second draw — one such flip moves the conv0-side gradients by 1e-3 ..
     # 2e-2 in max norm (seeds 0, 2, 3; seed 1 has none: 4e-6), which is why the seed is pinned here)
     parity.check_lka2d_attention("cpu", 1, 32, 40, 72, seed=1, offset_std=0.2, report=True)
+
+
+def test_stack_with_hoisted_weight_preparation_equals_per_block_calls():
+    """DLKABlockStack prepares the weights of all blocks with ONE table-driven launch (dlka_lka3d_tokens_prepare_run) and calls
+    ..._forward_prepared; the result must equal the ordinary per-block entry point (which prepares inside the call) — up to the order of the
+    fp32 atomics the tap-split convs of tiny volumes use."""
+    from ctypes import byref
+    from deformablelka_amd import _lib as L
+    from deformablelka_amd.stack import DLKABlockStack
+    st = DLKABlockStack(1, stages=((32, (2, 3, 4), 2), (64, (2, 2, 2), 1)), device="cpu", seed=5)
+    st.forward()
+    ys = [b.y.clone() for b in st.blocks]
+    lib = L.get_lib()
+    for blk, y_ref in zip(st.blocks, ys):
+        H, W, D = blk.dims
+        y = torch.empty_like(blk.y)
+        saved = torch.zeros_like(blk.saved)
+        rc = lib.dlka_lka3d_attention_tokens_forward(L.ptr(blk.x), byref(blk.pstruct), L.ptr(y), L.ptr(saved), blk.saved_bytes, L.ptr(st.ws),
+                                                     st.ws_bytes, st.B, blk.C, H, W, D, st.dt, None)
+        assert rc == 0
+        assert torch.allclose(y, y_ref, rtol=1e-6, atol=1e-6)
