@@ -72,14 +72,15 @@ bool dw_supported(const SameConv &s)
 }
 bool dense_fwd_supported(const SameConv &s) { return s.group == 1 && s.Cin % 32 == 0 && nt_ok(round_up(s.Cout, 32)); }
 
-// Gradient contractions with K > 1 taps (data and weight gradient of the offset-predict conv) are MFMA-bound in fp32; they
-// run on the bf16 matrix cores with two-term split operands (fp32 accumulation, ~1e-5 relative; cl_igemm.hip) unless
-// DLKA_EXACT_FP32=1.  The FORWARD offset conv stays on the exact fp32-input MFMA: its output decides floor() of every
-// sampling position, and a 1e-5 perturbation flips the cell of the samples that sit within 1e-5 of an integer — harmless
-// for training, but each flip changes that sample's grad_offset by O(1), which showed as a 1.5e-2 relative difference of
-// conv_offset.weight.grad against the oracle when the offsets are concentrated near 0 (tests/test_parity_gpu.py).
-// Returns the number of bf16 terms per operand (0 = exact fp32-input MFMA).  Gradient contractions: 2 (three products, ~1e-5).
-// Forward: 3 (six products, fp32-equivalent) — see cl_igemm.hip; DLKA_SPLIT_FORWARD=2 forces the two-term split there for A/B runs.
+// Contractions with K > 1 taps (the offset-predict conv, its data gradient and its weight gradient) are MFMA-bound with fp32
+// inputs; they run on the bf16 matrix cores with split operands and fp32 accumulation (cl_igemm.hip) unless DLKA_EXACT_FP32=1.
+// Returns the number of bf16 terms per operand (0 = exact fp32-input MFMA):
+//   gradient contractions: 2 (three products, ~1e-5 relative);
+//   FORWARD offset conv:   3 (six products, fp32-equivalent).  Its output decides floor() of every sampling position: a 1e-5
+//     perturbation flips the cell of the samples that sit within 1e-5 of an integer, and each flip changes that sample's
+//     grad_offset by O(1) (seen as 1.5e-2 on conv_offset.weight.grad with offsets concentrated near 0), so the two-term split is
+//     not used there by default; DLKA_SPLIT_FORWARD=2 forces it for A/B runs;
+//   bf16 activations (DLKA_BF16): the activation is its own high term, weights are split in two, no a_lo products.
 int use_split(const SameConv &s, bool forward)
 {
     static const bool exact = getenv("DLKA_EXACT_FP32") != nullptr;
