@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void cl_deform_goff_kernel(DeformBwdArgs p, in
 // (An intermediate version kept Col in the gather layout and reduced 8-lane groups with DPP; it needed 435 registers,
 //  ran one wave per SIMD and was no faster than the first kernel.)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NKC_REG, typename T = float>   // T: storage of `in` and `g` (channels-last); offsets / grad_offset are fp32 planar
+// SAMP: also store the samples S[tap][m][c] (DeformBwdArgs::samp) for the weight gradient
+template <int NKC_REG, typename T = float, bool SAMP = false>   // T: storage of `in` and `g` (channels-last); offsets / grad_offset are fp32 planar
 __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p, int taps_per_block)
 {
     constexpr unsigned XB = sizeof(T);
@@ -239,6 +240,9 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
     const int cc_lo = blockIdx.z * p.cc_per_block, cc_hi = min(ncc, cc_lo + p.cc_per_block), ncb = cc_hi - cc_lo;
     const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.C * XB);
     float *Tt = &Tsm[wave][0][0], *Dt = Dsm[wave];
+    // samples for the weight gradient: S[tap][m][c], this lane's rows mbase + RPI*g + gr, channels PE*gp .. of the current chunk
+    const BufRsrc rsamp = make_rsrc(p.samp, SAMP ? (size_t)p.K * p.M * p.C * 4 : 0);
+    const unsigned samp_v0 = (unsigned)((mbase + gr) * p.C + GG::PE * gp) * 4u;
 
     if (p.goff_cpad && blockIdx.y == 0 && blockIdx.z == 0 && h == 0 && row_ok) {   // the zero planes 3K .. goff_cpad-1 of the packed layout
         float *dst = p.goff + ((long)b * p.goff_cpad + 3 * p.K) * p.N + v;
@@ -349,9 +353,10 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
 #pragma unroll
             for (int g = 0; g < GG::NG; ++g) {
                 const float fd[2] = {1.f - rd[g].ld, rd[g].ld}, fh[2] = {1.f - rd[g].lh, rd[g].lh}, fw[2] = {1.f - rd[g].lw, rd[g].lw};
+                const unsigned vs = (SAMP && mbase + GG::RPI * g + gr < p.M) ? samp_v0 : DLKA_OOB;
 #pragma unroll
                 for (int v = 0; v < GG::PE / 4; ++v) {
-                    f32x4 dd = {0.f, 0.f, 0.f, 0.f}, dh = {0.f, 0.f, 0.f, 0.f}, dw = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 dd = {0.f, 0.f, 0.f, 0.f}, dh = {0.f, 0.f, 0.f, 0.f}, dw = {0.f, 0.f, 0.f, 0.f}, s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
@@ -361,11 +366,17 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
                         for (int e = 0; e < 4; ++e) {
                             dd[e] = fmaf(kd_, x4[e], dd[e]); dh[e] = fmaf(kh_, x4[e], dh[e]); dw[e] = fmaf(kw_, x4[e], dw[e]);
                         }
+                        if (SAMP) {   // the trilinear sample itself (weights and fma order of gather_weights / cl_wgrad_deform_kernel: bit-equal tiles)
+                            const float ws_ = fd[cd] * fh[ch] * fw[cw];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s4[e] = fmaf(ws_, x4[e], s4[e]);
+                        }
                     }
                     float *dst = Tt + (GG::RPI * g + gr) * SROW + GG::PE * gp + 4 * v;
                     *reinterpret_cast<f32x4 *>(dst) = dd;
                     *reinterpret_cast<f32x4 *>(dst + 32 * SROW) = dh;
                     *reinterpret_cast<f32x4 *>(dst + 2 * 32 * SROW) = dw;
+                    if (SAMP) buf_store_f32x4_s(rsamp, vs, (unsigned)((tap * p.M + GG::RPI * g) * p.C + cc * 32 + 4 * v) * 4u, s4);
                 }
             }
             // the next unit's corner loads go out now: in flight under the dots below, the next staging and the next MFMAs
@@ -784,6 +795,7 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
 {
     if (a.C % 32 || a.CoutP % 32) return DLKA_ERR_UNSUPPORTED;
     if ((long)a.M * a.C * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+    if (a.samp && (long)a.K * a.M * a.C * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;
     if (a.goff) {
         const int mblocks = cdiv(a.M, 128);
         int tsplit = 1;
@@ -806,14 +818,16 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
             else if (nkc == 2) { auto k = cl_deform_goff_kernel<2>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
             else { auto k = cl_deform_goff_kernel<0>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
         } else {
+#define DLKA_GOFF2(NK, TT)                                                                                                           \
+    {                                                                                                                                \
+        if (a.samp) { auto k = cl_deform_goff2_kernel<NK, TT, true>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }           \
+        else { auto k = cl_deform_goff2_kernel<NK, TT, false>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }                 \
+    }
             if (a.act_bf16) {
-                if (nkc == 1) { auto k = cl_deform_goff2_kernel<1, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
-                else if (nkc == 2) { auto k = cl_deform_goff2_kernel<2, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
-                else { auto k = cl_deform_goff2_kernel<0, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
+                if (nkc == 1) DLKA_GOFF2(1, bf16_t) else if (nkc == 2) DLKA_GOFF2(2, bf16_t) else DLKA_GOFF2(0, bf16_t)
             }
-            else if (nkc == 1) { auto k = cl_deform_goff2_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
-            else if (nkc == 2) { auto k = cl_deform_goff2_kernel<2>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
-            else { auto k = cl_deform_goff2_kernel<0>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }
+            else if (nkc == 1) DLKA_GOFF2(1, float) else if (nkc == 2) DLKA_GOFF2(2, float) else DLKA_GOFF2(0, float)
+#undef DLKA_GOFF2
         }
         DLKA_CHECK_LAUNCH();
     }

@@ -312,6 +312,91 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Deformable weight gradient from STORED samples: cl_deform_goff2_kernel (which holds the 8 corners of every (row, tap) anyway)
+// has written S[tap][m][ci] (fp32, WgradArgs::samp), so the contraction  gW[co][ci][tap] = sum_m G[m][co] * S[tap][m][ci]  is a dense
+// stream: per 32-row step a lane loads its 16 G elements and 16 S elements per tap (each wave load = two whole 128-byte rows), the next
+// step's operands are in flight under the current step's 16 * TPW MFMAs.  Same tile / chunk / partial layout as cl_wgrad_deform_kernel,
+// and the same arithmetic: S is produced by the same fma chain, the MFMA order over the rows is the same.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TPW, typename T = float>   // T: storage of the channels-last `g`
+__global__ __launch_bounds__(64, 2) void cl_wgrad_samp_kernel(WgradArgs p)
+{
+    constexpr unsigned XB = sizeof(T);
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    int chunk = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_total) {
+        const int r = xcd_item(blockIdx.x, p.xcd_total);
+        if (r < 0) return;
+        chunk = r / (p.xcd_ny * p.xcd_nz); by = (r / p.xcd_nz) % p.xcd_ny; bz = r % p.xcd_nz;
+    }
+    const int ot = by / p.CT, ct = by % p.CT;
+    const int tap0 = bz * TPW;
+    const int co = ot * 32 + i, ci = ct * 32 + i;
+    const bool want_bias = p.bpart && ct == 0 && bz == 0;
+    const BufRsrc rg = make_rsrc(p.g, (size_t)p.M * p.Cout * XB), rs = make_rsrc(p.samp, (size_t)p.K * p.M * p.Cin * 4);
+
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+
+    const int m_lo = chunk * p.rows_per_chunk;
+    const int m_hi = min(p.M, m_lo + p.rows_per_chunk);
+    float ga[2][16], sv[2][TPW][16];
+    // one per-lane offset per operand (rows 16h.., column co / ci); the row step and the tap go through the wave-uniform offset
+    const unsigned vg = co < p.Cout ? (unsigned)(16 * h * p.Cout + co) * XB : DLKA_OOB, vs = (unsigned)(16 * h * p.Cin + ci) * 4u;
+    unsigned tapbit[TPW];   // 0, or the out-of-range bit for taps past K (uniform)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) tapbit[t] = tap0 + t < p.K ? 0u : DLKA_OOB;
+    auto load_step = [&](int buf, int mbase) {
+        const int lim = m_hi - mbase - 16 * h;   // rows of this half-wave inside the chunk (ragged only at m_hi == M)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const unsigned rowbit = s < lim ? 0u : DLKA_OOB;   // offsets are < 2^31: OR-ing the top bit sends the load out of range -> 0
+            ga[buf][s] = act_buf_load1_s<T>(rg, vg | rowbit, (unsigned)((mbase + s) * p.Cout) * XB);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                sv[buf][t][s] = buf_load_f32_s(rs, vs | rowbit | tapbit[t], (unsigned)(((tap0 + t) * p.M + mbase + s) * p.Cin) * 4u);
+        }
+    };
+    auto compute = [&](int buf) {
+        if (want_bias) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) bsum += ga[buf][s];
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc[t] = mfma_32x32x2(ga[buf][s], sv[buf][t][s], acc[t]);
+    };
+    if (m_lo < m_hi) load_step(0, m_lo);
+    for (int mbase = m_lo; mbase < m_hi; mbase += 64) {   // two steps per trip: the register buffers are addressed statically
+        if (mbase + 32 < m_hi) load_step(1, mbase + 32);
+        compute(0);
+        if (mbase + 32 < m_hi) {
+            if (mbase + 64 < m_hi) load_step(0, mbase + 64);
+            compute(1);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tap = tap0 + t;
+        if (tap >= p.K) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            p.part[(((long)chunk * p.K + tap) * p.CoutP + ot * 32 + row) * p.Cin + ct * 32 + i] = acc[t][r];
+        }
+    }
+    if (want_bias) {
+        bsum += __shfl_xor(bsum, 32);
+        if (h == 0) p.bpart[(long)chunk * p.CoutP + co] = bsum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Dense (plain-neighbour) weight gradient, second generation.  One wave owns COT co-tiles x TPW taps x one 32-channel
 // ci-tile: the B operand (input rows of a tap) is loaded once and feeds COT MFMA chains, the A operand (grad_out rows of
 // a co-tile) once and feeds TPW chains -> (COT + TPW) * 16 loads per COT * TPW * 16 MFMAs per 32-row step (3x3: 96 / 144
@@ -667,7 +752,12 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
             a.xcd_ny = grid.y; a.xcd_nz = grid.z; a.xcd_total = (int)(grid.x * grid.y * grid.z);
             grid = dim3(xcd_grid(a.xcd_total), 1, 1);
         }
-        if (a.act_bf16) {
+        if (a.samp) {   // samples stored by the grad_offset kernel: dense stream, no gather
+            if (pl.tpw != 3 || (long)a.K * a.M * a.Cin * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets below DLKA_OOB
+            if (a.act_bf16) { auto k = cl_wgrad_samp_kernel<3, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+            else { auto k = cl_wgrad_samp_kernel<3>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        }
+        else if (a.act_bf16) {
             if (v1 || pl.tpw != 3) return DLKA_ERR_UNSUPPORTED;
             auto k = cl_wgrad_deform_kernel<3, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, a);
         }

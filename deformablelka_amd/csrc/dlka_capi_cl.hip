@@ -271,19 +271,21 @@ int deform_bwd_variant() { return 0; }   // (two earlier generations — one fus
 
 int deform_backward(const SameConv &s, const float *x, const float *off, const float *w, const float *gout, float *gx, float *goff,
                     float *gw, float *gb, float *wp, float *part, float *scratch, hipStream_t st, FinalizeJob *defer = nullptr, bool gx_zeroed = false,
-                    bool goff_zeroed = false, int goff_cpad = 0)
+                    bool goff_zeroed = false, int goff_cpad = 0, float *samp = nullptr)
 {
+    // samp ([K][M][C] fp32): a grad_offset call stores the trilinear samples there, a weight-gradient call reads them instead of gathering again
     if (gx || goff) {
         if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cout, s.Cin, 2, st));
         DeformBwdArgs a;
         fill_deform_bwd(a, s);
         a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff; a.gx_zeroed = gx_zeroed ? 1 : 0; a.goff_zeroed = goff_zeroed ? 1 : 0; a.goff_cpad = goff_cpad;
+        a.samp = goff ? samp : nullptr;
         DLKA_TRY(launch_cl_deform_bwd2(a, scratch, st));
     }
     if (gw) {
         WgradArgs a;
         memset(&a, 0, sizeof(a));
-        a.g = gout; a.in = x; a.off = off; a.part = part;
+        a.g = gout; a.in = x; a.off = off; a.part = part; a.samp = samp;
         a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.Cin = s.Cin; a.Cout = s.Cout;
         a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
         a.act_bf16 = s.act_bf16;
@@ -330,6 +332,13 @@ struct TokGeoms {
         return m;
     }
     size_t scratch_floats() const { return deform_scratch_floats(dcn); }
+    // the deformable conv's samples S[tap][m][c], handed from the grad_offset kernel to the weight gradient (0: too large for 32-bit buffer
+    // offsets, or switched off — the weight gradient then gathers for itself)
+    size_t samp_floats() const
+    {
+        const size_t n = (size_t)dcn.K * dcn.M * dcn.Cin;
+        return (n * 4 < ((size_t)1 << 31) && getenv("DLKA_WGRAD_GATHER") == nullptr) ? n : 0;
+    }
     // prepared weights, kept in `saved` from the forward to the backward call (floats)
     size_t pw_floats() const { return (size_t)pw.Cin * pw.Cin; }
     size_t offc_floats() const { return dense_wp_floats(offc); }
@@ -774,7 +783,7 @@ size_t dlka_lka3d_tokens_workspace_bytes(int B, int C, int D, int H, int W, int 
     if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return 0;
     TokGeoms G(B, C, D, H, W, dtype);   // (the eight gradient buffers keep their fp32 size on the bf16 path: gta and the split scratch ARE fp32)
     return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 8 * align256(G.E * 4) + align256(G.GOff * 4) +
-           align256(G.scratch_floats() * 4) + align256(4096);
+           align256(G.scratch_floats() * 4) + align256(G.samp_floats() * 4) + align256(4096);
 }
 
 static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void *y_, void *saved, size_t saved_bytes, void *workspace,
@@ -931,6 +940,7 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     float *gt = (float *)cv.take(G.E * 4), *gt1 = (float *)cv.take(G.E * 4), *ga2 = (float *)cv.take(G.E * 4), *gh = (float *)cv.take(G.E * 4);
     float *goff = (float *)cv.take(G.GOff * 4);
     float *scratch = (float *)cv.take(G.scratch_floats() * 4);
+    float *samp = G.samp_floats() ? (float *)cv.take(G.samp_floats() * 4) : nullptr;
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const float *x = (const float *)x_, *gy = (const float *)gy_;
     float *gx = (float *)gx_;
@@ -990,11 +1000,16 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     // conv1:  g1 = P0 f
     DLKA_TRY(dense_backward_data(G.pw, gg1, 0, N0, gf, PW.pw_b[1], 0, nullptr, st, nullptr, nullptr, true));
     DLKA_TRY(publish());
-    // deformable conv:  f = DCN(t, off):  weight gradient on the side stream, grad_offset and grad_input on the main one
-    DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
-                             &fb.j[fb.njobs++]));
-    DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, goff, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, false, true, goff_cpad));
+    // deformable conv:  f = DCN(t, off):  grad_offset and grad_input on the main stream, the weight gradient on the side one — after
+    // grad_offset when that kernel hands over the samples it interpolated (samp), else at once with its own gather
+    if (!samp)
+        DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
+                                 &fb.j[fb.njobs++]));
+    DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, goff, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, false, true, goff_cpad, samp));
     DLKA_TRY(publish());
+    if (samp)
+        DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
+                                 &fb.j[fb.njobs++], false, false, 0, samp));
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
     DLKA_TRY(dense_backward_weight(G.offc, t, goff, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, ws_, &fb.j[fb.njobs++], goff_cpad));
     DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, true));

@@ -40,6 +40,10 @@ template <> __device__ __forceinline__ f32x4 act_buf_load4<bf16_t>(BufRsrc r, un
 template <typename T> __device__ __forceinline__ float act_buf_load1(BufRsrc r, unsigned byteoff);
 template <> __device__ __forceinline__ float act_buf_load1<float>(BufRsrc r, unsigned byteoff) { return buf_load_f32(r, byteoff); }
 template <> __device__ __forceinline__ float act_buf_load1<bf16_t>(BufRsrc r, unsigned byteoff) { return buf_load_bf16(r, byteoff); }
+// the same with a wave-uniform offset on top of the (range-checked) per-lane one — see buf_load_f32_s
+template <typename T> __device__ __forceinline__ float act_buf_load1_s(BufRsrc r, unsigned voff, unsigned soff);
+template <> __device__ __forceinline__ float act_buf_load1_s<float>(BufRsrc r, unsigned voff, unsigned soff) { return buf_load_f32_s(r, voff, soff); }
+template <> __device__ __forceinline__ float act_buf_load1_s<bf16_t>(BufRsrc r, unsigned voff, unsigned soff) { return buf_load_bf16_s(r, voff, soff); }
 // pointer flavours: element index, 4 consecutive elements (aligned to 4 elements)
 struct alignas(8) ActU2 { unsigned x, y; };
 __device__ __forceinline__ f32x4 act_load4(const float *p, long i) { return *reinterpret_cast<const f32x4 *>(p + i); }

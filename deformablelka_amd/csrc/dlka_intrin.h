@@ -73,6 +73,12 @@ __device__ __forceinline__ float buf_load_f32_s(BufRsrc r, unsigned voff, unsign
     if (!(voff < r.bytes)) return 0.f;
     return buf_load_f32(r, voff + soff);
 }
+// 16-byte store with the same addressing: dropped when voff is out of range (DLKA_OOB)
+__device__ __forceinline__ void buf_store_f32x4_s(BufRsrc r, unsigned voff, unsigned soff, f32x4 v)
+{
+    if (!(voff < r.bytes) || (size_t)voff + soff + 16 > r.bytes) return;
+    memcpy(const_cast<unsigned char *>(r.base) + voff + soff, &v, 16);
+}
 // ---- bf16 activation storage (DLKA_BF16 token path): 4 consecutive bf16 -> 4 floats, one 8-byte buffer load ----
 __device__ __forceinline__ f32x4 buf_load_bf16x4(BufRsrc r, unsigned off)
 {
@@ -89,6 +95,11 @@ __device__ __forceinline__ float buf_load_bf16(BufRsrc r, unsigned off)
     unsigned short h = 0;
     if (off < r.bytes && off + 2 <= r.bytes) memcpy(&h, r.base + off, 2);
     return hipemu::hipemu_bf16_to_f32(h);
+}
+__device__ __forceinline__ float buf_load_bf16_s(BufRsrc r, unsigned voff, unsigned soff)
+{
+    if (!(voff < r.bytes)) return 0.f;
+    return buf_load_bf16(r, voff + soff);
 }
 // 8 consecutive bf16 (one 16-byte load) -> lo = elements 0..3, hi = 4..7
 __device__ __forceinline__ void buf_load_bf16x8(BufRsrc r, unsigned off, f32x4 &lo, f32x4 &hi)
@@ -174,6 +185,11 @@ __device__ __forceinline__ float buf_load_f32_s(BufRsrc r, unsigned voff, unsign
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+__device__ __forceinline__ void buf_store_f32x4_s(BufRsrc r, unsigned voff, unsigned soff, f32x4 v)
+{
+    typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) raw128_t;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw128_t, v), r, voff, soff, 0);
+}
 // ---- bf16 activation storage (DLKA_BF16 token path): 4 consecutive bf16 -> 4 floats, one 8-byte buffer load ----
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -188,6 +204,10 @@ __device__ __forceinline__ f32x4 buf_load_bf16x4(BufRsrc r, unsigned off)
 __device__ __forceinline__ float buf_load_bf16(BufRsrc r, unsigned off)
 {
     return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0) << 16);
+}
+__device__ __forceinline__ float buf_load_bf16_s(BufRsrc r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0) << 16);
 }
 // 8 consecutive bf16 (one 16-byte load) -> lo = elements 0..3, hi = 4..7
 __device__ __forceinline__ void buf_load_bf16x8(BufRsrc r, unsigned off, f32x4 &lo, f32x4 &hi)

@@ -270,6 +270,44 @@ def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=2e-4, rtol
             assert_close("tokens grad " + k, p.grad, g, rtol=4 * rtol if "conv_offset" in k else rtol)
 
 
+def check_lka3d_tokens_sample_handover(dev, B, C, dims, dtype=torch.float32, seed=0, offset_std=0.3):
+    """The deformable conv's weight gradient from the samples the grad_offset kernel stores (default) against the weight-gradient kernel that
+    gathers for itself (DLKA_WGRAD_GATHER=1): same fma chain for every sample, same MFMA order over the rows -> the two agree to summation
+    order, and no other gradient notices the switch."""
+    import deformablelka_amd as dk
+    from oracle import blocks
+    torch.manual_seed(seed)
+    H, W, D = dims
+    m = dk.LKA_Attention3d_deform(C)
+    blocks.randomize_offsets_(m, std=offset_std)
+    m = m.to(dev)
+    x = torch.randn(B, H * W * D, C).to(dev).to(dtype)
+    gy = torch.randn(B, H * W * D, C).to(dev).to(dtype)
+
+    def run():
+        for q in m.parameters():
+            q.grad = None
+        xd = x.clone().requires_grad_(True)
+        m(xd, B, C, H, W, D).backward(gy)
+        return {"x": xd.grad.float().cpu(), **{k: q.grad.detach().float().cpu().clone() for k, q in m.named_parameters()}}
+
+    old = os.environ.get("DLKA_WGRAD_GATHER")
+    try:
+        os.environ.pop("DLKA_WGRAD_GATHER", None)
+        g_s = run()
+        os.environ["DLKA_WGRAD_GATHER"] = "1"
+        g_g = run()
+    finally:
+        if old is None:
+            os.environ.pop("DLKA_WGRAD_GATHER", None)
+        else:
+            os.environ["DLKA_WGRAD_GATHER"] = old
+    k = "spatial_gating_unit.deform_conv.weight"
+    assert g_s[k].abs().max() > 0
+    for name in g_s:   # (not bit-equal at block level: upstream tap-split partial sums meet in atomics, so grad_out itself moves by ~1e-7 per run)
+        assert rel_err(g_s[name], g_g[name]) < (1e-5 if dtype == torch.float32 else 2e-2), (name, rel_err(g_s[name], g_g[name]))
+
+
 def check_lka2d_attention(dev, B, C, H, W, seed=0, offset_std=0.03, atol=2e-4, rtol=2e-3, report=False):
     """deformable_LKA_Attention (2D/deformable_LKA/deformable_LKA.py:124-140) vs the oracle block; widths with C % 32 == 0 take the
     channels-last fast path (MFMA offset nets + cl_ddw2d.hip), the rest the general NCHW kernels."""

@@ -235,3 +235,13 @@ def test_stack_with_hoisted_weight_preparation_equals_per_block_calls():
                                                      st.ws_bytes, st.B, blk.C, H, W, D, st.dt, None)
         assert rc == 0
         assert torch.allclose(y, y_ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("C,dims", [(32, (4, 4, 4)), (64, (3, 4, 5))])
+def test_lka3d_tokens_weight_gradient_from_stored_samples(C, dims):
+    parity.check_lka3d_tokens_sample_handover("cpu", 1, C, dims)
+
+
+def test_lka3d_tokens_weight_gradient_from_stored_samples_bf16():
+    parity.check_lka3d_tokens_sample_handover("cpu", 1, 32, (4, 4, 4), dtype=torch.bfloat16)
+

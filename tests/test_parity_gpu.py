@@ -369,3 +369,10 @@ def test_tblock3d_vs_oracle(C, dims, training, pos):
 
 def test_tblock3d_chain():
     parity.check_tblock3d(DEV, 1, 32, (6, 8, 10), True, True, chain=True)
+
+
+@pytest.mark.parametrize("C,dims,dtype", [(32, (32, 32, 32), torch.float32), (64, (16, 16, 16), torch.float32), (256, (4, 4, 4), torch.float32),
+                                          (32, (16, 16, 16), torch.bfloat16)])
+def test_lka3d_tokens_weight_gradient_from_stored_samples(C, dims, dtype):
+    parity.check_lka3d_tokens_sample_handover(DEV, 2, C, dims, dtype=dtype)
+
