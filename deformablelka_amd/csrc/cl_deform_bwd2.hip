@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void cl_deform_goff_kernel(DeformBwdArgs p, in
 // (An intermediate version kept Col in the gather layout and reduced 8-lane groups with DPP; it needed 435 registers,
 //  ran one wave per SIMD and was no faster than the first kernel.)
 // ---------------------------------------------------------------------------------------------------------------------
-// SAMP: also store the samples S[tap][m][c] (DeformBwdArgs::samp) for the weight gradient
+// SAMP: also store the samples S[tap][m][c] (DeformBwdArgs::samp) for the weight gradient.  Always with NKC_REG = 0 (grad_out rows re-read per
+// unit instead of held in registers): the sample accumulators need the room — with NKC_REG = 1 the kernel spilled 250 bytes per lane.
 template <int NKC_REG, typename T = float, bool SAMP = false>   // T: storage of `in` and `g` (channels-last); offsets / grad_offset are fp32 planar
 __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p, int taps_per_block)
 {
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
     // samples for the weight gradient: S[tap][m][c], this lane's rows mbase + RPI*g + gr, channels PE*gp .. of the current chunk
     const BufRsrc rsamp = make_rsrc(p.samp, SAMP ? (size_t)p.K * p.M * p.C * 4 : 0);
     const unsigned samp_v0 = (unsigned)((mbase + gr) * p.C + GG::PE * gp) * 4u;
+    const bool tile_full = mbase + 32 <= p.M;   // wave-uniform: only the last tile of a ragged M needs per-row checks
 
     if (p.goff_cpad && blockIdx.y == 0 && blockIdx.z == 0 && h == 0 && row_ok) {   // the zero planes 3K .. goff_cpad-1 of the packed layout
         float *dst = p.goff + ((long)b * p.goff_cpad + 3 * p.K) * p.N + v;
@@ -348,12 +350,13 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
                     for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], gl[st], acc);
                 }
             }
-            // ---- 2. derivative samples of this lane's 4 gather rows -> LDS tiles ----
+            // ---- 2. derivative samples of this lane's 4 gather rows -> LDS tiles (SAMP: and the sample itself -> S) ----
+            // (a separate pass for the samples was tried to shorten live ranges: the scheduler interleaved it anyway, 700 bytes of spills)
             wave_sync();   // previous tiles consumed
 #pragma unroll
             for (int g = 0; g < GG::NG; ++g) {
                 const float fd[2] = {1.f - rd[g].ld, rd[g].ld}, fh[2] = {1.f - rd[g].lh, rd[g].lh}, fw[2] = {1.f - rd[g].lw, rd[g].lw};
-                const unsigned vs = (SAMP && mbase + GG::RPI * g + gr < p.M) ? samp_v0 : DLKA_OOB;
+                const bool srow = SAMP && (tile_full || mbase + GG::RPI * g + gr < p.M);
 #pragma unroll
                 for (int v = 0; v < GG::PE / 4; ++v) {
                     f32x4 dd = {0.f, 0.f, 0.f, 0.f}, dh = {0.f, 0.f, 0.f, 0.f}, dw = {0.f, 0.f, 0.f, 0.f}, s4 = {0.f, 0.f, 0.f, 0.f};
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
                     *reinterpret_cast<f32x4 *>(dst) = dd;
                     *reinterpret_cast<f32x4 *>(dst + 32 * SROW) = dh;
                     *reinterpret_cast<f32x4 *>(dst + 2 * 32 * SROW) = dw;
-                    if (SAMP) buf_store_f32x4_s(rsamp, vs, (unsigned)((tap * p.M + GG::RPI * g) * p.C + cc * 32 + 4 * v) * 4u, s4);
+                    if (SAMP) buf_store_f32x4(rsamp, srow ? samp_v0 + (unsigned)((tap * p.M + GG::RPI * g) * p.C + cc * 32 + 4 * v) * 4u : DLKA_OOB, s4);
                 }
             }
             // the next unit's corner loads go out now: in flight under the dots below, the next staging and the next MFMAs
@@ -820,7 +823,7 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         } else {
 #define DLKA_GOFF2(NK, TT)                                                                                                           \
     {                                                                                                                                \
-        if (a.samp) { auto k = cl_deform_goff2_kernel<NK, TT, true>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }           \
+        if (a.samp) { auto k = cl_deform_goff2_kernel<0, TT, true>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }            \
         else { auto k = cl_deform_goff2_kernel<NK, TT, false>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }                 \
     }
             if (a.act_bf16) {

@@ -73,11 +73,11 @@ __device__ __forceinline__ float buf_load_f32_s(BufRsrc r, unsigned voff, unsign
     if (!(voff < r.bytes)) return 0.f;
     return buf_load_f32(r, voff + soff);
 }
-// 16-byte store with the same addressing: dropped when voff is out of range (DLKA_OOB)
-__device__ __forceinline__ void buf_store_f32x4_s(BufRsrc r, unsigned voff, unsigned soff, f32x4 v)
+// 16-byte store, dropped when the offset is out of range (DLKA_OOB)
+__device__ __forceinline__ void buf_store_f32x4(BufRsrc r, unsigned off, f32x4 v)
 {
-    if (!(voff < r.bytes) || (size_t)voff + soff + 16 > r.bytes) return;
-    memcpy(const_cast<unsigned char *>(r.base) + voff + soff, &v, 16);
+    if (!(off < r.bytes) || (size_t)off + 16 > r.bytes) return;
+    memcpy(const_cast<unsigned char *>(r.base) + off, &v, 16);
 }
 // ---- bf16 activation storage (DLKA_BF16 token path): 4 consecutive bf16 -> 4 floats, one 8-byte buffer load ----
 __device__ __forceinline__ f32x4 buf_load_bf16x4(BufRsrc r, unsigned off)
@@ -185,10 +185,14 @@ __device__ __forceinline__ float buf_load_f32_s(BufRsrc r, unsigned voff, unsign
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
-__device__ __forceinline__ void buf_store_f32x4_s(BufRsrc r, unsigned voff, unsigned soff, f32x4 v)
+// No wave-uniform (SGPR) offset variant for stores, on purpose.  Measured on the MI355X (scripts/debug_samp.py, round 2): with an SGPR soffset the
+// compiler (ROCm 7.2 clang) assumes the "VALU overwrites the data registers of a > 64-bit VMEM store" hazard away and schedules such a VALU
+// write directly behind buffer_store_dwordx4 — lanes 8-15 / 24-31 / 40-47 / 56-63 then stored the NEW register contents.  With the whole offset
+// in the VGPR (soffset = literal 0) the hazard recogniser inserts the wait state.
+__device__ __forceinline__ void buf_store_f32x4(BufRsrc r, unsigned off, f32x4 v)
 {
     typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) raw128_t;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw128_t, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw128_t, v), r, off, 0, 0);
 }
 // ---- bf16 activation storage (DLKA_BF16 token path): 4 consecutive bf16 -> 4 floats, one 8-byte buffer load ----
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
