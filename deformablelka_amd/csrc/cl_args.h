@@ -32,7 +32,7 @@ struct WgradArgs {
     const float *g;
     const float *in;    // [B][N][Cin] channels-last
     const float *off;   // AMODE 1: planar offsets [B][3K][N]
-    const float *samp;  // AMODE 1, optional: [K][M][Cin] fp32 samples stored by cl_deform_goff2_kernel (DeformBwdArgs::samp) — no gather
+    const float *samp;  // AMODE 1, optional: [K][M][Cin] samples (fp32; bf16 when act_bf16) stored by cl_deform_goff2_kernel (DeformBwdArgs::samp) — no gather
     float *part;        // [chunks][K][CoutP][Cin] partial weight-gradient tiles, followed by [chunks][CoutP] partial bias sums
     float *bpart;       // = part + chunks*K*CoutP*Cin when the bias gradient is wanted, else null (set by the launcher)
     int B, D, H, W, N, M;
@@ -121,7 +121,7 @@ struct DeformBwdArgs {
     const float *wp;    // [K][CoutP][C]: wp[tap][co][ci] = W[co][ci][tap], rows co >= Cout are zero
     float *gx;          // [B][N][C] fp32, zero-initialised (atomics)
     float *goff;        // [B][3K][N] planar
-    float *samp;        // optional [K][M][C] fp32: the grad_offset kernel also stores the trilinear samples S(m, tap, c) it has the corners of —
+    float *samp;        // optional [K][M][C], fp32 (bf16 when act_bf16): the grad_offset kernel also stores the trilinear samples S(m, tap, c) it has the corners of —
                         //   the deformable weight gradient then contracts G^T S as a dense stream instead of gathering again (cl_wgrad_samp_kernel)
     int B, D, H, W, N, M;
     int C, Cout, CoutP;

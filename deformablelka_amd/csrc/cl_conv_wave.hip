@@ -15,9 +15,12 @@
 
 namespace dlka {
 
-template <int AMODE, int OMODE, int NT, int SPLIT, int DEPTH>
+// T: storage of a channels-last `in` (AMODE 0).  bf16 rows are their own high term: the two-term contraction drops the a_lo product.
+// (bf16 storage is wired for the planar-output forward only — the offset-predict conv; outputs of the other modes stay fp32.)
+template <int AMODE, int OMODE, int NT, int SPLIT, int DEPTH, typename T = float>
 __global__ __launch_bounds__(256) void cl_conv_wave_kernel(IgemmArgs p)
 {
+    constexpr bool A16 = AMODE == 0 && sizeof(T) == 2;
     constexpr int NPB = NT * 32;
     constexpr int UF = SPLIT == 3 ? 48 : 32;      // floats of prepared weights per unit and column
     constexpr int NB = 2 * SPLIT * NT;            // B records (16 bytes) per lane and unit
@@ -43,12 +46,12 @@ __global__ __launch_bounds__(256) void cl_conv_wave_kernel(IgemmArgs p)
     const int nchunk = p.CinP / 32;
     const int unit_lo = blockIdx.y * p.units_per_split;
     const int unit_hi = min(p.K * nchunk, unit_lo + p.units_per_split);
-    const BufRsrc rin = make_rsrc(p.in, AMODE == 2 ? (size_t)p.B * p.CinReal * p.N * 4 : (size_t)p.M * p.Cin * 4);
+    const BufRsrc rin = make_rsrc(p.in, AMODE == 2 ? (size_t)p.B * p.CinReal * p.N * 4 : (size_t)p.M * p.Cin * sizeof(T));
     const BufRsrc rw = make_rsrc(p.wp, (size_t)p.K * nchunk * UF * p.NP * 4);
     const unsigned unit_bytes = (unsigned)(UF * p.NP) * 4u, seg_bytes = (unsigned)p.NP * 16u;
     const unsigned blane = (unsigned)(h * p.NP + n0 + i) * 16u;   // this lane's record inside segment (part, mf)
 
-    ARow<AMODE> arow;
+    ARow<AMODE, T> arow;
     float abuf[DEPTH][16];
     f32x4 bbuf[DEPTH][NB];   // [(part * 2 + mf) * NT + t]
     // A rows and B records of one unit into a register set (all loads unconditional buffer loads)
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void cl_conv_wave_kernel(IgemmArgs p)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const bf16x8 bhi = __builtin_bit_cast(bf16x8, b_cur[(0 * 2 + mf) * NT + t]), blo = __builtin_bit_cast(bf16x8, b_cur[(1 * 2 + mf) * NT + t]);
-                    acc[t] = mfma_32x32x16_bf16(alo, bhi, acc[t]);
+                    if (!A16) acc[t] = mfma_32x32x16_bf16(alo, bhi, acc[t]);
                     acc[t] = mfma_32x32x16_bf16(ahi, blo, acc[t]);
                     acc[t] = mfma_32x32x16_bf16(ahi, bhi, acc[t]);
                 }
@@ -113,19 +116,19 @@ __global__ __launch_bounds__(256) void cl_conv_wave_kernel(IgemmArgs p)
     // ---- epilogue (same contract as cl_igemm_kernel): D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
     const bool split = gridDim.y > 1;
     if (OMODE == 1) {   // planar output [B][Cout][N]: transpose each tile through a wave-private LDS tile so that lanes run over voxels
-        float *T = Tsm + wave * (32 * 33);
+        float *Tt = Tsm + wave * (32 * 33);
         const bool rok = row_ok;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             wave_sync();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + i] = acc[t][r];
+            for (int r = 0; r < 16; ++r) Tt[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + i] = acc[t][r];
             wave_sync();
 #pragma unroll
             for (int cc = 0; cc < 16; ++cc) {
                 const int col = 2 * cc + h, n = n0 + t * 32 + col;
                 if (n >= p.Cout) continue;   // uniform per half-wave
-                float val = T[i * 33 + col];
+                float val = Tt[i * 33 + col];
                 if (p.bias && blockIdx.y == 0) val += p.bias[n];
                 if (!rok) continue;
                 float *dst = p.out + ((long)b * p.Cout + n) * p.N + v;
@@ -176,8 +179,11 @@ int launch_cl_conv_wave(int amode, int omode, const IgemmArgs &a, int splits, hi
         // but 46 vs 52 at C=64/16^3 and 28 vs 39 at C=128/8^3; data gradient (two-term) 88 vs 104 at C=32/32^3, equal elsewhere.  A deeper
         // register ring (3 stages) changed nothing: these launches are not waiting on latency.
         if (a.split_bf16 == 3 && a.M > 16384) return DLKA_ERR_UNSUPPORTED;
-        if (a.split_bf16 == 2 && NT_total != 1) return DLKA_ERR_UNSUPPORTED;
+        if (a.split_bf16 == 2 && NT_total != 1 && !a.act_bf16) return DLKA_ERR_UNSUPPORTED;
+        // bf16 activations: the offset-predict conv forward only, where the fp32 path takes this kernel too (its three-term variant)
+        if (a.act_bf16 && !(amode == 0 && omode == 1 && a.split_bf16 == 2 && a.M <= 16384)) return DLKA_ERR_UNSUPPORTED;
     }
+    if (a.act_bf16 && (NT != 1 || DEPTH != 2)) return DLKA_ERR_UNSUPPORTED;
     if (NT < 1 || NT > 3 || NT_total % NT || (DEPTH != 2 && DEPTH != 3)) return DLKA_ERR_UNSUPPORTED;
     dim3 grid(cdiv(a.M, 128), splits, NT_total / NT), block(256);
     IgemmArgs ax = a;
@@ -197,7 +203,10 @@ int launch_cl_conv_wave(int amode, int omode, const IgemmArgs &a, int splits, hi
         else if (DEPTH == 2) DLKA_CW(AM, OM, 3, SP, 2)                      \
         else return DLKA_ERR_UNSUPPORTED;                                   \
     }
-    if (a.split_bf16 == 3) {
+    if (a.act_bf16) {
+        auto k = cl_conv_wave_kernel<0, 1, 1, 2, 2, bf16_t>;
+        hipLaunchKernelGGL(k, grid, block, 0, st, ax);
+    } else if (a.split_bf16 == 3) {
         if (amode == 0 && omode == 1) DLKA_CW_NT(0, 1, 3)
         else if (amode == 0 && omode == 0) DLKA_CW_NT(0, 0, 3)
         else return DLKA_ERR_UNSUPPORTED;

@@ -242,8 +242,9 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
     const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.C * XB);
     float *Tt = &Tsm[wave][0][0], *Dt = Dsm[wave];
     // samples for the weight gradient: S[tap][m][c], this lane's rows mbase + RPI*g + gr, channels PE*gp .. of the current chunk
-    const BufRsrc rsamp = make_rsrc(p.samp, SAMP ? (size_t)p.K * p.M * p.C * 4 : 0);
-    const unsigned samp_v0 = (unsigned)((mbase + gr) * p.C + GG::PE * gp) * 4u;
+    // (S has the storage type of the activations: fp32, or bf16 on the DLKA_BF16 path)
+    const BufRsrc rsamp = make_rsrc(p.samp, SAMP ? (size_t)p.K * p.M * p.C * XB : 0);
+    const unsigned samp_v0 = (unsigned)((mbase + gr) * p.C + GG::PE * gp) * XB;
     const bool tile_full = mbase + 32 <= p.M;   // wave-uniform: only the last tile of a ragged M needs per-row checks
 
     if (p.goff_cpad && blockIdx.y == 0 && blockIdx.z == 0 && h == 0 && row_ok) {   // the zero planes 3K .. goff_cpad-1 of the packed layout
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
             for (int g = 0; g < GG::NG; ++g) {
                 const float fd[2] = {1.f - rd[g].ld, rd[g].ld}, fh[2] = {1.f - rd[g].lh, rd[g].lh}, fw[2] = {1.f - rd[g].lw, rd[g].lw};
                 const bool srow = SAMP && (tile_full || mbase + GG::RPI * g + gr < p.M);
+                f32x4 s4_lo = {0.f, 0.f, 0.f, 0.f};   // bf16 storage: the piece's first four samples wait for the other four (one 16-byte store)
 #pragma unroll
                 for (int v = 0; v < GG::PE / 4; ++v) {
                     f32x4 dd = {0.f, 0.f, 0.f, 0.f}, dh = {0.f, 0.f, 0.f, 0.f}, dw = {0.f, 0.f, 0.f, 0.f}, s4 = {0.f, 0.f, 0.f, 0.f};
@@ -379,7 +381,8 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
                     *reinterpret_cast<f32x4 *>(dst) = dd;
                     *reinterpret_cast<f32x4 *>(dst + 32 * SROW) = dh;
                     *reinterpret_cast<f32x4 *>(dst + 2 * 32 * SROW) = dw;
-                    if (SAMP) buf_store_f32x4(rsamp, srow ? samp_v0 + (unsigned)((tap * p.M + GG::RPI * g) * p.C + cc * 32 + 4 * v) * 4u : DLKA_OOB, s4);
+                    if (SAMP && XB == 4) buf_store_f32x4(rsamp, srow ? samp_v0 + (unsigned)((tap * p.M + GG::RPI * g) * p.C + cc * 32 + 4 * v) * 4u : DLKA_OOB, s4);
+                    if (SAMP && XB == 2) { if (v == 0) s4_lo = s4; else buf_store_bf16x8(rsamp, srow ? samp_v0 + (unsigned)((tap * p.M + GG::RPI * g) * p.C + cc * 32) * 2u : DLKA_OOB, s4_lo, s4); }
                 }
             }
             // the next unit's corner loads go out now: in flight under the dots below, the next staging and the next MFMAs
@@ -798,7 +801,7 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
 {
     if (a.C % 32 || a.CoutP % 32) return DLKA_ERR_UNSUPPORTED;
     if ((long)a.M * a.C * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
-    if (a.samp && (long)a.K * a.M * a.C * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;
+    if (a.samp && (long)a.K * a.M * a.C * (a.act_bf16 ? 2 : 4) >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;
     if (a.goff) {
         const int mblocks = cdiv(a.M, 128);
         int tsplit = 1;

@@ -406,7 +406,11 @@ int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t s
     }
     if (a.act_bf16) {   // bf16 activation storage (DLKA_BF16 token path): the two 27-tap convs of the block, two-term weight layout
         if (a.split_bf16 != 2) return DLKA_ERR_UNSUPPORTED;
-        if (amode == 0 && omode == 1) return launch_igemm_nt<0, 1, 2, bf16_t>(a, splits, st);   // offset-predict conv forward (fp32 planar out)
+        if (amode == 0 && omode == 1) {   // offset-predict conv forward (fp32 planar out): wave-granular kernel where the fp32 path uses it too
+            const int rc = launch_cl_conv_wave(amode, omode, a, splits, st);
+            if (rc != DLKA_ERR_UNSUPPORTED) return rc;
+            return launch_igemm_nt<0, 1, 2, bf16_t>(a, splits, st);
+        }
         if (amode == 2 && omode == 0) return launch_igemm_nt<2, 0, 2, bf16_t>(a, splits, st);   // its data gradient (fp32 planar in, bf16 out)
         return DLKA_ERR_UNSUPPORTED;
     }

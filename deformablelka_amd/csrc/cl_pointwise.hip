@@ -34,13 +34,34 @@ __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
     // load latency -> MFMAs -> a second load latency for them
     float auxv[16], aux2v[16];
     const bool n_ok = n < p.Cout;
+    // bf16 storage: 2-byte accesses were the slow part of this kernel (10.5 vs 7.7 us against fp32 at C=64 / 16^3).  Rows come in pairs
+    // (r, r + 1) = (R, R + 1); the even lane of a column pair handles row R, the odd lane row R + 1, each with ONE dword holding both columns
+    // of the pair, and the halves that belong to the neighbour cross over with one DPP move.
+    constexpr bool B16 = sizeof(T) == 2;
+    const bool odd = i & 1;
+    auto pair_load = [&](const T *src, int r, float &x0, float &x1) {   // src[R][n], src[R + 1][n] for this lane's column n
+        const int mrow = mbase + (r & 3) + 8 * (r >> 2) + 4 * h + (odd ? 1 : 0);
+        const unsigned own = (n_ok && mrow < p.M) ? *reinterpret_cast<const unsigned *>(src + ((long)mrow * p.Cout + (n & ~1))) : 0u;
+        const unsigned oth = lane_xor1(own);
+        x0 = __uint_as_float(odd ? (oth & 0xffff0000u) : (own << 16));
+        x1 = __uint_as_float(odd ? (own & 0xffff0000u) : (oth << 16));
+    };
     if (p.epi >= 2) {   // uniform
+        if (B16) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mr = mbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const bool ok = n_ok && mr < p.M;
-            auxv[r] = ok ? act_load1(auxp, (long)mr * p.Cout + n) : 0.f;
-            aux2v[r] = (ok && p.epi == 4) ? act_load1(aux2p, (long)mr * p.Cout + n) : 0.f;
+            for (int r = 0; r < 16; r += 2) {
+                pair_load(auxp, r, auxv[r], auxv[r + 1]);
+                if (p.epi == 4) pair_load(aux2p, r, aux2v[r], aux2v[r + 1]);
+                else aux2v[r] = aux2v[r + 1] = 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mr = mbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const bool ok = n_ok && mr < p.M;
+                auxv[r] = ok ? act_load1(auxp, (long)mr * p.Cout + n) : 0.f;
+                aux2v[r] = (ok && p.epi == 4) ? act_load1(aux2p, (long)mr * p.Cout + n) : 0.f;
+            }
         }
     }
     const int nchunk = p.CinP / 32;
@@ -52,8 +73,13 @@ __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
             if (c0 + u >= nchunk) break;   // uniform
             const unsigned ao = abase + (unsigned)(c0 + u) * 32u * SB;
             const unsigned bo = bbase + (unsigned)(c0 + u) * 32u * bstep;
+            if (B16) {   // 16 channels = 32 bytes: two 16-byte loads
+                buf_load_bf16x8(rin, ao, a[u][0], a[u][1]);
+                buf_load_bf16x8(rin, ao == DLKA_OOB ? DLKA_OOB : ao + 16u, a[u][2], a[u][3]);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[u][e] = act_buf_load4<T>(rin, ao + 4u * SB * e);
+                for (int e = 0; e < 4; ++e) a[u][e] = act_buf_load4<T>(rin, ao + 4u * SB * e);
+            }
 #pragma unroll
             for (int s = 0; s < 16; ++s) b[u][s] = buf_load_f32(rw, bo + (unsigned)s * bstep);
         }
@@ -65,8 +91,36 @@ __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
         }
     }
     // ---- epilogue: D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); same menu as cl_igemm_kernel ----
-    if (n >= p.Cout) return;
+    if (n >= p.Cout) return;   // (whole waves: Cout % 32 == 0 on the bf16 path, so the lane exchanges below stay complete)
     const float bv = p.bias ? p.bias[n] : 0.f;
+    if (B16) {
+        auto pair_store = [&](T *dst, int r, float x0, float x1) {   // dst[R][n] = x0, dst[R + 1][n] = x1 (bf16, round to nearest even)
+            const unsigned give = bf16_bits(odd ? x0 : x1), mine = bf16_bits(odd ? x1 : x0);
+            const unsigned got = lane_xor1(give);
+            const unsigned word = odd ? (got | (mine << 16)) : (mine | (got << 16));
+            const int mrow = mbase + (r & 3) + 8 * (r >> 2) + 4 * h + (odd ? 1 : 0);
+            if (mrow < p.M) *reinterpret_cast<unsigned *>(dst + ((long)mrow * p.Cout + (n & ~1))) = word;
+        };
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float v0 = acc[r] + bv, v1 = acc[r + 1] + bv;
+            if (p.epi == 0) {
+                pair_store(outp, r, v0, v1);
+            } else if (p.epi == 1) {
+                pair_store(outp, r, v0, v1);
+                pair_store(out2p, r, gelu_f(v0), gelu_f(v1));
+            } else if (p.epi == 2) {
+                pair_store(outp, r, v0, v1);
+                pair_store(out2p, r, auxv[r] * v0, auxv[r + 1] * v1);
+            } else if (p.epi == 3) {
+                pair_store(outp, r, v0 + auxv[r], v1 + auxv[r + 1]);
+            } else {
+                pair_store(outp, r, v0 * auxv[r], v1 * auxv[r + 1]);
+                pair_store(out2p, r, v0 * aux2v[r], v1 * aux2v[r + 1]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int mr = mbase + (r & 3) + 8 * (r >> 2) + 4 * h;

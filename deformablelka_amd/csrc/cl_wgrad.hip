@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Deformable weight gradient from STORED samples: cl_deform_goff2_kernel (which holds the 8 corners of every (row, tap) anyway)
-// has written S[tap][m][ci] (fp32, WgradArgs::samp), so the contraction  gW[co][ci][tap] = sum_m G[m][co] * S[tap][m][ci]  is a dense
+// has written S[tap][m][ci] (WgradArgs::samp; fp32, or bf16 with bf16 activations), so the contraction  gW[co][ci][tap] = sum_m G[m][co] * S[tap][m][ci]  is a dense
 // stream: per 32-row step a lane loads its 16 G elements and 16 S elements per tap (each wave load = two whole 128-byte rows), the next
 // step's operands are in flight under the current step's 16 * TPW MFMAs.  Same tile / chunk / partial layout as cl_wgrad_deform_kernel,
 // and the same arithmetic: S is produced by the same fma chain, the MFMA order over the rows is the same.
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64, 2) void cl_wgrad_samp_kernel(WgradArgs p)
     const int tap0 = bz * TPW;
     const int co = ot * 32 + i, ci = ct * 32 + i;
     const bool want_bias = p.bpart && ct == 0 && bz == 0;
-    const BufRsrc rg = make_rsrc(p.g, (size_t)p.M * p.Cout * XB), rs = make_rsrc(p.samp, (size_t)p.K * p.M * p.Cin * 4);
+    const BufRsrc rg = make_rsrc(p.g, (size_t)p.M * p.Cout * XB), rs = make_rsrc(p.samp, (size_t)p.K * p.M * p.Cin * XB);
 
     f32x16 acc[TPW];
 #pragma unroll
@@ -346,7 +346,10 @@ __global__ __launch_bounds__(64, 2) void cl_wgrad_samp_kernel(WgradArgs p)
     const int m_hi = min(p.M, m_lo + p.rows_per_chunk);
     float ga[2][16], sv[2][TPW][16];
     // one per-lane offset per operand (rows 16h.., column co / ci); the row step and the tap go through the wave-uniform offset
-    const unsigned vg = co < p.Cout ? (unsigned)(16 * h * p.Cout + co) * XB : DLKA_OOB, vs = (unsigned)(16 * h * p.Cin + ci) * 4u;
+    // (bf16 grad_out: a dword holding the column pair (co & ~1, co | 1) instead of a 2-byte load — 2-byte loads made this kernel 96 instead of
+    //  60 us at 32^3; the lane keeps its half)
+    constexpr bool G16 = sizeof(T) == 2;
+    const unsigned vg = co < p.Cout ? (unsigned)(16 * h * p.Cout + (G16 ? (co & ~1) : co)) * XB : DLKA_OOB, vs = (unsigned)(16 * h * p.Cin + (G16 ? (ci & ~1) : ci)) * XB;   // (the samples have the storage type of grad_out)
     unsigned tapbit[TPW];   // 0, or the out-of-range bit for taps past K (uniform)
 #pragma unroll
     for (int t = 0; t < TPW; ++t) tapbit[t] = tap0 + t < p.K ? 0u : DLKA_OOB;
@@ -355,10 +358,17 @@ __global__ __launch_bounds__(64, 2) void cl_wgrad_samp_kernel(WgradArgs p)
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const unsigned rowbit = s < lim ? 0u : DLKA_OOB;   // offsets are < 2^31: OR-ing the top bit sends the load out of range -> 0
-            ga[buf][s] = act_buf_load1_s<T>(rg, vg | rowbit, (unsigned)((mbase + s) * p.Cout) * XB);
+            if (G16) {
+                const unsigned w = __float_as_uint(buf_load_f32_s(rg, vg | rowbit, (unsigned)((mbase + s) * p.Cout) * XB));
+                ga[buf][s] = __uint_as_float((co & 1) ? (w & 0xffff0000u) : (w << 16));
+            } else {
+                ga[buf][s] = act_buf_load1_s<T>(rg, vg | rowbit, (unsigned)((mbase + s) * p.Cout) * XB);
+            }
 #pragma unroll
-            for (int t = 0; t < TPW; ++t)
-                sv[buf][t][s] = buf_load_f32_s(rs, vs | rowbit | tapbit[t], (unsigned)(((tap0 + t) * p.M + mbase + s) * p.Cin) * 4u);
+            for (int t = 0; t < TPW; ++t) {
+                const float w = buf_load_f32_s(rs, vs | rowbit | tapbit[t], (unsigned)(((tap0 + t) * p.M + mbase + s) * p.Cin) * XB);
+                sv[buf][t][s] = !G16 ? w : __uint_as_float((ci & 1) ? (__float_as_uint(w) & 0xffff0000u) : (__float_as_uint(w) << 16));
+            }
         }
     };
     auto compute = [&](int buf) {
@@ -753,7 +763,7 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
             grid = dim3(xcd_grid(a.xcd_total), 1, 1);
         }
         if (a.samp) {   // samples stored by the grad_offset kernel: dense stream, no gather
-            if (pl.tpw != 3 || (long)a.K * a.M * a.Cin * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets below DLKA_OOB
+            if (pl.tpw != 3 || (long)a.K * a.M * a.Cin * (a.act_bf16 ? 2 : 4) >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets below DLKA_OOB
             if (a.act_bf16) { auto k = cl_wgrad_samp_kernel<3, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
             else { auto k = cl_wgrad_samp_kernel<3>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
         }

@@ -336,8 +336,8 @@ struct TokGeoms {
     // offsets, or switched off — the weight gradient then gathers for itself)
     size_t samp_floats() const
     {
-        const size_t n = (size_t)dcn.K * dcn.M * dcn.Cin;
-        return (n * 4 < ((size_t)1 << 31) && getenv("DLKA_WGRAD_GATHER") == nullptr) ? n : 0;
+        const size_t n = (size_t)dcn.K * dcn.M * dcn.Cin;   // elements of the activation storage type (SB bytes each)
+        return (n * SB < ((size_t)1 << 31) && getenv("DLKA_WGRAD_GATHER") == nullptr) ? n * SB / 4 : 0;
     }
     // prepared weights, kept in `saved` from the forward to the backward call (floats)
     size_t pw_floats() const { return (size_t)pw.Cin * pw.Cin; }

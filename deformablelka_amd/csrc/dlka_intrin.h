@@ -40,6 +40,8 @@ __device__ __forceinline__ float bf16_value(unsigned short h) { return hipemu::h
 __device__ __forceinline__ void wave_sync() { (void)hipemu::shfl_any(0, 0); }
 // a value the caller guarantees to be equal in all active lanes of the wave (moves it to a scalar register on the GPU)
 __device__ __forceinline__ int wave_uniform(int x) { return x; }
+// the value of lane ^ 1 (every lane of the wave must call it)
+__device__ __forceinline__ unsigned lane_xor1(unsigned x) { return hipemu::shfl_any(x, (hipemu::F().lin & 63) ^ 1); }
 __device__ __forceinline__ int rint_i32(float x) { return (int)lrintf(x); }
 __device__ __forceinline__ unsigned __float_as_uint(float f) { unsigned v; memcpy(&v, &f, 4); return v; }
 __device__ __forceinline__ float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
@@ -78,6 +80,14 @@ __device__ __forceinline__ void buf_store_f32x4(BufRsrc r, unsigned off, f32x4 v
 {
     if (!(off < r.bytes) || (size_t)off + 16 > r.bytes) return;
     memcpy(const_cast<unsigned char *>(r.base) + off, &v, 16);
+}
+// 8 floats -> 8 bf16 (round to nearest even), one 16-byte store
+__device__ __forceinline__ void buf_store_bf16x8(BufRsrc r, unsigned off, f32x4 lo, f32x4 hi)
+{
+    if (!(off < r.bytes) || (size_t)off + 16 > r.bytes) return;
+    unsigned short h[8];
+    for (int e = 0; e < 4; ++e) { h[e] = hipemu::hipemu_f32_to_bf16(lo[e]); h[4 + e] = hipemu::hipemu_f32_to_bf16(hi[e]); }
+    memcpy(const_cast<unsigned char *>(r.base) + off, h, 16);
 }
 // ---- bf16 activation storage (DLKA_BF16 token path): 4 consecutive bf16 -> 4 floats, one 8-byte buffer load ----
 __device__ __forceinline__ f32x4 buf_load_bf16x4(BufRsrc r, unsigned off)
@@ -162,6 +172,8 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // a value the caller guarantees to be equal in all active lanes of the wave: into a scalar register, so that pointers / buffer
 // descriptors derived from it are built by the scalar unit
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// the value of lane ^ 1: one DPP move (quad_perm [1, 0, 3, 2])
+__device__ __forceinline__ unsigned lane_xor1(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false); }
 __device__ __forceinline__ int rint_i32(float x) { return __float2int_rn(x); }
 // sum over the 8 lanes that share lane >> 3 (result in all 8): three DPP adds, no LDS traffic
 // quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141 (lane k <-> 7-k inside each 8)
@@ -193,6 +205,16 @@ __device__ __forceinline__ void buf_store_f32x4(BufRsrc r, unsigned off, f32x4 v
 {
     typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) raw128_t;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw128_t, v), r, off, 0, 0);
+}
+// 8 floats -> 8 bf16 (round to nearest even), one 16-byte store
+__device__ __forceinline__ void buf_store_bf16x8(BufRsrc r, unsigned off, f32x4 lo, f32x4 hi)
+{
+    typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) raw128_t;
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    u4_t w;
+    w[0] = (unsigned)bf16_bits(lo[0]) | ((unsigned)bf16_bits(lo[1]) << 16); w[1] = (unsigned)bf16_bits(lo[2]) | ((unsigned)bf16_bits(lo[3]) << 16);
+    w[2] = (unsigned)bf16_bits(hi[0]) | ((unsigned)bf16_bits(hi[1]) << 16); w[3] = (unsigned)bf16_bits(hi[2]) | ((unsigned)bf16_bits(hi[3]) << 16);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw128_t, w), r, off, 0, 0);
 }
 // ---- bf16 activation storage (DLKA_BF16 token path): 4 consecutive bf16 -> 4 floats, one 8-byte buffer load ----
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
