@@ -45,7 +45,13 @@ struct ARow {
             }
         }
         const int c0 = ck * 32 + 16 * h;
-        if (AMODE == 0) {
+        if (AMODE == 0 && sizeof(T) == 2) {
+            // bf16 rows feed the bf16 matrix cores as they are: a[0..7] carry the 16 channels as RAW packed words (two 16-byte loads, no
+            // conversion; the consumer uses bf16x8_from_words(a + 4 * mf)); a[8..15] are unused
+            const f32x4 t0 = buf_load_f32x4(rin, rowoff == DLKA_OOB ? DLKA_OOB : rowoff + (unsigned)c0 * 2u);
+            const f32x4 t1 = buf_load_f32x4(rin, rowoff == DLKA_OOB ? DLKA_OOB : rowoff + (unsigned)c0 * 2u + 16u);
+            a[0] = t0[0]; a[1] = t0[1]; a[2] = t0[2]; a[3] = t0[3]; a[4] = t1[0]; a[5] = t1[1]; a[6] = t1[2]; a[7] = t1[3];
+        } else if (AMODE == 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const f32x4 t = act_buf_load4<T>(rin, rowoff + (unsigned)(c0 + 4 * e) * (unsigned)sizeof(T));

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void cl_conv_wave_kernel(IgemmArgs p)
                 }
             } else {
                 bf16x8 ahi, alo;
-                if (AMODE == 2 && p.a_packed) unpack_split2x8(a_cur + 8 * mf, ahi, alo);
+                if (A16) ahi = alo = bf16x8_from_words(a_cur + 4 * mf);   // raw bf16 rows (ARow): their own high term, no low term
+                else if (AMODE == 2 && p.a_packed) unpack_split2x8(a_cur + 8 * mf, ahi, alo);
                 else split_bf16x8(a_cur + 8 * mf, ahi, alo);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {

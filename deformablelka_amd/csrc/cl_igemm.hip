@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) {
                 bf16x8 ahi, alo;
-                if (AMODE == 2 && p.a_packed) unpack_split2x8(a_cur + 8 * mf, ahi, alo);   // split once by the producer (cl_deform_goff2_kernel)
+                if (A16) ahi = alo = bf16x8_from_words(a_cur + 4 * mf);   // raw bf16 rows (ARow): their own high term, no low term
+                else if (AMODE == 2 && p.a_packed) unpack_split2x8(a_cur + 8 * mf, ahi, alo);   // split once by the producer (cl_deform_goff2_kernel)
                 else split_bf16x8(a_cur + 8 * mf, ahi, alo);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {

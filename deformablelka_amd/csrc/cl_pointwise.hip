@@ -39,9 +39,13 @@ __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
     // of the pair, and the halves that belong to the neighbour cross over with one DPP move.
     constexpr bool B16 = sizeof(T) == 2;
     const bool odd = i & 1;
-    auto pair_load = [&](const T *src, int r, float &x0, float &x1) {   // src[R][n], src[R + 1][n] for this lane's column n
+    // (the epilogue operands are only REQUESTED here — raw words; exchanged and converted in the epilogue, so that nothing waits on them now)
+    unsigned auxw[8], aux2w[8];
+    auto pair_request = [&](const T *src, int r) -> unsigned {   // the dword (src[Rl][n & ~1], src[Rl][n | 1]) of this lane's row Rl = R + odd
         const int mrow = mbase + (r & 3) + 8 * (r >> 2) + 4 * h + (odd ? 1 : 0);
-        const unsigned own = (n_ok && mrow < p.M) ? *reinterpret_cast<const unsigned *>(src + ((long)mrow * p.Cout + (n & ~1))) : 0u;
+        return (n_ok && mrow < p.M) ? *reinterpret_cast<const unsigned *>(src + ((long)mrow * p.Cout + (n & ~1))) : 0u;
+    };
+    auto pair_finish = [&](unsigned own, float &x0, float &x1) {   // -> src[R][n], src[R + 1][n]
         const unsigned oth = lane_xor1(own);
         x0 = __uint_as_float(odd ? (oth & 0xffff0000u) : (own << 16));
         x1 = __uint_as_float(odd ? (own & 0xffff0000u) : (oth << 16));
@@ -50,9 +54,8 @@ __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
         if (B16) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                pair_load(auxp, r, auxv[r], auxv[r + 1]);
-                if (p.epi == 4) pair_load(aux2p, r, aux2v[r], aux2v[r + 1]);
-                else aux2v[r] = aux2v[r + 1] = 0.f;
+                auxw[r >> 1] = pair_request(auxp, r);
+                aux2w[r >> 1] = p.epi == 4 ? pair_request(aux2p, r) : 0u;
             }
         } else {
 #pragma unroll
@@ -101,6 +104,13 @@ __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
             const int mrow = mbase + (r & 3) + 8 * (r >> 2) + 4 * h + (odd ? 1 : 0);
             if (mrow < p.M) *reinterpret_cast<unsigned *>(dst + ((long)mrow * p.Cout + (n & ~1))) = word;
         };
+        if (p.epi >= 2) {   // uniform
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                pair_finish(auxw[r >> 1], auxv[r], auxv[r + 1]);
+                pair_finish(aux2w[r >> 1], aux2v[r], aux2v[r + 1]);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const float v0 = acc[r] + bv, v1 = acc[r + 1] + bv;

@@ -344,12 +344,15 @@ __global__ __launch_bounds__(64, 2) void cl_wgrad_samp_kernel(WgradArgs p)
 
     const int m_lo = chunk * p.rows_per_chunk;
     const int m_hi = min(p.M, m_lo + p.rows_per_chunk);
+    // register ring of RAW loaded words: any conversion (bf16 half -> float) happens at compute time — a conversion next to its load makes the
+    // compiler wait for that load on the spot, which serialises the prefetch (measured: 96 instead of 60 us with 2-byte loads converted at once)
     float ga[2][16], sv[2][TPW][16];
     // one per-lane offset per operand (rows 16h.., column co / ci); the row step and the tap go through the wave-uniform offset
-    // (bf16 grad_out: a dword holding the column pair (co & ~1, co | 1) instead of a 2-byte load — 2-byte loads made this kernel 96 instead of
-    //  60 us at 32^3; the lane keeps its half)
+    // (bf16 grad_out / samples: a dword holding the column pair (c & ~1, c | 1); the lane keeps its half)
     constexpr bool G16 = sizeof(T) == 2;
-    const unsigned vg = co < p.Cout ? (unsigned)(16 * h * p.Cout + (G16 ? (co & ~1) : co)) * XB : DLKA_OOB, vs = (unsigned)(16 * h * p.Cin + (G16 ? (ci & ~1) : ci)) * XB;   // (the samples have the storage type of grad_out)
+    const unsigned vg = co < p.Cout ? (unsigned)(16 * h * p.Cout + (G16 ? (co & ~1) : co)) * XB : DLKA_OOB;
+    const unsigned vs = (unsigned)(16 * h * p.Cin + (G16 ? (ci & ~1) : ci)) * XB;   // (the samples have the storage type of grad_out)
+    const unsigned gsh = (co & 1) ? 0u : 16u, ssh = (ci & 1) ? 0u : 16u;           // half selection: (word << sh) & 0xffff0000
     unsigned tapbit[TPW];   // 0, or the out-of-range bit for taps past K (uniform)
 #pragma unroll
     for (int t = 0; t < TPW; ++t) tapbit[t] = tap0 + t < p.K ? 0u : DLKA_OOB;
@@ -358,28 +361,25 @@ __global__ __launch_bounds__(64, 2) void cl_wgrad_samp_kernel(WgradArgs p)
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const unsigned rowbit = s < lim ? 0u : DLKA_OOB;   // offsets are < 2^31: OR-ing the top bit sends the load out of range -> 0
-            if (G16) {
-                const unsigned w = __float_as_uint(buf_load_f32_s(rg, vg | rowbit, (unsigned)((mbase + s) * p.Cout) * XB));
-                ga[buf][s] = __uint_as_float((co & 1) ? (w & 0xffff0000u) : (w << 16));
-            } else {
-                ga[buf][s] = act_buf_load1_s<T>(rg, vg | rowbit, (unsigned)((mbase + s) * p.Cout) * XB);
-            }
+            ga[buf][s] = buf_load_f32_s(rg, vg | rowbit, (unsigned)((mbase + s) * p.Cout) * XB);
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const float w = buf_load_f32_s(rs, vs | rowbit | tapbit[t], (unsigned)(((tap0 + t) * p.M + mbase + s) * p.Cin) * XB);
-                sv[buf][t][s] = !G16 ? w : __uint_as_float((ci & 1) ? (__float_as_uint(w) & 0xffff0000u) : (__float_as_uint(w) << 16));
-            }
+            for (int t = 0; t < TPW; ++t)
+                sv[buf][t][s] = buf_load_f32_s(rs, vs | rowbit | tapbit[t], (unsigned)(((tap0 + t) * p.M + mbase + s) * p.Cin) * XB);
         }
     };
+    auto half = [&](float w, unsigned sh) { return G16 ? __uint_as_float((__float_as_uint(w) << sh) & 0xffff0000u) : w; };
     auto compute = [&](int buf) {
+        float g[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) g[s] = half(ga[buf][s], gsh);
         if (want_bias) {
 #pragma unroll
-            for (int s = 0; s < 16; ++s) bsum += ga[buf][s];
+            for (int s = 0; s < 16; ++s) bsum += g[s];
         }
 #pragma unroll
         for (int t = 0; t < TPW; ++t)
 #pragma unroll
-            for (int s = 0; s < 16; ++s) acc[t] = mfma_32x32x2(ga[buf][s], sv[buf][t][s], acc[t]);
+            for (int s = 0; s < 16; ++s) acc[t] = mfma_32x32x2(g[s], half(sv[buf][t][s], ssh), acc[t]);
     };
     if (m_lo < m_hi) load_step(0, m_lo);
     for (int mbase = m_lo; mbase < m_hi; mbase += 64) {   // two steps per trip: the register buffers are addressed statically

@@ -33,6 +33,8 @@ __device__ __forceinline__ void split3_bf16x8(const float *a, bf16x8 &hi, bf16x8
     }
 }
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return hipemu::hipemu_f32_to_bf16(x); }
+// 8 bf16 values that are already packed in four 32-bit words (element 0 = low half of word 0): no conversion
+__device__ __forceinline__ bf16x8 bf16x8_from_words(const float *w4) { bf16x8 r; memcpy(r.v, w4, 16); return r; }
 __device__ __forceinline__ float bf16_value(unsigned short h) { return hipemu::hipemu_bf16_to_f32(h); }
 #define DLKA_DYN_SMEM(type, name) type *name = reinterpret_cast<type *>(hipemu::dyn_smem())
 // lanes of one wave exchange data through LDS without a workgroup barrier: on the GPU the wave executes in lockstep and
@@ -162,6 +164,12 @@ __device__ __forceinline__ void split3_bf16x8(const float *a, bf16x8 &hi, bf16x8
     }
 }
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+// 8 bf16 values that are already packed in four 32-bit words (element 0 = low half of word 0): no conversion
+__device__ __forceinline__ bf16x8 bf16x8_from_words(const float *w4)
+{
+    const f32x4 t = {w4[0], w4[1], w4[2], w4[3]};
+    return __builtin_bit_cast(bf16x8, t);
+}
 __device__ __forceinline__ float bf16_value(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 // Buffer loads (buffer_load_dword / _dwordx4 ... offen): 32-bit byte offsets against a wave-uniform descriptor, and the
 // hardware range check returns 0 for offsets >= the buffer size.  The gather kernels use that for zero padding and for
