@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
                     for (int q = 0; q < 8; ++q) {
                         const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
                         const float kd_ = (cd ? 1.f : -1.f) * fh[ch] * fw[cw], kh_ = (ch ? 1.f : -1.f) * fd[cd] * fw[cw], kw_ = (cw ? 1.f : -1.f) * fd[cd] * fh[ch];
-                        const f32x4 x4 = xr[g][q].v[v];
+                        const f32x4 x4 = xr[g][q].get(v);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             dd[e] = fmaf(kd_, x4[e], dd[e]); dh[e] = fmaf(kh_, x4[e], dh[e]); dw[e] = fmaf(kw_, x4[e], dw[e]);

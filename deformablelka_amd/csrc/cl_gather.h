@@ -87,18 +87,27 @@ __device__ __forceinline__ unsigned gather_offset(const RowDesc &r, int q, int H
 // measured slower than fp32 itself: 117 vs 102 us for the stage-0 forward, profiles/r03c).
 template <typename T> struct GatherGeom { static constexpr int NG = 4, RPI = 8, PE = 4, PSHIFT = 3; };
 template <> struct GatherGeom<bf16_t> { static constexpr int NG = 2, RPI = 16, PE = 8, PSHIFT = 2; };
-template <typename T> struct GatherPiece { f32x4 v[GatherGeom<T>::PE / 4]; };
-template <typename T> __device__ __forceinline__ GatherPiece<T> gather_load(BufRsrc r, unsigned byteoff);
-template <> __device__ __forceinline__ GatherPiece<float> gather_load<float>(BufRsrc r, unsigned byteoff)
+// What one lane holds of one corner row: fp32 = 4 channels; bf16 = 8 channels as the four RAW 32-bit words the load returned — converted
+// by get() where they are consumed.  (A conversion next to its load makes the compiler wait for that load on the spot, which serialises
+// the "next unit's corners fly under this unit's MFMAs" prefetch; raw words also halve the registers of the pieces in flight.)
+template <typename T> struct GatherPiece {
+    f32x4 w;
+    __device__ __forceinline__ f32x4 get(int) const { return w; }
+};
+template <> struct GatherPiece<bf16_t> {
+    f32x4 w;   // bit patterns: word k = channels 2k (low half) and 2k + 1 (high half)
+    __device__ __forceinline__ f32x4 get(int v) const   // channels 4v .. 4v + 3
+    {
+        const unsigned a = __float_as_uint(w[2 * v]), b = __float_as_uint(w[2 * v + 1]);
+        f32x4 r;
+        r[0] = __uint_as_float(a << 16); r[1] = __uint_as_float(a & 0xffff0000u); r[2] = __uint_as_float(b << 16); r[3] = __uint_as_float(b & 0xffff0000u);
+        return r;
+    }
+};
+template <typename T> __device__ __forceinline__ GatherPiece<T> gather_load(BufRsrc r, unsigned byteoff)
 {
-    GatherPiece<float> p;
-    p.v[0] = buf_load_f32x4(r, byteoff);
-    return p;
-}
-template <> __device__ __forceinline__ GatherPiece<bf16_t> gather_load<bf16_t>(BufRsrc r, unsigned byteoff)
-{
-    GatherPiece<bf16_t> p;
-    buf_load_bf16x8(r, byteoff, p.v[0], p.v[1]);
+    GatherPiece<T> p;
+    p.w = buf_load_f32x4(r, byteoff);   // 16 bytes either way
     return p;
 }
 

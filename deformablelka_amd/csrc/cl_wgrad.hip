@@ -282,8 +282,9 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
                     f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        s4[0] = fmaf(wq[q], xr[g][q].v[v][0], s4[0]); s4[1] = fmaf(wq[q], xr[g][q].v[v][1], s4[1]);
-                        s4[2] = fmaf(wq[q], xr[g][q].v[v][2], s4[2]); s4[3] = fmaf(wq[q], xr[g][q].v[v][3], s4[3]);
+                        const f32x4 x4 = xr[g][q].get(v);
+                    s4[0] = fmaf(wq[q], x4[0], s4[0]); s4[1] = fmaf(wq[q], x4[1], s4[1]);
+                        s4[2] = fmaf(wq[q], x4[2], s4[2]); s4[3] = fmaf(wq[q], x4[3], s4[3]);
                     }
                     *reinterpret_cast<f32x4 *>(S + (GG::RPI * g + gr) * SROW + GG::PE * gp + 4 * v) = s4;
                 }
