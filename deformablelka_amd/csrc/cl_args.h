@@ -24,16 +24,9 @@ struct IgemmArgs {
     int act_bf16;        // 1: the activation tensors (in, aux, aux2, out, out2 — whatever is channels-last) are bf16 storage (DLKA_BF16 token path;
                          //    fp32 arithmetic, fp32 weights / bias); planar tensors (offsets, grad_offset) are always fp32
     int aux_f32;         // act_bf16 only: `aux` is fp32 all the same (the grad_input accumulation target of the deformable conv)
-    // bf16 storage with a tap split (gridDim.y > 1): the partial sums meet in the fp32 buffer `out`; when fin_cnt is set, the LAST split block to
-    // finish a (row block, column slice) tile converts that tile into fin_out (bf16 [M][Cout]) — no separate conversion launch.  fin_cnt:
-    // one zero-initialised counter per tile (row blocks x gridDim.z <= DLKA_FIN_TILES), zeroed by the caller before every launch.
-    unsigned *fin_cnt;
-    void *fin_out;
     int epi;             // 0: out = acc+bias | 1: out = acc+bias, out2 = gelu(out) | 2: out = acc+bias, out2 = aux*out | 3: out = acc+bias+aux
                          // 4: out = (acc+bias)*aux, out2 = (acc+bias)*aux2   (gate backward fused into proj_2's data gradient)
 };
-
-constexpr int DLKA_FIN_TILES = 1024;
 
 struct WgradArgs {
     const float *g;
@@ -98,9 +91,8 @@ struct PrepJob {
     int mode;           // 0 fwd, 1 data-grad (flipped), 2 column matrix (| 8 / | 16: bf16 split layouts); 3 depthwise, 4 depthwise flipped; 5 zero fill of dst
     long n;             // elements of dst
 };
-constexpr int PREP_MAX_JOBS = 20;
 struct PrepBatch {
-    PrepJob j[PREP_MAX_JOBS];
+    PrepJob j[16];
     int njobs;
     long total;
 };
@@ -150,8 +142,7 @@ struct ZeroBatch {
     float *p[8];
     long cnt[8];          // floats
     unsigned block0[9];   // first workgroup of each region (set by the launcher)
-    bool overflow;        // more than 8 regions were added: the launcher refuses (a dropped zero fill would be a silent wrong answer)
-    void add(float *ptr, size_t floats) { if (!ptr || !floats) return; if (n >= 8) { overflow = true; return; } p[n] = ptr; cnt[n] = (long)floats; ++n; }
+    void add(float *ptr, size_t floats) { if (ptr && floats && n < 8) { p[n] = ptr; cnt[n] = (long)floats; ++n; } }
 };
 
 }  // namespace dlka

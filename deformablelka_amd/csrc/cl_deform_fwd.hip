@@ -155,14 +155,9 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
             const int mr = mbase + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (mr >= p.M) continue;
             const float val = acc[t][r] + bv;
-            if (split) atomicAdd(p.out + (long)mr * p.Cout + n, val);   // fp32 accumulation buffer (bf16 storage: converted below or by the caller)
+            if (split) atomicAdd(p.out + (long)mr * p.Cout + n, val);   // fp32 accumulation buffer (the launcher's caller casts it for bf16)
             else act_store1(reinterpret_cast<T *>(p.out), (long)mr * p.Cout + n, val);
         }
-    }
-    if (sizeof(T) == 2 && split && p.fin_cnt) {   // uniform
-        __shared__ int s_last;
-        finish_split_tile_bf16(p.out, reinterpret_cast<bf16_t *>(p.fin_out), p.fin_cnt, bx * (int)gridDim.z + (int)blockIdx.z, (int)gridDim.y, bx * 128, 128, p.M, n0,
-                               NT * 32 < p.Cout - n0 ? NT * 32 : p.Cout - n0, p.Cout, tid, (int)blockDim.x, &s_last);
     }
 }
 

@@ -209,11 +209,6 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
             }
         }
     }
-    if (sizeof(T) == 2 && OMODE == 0 && split && p.fin_cnt) {   // uniform: bf16 storage, the last split block of the tile converts it
-        __shared__ int s_last;
-        finish_split_tile_bf16(p.out, reinterpret_cast<bf16_t *>(p.fin_out), p.fin_cnt, bx * (int)gridDim.z + (int)blockIdx.z, (int)gridDim.y, bx * 128, 128, p.M, n0,
-                               NPB < p.Cout - n0 ? NPB : p.Cout - n0, p.Cout, tid, (int)blockDim.x, &s_last);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -127,7 +127,7 @@ int dense_forward(const SameConv &s, const float *x, const float *w, const float
 // partial sums and is converted into gx afterwards
 int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, const float *w, float *gx, float *wp, int epi,
                         const float *aux, hipStream_t st, const float *aux2 = nullptr, float *out2 = nullptr, bool zeroed = false, bool g_packed = false,
-                        bool aux_f32 = false, float *acc32 = nullptr, unsigned *fin_cnt = nullptr)
+                        bool aux_f32 = false, float *acc32 = nullptr)
 {
     const int KP = round_up(s.Cout, 32), NP = s.Cin;
     if (!(nt_ok(NP) || NP == 192 || NP == 384) || s.Cin % 32) return DLKA_ERR_UNSUPPORTED;   // (192 / 384: the 2-D block's widths, 3 / 4 column tiles per workgroup)
@@ -149,10 +149,6 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
     if (s.act_bf16 && splits > 1) {
         if (!acc32) return DLKA_ERR_WORKSPACE;
         a.out = acc32; a.out_zeroed = 1;
-        if (fin_cnt && cdiv(s.M, 128) * (NP / 32) <= DLKA_FIN_TILES) {   // the kernel's last split block converts each tile itself
-            a.fin_cnt = fin_cnt; a.fin_out = gx;
-            return launch_cl_igemm(gout_planar ? 2 : 0, 0, a, splits, st);
-        }
         DLKA_TRY(launch_cl_igemm(gout_planar ? 2 : 0, 0, a, splits, st));
         return launch_cast_from_f32<bf16_t>(acc32, reinterpret_cast<bf16_t *>(gx), (long)s.M * s.Cin, st);
     }
@@ -229,9 +225,8 @@ int dw_backward_weight(const SameConv &s, const float *x, const float *gout, flo
 bool deform_supported(const SameConv &s) { return s.group == 1 && s.Cin % 32 == 0 && s.Cout % 32 == 0 && nt_ok(s.Cout) && nt_ok(s.Cin); }
 
 // bf16 storage with a tap split: `acc32` (fp32 [M][Cout], ZEROED by the caller) receives the partial sums and is converted into `out`
-// fin_cnt (DLKA_FIN_TILES zeroed counters): the kernel's last split block converts each tile itself, no conversion launch
 int deform_forward(const SameConv &s, const float *x, const float *off, const float *w, const float *bias, float *out, float *wp, hipStream_t st,
-                   bool zeroed = false, float *acc32 = nullptr, unsigned *fin_cnt = nullptr)
+                   bool zeroed = false, float *acc32 = nullptr)
 {
     if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, s.Cout, 0, st));
     IgemmArgs a;
@@ -243,10 +238,6 @@ int deform_forward(const SameConv &s, const float *x, const float *off, const fl
         if (splits > 1) {
             if (!acc32) return DLKA_ERR_WORKSPACE;
             a.out = acc32; a.out_zeroed = 1;
-            if (fin_cnt && cdiv(s.M, 128) * (s.Cout / 32) <= DLKA_FIN_TILES) {
-                a.fin_cnt = fin_cnt; a.fin_out = out;
-                return launch_cl_deform_fwd(a, splits, st);
-            }
             DLKA_TRY(launch_cl_deform_fwd(a, splits, st));
             return launch_cast_from_f32<bf16_t>(acc32, reinterpret_cast<bf16_t *>(out), (long)s.M * s.Cout, st);
         }
@@ -404,9 +395,8 @@ int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_para
     add_job(pb, p->conv0_w, t.dw5_b, C, C, 125, 0, 0, 4);
     add_job(pb, p->conv_spatial_w, t.dw7_f, C, C, 343, 0, 0, 3);
     add_job(pb, p->conv_spatial_w, t.dw7_b, C, C, 343, 0, 0, 4);
-    if (zb && pb.njobs + zb->n > PREP_MAX_JOBS) return DLKA_ERR_WORKSPACE;   // (a dropped zero fill would be a silent wrong answer)
     if (zb)   // the forward pass's zero fills ride along (one launch less per block)
-        for (int r = 0; r < zb->n; ++r) {
+        for (int r = 0; r < zb->n && pb.njobs < 16; ++r) {
             PrepJob &j = pb.j[pb.njobs++];
             memset(&j, 0, sizeof(j));
             j.dst = zb->p[r]; j.n = zb->cnt[r]; j.mode = 5;
@@ -793,7 +783,7 @@ size_t dlka_lka3d_tokens_workspace_bytes(int B, int C, int D, int H, int W, int 
     if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return 0;
     TokGeoms G(B, C, D, H, W, dtype);   // (the eight gradient buffers keep their fp32 size on the bf16 path: gta and the split scratch ARE fp32)
     return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 8 * align256(G.E * 4) + align256(G.GOff * 4) +
-           align256(G.scratch_floats() * 4) + align256(G.samp_floats() * 4) + align256(DLKA_FIN_TILES * 4) + align256(4096);
+           align256(G.scratch_floats() * 4) + align256(G.samp_floats() * 4) + align256(4096);
 }
 
 static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void *y_, void *saved, size_t saved_bytes, void *workspace,
@@ -816,7 +806,6 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     (void)cv.take(G.wp_floats() * 4);
     (void)cv.take(G.part_floats() * 4);
     float *acc32 = (float *)cv.take(G.E * 4);   // bf16 path: fp32 landing zone of a tap-split deformable conv (small stages)
-    unsigned *fin = (unsigned *)cv.take(DLKA_FIN_TILES * 4);   // ... and the tile counters of its in-kernel conversion (IgemmArgs::fin_cnt)
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const bool bf = dtype == DLKA_BF16;
     const float *x = (const float *)x_;
@@ -827,7 +816,7 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     ZeroBatch zb;
     memset(&zb, 0, sizeof(zb));
     if (dense_forward_splits(G.offc, 0) > 1) zb.add(off, G.Off);
-    if (dense_forward_splits(G.dcn, 0) > 1) { zb.add(bf ? acc32 : f, G.E); if (bf) zb.add((float *)fin, DLKA_FIN_TILES); }
+    if (dense_forward_splits(G.dcn, 0) > 1) zb.add(bf ? acc32 : f, G.E);
     if (dense_forward_splits(G.pw, 3) > 1) zb.add(y, G.E);
     TokPrep PW;
     if (prepared) {   // the prepared weights are already in `saved` (dlka_lka3d_tokens_prepare_run): only the zero fills remain
@@ -844,7 +833,7 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     // offset-predict conv C -> 81 (synapse/deform_conv.py:94); offsets stay in the reference's planar layout
     DLKA_TRY(dense_forward(G.offc, t, N0, (const float *)p->offset_b, off, 1, PW.off_f, 0, nullptr, nullptr, st, true));
     // deformable 3^3 conv (deform_conv.py:95-105)
-    DLKA_TRY(deform_forward(G.dcn, t, off, N0, (const float *)p->deform_b, f, PW.dcn_f, st, true, acc32, fin));
+    DLKA_TRY(deform_forward(G.dcn, t, off, N0, (const float *)p->deform_b, f, PW.dcn_f, st, true, acc32));
     // conv1 + gate u*attn (:650-652): g1 kept, m = a * g1
     DLKA_TRY(dense_forward(G.pw, f, N0, (const float *)p->conv1_b, g1, 0, PW.pw_f[1], 2, a, m, st));
     // proj_2 + shortcut (:670-671)
@@ -952,7 +941,6 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     float *goff = (float *)cv.take(G.GOff * 4);
     float *scratch = (float *)cv.take(G.scratch_floats() * 4);
     float *samp = G.samp_floats() ? (float *)cv.take(G.samp_floats() * 4) : nullptr;
-    unsigned *fin = (unsigned *)cv.take(DLKA_FIN_TILES * 4);   // tile counters of the in-kernel bf16 conversion of tap-split outputs
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const float *x = (const float *)x_, *gy = (const float *)gy_;
     float *gx = (float *)gx_;
@@ -999,7 +987,7 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
         else if (!fp32_goff && deform_bwd_variant() == 0 && use_split(G.offc, false) == 2 && (G.offc.N & 15) == 0) goff_cpad = 96;
     }
     if (dense_backward_data_splits(G.pw, 0) > 1) zb.add(gf, G.E);
-    if (dense_backward_data_splits(G.offc, 3) > 1) { zb.add(bf ? ga2 : gt, G.E); if (bf) zb.add((float *)fin, DLKA_FIN_TILES); }   // bf16: split partial sums land in the fp32 scratch ga2
+    if (dense_backward_data_splits(G.offc, 3) > 1) zb.add(bf ? ga2 : gt, G.E);   // bf16: split partial sums land in the fp32 scratch ga2
     if (dense_backward_data_splits(G.pw, 3) > 1) zb.add(gx, G.E);
     DLKA_TRY(launch_zero_batch(zb, st));
     DLKA_TRY(publish());   // fork: everything issued before this call (gy, saved activations, the previous block's use of the workspace)
@@ -1025,7 +1013,7 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
     DLKA_TRY(dense_backward_weight(G.offc, t, goff, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, ws_, &fb.j[fb.njobs++], goff_cpad));
     DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, true));
-    DLKA_TRY(dense_backward_data(G.offc, goff, 1, N0, gt, PW.off_b, 3, gta, st, nullptr, nullptr, true, goff_cpad != 0, true, ga2, fin));
+    DLKA_TRY(dense_backward_data(G.offc, goff, 1, N0, gt, PW.off_b, 3, gta, st, nullptr, nullptr, true, goff_cpad != 0, true, ga2));
     DLKA_TRY(publish());
     // depthwise 7^3 dil 3:  t = DW7 t1
     DLKA_TRY(dw_backward_weight(G.dw7, t1, gt, (float *)gr->conv_spatial_w, (float *)gr->conv_spatial_b, stage7, ws_, &fb.j[fb.njobs++]));

@@ -68,28 +68,6 @@ __device__ __forceinline__ float act_load1(const bf16_t *p, long i) { return __u
 __device__ __forceinline__ void act_store1(float *p, long i, float v) { p[i] = v; }
 __device__ __forceinline__ void act_store1(bf16_t *p, long i, float v) { p[i].v = bf16_bits(v); }
 
-// Tap-split outputs with bf16 storage (IgemmArgs::fin_cnt): every split block of a tile calls this after its atomics; the last one to arrive
-// converts the tile's rows [row0, row0 + rows) x columns [n0, n0 + ncols) of the fp32 sums `acc` into `out`.  s_last: one __shared__ int.
-__device__ __forceinline__ void finish_split_tile_bf16(const float *acc, bf16_t *out, unsigned *cnt, int tile, int nsplit, int row0, int rows, int M,
-                                                       int n0, int ncols, int ld, int tid, int nthreads, int *s_last)
-{
-    __threadfence();   // release: this block's atomics are performed device-wide before its ticket
-    __syncthreads();
-    if (tid == 0) *s_last = atomicAdd(cnt + tile, 1u) == (unsigned)(nsplit - 1) ? 1 : 0;
-    __syncthreads();
-    if (!*s_last) return;
-    __threadfence();   // acquire
-    const int c4 = ncols / 4;
-    for (int e = tid; e < rows * c4; e += nthreads) {
-        const int r = row0 + e / c4, c = n0 + (e - (e / c4) * c4) * 4;
-        if (r >= M) continue;
-        const long o = (long)r * ld + c;
-        f32x4 v;
-        v[0] = coherent_load_f32(acc + o); v[1] = coherent_load_f32(acc + o + 1); v[2] = coherent_load_f32(acc + o + 2); v[3] = coherent_load_f32(acc + o + 3);
-        act_store4(out, o, v);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // geometry with the derived sizes every kernel needs
 // ---------------------------------------------------------------------------------------------

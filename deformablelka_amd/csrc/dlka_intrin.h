@@ -42,8 +42,6 @@ __device__ __forceinline__ float bf16_value(unsigned short h) { return hipemu::h
 __device__ __forceinline__ void wave_sync() { (void)hipemu::shfl_any(0, 0); }
 // a value the caller guarantees to be equal in all active lanes of the wave (moves it to a scalar register on the GPU)
 __device__ __forceinline__ int wave_uniform(int x) { return x; }
-// a load that sees what other workgroups' device-scope atomics have produced (after a fence)
-__device__ __forceinline__ float coherent_load_f32(const float *p) { return reinterpret_cast<const std::atomic<float> *>(p)->load(std::memory_order_relaxed); }
 // the value of lane ^ 1 (every lane of the wave must call it)
 __device__ __forceinline__ unsigned lane_xor1(unsigned x) { return hipemu::shfl_any(x, (hipemu::F().lin & 63) ^ 1); }
 __device__ __forceinline__ int rint_i32(float x) { return (int)lrintf(x); }
@@ -182,8 +180,6 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // a value the caller guarantees to be equal in all active lanes of the wave: into a scalar register, so that pointers / buffer
 // descriptors derived from it are built by the scalar unit
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
-// a load that sees what other workgroups' device-scope atomics have produced (after a fence): agent scope, not served from a stale L2 / L1 line
-__device__ __forceinline__ float coherent_load_f32(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // the value of lane ^ 1: one DPP move (quad_perm [1, 0, 3, 2])
 __device__ __forceinline__ unsigned lane_xor1(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false); }
 __device__ __forceinline__ int rint_i32(float x) { return __float2int_rn(x); }

@@ -248,8 +248,6 @@ inline double atomicAdd(double *addr, double v) {
     return f;
 }
 inline int atomicAdd(int *addr, int v) { return reinterpret_cast<std::atomic<int> *>(addr)->fetch_add(v); }
-inline unsigned atomicAdd(unsigned *addr, unsigned v) { return reinterpret_cast<std::atomic<unsigned> *>(addr)->fetch_add(v); }
-inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 inline unsigned long long atomicAdd(unsigned long long *addr, unsigned long long v) {
     return reinterpret_cast<std::atomic<unsigned long long> *>(addr)->fetch_add(v);
 }
