@@ -91,8 +91,9 @@ struct PrepJob {
     int mode;           // 0 fwd, 1 data-grad (flipped), 2 column matrix (| 8 / | 16: bf16 split layouts); 3 depthwise, 4 depthwise flipped; 5 zero fill of dst
     long n;             // elements of dst
 };
+constexpr int PREP_MAX_JOBS = 20;
 struct PrepBatch {
-    PrepJob j[16];
+    PrepJob j[PREP_MAX_JOBS];
     int njobs;
     long total;
 };
@@ -142,7 +143,8 @@ struct ZeroBatch {
     float *p[8];
     long cnt[8];          // floats
     unsigned block0[9];   // first workgroup of each region (set by the launcher)
-    void add(float *ptr, size_t floats) { if (ptr && floats && n < 8) { p[n] = ptr; cnt[n] = (long)floats; ++n; } }
+    bool overflow;        // more than 8 regions were added: the launcher refuses (a dropped zero fill would be a silent wrong answer)
+    void add(float *ptr, size_t floats) { if (!ptr || !floats) return; if (n >= 8) { overflow = true; return; } p[n] = ptr; cnt[n] = (long)floats; ++n; }
 };
 
 }  // namespace dlka

@@ -395,8 +395,9 @@ int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_para
     add_job(pb, p->conv0_w, t.dw5_b, C, C, 125, 0, 0, 4);
     add_job(pb, p->conv_spatial_w, t.dw7_f, C, C, 343, 0, 0, 3);
     add_job(pb, p->conv_spatial_w, t.dw7_b, C, C, 343, 0, 0, 4);
+    if (zb && pb.njobs + zb->n > PREP_MAX_JOBS) return DLKA_ERR_WORKSPACE;   // (a dropped zero fill would be a silent wrong answer)
     if (zb)   // the forward pass's zero fills ride along (one launch less per block)
-        for (int r = 0; r < zb->n && pb.njobs < 16; ++r) {
+        for (int r = 0; r < zb->n; ++r) {
             PrepJob &j = pb.j[pb.njobs++];
             memset(&j, 0, sizeof(j));
             j.dst = zb->p[r]; j.n = zb->cnt[r]; j.mode = 5;

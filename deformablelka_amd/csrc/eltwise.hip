@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void zero_batch_kernel(ZeroBatch b)
 
 int launch_zero_batch(ZeroBatch &b, hipStream_t st)
 {
+    if (b.overflow) return DLKA_ERR_WORKSPACE;
     if (b.n <= 0) return DLKA_OK;
     unsigned blk = 0;
     for (int r = 0; r < b.n; ++r) {
