@@ -211,8 +211,7 @@ __global__ __launch_bounds__(256) void cl_deform_goff_kernel(DeformBwdArgs p, in
 // (An intermediate version kept Col in the gather layout and reduced 8-lane groups with DPP; it needed 435 registers,
 //  ran one wave per SIMD and was no faster than the first kernel.)
 // ---------------------------------------------------------------------------------------------------------------------
-// SAMP: also store the samples S[tap][m][c] (DeformBwdArgs::samp) for the weight gradient.  Always with NKC_REG = 0 (grad_out rows re-read per
-// unit instead of held in registers): the sample accumulators need the room — with NKC_REG = 1 the kernel spilled 250 bytes per lane.
+// SAMP: also store the samples S[tap][m][c] (DeformBwdArgs::samp) for the weight gradient (the launcher picks NKC_REG by measurement).
 template <int NKC_REG, typename T = float, bool SAMP = false>   // T: storage of `in` and `g` (channels-last); offsets / grad_offset are fp32 planar
 __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p, int taps_per_block)
 {
@@ -267,7 +266,6 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
     }
 
     GatherPiece<T> xr[GG::NG][8];   // corner pieces of the unit in flight
-    RowDesc rd[GG::NG];
     float onx[3] = {0.f, 0.f, 0.f};   // offsets of the next tap to describe, loaded a whole tap ahead
     auto load_offsets = [&](int tap) {
         const float *op = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
@@ -282,16 +280,17 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
             if (row_ok) r = gather_describe3(onx[0], onx[1], onx[2], p.N, b, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw, p.D, p.H, p.W);
             gather_publish(Dt, j, r);
         }
-        wave_sync();
-#pragma unroll
-        for (int g = 0; g < GG::NG; ++g) rd[g] = gather_lookup(Dt, GG::RPI * g + gr);
+        wave_sync();   // (the descriptions stay in the LDS table; issue() and the interpolation read their rows back when they need them —
+                       //  held in registers across the MFMA phase they cost 20 VGPRs the kernel does not have)
     };
     auto issue = [&](int cc) {
         const unsigned cbyte = (unsigned)(cc * 32 + GG::PE * gp) * XB;
 #pragma unroll
-        for (int g = 0; g < GG::NG; ++g)
+        for (int g = 0; g < GG::NG; ++g) {
+            const RowDesc r = gather_lookup(Dt, GG::RPI * g + gr);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) xr[g][q] = gather_load<T>(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
+            for (int q = 0; q < 8; ++q) xr[g][q] = gather_load<T>(rin, gather_offset(r, q, HW, p.W, rowbytes, cbyte));
+        }
     };
 
     // weight tile of stage s = (tap, cc, kc) in flight in a register while the previous stage computes
@@ -356,7 +355,8 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
             wave_sync();   // previous tiles consumed
 #pragma unroll
             for (int g = 0; g < GG::NG; ++g) {
-                const float fd[2] = {1.f - rd[g].ld, rd[g].ld}, fh[2] = {1.f - rd[g].lh, rd[g].lh}, fw[2] = {1.f - rd[g].lw, rd[g].lw};
+                const RowDesc rdg = gather_lookup(Dt, GG::RPI * g + gr);
+                const float fd[2] = {1.f - rdg.ld, rdg.ld}, fh[2] = {1.f - rdg.lh, rdg.lh}, fw[2] = {1.f - rdg.lw, rdg.lw};
                 const bool srow = SAMP && (tile_full || mbase + GG::RPI * g + gr < p.M);
                 f32x4 s4_lo = {0.f, 0.f, 0.f, 0.f};   // bf16 storage: the piece's first four samples wait for the other four (one 16-byte store)
 #pragma unroll
@@ -824,9 +824,11 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
             else if (nkc == 2) { auto k = cl_deform_goff_kernel<2>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
             else { auto k = cl_deform_goff_kernel<0>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
         } else {
+            // storing variant: grad_out rows in registers only at Cout = 32 / fp32 (measured at 32^3: 179 vs 186 us; bf16 149 vs 155 us the other way)
 #define DLKA_GOFF2(NK, TT)                                                                                                           \
     {                                                                                                                                \
-        if (a.samp) { auto k = cl_deform_goff2_kernel<0, TT, true>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }            \
+        if (a.samp && (NK) == 1 && sizeof(TT) == 4) { auto k = cl_deform_goff2_kernel<1, TT, true>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); } \
+        else if (a.samp) { auto k = cl_deform_goff2_kernel<0, TT, true>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }       \
         else { auto k = cl_deform_goff2_kernel<NK, TT, false>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }                 \
     }
             if (a.act_bf16) {
