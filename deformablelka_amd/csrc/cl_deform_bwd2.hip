@@ -706,6 +706,196 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fixed-point window, second generation.  The first one is VALU-bound, not LDS-bound: ~600 VALU instructions per (32 voxels x 2 taps) scatter
+// step — per corner an in-window test, a trash-cell select, a weight select, the bookkeeping of the global-atomic fallback and runtime index
+// arithmetic — against 16 LDS atomics (ISA count).  Here
+//   * the window has COMPILE-TIME strides (SW cells per w-row, SH rows per plane, SD planes per channel pair): a sample's 16 atomics share
+//     ONE address register, corner and channel-pair offsets ride in the instruction's immediate offset field;
+//   * where the window is clipped by a volume face it gets one GUARD cell beyond the face: a corner outside the volume lands there (never
+//     flushed) instead of being tested for — the guard q > -1 && q < size keeps every corner within one cell of the volume;
+//   * one test per SAMPLE ("all eight corners inside window + guard") replaces the eight per-corner tests; the rare sample that fails it
+//     (|offset| beyond the halo) sends its in-volume corners to global atomics, exactly as before.
+// Same MFMA phase, same scale (Cauchy-Schwarz bound, see cl_deform_gx_kernel), same rounding: the integer window sums — hence the slabs it
+// flushes — are bit-identical to the first generation's.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int SW, int SH, int SD, typename T = float>
+__global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs p, GxGeom gg, float *__restrict__ scratch)
+{
+    constexpr int PS = SD * SH * SW;   // cells per channel-pair plane
+    const T *gin = reinterpret_cast<const T *>(p.g);
+    DLKA_DYN_SMEM(unsigned char, smem0);
+    unsigned *smax = reinterpret_cast<unsigned *>(smem0);
+    unsigned long long *WinI = reinterpret_cast<unsigned long long *>(smem0 + 16);                  // [CS / 2][SD][SH][SW]
+    float *Bs = reinterpret_cast<float *>(smem0 + 16 + (size_t)PS * (CS / 2) * sizeof(double));     // [ngroups][CoutP][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int bk = DLKA_XCD_BX(gg.xcd_nx);
+    if (bk < 0) return;
+    const int brick = bk, slice = (int)blockIdx.y;
+    int bid = brick;
+    const int bw_i = bid % gg.nbw; bid /= gg.nbw;
+    const int bh_i = bid % gg.nbh; bid /= gg.nbh;
+    const int bd_i = bid % gg.nbd; const int b = bid / gg.nbd;
+    const int bd0 = bd_i * gg.bd, bh0 = bh_i * gg.bh, bw0 = bw_i * gg.bw;
+    int wd0, wh0, ww0, WD, WH, WW;
+    gx_window(bd0, gg.bd, p.D, wd0, WD);
+    gx_window(bh0, gg.bh, p.H, wh0, WH);
+    gx_window(bw0, gg.bw, p.W, ww0, WW);
+    // guard cells beyond the volume faces the window touches; (od, oh, ow) = volume coordinates of cell (0, 0, 0)
+    const int gld = wd0 == 0, glh = wh0 == 0, glw = ww0 == 0;
+    const int ND = WD + gld + (wd0 + WD == p.D), NH = WH + glh + (wh0 + WH == p.H), NW = WW + glw + (ww0 + WW == p.W);
+    const int od = wd0 - gld, oh = wh0 - glh, ow = ww0 - glw;
+    const int wvox = WD * WH * WW, WHW = WH * WW;
+    const int R = gg.bd * gg.bh * gg.bw, ntiles = cdiv(R, 32);
+    const int nkc = p.CoutP / 32;
+
+    for (int e = tid; e < PS * (CS / 2); e += blockDim.x) WinI[e] = 0ull;
+    for (int grp = 0; grp < gg.ngroups; ++grp) {   // A operand tiles: Bs[grp][co][t8*4 + c4] = W[co][slice*4 + c4][tap = grp*8 + t8]
+        float *dstB = Bs + (size_t)grp * p.CoutP * 32;
+        for (int e = tid; e < p.CoutP * TG; e += blockDim.x) {
+            const int co = e / TG, t8 = e - co * TG, tap = grp * TG + t8;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (tap < p.K) val = *reinterpret_cast<const f32x4 *>(p.wp + ((long)tap * p.CoutP + co) * p.C + slice * CS);
+            reinterpret_cast<f32x4 *>(dstB)[e] = val;
+        }
+    }
+    if (tid < 2) smax[tid] = 0u;
+    __syncthreads();
+    // scale with the provable overflow bound of the first generation (see there)
+    float fx_scale = 1.f, fx_inv = 1.f;
+    {
+        float wm = 0.f;
+        if (tid < gg.ngroups * 32) {
+            const float *col = Bs + (size_t)(tid >> 5) * p.CoutP * 32 + (tid & 31);
+            float ss = 0.f;
+            for (int co = 0; co < p.CoutP; ++co) ss = fmaf(col[co * 32], col[co * 32], ss);
+            wm = sqrtf(ss);
+        }
+        float gm = 0.f;
+        for (int row = tid; row < R; row += blockDim.x) {
+            const int rw = row % gg.bw, rh = (row / gg.bw) % gg.bh, rd = row / (gg.bw * gg.bh);
+            const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
+            if (vd < p.D && vh < p.H && vw < p.W) {
+                const long gi = ((long)b * p.N + (vd * p.H + vh) * p.W + vw) * p.Cout;
+                float ss = 0.f;
+                for (int co = 0; co < p.Cout; co += 4) {
+                    const f32x4 g4 = act_load4(gin, gi + co);
+                    ss = fmaf(g4[0], g4[0], fmaf(g4[1], g4[1], fmaf(g4[2], g4[2], fmaf(g4[3], g4[3], ss))));
+                }
+                gm = fmaxf(gm, sqrtf(ss));
+            }
+        }
+        atomicMax(&smax[0], __float_as_uint(wm));
+        atomicMax(&smax[1], __float_as_uint(gm));
+        __syncthreads();
+        const float vmax = __uint_as_float(smax[0]) * __uint_as_float(smax[1]) * 1.0001f;
+        if (vmax > 1e-30f && vmax < 3.0e38f) {
+            fx_scale = gg.fx_lim / vmax * 0.999999f;
+            fx_inv = 1.f / fx_scale;
+        }
+    }
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int row = tile * 32 + j;
+        const int rw = row % gg.bw, rh = (row / gg.bw) % gg.bh, rd = row / (gg.bw * gg.bh);
+        const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
+        const bool ok = row < R && vd < p.D && vh < p.H && vw < p.W;
+        const int v = ok ? (vd * p.H + vh) * p.W + vw : 0;
+        float gl[4][16];   // this voxel's grad_out row (16 of each 32-channel chunk), loaded once for all tap groups
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            if (kc >= nkc) break;
+            const bool okg = ok && kc * 32 + 16 * h < p.Cout;
+            const long gi = okg ? ((long)b * p.N + v) * p.Cout + kc * 32 + 16 * h : 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 t = act_load4(gin, gi + 4 * e);
+                gl[kc][4 * e] = okg ? t[0] : 0.f; gl[kc][4 * e + 1] = okg ? t[1] : 0.f; gl[kc][4 * e + 2] = okg ? t[2] : 0.f; gl[kc][4 * e + 3] = okg ? t[3] : 0.f;
+            }
+        }
+        for (int grp = 0; grp < gg.ngroups; ++grp) {
+            const float *Bg = Bs + (size_t)grp * p.CoutP * 32;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                if (kc >= nkc) break;
+                const float *arow = Bg + (kc * 32 + 16 * h) * 32 + j;   // A[i = (t8, c4) = j][k = co]
+#pragma unroll
+                for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], gl[kc][st], acc);
+            }
+            // acc[r]: MFMA row (r&3) + 8*(r>>2) + 4h  ->  c4 = r & 3, t8 = 2*(r>>2) + h;   column = voxel j
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int tap = grp * TG + 2 * r4 + h;
+                if (!ok || tap >= p.K) continue;
+                int ti, tj, tk;
+                if (p.kw == 3 && p.kh == 3) { ti = tap / 9; const int rr = tap - 9 * ti; tj = rr / 3; tk = rr - 3 * tj; }   // uniform
+                else { tk = tap % p.kw; tj = (tap / p.kw) % p.kh; ti = tap / (p.kw * p.kh); }
+                // sampling rule of deform_im2col_cuda.cuh:244-259 (identical to lane_tap / setup_tap<3>)
+                const float *op = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
+                const float qd = (float)(vd + ti * p.dd - p.pd) + op[0];
+                const float qh = (float)(vh + tj * p.dh - p.ph) + op[p.N];
+                const float qw = (float)(vw + tk * p.dw - p.pw) + op[2 * (long)p.N];
+                if (!(qd > -1.f && qh > -1.f && qw > -1.f && qd < (float)p.D && qh < (float)p.H && qw < (float)p.W)) continue;
+                const float fld = floorf(qd), flh = floorf(qh), flw = floorf(qw);   // in [-1, size - 1]
+                const int zd = (int)fld, zh = (int)flh, zw = (int)flw;
+                const float ld = qd - fld, lh = qh - flh, lw = qw - flw;
+                const float fd[2] = {1.f - ld, ld}, fh[2] = {1.f - lh, lh}, fw[2] = {1.f - lw, lw};
+                const float wdh[4] = {fd[0] * fh[0], fd[0] * fh[1], fd[1] * fh[0], fd[1] * fh[1]};
+                const int xd = zd - od, xh = zh - oh, xw = zw - ow;
+                // all eight corners inside window + guard cells?  (a corner outside the volume is then in a guard cell)
+                const bool near = ((unsigned)xd < (unsigned)(ND - 1)) & ((unsigned)xh < (unsigned)(NH - 1)) & ((unsigned)xw < (unsigned)(NW - 1));
+                if (near) {
+                    unsigned long long *cell = WinI + (xd * SH + xh) * SW + xw;
+                    const float fws[2] = {fw[0] * fx_scale, fw[1] * fx_scale};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
+                        const float ws = wdh[2 * cd + ch] * fws[cw];
+#pragma unroll
+                        for (int pr = 0; pr < CS / 2; ++pr) {
+                            const int i0 = rint_i32(acc[4 * r4 + 2 * pr] * ws), i1 = rint_i32(acc[4 * r4 + 2 * pr + 1] * ws);
+                            // packed = (int64)i1 * 2^32 + (int64)i0: low word i0, high word i1 - 1 if i0 < 0
+                            const unsigned long long pk = ((unsigned long long)(unsigned)(i1 + (i0 >> 31)) << 32) | (unsigned long long)(unsigned)i0;
+                            atomicAdd(cell + (cd * SH * SW + ch * SW + cw) + pr * PS, pk);
+                        }
+                    }
+                } else {   // rare: |offset| beyond the halo — every in-volume corner goes to global atomics
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
+                        const int cz = zd + cd, cy = zh + ch, cx = zw + cw;
+                        if ((unsigned)cz >= (unsigned)p.D || (unsigned)cy >= (unsigned)p.H || (unsigned)cx >= (unsigned)p.W) continue;
+                        const float wq = wdh[2 * cd + ch] * fw[cw];
+                        float *dst = p.gx + ((long)b * p.N + (long)(cz * p.H + cy) * p.W + cx) * p.C + slice * CS;
+#pragma unroll
+                        for (int c = 0; c < CS; ++c) atomicAdd(dst + c, acc[4 * r4 + c] * wq);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // flush the window proper (no guard cells) in compact (d, h, w) order: scratch[brick][slice][cell] as float4, as the first generation does
+    f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + ((long)brick * gg.nslices + slice) * gg.wvox_max;
+    for (int e = tid; e < wvox; e += blockDim.x) {
+        const int d = e / WHW, r = e - d * WHW, hh = r / WW, w = r - hh * WW;
+        const int c = ((d + gld) * SH + (hh + glh)) * SW + (w + glw);
+        f32x4 o;
+#pragma unroll
+        for (int pr = 0; pr < CS / 2; ++pr) {
+            const long long sv = (long long)WinI[pr * PS + c];
+            const int lo = (int)(unsigned)(sv & 0xffffffffll);          // sum of the low fields (sign carried by the two's complement)
+            const long long hi = (sv - (long long)lo) >> 32;            // sum of the high fields
+            o[2 * pr] = (float)lo * fx_inv;
+            o[2 * pr + 1] = (float)hi * fx_inv;
+        }
+        dst[e] = o;
+    }
+}
+
 // grad_input[b][voxel][slice*4 .. +3] += sum over the bricks whose window covers the voxel (ascending brick order).
 __global__ __launch_bounds__(256) void cl_deform_gx_gather_kernel(DeformBwdArgs p, GxGeom gg, const float *__restrict__ scratch)
 {
@@ -875,9 +1065,11 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         if (hipGetDevice(&dev) != hipSuccess) return DLKA_ERR_LAUNCH;
         const uint64_t bit = 1ull << (dev & 63);
         if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-            const void *fns[4] = {reinterpret_cast<const void *>(cl_deform_gx_kernel<false>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true>),
-                                  reinterpret_cast<const void *>(cl_deform_gx_kernel<false, bf16_t>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true, bf16_t>)};
-            for (int f = 0; f < 4; ++f)
+            const void *fns[8] = {reinterpret_cast<const void *>(cl_deform_gx_kernel<false>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true>),
+                                  reinterpret_cast<const void *>(cl_deform_gx_kernel<false, bf16_t>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true, bf16_t>),
+                                  reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<18, 10, 14, float>), reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<18, 10, 14, bf16_t>),
+                                  reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<34, 10, 10, float>), reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<34, 10, 10, bf16_t>)};
+            for (int f = 0; f < 8; ++f)
                 if (hipFuncSetAttribute(fns[f], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DLKA_ERR_LAUNCH;
             attr_done.fetch_or(bit, std::memory_order_release);
         }
@@ -893,6 +1085,33 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const dim3 gx_grid(gl_.xcd_nx ? xcd_grid(nx) : nx, item_grid ? 1 : g.nslices);
         static int gx_threads = 0;
         if (!gx_threads) gx_threads = 512;
+        // second-generation fixed-point kernel (compile-time window strides + guard cells) where one of its window shapes fits;
+        // DLKA_GX_FIXED=2 keeps the first generation for A/B runs
+        if (fixed && gl_.resident && !item_grid && !(fx_env && atoi(fx_env) == 2)) {
+            auto ext2 = [](int bs, int size) { const int a = size + 2, b = bs + 2 * HALO; return a < b ? a : b; };   // window + guard cells, worst brick
+            const int nd = ext2(g.bd, a.D), nh = ext2(g.bh, a.H), nw = ext2(g.bw, a.W);
+            const size_t wbytes = (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
+#define DLKA_GX2(SWv, SHv, SDv)                                                                                                    \
+    if (nw <= SWv && nh <= SHv && nd <= SDv && 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes <= 79 * 1024) {                 \
+        const size_t lds2 = 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes;                                                  \
+        if (a.act_bf16) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t>; hipLaunchKernelGGL(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); } \
+        else { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float>; hipLaunchKernelGGL(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }             \
+        launched = true;                                                                                                           \
+    }
+            bool launched = false;
+            DLKA_GX2(18, 10, 14)
+            else DLKA_GX2(34, 10, 10)
+#undef DLKA_GX2
+            if (launched) {
+                DLKA_CHECK_LAUNCH();
+                const long total = (long)a.B * a.N * g.nslices;
+                long gb = cdivl(total, 256);
+                if (gb > 4096) gb = 4096;
+                hipLaunchKernelGGL(cl_deform_gx_gather_kernel, dim3((unsigned)gb), dim3(256), 0, st, a, g, (const float *)scratch);
+                DLKA_CHECK_LAUNCH();
+                return DLKA_OK;
+            }
+        }
         if (a.act_bf16) {
             if (fixed) { auto k = cl_deform_gx_kernel<true, bf16_t>; hipLaunchKernelGGL(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
             else { auto k = cl_deform_gx_kernel<false, bf16_t>; hipLaunchKernelGGL(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }

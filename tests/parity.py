@@ -234,6 +234,35 @@ def check_deform3d_cl_gx_fixed_vs_fp64(dev, B, C, dims, max_rel=4e-4):
     return err
 
 
+def check_deform3d_cl_gx_fx2_vs_fx1(dev, B, C, dims, off_mode="normal", scale=1.0):
+    """Second-generation fixed-point grad_input kernel (compile-time window strides, guard cells, one test per sample) against the first one
+    (DLKA_GX_FIXED=2): same scale, same rounding, integer window sums -> the two must agree BIT for bit wherever every sample stays inside
+    window + guard; a sample beyond the halo is quantised partly (fx1) or not at all (fx2: all its corners take fp32 global atomics) -> 2e-4 there."""
+    x, off, w, b, go, _ = make_deform3d(B, C, C, dims, 3, 1, 1, 1, 1, 1, off_mode, 0, scale=scale)
+    args = (to_cl(x).to(dev), off.to(dev), w.to(dev), to_cl(go).to(dev), 1, 1)
+    old = os.environ.get("DLKA_GX_FIXED")
+    try:
+        os.environ["DLKA_GX_FIXED"] = "1"
+        g2 = ops.deform_conv3d_backward_cl(*args)[0].cpu()
+        os.environ["DLKA_GX_FIXED"] = "2"
+        g1 = ops.deform_conv3d_backward_cl(*args)[0].cpu()
+        os.environ["DLKA_GX_FIXED"] = "0"
+        g64 = ops.deform_conv3d_backward_cl(*args)[0].cpu()
+    finally:
+        if old is None:
+            os.environ.pop("DLKA_GX_FIXED", None)
+        else:
+            os.environ["DLKA_GX_FIXED"] = old
+    far = off.abs().max().item() > 2.9
+    err = rel_err(g2, g1)
+    print(f"[gx fx2 vs fx1 C={C} dims={dims} {off_mode} x{scale}] rel err {err:.3e}; fx2 vs fp64 window {rel_err(g2, g64):.3e}")
+    if far:   # a sample beyond the halo: fx1 quantises its in-window corners, fx2 sends all of them through exact fp32 atomics
+        assert err < 2e-4, err
+    else:
+        assert torch.equal(g2, g1), err
+    assert rel_err(g2, g64) < 4e-4
+
+
 def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=2e-4, rtol=2e-3, report_offsets=False):
     """Token-layout fused block vs the oracle block (oracle/blocks.py)."""
     import deformablelka_amd as dk

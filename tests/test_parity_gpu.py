@@ -376,3 +376,9 @@ def test_tblock3d_chain():
 def test_lka3d_tokens_weight_gradient_from_stored_samples(C, dims, dtype):
     parity.check_lka3d_tokens_sample_handover(DEV, 2, C, dims, dtype=dtype)
 
+
+
+@pytest.mark.parametrize("C,dims,mode", [(32, (32, 32, 32), "normal"), (64, (16, 16, 16), "normal"), (32, (16, 16, 16), "wild"), (32, (8, 8, 8), "uniform3"),
+                                         (64, (5, 6, 7), "normal")])
+def test_deform3d_cl_gx_second_generation_fixed_point_kernel(C, dims, mode):
+    parity.check_deform3d_cl_gx_fx2_vs_fx1(DEV, 2, C, dims, mode)
