@@ -719,6 +719,32 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
 // Same MFMA phase, same scale (Cauchy-Schwarz bound, see cl_deform_gx_kernel), same rounding: the integer window sums — hence the slabs it
 // flushes — are bit-identical to the first generation's.
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr int GX_QW = 24;   // far-sample records per wave (8 floats each)
+
+// Drains a wave's far-sample queue: lane = (record r0 + (lane >> 5), corner (lane >> 2) & 7, channel lane & 3): every in-volume corner of a
+// queued sample adds Col * weight to grad_input with a global fp32 atomic (grad_input is zero-initialised by the caller).
+__device__ __forceinline__ void gx_drain_far(const DeformBwdArgs &p, const float *Qw, int count, int b, int slice, int lane)
+{
+    wave_sync();   // the records written by other lanes are visible
+    const int q = (lane >> 2) & 7, c = lane & 3;
+    const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
+    for (int r0 = 0; r0 < count; r0 += 2) {
+        const int r = r0 + (lane >> 5);
+        if (r < count) {
+            const float *rec = Qw + r * 8;
+            const int z = __float_as_int(rec[0]);
+            const int cz = (z >> 20) - 1 + cd, cy = ((z >> 10) & 1023) - 1 + ch, cx = (z & 1023) - 1 + cw;
+            if ((unsigned)cz < (unsigned)p.D && (unsigned)cy < (unsigned)p.H && (unsigned)cx < (unsigned)p.W) {
+                const float ld = rec[1], lh = rec[2], lw = rec[3];
+                // same product order as the regular path: (fd * fh) * fw
+                const float wq = ((cd ? ld : 1.f - ld) * (ch ? lh : 1.f - lh)) * (cw ? lw : 1.f - lw);
+                atomicAdd(p.gx + ((long)b * p.N + (long)(cz * p.H + cy) * p.W + cx) * p.C + slice * CS + c, rec[4 + c] * wq);
+            }
+        }
+    }
+    wave_sync();   // the queue may be refilled
+}
+
 template <int SW, int SH, int SD, typename T = float>
 __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs p, GxGeom gg, float *__restrict__ scratch)
 {
@@ -730,6 +756,11 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
     float *Bs = reinterpret_cast<float *>(smem0 + 16 + (size_t)PS * (CS / 2) * sizeof(double));     // [ngroups][CoutP][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int j = lane & 31, h = lane >> 5;
+    // per-wave queue of the rare samples that leave window + guard ("far"): record = {packed floor cell, ld, lh, lw, Col[4]}.  Handling them on
+    // the spot — a divergent branch with 32 global atomics behind it — cost more than the whole regular scatter (311 vs 179 us at 32^3 with
+    // ~1-voxel offsets: some lane of most waves is far); queued, they are drained with all 64 lanes busy (lane = (record, corner, channel)).
+    float *Qw = Bs + (size_t)gg.ngroups * p.CoutP * 32 + (size_t)wave * GX_QW * 8;
+    int qcount = 0;   // wave-uniform
     const int bk = DLKA_XCD_BX(gg.xcd_nx);
     if (bk < 0) return;
     const int brick = bk, slice = (int)blockIdx.y;
@@ -828,17 +859,20 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
             // acc[r]: MFMA row (r&3) + 8*(r>>2) + 4h  ->  c4 = r & 3, t8 = 2*(r>>2) + h;   column = voxel j
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const int tap = grp * TG + 2 * r4 + h;
-                if (!ok || tap >= p.K) continue;
+                // (no early exits: every lane reaches the ballot of the far-sample queue below; lanes without a sample carry valid = false)
+                const int tap_ = grp * TG + 2 * r4 + h;
+                const bool tv = ok && tap_ < p.K;
+                const int tap = tap_ < p.K ? tap_ : 0;
                 int ti, tj, tk;
                 if (p.kw == 3 && p.kh == 3) { ti = tap / 9; const int rr = tap - 9 * ti; tj = rr / 3; tk = rr - 3 * tj; }   // uniform
                 else { tk = tap % p.kw; tj = (tap / p.kw) % p.kh; ti = tap / (p.kw * p.kh); }
                 // sampling rule of deform_im2col_cuda.cuh:244-259 (identical to lane_tap / setup_tap<3>)
                 const float *op = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
-                const float qd = (float)(vd + ti * p.dd - p.pd) + op[0];
-                const float qh = (float)(vh + tj * p.dh - p.ph) + op[p.N];
-                const float qw = (float)(vw + tk * p.dw - p.pw) + op[2 * (long)p.N];
-                if (!(qd > -1.f && qh > -1.f && qw > -1.f && qd < (float)p.D && qh < (float)p.H && qw < (float)p.W)) continue;
+                const float qd_ = (float)(vd + ti * p.dd - p.pd) + op[0];
+                const float qh_ = (float)(vh + tj * p.dh - p.ph) + op[p.N];
+                const float qw_ = (float)(vw + tk * p.dw - p.pw) + op[2 * (long)p.N];
+                const bool valid = tv && qd_ > -1.f && qh_ > -1.f && qw_ > -1.f && qd_ < (float)p.D && qh_ < (float)p.H && qw_ < (float)p.W;
+                const float qd = valid ? qd_ : 0.f, qh = valid ? qh_ : 0.f, qw = valid ? qw_ : 0.f;
                 const float fld = floorf(qd), flh = floorf(qh), flw = floorf(qw);   // in [-1, size - 1]
                 const int zd = (int)fld, zh = (int)flh, zw = (int)flw;
                 const float ld = qd - fld, lh = qh - flh, lw = qw - flw;
@@ -846,7 +880,7 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
                 const float wdh[4] = {fd[0] * fh[0], fd[0] * fh[1], fd[1] * fh[0], fd[1] * fh[1]};
                 const int xd = zd - od, xh = zh - oh, xw = zw - ow;
                 // all eight corners inside window + guard cells?  (a corner outside the volume is then in a guard cell)
-                const bool near = ((unsigned)xd < (unsigned)(ND - 1)) & ((unsigned)xh < (unsigned)(NH - 1)) & ((unsigned)xw < (unsigned)(NW - 1));
+                const bool near = valid & ((unsigned)xd < (unsigned)(ND - 1)) & ((unsigned)xh < (unsigned)(NH - 1)) & ((unsigned)xw < (unsigned)(NW - 1));
                 if (near) {
                     unsigned long long *cell = WinI + (xd * SH + xh) * SW + xw;
                     const float fws[2] = {fw[0] * fx_scale, fw[1] * fx_scale};
@@ -862,21 +896,38 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
                             atomicAdd(cell + (cd * SH * SW + ch * SW + cw) + pr * PS, pk);
                         }
                     }
-                } else {   // rare: |offset| beyond the halo — every in-volume corner goes to global atomics
+                }
+                // far samples: into the wave's queue (prefix slot from the ballot); an overflowing batch takes the global atomics directly
+                const bool far_s = valid && !near;
+                const unsigned long long fm = __ballot(far_s);
+                if (fm) {   // wave-uniform
+                    const int nf = __popcll(fm);
+                    if (qcount + nf <= GX_QW) {
+                        if (far_s) {
+                            float *rec = Qw + (qcount + __popcll(fm & ((1ull << lane) - 1ull))) * 8;
+                            rec[0] = __int_as_float(((zd + 1) << 20) | ((zh + 1) << 10) | (zw + 1));
+                            rec[1] = ld; rec[2] = lh; rec[3] = lw;
+                            rec[4] = acc[4 * r4]; rec[5] = acc[4 * r4 + 1]; rec[6] = acc[4 * r4 + 2]; rec[7] = acc[4 * r4 + 3];
+                        }
+                        qcount += nf;
+                    } else if (far_s) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
-                        const int cz = zd + cd, cy = zh + ch, cx = zw + cw;
-                        if ((unsigned)cz >= (unsigned)p.D || (unsigned)cy >= (unsigned)p.H || (unsigned)cx >= (unsigned)p.W) continue;
-                        const float wq = wdh[2 * cd + ch] * fw[cw];
-                        float *dst = p.gx + ((long)b * p.N + (long)(cz * p.H + cy) * p.W + cx) * p.C + slice * CS;
+                        for (int q = 0; q < 8; ++q) {
+                            const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
+                            const int cz = zd + cd, cy = zh + ch, cx = zw + cw;
+                            if ((unsigned)cz >= (unsigned)p.D || (unsigned)cy >= (unsigned)p.H || (unsigned)cx >= (unsigned)p.W) continue;
+                            const float wq = wdh[2 * cd + ch] * fw[cw];
+                            float *dst = p.gx + ((long)b * p.N + (long)(cz * p.H + cy) * p.W + cx) * p.C + slice * CS;
 #pragma unroll
-                        for (int c = 0; c < CS; ++c) atomicAdd(dst + c, acc[4 * r4 + c] * wq);
+                            for (int c = 0; c < CS; ++c) atomicAdd(dst + c, acc[4 * r4 + c] * wq);
+                        }
                     }
                 }
             }
+            if (qcount > GX_QW / 2) { gx_drain_far(p, Qw, qcount, b, slice, lane); qcount = 0; }   // uniform
         }
     }
+    if (qcount) gx_drain_far(p, Qw, qcount, b, slice, lane);
     __syncthreads();
     // flush the window proper (no guard cells) in compact (d, h, w) order: scratch[brick][slice][cell] as float4, as the first generation does
     f32x4 *dst = reinterpret_cast<f32x4 *>(scratch) + ((long)brick * gg.nslices + slice) * gg.wvox_max;
@@ -1051,7 +1102,7 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const size_t lds_win = 16 + (size_t)(g.wvox_max + 64) * (fixed ? CS / 2 : CS) * sizeof(double);
         const size_t lds_all = lds_win + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
         gl_.resident = (lds_all <= 150 * 1024 && a.CoutP <= 128) ? 1 : 0;
-        constexpr int abl = 0;
+        const int abl = getenv("DLKA_GX_ABL") ? atoi(getenv("DLKA_GX_ABL")) : 0;   // profiling only (wrong results)
         gl_.ablate = abl;
         constexpr bool far_taps = false;   // (measured: 390 vs 370 us at 32^3 — slower)
         gl_.tap_far = (far_taps && g.ngroups == 4) ? 1 : 0;
@@ -1091,9 +1142,10 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
             auto ext2 = [](int bs, int size) { const int a = size + 2, b = bs + 2 * HALO; return a < b ? a : b; };   // window + guard cells, worst brick
             const int nd = ext2(g.bd, a.D), nh = ext2(g.bh, a.H), nw = ext2(g.bw, a.W);
             const size_t wbytes = (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
+            const size_t qbytes = (size_t)8 * GX_QW * 8 * sizeof(float);   // 8 waves x GX_QW far-sample records
 #define DLKA_GX2(SWv, SHv, SDv)                                                                                                    \
-    if (nw <= SWv && nh <= SHv && nd <= SDv && 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes <= 79 * 1024) {                 \
-        const size_t lds2 = 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes;                                                  \
+    if (nw <= SWv && nh <= SHv && nd <= SDv && 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes + qbytes <= 79 * 1024) {        \
+        const size_t lds2 = 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes + qbytes;                                         \
         if (a.act_bf16) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t>; hipLaunchKernelGGL(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); } \
         else { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float>; hipLaunchKernelGGL(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }             \
         launched = true;                                                                                                           \

@@ -287,6 +287,7 @@ template <typename T> inline T __shfl_up(T v, unsigned d, int = 64) {
     int l = hipemu::F().lin & 63;
     return hipemu::shfl_any(v, (l - (int)d >= 0) ? l - (int)d : l);
 }
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline unsigned long long __ballot(int pred) {
     using namespace hipemu;
     Fiber &f = F();
