@@ -716,8 +716,8 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
 //     flushed) instead of being tested for — the guard q > -1 && q < size keeps every corner within one cell of the volume;
 //   * one test per SAMPLE ("all eight corners inside window + guard") replaces the eight per-corner tests; the rare sample that fails it
 //     (|offset| beyond the halo) sends its in-volume corners to global atomics, exactly as before.
-// Same MFMA phase, same scale (Cauchy-Schwarz bound, see cl_deform_gx_kernel), same rounding: the integer window sums — hence the slabs it
-// flushes — are bit-identical to the first generation's.
+// Same MFMA phase and scale (Cauchy-Schwarz bound, see cl_deform_gx_kernel); every contribution is rounded to nearest-even once, from the exact
+// product (the first generation rounds the fp32 product): the window sums agree with the first generation's to a few quanta.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int GX_QW = 24;   // far-sample records per wave (8 floats each)
 
@@ -890,9 +890,12 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
                         const float ws = wdh[2 * cd + ch] * fws[cw];
 #pragma unroll
                         for (int pr = 0; pr < CS / 2; ++pr) {
-                            const int i0 = rint_i32(acc[4 * r4 + 2 * pr] * ws), i1 = rint_i32(acc[4 * r4 + 2 * pr + 1] * ws);
+                            // round(Col * ws) without v_rndne + v_cvt: |Col * ws| <= fx_lim < 2^22, so adding 1.5 * 2^23 in ONE fma leaves the
+                            // integer (round to nearest even of the exact product) in the low mantissa bits: bits = 0x4B400000 + i
+                            const int t0 = __float_as_int(fmaf(acc[4 * r4 + 2 * pr], ws, 12582912.f)), t1 = __float_as_int(fmaf(acc[4 * r4 + 2 * pr + 1], ws, 12582912.f));
+                            const int i0 = t0 - 0x4B400000;
                             // packed = (int64)i1 * 2^32 + (int64)i0: low word i0, high word i1 - 1 if i0 < 0
-                            const unsigned long long pk = ((unsigned long long)(unsigned)(i1 + (i0 >> 31)) << 32) | (unsigned long long)(unsigned)i0;
+                            const unsigned long long pk = ((unsigned long long)(unsigned)(t1 + (i0 >> 31) - 0x4B400000) << 32) | (unsigned long long)(unsigned)i0;
                             atomicAdd(cell + (cd * SH * SW + ch * SW + cw) + pr * PS, pk);
                         }
                     }
@@ -1097,7 +1100,8 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const bool fx_possible = lds_win_fx + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float) <= 150 * 1024 && a.CoutP <= 128 && g.ngroups * 32 <= 512 &&
                                  fx_bits >= 12 && !abl_on;
         const bool fixed = fx_possible && (fx_env ? atoi(fx_env) != 0 : a.C <= 64);
-        gl_.fx_lim = (float)fx_lim;
+        // (capped below 2^22: the second-generation kernel rounds with the 1.5 * 2^23 trick, exact for |value| < 2^22; tiny bricks would allow more)
+        gl_.fx_lim = (float)(fx_lim < 4.0e6 ? fx_lim : 4.0e6);
         // scalars, window + one trash cell per lane and channel plane (the fixed-point window packs two channels per cell)
         const size_t lds_win = 16 + (size_t)(g.wvox_max + 64) * (fixed ? CS / 2 : CS) * sizeof(double);
         const size_t lds_all = lds_win + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);

@@ -236,8 +236,8 @@ def check_deform3d_cl_gx_fixed_vs_fp64(dev, B, C, dims, max_rel=4e-4):
 
 def check_deform3d_cl_gx_fx2_vs_fx1(dev, B, C, dims, off_mode="normal", scale=1.0):
     """Second-generation fixed-point grad_input kernel (compile-time window strides, guard cells, one test per sample) against the first one
-    (DLKA_GX_FIXED=2): same scale, same rounding, integer window sums -> the two must agree BIT for bit wherever every sample stays inside
-    window + guard; a sample beyond the halo is quantised partly (fx1) or not at all (fx2: all its corners take fp32 global atomics) -> 2e-4 there."""
+    (DLKA_GX_FIXED=2): same scale, integer window sums, roundings that differ by at most one quantum per contribution -> 2e-5 wherever every
+    sample stays inside window + guard; a sample beyond the halo is quantised partly (fx1) or not at all (fx2: all its corners take fp32 global atomics) -> 2e-4 there."""
     x, off, w, b, go, _ = make_deform3d(B, C, C, dims, 3, 1, 1, 1, 1, 1, off_mode, 0, scale=scale)
     args = (to_cl(x).to(dev), off.to(dev), w.to(dev), to_cl(go).to(dev), 1, 1)
     old = os.environ.get("DLKA_GX_FIXED")
@@ -258,8 +258,8 @@ def check_deform3d_cl_gx_fx2_vs_fx1(dev, B, C, dims, off_mode="normal", scale=1.
     print(f"[gx fx2 vs fx1 C={C} dims={dims} {off_mode} x{scale}] rel err {err:.3e}; fx2 vs fp64 window {rel_err(g2, g64):.3e}")
     if far:   # a sample beyond the halo: fx1 quantises its in-window corners, fx2 sends all of them through exact fp32 atomics
         assert err < 2e-4, err
-    else:
-        assert torch.equal(g2, g1), err
+    else:   # same scale; fx2 rounds the exact product once, fx1 the fp32 product: a few quanta (1 / 155 343 of the largest contribution) at most
+        assert err < 2e-5, err
     assert rel_err(g2, g64) < 4e-4
 
 
