@@ -668,6 +668,15 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
                 fx_inv = 1.f / fx_scale;
             }
         }
+        if (ntiles < nwaves || nkc > 4) {
+            // tiny volumes (fewer tiles than waves: at 4^3 / 8^3 a brick is 2 tiles and 6 of the 8 waves had nothing to do), or more grad_out
+            // chunks than the register copy holds (Cout = 256): the waves share (tile, tap group) ITEMS and re-read the grad_out rows per item
+            const int nitems = ntiles * gg.ngroups;
+            for (int item = wave; item < nitems; item += nwaves) {
+                const int tile = item / gg.ngroups, grp = item - tile * gg.ngroups;
+                tile_group(tile, grp, Bs + (size_t)grp * p.CoutP * 32, nullptr, true);
+            }
+        } else
         for (int tile = wave; tile < ntiles; tile += nwaves) {
             float gl[4][16];
 #pragma unroll
@@ -1105,7 +1114,7 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         // scalars, window + one trash cell per lane and channel plane (the fixed-point window packs two channels per cell)
         const size_t lds_win = 16 + (size_t)(g.wvox_max + 64) * (fixed ? CS / 2 : CS) * sizeof(double);
         const size_t lds_all = lds_win + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
-        gl_.resident = (lds_all <= 150 * 1024 && a.CoutP <= 128) ? 1 : 0;
+        gl_.resident = (lds_all <= 150 * 1024 && (a.CoutP <= 128 || !fixed)) ? 1 : 0;   // (Cout = 256: resident weights, grad_out rows re-read per item)
         const int abl = getenv("DLKA_GX_ABL") ? atoi(getenv("DLKA_GX_ABL")) : 0;   // profiling only (wrong results)
         gl_.ablate = abl;
         constexpr bool far_taps = false;   // (measured: 390 vs 370 us at 32^3 — slower)
@@ -1148,7 +1157,7 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
             const size_t wbytes = (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
             const size_t qbytes = (size_t)8 * GX_QW * 8 * sizeof(float);   // 8 waves x GX_QW far-sample records
 #define DLKA_GX2(SWv, SHv, SDv)                                                                                                    \
-    if (nw <= SWv && nh <= SHv && nd <= SDv && 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes + qbytes <= 79 * 1024) {        \
+    if (nw <= SWv && nh <= SHv && nd <= SDv && 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes + qbytes <= 150 * 1024) {       \
         const size_t lds2 = 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes + qbytes;                                         \
         if (a.act_bf16) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t>; hipLaunchKernelGGL(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); } \
         else { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float>; hipLaunchKernelGGL(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }             \
