@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--extras", action="store_true", help="also report the full-net training iteration, the 2-D block images/s and the sliding-window tiles/s "
                     "(SURVEY §8d secondary metrics; ~1 min)")
+    ap.add_argument("--no-companion", action="store_true", help="skip the same step measured with the other activation dtype (N = 1 only)")
     ap.add_argument("--no-tblock", action="store_true", help="skip the second metric (wrapper-block stack through nn.Module/autograd)")
     ap.add_argument("--cpu-sample", default="stage", choices=["stage", "tiny"])
     return ap.parse_args()
@@ -445,6 +446,36 @@ def inference_metric(dev):
             "value": round(n / dt, 2), "unit": "tiles/s", "tiles": n, "seconds_per_volume": round(dt, 2), "tile_batch": 4}
 
 
+def companion_metric(batch, steps, warmup, dev, dtype, lr):
+    """The same stack step (fwd + bwd of the 21 blocks + SGD update, hipGraph replay) with the OTHER activation storage type — reported next to
+    the headline so that one default run shows both: fp32 (the reference's arithmetic, 1e-4 parity) and bf16 activations (north_star's target
+    dtype; parity against the bf16-storage oracle)."""
+    from deformablelka_amd.stack import DLKABlockStack
+    from deformablelka_amd import dp
+    st = DLKABlockStack(batch, device=dev, dtype=dtype, seed=1234, data_seed=4321)
+    st.forward_backward()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        st.forward_backward()
+
+    def step():
+        dp.step_single(st, lr, 1, None, g.replay)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    h = st.health()
+    if not h["finite"]:
+        raise RuntimeError(f"non-finite parameters or gradients: {h}")
+    return {"dtype": "bf16" if dtype == torch.bfloat16 else "f32", "value": round(batch * steps / el, 3), "unit": "volumes/s",
+            "ms_per_step": round(el / steps * 1e3, 4), "steps": steps, "offset_std_voxels_by_stage": h["offset_std"]}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -621,6 +652,13 @@ def main():
         if dtype == torch.bfloat16:
             out["config"]["bf16"] = ("bf16 STORAGE of every activation tensor (x, y, saved, intermediate gradients); fp32 parameters, offsets, "
                                      "grad_offset and accumulation; offset-predict conv on single bf16 MFMA products, the other contractions on fp32 MFMA")
+        if world == 1 and not args.no_companion:
+            try:
+                out["other_dtype"] = companion_metric(args.batch, args.steps, args.warmup, dev, torch.bfloat16 if dtype == torch.float32 else torch.float32, lr)
+            except Exception as e:
+                log("companion dtype measurement failed:", repr(e))
+                out["other_dtype"] = None
+            torch.cuda.empty_cache()
         if not args.no_tblock and world == 1 and dtype == torch.float32:
             try:
                 out["tblock"] = tblock_metric(args.batch, max(3, args.steps // 2), 2, dev)
