@@ -165,10 +165,11 @@ def time_ops(B, C, N, dtype, iters=10, only=None):
 OP_COUNT = {"pointwise_fwd": 3, "pointwise_bwd_data": 3, "pointwise_bwd_weight": 3}
 # the HIP kernel that carries each op (rocprofv3 --kernel-trace name) and what else the op launches
 OP_KERNEL = {
-    "deform_bwd_input": ("dlka::cl_deform_gx_kernel", "+ cl_prep_weight (5 us) + zero_fill (5 us) + cl_deform_gx_gather_kernel (15 us)"),
-    "deform_bwd_offset": ("dlka::cl_deform_goff2_kernel<1>", "+ cl_prep_weight (5 us)"),
+    "deform_bwd_input": ("dlka::cl_deform_gx_fx2_kernel<34, 10, 10>", "+ cl_prep_weight (5 us) + zero_fill (5 us) + cl_deform_gx_gather_kernel (15 us)"),
+    "deform_bwd_offset": ("dlka::cl_deform_goff2_kernel<1>", "+ cl_prep_weight (5 us); inside the block this kernel also stores the samples for the weight gradient"),
     "deform_fwd": ("dlka::cl_deform_fwd_kernel<1>", "+ cl_prep_weight (5 us)"),
-    "deform_bwd_weight": ("dlka::cl_wgrad_deform_kernel<3>", "+ cl_wgrad_reduce_kernel (13 us)"),
+    "deform_bwd_weight": ("dlka::cl_wgrad_deform_kernel<3>", "+ cl_wgrad_reduce_kernel (13 us); the operator call gathers for itself — inside the block "
+                          "cl_wgrad_samp_kernel<3> contracts the samples cl_deform_goff2_kernel stored (59 us, profiles/r03n_f32_stage0_block_kernel_stats.csv)"),
     "offset_conv_fwd": ("dlka::cl_igemm_kernel<0, 1, 3, 3>", "+ cl_prep_weight (5 us)"),
     "offset_conv_bwd_data": ("dlka::cl_conv_wave_kernel<2, 0, 1, 2, 2>", "+ cl_prep_weight (5 us)"),
     "offset_conv_bwd_weight": ("dlka::cl_wgrad_dense_kernel<1, 3, 3, true, true>", "+ cl_wgrad_reduce_kernel (9 us)"),
