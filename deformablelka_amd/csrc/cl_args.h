@@ -4,6 +4,32 @@
 
 namespace dlka {
 
+// Several zero fills in one launch (every dependent kernel node costs ~4.5 us of dispatch latency inside a hipGraph on
+// MI355X, profiles/r01n): regions are 16-byte aligned float arrays.
+struct ZeroBatch {
+    int n;
+    float *p[8];
+    long cnt[8];          // floats
+    unsigned block0[9];   // first workgroup of each region (set by the launcher)
+    bool overflow;        // more than 8 regions were added: the launcher refuses (a dropped zero fill would be a silent wrong answer)
+    void add(float *ptr, size_t floats) { if (!ptr || !floats) return; if (n >= 8) { overflow = true; return; } p[n] = ptr; cnt[n] = (long)floats; ++n; }
+};
+
+// zero-fill workgroup `zb` of a ZeroBatch (4096 floats of one region), run by `nthreads` threads of any kernel
+__device__ __forceinline__ void zero_batch_block(const ZeroBatch &b, unsigned zb, int tid, int nthreads)
+{
+    if (zb >= b.block0[b.n]) return;
+    int r = 0;
+    while (r + 1 < b.n && zb >= b.block0[r + 1]) ++r;
+    float *p = b.p[r];
+    const long n = b.cnt[r], base = (long)(zb - b.block0[r]) * 4096;
+    for (int k = tid; k < 1024; k += nthreads) {
+        const long i = base + (long)k * 4;
+        if (i + 3 < n) *reinterpret_cast<f32x4 *>(p + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+        else for (long j = i; j < n && j < base + 4096; ++j) p[j] = 0.f;
+    }
+}
+
 struct IgemmArgs {
     const float *in;     // AMODE 0/1: [B][N][Cin] channels-last; AMODE 2: [B][CinReal][N] planar
     const float *off;    // AMODE 1: [B][3K][N] planar offsets (reference layout)
@@ -24,6 +50,8 @@ struct IgemmArgs {
     int act_bf16;        // 1: the activation tensors (in, aux, aux2, out, out2 — whatever is channels-last) are bf16 storage (DLKA_BF16 token path;
                          //    fp32 arithmetic, fp32 weights / bias); planar tensors (offsets, grad_offset) are always fp32
     int aux_f32;         // act_bf16 only: `aux` is fp32 all the same (the grad_input accumulation target of the deformable conv)
+    ZeroBatch zero;      // optional zero fills that RIDE in this launch (cl_pointwise_kernel only: extra workgroups behind the row tiles) — one
+    int zero_xblocks;    //   dependent graph node less per block and direction; zero_xblocks (set by the launcher) = those extra blockIdx.x
     int epi;             // 0: out = acc+bias | 1: out = acc+bias, out2 = gelu(out) | 2: out = acc+bias, out2 = aux*out | 3: out = acc+bias+aux
                          // 4: out = (acc+bias)*aux, out2 = (acc+bias)*aux2   (gate backward fused into proj_2's data gradient)
 };
@@ -134,17 +162,6 @@ struct DeformBwdArgs {
     int act_bf16;       // 1: in / g are bf16 storage (gx, goff stay fp32: atomics / planar)
     int goff_cpad;      // > 0: goff is written as pack_split2() words with goff_cpad channel planes per batch (planes >= 3K zero) for the
                         //      split-MFMA consumers (offset-conv data / weight gradient); 0: plain fp32 [B][3K][N]
-};
-
-// Several zero fills in one launch (every dependent kernel node costs ~4.5 us of dispatch latency inside a hipGraph on
-// MI355X, profiles/r01n): regions are 16-byte aligned float arrays.
-struct ZeroBatch {
-    int n;
-    float *p[8];
-    long cnt[8];          // floats
-    unsigned block0[9];   // first workgroup of each region (set by the launcher)
-    bool overflow;        // more than 8 regions were added: the launcher refuses (a dropped zero fill would be a silent wrong answer)
-    void add(float *ptr, size_t floats) { if (!ptr || !floats) return; if (n >= 8) { overflow = true; return; } p[n] = ptr; cnt[n] = (long)floats; ++n; }
 };
 
 }  // namespace dlka

@@ -401,6 +401,10 @@ int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t s
         const int rc = launch_cl_pointwise(a, st);
         if (rc != DLKA_ERR_UNSUPPORTED) return rc;
     }
+    if (a.zero.n > 0) {   // only the pointwise kernel carries riding zero fills: anything else gets them as a launch of their own
+        if (launch_zero_batch(a.zero, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
+        a.zero.n = 0;
+    }
     if (splits > 1 && !a.out_zeroed) {
         const long n = (long)a.M * a.Cout;
         if (launch_zero(a.out, (size_t)n * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;

@@ -19,6 +19,10 @@ __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
     const T *auxp = reinterpret_cast<const T *>(p.aux), *aux2p = reinterpret_cast<const T *>(p.aux2);
     T *outp = reinterpret_cast<T *>(p.out), *out2p = reinterpret_cast<T *>(p.out2);
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    if (p.zero_xblocks && (int)blockIdx.x >= (int)gridDim.x - p.zero_xblocks) {   // riding zero fills (IgemmArgs::zero): the workgroups behind the row tiles
+        zero_batch_block(p.zero, (blockIdx.x - (gridDim.x - p.zero_xblocks)) * gridDim.y + blockIdx.y, lane, 64);
+        return;
+    }
     const int mbase = blockIdx.x * 32, n0 = blockIdx.y * 32;
     const int m = mbase + i, n = n0 + i;
     const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * SB);
@@ -160,8 +164,22 @@ int launch_cl_pointwise(const IgemmArgs &a, hipStream_t st)
     if (a.K != 1 || a.split_bf16 || a.Cin % 32 || a.CinP != a.Cin || a.NP % 32) return DLKA_ERR_UNSUPPORTED;
     if ((long)a.M * a.Cin * 4 >= (1l << 31) || (long)a.CinP * a.NP * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     dim3 grid(cdiv(a.M, 32), a.NP / 32), block(64);
-    if (a.act_bf16) { auto k = cl_pointwise_kernel<bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-    else { auto k = cl_pointwise_kernel<float>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    IgemmArgs ax = a;
+    ax.zero_xblocks = 0;
+    if (a.zero.n > 0) {   // zero fills riding in this launch: 4096 floats per extra workgroup
+        if (a.zero.overflow) return DLKA_ERR_WORKSPACE;
+        unsigned blk = 0;
+        for (int r = 0; r < a.zero.n; ++r) {
+            if ((uintptr_t)a.zero.p[r] & 15) return DLKA_ERR_UNSUPPORTED;
+            ax.zero.block0[r] = blk;
+            blk += (unsigned)cdivl(a.zero.cnt[r], 4096);
+        }
+        ax.zero.block0[a.zero.n] = blk;
+        ax.zero_xblocks = (int)cdiv((int)blk, (int)grid.y);
+        grid.x += ax.zero_xblocks;
+    }
+    if (a.act_bf16) { auto k = cl_pointwise_kernel<bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, ax); }
+    else { auto k = cl_pointwise_kernel<float>; hipLaunchKernelGGL(k, grid, block, 0, st, ax); }
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }

@@ -106,8 +106,9 @@ int dense_forward_splits(const SameConv &s, int epi) { return cl_igemm_pick_spli
 int dense_backward_data_splits(const SameConv &s, int epi) { return cl_igemm_pick_splits(s.M, s.K * (round_up(s.Cout, 32) / 32), epi, s.K); }
 
 // zeroed: the caller has zero-filled `out` (needed when the tap split is > 1; one batched fill per block instead of one per conv)
+// ride: zero fills that go out with this launch (pointwise kernel; any other kernel gets them as a launch of their own, cl_igemm.hip)
 int dense_forward(const SameConv &s, const float *x, const float *w, const float *bias, float *out, int out_planar, float *wp,
-                  int epi, const float *aux, float *out2, hipStream_t st, bool zeroed = false)
+                  int epi, const float *aux, float *out2, hipStream_t st, bool zeroed = false, const ZeroBatch *ride = nullptr)
 {
     const int NP = round_up(s.Cout, 32);
     const int split = use_split(s, true);
@@ -117,6 +118,7 @@ int dense_forward(const SameConv &s, const float *x, const float *w, const float
     a.split_bf16 = split;
     a.in = x; a.wp = wp; a.bias = bias; a.out = out; a.out2 = out2; a.aux = aux; a.epi = epi; a.out_zeroed = zeroed ? 1 : 0;
     a.Cin = s.Cin; a.CinReal = s.Cin; a.CinP = s.Cin; a.Cout = s.Cout; a.NP = NP;
+    if (ride) a.zero = *ride;
     const int splits = dense_forward_splits(s, epi);
     return launch_cl_igemm(0, out_planar ? 1 : 0, a, splits, st);
 }
@@ -127,7 +129,7 @@ int dense_forward(const SameConv &s, const float *x, const float *w, const float
 // partial sums and is converted into gx afterwards
 int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, const float *w, float *gx, float *wp, int epi,
                         const float *aux, hipStream_t st, const float *aux2 = nullptr, float *out2 = nullptr, bool zeroed = false, bool g_packed = false,
-                        bool aux_f32 = false, float *acc32 = nullptr)
+                        bool aux_f32 = false, float *acc32 = nullptr, const ZeroBatch *ride = nullptr)
 {
     const int KP = round_up(s.Cout, 32), NP = s.Cin;
     if (!(nt_ok(NP) || NP == 192 || NP == 384) || s.Cin % 32) return DLKA_ERR_UNSUPPORTED;   // (192 / 384: the 2-D block's widths, 3 / 4 column tiles per workgroup)
@@ -145,6 +147,7 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
         a.a_packed = 1; a.CinReal = KP;
     }
     a.aux_f32 = aux_f32 ? 1 : 0;
+    if (ride) a.zero = *ride;
     const int splits = dense_backward_data_splits(s, epi);
     if (s.act_bf16 && splits > 1) {
         if (!acc32) return DLKA_ERR_WORKSPACE;
@@ -820,14 +823,15 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     if (dense_forward_splits(G.dcn, 0) > 1) zb.add(bf ? acc32 : f, G.E);
     if (dense_forward_splits(G.pw, 3) > 1) zb.add(y, G.E);
     TokPrep PW;
-    if (prepared) {   // the prepared weights are already in `saved` (dlka_lka3d_tokens_prepare_run): only the zero fills remain
+    const ZeroBatch *ride = nullptr;
+    if (prepared) {   // the prepared weights are already in `saved` (dlka_lka3d_tokens_prepare_run): the zero fills ride in the first kernel
         DLKA_TRY(carve_prep(G, prep, PW, p, st, false));
-        if (zb.n) DLKA_TRY(launch_zero_batch(zb, st));
+        if (zb.n) ride = &zb;
     } else {
         DLKA_TRY(carve_prep(G, prep, PW, p, st, true, &zb));
     }
     // proj_1 + GELU (transformerblock.py:667-668): h kept for the GELU gradient, a = GELU(h)
-    DLKA_TRY(dense_forward(G.pw, x, N0, (const float *)p->proj_1_b, h, 0, PW.pw_f[0], 1, nullptr, a, st));
+    DLKA_TRY(dense_forward(G.pw, x, N0, (const float *)p->proj_1_b, h, 0, PW.pw_f[0], 1, nullptr, a, st, false, ride));
     // depthwise 5^3 then 7^3 dilation 3 (:646-647)
     DLKA_TRY(dw_forward(G.dw5, a, N0, (const float *)p->conv0_b, t1, PW.dw5_f, 0, st));
     DLKA_TRY(dw_forward(G.dw7, t1, N0, (const float *)p->conv_spatial_b, t, PW.dw7_f, 0, st));
@@ -990,14 +994,14 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     if (dense_backward_data_splits(G.pw, 0) > 1) zb.add(gf, G.E);
     if (dense_backward_data_splits(G.offc, 3) > 1) zb.add(bf ? ga2 : gt, G.E);   // bf16: split partial sums land in the fp32 scratch ga2
     if (dense_backward_data_splits(G.pw, 3) > 1) zb.add(gx, G.E);
-    DLKA_TRY(launch_zero_batch(zb, st));
-    DLKA_TRY(publish());   // fork: everything issued before this call (gy, saved activations, the previous block's use of the workspace)
+    if (zb.overflow) return DLKA_ERR_WORKSPACE;
+    // (the zero fills ride in the first kernel below: one dependent node less per block)
 
     // proj_2:  y = P2 m + x.   Its data gradient gm = P2^T gy feeds only the gate  m = a * g1, whose backward is fused into
     // the epilogue:  gg1 = gm * a,  ga1 = gm * g1
     // (the three pointwise weight gradients run as ONE launch at the end: their operands m/gy, f/gg1, x/gh all stay live)
-    DLKA_TRY(dense_backward_data(G.pw, gy, 0, N0, gg1, PW.pw_b[2], 4, a, st, g1, ga1));
-    DLKA_TRY(publish());
+    DLKA_TRY(dense_backward_data(G.pw, gy, 0, N0, gg1, PW.pw_b[2], 4, a, st, g1, ga1, false, false, false, nullptr, &zb));
+    DLKA_TRY(publish());   // fork: everything issued so far (gy, saved activations, the zero fills, the previous block's use of the workspace)
     // conv1:  g1 = P0 f
     DLKA_TRY(dense_backward_data(G.pw, gg1, 0, N0, gf, PW.pw_b[1], 0, nullptr, st, nullptr, nullptr, true));
     DLKA_TRY(publish());
