@@ -246,7 +246,6 @@ def test_lka3d_tokens_weight_gradient_from_stored_samples_bf16():
     parity.check_lka3d_tokens_sample_handover("cpu", 1, 32, (4, 4, 4), dtype=torch.bfloat16)
 
 
-
 @pytest.mark.parametrize("C,dims,mode,scale", [(32, (6, 5, 7), "normal", 1.0), (32, (3, 9, 32), "normal", 1.0), (64, (5, 4, 16), "uniform3", 1.0),
                                                (32, (6, 5, 7), "wild", 1.0)])
 def test_deform3d_cl_gx_second_generation_fixed_point_kernel(C, dims, mode, scale):

@@ -372,10 +372,9 @@ def test_tblock3d_chain():
 
 
 @pytest.mark.parametrize("C,dims,dtype", [(32, (32, 32, 32), torch.float32), (64, (16, 16, 16), torch.float32), (256, (4, 4, 4), torch.float32),
-                                          (32, (16, 16, 16), torch.bfloat16)])
+                                          (32, (16, 16, 16), torch.bfloat16), (64, (5, 6, 7), torch.float32), (128, (3, 5, 7), torch.bfloat16)])
 def test_lka3d_tokens_weight_gradient_from_stored_samples(C, dims, dtype):
     parity.check_lka3d_tokens_sample_handover(DEV, 2, C, dims, dtype=dtype)
-
 
 
 @pytest.mark.parametrize("C,dims,mode", [(32, (32, 32, 32), "normal"), (64, (16, 16, 16), "normal"), (32, (16, 16, 16), "wild"), (32, (8, 8, 8), "uniform3"),
