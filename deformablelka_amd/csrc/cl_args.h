@@ -56,6 +56,18 @@ struct IgemmArgs {
                          // 4: out = (acc+bias)*aux, out2 = (acc+bias)*aux2   (gate backward fused into proj_2's data gradient)
 };
 
+// Two pointwise convs back to back in one launch (cl_pointwise_pair_kernel, C <= 64):
+//   forward  (bwd = 0):  t = in * W1 + bias1;  out1 = t;  out1b = a * t;   out2 = out1b * W2 + bias2 + b          (conv1 + gate, proj_2 + shortcut)
+//   backward (bwd = 1):  t = in * W1;          out1 = t * a;  out1b = t * b;  out2 = out1 * W2                       (proj_2^T + gate backward, conv1^T)
+// W1 / W2: prepared [C][C] operand layouts (cl_prep, mode 0 forward / mode 1 data gradient); all tensors channels-last [M][C].
+struct PwPairArgs {
+    const float *in, *wp1, *bias1, *wp2, *bias2, *a, *b;
+    float *out1, *out1b, *out2;
+    int M, C, bwd, act_bf16;
+    ZeroBatch zero;      // riding zero fills, as in IgemmArgs
+    int zero_blocks;     // set by the launcher
+};
+
 struct WgradArgs {
     const float *g;
     const float *in;    // [B][N][Cin] channels-last

@@ -158,6 +158,175 @@ __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two dependent pointwise convs in ONE launch (PwPairArgs): conv1 + gate -> proj_2 + shortcut in the forward pass, proj_2^T + gate backward ->
+// conv1^T in the backward pass.  Each of these kernels is ~8-10 us of load latency -> 16 MFMAs -> store latency, plus ~4.5 us of graph
+// dispatch; a wave that owns ALL C <= 64 columns of its 32 rows can feed the second contraction from its own first result: the intermediate
+// tile goes through a wave-private LDS tile (D layout in, A-operand rows out), nothing else changes — same MFMA order, same epilogue
+// arithmetic, same rounding of the stored intermediate (bf16 storage: the second conv consumes the ROUNDED values, as it does unfused).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int NTC>   // NTC = C / 32 column tiles = 32-channel chunks
+__global__ __launch_bounds__(64, 2) void cl_pointwise_pair_kernel(PwPairArgs p)
+{
+    constexpr unsigned SB = sizeof(T);
+    constexpr bool B16 = SB == 2;
+    constexpr int C = NTC * 32, LD = C + 4;
+    __shared__ __attribute__((aligned(16))) float Tm[32 * LD];
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int mtiles = (int)gridDim.x - p.zero_blocks;
+    if ((int)blockIdx.x >= mtiles) {   // riding zero fills
+        zero_batch_block(p.zero, blockIdx.x - mtiles, lane, 64);
+        return;
+    }
+    const T *ap = reinterpret_cast<const T *>(p.a), *bp = reinterpret_cast<const T *>(p.b);
+    T *o1 = reinterpret_cast<T *>(p.out1), *o1b = reinterpret_cast<T *>(p.out1b), *o2 = reinterpret_cast<T *>(p.out2);
+    const int mbase = blockIdx.x * 32, m = mbase + i;
+    const bool odd = i & 1;
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * C * SB);
+    const BufRsrc rw1 = make_rsrc(p.wp1, (size_t)C * C * 4), rw2 = make_rsrc(p.wp2, (size_t)C * C * 4);
+    const unsigned abase = m < p.M ? (unsigned)m * (unsigned)C * SB + 16u * SB * h : DLKA_OOB;
+    // element (row R(r), column n) of a channels-last tensor, D layout: R(r) = mbase + (r & 3) + 8 * (r >> 2) + 4 * h
+    auto row_of = [&](int r) { return mbase + (r & 3) + 8 * (r >> 2) + 4 * h; };
+    auto load_tile = [&](const T *src, int nt, float *v) {   // v[r] = src[R(r)][nt * 32 + i]
+        const int n = nt * 32 + i;
+        if (B16) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int mrow = row_of(r) + (odd ? 1 : 0);
+                const unsigned own = mrow < p.M ? *reinterpret_cast<const unsigned *>(src + ((long)mrow * C + (n & ~1))) : 0u;
+                const unsigned oth = lane_xor1(own);
+                v[r] = __uint_as_float(odd ? (oth & 0xffff0000u) : (own << 16));
+                v[r + 1] = __uint_as_float(odd ? (own & 0xffff0000u) : (oth << 16));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = row_of(r) < p.M ? act_load1(src, (long)row_of(r) * C + n) : 0.f;
+        }
+    };
+    auto store_tile = [&](T *dst, int nt, const float *v) {   // dst[R(r)][nt * 32 + i] = v[r]
+        const int n = nt * 32 + i;
+        if (B16) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const unsigned give = bf16_bits(odd ? v[r] : v[r + 1]), mine = bf16_bits(odd ? v[r + 1] : v[r]);
+                const unsigned got = lane_xor1(give);
+                const unsigned word = odd ? (got | (mine << 16)) : (mine | (got << 16));
+                const int mrow = row_of(r) + (odd ? 1 : 0);
+                if (mrow < p.M) *reinterpret_cast<unsigned *>(dst + ((long)mrow * C + (n & ~1))) = word;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (row_of(r) < p.M) act_store1(dst, (long)row_of(r) * C + n, v[r]);
+        }
+    };
+    auto stored = [&](float x) { return B16 ? bf16_value(bf16_bits(x)) : x; };   // the value a tensor of type T holds after x was stored
+
+    // ---- first conv: A rows from global memory ----
+    f32x4 a[NTC][4];
+#pragma unroll
+    for (int u = 0; u < NTC; ++u) {
+        const unsigned ao = abase == DLKA_OOB ? DLKA_OOB : abase + (unsigned)u * 32u * SB;
+        if (B16) {
+            buf_load_bf16x8(rin, ao, a[u][0], a[u][1]);
+            buf_load_bf16x8(rin, ao == DLKA_OOB ? DLKA_OOB : ao + 16u, a[u][2], a[u][3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[u][e] = act_buf_load4<T>(rin, ao == DLKA_OOB ? DLKA_OOB : ao + 16u * e);
+        }
+    }
+#pragma unroll 1
+    for (int nt = 0; nt < NTC; ++nt) {   // (not unrolled: two column tiles in flight at once spill)
+        const int n = nt * 32 + i;
+        float av[16], bv2[16];
+        load_tile(ap, nt, av);                       // gate operand a
+        if (p.bwd) load_tile(bp, nt, bv2);           // backward: the second gate operand (g1)
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < NTC; ++u) {
+            float b[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) b[s] = buf_load_f32(rw1, (unsigned)((u * 32 + 16 * h + s) * C + n) * 4u);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = mfma_32x32x2(a[u][s >> 2][s & 3], b[s], acc);
+        }
+        const float bias = (!p.bwd && p.bias1) ? p.bias1[n] : 0.f;
+        float t1[16], t2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float t = acc[r] + bias;
+            if (p.bwd) { t1[r] = t * av[r]; t2[r] = t * bv2[r]; }   // gg1 = gm * a, ga1 = gm * g1
+            else { t1[r] = t; t2[r] = av[r] * t; }                     // g1, m = a * g1
+        }
+        store_tile(o1, nt, t1);
+        store_tile(o1b, nt, t2);
+        // operand of the second conv (backward: out1, forward: out1b) -> LDS tile, rows = voxels
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Tm[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + n] = stored(p.bwd ? t1[r] : t2[r]);
+    }
+    wave_sync();
+    // ---- second conv: A rows from the LDS tile ----
+    f32x4 a2[NTC][4];
+#pragma unroll
+    for (int u = 0; u < NTC; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a2[u][e] = *reinterpret_cast<const f32x4 *>(Tm + i * LD + u * 32 + 16 * h + 4 * e);
+#pragma unroll 1
+    for (int nt = 0; nt < NTC; ++nt) {
+        const int n = nt * 32 + i;
+        float res[16];
+        if (!p.bwd) load_tile(bp, nt, res);   // forward: the shortcut operand
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int u = 0; u < NTC; ++u) {
+            float b[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) b[s] = buf_load_f32(rw2, (unsigned)((u * 32 + 16 * h + s) * C + n) * 4u);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = mfma_32x32x2(a2[u][s >> 2][s & 3], b[s], acc);
+        }
+        const float bias = (!p.bwd && p.bias2) ? p.bias2[n] : 0.f;
+        float y[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = p.bwd ? acc[r] : acc[r] + bias + res[r];
+        store_tile(o2, nt, y);
+    }
+}
+
+int launch_cl_pointwise_pair(const PwPairArgs &a, hipStream_t st)
+{
+    if ((a.C != 32 && a.C != 64) || (long)a.M * a.C * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;
+    PwPairArgs ax = a;
+    ax.zero_blocks = 0;
+    unsigned blocks = (unsigned)cdiv(a.M, 32);
+    if (a.zero.n > 0) {
+        if (a.zero.overflow) return DLKA_ERR_WORKSPACE;
+        unsigned blk = 0;
+        for (int r = 0; r < a.zero.n; ++r) {
+            if ((uintptr_t)a.zero.p[r] & 15) return DLKA_ERR_UNSUPPORTED;
+            ax.zero.block0[r] = blk;
+            blk += (unsigned)cdivl(a.zero.cnt[r], 4096);
+        }
+        ax.zero.block0[a.zero.n] = blk;
+        ax.zero_blocks = (int)blk;
+        blocks += blk;
+    }
+    dim3 grid(blocks), block(64);
+    if (a.act_bf16) {
+        if (a.C == 32) { auto k = cl_pointwise_pair_kernel<bf16_t, 1>; hipLaunchKernelGGL(k, grid, block, 0, st, ax); }
+        else { auto k = cl_pointwise_pair_kernel<bf16_t, 2>; hipLaunchKernelGGL(k, grid, block, 0, st, ax); }
+    } else {
+        if (a.C == 32) { auto k = cl_pointwise_pair_kernel<float, 1>; hipLaunchKernelGGL(k, grid, block, 0, st, ax); }
+        else { auto k = cl_pointwise_pair_kernel<float, 2>; hipLaunchKernelGGL(k, grid, block, 0, st, ax); }
+    }
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
 // K = 1, channels-last in and out, unsplit, exact fp32.  Returns DLKA_ERR_UNSUPPORTED for anything else.
 int launch_cl_pointwise(const IgemmArgs &a, hipStream_t st)
 {

@@ -300,6 +300,21 @@ int deform_backward(const SameConv &s, const float *x, const float *off, const f
     return DLKA_OK;
 }
 
+// conv1 + gate -> proj_2 + shortcut (bwd = 0) / their data gradients (bwd = 1) as ONE launch where the pair kernel exists (C = 32 / 64).
+// DLKA_PW_UNFUSED=1 keeps the two launches (A/B runs).  Returns DLKA_ERR_UNSUPPORTED when the caller has to issue the two convs itself.
+int pointwise_pair(const SameConv &s, int bwd, const float *in, const float *wp1, const float *bias1, const float *wp2, const float *bias2,
+                   const float *a, const float *b, float *out1, float *out1b, float *out2, hipStream_t st, const ZeroBatch *ride = nullptr)
+{
+    static const bool unfused = getenv("DLKA_PW_UNFUSED") != nullptr;
+    if (unfused || (s.Cin != 32 && s.Cin != 64) || s.Cin != s.Cout || s.K != 1) return DLKA_ERR_UNSUPPORTED;
+    PwPairArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.in = in; pa.wp1 = wp1; pa.bias1 = bias1; pa.wp2 = wp2; pa.bias2 = bias2; pa.a = a; pa.b = b;
+    pa.out1 = out1; pa.out1b = out1b; pa.out2 = out2; pa.M = s.M; pa.C = s.Cin; pa.bwd = bwd; pa.act_bf16 = s.act_bf16;
+    if (ride) pa.zero = *ride;
+    return launch_cl_pointwise_pair(pa, st);
+}
+
 // ---- the token-layout 3-D block ----------------------------------------------------------------------------------------
 SameConv block_conv(int B, int C, int Cout, int D, int H, int W, int k, int pad, int dil, int group, int act_bf16 = 0)
 {
@@ -840,8 +855,10 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     // deformable 3^3 conv (deform_conv.py:95-105)
     DLKA_TRY(deform_forward(G.dcn, t, off, N0, (const float *)p->deform_b, f, PW.dcn_f, st, true, acc32));
     // conv1 + gate u*attn (:650-652): g1 kept, m = a * g1
+    // ... and proj_2 + shortcut (:670-671) — one launch at C <= 64 (cl_pointwise_pair_kernel)
+    const int prc = pointwise_pair(G.pw, 0, f, PW.pw_f[1], (const float *)p->conv1_b, PW.pw_f[2], (const float *)p->proj_2_b, a, x, g1, m, y, st);
+    if (prc != DLKA_ERR_UNSUPPORTED) return prc;
     DLKA_TRY(dense_forward(G.pw, f, N0, (const float *)p->conv1_b, g1, 0, PW.pw_f[1], 2, a, m, st));
-    // proj_2 + shortcut (:670-671)
     DLKA_TRY(dense_forward(G.pw, m, N0, (const float *)p->proj_2_b, y, 0, PW.pw_f[2], 3, x, nullptr, st, true));
     return DLKA_OK;
 }
@@ -1000,10 +1017,15 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     // proj_2:  y = P2 m + x.   Its data gradient gm = P2^T gy feeds only the gate  m = a * g1, whose backward is fused into
     // the epilogue:  gg1 = gm * a,  ga1 = gm * g1
     // (the three pointwise weight gradients run as ONE launch at the end: their operands m/gy, f/gg1, x/gh all stay live)
-    DLKA_TRY(dense_backward_data(G.pw, gy, 0, N0, gg1, PW.pw_b[2], 4, a, st, g1, ga1, false, false, false, nullptr, &zb));
-    DLKA_TRY(publish());   // fork: everything issued so far (gy, saved activations, the zero fills, the previous block's use of the workspace)
-    // conv1:  g1 = P0 f
-    DLKA_TRY(dense_backward_data(G.pw, gg1, 0, N0, gf, PW.pw_b[1], 0, nullptr, st, nullptr, nullptr, true));
+    // ... and conv1:  g1 = P0 f,  gf = P0^T gg1 — one launch at C <= 64
+    const int prc = dense_backward_data_splits(G.pw, 0) > 1 ? DLKA_ERR_UNSUPPORTED
+                                                            : pointwise_pair(G.pw, 1, gy, PW.pw_b[2], nullptr, PW.pw_b[1], nullptr, a, g1, gg1, ga1, gf, st, &zb);
+    if (prc != DLKA_ERR_UNSUPPORTED) DLKA_TRY(prc);
+    else {
+        DLKA_TRY(dense_backward_data(G.pw, gy, 0, N0, gg1, PW.pw_b[2], 4, a, st, g1, ga1, false, false, false, nullptr, &zb));
+        DLKA_TRY(publish());   // fork: everything issued so far (gy, saved activations, the zero fills, the previous block's use of the workspace)
+        DLKA_TRY(dense_backward_data(G.pw, gg1, 0, N0, gf, PW.pw_b[1], 0, nullptr, st, nullptr, nullptr, true));
+    }
     DLKA_TRY(publish());
     // deformable conv:  f = DCN(t, off):  grad_offset and grad_input on the main stream, the weight gradient on the side one — after
     // grad_offset when that kernel hands over the samples it interpolated (samp), else at once with its own gather

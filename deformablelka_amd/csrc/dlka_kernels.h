@@ -52,6 +52,7 @@ int cl_prep_table_blocks(long n);
 int launch_cl_prep_table(const PrepJob *jobs_dev, const int *first_dev, int njobs, int nblocks, hipStream_t st);
 int cl_igemm_pick_splits(int M, int units, int epi, int K);
 int launch_cl_pointwise(const IgemmArgs &a, hipStream_t st);
+int launch_cl_pointwise_pair(const PwPairArgs &a, hipStream_t st);   // two dependent pointwise convs in one launch (C = 32 / 64)
 int launch_cl_conv_wave(int amode, int omode, const IgemmArgs &a, int splits, hipStream_t st);
 int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t st);
 int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st);
