@@ -300,13 +300,14 @@ int deform_backward(const SameConv &s, const float *x, const float *off, const f
     return DLKA_OK;
 }
 
-// conv1 + gate -> proj_2 + shortcut (bwd = 0) / their data gradients (bwd = 1) as ONE launch where the pair kernel exists (C = 32 / 64).
+// conv1 + gate -> proj_2 + shortcut (bwd = 0) / their data gradients (bwd = 1) as ONE launch where the pair kernel pays (C = 32).
 // DLKA_PW_UNFUSED=1 keeps the two launches (A/B runs).  Returns DLKA_ERR_UNSUPPORTED when the caller has to issue the two convs itself.
 int pointwise_pair(const SameConv &s, int bwd, const float *in, const float *wp1, const float *bias1, const float *wp2, const float *bias2,
                    const float *a, const float *b, float *out1, float *out1b, float *out2, hipStream_t st, const ZeroBatch *ride = nullptr)
 {
-    static const bool unfused = getenv("DLKA_PW_UNFUSED") != nullptr;
-    if (unfused || (s.Cin != 32 && s.Cin != 64) || s.Cin != s.Cout || s.K != 1) return DLKA_ERR_UNSUPPORTED;
+    const bool unfused = getenv("DLKA_PW_UNFUSED") != nullptr;   // (not cached: a parity test toggles it)
+    // (C = 64 exists in the kernel but loses: 26 us against 2 x 7.7 + 4.5 us at 16^3 — M / 32 = 256 waves are too few; profiles/r03n notes)
+    if (unfused || s.Cin != 32 || s.Cin != s.Cout || s.K != 1) return DLKA_ERR_UNSUPPORTED;
     PwPairArgs pa;
     memset(&pa, 0, sizeof(pa));
     pa.in = in; pa.wp1 = wp1; pa.bias1 = bias1; pa.wp2 = wp2; pa.bias2 = bias2; pa.a = a; pa.b = b;

@@ -337,6 +337,46 @@ def check_lka3d_tokens_sample_handover(dev, B, C, dims, dtype=torch.float32, see
         assert rel_err(g_s[name], g_g[name]) < (1e-5 if dtype == torch.float32 else 2e-2), (name, rel_err(g_s[name], g_g[name]))
 
 
+def check_lka3d_tokens_pointwise_pair(dev, B, dims, dtype=torch.float32, seed=0):
+    """conv1 + gate -> proj_2 + shortcut (and their data gradients) as one launch (cl_pointwise_pair_kernel, C = 32) against the two separate
+    launches (DLKA_PW_UNFUSED=1): same MFMA order, same epilogue arithmetic, same rounding of the stored intermediate -> output and gradients
+    agree to the summation order of the atomics elsewhere in the block."""
+    import deformablelka_amd as dk
+    from oracle import blocks
+    torch.manual_seed(seed)
+    C = 32
+    H, W, D = dims
+    m = dk.LKA_Attention3d_deform(C)
+    blocks.randomize_offsets_(m, std=0.2)
+    m = m.to(dev)
+    x = torch.randn(B, H * W * D, C).to(dev).to(dtype)
+    gy = torch.randn(B, H * W * D, C).to(dev).to(dtype)
+
+    def run():
+        for q in m.parameters():
+            q.grad = None
+        xd = x.clone().requires_grad_(True)
+        y = m(xd, B, C, H, W, D)
+        y.backward(gy)
+        return y.detach().float().cpu(), {"x": xd.grad.float().cpu(), **{k: q.grad.detach().float().cpu().clone() for k, q in m.named_parameters()}}
+
+    old = os.environ.get("DLKA_PW_UNFUSED")
+    try:
+        os.environ.pop("DLKA_PW_UNFUSED", None)
+        y_f, g_f = run()
+        os.environ["DLKA_PW_UNFUSED"] = "1"
+        y_u, g_u = run()
+    finally:
+        if old is None:
+            os.environ.pop("DLKA_PW_UNFUSED", None)
+        else:
+            os.environ["DLKA_PW_UNFUSED"] = old
+    # (not torch.equal: at small volumes the deformable conv upstream is tap-split and its partial sums meet in atomics — f itself moves by ~1e-7)
+    assert rel_err(y_f, y_u) < (1e-6 if dtype == torch.float32 else 1e-2), rel_err(y_f, y_u)
+    for name in g_f:
+        assert rel_err(g_f[name], g_u[name]) < (1e-5 if dtype == torch.float32 else 2e-2), (name, rel_err(g_f[name], g_u[name]))
+
+
 def check_lka2d_attention(dev, B, C, H, W, seed=0, offset_std=0.03, atol=2e-4, rtol=2e-3, report=False):
     """deformable_LKA_Attention (2D/deformable_LKA/deformable_LKA.py:124-140) vs the oracle block; widths with C % 32 == 0 take the
     channels-last fast path (MFMA offset nets + cl_ddw2d.hip), the rest the general NCHW kernels."""

@@ -250,3 +250,9 @@ def test_lka3d_tokens_weight_gradient_from_stored_samples_bf16():
                                                (32, (6, 5, 7), "wild", 1.0)])
 def test_deform3d_cl_gx_second_generation_fixed_point_kernel(C, dims, mode, scale):
     parity.check_deform3d_cl_gx_fx2_vs_fx1("cpu", 1, C, dims, mode, scale)
+
+
+@pytest.mark.parametrize("dims,dtype", [((4, 4, 4), torch.float32), ((3, 5, 7), torch.float32), ((4, 4, 8), torch.bfloat16)])
+def test_lka3d_tokens_pointwise_pair_equals_two_launches(dims, dtype):
+    parity.check_lka3d_tokens_pointwise_pair("cpu", 1, dims, dtype)
+

@@ -381,3 +381,9 @@ def test_lka3d_tokens_weight_gradient_from_stored_samples(C, dims, dtype):
                                          (64, (5, 6, 7), "normal")])
 def test_deform3d_cl_gx_second_generation_fixed_point_kernel(C, dims, mode):
     parity.check_deform3d_cl_gx_fx2_vs_fx1(DEV, 2, C, dims, mode)
+
+
+@pytest.mark.parametrize("dims,dtype", [((32, 32, 32), torch.float32), ((5, 6, 7), torch.float32), ((16, 16, 16), torch.bfloat16)])
+def test_lka3d_tokens_pointwise_pair_equals_two_launches(dims, dtype):
+    parity.check_lka3d_tokens_pointwise_pair(DEV, 2, dims, dtype)
+
