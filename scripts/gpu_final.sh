@@ -7,6 +7,9 @@ echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q > $OUT/py
 echo "== smoke"; timeout 600 python -c 'import __graft_entry__ as g; g.smoke()' > $OUT/smoke.log 2>&1; echo "exit $?"; tail -2 $OUT/smoke.log
 echo "== bench (default)"; timeout 900 python bench.py > $OUT/bench_f32.json 2> $OUT/bench_f32.err; echo "exit $?"
 echo "== bench --dtype bf16"; timeout 900 python bench.py --dtype bf16 --no-cpu-baseline > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err; echo "exit $?"
+echo "== bench under torch.distributed.run (1 rank, nccl), overlapped all-reduce schedule forced"
+DLKA_BENCH_FORCE_SPLIT=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-tblock --no-companion --no-roofline > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err; echo "exit $?"; python -c "
+import json; d=json.load(open('$OUT/bench_dist1.json')); print('dist1', d['value'], d['ms_per_step'], d['config']['allreduce_overlap'], d['config']['allreduce_split_block'])"
 if [ "${EXTRAS:-1}" = 1 ]; then echo "== bench --extras"; timeout 1200 python bench.py --extras --no-cpu-baseline --no-companion > $OUT/bench_extras.json 2> $OUT/bench_extras.err; echo "exit $?"; fi
 python - <<PY
 import json
