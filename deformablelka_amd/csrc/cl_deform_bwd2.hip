@@ -8,10 +8,9 @@
 // the locality (1.0-1.6 ms for the 4.5e8 corner updates of one C=32, 32^3, B=2 call), LDS *fp32* atomics (ds_add_f32)
 // are no faster (0.33 lanes/clk/CU), but LDS *fp64* atomics (ds_add_f64) run at 6.7 lanes/clk/CU — 20x.  Hence:
 //
-//   cl_deform_goff_kernel   grad_offset only: a pure gather, no atomics.  MFMA orientation D[channel][voxel]
-//                           (A = W_tap^T from LDS, B = grad_out rows kept in registers for all 27 taps), so a lane owns
-//                           ONE voxel: its sampling description is lane-local and the channel reduction of
-//                           Col * d(sample)/d(q) is 16 in-register FMAs per corner plus one cross-half add.
+//   cl_deform_goff2_kernel  grad_offset only: a pure gather, no atomics.  MFMA orientation D[channel][voxel]
+//                           (A = W_tap^T from LDS, B = grad_out rows), corner rows gathered in the line-friendly layout of
+//                           cl_gather.h; optionally stores the interpolated samples for the weight gradient.
 //   cl_deform_gx_kernel     grad_input: a workgroup owns a brick of OUTPUT voxels and a 4-channel slice; the scatter
 //                           accumulates in an fp64 LDS window (brick + 3-voxel halo) with ds_add_f64 — the sum is exact
 //                           to fp64 and independent of the order —; MFMA rows = 8 taps x 4 channels, columns = voxels.
@@ -70,134 +69,6 @@ __device__ __forceinline__ void lane_tap(LaneTap &s, const float *__restrict__ o
 // =====================================================================================================================
 // grad_offset
 // =====================================================================================================================
-// grid: (ceil(M / 128), tap groups); block 256 = 4 waves x 32 voxels.  Lane (j = lane & 31, h = lane >> 5): voxel j of the
-// wave; MFMA D regs r <-> channel (r & 3) + 8 * (r >> 2) + 4 * h of the current 32-channel chunk.
-template <int NKC_REG>   // grad_out chunks (32 channels each) kept in registers across taps; 0 = reload per use
-__global__ __launch_bounds__(256) void cl_deform_goff_kernel(DeformBwdArgs p, int taps_per_block)
-{
-    __shared__ __attribute__((aligned(16))) float Bs[32 * 32];          // W[tap][co chunk][ci chunk]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const int m = (blockIdx.x * 4 + wave) * 32 + j;
-    const bool row_ok = m < p.M;
-    const int b = row_ok ? m / p.N : 0;
-    const int v = row_ok ? m - b * p.N : 0;
-    const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / (p.W * p.H);
-    const int HW = p.H * p.W;
-    const int ncc = p.C / 32, nkc = p.CoutP / 32;
-    const int tap_lo = blockIdx.y * taps_per_block, tap_hi = min(p.K, tap_lo + taps_per_block);
-    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.C * 4);
-
-    // B operand: grad_out[m][kc*32 + 16h + s]
-    float greg[NKC_REG > 0 ? NKC_REG : 1][16];
-    if (NKC_REG > 0) {
-#pragma unroll
-        for (int kc = 0; kc < NKC_REG; ++kc) {
-            if (row_ok && kc < nkc && kc * 32 + 16 * h < p.Cout) {
-                const f32x4 *g4 = reinterpret_cast<const f32x4 *>(p.g + (long)m * p.Cout + kc * 32 + 16 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const f32x4 t = g4[e];
-                    greg[kc][4 * e] = t[0]; greg[kc][4 * e + 1] = t[1]; greg[kc][4 * e + 2] = t[2]; greg[kc][4 * e + 3] = t[3];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) greg[kc][e] = 0.f;
-            }
-        }
-    }
-
-    for (int tap = tap_lo; tap < tap_hi; ++tap) {
-        const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
-        LaneTap s;
-        s.okm = 0; s.zd = s.zh = s.zw = 0; s.ld = s.lh = s.lw = 0.f;
-        if (row_ok)
-            lane_tap(s, p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v, p.N, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw,
-                     p.D, p.H, p.W);
-        float S[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) S[q] = 0.f;
-        const unsigned cbase = (unsigned)(((b * p.N + (s.zd * p.H + s.zh) * p.W + s.zw) * p.C + 4 * h) * 4);   // bytes; only used where okm is set
-
-        for (int cc = 0; cc < ncc; ++cc) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 1
-            for (int kc = 0; kc < nkc; ++kc) {
-                __syncthreads();   // Bs consumed
-                {
-                    const int rr = tid >> 3, c4 = tid & 7;   // 32 rows (co) x 32 floats (ci): 256 float4
-                    reinterpret_cast<f32x4 *>(Bs)[rr * 8 + c4] =
-                        *(reinterpret_cast<const f32x4 *>(p.wp + ((long)tap * p.CoutP + kc * 32 + rr) * p.C + cc * 32) + c4);
-                }
-                float gl[16];
-                if (NKC_REG == 0) {
-                    if (row_ok && kc * 32 + 16 * h < p.Cout) {
-                        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(p.g + (long)m * p.Cout + kc * 32 + 16 * h);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const f32x4 t = g4[e];
-                            gl[4 * e] = t[0]; gl[4 * e + 1] = t[1]; gl[4 * e + 2] = t[2]; gl[4 * e + 3] = t[3];
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) gl[e] = 0.f;
-                    }
-                }
-                __syncthreads();
-                const float *arow = Bs + (16 * h) * 32 + j;   // A[i = channel j][k = co 16h + st]
-                if (NKC_REG == 1) {
-#pragma unroll
-                    for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], greg[0][st], acc);
-                } else if (NKC_REG == 2) {
-                    if (kc == 0) {
-#pragma unroll
-                        for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], greg[0][st], acc);
-                    } else {
-#pragma unroll
-                        for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], greg[NKC_REG > 1 ? 1 : 0][st], acc);
-                    }
-                } else {
-#pragma unroll
-                    for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], gl[st], acc);
-                }
-            }
-            // acc[r] = Col[voxel j][ci = cc*32 + (r&3) + 8*(r>>2) + 4h];  unconditional buffer loads, dropped corners -> 0
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
-                const unsigned off = ((s.okm >> q) & 1u) ? cbase + (unsigned)((cd * HW + ch * p.W + cw) * p.C + cc * 32) * 4u : DLKA_OOB;
-                float sq = S[q];
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const f32x4 x4 = buf_load_f32x4(rin, off + 32u * g4);
-                    sq = fmaf(acc[4 * g4], x4[0], sq); sq = fmaf(acc[4 * g4 + 1], x4[1], sq);
-                    sq = fmaf(acc[4 * g4 + 2], x4[2], sq); sq = fmaf(acc[4 * g4 + 3], x4[3], sq);
-                }
-                S[q] = sq;
-            }
-        }
-        // d(sample)/d(q_axis) = sum_q sign_axis(q) * (product of the other two axis weights) * x_q   (cuh:111-190)
-        const float fd[2] = {1.f - s.ld, s.ld}, fh[2] = {1.f - s.lh, s.lh}, fw[2] = {1.f - s.lw, s.lw};
-        float gd = 0.f, gh = 0.f, gw = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
-            gd = fmaf((cd ? 1.f : -1.f) * fh[ch] * fw[cw], S[q], gd);
-            gh = fmaf((ch ? 1.f : -1.f) * fd[cd] * fw[cw], S[q], gh);
-            gw = fmaf((cw ? 1.f : -1.f) * fd[cd] * fh[ch], S[q], gw);
-        }
-        gd += __shfl_xor(gd, 32);   // the two halves hold complementary channel sets of the same voxel
-        gh += __shfl_xor(gh, 32);
-        gw += __shfl_xor(gw, 32);
-        if (h == 0 && row_ok) {
-            float *dst = p.goff + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
-            dst[0] = gd; dst[p.N] = gh; dst[2 * (long)p.N] = gw;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // grad_offset with the line-friendly gather of cl_gather.h.
 //   goff_axis[m, tap] = sum_c Col[m, tap, c] * Dax[m, tap, c],   Dax = sum_q dcoef_axis(q) * x_q   (cuh:111-190)
@@ -1062,21 +933,16 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const int tpb = cdiv(a.K, tsplit);
         tsplit = cdiv(a.K, tpb);
         const int nkc = a.CoutP / 32;
-        constexpr bool v1 = false;   // (first "lane = voxel" gather, cl_deform_goff_kernel: superseded, 225-250 us against 150)
-        const int ccsplit = v1 ? 1 : cl_deform_goff_ccsplit(a);
+        // (the first "lane = voxel" gather kernel, 225-250 us against 150 at 32^3, was removed in round 2)
+        const int ccsplit = cl_deform_goff_ccsplit(a);
         DeformBwdArgs ag = a;
         ag.cc_per_block = cdiv(a.C / 32, ccsplit);
-        if (a.goff_cpad && (ccsplit > 1 || v1)) return DLKA_ERR_UNSUPPORTED;   // the packed layout needs the single-writer path
+        if (a.goff_cpad && ccsplit > 1) return DLKA_ERR_UNSUPPORTED;   // the packed layout needs the single-writer path
         if (ccsplit > 1 && !a.goff_zeroed && launch_zero(a.goff, (size_t)a.B * 3 * a.K * a.N * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         dim3 grid(mblocks, tsplit, ccsplit), block(256);
         ag.xcd_nx = 0;
-        if (!v1 && xcd_swizzle_enabled() && mblocks >= xcd_min_blocks()) { ag.xcd_nx = mblocks; grid.x = xcd_grid(mblocks); }
-        if (v1 && a.act_bf16) return DLKA_ERR_UNSUPPORTED;
-        if (v1) {
-            if (nkc == 1) { auto k = cl_deform_goff_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
-            else if (nkc == 2) { auto k = cl_deform_goff_kernel<2>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
-            else { auto k = cl_deform_goff_kernel<0>; hipLaunchKernelGGL(k, grid, block, 0, st, a, tpb); }
-        } else {
+        if (xcd_swizzle_enabled() && mblocks >= xcd_min_blocks()) { ag.xcd_nx = mblocks; grid.x = xcd_grid(mblocks); }
+        {
             // storing variant: grad_out rows in registers only at Cout = 32 / fp32 (measured at 32^3: 179 vs 186 us; bf16 149 vs 155 us the other way)
 #define DLKA_GOFF2(NK, TT)                                                                                                           \
     {                                                                                                                                \
