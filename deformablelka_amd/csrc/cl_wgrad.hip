@@ -4,7 +4,8 @@
 //   AMODE 0  A = in[b][voxel + tap offset][ci]  (zero padded)     1x1x1 projections, offset-predict conv
 //   AMODE 1  A = trilinear sample                                  deformable conv; the reference recomputes the whole
 //                                                                  im2col buffer for this (deform_conv_cuda.cu:254-261),
-//                                                                  here a 32-row x 7-tap sample tile lives in LDS only
+//                                                                  here a 32-row sample tile per tap lives in LDS only, or the
+//                                                                  samples come stored from the grad_offset kernel (samp)
 //   GMODE 0  G channels-last [M][Cout];  GMODE 1  G planar [B][Cout][N] (the offset tensor keeps the reference layout)
 //
 // One wave (64-thread workgroup) owns one 32(co) x 32(ci) output tile for TPW taps and walks a chunk of rows, 32 at a
@@ -18,176 +19,6 @@
 #include "dlka_kernels.h"
 
 namespace dlka {
-
-template <int AMODE, int GMODE, int TPW>
-__global__ __launch_bounds__(64) void cl_wgrad_kernel(WgradArgs p)
-{
-    constexpr int SROW = 36;  // padded row (floats): conflict-free 16-byte writes, 16-byte aligned
-    __shared__ __attribute__((aligned(16))) float S[(AMODE == 1) ? TPW * 32 * SROW : 4];
-    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
-    const int chunk = blockIdx.x;
-    const int ot = blockIdx.y / p.CT, ct = blockIdx.y % p.CT;
-    const int tap0 = blockIdx.z * TPW;
-    const int co = ot * 32 + i;      // A-operand row (as lane i)
-    const int ci = ct * 32 + i;      // B-operand column (as lane j = i)
-    const bool want_bias = p.bpart && ct == 0 && blockIdx.z == 0;
-    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * 4);
-
-    f32x16 acc[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float bsum = 0.f;
-
-    // tap offsets of this wave (uniform): neighbour = voxel + (od, oh, ow)
-    int od[TPW], oh[TPW], ow[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int tap = tap0 + t;
-        od[t] = (tap / (p.kw * p.kh)) * p.dd - p.pd;
-        oh[t] = ((tap / p.kw) % p.kh) * p.dh - p.ph;
-        ow[t] = (tap % p.kw) * p.dw - p.pw;
-    }
-
-    const int m_lo = chunk * p.rows_per_chunk;
-    const int m_hi = min(p.M, m_lo + p.rows_per_chunk);
-    for (int mbase = m_lo; mbase < m_hi; mbase += 32) {
-        // ---- rows this lane touches in the MFMA k dimension: m = mbase + 16h + s ----
-        const int mrow0 = mbase + 16 * h;
-        const int b0 = mrow0 / p.N, v0 = mrow0 - b0 * p.N;
-        // ---- A operand: G[m][co], s = 0..15 ----
-        float ga[16];
-        if (GMODE == 0) {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int m = mrow0 + s;
-                ga[s] = (m < m_hi && co < p.Cout) ? p.g[(long)m * p.Cout + co] : 0.f;
-            }
-        } else {
-            const bool contiguous = (v0 + 15 < p.N) && (mrow0 + 15 < m_hi) && ((p.N & 3) == 0) && ((v0 & 3) == 0);
-            if (contiguous && co < p.Cout) {   // 16 consecutive voxels of one plane: four 16-byte loads
-                const f32x4 *g4 = reinterpret_cast<const f32x4 *>(p.g + ((long)b0 * p.Cout + co) * p.N + v0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const f32x4 t4 = g4[e];
-                    ga[4 * e] = t4[0]; ga[4 * e + 1] = t4[1]; ga[4 * e + 2] = t4[2]; ga[4 * e + 3] = t4[3];
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int m = mrow0 + s;
-                    float val = 0.f;
-                    if (m < m_hi && co < p.Cout) {
-                        const int b = m / p.N, v = m - b * p.N;
-                        val = p.g[((long)b * p.Cout + co) * p.N + v];
-                    }
-                    ga[s] = val;
-                }
-            }
-        }
-        if (want_bias) {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) bsum += ga[s];
-        }
-        if (AMODE == 1) {
-            // ---- phase 1: sample tile S[t][row][32 ch] for this wave's TPW taps (lane = (row i, channel half h)) ----
-            __syncthreads();  // previous tile consumed
-            const int m = mbase + i;
-            const bool row_ok = m < m_hi;
-            const int b = row_ok ? m / p.N : 0, v = row_ok ? m - b * p.N : 0;
-            const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / (p.W * p.H);
-            const unsigned cbyte = (unsigned)(ct * 32 + 16 * h) * 4u;
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int tap = tap0 + t;
-                float a[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) a[e] = 0.f;
-                if (tap < p.K) {   // uniform
-                    TapSample<3> s;
-                    if (row_ok) {
-                        const float *offp = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
-                        setup_tap<3>(s, offp, p.N, d0 + od[t], h0 + oh[t], w0 + ow[t], p.D, p.H, p.W);
-                    } else {
-                        s.ok = 0;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) { s.idx[q] = 0; s.w[q] = 0.f; }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {   // unconditional buffer loads: dropped corners read DLKA_OOB -> 0
-                        const unsigned off = ((s.ok >> q) & 1u) ? (unsigned)((b * p.N + s.idx[q]) * p.Cin) * 4u + cbyte : DLKA_OOB;
-                        const float wq = s.w[q];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const f32x4 x4 = buf_load_f32x4(rin, off + 16u * e);
-                            a[4 * e] = fmaf(wq, x4[0], a[4 * e]); a[4 * e + 1] = fmaf(wq, x4[1], a[4 * e + 1]);
-                            a[4 * e + 2] = fmaf(wq, x4[2], a[4 * e + 2]); a[4 * e + 3] = fmaf(wq, x4[3], a[4 * e + 3]);
-                        }
-                    }
-                }
-                f32x4 *dst = reinterpret_cast<f32x4 *>(S + (t * 32 + i) * SROW + 16 * h);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    f32x4 o4;
-                    o4[0] = a[4 * e]; o4[1] = a[4 * e + 1]; o4[2] = a[4 * e + 2]; o4[3] = a[4 * e + 3];
-                    dst[e] = o4;
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const float *srow = S + (t * 32 + 16 * h) * SROW + i;
-#pragma unroll
-                for (int s = 0; s < 16; ++s) acc[t] = mfma_32x32x2(ga[s], srow[s * SROW], acc[t]);
-            }
-        } else {
-            // ---- B operand straight from global: in[neighbour(m = mrow0 + s)][ci] ----
-            // voxel coordinates of the 16 rows, decoded once per tile (packed d:10 | h:10 | w:10, b in the row offset)
-            int crd[16];
-            int rowoff[16];   // element offset of in[b][v][ci] (fits int: B*N*Cin < 2^31 checked by the launcher)
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                int v = v0 + s, b = b0;
-                if (v >= p.N) { v -= p.N; b += 1; }   // a tile spans at most two batch items when N >= 32; else general:
-                if (v >= p.N) { b = (mrow0 + s) / p.N; v = (mrow0 + s) - b * p.N; }
-                const int w_ = v % p.W, hh = (v / p.W) % p.H, d_ = v / (p.W * p.H);
-                crd[s] = (mrow0 + s < m_hi) ? ((d_ << 20) | (hh << 10) | w_) : -1;
-                rowoff[s] = (b * p.N + v) * p.Cin + ci;
-            }
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                if (tap0 + t >= p.K) continue;  // uniform
-                const int doff = ((od[t] * p.H + oh[t]) * p.W + ow[t]) * p.Cin;
-                float bv[16];
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int c_ = crd[s];
-                    const int zd = (c_ >> 20) + od[t], zh = ((c_ >> 10) & 1023) + oh[t], zw = (c_ & 1023) + ow[t];
-                    const bool ok = c_ >= 0 && zd >= 0 && zd < p.D && zh >= 0 && zh < p.H && zw >= 0 && zw < p.W;
-                    bv[s] = ok ? p.in[rowoff[s] + doff] : 0.f;
-                }
-#pragma unroll
-                for (int s = 0; s < 16; ++s) acc[t] = mfma_32x32x2(ga[s], bv[s], acc[t]);
-            }
-        }
-    }
-    // ---- partial tile out: D row = co_local, col = ci_local ----
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int tap = tap0 + t;
-        if (tap >= p.K) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            p.part[(((long)chunk * p.K + tap) * p.CoutP + ot * 32 + row) * p.Cin + ci] = acc[t][r];
-        }
-    }
-    if (want_bias) {
-        bsum += __shfl_xor(bsum, 32);   // the two halves hold the same co for different rows
-        if (h == 0) p.bpart[(long)chunk * p.CoutP + co] = bsum;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Deformable weight gradient, second generation: the sample tile of each tap is gathered in the line-friendly layout of
@@ -699,9 +530,7 @@ static WgradPlan wgrad_plan(int M, int K, int Cout, int Cin, int amode)
     WgradPlan pl;
     const int OT = round_up(Cout, 32) / 32, CT = Cin / 32;
     if (amode == 1) {
-        static int tpw_d = -1;
-        if (tpw_d < 0) tpw_d = 3;   // measured best (4 and 7 taps per wave: more registers, fewer waves)
-        pl.tpw = tpw_d == 0 ? 7 : tpw_d; pl.cot = 1;   // 0 selects the first-generation kernel (TPW 7)
+        pl.tpw = 3; pl.cot = 1;   // measured best (4 and 7 taps per wave: more registers, fewer waves)
     }
     else if (K == 1) { pl.tpw = 1; pl.cot = (OT % 2 == 0) ? 2 : 1; }
     else {
@@ -756,10 +585,9 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
     dim3 block(64);
     if (amode == 1) {
         if (gmode != 0 || a.K == 1) return DLKA_ERR_UNSUPPORTED;
-        constexpr bool v1 = false;   // (first-generation kernel cl_wgrad_kernel<1, 0, 7>: kept for the general igemm fallback only)
         dim3 grid(nchunks, OT * a.CT, cdiv(a.K, pl.tpw));
         static const bool no_xcd = getenv("DLKA_NO_XCD_SWIZZLE") != nullptr;   // A/B switch
-        if (!v1 && !no_xcd && nchunks >= xcd_min_blocks()) {
+        if (!no_xcd && nchunks >= xcd_min_blocks()) {
             a.xcd_ny = grid.y; a.xcd_nz = grid.z; a.xcd_total = (int)(grid.x * grid.y * grid.z);
             grid = dim3(xcd_grid(a.xcd_total), 1, 1);
         }
@@ -769,13 +597,11 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
             else { auto k = cl_wgrad_samp_kernel<3>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
         }
         else if (a.act_bf16) {
-            if (v1 || pl.tpw != 3) return DLKA_ERR_UNSUPPORTED;
+            if (pl.tpw != 3) return DLKA_ERR_UNSUPPORTED;
             auto k = cl_wgrad_deform_kernel<3, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, a);
         }
-        else if (v1) { auto k = cl_wgrad_kernel<1, 0, 7>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
         else if (pl.tpw == 3) { auto k = cl_wgrad_deform_kernel<3>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-        else if (pl.tpw == 4) { auto k = cl_wgrad_deform_kernel<4>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-        else { auto k = cl_wgrad_deform_kernel<7>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else return DLKA_ERR_UNSUPPORTED;   // (4 and 7 taps per wave measured slower: more registers, fewer waves)
     } else {
         dim3 grid(nchunks, cdiv(OT, pl.cot) * a.CT, cdiv(a.K, pl.tpw));
         static const bool no_xcd2 = getenv("DLKA_NO_XCD_SWIZZLE") != nullptr;
