@@ -299,6 +299,7 @@ struct GxGeom {
     int item_grid;          // 1: 1-D grid over (brick, slice) items; 0: x = brick, y = slice
     int tap_far;            // 1: half-waves take taps 16 apart (K <= 32 = 4 groups of 8), see gx_tap()
     int ablate;             // profiling only (DLKA_GX_ABL): 1 = no LDS atomics, 2 = no sampling description / scatter at all
+    float fx_magic;         // 1.5 * 2^23 (second-generation kernel: rounding constant, passed in a register on purpose)
     float fx_lim;           // fixed-point window: largest scaled magnitude of one contribution, R*K * (fx_lim + 1/2) < 2^31 (R = rows of a
                             // brick, K = taps), see the kernel
 };
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
     __syncthreads();
     // scale with the provable overflow bound of the first generation (see there)
     float fx_scale = 1.f, fx_inv = 1.f;
+    const float fx_magic = gg.fx_magic;   // 1.5 * 2^23
     {
         float wm = 0.f;
         if (tid < gg.ngroups * 32) {
@@ -726,6 +728,16 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
         }
         for (int grp = 0; grp < gg.ngroups; ++grp) {
             const float *Bg = Bs + (size_t)grp * p.CoutP * 32;
+            // the offsets of this lane's four (voxel, tap) samples of the group are requested BEFORE the MFMA phase: loaded where they are
+            // used, every scatter step began with an exposed L2 round trip (the kernel reacted to neither fewer VALU instructions nor the
+            // removal of its LDS atomics — it was waiting)
+            float offv[4][3];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int tq = grp * TG + 2 * r4 + h;
+                const float *op = p.off + ((long)b * 3 * p.K + 3 * (tq < p.K ? tq : 0)) * p.N + v;
+                offv[r4][0] = op[0]; offv[r4][1] = op[p.N]; offv[r4][2] = op[2 * (long)p.N];
+            }
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -747,10 +759,9 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
                 if (p.kw == 3 && p.kh == 3) { ti = tap / 9; const int rr = tap - 9 * ti; tj = rr / 3; tk = rr - 3 * tj; }   // uniform
                 else { tk = tap % p.kw; tj = (tap / p.kw) % p.kh; ti = tap / (p.kw * p.kh); }
                 // sampling rule of deform_im2col_cuda.cuh:244-259 (identical to lane_tap / setup_tap<3>)
-                const float *op = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
-                const float qd_ = (float)(vd + ti * p.dd - p.pd) + op[0];
-                const float qh_ = (float)(vh + tj * p.dh - p.ph) + op[p.N];
-                const float qw_ = (float)(vw + tk * p.dw - p.pw) + op[2 * (long)p.N];
+                const float qd_ = (float)(vd + ti * p.dd - p.pd) + offv[r4][0];
+                const float qh_ = (float)(vh + tj * p.dh - p.ph) + offv[r4][1];
+                const float qw_ = (float)(vw + tk * p.dw - p.pw) + offv[r4][2];
                 const bool valid = tv && qd_ > -1.f && qh_ > -1.f && qw_ > -1.f && qd_ < (float)p.D && qh_ < (float)p.H && qw_ < (float)p.W;
                 const float qd = valid ? qd_ : 0.f, qh = valid ? qh_ : 0.f, qw = valid ? qw_ : 0.f;
                 const float fld = floorf(qd), flh = floorf(qh), flw = floorf(qw);   // in [-1, size - 1]
@@ -772,7 +783,12 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
                         for (int pr = 0; pr < CS / 2; ++pr) {
                             // round(Col * ws) without v_rndne + v_cvt: |Col * ws| <= fx_lim < 2^22, so adding 1.5 * 2^23 in ONE fma leaves the
                             // integer (round to nearest even of the exact product) in the low mantissa bits: bits = 0x4B400000 + i
-                            const int t0 = __float_as_int(fmaf(acc[4 * r4 + 2 * pr], ws, 12582912.f)), t1 = __float_as_int(fmaf(acc[4 * r4 + 2 * pr + 1], ws, 12582912.f));
+                            // (two channels at once: the pair sits in adjacent accumulator registers -> one v_pk_fma_f32; the constant comes from a
+                            //  register — as a literal it forces the scalar v_fmaak form)
+                            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                            const f32x2_t cp = {acc[4 * r4 + 2 * pr], acc[4 * r4 + 2 * pr + 1]}, wp2 = {ws, ws}, mg = {fx_magic, fx_magic};
+                            const f32x2_t tp = cp * wp2 + mg;
+                            const int t0 = __float_as_int(tp[0]), t1 = __float_as_int(tp[1]);
                             const int i0 = t0 - 0x4B400000;
                             // packed = (int64)i1 * 2^32 + (int64)i0: low word i0, high word i1 - 1 if i0 < 0
                             const unsigned long long pk = ((unsigned long long)(unsigned)(t1 + (i0 >> 31) - 0x4B400000) << 32) | (unsigned long long)(unsigned)i0;
@@ -977,6 +993,7 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const bool fixed = fx_possible && (fx_env ? atoi(fx_env) != 0 : a.C <= 64);
         // (capped below 2^22: the second-generation kernel rounds with the 1.5 * 2^23 trick, exact for |value| < 2^22; tiny bricks would allow more)
         gl_.fx_lim = (float)(fx_lim < 4.0e6 ? fx_lim : 4.0e6);
+        gl_.fx_magic = 12582912.f;
         // scalars, window + one trash cell per lane and channel plane (the fixed-point window packs two channels per cell)
         const size_t lds_win = 16 + (size_t)(g.wvox_max + 64) * (fixed ? CS / 2 : CS) * sizeof(double);
         const size_t lds_all = lds_win + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);

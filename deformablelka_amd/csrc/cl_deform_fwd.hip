@@ -67,6 +67,17 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
             breg[e] = reinterpret_cast<const f32x4 *>(src_ + (long)rr_ * p.NP)[c4_];              \
         }                                                                                          \
     }
+    // The offsets of a tap are requested one tap AHEAD of their description (onx): loaded inside the description, every tap began with two
+    // dependent L2 round trips — offsets, then the corner rows they address — of which the one-unit prefetch distance hides one at best.
+    float onx[3] = {0.f, 0.f, 0.f};
+    const int tap_first = unit_lo / nchunk, tap_last = (unit_hi - 1) / nchunk;
+    auto load_offsets = [&](int tap) {
+        if (h == 0 && row_ok && tap <= tap_last) {
+            const float *op = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
+            onx[0] = op[0]; onx[1] = op[p.N]; onx[2] = op[2 * (long)p.N];
+        }
+    };
+    if (unit_lo < unit_hi) load_offsets(tap_first);
     // describe (when the tap changes) and issue the 32 corner loads of one unit
     auto issue = [&](int unit) {
         const int tap = unit / nchunk, ck = unit - tap * nchunk;
@@ -78,10 +89,10 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
                 RowDesc r;
                 r.base = 0; r.okm = 0; r.ld = r.lh = r.lw = 0.f;
                 if (row_ok)
-                    r = gather_describe(p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v, p.N, b, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph,
-                                        w0 + tk * p.dw - p.pw, p.D, p.H, p.W);
+                    r = gather_describe3(onx[0], onx[1], onx[2], p.N, b, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw, p.D, p.H, p.W);
                 gather_publish(Dt, i, r);
             }
+            load_offsets(tap + 1);   // in flight until the next tap is described
             wave_sync();
 #pragma unroll
             for (int g = 0; g < GG::NG; ++g) rd[g] = gather_lookup(Dt, GG::RPI * g + gr);
