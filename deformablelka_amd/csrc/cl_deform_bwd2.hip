@@ -40,11 +40,11 @@ struct LaneTap {
 };
 
 // Sampling rule of deform_im2col_cuda.cuh:244-259 for one (voxel, tap); identical to setup_tap<3> (deform_sample.h).
-__device__ __forceinline__ void lane_tap(LaneTap &s, const float *__restrict__ off, long N, int bd, int bh, int bw, int D, int H, int W)
+__device__ __forceinline__ void lane_tap(LaneTap &s, float od, float oh, float ow, int bd, int bh, int bw, int D, int H, int W)
 {
-    const float qd = (float)bd + off[0];
-    const float qh = (float)bh + off[N];
-    const float qw = (float)bw + off[2 * N];
+    const float qd = (float)bd + od;
+    const float qh = (float)bh + oh;
+    const float qw = (float)bw + ow;
     s.okm = 0;
     s.zd = s.zh = s.zw = 0;
     s.ld = s.lh = s.lw = 0.f;
@@ -399,6 +399,15 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
         const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
         const bool ok = row < R && vd < p.D && vh < p.H && vw < p.W;
         const int v = ok ? (vd * p.H + vh) * p.W + vw : 0;
+        // the offsets of this lane's four samples of the group, requested before the MFMA phase (see cl_deform_gx_fx2_kernel: loaded inside the
+        // scatter step, each step began with an exposed L2 round trip)
+        float offv[4][3];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int tq = gx_tap(grp, 2 * r4 + h, gg.tap_far);
+            const float *op = p.off + ((long)b * 3 * p.K + 3 * (tq < p.K ? tq : 0)) * p.N + v;
+            offv[r4][0] = op[0]; offv[r4][1] = op[p.N]; offv[r4][2] = op[2 * (long)p.N];
+        }
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -439,8 +448,7 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
             if (p.kw == 3 && p.kh == 3) { ti = tap / 9; const int rr = tap - 9 * ti; tj = rr / 3; tk = rr - 3 * tj; }   // uniform
             else { tk = tap % p.kw; tj = (tap / p.kw) % p.kh; ti = tap / (p.kw * p.kh); }
             LaneTap s;
-            lane_tap(s, p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v, p.N, vd + ti * p.dd - p.pd, vh + tj * p.dh - p.ph, vw + tk * p.dw - p.pw,
-                     p.D, p.H, p.W);
+            lane_tap(s, offv[r4][0], offv[r4][1], offv[r4][2], vd + ti * p.dd - p.pd, vh + tj * p.dh - p.ph, vw + tk * p.dw - p.pw, p.D, p.H, p.W);
             if (!s.okm) continue;
             const float fd[2] = {1.f - s.ld, s.ld}, fh[2] = {1.f - s.lh, s.lh}, fw[2] = {1.f - s.lw, s.lw};
             const int xd = s.zd - wd0, xh = s.zh - wh0, xw = s.zw - ww0;
