@@ -273,6 +273,21 @@ static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st
             const long runs2 = (long)a.B * a.D * dil_w * cdiv(a.H, th * dil_w) * cdiv(a.W, TW);
             dim3 grid2((unsigned)cdivl(runs2, rpb), 1, cdiv(a.C, cpb));
             swz(grid2);
+            // Small volumes: with 8 outputs along W per work-item the launch is a fraction of a wave per SIMD (16^3 x 64 channels: 576 waves) and the
+            // kernel's time is ONE wave's serial instruction stream (~7.7 K instructions at 7^3); 4 outputs per work-item double the waves
+            // and halve the stream.  Chosen where the 8-wide grid leaves SIMDs empty.
+            const long waves8 = runs2 * cpb / 64 * cdiv(a.C, cpb);
+            static const bool no_tw4 = getenv("DLKA_DW_NO_TW4") != nullptr;   // A/B
+            // (measured at the stage shapes, us, 4 vs 8 wide: 5^3 13.3 / 17.9 at 16^3, 12.7 / 17.4 at 8^3, 11.0 / 12.4 at 4^3; 7^3 19.0 / 18.5 at 16^3, 8.8 / 9.5 at 8^3)
+            if (!no_tw4 && th == 2 && waves8 < (kw == 5 ? 1024 : 384) && a.W % 4 == 0 && cdiv(a.W, 4) % wpr == 0) {
+                const long runs4 = (long)a.B * a.D * dil_w * cdiv(a.H, th * dil_w) * cdiv(a.W, 4);
+                dim3 grid4((unsigned)cdivl(runs4, rpb), 1, cdiv(a.C, cpb));
+                swz(grid4);
+                if (kw == 7) { auto k = cl_dwconv_rowsN_kernel<T, 7, 3, 4, 2>; hipLaunchKernelGGL(k, grid4, block, 0, st, ax); }
+                else { auto k = cl_dwconv_rowsN_kernel<T, 5, 1, 4, 2>; hipLaunchKernelGGL(k, grid4, block, 0, st, ax); }
+                DLKA_CHECK_LAUNCH();
+                return DLKA_OK;
+            }
             if (kw == 7 && th == 2) { auto k = cl_dwconv_rowsN_kernel<T, 7, 3, TW, 2>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
             else if (kw == 5 && th == 2) { auto k = cl_dwconv_rowsN_kernel<T, 5, 1, TW, 2>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
             else if constexpr (F32) {
