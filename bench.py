@@ -16,6 +16,7 @@ Prints ONE JSON line on rank 0 (see the driver contract), including
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -53,167 +54,154 @@ def parse():
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# per-op HIP-event timing of the stage-0 block (C=32, 32^3, B): finds the dominant kernel and its roofline fraction
+# roofline: per-kernel HIP-event durations of the step's OWN kernels (launch trace of the library, include/dlka.h)
 # ----------------------------------------------------------------------------------------------------------------
-def op_table(B, C, N, dtype_bytes):
-    """(name, launches per step over the 21 blocks is derived separately) algorithmic flops / bytes for ONE launch at
-    stage (C, N^3, B).  Bytes follow SURVEY §8d's rule: unique input bytes + output bytes, intermediates on-chip = 0."""
-    n = N ** 3
-    E = B * C * n
-    Off = B * 81 * n
-    s = dtype_bytes
-    t = {}
-    t["pointwise_fwd"] = (2 * C * E, 2 * E * s)
-    t["dw5_fwd"] = (2 * 125 * E, 2 * E * s)
-    t["dw7_fwd"] = (2 * 343 * E, 2 * E * s)
-    t["offset_conv_fwd"] = (2 * 27 * C * 81 * B * n, (E + Off) * s)
-    t["deform_fwd"] = (2 * 27 * C * C * B * n + 27 * B * n * (15 * C + 30), (2 * E + Off) * s)
-    t["pointwise_bwd_data"] = (2 * C * E, 2 * E * s)
-    t["pointwise_bwd_weight"] = (2 * C * E, 2 * E * s)
-    t["dw5_bwd_data"] = (2 * 125 * E, 2 * E * s)
-    t["dw5_bwd_weight"] = (2 * 125 * E, 2 * E * s)
-    t["dw7_bwd_data"] = (2 * 343 * E, 2 * E * s)
-    t["dw7_bwd_weight"] = (2 * 343 * E, 2 * E * s)
-    t["offset_conv_bwd_data"] = (2 * 27 * C * 81 * B * n, (E + Off) * s)
-    t["offset_conv_bwd_weight"] = (2 * 27 * C * 81 * B * n, (E + Off) * s)
-    # grad_input (brick scatter): Col = G W_tap^T on the matrix cores + 8 corners x C multiply-adds per (voxel, tap);
-    # reads grad_out, offsets, writes grad_input.   grad_offset (gather): Col again + 8 x C dot products + 3 x 8 blends;
-    # reads x, grad_out, offsets, writes grad_offset.
-    t["deform_bwd_input"] = (2 * 27 * C * C * B * n + 27 * B * n * (16 * C), (2 * E + Off) * s)
-    t["deform_bwd_offset"] = (2 * 27 * C * C * B * n + 27 * B * n * (16 * C + 48), (2 * E + 2 * Off) * s)
-    t["deform_bwd_weight"] = (2 * 27 * C * C * B * n + 27 * B * n * (15 * C + 30), (2 * E + Off) * s)
-    return t
+def kernel_work(name, B, C, n, dbytes):
+    """Algorithmic (flops, bytes) of ONE launch of kernel `name` inside a block of stage (C, n voxels per volume, batch B) — SURVEY.md §8d:
+    flops per the block's formula terms, bytes = unique input bytes + output bytes of the operator the kernel implements (activations
+    `dbytes` per element, offsets / grad_offset always fp32).  Kernels that only re-lay / fold / zero return (0, bytes or 0)."""
+    E, Off, M = B * C * n, B * 81 * n, B * n
+    s = dbytes
+    contr, interp = 2 * 27 * C * C * M, 27 * M * (15 * C + 30)
+    offc = 2 * 27 * C * 81 * M
+    if "cl_deform_goff2_kernel" in name:      # Col (MFMA) + 8 corners x C dot products + 3 axes; writes grad_offset (+ the sample hand-over, see `extra`)
+        return contr + 27 * M * (16 * C + 48), (2 * E) * s + 2 * Off * 4
+    if "cl_deform_gx_fx2_kernel" in name or "cl_deform_gx_kernel" in name:
+        return contr + 27 * M * (16 * C), 2 * E * s + Off * 4
+    if "cl_deform_fwd_kernel" in name:
+        return contr + interp, 2 * E * s + Off * 4
+    if "cl_wgrad_samp_kernel" in name:        # dense stream over the stored samples S[tap][m][c]
+        return contr, (27 * E + E) * s
+    if "cl_wgrad_deform_kernel" in name:
+        return contr + interp, 2 * E * s + Off * 4
+    if "cl_wgrad_dense_kernel" in name:
+        return offc, E * s + Off * 4
+    m = re.search(r"cl_(?:igemm|conv_wave)_kernel<(\d+), (\d+)", name)
+    if m:                                     # <mode, planar output, ...>: mode 0 = forward conv, 2 = data gradient from a planar grad_out
+        return offc, E * s + Off * 4
+    m = re.search(r"cl_dwconv_(?:rowsN|rows|wgrad2|wgrad)_kernel<[^,]+, (\d+), (\d+)", name)
+    if m:
+        k = int(m.group(1))
+        return 2 * k ** 3 * E, 2 * E * s
+    if "cl_pointwise_pair_kernel" in name:
+        return 2 * 2 * C * E, 4 * E * s
+    if "cl_pointwise_kernel" in name:
+        return 2 * C * E, 2 * E * s
+    if "cl_wgrad_pw3_kernel" in name:
+        return 3 * 2 * C * E, 6 * E * s
+    return 0, 0
 
 
-def time_ops(B, C, N, dtype, iters=10, only=None):
-    """HIP-event timing (torch.cuda.Event on the current stream == the stream the C-ABI launches on) of every
-    kernel-level op of one token-layout block, through the channels-last entry points the block itself uses."""
-    from ctypes import byref
+def trace_step(stack, reps=3):
+    """Run the step's forward + backward `reps` times EAGERLY under the library's launch trace: a HIP timing event behind every kernel launch,
+    on the launch's own stream (torch's current stream = the stream the C-ABI launches on).  Marks separate the blocks, so every record is
+    attributed to its block's stage.  Returns {(stage, kernel name): [count per step, mean ms]} and the per-step sum of all records."""
+    from ctypes import byref, c_float, create_string_buffer
     from deformablelka_amd import _lib as L
     lib = L.get_lib()
-    dev = torch.device("cuda", torch.cuda.current_device())
-    dt = L.DLKA_F32 if dtype == torch.float32 else L.DLKA_BF16
-    st = L.stream_ptr(torch.empty(1, device=dev))
-    g = torch.Generator().manual_seed(0)
-    bf16 = dtype == torch.bfloat16
-    mk = lambda *s: torch.randn(*s, generator=g).to(dev, dtype)              # activations in the run's storage type
-    mkf = lambda *s: torch.randn(*s, generator=g).to(dev, torch.float32)     # offsets, parameters: always fp32
-    x, go = mk(B, N, N, N, C), mk(B, N, N, N, C)                     # channels-last activations
-    off, goff = mkf(B, 81, N, N, N), mkf(B, 81, N, N, N)             # planar offsets
-    out, out_off = torch.empty(B, N, N, N, C, dtype=torch.float32, device=dev), torch.empty_like(off)   # (fp32-sized: also serves as fp32 grad_x)
-    w_pw, w5, w7 = mkf(C, C, 1, 1, 1), mkf(C, 1, 5, 5, 5), mkf(C, 1, 7, 7, 7)
-    w_off, w_dc = mkf(81, C, 3, 3, 3) * 0.02, mkf(C, C, 3, 3, 3) * 0.03
-    b_c, b_81 = mkf(C), mkf(81)
-    if bf16 and only is None:   # the per-op entry points carry bf16 activations for the deformable conv only (the dominant ops)
-        only = ("deform_fwd", "deform_bwd_input", "deform_bwd_offset", "deform_bwd_weight")
-    gw_pw, gw5, gw7, gw_off, gw_dc = (torch.empty_like(t) for t in (w_pw, w5, w7, w_off, w_dc))
+    dev = stack.device
+    st = torch.cuda.current_stream(dev).cuda_stream
+    stage_of = {}
+    cs = sorted({b.C for b in stack.blocks})
+    for i, b in enumerate(stack.blocks):
+        stage_of[i] = cs.index(b.C)
+    order = []      # (block index) per mark, in issue order
 
-    def geom(cout, k, p, d, grp):
-        return L.ConvGeom(B, C, N, N, N, cout, k, k, k, 1, 1, 1, p, p, p, d, d, d, grp, 1, 64)
+    def hook(i):
+        order.append(i)
+        L.check(lib.dlka_trace_mark(st), "trace_mark")
 
-    G = {"pw": geom(C, 1, 0, 1, 1), "dw5": geom(C, 5, 2, 1, C), "dw7": geom(C, 7, 9, 3, C), "off": geom(81, 3, 1, 1, 1),
-         "dcn": geom(C, 3, 1, 1, 1)}
-    wsb = max([lib.dlka_conv3d_cl_workspace(byref(v), dt, 1) for v in G.values()] +
-              [lib.dlka_deform_conv3d_cl_workspace(byref(G["dcn"]), dt, 1)])
-    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    P = L.ptr
-    N0 = None
-
-    def conv_fwd(key, w, b, inp, o, planar=0):
-        return lambda: lib.dlka_conv3d_forward_cl(P(inp), P(w), P(b), P(o), planar, P(ws), wsb, byref(G[key]), dt, st)
-
-    def conv_bwd(key, w, inp, gout, gx, gw, planar=0):
-        return lambda: lib.dlka_conv3d_backward_cl(P(inp), P(w), P(gout), planar, P(gx), P(gw), P(N0), P(ws), wsb, byref(G[key]), dt, st)
-
-    ops = {
-        "pointwise_fwd": conv_fwd("pw", w_pw, b_c, x, out),
-        "dw5_fwd": conv_fwd("dw5", w5, b_c, x, out),
-        "dw7_fwd": conv_fwd("dw7", w7, b_c, x, out),
-        "offset_conv_fwd": conv_fwd("off", w_off, b_81, x, out_off, 1),
-        "deform_fwd": lambda: lib.dlka_deform_conv3d_forward_cl(P(x), P(off), P(w_dc), P(b_c), P(out), P(ws), wsb, byref(G["dcn"]), dt, st),
-        "pointwise_bwd_data": conv_bwd("pw", w_pw, x, go, out, None),
-        "pointwise_bwd_weight": conv_bwd("pw", w_pw, x, go, None, gw_pw),
-        "dw5_bwd_data": conv_bwd("dw5", w5, x, go, out, None),
-        "dw5_bwd_weight": conv_bwd("dw5", w5, x, go, None, gw5),
-        "dw7_bwd_data": conv_bwd("dw7", w7, x, go, out, None),
-        "dw7_bwd_weight": conv_bwd("dw7", w7, x, go, None, gw7),
-        "offset_conv_bwd_data": conv_bwd("off", w_off, x, goff, out, None, 1),
-        "offset_conv_bwd_weight": conv_bwd("off", w_off, x, goff, None, gw_off, 1),
-        "deform_bwd_input": lambda: lib.dlka_deform_conv3d_backward_cl(P(x), P(off), P(w_dc), P(go), P(out), P(N0), P(N0), P(N0), P(ws), wsb, byref(G["dcn"]), dt, st),
-        "deform_bwd_offset": lambda: lib.dlka_deform_conv3d_backward_cl(P(x), P(off), P(w_dc), P(go), P(N0), P(out_off), P(N0), P(N0), P(ws), wsb, byref(G["dcn"]), dt, st),
-        "deform_bwd_weight": lambda: lib.dlka_deform_conv3d_backward_cl(P(x), P(off), P(w_dc), P(go), P(N0), P(N0), P(gw_dc), P(N0), P(ws), wsb, byref(G["dcn"]), dt, st),
-    }
-    res = {}
-    for name, fn in ops.items():
-        if only is not None and name not in only:
+    stack.forward_backward()            # warm
+    torch.cuda.synchronize()
+    # keep the host AHEAD of the device: the records measure back-to-back execution only if every launch is queued before its turn
+    try:
+        torch.cuda._sleep(int(60e6))
+    except Exception:
+        pass
+    L.check(lib.dlka_trace_start(8192, st), "trace_start")
+    try:
+        for _ in range(reps):
+            order.append(-1)
+            L.check(lib.dlka_trace_mark(st), "trace_mark")
+            stack.forward_backward(on_block=hook)
+    finally:
+        rc = lib.dlka_trace_stop()
+    L.check(rc, "trace_stop")
+    n = lib.dlka_trace_count()
+    buf = create_string_buffer(512)
+    ms = c_float()
+    acc, mark_i, cur, total, overhead = {}, -1, -1, 0.0, []
+    for i in range(n):
+        L.check(lib.dlka_trace_get(i, buf, 512, byref(ms)), "trace_get")
+        name = buf.value.decode()
+        if name == "(mark)":
+            mark_i += 1
+            cur = order[mark_i]
+            overhead.append(ms.value)
             continue
-        rc = fn()
-        if rc != 0:
-            raise RuntimeError(f"{name}: dlka status {rc}")
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        res[name] = e0.elapsed_time(e1) / iters  # ms per launch
-    return res
+        key = (stage_of.get(cur, -1), name)
+        a = acc.setdefault(key, [0, 0.0])
+        a[0] += 1
+        a[1] += ms.value
+        total += ms.value
+    out = {k: (v[0] / reps, v[1] / v[0]) for k, v in acc.items()}
+    nrec = sum(v[0] for v in acc.values()) / reps
+    return out, total / reps, (sorted(overhead)[len(overhead) // 2] if overhead else 0.0), nrec
 
 
-# launches of each op per stage-block fwd+bwd (3 pointwise convs per block)
-OP_COUNT = {"pointwise_fwd": 3, "pointwise_bwd_data": 3, "pointwise_bwd_weight": 3}
-# the HIP kernel that carries each op (rocprofv3 --kernel-trace name) and what else the op launches
-OP_KERNEL = {
-    "deform_bwd_input": ("dlka::cl_deform_gx_fx2_kernel<34, 10, 10>", "+ cl_prep_weight (5 us) + zero_fill (5 us) + cl_deform_gx_gather_kernel (15 us)"),
-    "deform_bwd_offset": ("dlka::cl_deform_goff2_kernel<1>", "+ cl_prep_weight (5 us); inside the block this kernel also stores the samples for the weight gradient"),
-    "deform_fwd": ("dlka::cl_deform_fwd_kernel<1>", "+ cl_prep_weight (5 us)"),
-    "deform_bwd_weight": ("dlka::cl_wgrad_deform_kernel<3>", "+ cl_wgrad_reduce_kernel (13 us); the operator call gathers for itself — inside the block "
-                          "cl_wgrad_samp_kernel<3> contracts the samples cl_deform_goff2_kernel stored (59 us, profiles/r03n_f32_stage0_block_kernel_stats.csv)"),
-    "offset_conv_fwd": ("dlka::cl_igemm_kernel<0, 1, 3, 3>", "+ cl_prep_weight (5 us)"),
-    "offset_conv_bwd_data": ("dlka::cl_conv_wave_kernel<2, 0, 1, 2, 2>", "+ cl_prep_weight (5 us)"),
-    "offset_conv_bwd_weight": ("dlka::cl_wgrad_dense_kernel<1, 3, 3, true, true>", "+ cl_wgrad_reduce_kernel (9 us)"),
-    "dw7_fwd": ("dlka::cl_dwconv_rows2_kernel<7, 3, 8>", "+ cl_dw_prep_weight (5 us)"),
-    "dw7_bwd_data": ("dlka::cl_dwconv_rows2_kernel<7, 3, 8>", "+ cl_dw_prep_weight (5 us)"),
-    "dw7_bwd_weight": ("dlka::cl_dwconv_wgrad2_kernel<7, 3, 8>", "+ zero_fill + cl_dw_unprep"),
-}
+def short_kernel(name):
+    return name.replace("void dlka::", "").replace("dlka::", "").split("(")[0]
 
 
-def roofline_report(B, dtype):
+def roofline_report(stack, B, dtype, ms_per_step):
+    from deformablelka_amd.stack import SYNAPSE_STAGES
     dbytes = 4 if dtype == torch.float32 else 2
-    C, N = 32, 32  # stage 0 carries ~70% of the step's FLOPs
-    ms = time_ops(B, C, N, dtype)
-    tab = op_table(B, C, N, dbytes)
+    per, traced_ms, mark_ms, nrec = trace_step(stack)
+    # every record also holds its timing event's own cost: (sum of records - the hipGraph replay of the same kernels) / records
+    ev_us = max(0.0, (traced_ms - ms_per_step) / max(nrec, 1.0) * 1e3)
+    rows = []
+    for (stage, name), (cnt, ms) in per.items():
+        C, (H, W, D), _ = SYNAPSE_STAGES[stage] if 0 <= stage < len(SYNAPSE_STAGES) else (0, (0, 0, 0), 0)
+        fl, by = kernel_work(name, B, C, H * W * D, dbytes) if C else (0, 0)
+        rows.append({"kernel": short_kernel(name), "stage": stage, "launches_per_step": round(cnt, 2), "avg_us": round(ms * 1e3, 2),
+                     "step_share": round(cnt * ms / traced_ms, 4), "algorithmic_flops": fl, "algorithmic_bytes": by})
+    rows.sort(key=lambda r: -r["step_share"])
+    log("launch trace of the step (eager, HIP events behind every launch): %.3f ms of kernel time per step, graph replay %.3f ms" % (traced_ms, ms_per_step))
+    for r in rows[:24]:
+        fl, us = r["algorithmic_flops"], r["avg_us"]
+        log(f"  s{r['stage']} {r['kernel'][:70]:70s} x{r['launches_per_step']:<5} {us:9.2f} us  {100 * r['step_share']:5.1f} %  "
+            f"{fl / us / 1e6 if us else 0:8.2f} TFLOP/s  {r['algorithmic_bytes'] / us / 1e3 if us else 0:8.1f} GB/s")
+    dom = rows[0]
+    fl, by, t = dom["algorithmic_flops"], dom["algorithmic_bytes"], dom["avg_us"] * 1e-6
     peak_tf = PEAK_F32_TFLOPS   # the deformable conv's contractions run on the fp32-input MFMA in both storage modes
     ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
-    rows = []
-    for name, t in ms.items():
-        fl, by = tab[name]
-        rows.append((t * OP_COUNT.get(name, 1), name, t, fl, by))
-    rows.sort(reverse=True)
-    log("per-op HIP-event timing, stage 0 (C=32, 32^3, B=%d), ms per launch:" % B)
-    for tot, name, t, fl, by in rows:
-        log(f"  {name:26s} {t:9.4f} ms  x{OP_COUNT.get(name, 1)}  {fl / t / 1e9:9.2f} TFLOP/s  {by / t / 1e6:9.1f} GB/s")
-    _, name, t, fl, by = rows[0]
-    ai = fl / by
-    if ai > ridge:
-        ach, peak, unit, bound = fl / (t * 1e-3) / 1e12, peak_tf, "TFLOP/s", "mfma"
+    if by and fl / by > ridge:
+        ach, peak, unit, bound = fl / t / 1e12, peak_tf, "TFLOP/s", "mfma"
     else:
-        ach, peak, unit, bound = by / (t * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+        ach, peak, unit, bound = by / t / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
     traffic = traffic_source = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/pmc_traffic.sh)
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic_block.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the stage blocks (scripts/pmc_block.sh)
     if os.path.exists(pmc):
         try:
             blob = json.load(open(pmc))
-            traffic = blob.get(name, {}).get("traffic_bytes_per_launch")
-            traffic_source = "profiles/pmc_traffic.json (%s): committed rocprofv3 --pmc passes, NOT measured by this run" % blob.get("_meta", {}).get("round", "r02f")
+            ent = blob.get("stage%d_%s" % (dom["stage"], "f32" if dbytes == 4 else "bf16"), {}).get(dom["kernel"])
+            if ent:
+                traffic = ent["hbm_bytes_per_launch"]
+                traffic_source = "profiles/pmc_traffic_block.json (%s): committed rocprofv3 --pmc passes over the same block, NOT measured by this run" % blob.get("_meta", {}).get("round", "?")
         except Exception:
             traffic = None
-    kern, extra = OP_KERNEL.get(name, (name, ""))
+    C, (H, W, D), _ = SYNAPSE_STAGES[dom["stage"]]
     return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5),
-            "traffic": traffic, "traffic_source": traffic_source, "kernel": kern, "op": name, "op_also_launches": extra,
-            "kernel_ms": round(t, 4), "algorithmic_flops": fl, "algorithmic_bytes": by,
-            "shape": f"C={C},{N}^3,B={B}", "per_op_ms": {k: round(v, 4) for k, v in ms.items()}}
+            "traffic": traffic, "traffic_source": traffic_source, "kernel": dom["kernel"], "kernel_us": dom["avg_us"],
+            "kernel_us_less_event_cost": round(dom["avg_us"] - ev_us, 2),
+            "launches_per_step": dom["launches_per_step"], "step_share": dom["step_share"],
+            "algorithmic_flops": fl, "algorithmic_bytes": by, "shape": f"C={C},{H}x{W}x{D},B={B}",
+            "method": "HIP events recorded on the launch stream behind EVERY kernel launch of the step's own forward+backward (library launch trace, "
+                      "eager replay of the same call sequence the hipGraph holds; mean over 3 passes); dominant = largest launches x duration",
+            "traced_kernel_ms_per_step": round(traced_ms, 4), "records_per_step": round(nrec, 1),
+            "event_cost_us": {"per_record_vs_graph_replay": round(ev_us, 2), "two_events_back_to_back": round(mark_ms * 1e3, 2),
+                              "note": "`achieved` uses the raw record (kernel + its event), i.e. it UNDERSTATES the kernel by this much"},
+            "kernels": rows[:16]}
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -477,26 +465,75 @@ def companion_metric(batch, steps, warmup, dev, dtype, lr):
             "ms_per_step": round(el / steps * 1e3, 4), "steps": steps, "offset_std_voxels_by_stage": h["offset_std"]}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks ourselves (one process per GPU, torch.distributed.run
+    = torchrun, rendezvous on 127.0.0.1) with the same arguments; rank 0 of the child job prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    if not EMU:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log("bench.py: spawning", args.gpus, "ranks:", " ".join(cmd))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+# TEST HOOK (tests/test_bench_spawn.py): DLKA_BENCH_EMU=1 runs the rank logic of this file — self-spawn, process group, shard seeds, barrier
+# + max-over-ranks timing, the JSON line — on CPU tensors, `gloo`, the host emulator build of the kernels and a two-block toy stack.  The line it
+# prints says so in `data`; it is never a measurement.
+EMU = os.environ.get("DLKA_BENCH_EMU") == "1"
+EMU_STAGES = ((32, (2, 2, 3), 1), (64, (2, 2, 2), 1))
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch N ranks, or let --gpus N spawn them)")
+    if EMU:
+        from deformablelka_amd import _lib
+        from tests import emu
+        _lib._set_backend_for_tests(emu.load())
+        torch.set_num_threads(1)
+        dev = torch.device("cpu")
+        args.no_graph = args.no_roofline = args.no_cpu_baseline = args.no_companion = args.no_tblock = True
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {rank} has no GPU of its own (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    sync = (lambda: None) if EMU else torch.cuda.synchronize
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm; ranks talk over xGMI
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        if EMU:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm; ranks talk over xGMI
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from deformablelka_amd.stack import DLKABlockStack
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
     # replicas start from the same parameters (seed); every rank gets its own shard of synthetic volumes (data_seed)
-    stack = DLKABlockStack(args.batch, device=dev, dtype=dtype, seed=1234, data_seed=4321 + rank)
+    stack = DLKABlockStack(args.batch, device=dev, dtype=dtype, seed=1234, data_seed=4321 + rank, **({"stages": EMU_STAGES} if EMU else {}))
     # Synthetic grad_outputs (N(0,1), no loss behind them) make the block gradients huge; a training-sized step would blow
     # the parameters up within a few iterations (offsets -> inf/NaN, every sample dropped, kernels get FASTER: observed,
     # profiles/r01i).  The SGD update is executed in full but with a step small enough that the data distribution the
@@ -529,7 +566,7 @@ def main():
     graph_a = graph_b = None
     # eager warm-up (also first-touch of every kernel), then capture
     compute()
-    torch.cuda.synchronize()
+    sync()
     if not args.no_graph:
         try:
             graph = torch.cuda.CUDAGraph()
@@ -543,7 +580,7 @@ def main():
         except Exception as e:  # capture is an optimisation, not a requirement
             log("hipGraph capture failed, running eagerly:", repr(e))
             graph = None
-            torch.cuda.synchronize()
+            sync()
         if not dp.all_ranks_agree(graph is not None, dist, world, dev):   # every rank replays a graph, or none does
             graph = None
 
@@ -561,7 +598,7 @@ def main():
             return True
         except Exception as e:
             log("split capture failed:", repr(e))
-            torch.cuda.synchronize()
+            sync()
             return False
 
     def run_a():
@@ -574,11 +611,11 @@ def main():
         try:
             run_a()
             run_b()
-            torch.cuda.synchronize()
+            sync()
             return True
         except Exception as e:
             log("overlapped trial failed:", repr(e))
-            torch.cuda.synchronize()
+            sync()
             return False
 
     # the ADVICE-r1 finding: every local decision is reduced over the ranks before anyone acts on it (deformablelka_amd/dp.py,
@@ -597,17 +634,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -623,7 +660,8 @@ def main():
         out = {
             "metric": "3D D-LKA fwd+bwd volumes/sec (64x128x128, b2)", "value": round(value, 3), "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic" if not EMU else "synthetic (EMULATOR TEST RUN on CPU: exercises the rank logic only, NOT a measurement)",
             "config": {"workload": "3D D-LKA Former Synapse 64x128x128 patch: fwd+bwd of its 21 D-LKA attention blocks "
                                    "(6x(32,32^3)+6x(64,16^3)+6x(128,8^3)+3x(256,4^3)) + grad all-reduce + SGD update",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
@@ -633,7 +671,7 @@ def main():
         }
         if not args.no_roofline:
             try:
-                out["roofline"] = roofline_report(args.batch, dtype)
+                out["roofline"] = roofline_report(stack, args.batch, dtype, ms_per_step)
                 fl, by = step_work(args.batch, 4 if dtype == torch.float32 else 2)
                 t_step = ms_per_step * 1e-3
                 out["roofline"]["step"] = {   # the WHOLE step against both roofs (north_star: achieved-HBM-bandwidth fraction)

@@ -124,6 +124,15 @@ SIGNATURES = {
                                       c_void_p, c_size_t] + [c_int] * 5 + [ctypes.c_float, ctypes.c_float, c_int, c_void_p]),
     "dlka_tblock3d_backward": (c_int, [POINTER(TBlock3dPtrs), POINTER(Lka3dPtrs), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
                                        POINTER(TBlock3dPtrs), POINTER(Lka3dPtrs), c_void_p, c_size_t] + [c_int] * 6 + [c_void_p]),
+    "dlka_deform_conv2d_sample_index_path": (c_int, [c_void_p] * 3 + [_G, c_int, c_int, c_void_p]),
+    "dlka_deform_dwconv2d_cl_workspace": (c_size_t, [_G, c_int, c_int]),
+    "dlka_deform_dwconv2d_forward_cl": (c_int, [c_void_p] * 5 + [c_size_t, _G, c_int, c_void_p]),
+    "dlka_deform_dwconv2d_backward_cl": (c_int, [c_void_p] * 8 + [c_size_t, _G, c_int, c_void_p]),
+    "dlka_trace_start": (c_int, [c_int, c_void_p]),
+    "dlka_trace_mark": (c_int, [c_void_p]),
+    "dlka_trace_stop": (c_int, []),
+    "dlka_trace_count": (c_int, []),
+    "dlka_trace_get": (c_int, [c_int, ctypes.c_char_p, c_size_t, POINTER(ctypes.c_float)]),
 }
 
 

@@ -39,6 +39,8 @@ struct IgemmArgs {
     const float *aux2;   // second epilogue operand (epi 4)
     float *out;          // OMODE 0: [M][Cout] channels-last; OMODE 1: [B][Cout][N] planar
     float *out2;         // second epilogue output or null
+    float *out2_f32;     // act_bf16, epi 1 (pointwise kernel): ALSO store out2 = gelu(out) unrounded, fp32 [M][Cout] — the input of the fp32 chain
+                         // that decides the sampling cells (dlka_capi_cl.hip: "offset-determining chain"); null = off
     int B, D, H, W, N, M;
     int Cin, CinReal, CinP, Cout, NP;
     int kd, kh, kw, pd, ph, pw, dd, dh, dw, K;
@@ -91,6 +93,7 @@ struct DwArgs {
     const float *wp;    // [K][C] prepared weights (tap-major, channel contiguous)
     const float *bias;  // [C] or null
     float *out;         // [B][D][H][W][C]
+    float *out_lo;      // fp32 kernels only, plain (non-GELU) epilogue: ALSO store the result rounded to bf16 there ([B][D][H][W][C] bf16), or null
     int xcd_nx;            // set by the launcher: > 0 = blockIdx.x is mapped through xcd_item()
     const float *gelu_x;   // optional fused epilogue (data gradient of dw 5^3 inside the D-LKA block): out = (acc + gelu_add) * gelu'(gelu_x)
     const float *gelu_add;

@@ -193,7 +193,7 @@ int launch_cl_conv_wave(int amode, int omode, const IgemmArgs &a, int splits, hi
 #define DLKA_CW(AM, OM, NTV, SP, DP)                                        \
     {                                                                       \
         auto k = cl_conv_wave_kernel<AM, OM, NTV, SP, DP>;                  \
-        hipLaunchKernelGGL(k, grid, block, 0, st, ax);                      \
+        DLKA_LAUNCH(k, grid, block, 0, st, ax);                      \
     }
 #define DLKA_CW_NT(AM, OM, SP)                                              \
     {                                                                       \
@@ -206,7 +206,7 @@ int launch_cl_conv_wave(int amode, int omode, const IgemmArgs &a, int splits, hi
     }
     if (a.act_bf16) {
         auto k = cl_conv_wave_kernel<0, 1, 1, 2, 2, bf16_t>;
-        hipLaunchKernelGGL(k, grid, block, 0, st, ax);
+        DLKA_LAUNCH(k, grid, block, 0, st, ax);
     } else if (a.split_bf16 == 3) {
         if (amode == 0 && omode == 1) DLKA_CW_NT(0, 1, 3)
         else if (amode == 0 && omode == 0) DLKA_CW_NT(0, 0, 3)

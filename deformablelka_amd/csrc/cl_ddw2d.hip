@@ -22,52 +22,11 @@
 
 #include <atomic>
 #include "cl_args.h"
+#include "cl_ddw2d_describe.h"
 #include "dlka_kernels.h"
 
 namespace dlka {
 
-namespace {
-
-struct Tap2 {
-    unsigned off[4];   // byte offsets of the 4 corner ROWS (pixel * C * 4); DLKA_OOB (-> loads 0) for corners outside the image
-    float wt[4];       // bilinear weights; 0 for corners outside the image AND for samples outside the guard
-    float ly, lx;
-    unsigned okm;      // corners that contribute to the sample / receive grad_input (inside the image and the guard)
-};
-
-// torchvision bilinear_interpolate / get_coordinate_weight (deform_conv2d_kernel.cpp): corners (y0,x0) (y0,x1) (y1,x0) (y1,x1).
-// The SAMPLE (forward, weight gradient, grad_input) is guarded: 0 unless -1 < q < size.  The coordinate weight (grad_offset) has no guard,
-// only the per-corner bounds — the two differ exactly at q == -1, where the high corner is inside the image: its row offset stays valid
-// here (the loads feed the derivative) while its bilinear weight and okm bit are cleared.
-__device__ __forceinline__ void describe2(Tap2 &s, float oy, float ox, int b, int by, int bx, int H, int W, int N, int rowbytes)
-{
-    const float qy = (float)by + oy, qx = (float)bx + ox;
-    s.okm = 0;
-    s.ly = s.lx = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { s.off[q] = DLKA_OOB; s.wt[q] = 0.f; }
-    const bool reach = (qy >= -1.f) & (qx >= -1.f) & (qy < (float)H) & (qx < (float)W);   // some corner can lie inside the image
-    if (reach) {
-        const bool inside = (qy > -1.f) & (qx > -1.f);
-        const float fy = floorf(qy), fx = floorf(qx);
-        const int y0 = (int)fy, x0 = (int)fx;
-        const float ly = qy - fy, lx = qx - fx, hy = 1.f - ly, hx = 1.f - lx;
-        s.ly = ly; s.lx = lx;
-        const bool vy0 = y0 >= 0, vy1 = y0 + 1 <= H - 1, vx0 = x0 >= 0, vx1 = x0 + 1 <= W - 1;
-        const bool ok[4] = {vy0 && vx0, vy0 && vx1, vy1 && vx0, vy1 && vx1};
-        const float w4[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
-        const int base = b * N + y0 * W + x0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (ok[q]) {
-                s.off[q] = (unsigned)(base + (q >> 1) * W + (q & 1)) * (unsigned)rowbytes;
-                if (inside) { s.wt[q] = w4[q]; s.okm |= 1u << q; }
-            }
-        }
-    }
-}
-
-}  // namespace
 
 struct Ddw2dArgs {
     const float *in;     // [B][N][C] channels-last
@@ -248,12 +207,12 @@ __global__ __launch_bounds__(256) void cl_ddw2d_gx_kernel(Ddw2dArgs p, int TH, i
         const float *offp = p.off + (long)b * 2 * p.K * p.N + n;
         for (int tap = 0; tap < p.K; ++tap) {
             const int ti = tap / p.kw, tj = tap - ti * p.kw;
-            const float qy = (float)(oy - p.ph + ti * p.dh) + offp[(long)(2 * tap) * p.N];
-            const float qx = (float)(ox - p.pw + tj * p.dw) + offp[(long)(2 * tap + 1) * p.N];
-            if (!((qy > -1.f) & (qx > -1.f) & (qy < (float)p.H) & (qx < (float)p.W))) continue;   // the sample's guard
-            const float fy = floorf(qy), fx = floorf(qx);
-            const int y0 = (int)fy, x0 = (int)fx;
-            const float ly = qy - fy, lx = qx - fx;
+            int y0, x0;
+            float ly, lx;
+            bool reach;
+            if (!sample_cell2(offp[(long)(2 * tap) * p.N], offp[(long)(2 * tap + 1) * p.N], oy - p.ph + ti * p.dh, ox - p.pw + tj * p.dw, p.H, p.W, y0, x0, ly, lx,
+                              reach))
+                continue;   // the sample's guard (the one sampling rule, deform_sample.h)
             const float wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
             const f32x4 w4 = *reinterpret_cast<const f32x4 *>(Ws + tap * GX2_CS);
             const float col[4] = {g4[0] * w4[0], g4[1] * w4[1], g4[2] * w4[2], g4[3] * w4[3]};
@@ -340,7 +299,7 @@ int launch_cl_ddw2d_fwd(const DwArgs2d &d, hipStream_t st)
     while (per > 1 && mblocks * (nch / per) < 1024 && per % 2 == 0) per /= 2;
     if (per == 3 && mblocks * (nch / 3) < 512) per = 1;
     dim3 grid(mblocks, nch / per), block(256);
-#define DLKA_DDW_F(N_) case N_: { auto k = cl_ddw2d_fwd_kernel<N_>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
+#define DLKA_DDW_F(N_) case N_: { auto k = cl_ddw2d_fwd_kernel<N_>; DLKA_LAUNCH(k, grid, block, 0, st, a); } break;
     switch (per) {
         DLKA_DDW_F(1) DLKA_DDW_F(2) DLKA_DDW_F(3) DLKA_DDW_F(4) DLKA_DDW_F(6) DLKA_DDW_F(8) DLKA_DDW_F(12)
         default: return DLKA_ERR_UNSUPPORTED;
@@ -361,14 +320,14 @@ int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st)
     a.px_per_block = cl_ddw2d_bwd_px_per_block(a.M);
     const int nblocks = cdiv(a.M, a.px_per_block);
     dim3 grid(nblocks), block(256);
-#define DLKA_DDW_B(N_) case N_: { auto k = cl_ddw2d_bwd_kernel<N_>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
+#define DLKA_DDW_B(N_) case N_: { auto k = cl_ddw2d_bwd_kernel<N_>; DLKA_LAUNCH(k, grid, block, 0, st, a); } break;
     switch (nch) {
         DLKA_DDW_B(1) DLKA_DDW_B(2) DLKA_DDW_B(3) DLKA_DDW_B(4) DLKA_DDW_B(6) DLKA_DDW_B(8) DLKA_DDW_B(12)
         default: return DLKA_ERR_UNSUPPORTED;
     }
 #undef DLKA_DDW_B
     DLKA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(cl_ddw2d_fold_kernel, dim3(cdiv(a.K * a.C, 256)), dim3(256), 0, st, (const float *)a.part, gw, nblocks, a.K, a.C);
+    DLKA_LAUNCH(cl_ddw2d_fold_kernel, dim3(cdiv(a.K * a.C, 256)), dim3(256), 0, st, (const float *)a.part, gw, nblocks, a.K, a.C);
     DLKA_CHECK_LAUNCH();
     {   // grad_input: LDS-window scatter
         const int reach_y = a.ph > (a.kh - 1) * a.dh - a.ph ? a.ph : (a.kh - 1) * a.dh - a.ph;   // |base - output pixel| <= reach
@@ -400,7 +359,7 @@ int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st)
         const int ntx = cdiv(a.W, TW), nty = cdiv(a.H, TH);
         dim3 ggrid(a.B * nty * ntx, a.C / GX2_CS);
         auto k = cl_ddw2d_gx_kernel<0>;
-        hipLaunchKernelGGL(k, ggrid, dim3(256), lds, st, a, TH, TW, ntx, nty, reach_y, reach_x);
+        DLKA_LAUNCH(k, ggrid, dim3(256), lds, st, a, TH, TW, ntx, nty, reach_y, reach_x);
         DLKA_CHECK_LAUNCH();
     }
     return DLKA_OK;

@@ -33,37 +33,6 @@ constexpr int HALO = 3;
 constexpr int CS = 4;     // channels per grad_input slice
 constexpr int TG = 8;     // taps per MFMA row group (TG * CS = 32 MFMA rows)
 
-struct LaneTap {
-    int zd, zh, zw;        // floor corner (may be -1)
-    float ld, lh, lw;      // fractions
-    unsigned okm;          // bit q set <=> corner q is inside the volume and the sample passes the guard
-};
-
-// Sampling rule of deform_im2col_cuda.cuh:244-259 for one (voxel, tap); identical to setup_tap<3> (deform_sample.h).
-__device__ __forceinline__ void lane_tap(LaneTap &s, float od, float oh, float ow, int bd, int bh, int bw, int D, int H, int W)
-{
-    const float qd = (float)bd + od;
-    const float qh = (float)bh + oh;
-    const float qw = (float)bw + ow;
-    s.okm = 0;
-    s.zd = s.zh = s.zw = 0;
-    s.ld = s.lh = s.lw = 0.f;
-    const bool inside = qd > -1.f && qh > -1.f && qw > -1.f && qd < (float)D && qh < (float)H && qw < (float)W;
-    if (inside) {  // floor in [-1, size-1]
-        const float fd_ = floorf(qd), fh_ = floorf(qh), fw_ = floorf(qw);
-        s.zd = (int)fd_; s.zh = (int)fh_; s.zw = (int)fw_;
-        s.ld = qd - fd_; s.lh = qh - fh_; s.lw = qw - fw_;
-        unsigned okm = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
-            const bool ok = (cd ? s.zd + 1 <= D - 1 : s.zd >= 0) && (ch ? s.zh + 1 <= H - 1 : s.zh >= 0) && (cw ? s.zw + 1 <= W - 1 : s.zw >= 0);
-            okm |= (ok ? 1u : 0u) << q;
-        }
-        s.okm = okm;
-    }
-}
-
 }  // namespace
 
 // =====================================================================================================================
@@ -766,15 +735,12 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
                 int ti, tj, tk;
                 if (p.kw == 3 && p.kh == 3) { ti = tap / 9; const int rr = tap - 9 * ti; tj = rr / 3; tk = rr - 3 * tj; }   // uniform
                 else { tk = tap % p.kw; tj = (tap / p.kw) % p.kh; ti = tap / (p.kw * p.kh); }
-                // sampling rule of deform_im2col_cuda.cuh:244-259 (identical to lane_tap / setup_tap<3>)
-                const float qd_ = (float)(vd + ti * p.dd - p.pd) + offv[r4][0];
-                const float qh_ = (float)(vh + tj * p.dh - p.ph) + offv[r4][1];
-                const float qw_ = (float)(vw + tk * p.dw - p.pw) + offv[r4][2];
-                const bool valid = tv && qd_ > -1.f && qh_ > -1.f && qw_ > -1.f && qd_ < (float)p.D && qh_ < (float)p.H && qw_ < (float)p.W;
-                const float qd = valid ? qd_ : 0.f, qh = valid ? qh_ : 0.f, qw = valid ? qw_ : 0.f;
-                const float fld = floorf(qd), flh = floorf(qh), flw = floorf(qw);   // in [-1, size - 1]
-                const int zd = (int)fld, zh = (int)flh, zw = (int)flw;
-                const float ld = qd - fld, lh = qh - flh, lw = qw - flw;
+                // the one sampling rule (deform_sample.h: deform_im2col_cuda.cuh:244-259); outside the guard the cell is (0,0,0) and `valid` is false
+                int zd, zh, zw;
+                float ld, lh, lw;
+                const bool inside = sample_cell3(offv[r4][0], offv[r4][1], offv[r4][2], vd + ti * p.dd - p.pd, vh + tj * p.dh - p.ph, vw + tk * p.dw - p.pw,
+                                                 p.D, p.H, p.W, zd, zh, zw, ld, lh, lw);
+                const bool valid = tv && inside;
                 const float fd[2] = {1.f - ld, ld}, fh[2] = {1.f - lh, lh}, fw[2] = {1.f - lw, lw};
                 const float wdh[4] = {fd[0] * fh[0], fd[0] * fh[1], fd[1] * fh[0], fd[1] * fh[1]};
                 const int xd = zd - od, xh = zh - oh, xw = zw - ow;
@@ -970,9 +936,9 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
             // storing variant: grad_out rows in registers only at Cout = 32 / fp32 (measured at 32^3: 179 vs 186 us; bf16 149 vs 155 us the other way)
 #define DLKA_GOFF2(NK, TT)                                                                                                           \
     {                                                                                                                                \
-        if (a.samp && (NK) == 1 && sizeof(TT) == 4) { auto k = cl_deform_goff2_kernel<1, TT, true>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); } \
-        else if (a.samp) { auto k = cl_deform_goff2_kernel<0, TT, true>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }       \
-        else { auto k = cl_deform_goff2_kernel<NK, TT, false>; hipLaunchKernelGGL(k, grid, block, 0, st, ag, tpb); }                 \
+        if (a.samp && (NK) == 1 && sizeof(TT) == 4) { auto k = cl_deform_goff2_kernel<1, TT, true>; DLKA_LAUNCH(k, grid, block, 0, st, ag, tpb); } \
+        else if (a.samp) { auto k = cl_deform_goff2_kernel<0, TT, true>; DLKA_LAUNCH(k, grid, block, 0, st, ag, tpb); }       \
+        else { auto k = cl_deform_goff2_kernel<NK, TT, false>; DLKA_LAUNCH(k, grid, block, 0, st, ag, tpb); }                 \
     }
             if (a.act_bf16) {
                 if (nkc == 1) DLKA_GOFF2(1, bf16_t) else if (nkc == 2) DLKA_GOFF2(2, bf16_t) else DLKA_GOFF2(0, bf16_t)
@@ -1050,8 +1016,8 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
 #define DLKA_GX2(SWv, SHv, SDv)                                                                                                    \
     if (nw <= SWv && nh <= SHv && nd <= SDv && 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes + qbytes <= 150 * 1024) {       \
         const size_t lds2 = 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes + qbytes;                                         \
-        if (a.act_bf16) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t>; hipLaunchKernelGGL(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); } \
-        else { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float>; hipLaunchKernelGGL(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }             \
+        if (a.act_bf16) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); } \
+        else { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }             \
         launched = true;                                                                                                           \
     }
             bool launched = false;
@@ -1063,22 +1029,22 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
                 const long total = (long)a.B * a.N * g.nslices;
                 long gb = cdivl(total, 256);
                 if (gb > 4096) gb = 4096;
-                hipLaunchKernelGGL(cl_deform_gx_gather_kernel, dim3((unsigned)gb), dim3(256), 0, st, a, g, (const float *)scratch);
+                DLKA_LAUNCH(cl_deform_gx_gather_kernel, dim3((unsigned)gb), dim3(256), 0, st, a, g, (const float *)scratch);
                 DLKA_CHECK_LAUNCH();
                 return DLKA_OK;
             }
         }
         if (a.act_bf16) {
-            if (fixed) { auto k = cl_deform_gx_kernel<true, bf16_t>; hipLaunchKernelGGL(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
-            else { auto k = cl_deform_gx_kernel<false, bf16_t>; hipLaunchKernelGGL(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
+            if (fixed) { auto k = cl_deform_gx_kernel<true, bf16_t>; DLKA_LAUNCH(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
+            else { auto k = cl_deform_gx_kernel<false, bf16_t>; DLKA_LAUNCH(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
         }
-        else if (fixed) { auto k = cl_deform_gx_kernel<true>; hipLaunchKernelGGL(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
-        else { auto k = cl_deform_gx_kernel<false>; hipLaunchKernelGGL(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
+        else if (fixed) { auto k = cl_deform_gx_kernel<true>; DLKA_LAUNCH(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
+        else { auto k = cl_deform_gx_kernel<false>; DLKA_LAUNCH(k, gx_grid, dim3(gx_threads), lds, st, a, gl_, scratch); }
         DLKA_CHECK_LAUNCH();
         const long total = (long)a.B * a.N * g.nslices;
         long gb = cdivl(total, 256);
         if (gb > 4096) gb = 4096;
-        hipLaunchKernelGGL(cl_deform_gx_gather_kernel, dim3((unsigned)gb), dim3(256), 0, st, a, g, (const float *)scratch);
+        DLKA_LAUNCH(cl_deform_gx_gather_kernel, dim3((unsigned)gb), dim3(256), 0, st, a, g, (const float *)scratch);
         DLKA_CHECK_LAUNCH();
     }
     return DLKA_OK;

@@ -198,16 +198,16 @@ int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
     if (xcd_swizzle_enabled() && mblocks >= (unsigned)xcd_min_blocks()) { a.xcd_nx = mblocks; grid.x = xcd_grid(mblocks); }
     if (a.act_bf16) {
         switch (NT) {
-            case 1: { auto k = cl_deform_fwd_kernel<bf16_t, 1>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
-            case 2: { auto k = cl_deform_fwd_kernel<bf16_t, 2>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
-            case 4: { auto k = cl_deform_fwd_kernel<bf16_t, 4>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
+            case 1: { auto k = cl_deform_fwd_kernel<bf16_t, 1>; DLKA_LAUNCH(k, grid, block, 0, st, a); } break;
+            case 2: { auto k = cl_deform_fwd_kernel<bf16_t, 2>; DLKA_LAUNCH(k, grid, block, 0, st, a); } break;
+            case 4: { auto k = cl_deform_fwd_kernel<bf16_t, 4>; DLKA_LAUNCH(k, grid, block, 0, st, a); } break;
             default: return DLKA_ERR_UNSUPPORTED;
         }
     } else {
         switch (NT) {
-            case 1: { auto k = cl_deform_fwd_kernel<float, 1>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
-            case 2: { auto k = cl_deform_fwd_kernel<float, 2>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
-            case 4: { auto k = cl_deform_fwd_kernel<float, 4>; hipLaunchKernelGGL(k, grid, block, 0, st, a); } break;
+            case 1: { auto k = cl_deform_fwd_kernel<float, 1>; DLKA_LAUNCH(k, grid, block, 0, st, a); } break;
+            case 2: { auto k = cl_deform_fwd_kernel<float, 2>; DLKA_LAUNCH(k, grid, block, 0, st, a); } break;
+            case 4: { auto k = cl_deform_fwd_kernel<float, 4>; DLKA_LAUNCH(k, grid, block, 0, st, a); } break;
             default: return DLKA_ERR_UNSUPPORTED;
         }
     }

@@ -77,6 +77,12 @@ __global__ __launch_bounds__(256) void cl_dwconv_kernel(DwArgs p)
 #pragma unroll
     for (int t = 0; t < TW; ++t)
         if (w0 + t < p.W) act_store1(outp, obase + (long)t * p.C, acc[t]);
+    if (sizeof(T) == 4 && p.out_lo) {   // uniform: the bf16 copy the gathers / the backward pass read (mixed-precision DLKA_BF16 block)
+        bf16_t *lo = reinterpret_cast<bf16_t *>(p.out_lo);
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+            if (w0 + t < p.W) act_store1(lo, obase + (long)t * p.C, acc[t]);
+    }
 }
 
 // Second generation of the forward / data-gradient kernel.  Same tiling; what changes is how the input row segment is read.  The first
@@ -145,6 +151,12 @@ __global__ __launch_bounds__(256) void cl_dwconv_rows_kernel(DwArgs p)
 #pragma unroll
     for (int t = 0; t < TW; ++t)
         if (w0 + t < p.W) act_store1(outp, obase + (long)t * p.C, acc[t]);
+    if (sizeof(T) == 4 && p.out_lo) {   // uniform: the bf16 copy the gathers / the backward pass read (mixed-precision DLKA_BF16 block)
+        bf16_t *lo = reinterpret_cast<bf16_t *>(p.out_lo);
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+            if (w0 + t < p.W) act_store1(lo, obase + (long)t * p.C, acc[t]);
+    }
 }
 
 // ... and with TH output rows per work-item, h0, h0 + DIL, ...: with the loads lean, the kernel sits on the L1 return path (one 256-byte
@@ -226,6 +238,12 @@ __global__ __launch_bounds__(256) void cl_dwconv_rowsN_kernel(DwArgs p)
 #pragma unroll
             for (int t = 0; t < TW; ++t)
                 if (w0 + t < p.W) act_store1(outp, obase + (long)t * p.C, acc[o][t]);
+            if (sizeof(T) == 4 && p.out_lo) {   // uniform: bf16 copy (see cl_args.h: DwArgs::out_lo)
+                bf16_t *lo = reinterpret_cast<bf16_t *>(p.out_lo);
+#pragma unroll
+                for (int t = 0; t < TW; ++t)
+                    if (w0 + t < p.W) act_store1(lo, obase + (long)t * p.C, acc[o][t]);
+            }
         }
     }
 }
@@ -242,7 +260,7 @@ __global__ void cl_dw_prep_weight_kernel(const float *__restrict__ w, float *__r
 
 int launch_cl_dw_prep_weight(const float *w, float *wp, int C, int K, int flip, hipStream_t st)
 {
-    hipLaunchKernelGGL(cl_dw_prep_weight_kernel, dim3(cdiv(C * K, 256)), dim3(256), 0, st, w, wp, C, K, flip);
+    DLKA_LAUNCH(cl_dw_prep_weight_kernel, dim3(cdiv(C * K, 256)), dim3(256), 0, st, w, wp, C, K, flip);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -283,16 +301,16 @@ static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st
                 const long runs4 = (long)a.B * a.D * dil_w * cdiv(a.H, th * dil_w) * cdiv(a.W, 4);
                 dim3 grid4((unsigned)cdivl(runs4, rpb), 1, cdiv(a.C, cpb));
                 swz(grid4);
-                if (kw == 7) { auto k = cl_dwconv_rowsN_kernel<T, 7, 3, 4, 2>; hipLaunchKernelGGL(k, grid4, block, 0, st, ax); }
-                else { auto k = cl_dwconv_rowsN_kernel<T, 5, 1, 4, 2>; hipLaunchKernelGGL(k, grid4, block, 0, st, ax); }
+                if (kw == 7) { auto k = cl_dwconv_rowsN_kernel<T, 7, 3, 4, 2>; DLKA_LAUNCH(k, grid4, block, 0, st, ax); }
+                else { auto k = cl_dwconv_rowsN_kernel<T, 5, 1, 4, 2>; DLKA_LAUNCH(k, grid4, block, 0, st, ax); }
                 DLKA_CHECK_LAUNCH();
                 return DLKA_OK;
             }
-            if (kw == 7 && th == 2) { auto k = cl_dwconv_rowsN_kernel<T, 7, 3, TW, 2>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
-            else if (kw == 5 && th == 2) { auto k = cl_dwconv_rowsN_kernel<T, 5, 1, TW, 2>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
+            if (kw == 7 && th == 2) { auto k = cl_dwconv_rowsN_kernel<T, 7, 3, TW, 2>; DLKA_LAUNCH(k, grid2, block, 0, st, ax); }
+            else if (kw == 5 && th == 2) { auto k = cl_dwconv_rowsN_kernel<T, 5, 1, TW, 2>; DLKA_LAUNCH(k, grid2, block, 0, st, ax); }
             else if constexpr (F32) {
-                if (kw == 7) { auto k = cl_dwconv_rowsN_kernel<float, 7, 3, TW, 3>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
-                else { auto k = cl_dwconv_rowsN_kernel<float, 5, 1, TW, 3>; hipLaunchKernelGGL(k, grid2, block, 0, st, ax); }
+                if (kw == 7) { auto k = cl_dwconv_rowsN_kernel<float, 7, 3, TW, 3>; DLKA_LAUNCH(k, grid2, block, 0, st, ax); }
+                else { auto k = cl_dwconv_rowsN_kernel<float, 5, 1, TW, 3>; DLKA_LAUNCH(k, grid2, block, 0, st, ax); }
             }
             DLKA_CHECK_LAUNCH();
             return DLKA_OK;
@@ -300,27 +318,27 @@ static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st
         bool done = true;
         dim3 grid1 = grid;
         swz(grid1);
-        if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<T, 5, 1, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
-        else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_rows_kernel<T, 7, 3, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
+        if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<T, 5, 1, TW>; DLKA_LAUNCH(k, grid1, block, 0, st, ax); }
+        else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_rows_kernel<T, 7, 3, TW>; DLKA_LAUNCH(k, grid1, block, 0, st, ax); }
         else if constexpr (F32) {
-            if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<float, 3, 1, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
-            else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_rows_kernel<float, 5, 3, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
-            else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<float, 7, 1, TW>; hipLaunchKernelGGL(k, grid1, block, 0, st, ax); }
+            if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<float, 3, 1, TW>; DLKA_LAUNCH(k, grid1, block, 0, st, ax); }
+            else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_rows_kernel<float, 5, 3, TW>; DLKA_LAUNCH(k, grid1, block, 0, st, ax); }
+            else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_rows_kernel<float, 7, 1, TW>; DLKA_LAUNCH(k, grid1, block, 0, st, ax); }
             else done = false;
         } else done = false;
         if (done) { DLKA_CHECK_LAUNCH(); return DLKA_OK; }
     }
-    if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_kernel<T, 5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_kernel<T, 5, 1, TW>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
     else if (kw == 7 && dil_w == 3) {
         constexpr int abl = 0;
-        if (F32 && abl == 1) { auto k = cl_dwconv_kernel<float, 7, 3, TW, 1>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-        else if (F32 && abl == 2) { auto k = cl_dwconv_kernel<float, 7, 3, TW, 2>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-        else { auto k = cl_dwconv_kernel<T, 7, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        if (F32 && abl == 1) { auto k = cl_dwconv_kernel<float, 7, 3, TW, 1>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
+        else if (F32 && abl == 2) { auto k = cl_dwconv_kernel<float, 7, 3, TW, 2>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
+        else { auto k = cl_dwconv_kernel<T, 7, 3, TW>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
     }
     else if constexpr (F32) {
-        if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_kernel<float, 3, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-        else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_kernel<float, 5, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-        else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_kernel<float, 7, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        if (kw == 3 && dil_w == 1) { auto k = cl_dwconv_kernel<float, 3, 1, TW>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
+        else if (kw == 5 && dil_w == 3) { auto k = cl_dwconv_kernel<float, 5, 3, TW>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
+        else if (kw == 7 && dil_w == 1) { auto k = cl_dwconv_kernel<float, 7, 1, TW>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
         else return DLKA_ERR_UNSUPPORTED;
     }
     else return DLKA_ERR_UNSUPPORTED;
@@ -553,21 +571,21 @@ static int launch_cl_dwconv_wgrad_t(DwWgradArgs a, int kw, int dil_w, hipStream_
         dim3 grid2(xb, a.kd, cdiv(a.C, cpb));
         a.xcd_nx = 0;
         if (xcd_swizzle_enabled() && xb >= (unsigned)xcd_min_blocks()) { a.xcd_nx = xb; grid2.x = xcd_grid(xb); }
-        if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<T, 5, 1, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
-        else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_wgrad2_kernel<T, 7, 3, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
-        else if (F32 && kw == 3 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<float, 3, 1, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
-        else if (F32 && kw == 5 && dil_w == 3) { auto k = cl_dwconv_wgrad2_kernel<float, 5, 3, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
-        else if (F32 && kw == 7 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<float, 7, 1, TW>; hipLaunchKernelGGL(k, grid2, block256(), 0, st, a); }
+        if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<T, 5, 1, TW>; DLKA_LAUNCH(k, grid2, block256(), 0, st, a); }
+        else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_wgrad2_kernel<T, 7, 3, TW>; DLKA_LAUNCH(k, grid2, block256(), 0, st, a); }
+        else if (F32 && kw == 3 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<float, 3, 1, TW>; DLKA_LAUNCH(k, grid2, block256(), 0, st, a); }
+        else if (F32 && kw == 5 && dil_w == 3) { auto k = cl_dwconv_wgrad2_kernel<float, 5, 3, TW>; DLKA_LAUNCH(k, grid2, block256(), 0, st, a); }
+        else if (F32 && kw == 7 && dil_w == 1) { auto k = cl_dwconv_wgrad2_kernel<float, 7, 1, TW>; DLKA_LAUNCH(k, grid2, block256(), 0, st, a); }
         else return DLKA_ERR_UNSUPPORTED;
         DLKA_CHECK_LAUNCH();
         return DLKA_OK;
     }
     dim3 grid(xb, a.kd * a.kh, cdiv(a.C, cpb)), block(256);
-    if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<T, 5, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-    else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_wgrad_kernel<T, 7, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-    else if (F32 && kw == 3 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<float, 3, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-    else if (F32 && kw == 5 && dil_w == 3) { auto k = cl_dwconv_wgrad_kernel<float, 5, 3, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-    else if (F32 && kw == 7 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<float, 7, 1, TW>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+    if (kw == 5 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<T, 5, 1, TW>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
+    else if (kw == 7 && dil_w == 3) { auto k = cl_dwconv_wgrad_kernel<T, 7, 3, TW>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
+    else if (F32 && kw == 3 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<float, 3, 1, TW>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
+    else if (F32 && kw == 5 && dil_w == 3) { auto k = cl_dwconv_wgrad_kernel<float, 5, 3, TW>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
+    else if (F32 && kw == 7 && dil_w == 1) { auto k = cl_dwconv_wgrad_kernel<float, 7, 1, TW>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
     else return DLKA_ERR_UNSUPPORTED;
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
@@ -593,7 +611,7 @@ template <typename T>
 int launch_cl_dw_unprep(const float *gwp, T *gw, int C, int K, hipStream_t st)
 {
     auto k = cl_dw_unprep_kernel<T>;
-    hipLaunchKernelGGL(k, dim3(cdiv(C * K, 256)), dim3(256), 0, st, gwp, gw, C, K);
+    DLKA_LAUNCH(k, dim3(cdiv(C * K, 256)), dim3(256), 0, st, gwp, gw, C, K);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -630,8 +648,8 @@ __global__ __launch_bounds__(256) void cl_transpose_kernel(const float *__restri
 int launch_cl_transpose(const float *src, float *dst, int B, int C, int N, int to_cl, hipStream_t st)
 {
     dim3 grid(cdiv(N, 32), cdiv(C, 32), B), block(256);
-    if (to_cl) { auto k = cl_transpose_kernel<1>; hipLaunchKernelGGL(k, grid, block, 0, st, src, dst, C, N); }
-    else { auto k = cl_transpose_kernel<0>; hipLaunchKernelGGL(k, grid, block, 0, st, src, dst, C, N); }
+    if (to_cl) { auto k = cl_transpose_kernel<1>; DLKA_LAUNCH(k, grid, block, 0, st, src, dst, C, N); }
+    else { auto k = cl_transpose_kernel<0>; DLKA_LAUNCH(k, grid, block, 0, st, src, dst, C, N); }
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }

@@ -11,6 +11,7 @@
 // 8 corner loads of 16 bytes (channels 4p .. 4p+3 of the current 32-channel chunk) per row.
 #pragma once
 #include "dlka_common.h"
+#include "deform_sample.h"
 
 namespace dlka {
 
@@ -27,17 +28,11 @@ constexpr int GATHER_DESC_WORDS = 8;   // LDS words per row in the description t
 __device__ __forceinline__ RowDesc gather_describe3(float od, float oh, float ow, long N, int b, int bd, int bh, int bw, int D, int H, int W)
 {
     RowDesc r;
-    r.base = 0; r.okm = 0; r.ld = r.lh = r.lw = 0.f;
-    r.zd = r.zh = r.zw = 0;
-    const float qd = (float)bd + od;
-    const float qh = (float)bh + oh;
-    const float qw = (float)bw + ow;
-    const bool inside = (qd > -1.f) & (qh > -1.f) & (qw > -1.f) & (qd < (float)D) & (qh < (float)H) & (qw < (float)W);
+    r.base = 0; r.okm = 0;
+    int zd, zh, zw;
+    const bool inside = sample_cell3(od, oh, ow, bd, bh, bw, D, H, W, zd, zh, zw, r.ld, r.lh, r.lw);   // the one sampling rule (deform_sample.h)
+    r.zd = zd; r.zh = zh; r.zw = zw;
     if (inside) {  // floor in [-1, size-1]
-        const float fd_ = floorf(qd), fh_ = floorf(qh), fw_ = floorf(qw);
-        const int zd = (int)fd_, zh = (int)fh_, zw = (int)fw_;
-        r.ld = qd - fd_; r.lh = qh - fh_; r.lw = qw - fw_;
-        r.zd = zd; r.zh = zh; r.zw = zw;
         r.base = b * (int)N + (zd * H + zh) * W + zw;
         const unsigned vd0 = zd >= 0, vd1 = zd + 1 <= D - 1, vh0 = zh >= 0, vh1 = zh + 1 <= H - 1, vw0 = zw >= 0, vw1 = zw + 1 <= W - 1;
         unsigned okm = 0;
@@ -116,6 +111,30 @@ __device__ __forceinline__ void gather_weights(const RowDesc &r, float w[8])
     const float fd[2] = {1.f - r.ld, r.ld}, fh[2] = {1.f - r.lh, r.lh}, fw[2] = {1.f - r.lw, r.lw};
 #pragma unroll
     for (int q = 0; q < 8; ++q) w[q] = fd[(q >> 2) & 1] * fh[(q >> 1) & 1] * fw[q & 1];
+}
+
+// ---- the grad_input window kernels' per-(voxel, tap) description (cl_deform_bwd2.hip) ----
+struct LaneTap {
+    int zd, zh, zw;        // floor corner (may be -1)
+    float ld, lh, lw;      // fractions
+    unsigned okm;          // bit q set <=> corner q is inside the volume and the sample passes the guard
+};
+
+// Sampling rule of deform_im2col_cuda.cuh:244-259 for one (voxel, tap); identical to setup_tap<3> (deform_sample.h).
+__device__ __forceinline__ void lane_tap(LaneTap &s, float od, float oh, float ow, int bd, int bh, int bw, int D, int H, int W)
+{
+    s.okm = 0;
+    const bool inside = sample_cell3(od, oh, ow, bd, bh, bw, D, H, W, s.zd, s.zh, s.zw, s.ld, s.lh, s.lw);   // the one sampling rule (deform_sample.h)
+    if (inside) {  // floor in [-1, size-1]
+        unsigned okm = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
+            const bool ok = (cd ? s.zd + 1 <= D - 1 : s.zd >= 0) && (ch ? s.zh + 1 <= H - 1 : s.zh >= 0) && (cw ? s.zw + 1 <= W - 1 : s.zw >= 0);
+            okm |= (ok ? 1u : 0u) << q;
+        }
+        s.okm = okm;
+    }
 }
 
 }  // namespace dlka

@@ -262,7 +262,7 @@ int launch_cl_prep_weight(const float *w, float *wp, int Cout, int Cin, int K, i
     const long n_el = (long)K * KP * NP;
     long blocks = cdivl(n_el, 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(cl_prep_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, wp, Cout, Cin, K, KP, NP, mode);
+    DLKA_LAUNCH(cl_prep_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, wp, Cout, Cin, K, KP, NP, mode);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -319,7 +319,7 @@ int cl_prep_table_blocks(long n) { return (int)cdivl(n, PREP_TABLE_CHUNK); }
 int launch_cl_prep_table(const PrepJob *jobs_dev, const int *first_dev, int njobs, int nblocks, hipStream_t st)
 {
     if (njobs <= 0) return DLKA_OK;
-    hipLaunchKernelGGL(cl_prep_table_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, jobs_dev, first_dev, njobs);
+    DLKA_LAUNCH(cl_prep_table_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, jobs_dev, first_dev, njobs);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -329,7 +329,7 @@ int launch_cl_prep_batch(const PrepBatch &b, hipStream_t st)
     if (b.njobs <= 0) return DLKA_OK;
     long blocks = cdivl(b.total, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(cl_prep_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+    DLKA_LAUNCH(cl_prep_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -353,7 +353,7 @@ static int launch_igemm_nt(const IgemmArgs &a, int splits, hipStream_t st)
 #define DLKA_IG(NTV)                                              \
     {                                                             \
         auto k = cl_igemm_kernel<AMODE, OMODE, NTV, SPLIT, T>;    \
-        hipLaunchKernelGGL(k, grid, block, 0, st, ax);            \
+        DLKA_LAUNCH(k, grid, block, 0, st, ax);            \
     }
     switch (NT) {
         case 1: DLKA_IG(1) break;

@@ -366,7 +366,7 @@ int launch_cl_layernorm_fwd(const float *x, int x_planar, const float *pos, cons
                             int C, float eps, hipStream_t st)
 {
     if (C > 64 * KMAX) return DLKA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(cl_layernorm_fwd_kernel, dim3(grid_for((long)B * N, NT / 64, 4096)), dim3(NT), 0, st, x, x_planar, pos, w, b, xt, xn, stats, B, N, C, eps);
+    DLKA_LAUNCH(cl_layernorm_fwd_kernel, dim3(grid_for((long)B * N, NT / 64, 4096)), dim3(NT), 0, st, x, x_planar, pos, w, b, xt, xn, stats, B, N, C, eps);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -380,7 +380,7 @@ int launch_cl_layernorm_bwd(const float *g, const float *g_res, const float *xt,
         DLKA_TRY_LAUNCH(launch_zero(gb, (size_t)C * 4, st));
         if (gpos) DLKA_TRY_LAUNCH(launch_zero(gpos, (size_t)N * C * 4, st));
     }
-    hipLaunchKernelGGL(cl_layernorm_bwd_kernel, dim3(grid_for((long)B * N, NT / 64, 1024)), dim3(NT), (NT / 64) * 2 * C * sizeof(float), st, g, g_res, xt, stats, w, gxt, gw, gb,
+    DLKA_LAUNCH(cl_layernorm_bwd_kernel, dim3(grid_for((long)B * N, NT / 64, 1024)), dim3(NT), (NT / 64) * 2 * C * sizeof(float), st, g, g_res, xt, stats, w, gxt, gw, gb,
                        gpos, B, N, C);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
@@ -388,7 +388,7 @@ int launch_cl_layernorm_bwd(const float *g, const float *g_res, const float *xt,
 
 int launch_cl_scale_residual_fwd(const float *xt, const float *e, const float *gamma, float *out, long M, int C, hipStream_t st)
 {
-    hipLaunchKernelGGL(cl_scale_residual_fwd_kernel, dim3(grid_for(M * C, NT)), dim3(NT), 0, st, xt, e, gamma, out, M, C);
+    DLKA_LAUNCH(cl_scale_residual_fwd_kernel, dim3(grid_for(M * C, NT)), dim3(NT), 0, st, xt, e, gamma, out, M, C);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -397,7 +397,7 @@ int launch_cl_scale_residual_bwd(const float *g, const float *e, const float *ga
 {
     if (!zeroed) DLKA_TRY_LAUNCH(launch_zero(ggamma, (size_t)C * 4, st));
     const int rpb = NT / (C < NT ? C : NT);
-    hipLaunchKernelGGL(cl_scale_residual_bwd_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), C * sizeof(float), st, g, e, gamma, ge, ggamma, M, C);
+    DLKA_LAUNCH(cl_scale_residual_bwd_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), C * sizeof(float), st, g, e, gamma, ge, ggamma, M, C);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -407,9 +407,9 @@ int launch_cl_bn_stats(const float *x, float *sums, float *stats, long M, int C,
 {
     if (!zeroed) DLKA_TRY_LAUNCH(launch_zero(sums, (size_t)2 * C * 4, st));
     const int rpb = NT / (C < NT ? C : NT);
-    hipLaunchKernelGGL(cl_bn_stats_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), 2 * C * sizeof(float), st, x, sums, M, C);
+    DLKA_LAUNCH(cl_bn_stats_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), 2 * C * sizeof(float), st, x, sums, M, C);
     DLKA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(cl_bn_finish_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, x, (const float *)sums, stats, M, C, eps);
+    DLKA_LAUNCH(cl_bn_finish_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, x, (const float *)sums, stats, M, C, eps);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -417,7 +417,7 @@ int launch_cl_bn_stats(const float *x, float *sums, float *stats, long M, int C,
 int launch_cl_bn_apply(const float *x, const float *res, const float *w, const float *b, const float *stats, const float *mask, float *y, long M, long N, int C,
                        float slope, hipStream_t st)
 {
-    hipLaunchKernelGGL(cl_bn_apply_kernel, dim3(grid_for(M * C, NT)), dim3(NT), 0, st, x, res, w, b, stats, mask, y, M, N, C, slope);
+    DLKA_LAUNCH(cl_bn_apply_kernel, dim3(grid_for(M * C, NT)), dim3(NT), 0, st, x, res, w, b, stats, mask, y, M, N, C, slope);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -427,16 +427,16 @@ int launch_cl_bn_bwd(const float *g, const float *gmask, const float *x, const f
 {
     if (!zeroed) DLKA_TRY_LAUNCH(launch_zero(sums, (size_t)2 * C * 4, st));
     const int rpb = NT / (C < NT ? C : NT);
-    hipLaunchKernelGGL(cl_bn_bwd_reduce_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), 2 * C * sizeof(float), st, g, gmask, x, y, stats, sums, gres, gres_add, M, N, C, slope);
+    DLKA_LAUNCH(cl_bn_bwd_reduce_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), 2 * C * sizeof(float), st, g, gmask, x, y, stats, sums, gres, gres_add, M, N, C, slope);
     DLKA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(cl_bn_bwd_apply_kernel, dim3(grid_for(M * C, NT)), dim3(NT), 0, st, g, gmask, x, y, w, stats, (const float *)sums, gx, gw, gb, M, N, C, slope, training);
+    DLKA_LAUNCH(cl_bn_bwd_apply_kernel, dim3(grid_for(M * C, NT)), dim3(NT), 0, st, g, gmask, x, y, w, stats, (const float *)sums, gx, gw, gb, M, N, C, slope, training);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
 
 int launch_cl_channel_scale(const float *x, const float *mask, float *y, int B, long N, int C, hipStream_t st)
 {
-    hipLaunchKernelGGL(cl_channel_scale_kernel, dim3(grid_for((long)B * N * C, NT)), dim3(NT), 0, st, x, mask, y, B, N, C);
+    DLKA_LAUNCH(cl_channel_scale_kernel, dim3(grid_for((long)B * N * C, NT)), dim3(NT), 0, st, x, mask, y, B, N, C);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }

@@ -121,8 +121,14 @@ __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
             if (p.epi == 0) {
                 pair_store(outp, r, v0, v1);
             } else if (p.epi == 1) {
+                const float g0 = gelu_f(v0), g1 = gelu_f(v1);
                 pair_store(outp, r, v0, v1);
-                pair_store(out2p, r, gelu_f(v0), gelu_f(v1));
+                pair_store(out2p, r, g0, g1);
+                if (p.out2_f32) {   // uniform: the unrounded a = GELU(h) for the fp32 offset-determining chain (lanes 0..31 of a half cover one 128-byte row piece)
+                    const int mr0 = mbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (mr0 < p.M) p.out2_f32[(long)mr0 * p.Cout + n] = g0;
+                    if (mr0 + 1 < p.M) p.out2_f32[(long)(mr0 + 1) * p.Cout + n] = g1;
+                }
             } else if (p.epi == 2) {
                 pair_store(outp, r, v0, v1);
                 pair_store(out2p, r, auxv[r] * v0, auxv[r + 1] * v1);
@@ -317,11 +323,11 @@ int launch_cl_pointwise_pair(const PwPairArgs &a, hipStream_t st)
     }
     dim3 grid(blocks), block(64);
     if (a.act_bf16) {
-        if (a.C == 32) { auto k = cl_pointwise_pair_kernel<bf16_t, 1>; hipLaunchKernelGGL(k, grid, block, 0, st, ax); }
-        else { auto k = cl_pointwise_pair_kernel<bf16_t, 2>; hipLaunchKernelGGL(k, grid, block, 0, st, ax); }
+        if (a.C == 32) { auto k = cl_pointwise_pair_kernel<bf16_t, 1>; DLKA_LAUNCH(k, grid, block, 0, st, ax); }
+        else { auto k = cl_pointwise_pair_kernel<bf16_t, 2>; DLKA_LAUNCH(k, grid, block, 0, st, ax); }
     } else {
-        if (a.C == 32) { auto k = cl_pointwise_pair_kernel<float, 1>; hipLaunchKernelGGL(k, grid, block, 0, st, ax); }
-        else { auto k = cl_pointwise_pair_kernel<float, 2>; hipLaunchKernelGGL(k, grid, block, 0, st, ax); }
+        if (a.C == 32) { auto k = cl_pointwise_pair_kernel<float, 1>; DLKA_LAUNCH(k, grid, block, 0, st, ax); }
+        else { auto k = cl_pointwise_pair_kernel<float, 2>; DLKA_LAUNCH(k, grid, block, 0, st, ax); }
     }
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
@@ -347,8 +353,8 @@ int launch_cl_pointwise(const IgemmArgs &a, hipStream_t st)
         ax.zero_xblocks = (int)cdiv((int)blk, (int)grid.y);
         grid.x += ax.zero_xblocks;
     }
-    if (a.act_bf16) { auto k = cl_pointwise_kernel<bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, ax); }
-    else { auto k = cl_pointwise_kernel<float>; hipLaunchKernelGGL(k, grid, block, 0, st, ax); }
+    if (a.act_bf16) { auto k = cl_pointwise_kernel<bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, ax); }
+    else { auto k = cl_pointwise_kernel<float>; DLKA_LAUNCH(k, grid, block, 0, st, ax); }
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }

@@ -593,14 +593,14 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
         }
         if (a.samp) {   // samples stored by the grad_offset kernel: dense stream, no gather
             if (pl.tpw != 3 || (long)a.K * a.M * a.Cin * (a.act_bf16 ? 2 : 4) >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets below DLKA_OOB
-            if (a.act_bf16) { auto k = cl_wgrad_samp_kernel<3, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
-            else { auto k = cl_wgrad_samp_kernel<3>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+            if (a.act_bf16) { auto k = cl_wgrad_samp_kernel<3, bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
+            else { auto k = cl_wgrad_samp_kernel<3>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
         }
         else if (a.act_bf16) {
             if (pl.tpw != 3) return DLKA_ERR_UNSUPPORTED;
-            auto k = cl_wgrad_deform_kernel<3, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, a);
+            auto k = cl_wgrad_deform_kernel<3, bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, a);
         }
-        else if (pl.tpw == 3) { auto k = cl_wgrad_deform_kernel<3>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }
+        else if (pl.tpw == 3) { auto k = cl_wgrad_deform_kernel<3>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
         else return DLKA_ERR_UNSUPPORTED;   // (4 and 7 taps per wave measured slower: more registers, fewer waves)
     } else {
         dim3 grid(nchunks, cdiv(OT, pl.cot) * a.CT, cdiv(a.K, pl.tpw));
@@ -614,16 +614,16 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
         if (a.g_cpad && !((a.N & 15) == 0 && split && gmode == 1)) return DLKA_ERR_UNSUPPORTED;   // packed g: split + N16 variant only
 #define DLKA_WG(GM, CO, TP)                                                                                      \
     {                                                                                                            \
-        if ((a.N & 15) == 0 && split) { auto k = cl_wgrad_dense_kernel<GM, CO, TP, true, true>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }  \
-        else if ((a.N & 15) == 0) { auto k = cl_wgrad_dense_kernel<GM, CO, TP, true>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }  \
-        else { auto k = cl_wgrad_dense_kernel<GM, CO, TP, false>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }              \
+        if ((a.N & 15) == 0 && split) { auto k = cl_wgrad_dense_kernel<GM, CO, TP, true, true>; DLKA_LAUNCH(k, grid, block, 0, st, a); }  \
+        else if ((a.N & 15) == 0) { auto k = cl_wgrad_dense_kernel<GM, CO, TP, true>; DLKA_LAUNCH(k, grid, block, 0, st, a); }  \
+        else { auto k = cl_wgrad_dense_kernel<GM, CO, TP, false>; DLKA_LAUNCH(k, grid, block, 0, st, a); }              \
     }
         if (a.act_bf16) {   // DLKA_BF16 token path: only the offset-predict conv's weight gradient comes through here (planar fp32 g, bf16 in)
             if (a.K == 1 || gmode != 1 || !split || a.g_cpad || pl.tpw != 3) return DLKA_ERR_UNSUPPORTED;
 #define DLKA_WGB(CO)                                                                                                                           \
     {                                                                                                                                          \
-        if ((a.N & 15) == 0) { auto k = cl_wgrad_dense_kernel<1, CO, 3, true, true, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }    \
-        else { auto k = cl_wgrad_dense_kernel<1, CO, 3, false, true, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, a); }                   \
+        if ((a.N & 15) == 0) { auto k = cl_wgrad_dense_kernel<1, CO, 3, true, true, bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, a); }    \
+        else { auto k = cl_wgrad_dense_kernel<1, CO, 3, false, true, bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, a); }                   \
     }
             if (pl.cot == 3) DLKA_WGB(3) else if (pl.cot == 2) DLKA_WGB(2) else DLKA_WGB(1)
 #undef DLKA_WGB
@@ -648,7 +648,7 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
     long blocks = cdivl(n, 32);
     if (blocks > 4096) blocks = 4096;
     auto rk = cl_wgrad_reduce_kernel<T>;
-    hipLaunchKernelGGL(rk, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)a.part, (const float *)a.bpart, gw, gb, nchunks, a.K, a.CoutP, a.Cout, a.Cin);
+    DLKA_LAUNCH(rk, dim3((unsigned)blocks), dim3(256), 0, st, (const float *)a.part, (const float *)a.bpart, gw, gb, nchunks, a.K, a.CoutP, a.Cout, a.Cin);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -678,15 +678,15 @@ int launch_cl_wgrad_pw3(const WgradArgs *jobs, float *const *gw, float *const *g
     dim3 grid(nchunks, cdiv(OT, pl.cot) * CT, 3), block(64);
     const bool n16 = (a0.N & 15) == 0;
     if (a0.act_bf16) {
-        if (pl.cot == 2 && n16) { auto k = cl_wgrad_pw3_kernel<2, true, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
-        else if (pl.cot == 2) { auto k = cl_wgrad_pw3_kernel<2, false, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
-        else if (n16) { auto k = cl_wgrad_pw3_kernel<1, true, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
-        else { auto k = cl_wgrad_pw3_kernel<1, false, bf16_t>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
+        if (pl.cot == 2 && n16) { auto k = cl_wgrad_pw3_kernel<2, true, bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, b); }
+        else if (pl.cot == 2) { auto k = cl_wgrad_pw3_kernel<2, false, bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, b); }
+        else if (n16) { auto k = cl_wgrad_pw3_kernel<1, true, bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, b); }
+        else { auto k = cl_wgrad_pw3_kernel<1, false, bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, b); }
     }
-    else if (pl.cot == 2 && n16) { auto k = cl_wgrad_pw3_kernel<2, true>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
-    else if (pl.cot == 2) { auto k = cl_wgrad_pw3_kernel<2, false>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
-    else if (n16) { auto k = cl_wgrad_pw3_kernel<1, true>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
-    else { auto k = cl_wgrad_pw3_kernel<1, false>; hipLaunchKernelGGL(k, grid, block, 0, st, b); }
+    else if (pl.cot == 2 && n16) { auto k = cl_wgrad_pw3_kernel<2, true>; DLKA_LAUNCH(k, grid, block, 0, st, b); }
+    else if (pl.cot == 2) { auto k = cl_wgrad_pw3_kernel<2, false>; DLKA_LAUNCH(k, grid, block, 0, st, b); }
+    else if (n16) { auto k = cl_wgrad_pw3_kernel<1, true>; DLKA_LAUNCH(k, grid, block, 0, st, b); }
+    else { auto k = cl_wgrad_pw3_kernel<1, false>; DLKA_LAUNCH(k, grid, block, 0, st, b); }
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -792,7 +792,7 @@ int launch_cl_wgrad_finalize(FinalizeBatch &b, hipStream_t st)
     }
     b.nblocks = blk;
     if (blk > 0x7fffffffL) return DLKA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(cl_wgrad_finalize_kernel, dim3((unsigned)blk), dim3(256), 0, st, b);
+    DLKA_LAUNCH(cl_wgrad_finalize_kernel, dim3((unsigned)blk), dim3(256), 0, st, b);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -830,7 +830,7 @@ int launch_cl_colsum(const float *g, float *gb32, int M, int Cout, hipStream_t s
     if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
     const int rpb = cdiv(M, blocks);
-    hipLaunchKernelGGL(cl_colsum_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, st, g, gb32, M, Cout, rpb);
+    DLKA_LAUNCH(cl_colsum_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, st, g, gb32, M, Cout, rpb);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }

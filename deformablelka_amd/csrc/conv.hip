@@ -91,7 +91,7 @@ int launch_conv_fwd(const T *x, const T *w, const T *bias, T *out, float *wt, co
 #define DLKA_L(COB)                                                                    \
     {                                                                                  \
         auto k = conv_fwd_kernel<T, COB>;                                              \
-        hipLaunchKernelGGL(k, grid, block, 0, st, x, (const float *)wt, bias, out, g, OgP); \
+        DLKA_LAUNCH(k, grid, block, 0, st, x, (const float *)wt, bias, out, g, OgP); \
     }
     switch (cob) {
         case 1: DLKA_L(1) break;
@@ -164,14 +164,14 @@ int launch_conv_bwd_data(const T *gout, const T *w, T *gx, float *wb, const Geom
     {
         const int n = g.group * g.K * g.Og * CgP;
         auto k = relayout_weight_bwd_kernel<T>;
-        hipLaunchKernelGGL(k, dim3(cdiv(n, 256)), dim3(256), 0, st, w, wb, g.group, g.Og, g.Cg, g.K, CgP);
+        DLKA_LAUNCH(k, dim3(cdiv(n, 256)), dim3(256), 0, st, w, wb, g.group, g.Og, g.Cg, g.K, CgP);
         DLKA_CHECK_LAUNCH();
     }
     dim3 grid(cdiv(g.Ni, DLKA_THREADS), g.group * (CgP / cib), g.B), block(DLKA_THREADS);
 #define DLKA_L(CIB)                                                               \
     {                                                                             \
         auto k = conv_bwd_data_kernel<T, CIB>;                                    \
-        hipLaunchKernelGGL(k, grid, block, 0, st, gout, (const float *)wb, gx, g, CgP); \
+        DLKA_LAUNCH(k, grid, block, 0, st, gout, (const float *)wb, gx, g, CgP); \
     }
     switch (cib) {
         case 1: DLKA_L(1) break;
@@ -267,7 +267,7 @@ int launch_conv_bwd_weight(const T *x, const T *gout, float *gw32, const Geom &g
 #define DLKA_L(COB)                                                    \
     {                                                                  \
         auto k = conv_bwd_weight_kernel<T, TPC, COB>;                  \
-        hipLaunchKernelGGL(k, grid, block, 0, st, x, gout, gw32, g, cochunks); \
+        DLKA_LAUNCH(k, grid, block, 0, st, x, gout, gw32, g, cochunks); \
     }
     switch (cob) {
         case 1: DLKA_L(1) break;

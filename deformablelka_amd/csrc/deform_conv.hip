@@ -13,6 +13,7 @@
 // (cl_*.hip), entered through dlka_capi_cl.hip.
 #include "deform_sample.h"
 #include "cl_gather.h"
+#include "cl_ddw2d_describe.h"
 #include "dlka_kernels.h"
 
 namespace dlka {
@@ -36,7 +37,7 @@ int launch_relayout_weight(const T *w, float *wt, int group, int Og, int Cg, int
 {
     const int n = group * K * Cg * OgP;
     auto k = relayout_weight_kernel<T>;
-    hipLaunchKernelGGL(k, dim3(cdiv(n, 256)), dim3(256), 0, st, w, wt, group, Og, Cg, K, OgP);
+    DLKA_LAUNCH(k, dim3(cdiv(n, 256)), dim3(256), 0, st, w, wt, group, Og, Cg, K, OgP);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -116,7 +117,7 @@ int launch_deform_fwd(const T *x, const T *off, const T *w, const T *bias, T *ou
 #define DLKA_LAUNCH_FWD(COB)                                                                 \
     {                                                                                        \
         auto k = deform_fwd_kernel<T, NOFF, COB>;                                            \
-        hipLaunchKernelGGL(k, grid, block, 0, st, x, off, (const float *)wt, bias, out, g, OgP); \
+        DLKA_LAUNCH(k, grid, block, 0, st, x, off, (const float *)wt, bias, out, g, OgP); \
     }
     switch (cob) {
         case 1: DLKA_LAUNCH_FWD(1) break;
@@ -222,7 +223,7 @@ int launch_deform_bwd_input_offset(const T *x, const T *off, const float *wt, in
 #define DLKA_LAUNCH_BIO(OGR)                                                            \
     {                                                                                   \
         auto k = deform_bwd_input_offset_kernel<T, NOFF, OGR>;                          \
-        hipLaunchKernelGGL(k, grid, block, 0, st, x, off, wt, gout, gx32, goff, g, OgP); \
+        DLKA_LAUNCH(k, grid, block, 0, st, x, off, wt, gout, gx32, goff, g, OgP); \
     }
     if (g.group == 1 && g.Og <= 8 && OgP >= 8) DLKA_LAUNCH_BIO(8)
     else if (g.group == 1 && g.Og <= 16 && OgP >= 16) DLKA_LAUNCH_BIO(16)
@@ -327,7 +328,7 @@ int launch_deform_bwd_weight(const T *x, const T *off, const T *gout, float *gw3
 #define DLKA_LAUNCH_BW(COB)                                                    \
     {                                                                          \
         auto k = deform_bwd_weight_kernel<T, NOFF, TPC, COB>;                  \
-        hipLaunchKernelGGL(k, grid, block, 0, st, x, off, gout, gw32, g, cochunks); \
+        DLKA_LAUNCH(k, grid, block, 0, st, x, off, gout, gw32, g, cochunks); \
     }
     switch (cob) {
         case 1: DLKA_LAUNCH_BW(1) break;
@@ -370,7 +371,7 @@ template <typename T>
 int launch_bias_grad(const T *gout, T *gb, int B, int Cout, int No, hipStream_t st)
 {
     auto k = bias_grad_kernel<T>;
-    hipLaunchKernelGGL(k, dim3(Cout), dim3(DLKA_THREADS), 0, st, gout, gb, B, Cout, No);
+    DLKA_LAUNCH(k, dim3(Cout), dim3(DLKA_THREADS), 0, st, gout, gb, B, Cout, No);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -389,7 +390,7 @@ int launch_cast_from_f32(const float *src, T *dst, long n, hipStream_t st)
     long blocks = cdivl(n, 256);
     if (blocks > 4096) blocks = 4096;
     auto k = cast_from_f32_kernel<T>;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n);
+    DLKA_LAUNCH(k, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -411,14 +412,14 @@ __global__ void sample_index_kernel(const T *__restrict__ off, int32_t *__restri
         const int k = tap % g.kw, j = (tap / g.kw) % g.kh, i = tap / (g.kw * g.kh);
         const T *offp = off + (bg * 3 * g.K + 3 * tap) * g.No + v;
         const int bd = od * g.sd - g.pd + i * g.dd, bh = oh * g.sh - g.ph + j * g.dh, bw = ow * g.sw - g.pw + k * g.dw;
-        if (PATH == 0) {
-            const float qd = (float)bd + ldf(offp);
-            const float qh = (float)bh + ldf(offp + g.No);
-            const float qw = (float)bw + ldf(offp + 2 * (long)g.No);
-            idx[e * 3 + 0] = (int32_t)floorf(qd);
-            idx[e * 3 + 1] = (int32_t)floorf(qh);
-            idx[e * 3 + 2] = (int32_t)floorf(qw);
-            mask[e] = (qd > -1.f && qh > -1.f && qw > -1.f && qd < (float)g.D && qh < (float)g.H && qw < (float)g.W) ? 1 : 0;
+        if (PATH == 0) {   // the rule itself (also what cl_deform_gx_fx2_kernel calls directly)
+            int zd, zh, zw;
+            float ld, lh, lw;
+            const bool in = sample_cell3(ldf(offp), ldf(offp + g.No), ldf(offp + 2 * (long)g.No), bd, bh, bw, g.D, g.H, g.W, zd, zh, zw, ld, lh, lw);
+            idx[e * 3 + 0] = zd;
+            idx[e * 3 + 1] = zh;
+            idx[e * 3 + 2] = zw;
+            mask[e] = in ? 1 : 0;
         } else if (PATH == 1) {
             TapSample<3> s;
             setup_tap<3, T>(s, offp, g.No, bd, bh, bw, g.D, g.H, g.W);
@@ -426,14 +427,79 @@ __global__ void sample_index_kernel(const T *__restrict__ off, int32_t *__restri
             idx[e * 3 + 1] = s.inside ? s.z0[1] : 0;
             idx[e * 3 + 2] = s.inside ? s.z0[2] : 0;
             mask[e] = s.inside ? 1 : 0;
-        } else {
+        } else if (PATH == 2) {
             const RowDesc r = gather_describe3(ldf(offp), ldf(offp + g.No), ldf(offp + 2 * (long)g.No), (long)g.Ni, 0, bd, bh, bw, g.D, g.H, g.W);
             idx[e * 3 + 0] = r.zd;
             idx[e * 3 + 1] = r.zh;
             idx[e * 3 + 2] = r.zw;
             mask[e] = r.okm ? 1 : 0;   // inside the guard <=> at least one corner contributes
+        } else {   // PATH 3: lane_tap of the grad_input window kernels (cl_deform_bwd2.hip)
+            LaneTap lt;
+            lane_tap(lt, ldf(offp), ldf(offp + g.No), ldf(offp + 2 * (long)g.No), bd, bh, bw, g.D, g.H, g.W);
+            idx[e * 3 + 0] = lt.zd;
+            idx[e * 3 + 1] = lt.zh;
+            idx[e * 3 + 2] = lt.zw;
+            mask[e] = lt.okm ? 1 : 0;
         }
     }
+}
+
+// 2-D (torchvision layout: (dy, dx) per tap).  idx [.][2] = the floor cell where `reach`, else 0; mask bit 0 = sample inside the guard,
+// bit 1 = reach (some corner can lie inside the image: the coordinate weight's domain).  PATH 0 = sample_cell2, 1 = setup_tap<2> (general
+// kernels), 2 = describe2 (cl_ddw2d.hip; also what its window scatter calls through sample_cell2).
+template <typename T, int PATH>
+__global__ void sample_index2_kernel(const T *__restrict__ off, int32_t *__restrict__ idx, uint8_t *__restrict__ mask, Geom g)
+{
+    const long n = (long)g.B * g.dg * g.K * g.No;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int v = (int)(e % g.No), tap = (int)((e / g.No) % g.K);
+        const long bg = e / g.No / g.K;
+        const int ow = v % g.Wo, oh = v / g.Wo;
+        const int k = tap % g.kw, j = tap / g.kw;
+        const T *offp = off + (bg * 2 * g.K + 2 * tap) * g.No + v;
+        const int bh = oh * g.sh - g.ph + j * g.dh, bw = ow * g.sw - g.pw + k * g.dw;
+        if (PATH == 0) {
+            int y0, x0;
+            float ly, lx;
+            bool reach;
+            const bool in = sample_cell2(ldf(offp), ldf(offp + g.No), bh, bw, g.H, g.W, y0, x0, ly, lx, reach);
+            idx[e * 2 + 0] = y0;
+            idx[e * 2 + 1] = x0;
+            mask[e] = (in ? 1 : 0) | (reach ? 2 : 0);
+        } else if (PATH == 1) {
+            TapSample<2> s;
+            setup_tap<2, T>(s, offp, g.No, 0, bh, bw, 1, g.H, g.W);
+            idx[e * 2 + 0] = s.z0[1];
+            idx[e * 2 + 1] = s.z0[2];
+            mask[e] = (s.inside ? 1 : 0) | (s.reach ? 2 : 0);
+        } else {
+            // describe2 does not keep the cell: it is recovered from the row offset of the first corner inside the image (rowbytes = 1 -> offset = pixel)
+            Tap2 t2;
+            describe2(t2, ldf(offp), ldf(offp + g.No), 0, bh, bw, g.H, g.W, g.H * g.W, 1);
+            int y0 = 0, x0 = 0;
+            bool any = false;
+#pragma unroll
+            for (int q = 3; q >= 0; --q)
+                if (t2.off[q] != DLKA_OOB) { const int px = (int)t2.off[q]; y0 = px / g.W - (q >> 1); x0 = px % g.W - (q & 1); any = true; }
+            idx[e * 2 + 0] = any ? y0 : 0;
+            idx[e * 2 + 1] = any ? x0 : 0;
+            mask[e] = (t2.okm ? 1 : 0) | (any ? 2 : 0);
+        }
+    }
+}
+
+template <typename T>
+int launch_sample_index2(const T *off, int32_t *idx, uint8_t *mask, const Geom &g, int path, hipStream_t st)
+{
+    const long n = (long)g.B * g.dg * g.K * g.No;
+    long blocks = cdivl(n, 256);
+    if (blocks > 8192) blocks = 8192;
+    if (path == 0) DLKA_LAUNCH((sample_index2_kernel<T, 0>), dim3((unsigned)blocks), dim3(256), 0, st, off, idx, mask, g);
+    else if (path == 1) DLKA_LAUNCH((sample_index2_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, off, idx, mask, g);
+    else if (path == 2) DLKA_LAUNCH((sample_index2_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), 0, st, off, idx, mask, g);
+    else return DLKA_ERR_UNSUPPORTED;
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
 }
 
 template <typename T>
@@ -442,9 +508,10 @@ int launch_sample_index(const T *off, int32_t *idx, uint8_t *mask, const Geom &g
     const long n = (long)g.B * g.dg * g.K * g.No;
     long blocks = cdivl(n, 256);
     if (blocks > 8192) blocks = 8192;
-    if (path == 0) hipLaunchKernelGGL((sample_index_kernel<T, 0>), dim3((unsigned)blocks), dim3(256), 0, st, off, idx, mask, g);
-    else if (path == 1) hipLaunchKernelGGL((sample_index_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, off, idx, mask, g);
-    else if (path == 2) hipLaunchKernelGGL((sample_index_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), 0, st, off, idx, mask, g);
+    if (path == 0) DLKA_LAUNCH((sample_index_kernel<T, 0>), dim3((unsigned)blocks), dim3(256), 0, st, off, idx, mask, g);
+    else if (path == 1) DLKA_LAUNCH((sample_index_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, off, idx, mask, g);
+    else if (path == 2) DLKA_LAUNCH((sample_index_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), 0, st, off, idx, mask, g);
+    else if (path == 3) DLKA_LAUNCH((sample_index_kernel<T, 3>), dim3((unsigned)blocks), dim3(256), 0, st, off, idx, mask, g);
     else return DLKA_ERR_UNSUPPORTED;
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
@@ -461,7 +528,8 @@ int launch_sample_index(const T *off, int32_t *idx, uint8_t *mask, const Geom &g
     template int launch_deform_bwd_weight<T, 2>(const T *, const T *, const T *, float *, const Geom &, hipStream_t);          \
     template int launch_bias_grad<T>(const T *, T *, int, int, int, hipStream_t);                                              \
     template int launch_cast_from_f32<T>(const float *, T *, long, hipStream_t);                                               \
-    template int launch_sample_index<T>(const T *, int32_t *, uint8_t *, const Geom &, int, hipStream_t);
+    template int launch_sample_index<T>(const T *, int32_t *, uint8_t *, const Geom &, int, hipStream_t);                      \
+    template int launch_sample_index2<T>(const T *, int32_t *, uint8_t *, const Geom &, int, hipStream_t);
 DLKA_INST(float)
 DLKA_INST(bf16_t)
 #undef DLKA_INST

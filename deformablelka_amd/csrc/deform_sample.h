@@ -13,6 +13,41 @@
 
 namespace dlka {
 
+// ---------------------------------------------------------------------------------------------------------------------
+// THE sampling rule.  sample_cell3 / sample_cell2 are the ONLY places in the library that form the coordinate q, test the guard
+// and take the floor; every deformable kernel — general NCDHW (setup_tap), channels-last gathers (gather_describe3, cl_gather.h),
+// the grad_input scatters (lane_tap and the fixed-point kernel, cl_deform_bwd2.hip), the 2-D depthwise kernels (describe2 and the
+// window scatter, cl_ddw2d.hip) — calls them, and so do the debug entries dlka_deform_conv{3,2}d_sample_index_path that the
+// parity tests compare BIT FOR BIT with the oracle ("integer sampling indices bit-exact", north_star).
+// Outside the guard the cell is (0, 0, 0) with zero fractions: callers key everything on the returned flag.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sample_cell3(float od, float oh, float ow, int bd, int bh, int bw, int D, int H, int W,
+                                             int &zd, int &zh, int &zw, float &ld, float &lh, float &lw)
+{
+    const float qd_ = (float)bd + od, qh_ = (float)bh + oh, qw_ = (float)bw + ow;                                     // cuh:244-246 (Q8: int, then float)
+    const bool inside = (qd_ > -1.f) & (qh_ > -1.f) & (qw_ > -1.f) & (qd_ < (float)D) & (qh_ < (float)H) & (qw_ < (float)W);   // cuh:247
+    const float qd = inside ? qd_ : 0.f, qh = inside ? qh_ : 0.f, qw = inside ? qw_ : 0.f;
+    const float fd_ = floorf(qd), fh_ = floorf(qh), fw_ = floorf(qw);                                                 // in [-1, size - 1]   cuh:30-32
+    zd = (int)fd_; zh = (int)fh_; zw = (int)fw_;
+    ld = qd - fd_; lh = qh - fh_; lw = qw - fw_;
+    return inside;
+}
+
+// torchvision 0.12 deform_conv2d (un-vendored; restated): the SAMPLE is guarded (bilinear_interpolate: 0 unless -1 < q < size), the
+// coordinate weight is not (get_coordinate_weight: per-corner bounds only) — `reach` says whether any corner can lie inside the image
+// (q >= -1 && q < size on both axes); the two flags differ exactly at q == -1.  The cell is formed when `reach`.
+__device__ __forceinline__ bool sample_cell2(float oy, float ox, int by, int bx, int H, int W, int &y0, int &x0, float &ly, float &lx, bool &reach)
+{
+    const float qy_ = (float)by + oy, qx_ = (float)bx + ox;
+    reach = (qy_ >= -1.f) & (qx_ >= -1.f) & (qy_ < (float)H) & (qx_ < (float)W);
+    const bool inside = reach & (qy_ > -1.f) & (qx_ > -1.f);
+    const float qy = reach ? qy_ : 0.f, qx = reach ? qx_ : 0.f;
+    const float fy = floorf(qy), fx = floorf(qx);
+    y0 = (int)fy; x0 = (int)fx;
+    ly = qy - fy; lx = qx - fx;
+    return inside;
+}
+
 template <int NOFF>
 struct TapSample {
     static constexpr int NC = (NOFF == 3) ? 8 : 4;
@@ -22,7 +57,8 @@ struct TapSample {
     unsigned cok;     // bit q set <=> corner q is inside the volume (ignores the guard) — torchvision's coord weight
     float fd[2], fh[2], fw[2];  // per-axis weights of the low / high corner
     bool inside;
-    int z0[3];        // floor cell (d,h,w), clamped to [-2, size]; read by the index-parity debug entry only
+    bool reach;       // NOFF == 2: some corner can lie inside the image (sample_cell2); NOFF == 3: == inside
+    int z0[3];        // floor cell (d,h,w) when inside (2-D: when reach), else 0; read by the index-parity debug entry only
 };
 
 // offp points at offset channel (NOFF*tap) of this (b, dg) at output voxel v; consecutive channels are No apart.
@@ -30,24 +66,17 @@ template <int NOFF, typename T>
 __device__ __forceinline__ void setup_tap(TapSample<NOFF> &s, const T *__restrict__ offp, int No,
                                           int base_d, int base_h, int base_w, int D, int H, int W)
 {
-    float qd = 0.f, qh, qw;
+    int d0 = 0, h0, w0;
+    float ld = 0.f, lh, lw;
+    bool inside, reach;
     if (NOFF == 3) {
-        qd = (float)base_d + ldf(offp);
-        qh = (float)base_h + ldf(offp + No);
-        qw = (float)base_w + ldf(offp + 2 * (long)No);
+        inside = sample_cell3(ldf(offp), ldf(offp + No), ldf(offp + 2 * (long)No), base_d, base_h, base_w, D, H, W, d0, h0, w0, ld, lh, lw);
+        reach = inside;
     } else {
-        qh = (float)base_h + ldf(offp);
-        qw = (float)base_w + ldf(offp + No);
+        inside = sample_cell2(ldf(offp), ldf(offp + No), base_h, base_w, H, W, h0, w0, lh, lw, reach);
     }
-    bool inside = (qh > -1.f) && (qw > -1.f) && (qh < (float)H) && (qw < (float)W);
-    if (NOFF == 3) inside = inside && (qd > -1.f) && (qd < (float)D);
     s.inside = inside;
-    const float fl_d = floorf(qd), fl_h = floorf(qh), fl_w = floorf(qw);
-    // keep the int conversion safe for absurd offsets: values outside the guard never index memory
-    const int d0 = (NOFF == 3) ? (int)fminf(fmaxf(fl_d, -2.f), (float)D) : 0;
-    const int h0 = (int)fminf(fmaxf(fl_h, -2.f), (float)H);
-    const int w0 = (int)fminf(fmaxf(fl_w, -2.f), (float)W);
-    const float ld = qd - fl_d, lh = qh - fl_h, lw = qw - fl_w;
+    s.reach = reach;
     s.z0[0] = d0; s.z0[1] = h0; s.z0[2] = w0;
     s.fd[0] = 1.f - ld; s.fd[1] = ld;
     s.fh[0] = 1.f - lh; s.fh[1] = lh;
@@ -62,6 +91,7 @@ __device__ __forceinline__ void setup_tap(TapSample<NOFF> &s, const T *__restric
         // a high corner can be valid by the reference's test while negative (e.g. floor = -2 is excluded by the
         // guard, floor = -1 gives high = 0): require a legal address as well.
         v = v && zh >= 0 && zh <= H - 1 && zw >= 0 && zw <= W - 1 && zd >= 0 && zd <= D - 1;
+        v = v && reach;          // (outside `reach` the cell is the dummy (0, 0, 0): no corner counts)
         const bool use = v && inside;
         cok |= (v ? 1u : 0u) << q;
         ok |= (use ? 1u : 0u) << q;

@@ -581,6 +581,17 @@ int dlka_deform_conv2d_backward(const void *x, const void *offset, const void *w
                          (deform_backward_t<bf16_t, 2>(x, offset, weight, grad_out, grad_x, grad_offset, grad_weight, grad_bias, workspace, workspace_bytes, g, dtype, st)));
 }
 
+int dlka_deform_conv2d_sample_index_path(const void *offset, int32_t *idx, uint8_t *mask, const dlka_conv_geom *c, int dtype, int path, void *stream)
+{
+    if (!offset || !idx || !mask) return DLKA_ERR_NULL;
+    DLKA_TRY(check_2d(c));
+    Geom g;
+    DLKA_TRY(make_geom(c, true, g));
+    hipStream_t st = (hipStream_t)stream;
+    return DLKA_DISPATCH(dtype, launch_sample_index2<float>((const float *)offset, idx, mask, g, path, st),
+                         launch_sample_index2<bf16_t>((const bf16_t *)offset, idx, mask, g, path, st));
+}
+
 // ---- plain conv -----------------------------------------------------------------------------------------------
 size_t dlka_conv3d_forward_workspace(const dlka_conv_geom *c, int dtype)
 {

@@ -108,7 +108,7 @@ int dense_backward_data_splits(const SameConv &s, int epi) { return cl_igemm_pic
 // zeroed: the caller has zero-filled `out` (needed when the tap split is > 1; one batched fill per block instead of one per conv)
 // ride: zero fills that go out with this launch (pointwise kernel; any other kernel gets them as a launch of their own, cl_igemm.hip)
 int dense_forward(const SameConv &s, const float *x, const float *w, const float *bias, float *out, int out_planar, float *wp,
-                  int epi, const float *aux, float *out2, hipStream_t st, bool zeroed = false, const ZeroBatch *ride = nullptr)
+                  int epi, const float *aux, float *out2, hipStream_t st, bool zeroed = false, const ZeroBatch *ride = nullptr, float *out2_f32 = nullptr)
 {
     const int NP = round_up(s.Cout, 32);
     const int split = use_split(s, true);
@@ -120,6 +120,10 @@ int dense_forward(const SameConv &s, const float *x, const float *w, const float
     a.Cin = s.Cin; a.CinReal = s.Cin; a.CinP = s.Cin; a.Cout = s.Cout; a.NP = NP;
     if (ride) a.zero = *ride;
     const int splits = dense_forward_splits(s, epi);
+    if (out2_f32) {   // only the pointwise kernel's bf16 GELU epilogue carries the fp32 side output
+        if (!(s.act_bf16 && epi == 1 && s.K == 1 && splits == 1 && !split && !out_planar)) return DLKA_ERR_UNSUPPORTED;
+        a.out2_f32 = out2_f32;
+    }
     return launch_cl_igemm(0, out_planar ? 1 : 0, a, splits, st);
 }
 
@@ -190,11 +194,12 @@ void fill_pw_wgrad(WgradArgs &a, const SameConv &s, const float *x, const float 
 
 // ---- depthwise ------------------------------------------------------------------------------------------------------
 int dw_forward(const SameConv &s, const float *x, const float *w, const float *bias, float *out, float *wp, int flip, hipStream_t st,
-               const float *gelu_x = nullptr, const float *gelu_add = nullptr)
+               const float *gelu_x = nullptr, const float *gelu_add = nullptr, float *out_lo = nullptr)
 {
     if (w) DLKA_TRY(launch_cl_dw_prep_weight(w, wp, s.Cin, s.K, flip, st));
+    if (out_lo && s.act_bf16) return DLKA_ERR_UNSUPPORTED;   // (the bf16 copy rides in the fp32 kernels only)
     DwArgs a;
-    a.in = x; a.wp = wp; a.bias = bias; a.out = out; a.gelu_x = gelu_x; a.gelu_add = gelu_add;
+    a.in = x; a.wp = wp; a.bias = bias; a.out = out; a.out_lo = out_lo; a.gelu_x = gelu_x; a.gelu_add = gelu_add;
     a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.C = s.Cin;
     a.act_bf16 = s.act_bf16; a.xcd_nx = 0;
     a.kd = s.kd; a.kh = s.kh; a.dd = s.dd; a.dh = s.dh;
@@ -326,8 +331,17 @@ SameConv block_conv(int B, int C, int Cout, int D, int H, int W, int k, int pad,
     return s;
 }
 
+// DLKA_BF16 is MIXED precision: bf16 storage for x, y, every saved activation and the intermediate gradients — except the chain that
+// decides WHERE the deformable conv samples:  a = GELU(proj_1 x) -> t1 = DW5 a -> t = DW7 t1 -> offsets = Coff t  runs on fp32 tensors
+// (a32, t1_32, t_32: forward-only workspace, never saved) with the fp32 path's own kernels, so that the predicted offsets equal the fp32
+// block's to fp32 rounding.  floor() of a sampling coordinate is discontinuous: with bf16-stored a / t1 / t the offsets move by ~0.4 %, the
+// samples within that distance of an integer coordinate change cell, and conv_offset / conv_spatial / conv0 / proj_1 gradients land
+// 5e-2 .. 1.8e-1 from the fp32 block's (measured round 2; reproduced on the CPU by oracle.blocks with per-tensor storage flags:
+// storing ONLY t in fp32 does not help — 1.1e-1 —, the whole chain does — 3e-3).  The dw convs also write the bf16 copies of t1 / t that the
+// gathers and the backward pass read: the sampled VALUES and every gradient are smooth in those, 2^-9 rounding is inside the 2e-2 contract.
 struct TokGeoms {
     SameConv pw, dw5, dw7, offc, dcn;
+    SameConv dw5_f, dw7_f, offc_f;   // the forward chain's geometries: == dw5 / dw7 / offc on the fp32 path, their fp32-storage twins on DLKA_BF16
     size_t E, Off, GOff;   // GOff: the backward's internal grad_offset buffer, 96 channel planes per batch (packed layout, DeformBwdArgs::goff_cpad)
     size_t SB;             // bytes per activation element (4, or 2 on the DLKA_BF16 path)
     TokGeoms(int B, int C, int D, int H, int W, int dtype = DLKA_F32)
@@ -339,6 +353,9 @@ struct TokGeoms {
         dw7 = block_conv(B, C, C, D, H, W, 7, 9, 3, C, bf);
         offc = block_conv(B, C, 81, D, H, W, 3, 1, 1, 1, bf);
         dcn = block_conv(B, C, C, D, H, W, 3, 1, 1, 1, bf);
+        dw5_f = block_conv(B, C, C, D, H, W, 5, 2, 1, C, 0);
+        dw7_f = block_conv(B, C, C, D, H, W, 7, 9, 3, C, 0);
+        offc_f = block_conv(B, C, 81, D, H, W, 3, 1, 1, 1, 0);
         E = (size_t)B * C * D * H * W;
         Off = (size_t)B * 81 * D * H * W;
         GOff = (size_t)B * 96 * D * H * W;
@@ -406,7 +423,7 @@ int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_para
         add_job(pb, pw_w[k], t.pw_f[k], C, C, 1, C, C, 0);
         add_job(pb, pw_w[k], t.pw_b[k], C, C, 1, C, C, 1);
     }
-    add_job(pb, p->offset_w, t.off_f, 81, C, 27, C, 96, split_mode_flag(use_split(G.offc, true)));
+    add_job(pb, p->offset_w, t.off_f, 81, C, 27, C, 96, split_mode_flag(use_split(G.offc_f, true)));   // (fp32 A operand on both paths)
     add_job(pb, p->offset_w, t.off_b, 81, C, 27, 96, C, use_split(G.offc, false) ? 9 : 1);
     add_job(pb, p->deform_w, t.dcn_f, C, C, 27, C, C, 0);
     add_job(pb, p->deform_w, t.dcn_b, C, C, 27, C, C, 2);
@@ -774,6 +791,70 @@ int dlka_deform_conv3d_backward_cl(const void *x, const void *offset, const void
     return DLKA_OK;
 }
 
+// ---- channels-last 2-D DEPTHWISE deformable conv (cl_ddw2d.hip: the 2-D D-LKA block's conv0 / conv_spatial) on its own ------------------
+// torchvision.ops.deform_conv2d(input, offset, weight, bias=None, stride 1, "same" padding, groups = C, one offset group) as the reference
+// calls it (2D/deformable_LKA/deformable_LKA.py:18-30, 93-94).  x / out / grad_out / grad_x [B][H][W][C], offsets / grad_offset planar
+// [B][2K][H][W] as torchvision lays them out, weight / grad_weight [C][1][kh][kw].  Lets the parity tests hold the fast-path kernels
+// against the reference's own op (tests/test_ref_d3d_2d_gpu.py) without the rest of the block around them.
+namespace {
+int make_ddw2d(const dlka_conv_geom *c, DwArgs2d &d)
+{
+    if (!c) return DLKA_ERR_NULL;
+    if (c->D != 1 || c->kd != 1 || c->sd != 1 || c->dd != 1 || c->pd != 0) return DLKA_ERR_SHAPE;
+    if (c->B <= 0 || c->C <= 0 || c->H <= 0 || c->W <= 0 || c->kh <= 0 || c->kw <= 0 || c->dh <= 0 || c->dw <= 0) return DLKA_ERR_SHAPE;
+    if (c->group != c->C || c->Cout != c->C || c->deformable_group != 1 || c->sh != 1 || c->sw != 1) return DLKA_ERR_UNSUPPORTED;
+    if (dlka_conv_out_size(c->H, c->ph, c->dh, c->kh, 1) != c->H || dlka_conv_out_size(c->W, c->pw, c->dw, c->kw, 1) != c->W) return DLKA_ERR_UNSUPPORTED;
+    if (!cl_ddw2d_supported(c->C)) return DLKA_ERR_UNSUPPORTED;
+    memset(&d, 0, sizeof(d));
+    d.B = c->B; d.H = c->H; d.W = c->W; d.C = c->C; d.kh = c->kh; d.kw = c->kw; d.ph = c->ph; d.pw = c->pw; d.dh = c->dh; d.dw = c->dw;
+    return DLKA_OK;
+}
+}  // namespace
+
+size_t dlka_deform_dwconv2d_cl_workspace(const dlka_conv_geom *c, int dtype, int backward)
+{
+    DwArgs2d d;
+    if (dtype != DLKA_F32 || make_ddw2d(c, d)) return 0;
+    size_t n = align256((size_t)d.kh * d.kw * d.C * 4);
+    if (backward) n += align256(cl_ddw2d_part_floats(d.B * d.H * d.W, d.kh * d.kw, d.C) * 4);
+    return n;
+}
+
+int dlka_deform_dwconv2d_forward_cl(const void *x, const void *offset, const void *weight, void *out, void *workspace, size_t workspace_bytes,
+                                    const dlka_conv_geom *c, int dtype, void *stream)
+{
+    if (!x || !offset || !weight || !out) return DLKA_ERR_NULL;
+    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    DwArgs2d d;
+    DLKA_TRY(make_ddw2d(c, d));
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(workspace, workspace_bytes);
+    float *wp = (float *)cv.take((size_t)d.kh * d.kw * d.C * 4);
+    if (!cv.ok()) return DLKA_ERR_WORKSPACE;
+    DLKA_TRY(launch_cl_dw_prep_weight((const float *)weight, wp, d.C, d.kh * d.kw, 0, st));
+    d.in = (const float *)x; d.off = (const float *)offset; d.wp = wp; d.out = (float *)out;
+    return launch_cl_ddw2d_fwd(d, st);
+}
+
+int dlka_deform_dwconv2d_backward_cl(const void *x, const void *offset, const void *weight, const void *grad_out, void *grad_x, void *grad_offset,
+                                     void *grad_weight, void *workspace, size_t workspace_bytes, const dlka_conv_geom *c, int dtype, void *stream)
+{
+    if (!x || !offset || !weight || !grad_out || !grad_x || !grad_offset || !grad_weight) return DLKA_ERR_NULL;   // one traversal produces all three
+    if (dtype != DLKA_F32) return DLKA_ERR_UNSUPPORTED;
+    DwArgs2d d;
+    DLKA_TRY(make_ddw2d(c, d));
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(workspace, workspace_bytes);
+    float *wp = (float *)cv.take((size_t)d.kh * d.kw * d.C * 4);
+    float *part = (float *)cv.take(cl_ddw2d_part_floats(d.B * d.H * d.W, d.kh * d.kw, d.C) * 4);
+    if (!cv.ok()) return DLKA_ERR_WORKSPACE;
+    DLKA_TRY(launch_cl_dw_prep_weight((const float *)weight, wp, d.C, d.kh * d.kw, 0, st));
+    DLKA_TRY(launch_zero(grad_x, (size_t)d.B * d.H * d.W * d.C * 4, st));   // the window scatter accumulates with atomics
+    d.in = (const float *)x; d.off = (const float *)offset; d.wp = wp; d.g = (const float *)grad_out;
+    d.gx = (float *)grad_x; d.goff = (float *)grad_offset; d.part = part;
+    return launch_cl_ddw2d_bwd(d, (float *)grad_weight, st);
+}
+
 // ---- layout helpers -------------------------------------------------------------------------------------------------------
 int dlka_ncdhw_to_ndhwc(const void *src, void *dst, int B, int C, int N, int dtype, void *stream)
 {
@@ -826,6 +907,8 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     (void)cv.take(G.wp_floats() * 4);
     (void)cv.take(G.part_floats() * 4);
     float *acc32 = (float *)cv.take(G.E * 4);   // bf16 path: fp32 landing zone of a tap-split deformable conv (small stages)
+    // bf16 path: the fp32 offset-determining chain (TokGeoms): a32, t1_32, t_32 — the next three of the backward pass's gradient buffers
+    float *a32 = (float *)cv.take(G.E * 4), *t1_32 = (float *)cv.take(G.E * 4), *t_32 = (float *)cv.take(G.E * 4);
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const bool bf = dtype == DLKA_BF16;
     const float *x = (const float *)x_;
@@ -835,7 +918,7 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     // outputs of tap-split convs (small stages) collect partial sums with atomics: their zero fills ride in the weight-preparation launch
     ZeroBatch zb;
     memset(&zb, 0, sizeof(zb));
-    if (dense_forward_splits(G.offc, 0) > 1) zb.add(off, G.Off);
+    if (dense_forward_splits(G.offc_f, 0) > 1) zb.add(off, G.Off);
     if (dense_forward_splits(G.dcn, 0) > 1) zb.add(bf ? acc32 : f, G.E);
     if (dense_forward_splits(G.pw, 3) > 1) zb.add(y, G.E);
     TokPrep PW;
@@ -846,14 +929,16 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     } else {
         DLKA_TRY(carve_prep(G, prep, PW, p, st, true, &zb));
     }
-    // proj_1 + GELU (transformerblock.py:667-668): h kept for the GELU gradient, a = GELU(h)
-    DLKA_TRY(dense_forward(G.pw, x, N0, (const float *)p->proj_1_b, h, 0, PW.pw_f[0], 1, nullptr, a, st, false, ride));
-    // depthwise 5^3 then 7^3 dilation 3 (:646-647)
-    DLKA_TRY(dw_forward(G.dw5, a, N0, (const float *)p->conv0_b, t1, PW.dw5_f, 0, st));
-    DLKA_TRY(dw_forward(G.dw7, t1, N0, (const float *)p->conv_spatial_b, t, PW.dw7_f, 0, st));
-    // offset-predict conv C -> 81 (synapse/deform_conv.py:94); offsets stay in the reference's planar layout
-    DLKA_TRY(dense_forward(G.offc, t, N0, (const float *)p->offset_b, off, 1, PW.off_f, 0, nullptr, nullptr, st, true));
-    // deformable 3^3 conv (deform_conv.py:95-105)
+    // proj_1 + GELU (transformerblock.py:667-668): h kept for the GELU gradient, a = GELU(h)   (bf16: + the unrounded a for the fp32 chain)
+    DLKA_TRY(dense_forward(G.pw, x, N0, (const float *)p->proj_1_b, h, 0, PW.pw_f[0], 1, nullptr, a, st, false, ride, bf ? a32 : nullptr));
+    // depthwise 5^3 then 7^3 dilation 3 (:646-647)   (bf16: fp32 in / out, the bf16 copies t1 / t ride in the same kernels)
+    const float *a_in = bf ? a32 : a;
+    float *t1_out = bf ? t1_32 : t1, *t_out = bf ? t_32 : t;
+    DLKA_TRY(dw_forward(G.dw5_f, a_in, N0, (const float *)p->conv0_b, t1_out, PW.dw5_f, 0, st, nullptr, nullptr, bf ? t1 : nullptr));
+    DLKA_TRY(dw_forward(G.dw7_f, t1_out, N0, (const float *)p->conv_spatial_b, t_out, PW.dw7_f, 0, st, nullptr, nullptr, bf ? t : nullptr));
+    // offset-predict conv C -> 81 (synapse/deform_conv.py:94) on the fp32 t; offsets stay in the reference's planar layout
+    DLKA_TRY(dense_forward(G.offc_f, t_out, N0, (const float *)p->offset_b, off, 1, PW.off_f, 0, nullptr, nullptr, st, true));
+    // deformable 3^3 conv (deform_conv.py:95-105)   (bf16: samples the bf16 copy of t)
     DLKA_TRY(deform_forward(G.dcn, t, off, N0, (const float *)p->deform_b, f, PW.dcn_f, st, true, acc32));
     // conv1 + gate u*attn (:650-652): g1 kept, m = a * g1
     // ... and proj_2 + shortcut (:670-671) — one launch at C <= 64 (cl_pointwise_pair_kernel)

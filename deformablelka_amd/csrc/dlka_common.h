@@ -122,6 +122,22 @@ inline int xcd_min_blocks()
 
 #define DLKA_THREADS 256
 
+// Every kernel launch of the library goes through DLKA_LAUNCH.  With the launch trace switched on (dlka_trace_start, include/dlka.h: a
+// measurement aid for bench.py's `roofline` block) a timing event is recorded on the launch's own stream right behind each launch; the
+// interval between consecutive events is that kernel's duration as the timed step really runs it (same arguments, same predecessor state).
+// Off (the normal state): one predictable branch on a global.  Never switch it on during hipGraph capture.
+#if defined(HIPEMU)
+#define DLKA_LAUNCH(kernel, grid, block, shmem, stream, ...) hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
+#else
+extern int g_trace_on;
+void trace_after_launch(const void *kernel_fn, hipStream_t st);
+#define DLKA_LAUNCH(kernel, grid, block, shmem, stream, ...)                                             \
+    do {                                                                                                 \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                             \
+        if (dlka::g_trace_on) dlka::trace_after_launch(reinterpret_cast<const void *>(kernel), stream);  \
+    } while (0)
+#endif
+
 #define DLKA_CHECK_LAUNCH()                                  \
     do {                                                     \
         if (hipGetLastError() != hipSuccess) return DLKA_ERR_LAUNCH; \

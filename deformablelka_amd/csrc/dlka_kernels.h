@@ -23,6 +23,8 @@ template <typename T>
 int launch_cast_from_f32(const float *src, T *dst, long n, hipStream_t st);
 template <typename T>
 int launch_sample_index(const T *off, int32_t *idx, uint8_t *mask, const Geom &g, int path, hipStream_t st);
+template <typename T>
+int launch_sample_index2(const T *off, int32_t *idx, uint8_t *mask, const Geom &g, int path, hipStream_t st);
 
 // ---- conv.hip (general grouped convolution: depthwise, dense, pointwise) -----------------------------------
 int conv_fwd_wt_floats(const Geom &g);

@@ -41,7 +41,7 @@ static int launch_elt(const T *a, const T *b, const T *c, T *o1, T *o2, long n, 
     long blocks = cdivl(n, 256);
     if (blocks > 2048) blocks = 2048;
     auto k = eltwise_kernel<T, MODE>;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), 0, st, a, b, c, o1, o2, n);
+    DLKA_LAUNCH(k, dim3((unsigned)blocks), dim3(256), 0, st, a, b, c, o1, o2, n);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -70,7 +70,7 @@ int launch_zero(void *ptr, size_t bytes, hipStream_t st)
     long blocks = cdivl(n4 > 0 ? n4 : n, 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (float *)ptr, n4, n);
+    DLKA_LAUNCH(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (float *)ptr, n4, n);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
@@ -101,7 +101,7 @@ int launch_zero_batch(ZeroBatch &b, hipStream_t st)
         blk += (unsigned)cdivl(b.cnt[r], 4096);
     }
     b.block0[b.n] = blk;
-    hipLaunchKernelGGL(zero_batch_kernel, dim3(blk), dim3(256), 0, st, b);
+    DLKA_LAUNCH(zero_batch_kernel, dim3(blk), dim3(256), 0, st, b);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }

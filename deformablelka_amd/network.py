@@ -165,8 +165,9 @@ def _chain(blocks: nn.Sequential, x):
     n = len(blocks)
     for i, blk in enumerate(blocks):
         if isinstance(blk, TransformerBlock_3D_single_deform_LKA):
-            blk.keep_channels_last = i + 1 < n
-        x = blk(x)
+            x = blk(x, keep_channels_last=i + 1 < n)   # per call: no module state is touched (a stand-alone call of the block keeps its contiguous output)
+        else:
+            x = blk(x)
     return x
 
 

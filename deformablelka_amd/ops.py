@@ -105,8 +105,9 @@ def deform_conv3d_backward(input, weight, bias, offset, grad_output, kernel_size
 
 def deform_conv3d_sample_index(offset, in_size: Sequence[int], kernel_size, stride, padding, dilation, deformable_groups=1, path=0):
     """floor() indices [B,dg,K,Do,Ho,Wo,3] (int32) and guard mask [B,dg,K,Do,Ho,Wo] (uint8).
-    ``path``: 0 = standalone rule, 1 = through ``setup_tap`` (general kernels), 2 = through ``gather_describe3``
-    (channels-last fast path); 1/2 report idx = 0 where the mask is 0."""
+    ``path``: 0 = ``sample_cell3`` on its own (the one rule every kernel calls; the fixed-point grad_input kernel calls it directly),
+    1 = through ``setup_tap`` (general kernels), 2 = through ``gather_describe3`` (channels-last gathers), 3 = through ``lane_tap``
+    (grad_input window kernels); idx = 0 where the mask is 0."""
     L.require_device(offset)
     k, s, p, d = _triple(kernel_size), _triple(stride), _triple(padding), _triple(dilation)
     offset = offset.contiguous()
@@ -174,6 +175,66 @@ def deform_conv2d_backward(input, offset, weight, grad_output, stride=1, padding
                                          L.ptr(gw), L.ptr(gb), L.ptr(ws), wsb, byref(g), dt, L.stream_ptr(input))
     L.check(rc, "deform_conv2d backward")
     return gi, go, gw, gb
+
+
+def deform_conv2d_sample_index(offset, in_size: Sequence[int], kernel_size, stride=1, padding=0, dilation=1, offset_groups=1, path=0):
+    """2-D index-parity entry: floor cell [B,og,K,Ho,Wo,2] (int32; 0 outside `reach`) and mask [B,og,K,Ho,Wo] (uint8: bit 0 = sample inside
+    the guard, bit 1 = reach).  ``path``: 0 = ``sample_cell2`` on its own, 1 = ``setup_tap<2>`` (general kernels), 2 = ``describe2``
+    (channels-last depthwise kernels)."""
+    L.require_device(offset)
+    k, s, p, d = _pair(kernel_size), _pair(stride), _pair(padding), _pair(dilation)
+    offset = offset.contiguous()
+    B, H, W = int(offset.shape[0]), int(in_size[0]), int(in_size[1])
+    g = L.ConvGeom(B, offset_groups, 1, H, W, offset_groups, 1, k[0], k[1], 1, s[0], s[1], 0, p[0], p[1], 1, d[0], d[1], 1, offset_groups, 64)
+    _, Ho, Wo = _out_dims(g)
+    K = k[0] * k[1]
+    if tuple(offset.shape) != (B, offset_groups * 2 * K, Ho, Wo):
+        raise RuntimeError(f"offset shape {tuple(offset.shape)} does not match {(B, offset_groups * 2 * K, Ho, Wo)}")
+    idx = torch.empty((B, offset_groups, K, Ho, Wo, 2), dtype=torch.int32, device=offset.device)
+    mask = torch.empty((B, offset_groups, K, Ho, Wo), dtype=torch.uint8, device=offset.device)
+    rc = L.get_lib().dlka_deform_conv2d_sample_index_path(L.ptr(offset), L.ptr(idx), L.ptr(mask), byref(g), L.dtype_code(offset), int(path),
+                                                          L.stream_ptr(offset))
+    L.check(rc, "deform_conv2d_sample_index")
+    return idx, mask
+
+
+def _geom_dw2d_cl(x, weight, padding, dilation):
+    B, H, W, C = (int(v) for v in x.shape)
+    p, d = _pair(padding), _pair(dilation)
+    if tuple(weight.shape[:2]) != (C, 1):
+        raise RuntimeError(f"depthwise weight [C][1][kh][kw] expected, got {tuple(weight.shape)}")
+    kh, kw = int(weight.shape[2]), int(weight.shape[3])
+    return L.ConvGeom(B, C, 1, H, W, C, 1, kh, kw, 1, 1, 1, 0, p[0], p[1], 1, d[0], d[1], C, 1, 64)
+
+
+def deform_dwconv2d_forward_cl(x, offset, weight, padding, dilation=1):
+    """The 2-D D-LKA block's depthwise deformable conv on its own, channels-last (cl_ddw2d.hip): x [B,H,W,C], offset [B,2K,H,W] planar
+    ((dy, dx) per tap, torchvision layout), weight [C,1,kh,kw] -> out [B,H,W,C]."""
+    L.require_device(x, offset, weight)
+    x, offset, weight = x.contiguous(), offset.contiguous(), weight.contiguous()
+    g = _geom_dw2d_cl(x, weight, padding, dilation)
+    lib, dt = L.get_lib(), L.dtype_code(x)
+    out = torch.empty_like(x)
+    wsb = lib.dlka_deform_dwconv2d_cl_workspace(byref(g), dt, 0)
+    ws = L.scratch(wsb, x)
+    rc = lib.dlka_deform_dwconv2d_forward_cl(L.ptr(x), L.ptr(offset), L.ptr(weight), L.ptr(out), L.ptr(ws), wsb, byref(g), dt, L.stream_ptr(x))
+    L.check(rc, "deform_dwconv2d_forward_cl")
+    return out
+
+
+def deform_dwconv2d_backward_cl(x, offset, weight, grad_out, padding, dilation=1):
+    """-> (grad_x [B,H,W,C], grad_offset [B,2K,H,W], grad_weight [C,1,kh,kw])."""
+    L.require_device(x, offset, weight, grad_out)
+    x, offset, weight, grad_out = x.contiguous(), offset.contiguous(), weight.contiguous(), grad_out.contiguous()
+    g = _geom_dw2d_cl(x, weight, padding, dilation)
+    lib, dt = L.get_lib(), L.dtype_code(x)
+    gx, go, gw = torch.empty_like(x), torch.empty_like(offset), torch.empty_like(weight)
+    wsb = lib.dlka_deform_dwconv2d_cl_workspace(byref(g), dt, 1)
+    ws = L.scratch(wsb, x)
+    rc = lib.dlka_deform_dwconv2d_backward_cl(L.ptr(x), L.ptr(offset), L.ptr(weight), L.ptr(grad_out), L.ptr(gx), L.ptr(go), L.ptr(gw), L.ptr(ws),
+                                              wsb, byref(g), dt, L.stream_ptr(x))
+    L.check(rc, "deform_dwconv2d_backward_cl")
+    return gx, go, gw
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -398,10 +459,12 @@ def deform_conv3d_backward_cl(x, offset, weight, grad_out, padding=1, dilation=1
 
 
 def lka3d_tokens_supported(x, B, C, D, H, W) -> bool:
-    """float32, or bfloat16 activations (DLKA_BF16: bf16 storage of x / y / saved activations, fp32 parameters, offsets and accumulation)."""
-    if x.dtype not in (torch.float32, torch.bfloat16):
+    """x: a tensor or a torch dtype.  float32, or bfloat16 activations (DLKA_BF16: bf16 storage of x / y / saved activations, fp32 parameters,
+    offsets and accumulation)."""
+    dt = x if isinstance(x, torch.dtype) else x.dtype
+    if dt not in (torch.float32, torch.bfloat16):
         return False
-    return bool(L.get_lib().dlka_lka3d_tokens_supported(B, C, D, H, W, L.dtype_code(x)))
+    return bool(L.get_lib().dlka_lka3d_tokens_supported(B, C, D, H, W, L.DLKA_F32 if dt == torch.float32 else L.DLKA_BF16))
 
 
 def autocast_activation_dtype(x):

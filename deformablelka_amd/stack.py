@@ -143,29 +143,36 @@ class DLKABlockStack:
             return None
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def forward(self):
+    def forward(self, on_block=None):
+        """on_block(i): called before block i is issued (bench.py's launch trace separates the blocks with it)."""
         st = self._stream()
         self.prepare()
-        for blk in self.blocks:
+        for i, blk in enumerate(self.blocks):
+            if on_block is not None:
+                on_block(i)
             H, W, D = blk.dims
             rc = self.lib.dlka_lka3d_attention_tokens_forward_prepared(L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.y), L.ptr(blk.saved),
                                                                 blk.saved_bytes, L.ptr(self.ws), self.ws_bytes, self.B, blk.C, H, W, D,
                                                                 self.dt, st)
             L.check(rc, "lka3d_attention_tokens_forward_prepared")
 
-    def backward(self, lo: int = 0, hi: int = None):
+    def backward(self, lo: int = 0, hi: int = None, on_block=None):
         """Backward pass of blocks[lo:hi] in reverse order (default: all)."""
         st = self._stream()
-        for blk in reversed(self.blocks[lo:hi]):
+        idx = list(range(len(self.blocks)))[lo:hi]
+        for i in reversed(idx):
+            blk = self.blocks[i]
+            if on_block is not None:
+                on_block(i)
             H, W, D = blk.dims
             rc = self.lib.dlka_lka3d_attention_tokens_backward(L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.gy), L.ptr(blk.saved),
                                                         blk.saved_bytes, L.ptr(blk.gx), byref(blk.gstruct), L.ptr(self.ws),
                                                         self.ws_bytes, self.B, blk.C, H, W, D, self.dt, st)
             L.check(rc, "lka3d_attention_tokens_backward")
 
-    def forward_backward(self):
-        self.forward()
-        self.backward()
+    def forward_backward(self, on_block=None):
+        self.forward(on_block)
+        self.backward(on_block=on_block)
 
     def split_index(self, frac: float = 0.8) -> int:
         """Block index i such that blocks[i:] hold at least `frac` of the gradient bytes and start a stage: the backward pass produces

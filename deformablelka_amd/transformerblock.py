@@ -97,10 +97,13 @@ class LKA_Attention3d_deform(nn.Module):
         # Autocast policy (the reference has none — its op would raise on half inputs, deform_conv_cuda.cu:96): inside
         # torch.autocast(dtype=torch.bfloat16) the block takes bf16 activations with fp32 parameters and accumulation.
         act = ops.autocast_activation_dtype(x)
-        if act != x.dtype and self.proj_1.weight.dtype == torch.float32 and ops.lka3d_tokens_supported(x.to(act), B, C, H, W, D):
-            x = x.to(act)
-        if self.proj_1.weight.dtype == torch.float32 and ops.lka3d_tokens_supported(x, B, C, H, W, D):
+        fp32_params = self.proj_1.weight.dtype == torch.float32
+        if act != x.dtype and fp32_params and ops.lka3d_tokens_supported(act, B, C, H, W, D):
+            x = x.to(act)   # (one cast: the support query takes the dtype, not a tensor)
+        if fp32_params and ops.lka3d_tokens_supported(x.dtype, B, C, H, W, D):
             return _LKA3dTokensFn.apply(x, (H, W, D), *self.block_params())
+        if x.dtype != self.proj_1.weight.dtype:   # general path: one dtype for activations and parameters
+            x = x.to(self.proj_1.weight.dtype)
         # General path (any C / dtype): the reference's own data movement around the NCDHW block.
         x = x.permute(0, 2, 1).reshape(B, C, H, W, D)  # B N C --> B C N --> B C H W D   (:665)
         x = self.forward_volume(x)
@@ -174,8 +177,13 @@ class TransformerBlock_3D_single_deform_LKA(nn.Module):
         return (self.norm.weight, self.norm.bias, self.gamma, self.pos_embed, c.conv1.conv.weight, c.conv2.conv.weight, c.norm1.weight, c.norm1.bias,
                 c.norm2.weight, c.norm2.bias, self.conv8[1].weight, self.conv8[1].bias)
 
-    def forward(self, x):
+    def forward(self, x, keep_channels_last=None):
+        """keep_channels_last: None = the module attribute; True / False = this call only (``network._chain`` passes it per call)."""
         B, C, H, W, D = x.shape
+        if x.dtype == torch.bfloat16:
+            # The wrapper block (LayerNorm, UnetResBlock's BatchNorm statistics, the gamma residual) runs in fp32 on this path: a bf16 tensor
+            # reaching it — e.g. from a torch layer inside torch.autocast — is widened here, explicitly (no silent dtype mismatch further down).
+            x = x.float()
         if not ops.tblock3d_supported(x, B, C, H, W, D):
             raise NotImplementedError(f"TransformerBlock_3D_single_deform_LKA on the HIP path needs float32 and hidden_size in {{32, 64, 128, 256}}; "
                                       f"got {x.dtype}, C={C}")
@@ -198,4 +206,5 @@ class TransformerBlock_3D_single_deform_LKA(nn.Module):
             bn_update_running(c.norm1, stats[:3 * C])
             bn_update_running(c.norm2, stats[3 * C:])
         y = y.view(B, H, W, D, C).permute(0, 4, 1, 2, 3)
-        return y if self.keep_channels_last else y.contiguous()
+        keep = self.keep_channels_last if keep_channels_last is None else keep_channels_last
+        return y if keep else y.contiguous()

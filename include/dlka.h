@@ -103,9 +103,10 @@ int dlka_deform_conv3d_backward(const void *x, const void *offset, const void *w
 int dlka_deform_conv3d_sample_index(const void *offset, int32_t *idx, uint8_t *mask,
                                     const dlka_conv_geom *g, int dtype, void *stream);
 /* Same outputs, computed by the very device functions the hot kernels call, so that the bit-exact index claim covers
- * the code that runs:  path 0 = the rule on its own (as above); path 1 = setup_tap<3> (deform_sample.h — every
- * general NCDHW kernel); path 2 = gather_describe3 (cl_gather.h — every channels-last fast-path kernel).  Paths 1/2
- * report idx = 0 where mask == 0 (outside the guard of cuh:247 the kernels never form a cell). */
+ * the code that runs.  ONE device function forms q, tests the guard and takes the floor (sample_cell3, deform_sample.h);
+ * path 0 = that function on its own (cl_deform_gx_fx2_kernel calls it directly); path 1 = setup_tap<3> (every general NCDHW
+ * kernel); path 2 = gather_describe3 (cl_gather.h — the channels-last forward / grad_offset / weight-gradient kernels);
+ * path 3 = lane_tap (the grad_input window kernels).  idx = 0 where mask == 0 (outside the guard of cuh:247 no cell is formed). */
 int dlka_deform_conv3d_sample_index_path(const void *offset, int32_t *idx, uint8_t *mask,
                                          const dlka_conv_geom *g, int dtype, int path, void *stream);
 
@@ -370,6 +371,37 @@ int dlka_tblock3d_backward(const dlka_tblock3d_params *p, const dlka_lka3d_param
                            const void *bn_stats, const void *grad_y, const void *saved, size_t saved_bytes, void *grad_x,
                            const dlka_tblock3d_grads *grads, const dlka_lka3d_grads *lka_grads,
                            void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, void *stream);
+
+/* 2-D counterpart (torchvision 0.12 deform_conv2d, un-vendored; 2D/deformable_LKA/deformable_LKA.py:18-30): idx int32 [B][og][K][No][2]
+ * = the floor cell (y, x) where `reach`, else 0; mask uint8: bit 0 = the sample is inside the guard (-1 < q < size), bit 1 = reach
+ * (q >= -1 && q < size: the domain of torchvision's unguarded coordinate weight).  path 0 = sample_cell2 (deform_sample.h; the
+ * window scatter of cl_ddw2d.hip calls it directly), path 1 = setup_tap<2> (general kernels), path 2 = describe2 (cl_ddw2d.hip). */
+int dlka_deform_conv2d_sample_index_path(const void *offset, int32_t *idx, uint8_t *mask,
+                                         const dlka_conv_geom *g, int dtype, int path, void *stream);
+
+/* Channels-last 2-D DEPTHWISE deformable conv on its own — the two large-kernel convs of the 2-D D-LKA block
+ * (2D/deformable_LKA/deformable_LKA.py:93-94 -> :18-30: torchvision.ops.DeformConv2d(C, C, k, padding, groups=C, dilation,
+ * bias=False)(x, offsets)).  x / out / grad_out / grad_x [B][H][W][C]; offset / grad_offset [B][2 kh kw][H][W] ((dy, dx) per tap, as
+ * torchvision); weight / grad_weight [C][1][kh][kw].  Stride 1, "same" padding, C % 32 == 0, fp32.  All three gradients at once. */
+size_t dlka_deform_dwconv2d_cl_workspace(const dlka_conv_geom *g, int dtype, int backward);
+int dlka_deform_dwconv2d_forward_cl(const void *x, const void *offset, const void *weight, void *out,
+                                    void *workspace, size_t workspace_bytes, const dlka_conv_geom *g, int dtype, void *stream);
+int dlka_deform_dwconv2d_backward_cl(const void *x, const void *offset, const void *weight, const void *grad_out,
+                                     void *grad_x, void *grad_offset, void *grad_weight,
+                                     void *workspace, size_t workspace_bytes, const dlka_conv_geom *g, int dtype, void *stream);
+
+/* =======================================================================================
+ * Launch trace — measurement aid (no reference counterpart; the reference has no profiling hooks)
+ * =======================================================================================
+ * Between dlka_trace_start and dlka_trace_stop every kernel launch of the library is followed by a HIP timing event on the
+ * launch's own stream; record i = (kernel name, milliseconds since the previous record).  bench.py runs the timed step once
+ * more under the trace to report the roofline of the kernels the step REALLY launches.  dlka_trace_mark inserts a record
+ * without a kernel (name "(mark)") to separate phases.  Not thread-safe; illegal during hipGraph capture.  */
+int dlka_trace_start(int max_events, void *stream);
+int dlka_trace_mark(void *stream);
+int dlka_trace_stop(void);                 /* synchronises with the last record; DLKA_ERR_WORKSPACE if records were dropped */
+int dlka_trace_count(void);
+int dlka_trace_get(int i, char *name, size_t name_cap, float *ms);
 
 #ifdef __cplusplus
 }

@@ -20,19 +20,21 @@ def bf16_storage(t):
 def lka3d_attention_volume(x, P, store=None):
     """LKA_Attention3d_deform on an NCDHW volume — 3D/d_lka_former/network_architecture/synapse/transformerblock.py:664-673
     (minus the token permutes), LKA3d_deform.forward :644-652, DeformConvPack.forward synapse/deform_conv.py:93-105.
-    store: None = the reference's fp32 block; ``bf16_storage`` = the same arithmetic with every activation the DLKA_BF16 path writes to HBM
-    rounded to bf16 where it is written (offsets stay fp32) — the model of "bf16 activations, fp32 parameters and accumulation"."""
+    store: None = the reference's fp32 block; ``bf16_storage`` = the model of the DLKA_BF16 path: the same arithmetic with every activation
+    that path writes to HBM AS bf16 rounded where it is written.  The chain that decides the sampling cells — a = GELU(proj_1 x) -> conv0 ->
+    conv_spatial -> conv_offset — stays fp32 there (deformablelka_amd/csrc/dlka_capi_cl.hip, TokGeoms), so it is not rounded here either; the
+    gate and the deformable conv's SAMPLES read the bf16 copies of a and t."""
     st = store if store is not None else (lambda t: t)
     C = x.shape[1]
     shortcut = x.clone()                                                         # :666
-    a = st(F.gelu(F.conv3d(x, P["proj_1.weight"], P["proj_1.bias"])))            # :667-668
-    u = a.clone()                                                                # :645
+    a = F.gelu(F.conv3d(x, P["proj_1.weight"], P["proj_1.bias"]))                # :667-668
+    u = st(a)                                                                    # :645 (the gate's copy)
     s = "spatial_gating_unit."
-    attn = st(F.conv3d(a, P[s + "conv0.weight"], P[s + "conv0.bias"], padding=2, groups=C))                             # :646
-    attn = st(F.conv3d(attn, P[s + "conv_spatial.weight"], P[s + "conv_spatial.bias"], padding=9, dilation=3, groups=C))  # :647
+    attn = F.conv3d(a, P[s + "conv0.weight"], P[s + "conv0.bias"], padding=2, groups=C)                             # :646
+    attn = F.conv3d(attn, P[s + "conv_spatial.weight"], P[s + "conv_spatial.bias"], padding=9, dilation=3, groups=C)  # :647
     attn = attn.contiguous()                                                     # :648
     off = F.conv3d(attn, P[s + "deform_conv.conv_offset.weight"], P[s + "deform_conv.conv_offset.bias"], stride=1, padding=1)
-    attn = st(oracle.DeformConv3dFunction.apply(attn, off, P[s + "deform_conv.weight"], P[s + "deform_conv.bias"],
+    attn = st(oracle.DeformConv3dFunction.apply(st(attn), off, P[s + "deform_conv.weight"], P[s + "deform_conv.bias"],
                                                 1, 1, 1, 1, 1, 64))              # deform_conv.py:95-105
     attn = F.conv3d(attn, P[s + "conv1.weight"], P[s + "conv1.bias"])            # :650  (the gate consumes conv1's fp32 value in the fused epilogue)
     y = F.conv3d(st(u * attn), P["proj_2.weight"], P["proj_2.bias"])             # :652, :670

@@ -66,10 +66,12 @@ def check_deform3d(dev, B, C, Cout, dims, k, s, p, d, g, dg, off_mode="normal", 
     assert_close("deform3d fwd", out, ref, atol=FWD_ATOL)
     if check_index:
         ridx, rmask = oracle.deform_conv3d_sample_index(off, dims, k3, s3, p3, d3, dg)
-        for path in (0, 1, 2):   # standalone rule; setup_tap (general kernels); gather_describe3 (channels-last fast path)
+        # sample_cell3 on its own (= what the fixed-point grad_input kernel calls); setup_tap (general kernels); gather_describe3 (channels-last
+        # gathers); lane_tap (grad_input window kernels) — every site of the rule in the library.  A cell is reported only inside the guard.
+        want = ridx * rmask[..., None].to(ridx.dtype)
+        for path in (0, 1, 2, 3):
             idx, mask = ops.deform_conv3d_sample_index(od, dims, k3, s3, p3, d3, dg, path=path)
             assert torch.equal(mask.cpu(), rmask), f"guard mask not bit-exact (path {path})"
-            want = ridx if path == 0 else ridx * rmask[..., None].to(ridx.dtype)   # paths 1/2 report a cell only inside the guard
             assert torch.equal(idx.cpu(), want), f"floor indices not bit-exact (path {path})"
     if check_bwd:
         rgi, rgo, rgw, rgb = oracle.deform_conv3d_backward(x, w, b, off, go, s3, p3, d3, g, dg, q1_literal=False)
@@ -102,8 +104,50 @@ def make_deform2d(B, C, Cout, H, W, k, s, p, d, g, og, off_mode="normal", seed=0
     return x, off, w, go
 
 
+def embed_offsets_2d_in_3d(off, K, og):
+    """torchvision offsets [B, og*2K, Ho, Wo] ((dy, dx) per tap) -> D3D offsets [B, og*3K, 1, Ho, Wo] ((dd = 0, dh = dy, dw = dx) per tap)."""
+    B, _, Ho, Wo = off.shape
+    o2 = off.reshape(B, og, K, 2, Ho, Wo)
+    o3 = torch.zeros(B, og, K, 3, 1, Ho, Wo, dtype=off.dtype)
+    o3[:, :, :, 1, 0] = o2[:, :, :, 0]
+    o3[:, :, :, 2, 0] = o2[:, :, :, 1]
+    return o3.reshape(B, og * 3 * K, 1, Ho, Wo)
+
+
+def expected_index_2d(off, H, W, k, s, p, d, og):
+    """(idx [B,og,K,Ho,Wo,2], mask [B,og,K,Ho,Wo]) the 2-D index entry must produce BIT FOR BIT: floor cell and guard from the oracle's D3D
+    index routine on the D = 1 embedding (deform_im2col_cuda.cuh:244-259 with qd = 0 exactly), `reach` (q >= -1 && q < size: the domain of
+    torchvision's unguarded coordinate weight) formed here in fp32 exactly as the rule forms q: float(int base) + offset."""
+    kh, kw = k
+    K = kh * kw
+    B, _, Ho, Wo = off.shape
+    ridx, rmask = oracle.deform_conv3d_sample_index(embed_offsets_2d_in_3d(off, K, og), (1, H, W), (1, kh, kw), (1, s, s), (0, p, p), (1, d, d), og)
+    ridx, rmask = ridx[:, :, :, 0], rmask[:, :, :, 0]          # [B,og,K,Ho,Wo,(3)]
+    o2 = off.reshape(B, og, K, 2, Ho, Wo).float()
+    tj = (torch.arange(K) // kw).view(1, 1, K, 1, 1)
+    tk = (torch.arange(K) % kw).view(1, 1, K, 1, 1)
+    by = (torch.arange(Ho).view(1, 1, 1, Ho, 1) * s - p + tj * d).to(torch.float32)
+    bx = (torch.arange(Wo).view(1, 1, 1, 1, Wo) * s - p + tk * d).to(torch.float32)
+    qy, qx = by + o2[:, :, :, 0], bx + o2[:, :, :, 1]
+    reach = (qy >= -1) & (qx >= -1) & (qy < H) & (qx < W)
+    assert bool((rmask.bool() & ~reach).sum() == 0)
+    cell = torch.stack([torch.floor(qy), torch.floor(qx)], -1).to(torch.int32) * reach[..., None].to(torch.int32)
+    inside = rmask.bool()
+    assert torch.equal(cell[inside], ridx[..., 1:3][inside])    # the fp32 floor formed here == the oracle's, wherever the oracle forms one
+    return cell, rmask | (reach.to(torch.uint8) << 1)
+
+
+def check_index2d(dev, off, H, W, k, s, p, d, og, paths=(0, 1, 2)):
+    want_idx, want_mask = expected_index_2d(off, H, W, k, s, p, d, og)
+    for path in paths:   # sample_cell2 on its own (= the window scatter of cl_ddw2d.hip); setup_tap<2> (general kernels); describe2 (cl_ddw2d.hip)
+        idx, mask = ops.deform_conv2d_sample_index(off.to(dev), (H, W), k, s, p, d, og, path=path)
+        assert torch.equal(mask.cpu(), want_mask), f"2-D guard / reach mask not bit-exact (path {path})"
+        assert torch.equal(idx.cpu(), want_idx), f"2-D floor cell not bit-exact (path {path})"
+
+
 def check_deform2d(dev, B, C, Cout, H, W, k, s, p, d, g, og, off_mode="normal", seed=0, with_bias=False):
     x, off, w, go = make_deform2d(B, C, Cout, H, W, k, s, p, d, g, og, off_mode, seed)
+    check_index2d(dev, off, H, W, k, s, p, d, og)
     bias = torch.randn(Cout, generator=torch.Generator().manual_seed(5)) if with_bias else None
     ref = oracle.deform_conv2d_forward(x, off, w, bias, s, p, d)
     xd, od, wd, god = (t.to(dev) for t in (x, off, w, go))
@@ -457,25 +501,14 @@ def check_lka3d_tokens_bf16(dev, B, C, dims, seed=0, offset_std=0.38, rtol=BF16_
         short = lambda k: ".".join(k.split(".")[-2:])
         print(f"[bf16 tokens C={C} dims={dims}] vs fp32 oracle: " + " ".join(f"{short(k)}={v:.1e}" for k, v in errs.items()))
         print(f"[bf16 tokens C={C} dims={dims}] vs bf16-storage oracle: " + " ".join(f"{short(k)}={v:.1e}" for k, v in errs16.items()))
-    # grad_offset is DISCONTINUOUS where a sampling coordinate crosses an integer.  Rounding the offset conv's input to bf16 moves the
-    # predicted offsets by ~0.4 % and flips the cell of the samples that sit that close to a boundary; each flip changes that sample's
-    # grad_offset by O(1).  conv_offset.{weight,bias}.grad sum grad_offset with random signs, so they move by ~2*sqrt(flip rate) = O(10 %), and
-    # through grad_t everything UPSTREAM of the deformable conv in the backward pass (conv_spatial, conv0, proj_1) moves by a few percent —
-    # for ANY implementation with bf16 activations: the bf16-storage oracle sits at the same distance from the fp32 one (printed above).
-    # Even two bf16 implementations differ there, because a last-bit difference in an fp32 sum occasionally rounds to the other bf16
-    # neighbour.  Measured on the MI355X at the four full stage shapes (vs bf16-storage / vs fp32): conv_offset <= 8.6e-2 / 1.8e-1,
-    # conv0 / conv_spatial <= 4.4e-2 / 1.1e-1, proj_1 <= 1.0e-2 / 3.5e-2; everything else (y, gx, deform_conv, conv1, proj_2) <= 8e-3.
-    def limits(k):
-        if "conv_offset" in k:
-            return 1.5e-1, None                   # (vs bf16-storage oracle, vs fp32 oracle: reported only)
-        if any(t in k for t in ("conv0.", "conv_spatial.", "proj_1.")):
-            return 3 * rtol, 1.5e-1
-        return rtol, rtol                         # y, gx and every gradient not exposed to the discontinuity: the SURVEY §8c bar, 2e-2
+    # the bf16 path within 2e-2 (of max |reference|) of the fp32 oracle — EVERY quantity, no exceptions.  That holds because the
+    # DLKA_BF16 block keeps the chain that decides the sampling cells (a -> conv0 -> conv_spatial -> conv_offset) on fp32 tensors: with those
+    # stored as bf16 the predicted offsets move by ~0.4 %, samples near an integer coordinate change cell, and conv_offset / conv_spatial / conv0 /
+    # proj_1 gradients land 5e-2 .. 1.8e-1 from the fp32 block (round 2 measured exactly that; tests/test_oracle_bf16_model.py reproduces it on the
+    # CPU with per-tensor storage flags).  The bf16-storage model (oracle.blocks.bf16_storage) must be matched at least as closely.
     for k in errs:
-        l16, l32 = limits(k)
-        assert errs16[k] <= l16, f"bf16 tokens {k}: rel err vs bf16-storage oracle {errs16[k]:.3e} > {l16}"
-        if l32 is not None:
-            assert errs[k] <= l32, f"bf16 tokens {k}: rel err vs fp32 oracle {errs[k]:.3e} > {l32}"
+        assert errs[k] <= rtol, f"bf16 tokens {k}: rel err vs fp32 oracle {errs[k]:.3e} > {rtol}"
+        assert errs16[k] <= rtol, f"bf16 tokens {k}: rel err vs bf16-storage oracle {errs16[k]:.3e} > {rtol}"
     return errs
 
 
