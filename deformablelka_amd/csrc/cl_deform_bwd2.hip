@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
             RowDesc r;
             r.base = 0; r.okm = 0; r.ld = r.lh = r.lw = 0.f;
             if (row_ok) r = gather_describe3(onx[0], onx[1], onx[2], p.N, b, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw, p.D, p.H, p.W);
-            gather_publish(Dt, j, r);
+            gather_publish(Dt, j, r, rowbytes);
         }
         wave_sync();   // (the descriptions stay in the LDS table; issue() and the interpolation read their rows back when they need them —
                        //  held in registers across the MFMA phase they cost 20 VGPRs the kernel does not have)
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
         const unsigned cbyte = (unsigned)(cc * 32 + GG::PE * gp) * XB;
 #pragma unroll
         for (int g = 0; g < GG::NG; ++g) {
-            const RowDesc r = gather_lookup(Dt, GG::RPI * g + gr);
+            const RowLook r = gather_lookup(Dt, GG::RPI * g + gr);
 #pragma unroll
             for (int q = 0; q < 8; ++q) xr[g][q] = gather_load<T>(rin, gather_offset(r, q, HW, p.W, rowbytes, cbyte));
         }
@@ -195,27 +195,41 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
             wave_sync();   // previous tiles consumed
 #pragma unroll
             for (int g = 0; g < GG::NG; ++g) {
-                const RowDesc rdg = gather_lookup(Dt, GG::RPI * g + gr);
-                const float fd[2] = {1.f - rdg.ld, rdg.ld}, fh[2] = {1.f - rdg.lh, rdg.lh}, fw[2] = {1.f - rdg.lw, rdg.lw};
+                const RowLook rdg = gather_lookup(Dt, GG::RPI * g + gr);
                 const bool srow = SAMP && (tile_full || mbase + GG::RPI * g + gr < p.M);
                 f32x4 s4_lo = {0.f, 0.f, 0.f, 0.f};   // bf16 storage: the piece's first four samples wait for the other four (one 16-byte store)
 #pragma unroll
                 for (int v = 0; v < GG::PE / 4; ++v) {
-                    f32x4 dd = {0.f, 0.f, 0.f, 0.f}, dh = {0.f, 0.f, 0.f, 0.f}, dw = {0.f, 0.f, 0.f, 0.f}, s4 = {0.f, 0.f, 0.f, 0.f};
+                    // SEPARABLE trilinear sample + its three coordinate derivatives (cuh:111-190), axis by axis: w, then h, then d.  The per-corner
+                    // form (8 corners x (3 derivative + 1 sample) fmas, plus 32 coefficient products per row and lane) was ~45 % of this kernel's
+                    // vector instructions, and the kernel is bound by their issue (scripts/isa_loop_mix.py); 22 lerps / differences do the same:
+                    //   along w:  sw(cd,ch) = x0 + lw (x1 - x0),  dq(cd,ch) = x1 - x0
+                    //   along h:  shw(cd) = lerp_h sw,  eh(cd) = sw(cd,1) - sw(cd,0),  ew(cd) = lerp_h dq
+                    //   along d:  S = lerp_d shw,  dS/dd = shw(1) - shw(0),  dS/dh = lerp_d eh,  dS/dw = lerp_d ew
+                    // Dropped corners (outside the volume, or the whole sample outside the guard) arrive as zeros from the range-checked loads.
+                    f32x4 sw[4], dq[4];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int cd = (q >> 2) & 1, ch = (q >> 1) & 1, cw = q & 1;
-                        const float kd_ = (cd ? 1.f : -1.f) * fh[ch] * fw[cw], kh_ = (ch ? 1.f : -1.f) * fd[cd] * fw[cw], kw_ = (cw ? 1.f : -1.f) * fd[cd] * fh[ch];
-                        const f32x4 x4 = xr[g][q].get(v);
+                    for (int pr = 0; pr < 4; ++pr) {
+                        const f32x4 x0 = xr[g][2 * pr].get(v), x1 = xr[g][2 * pr + 1].get(v);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { dq[pr][e] = x1[e] - x0[e]; sw[pr][e] = fmaf(rdg.lw, dq[pr][e], x0[e]); }
+                    }
+                    f32x4 shw[2], eh[2], ew[2];
+#pragma unroll
+                    for (int cd = 0; cd < 2; ++cd)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            dd[e] = fmaf(kd_, x4[e], dd[e]); dh[e] = fmaf(kh_, x4[e], dh[e]); dw[e] = fmaf(kw_, x4[e], dw[e]);
+                            eh[cd][e] = sw[2 * cd + 1][e] - sw[2 * cd][e];
+                            shw[cd][e] = fmaf(rdg.lh, eh[cd][e], sw[2 * cd][e]);
+                            ew[cd][e] = fmaf(rdg.lh, dq[2 * cd + 1][e] - dq[2 * cd][e], dq[2 * cd][e]);
                         }
-                        if (SAMP) {   // the trilinear sample itself (weights and fma order of gather_weights / cl_wgrad_deform_kernel: bit-equal tiles)
-                            const float ws_ = fd[cd] * fh[ch] * fw[cw];
+                    f32x4 dd, dh, dw, s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) s4[e] = fmaf(ws_, x4[e], s4[e]);
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        dd[e] = shw[1][e] - shw[0][e];
+                        if (SAMP) s4[e] = fmaf(rdg.ld, dd[e], shw[0][e]);
+                        dh[e] = fmaf(rdg.ld, eh[1][e] - eh[0][e], eh[0][e]);
+                        dw[e] = fmaf(rdg.ld, ew[1][e] - ew[0][e], ew[0][e]);
                     }
                     float *dst = Tt + (GG::RPI * g + gr) * SROW + GG::PE * gp + 4 * v;
                     *reinterpret_cast<f32x4 *>(dst) = dd;

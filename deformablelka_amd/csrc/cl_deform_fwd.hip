@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
     constexpr int SROW = 36;   // padded sample-tile row (floats): 16-byte aligned, conflict-free b128 rows
     __shared__ __attribute__((aligned(16))) float Bs[2][32 * NPB];
     __shared__ __attribute__((aligned(16))) float Ssm[4][32 * SROW];
-    __shared__ __attribute__((aligned(16))) float Dsm[4][32 * GATHER_DESC_WORDS];
+    __shared__ __attribute__((aligned(16))) float Dsm[4][32 * GATHER_DESCW_WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;      // MFMA roles
     using GG = GatherGeom<T>;
@@ -54,7 +54,6 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
 
     f32x4 breg[BV];
     GatherPiece<T> xr[GG::NG][8];   // gathered corner pieces of the next unit, in flight
-    RowDesc rd[GG::NG];             // descriptions of this lane's gather rows (current tap)
     int cur_tap = -1;
 
 #define DLKA_LOAD_B(unit_)                                                                         \
@@ -90,26 +89,26 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
                 r.base = 0; r.okm = 0; r.ld = r.lh = r.lw = 0.f;
                 if (row_ok)
                     r = gather_describe3(onx[0], onx[1], onx[2], p.N, b, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw, p.D, p.H, p.W);
-                gather_publish(Dt, i, r);
+                gather_publish_w(Dt, i, r, rowbytes);
             }
             load_offsets(tap + 1);   // in flight until the next tap is described
-            wave_sync();
-#pragma unroll
-            for (int g = 0; g < GG::NG; ++g) rd[g] = gather_lookup(Dt, GG::RPI * g + gr);
+            wave_sync();   // (the table keeps this tap's rows until the next tap is described: descriptions and weights are read where they are used)
         }
         const unsigned cbyte = (unsigned)(ck * 32 + GG::PE * gp) * SB;
 #pragma unroll
-        for (int g = 0; g < GG::NG; ++g)
+        for (int g = 0; g < GG::NG; ++g) {
+            const RowLook r = gather_lookup_d(Dt, GG::RPI * g + gr);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) xr[g][q] = gather_load<T>(rin, gather_offset(rd[g], q, HW, p.W, rowbytes, cbyte));
+            for (int q = 0; q < 8; ++q) xr[g][q] = gather_load<T>(rin, gather_offset(r, q, HW, p.W, rowbytes, cbyte));
+        }
     };
     // interpolate, transpose through the wave-private tile, return the MFMA A values of this lane
     auto finish = [&](float *a) {
         wave_sync();   // previous tile consumed
 #pragma unroll
         for (int g = 0; g < GG::NG; ++g) {
-            float wq[8];
-            gather_weights(rd[g], wq);
+            float wq[8];   // formed once per row by the publishing lane
+            gather_lookup_weights(Dt, GG::RPI * g + gr, wq);
 #pragma unroll
             for (int v = 0; v < GG::PE / 4; ++v) {
                 f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
@@ -172,6 +171,161 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 16-row waves (round 3).  The kernel above is latency-bound at 2 waves per SIMD (profiles/r03p_pmc_issue_wait_stage0_f32.txt: an instruction of
+// any kind issues in 37 % of the resident wave-cycles): 128 VGPRs of corner pieces in flight per 32-row wave, and a 32-row tile count that gives
+// the chip exactly two waves per SIMD at stage 0 (65 536 rows / 32 = 2048 waves on 1024 SIMDs).  Here a wave owns 16 rows: half the corner pieces
+// (64 VGPRs), v_mfma_f32_16x16x4_f32 (same FLOP rate as 32x32x2, MI355X_MICROARCH.md), twice the waves — 4 per SIMD under the 128-register budget.
+// Same arithmetic per output element: the k order within a 32-channel chunk is permuted identically on both operands (lane group g holds
+// channels 8g .. 8g+7), the fmaf order of the interpolation is unchanged.  One 32-column tile per workgroup (blockIdx.z walks wider outputs).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512, 4) void cl_deform_fwd16_kernel(IgemmArgs p)
+{
+    constexpr unsigned SB = sizeof(T);
+    constexpr int WAVES = 8;
+    constexpr int SROW = 36;   // padded sample-tile row (floats)
+    using GG = GatherGeom<T>;
+    constexpr int NG = GG::NG / 2;   // row groups of a 16-row tile: fp32 2 x 8 rows, bf16 1 x 16 rows
+    __shared__ __attribute__((aligned(16))) float Bs[2][32 * 32];
+    __shared__ __attribute__((aligned(16))) float Ssm[WAVES][16 * SROW];
+    __shared__ __attribute__((aligned(16))) float Dsm[WAVES][16 * GATHER_DESCW_WORDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g4 = lane >> 4;                                  // MFMA roles: row / column index, k group
+    const int gr = lane >> GG::PSHIFT, gp = lane & ((1 << GG::PSHIFT) - 1);   // gather roles: row gr of each group of RPI, 16-byte piece gp
+    const int bx = DLKA_XCD_BX(p.xcd_nx);
+    if (bx < 0) return;
+    const int mbase = (bx * WAVES + wave) * 16;
+    const int m = mbase + i;
+    const bool row_ok = m < p.M;
+    const int b = row_ok ? m / p.N : 0;
+    const int v = row_ok ? m - b * p.N : 0;
+    const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / (p.W * p.H);
+    const int n0 = blockIdx.z * 32;
+    const int HW = p.H * p.W, rowbytes = p.Cin * SB;
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * SB);
+    float *S = Ssm[wave], *Dt = Dsm[wave];
+
+    f32x4 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunk = p.CinP / 32;
+    const int unit_lo = blockIdx.y * p.units_per_split;
+    const int unit_hi = min(p.K * nchunk, unit_lo + p.units_per_split);
+
+    f32x4 breg = {0.f, 0.f, 0.f, 0.f};
+    GatherPiece<T> xr[NG][8];   // gathered corner pieces of the next unit, in flight
+    int cur_tap = -1;
+    auto load_b = [&](int unit) {   // 32 x 32 weight chunk: one 16-byte piece per thread of the first four waves
+        if (tid < 256) {
+            const int tap = unit / nchunk, ck = unit - tap * nchunk;
+            const float *src = p.wp + ((long)tap * p.CinP + ck * 32) * p.NP + n0;
+            breg = reinterpret_cast<const f32x4 *>(src + (long)(tid >> 3) * p.NP)[tid & 7];
+        }
+    };
+    float onx[3] = {0.f, 0.f, 0.f};   // the next tap's offsets, requested one tap ahead (see cl_deform_fwd_kernel)
+    const int tap_last = (unit_hi - 1) / nchunk;
+    auto load_offsets = [&](int tap) {
+        if (g4 == 0 && row_ok && tap <= tap_last) {
+            const float *op = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
+            onx[0] = op[0]; onx[1] = op[p.N]; onx[2] = op[2 * (long)p.N];
+        }
+    };
+    if (unit_lo < unit_hi) load_offsets(unit_lo / nchunk);
+    auto issue = [&](int unit) {
+        const int tap = unit / nchunk, ck = unit - tap * nchunk;
+        if (tap != cur_tap) {   // uniform
+            cur_tap = tap;
+            const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
+            wave_sync();        // every lane has consumed the previous table
+            if (g4 == 0) {
+                RowDesc r;
+                r.base = 0; r.okm = 0; r.ld = r.lh = r.lw = 0.f;
+                if (row_ok)
+                    r = gather_describe3(onx[0], onx[1], onx[2], p.N, b, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw, p.D, p.H, p.W);
+                gather_publish_w(Dt, i, r, rowbytes);
+            }
+            load_offsets(tap + 1);
+            wave_sync();
+        }
+        const unsigned cbyte = (unsigned)(ck * 32 + GG::PE * gp) * SB;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const RowLook r = gather_lookup_d(Dt, GG::RPI * g + gr);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xr[g][q] = gather_load<T>(rin, gather_offset(r, q, HW, p.W, rowbytes, cbyte));
+        }
+    };
+    // interpolate, transpose through the wave-private tile, return this lane's A values: channels 8 g4 .. 8 g4 + 7 of row i
+    auto finish = [&](float *a) {
+        wave_sync();   // previous tile consumed
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float wq[8];
+            gather_lookup_weights(Dt, GG::RPI * g + gr, wq);
+#pragma unroll
+            for (int vv = 0; vv < GG::PE / 4; ++vv) {
+                f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f32x4 x4 = xr[g][q].get(vv);
+                    s4[0] = fmaf(wq[q], x4[0], s4[0]); s4[1] = fmaf(wq[q], x4[1], s4[1]);
+                    s4[2] = fmaf(wq[q], x4[2], s4[2]); s4[3] = fmaf(wq[q], x4[3], s4[3]);
+                }
+                *reinterpret_cast<f32x4 *>(S + (GG::RPI * g + gr) * SROW + GG::PE * gp + 4 * vv) = s4;
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(S + i * SROW + 8 * g4 + 4 * e);
+            a[4 * e] = t[0]; a[4 * e + 1] = t[1]; a[4 * e + 2] = t[2]; a[4 * e + 3] = t[3];
+        }
+    };
+
+    if (unit_lo < unit_hi) {
+        load_b(unit_lo);
+        issue(unit_lo);
+    }
+    int buf = 0;
+    for (int unit = unit_lo; unit < unit_hi; ++unit, buf ^= 1) {
+        float a_cur[8];
+        if (tid < 256) reinterpret_cast<f32x4 *>(Bs[buf])[tid] = breg;
+        finish(a_cur);      // consumes xr (the loads issued one iteration ago)
+        __syncthreads();    // Bs[buf] staged; Bs[buf^1] (read two iterations ago) is free again
+        if (unit + 1 < unit_hi) {
+            load_b(unit + 1);
+            issue(unit + 1);
+        }
+        // B[k = 8 g4 + s][n = 2 i + t]: one 8-byte LDS read per step feeds both column tiles (columns 2i and 2i + 1)
+        const float *brow = Bs[buf] + (8 * g4) * 32 + 2 * i;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const float b0 = brow[st * 32], b1 = brow[st * 32 + 1];
+            acc[0] = mfma_16x16x4(a_cur[st], b0, acc[0]);
+            acc[1] = mfma_16x16x4(a_cur[st], b1, acc[1]);
+        }
+    }
+
+    // ---- epilogue: D layout col = lane & 15 -> output columns n0 + 2 i + t, row = 4 * (lane >> 4) + r ----
+    const bool split = gridDim.y > 1;
+    const int n = n0 + 2 * i;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (n + t >= p.Cout) continue;
+        const float bv = (p.bias && blockIdx.y == 0) ? p.bias[n + t] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mr = mbase + 4 * g4 + r;
+            if (mr >= p.M) continue;
+            const float val = acc[t][r] + bv;
+            if (split) atomicAdd(p.out + (long)mr * p.Cout + n + t, val);
+            else act_store1(reinterpret_cast<T *>(p.out), (long)mr * p.Cout + n + t, val);
+        }
+    }
+}
+
 int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
 {
     if ((long)a.M * a.Cin * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
@@ -193,6 +347,21 @@ int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
     else if (a.M <= 2048 && NT_total == 4) NT = 2;
     constexpr int nt_env = 0;
     if (nt_env == 1 || nt_env == 2 || nt_env == 4) { if (NT_total % nt_env == 0 && nt_env <= NT_total) NT = nt_env; }
+    // 16-row waves where the 32-row tiling leaves the chip at two waves per SIMD and the output is one 32-column tile (stage 0: C = 32)
+    {
+        static const char *e16 = getenv("DLKA_FWD16");   // A/B switch of round 3 (0 = never, 1 = wherever the shape allows)
+        const bool want16 = e16 ? atoi(e16) != 0 : (NT_total == 1 && a.M >= 16384);
+        if (want16 && NT_total <= 4 && a.NP % 32 == 0) {
+            const int mb16 = cdiv(a.M, 128);
+            dim3 grid16(mb16, splits, NT_total), block16(512);
+            a.xcd_nx = 0;
+            if (xcd_swizzle_enabled() && mb16 >= (unsigned)xcd_min_blocks()) { a.xcd_nx = mb16; grid16.x = xcd_grid(mb16); }
+            if (a.act_bf16) { auto k = cl_deform_fwd16_kernel<bf16_t>; DLKA_LAUNCH(k, grid16, block16, 0, st, a); }
+            else { auto k = cl_deform_fwd16_kernel<float>; DLKA_LAUNCH(k, grid16, block16, 0, st, a); }
+            DLKA_CHECK_LAUNCH();
+            return DLKA_OK;
+        }
+    }
     dim3 grid(mblocks, splits, NT_total / NT), block(256);
     a.xcd_nx = 0;
     if (xcd_swizzle_enabled() && mblocks >= (unsigned)xcd_min_blocks()) { a.xcd_nx = mblocks; grid.x = xcd_grid(mblocks); }

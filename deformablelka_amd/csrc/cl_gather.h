@@ -51,29 +51,90 @@ __device__ __forceinline__ RowDesc gather_describe(const float *__restrict__ off
     return gather_describe3(off[0], off[N], off[2 * N], N, b, bd, bh, bw, D, H, W);
 }
 
-__device__ __forceinline__ void gather_publish(float *tab, int row, const RowDesc &r)
+// What a lane reads back for a row it serves.  The table does not hold RowDesc as it is: the publisher (one lane per row) does the work that
+// would otherwise be repeated by the 8 lanes of every row for every corner — round 3 found the gather kernels bound by VALU issue, and ~55 % of
+// the forward kernel's vector instructions were corner ADDRESS arithmetic (v_mul_lo, v_add, v_and, v_cmp, v_cndmask per corner; scripts/isa_loop_mix.py):
+//   bbyte = base * rowbytes    (the 32-bit product wraps for base < 0 — floor cell -1 next to the volume's first rows; the sum with a VALID
+//                               corner's delta wraps back to the true offset)
+//   nokm  = ~okm               (bit q SET <=> corner q is dropped)
+// so that a corner's load offset is add + shift + and_or (gather_offset below).
+struct RowLook {
+    unsigned bbyte, nokm;
+    float ld, lh, lw;
+};
+
+__device__ __forceinline__ void gather_publish(float *tab, int row, const RowDesc &r, int rowbytes)
 {
     f32x4 a, b;
-    a[0] = __int_as_float(r.base); a[1] = __int_as_float((int)r.okm); a[2] = r.ld; a[3] = r.lh;
+    a[0] = __uint_as_float((unsigned)r.base * (unsigned)rowbytes); a[1] = __uint_as_float(~r.okm); a[2] = r.ld; a[3] = r.lh;
     b[0] = r.lw; b[1] = 0.f; b[2] = 0.f; b[3] = 0.f;
     reinterpret_cast<f32x4 *>(tab + row * GATHER_DESC_WORDS)[0] = a;
     reinterpret_cast<f32x4 *>(tab + row * GATHER_DESC_WORDS)[1] = b;
 }
 
-__device__ __forceinline__ RowDesc gather_lookup(const float *tab, int row)
+__device__ __forceinline__ RowLook gather_lookup(const float *tab, int row)
 {
     const f32x4 a = reinterpret_cast<const f32x4 *>(tab + row * GATHER_DESC_WORDS)[0];
-    RowDesc r;
-    r.base = __float_as_int(a[0]); r.okm = (unsigned)__float_as_int(a[1]); r.ld = a[2]; r.lh = a[3];
+    RowLook r;
+    r.bbyte = __float_as_uint(a[0]); r.nokm = __float_as_uint(a[1]); r.ld = a[2]; r.lh = a[3];
     r.lw = tab[row * GATHER_DESC_WORDS + 4];
     return r;
 }
 
-// byte offset of corner q of a described row, channel byte offset cbyte; DLKA_OOB (-> loads 0) for dropped corners
-__device__ __forceinline__ unsigned gather_offset(const RowDesc &r, int q, int HW, int W, int rowbytes, unsigned cbyte)
+// byte offset of corner q of a looked-up row, channel byte offset cbyte; >= DLKA_OOB (-> loads 0) for dropped corners.  The corner's delta
+// (q_d HW + q_h W + q_w) * rowbytes is wave-uniform (a scalar register); a dropped corner gets bit 31 set — valid offsets stay below 2 GB.
+__device__ __forceinline__ unsigned gather_offset(const RowLook &r, int q, int HW, int W, int rowbytes, unsigned cbyte)
 {
-    const int idx = r.base + ((q >> 2) & 1) * HW + ((q >> 1) & 1) * W + (q & 1);
-    return ((r.okm >> q) & 1u) ? (unsigned)idx * (unsigned)rowbytes + cbyte : DLKA_OOB;
+    const unsigned delta = (unsigned)(((q >> 2) & 1) * HW + ((q >> 1) & 1) * W + (q & 1)) * (unsigned)rowbytes;
+    const unsigned off = (r.bbyte + cbyte) + delta;
+    return ((r.nokm << (31 - q)) & DLKA_OOB) | off;
+}
+
+// ---- the same table with the eight trilinear weights of the row behind the description (16 words per row): kernels that only need the SAMPLE
+// (forward, gathering weight gradient) read them back instead of forming them per lane (18 vector instructions per row group and lane) ----
+constexpr int GATHER_DESCW_WORDS = 16;
+
+__device__ __forceinline__ void gather_weights(const RowDesc &r, float w[8]);
+
+__device__ __forceinline__ void gather_publish_w(float *tab, int row, const RowDesc &r, int rowbytes)
+{
+    float w[8];
+    gather_weights(r, w);
+    f32x4 a, b, c, d;
+    a[0] = __uint_as_float((unsigned)r.base * (unsigned)rowbytes); a[1] = __uint_as_float(~r.okm); a[2] = r.ld; a[3] = r.lh;
+    b[0] = r.lw; b[1] = 0.f; b[2] = 0.f; b[3] = 0.f;
+    c[0] = w[0]; c[1] = w[1]; c[2] = w[2]; c[3] = w[3];
+    d[0] = w[4]; d[1] = w[5]; d[2] = w[6]; d[3] = w[7];
+    f32x4 *dst = reinterpret_cast<f32x4 *>(tab + row * GATHER_DESCW_WORDS);
+    dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
+}
+
+// description only / weights only of a 16-word row: the kernels read each where it is needed instead of holding 13 registers per row group
+// across their MFMA phase
+__device__ __forceinline__ RowLook gather_lookup_d(const float *tab, int row)
+{
+    const f32x4 a = reinterpret_cast<const f32x4 *>(tab + row * GATHER_DESCW_WORDS)[0];
+    RowLook r;
+    r.bbyte = __float_as_uint(a[0]); r.nokm = __float_as_uint(a[1]); r.ld = a[2]; r.lh = a[3];
+    r.lw = 0.f;   // (not read back: the weights are)
+    return r;
+}
+__device__ __forceinline__ void gather_lookup_weights(const float *tab, int row, float w[8])
+{
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(tab + row * GATHER_DESCW_WORDS);
+    const f32x4 c = src[2], d = src[3];
+    w[0] = c[0]; w[1] = c[1]; w[2] = c[2]; w[3] = c[3]; w[4] = d[0]; w[5] = d[1]; w[6] = d[2]; w[7] = d[3];
+}
+
+__device__ __forceinline__ RowLook gather_lookup_w(const float *tab, int row, float w[8])
+{
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(tab + row * GATHER_DESCW_WORDS);
+    const f32x4 a = src[0], c = src[2], d = src[3];
+    RowLook r;
+    r.bbyte = __float_as_uint(a[0]); r.nokm = __float_as_uint(a[1]); r.ld = a[2]; r.lh = a[3];
+    r.lw = tab[row * GATHER_DESCW_WORDS + 4];
+    w[0] = c[0]; w[1] = c[1]; w[2] = c[2]; w[3] = c[3]; w[4] = d[0]; w[5] = d[1]; w[6] = d[2]; w[7] = d[3];
+    return r;
 }
 
 // Lane layout of the gather, by activation storage type.  fp32: a 32-channel chunk of a row is 128 bytes — lane = (row of 8, 16-byte piece
@@ -106,6 +167,13 @@ template <typename T> __device__ __forceinline__ GatherPiece<T> gather_load(BufR
     return p;
 }
 
+template <typename R> __device__ __forceinline__ void gather_weights_of(const R &r, float w[8])
+{
+    const float fd[2] = {1.f - r.ld, r.ld}, fh[2] = {1.f - r.lh, r.lh}, fw[2] = {1.f - r.lw, r.lw};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w[q] = fd[(q >> 2) & 1] * fh[(q >> 1) & 1] * fw[q & 1];
+}
+__device__ __forceinline__ void gather_weights(const RowLook &r, float w[8]) { gather_weights_of(r, w); }
 __device__ __forceinline__ void gather_weights(const RowDesc &r, float w[8])
 {
     const float fd[2] = {1.f - r.ld, r.ld}, fh[2] = {1.f - r.lh, r.lh}, fw[2] = {1.f - r.lw, r.lw};

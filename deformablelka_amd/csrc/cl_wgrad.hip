@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
     const int m_lo = chunk * p.rows_per_chunk;
     const int m_hi = min(p.M, m_lo + p.rows_per_chunk);
     GatherPiece<T> xr[GG::NG][8];
-    RowDesc rd[GG::NG];
+    RowLook rd[GG::NG];
     for (int mbase = m_lo; mbase < m_hi; mbase += 32) {
         // A operand: G[m = mbase + 16h + s][co]
         float ga[16];
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
                 RowDesc r;
                 r.base = 0; r.okm = 0; r.ld = r.lh = r.lw = 0.f;
                 if (row_ok) r = gather_describe(p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v, p.N, b, d0 + od, h0 + oh, w0 + ow, p.D, p.H, p.W);
-                gather_publish(Dt, i, r);
+                gather_publish(Dt, i, r, rowbytes);
             }
             wave_sync();
 #pragma unroll

@@ -17,21 +17,24 @@ def bf16_storage(t):
     return t + (t.bfloat16().float() - t).detach()
 
 
-def lka3d_attention_volume(x, P, store=None):
+def lka3d_attention_volume(x, P, store=None, chain_store=None):
     """LKA_Attention3d_deform on an NCDHW volume — 3D/d_lka_former/network_architecture/synapse/transformerblock.py:664-673
     (minus the token permutes), LKA3d_deform.forward :644-652, DeformConvPack.forward synapse/deform_conv.py:93-105.
     store: None = the reference's fp32 block; ``bf16_storage`` = the model of the DLKA_BF16 path: the same arithmetic with every activation
     that path writes to HBM AS bf16 rounded where it is written.  The chain that decides the sampling cells — a = GELU(proj_1 x) -> conv0 ->
     conv_spatial -> conv_offset — stays fp32 there (deformablelka_amd/csrc/dlka_capi_cl.hip, TokGeoms), so it is not rounded here either; the
-    gate and the deformable conv's SAMPLES read the bf16 copies of a and t."""
+    gate and the deformable conv's SAMPLES read the bf16 copies of a and t.
+    chain_store: rounding applied to the chain tensors a / t1 / t as the offset-determining convs READ them (None = fp32, what the product does;
+    ``bf16_storage`` = the round-2 design with every activation in bf16 — kept so that tests/test_oracle_bf16_model.py can show why it was dropped)."""
     st = store if store is not None else (lambda t: t)
+    cs = chain_store if chain_store is not None else (lambda t: t)
     C = x.shape[1]
     shortcut = x.clone()                                                         # :666
     a = F.gelu(F.conv3d(x, P["proj_1.weight"], P["proj_1.bias"]))                # :667-668
     u = st(a)                                                                    # :645 (the gate's copy)
     s = "spatial_gating_unit."
-    attn = F.conv3d(a, P[s + "conv0.weight"], P[s + "conv0.bias"], padding=2, groups=C)                             # :646
-    attn = F.conv3d(attn, P[s + "conv_spatial.weight"], P[s + "conv_spatial.bias"], padding=9, dilation=3, groups=C)  # :647
+    attn = cs(F.conv3d(cs(a), P[s + "conv0.weight"], P[s + "conv0.bias"], padding=2, groups=C))                        # :646
+    attn = cs(F.conv3d(attn, P[s + "conv_spatial.weight"], P[s + "conv_spatial.bias"], padding=9, dilation=3, groups=C))  # :647
     attn = attn.contiguous()                                                     # :648
     off = F.conv3d(attn, P[s + "deform_conv.conv_offset.weight"], P[s + "deform_conv.conv_offset.bias"], stride=1, padding=1)
     attn = st(oracle.DeformConv3dFunction.apply(st(attn), off, P[s + "deform_conv.weight"], P[s + "deform_conv.bias"],
@@ -41,10 +44,10 @@ def lka3d_attention_volume(x, P, store=None):
     return st(y + shortcut)                                                      # :671
 
 
-def lka3d_attention_tokens(x, P, B, C, H, W, D, store=None):
+def lka3d_attention_tokens(x, P, B, C, H, W, D, store=None, chain_store=None):
     """The full forward(x, B, C, H, W, D) on (B, N, C) tokens, :664-673."""
     v = x.permute(0, 2, 1).reshape(B, C, H, W, D)
-    v = lka3d_attention_volume(v, P, store)
+    v = lka3d_attention_volume(v, P, store, chain_store)
     return v.reshape(B, C, H * W * D).permute(0, 2, 1)
 
 
