@@ -374,9 +374,11 @@ def fullnet_metric(batch, steps, dev, bf16=False):
             "path": "nn.Module + autograd, eager; D-LKA blocks = HIP kernels; plumbing convs = GEMM re-expressions (rocBLAS) / HIP 3^3 convs, norms = torch" + ("; bf16 autocast policy" if bf16 else "")}
 
 
-def lka2d_metric(steps, dev):
-    """Secondary metric of SURVEY §8d: the 2-D D-LKA attention block fwd+bwd at B=24 on the three decoder shapes of the 224^2 net
-    (2D/networks/MaxViT_deform_LKA.py:643-679), two blocks each — images/s through deformable_LKA_Attention."""
+def lka2d_metric(steps, dev, dtype=torch.float32, with_cpu=False):
+    """Secondary metric of SURVEY §8d / BASELINE.json config 2: the 2-D D-LKA attention block fwd+bwd at B=24 on the three decoder shapes of the
+    224^2 net (2D/networks/MaxViT_deform_LKA.py:643-679), two blocks each — images/s through deformable_LKA_Attention, with the activation storage
+    type `dtype` (bf16 = config 2 as written: "bf16 training"; fp32 parameters either way).  Also: the launch-trace roofline of its dominant kernel
+    and (with_cpu) the BASELINE.md §3 "2D companion": the oracle block on the host cores, bounded."""
     import deformablelka_amd as dk
     from deformablelka_amd.init_utils import randomize_offset_nets
     shapes = [(384, 14), (192, 28), (96, 56)]
@@ -387,8 +389,8 @@ def lka2d_metric(steps, dev):
             m = dk.deformable_LKA_Attention(C).to(dev)
             randomize_offset_nets(m, 0.02)
             mods.append(m)
-            xs.append(torch.randn(24, C, n, n, device=dev, requires_grad=True))
-            gys.append(torch.randn(24, C, n, n, device=dev))
+            xs.append(torch.randn(24, C, n, n, device=dev).to(dtype).requires_grad_(True))
+            gys.append(torch.randn(24, C, n, n, device=dev).to(dtype))
 
     def step():
         for m, x, gy in zip(mods, xs, gys):
@@ -410,8 +412,113 @@ def lka2d_metric(steps, dev):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"metric": "2D D-LKA attention blocks fwd+bwd images/sec (224x224 net, B=24: 2x(384,14^2)+2x(192,28^2)+2x(96,56^2))", "value": round(24 / dt, 2),
-            "unit": "images/s", "ms_per_step": round(dt * 1e3, 2), "ms_per_block_fwd_bwd": dict(zip(["384x14^2", "192x28^2", "96x56^2"], per))}
+    out = {"metric": "2D D-LKA attention blocks fwd+bwd images/sec (224x224 net, B=24: 2x(384,14^2)+2x(192,28^2)+2x(96,56^2))", "value": round(24 / dt, 2),
+           "unit": "images/s", "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "ms_per_step": round(dt * 1e3, 2),
+           "ms_per_block_fwd_bwd": dict(zip(["384x14^2", "192x28^2", "96x56^2"], per))}
+    # ---- launch trace of one step: per-kernel durations, dominant kernel, roofline ----
+    try:
+        from ctypes import byref, c_float, create_string_buffer
+        from deformablelka_amd import _lib as L
+        lib = L.get_lib()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        try:
+            torch.cuda._sleep(int(60e6))
+        except Exception:
+            pass
+        L.check(lib.dlka_trace_start(8192, st), "trace_start")
+        try:
+            for i, (m, x, gy) in enumerate(zip(mods, xs, gys)):
+                L.check(lib.dlka_trace_mark(st), "trace_mark")
+                m(x).backward(gy)
+        finally:
+            rc = lib.dlka_trace_stop()
+        L.check(rc, "trace_stop")
+        buf, ms, acc, blk, total = create_string_buffer(512), c_float(), {}, -1, 0.0
+        for i in range(lib.dlka_trace_count()):
+            L.check(lib.dlka_trace_get(i, buf, 512, byref(ms)), "trace_get")
+            name = buf.value.decode()
+            if name == "(mark)":
+                blk += 1
+                continue
+            a = acc.setdefault((blk // 2, short_kernel(name)), [0, 0.0])
+            a[0] += 1
+            a[1] += ms.value
+            total += ms.value
+        rows = sorted(((v[1], k, v[0]) for k, v in acc.items()), reverse=True)
+        dbytes = 2 if dtype == torch.bfloat16 else 4
+        kern = []
+        for tot, (si, name), cnt in rows[:10]:
+            kern.append({"kernel": name, "shape": "C=%d,%dx%d" % (shapes[si][0], shapes[si][1], shapes[si][1]), "launches_per_step": cnt,
+                         "avg_us": round(tot / cnt * 1e3, 2), "step_share": round(tot / total, 4)})
+        tot, (si, name), cnt = rows[0]
+        C, n = shapes[si]
+        M, E = 24 * n * n, 24 * C * n * n
+        t = tot / cnt * 1e-3
+        # algorithmic work of the dominant kernel's operator: offset nets 2*K*C*2K flops per pixel, in E + offsets out;
+        # depthwise deformable conv K taps x (7 flops blend + 2 MAC) per channel, x / offsets in, out
+        if "igemm" in name or "conv_wave" in name or "wgrad_dense" in name:
+            big = True   # the 7x7 net dominates where both exist under one name; report the mean over the launches it aggregates
+            fl = 2 * C * M * (25 * 50 + 49 * 98) / 2
+            by = E * dbytes + M * (50 + 98) / 2 * 4
+        elif "ddw2d" in name:
+            fl = M * C * (25 + 49) / 2 * 9
+            by = 2 * E * dbytes + M * (50 + 98) / 2 * 4
+        else:
+            fl, by = 2 * C * E, 2 * E * dbytes
+        ridge = PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+        if by and fl / by > ridge:
+            ach, peak, unit, bound = fl / t / 1e12, PEAK_F32_TFLOPS, "TFLOP/s", "mfma"
+        else:
+            ach, peak, unit, bound = by / t / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+        out["roofline"] = {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5), "traffic": None,
+                           "kernel": name, "kernel_us": round(t * 1e6, 2), "shape": "C=%d,%dx%d,B=24" % (C, n, n), "algorithmic_flops": fl,
+                           "algorithmic_bytes": by, "method": "library launch trace (HIP events behind every launch), one eager step",
+                           "kernels": kern}
+    except Exception as e:
+        log("lka2d launch trace failed:", repr(e))
+    if with_cpu:
+        try:
+            out["cpu_baseline"] = lka2d_cpu_baseline()
+        except Exception as e:
+            log("lka2d cpu baseline failed:", repr(e))
+    return out
+
+
+def lka2d_cpu_baseline(budget_s=25.0):
+    """BASELINE.md §3 "2D companion": the oracle 2-D block (ATen CPU convs for the offset nets / projections = the reference's own CPU path for
+    nn.Conv2d, the C restatement of torchvision's deform_conv2d for the deformable convs, autograd backward) fwd+bwd at B=24 on the three decoder
+    shapes, all host threads; bounded — repetitions actually run are reported."""
+    import statistics
+    import oracle
+    from oracle import blocks
+    import deformablelka_amd as dk
+    from deformablelka_amd.init_utils import randomize_offset_nets
+    oracle.build()
+    cores = torch.get_num_threads()
+    per, reps = [], []
+    t_start = time.perf_counter()
+    for C, n in [(384, 14), (192, 28), (96, 56)]:
+        torch.manual_seed(0)
+        m = dk.deformable_LKA_Attention(C)
+        randomize_offset_nets(m, 0.02)
+        P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+        x, gy = torch.randn(24, C, n, n, requires_grad=True), torch.randn(24, C, n, n)
+
+        def once():
+            t0 = time.perf_counter()
+            blocks.lka2d_attention(x, P).backward(gy)
+            return time.perf_counter() - t0
+        once()
+        ts = []
+        while len(ts) < 5 and (len(ts) < 1 or time.perf_counter() - t_start < budget_s * (len(per) + 1) / 3):
+            ts.append(once())
+        per.append(statistics.median(ts))
+        reps.append(len(ts))
+    total = 2 * sum(per)
+    return {"value": round(24 / total, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle 2-D D-LKA block fwd+bwd at B=24, fp32, one block of each of the 3 decoder shapes timed (1 warm-up, {reps} timed, median), "
+                      f"step = 2 blocks per shape; bounded to ~{budget_s:.0f} s (BASELINE.md §3 asks 3 + 10)",
+            "per_block_s": [round(t, 4) for t in per], "wall_s": round(time.perf_counter() - t_start, 1)}
 
 
 def inference_metric(dev):
@@ -433,6 +540,32 @@ def inference_metric(dev):
     assert lab.shape == vol.shape and bool(torch.isfinite(score).all())
     return {"metric": "3D D-LKA Former sliding-window inference tiles/sec (96^3 tiles, stride 16, 240x240x160 volume resident in HBM)",
             "value": round(n / dt, 2), "unit": "tiles/s", "tiles": n, "seconds_per_volume": round(dt, 2), "tile_batch": 4}
+
+
+def inference_config5_metric(dev):
+    """BASELINE.json config 5 AS WRITTEN: "40x224x224 tiles".  Such a tile only divides through the ACDC net's stem (1,4,4)
+    (acdc/model_components.py:21) -> per-tile stage shapes 40x56x56 / 20x28x28 / 10x14x14 / 5x7x7 at C = 32 / 64 / 128 / 256, with the ACDC variant's
+    anisotropic depthwise kernels (acdc/transformerblock.py:213-237) — deformablelka_amd.acdc on the fused kernels.  Synthetic stand-in volume
+    (the dataset is not in the reference): 80 x 448 x 448 = 3 x 3 x 3 = 27 tiles at nnU-Net's step 0.5 with Gaussian blending
+    (neural_network.py:292-428), the padded volume, score map and weights resident in HBM; tiles/s, forward only."""
+    from deformablelka_amd import acdc, inference, training
+    torch.manual_seed(0)
+    tile = (40, 224, 224)
+    net = training.initialize_network(1, 4, tile, device=dev, patch_size=(1, 4, 4), trans_block=acdc.TransformerBlock_3D_single_deform_LKA).eval()
+    net.do_ds = False
+    vol = torch.randn(1, 80, 448, 448, device=dev)
+    inference.predict_3d_tiled(net, vol[:, :40, :224, :336].contiguous(), tile, 0.5, True, num_classes=4, tile_batch=2)     # warm-up: 1 x 1 x 2 tiles
+    torch.cuda.synchronize()
+    steps_ = inference.compute_steps_for_sliding_window(tile, vol.shape[1:], 0.5)
+    n = len(steps_[0]) * len(steps_[1]) * len(steps_[2])
+    t0 = time.perf_counter()
+    seg, probs = inference.predict_3d_tiled(net, vol, tile, 0.5, True, num_classes=4, tile_batch=2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert seg.shape == vol.shape[1:] and bool(torch.isfinite(probs).all())
+    return {"metric": "3D D-LKA Former (ACDC variant, stem (1,4,4)) sliding-window inference tiles/sec (40x224x224 tiles, step 0.5, Gaussian blending, "
+                      "80x448x448 volume resident in HBM)", "value": round(n / dt, 2), "unit": "tiles/s", "tiles": n, "seconds_per_volume": round(dt, 2),
+            "tile_batch": 2, "stage_shapes": "40x56x56 / 20x28x28 / 10x14x14 / 5x7x7"}
 
 
 def companion_metric(batch, steps, warmup, dev, dtype, lr):
@@ -706,7 +839,9 @@ def main():
                 out["tblock"] = None
         if args.extras and world == 1:
             for key, fn in (("fullnet", lambda: fullnet_metric(args.batch, 5, dev, bf16=(dtype == torch.bfloat16))),
-                            ("lka2d", lambda: lka2d_metric(5, dev)), ("inference", lambda: inference_metric(dev))):
+                            ("lka2d", lambda: lka2d_metric(5, dev, torch.bfloat16, with_cpu=not args.no_cpu_baseline)),   # BASELINE.json config 2: bf16, B=24
+                            ("lka2d_f32", lambda: lka2d_metric(5, dev, torch.float32)), ("inference", lambda: inference_metric(dev)),
+                            ("inference_config5", lambda: inference_config5_metric(dev))):
                 if dtype == torch.bfloat16 and key != "fullnet":
                     continue
                 try:

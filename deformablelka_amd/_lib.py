@@ -19,6 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libdlka_hip.so")
 
 DLKA_F32, DLKA_BF16 = 0, 1
+LKA3D_SYNAPSE, LKA3D_ACDC = 0, 1   # dlka_lka3d_variant (include/dlka.h)
 
 
 class ConvGeom(ctypes.Structure):
@@ -90,6 +91,7 @@ SIGNATURES = {
                                      + [c_int] * 5 + [c_void_p]),
     "dlka_lka2d_attention_backward": (c_int, [c_void_p, POINTER(Lka2dPtrs), c_void_p, c_void_p, c_size_t, c_void_p,
                                               POINTER(Lka2dPtrs), c_void_p, c_size_t] + [c_int] * 5 + [c_void_p]),
+    "dlka_lka2d_force_general": (c_int, [c_int]),
     "dlka_conv3d_cl_workspace": (c_size_t, [_G, c_int, c_int]),
     "dlka_conv3d_forward_cl": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_size_t, _G, c_int, c_void_p]),
     "dlka_conv3d_backward_cl": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 4 + [c_size_t, _G, c_int, c_void_p]),
@@ -128,6 +130,20 @@ SIGNATURES = {
     "dlka_deform_dwconv2d_cl_workspace": (c_size_t, [_G, c_int, c_int]),
     "dlka_deform_dwconv2d_forward_cl": (c_int, [c_void_p] * 5 + [c_size_t, _G, c_int, c_void_p]),
     "dlka_deform_dwconv2d_backward_cl": (c_int, [c_void_p] * 8 + [c_size_t, _G, c_int, c_void_p]),
+    "dlka_lka3d_tokens_supported_v": (c_int, [c_int] * 7),
+    "dlka_lka3d_tokens_saved_bytes_v": (c_size_t, [c_int] * 7),
+    "dlka_lka3d_tokens_workspace_bytes_v": (c_size_t, [c_int] * 7),
+    "dlka_lka3d_attention_tokens_forward_v": (c_int, [c_void_p, POINTER(Lka3dPtrs), c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]
+                                              + [c_int] * 7 + [c_void_p]),
+    "dlka_lka3d_attention_tokens_backward_v": (c_int, [c_void_p, POINTER(Lka3dPtrs), c_void_p, c_void_p, c_size_t, c_void_p,
+                                                       POINTER(Lka3dPtrs), c_void_p, c_size_t] + [c_int] * 7 + [c_void_p]),
+    "dlka_tblock3d_supported_v": (c_int, [c_int] * 7),
+    "dlka_tblock3d_saved_bytes_v": (c_size_t, [c_int] * 7),
+    "dlka_tblock3d_workspace_bytes_v": (c_size_t, [c_int] * 7),
+    "dlka_tblock3d_forward_v": (c_int, [c_void_p, c_int, POINTER(TBlock3dPtrs), POINTER(Lka3dPtrs), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                                        c_void_p, c_size_t] + [c_int] * 5 + [ctypes.c_float, ctypes.c_float, c_int, c_int, c_void_p]),
+    "dlka_tblock3d_backward_v": (c_int, [POINTER(TBlock3dPtrs), POINTER(Lka3dPtrs), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                         POINTER(TBlock3dPtrs), POINTER(Lka3dPtrs), c_void_p, c_size_t] + [c_int] * 7 + [c_void_p]),
     "dlka_trace_start": (c_int, [c_int, c_void_p]),
     "dlka_trace_mark": (c_int, [c_void_p]),
     "dlka_trace_stop": (c_int, []),

@@ -108,11 +108,13 @@ struct DwArgs2d {
     const float *off;    // [B][2 kh kw][H][W] planar (dy, dx) per tap
     const float *wp;     // [kh kw][C] prepared tap weights (launch_cl_dw_prep_weight, unflipped)
     const float *g;      // [B][H][W][C] grad_out
-    float *out;          // [B][H][W][C]
-    float *gx;           // [B][H][W][C], zero-filled by the caller
+    float *out;          // [B][H][W][C]  (forward; may be null when only out_lo is wanted)
+    float *out_lo;       // forward, optional: the result rounded to bf16, [B][H][W][C] bf16 (the mixed-precision DLKA_BF16 2-D block)
+    float *gx;           // [B][H][W][C] fp32, zero-filled by the caller
     float *goff;         // [B][2 kh kw][H][W]
     float *part;         // cl_ddw2d_part_floats() floats of weight-gradient partials
     int B, H, W, C, kh, kw, ph, pw, dh, dw;
+    int act_bf16;        // backward: in / g are bf16 storage (gx, goff, the weight-gradient partials stay fp32); the forward kernel is fp32-in only
 };
 
 struct DwWgradArgs {

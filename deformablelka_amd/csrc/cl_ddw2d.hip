@@ -33,7 +33,8 @@ struct Ddw2dArgs {
     const float *off;    // [B][2K][N] planar (dy, dx) per tap
     const float *wp;     // [K][C] prepared tap weights
     const float *g;      // [B][N][C] grad_out (backward)
-    float *out;          // forward: [B][N][C]
+    float *out;          // forward: [B][N][C] (may be null)
+    float *out_lo;       // forward: optional bf16 copy [B][N][C]
     float *gx;           // backward: [B][N][C], ZERO-FILLED by the caller (atomics)
     float *goff;         // backward: [B][2K][N]
     float *part;         // backward: [nblocks][K][C] weight-gradient partials
@@ -80,20 +81,28 @@ __global__ __launch_bounds__(256) void cl_ddw2d_fwd_kernel(Ddw2dArgs p)
         }
     }
     if (!ok) return;
+    if (p.out) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) *reinterpret_cast<f32x4 *>(p.out + (long)m * p.C + c0 + 32 * c) = acc[c];
+        for (int c = 0; c < NCH; ++c) *reinterpret_cast<f32x4 *>(p.out + (long)m * p.C + c0 + 32 * c) = acc[c];
+    }
+    if (p.out_lo) {   // uniform
+        bf16_t *lo = reinterpret_cast<bf16_t *>(p.out_lo);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) act_store4(lo, (long)m * p.C + c0 + 32 * c, acc[c]);
+    }
 }
 
 // grid (ceil(M / px_per_block)); block 256 = 4 waves; a wave walks its share of the block's pixels 8 at a time, for ONE tap at a time
 // (tap-outer), all NCH chunks of the row per (pixel, tap).
-template <int NCH>
+template <int NCH, typename T>   // T: storage of `in` and `g` (float | bf16_t); arithmetic, grad_offset and the weight-gradient partials are fp32
 __global__ __launch_bounds__(256) void cl_ddw2d_bwd_kernel(Ddw2dArgs p)
 {
+    constexpr unsigned SB = sizeof(T);
     __shared__ float red[4][NCH * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane >> 3, pp = lane & 7;
-    const int rowbytes = p.C * 4;
-    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.C * 4), rg = make_rsrc(p.g, (size_t)p.M * p.C * 4), rw = make_rsrc(p.wp, (size_t)p.K * p.C * 4);
+    const int rowbytes = p.C * SB;
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.C * SB), rg = make_rsrc(p.g, (size_t)p.M * p.C * SB), rw = make_rsrc(p.wp, (size_t)p.K * p.C * 4);
     const int m_lo = blockIdx.x * p.px_per_block, m_hi = min(p.M, m_lo + p.px_per_block);
     for (int tap = 0; tap < p.K; ++tap) {
         const int ti = tap / p.kw, tj = tap - ti * p.kw;
@@ -120,11 +129,11 @@ __global__ __launch_bounds__(256) void cl_ddw2d_bwd_kernel(Ddw2dArgs p)
             const unsigned gb = ok ? (unsigned)m * (unsigned)rowbytes : DLKA_OOB;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                const unsigned cb = (unsigned)(32 * c + 4 * pp) * 4u;
+                const unsigned cb = (unsigned)(32 * c + 4 * pp) * SB;
                 f32x4 x4[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) x4[q] = buf_load_f32x4(rin, s.off[q] == DLKA_OOB ? DLKA_OOB : s.off[q] + cb);
-                const f32x4 g4 = buf_load_f32x4(rg, gb == DLKA_OOB ? DLKA_OOB : gb + cb);
+                for (int q = 0; q < 4; ++q) x4[q] = act_buf_load4<T>(rin, s.off[q] == DLKA_OOB ? DLKA_OOB : s.off[q] + cb);
+                const f32x4 g4 = act_buf_load4<T>(rg, gb == DLKA_OOB ? DLKA_OOB : gb + cb);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float sv = s.wt[0] * x4[0][e];
@@ -178,9 +187,10 @@ __global__ __launch_bounds__(256) void cl_ddw2d_bwd_kernel(Ddw2dArgs p)
 constexpr int GX2_CS = 4;        // channels per slice
 constexpr int GX2_MARGIN = 3;    // offset margin of the window beyond the kernel reach
 
-template <int DUMMY>
+template <typename T>   // T: storage of grad_out `g`
 __global__ __launch_bounds__(256) void cl_ddw2d_gx_kernel(Ddw2dArgs p, int TH, int TW, int ntx, int nty, int reach_y, int reach_x)
 {
+    const T *gin = reinterpret_cast<const T *>(p.g);
     DLKA_DYN_SMEM(unsigned char, smem);
     const int tid = threadIdx.x, lane = tid & 63;
     int t = blockIdx.x;
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(256) void cl_ddw2d_gx_kernel(Ddw2dArgs p, int TH, i
         const int oy = oy0 + px / TW, ox = ox0 + px % TW;
         if (oy >= p.H || ox >= p.W) continue;
         const int n = oy * p.W + ox;
-        const f32x4 g4 = *reinterpret_cast<const f32x4 *>(p.g + ((long)b * p.N + n) * p.C + slice * GX2_CS);
+        const f32x4 g4 = act_load4(gin, ((long)b * p.N + n) * p.C + slice * GX2_CS);
         const float *offp = p.off + (long)b * 2 * p.K * p.N + n;
         for (int tap = 0; tap < p.K; ++tap) {
             const int ti = tap / p.kw, tj = tap - ti * p.kw;
@@ -281,7 +291,7 @@ size_t cl_ddw2d_part_floats(int M, int K, int C) { return (size_t)cdiv(M, cl_ddw
 static void fill_ddw(Ddw2dArgs &a, const DwArgs2d &d)
 {
     memset(&a, 0, sizeof(a));
-    a.in = d.in; a.off = d.off; a.wp = d.wp; a.g = d.g; a.out = d.out; a.gx = d.gx; a.goff = d.goff; a.part = d.part;
+    a.in = d.in; a.off = d.off; a.wp = d.wp; a.g = d.g; a.out = d.out; a.out_lo = d.out_lo; a.gx = d.gx; a.goff = d.goff; a.part = d.part;
     a.B = d.B; a.H = d.H; a.W = d.W; a.N = d.H * d.W; a.M = d.B * d.H * d.W; a.C = d.C; a.K = d.kh * d.kw; a.kh = d.kh; a.kw = d.kw;
     a.ph = d.ph; a.pw = d.pw; a.dh = d.dh; a.dw = d.dw;
 }
@@ -293,6 +303,7 @@ int launch_cl_ddw2d_fwd(const DwArgs2d &d, hipStream_t st)
     Ddw2dArgs a;
     fill_ddw(a, d);
     if ((long)a.M * a.C * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+    if (d.act_bf16 || (!d.out && !d.out_lo)) return DLKA_ERR_UNSUPPORTED;  // (fp32 input only: the DLKA_BF16 block feeds it its fp32 chain tensors)
     const int mblocks = cdiv(a.M, 32);
     // few pixels (14^2 stages): split the channel chunks over gridDim.y so that the chip still fills
     int per = nch;
@@ -320,7 +331,8 @@ int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st)
     a.px_per_block = cl_ddw2d_bwd_px_per_block(a.M);
     const int nblocks = cdiv(a.M, a.px_per_block);
     dim3 grid(nblocks), block(256);
-#define DLKA_DDW_B(N_) case N_: { auto k = cl_ddw2d_bwd_kernel<N_>; DLKA_LAUNCH(k, grid, block, 0, st, a); } break;
+#define DLKA_DDW_B(N_) case N_: { if (d.act_bf16) { auto k = cl_ddw2d_bwd_kernel<N_, bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, a); }   \
+                                  else { auto k = cl_ddw2d_bwd_kernel<N_, float>; DLKA_LAUNCH(k, grid, block, 0, st, a); } } break;
     switch (nch) {
         DLKA_DDW_B(1) DLKA_DDW_B(2) DLKA_DDW_B(3) DLKA_DDW_B(4) DLKA_DDW_B(6) DLKA_DDW_B(8) DLKA_DDW_B(12)
         default: return DLKA_ERR_UNSUPPORTED;
@@ -351,15 +363,16 @@ int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st)
         if (hipGetDevice(&dev) != hipSuccess) return DLKA_ERR_LAUNCH;
         const uint64_t bit = 1ull << (dev & 63);
         if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(cl_ddw2d_gx_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(cl_ddw2d_gx_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(cl_ddw2d_gx_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return DLKA_ERR_LAUNCH;
             attr_done.fetch_or(bit, std::memory_order_release);
         }
 #endif
         const int ntx = cdiv(a.W, TW), nty = cdiv(a.H, TH);
         dim3 ggrid(a.B * nty * ntx, a.C / GX2_CS);
-        auto k = cl_ddw2d_gx_kernel<0>;
-        DLKA_LAUNCH(k, ggrid, dim3(256), lds, st, a, TH, TW, ntx, nty, reach_y, reach_x);
+        if (d.act_bf16) { auto k = cl_ddw2d_gx_kernel<bf16_t>; DLKA_LAUNCH(k, ggrid, dim3(256), lds, st, a, TH, TW, ntx, nty, reach_y, reach_x); }
+        else { auto k = cl_ddw2d_gx_kernel<float>; DLKA_LAUNCH(k, ggrid, dim3(256), lds, st, a, TH, TW, ntx, nty, reach_y, reach_x); }
         DLKA_CHECK_LAUNCH();
     }
     return DLKA_OK;

@@ -621,35 +621,42 @@ template int launch_cl_dw_unprep<float>(const float *, float *, int, int, hipStr
 // layout changes between the reference's planar NCDHW and channels-last (used by the *_ndhwc test entry points and by
 // LKA_Attention3d_deform.forward_volume; the token entry point needs none).
 // ---------------------------------------------------------------------------------------------
-template <int TO_CL>
-__global__ __launch_bounds__(256) void cl_transpose_kernel(const float *__restrict__ src, float *__restrict__ dst, int C, int N)
+template <int TO_CL, typename T>
+__global__ __launch_bounds__(256) void cl_transpose_kernel(const T *__restrict__ src, T *__restrict__ dst, int C, int N)
 {
     // tile 32 (voxels) x 32 (channels) through LDS; grid = (ceil(N/32), ceil(C/32), B)
     __shared__ float tile[32][33];
     const int b = blockIdx.z, n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    const float *s = src + (long)b * C * N;
-    float *d = dst + (long)b * C * N;
+    const T *s = src + (long)b * C * N;
+    T *d = dst + (long)b * C * N;
     if (TO_CL) {  // src [C][N] -> dst [N][C]
         for (int r = ty; r < 32; r += 8)
-            if (c0 + r < C && n0 + tx < N) tile[r][tx] = s[(long)(c0 + r) * N + n0 + tx];
+            if (c0 + r < C && n0 + tx < N) tile[r][tx] = act_load1(s, (long)(c0 + r) * N + n0 + tx);
         __syncthreads();
         for (int r = ty; r < 32; r += 8)
-            if (n0 + r < N && c0 + tx < C) d[(long)(n0 + r) * C + c0 + tx] = tile[tx][r];
+            if (n0 + r < N && c0 + tx < C) act_store1(d, (long)(n0 + r) * C + c0 + tx, tile[tx][r]);
     } else {      // src [N][C] -> dst [C][N]
         for (int r = ty; r < 32; r += 8)
-            if (n0 + r < N && c0 + tx < C) tile[r][tx] = s[(long)(n0 + r) * C + c0 + tx];
+            if (n0 + r < N && c0 + tx < C) tile[r][tx] = act_load1(s, (long)(n0 + r) * C + c0 + tx);
         __syncthreads();
         for (int r = ty; r < 32; r += 8)
-            if (c0 + r < C && n0 + tx < N) d[(long)(c0 + r) * N + n0 + tx] = tile[tx][r];
+            if (c0 + r < C && n0 + tx < N) act_store1(d, (long)(c0 + r) * N + n0 + tx, tile[tx][r]);
     }
 }
 
-int launch_cl_transpose(const float *src, float *dst, int B, int C, int N, int to_cl, hipStream_t st)
+// bf16 = 1: src / dst are bf16 storage (the values pass through unchanged)
+int launch_cl_transpose(const float *src, float *dst, int B, int C, int N, int to_cl, hipStream_t st, int bf16)
 {
     dim3 grid(cdiv(N, 32), cdiv(C, 32), B), block(256);
-    if (to_cl) { auto k = cl_transpose_kernel<1>; DLKA_LAUNCH(k, grid, block, 0, st, src, dst, C, N); }
-    else { auto k = cl_transpose_kernel<0>; DLKA_LAUNCH(k, grid, block, 0, st, src, dst, C, N); }
+    if (bf16) {
+        const bf16_t *s16 = reinterpret_cast<const bf16_t *>(src);
+        bf16_t *d16 = reinterpret_cast<bf16_t *>(dst);
+        if (to_cl) { auto k = cl_transpose_kernel<1, bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, s16, d16, C, N); }
+        else { auto k = cl_transpose_kernel<0, bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, s16, d16, C, N); }
+    }
+    else if (to_cl) { auto k = cl_transpose_kernel<1, float>; DLKA_LAUNCH(k, grid, block, 0, st, src, dst, C, N); }
+    else { auto k = cl_transpose_kernel<0, float>; DLKA_LAUNCH(k, grid, block, 0, st, src, dst, C, N); }
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }

@@ -1,6 +1,8 @@
 // C-ABI entry points of libdlka_hip.so (declared in include/dlka.h): argument validation that mirrors the
 // reference's AT_ASSERTM checks (3D/dcn/src/cuda/deform_conv_cuda.cu:41-76,193-200), workspace carving and the
 // launch sequences.  No allocation, no synchronisation: every function is legal inside hipGraph capture.
+#include <algorithm>
+
 #include "dlka_kernels.h"
 
 using namespace dlka;
@@ -719,21 +721,39 @@ int dlka_lka3d_attention_backward(const void *x, const dlka_lka3d_params *p, con
                          lka3d_backward_t<bf16_t>(x, p, grad_y, saved, saved_bytes, grad_x, grads, workspace, workspace_bytes, B, C, D, H, W, dtype, st));
 }
 
+// Which path a 2-D block call takes: the channels-last fast path wherever the width allows, unless the general NCHW kernels are forced.  ONE
+// process-wide switch (initialised once from DLKA_LKA2D_GENERAL, changed only through dlka_lka2d_force_general), read by the size queries, the
+// forward and the backward call alike — so a forward / backward pair and their buffer sizes cannot disagree because the environment changed in
+// between.  Buffer sizes are the maximum over both paths: a switch between two calls never under-sizes a buffer.
+static int g_lka2d_general = -1;
+static bool lka2d_general()
+{
+    if (g_lka2d_general < 0) g_lka2d_general = getenv("DLKA_LKA2D_GENERAL") != nullptr ? 1 : 0;
+    return g_lka2d_general != 0;
+}
+int dlka_lka2d_force_general(int on)
+{
+    const int old = lka2d_general() ? 1 : 0;
+    g_lka2d_general = on ? 1 : 0;
+    return old;
+}
+
 size_t dlka_lka2d_saved_bytes(int B, int C, int H, int W, int dtype)
 {
     if (check_block(B, C, 1, H, W)) return 0;
-    if (lka2d_cl_supported(B, C, H, W, dtype)) return lka2d_cl_saved_bytes(B, C, H, W);   // channels-last fast path (dlka_capi_cl.hip)
     Lka2dGeoms G(B, C, H, W);
-    return 5 * align256(G.E * esz(dtype)) + align256(G.Off5 * esz(dtype)) + align256(G.Off7 * esz(dtype));
+    size_t n = 5 * align256(G.E * esz(dtype)) + align256(G.Off5 * esz(dtype)) + align256(G.Off7 * esz(dtype));
+    if (lka2d_cl_supported(B, C, H, W, dtype)) n = std::max(n, lka2d_cl_saved_bytes(B, C, H, W, dtype));   // channels-last fast path (dlka_capi_cl.hip)
+    return n;
 }
 
 size_t dlka_lka2d_workspace_bytes(int B, int C, int H, int W, int dtype)
 {
     if (check_block(B, C, 1, H, W)) return 0;
-    if (lka2d_cl_supported(B, C, H, W, dtype)) return lka2d_cl_workspace_bytes(B, C, H, W);
     Lka2dGeoms G(B, C, H, W);
     size_t n = align256(G.scratch_floats() * 4) + 4 * align256(G.E * esz(dtype)) + align256(G.Off7 * esz(dtype));
     if (dtype != DLKA_F32) n += align256(G.max_weight_elems() * 4) + align256(G.E * 4);
+    if (lka2d_cl_supported(B, C, H, W, dtype)) n = std::max(n, lka2d_cl_workspace_bytes(B, C, H, W, dtype));
     return n;
 }
 
@@ -745,10 +765,10 @@ int dlka_lka2d_attention_forward(const void *x, const dlka_lka2d_params *p, void
     for (size_t i = 0; i < sizeof(*p) / sizeof(void *); ++i) if (!pp[i]) return DLKA_ERR_NULL;
     DLKA_TRY(check_block(B, C, 1, H, W));
     hipStream_t st = (hipStream_t)stream;
-    // channels-last fast path (MFMA offset nets, gather-layout depthwise deformable convs) wherever the width allows; DLKA_LKA2D_GENERAL=1
-    // forces the general NCHW kernels (A/B runs and the parity test of one path against the other)
-    if (lka2d_cl_supported(B, C, H, W, dtype) && !getenv("DLKA_LKA2D_GENERAL"))
-        return lka2d_cl_forward(x, p, y, saved, saved_bytes, workspace, workspace_bytes, B, C, H, W, st);
+    // channels-last fast path (MFMA offset nets, gather-layout depthwise deformable convs) wherever the width allows
+    if (lka2d_cl_supported(B, C, H, W, dtype) && !lka2d_general())
+        return lka2d_cl_forward(x, p, y, saved, saved_bytes, workspace, workspace_bytes, B, C, H, W, dtype, st);
+    if (dtype == DLKA_BF16) return DLKA_ERR_UNSUPPORTED;   // DLKA_BF16 = bf16 activations with FP32 parameters: the channels-last path only
     return DLKA_DISPATCH(dtype, lka2d_forward_t<float>(x, p, y, saved, saved_bytes, workspace, workspace_bytes, B, C, H, W, st),
                          lka2d_forward_t<bf16_t>(x, p, y, saved, saved_bytes, workspace, workspace_bytes, B, C, H, W, st));
 }
@@ -764,8 +784,9 @@ int dlka_lka2d_attention_backward(const void *x, const dlka_lka2d_params *p, con
     for (size_t i = 0; i < sizeof(*grads) / sizeof(void *); ++i) if (!gp[i]) return DLKA_ERR_NULL;
     DLKA_TRY(check_block(B, C, 1, H, W));
     hipStream_t st = (hipStream_t)stream;
-    if (lka2d_cl_supported(B, C, H, W, dtype) && !getenv("DLKA_LKA2D_GENERAL"))
-        return lka2d_cl_backward(x, p, grad_y, saved, saved_bytes, grad_x, grads, workspace, workspace_bytes, B, C, H, W, st);
+    if (lka2d_cl_supported(B, C, H, W, dtype) && !lka2d_general())
+        return lka2d_cl_backward(x, p, grad_y, saved, saved_bytes, grad_x, grads, workspace, workspace_bytes, B, C, H, W, dtype, st);
+    if (dtype == DLKA_BF16) return DLKA_ERR_UNSUPPORTED;
     return DLKA_DISPATCH(dtype,
                          lka2d_backward_t<float>(x, p, grad_y, saved, saved_bytes, grad_x, grads, workspace, workspace_bytes, B, C, H, W, dtype, st),
                          lka2d_backward_t<bf16_t>(x, p, grad_y, saved, saved_bytes, grad_x, grads, workspace, workspace_bytes, B, C, H, W, dtype, st));

@@ -339,22 +339,53 @@ SameConv block_conv(int B, int C, int Cout, int D, int H, int W, int k, int pad,
 // 5e-2 .. 1.8e-1 from the fp32 block's (measured round 2; reproduced on the CPU by oracle.blocks with per-tensor storage flags:
 // storing ONLY t in fp32 does not help — 1.1e-1 —, the whole chain does — 3e-3).  The dw convs also write the bf16 copies of t1 / t that the
 // gathers and the backward pass read: the sampled VALUES and every gradient are smooth in those, 2^-9 rounding is inside the 2e-2 contract.
+// The depthwise pair conv0 / conv_spatial of LKA3d_deform by net variant (include/dlka.h: dlka_lka3d_variant) and width:
+//   SYNAPSE (synapse/transformerblock.py:637-638; also the pancreas copy): 5^3 pad 2, then 7^3 dilation 3 pad 9 at every width
+//   ACDC (acdc/transformerblock.py:213-237): C <= 64: 5^3 pad 2, (5,7,7) dilation 3 pad (6,9,9); C = 128: 5^3 pad 2, (3,5,5) dilation (1,3,3)
+//         pad (1,6,6); C = 256: 3^3 pad 1, 3^3 pad 1
+// (kernel / pad / dilation triples are in the tensor's axis order: the reference's "H, W, D" = this file's D, H, W)
+struct DwPairCfg { int k0[3], p0[3], d0[3], k1[3], p1[3], d1[3]; };
+static bool dw_pair_cfg(int variant, int C, DwPairCfg &c)
+{
+    auto set = [](int *dst, int a, int b, int cc) { dst[0] = a; dst[1] = b; dst[2] = cc; };
+    if (variant == DLKA_LKA3D_SYNAPSE) {
+        set(c.k0, 5, 5, 5); set(c.p0, 2, 2, 2); set(c.d0, 1, 1, 1); set(c.k1, 7, 7, 7); set(c.p1, 9, 9, 9); set(c.d1, 3, 3, 3);
+        return true;
+    }
+    if (variant != DLKA_LKA3D_ACDC) return false;
+    if (C == 32 || C == 64) { set(c.k0, 5, 5, 5); set(c.p0, 2, 2, 2); set(c.d0, 1, 1, 1); set(c.k1, 5, 7, 7); set(c.p1, 6, 9, 9); set(c.d1, 3, 3, 3); }
+    else if (C == 128) { set(c.k0, 5, 5, 5); set(c.p0, 2, 2, 2); set(c.d0, 1, 1, 1); set(c.k1, 3, 5, 5); set(c.p1, 1, 6, 6); set(c.d1, 1, 3, 3); }
+    else if (C == 256) { set(c.k0, 3, 3, 3); set(c.p0, 1, 1, 1); set(c.d0, 1, 1, 1); set(c.k1, 3, 3, 3); set(c.p1, 1, 1, 1); set(c.d1, 1, 1, 1); }
+    else return false;
+    return true;
+}
+static SameConv dw_conv(int B, int C, int D, int H, int W, const int *k, const int *p, const int *d, int act_bf16)
+{
+    SameConv s;
+    s.act_bf16 = act_bf16;
+    s.B = B; s.D = D; s.H = H; s.W = W; s.N = D * H * W; s.M = B * s.N; s.Cin = C; s.Cout = C; s.group = C;
+    s.kd = k[0]; s.kh = k[1]; s.kw = k[2]; s.pd = p[0]; s.ph = p[1]; s.pw = p[2]; s.dd = d[0]; s.dh = d[1]; s.dw = d[2]; s.K = k[0] * k[1] * k[2];
+    return s;
+}
+
 struct TokGeoms {
-    SameConv pw, dw5, dw7, offc, dcn;
+    SameConv pw, dw5, dw7, offc, dcn;   // (dw5 / dw7: conv0 / conv_spatial, whatever their kernels are in the variant)
     SameConv dw5_f, dw7_f, offc_f;   // the forward chain's geometries: == dw5 / dw7 / offc on the fp32 path, their fp32-storage twins on DLKA_BF16
     size_t E, Off, GOff;   // GOff: the backward's internal grad_offset buffer, 96 channel planes per batch (packed layout, DeformBwdArgs::goff_cpad)
     size_t SB;             // bytes per activation element (4, or 2 on the DLKA_BF16 path)
-    TokGeoms(int B, int C, int D, int H, int W, int dtype = DLKA_F32)
+    TokGeoms(int B, int C, int D, int H, int W, int dtype = DLKA_F32, int variant = DLKA_LKA3D_SYNAPSE)
     {
         const int bf = dtype == DLKA_BF16 ? 1 : 0;
         SB = bf ? 2 : 4;
+        DwPairCfg dc;
+        if (!dw_pair_cfg(variant, C, dc)) dw_pair_cfg(DLKA_LKA3D_SYNAPSE, C, dc);   // (callers check the variant with tokens_supported first)
         pw = block_conv(B, C, C, D, H, W, 1, 0, 1, 1, bf);
-        dw5 = block_conv(B, C, C, D, H, W, 5, 2, 1, C, bf);
-        dw7 = block_conv(B, C, C, D, H, W, 7, 9, 3, C, bf);
+        dw5 = dw_conv(B, C, D, H, W, dc.k0, dc.p0, dc.d0, bf);
+        dw7 = dw_conv(B, C, D, H, W, dc.k1, dc.p1, dc.d1, bf);
         offc = block_conv(B, C, 81, D, H, W, 3, 1, 1, 1, bf);
         dcn = block_conv(B, C, C, D, H, W, 3, 1, 1, 1, bf);
-        dw5_f = block_conv(B, C, C, D, H, W, 5, 2, 1, C, 0);
-        dw7_f = block_conv(B, C, C, D, H, W, 7, 9, 3, C, 0);
+        dw5_f = dw_conv(B, C, D, H, W, dc.k0, dc.p0, dc.d0, 0);
+        dw7_f = dw_conv(B, C, D, H, W, dc.k1, dc.p1, dc.d1, 0);
         offc_f = block_conv(B, C, 81, D, H, W, 3, 1, 1, 1, 0);
         E = (size_t)B * C * D * H * W;
         Off = (size_t)B * 81 * D * H * W;
@@ -364,7 +395,7 @@ struct TokGeoms {
     {
         size_t m = dense_wp_floats(offc);
         if (dense_wp_floats(dcn) > m) m = dense_wp_floats(dcn);
-        if ((size_t)343 * dw7.Cin > m) m = (size_t)343 * dw7.Cin;
+        if ((size_t)dw7.K * dw7.Cin > m) m = (size_t)dw7.K * dw7.Cin;
         return m;
     }
     size_t scratch_floats() const { return deform_scratch_floats(dcn); }
@@ -379,14 +410,14 @@ struct TokGeoms {
     size_t pw_floats() const { return (size_t)pw.Cin * pw.Cin; }
     size_t offc_floats() const { return dense_wp_floats(offc); }
     size_t dcn_floats() const { return dense_wp_floats(dcn); }
-    size_t dw5_floats() const { return (size_t)125 * dw5.Cin; }
-    size_t dw7_floats() const { return (size_t)343 * dw7.Cin; }
+    size_t dw5_floats() const { return (size_t)dw5.K * dw5.Cin; }
+    size_t dw7_floats() const { return (size_t)dw7.K * dw7.Cin; }
     size_t prep_floats() const { return 6 * pw_floats() + 2 * offc_floats() + 2 * dcn_floats() + 2 * dw5_floats() + 2 * dw7_floats() + 16 * 64; }
     // weight-gradient partials: every gradient of the block has its own area (folded by one fused launch at the end)
     size_t part_pw() const { return (cl_wgrad_part_floats_mode(pw.M, 1, pw.Cin, pw.Cin, 0) + 63) & ~(size_t)63; }
     size_t part_off() const { return (cl_wgrad_part_floats_mode(pw.M, 27, 81, pw.Cin, 0) + 63) & ~(size_t)63; }
     size_t part_dcn() const { return (cl_wgrad_part_floats_mode(pw.M, 27, pw.Cin, pw.Cin, 1) + 63) & ~(size_t)63; }
-    size_t stage_dw() const { return (size_t)(125 + 1 + 343 + 1) * pw.Cin; }   // dw5 [126][C] then dw7 [344][C]
+    size_t stage_dw() const { return (size_t)(dw5.K + 1 + dw7.K + 1) * pw.Cin; }   // conv0 [K0 + 1][C] then conv_spatial [K1 + 1][C]
     size_t part_floats() const { return 3 * part_pw() + part_off() + part_dcn() + ((stage_dw() + 63) & ~(size_t)63); }
 };
 
@@ -427,10 +458,10 @@ int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_para
     add_job(pb, p->offset_w, t.off_b, 81, C, 27, 96, C, use_split(G.offc, false) ? 9 : 1);
     add_job(pb, p->deform_w, t.dcn_f, C, C, 27, C, C, 0);
     add_job(pb, p->deform_w, t.dcn_b, C, C, 27, C, C, 2);
-    add_job(pb, p->conv0_w, t.dw5_f, C, C, 125, 0, 0, 3);
-    add_job(pb, p->conv0_w, t.dw5_b, C, C, 125, 0, 0, 4);
-    add_job(pb, p->conv_spatial_w, t.dw7_f, C, C, 343, 0, 0, 3);
-    add_job(pb, p->conv_spatial_w, t.dw7_b, C, C, 343, 0, 0, 4);
+    add_job(pb, p->conv0_w, t.dw5_f, C, C, G.dw5.K, 0, 0, 3);
+    add_job(pb, p->conv0_w, t.dw5_b, C, C, G.dw5.K, 0, 0, 4);
+    add_job(pb, p->conv_spatial_w, t.dw7_f, C, C, G.dw7.K, 0, 0, 3);
+    add_job(pb, p->conv_spatial_w, t.dw7_b, C, C, G.dw7.K, 0, 0, 4);
     if (zb && pb.njobs + zb->n > PREP_MAX_JOBS) return DLKA_ERR_WORKSPACE;   // (a dropped zero fill would be a silent wrong answer)
     if (zb)   // the forward pass's zero fills ride along (one launch less per block)
         for (int r = 0; r < zb->n; ++r) {
@@ -468,12 +499,14 @@ SideCtx &side_ctx()
     return c;
 }
 
-bool tokens_supported(int B, int C, int D, int H, int W)
+bool tokens_supported(int B, int C, int D, int H, int W, int variant = DLKA_LKA3D_SYNAPSE)
 {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return false;
     if (!(C == 32 || C == 64 || C == 128 || C == 256)) return false;
     if ((long)B * D * H * W > (1l << 28)) return false;
-    return true;
+    DwPairCfg dc;
+    if (!dw_pair_cfg(variant, C, dc)) return false;
+    return dw_supported(dw_conv(B, C, D, H, W, dc.k0, dc.p0, dc.d0, 0)) && dw_supported(dw_conv(B, C, D, H, W, dc.k1, dc.p1, dc.d1, 0));
 }
 
 }  // namespace
@@ -492,24 +525,34 @@ namespace dlka {
 
 namespace {
 
-SameConv block_conv2d(int B, int C, int Cout, int H, int W, int k, int pad, int dil)
+SameConv block_conv2d(int B, int C, int Cout, int H, int W, int k, int pad, int dil, int act_bf16 = 0)
 {
     SameConv s;
-    s.act_bf16 = 0;
+    s.act_bf16 = act_bf16;
     s.B = B; s.D = 1; s.H = H; s.W = W; s.N = H * W; s.M = B * s.N; s.Cin = C; s.Cout = Cout; s.group = 1;
     s.kd = 1; s.kh = s.kw = k; s.pd = 0; s.ph = s.pw = pad; s.dd = 1; s.dh = s.dw = dil; s.K = k * k;
     return s;
 }
 
+// DLKA_BF16 (BASELINE.json config 2: "224x224 bf16 training, batch 24") is MIXED precision, like the 3-D block (TokGeoms): bf16 storage for x, y,
+// every saved activation and the intermediate gradients — except the chain that decides WHERE the two deformable convs sample:
+//     a = GELU(proj_1 x)  ->  o5 = offnet5(a)  ->  t1 = DDW5(a, o5)  ->  o7 = offnet7(t1)
+// runs on fp32 tensors (a32, t1_32: forward-only workspace) with the fp32 path's own kernels, so that both offset fields equal the fp32 block's to
+// fp32 rounding.  The bf16 copies of a / t1 (saved for the backward pass) ride in the producing kernels.
 struct Lka2dCl {
-    SameConv pw, off5, off7;
-    size_t E, O5, O7;
-    int B, C, H, W;
-    Lka2dCl(int B_, int C_, int H_, int W_) : B(B_), C(C_), H(H_), W(W_)
+    SameConv pw, off5, off7;      // activation-typed (bf16 on DLKA_BF16): the pointwise convs, the offset nets' backward passes
+    SameConv off5_f, off7_f;      // the offset nets' FORWARD passes: fp32 input on both paths
+    size_t E, O5, O7, SB;
+    int B, C, H, W, bf;
+    Lka2dCl(int B_, int C_, int H_, int W_, int dtype = DLKA_F32) : B(B_), C(C_), H(H_), W(W_)
     {
-        pw = block_conv2d(B, C, C, H, W, 1, 0, 1);
-        off5 = block_conv2d(B, C, 50, H, W, 5, 2, 1);
-        off7 = block_conv2d(B, C, 98, H, W, 7, 9, 3);
+        bf = dtype == DLKA_BF16 ? 1 : 0;
+        SB = bf ? 2 : 4;
+        pw = block_conv2d(B, C, C, H, W, 1, 0, 1, bf);
+        off5 = block_conv2d(B, C, 50, H, W, 5, 2, 1, bf);
+        off7 = block_conv2d(B, C, 98, H, W, 7, 9, 3, bf);
+        off5_f = block_conv2d(B, C, 50, H, W, 5, 2, 1, 0);
+        off7_f = block_conv2d(B, C, 98, H, W, 7, 9, 3, 0);
         E = (size_t)B * C * H * W; O5 = (size_t)B * 50 * H * W; O7 = (size_t)B * 98 * H * W;
     }
     size_t pw_floats() const { return (size_t)C * C; }
@@ -542,9 +585,9 @@ int carve_prep2d(const Lka2dCl &G, float *base, Prep2d &t, const dlka_lka2d_para
         add_job(pb, pw_w[k], t.pw_f[k], C, C, 1, C, C, 0);
         add_job(pb, pw_w[k], t.pw_b[k], C, C, 1, C, C, 1);
     }
-    add_job(pb, p->conv0_offset_w, t.o5_f, 50, C, 25, C, 64, split_mode_flag(use_split(G.off5, true)));
+    add_job(pb, p->conv0_offset_w, t.o5_f, 50, C, 25, C, 64, split_mode_flag(use_split(G.off5_f, true)));
     add_job(pb, p->conv0_offset_w, t.o5_b, 50, C, 25, 64, C, use_split(G.off5, false) ? 9 : 1);
-    add_job(pb, p->conv_spatial_offset_w, t.o7_f, 98, C, 49, C, 128, split_mode_flag(use_split(G.off7, true)));
+    add_job(pb, p->conv_spatial_offset_w, t.o7_f, 98, C, 49, C, 128, split_mode_flag(use_split(G.off7_f, true)));
     add_job(pb, p->conv_spatial_offset_w, t.o7_b, 98, C, 49, 128, C, use_split(G.off7, false) ? 9 : 1);
     add_job(pb, p->conv0_w, t.dw5, C, C, 25, 0, 0, 3);
     add_job(pb, p->conv_spatial_w, t.dw7, C, C, 49, 0, 0, 3);
@@ -561,64 +604,74 @@ void fill_ddw(DwArgs2d &d, const Lka2dCl &G, int k, int pad, int dil)
 
 int lka2d_cl_supported(int B, int C, int H, int W, int dtype)
 {
-    if (dtype != DLKA_F32 || B <= 0 || H <= 0 || W <= 0 || !cl_ddw2d_supported(C)) return 0;
+    if ((dtype != DLKA_F32 && dtype != DLKA_BF16) || B <= 0 || H <= 0 || W <= 0 || !cl_ddw2d_supported(C)) return 0;
     if (!(nt_ok(C) || C == 192 || C == 384)) return 0;   // the offset nets' data gradient has C columns: the igemm launcher's tile menu
     if ((long)B * H * W * C >= (1l << 29)) return 0;
     return dense_fwd_supported(block_conv2d(B, C, 50, H, W, 5, 2, 1)) ? 1 : 0;
 }
 
-size_t lka2d_cl_saved_bytes(int B, int C, int H, int W)
+// saved: xt, h, a, t1, t2, g1, m, (spare) — activation-typed —, o5, o7 (fp32), prepared weights
+size_t lka2d_cl_saved_bytes(int B, int C, int H, int W, int dtype)
 {
-    Lka2dCl G(B, C, H, W);
-    return 8 * align256(G.E * 4) + align256(G.O5 * 4) + align256(G.O7 * 4) + align256(G.prep_floats() * 4);
+    Lka2dCl G(B, C, H, W, dtype);
+    return 8 * align256(G.E * G.SB) + align256(G.O5 * 4) + align256(G.O7 * 4) + align256(G.prep_floats() * 4);
 }
 
-size_t lka2d_cl_workspace_bytes(int B, int C, int H, int W)
+// (the nine gradient buffers keep their fp32 size on the bf16 path: the two grad_input accumulators ARE fp32, two more serve as the forward
+//  pass's fp32 chain tensors and as landing zones of tap-split sums)
+size_t lka2d_cl_workspace_bytes(int B, int C, int H, int W, int dtype)
 {
-    Lka2dCl G(B, C, H, W);
+    Lka2dCl G(B, C, H, W, dtype);
     return 9 * align256(G.E * 4) + align256(G.O7 * 4) + align256(G.part_floats() * 4) + align256(4096);
 }
 
 int lka2d_cl_forward(const void *x_, const dlka_lka2d_params *p, void *y_, void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes, int B,
-                     int C, int H, int W, hipStream_t st)
+                     int C, int H, int W, int dtype, hipStream_t st)
 {
-    Lka2dCl G(B, C, H, W);
+    Lka2dCl G(B, C, H, W, dtype);
+    const size_t SB = G.SB;
+    const int bf = G.bf;
     Carver sv(saved, saved_bytes), cv(workspace, workspace_bytes);
-    float *xt = (float *)sv.take(G.E * 4), *h = (float *)sv.take(G.E * 4), *a = (float *)sv.take(G.E * 4), *t1 = (float *)sv.take(G.E * 4);
-    float *t2 = (float *)sv.take(G.E * 4), *g1 = (float *)sv.take(G.E * 4), *m = (float *)sv.take(G.E * 4), *spare = (float *)sv.take(G.E * 4);
+    float *xt = (float *)sv.take(G.E * SB), *h = (float *)sv.take(G.E * SB), *a = (float *)sv.take(G.E * SB), *t1 = (float *)sv.take(G.E * SB);
+    float *t2 = (float *)sv.take(G.E * SB), *g1 = (float *)sv.take(G.E * SB), *m = (float *)sv.take(G.E * SB), *spare = (float *)sv.take(G.E * SB);
     float *o5 = (float *)sv.take(G.O5 * 4), *o7 = (float *)sv.take(G.O7 * 4);
     float *prep = (float *)sv.take(G.prep_floats() * 4);
     float *yt = (float *)cv.take(G.E * 4);
+    float *a32 = (float *)cv.take(G.E * 4), *t1_32 = (float *)cv.take(G.E * 4);   // bf16 path: the fp32 offset-determining chain
     (void)spare;
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const float *N0 = nullptr;
     Prep2d PW;
     DLKA_TRY(carve_prep2d(G, prep, PW, p, st, true));
-    DLKA_TRY(launch_cl_transpose((const float *)x_, xt, B, C, G.pw.N, 1, st));                                               // NCHW -> NHWC
-    DLKA_TRY(dense_forward(G.pw, xt, N0, (const float *)p->proj_1_b, h, 0, PW.pw_f[0], 1, nullptr, a, st));                    // :135-136 (+GELU)
-    DLKA_TRY(dense_forward(G.off5, a, N0, (const float *)p->conv0_offset_b, o5, 1, PW.o5_f, 0, nullptr, nullptr, st));         // :28 offset_net
+    DLKA_TRY(launch_cl_transpose((const float *)x_, xt, B, C, G.pw.N, 1, st, bf));                                           // NCHW -> NHWC
+    DLKA_TRY(dense_forward(G.pw, xt, N0, (const float *)p->proj_1_b, h, 0, PW.pw_f[0], 1, nullptr, a, st, false, nullptr, bf ? a32 : nullptr));   // :135-136 (+GELU)
+    const float *a_in = bf ? a32 : a;
+    DLKA_TRY(dense_forward(G.off5_f, a_in, N0, (const float *)p->conv0_offset_b, o5, 1, PW.o5_f, 0, nullptr, nullptr, st));     // :28 offset_net
     DwArgs2d d;
     fill_ddw(d, G, 5, 2, 1);
-    d.in = a; d.off = o5; d.wp = PW.dw5; d.out = t1;
+    d.in = a_in; d.off = o5; d.wp = PW.dw5; d.out = bf ? t1_32 : t1; d.out_lo = bf ? t1 : nullptr;
     DLKA_TRY(launch_cl_ddw2d_fwd(d, st));                                                                                     // :29
-    DLKA_TRY(dense_forward(G.off7, t1, N0, (const float *)p->conv_spatial_offset_b, o7, 1, PW.o7_f, 0, nullptr, nullptr, st));
+    const float *t1_in = bf ? t1_32 : t1;
+    DLKA_TRY(dense_forward(G.off7_f, t1_in, N0, (const float *)p->conv_spatial_offset_b, o7, 1, PW.o7_f, 0, nullptr, nullptr, st));
     fill_ddw(d, G, 7, 9, 3);
-    d.in = t1; d.off = o7; d.wp = PW.dw7; d.out = t2;
+    d.in = t1_in; d.off = o7; d.wp = PW.dw7; d.out = bf ? nullptr : t2; d.out_lo = bf ? t2 : nullptr;
     DLKA_TRY(launch_cl_ddw2d_fwd(d, st));
     DLKA_TRY(dense_forward(G.pw, t2, N0, (const float *)p->conv1_b, g1, 0, PW.pw_f[1], 2, a, m, st));                          // :102-104 conv1 + gate
     DLKA_TRY(dense_forward(G.pw, m, N0, (const float *)p->proj_2_b, yt, 0, PW.pw_f[2], 3, xt, nullptr, st));                   // :138-139 proj_2 + shortcut
-    return launch_cl_transpose(yt, (float *)y_, B, C, G.pw.N, 0, st);
+    return launch_cl_transpose(yt, (float *)y_, B, C, G.pw.N, 0, st, bf);
 }
 
 int lka2d_cl_backward(const void *x_, const dlka_lka2d_params *p, const void *gy_, const void *saved, size_t saved_bytes, void *gx_, const dlka_lka2d_grads *gr,
-                      void *workspace, size_t workspace_bytes, int B, int C, int H, int W, hipStream_t st)
+                      void *workspace, size_t workspace_bytes, int B, int C, int H, int W, int dtype, hipStream_t st)
 {
     (void)x_;
-    Lka2dCl G(B, C, H, W);
+    Lka2dCl G(B, C, H, W, dtype);
+    const size_t SB = G.SB;
+    const int bf = G.bf;
     Carver sv((void *)saved, saved_bytes), cv(workspace, workspace_bytes);
-    const float *xt = (float *)sv.take(G.E * 4), *h = (float *)sv.take(G.E * 4), *a = (float *)sv.take(G.E * 4), *t1 = (float *)sv.take(G.E * 4);
-    const float *t2 = (float *)sv.take(G.E * 4), *g1 = (float *)sv.take(G.E * 4), *m = (float *)sv.take(G.E * 4);
-    (void)sv.take(G.E * 4);
+    const float *xt = (float *)sv.take(G.E * SB), *h = (float *)sv.take(G.E * SB), *a = (float *)sv.take(G.E * SB), *t1 = (float *)sv.take(G.E * SB);
+    const float *t2 = (float *)sv.take(G.E * SB), *g1 = (float *)sv.take(G.E * SB), *m = (float *)sv.take(G.E * SB);
+    (void)sv.take(G.E * SB);
     const float *o5 = (float *)sv.take(G.O5 * 4), *o7 = (float *)sv.take(G.O7 * 4);
     float *prep = (float *)sv.take(G.prep_floats() * 4);
     float *gyt = (float *)cv.take(G.E * 4), *gg1 = (float *)cv.take(G.E * 4), *ga1 = (float *)cv.take(G.E * 4), *gt2 = (float *)cv.take(G.E * 4);
@@ -634,31 +687,40 @@ int lka2d_cl_backward(const void *x_, const dlka_lka2d_params *p, const void *gy
     float *part_o7 = part_o5 + G.part_o5(), *part_dw = part_o7 + G.part_o7();
     FinalizeBatch fb;
     memset(&fb, 0, sizeof(fb));
+    // bf16: the fp32 landing zone of a tap-split offset-net data gradient (converted into its bf16 destination afterwards): gg1 is dead by then for
+    // the first one, gt2 for the second
     ZeroBatch zb;
     memset(&zb, 0, sizeof(zb));
     zb.add(gta, G.E);   // grad_input targets of the two depthwise deformable convs (fp32 atomics)
     zb.add(gaa, G.E);
+    const bool split7 = dense_backward_data_splits(G.off7, 3) > 1, split5 = dense_backward_data_splits(G.off5, 3) > 1;
+    if (bf && split7) zb.add(gh, G.E);     // (gh is written last: free until then)
+    if (zb.overflow) return DLKA_ERR_WORKSPACE;
     DLKA_TRY(launch_zero_batch(zb, st));
     float *gxt = gt2;   // (gt2 is dead by the time the last projection's data gradient is written)
-    DLKA_TRY(launch_cl_transpose((const float *)gy_, gyt, B, C, G.pw.N, 1, st));
+    DLKA_TRY(launch_cl_transpose((const float *)gy_, gyt, B, C, G.pw.N, 1, st, bf));
     // proj_2 data gradient with the gate's backward in the epilogue: gg1 = gm * a, ga1 = gm * g1
     DLKA_TRY(dense_backward_data(G.pw, gyt, 0, N0, gg1, PW.pw_b[2], 4, a, st, g1, ga1));
     DLKA_TRY(dense_backward_data(G.pw, gg1, 0, N0, gt2, PW.pw_b[1], 0, nullptr, st));                                           // conv1
     // conv_spatial = DeformConv(7x7 dil 3): t2 = DDW7(t1, o7 = offnet7(t1))
     DwArgs2d d;
     fill_ddw(d, G, 7, 9, 3);
+    d.act_bf16 = bf;
     d.in = t1; d.off = o7; d.wp = PW.dw7; d.g = gt2; d.gx = gta; d.goff = goff; d.part = part_dw;
     DLKA_TRY(launch_cl_ddw2d_bwd(d, (float *)gr->conv_spatial_w, st));
     DLKA_TRY(dense_backward_weight(G.off7, t1, goff, 1, (float *)gr->conv_spatial_offset_w, (float *)gr->conv_spatial_offset_b, part_o7, st, &fb.j[fb.njobs++]));
-    DLKA_TRY(dense_backward_data(G.off7, goff, 1, N0, gt1, PW.o7_b, 3, gta, st));                                               // gt1 = gta + offnet7^T goff
+    DLKA_TRY(dense_backward_data(G.off7, goff, 1, N0, gt1, PW.o7_b, 3, gta, st, nullptr, nullptr, bf && split7, false, bf != 0, bf ? gh : nullptr));   // gt1 = gta + offnet7^T goff
     // conv0 = DeformConv(5x5): t1 = DDW5(a, o5 = offnet5(a))
     fill_ddw(d, G, 5, 2, 1);
+    d.act_bf16 = bf;
     d.in = a; d.off = o5; d.wp = PW.dw5; d.g = gt1; d.gx = gaa; d.goff = goff; d.part = part_dw;
     DLKA_TRY(launch_cl_ddw2d_bwd(d, (float *)gr->conv0_w, st));
     DLKA_TRY(dense_backward_weight(G.off5, a, goff, 1, (float *)gr->conv0_offset_w, (float *)gr->conv0_offset_b, part_o5, st, &fb.j[fb.njobs++]));
-    DLKA_TRY(dense_backward_data(G.off5, goff, 1, N0, gab, PW.o5_b, 3, gaa, st));                                               // gab = gaa + offnet5^T goff
+    if (bf && split5) DLKA_TRY(launch_zero(gh, G.E * 4, st));
+    DLKA_TRY(dense_backward_data(G.off5, goff, 1, N0, gab, PW.o5_b, 3, gaa, st, nullptr, nullptr, bf && split5, false, bf != 0, bf ? gh : nullptr));   // gab = gaa + offnet5^T goff
     // a = GELU(h) feeds the gate and conv0: gh = (ga1 + gab) * gelu'(h)
-    DLKA_TRY(launch_gelu_bwd_sum<float>(h, ga1, gab, gh, (long)G.E, st));
+    if (bf) DLKA_TRY(launch_gelu_bwd_sum<bf16_t>((const bf16_t *)h, (const bf16_t *)ga1, (const bf16_t *)gab, (bf16_t *)gh, (long)G.E, st));
+    else DLKA_TRY(launch_gelu_bwd_sum<float>(h, ga1, gab, gh, (long)G.E, st));
     {
         WgradArgs jobs[3];
         fill_pw_wgrad(jobs[0], G.pw, m, gyt, part_p2);
@@ -671,7 +733,7 @@ int lka2d_cl_backward(const void *x_, const dlka_lka2d_params *p, const void *gy
     }
     DLKA_TRY(launch_cl_wgrad_finalize(fb, st));
     DLKA_TRY(dense_backward_data(G.pw, gh, 0, N0, gxt, PW.pw_b[0], 3, gyt, st));                                                // gx = P1^T gh + gy
-    return launch_cl_transpose(gxt, (float *)gx_, B, C, G.pw.N, 0, st);
+    return launch_cl_transpose(gxt, (float *)gx_, B, C, G.pw.N, 0, st, bf);
 }
 
 }  // namespace dlka
@@ -870,34 +932,41 @@ int dlka_ndhwc_to_ncdhw(const void *src, void *dst, int B, int C, int N, int dty
 }
 
 // ---- token-layout D-LKA block ------------------------------------------------------------------------------------------------
-int dlka_lka3d_tokens_supported(int B, int C, int D, int H, int W, int dtype) { return ((dtype == DLKA_F32 || dtype == DLKA_BF16) && tokens_supported(B, C, D, H, W)) ? 1 : 0; }
-
-size_t dlka_lka3d_tokens_saved_bytes(int B, int C, int D, int H, int W, int dtype)
+int dlka_lka3d_tokens_supported_v(int B, int C, int D, int H, int W, int dtype, int variant)
 {
-    if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return 0;
-    TokGeoms G(B, C, D, H, W, dtype);
+    return ((dtype == DLKA_F32 || dtype == DLKA_BF16) && tokens_supported(B, C, D, H, W, variant)) ? 1 : 0;
+}
+int dlka_lka3d_tokens_supported(int B, int C, int D, int H, int W, int dtype) { return dlka_lka3d_tokens_supported_v(B, C, D, H, W, dtype, DLKA_LKA3D_SYNAPSE); }
+
+size_t dlka_lka3d_tokens_saved_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant)
+{
+    if (!dlka_lka3d_tokens_supported_v(B, C, D, H, W, dtype, variant)) return 0;
+    TokGeoms G(B, C, D, H, W, dtype, variant);
     return 7 * align256(G.E * G.SB) + align256(G.Off * 4) + align256(G.prep_floats() * 4);
 }
+size_t dlka_lka3d_tokens_saved_bytes(int B, int C, int D, int H, int W, int dtype) { return dlka_lka3d_tokens_saved_bytes_v(B, C, D, H, W, dtype, DLKA_LKA3D_SYNAPSE); }
 
-size_t dlka_lka3d_tokens_workspace_bytes(int B, int C, int D, int H, int W, int dtype)
+size_t dlka_lka3d_tokens_workspace_bytes(int B, int C, int D, int H, int W, int dtype) { return dlka_lka3d_tokens_workspace_bytes_v(B, C, D, H, W, dtype, DLKA_LKA3D_SYNAPSE); }
+size_t dlka_lka3d_tokens_workspace_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant)
 {
-    if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return 0;
-    TokGeoms G(B, C, D, H, W, dtype);   // (the eight gradient buffers keep their fp32 size on the bf16 path: gta and the split scratch ARE fp32)
+    if (!dlka_lka3d_tokens_supported_v(B, C, D, H, W, dtype, variant)) return 0;
+    TokGeoms G(B, C, D, H, W, dtype, variant);   // (the eight gradient buffers keep their fp32 size on the bf16 path: gta and the split scratch ARE fp32)
     return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 8 * align256(G.E * 4) + align256(G.GOff * 4) +
            align256(G.scratch_floats() * 4) + align256(G.samp_floats() * 4) + align256(4096);
 }
 
 static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void *y_, void *saved, size_t saved_bytes, void *workspace,
-                               size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, void *stream, bool prepared)
+                               size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, void *stream, bool prepared,
+                               int variant = DLKA_LKA3D_SYNAPSE)
 {
     if (!x_ || !p || !y_ || !saved || !workspace) return DLKA_ERR_NULL;
     const void *const *pp = (const void *const *)p;
     for (size_t k = 0; k < sizeof(*p) / sizeof(void *); ++k) if (!pp[k]) return DLKA_ERR_NULL;
-    if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return DLKA_ERR_UNSUPPORTED;
+    if (!dlka_lka3d_tokens_supported_v(B, C, D, H, W, dtype, variant)) return DLKA_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     // DLKA_BF16: x, y and every saved activation are bf16 storage (`float *` below is then just an address: the kernels reinterpret it);
     // offsets, prepared weights, parameters and all accumulators are fp32
-    TokGeoms G(B, C, D, H, W, dtype);
+    TokGeoms G(B, C, D, H, W, dtype, variant);
     const size_t SB = G.SB;
     Carver sv(saved, saved_bytes), cv(workspace, workspace_bytes);
     float *h = (float *)sv.take(G.E * SB), *a = (float *)sv.take(G.E * SB), *t1 = (float *)sv.take(G.E * SB), *t = (float *)sv.take(G.E * SB);
@@ -953,6 +1022,12 @@ int dlka_lka3d_attention_tokens_forward(const void *x, const dlka_lka3d_params *
                                         size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, void *stream)
 {
     return tokens_forward_impl(x, p, y, saved, saved_bytes, workspace, workspace_bytes, B, C, D, H, W, dtype, stream, false);
+}
+
+int dlka_lka3d_attention_tokens_forward_v(const void *x, const dlka_lka3d_params *p, void *y, void *saved, size_t saved_bytes, void *workspace,
+                                          size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant, void *stream)
+{
+    return tokens_forward_impl(x, p, y, saved, saved_bytes, workspace, workspace_bytes, B, C, D, H, W, dtype, stream, false, variant);
 }
 
 int dlka_lka3d_attention_tokens_forward_prepared(const void *x, const dlka_lka3d_params *p, void *y, void *saved, size_t saved_bytes, void *workspace,
@@ -1024,16 +1099,23 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
                                          void *gx_, const dlka_lka3d_grads *gr, void *workspace, size_t workspace_bytes, int B, int C,
                                          int D, int H, int W, int dtype, void *stream)
 {
+    return dlka_lka3d_attention_tokens_backward_v(x_, p, gy_, saved, saved_bytes, gx_, gr, workspace, workspace_bytes, B, C, D, H, W, dtype, DLKA_LKA3D_SYNAPSE, stream);
+}
+
+int dlka_lka3d_attention_tokens_backward_v(const void *x_, const dlka_lka3d_params *p, const void *gy_, const void *saved, size_t saved_bytes,
+                                           void *gx_, const dlka_lka3d_grads *gr, void *workspace, size_t workspace_bytes, int B, int C,
+                                           int D, int H, int W, int dtype, int variant, void *stream)
+{
     if (!x_ || !p || !gy_ || !saved || !gx_ || !gr || !workspace) return DLKA_ERR_NULL;
     const void *const *pp = (const void *const *)p;
     for (size_t k = 0; k < sizeof(*p) / sizeof(void *); ++k) if (!pp[k]) return DLKA_ERR_NULL;
     void *const *gp = (void *const *)gr;
     for (size_t k = 0; k < sizeof(*gr) / sizeof(void *); ++k) if (!gp[k]) return DLKA_ERR_NULL;
-    if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return DLKA_ERR_UNSUPPORTED;
+    if (!dlka_lka3d_tokens_supported_v(B, C, D, H, W, dtype, variant)) return DLKA_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     // DLKA_BF16: x, gy, gx, the saved activations and the intermediate gradients gg1, ga1, gf, gt, gt1, gh are bf16 storage; grad_offset, the
     // deformable conv's grad_input accumulator gta (atomics), the weight-gradient partials and the parameter gradients are fp32
-    TokGeoms G(B, C, D, H, W, dtype);
+    TokGeoms G(B, C, D, H, W, dtype, variant);
     const size_t SB = G.SB;
     const bool bf = dtype == DLKA_BF16;
     Carver sv((void *)saved, saved_bytes), cv(workspace, workspace_bytes);
@@ -1058,7 +1140,7 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     DLKA_TRY(carve_prep(G, prep, PW, p, st, false));
     // partial-sum areas, one per weight gradient; folded by ONE launch at the end
     float *part_p2 = part, *part_c1 = part_p2 + G.part_pw(), *part_p1 = part_c1 + G.part_pw(), *part_off = part_p1 + G.part_pw();
-    float *part_dcn = part_off + G.part_off(), *stage5 = part_dcn + G.part_dcn(), *stage7 = stage5 + (size_t)126 * C;
+    float *part_dcn = part_off + G.part_off(), *stage5 = part_dcn + G.part_dcn(), *stage7 = stage5 + (size_t)(G.dw5.K + 1) * C;
     FinalizeBatch fb;
     memset(&fb, 0, sizeof(fb));
 
@@ -1248,7 +1330,7 @@ struct TBlockGeoms {
     size_t part_floats() const { return cl_wgrad_part_floats(c3.M, c3.K, c3.Cout, c3.Cin); }
 };
 
-bool tblock_supported(int B, int C, int D, int H, int W) { return tokens_supported(B, C, D, H, W) && (long)D * H * W < (1l << 31); }
+bool tblock_supported(int B, int C, int D, int H, int W, int variant = DLKA_LKA3D_SYNAPSE) { return tokens_supported(B, C, D, H, W, variant) && (long)D * H * W < (1l << 31); }
 
 struct TBlockSaved {
     float *xt, *xn, *e, *attn, *c1, *a1, *c2, *rd, *lnstats;
@@ -1257,7 +1339,7 @@ struct TBlockSaved {
     size_t lka_bytes;
 };
 
-bool carve_tblock_saved(Carver &sv, const TBlockGeoms &G, int B, int C, int D, int H, int W, TBlockSaved &S)
+bool carve_tblock_saved(Carver &sv, const TBlockGeoms &G, int B, int C, int D, int H, int W, TBlockSaved &S, int variant = DLKA_LKA3D_SYNAPSE)
 {
     S.xt = (float *)sv.take(G.E * 4); S.xn = (float *)sv.take(G.E * 4); S.e = (float *)sv.take(G.E * 4); S.attn = (float *)sv.take(G.E * 4);
     S.c1 = (float *)sv.take(G.E * 4); S.a1 = (float *)sv.take(G.E * 4); S.c2 = (float *)sv.take(G.E * 4); S.rd = (float *)sv.take(G.E * 4);
@@ -1265,28 +1347,31 @@ bool carve_tblock_saved(Carver &sv, const TBlockGeoms &G, int B, int C, int D, i
     S.w1_f = (float *)sv.take(dense_wp_floats(G.c3) * 4); S.w1_b = (float *)sv.take(dense_wp_floats(G.c3) * 4);
     S.w2_f = (float *)sv.take(dense_wp_floats(G.c3) * 4); S.w2_b = (float *)sv.take(dense_wp_floats(G.c3) * 4);
     S.w8_f = (float *)sv.take(dense_wp_floats(G.pw) * 4); S.w8_b = (float *)sv.take(dense_wp_floats(G.pw) * 4);
-    S.lka_bytes = dlka_lka3d_tokens_saved_bytes(B, C, D, H, W, DLKA_F32);
+    S.lka_bytes = dlka_lka3d_tokens_saved_bytes_v(B, C, D, H, W, DLKA_F32, variant);
     S.lka = sv.take(S.lka_bytes);
     return sv.ok();
 }
 
 }  // namespace
 
-int dlka_tblock3d_supported(int B, int C, int D, int H, int W, int dtype) { return (dtype == DLKA_F32 && tblock_supported(B, C, D, H, W)) ? 1 : 0; }
+int dlka_tblock3d_supported_v(int B, int C, int D, int H, int W, int dtype, int variant) { return (dtype == DLKA_F32 && tblock_supported(B, C, D, H, W, variant)) ? 1 : 0; }
+int dlka_tblock3d_supported(int B, int C, int D, int H, int W, int dtype) { return dlka_tblock3d_supported_v(B, C, D, H, W, dtype, DLKA_LKA3D_SYNAPSE); }
 
-size_t dlka_tblock3d_saved_bytes(int B, int C, int D, int H, int W, int dtype)
+size_t dlka_tblock3d_saved_bytes(int B, int C, int D, int H, int W, int dtype) { return dlka_tblock3d_saved_bytes_v(B, C, D, H, W, dtype, DLKA_LKA3D_SYNAPSE); }
+size_t dlka_tblock3d_saved_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant)
 {
-    if (!dlka_tblock3d_supported(B, C, D, H, W, dtype)) return 0;
+    if (!dlka_tblock3d_supported_v(B, C, D, H, W, dtype, variant)) return 0;
     TBlockGeoms G(B, C, D, H, W);
     return 8 * align256(G.E * 4) + align256(G.M * 2 * 4) + 4 * align256(dense_wp_floats(G.c3) * 4) + 2 * align256(dense_wp_floats(G.pw) * 4) +
-           align256(dlka_lka3d_tokens_saved_bytes(B, C, D, H, W, dtype));
+           align256(dlka_lka3d_tokens_saved_bytes_v(B, C, D, H, W, dtype, variant));
 }
 
-size_t dlka_tblock3d_workspace_bytes(int B, int C, int D, int H, int W, int dtype)
+size_t dlka_tblock3d_workspace_bytes(int B, int C, int D, int H, int W, int dtype) { return dlka_tblock3d_workspace_bytes_v(B, C, D, H, W, dtype, DLKA_LKA3D_SYNAPSE); }
+size_t dlka_tblock3d_workspace_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant)
 {
-    if (!dlka_tblock3d_supported(B, C, D, H, W, dtype)) return 0;
+    if (!dlka_tblock3d_supported_v(B, C, D, H, W, dtype, variant)) return 0;
     TBlockGeoms G(B, C, D, H, W);
-    return align256(dlka_lka3d_tokens_workspace_bytes(B, C, D, H, W, dtype)) + align256(G.wp_floats() * 4) + 2 * align256(G.part_floats() * 4) +
+    return align256(dlka_lka3d_tokens_workspace_bytes_v(B, C, D, H, W, dtype, variant)) + align256(G.wp_floats() * 4) + 2 * align256(G.part_floats() * 4) +
            align256(cl_wgrad_part_floats(G.pw.M, 1, G.pw.Cout, G.pw.Cin) * 4) + 6 * align256(G.E * 4) + align256(4096);
 }
 
@@ -1294,17 +1379,25 @@ int dlka_tblock3d_forward(const void *x, int x_planar, const dlka_tblock3d_param
                           void *bn_stats, void *y, void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W,
                           float ln_eps, float bn_eps, int dtype, void *stream)
 {
+    return dlka_tblock3d_forward_v(x, x_planar, p, lka, drop_mask, training, bn_stats, y, saved, saved_bytes, workspace, workspace_bytes, B, C, D, H, W, ln_eps, bn_eps,
+                                   dtype, DLKA_LKA3D_SYNAPSE, stream);
+}
+
+int dlka_tblock3d_forward_v(const void *x, int x_planar, const dlka_tblock3d_params *p, const dlka_lka3d_params *lka, const void *drop_mask, int training,
+                            void *bn_stats, void *y, void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W,
+                            float ln_eps, float bn_eps, int dtype, int variant, void *stream)
+{
     if (!x || !p || !lka || !bn_stats || !y || !saved || !workspace) return DLKA_ERR_NULL;
     if (!p->norm_w || !p->norm_b || !p->gamma || !p->conv51_conv1_w || !p->conv51_conv2_w || !p->conv51_norm1_w || !p->conv51_norm1_b ||
         !p->conv51_norm2_w || !p->conv51_norm2_b || !p->conv8_w || !p->conv8_b)
         return DLKA_ERR_NULL;
-    if (!dlka_tblock3d_supported(B, C, D, H, W, dtype)) return DLKA_ERR_UNSUPPORTED;
+    if (!dlka_tblock3d_supported_v(B, C, D, H, W, dtype, variant)) return DLKA_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     TBlockGeoms G(B, C, D, H, W);
     Carver sv(saved, saved_bytes), cv(workspace, workspace_bytes);
     TBlockSaved S;
-    if (!carve_tblock_saved(sv, G, B, C, D, H, W, S)) return DLKA_ERR_WORKSPACE;
-    const size_t lka_ws_bytes = dlka_lka3d_tokens_workspace_bytes(B, C, D, H, W, dtype);
+    if (!carve_tblock_saved(sv, G, B, C, D, H, W, S, variant)) return DLKA_ERR_WORKSPACE;
+    const size_t lka_ws_bytes = dlka_lka3d_tokens_workspace_bytes_v(B, C, D, H, W, dtype, variant);
     void *lka_ws = cv.take(lka_ws_bytes);
     float *wp = (float *)cv.take(G.wp_floats() * 4);
     float *sums = (float *)cv.take(4096);
@@ -1335,7 +1428,7 @@ int dlka_tblock3d_forward(const void *x, int x_planar, const dlka_tblock3d_param
     DLKA_TRY(launch_cl_layernorm_fwd((const float *)x, x_planar, (const float *)p->pos_embed, (const float *)p->norm_w, (const float *)p->norm_b, S.xt, S.xn,
                                      S.lnstats, B, (int)N, C, ln_eps, st));
     // epa_block = the D-LKA block (:624)
-    DLKA_TRY(dlka_lka3d_attention_tokens_forward(S.xn, lka, S.e, S.lka, S.lka_bytes, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, stream));
+    DLKA_TRY(dlka_lka3d_attention_tokens_forward_v(S.xn, lka, S.e, S.lka, S.lka_bytes, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, variant, stream));
     // attn = x + gamma * epa (:624); attn IS attn_skip in channels-last memory (:626 is a view here)
     DLKA_TRY(launch_cl_scale_residual_fwd(S.xt, S.e, (const float *)p->gamma, S.attn, M, C, st));
     // conv51 = UnetResBlock (dynunet_block.py:66-80)
@@ -1355,18 +1448,27 @@ int dlka_tblock3d_backward(const dlka_tblock3d_params *p, const dlka_lka3d_param
                            const void *grad_y, const void *saved, size_t saved_bytes, void *grad_x, const dlka_tblock3d_grads *gr,
                            const dlka_lka3d_grads *glka, void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, void *stream)
 {
+    return dlka_tblock3d_backward_v(p, lka, drop_mask, training, bn_stats, grad_y, saved, saved_bytes, grad_x, gr, glka, workspace, workspace_bytes, B, C, D, H, W, dtype,
+                                    DLKA_LKA3D_SYNAPSE, stream);
+}
+
+int dlka_tblock3d_backward_v(const dlka_tblock3d_params *p, const dlka_lka3d_params *lka, const void *drop_mask, int training, const void *bn_stats,
+                             const void *grad_y, const void *saved, size_t saved_bytes, void *grad_x, const dlka_tblock3d_grads *gr,
+                             const dlka_lka3d_grads *glka, void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant,
+                             void *stream)
+{
     if (!p || !lka || !bn_stats || !grad_y || !saved || !grad_x || !gr || !glka || !workspace) return DLKA_ERR_NULL;
     if (!gr->norm_w || !gr->norm_b || !gr->gamma || !gr->conv51_conv1_w || !gr->conv51_conv2_w || !gr->conv51_norm1_w || !gr->conv51_norm1_b ||
         !gr->conv51_norm2_w || !gr->conv51_norm2_b || !gr->conv8_w || !gr->conv8_b)
         return DLKA_ERR_NULL;
     if ((p->pos_embed != nullptr) != (gr->pos_embed != nullptr)) return DLKA_ERR_NULL;
-    if (!dlka_tblock3d_supported(B, C, D, H, W, dtype)) return DLKA_ERR_UNSUPPORTED;
+    if (!dlka_tblock3d_supported_v(B, C, D, H, W, dtype, variant)) return DLKA_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     TBlockGeoms G(B, C, D, H, W);
     Carver sv((void *)saved, saved_bytes), cv(workspace, workspace_bytes);
     TBlockSaved S;
-    if (!carve_tblock_saved(sv, G, B, C, D, H, W, S)) return DLKA_ERR_WORKSPACE;
-    const size_t lka_ws_bytes = dlka_lka3d_tokens_workspace_bytes(B, C, D, H, W, dtype);
+    if (!carve_tblock_saved(sv, G, B, C, D, H, W, S, variant)) return DLKA_ERR_WORKSPACE;
+    const size_t lka_ws_bytes = dlka_lka3d_tokens_workspace_bytes_v(B, C, D, H, W, dtype, variant);
     void *lka_ws = cv.take(lka_ws_bytes);
     (void)cv.take(G.wp_floats() * 4);   // (layout kept: the forward call carves the same region)
     float *part1 = (float *)cv.take(G.part_floats() * 4), *part2 = (float *)cv.take(G.part_floats() * 4);
@@ -1415,7 +1517,7 @@ int dlka_tblock3d_backward(const dlka_tblock3d_params *p, const dlka_lka3d_param
     // attn = xt + gamma * e
     DLKA_TRY(launch_cl_scale_residual_bwd(g_attn, S.e, (const float *)p->gamma, g_e, (float *)gr->gamma, M, C, st, true));
     // epa_block
-    DLKA_TRY(dlka_lka3d_attention_tokens_backward(S.xn, lka, g_e, S.lka, S.lka_bytes, g_xn, glka, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, stream));
+    DLKA_TRY(dlka_lka3d_attention_tokens_backward_v(S.xn, lka, g_e, S.lka, S.lka_bytes, g_xn, glka, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, variant, stream));
     // LayerNorm (+ the residual branch g_attn), pos_embed
     DLKA_TRY(launch_cl_layernorm_bwd(g_xn, g_attn, S.xt, S.lnstats, (const float *)p->norm_w, (float *)grad_x, (float *)gr->norm_w, (float *)gr->norm_b,
                                      (float *)gr->pos_embed, B, (int)N, C, st, true));

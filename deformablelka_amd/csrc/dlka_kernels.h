@@ -69,7 +69,7 @@ int launch_cl_dw_prep_weight(const float *w, float *wp, int C, int K, int flip, 
 int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st);
 int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st, bool zero_init = true);
 template <typename T> int launch_cl_dw_unprep(const float *gwp, T *gw, int C, int K, hipStream_t st);
-int launch_cl_transpose(const float *src, float *dst, int B, int C, int N, int to_cl, hipStream_t st);
+int launch_cl_transpose(const float *src, float *dst, int B, int C, int N, int to_cl, hipStream_t st, int bf16 = 0);
 size_t cl_deform_bwd2_scratch_floats(const DeformBwdArgs &a);
 int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st);
 int cl_deform_goff_ccsplit(const DeformBwdArgs &a);
@@ -81,12 +81,12 @@ int launch_cl_ddw2d_fwd(const DwArgs2d &d, hipStream_t st);
 int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st);
 // the 2-D D-LKA block on the channels-last kernels (dlka_capi_cl.hip); NCHW in / out, transposed inside
 int lka2d_cl_supported(int B, int C, int H, int W, int dtype);
-size_t lka2d_cl_saved_bytes(int B, int C, int H, int W);
-size_t lka2d_cl_workspace_bytes(int B, int C, int H, int W);
+size_t lka2d_cl_saved_bytes(int B, int C, int H, int W, int dtype);
+size_t lka2d_cl_workspace_bytes(int B, int C, int H, int W, int dtype);
 int lka2d_cl_forward(const void *x, const dlka_lka2d_params *p, void *y, void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes, int B,
-                     int C, int H, int W, hipStream_t st);
+                     int C, int H, int W, int dtype, hipStream_t st);
 int lka2d_cl_backward(const void *x, const dlka_lka2d_params *p, const void *gy, const void *saved, size_t saved_bytes, void *gx, const dlka_lka2d_grads *gr,
-                      void *workspace, size_t workspace_bytes, int B, int C, int H, int W, hipStream_t st);
+                      void *workspace, size_t workspace_bytes, int B, int C, int H, int W, int dtype, hipStream_t st);
 
 // ---- cl_norm.hip: the non-convolutional pieces of TransformerBlock_3D_single_deform_LKA ---------------------------------
 int launch_cl_layernorm_fwd(const float *x, int x_planar, const float *pos, const float *w, const float *b, float *xt, float *xn, float *stats, int B, int N,

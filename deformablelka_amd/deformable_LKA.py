@@ -80,4 +80,9 @@ class deformable_LKA_Attention(nn.Module):
                 s.conv_spatial.deform_conv.weight, s.conv1.weight, s.conv1.bias, self.proj_2.weight, self.proj_2.bias)
 
     def forward(self, x):
+        # Autocast policy (the reference registers none): inside torch.autocast(dtype=torch.bfloat16) the block takes bf16 activations with fp32
+        # parameters / offsets / accumulation where the DLKA_BF16 path covers the width (BASELINE.json config 2: bf16 training).
+        act = ops.autocast_activation_dtype(x)
+        if act != x.dtype and act == torch.bfloat16 and self.proj_1.weight.dtype == torch.float32 and ops.lka2d_bf16_supported(x.shape[1]):
+            x = x.to(act)
         return _LKA2dAttentionFn.apply(x, *self.block_params())

@@ -341,10 +341,23 @@ def lka3d_attention_backward(x, params, grad_y, saved):
     return gx, grads
 
 
+def lka2d_bf16_supported(C: int) -> bool:
+    """Widths the DLKA_BF16 2-D block covers (channels-last fast path: C / 32 in {1, 2, 3, 4, 6, 8, 12})."""
+    return C % 32 == 0 and C // 32 in (1, 2, 3, 4, 6, 8, 12)
+
+
+def _lka2d_params(x, params):
+    if x.dtype == torch.bfloat16:   # DLKA_BF16: bf16 ACTIVATIONS, fp32 master parameters (include/dlka.h)
+        if not lka2d_bf16_supported(int(x.shape[1])):
+            raise RuntimeError(f"deformable_LKA_Attention with bfloat16 activations needs C / 32 in {{1,2,3,4,6,8,12}}, got C={int(x.shape[1])}")
+        return [_fp32_param(t) for t in params]
+    return [t.contiguous() for t in params]
+
+
 def lka2d_attention_forward(x, params: Sequence[torch.Tensor]):
     L.require_device(x, *params)
     x = x.contiguous()
-    params = [t.contiguous() for t in params]
+    params = _lka2d_params(x, params)
     B, C, H, W = (int(v) for v in x.shape)
     lib = L.get_lib()
     dt = L.dtype_code(x)
@@ -362,8 +375,8 @@ def lka2d_attention_forward(x, params: Sequence[torch.Tensor]):
 
 def lka2d_attention_backward(x, params, grad_y, saved):
     L.require_device(x, grad_y, saved, *params)
-    x, grad_y = x.contiguous(), grad_y.contiguous()
-    params = [t.contiguous() for t in params]
+    x, grad_y = x.contiguous(), grad_y.to(x.dtype).contiguous()
+    params = _lka2d_params(x, params)
     B, C, H, W = (int(v) for v in x.shape)
     lib = L.get_lib()
     dt = L.dtype_code(x)
@@ -458,13 +471,13 @@ def deform_conv3d_backward_cl(x, offset, weight, grad_out, padding=1, dilation=1
     return gi, go, gw, gb
 
 
-def lka3d_tokens_supported(x, B, C, D, H, W) -> bool:
-    """x: a tensor or a torch dtype.  float32, or bfloat16 activations (DLKA_BF16: bf16 storage of x / y / saved activations, fp32 parameters,
+def lka3d_tokens_supported(x, B, C, D, H, W, variant=0) -> bool:
+    """x: a tensor or a torch dtype; variant: 0 = Synapse depthwise pair, 1 = ACDC (include/dlka.h: dlka_lka3d_variant).  float32, or bfloat16 activations (DLKA_BF16: bf16 storage of x / y / saved activations, fp32 parameters,
     offsets and accumulation)."""
     dt = x if isinstance(x, torch.dtype) else x.dtype
     if dt not in (torch.float32, torch.bfloat16):
         return False
-    return bool(L.get_lib().dlka_lka3d_tokens_supported(B, C, D, H, W, L.DLKA_F32 if dt == torch.float32 else L.DLKA_BF16))
+    return bool(L.get_lib().dlka_lka3d_tokens_supported_v(B, C, D, H, W, L.DLKA_F32 if dt == torch.float32 else L.DLKA_BF16, int(variant)))
 
 
 def autocast_activation_dtype(x):
@@ -486,7 +499,7 @@ def _fp32_param(t):
     return t.contiguous()
 
 
-def lka3d_attention_tokens_forward(x, params, dims):
+def lka3d_attention_tokens_forward(x, params, dims, variant=0):
     """x: [B, N, C] tokens, dims = (D, H, W) spatial extents (the reference's H, W, D). Returns (y, saved)."""
     L.require_device(x, *params)
     x = x.contiguous()
@@ -496,19 +509,32 @@ def lka3d_attention_tokens_forward(x, params, dims):
     assert N == D * H * W
     lib = L.get_lib()
     dt = L.dtype_code(x)
-    sb, wb = lib.dlka_lka3d_tokens_saved_bytes(B, C, D, H, W, dt), lib.dlka_lka3d_tokens_workspace_bytes(B, C, D, H, W, dt)
+    v = int(variant)
+    sb, wb = lib.dlka_lka3d_tokens_saved_bytes_v(B, C, D, H, W, dt, v), lib.dlka_lka3d_tokens_workspace_bytes_v(B, C, D, H, W, dt, v)
     if sb == 0:
         L.check(-8, "lka3d_attention_tokens_forward")
     saved, ws = L.scratch(sb, x), L.scratch(wb, x)
     y = torch.empty_like(x)
     ps = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, params)
-    rc = lib.dlka_lka3d_attention_tokens_forward(L.ptr(x), byref(ps), L.ptr(y), L.ptr(saved), sb, L.ptr(ws), wb, B, C, D, H, W, dt,
-                                                 L.stream_ptr(x))
+    rc = lib.dlka_lka3d_attention_tokens_forward_v(L.ptr(x), byref(ps), L.ptr(y), L.ptr(saved), sb, L.ptr(ws), wb, B, C, D, H, W, dt, v,
+                                                   L.stream_ptr(x))
     L.check(rc, "lka3d_attention_tokens_forward")
     return y, saved
 
 
-def lka3d_attention_tokens_backward(x, params, grad_y, saved, dims):
+def lka3d_tokens_saved_offsets(saved, B, C, dims, act_dtype=torch.float32):
+    """The predicted sampling offsets [B, 81, D, H, W] (fp32, the reference's planar layout) inside the opaque ``saved`` buffer of a token-layout
+    forward call (include/dlka.h: h, a, t1, t — one activation-sized tensor each, 256-byte aligned — then the offsets).  Diagnostics: bench.py's
+    health check and the cell-flip analysis of the parity tests read them."""
+    D, H, W = (int(v) for v in dims)
+    n = D * H * W
+    sb = 4 if act_dtype == torch.float32 else 2
+    a256 = lambda v: (v + 255) & ~255
+    o = 4 * a256(B * C * n * sb)
+    return saved[o:o + B * 81 * n * 4].view(torch.float32).view(B, 81, D, H, W)
+
+
+def lka3d_attention_tokens_backward(x, params, grad_y, saved, dims, variant=0):
     L.require_device(x, grad_y, saved, *params)
     x, grad_y = x.contiguous(), grad_y.to(x.dtype).contiguous()
     params = [_fp32_param(t) for t in params]
@@ -516,14 +542,14 @@ def lka3d_attention_tokens_backward(x, params, grad_y, saved, dims):
     D, H, W = (int(v) for v in dims)
     lib = L.get_lib()
     dt = L.dtype_code(x)
-    wb = lib.dlka_lka3d_tokens_workspace_bytes(B, C, D, H, W, dt)
+    wb = lib.dlka_lka3d_tokens_workspace_bytes_v(B, C, D, H, W, dt, int(variant))
     ws = L.scratch(wb, x)
     gx = torch.empty_like(x)
     grads = [torch.empty_like(t) for t in params]
     ps = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, params)
     gs = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, grads)
-    rc = lib.dlka_lka3d_attention_tokens_backward(L.ptr(x), byref(ps), L.ptr(grad_y), L.ptr(saved), saved.numel(), L.ptr(gx), byref(gs),
-                                                  L.ptr(ws), wb, B, C, D, H, W, dt, L.stream_ptr(x))
+    rc = lib.dlka_lka3d_attention_tokens_backward_v(L.ptr(x), byref(ps), L.ptr(grad_y), L.ptr(saved), saved.numel(), L.ptr(gx), byref(gs),
+                                                  L.ptr(ws), wb, B, C, D, H, W, dt, int(variant), L.stream_ptr(x))
     L.check(rc, "lka3d_attention_tokens_backward")
     return gx, grads
 
@@ -531,10 +557,10 @@ def lka3d_attention_tokens_backward(x, params, grad_y, saved, dims):
 # ------------------------------------------------------------------------------------------------------------
 # TransformerBlock_3D_single_deform_LKA (transformerblock.py:570-630): the wrapper around the D-LKA block
 # ------------------------------------------------------------------------------------------------------------
-def tblock3d_supported(x, B, C, D, H, W) -> bool:
+def tblock3d_supported(x, B, C, D, H, W, variant=0) -> bool:
     if x.dtype != torch.float32:
         return False
-    return bool(L.get_lib().dlka_tblock3d_supported(B, C, D, H, W, L.DLKA_F32))
+    return bool(L.get_lib().dlka_tblock3d_supported_v(B, C, D, H, W, L.DLKA_F32, int(variant)))
 
 
 def _opt_ptr_struct(cls, fields, tensors):
@@ -544,7 +570,7 @@ def _opt_ptr_struct(cls, fields, tensors):
     return st
 
 
-def tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_stats, dims, ln_eps=1e-5, bn_eps=1e-5):
+def tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_stats, dims, ln_eps=1e-5, bn_eps=1e-5, variant=0):
     """x: [B, C, N...] contiguous NCDHW (x_planar) or [B, N, C] tokens; dims = the reference's (H, W, D).
     Returns (y tokens [B, N, C], saved).  bn_stats [6*C] is written (training) or read (eval)."""
     L.require_device(x, bn_stats, drop_mask, *[t for t in tparams if t is not None], *lka_params)
@@ -558,20 +584,21 @@ def tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_s
     assert x.numel() == B * N * C
     lib = L.get_lib()
     dt = L.dtype_code(x)
-    sb, wb = lib.dlka_tblock3d_saved_bytes(B, C, D, H, W, dt), lib.dlka_tblock3d_workspace_bytes(B, C, D, H, W, dt)
+    v = int(variant)
+    sb, wb = lib.dlka_tblock3d_saved_bytes_v(B, C, D, H, W, dt, v), lib.dlka_tblock3d_workspace_bytes_v(B, C, D, H, W, dt, v)
     if sb == 0:
         L.check(-8, "tblock3d_forward")
     saved, ws = L.scratch(sb, x), L.scratch(wb, x)
     y = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
     ps = _opt_ptr_struct(L.TBlock3dPtrs, L.TBLOCK3D_FIELDS, tparams)
     lk = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, lka_params)
-    rc = lib.dlka_tblock3d_forward(L.ptr(x), int(bool(x_planar)), byref(ps), byref(lk), L.ptr(drop_mask), int(bool(training)), L.ptr(bn_stats),
-                                   L.ptr(y), L.ptr(saved), sb, L.ptr(ws), wb, B, C, D, H, W, float(ln_eps), float(bn_eps), dt, L.stream_ptr(x))
+    rc = lib.dlka_tblock3d_forward_v(L.ptr(x), int(bool(x_planar)), byref(ps), byref(lk), L.ptr(drop_mask), int(bool(training)), L.ptr(bn_stats),
+                                     L.ptr(y), L.ptr(saved), sb, L.ptr(ws), wb, B, C, D, H, W, float(ln_eps), float(bn_eps), dt, v, L.stream_ptr(x))
     L.check(rc, "tblock3d_forward")
     return y, saved
 
 
-def tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, grad_y, saved, dims):
+def tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, grad_y, saved, dims, variant=0):
     """Returns (grad_x tokens [B, N, C], grads of tparams (None where the parameter is None), grads of lka_params)."""
     L.require_device(grad_y, saved, bn_stats)
     grad_y = grad_y.contiguous()
@@ -581,7 +608,7 @@ def tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, grad_y
     D, H, W = (int(v) for v in dims)
     lib = L.get_lib()
     dt = L.dtype_code(grad_y)
-    wb = lib.dlka_tblock3d_workspace_bytes(B, C, D, H, W, dt)
+    wb = lib.dlka_tblock3d_workspace_bytes_v(B, C, D, H, W, dt, int(variant))
     ws = L.scratch(wb, grad_y)
     gx = torch.empty_like(grad_y)
     tg = [None if t is None else torch.empty_like(t) for t in tparams]
@@ -590,8 +617,8 @@ def tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, grad_y
     lk = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, lka_params)
     gs = _opt_ptr_struct(L.TBlock3dPtrs, L.TBLOCK3D_FIELDS, tg)
     gl = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, lg)
-    rc = lib.dlka_tblock3d_backward(byref(ps), byref(lk), L.ptr(drop_mask), int(bool(training)), L.ptr(bn_stats), L.ptr(grad_y), L.ptr(saved),
-                                    saved.numel(), L.ptr(gx), byref(gs), byref(gl), L.ptr(ws), wb, B, C, D, H, W, dt, L.stream_ptr(grad_y))
+    rc = lib.dlka_tblock3d_backward_v(byref(ps), byref(lk), L.ptr(drop_mask), int(bool(training)), L.ptr(bn_stats), L.ptr(grad_y), L.ptr(saved),
+                                      saved.numel(), L.ptr(gx), byref(gs), byref(gl), L.ptr(ws), wb, B, C, D, H, W, dt, int(variant), L.stream_ptr(grad_y))
     L.check(rc, "tblock3d_backward")
     return gx, tg, lg
 

@@ -205,17 +205,13 @@ class DLKABlockStack:
         """Finite-ness of parameters / gradients and the std of the predicted offsets (voxels) of the first block of each
         stage, read from the activations the last forward pass saved."""
         finite = bool(torch.isfinite(self.flat_params).all().item() and torch.isfinite(self.flat_grads).all().item())
+        from . import ops
         stds, seen = [], set()
-        a256 = lambda n: (n + 255) & ~255
         for blk in self.blocks:
             if blk.C in seen:
                 continue
             seen.add(blk.C)
-            H, W, D = blk.dims
-            N = H * W * D
-            E, Off = self.B * blk.C * N, self.B * 81 * N
-            o = 4 * a256(E * (4 if self.dtype == torch.float32 else 2))   # saved = h, a, t1, t, off, ...  (activations in the run's storage type)
-            off = blk.saved[o:o + Off * 4].view(torch.float32)
+            off = ops.lka3d_tokens_saved_offsets(blk.saved, self.B, blk.C, blk.dims, self.dtype)
             stds.append(round(float(off.std().item()), 3))
         return {"finite": finite, "offset_std": stds}
 

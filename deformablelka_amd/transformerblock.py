@@ -19,10 +19,15 @@ from .modules.deform_conv import DeformConvPack
 class LKA3d_deform(nn.Module):
     """transformerblock.py:634-652."""
 
+    VARIANT = 0   # dlka_lka3d_variant (include/dlka.h): which depthwise pair the fused entry points assume
+
+    def _make_depthwise_pair(self, dim):
+        """(conv0, conv_spatial): synapse/transformerblock.py:637-638."""
+        return nn.Conv3d(dim, dim, 5, padding=2, groups=dim), nn.Conv3d(dim, dim, 7, stride=1, padding=9, groups=dim, dilation=3)
+
     def __init__(self, dim):
         super().__init__()
-        self.conv0 = nn.Conv3d(dim, dim, 5, padding=2, groups=dim)
-        self.conv_spatial = nn.Conv3d(dim, dim, 7, stride=1, padding=9, groups=dim, dilation=3)
+        self.conv0, self.conv_spatial = self._make_depthwise_pair(dim)
         self.deform_conv = DeformConvPack(in_channels=dim, out_channels=dim, kernel_size=(3, 3, 3), stride=1, padding=1)
         self.conv1 = nn.Conv3d(dim, dim, 1)
 
@@ -56,9 +61,9 @@ class _LKA3dTokensFn(Function):
     """Whole block on the token tensor [B, N, C] (channels-last end to end, no permutes)."""
 
     @staticmethod
-    def forward(ctx, x, dims, *params):
-        y, saved = ops.lka3d_attention_tokens_forward(x, params, dims)
-        ctx.dims = dims
+    def forward(ctx, x, dims, variant, *params):
+        y, saved = ops.lka3d_attention_tokens_forward(x, params, dims, variant)
+        ctx.dims, ctx.variant = dims, variant
         ctx.save_for_backward(x, saved, *params)
         return y
 
@@ -66,19 +71,25 @@ class _LKA3dTokensFn(Function):
     @once_differentiable
     def backward(ctx, gy):
         x, saved, *params = ctx.saved_tensors
-        gx, grads = ops.lka3d_attention_tokens_backward(x, params, gy, saved, ctx.dims)
-        return (gx, None, *grads)
+        gx, grads = ops.lka3d_attention_tokens_backward(x, params, gy, saved, ctx.dims, ctx.variant)
+        return (gx, None, None, *grads)
 
 
 class LKA_Attention3d_deform(nn.Module):
     """transformerblock.py:655-673."""
 
+    GATING_UNIT = LKA3d_deform
+
     def __init__(self, d_model):
         super().__init__()
         self.proj_1 = nn.Conv3d(d_model, d_model, 1)
         self.activation = nn.GELU()
-        self.spatial_gating_unit = LKA3d_deform(d_model)
+        self.spatial_gating_unit = self.GATING_UNIT(d_model)
         self.proj_2 = nn.Conv3d(d_model, d_model, 1)
+
+    @property
+    def variant(self):
+        return self.spatial_gating_unit.VARIANT
 
     def block_params(self):
         """The 14 tensors in ``dlka_lka3d_params`` order (include/dlka.h)."""
@@ -90,6 +101,10 @@ class LKA_Attention3d_deform(nn.Module):
 
     def forward_volume(self, x):
         """x: [B, C, H, W, D] volume -> same shape (the block without the token<->volume permutes)."""
+        if self.variant != 0:   # the fused NCDHW entry point assumes the Synapse depthwise pair: other variants compose the per-op kernels
+            p1, p2 = self.proj_1, self.proj_2
+            a = nn_ops.gelu(nn_ops.conv3d(x, p1.weight, p1.bias))
+            return nn_ops.conv3d(self.spatial_gating_unit(a), p2.weight, p2.bias) + x
         return _LKA3dAttentionFn.apply(x, *self.block_params())
 
     def forward(self, x, B, C, H, W, D):
@@ -98,10 +113,11 @@ class LKA_Attention3d_deform(nn.Module):
         # torch.autocast(dtype=torch.bfloat16) the block takes bf16 activations with fp32 parameters and accumulation.
         act = ops.autocast_activation_dtype(x)
         fp32_params = self.proj_1.weight.dtype == torch.float32
-        if act != x.dtype and fp32_params and ops.lka3d_tokens_supported(act, B, C, H, W, D):
+        v = self.variant
+        if act != x.dtype and fp32_params and ops.lka3d_tokens_supported(act, B, C, H, W, D, v):
             x = x.to(act)   # (one cast: the support query takes the dtype, not a tensor)
-        if fp32_params and ops.lka3d_tokens_supported(x.dtype, B, C, H, W, D):
-            return _LKA3dTokensFn.apply(x, (H, W, D), *self.block_params())
+        if fp32_params and ops.lka3d_tokens_supported(x.dtype, B, C, H, W, D, v):
+            return _LKA3dTokensFn.apply(x, (H, W, D), v, *self.block_params())
         if x.dtype != self.proj_1.weight.dtype:   # general path: one dtype for activations and parameters
             x = x.to(self.proj_1.weight.dtype)
         # General path (any C / dtype): the reference's own data movement around the NCDHW block.
@@ -115,22 +131,22 @@ class _TBlock3dFn(Function):
     """The whole wrapper block: one C-ABI call per direction (``dlka_tblock3d_forward/backward``)."""
 
     @staticmethod
-    def forward(ctx, x, x_planar, dims, drop_mask, training, bn_stats, eps, *params):
+    def forward(ctx, x, x_planar, dims, drop_mask, training, bn_stats, eps, variant, *params):
         tparams, lka_params = params[:12], params[12:]
-        y, saved = ops.tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_stats, dims, eps[0], eps[1])
-        ctx.cfg = (x_planar, dims, training, tuple(x.shape), [p is not None for p in tparams])
+        y, saved = ops.tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_stats, dims, eps[0], eps[1], variant)
+        ctx.cfg = (x_planar, dims, training, tuple(x.shape), [p is not None for p in tparams], variant)
         ctx.save_for_backward(saved, bn_stats, drop_mask, *[p for p in params if p is not None])
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x_planar, dims, training, xshape, present = ctx.cfg
+        x_planar, dims, training, xshape, present, variant = ctx.cfg
         saved, bn_stats, drop_mask, *ps = ctx.saved_tensors
         it = iter(ps)
         tparams = [next(it) if here else None for here in present]
         lka_params = list(it)
-        gx, tg, lg = ops.tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, gy, saved, dims)
+        gx, tg, lg = ops.tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, gy, saved, dims, variant)
         if x_planar:   # gradient w.r.t. the NCDHW input: tokens -> NCDHW.  A contiguous tensor, not the permuted view: the producer of x is a
             # torch layer whose backward (MIOpen) falls to its naive "nonpacked" kernels on a strided grad_output (profiles/r03e: 61 % of a
             # full-net step)
@@ -138,7 +154,7 @@ class _TBlock3dFn(Function):
             gx = ops.ndhwc_to_ncdhw(gx.view(B, *xshape[2:], C))
         else:
             gx = gx.view(xshape)
-        return (gx, None, None, None, None, None, None, *tg, *lg)
+        return (gx, None, None, None, None, None, None, None, *tg, *lg)
 
 
 class TransformerBlock_3D_single_deform_LKA(nn.Module):
@@ -150,6 +166,7 @@ class TransformerBlock_3D_single_deform_LKA(nn.Module):
     the layout and reads the tokens in place.  ``deformablelka_amd.network`` sets it on the blocks it chains."""
 
     keep_channels_last = False
+    EPA_BLOCK = LKA_Attention3d_deform
 
     def __init__(self, input_size: int, hidden_size: int, proj_size: int, num_heads: int, dropout_rate: float = 0.0, pos_embed=False) -> None:
         super().__init__()
@@ -159,7 +176,7 @@ class TransformerBlock_3D_single_deform_LKA(nn.Module):
             raise ValueError("hidden_size should be divisible by num_heads.")
         self.norm = nn.LayerNorm(hidden_size)
         self.gamma = nn.Parameter(1e-6 * torch.ones(hidden_size), requires_grad=True)
-        self.epa_block = LKA_Attention3d_deform(d_model=hidden_size)
+        self.epa_block = self.EPA_BLOCK(d_model=hidden_size)
         self.conv51 = UnetResBlock(3, hidden_size, hidden_size, kernel_size=3, stride=1, norm_name="batch")
         self.conv8 = nn.Sequential(nn.Dropout3d(0.1, False), nn.Conv3d(hidden_size, hidden_size, 1))
         self.pos_embed = None
@@ -184,7 +201,8 @@ class TransformerBlock_3D_single_deform_LKA(nn.Module):
             # The wrapper block (LayerNorm, UnetResBlock's BatchNorm statistics, the gamma residual) runs in fp32 on this path: a bf16 tensor
             # reaching it — e.g. from a torch layer inside torch.autocast — is widened here, explicitly (no silent dtype mismatch further down).
             x = x.float()
-        if not ops.tblock3d_supported(x, B, C, H, W, D):
+        v = self.epa_block.variant
+        if not ops.tblock3d_supported(x, B, C, H, W, D, v):
             raise NotImplementedError(f"TransformerBlock_3D_single_deform_LKA on the HIP path needs float32 and hidden_size in {{32, 64, 128, 256}}; "
                                       f"got {x.dtype}, C={C}")
         tokens = x.permute(0, 2, 3, 4, 1)
@@ -200,7 +218,7 @@ class TransformerBlock_3D_single_deform_LKA(nn.Module):
             stats = torch.empty(6 * C, dtype=torch.float32, device=x.device)
         else:
             stats = torch.cat([bn_eval_stats(c.norm1), bn_eval_stats(c.norm2)])
-        y = _TBlock3dFn.apply(xin, planar, (H, W, D), mask, training, stats, (self.norm.eps, c.norm1.eps), *self.wrapper_params(),
+        y = _TBlock3dFn.apply(xin, planar, (H, W, D), mask, training, stats, (self.norm.eps, c.norm1.eps), v, *self.wrapper_params(),
                               *self.epa_block.block_params())
         if training:
             bn_update_running(c.norm1, stats[:3 * C])

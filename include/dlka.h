@@ -222,11 +222,19 @@ typedef struct dlka_lka2d_grads {
 
 /* Replaces  deformable_LKA_Attention.forward (deformable_LKA.py:133-140) incl. deformable_LKA.forward (:98-104)
  *           and DeformConv.forward (:27-30).  x, y: [B][C][H][W]. */
+/* dtype DLKA_BF16 (BASELINE.json config 2, "bf16 training"): x / y / grad_y / grad_x and the saved activations are bf16 storage, the
+ * PARAMETERS and their gradients stay fp32 masters, offsets and accumulation are fp32, and the chain that decides the sampling cells
+ * (a -> offset net 5 -> DDW5 -> offset net 7) is kept in fp32.  Channels-last fast path only: C / 32 in {1, 2, 3, 4, 6, 8, 12};
+ * other widths return DLKA_ERR_UNSUPPORTED for DLKA_BF16. */
 size_t dlka_lka2d_saved_bytes(int B, int C, int H, int W, int dtype);
 size_t dlka_lka2d_workspace_bytes(int B, int C, int H, int W, int dtype);
 int dlka_lka2d_attention_forward(const void *x, const dlka_lka2d_params *p, void *y,
                                  void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes,
                                  int B, int C, int H, int W, int dtype, void *stream);
+/* Forces (1) / releases (0) the general NCHW kernels for blocks the channels-last fast path would take; returns the previous setting.  Initial
+ * value: 1 iff the environment variable DLKA_LKA2D_GENERAL is set when the first 2-D block call is made.  For A/B runs and the parity test of
+ * one path against the other; the size queries return the maximum over both paths, so a switch never under-sizes a buffer. */
+int dlka_lka2d_force_general(int on);
 int dlka_lka2d_attention_backward(const void *x, const dlka_lka2d_params *p, const void *grad_y,
                                   const void *saved, size_t saved_bytes,
                                   void *grad_x, const dlka_lka2d_grads *grads,
@@ -389,6 +397,37 @@ int dlka_deform_dwconv2d_forward_cl(const void *x, const void *offset, const voi
 int dlka_deform_dwconv2d_backward_cl(const void *x, const void *offset, const void *weight, const void *grad_out,
                                      void *grad_x, void *grad_offset, void *grad_weight,
                                      void *workspace, size_t workspace_bytes, const dlka_conv_geom *g, int dtype, void *stream);
+
+/* =======================================================================================
+ * Net variants of the 3-D block (the depthwise pair conv0 / conv_spatial of LKA3d_deform)
+ * =======================================================================================
+ * DLKA_LKA3D_SYNAPSE  3D/d_lka_former/network_architecture/synapse/transformerblock.py:637-638 (and the pancreas copy): 5^3 pad 2, then
+ *                     7^3 dilation 3 pad 9, at every width.  All entry points without the _v suffix.
+ * DLKA_LKA3D_ACDC     3D/d_lka_former/network_architecture/acdc/transformerblock.py:213-237: C <= 64: 5^3 pad 2, (5,7,7) dilation 3 pad (6,9,9);
+ *                     C = 128: 5^3 pad 2, (3,5,5) dilation (1,3,3) pad (1,6,6); C = 256: 3^3 pad 1, 3^3 pad 1 — the stem (1,4,4) net whose stage
+ *                     shapes BASELINE.json config 5's 40x224x224 tiles divide through (acdc/model_components.py:21).  conv0_w / conv_spatial_w
+ *                     (and their gradients) have the variant's kernel shapes.
+ * The _v entry points are their un-suffixed namesakes with the variant as an extra argument (before `stream`). */
+typedef enum dlka_lka3d_variant { DLKA_LKA3D_SYNAPSE = 0, DLKA_LKA3D_ACDC = 1 } dlka_lka3d_variant;
+int    dlka_lka3d_tokens_supported_v(int B, int C, int D, int H, int W, int dtype, int variant);
+size_t dlka_lka3d_tokens_saved_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
+size_t dlka_lka3d_tokens_workspace_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
+int dlka_lka3d_attention_tokens_forward_v(const void *x, const dlka_lka3d_params *p, void *y, void *saved, size_t saved_bytes,
+                                          void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant, void *stream);
+int dlka_lka3d_attention_tokens_backward_v(const void *x, const dlka_lka3d_params *p, const void *grad_y, const void *saved, size_t saved_bytes,
+                                           void *grad_x, const dlka_lka3d_grads *grads, void *workspace, size_t workspace_bytes,
+                                           int B, int C, int D, int H, int W, int dtype, int variant, void *stream);
+int    dlka_tblock3d_supported_v(int B, int C, int D, int H, int W, int dtype, int variant);
+size_t dlka_tblock3d_saved_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
+size_t dlka_tblock3d_workspace_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
+int dlka_tblock3d_forward_v(const void *x, int x_planar, const dlka_tblock3d_params *p, const dlka_lka3d_params *lka,
+                            const void *drop_mask, int training, void *bn_stats, void *y, void *saved, size_t saved_bytes,
+                            void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, float ln_eps, float bn_eps,
+                            int dtype, int variant, void *stream);
+int dlka_tblock3d_backward_v(const dlka_tblock3d_params *p, const dlka_lka3d_params *lka, const void *drop_mask, int training,
+                             const void *bn_stats, const void *grad_y, const void *saved, size_t saved_bytes, void *grad_x,
+                             const dlka_tblock3d_grads *grads, const dlka_lka3d_grads *lka_grads,
+                             void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant, void *stream);
 
 /* =======================================================================================
  * Launch trace — measurement aid (no reference counterpart; the reference has no profiling hooks)

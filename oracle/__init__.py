@@ -12,8 +12,12 @@ path, but its native op builds for gfx950 (``oracle/ref.mk`` -> ``oracle/_ref/D3
 checked against its recorded outputs on CPU (tests/golden/d3d_reference_vectors.pt, tests/test_oracle_vs_reference_vectors.py)
 and against the op itself on the MI355X (tests/test_ref_d3d_gpu.py), besides derived known-answer properties and the golden
 vectors generated through the reference's Python modules (tests/golden/make_golden.py).
-Parity status (2-D, torchvision 0.12 deform_conv2d): **unpinned** — torchvision is neither vendored by the reference nor
-installed here; the restatement follows its published algorithm and is anchored on the reference's call sites only.
+Parity status (2-D, torchvision 0.12 deform_conv2d): **pinned by the reference's own 3-D op**.  torchvision is neither vendored by the
+reference nor installed here, but the D3D kernels compute exactly the 2-D operator on a depth-1 embedding (depth axis of size 1, kd = 1, pad_d = 0,
+zero depth offsets: qd = 0 -> floor 0, ld = 0, upper-depth corner dropped; deform_im2col_cuda.cuh:26-72,245-259).  ``oracle/_ref/D3D.so`` run on
+that embedding pins the 2-D restatement on the MI355X (tests/test_ref_d3d_2d_gpu.py) and, through recorded vectors
+(tests/golden/d3d_reference_vectors_2d.pt), in the CPU suite (tests/test_oracle_2d_pinned.py).  One line stays restated from torchvision's
+published kernel: its coordinate weight is unguarded, which differs from D3D's at q == -1 exactly (isolated in its own test).
 """
 from __future__ import annotations
 

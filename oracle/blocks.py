@@ -17,7 +17,7 @@ def bf16_storage(t):
     return t + (t.bfloat16().float() - t).detach()
 
 
-def lka3d_attention_volume(x, P, store=None, chain_store=None):
+def lka3d_attention_volume(x, P, store=None, chain_store=None, offsets_override=None):
     """LKA_Attention3d_deform on an NCDHW volume — 3D/d_lka_former/network_architecture/synapse/transformerblock.py:664-673
     (minus the token permutes), LKA3d_deform.forward :644-652, DeformConvPack.forward synapse/deform_conv.py:93-105.
     store: None = the reference's fp32 block; ``bf16_storage`` = the model of the DLKA_BF16 path: the same arithmetic with every activation
@@ -33,10 +33,18 @@ def lka3d_attention_volume(x, P, store=None, chain_store=None):
     a = F.gelu(F.conv3d(x, P["proj_1.weight"], P["proj_1.bias"]))                # :667-668
     u = st(a)                                                                    # :645 (the gate's copy)
     s = "spatial_gating_unit."
-    attn = cs(F.conv3d(cs(a), P[s + "conv0.weight"], P[s + "conv0.bias"], padding=2, groups=C))                        # :646
-    attn = cs(F.conv3d(attn, P[s + "conv_spatial.weight"], P[s + "conv_spatial.bias"], padding=9, dilation=3, groups=C))  # :647
+    # the depthwise pair by its weight shapes: Synapse 5^3 p2 + 7^3 dil 3 p9 (:637-638); ACDC (acdc/transformerblock.py:213-237) (5,7,7) dil 3
+    # p (6,9,9) / (3,5,5) dil (1,3,3) p (1,6,6) / 3^3 p1 after 5^3 p2 / 3^3 p1 — "same" padding with dilation 3 on every axis whose kernel > 3
+    k0, k1 = tuple(P[s + "conv0.weight"].shape[2:]), tuple(P[s + "conv_spatial.weight"].shape[2:])
+    d1 = {(7, 7, 7): (3, 3, 3), (5, 7, 7): (3, 3, 3), (3, 5, 5): (1, 3, 3), (3, 3, 3): (1, 1, 1)}[k1]
+    p0 = tuple(k // 2 for k in k0)
+    p1 = tuple(d * (k - 1) // 2 for k, d in zip(k1, d1))
+    attn = cs(F.conv3d(cs(a), P[s + "conv0.weight"], P[s + "conv0.bias"], padding=p0, groups=C))                        # :646
+    attn = cs(F.conv3d(attn, P[s + "conv_spatial.weight"], P[s + "conv_spatial.bias"], padding=p1, dilation=d1, groups=C))  # :647
     attn = attn.contiguous()                                                     # :648
     off = F.conv3d(attn, P[s + "deform_conv.conv_offset.weight"], P[s + "deform_conv.conv_offset.bias"], stride=1, padding=1)
+    if offsets_override is not None:   # VALUES from another implementation's forward pass, gradient path unchanged (straight through): both sides
+        off = off + (offsets_override - off).detach()   # then sample the same cells, which removes grad_offset's discontinuity from a comparison
     attn = st(oracle.DeformConv3dFunction.apply(st(attn), off, P[s + "deform_conv.weight"], P[s + "deform_conv.bias"],
                                                 1, 1, 1, 1, 1, 64))              # deform_conv.py:95-105
     attn = F.conv3d(attn, P[s + "conv1.weight"], P[s + "conv1.bias"])            # :650  (the gate consumes conv1's fp32 value in the fused epilogue)
@@ -44,10 +52,10 @@ def lka3d_attention_volume(x, P, store=None, chain_store=None):
     return st(y + shortcut)                                                      # :671
 
 
-def lka3d_attention_tokens(x, P, B, C, H, W, D, store=None, chain_store=None):
+def lka3d_attention_tokens(x, P, B, C, H, W, D, store=None, chain_store=None, offsets_override=None):
     """The full forward(x, B, C, H, W, D) on (B, N, C) tokens, :664-673."""
     v = x.permute(0, 2, 1).reshape(B, C, H, W, D)
-    v = lka3d_attention_volume(v, P, store, chain_store)
+    v = lka3d_attention_volume(v, P, store, chain_store, offsets_override)
     return v.reshape(B, C, H * W * D).permute(0, 2, 1)
 
 
@@ -67,7 +75,7 @@ def unet_res_block(x, P, prefix, training, stats_out=None):
     return F.leaky_relu(out + x, 0.01)                                           # :77-79
 
 
-def transformer_block_3d(x, P, training=False, drop_mask=None):
+def transformer_block_3d(x, P, training=False, drop_mask=None, offsets_override=None):
     """TransformerBlock_3D_single_deform_LKA.forward — transformerblock.py:617-630.  drop_mask: the (B, C) multipliers of
     conv8[0] = Dropout3d(0.1) (None = eval / no dropout)."""
     B, C, H, W, D = x.shape
@@ -76,7 +84,7 @@ def transformer_block_3d(x, P, training=False, drop_mask=None):
         t = t + P["pos_embed"]                                                   # :622-623
     n = F.layer_norm(t, (C,), P["norm.weight"], P["norm.bias"], 1e-5)
     lka = {k[len("epa_block."):]: v for k, v in P.items() if k.startswith("epa_block.")}
-    attn = t + P["gamma"] * lka3d_attention_tokens(n, lka, B, C, H, W, D)        # :624
+    attn = t + P["gamma"] * lka3d_attention_tokens(n, lka, B, C, H, W, D, offsets_override=offsets_override)        # :624
     skip = attn.reshape(B, H, W, D, C).permute(0, 4, 1, 2, 3)                    # :626
     a = unet_res_block(skip, P, "conv51.", training)                             # :627
     if drop_mask is not None:
@@ -84,24 +92,30 @@ def transformer_block_3d(x, P, training=False, drop_mask=None):
     return skip + F.conv3d(a, P["conv8.1.weight"], P["conv8.1.bias"])            # :628
 
 
-def deform_conv_2d_pack(x, P, prefix, k, pad, dil, groups):
-    """2-D ``DeformConv.forward`` — 2D/deformable_LKA/deformable_LKA.py:27-30."""
+def deform_conv_2d_pack(x, P, prefix, k, pad, dil, groups, sample_store=None):
+    """2-D ``DeformConv.forward`` — 2D/deformable_LKA/deformable_LKA.py:27-30.  sample_store: rounding applied to the tensor the deformable conv
+    SAMPLES (the offset net always reads x as it is)."""
     off = F.conv2d(x, P[prefix + "offset_net.weight"], P[prefix + "offset_net.bias"], padding=pad, dilation=dil)
-    return oracle.DeformConv2dFunction.apply(x, off, P[prefix + "deform_conv.weight"], None, 1, pad, dil)
+    xs = x if sample_store is None else sample_store(x)
+    return oracle.DeformConv2dFunction.apply(xs, off, P[prefix + "deform_conv.weight"], None, 1, pad, dil)
 
 
-def lka2d_attention(x, P):
-    """deformable_LKA_Attention.forward — deformable_LKA.py:133-140 with deformable_LKA.forward :98-104."""
+def lka2d_attention(x, P, store=None):
+    """deformable_LKA_Attention.forward — deformable_LKA.py:133-140 with deformable_LKA.forward :98-104.
+    store: None = the reference's fp32 block; ``bf16_storage`` = the model of the DLKA_BF16 2-D path: every activation that path writes to HBM as
+    bf16 is rounded where it is written; the chain that decides the sampling cells (a -> offset net 5 -> t1 = DDW5(a) -> offset net 7) stays fp32
+    there (dlka_capi_cl.hip, Lka2dCl) and is not rounded here either."""
+    st = store if store is not None else (lambda t: t)
     C = x.shape[1]
     shortcut = x.clone()
     a = F.gelu(F.conv2d(x, P["proj_1.weight"], P["proj_1.bias"]))
-    u = a.clone()
+    u = st(a)
     s = "spatial_gating_unit."
-    attn = deform_conv_2d_pack(a, P, s + "conv0.", 5, 2, 1, C)                   # :93
-    attn = deform_conv_2d_pack(attn, P, s + "conv_spatial.", 7, 9, 3, C)         # :94
+    attn = deform_conv_2d_pack(a, P, s + "conv0.", 5, 2, 1, C)                   # :93   fp32 in, fp32 out (t1_32)
+    attn = st(deform_conv_2d_pack(attn, P, s + "conv_spatial.", 7, 9, 3, C))     # :94   samples the fp32 t1, t2 stored as bf16
     attn = F.conv2d(attn, P[s + "conv1.weight"], P[s + "conv1.bias"])
-    y = F.conv2d(u * attn, P["proj_2.weight"], P["proj_2.bias"])
-    return y + shortcut
+    y = F.conv2d(st(u * attn), P["proj_2.weight"], P["proj_2.bias"])
+    return st(y + shortcut)
 
 
 def randomize_offsets_(module, std=0.05, seed=123):

