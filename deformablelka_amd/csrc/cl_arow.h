@@ -21,7 +21,8 @@ struct ARow {
     {
         if (tap != cur_tap) {   // wave-uniform
             cur_tap = tap;
-            const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
+            int ti, tj, tk;
+            tap_decode(tap, p.kw, p.kh, ti, tj, tk);
             if (AMODE == 0 || AMODE == 2) {
                 const int zd = d0 + ti * p.dd - p.pd, zh = h0 + tj * p.dh - p.ph, zw = w0 + tk * p.dw - p.pw;
                 const bool ok = row_ok & ((unsigned)zd < (unsigned)p.D) & ((unsigned)zh < (unsigned)p.H) & ((unsigned)zw < (unsigned)p.W);

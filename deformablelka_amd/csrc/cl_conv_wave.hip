@@ -56,8 +56,9 @@ __global__ __launch_bounds__(256) void cl_conv_wave_kernel(IgemmArgs p)
     f32x4 bbuf[DEPTH][NB];   // [(part * 2 + mf) * NT + t]
     // A rows and B records of one unit into a register set (all loads unconditional buffer loads)
     auto issue = [&](int unit, float *ad, f32x4 *bd) {
-        const int tap = unit / nchunk;
-        arow.fetch(p, rin, tap, unit - tap * nchunk, h, row_ok, b, v, d0, h0, w0, ad);
+        int ck;
+        const int tap = divmod_fast(unit, nchunk, ck);
+        arow.fetch(p, rin, tap, ck, h, row_ok, b, v, d0, h0, w0, ad);
         const unsigned ub = (unsigned)unit * unit_bytes + blane;
 #pragma unroll
         for (int part = 0; part < SPLIT; ++part)

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
         onx[0] = op[0]; onx[1] = op[p.N]; onx[2] = op[2 * (long)p.N];
     };
     auto describe = [&](int tap) {
-        const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
+        int ti, tj, tk;
+        tap_decode(tap, p.kw, p.kh, ti, tj, tk);
         wave_sync();
         if (h == 0) {
             RowDesc r;
@@ -137,7 +138,10 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
     const int nstage = (tap_hi - tap_lo) * ncb * nkc;
     f32x4 wreg;
     auto load_w = [&](int s) {
-        const int kc = s % nkc, cc = cc_lo + (s / nkc) % ncb, tap = tap_lo + s / (nkc * ncb);
+        int kc, ccr;
+        const int sq = divmod_fast(s, nkc, kc);
+        const int tq = divmod_fast(sq, ncb, ccr);
+        const int cc = cc_lo + ccr, tap = tap_lo + tq;
         const int rr = tid >> 3, c4 = tid & 7;
         wreg = *(reinterpret_cast<const f32x4 *>(p.wp + ((long)tap * p.CoutP + kc * 32 + rr) * p.C + cc * 32) + c4);
     };
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
             if (!ok || tap >= p.K) continue;
             int ti, tj, tk;
             if (p.kw == 3 && p.kh == 3) { ti = tap / 9; const int rr = tap - 9 * ti; tj = rr / 3; tk = rr - 3 * tj; }   // uniform
-            else { tk = tap % p.kw; tj = (tap / p.kw) % p.kh; ti = tap / (p.kw * p.kh); }
+            else tap_decode(tap, p.kw, p.kh, ti, tj, tk);
             LaneTap s;
             lane_tap(s, offv[r4][0], offv[r4][1], offv[r4][2], vd + ti * p.dd - p.pd, vh + tj * p.dh - p.ph, vw + tk * p.dw - p.pw, p.D, p.H, p.W);
             if (!s.okm) continue;
@@ -748,7 +752,7 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
                 const int tap = tap_ < p.K ? tap_ : 0;
                 int ti, tj, tk;
                 if (p.kw == 3 && p.kh == 3) { ti = tap / 9; const int rr = tap - 9 * ti; tj = rr / 3; tk = rr - 3 * tj; }   // uniform
-                else { tk = tap % p.kw; tj = (tap / p.kw) % p.kh; ti = tap / (p.kw * p.kh); }
+                else tap_decode(tap, p.kw, p.kh, ti, tj, tk);
                 // the one sampling rule (deform_sample.h: deform_im2col_cuda.cuh:244-259); outside the guard the cell is (0,0,0) and `valid` is false
                 int zd, zh, zw;
                 float ld, lh, lw;

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
 
 #define DLKA_LOAD_B(unit_)                                                                         \
     {                                                                                              \
-        const int tap_ = (unit_) / nchunk, ck_ = (unit_) - tap_ * nchunk;                          \
+        int ck_;                                                                                   \
+        const int tap_ = divmod_fast((unit_), nchunk, ck_);                                        \
         const float *src_ = p.wp + ((long)tap_ * p.CinP + ck_ * 32) * p.NP + n0;                   \
         _Pragma("unroll") for (int e = 0; e < BV; ++e) {                                           \
             const int idx_ = tid + e * 256;                                                        \
@@ -79,10 +80,12 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
     if (unit_lo < unit_hi) load_offsets(tap_first);
     // describe (when the tap changes) and issue the 32 corner loads of one unit
     auto issue = [&](int unit) {
-        const int tap = unit / nchunk, ck = unit - tap * nchunk;
+        int ck;
+        const int tap = divmod_fast(unit, nchunk, ck);
         if (tap != cur_tap) {   // uniform
             cur_tap = tap;
-            const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
+            int ti, tj, tk;
+            tap_decode(tap, p.kw, p.kh, ti, tj, tk);
             wave_sync();        // every lane has consumed the previous table
             if (h == 0) {
                 RowDesc r;
@@ -185,13 +188,14 @@ __global__ __launch_bounds__(512, 4) void cl_deform_fwd16_kernel(IgemmArgs p)
     constexpr unsigned SB = sizeof(T);
     constexpr int WAVES = 8;
     constexpr int SROW = 36;   // padded sample-tile row (floats)
+    constexpr int TGRP = 4;    // taps described at once: lane (row i, sub-tap g4) — all 64 lanes work (a per-tap description keeps 16 of them busy)
     using GG = GatherGeom<T>;
     constexpr int NG = GG::NG / 2;   // row groups of a 16-row tile: fp32 2 x 8 rows, bf16 1 x 16 rows
     __shared__ __attribute__((aligned(16))) float Bs[2][32 * 32];
     __shared__ __attribute__((aligned(16))) float Ssm[WAVES][16 * SROW];
-    __shared__ __attribute__((aligned(16))) float Dsm[WAVES][16 * GATHER_DESCW_WORDS];
+    __shared__ __attribute__((aligned(16))) float Dsm[WAVES][TGRP * 16 * GATHER_DESCW_WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 15, g4 = lane >> 4;                                  // MFMA roles: row / column index, k group
+    const int i = lane & 15, g4 = lane >> 4;                                  // MFMA roles: row / column index, k group; description role: row, sub-tap
     const int gr = lane >> GG::PSHIFT, gp = lane & ((1 << GG::PSHIFT) - 1);   // gather roles: row gr of each group of RPI, 16-byte piece gp
     const int bx = DLKA_XCD_BX(p.xcd_nx);
     if (bx < 0) return;
@@ -216,54 +220,67 @@ __global__ __launch_bounds__(512, 4) void cl_deform_fwd16_kernel(IgemmArgs p)
 
     f32x4 breg = {0.f, 0.f, 0.f, 0.f};
     GatherPiece<T> xr[NG][8];   // gathered corner pieces of the next unit, in flight
-    int cur_tap = -1;
+    int cur_grp = -1, cur_tap = 0;
     auto load_b = [&](int unit) {   // 32 x 32 weight chunk: one 16-byte piece per thread of the first four waves
         if (tid < 256) {
-            const int tap = unit / nchunk, ck = unit - tap * nchunk;
+            int ck;
+            const int tap = divmod_fast(unit, nchunk, ck);
             const float *src = p.wp + ((long)tap * p.CinP + ck * 32) * p.NP + n0;
             breg = reinterpret_cast<const f32x4 *>(src + (long)(tid >> 3) * p.NP)[tid & 7];
         }
     };
-    float onx[3] = {0.f, 0.f, 0.f};   // the next tap's offsets, requested one tap ahead (see cl_deform_fwd_kernel)
+    // s_memtime stamps (round 3, scripts/fwd_stamps.py history in profiles/r04_notes.md) showed a THIRD of every (tile, tap) step going into the
+    // description of the tap — offsets, guard, floor, corner mask, weights — executed as full-wave instructions for 16 useful lanes, on the critical
+    // path of a kernel that is bound by its per-step instruction chain.  Four taps are therefore described at once, lane = (row, sub-tap): the same
+    // instructions, every fourth tap.  The offsets of a group are requested a whole group ahead.
+    float onx[3] = {0.f, 0.f, 0.f};
     const int tap_last = (unit_hi - 1) / nchunk;
-    auto load_offsets = [&](int tap) {
-        if (g4 == 0 && row_ok && tap <= tap_last) {
+    auto load_offsets = [&](int grp) {
+        const int tap = TGRP * grp + g4;
+        if (row_ok && tap <= tap_last && tap < p.K) {
             const float *op = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
             onx[0] = op[0]; onx[1] = op[p.N]; onx[2] = op[2 * (long)p.N];
         }
     };
-    if (unit_lo < unit_hi) load_offsets(unit_lo / nchunk);
+    if (unit_lo < unit_hi) load_offsets((unit_lo / nchunk) / TGRP);
     auto issue = [&](int unit) {
-        const int tap = unit / nchunk, ck = unit - tap * nchunk;
-        if (tap != cur_tap) {   // uniform
-            cur_tap = tap;
-            const int tk = tap % p.kw, tj = (tap / p.kw) % p.kh, ti = tap / (p.kw * p.kh);
+        int ck;
+        const int tap = divmod_fast(unit, nchunk, ck);
+        const int grp = tap / TGRP;
+        cur_tap = tap;
+        if (grp != cur_grp) {   // uniform
+            cur_grp = grp;
+            const int mytap = TGRP * grp + g4;
+            int ti, tj, tk;
+            tap_decode(mytap < p.K ? mytap : 0, p.kw, p.kh, ti, tj, tk);
             wave_sync();        // every lane has consumed the previous table
-            if (g4 == 0) {
-                RowDesc r;
-                r.base = 0; r.okm = 0; r.ld = r.lh = r.lw = 0.f;
-                if (row_ok)
-                    r = gather_describe3(onx[0], onx[1], onx[2], p.N, b, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw, p.D, p.H, p.W);
-                gather_publish_w(Dt, i, r, rowbytes);
-            }
-            load_offsets(tap + 1);
+            RowDesc r;
+            r.base = 0; r.okm = 0; r.ld = r.lh = r.lw = 0.f;
+            r.zd = r.zh = r.zw = 0;
+            if (row_ok && mytap <= tap_last && mytap < p.K)
+                r = gather_describe3(onx[0], onx[1], onx[2], p.N, b, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw, p.D, p.H, p.W);
+            gather_publish_w(Dt, g4 * 16 + i, r, rowbytes);
+            load_offsets(grp + 1);
             wave_sync();
         }
+        const float *tab = Dt + (tap - TGRP * grp) * 16 * GATHER_DESCW_WORDS;
         const unsigned cbyte = (unsigned)(ck * 32 + GG::PE * gp) * SB;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const RowLook r = gather_lookup_d(Dt, GG::RPI * g + gr);
+            const RowLook r = gather_lookup_d(tab, GG::RPI * g + gr);
 #pragma unroll
             for (int q = 0; q < 8; ++q) xr[g][q] = gather_load<T>(rin, gather_offset(r, q, HW, p.W, rowbytes, cbyte));
         }
     };
     // interpolate, transpose through the wave-private tile, return this lane's A values: channels 8 g4 .. 8 g4 + 7 of row i
-    auto finish = [&](float *a) {
+    // (tap_of_tile: the tap the pieces in xr belong to — its weights are still in the table: a group is only re-described by a LATER issue())
+    auto finish = [&](float *a, int tap_of_tile) {
+        const float *tab = Dt + (tap_of_tile & (TGRP - 1)) * 16 * GATHER_DESCW_WORDS;
         wave_sync();   // previous tile consumed
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             float wq[8];
-            gather_lookup_weights(Dt, GG::RPI * g + gr, wq);
+            gather_lookup_weights(tab, GG::RPI * g + gr, wq);
 #pragma unroll
             for (int vv = 0; vv < GG::PE / 4; ++vv) {
                 f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
@@ -292,7 +309,7 @@ __global__ __launch_bounds__(512, 4) void cl_deform_fwd16_kernel(IgemmArgs p)
     for (int unit = unit_lo; unit < unit_hi; ++unit, buf ^= 1) {
         float a_cur[8];
         if (tid < 256) reinterpret_cast<f32x4 *>(Bs[buf])[tid] = breg;
-        finish(a_cur);      // consumes xr (the loads issued one iteration ago)
+        finish(a_cur, cur_tap);      // consumes xr (the loads issued one iteration ago, for tap cur_tap)
         __syncthreads();    // Bs[buf] staged; Bs[buf^1] (read two iterations ago) is free again
         if (unit + 1 < unit_hi) {
             load_b(unit + 1);

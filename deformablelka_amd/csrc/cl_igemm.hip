@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
     float a_cur[16], a_nxt[16];
 #define DLKA_LOAD_B(unit_)                                                                         \
     {                                                                                              \
-        const int tap_ = (unit_) / nchunk, ck_ = (unit_) - tap_ * nchunk;                          \
+        int ck_;                                                                                   \
+        const int tap_ = divmod_fast((unit_), nchunk, ck_);                                        \
         const float *src_ = p.wp + ((long)tap_ * nchunk + ck_) * UF * p.NP + (SPLIT ? 0 : n0);      \
         _Pragma("unroll") for (int e = 0; e < BV; ++e) {                                           \
             const int idx_ = tid + e * 256;                                                        \
@@ -83,8 +84,9 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
     }
     if (unit_lo < unit_hi) {
         DLKA_LOAD_B(unit_lo)
-        const int tap = unit_lo / nchunk;
-        arow.fetch(p, rin, tap, unit_lo - tap * nchunk, h, row_ok, b, v, d0, h0, w0, a_nxt);
+        int ck;
+        const int tap = divmod_fast(unit_lo, nchunk, ck);
+        arow.fetch(p, rin, tap, ck, h, row_ok, b, v, d0, h0, w0, a_nxt);
     }
     int buf = 0;
     for (int unit = unit_lo; unit < unit_hi; ++unit, buf ^= 1) {
@@ -96,8 +98,9 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
         __syncthreads();   // Bs[buf] staged; Bs[buf^1] (read two iterations ago) is free again
         if (unit + 1 < unit_hi) {
             DLKA_LOAD_B(unit + 1)
-            const int tap = (unit + 1) / nchunk;
-            arow.fetch(p, rin, tap, unit + 1 - tap * nchunk, h, row_ok, b, v, d0, h0, w0, a_nxt);
+            int ck;
+            const int tap = divmod_fast(unit + 1, nchunk, ck);
+            arow.fetch(p, rin, tap, ck, h, row_ok, b, v, d0, h0, w0, a_nxt);
         }
         if (SPLIT == 3) {
             const bf16x8 *B16 = reinterpret_cast<const bf16x8 *>(Bs[buf]);   // [(part*2 + mf)*2 + h][NPB] records of 8 bf16, part = hi, mid, lo

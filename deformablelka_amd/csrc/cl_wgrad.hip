@@ -78,7 +78,9 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
         const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / (p.W * p.H);
         auto describe_issue = [&](int t) {
             const int tap = tap0 + t;
-            const int od = (tap / (p.kw * p.kh)) * p.dd - p.pd, oh = ((tap / p.kw) % p.kh) * p.dh - p.ph, ow = (tap % p.kw) * p.dw - p.pw;
+            int ti_, tj_, tk_;
+            tap_decode(tap, p.kw, p.kh, ti_, tj_, tk_);
+            const int od = ti_ * p.dd - p.pd, oh = tj_ * p.dh - p.ph, ow = tk_ * p.dw - p.pw;
             wave_sync();
             if (h == 0) {
                 RowDesc r;

@@ -120,6 +120,27 @@ inline int xcd_min_blocks()
     return e ? atoi(e) : 16;
 }
 
+// Hot-loop index decoding WITHOUT runtime integer divisions.  A division by a run-time value compiles to ~35 dependent instructions (v_rcp_iflag,
+// v_mul_hi, corrections); s_memtime stamps inside the deformable forward kernel (scripts/fwd_stamps.py, round 3) showed "unit -> tap", "tap -> (i, j, k)"
+// and the description that follows taking a THIRD of every (tile, tap) step — five such divisions on the wave's critical path.  The D-LKA block's
+// kernels are 3^3 (2-D offset nets: 5x5, 7x7) and its channel-chunk counts are powers of two: constant divisors become multiply-shift, powers of
+// two a shift; anything else still takes the general form.  All branches are wave-uniform.
+__device__ __forceinline__ void tap_decode(int tap, int kw, int kh, int &ti, int &tj, int &tk)
+{
+    if (kw == 3 && kh == 3) { ti = tap / 9; const int r = tap - 9 * ti; tj = r / 3; tk = r - 3 * tj; }
+    else if (kw == 5 && kh == 5) { ti = tap / 25; const int r = tap - 25 * ti; tj = r / 5; tk = r - 5 * tj; }
+    else if (kw == 7 && kh == 7) { ti = tap / 49; const int r = tap - 49 * ti; tj = r / 7; tk = r - 7 * tj; }
+    else { tk = tap % kw; tj = (tap / kw) % kh; ti = tap / (kw * kh); }
+}
+// q = x / n, r = x % n for x >= 0, n > 0
+__device__ __forceinline__ int divmod_fast(int x, int n, int &r)
+{
+    if ((n & (n - 1)) == 0) { const int sh = __builtin_ctz((unsigned)n); r = x & (n - 1); return x >> sh; }
+    const int q = x / n;
+    r = x - q * n;
+    return q;
+}
+
 #define DLKA_THREADS 256
 
 // Every kernel launch of the library goes through DLKA_LAUNCH.  With the launch trace switched on (dlka_trace_start, include/dlka.h: a

@@ -72,8 +72,17 @@ class Convolution(nn.Sequential):
 
     def forward(self, x):
         c = self.conv
-        if not (self.gemm_path and x.is_cuda and x.dtype == torch.float32 and c.weight.dtype == torch.float32 and not torch.is_autocast_enabled()):
+        if not (self.gemm_path and x.is_cuda and c.weight.dtype == torch.float32 and x.dtype in (torch.float32, torch.bfloat16)):
             return c(x)
+        if x.dtype != torch.float32:   # (a bf16 tensor from an autocast region: the re-expressions below are fp32 — widen explicitly, do not fall back to
+            x = x.float()              #  the MIOpen 3-D paths this class exists to avoid)
+        if torch.is_autocast_enabled():
+            with torch.autocast(x.device.type, enabled=False):
+                return self._forward_fp32(x)
+        return self._forward_fp32(x)
+
+    def _forward_fp32(self, x):
+        c = self.conv
         k, s, p = tuple(c.kernel_size), tuple(c.stride), tuple(c.padding)
         B, Cin = x.shape[:2]
         if isinstance(c, nn.ConvTranspose3d):

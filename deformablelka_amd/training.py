@@ -65,8 +65,13 @@ def deep_supervision_loss(outputs, target, weights=None, base_loss: Callable = N
 
 def run_iteration(net: nn.Module, optimizer, data: torch.Tensor, target, loss_fn: Callable = deep_supervision_loss, do_backprop: bool = True,
                   clip_norm: float = 12.0, bf16_autocast: bool = False, forward: Callable = None):
-    """:259-309: zero_grad, forward, loss, backward, clip_grad_norm_(12), step.  ``bf16_autocast`` runs the D-LKA blocks on bf16 activations
-    (their autocast policy; bf16 needs no gradient scaler — the reference's fp16 branch does, :281-290)."""
+    """:259-309: zero_grad, forward, loss, backward, clip_grad_norm_(12), step.  ``bf16_autocast`` wraps forward + loss in
+    ``torch.autocast(dtype=bfloat16)`` (bf16 needs no gradient scaler — the reference's fp16 branch does, :281-290).  What that changes HERE: torch's own
+    layers (norms, activations, the loss) follow autocast; the 21 ``TransformerBlock_3D_single_deform_LKA`` wrappers keep their fused fp32 path — their
+    LayerNorm / BatchNorm statistics and residual stream are fp32 by design, and a bf16 tensor reaching one is widened explicitly — and the conv
+    re-expressions of ``network.Convolution`` stay fp32 GEMMs.  The bf16-ACTIVATION kernels are the block-level entry points
+    (``LKA_Attention3d_deform`` / ``deformable_LKA_Attention`` under autocast, ``DLKABlockStack(dtype=bfloat16)``), which is what ``bench.py --dtype
+    bf16`` measures."""
     fwd = forward if forward is not None else net      # (modules whose forward takes more than the data tensor)
     optimizer.zero_grad()
     if bf16_autocast:

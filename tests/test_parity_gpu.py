@@ -257,6 +257,24 @@ def test_lka2d_attention_bf16_real_shapes_vs_oracle(C, hw):
     parity.check_lka2d_attention_bf16(DEV, 2, C, hw, hw, report=True)
 
 
+def test_lka2d_attention_bf16_autocast_policy():
+    """fp32 tensors inside torch.autocast(dtype=bfloat16): the 2-D block's policy hands the kernels bf16 activations (DLKA_BF16) and fp32 parameters —
+    the output comes back bf16, the parameter gradients fp32."""
+    import deformablelka_amd as dk
+    from oracle import blocks
+    torch.manual_seed(0)
+    m = dk.deformable_LKA_Attention(96).to(DEV)
+    blocks.randomize_offsets_(m, std=0.03)
+    x = torch.randn(2, 96, 20, 17, device=DEV, requires_grad=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(x)
+    assert y.dtype == torch.bfloat16
+    y.float().sum().backward()
+    assert x.grad.dtype == torch.float32 and all(p.grad.dtype == torch.float32 and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    y32 = m(x.detach())
+    assert y32.dtype == torch.float32 and parity.rel_err(y, y32) < 2e-2
+
+
 def test_lka2d_attention_fast_path_equals_general_path():
     """Same inputs through the channels-last fast path and (dlka_lka2d_force_general) the general NCHW kernels."""
     import deformablelka_amd as dk
