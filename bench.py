@@ -68,7 +68,7 @@ def kernel_work(name, B, C, n, dbytes):
         return contr + 27 * M * (16 * C + 48), (2 * E) * s + 2 * Off * 4
     if "cl_deform_gx_fx2_kernel" in name or "cl_deform_gx_kernel" in name:
         return contr + 27 * M * (16 * C), 2 * E * s + Off * 4
-    if "cl_deform_fwd_kernel" in name:
+    if "cl_deform_fwd" in name:
         return contr + interp, 2 * E * s + Off * 4
     if "cl_wgrad_samp_kernel" in name:        # dense stream over the stored samples S[tap][m][c]
         return contr, (27 * E + E) * s

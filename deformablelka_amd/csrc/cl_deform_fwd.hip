@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
 // Same arithmetic per output element: the k order within a 32-channel chunk is permuted identically on both operands (lane group g holds
 // channels 8g .. 8g+7), the fmaf order of the interpolation is unchanged.  One 32-column tile per workgroup (blockIdx.z walks wider outputs).
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NTC>   // NTC: 32-column tiles per workgroup (1 | 2)
 __global__ __launch_bounds__(512, 4) void cl_deform_fwd16_kernel(IgemmArgs p)
 {
     constexpr unsigned SB = sizeof(T);
@@ -191,7 +191,8 @@ __global__ __launch_bounds__(512, 4) void cl_deform_fwd16_kernel(IgemmArgs p)
     constexpr int TGRP = 4;    // taps described at once: lane (row i, sub-tap g4) — all 64 lanes work (a per-tap description keeps 16 of them busy)
     using GG = GatherGeom<T>;
     constexpr int NG = GG::NG / 2;   // row groups of a 16-row tile: fp32 2 x 8 rows, bf16 1 x 16 rows
-    __shared__ __attribute__((aligned(16))) float Bs[2][32 * 32];
+    constexpr int NPB = 32 * NTC;
+    __shared__ __attribute__((aligned(16))) float Bs[2][32 * NPB];
     __shared__ __attribute__((aligned(16))) float Ssm[WAVES][16 * SROW];
     __shared__ __attribute__((aligned(16))) float Dsm[WAVES][TGRP * 16 * GATHER_DESCW_WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -205,28 +206,29 @@ __global__ __launch_bounds__(512, 4) void cl_deform_fwd16_kernel(IgemmArgs p)
     const int b = row_ok ? m / p.N : 0;
     const int v = row_ok ? m - b * p.N : 0;
     const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / (p.W * p.H);
-    const int n0 = blockIdx.z * 32;
+    const int n0 = blockIdx.z * NPB;
     const int HW = p.H * p.W, rowbytes = p.Cin * SB;
     const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * SB);
     float *S = Ssm[wave], *Dt = Dsm[wave];
 
-    f32x4 acc[2];
+    f32x4 acc[2 * NTC];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 2 * NTC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunk = p.CinP / 32;
     const int unit_lo = blockIdx.y * p.units_per_split;
     const int unit_hi = min(p.K * nchunk, unit_lo + p.units_per_split);
 
     f32x4 breg = {0.f, 0.f, 0.f, 0.f};
+    const bool bload = tid < 256 * NTC;   // 32 x NPB weight chunk: one 16-byte piece per thread (NTC = 1: the first four waves)
     GatherPiece<T> xr[NG][8];   // gathered corner pieces of the next unit, in flight
     int cur_grp = -1, cur_tap = 0;
-    auto load_b = [&](int unit) {   // 32 x 32 weight chunk: one 16-byte piece per thread of the first four waves
-        if (tid < 256) {
+    auto load_b = [&](int unit) {
+        if (bload) {
             int ck;
             const int tap = divmod_fast(unit, nchunk, ck);
             const float *src = p.wp + ((long)tap * p.CinP + ck * 32) * p.NP + n0;
-            breg = reinterpret_cast<const f32x4 *>(src + (long)(tid >> 3) * p.NP)[tid & 7];
+            breg = reinterpret_cast<const f32x4 *>(src + (long)(tid / (NPB / 4)) * p.NP)[tid % (NPB / 4)];
         }
     };
     // s_memtime stamps (round 3, scripts/fwd_stamps.py history in profiles/r04_notes.md) showed a THIRD of every (tile, tap) step going into the
@@ -308,37 +310,40 @@ __global__ __launch_bounds__(512, 4) void cl_deform_fwd16_kernel(IgemmArgs p)
     int buf = 0;
     for (int unit = unit_lo; unit < unit_hi; ++unit, buf ^= 1) {
         float a_cur[8];
-        if (tid < 256) reinterpret_cast<f32x4 *>(Bs[buf])[tid] = breg;
+        if (bload) reinterpret_cast<f32x4 *>(Bs[buf])[tid] = breg;
         finish(a_cur, cur_tap);      // consumes xr (the loads issued one iteration ago, for tap cur_tap)
         __syncthreads();    // Bs[buf] staged; Bs[buf^1] (read two iterations ago) is free again
         if (unit + 1 < unit_hi) {
             load_b(unit + 1);
             issue(unit + 1);
         }
-        // B[k = 8 g4 + s][n = 2 i + t]: one 8-byte LDS read per step feeds both column tiles (columns 2i and 2i + 1)
-        const float *brow = Bs[buf] + (8 * g4) * 32 + 2 * i;
+        // B[k = 8 g4 + s][n = 32 c + 2 i + t]: one 8-byte LDS read per step and 32-column tile feeds two 16-column MFMAs (columns 2i and 2i + 1)
+        const float *brow = Bs[buf] + (8 * g4) * NPB + 2 * i;
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
-            const float b0 = brow[st * 32], b1 = brow[st * 32 + 1];
-            acc[0] = mfma_16x16x4(a_cur[st], b0, acc[0]);
-            acc[1] = mfma_16x16x4(a_cur[st], b1, acc[1]);
+#pragma unroll
+            for (int c = 0; c < NTC; ++c) {
+                const float b0 = brow[st * NPB + 32 * c], b1 = brow[st * NPB + 32 * c + 1];
+                acc[2 * c] = mfma_16x16x4(a_cur[st], b0, acc[2 * c]);
+                acc[2 * c + 1] = mfma_16x16x4(a_cur[st], b1, acc[2 * c + 1]);
+            }
         }
     }
 
     // ---- epilogue: D layout col = lane & 15 -> output columns n0 + 2 i + t, row = 4 * (lane >> 4) + r ----
     const bool split = gridDim.y > 1;
-    const int n = n0 + 2 * i;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (n + t >= p.Cout) continue;
-        const float bv = (p.bias && blockIdx.y == 0) ? p.bias[n + t] : 0.f;
+    for (int t = 0; t < 2 * NTC; ++t) {
+        const int n = n0 + 32 * (t >> 1) + 2 * i + (t & 1);
+        if (n >= p.Cout) continue;
+        const float bv = (p.bias && blockIdx.y == 0) ? p.bias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int mr = mbase + 4 * g4 + r;
             if (mr >= p.M) continue;
             const float val = acc[t][r] + bv;
-            if (split) atomicAdd(p.out + (long)mr * p.Cout + n + t, val);
-            else act_store1(reinterpret_cast<T *>(p.out), (long)mr * p.Cout + n + t, val);
+            if (split) atomicAdd(p.out + (long)mr * p.Cout + n, val);
+            else act_store1(reinterpret_cast<T *>(p.out), (long)mr * p.Cout + n, val);
         }
     }
 }
@@ -366,15 +371,21 @@ int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
     if (nt_env == 1 || nt_env == 2 || nt_env == 4) { if (NT_total % nt_env == 0 && nt_env <= NT_total) NT = nt_env; }
     // 16-row waves where the 32-row tiling leaves the chip at two waves per SIMD and the output is one 32-column tile (stage 0: C = 32)
     {
-        static const char *e16 = getenv("DLKA_FWD16");   // A/B switch of round 3 (0 = never, 1 = wherever the shape allows)
-        const bool want16 = e16 ? atoi(e16) != 0 : (NT_total == 1 && a.M >= 16384);
-        if (want16 && NT_total <= 4 && a.NP % 32 == 0) {
+        // Measured (profiles/r04_notes.md): 81 vs 94 us at C = 32 / 32^3 (fp32; 75 vs 86 bf16); no gain at the smaller stages with the
+        // two-tile variant (47.0 vs 48.1 / 36.4 vs 34.1 / 25.6 vs 25.5 us at stages 1 - 3), so it is used for one 32-column tile and large M.
+        // DLKA_FWD16_MIN_ROWS lowers the row threshold so that small test shapes take this kernel too (not cached: tests toggle it).
+        const char *e16 = getenv("DLKA_FWD16_MIN_ROWS");
+        const bool want16 = e16 ? a.M >= atoi(e16) : (NT_total == 1 && a.M >= 16384);
+        if (want16 && (NT_total == 1 || NT_total % 2 == 0) && NT_total <= 8 && a.NP % 32 == 0) {
+            const int ntc = NT_total == 1 ? 1 : 2;
             const int mb16 = cdiv(a.M, 128);
-            dim3 grid16(mb16, splits, NT_total), block16(512);
+            dim3 grid16(mb16, splits, NT_total / ntc), block16(512);
             a.xcd_nx = 0;
             if (xcd_swizzle_enabled() && mb16 >= (unsigned)xcd_min_blocks()) { a.xcd_nx = mb16; grid16.x = xcd_grid(mb16); }
-            if (a.act_bf16) { auto k = cl_deform_fwd16_kernel<bf16_t>; DLKA_LAUNCH(k, grid16, block16, 0, st, a); }
-            else { auto k = cl_deform_fwd16_kernel<float>; DLKA_LAUNCH(k, grid16, block16, 0, st, a); }
+            if (a.act_bf16 && ntc == 1) { auto k = cl_deform_fwd16_kernel<bf16_t, 1>; DLKA_LAUNCH(k, grid16, block16, 0, st, a); }
+            else if (a.act_bf16) { auto k = cl_deform_fwd16_kernel<bf16_t, 2>; DLKA_LAUNCH(k, grid16, block16, 0, st, a); }
+            else if (ntc == 1) { auto k = cl_deform_fwd16_kernel<float, 1>; DLKA_LAUNCH(k, grid16, block16, 0, st, a); }
+            else { auto k = cl_deform_fwd16_kernel<float, 2>; DLKA_LAUNCH(k, grid16, block16, 0, st, a); }
             DLKA_CHECK_LAUNCH();
             return DLKA_OK;
         }

@@ -188,6 +188,19 @@ def test_xcd_swizzled_tile_order():
         del os.environ["DLKA_XCD_MIN"]
 
 
+def test_deform3d_cl_forward_16_row_kernel():
+    """cl_deform_fwd16_kernel (16-row waves, four taps described at once; the stage-0 forward on the GPU) at test sizes: one and two column
+    tiles per workgroup, ragged M, tap splits, fp32 and bf16 activations."""
+    os.environ["DLKA_FWD16_MIN_ROWS"] = "1"
+    try:
+        parity.check_deform3d_cl("cpu", 2, 32, 32, (5, 6, 7), off_mode="wild")
+        parity.check_deform3d_cl("cpu", 1, 64, 64, (3, 4, 5), off_mode="normal")
+        parity.check_deform3d_cl("cpu", 1, 128, 128, (2, 3, 3), off_mode="integer")
+        parity.check_lka3d_tokens_bf16("cpu", 1, 32, (4, 4, 8))
+    finally:
+        del os.environ["DLKA_FWD16_MIN_ROWS"]
+
+
 def test_gx_fixed_point_window_worst_case_and_error():
     """cl_deform_gx_kernel<true> (default at C <= 64): no overflow on the adversarial input its bound is built for, and its
     quantisation error against the fp64 window."""
