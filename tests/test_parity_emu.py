@@ -1,6 +1,8 @@
 """Kernel-logic parity on the CPU: the real kernel sources (deformablelka_amd/csrc/*.hip) compiled by a host
 compiler against tests/emu's wavefront emulator, driven through the same C-ABI + Python wrappers as on the GPU,
 and compared with the oracle.  Small shapes only (the emulator runs every work-item as a fiber)."""
+import os
+
 import pytest
 import torch
 
