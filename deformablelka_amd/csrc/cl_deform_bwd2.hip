@@ -285,7 +285,6 @@ struct GxGeom {
     int xcd_nx;             // > 0: blockIdx.x is mapped through xcd_item() (set by the launcher)
     int item_grid;          // 1: 1-D grid over (brick, slice) items; 0: x = brick, y = slice
     int tap_far;            // 1: half-waves take taps 16 apart (K <= 32 = 4 groups of 8), see gx_tap()
-    int ablate;             // profiling only (DLKA_GX_ABL): 1 = no LDS atomics, 2 = no sampling description / scatter at all
     float fx_magic;         // 1.5 * 2^23 (second-generation kernel: rounding constant, passed in a register on purpose)
     float fx_lim;           // fixed-point window: largest scaled magnitude of one contribution, R*K * (fx_lim + 1/2) < 2^31 (R = rows of a
                             // brick, K = taps), see the kernel
@@ -415,13 +414,6 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
                 for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], g1[st], acc);
             }
         }
-        if (gg.ablate == 2) {   // profiling: keep the MFMA results alive, skip the scatter
-            float sum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sum += acc[r];
-            if (sum == 12345.678f) p.gx[0] = sum;
-            return;
-        }
         {
             // acc[r]: MFMA row (r&3) + 8*(r>>2) + 4h  ->  c4 = r & 3, t8 = 2*(r>>2) + h;   column = voxel j
             // The window part of the scatter is branch-free: a corner outside the window keeps its 4 atomics but they add 0.0 to
@@ -455,11 +447,6 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
                 const int idx = inwin ? base + cd * WHW + ch * WW + cw : trash;
                 const float wv = inwin ? wq : 0.f;
                 double *cell = Win + idx;
-                if (gg.ablate == 1) {   // profiling: plain (racy) stores instead of atomics
-#pragma unroll
-                    for (int c = 0; c < CS; ++c) cell[c * wstride] = (double)(acc[4 * r4 + c] * wv);
-                    continue;
-                }
                 if (FX) {
                     const float ws = wv * fx_scale;
 #pragma unroll
@@ -975,13 +962,12 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         // resident in LDS (252 vs 362 us at C=32 / 32^3; at C >= 128 the scale pre-pass costs more than the atomics it saves).
         // DLKA_GX_FIXED=0 forces the fp64 window, =1 the fixed-point one wherever it is possible (A/B runs; not cached: tests toggle it).
         const char *fx_env = getenv("DLKA_GX_FIXED");
-        constexpr bool abl_on = false;
         const long rk = (long)g.bd * g.bh * g.bw * a.K;
         const double fx_lim = 2147483648.0 / (double)rk - 1.0;   // rk * (fx_lim + 1/2) = 2^31 - rk/2 < 2^31
         const int fx_bits = fx_lim > 1.0 ? (int)floor(log2(fx_lim)) : 0;
         const size_t lds_win_fx = 16 + (size_t)(g.wvox_max + 64) * (CS / 2) * sizeof(double);
         const bool fx_possible = lds_win_fx + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float) <= 150 * 1024 && a.CoutP <= 128 && g.ngroups * 32 <= 512 &&
-                                 fx_bits >= 12 && !abl_on;
+                                 fx_bits >= 12;
         const bool fixed = fx_possible && (fx_env ? atoi(fx_env) != 0 : a.C <= 64);
         // (capped below 2^22: the second-generation kernel rounds with the 1.5 * 2^23 trick, exact for |value| < 2^22; tiny bricks would allow more)
         gl_.fx_lim = (float)(fx_lim < 4.0e6 ? fx_lim : 4.0e6);
@@ -990,8 +976,6 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         const size_t lds_win = 16 + (size_t)(g.wvox_max + 64) * (fixed ? CS / 2 : CS) * sizeof(double);
         const size_t lds_all = lds_win + (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
         gl_.resident = (lds_all <= 150 * 1024 && (a.CoutP <= 128 || !fixed)) ? 1 : 0;   // (Cout = 256: resident weights, grad_out rows re-read per item)
-        const int abl = getenv("DLKA_GX_ABL") ? atoi(getenv("DLKA_GX_ABL")) : 0;   // profiling only (wrong results)
-        gl_.ablate = abl;
         constexpr bool far_taps = false;   // (measured: 390 vs 370 us at 32^3 — slower)
         gl_.tap_far = (far_taps && g.ngroups == 4) ? 1 : 0;
         const size_t lds = gl_.resident ? lds_all : lds_win + (size_t)a.CoutP * 32 * sizeof(float);

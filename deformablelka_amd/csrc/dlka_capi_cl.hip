@@ -400,7 +400,9 @@ struct TokGeoms {
     }
     size_t scratch_floats() const { return deform_scratch_floats(dcn); }
     // the deformable conv's samples S[tap][m][c], handed from the grad_offset kernel to the weight gradient (0: too large for 32-bit buffer
-    // offsets, or switched off — the weight gradient then gathers for itself)
+    // offsets, or switched off — the weight gradient then gathers for itself).  DLKA_WGRAD_GATHER is read when the caller sizes the workspace and
+    // again inside the backward call (not cached: a parity test compares the two routes); both only CARVE from the caller's buffer, so a switch
+    // flipped between the two calls either leaves slack or fails the call with DLKA_ERR_WORKSPACE — never reads another layout.
     size_t samp_floats() const
     {
         const size_t n = (size_t)dcn.K * dcn.M * dcn.Cin;   // elements of the activation storage type (SB bytes each)
