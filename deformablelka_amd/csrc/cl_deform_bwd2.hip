@@ -608,7 +608,7 @@ __device__ __forceinline__ void gx_drain_far(const DeformBwdArgs &p, const float
     wave_sync();   // the queue may be refilled
 }
 
-template <int SW, int SH, int SD, typename T = float>
+template <int SW, int SH, int SD, typename T = float, int NKC = 0>   // NKC: 32-channel chunks of a grad_out row known at compile time (1, 2), 0 = up to 4
 __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs p, GxGeom gg, float *__restrict__ scratch)
 {
     constexpr int PS = SD * SH * SW;   // cells per channel-pair plane
@@ -642,7 +642,8 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
     const int od = wd0 - gld, oh = wh0 - glh, ow = ww0 - glw;
     const int wvox = WD * WH * WW, WHW = WH * WW;
     const int R = gg.bd * gg.bh * gg.bw, ntiles = cdiv(R, 32);
-    const int nkc = p.CoutP / 32;
+    constexpr int KCMAX = NKC ? NKC : 4;   // (register arrays are sized by it: with 4 the unused chunks' registers spill)
+    const int nkc = NKC ? NKC : p.CoutP / 32;
 
     for (int e = tid; e < PS * (CS / 2); e += blockDim.x) WinI[e] = 0ull;
     for (int grp = 0; grp < gg.ngroups; ++grp) {   // A operand tiles: Bs[grp][co][t8*4 + c4] = W[co][slice*4 + c4][tap = grp*8 + t8]
@@ -667,22 +668,60 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
             for (int co = 0; co < p.CoutP; ++co) ss = fmaf(col[co * 32], col[co * 32], ss);
             wm = sqrtf(ss);
         }
+        // largest grad_out row norm of the brick.  One row per THREAD — eight dependent 16-byte loads from 64 different rows per wave instruction —
+        // cost 15 us of a workgroup's 79 (s_memtime stamps, round 3); here a wave instruction covers whole rows: lane = (row, 16-byte piece), the
+        // squared pieces are summed across the row's lanes, all loads of a wave in flight at once.
         float gm = 0.f;
-        for (int row = tid; row < R; row += blockDim.x) {
-            const int rw = row % gg.bw, rh = (row / gg.bw) % gg.bh, rd = row / (gg.bw * gg.bh);
-            const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
-            if (vd < p.D && vh < p.H && vw < p.W) {
-                const long gi = ((long)b * p.N + (vd * p.H + vh) * p.W + vw) * p.Cout;
-                float ss = 0.f;
-                for (int co = 0; co < p.Cout; co += 4) {
-                    const f32x4 g4 = act_load4(gin, gi + co);
-                    ss = fmaf(g4[0], g4[0], fmaf(g4[1], g4[1], fmaf(g4[2], g4[2], fmaf(g4[3], g4[3], ss))));
+        const int P = p.Cout >> 2;   // 4-element pieces per row
+        if (P == 8 || P == 16) {
+            const int rpw = 64 / P, pl = lane & (P - 1), rl = lane / P;
+            float g2 = 0.f;
+            // eight row groups per trip (a 512-row brick of 128-byte rows: one trip): their loads are issued back to back — a plain loop waited for
+            // each load in turn
+            for (int row0 = wave * rpw; row0 < R; row0 += 8 * nwaves * rpw) {
+                f32x4 g4[8];
+                bool okr[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = row0 + u * nwaves * rpw + rl;
+                    int rw, rh;
+                    const int t = divmod_fast(row, gg.bw, rw);
+                    const int rd = divmod_fast(t, gg.bh, rh);
+                    const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
+                    okr[u] = row < R && vd < p.D && vh < p.H && vw < p.W;
+                    const long gi = okr[u] ? ((long)b * p.N + (vd * p.H + vh) * p.W + vw) * p.Cout + 4 * pl : 0;
+                    g4[u] = act_load4(gin, gi);
                 }
-                gm = fmaxf(gm, sqrtf(ss));
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float ss = fmaf(g4[u][0], g4[u][0], fmaf(g4[u][1], g4[u][1], fmaf(g4[u][2], g4[u][2], g4[u][3] * g4[u][3])));
+                    ss = sum8(okr[u] ? ss : 0.f);
+                    if (P == 16) ss += __shfl_xor(ss, 8);
+                    g2 = fmaxf(g2, ss);
+                }
+            }
+            gm = sqrtf(g2);
+        } else {
+            for (int row = tid; row < R; row += blockDim.x) {
+                const int rw = row % gg.bw, rh = (row / gg.bw) % gg.bh, rd = row / (gg.bw * gg.bh);
+                const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
+                if (vd < p.D && vh < p.H && vw < p.W) {
+                    const long gi = ((long)b * p.N + (vd * p.H + vh) * p.W + vw) * p.Cout;
+                    float ss = 0.f;
+                    for (int co = 0; co < p.Cout; co += 4) {
+                        const f32x4 g4 = act_load4(gin, gi + co);
+                        ss = fmaf(g4[0], g4[0], fmaf(g4[1], g4[1], fmaf(g4[2], g4[2], fmaf(g4[3], g4[3], ss))));
+                    }
+                    gm = fmaxf(gm, sqrtf(ss));
+                }
             }
         }
-        atomicMax(&smax[0], __float_as_uint(wm));
-        atomicMax(&smax[1], __float_as_uint(gm));
+        // one LDS atomic per wave, not per lane (512 same-address atomics serialise)
+        for (int o = 32; o >= 1; o >>= 1) { wm = fmaxf(wm, __shfl_xor(wm, o)); gm = fmaxf(gm, __shfl_xor(gm, o)); }
+        if (lane == 0) {
+            atomicMax(&smax[0], __float_as_uint(wm));
+            atomicMax(&smax[1], __float_as_uint(gm));
+        }
         __syncthreads();
         const float vmax = __uint_as_float(smax[0]) * __uint_as_float(smax[1]) * 1.0001f;
         if (vmax > 1e-30f && vmax < 3.0e38f) {
@@ -690,21 +729,47 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
             fx_inv = 1.f / fx_scale;
         }
     }
-    for (int tile = wave; tile < ntiles; tile += nwaves) {
+    // A tile's grad_out rows are REQUESTED a tile ahead — behind the last MFMA phase of the previous tile, so that they fly under its last scatter
+    // (loaded at the top of the tile they cost an exposed round trip per tile: 7.6 k of a workgroup's 190 k ticks, twice) — as raw words; the
+    // "row outside the brick / chunk beyond Cout" zeroing happens when the tile starts.
+    constexpr bool AHEAD = NKC == 1;   // (with more chunks the raw words do not fit next to the scatter's registers: 53 spilled at two chunks)
+    f32x4 graw[AHEAD ? KCMAX : 1][4];
+    auto request_rows = [&](int tile) {
         const int row = tile * 32 + j;
-        const int rw = row % gg.bw, rh = (row / gg.bw) % gg.bh, rd = row / (gg.bw * gg.bh);
+        int rw, rh;
+        const int t = divmod_fast(row, gg.bw, rw);
+        const int rd = divmod_fast(t, gg.bh, rh);
         const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
         const bool ok = row < R && vd < p.D && vh < p.H && vw < p.W;
         const int v = ok ? (vd * p.H + vh) * p.W + vw : 0;
-        float gl[4][16];   // this voxel's grad_out row (16 of each 32-channel chunk), loaded once for all tap groups
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
+        for (int kc = 0; kc < (AHEAD ? KCMAX : 1); ++kc) {
+            const bool okg = ok && kc * 32 + 16 * h < p.Cout;
+            const long gi = okg ? ((long)b * p.N + v) * p.Cout + kc * 32 + 16 * h : 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) graw[kc][e] = act_load4(gin, gi + 4 * e);
+        }
+    };
+    if (AHEAD && wave < ntiles) request_rows(wave);
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int row = tile * 32 + j;
+        int rw, rh;
+        const int rt = divmod_fast(row, gg.bw, rw);
+        const int rd = divmod_fast(rt, gg.bh, rh);
+        const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
+        const bool ok = row < R && vd < p.D && vh < p.H && vw < p.W;
+        const int v = ok ? (vd * p.H + vh) * p.W + vw : 0;
+        float gl[KCMAX][16];   // this voxel's grad_out row (16 of each 32-channel chunk), loaded once for all tap groups
+#pragma unroll
+        for (int kc = 0; kc < KCMAX; ++kc) {
             if (kc >= nkc) break;
             const bool okg = ok && kc * 32 + 16 * h < p.Cout;
             const long gi = okg ? ((long)b * p.N + v) * p.Cout + kc * 32 + 16 * h : 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const f32x4 t = act_load4(gin, gi + 4 * e);
+                f32x4 t;
+                if constexpr (AHEAD) t = graw[kc][e];
+                else t = act_load4(gin, gi + 4 * e);
                 gl[kc][4 * e] = okg ? t[0] : 0.f; gl[kc][4 * e + 1] = okg ? t[1] : 0.f; gl[kc][4 * e + 2] = okg ? t[2] : 0.f; gl[kc][4 * e + 3] = okg ? t[3] : 0.f;
             }
         }
@@ -724,12 +789,13 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
+            for (int kc = 0; kc < KCMAX; ++kc) {
                 if (kc >= nkc) break;
                 const float *arow = Bg + (kc * 32 + 16 * h) * 32 + j;   // A[i = (t8, c4) = j][k = co]
 #pragma unroll
                 for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], gl[kc][st], acc);
             }
+            if (AHEAD && grp == gg.ngroups - 1 && tile + nwaves < ntiles) request_rows(tile + nwaves);   // uniform
             // acc[r]: MFMA row (r&3) + 8*(r>>2) + 4h  ->  c4 = r & 3, t8 = 2*(r>>2) + h;   column = voxel j
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
@@ -767,10 +833,11 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
                             typedef float f32x2_t __attribute__((ext_vector_type(2)));
                             const f32x2_t cp = {acc[4 * r4 + 2 * pr], acc[4 * r4 + 2 * pr + 1]}, wp2 = {ws, ws}, mg = {fx_magic, fx_magic};
                             const f32x2_t tp = cp * wp2 + mg;
-                            const int t0 = __float_as_int(tp[0]), t1 = __float_as_int(tp[1]);
-                            const int i0 = t0 - 0x4B400000;
-                            // packed = (int64)i1 * 2^32 + (int64)i0: low word i0, high word i1 - 1 if i0 < 0
-                            const unsigned long long pk = ((unsigned long long)(unsigned)(t1 + (i0 >> 31) - 0x4B400000) << 32) | (unsigned long long)(unsigned)i0;
+                            // bits(tp) = 0x4B400000 + i (i < 0 included: no wrap, |i| < 2^22), so the register PAIR read as one 64-bit integer is
+                            // (M + i1) * 2^32 + (M + i0), and the packed word i1 * 2^32 + i0 (two's complement, borrow included) is that minus the
+                            // constant M * (2^32 + 1): ONE 64-bit add instead of subtract / sign / add-with-borrow per field
+                            const unsigned long long tt = ((unsigned long long)__float_as_uint(tp[1]) << 32) | (unsigned long long)__float_as_uint(tp[0]);
+                            const unsigned long long pk = tt - 0x4B4000004B400000ull;
                             atomicAdd(cell + (cd * SH * SW + ch * SW + cw) + pr * PS, pk);
                         }
                     }
@@ -988,11 +1055,13 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         if (hipGetDevice(&dev) != hipSuccess) return DLKA_ERR_LAUNCH;
         const uint64_t bit = 1ull << (dev & 63);
         if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-            const void *fns[8] = {reinterpret_cast<const void *>(cl_deform_gx_kernel<false>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true>),
-                                  reinterpret_cast<const void *>(cl_deform_gx_kernel<false, bf16_t>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true, bf16_t>),
-                                  reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<18, 10, 14, float>), reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<18, 10, 14, bf16_t>),
-                                  reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<34, 10, 10, float>), reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<34, 10, 10, bf16_t>)};
-            for (int f = 0; f < 8; ++f)
+#define DLKA_FX2_FNS(SWv, SHv, SDv, NK) reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float, NK>), reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, NK>)
+            const void *fns[16] = {reinterpret_cast<const void *>(cl_deform_gx_kernel<false>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true>),
+                                   reinterpret_cast<const void *>(cl_deform_gx_kernel<false, bf16_t>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true, bf16_t>),
+                                   DLKA_FX2_FNS(18, 10, 14, 0), DLKA_FX2_FNS(18, 10, 14, 1), DLKA_FX2_FNS(18, 10, 14, 2),
+                                   DLKA_FX2_FNS(34, 10, 10, 0), DLKA_FX2_FNS(34, 10, 10, 1), DLKA_FX2_FNS(34, 10, 10, 2)};
+#undef DLKA_FX2_FNS
+            for (int f = 0; f < 16; ++f)
                 if (hipFuncSetAttribute(fns[f], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DLKA_ERR_LAUNCH;
             attr_done.fetch_or(bit, std::memory_order_release);
         }
@@ -1018,8 +1087,16 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
 #define DLKA_GX2(SWv, SHv, SDv)                                                                                                    \
     if (nw <= SWv && nh <= SHv && nd <= SDv && 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes + qbytes <= 150 * 1024) {       \
         const size_t lds2 = 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes + qbytes;                                         \
-        if (a.act_bf16) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); } \
-        else { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }             \
+        const int nk_ = a.CoutP / 32;                                                                                              \
+        if (a.act_bf16) {                                                                                                          \
+            if (nk_ == 1) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, 1>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }      \
+            else if (nk_ == 2) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, 2>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); } \
+            else { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, 0>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }               \
+        } else {                                                                                                                   \
+            if (nk_ == 1) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float, 1>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }       \
+            else if (nk_ == 2) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float, 2>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }  \
+            else { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float, 0>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }                \
+        }                                                                                                                          \
         launched = true;                                                                                                           \
     }
             bool launched = false;
