@@ -272,6 +272,194 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// grad_offset with 16-row waves (round 3) for the stage the step spends most of its time in: C = C_out = 32, all taps in one workgroup.
+// The kernel above runs two waves per SIMD at 243 registers and s_memtime stamps show its (tile, tap) unit as one serial chain — weights to LDS +
+// barrier 1.2 k ticks | 16 MFMAs 1.2 k | interpolation + tile stores 3.0 k | description 0.8 k | 32 corner loads 2.1 k | tile reads + dots 2.1 k —
+// with nothing to overlap it with.  Here, as in cl_deform_fwd16_kernel:
+//   * a wave owns 16 rows and gathers 64 bytes of each per pass (lane = (row of 16, 16-byte piece of 4); fp32: two passes of 16 channels per tap,
+//     bf16: one of 32): 32 registers of corner pieces in flight instead of 128, v_mfma_f32_16x16x4_f32 (same FLOP rate), 168 registers, three
+//     waves per SIMD.  The register budget is the design constraint: a spilled value is reloaded through scratch, and every scratch reload waits
+//     with vmcnt(0) — i.e. for ALL corner loads in flight (the first version of this kernel, with 50 - 140 spilled registers: 290 us);
+//   * four taps are described at once, lane = (row, sub-tap) — all 64 lanes form one description each;
+//   * the transposition between the MFMA layout (lane = voxel, consecutive channels) and the gather layout moves Col — one 16-byte LDS write and
+//     one read per lane and pass — instead of the three derivative tiles (12 + 12 per 32 rows above); the dots with Col happen in the gather
+//     layout, channel by channel, and the channel sum of a row is two DPP adds over its 4 lanes.
+// Same arithmetic per (voxel, tap, channel) as the kernel above (same separable interpolation, same sample stored for the weight gradient); the
+// order of the channel sum differs (rounding only).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, bool SAMP, int WAVES, int OCC>   // WAVES per workgroup (4 | 8), OCC = waves per SIMD the register budget is set for
+__global__ __launch_bounds__(64 * WAVES, OCC) void cl_deform_goff16_kernel(DeformBwdArgs p)
+{
+    constexpr unsigned XB = sizeof(T);
+    constexpr int TGRP = 4;
+    constexpr int PE = 16 / XB;            // channels per 16-byte piece: 4 (fp32) | 8 (bf16)
+    constexpr int CPP = 4 * PE;            // channels per pass (4 pieces = 64 bytes of a row): 16 | 32
+    constexpr int NPASS = 32 / CPP;        // 2 | 1
+    constexpr int TP = CPP / 16;           // 16-row MFMA tiles per pass: 1 | 2
+    constexpr int SROW = CPP + 4;          // padded Col tile row (floats)
+    const T *gin = reinterpret_cast<const T *>(p.g);
+    __shared__ __attribute__((aligned(16))) float Bs2[2][32 * 32];                          // W[tap][co][ci], double buffered
+    __shared__ __attribute__((aligned(16))) float Csm[WAVES][16 * SROW];                    // per wave: Col[row][channel of the pass]
+    __shared__ __attribute__((aligned(16))) float Dsm[WAVES][TGRP * 16 * GATHER_DESC_WORDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g4 = lane >> 4;   // MFMA roles: voxel (column) / W row, k group; description role: row, sub-tap
+    const int gr = lane >> 2, gp = lane & 3;   // gather roles: row, 16-byte piece of the pass's 64 bytes
+    const int bx = DLKA_XCD_BX(p.xcd_nx);
+    if (bx < 0) return;
+    const int mbase = (bx * WAVES + wave) * 16;
+    const int HW = p.H * p.W, rowbytes = p.C * XB;
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.C * XB);
+    const BufRsrc rsamp = make_rsrc(p.samp, SAMP ? (size_t)p.K * p.M * p.C * XB : 0);
+    const BufRsrc rgoff = make_rsrc(p.goff, (size_t)p.B * 3 * p.K * p.N * 4);
+    float *Ct = Csm[wave], *Dt = Dsm[wave];
+
+    // B operand of all taps' MFMAs: grad_out[voxel i][co = 8 g4 + s]
+    float greg[8];
+    {
+        const bool okr = mbase + i < p.M;
+        const long gi = okr ? (long)(mbase + i) * p.Cout + 8 * g4 : 0;
+        const f32x4 t0 = act_load4(gin, gi), t1 = act_load4(gin, gi + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { greg[e] = okr ? t0[e] : 0.f; greg[4 + e] = okr ? t1[e] : 0.f; }
+    }
+    // where the row this lane reduces (gather role, piece 0) goes: grad_offset is planar, [b][3 K][N]; byte offset of plane 0, DLKA_OOB = no store
+    unsigned gbyte = DLKA_OOB;
+    {
+        const int mr = mbase + gr;
+        if (mr < p.M && gp == 0) { const int br = mr / p.N; gbyte = (unsigned)(br * 3 * p.K * p.N + (mr - br * p.N)) * 4u; }
+    }
+    const unsigned samp_v0 = (mbase + gr < p.M) ? (unsigned)((mbase + gr) * p.C + PE * gp) * XB : DLKA_OOB;   // S[tap][m][c]: + (tap M C + channel) bytes
+
+    GatherPiece<T> xr[8];   // corner pieces of the unit (tap, pass) in flight
+    float onx[3] = {0.f, 0.f, 0.f};
+    auto load_offsets = [&](int grp) {
+        const int tap = TGRP * grp + g4, m = mbase + i;
+        if (m < p.M && tap < p.K) {
+            const int b = m / p.N;
+            const float *op = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + (m - b * p.N);
+            onx[0] = op[0]; onx[1] = op[p.N]; onx[2] = op[2 * (long)p.N];
+        }
+    };
+    int cur_grp = -1;
+    auto issue = [&](int tap, int pass) {
+        const int grp = tap / TGRP;
+        if (grp != cur_grp) {   // uniform: describe the four taps of the group, lane = (row i, sub-tap g4)
+            cur_grp = grp;
+            const int mytap = TGRP * grp + g4, m = mbase + i;
+            int ti, tj, tk;
+            tap_decode(mytap < p.K ? mytap : 0, p.kw, p.kh, ti, tj, tk);
+            wave_sync();        // every lane has consumed the previous table
+            RowDesc r;
+            r.base = 0; r.okm = 0; r.ld = r.lh = r.lw = 0.f;
+            r.zd = r.zh = r.zw = 0;
+            if (m < p.M && mytap < p.K) {
+                // (row coordinates re-derived here, every fourth tap, rather than held in registers across the loop)
+                const int b = m / p.N, v = m - b * p.N;
+                const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / HW;
+                r = gather_describe3(onx[0], onx[1], onx[2], p.N, b, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw, p.D, p.H, p.W);
+            }
+            gather_publish(Dt, g4 * 16 + i, r, rowbytes);
+            load_offsets(grp + 1);
+            wave_sync();
+        }
+        const RowLook r = gather_lookup(Dt + (tap - TGRP * grp) * 16 * GATHER_DESC_WORDS, gr);
+        const unsigned cbyte = (unsigned)(CPP * pass + PE * gp) * XB;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xr[q] = gather_load<T>(rin, gather_offset(r, q, HW, p.W, rowbytes, cbyte));
+    };
+    f32x4 wreg = {0.f, 0.f, 0.f, 0.f};
+    const bool wload = tid < 256;   // a tap's 32 x 32 weight tile: one 16-byte piece per thread of the first four waves
+    auto load_w = [&](int tap) {
+        if (wload) wreg = *(reinterpret_cast<const f32x4 *>(p.wp + ((long)tap * p.CoutP + (tid >> 3)) * p.C) + (tid & 7));
+    };
+
+    if (p.K > 0) {
+        load_w(0);
+        load_offsets(0);
+        issue(0, 0);
+    }
+#pragma unroll 1
+    for (int tap = 0; tap < p.K; ++tap) {
+        float *Bs = Bs2[tap & 1];
+        if (wload) reinterpret_cast<f32x4 *>(Bs)[tid] = wreg;
+        __syncthreads();   // this tap's tile staged; the other buffer (read one tap ago) is free for the next
+        if (tap + 1 < p.K) load_w(tap + 1);
+        const RowLook rdg = gather_lookup(Dt + (tap & (TGRP - 1)) * 16 * GATHER_DESC_WORDS, gr);
+        float gd = 0.f, gh = 0.f, gw = 0.f;
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            // ---- 1. Col[voxel][ci] = sum_co grad_out[voxel][co] W[tap][co][ci] for the pass's channels: D rows = ci, columns = voxels ----
+            f32x4 acc[TP];
+#pragma unroll
+            for (int t = 0; t < TP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            {
+                // A[row][k = co = 8 g4 + s].  One tile per pass (fp32): row i <-> ci = 16 pass + i, the lane ends up with channels 4 g4 .. 4 g4 + 3 of
+                // the pass.  Two tiles (bf16): one 8-byte read feeds both, tile t <-> ci = 2 i + t, the lane ends up with channels 8 g4 .. 8 g4 + 7.
+                const float *arow = Bs + (8 * g4) * 32 + (TP == 2 ? 2 * i : CPP * pass + i);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                    for (int t = 0; t < TP; ++t) acc[t] = mfma_16x16x4(arow[s * 32 + t], greg[s], acc[t]);
+                }
+            }
+            wave_sync();   // the previous pass's Col tile has been read by every lane
+            if (TP == 1) *reinterpret_cast<f32x4 *>(Ct + i * SROW + 4 * g4) = acc[0];
+            else {
+                f32x4 c0, c1;
+                c0[0] = acc[0][0]; c0[1] = acc[TP - 1][0]; c0[2] = acc[0][1]; c0[3] = acc[TP - 1][1];
+                c1[0] = acc[0][2]; c1[1] = acc[TP - 1][2]; c1[2] = acc[0][3]; c1[3] = acc[TP - 1][3];
+                f32x4 *dst = reinterpret_cast<f32x4 *>(Ct + i * SROW + 8 * g4);
+                dst[0] = c0; dst[1] = c1;
+            }
+            wave_sync();
+            // ---- 2. in the gather layout: derivative samples of this lane's 16-byte piece, channel by channel, dotted with Col on the spot ----
+            f32x4 sraw = {0.f, 0.f, 0.f, 0.f};   // the piece's samples as they are stored: 4 floats, or 8 bf16 in 4 words (packed per 4 channels: 8 floats held spill)
+#pragma unroll
+            for (int vv = 0; vv < PE / 4; ++vv) {
+                const f32x4 col = *reinterpret_cast<const f32x4 *>(Ct + gr * SROW + PE * gp + 4 * vv);
+                float sv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // separable (see the kernel above, cuh:111-190): along w, then h, then d
+                    const int k = 4 * vv + e;
+                    const float x0 = xr[0].elem(k), x1 = xr[1].elem(k), x2 = xr[2].elem(k), x3 = xr[3].elem(k);
+                    const float x4 = xr[4].elem(k), x5 = xr[5].elem(k), x6 = xr[6].elem(k), x7 = xr[7].elem(k);
+                    const float dq0 = x1 - x0, dq1 = x3 - x2, dq2 = x5 - x4, dq3 = x7 - x6;
+                    const float sw0 = fmaf(rdg.lw, dq0, x0), sw1 = fmaf(rdg.lw, dq1, x2), sw2 = fmaf(rdg.lw, dq2, x4), sw3 = fmaf(rdg.lw, dq3, x6);
+                    const float eh0 = sw1 - sw0, eh1 = sw3 - sw2;
+                    const float shw0 = fmaf(rdg.lh, eh0, sw0), shw1 = fmaf(rdg.lh, eh1, sw2);
+                    const float ew0 = fmaf(rdg.lh, dq1 - dq0, dq0), ew1 = fmaf(rdg.lh, dq3 - dq2, dq2);
+                    const float dd = shw1 - shw0;
+                    if (SAMP) sv[e] = fmaf(rdg.ld, dd, shw0);
+                    const float dh = fmaf(rdg.ld, eh1 - eh0, eh0);
+                    const float dw = fmaf(rdg.ld, ew1 - ew0, ew0);
+                    gd = fmaf(col[e], dd, gd); gh = fmaf(col[e], dh, gh); gw = fmaf(col[e], dw, gw);
+                }
+                if (SAMP && XB == 4) { sraw[0] = sv[0]; sraw[1] = sv[1]; sraw[2] = sv[2]; sraw[3] = sv[3]; }
+                if (SAMP && XB == 2) {
+                    sraw[2 * vv] = __uint_as_float((unsigned)bf16_bits(sv[0]) | ((unsigned)bf16_bits(sv[1]) << 16));
+                    sraw[2 * vv + 1] = __uint_as_float((unsigned)bf16_bits(sv[2]) | ((unsigned)bf16_bits(sv[3]) << 16));
+                }
+            }
+            if (SAMP) buf_store_f32x4(rsamp, samp_v0 == DLKA_OOB ? DLKA_OOB : samp_v0 + (unsigned)(tap * p.M * p.C + CPP * pass) * XB, sraw);
+            // the next unit's corner loads go out now: in flight under the reduction below, the next staging and the next MFMAs
+            sched_fence();   // (the scheduler would hoist these loads above the interpolation into a SECOND set of piece registers — and spill)
+            if (pass + 1 < NPASS) issue(tap, pass + 1);
+            else if (tap + 1 < p.K) issue(tap + 1, 0);
+            sched_fence();
+        }
+        // ---- 3. channel sum of the row: over the 4 lanes that hold its pieces ----
+        gd = sum4(gd); gh = sum4(gh); gw = sum4(gw);
+        {
+            const unsigned o = gbyte == DLKA_OOB ? DLKA_OOB : gbyte + (unsigned)(3 * tap * p.N) * 4u;
+            buf_store_f32(rgoff, o, gd);
+            buf_store_f32(rgoff, o == DLKA_OOB ? DLKA_OOB : o + (unsigned)p.N * 4u, gh);
+            buf_store_f32(rgoff, o == DLKA_OOB ? DLKA_OOB : o + 2u * (unsigned)p.N * 4u, gw);
+        }
+    }
+}
+
 // =====================================================================================================================
 // grad_input: brick scatter into an fp64 LDS window
 // =====================================================================================================================
@@ -1001,10 +1189,34 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         ag.cc_per_block = cdiv(a.C / 32, ccsplit);
         if (a.goff_cpad && ccsplit > 1) return DLKA_ERR_UNSUPPORTED;   // the packed layout needs the single-writer path
         if (ccsplit > 1 && !a.goff_zeroed && launch_zero(a.goff, (size_t)a.B * 3 * a.K * a.N * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
-        dim3 grid(mblocks, tsplit, ccsplit), block(256);
-        ag.xcd_nx = 0;
-        if (xcd_swizzle_enabled() && mblocks >= xcd_min_blocks()) { ag.xcd_nx = mblocks; grid.x = xcd_grid(mblocks); }
+        // 16-row waves where the stage is large and one 32-channel chunk wide (stage 0).  DLKA_GOFF16_MIN_ROWS lowers the row threshold so that small
+        // test shapes take this kernel too (not cached: tests toggle it).
+        bool done16 = false;
         {
+            const char *e16 = getenv("DLKA_GOFF16_MIN_ROWS");
+            const bool shape16 = a.C == 32 && a.Cout == 32 && a.CoutP == 32 && !a.goff_cpad && (long)a.B * 3 * a.K * a.N * 4 < (1l << 31);
+            if (shape16 && (e16 ? a.M >= atoi(e16) : a.M >= 65536 - 127)) {
+                // 4-wave workgroups at 168 registers, three waves per SIMD.  (8-wave workgroups at 128 registers — four per SIMD — spill 60 - 70 registers
+                // in three of the four variants: 217 vs 149 us fp32, 150 vs 122 us bf16; the kernel above: 158 / 146 us on the same box.)
+                constexpr int WV = 4;
+                const int mb16 = cdiv(a.M, 16 * WV);
+                dim3 grid16(mb16), block16(64 * WV);
+                ag.xcd_nx = 0;
+                if (xcd_swizzle_enabled() && mb16 >= xcd_min_blocks()) { ag.xcd_nx = mb16; grid16.x = xcd_grid(mb16); }
+#define DLKA_G16(TT, SS) { auto k = cl_deform_goff16_kernel<TT, SS, WV, 3>; DLKA_LAUNCH(k, grid16, block16, 0, st, ag); }
+                if (a.act_bf16) { if (a.samp) DLKA_G16(bf16_t, true) else DLKA_G16(bf16_t, false) }
+                else { if (a.samp) DLKA_G16(float, true) else DLKA_G16(float, false) }
+#undef DLKA_G16
+                DLKA_CHECK_LAUNCH();
+                done16 = true;
+            }
+        }
+        dim3 grid(mblocks, tsplit, ccsplit), block(256);
+        if (!done16) {
+            ag.xcd_nx = 0;
+            if (xcd_swizzle_enabled() && mblocks >= xcd_min_blocks()) { ag.xcd_nx = mblocks; grid.x = xcd_grid(mblocks); }
+        }
+        if (!done16) {
             // storing variant: grad_out rows in registers only at Cout = 32 / fp32 (measured at 32^3: 179 vs 186 us; bf16 149 vs 155 us the other way)
 #define DLKA_GOFF2(NK, TT)                                                                                                           \
     {                                                                                                                                \

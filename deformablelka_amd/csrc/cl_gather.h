@@ -149,6 +149,7 @@ template <> struct GatherGeom<bf16_t> { static constexpr int NG = 2, RPI = 16, P
 template <typename T> struct GatherPiece {
     f32x4 w;
     __device__ __forceinline__ f32x4 get(int) const { return w; }
+    __device__ __forceinline__ float elem(int k) const { return w[k]; }   // channel k of the piece
 };
 template <> struct GatherPiece<bf16_t> {
     f32x4 w;   // bit patterns: word k = channels 2k (low half) and 2k + 1 (high half)
@@ -158,6 +159,11 @@ template <> struct GatherPiece<bf16_t> {
         f32x4 r;
         r[0] = __uint_as_float(a << 16); r[1] = __uint_as_float(a & 0xffff0000u); r[2] = __uint_as_float(b << 16); r[3] = __uint_as_float(b & 0xffff0000u);
         return r;
+    }
+    __device__ __forceinline__ float elem(int k) const   // channel k (0 .. 7) of the piece
+    {
+        const unsigned a = __float_as_uint(w[k >> 1]);
+        return __uint_as_float((k & 1) ? (a & 0xffff0000u) : (a << 16));
     }
 };
 template <typename T> __device__ __forceinline__ GatherPiece<T> gather_load(BufRsrc r, unsigned byteoff)

@@ -55,6 +55,14 @@ __device__ __forceinline__ float sum8(float x)
     x += hipemu::shfl_any(x, (hipemu::F().lin & 63) ^ 4);
     return x;
 }
+__device__ __forceinline__ void sched_fence() {}
+// sum over the 4 lanes that share lane >> 2 (result in all 4)
+__device__ __forceinline__ float sum4(float x)
+{
+    x += hipemu::shfl_any(x, (hipemu::F().lin & 63) ^ 1);
+    x += hipemu::shfl_any(x, (hipemu::F().lin & 63) ^ 2);
+    return x;
+}
 // buffer resource: loads at a byte offset >= the buffer size return 0 (the hardware range check of buffer_load)
 struct BufRsrc { const unsigned char *base; unsigned bytes; };
 __device__ __forceinline__ BufRsrc make_rsrc(const void *p, size_t bytes) { return BufRsrc{(const unsigned char *)p, (unsigned)bytes}; }
@@ -76,6 +84,12 @@ __device__ __forceinline__ float buf_load_f32_s(BufRsrc r, unsigned voff, unsign
 {
     if (!(voff < r.bytes)) return 0.f;
     return buf_load_f32(r, voff + soff);
+}
+// 4-byte store, dropped when the offset is out of range (DLKA_OOB)
+__device__ __forceinline__ void buf_store_f32(BufRsrc r, unsigned off, float v)
+{
+    if (!(off < r.bytes) || (size_t)off + 4 > r.bytes) return;
+    memcpy(const_cast<unsigned char *>(r.base) + off, &v, 4);
 }
 // 16-byte store, dropped when the offset is out of range (DLKA_OOB)
 __device__ __forceinline__ void buf_store_f32x4(BufRsrc r, unsigned off, f32x4 v)
@@ -192,6 +206,16 @@ __device__ __forceinline__ float sum8(float x)
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false));
     return x;
 }
+// nothing moves across it in the instruction scheduler (keeps register live ranges short where the scheduler would otherwise interleave two
+// independent register-hungry sections)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// sum over the 4 lanes that share lane >> 2 (result in all 4): the two quad_perm steps of sum8
+__device__ __forceinline__ float sum4(float x)
+{
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));
+    return x;
+}
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 __device__ __forceinline__ BufRsrc make_rsrc(const void *p, size_t bytes)
 {
@@ -209,6 +233,7 @@ __device__ __forceinline__ float buf_load_f32_s(BufRsrc r, unsigned voff, unsign
 // compiler (ROCm 7.2 clang) assumes the "VALU overwrites the data registers of a > 64-bit VMEM store" hazard away and schedules such a VALU
 // write directly behind buffer_store_dwordx4 — lanes 8-15 / 24-31 / 40-47 / 56-63 then stored the NEW register contents.  With the whole offset
 // in the VGPR (soffset = literal 0) the hazard recogniser inserts the wait state.
+__device__ __forceinline__ void buf_store_f32(BufRsrc r, unsigned off, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0); }
 __device__ __forceinline__ void buf_store_f32x4(BufRsrc r, unsigned off, f32x4 v)
 {
     typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)) raw128_t;

@@ -203,6 +203,20 @@ def test_deform3d_cl_forward_16_row_kernel():
         del os.environ["DLKA_FWD16_MIN_ROWS"]
 
 
+def test_deform3d_cl_grad_offset_16_row_kernel():
+    """cl_deform_goff16_kernel (16-row waves, four taps described at once, Col transposed instead of the derivative tiles; stage 0 on the GPU) at
+    test sizes: ragged M, offsets beyond the volume, fp32 and bf16 activations, with and without the sample hand-over to the weight gradient."""
+    os.environ["DLKA_GOFF16_MIN_ROWS"] = "1"
+    try:
+        parity.check_deform3d_cl("cpu", 2, 32, 32, (5, 6, 7), off_mode="wild")
+        parity.check_deform3d_cl("cpu", 1, 32, 32, (3, 4, 5), off_mode="integer")
+        parity.check_lka3d_tokens("cpu", 1, 32, (3, 4, 5))
+        parity.check_lka3d_tokens_sample_handover("cpu", 1, 32, (3, 4, 5))
+        parity.check_lka3d_tokens_bf16("cpu", 1, 32, (4, 4, 8))
+    finally:
+        del os.environ["DLKA_GOFF16_MIN_ROWS"]
+
+
 def test_gx_fixed_point_window_worst_case_and_error():
     """cl_deform_gx_kernel<true> (default at C <= 64): no overflow on the adversarial input its bound is built for, and its
     quantisation error against the fp64 window."""
