@@ -162,8 +162,11 @@ __global__ __launch_bounds__(256) void cl_dwconv_rows_kernel(DwArgs p)
 // ... and with TH output rows per work-item, h0, h0 + DIL, ...: with the loads lean, the kernel sits on the L1 return path (one 256-byte
 // wave load per segment element: 1.7 GB per launch at 32^3 for 7^3 dil 3), and output rows DIL apart share KH - 1 of their KH input
 // rows — KH + TH - 1 segment loads per tap plane feed TH * KH row products.  The tap plane's KH*KW weights sit in registers for all.
-template <typename T, int KW, int DIL, int TW, int TH>
-__global__ __launch_bounds__(256) void cl_dwconv_rowsN_kernel(DwArgs p)
+// WL: the tap weights of the workgroup's channels sit in LDS (all kd*KH*KW taps x <= 32 channels, staged once) and are read where they are used, instead
+// of a tap plane's KH*KW weights in registers: 7^3 then needs 125 instead of 174 registers — three waves per SIMD instead of two, and the stage-0 launch
+// (2304 waves) fits the chip in ONE round (at two per SIMD: 2048 slots, the last 256 waves ran a second round alone).
+template <typename T, int KW, int DIL, int TW, int TH, bool WL = false>
+__global__ __launch_bounds__(256, WL ? 3 : 1) void cl_dwconv_rowsN_kernel(DwArgs p)
 {
     constexpr int KH = KW;
     constexpr int SB = sizeof(T);
@@ -174,6 +177,16 @@ __global__ __launch_bounds__(256) void cl_dwconv_rowsN_kernel(DwArgs p)
     const int cpb = p.C < 256 ? p.C : 256;
     const int rpb = 256 / cpb;
     const int c = blockIdx.z * cpb + threadIdx.x % cpb;
+    __shared__ __attribute__((aligned(16))) float Wl[WL ? KW * KH * KW * 32 : 4];   // [tap][channel of the workgroup]  (WL: cpb == 32, kd == KW)
+    if (WL) {   // before any exit: every thread of the workgroup reaches the barrier
+        const int n4 = p.kd * KH * KW * 8;   // 16-byte pieces: 8 per tap
+        for (int e = threadIdx.x; e < n4; e += 256) {
+            const int tap = e >> 3, q = e & 7;
+            reinterpret_cast<f32x4 *>(Wl)[e] = *reinterpret_cast<const f32x4 *>(p.wp + (long)tap * p.C + blockIdx.z * 32 + 4 * q);
+        }
+        __syncthreads();
+    }
+    const int cl = threadIdx.x % cpb;
     const int bx = DLKA_XCD_BX(p.xcd_nx);   // XCD-aware: an XCD owns a contiguous slab of rows (neighbouring rows share their input rows)
     if (bx < 0) return;
     const int run = bx * rpb + threadIdx.x / cpb;
@@ -202,11 +215,14 @@ __global__ __launch_bounds__(256) void cl_dwconv_rowsN_kernel(DwArgs p)
     for (int i = 0; i < p.kd; ++i) {
         const int zd = d0 + i * p.dd - p.pd;
         if (zd < 0 || zd >= p.D) continue;                   // scalar
-        float wv[KH][KW];
+        float wv[WL ? 1 : KH][KW];
+        if (!WL) {
 #pragma unroll
-        for (int j = 0; j < KH; ++j)
+            for (int j = 0; j < KH; ++j)
 #pragma unroll
-            for (int k = 0; k < KW; ++k) wv[j][k] = buf_load_f32_s(rwt, cv, (unsigned)(((i * KH + j) * KW + k) * cbw));
+                for (int k = 0; k < KW; ++k) wv[WL ? 0 : j][k] = buf_load_f32_s(rwt, cv, (unsigned)(((i * KH + j) * KW + k) * cbw));
+        }
+        const float *wl = Wl + i * KH * KW * 32 + cl;
         const T *plane = inp + ((long)(b * p.D + zd) * p.H) * p.W * p.C;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {                       // input row h0 - ph + r*DIL: tap row r - o of output row o
@@ -220,9 +236,11 @@ __global__ __launch_bounds__(256) void cl_dwconv_rowsN_kernel(DwArgs p)
             for (int o = 0; o < TH; ++o) {
                 if (r - o < 0 || r - o >= KH) continue;      // compile time
 #pragma unroll
-                for (int k = 0; k < KW; ++k)
+                for (int k = 0; k < KW; ++k) {
+                    const float wk = WL ? wl[((r - o) * KW + k) * 32] : wv[WL ? 0 : r - o][k];
 #pragma unroll
-                    for (int t = 0; t < TW; ++t) acc[o][t] = fmaf(wv[r - o][k], seg[t + k * DIL], acc[o][t]);
+                    for (int t = 0; t < TW; ++t) acc[o][t] = fmaf(wk, seg[t + k * DIL], acc[o][t]);
+                }
             }
         }
     }
@@ -306,7 +324,9 @@ static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st
                 DLKA_CHECK_LAUNCH();
                 return DLKA_OK;
             }
-            if (kw == 7 && th == 2) { auto k = cl_dwconv_rowsN_kernel<T, 7, 3, TW, 2>; DLKA_LAUNCH(k, grid2, block, 0, st, ax); }
+            static const bool no_wl = getenv("DLKA_DW_NO_WL") != nullptr;   // A/B
+            if (kw == 7 && th == 2 && cpb == 32 && a.kd == 7 && !no_wl) { auto k = cl_dwconv_rowsN_kernel<T, 7, 3, TW, 2, true>; DLKA_LAUNCH(k, grid2, block, 0, st, ax); }
+            else if (kw == 7 && th == 2) { auto k = cl_dwconv_rowsN_kernel<T, 7, 3, TW, 2>; DLKA_LAUNCH(k, grid2, block, 0, st, ax); }
             else if (kw == 5 && th == 2) { auto k = cl_dwconv_rowsN_kernel<T, 5, 1, TW, 2>; DLKA_LAUNCH(k, grid2, block, 0, st, ax); }
             else if constexpr (F32) {
                 if (kw == 7) { auto k = cl_dwconv_rowsN_kernel<float, 7, 3, TW, 3>; DLKA_LAUNCH(k, grid2, block, 0, st, ax); }

@@ -99,6 +99,7 @@ CL_CONV = [
     (2, 32, 81, (2, 2, 16), 3, 1, 1, 1, True),      # the same with a planar grad_out (offset conv)
     (1, 32, 32, (5, 6, 9), 5, 2, 1, 32, False),     # depthwise 5^3
     (1, 32, 32, (7, 5, 10), 7, 9, 3, 32, False),    # depthwise 7^3 dil 3
+    (2, 32, 32, (3, 7, 9), 7, 9, 3, 32, False),     # the same with H >= 6 and 32 channels: two output rows per work-item, tap weights in LDS
 ]
 
 
