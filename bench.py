@@ -64,7 +64,7 @@ def kernel_work(name, B, C, n, dbytes):
     s = dbytes
     contr, interp = 2 * 27 * C * C * M, 27 * M * (15 * C + 30)
     offc = 2 * 27 * C * 81 * M
-    if "cl_deform_goff2_kernel" in name:      # Col (MFMA) + 8 corners x C dot products + 3 axes; writes grad_offset (+ the sample hand-over, see `extra`)
+    if "cl_deform_goff2_kernel" in name or "cl_deform_goff16_kernel" in name:      # Col (MFMA) + 8 corners x C dot products + 3 axes; writes grad_offset (+ the sample hand-over, see `extra`)
         return contr + 27 * M * (16 * C + 48), (2 * E) * s + 2 * Off * 4
     if "cl_deform_gx_fx2_kernel" in name or "cl_deform_gx_kernel" in name:
         return contr + 27 * M * (16 * C), 2 * E * s + Off * 4
