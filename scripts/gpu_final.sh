@@ -33,3 +33,7 @@ for dt in f32 bf16; do for s in 0 1 2 3; do
   echo "$dt $(grep ' ms' $R/$OUT/prof_${dt}_s$s.log)"
 done; done
 cd $R; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete; du -sh $OUT
+echo "== PMC traffic per kernel of the stage-0 / stage-1 blocks (fp32), stage 0 bf16"
+ROUND=${ROUND:-r04} bash scripts/pmc_block.sh $TAG/pmcb "0 1" "f32" > $OUT/pmc_block.log 2>&1; tail -14 $OUT/pmc_block.log
+ROUND=${ROUND:-r04} bash scripts/pmc_block.sh $TAG/pmcb_bf16 "0" "bf16" > $OUT/pmc_block_bf16.log 2>&1; tail -5 $OUT/pmc_block_bf16.log
+du -sh $OUT
