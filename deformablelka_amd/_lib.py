@@ -110,6 +110,14 @@ SIGNATURES = {
     "dlka_lka3d_tokens_prepare_plan_bytes": (c_size_t, [c_int]),
     "dlka_lka3d_tokens_prepare_plan": (c_int, [c_int, POINTER(Lka3dPtrs), POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int), c_int, c_void_p, c_size_t]),
     "dlka_lka3d_tokens_prepare_run": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "dlka_lka3d_tokens_partials_bytes_v": (c_size_t, [c_int] * 7),
+    "dlka_wgrad_finalize_plan_bytes": (c_size_t, [c_int]),
+    "dlka_wgrad_finalize_plan_init": (c_int, [c_void_p, c_size_t, c_int]),
+    "dlka_lka3d_attention_tokens_backward_deferred_v": (c_int, [c_void_p, POINTER(Lka3dPtrs), c_void_p, c_void_p, c_size_t, c_void_p,
+                                                               POINTER(Lka3dPtrs), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_int,
+                                                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dlka_wgrad_finalize_plan_seal": (c_int, [c_void_p]),
+    "dlka_wgrad_finalize_run": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dlka_lka3d_attention_tokens_backward": (c_int, [c_void_p, POINTER(Lka3dPtrs), c_void_p, c_void_p, c_size_t, c_void_p,
                                                      POINTER(Lka3dPtrs), c_void_p, c_size_t] + [c_int] * 6 + [c_void_p]),
     "dlka_layernorm_tokens_forward": (c_int, [c_void_p, c_int] + [c_void_p] * 6 + [c_int] * 3 + [ctypes.c_float, c_int, c_void_p]),

@@ -697,13 +697,11 @@ template int launch_cl_wgrad<float>(int, int, WgradArgs, float *, float *, hipSt
 
 // All weight-gradient finalisations of one D-LKA block in ONE launch: the five partial-sum folds (3 pointwise, offset
 // conv, deformable conv) and the two depthwise [tap][c] -> [c][tap] re-layouts were seven ~5-10 us launches per block.
-__global__ __launch_bounds__(256) void cl_wgrad_finalize_kernel(FinalizeBatch b)
+// (blk: workgroup index inside the job)
+__device__ __forceinline__ void wgrad_finalize_body(const FinalizeJob &jb, const long blk)
 {
     __shared__ float red[8][33];
-    int ji = 0;
-    while (ji + 1 < b.njobs && (long)blockIdx.x >= b.j[ji + 1].block0) ++ji;
-    const FinalizeJob &jb = b.j[ji];
-    const long e = ((long)blockIdx.x - jb.block0) * 32 + (threadIdx.x & 31);
+    const long e = blk * 32 + (threadIdx.x & 31);
     const int el = threadIdx.x & 31, cl = threadIdx.x >> 5;
     if (jb.kind == 1) {   // depthwise staging [K + 1][C] (row K = bias sums): gw[c][tap] = gwp[tap][c], gb[c] = gwp[K][c]
         if (cl == 0 && e < jb.n) {
@@ -725,7 +723,6 @@ __global__ __launch_bounds__(256) void cl_wgrad_finalize_kernel(FinalizeBatch b)
         // contiguous run of 32*K floats of gW[co][ci][tap] — the element-per-lane version wrote 4-byte pieces K*4 bytes apart
         // (67 us for the C = 256 block, profiles/r01n).
         __shared__ float tile[32 * 28];   // [ci][tap], K <= 27 (+1 padding)
-        const long blk = (long)blockIdx.x - jb.block0;
         const int cblocks = jb.Cin / 32;
         const long wblocks = (long)jb.Cout * cblocks;
         if (blk < wblocks) {
@@ -781,16 +778,52 @@ __global__ __launch_bounds__(256) void cl_wgrad_finalize_kernel(FinalizeBatch b)
     }
 }
 
+__global__ __launch_bounds__(256) void cl_wgrad_finalize_kernel(FinalizeBatch b)
+{
+    int ji = 0;
+    while (ji + 1 < b.njobs && (long)blockIdx.x >= b.j[ji + 1].block0) ++ji;
+    wgrad_finalize_body(b.j[ji], (long)blockIdx.x - b.j[ji].block0);
+}
+
+// The finalisations of MANY blocks (a whole backward pass) in one launch: the job table lives in device memory (built once: partial-sum areas and
+// gradient buffers never move), jobs[k].block0 ascending; this launch covers jobs [job_lo, job_hi) and workgroup 0 is jobs[job_lo].block0.
+__global__ __launch_bounds__(256) void cl_wgrad_finalize_table_kernel(const FinalizeJob *__restrict__ jobs, int job_lo, int job_hi)
+{
+    const long blk = (long)blockIdx.x + jobs[job_lo].block0;
+    int lo = job_lo, hi = job_hi - 1;   // last job whose block0 <= blk
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= blk) lo = mid; else hi = mid - 1;
+    }
+    const FinalizeJob jb = jobs[lo];
+    wgrad_finalize_body(jb, blk - jb.block0);
+}
+
+// workgroups a job needs; sets the job's fold variant
+long cl_wgrad_finalize_plan_job(FinalizeJob &j)
+{
+    constexpr bool no_tr = false;
+    j.tr = (!no_tr && j.kind == 0 && j.K > 1 && j.K <= 27 && j.chunks <= 16 && j.Cin % 32 == 0 && (long)j.Cout * j.Cin >= 1024) ? 1 : 0;
+    return j.tr ? (long)j.Cout * (j.Cin / 32) + (j.gb ? cdiv(j.Cout, 32) : 0) : cdivl(j.n, 32);
+}
+
+int launch_cl_wgrad_finalize_table(const FinalizeJob *jobs_device, int job_lo, int job_hi, long nblocks, hipStream_t st)
+{
+    if (job_hi <= job_lo || nblocks <= 0) return DLKA_OK;
+    if (nblocks > 0x7fffffffL) return DLKA_ERR_UNSUPPORTED;
+    DLKA_LAUNCH(cl_wgrad_finalize_table_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, jobs_device, job_lo, job_hi);
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
 int launch_cl_wgrad_finalize(FinalizeBatch &b, hipStream_t st)
 {
     if (b.njobs <= 0) return DLKA_OK;
     long blk = 0;
-    constexpr bool no_tr = false;
     for (int k = 0; k < b.njobs; ++k) {
         FinalizeJob &j = b.j[k];
         j.block0 = blk;
-        j.tr = (!no_tr && j.kind == 0 && j.K > 1 && j.K <= 27 && j.chunks <= 16 && j.Cin % 32 == 0 && (long)j.Cout * j.Cin >= 1024) ? 1 : 0;
-        blk += j.tr ? (long)j.Cout * (j.Cin / 32) + (j.gb ? cdiv(j.Cout, 32) : 0) : cdivl(j.n, 32);
+        blk += cl_wgrad_finalize_plan_job(j);
     }
     b.nblocks = blk;
     if (blk > 0x7fffffffL) return DLKA_ERR_UNSUPPORTED;

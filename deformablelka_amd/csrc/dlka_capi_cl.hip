@@ -1104,9 +1104,118 @@ int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params
     return dlka_lka3d_attention_tokens_backward_v(x_, p, gy_, saved, saved_bytes, gx_, gr, workspace, workspace_bytes, B, C, D, H, W, dtype, DLKA_LKA3D_SYNAPSE, stream);
 }
 
+// ---- weight-gradient finalisation of MANY blocks in one launch (include/dlka.h: dlka_wgrad_finalize_*) --------------------------------
+// plan (host; the caller copies it to the device once): [FinPlanHeader][int first_job[nblocks + 1]][FinalizeJob jobs[FIN_JOBS_PER_BLOCK * nblocks]]
+// jobs are stored block after block (block k: first_job[k] .. first_job[k + 1]), block0 = running workgroup count.
+namespace {
+constexpr int FIN_JOBS_PER_BLOCK = 8;
+struct FinPlanHeader { int nblocks, sealed, pad0, pad1; long total_blocks; long pad2; };
+size_t fin_first_off() { return sizeof(FinPlanHeader); }
+size_t fin_jobs_off(int nb) { return align256(sizeof(FinPlanHeader) + (size_t)(nb + 1) * sizeof(int)); }
+int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void *gy_, const void *saved, size_t saved_bytes, void *gx_,
+                         const dlka_lka3d_grads *gr, void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant,
+                         void *stream, void *partials, size_t partials_bytes, FinalizeJob *jobs_out, int *njobs_out);
+}  // namespace
+
+size_t dlka_lka3d_tokens_partials_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant)
+{
+    if (!dlka_lka3d_tokens_supported_v(B, C, D, H, W, dtype, variant)) return 0;
+    TokGeoms G(B, C, D, H, W, dtype, variant);
+    return align256(G.part_floats() * 4);
+}
+
+size_t dlka_wgrad_finalize_plan_bytes(int nblocks)
+{
+    if (nblocks <= 0) return 0;
+    return fin_jobs_off(nblocks) + (size_t)nblocks * FIN_JOBS_PER_BLOCK * sizeof(FinalizeJob);
+}
+
+int dlka_wgrad_finalize_plan_init(void *plan_host, size_t plan_bytes, int nblocks)
+{
+    if (!plan_host) return DLKA_ERR_NULL;
+    if (nblocks <= 0 || plan_bytes < dlka_wgrad_finalize_plan_bytes(nblocks)) return DLKA_ERR_WORKSPACE;
+    memset(plan_host, 0, dlka_wgrad_finalize_plan_bytes(nblocks));
+    ((FinPlanHeader *)plan_host)->nblocks = nblocks;
+    return DLKA_OK;
+}
+
+int dlka_lka3d_attention_tokens_backward_deferred_v(const void *x, const dlka_lka3d_params *p, const void *grad_y, const void *saved, size_t saved_bytes,
+                                                    void *grad_x, const dlka_lka3d_grads *grads, void *workspace, size_t workspace_bytes, void *partials,
+                                                    size_t partials_bytes, void *plan_host, int plan_slot, int B, int C, int D, int H, int W, int dtype,
+                                                    int variant, void *stream)
+{
+    if (!partials) return DLKA_ERR_NULL;
+    FinalizeJob jobs[FIN_JOBS_PER_BLOCK];
+    int nj = 0;
+    DLKA_TRY(tokens_backward_impl(x, p, grad_y, saved, saved_bytes, grad_x, grads, workspace, workspace_bytes, B, C, D, H, W, dtype, variant, stream, partials,
+                                  partials_bytes, jobs, &nj));
+    if (plan_host) {   // record this block's jobs (slots must be filled in ascending order, every slot once, before _plan_seal)
+        FinPlanHeader *hd = (FinPlanHeader *)plan_host;
+        if (plan_slot < 0 || plan_slot >= hd->nblocks || hd->sealed) return DLKA_ERR_SHAPE;
+        int *first = (int *)((unsigned char *)plan_host + fin_first_off());
+        FinalizeJob *all = (FinalizeJob *)((unsigned char *)plan_host + fin_jobs_off(hd->nblocks));
+        // slots may be recorded in any order: block k owns the fixed window [k * FIN_JOBS_PER_BLOCK, ..); sealing compacts them
+        for (int j = 0; j < nj; ++j) all[plan_slot * FIN_JOBS_PER_BLOCK + j] = jobs[j];
+        first[plan_slot] = nj;   // (count until sealed)
+    }
+    return DLKA_OK;
+}
+
+int dlka_wgrad_finalize_plan_seal(void *plan_host)
+{
+    if (!plan_host) return DLKA_ERR_NULL;
+    FinPlanHeader *hd = (FinPlanHeader *)plan_host;
+    if (hd->sealed) return DLKA_OK;
+    const int nb = hd->nblocks;
+    int *first = (int *)((unsigned char *)plan_host + fin_first_off());
+    FinalizeJob *all = (FinalizeJob *)((unsigned char *)plan_host + fin_jobs_off(nb));
+    int nj = 0;
+    long blk = 0;
+    for (int k = 0; k < nb; ++k) {
+        const int cnt = first[k];
+        if (cnt <= 0 || cnt > FIN_JOBS_PER_BLOCK) return DLKA_ERR_SHAPE;   // a slot was never recorded
+        first[k] = nj;
+        for (int j = 0; j < cnt; ++j) {
+            FinalizeJob jb = all[k * FIN_JOBS_PER_BLOCK + j];
+            jb.block0 = blk;
+            blk += cl_wgrad_finalize_plan_job(jb);
+            all[nj++] = jb;   // (nj <= k * FIN_JOBS_PER_BLOCK + j: compaction never overtakes the reads)
+        }
+    }
+    first[nb] = nj;
+    hd->total_blocks = blk;
+    hd->sealed = 1;
+    return DLKA_OK;
+}
+
+int dlka_wgrad_finalize_run(const void *plan_device, const void *plan_host, int block_lo, int block_hi, void *stream)
+{
+    if (!plan_device || !plan_host) return DLKA_ERR_NULL;
+    const FinPlanHeader *hd = (const FinPlanHeader *)plan_host;   // (counts are read from the host copy: no device round trip)
+    if (!hd->sealed || block_lo < 0 || block_hi > hd->nblocks || block_lo >= block_hi) return DLKA_ERR_SHAPE;
+    const int *first = (const int *)((const unsigned char *)plan_host + fin_first_off());
+    const FinalizeJob *all_h = (const FinalizeJob *)((const unsigned char *)plan_host + fin_jobs_off(hd->nblocks));
+    const int jlo = first[block_lo], jhi = first[block_hi];
+    const long b_lo = all_h[jlo].block0;
+    const long b_hi = block_hi == hd->nblocks ? hd->total_blocks : all_h[jhi].block0;
+    const FinalizeJob *all_d = (const FinalizeJob *)((const unsigned char *)plan_device + fin_jobs_off(hd->nblocks));
+    return launch_cl_wgrad_finalize_table(all_d, jlo, jhi, b_hi - b_lo, (hipStream_t)stream);
+}
+
 int dlka_lka3d_attention_tokens_backward_v(const void *x_, const dlka_lka3d_params *p, const void *gy_, const void *saved, size_t saved_bytes,
                                            void *gx_, const dlka_lka3d_grads *gr, void *workspace, size_t workspace_bytes, int B, int C,
                                            int D, int H, int W, int dtype, int variant, void *stream)
+{
+    return tokens_backward_impl(x_, p, gy_, saved, saved_bytes, gx_, gr, workspace, workspace_bytes, B, C, D, H, W, dtype, variant, stream, nullptr, 0, nullptr,
+                                nullptr);
+}
+
+namespace {
+// partials != nullptr: the weight gradients' partial sums go to that (block-private) area and the finalisation is NOT launched — its jobs are
+// returned in jobs_out / njobs_out for dlka_wgrad_finalize_run
+int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void *gy_, const void *saved, size_t saved_bytes, void *gx_,
+                         const dlka_lka3d_grads *gr, void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant,
+                         void *stream, void *partials, size_t partials_bytes, FinalizeJob *jobs_out, int *njobs_out)
 {
     if (!x_ || !p || !gy_ || !saved || !gx_ || !gr || !workspace) return DLKA_ERR_NULL;
     const void *const *pp = (const void *const *)p;
@@ -1127,6 +1236,10 @@ int dlka_lka3d_attention_tokens_backward_v(const void *x_, const dlka_lka3d_para
     const float *m = (const float *)sv.take(G.E * SB);
     (void)cv.take(G.wp_floats() * 4);
     float *part = (float *)cv.take(G.part_floats() * 4);
+    if (partials) {
+        if (partials_bytes < G.part_floats() * 4) return DLKA_ERR_WORKSPACE;
+        part = (float *)partials;
+    }
     // every intermediate gradient has its own buffer: the weight-gradient stream reads them while the data-gradient chain moves on
     float *gg1 = (float *)cv.take(G.E * 4), *ga1 = (float *)cv.take(G.E * 4), *gf = (float *)cv.take(G.E * 4), *gta = (float *)cv.take(G.E * 4);
     float *gt = (float *)cv.take(G.E * 4), *gt1 = (float *)cv.take(G.E * 4), *ga2 = (float *)cv.take(G.E * 4), *gh = (float *)cv.take(G.E * 4);
@@ -1233,13 +1346,20 @@ int dlka_lka3d_attention_tokens_backward_v(const void *x_, const dlka_lka3d_para
         DLKA_TRY(launch_cl_wgrad_pw3(jobs, gws, gbs, ws_, &fb.j[fb.njobs]));
         fb.njobs += 3;
     }
-    DLKA_TRY(launch_cl_wgrad_finalize(fb, ws_));
+    if (partials) {
+        if (fb.njobs > FIN_JOBS_PER_BLOCK || !jobs_out || !njobs_out) return DLKA_ERR_UNSUPPORTED;
+        for (int k = 0; k < fb.njobs; ++k) jobs_out[k] = fb.j[k];
+        *njobs_out = fb.njobs;
+    } else {
+        DLKA_TRY(launch_cl_wgrad_finalize(fb, ws_));
+    }
     DLKA_TRY(dense_backward_data(G.pw, gh, 0, N0, gx, PW.pw_b[0], 3, gy, st, nullptr, nullptr, true));
     if (fork) {   // join
         if (hipEventRecord(sc.ev[nev], ws_) != hipSuccess || hipStreamWaitEvent(st, sc.ev[nev], 0) != hipSuccess) return DLKA_ERR_LAUNCH;
     }
     return DLKA_OK;
 }
+}  // namespace
 
 // ---- the wrapper block's non-convolutional pieces (cl_norm.hip) ------------------------------------------------------------
 int dlka_layernorm_tokens_forward(const void *x, int x_planar, const void *pos, const void *w, const void *b, void *xt, void *xn, void *stats, int B,

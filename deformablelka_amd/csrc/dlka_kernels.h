@@ -63,6 +63,8 @@ size_t cl_wgrad_part_floats(int M, int K, int Cout, int Cin);
 template <typename T> int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t st, FinalizeJob *defer = nullptr);
 size_t cl_wgrad_part_floats_mode(int M, int K, int Cout, int Cin, int amode);
 int launch_cl_wgrad_finalize(FinalizeBatch &b, hipStream_t st);
+long cl_wgrad_finalize_plan_job(FinalizeJob &j);   // workgroups the job needs (sets its fold variant)
+int launch_cl_wgrad_finalize_table(const FinalizeJob *jobs_device, int job_lo, int job_hi, long nblocks, hipStream_t st);
 int launch_cl_wgrad_pw3(const WgradArgs *jobs, float *const *gw, float *const *gb, hipStream_t st, FinalizeJob *defer);
 int launch_cl_colsum(const float *g, float *gb32, int M, int Cout, hipStream_t st);
 int launch_cl_dw_prep_weight(const float *w, float *wp, int C, int K, int flip, hipStream_t st);

@@ -37,12 +37,12 @@ def _offset_std_for(C: int, offset_std_voxels: float = 1.0) -> float:
 
 
 class _Block:
-    __slots__ = ("C", "dims", "params", "grads", "pstruct", "gstruct", "saved", "x", "y", "gx", "gy", "saved_bytes")
+    __slots__ = ("C", "dims", "params", "grads", "pstruct", "gstruct", "saved", "x", "y", "gx", "gy", "saved_bytes", "partials", "partials_bytes")
 
 
 class DLKABlockStack:
     def __init__(self, batch: int, stages: Sequence = SYNAPSE_STAGES, device="cuda:0", dtype=torch.float32, seed: int = 0,
-                 offset_std_voxels: float = 1.0, data_seed=None):
+                 offset_std_voxels: float = 1.0, data_seed=None, defer_finalize: bool = True):
         """seed: parameters (identical on every data-parallel rank); data_seed: the synthetic inputs / grad_outputs of THIS rank's
         batch shard (None: drawn from the parameter generator, single-process use)."""
         self.B, self.device, self.dtype = batch, torch.device(device), dtype
@@ -83,6 +83,7 @@ class DLKABlockStack:
         self.ws_bytes = ws_bytes
         self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
         self._build_prepare_plan()
+        self._build_finalize_plan(defer_finalize)
         # activations: blocks of one stage instance are chained x -> y -> ... ; each chain has a synthetic input and
         # a synthetic grad_output (the layers between chains — down/up-sampling, UnetResBlock — are not D-LKA).
         if data_seed is not None:
@@ -133,6 +134,26 @@ class DLKABlockStack:
         L.check(rc, "lka3d_tokens_prepare_plan")
         self._plan_dev = self._plan_host.to(self.device) if self.device.type == "cuda" else self._plan_host
 
+    def _build_finalize_plan(self, enable: bool):
+        """The seven weight gradients of a block end in a "finalize" launch that folds their partial sums; nothing later in the backward pass
+        reads its results.  With block-PRIVATE partial-sum areas (288 GB of HBM: 0.4 GB for the 21 blocks) all blocks' finalisations become ONE
+        launch at the end of the backward pass (or of a slice of it) instead of 21 dependent launches of 15 - 30 us, most of each latency
+        (include/dlka.h: dlka_wgrad_finalize_*).  The job table is recorded by the first backward pass and then lives on the device."""
+        self._fin_host = self._fin_dev = None
+        self._fin_sealed = False
+        import os
+        if not enable or os.environ.get("DLKA_STACK_PER_BLOCK_FINALIZE"):   # (A/B switch: the per-block finalize launches)
+            return
+        import ctypes
+        n = len(self.blocks)
+        for blk in self.blocks:
+            H, W, D = blk.dims
+            blk.partials_bytes = self.lib.dlka_lka3d_tokens_partials_bytes_v(self.B, blk.C, H, W, D, self.dt, 0)
+            blk.partials = torch.empty(blk.partials_bytes, dtype=torch.uint8, device=self.device)
+        nbytes = self.lib.dlka_wgrad_finalize_plan_bytes(n)
+        self._fin_host = torch.zeros(nbytes, dtype=torch.uint8)
+        L.check(self.lib.dlka_wgrad_finalize_plan_init(ctypes.c_void_p(self._fin_host.data_ptr()), nbytes, n), "wgrad_finalize_plan_init")
+
     def prepare(self):
         """Re-lay the weights of all blocks (after every parameter update): one launch."""
         rc = self.lib.dlka_lka3d_tokens_prepare_run(L.ptr(self._plan_dev), L.ptr(self._plan_host), len(self.blocks), self._stream())
@@ -158,17 +179,39 @@ class DLKABlockStack:
 
     def backward(self, lo: int = 0, hi: int = None, on_block=None):
         """Backward pass of blocks[lo:hi] in reverse order (default: all)."""
+        import ctypes
         st = self._stream()
         idx = list(range(len(self.blocks)))[lo:hi]
+        defer = self._fin_host is not None
+        if defer and not self._fin_sealed and (len(idx) != len(self.blocks) or self._capturing()):
+            # the job table is recorded by a pass over ALL blocks outside graph capture
+            raise RuntimeError("DLKABlockStack: run one full eager backward() before a partial or a captured one (it records the finalize job table)")
         for i in reversed(idx):
             blk = self.blocks[i]
             if on_block is not None:
                 on_block(i)
             H, W, D = blk.dims
-            rc = self.lib.dlka_lka3d_attention_tokens_backward(L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.gy), L.ptr(blk.saved),
-                                                        blk.saved_bytes, L.ptr(blk.gx), byref(blk.gstruct), L.ptr(self.ws),
-                                                        self.ws_bytes, self.B, blk.C, H, W, D, self.dt, st)
-            L.check(rc, "lka3d_attention_tokens_backward")
+            if defer:
+                plan = None if self._fin_sealed else ctypes.c_void_p(self._fin_host.data_ptr())
+                rc = self.lib.dlka_lka3d_attention_tokens_backward_deferred_v(
+                    L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.gy), L.ptr(blk.saved), blk.saved_bytes, L.ptr(blk.gx), byref(blk.gstruct), L.ptr(self.ws),
+                    self.ws_bytes, L.ptr(blk.partials), blk.partials_bytes, plan, i, self.B, blk.C, H, W, D, self.dt, 0, st)
+                L.check(rc, "lka3d_attention_tokens_backward_deferred_v")
+            else:
+                rc = self.lib.dlka_lka3d_attention_tokens_backward(L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.gy), L.ptr(blk.saved),
+                                                            blk.saved_bytes, L.ptr(blk.gx), byref(blk.gstruct), L.ptr(self.ws),
+                                                            self.ws_bytes, self.B, blk.C, H, W, D, self.dt, st)
+                L.check(rc, "lka3d_attention_tokens_backward")
+        if defer and idx:
+            if not self._fin_sealed:
+                L.check(self.lib.dlka_wgrad_finalize_plan_seal(ctypes.c_void_p(self._fin_host.data_ptr())), "wgrad_finalize_plan_seal")
+                self._fin_dev = self._fin_host.to(self.device) if self.device.type == "cuda" else self._fin_host
+                self._fin_sealed = True
+            rc = self.lib.dlka_wgrad_finalize_run(L.ptr(self._fin_dev), ctypes.c_void_p(self._fin_host.data_ptr()), idx[0], idx[-1] + 1, st)
+            L.check(rc, "wgrad_finalize_run")
+
+    def _capturing(self) -> bool:
+        return self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
 
     def forward_backward(self, on_block=None):
         self.forward(on_block)

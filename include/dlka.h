@@ -308,6 +308,28 @@ int dlka_lka3d_attention_tokens_backward(const void *x, const dlka_lka3d_params 
                                          void *grad_x, const dlka_lka3d_grads *grads,
                                          void *workspace, size_t workspace_bytes,
                                          int B, int C, int D, int H, int W, int dtype, void *stream);
+/* Weight-gradient finalisation of MANY blocks in ONE launch.  The backward call above ends the block's seven weight gradients with one
+ * "finalize" launch (fold of the row-chunk partial sums, re-layout of the depthwise staging): 21 dependent launches of 15 - 30 us per step for the
+ * blocks of a D_LKA_Former patch, most of each latency.  Nothing later in the backward pass reads their results, so a model that steps all its
+ * blocks lets the partial sums of every block land in a block-PRIVATE area and folds them all at the end of the pass (or of a slice of it):
+ *   _partials_bytes_v        size of a block's private partial-sum area;
+ *   _plan_bytes / _plan_init a HOST job table for n blocks;
+ *   _backward_deferred_v     the backward call without its finalize launch; partial sums go to `partials`; with plan_host != NULL it records the
+ *                            block's jobs in slot `plan_slot` (pointers of `partials` and of the gradient buffers: they must stay put);
+ *   _plan_seal               after every slot has been recorded once: computes the launch geometry; the caller then copies the table to the device;
+ *   _run(plan_device, plan_host, block_lo, block_hi)   ONE launch that finalises the weight gradients of blocks [block_lo, block_hi).
+ * Results are identical to the per-block launch (same folds in the same order). */
+size_t dlka_lka3d_tokens_partials_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
+size_t dlka_wgrad_finalize_plan_bytes(int nblocks);
+int dlka_wgrad_finalize_plan_init(void *plan_host, size_t plan_bytes, int nblocks);
+int dlka_lka3d_attention_tokens_backward_deferred_v(const void *x, const dlka_lka3d_params *p, const void *grad_y,
+                                                    const void *saved, size_t saved_bytes,
+                                                    void *grad_x, const dlka_lka3d_grads *grads,
+                                                    void *workspace, size_t workspace_bytes,
+                                                    void *partials, size_t partials_bytes, void *plan_host, int plan_slot,
+                                                    int B, int C, int D, int H, int W, int dtype, int variant, void *stream);
+int dlka_wgrad_finalize_plan_seal(void *plan_host);
+int dlka_wgrad_finalize_run(const void *plan_device, const void *plan_host, int block_lo, int block_hi, void *stream);
 
 /* =======================================================================================
  * TransformerBlock_3D_single_deform_LKA: what surrounds the D-LKA block
