@@ -313,7 +313,7 @@ static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st
             // kernel's time is ONE wave's serial instruction stream (~7.7 K instructions at 7^3); 4 outputs per work-item double the waves
             // and halve the stream.  Chosen where the 8-wide grid leaves SIMDs empty.
             const long waves8 = runs2 * cpb / 64 * cdiv(a.C, cpb);
-            static const bool no_tw4 = getenv("DLKA_DW_NO_TW4") != nullptr;   // A/B
+            constexpr bool no_tw4 = false;
             // (measured at the stage shapes, us, 4 vs 8 wide: 5^3 13.3 / 17.9 at 16^3, 12.7 / 17.4 at 8^3, 11.0 / 12.4 at 4^3; 7^3 19.0 / 18.5 at 16^3, 8.8 / 9.5 at 8^3)
             if (!no_tw4 && th == 2 && waves8 < (kw == 5 ? 1024 : 384) && a.W % 4 == 0 && cdiv(a.W, 4) % wpr == 0) {
                 const long runs4 = (long)a.B * a.D * dil_w * cdiv(a.H, th * dil_w) * cdiv(a.W, 4);
@@ -324,7 +324,7 @@ static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st
                 DLKA_CHECK_LAUNCH();
                 return DLKA_OK;
             }
-            static const bool no_wl = getenv("DLKA_DW_NO_WL") != nullptr;   // A/B
+            constexpr bool no_wl = false;   // (measured: 54.3 -> 45.0 us at 32 channels / 32^3, profiles/r04_notes.md)
             if (kw == 7 && th == 2 && cpb == 32 && a.kd == 7 && !no_wl) { auto k = cl_dwconv_rowsN_kernel<T, 7, 3, TW, 2, true>; DLKA_LAUNCH(k, grid2, block, 0, st, ax); }
             else if (kw == 7 && th == 2) { auto k = cl_dwconv_rowsN_kernel<T, 7, 3, TW, 2>; DLKA_LAUNCH(k, grid2, block, 0, st, ax); }
             else if (kw == 5 && th == 2) { auto k = cl_dwconv_rowsN_kernel<T, 5, 1, TW, 2>; DLKA_LAUNCH(k, grid2, block, 0, st, ax); }
