@@ -127,6 +127,10 @@ SIGNATURES = {
     "dlka_batchnorm_cl_forward": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 2 + [c_int64, c_int, ctypes.c_float, ctypes.c_float, c_int, c_void_p]),
     "dlka_batchnorm_cl_backward": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 5 + [c_int64, c_int, ctypes.c_float, c_int, c_void_p]),
     "dlka_channel_scale": (c_int, [c_void_p] * 3 + [c_int, c_int64, c_int, c_int, c_void_p]),
+    "dlka_batchnorm_planar_forward": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int64, ctypes.c_float, c_void_p]),
+    "dlka_batchnorm_planar_backward": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int64, c_void_p]),
+    "dlka_pointwise_planar_forward": (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int64, c_void_p]),
+    "dlka_pointwise_planar_backward": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int64, c_void_p]),
     "dlka_tblock3d_supported": (c_int, [c_int] * 6),
     "dlka_tblock3d_saved_bytes": (c_size_t, [c_int] * 6),
     "dlka_tblock3d_workspace_bytes": (c_size_t, [c_int] * 6),

@@ -1419,6 +1419,36 @@ int dlka_batchnorm_cl_backward(const void *g, const void *x, const void *y, cons
                             (float *)gres, nullptr, (float *)gw, (float *)gb, (long)M, (long)M, C, slope, training, (hipStream_t)stream);
 }
 
+// ---- planar (NCDHW) plumbing of the full net (planar_ops.hip) -----------------------------------------------------------------------
+int dlka_batchnorm_planar_forward(const void *x, const void *w, const void *b, void *stats, void *y, void *scratch, int B, int C, int64_t N, float eps,
+                                  void *stream)
+{
+    if (!x || !stats || !y || !scratch) return DLKA_ERR_NULL;
+    return launch_pl_bn_forward((const float *)x, (const float *)w, (const float *)b, (float *)stats, (float *)y, (float *)scratch, B, C, (long)N, eps,
+                                (hipStream_t)stream);
+}
+
+int dlka_batchnorm_planar_backward(const void *g, const void *x, const void *w, const void *stats, void *gx, void *gw, void *gb, void *scratch, int B, int C,
+                                   int64_t N, void *stream)
+{
+    if (!g || !x || !stats || !gx || !scratch) return DLKA_ERR_NULL;
+    return launch_pl_bn_backward((const float *)g, (const float *)x, (const float *)w, (const float *)stats, (float *)gx, (float *)gw, (float *)gb,
+                                 (float *)scratch, B, C, (long)N, (hipStream_t)stream);
+}
+
+int dlka_pointwise_planar_forward(const void *x, const void *w, const void *bias, void *y, int B, int Cin, int Cout, int64_t N, void *stream)
+{
+    if (!x || !w || !y) return DLKA_ERR_NULL;
+    return launch_pl_pw_forward((const float *)x, (const float *)w, (const float *)bias, (float *)y, B, Cin, Cout, (long)N, (hipStream_t)stream);
+}
+
+int dlka_pointwise_planar_backward(const void *x, const void *w, const void *g, void *gx, void *gw, void *gb, int B, int Cin, int Cout, int64_t N, void *stream)
+{
+    if (!x || !w || !g) return DLKA_ERR_NULL;
+    return launch_pl_pw_backward((const float *)x, (const float *)w, (const float *)g, (float *)gx, (float *)gw, (float *)gb, B, Cin, Cout, (long)N,
+                                 (hipStream_t)stream);
+}
+
 int dlka_channel_scale(const void *x, const void *mask, void *y, int B, int64_t N, int C, int dtype, void *stream)
 {
     if (!x || !mask || !y) return DLKA_ERR_NULL;

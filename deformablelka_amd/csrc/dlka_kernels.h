@@ -63,6 +63,12 @@ size_t cl_wgrad_part_floats(int M, int K, int Cout, int Cin);
 template <typename T> int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t st, FinalizeJob *defer = nullptr);
 size_t cl_wgrad_part_floats_mode(int M, int K, int Cout, int Cin, int amode);
 int launch_cl_wgrad_finalize(FinalizeBatch &b, hipStream_t st);
+// planar_ops.hip: NCDHW plumbing of the full net (BatchNorm3d in training mode, 1x1x1 convs on few channels)
+int launch_pl_bn_forward(const float *x, const float *w, const float *b, float *stats, float *y, float *scratch, int B, int C, long N, float eps, hipStream_t st);
+int launch_pl_bn_backward(const float *g, const float *x, const float *w, const float *stats, float *gx, float *gw, float *gb, float *scratch, int B, int C,
+                          long N, hipStream_t st);
+int launch_pl_pw_forward(const float *x, const float *w, const float *bias, float *y, int B, int CI, int CO, long N, hipStream_t st);
+int launch_pl_pw_backward(const float *x, const float *w, const float *g, float *gx, float *gw, float *gb, int B, int CI, int CO, long N, hipStream_t st);
 long cl_wgrad_finalize_plan_job(FinalizeJob &j);   // workgroups the job needs (sets its fold variant)
 int launch_cl_wgrad_finalize_table(const FinalizeJob *jobs_device, int job_lo, int job_hi, long nblocks, hipStream_t st);
 int launch_cl_wgrad_pw3(const WgradArgs *jobs, float *const *gw, float *const *gb, hipStream_t st, FinalizeJob *defer);

@@ -52,3 +52,48 @@ class _GeluFn(Function):
 
 def gelu(x):
     return _GeluFn.apply(x)
+
+
+class _BatchNormPlanarFn(Function):
+    """nn.BatchNorm3d in training mode on the planar HIP kernels (csrc/planar_ops.hip); returns y and the batch statistics
+    (mean, unbiased variance) the module folds into its running estimates."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        y, stats = ops.batchnorm_planar_forward(x, weight, bias, eps)
+        ctx.save_for_backward(x, weight, stats)
+        ctx.affine = weight is not None
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, _gstats):
+        x, weight, stats = ctx.saved_tensors
+        gx, gw, gb = ops.batchnorm_planar_backward(gy.contiguous(), x, weight, stats, ctx.affine)
+        return gx, gw, gb, None
+
+
+def batch_norm_train(x, weight, bias, eps=1e-5):
+    return _BatchNormPlanarFn.apply(x, weight, bias, eps)
+
+
+class _PointwisePlanarFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight)
+        return ops.pointwise_planar_forward(x, weight, bias)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        gx, gw, gb = ops.pointwise_planar_backward(x, weight, gy.contiguous(), need)
+        return gx, gw, gb
+
+
+def pointwise_planar(x, weight, bias=None):
+    """1x1x1 conv on planar fp32 tensors with few channels; callers check ops.pointwise_planar_supported first."""
+    return _PointwisePlanarFn.apply(x, weight, bias)

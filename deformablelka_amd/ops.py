@@ -293,6 +293,67 @@ def gelu_backward(x, gy):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# planar (NCDHW) plumbing of the full net: BatchNorm3d in training mode, 1x1x1 convs on few channels (csrc/planar_ops.hip)
+# ------------------------------------------------------------------------------------------------------------
+PLANAR_PW_CIN = (1, 2, 4, 8, 14, 16, 32)
+
+
+def batchnorm_planar_forward(x, weight, bias, eps=1e-5):
+    """x (B, C, *spatial) fp32 contiguous -> y, stats (4, C) = mean, rstd, unbiased variance, mean - pivot (batch statistics)."""
+    L.require_device(x)
+    B, C = x.shape[:2]
+    N = x[0, 0].numel()
+    y = torch.empty_like(x)
+    stats = torch.empty(4, C, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    L.check(L.get_lib().dlka_batchnorm_planar_forward(L.ptr(x), L.ptr(weight), L.ptr(bias), L.ptr(stats), L.ptr(y), L.ptr(scratch), B, C, N, float(eps),
+                                                      L.stream_ptr(x)), "batchnorm_planar_forward")
+    return y, stats
+
+
+def batchnorm_planar_backward(g, x, weight, stats, affine=True):
+    L.require_device(x, g)
+    B, C = x.shape[:2]
+    N = x[0, 0].numel()
+    gx = torch.empty_like(x)
+    gw = torch.empty(C, dtype=torch.float32, device=x.device) if affine else None
+    gb = torch.empty(C, dtype=torch.float32, device=x.device) if affine else None
+    scratch = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    L.check(L.get_lib().dlka_batchnorm_planar_backward(L.ptr(g), L.ptr(x), L.ptr(weight), L.ptr(stats), L.ptr(gx), L.ptr(gw), L.ptr(gb), L.ptr(scratch), B, C, N,
+                                                       L.stream_ptr(x)), "batchnorm_planar_backward")
+    return gx, gw, gb
+
+
+def pointwise_planar_supported(x, weight, need_weight_grad=True) -> bool:
+    Cout, Cin = weight.shape[:2]
+    return (x.dtype == torch.float32 and weight.dtype == torch.float32 and Cin in PLANAR_PW_CIN and Cout <= (16 if need_weight_grad else 64)
+            and x[0, 0].numel() % 4 == 0 and (not need_weight_grad or Cout in PLANAR_PW_CIN))
+
+
+def pointwise_planar_forward(x, weight, bias=None):
+    """1x1x1 conv: x (B, Cin, *spatial) fp32 contiguous, weight (Cout, Cin, 1, 1, 1)."""
+    L.require_device(x, weight)
+    B, Cin = x.shape[:2]
+    Cout = weight.shape[0]
+    y = torch.empty((B, Cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    L.check(L.get_lib().dlka_pointwise_planar_forward(L.ptr(x), L.ptr(weight), L.ptr(bias), L.ptr(y), B, Cin, Cout, x[0, 0].numel(), L.stream_ptr(x)),
+            "pointwise_planar_forward")
+    return y
+
+
+def pointwise_planar_backward(x, weight, g, need=(True, True, True)):
+    L.require_device(x, weight, g)
+    B, Cin = x.shape[:2]
+    Cout = weight.shape[0]
+    gx = torch.empty_like(x) if need[0] else None
+    gw = torch.empty_like(weight) if need[1] else None
+    gb = torch.empty(Cout, dtype=torch.float32, device=x.device) if (need[1] and need[2]) else None
+    L.check(L.get_lib().dlka_pointwise_planar_backward(L.ptr(x), L.ptr(weight), L.ptr(g), L.ptr(gx), L.ptr(gw), L.ptr(gb), B, Cin, Cout, x[0, 0].numel(),
+                                                       L.stream_ptr(x)), "pointwise_planar_backward")
+    return gx, gw, gb
+
+
+# ------------------------------------------------------------------------------------------------------------
 # whole blocks
 # ------------------------------------------------------------------------------------------------------------
 def _ptr_struct(cls, fields, tensors):

@@ -364,6 +364,23 @@ int dlka_batchnorm_cl_backward(const void *g, const void *x, const void *y, cons
 /* y[b][n][c] = x[b][n][c] * mask[b][c]   (nn.Dropout3d drops whole channels per sample, :611; the mask comes from the caller's RNG) */
 int dlka_channel_scale(const void *x, const void *mask, void *y, int B, int64_t N, int C, int dtype, void *stream);
 
+/* ---- planar (NCDHW) plumbing of the full D_LKA_Former --------------------------------------------------------------
+ * nn.BatchNorm3d in TRAINING mode over fp32 [B][C][N] tensors (the UnetResBlock norms of encoder1 / decoder2 at full resolution,
+ * 3D/d_lka_former/network_architecture/dynunet_block.py:66-80): y = (x - mean) rstd w + b with batch statistics;
+ * stats = {mean[C], rstd[C], unbiased var[C], mean - x[0][c][0]} — 4*C floats; the caller updates its running estimates from rows 0 and 2;
+ * w / b may be NULL; scratch: 2*C floats.
+ * backward: gx fully overwritten, gw / gb (optional) = the affine gradients. */
+int dlka_batchnorm_planar_forward(const void *x, const void *w, const void *b, void *stats, void *y, void *scratch,
+                                  int B, int C, int64_t N, float eps, void *stream);
+int dlka_batchnorm_planar_backward(const void *g, const void *x, const void *w, const void *stats, void *gx, void *gw, void *gb,
+                                   void *scratch, int B, int C, int64_t N, void *stream);
+/* 1x1x1 nn.Conv3d on fp32 planar tensors with few channels (the output heads, d_lka_former_synapse.py:148-150; conv3 of a UnetResBlock whose channel
+ * count changes): y[b][co][v] = sum_ci W[co][ci] x[b][ci][v] + bias[co].  N % 4 == 0, Cin in {1, 2, 4, 8, 14, 16, 32}, Cout <= 64 (weight gradient:
+ * Cout <= 16); anything else returns DLKA_ERR_UNSUPPORTED.  backward: gx / gw (+ gb) optional, fully overwritten. */
+int dlka_pointwise_planar_forward(const void *x, const void *w, const void *bias, void *y, int B, int Cin, int Cout, int64_t N, void *stream);
+int dlka_pointwise_planar_backward(const void *x, const void *w, const void *g, void *gx, void *gw, void *gb,
+                                   int B, int Cin, int Cout, int64_t N, void *stream);
+
 /* ---- the whole wrapper block, one call per direction --------------------------------------------------------------- */
 /* Parameters of TransformerBlock_3D_single_deform_LKA other than epa_block's (those travel as dlka_lka3d_params):
  * state_dict keys norm.*, gamma, pos_embed, conv51.conv{1,2}.conv.weight, conv51.norm{1,2}.*, conv8.1.* (:609-616). */

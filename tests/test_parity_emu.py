@@ -332,3 +332,56 @@ def test_deform3d_cl_gx_second_generation_fixed_point_kernel(C, dims, mode, scal
 def test_lka3d_tokens_pointwise_pair_equals_two_launches(dims, dtype):
     parity.check_lka3d_tokens_pointwise_pair("cpu", 1, dims, dtype)
 
+
+
+# ---- planar (NCDHW) plumbing of the full net (csrc/planar_ops.hip) against torch's own CPU ops --------------------------------------
+@pytest.mark.parametrize("shape,affine", [((2, 16, 3, 8, 12), True), ((3, 5, 2, 3, 7), True), ((1, 4, 4, 4, 8), False)])
+def test_batchnorm_planar_training_mode(shape, affine):
+    """dlka_batchnorm_planar_*: batch statistics (with |mean| >> std in one channel), normalisation, all three gradients, the unbiased variance
+    for the running estimate — against torch.nn.functional.batch_norm in training mode (the reference's nn.BatchNorm3d, dynunet_block.py:66-80)."""
+    from deformablelka_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(shape, generator=g)
+    x[:, 0] = x[:, 0] * 0.01 + 300.0            # the pivoted sums must keep this channel's variance
+    C = shape[1]
+    w = torch.randn(C, generator=g) if affine else None
+    b = torch.randn(C, generator=g) if affine else None
+    gy = torch.randn(shape, generator=g)
+    y, stats = ops.batchnorm_planar_forward(x, w, b, 1e-5)
+    gx, gw, gb = ops.batchnorm_planar_backward(gy, x, w, stats, affine)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True) if affine else None
+    br = b.double().requires_grad_(True) if affine else None
+    rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    yr = torch.nn.functional.batch_norm(xr, rm, rv, wr, br, True, 1.0, 1e-5)
+    yr.backward(gy.double())
+    assert torch.allclose(y.double(), yr, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(stats[0].double(), rm, rtol=1e-5, atol=1e-5) and torch.allclose(stats[2].double(), rv, rtol=1e-3, atol=1e-7)
+    scale = float(xr.grad.abs().max())
+    assert torch.allclose(gx.double(), xr.grad, rtol=1e-3, atol=1e-4 * scale)
+    if affine:
+        assert torch.allclose(gw.double(), wr.grad, rtol=1e-3, atol=1e-3) and torch.allclose(gb.double(), br.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,dims,bias", [(16, 14, (2, 6, 8), True), (1, 16, (3, 4, 4), False), (32, 14, (1, 2, 8), True), (16, 16, (5, 5, 4), False)])
+def test_pointwise_planar_conv(cin, cout, dims, bias):
+    """dlka_pointwise_planar_*: the 1x1x1 convs of the plumbing (output heads 16 / 32 -> 14, conv3 of encoder1 1 -> 16) against F.conv3d: forward,
+    data gradient, weight gradient (voxel axis contracted on the matrix cores) and bias gradient."""
+    from deformablelka_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((2, cin) + dims, generator=g)
+    w = torch.randn(cout, cin, 1, 1, 1, generator=g) * 0.3
+    b = torch.randn(cout, generator=g) if bias else None
+    gy = torch.randn((2, cout) + dims, generator=g)
+    assert ops.pointwise_planar_supported(x, w)
+    y = ops.pointwise_planar_forward(x, w, b)
+    gx, gw, gb = ops.pointwise_planar_backward(x, w, gy, (True, True, bias))
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if bias else None
+    yr = torch.nn.functional.conv3d(xr, wr, br)
+    yr.backward(gy.double())
+    assert torch.allclose(y.double(), yr, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(gx.double(), xr.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(gw.double(), wr.grad, rtol=1e-4, atol=1e-4)
+    if bias:
+        assert torch.allclose(gb.double(), br.grad, rtol=1e-4, atol=1e-4)

@@ -435,3 +435,72 @@ def test_deform3d_cl_gx_second_generation_fixed_point_kernel(C, dims, mode):
 def test_lka3d_tokens_pointwise_pair_equals_two_launches(dims, dtype):
     parity.check_lka3d_tokens_pointwise_pair(DEV, 2, dims, dtype)
 
+
+
+# ---- planar plumbing of the full net at its real shapes (csrc/planar_ops.hip) against torch's own GPU ops --------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [16])
+def test_batchnorm_planar_full_resolution_vs_torch(C):
+    """The five BatchNorm3d layers of encoder1 / decoder2 at 2 x C x 64 x 128 x 128 through network.BatchNorm3d (HIP) against nn.BatchNorm3d
+    (torch / MIOpen) on the same tensors: output, running statistics, all gradients."""
+    import torch.nn as nn
+    from deformablelka_amd.network import BatchNorm3d
+    torch.manual_seed(0)
+    x = (torch.randn(2, C, 64, 128, 128, device="cuda") * 1.7 + 0.4)
+    gy = torch.randn_like(x)
+    a, b = BatchNorm3d(C).cuda(), nn.BatchNorm3d(C).cuda()
+    with torch.no_grad():
+        a.weight.normal_(1, 0.2); a.bias.normal_(0, 0.2)
+    b.load_state_dict(a.state_dict())
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = a(xa), b(xb)
+    ya.backward(gy); yb.backward(gy)
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(a.running_mean, b.running_mean, rtol=1e-5, atol=1e-6) and torch.allclose(a.running_var, b.running_var, rtol=1e-4, atol=1e-6)
+    assert int(a.num_batches_tracked) == 1
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-3, atol=1e-5)
+    assert torch.allclose(a.weight.grad, b.weight.grad, rtol=2e-3, atol=0.5) and torch.allclose(a.bias.grad, b.bias.grad, rtol=2e-3, atol=0.5)
+    a.eval(); b.eval()
+    assert torch.allclose(a(x), b(x), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_instancenorm_planar_full_resolution_vs_torch():
+    """network.InstanceNorm3d (the net's default norm: the UnetResBlock norms of encoder1 / decoder2 at 2 x 16 x 64 x 128 x 128) against
+    nn.InstanceNorm3d: output and input gradient, training and evaluation mode."""
+    import torch.nn as nn
+    from deformablelka_amd.network import InstanceNorm3d
+    torch.manual_seed(0)
+    x = (torch.randn(2, 16, 64, 128, 128, device="cuda") * 1.7 + 0.4)
+    gy = torch.randn_like(x)
+    a, b = InstanceNorm3d(16).cuda(), nn.InstanceNorm3d(16).cuda()
+    assert not list(a.state_dict().keys())
+    for mode in (True, False):
+        a.train(mode); b.train(mode)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya, yb = a(xa), b(xb)
+        ya.backward(gy); yb.backward(gy)
+        assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)
+        assert torch.allclose(xa.grad, xb.grad, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,dims", [(16, 14, (64, 128, 128)), (32, 14, (32, 32, 32)), (1, 16, (64, 128, 128))])
+def test_pointwise_planar_conv_real_shapes_vs_torch(cin, cout, dims):
+    """The 1x1x1 convs of the plumbing (output heads, conv3 of encoder1) through network.Convolution (HIP) against the same weights as one fp64 matmul."""
+    from deformablelka_amd.network import Convolution
+    torch.manual_seed(1)
+    conv = Convolution(cin, cout, 1, 1, bias=True).cuda()
+    x = torch.randn(2, cin, *dims, device="cuda", requires_grad=True)
+    gy = torch.randn(2, cout, *dims, device="cuda")
+    y = conv(x)
+    y.backward(gy)
+    w, b = conv.conv.weight.detach().double().reshape(cout, cin), conv.conv.bias.detach().double()
+    xr = x.detach().double().reshape(2, cin, -1)
+    yr = torch.matmul(w, xr) + b.view(1, -1, 1)
+    gyr = gy.double().reshape(2, cout, -1)
+    assert torch.allclose(y.double().reshape(2, cout, -1), yr, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(x.grad.double().reshape(2, cin, -1), torch.matmul(w.t(), gyr), rtol=1e-5, atol=1e-5)
+    gw = torch.einsum("bon,bin->oi", gyr, xr)
+    assert torch.allclose(conv.conv.weight.grad.double().reshape(cout, cin), gw, rtol=1e-4, atol=1e-4 * float(gw.abs().max()))
+    assert torch.allclose(conv.conv.bias.grad.double(), gyr.sum((0, 2)), rtol=1e-4, atol=1e-4 * float(gyr.sum((0, 2)).abs().max()))
