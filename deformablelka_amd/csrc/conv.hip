@@ -252,9 +252,113 @@ __global__ __launch_bounds__(DLKA_THREADS) void conv_bwd_weight_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same weight gradient for the full net's full-resolution plumbing convs (3^3, stride 1, padding 1, <= 16 -> <= 16 channels at
+// 2 x 64 x 128 x 128: encoder1 / decoder2, d_lka_former_synapse.py:89-133) on the matrix cores.  The thread-per-voxel kernel above needs 1.6 ms per
+// conv there (18 TFLOP/s; 15 % of a trainer iteration).  Here the VOXEL axis is the contraction of v_mfma_f32_16x16x4_f32: per tap,
+// A[i = co][k = voxel] = grad_out, B[k = voxel][j = ci] = x shifted by the tap.  Lane (i, kg = lane >> 4) owns voxels w0 + 4 kg .. + 3 of a (b, d, h) row:
+// one 16-byte load of its grad_out row, and per (tap_d, tap_h) one 16-byte load of its x row plus the two neighbours x[w - 1], x[w + 4] — the three
+// tap_w shifts are formed in registers.  27 accumulators (one 16 x 16 tile per tap) stay in registers over the wave's rows and leave as one atomic
+// per element at the end (gw is zero-initialised by the caller, as for the kernel above).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv3_bwd_weight_mfma_kernel(const float *__restrict__ x, const float *__restrict__ gout, float *__restrict__ gw, Geom g,
+                                                                      int rows_per_wave)
+{
+    const int lane = threadIdx.x & 63, i = lane & 15, kg = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nrows = (long)g.B * g.D * g.H;
+    const long r0 = (long)wave * rows_per_wave, r1 = r0 + rows_per_wave < nrows ? r0 + rows_per_wave : nrows;
+    f32x4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool co_ok = i < g.Cout, ci_ok = i < g.C;
+    const long plane = (long)g.D * g.H * g.W;
+    for (long r = r0; r < r1; ++r) {
+        const int h = (int)(r % g.H), d = (int)((r / g.H) % g.D), b = (int)(r / ((long)g.H * g.D));
+        const float *grow = gout + ((long)b * g.Cout + (co_ok ? i : 0)) * plane + ((long)d * g.H + h) * g.W;
+        const float *xbase = x + ((long)b * g.C + (ci_ok ? i : 0)) * plane;
+        for (int w0 = 0; w0 < g.W; w0 += 16) {   // wave-uniform trip count (the MFMAs are wave-wide)
+            const int w = w0 + 4 * kg;
+            const bool in = w < g.W;              // (W % 4 == 0: a lane's four voxels are inside the row or all outside)
+            f32x4 q = *reinterpret_cast<const f32x4 *>(grow + (in ? w : 0));
+            if (!in || !co_ok) q = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int td = 0; td < 3; ++td) {
+                const int zd = d + td - 1;
+                if (zd < 0 || zd >= g.D) continue;   // uniform
+#pragma unroll
+                for (int th = 0; th < 3; ++th) {
+                    const int zh = h + th - 1;
+                    if (zh < 0 || zh >= g.H) continue;   // uniform
+                    const float *xr = xbase + ((long)zd * g.H + zh) * g.W;
+                    f32x4 c = *reinterpret_cast<const f32x4 *>(xr + (in ? w : 0));
+                    float lft = xr[(in && w > 0) ? w - 1 : 0], rgt = xr[(in && w + 4 < g.W) ? w + 4 : 0];
+                    if (!in || !ci_ok) { c = f32x4{0.f, 0.f, 0.f, 0.f}; lft = 0.f; rgt = 0.f; }
+                    if (w == 0) lft = 0.f;
+                    if (w + 4 >= g.W) rgt = 0.f;
+                    const int t0 = (td * 3 + th) * 3;
+                    // tap_w = 0: x[w - 1 + s], 1: x[w + s], 2: x[w + 1 + s]
+                    acc[t0] = mfma_16x16x4(q[0], lft, acc[t0]); acc[t0] = mfma_16x16x4(q[1], c[0], acc[t0]);
+                    acc[t0] = mfma_16x16x4(q[2], c[1], acc[t0]); acc[t0] = mfma_16x16x4(q[3], c[2], acc[t0]);
+                    acc[t0 + 1] = mfma_16x16x4(q[0], c[0], acc[t0 + 1]); acc[t0 + 1] = mfma_16x16x4(q[1], c[1], acc[t0 + 1]);
+                    acc[t0 + 1] = mfma_16x16x4(q[2], c[2], acc[t0 + 1]); acc[t0 + 1] = mfma_16x16x4(q[3], c[3], acc[t0 + 1]);
+                    acc[t0 + 2] = mfma_16x16x4(q[0], c[1], acc[t0 + 2]); acc[t0 + 2] = mfma_16x16x4(q[1], c[2], acc[t0 + 2]);
+                    acc[t0 + 2] = mfma_16x16x4(q[2], c[3], acc[t0 + 2]); acc[t0 + 2] = mfma_16x16x4(q[3], rgt, acc[t0 + 2]);
+                }
+            }
+        }
+    }
+    // the four waves of the workgroup fold their tiles through LDS first (waves 2, 3 -> 0, 1; then 1 -> 0): every output element is hit by one
+    // atomic per WORKGROUP — with one per wave, 2048 waves queued on the same 6912 addresses and the atomics were most of the kernel's time
+    __shared__ __attribute__((aligned(16))) float red[2][27 * 64 * 4];
+    const int wv = threadIdx.x >> 6;
+    if (wv >= 2) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) *reinterpret_cast<f32x4 *>(&red[wv - 2][(t * 64 + lane) * 4]) = acc[t];
+    }
+    __syncthreads();
+    if (wv < 2) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const f32x4 o = *reinterpret_cast<const f32x4 *>(&red[wv][(t * 64 + lane) * 4]);
+            acc[t][0] += o[0]; acc[t][1] += o[1]; acc[t][2] += o[2]; acc[t][3] += o[3];
+        }
+    }
+    __syncthreads();
+    if (wv == 1) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) *reinterpret_cast<f32x4 *>(&red[0][(t * 64 + lane) * 4]) = acc[t];
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    // D layout: column j = lane & 15 = ci, rows 4 kg + r = co
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        const f32x4 o = *reinterpret_cast<const f32x4 *>(&red[0][(t * 64 + lane) * 4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = 4 * kg + r;
+            if (ci_ok && co < g.Cout) atomicAdd(gw + ((long)co * g.C + i) * 27 + t, acc[t][r] + o[r]);
+        }
+    }
+}
+
 template <typename T>
 int launch_conv_bwd_weight(const T *x, const T *gout, float *gw32, const Geom &g, hipStream_t st)
 {
+    if constexpr (sizeof(T) == 4) {
+        if (g.group == 1 && g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 1 && g.ph == 1 && g.pw == 1 && g.dd == 1 &&
+            g.dh == 1 && g.dw == 1 && g.C <= 16 && g.Cout <= 16 && (g.W & 3) == 0) {
+            const long nrows = (long)g.B * g.D * g.H;
+            int rpw = (int)cdivl(nrows, 2048);   // ~2 waves per SIMD over the chip
+            if (rpw < 8) rpw = 8;
+            const long waves = cdivl(nrows, rpw);
+            DLKA_LAUNCH(conv3_bwd_weight_mfma_kernel, dim3((unsigned)cdivl(waves, 4)), dim3(256), 0, st, reinterpret_cast<const float *>(x),
+                        reinterpret_cast<const float *>(gout), gw32, g, rpw);
+            DLKA_CHECK_LAUNCH();
+            return DLKA_OK;
+        }
+    }
     constexpr int TPC = 4;
     const int cob = g.Og >= 16 ? 16 : (g.Og >= 8 ? 8 : (g.Og >= 4 ? 4 : (g.Og >= 2 ? 2 : 1)));
     const int cochunks = cdiv(g.Og, cob), tchunks = cdiv(g.K, TPC);

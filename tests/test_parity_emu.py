@@ -58,6 +58,9 @@ CONV = [
     (1, 4, 4, (7, 8, 6), (3, 5, 5), 1, (1, 6, 6), (1, 3, 3), 4),
     (1, 4, 6, (7, 6, 5), 3, 2, 1, 1, 2),
     (1, 40, 8, (1, 6, 6), (1, 5, 5), 1, (0, 2, 2), 1, 1),
+    (2, 16, 16, (5, 6, 20), 3, 1, 1, 1, 1),     # the full net's plumbing convs: weight gradient on the matrix cores (conv3_bwd_weight_mfma_kernel), W % 16 != 0
+    (1, 1, 16, (4, 9, 8), 3, 1, 1, 1, 1),       # encoder1.conv1: one input channel
+    (2, 5, 14, (3, 3, 32), 3, 1, 1, 1, 1),      # ragged channel counts
 ]
 
 
