@@ -371,7 +371,8 @@ def fullnet_metric(batch, steps, dev, bf16=False):
         raise RuntimeError("full-net loss is not finite")
     return {"metric": "3D D-LKA Former full-net training iteration volumes/sec (64x128x128)", "value": round(batch / dt, 3), "unit": "volumes/s",
             "ms_per_step": round(dt * 1e3, 2), "params": sum(p.numel() for p in net.parameters()), "loss": round(float(loss), 4),
-            "path": "nn.Module + autograd, eager; D-LKA blocks = HIP kernels; plumbing convs = GEMM re-expressions (rocBLAS) / HIP 3^3 convs, norms = torch" +
+            "path": "nn.Module + autograd, eager; D-LKA blocks = HIP kernels; plumbing: stride == kernel convs = patchify / depth-to-space GEMMs (rocBLAS), 3^3 and 1x1x1 convs "
+                    "and Instance / BatchNorm3d = HIP kernels (weight gradients on the matrix cores), GroupNorm / loss / optimizer = torch" +
                     ("; torch.autocast(bf16) around forward + loss: torch layers only — the transformer blocks and the conv re-expressions stay on their fp32 paths" if bf16 else "")}
 
 
