@@ -323,7 +323,13 @@ def tblock_metric(batch, steps, warmup, dev):
             gy = torch.randn(batch, H, W, D, C, device=dev).permute(0, 4, 1, 2, 3)
             chains.append((mods, x, gy))
 
+    params = [p for mods, _, _ in chains for m in mods for p in m.parameters()] + [x for _, x, _ in chains]
+
     def step():
+        # as the trainer's iteration does (optimizer.zero_grad(), set_to_none): without it autograd ACCUMULATES into the existing .grad tensors —
+        # one extra elementwise add launch per parameter and block (26 x 21 x 4.7 us = 2.6 ms of a 21.4 ms step, rocprofv3 of scripts/prof_tblock.py)
+        for p in params:
+            p.grad = None
         for mods, x, gy in chains:
             y = x
             for m in mods:
@@ -338,9 +344,28 @@ def tblock_metric(batch, steps, warmup, dev):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"metric": "3D D-LKA transformer-block (wrapper + D-LKA) fwd+bwd volumes/sec (64x128x128)", "value": round(batch / dt, 3),
-            "unit": "volumes/s", "ms_per_step": round(dt * 1e3, 3), "path": "nn.Module + autograd, eager (no hipGraph), training mode",
-            "blocks": sum(len(c[0]) for c in chains)}
+    out = {"metric": "3D D-LKA transformer-block (wrapper + D-LKA) fwd+bwd volumes/sec (64x128x128)", "value": round(batch / dt, 3),
+           "unit": "volumes/s", "ms_per_step": round(dt * 1e3, 3), "path": "nn.Module + autograd, eager (no hipGraph), training mode",
+           "blocks": sum(len(c[0]) for c in chains)}
+    # the same nn.Module step captured in a hipGraph (autograd Functions launch on the capturing stream, outputs come from the graph's pool)
+    try:
+        for p in params:
+            p.grad = None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dg = (time.perf_counter() - t0) / steps
+        out["hipgraph"] = {"value": round(batch / dg, 3), "ms_per_step": round(dg * 1e3, 3), "path": "the same nn.Module step, captured once and replayed"}
+    except Exception as e:   # capture is an extra: the eager figure above stands on its own
+        out["hipgraph"] = {"error": repr(e)[:200]}
+    return out
 
 
 def fullnet_metric(batch, steps, dev, bf16=False):
