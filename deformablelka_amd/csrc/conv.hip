@@ -80,9 +80,101 @@ __global__ __launch_bounds__(DLKA_THREADS) void conv_fwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 3^3 / stride 1 / padding 1 convolution with <= 16 input and <= 16 output channels on planar fp32 tensors — the full net's full-resolution
+// plumbing convs (encoder1 / decoder2: 2 x 16 x 64 x 128 x 128, d_lka_former_synapse.py:89-133) — on the matrix cores; serves the forward
+// pass and, with the taps flipped and the channel roles exchanged (FLIP), the data gradient.  The thread-per-voxel kernels take 0.51 / 0.78 ms there.
+//   out[i][v] = sum_tap sum_k A_tap[i][k] in[k][v + tap],   v_mfma_f32_16x16x4_f32: D[i = out channel][j = voxel], k = in channel (4 steps of 4)
+// Lane (j = lane & 15, kg = lane >> 4): the voxel w0 + j of a (b, d, h) row and input channels 4 s + kg.  Per (tap_d, tap_h) and k-step three dword
+// loads (left, centre, right neighbour along w: the three tap_w operands); the 27 x 4 weight values a lane needs as A operand (row i = lane & 15,
+// k = 4 s + kg) are taken from the weight tensor once and stay in registers.  A wave walks a run of rows.
+// ---------------------------------------------------------------------------------------------
+template <bool FLIP>
+__global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ bias,
+                                                           float *__restrict__ out, Geom g, int rows_per_wave)
+{
+    const int lane = threadIdx.x & 63, j = lane & 15, kg = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int CI = FLIP ? g.Cout : g.C, CO = FLIP ? g.C : g.Cout;   // channels of `in` / `out` of THIS op
+    // A operand: forward A_tap[i = co][k = ci] = W[co][ci][tap]; data gradient A_tap[i = ci][k = co] = W[co][ci][26 - tap]
+    float areg[27][4];
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int i = j, k = 4 * s4 + kg;
+            float v = 0.f;
+            if (i < CO && k < CI) v = FLIP ? w[((long)k * g.C + i) * 27 + (26 - t)] : w[((long)i * g.C + k) * 27 + t];
+            areg[t][s4] = v;
+        }
+    const long nrows = (long)g.B * g.D * g.H;
+    const long r0 = (long)wave * rows_per_wave, r1 = r0 + rows_per_wave < nrows ? r0 + rows_per_wave : nrows;
+    const long plane = (long)g.D * g.H * g.W;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!FLIP && bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = 4 * kg + r < CO ? bias[4 * kg + r] : 0.f;
+    }
+    for (long r = r0; r < r1; ++r) {
+        const int h = (int)(r % g.H), d = (int)((r / g.H) % g.D), b = (int)(r / ((long)g.H * g.D));
+        for (int w0 = 0; w0 < g.W; w0 += 16) {   // wave-uniform trip count (the MFMAs are wave-wide)
+            const int wx = w0 + j;
+            const bool in_c = wx < g.W, in_l = in_c && wx > 0, in_r = wx + 1 < g.W;
+            f32x4 acc = {bv[0], bv[1], bv[2], bv[3]};
+#pragma unroll
+            for (int td = 0; td < 3; ++td) {
+                const int zd = d + td - 1;
+                if (zd < 0 || zd >= g.D) continue;   // uniform
+#pragma unroll
+                for (int th = 0; th < 3; ++th) {
+                    const int zh = h + th - 1;
+                    if (zh < 0 || zh >= g.H) continue;   // uniform
+                    const int t0 = (td * 3 + th) * 3;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int k = 4 * s4 + kg;
+                        const bool kok = k < CI;
+                        const float *xr = in + (((long)b * CI + (kok ? k : 0)) * g.D + zd) * (long)g.H * g.W + (long)zh * g.W;
+                        float l = xr[in_l ? wx - 1 : 0], c = xr[in_c ? wx : 0], rr = xr[in_r ? wx + 1 : 0];
+                        if (!kok || !in_l) l = 0.f;
+                        if (!kok || !in_c) c = 0.f;
+                        if (!kok || !in_r) rr = 0.f;
+                        acc = mfma_16x16x4(areg[t0][s4], l, acc);
+                        acc = mfma_16x16x4(areg[t0 + 1][s4], c, acc);
+                        acc = mfma_16x16x4(areg[t0 + 2][s4], rr, acc);
+                    }
+                }
+            }
+            if (in_c) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int i = 4 * kg + r4;
+                    if (i < CO) out[((long)b * CO + i) * plane + ((long)d * g.H + h) * g.W + wx] = acc[r4];
+                }
+            }
+        }
+    }
+}
+
+static bool conv3_mfma_shape(const Geom &g)
+{
+    return g.group == 1 && g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 1 && g.ph == 1 && g.pw == 1 && g.dd == 1 &&
+           g.dh == 1 && g.dw == 1 && g.C <= 16 && g.Cout <= 16;
+}
+static int conv3_mfma_rows_per_wave(const Geom &g, long &waves)
+{
+    const long nrows = (long)g.B * g.D * g.H;
+    int rpw = (int)cdivl(nrows, 2048);   // ~2 waves per SIMD over the chip
+    if (rpw < 1) rpw = 1;
+    waves = cdivl(nrows, rpw);
+    return rpw;
+}
+
 template <typename T>
 int launch_conv_fwd(const T *x, const T *w, const T *bias, T *out, float *wt, const Geom &g, hipStream_t st)
 {
+    // (conv3_mfma_kernel<false> serves this shape too, but measured SLOWER than the kernel above at 2 x 16 x 64x128x128: 627 vs 513 us — per 16 voxels it
+    //  issues 108 dword loads with their address arithmetic for 108 MFMAs; the data gradient, whose thread-per-voxel form is slower, gains: 617 vs 776 us)
     const int cob = pick_pow2_upto32(g.Og);
     const int OgP = round_up(g.Og, cob);
     int rc = launch_relayout_weight<T>(w, wt, g.group, g.Og, g.Cg, g.K, OgP, st);
@@ -159,6 +251,16 @@ __global__ __launch_bounds__(DLKA_THREADS) void conv_bwd_data_kernel(
 template <typename T>
 int launch_conv_bwd_data(const T *gout, const T *w, T *gx, float *wb, const Geom &g, hipStream_t st)
 {
+    if constexpr (sizeof(T) == 4) {
+        if (conv3_mfma_shape(g) && g.Cout >= 4) {
+            long waves;
+            const int rpw = conv3_mfma_rows_per_wave(g, waves);
+            DLKA_LAUNCH(conv3_mfma_kernel<true>, dim3((unsigned)cdivl(waves, 4)), dim3(256), 0, st, reinterpret_cast<const float *>(gout),
+                        reinterpret_cast<const float *>(w), (const float *)nullptr, reinterpret_cast<float *>(gx), g, rpw);
+            DLKA_CHECK_LAUNCH();
+            return DLKA_OK;
+        }
+    }
     const int cib = pick_pow2_upto32(g.Cg);
     const int CgP = round_up(g.Cg, cib);
     {
