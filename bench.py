@@ -394,7 +394,25 @@ def fullnet_metric(batch, steps, dev, bf16=False):
     dt = (time.perf_counter() - t0) / steps
     if not bool(torch.isfinite(loss)):
         raise RuntimeError("full-net loss is not finite")
+    graphed = None
+    if not bf16:
+        try:   # the same iteration as one hipGraph launch (training.GraphedIteration)
+            it = training.GraphedIteration(net, opt, x, tgt)
+            for _ in range(2):
+                it()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                gl = it()
+            torch.cuda.synchronize()
+            dg = (time.perf_counter() - t0) / steps
+            if bool(torch.isfinite(gl)):
+                graphed = {"value": round(batch / dg, 3), "ms_per_step": round(dg * 1e3, 2), "loss": round(float(gl), 4),
+                           "path": "the same trainer iteration captured once in a hipGraph and replayed (training.GraphedIteration)"}
+        except Exception as e:
+            graphed = {"error": repr(e)[:200]}
     return {"metric": "3D D-LKA Former full-net training iteration volumes/sec (64x128x128)", "value": round(batch / dt, 3), "unit": "volumes/s",
+            "hipgraph": graphed,
             "ms_per_step": round(dt * 1e3, 2), "params": sum(p.numel() for p in net.parameters()), "loss": round(float(loss), 4),
             "path": "nn.Module + autograd, eager; D-LKA blocks = HIP kernels; plumbing: stride == kernel convs = patchify / depth-to-space GEMMs (rocBLAS), 3^3 and 1x1x1 convs "
                     "and Instance / BatchNorm3d = HIP kernels (weight gradients on the matrix cores), GroupNorm / loss / optimizer = torch" +

@@ -86,3 +86,36 @@ def run_iteration(net: nn.Module, optimizer, data: torch.Tensor, target, loss_fn
         torch.nn.utils.clip_grad_norm_(net.parameters(), clip_norm)
         optimizer.step()
     return loss.detach()
+
+
+class GraphedIteration:
+    """``run_iteration`` captured ONCE in a hipGraph and replayed: forward, loss, backward, ``clip_grad_norm_`` and the optimizer step become one
+    graph launch per iteration (the D-LKA autograd Functions launch on the capturing stream; every tensor the iteration creates comes from the
+    graph's private pool).  Static shapes: ``data`` / ``target`` are copied into the captured input buffers.  The learning rate is read when the graph
+    is captured — re-capture after changing it (the reference's poly schedule changes it once per EPOCH).  Single process; with
+    ``DistributedDataParallel`` use the eager ``run_iteration``."""
+
+    def __init__(self, net: nn.Module, optimizer, data: torch.Tensor, target: torch.Tensor, loss_fn: Callable = deep_supervision_loss,
+                 clip_norm: float = 12.0, warmup: int = 3):
+        if not data.is_cuda:
+            raise RuntimeError("GraphedIteration needs GPU tensors")
+        self.net, self.optimizer = net, optimizer
+        self.data, self.target = data.clone(), target.clone()
+        side = torch.cuda.Stream(device=data.device)
+        side.wait_stream(torch.cuda.current_stream(data.device))
+        with torch.cuda.stream(side):   # warm-up off the default stream: optimizer state, lazily built tables and workspaces exist before the capture
+            for _ in range(max(1, warmup)):
+                run_iteration(net, optimizer, self.data, self.target, loss_fn, True, clip_norm)
+        torch.cuda.current_stream(data.device).wait_stream(side)
+        optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = run_iteration(net, optimizer, self.data, self.target, loss_fn, True, clip_norm)
+
+    def __call__(self, data: torch.Tensor = None, target: torch.Tensor = None) -> torch.Tensor:
+        if data is not None:
+            self.data.copy_(data, non_blocking=True)
+        if target is not None:
+            self.target.copy_(target, non_blocking=True)
+        self.graph.replay()
+        return self.loss

@@ -80,3 +80,26 @@ def test_sliding_window_with_the_real_network():
     assert lab.shape == vol.shape and bool(torch.isfinite(score).all()) and (score.sum(0) - 1).abs().max().item() < 1e-4
     seg, probs = inference.predict_3d_tiled(net, vol[None], (96, 96, 96), step_size=0.5, tile_batch=2)
     assert seg.shape == vol.shape and (probs.sum(0) - 1).abs().max().item() < 1e-4
+
+
+@pytest.mark.gpu
+def test_graphed_trainer_iteration_follows_the_eager_one():
+    """training.GraphedIteration (one hipGraph launch per trainer iteration) against the eager run_iteration from the same start: the losses of
+    three consecutive iterations agree (they depend on the parameter updates of the previous ones), and new inputs reach the captured buffers."""
+    from deformablelka_amd import training
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    x = torch.randn(1, 1, 64, 128, 128, device=dev)
+    tgt = torch.randint(0, 14, (1, 64, 128, 128), device=dev)
+    nets = []
+    for _ in range(2):
+        torch.manual_seed(1)
+        net = training.initialize_network(1, 14, (64, 128, 128), device=dev).train()
+        nets.append((net, training.initialize_optimizer(net, initial_lr=1e-3)))
+    nets[1][0].load_state_dict(nets[0][0].state_dict())
+    eager = [float(training.run_iteration(nets[0][0], nets[0][1], x, tgt)) for _ in range(6)]
+    it = training.GraphedIteration(nets[1][0], nets[1][1], x, tgt, warmup=3)    # three eager warm-up iterations inside
+    graphed = [float(it()) for _ in range(3)]
+    assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(eager[3:], graphed)), (eager, graphed)
+    x2 = torch.randn_like(x) * 3
+    assert abs(float(it(x2, tgt)) - graphed[-1]) > 0 and torch.equal(it.data, x2)
