@@ -117,6 +117,7 @@ SIGNATURES = {
                                                                POINTER(Lka3dPtrs), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_int,
                                                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dlka_wgrad_finalize_plan_seal": (c_int, [c_void_p]),
+    "dlka_wgrad_finalize_run_slot": (c_int, [c_void_p, c_int, c_void_p]),
     "dlka_wgrad_finalize_run": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dlka_lka3d_attention_tokens_backward": (c_int, [c_void_p, POINTER(Lka3dPtrs), c_void_p, c_void_p, c_size_t, c_void_p,
                                                      POINTER(Lka3dPtrs), c_void_p, c_size_t] + [c_int] * 6 + [c_void_p]),

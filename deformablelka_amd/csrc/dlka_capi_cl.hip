@@ -1161,6 +1161,22 @@ int dlka_lka3d_attention_tokens_backward_deferred_v(const void *x, const dlka_lk
     return DLKA_OK;
 }
 
+int dlka_wgrad_finalize_run_slot(const void *plan_host, int plan_slot, void *stream)
+{
+    if (!plan_host) return DLKA_ERR_NULL;
+    const FinPlanHeader *hd = (const FinPlanHeader *)plan_host;
+    if (hd->sealed || plan_slot < 0 || plan_slot >= hd->nblocks) return DLKA_ERR_SHAPE;
+    const int *first = (const int *)((const unsigned char *)plan_host + fin_first_off());
+    const FinalizeJob *all = (const FinalizeJob *)((const unsigned char *)plan_host + fin_jobs_off(hd->nblocks));
+    const int cnt = first[plan_slot];
+    if (cnt <= 0 || cnt > FIN_JOBS_PER_BLOCK) return DLKA_ERR_SHAPE;
+    FinalizeBatch fb;
+    memset(&fb, 0, sizeof(fb));
+    for (int j = 0; j < cnt; ++j) fb.j[j] = all[plan_slot * FIN_JOBS_PER_BLOCK + j];
+    fb.njobs = cnt;
+    return launch_cl_wgrad_finalize(fb, (hipStream_t)stream);
+}
+
 int dlka_wgrad_finalize_plan_seal(void *plan_host)
 {
     if (!plan_host) return DLKA_ERR_NULL;

@@ -138,9 +138,11 @@ class DLKABlockStack:
         """The seven weight gradients of a block end in a "finalize" launch that folds their partial sums; nothing later in the backward pass
         reads its results.  With block-PRIVATE partial-sum areas (288 GB of HBM: 0.4 GB for the 21 blocks) all blocks' finalisations become ONE
         launch at the end of the backward pass (or of a slice of it) instead of 21 dependent launches of 15 - 30 us, most of each latency
-        (include/dlka.h: dlka_wgrad_finalize_*).  The job table is recorded by the first backward pass and then lives on the device."""
+        (include/dlka.h: dlka_wgrad_finalize_*).  The job table is recorded while the blocks go through their first backward pass (which still
+        finalises block by block) and then lives on the device."""
         self._fin_host = self._fin_dev = None
         self._fin_sealed = False
+        self._fin_recorded = set()
         import os
         if not enable or os.environ.get("DLKA_STACK_PER_BLOCK_FINALIZE"):   # (A/B switch: the per-block finalize launches)
             return
@@ -183,32 +185,36 @@ class DLKABlockStack:
         st = self._stream()
         idx = list(range(len(self.blocks)))[lo:hi]
         defer = self._fin_host is not None
-        if defer and not self._fin_sealed and (len(idx) != len(self.blocks) or self._capturing()):
-            # the job table is recorded by a pass over ALL blocks outside graph capture
-            raise RuntimeError("DLKABlockStack: run one full eager backward() before a partial or a captured one (it records the finalize job table)")
+        plan_ptr = ctypes.c_void_p(self._fin_host.data_ptr()) if defer else None
         for i in reversed(idx):
             blk = self.blocks[i]
             if on_block is not None:
                 on_block(i)
             H, W, D = blk.dims
             if defer:
-                plan = None if self._fin_sealed else ctypes.c_void_p(self._fin_host.data_ptr())
+                record = not self._fin_sealed and i not in self._fin_recorded
                 rc = self.lib.dlka_lka3d_attention_tokens_backward_deferred_v(
                     L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.gy), L.ptr(blk.saved), blk.saved_bytes, L.ptr(blk.gx), byref(blk.gstruct), L.ptr(self.ws),
-                    self.ws_bytes, L.ptr(blk.partials), blk.partials_bytes, plan, i, self.B, blk.C, H, W, D, self.dt, 0, st)
+                    self.ws_bytes, L.ptr(blk.partials), blk.partials_bytes, plan_ptr if record else None, i, self.B, blk.C, H, W, D, self.dt, 0, st)
                 L.check(rc, "lka3d_attention_tokens_backward_deferred_v")
+                if record:
+                    self._fin_recorded.add(i)
+                if not self._fin_sealed:   # the table is still being recorded: this block's folds as the ordinary per-block launch
+                    L.check(self.lib.dlka_wgrad_finalize_run_slot(plan_ptr, i, st), "wgrad_finalize_run_slot")
             else:
                 rc = self.lib.dlka_lka3d_attention_tokens_backward(L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.gy), L.ptr(blk.saved),
                                                             blk.saved_bytes, L.ptr(blk.gx), byref(blk.gstruct), L.ptr(self.ws),
                                                             self.ws_bytes, self.B, blk.C, H, W, D, self.dt, st)
                 L.check(rc, "lka3d_attention_tokens_backward")
         if defer and idx:
-            if not self._fin_sealed:
-                L.check(self.lib.dlka_wgrad_finalize_plan_seal(ctypes.c_void_p(self._fin_host.data_ptr())), "wgrad_finalize_plan_seal")
+            if self._fin_sealed:
+                rc = self.lib.dlka_wgrad_finalize_run(L.ptr(self._fin_dev), plan_ptr, idx[0], idx[-1] + 1, st)
+                L.check(rc, "wgrad_finalize_run")
+            elif len(self._fin_recorded) == len(self.blocks) and not self._capturing():
+                # every block has been through a backward pass once: from the next pass on, ONE launch per pass (or slice)
+                L.check(self.lib.dlka_wgrad_finalize_plan_seal(plan_ptr), "wgrad_finalize_plan_seal")
                 self._fin_dev = self._fin_host.to(self.device) if self.device.type == "cuda" else self._fin_host
                 self._fin_sealed = True
-            rc = self.lib.dlka_wgrad_finalize_run(L.ptr(self._fin_dev), ctypes.c_void_p(self._fin_host.data_ptr()), idx[0], idx[-1] + 1, st)
-            L.check(rc, "wgrad_finalize_run")
 
     def _capturing(self) -> bool:
         return self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()

@@ -316,6 +316,8 @@ int dlka_lka3d_attention_tokens_backward(const void *x, const dlka_lka3d_params 
  *   _plan_bytes / _plan_init a HOST job table for n blocks;
  *   _backward_deferred_v     the backward call without its finalize launch; partial sums go to `partials`; with plan_host != NULL it records the
  *                            block's jobs in slot `plan_slot` (pointers of `partials` and of the gradient buffers: they must stay put);
+ *   _run_slot                (before sealing) finalises ONE recorded block with the ordinary per-block launch — what a caller does while the table is
+ *                            still being recorded, e.g. when its first backward pass covers only a slice of the blocks;
  *   _plan_seal               after every slot has been recorded once: computes the launch geometry; the caller then copies the table to the device;
  *   _run(plan_device, plan_host, block_lo, block_hi)   ONE launch that finalises the weight gradients of blocks [block_lo, block_hi).
  * Results are identical to the per-block launch (same folds in the same order). */
@@ -328,6 +330,7 @@ int dlka_lka3d_attention_tokens_backward_deferred_v(const void *x, const dlka_lk
                                                     void *workspace, size_t workspace_bytes,
                                                     void *partials, size_t partials_bytes, void *plan_host, int plan_slot,
                                                     int B, int C, int D, int H, int W, int dtype, int variant, void *stream);
+int dlka_wgrad_finalize_run_slot(const void *plan_host, int plan_slot, void *stream);
 int dlka_wgrad_finalize_plan_seal(void *plan_host);
 int dlka_wgrad_finalize_run(const void *plan_device, const void *plan_host, int block_lo, int block_hi, void *stream);
 
