@@ -17,7 +17,7 @@ def bf16_storage(t):
     return t + (t.bfloat16().float() - t).detach()
 
 
-def lka3d_attention_volume(x, P, store=None, chain_store=None, offsets_override=None):
+def lka3d_attention_volume(x, P, store=None, chain_store=None, offsets_override=None, offsets_out=None):
     """LKA_Attention3d_deform on an NCDHW volume — 3D/d_lka_former/network_architecture/synapse/transformerblock.py:664-673
     (minus the token permutes), LKA3d_deform.forward :644-652, DeformConvPack.forward synapse/deform_conv.py:93-105.
     store: None = the reference's fp32 block; ``bf16_storage`` = the model of the DLKA_BF16 path: the same arithmetic with every activation
@@ -45,6 +45,8 @@ def lka3d_attention_volume(x, P, store=None, chain_store=None, offsets_override=
     off = F.conv3d(attn, P[s + "deform_conv.conv_offset.weight"], P[s + "deform_conv.conv_offset.bias"], stride=1, padding=1)
     if offsets_override is not None:   # VALUES from another implementation's forward pass, gradient path unchanged (straight through): both sides
         off = off + (offsets_override - off).detach()   # then sample the same cells, which removes grad_offset's discontinuity from a comparison
+    if offsets_out is not None:        # the offset VALUES this very run samples with (a second evaluation of the chain need not be bit-identical:
+        offsets_out.append(off.detach().clone())   # ATen's CPU convs split their sums by thread count)
     attn = st(oracle.DeformConv3dFunction.apply(st(attn), off, P[s + "deform_conv.weight"], P[s + "deform_conv.bias"],
                                                 1, 1, 1, 1, 1, 64))              # deform_conv.py:95-105
     attn = F.conv3d(attn, P[s + "conv1.weight"], P[s + "conv1.bias"])            # :650  (the gate consumes conv1's fp32 value in the fused epilogue)
@@ -52,10 +54,10 @@ def lka3d_attention_volume(x, P, store=None, chain_store=None, offsets_override=
     return st(y + shortcut)                                                      # :671
 
 
-def lka3d_attention_tokens(x, P, B, C, H, W, D, store=None, chain_store=None, offsets_override=None):
+def lka3d_attention_tokens(x, P, B, C, H, W, D, store=None, chain_store=None, offsets_override=None, offsets_out=None):
     """The full forward(x, B, C, H, W, D) on (B, N, C) tokens, :664-673."""
     v = x.permute(0, 2, 1).reshape(B, C, H, W, D)
-    v = lka3d_attention_volume(v, P, store, chain_store, offsets_override)
+    v = lka3d_attention_volume(v, P, store, chain_store, offsets_override, offsets_out)
     return v.reshape(B, C, H * W * D).permute(0, 2, 1)
 
 

@@ -338,21 +338,36 @@ def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=FWD_ATOL, 
     def run_oracle(override=None):
         P = {k: v.detach().clone().requires_grad_(True) for k, v in m0.items()}
         xr = x.detach().clone().requires_grad_(True)   # (detach: on the CPU backend `x.to(dev)` below IS x, and requires_grad_ marks it)
-        yr = blocks.lka3d_attention_tokens(xr, P, B, C, H, W, D, offsets_override=override)
+        used = []
+        yr = blocks.lka3d_attention_tokens(xr, P, B, C, H, W, D, offsets_override=override, offsets_out=used)
         yr.backward(gy)
+        run_oracle.offsets = used[0]
         return yr.detach(), xr.grad, {k: v.grad for k, v in P.items()}
 
     yr, gxr, gr = run_oracle()
+    off_ref = run_oracle.offsets   # the offsets THIS oracle run sampled with
     m = m.to(dev)
     xd = x.to(dev).requires_grad_(True)
-    y = m(xd, B, C, H, W, D)
+    # the kernels' predicted offsets come from the `saved` buffer of THE forward call whose gradients are checked (a second, identical call can
+    # differ in the last bit where the offset conv is tap-split over fp32 atomics — enough to move a boundary sample into the other cell and to make
+    # the flip count and the same-cells comparison describe a different run: seen on the ACDC 20x28x28 stage, round 3)
+    captured = {}
+    orig_fwd = ops.lka3d_attention_tokens_forward
+
+    def spy(*a, **k):
+        out = orig_fwd(*a, **k)
+        captured["saved"] = out[1]
+        return out
+
+    ops.lka3d_attention_tokens_forward = spy
+    try:
+        y = m(xd, B, C, H, W, D)
+    finally:
+        ops.lka3d_attention_tokens_forward = orig_fwd
     y.backward(gy.to(dev))
-    # the kernels' predicted offsets, from the saved buffer of a second (identical) forward call
-    _, saved = ops.lka3d_attention_tokens_forward(x.detach().to(dev), [p_.detach() for p_ in m.block_params()], dims, variant)
-    off_hip = ops.lka3d_tokens_saved_offsets(saved, B, C, dims).cpu().clone()
-    P0 = {k: v for k, v in m0.items()}
-    with torch.no_grad():
-        off_ref = oracle_offsets(x.detach(), P0, B, C, H, W, D)
+    if "saved" not in captured:   # (a path that does not go through the fused token call: general per-op composition)
+        _, captured["saved"] = ops.lka3d_attention_tokens_forward(x.detach().to(dev), [p_.detach() for p_ in m.block_params()], dims, variant)
+    off_hip = ops.lka3d_tokens_saved_offsets(captured["saved"], B, C, dims).cpu().clone()
     k3 = ((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1))
     i_h, m_h = oracle.deform_conv3d_sample_index(off_hip, dims, *k3)
     i_r, m_r = oracle.deform_conv3d_sample_index(off_ref, dims, *k3)
@@ -376,18 +391,6 @@ def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=FWD_ATOL, 
             assert_close("tokens grad " + k, p.grad, g, rtol=flip_rtol if any(e in k for e in exposed) else rtol)
             assert_close("tokens grad (same cells) " + k, p.grad, g2[k], rtol=rtol)
     return flipped
-
-
-def oracle_offsets(x, P, B, C, H, W, D):
-    """The offsets the ORACLE block predicts for tokens x (the chain proj_1 -> GELU -> conv0 -> conv_spatial -> conv_offset of oracle.blocks)."""
-    v = x.permute(0, 2, 1).reshape(B, C, H, W, D)
-    s = "spatial_gating_unit."
-    a = F.gelu(F.conv3d(v, P["proj_1.weight"], P["proj_1.bias"]))
-    k0, k1 = tuple(P[s + "conv0.weight"].shape[2:]), tuple(P[s + "conv_spatial.weight"].shape[2:])
-    d1 = {(7, 7, 7): (3, 3, 3), (5, 7, 7): (3, 3, 3), (3, 5, 5): (1, 3, 3), (3, 3, 3): (1, 1, 1)}[k1]
-    t = F.conv3d(a, P[s + "conv0.weight"], P[s + "conv0.bias"], padding=tuple(k // 2 for k in k0), groups=C)
-    t = F.conv3d(t, P[s + "conv_spatial.weight"], P[s + "conv_spatial.bias"], padding=tuple(d * (k - 1) // 2 for k, d in zip(k1, d1)), dilation=d1, groups=C)
-    return F.conv3d(t, P[s + "deform_conv.conv_offset.weight"], P[s + "deform_conv.conv_offset.bias"], stride=1, padding=1)
 
 
 def check_lka3d_tokens_sample_handover(dev, B, C, dims, dtype=torch.float32, seed=0, offset_std=0.3):
