@@ -111,6 +111,11 @@ def trace_step(stack, reps=3):
         order.append(i)
         L.check(lib.dlka_trace_mark(st), "trace_mark")
 
+    # every kernel on ONE stream while tracing: the timed step lets the weight gradients of a block overlap the next block's data chain on a second
+    # stream (DLKABlockStack._overlap); events of two streams interleave in the trace and concurrent kernels stretch each other, so the per-kernel
+    # durations are taken from the same launches run back to back
+    overlap_was = getattr(stack, "_overlap", False)
+    stack._overlap = False
     stack.forward_backward()            # warm
     torch.cuda.synchronize()
     # keep the host AHEAD of the device: the records measure back-to-back execution only if every launch is queued before its turn
@@ -126,6 +131,7 @@ def trace_step(stack, reps=3):
             stack.forward_backward(on_block=hook)
     finally:
         rc = lib.dlka_trace_stop()
+        stack._overlap = overlap_was
     L.check(rc, "trace_stop")
     n = lib.dlka_trace_count()
     buf = create_string_buffer(512)
@@ -197,7 +203,8 @@ def roofline_report(stack, B, dtype, ms_per_step):
             "launches_per_step": dom["launches_per_step"], "step_share": dom["step_share"],
             "algorithmic_flops": fl, "algorithmic_bytes": by, "shape": f"C={C},{H}x{W}x{D},B={B}",
             "method": "HIP events recorded on the launch stream behind EVERY kernel launch of the step's own forward+backward (library launch trace, "
-                      "eager replay of the same call sequence the hipGraph holds; mean over 3 passes); dominant = largest launches x duration",
+                      "eager replay of the same call sequence the hipGraph holds, all on one stream — the timed step overlaps the weight gradients of a block "
+                      "with the next block's data chain on a second stream; mean over 3 passes); dominant = largest launches x duration",
             "traced_kernel_ms_per_step": round(traced_ms, 4), "records_per_step": round(nrec, 1),
             "event_cost_us": {"per_record_vs_graph_replay": round(ev_us, 2), "two_events_back_to_back": round(mark_ms * 1e3, 2),
                               "note": "`achieved` uses the raw record (kernel + its event), i.e. it UNDERSTATES the kernel by this much"},

@@ -116,6 +116,9 @@ SIGNATURES = {
     "dlka_lka3d_attention_tokens_backward_deferred_v": (c_int, [c_void_p, POINTER(Lka3dPtrs), c_void_p, c_void_p, c_size_t, c_void_p,
                                                                POINTER(Lka3dPtrs), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_int,
                                                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dlka_lka3d_attention_tokens_backward_phase_v": (c_int, [c_void_p, POINTER(Lka3dPtrs), c_void_p, c_void_p, c_size_t, c_void_p,
+                                                            POINTER(Lka3dPtrs), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_int, c_int,
+                                                            c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dlka_wgrad_finalize_plan_seal": (c_int, [c_void_p]),
     "dlka_wgrad_finalize_run_slot": (c_int, [c_void_p, c_int, c_void_p]),
     "dlka_wgrad_finalize_run": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -1114,7 +1114,7 @@ size_t fin_first_off() { return sizeof(FinPlanHeader); }
 size_t fin_jobs_off(int nb) { return align256(sizeof(FinPlanHeader) + (size_t)(nb + 1) * sizeof(int)); }
 int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void *gy_, const void *saved, size_t saved_bytes, void *gx_,
                          const dlka_lka3d_grads *gr, void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant,
-                         void *stream, void *partials, size_t partials_bytes, FinalizeJob *jobs_out, int *njobs_out);
+                         void *stream, void *partials, size_t partials_bytes, FinalizeJob *jobs_out, int *njobs_out, int phase = 0);
 }  // namespace
 
 size_t dlka_lka3d_tokens_partials_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant)
@@ -1157,6 +1157,28 @@ int dlka_lka3d_attention_tokens_backward_deferred_v(const void *x, const dlka_lk
         // slots may be recorded in any order: block k owns the fixed window [k * FIN_JOBS_PER_BLOCK, ..); sealing compacts them
         for (int j = 0; j < nj; ++j) all[plan_slot * FIN_JOBS_PER_BLOCK + j] = jobs[j];
         first[plan_slot] = nj;   // (count until sealed)
+    }
+    return DLKA_OK;
+}
+
+int dlka_lka3d_attention_tokens_backward_phase_v(const void *x, const dlka_lka3d_params *p, const void *grad_y, const void *saved, size_t saved_bytes,
+                                                 void *grad_x, const dlka_lka3d_grads *grads, void *workspace, size_t workspace_bytes, void *partials,
+                                                 size_t partials_bytes, void *plan_host, int plan_slot, int phase, int B, int C, int D, int H, int W, int dtype,
+                                                 int variant, void *stream)
+{
+    if (!partials) return DLKA_ERR_NULL;
+    if (phase != 1 && phase != 2) return DLKA_ERR_SHAPE;
+    FinalizeJob jobs[FIN_JOBS_PER_BLOCK];
+    int nj = 0;
+    DLKA_TRY(tokens_backward_impl(x, p, grad_y, saved, saved_bytes, grad_x, grads, workspace, workspace_bytes, B, C, D, H, W, dtype, variant, stream, partials,
+                                  partials_bytes, jobs, &nj, phase));
+    if (plan_host && phase == 2) {
+        FinPlanHeader *hd = (FinPlanHeader *)plan_host;
+        if (plan_slot < 0 || plan_slot >= hd->nblocks || hd->sealed) return DLKA_ERR_SHAPE;
+        int *first = (int *)((unsigned char *)plan_host + fin_first_off());
+        FinalizeJob *all = (FinalizeJob *)((unsigned char *)plan_host + fin_jobs_off(hd->nblocks));
+        for (int j = 0; j < nj; ++j) all[plan_slot * FIN_JOBS_PER_BLOCK + j] = jobs[j];
+        first[plan_slot] = nj;
     }
     return DLKA_OK;
 }
@@ -1231,9 +1253,10 @@ namespace {
 // returned in jobs_out / njobs_out for dlka_wgrad_finalize_run
 int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void *gy_, const void *saved, size_t saved_bytes, void *gx_,
                          const dlka_lka3d_grads *gr, void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant,
-                         void *stream, void *partials, size_t partials_bytes, FinalizeJob *jobs_out, int *njobs_out)
+                         void *stream, void *partials, size_t partials_bytes, FinalizeJob *jobs_out, int *njobs_out, int phase)
 {
     if (!x_ || !p || !gy_ || !saved || !gx_ || !gr || !workspace) return DLKA_ERR_NULL;
+    if (phase < 0 || phase > 2) return DLKA_ERR_SHAPE;
     const void *const *pp = (const void *const *)p;
     for (size_t k = 0; k < sizeof(*p) / sizeof(void *); ++k) if (!pp[k]) return DLKA_ERR_NULL;
     void *const *gp = (void *const *)gr;
@@ -1317,42 +1340,49 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
     // the epilogue:  gg1 = gm * a,  ga1 = gm * g1
     // (the three pointwise weight gradients run as ONE launch at the end: their operands m/gy, f/gg1, x/gh all stay live)
     // ... and conv1:  g1 = P0 f,  gf = P0^T gg1 — one launch at C <= 64
-    const int prc = dense_backward_data_splits(G.pw, 0) > 1 ? DLKA_ERR_UNSUPPORTED
-                                                            : pointwise_pair(G.pw, 1, gy, PW.pw_b[2], nullptr, PW.pw_b[1], nullptr, a, g1, gg1, ga1, gf, st, &zb);
-    if (prc != DLKA_ERR_UNSUPPORTED) DLKA_TRY(prc);
-    else {
-        DLKA_TRY(dense_backward_data(G.pw, gy, 0, N0, gg1, PW.pw_b[2], 4, a, st, g1, ga1, false, false, false, nullptr, &zb));
-        DLKA_TRY(publish());   // fork: everything issued so far (gy, saved activations, the zero fills, the previous block's use of the workspace)
-        DLKA_TRY(dense_backward_data(G.pw, gg1, 0, N0, gf, PW.pw_b[1], 0, nullptr, st, nullptr, nullptr, true));
+    // phase: 0 = the whole backward pass; 1 = the DATA-gradient chain only (everything the next block needs: gx; and what the weight gradients read:
+    // the intermediate gradients and the stored samples, all in `workspace`); 2 = the five WEIGHT-gradient launches only, reading those — a caller that
+    // runs phase 2 on another stream lets them overlap the next block's data chain (DLKABlockStack: two alternating workspaces).
+#define DLKA_P1(call) do { if (phase != 2) DLKA_TRY(call); } while (0)
+#define DLKA_P2(call) do { if (phase != 1) DLKA_TRY(call); } while (0)
+    if (phase != 2) {
+        const int prc = dense_backward_data_splits(G.pw, 0) > 1 ? DLKA_ERR_UNSUPPORTED
+                                                                : pointwise_pair(G.pw, 1, gy, PW.pw_b[2], nullptr, PW.pw_b[1], nullptr, a, g1, gg1, ga1, gf, st, &zb);
+        if (prc != DLKA_ERR_UNSUPPORTED) DLKA_TRY(prc);
+        else {
+            DLKA_TRY(dense_backward_data(G.pw, gy, 0, N0, gg1, PW.pw_b[2], 4, a, st, g1, ga1, false, false, false, nullptr, &zb));
+            DLKA_TRY(publish());   // fork: everything issued so far (gy, saved activations, the zero fills, the previous block's use of the workspace)
+            DLKA_TRY(dense_backward_data(G.pw, gg1, 0, N0, gf, PW.pw_b[1], 0, nullptr, st, nullptr, nullptr, true));
+        }
     }
     DLKA_TRY(publish());
     // deformable conv:  f = DCN(t, off):  grad_offset and grad_input on the main stream, the weight gradient on the side one — after
     // grad_offset when that kernel hands over the samples it interpolated (samp), else at once with its own gather
     if (!samp)
-        DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
-                                 &fb.j[fb.njobs++]));
-    DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, goff, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, false, true, goff_cpad, samp));
+        DLKA_P2(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
+                                &fb.j[fb.njobs++]));
+    DLKA_P1(deform_backward(G.dcn, t, off, N0, gf, nullptr, goff, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, false, true, goff_cpad, samp));
     DLKA_TRY(publish());
     if (samp)
-        DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
-                                 &fb.j[fb.njobs++], false, false, 0, samp));
+        DLKA_P2(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
+                                &fb.j[fb.njobs++], false, false, 0, samp));
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
-    DLKA_TRY(dense_backward_weight(G.offc, t, goff, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, ws_, &fb.j[fb.njobs++], goff_cpad));
-    DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, true));
-    DLKA_TRY(dense_backward_data(G.offc, goff, 1, N0, gt, PW.off_b, 3, gta, st, nullptr, nullptr, true, goff_cpad != 0, true, ga2));
+    DLKA_P2(dense_backward_weight(G.offc, t, goff, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, ws_, &fb.j[fb.njobs++], goff_cpad));
+    DLKA_P1(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, true));
+    DLKA_P1(dense_backward_data(G.offc, goff, 1, N0, gt, PW.off_b, 3, gta, st, nullptr, nullptr, true, goff_cpad != 0, true, ga2));
     DLKA_TRY(publish());
     // depthwise 7^3 dil 3:  t = DW7 t1
-    DLKA_TRY(dw_backward_weight(G.dw7, t1, gt, (float *)gr->conv_spatial_w, (float *)gr->conv_spatial_b, stage7, ws_, &fb.j[fb.njobs++]));
-    DLKA_TRY(dw_forward(G.dw7, gt, N0, nullptr, gt1, PW.dw7_b, 1, st));
+    DLKA_P2(dw_backward_weight(G.dw7, t1, gt, (float *)gr->conv_spatial_w, (float *)gr->conv_spatial_b, stage7, ws_, &fb.j[fb.njobs++]));
+    DLKA_P1(dw_forward(G.dw7, gt, N0, nullptr, gt1, PW.dw7_b, 1, st));
     DLKA_TRY(publish());
     // depthwise 5^3:  t1 = DW5 a
-    DLKA_TRY(dw_backward_weight(G.dw5, a, gt1, (float *)gr->conv0_w, (float *)gr->conv0_b, stage5, ws_, &fb.j[fb.njobs++]));
+    DLKA_P2(dw_backward_weight(G.dw5, a, gt1, (float *)gr->conv0_w, (float *)gr->conv0_b, stage5, ws_, &fb.j[fb.njobs++]));
     // ... with the GELU backward in its epilogue:  a = GELU(h),  gh = (ga1 + DW5^T gt1) * gelu'(h)
     (void)E;
-    DLKA_TRY(dw_forward(G.dw5, gt1, N0, nullptr, gh, PW.dw5_b, 1, st, h, ga1));
+    DLKA_P1(dw_forward(G.dw5, gt1, N0, nullptr, gh, PW.dw5_b, 1, st, h, ga1));
     DLKA_TRY(publish());
     // proj_1:  h = P1 x ;  gx = P1^T gh + gy (shortcut)
-    {
+    if (phase != 1) {
         WgradArgs jobs[3];
         fill_pw_wgrad(jobs[0], G.pw, m, gy, part_p2);
         fill_pw_wgrad(jobs[1], G.pw, f, gg1, part_c1);
@@ -1367,9 +1397,12 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
         for (int k = 0; k < fb.njobs; ++k) jobs_out[k] = fb.j[k];
         *njobs_out = fb.njobs;
     } else {
+        if (phase != 0) return DLKA_ERR_UNSUPPORTED;   // the split passes need the deferred finalisation (block-private partial sums)
         DLKA_TRY(launch_cl_wgrad_finalize(fb, ws_));
     }
-    DLKA_TRY(dense_backward_data(G.pw, gh, 0, N0, gx, PW.pw_b[0], 3, gy, st, nullptr, nullptr, true));
+    DLKA_P1(dense_backward_data(G.pw, gh, 0, N0, gx, PW.pw_b[0], 3, gy, st, nullptr, nullptr, true));
+#undef DLKA_P1
+#undef DLKA_P2
     if (fork) {   // join
         if (hipEventRecord(sc.ev[nev], ws_) != hipSuccess || hipStreamWaitEvent(st, sc.ev[nev], 0) != hipSuccess) return DLKA_ERR_LAUNCH;
     }

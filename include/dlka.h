@@ -330,6 +330,16 @@ int dlka_lka3d_attention_tokens_backward_deferred_v(const void *x, const dlka_lk
                                                     void *workspace, size_t workspace_bytes,
                                                     void *partials, size_t partials_bytes, void *plan_host, int plan_slot,
                                                     int B, int C, int D, int H, int W, int dtype, int variant, void *stream);
+/* The deferred backward pass in two calls: phase 1 = the data-gradient chain (produces grad_x and, in `workspace`, everything the weight gradients
+ * read), phase 2 = the five weight-gradient launches (reads them; records the block's finalize jobs).  Phase 2 may run on ANOTHER stream, after an
+ * event recorded behind phase 1, so that it overlaps the next block's data chain — the caller then alternates two workspaces and makes phase 1 of a
+ * block wait for the phase 2 that last used its workspace.  Same results as the one-call form. */
+int dlka_lka3d_attention_tokens_backward_phase_v(const void *x, const dlka_lka3d_params *p, const void *grad_y,
+                                                 const void *saved, size_t saved_bytes,
+                                                 void *grad_x, const dlka_lka3d_grads *grads,
+                                                 void *workspace, size_t workspace_bytes,
+                                                 void *partials, size_t partials_bytes, void *plan_host, int plan_slot, int phase,
+                                                 int B, int C, int D, int H, int W, int dtype, int variant, void *stream);
 int dlka_wgrad_finalize_run_slot(const void *plan_host, int plan_slot, void *stream);
 int dlka_wgrad_finalize_plan_seal(void *plan_host);
 int dlka_wgrad_finalize_run(const void *plan_device, const void *plan_host, int block_lo, int block_hi, void *stream);

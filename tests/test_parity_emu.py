@@ -325,6 +325,14 @@ def test_stack_step_level_weight_gradient_finalisation_equals_per_block_launches
     assert not st.flat_grads[:st.grad_offset_of(2)].any()
     st.backward(0, 2)
     check(st, range(4))
+    # the backward pass split into its data-gradient chain and its weight-gradient launches (two calls per block, alternating workspaces: what the
+    # GPU runs on two streams; here one after the other)
+    st2 = DLKABlockStack(1, stages=stages, device="cpu", seed=5, overlap_wgrad=True)
+    assert st2._overlap
+    for _ in range(2):                # the recording pass, then the table-driven one
+        st2.flat_grads.zero_()
+        st2.forward_backward()
+        check(st2, range(4))
 
 
 @pytest.mark.parametrize("C,dims", [(32, (4, 4, 4)), (64, (3, 4, 5))])
