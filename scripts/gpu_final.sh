@@ -3,6 +3,7 @@
 set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd $R
 TAG=${1:-final}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+if [ "${PROFILES_ONLY:-0}" != 1 ]; then
 echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "exit $?"; tail -3 $OUT/pytest_gpu.log
 echo "== smoke"; timeout 600 python -c 'import __graft_entry__ as g; g.smoke()' > $OUT/smoke.log 2>&1; echo "exit $?"; tail -2 $OUT/smoke.log
 echo "== bench (default)"; timeout 900 python bench.py > $OUT/bench_f32.json 2> $OUT/bench_f32.err; echo "exit $?"
@@ -23,10 +24,15 @@ for f in ("bench_f32","bench_bf16","bench_extras"):
           "roof:", r.get("kernel"), r.get("frac"), "cpu:", (d.get("cpu_baseline") or {}).get("value"),
           "fullnet:", (d.get("fullnet") or {}).get("value"), "lka2d:", (d.get("lka2d") or {}).get("value"), "inf:", (d.get("inference") or {}).get("value"))
 PY
+fi
 cd /tmp
-echo "== rocprof of the bench command"
+echo "== rocprof of the bench command (as timed: the weight gradients of a block overlap the next block's data chain on a second stream — concurrent kernels stretch each other)"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bench -o t -- python $R/bench.py --no-cpu-baseline --no-tblock --no-companion > $R/$OUT/prof_bench.log 2>&1
 F=$(find $R/$OUT/prof_bench -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" $R/$OUT/bench_kernel_stats.csv && head -6 $R/$OUT/bench_kernel_stats.csv | cut -c1-150
+echo "== rocprof of the bench command on ONE stream (DLKA_STACK_WGRAD_OVERLAP=0): the per-kernel durations the roofline block's launch trace must agree with"
+DLKA_STACK_WGRAD_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bench1 -o t -- python $R/bench.py --no-cpu-baseline --no-tblock --no-companion > $R/$OUT/prof_bench1.log 2>&1
+F=$(find $R/$OUT/prof_bench1 -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" $R/$OUT/bench_one_stream_kernel_stats.csv && head -6 $R/$OUT/bench_one_stream_kernel_stats.csv | cut -c1-150
+export DLKA_STACK_WGRAD_OVERLAP=0   # (one block per stage below: nothing to overlap with)
 for dt in f32 bf16; do for s in 0 1 2 3; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_${dt}_s$s -o t -- python $R/scripts/prof_stage.py --stage $s --dtype $dt > $R/$OUT/prof_${dt}_s$s.log 2>&1
   F=$(find $R/$OUT/prof_${dt}_s$s -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" $R/$OUT/${dt}_stage${s}_block_kernel_stats.csv
