@@ -110,6 +110,7 @@ SIGNATURES = {
     "dlka_lka3d_tokens_prepare_plan_bytes": (c_size_t, [c_int]),
     "dlka_lka3d_tokens_prepare_plan": (c_int, [c_int, POINTER(Lka3dPtrs), POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int), c_int, c_void_p, c_size_t]),
     "dlka_lka3d_tokens_prepare_run": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "dlka_lka3d_tokens_prepare_run_range": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dlka_lka3d_tokens_partials_bytes_v": (c_size_t, [c_int] * 7),
     "dlka_wgrad_finalize_plan_bytes": (c_size_t, [c_int]),
     "dlka_wgrad_finalize_plan_init": (c_int, [c_void_p, c_size_t, c_int]),

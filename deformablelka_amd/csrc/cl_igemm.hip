@@ -297,15 +297,17 @@ __global__ __launch_bounds__(256) void cl_prep_batch_kernel(PrepBatch b)
 // The same re-layouts for MANY blocks in one launch: the job table lives in device memory (built once per model, the pointers do not
 // change), `first[j]` = first workgroup of job j; a workgroup finds its job by bisection and covers PREP_TABLE_CHUNK elements of it.
 constexpr int PREP_TABLE_CHUNK = 2048;
-__global__ __launch_bounds__(256) void cl_prep_table_kernel(const PrepJob *__restrict__ jobs, const int *__restrict__ first, int njobs)
+// (this launch covers jobs [job_lo, job_hi); its workgroup 0 is workgroup first[job_lo] of the whole table)
+__global__ __launch_bounds__(256) void cl_prep_table_kernel(const PrepJob *__restrict__ jobs, const int *__restrict__ first, int job_lo, int job_hi)
 {
-    int lo = 0, hi = njobs - 1;
-    while (lo < hi) {   // last job whose first workgroup is <= blockIdx.x
+    const int wg = (int)blockIdx.x + first[job_lo];
+    int lo = job_lo, hi = job_hi - 1;
+    while (lo < hi) {   // last job whose first workgroup is <= wg
         const int mid = (lo + hi + 1) >> 1;
-        if (first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        if (first[mid] <= wg) lo = mid; else hi = mid - 1;
     }
     const PrepJob j = jobs[lo];
-    const long l0 = (long)((int)blockIdx.x - first[lo]) * PREP_TABLE_CHUNK;
+    const long l0 = (long)(wg - first[lo]) * PREP_TABLE_CHUNK;
     for (long l = l0 + threadIdx.x; l < l0 + PREP_TABLE_CHUNK && l < j.n; l += 256) {
         if (j.mode == 3 || j.mode == 4) {
             const int c = (int)(l % j.Cin), tap = (int)(l / j.Cin);
@@ -319,10 +321,10 @@ __global__ __launch_bounds__(256) void cl_prep_table_kernel(const PrepJob *__res
 
 int cl_prep_table_blocks(long n) { return (int)cdivl(n, PREP_TABLE_CHUNK); }
 
-int launch_cl_prep_table(const PrepJob *jobs_dev, const int *first_dev, int njobs, int nblocks, hipStream_t st)
+int launch_cl_prep_table(const PrepJob *jobs_dev, const int *first_dev, int job_lo, int job_hi, int nblocks, hipStream_t st)
 {
-    if (njobs <= 0) return DLKA_OK;
-    DLKA_LAUNCH(cl_prep_table_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, jobs_dev, first_dev, njobs);
+    if (job_hi <= job_lo || nblocks <= 0) return DLKA_OK;
+    DLKA_LAUNCH(cl_prep_table_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, jobs_dev, first_dev, job_lo, job_hi);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }

@@ -1039,12 +1039,13 @@ int dlka_lka3d_attention_tokens_forward_prepared(const void *x, const dlka_lka3d
 }
 
 // ---- weight preparation of MANY blocks in one launch --------------------------------------------------------------------------------
-// plan (host, then copied to the device by the caller): [int njobs][int nblocks][int first[MAXJ]][PrepJob jobs[MAXJ]]
+// plan (host, then copied to the device by the caller): [header][int first[MAXJ + 1]: first workgroup of job j][int blkjob[nblocks + 1]: first job of block k][PrepJob jobs[MAXJ]]
 namespace {
 constexpr int PLAN_JOBS_PER_BLOCK = 16;   // (14 today: 6 pointwise, 2 offset conv, 2 deformable, 4 depthwise forms)
 struct PlanHeader { int njobs, nblocks, pad0, pad1; };
 size_t plan_first_off() { return sizeof(PlanHeader); }
-size_t plan_jobs_off(int nb) { return align256(sizeof(PlanHeader) + (size_t)nb * PLAN_JOBS_PER_BLOCK * sizeof(int)); }
+size_t plan_blkjob_off(int nb) { return sizeof(PlanHeader) + ((size_t)nb * PLAN_JOBS_PER_BLOCK + 1) * sizeof(int); }
+size_t plan_jobs_off(int nb) { return align256(plan_blkjob_off(nb) + (size_t)(nb + 1) * sizeof(int)); }
 }  // namespace
 
 size_t dlka_lka3d_tokens_prepare_plan_bytes(int nblocks)
@@ -1062,8 +1063,10 @@ int dlka_lka3d_tokens_prepare_plan(int nblocks, const dlka_lka3d_params *params,
     PlanHeader *hd = (PlanHeader *)base;
     int *first = (int *)(base + plan_first_off());
     PrepJob *jobs = (PrepJob *)(base + plan_jobs_off(nblocks));
+    int *blkjob = (int *)(base + plan_blkjob_off(nblocks));
     int nj = 0, nb = 0;
     for (int k = 0; k < nblocks; ++k) {
+        blkjob[k] = nj;
         const int B = dims5[5 * k], C = dims5[5 * k + 1], D = dims5[5 * k + 2], H = dims5[5 * k + 3], W = dims5[5 * k + 4];
         if (!dlka_lka3d_tokens_supported(B, C, D, H, W, dtype)) return DLKA_ERR_UNSUPPORTED;
         TokGeoms G(B, C, D, H, W, dtype);
@@ -1084,17 +1087,27 @@ int dlka_lka3d_tokens_prepare_plan(int nblocks, const dlka_lka3d_params *params,
             ++nj;
         }
     }
+    blkjob[nblocks] = nj;
+    first[nj] = nb;   // (end marker: the workgroups of job j are first[j] .. first[j + 1])
     hd->njobs = nj; hd->nblocks = nb; hd->pad0 = hd->pad1 = 0;
     return DLKA_OK;
 }
 
-int dlka_lka3d_tokens_prepare_run(const void *plan_device, const void *plan_host, int nblocks, void *stream)
+int dlka_lka3d_tokens_prepare_run_range(const void *plan_device, const void *plan_host, int nblocks, int block_lo, int block_hi, void *stream)
 {
     if (!plan_device || !plan_host) return DLKA_ERR_NULL;
-    const PlanHeader *hd = (const PlanHeader *)plan_host;   // (the counts are read from the host copy: no device round trip)
+    if (block_lo < 0 || block_hi > nblocks || block_lo >= block_hi) return DLKA_ERR_SHAPE;
+    const unsigned char *hst = (const unsigned char *)plan_host;   // (the counts are read from the host copy: no device round trip)
+    const int *first = (const int *)(hst + plan_first_off()), *blkjob = (const int *)(hst + plan_blkjob_off(nblocks));
+    const int jlo = blkjob[block_lo], jhi = blkjob[block_hi];
     const unsigned char *dev = (const unsigned char *)plan_device;
-    return launch_cl_prep_table((const PrepJob *)(dev + plan_jobs_off(nblocks)), (const int *)(dev + plan_first_off()), hd->njobs, hd->nblocks,
+    return launch_cl_prep_table((const PrepJob *)(dev + plan_jobs_off(nblocks)), (const int *)(dev + plan_first_off()), jlo, jhi, first[jhi] - first[jlo],
                                 (hipStream_t)stream);
+}
+
+int dlka_lka3d_tokens_prepare_run(const void *plan_device, const void *plan_host, int nblocks, void *stream)
+{
+    return dlka_lka3d_tokens_prepare_run_range(plan_device, plan_host, nblocks, 0, nblocks, stream);
 }
 
 int dlka_lka3d_attention_tokens_backward(const void *x_, const dlka_lka3d_params *p, const void *gy_, const void *saved, size_t saved_bytes,

@@ -166,6 +166,7 @@ class DLKABlockStack:
         if enable is None:   # default: on (measured 11.95 -> 11.47 ms per step under hipGraph replay); DLKA_STACK_WGRAD_OVERLAP=0 = one stream
             enable = os.environ.get("DLKA_STACK_WGRAD_OVERLAP", "1") != "0"
         self._overlap = bool(enable) and self._fin_host is not None
+        self._prep_pending, self._prep_split = None, 0
         if not self._overlap:
             return
         self.ws2 = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
@@ -173,12 +174,30 @@ class DLKABlockStack:
             self._side = torch.cuda.Stream(device=self.device)
             self._ev_data = [torch.cuda.Event() for _ in range(2)]
             self._ev_wg = [torch.cuda.Event() for _ in range(2)]
+            self._ev_prep, self._ev_prep2 = torch.cuda.Event(), torch.cuda.Event()
+            c0 = self.blocks[0].C
+            self._prep_split = sum(1 for b in self.blocks if b.C == c0)   # blocks of the first stage
         else:
             self._side = None
 
     def prepare(self):
-        """Re-lay the weights of all blocks (after every parameter update): one launch."""
-        rc = self.lib.dlka_lka3d_tokens_prepare_run(L.ptr(self._plan_dev), L.ptr(self._plan_host), len(self.blocks), self._stream())
+        """Re-lay the weights of all blocks (after every parameter update): one launch — or two, when a side stream exists: the blocks of the first stage
+        (small weights) on the calling stream, the rest (95 % of the bytes) on the side stream while the first stage's forward passes run; ``forward``
+        waits for it in front of the first block that needs it."""
+        n, st = len(self.blocks), self._stream()
+        self._prep_pending = None
+        k = self._prep_split if getattr(self, "_overlap", False) and getattr(self, "_side", None) is not None else 0
+        if 0 < k < n:
+            cur = torch.cuda.current_stream(self.device)
+            L.check(self.lib.dlka_lka3d_tokens_prepare_run_range(L.ptr(self._plan_dev), L.ptr(self._plan_host), n, 0, k, st), "lka3d_tokens_prepare_run_range")
+            self._ev_prep.record(cur)            # (behind the parameter update that precedes this call on the calling stream)
+            self._side.wait_event(self._ev_prep)
+            L.check(self.lib.dlka_lka3d_tokens_prepare_run_range(L.ptr(self._plan_dev), L.ptr(self._plan_host), n, k, n, self._side.cuda_stream),
+                    "lka3d_tokens_prepare_run_range")
+            self._ev_prep2.record(self._side)
+            self._prep_pending = k
+            return
+        rc = self.lib.dlka_lka3d_tokens_prepare_run(L.ptr(self._plan_dev), L.ptr(self._plan_host), n, st)
         L.check(rc, "lka3d_tokens_prepare_run")
 
     def _stream(self):
@@ -193,6 +212,9 @@ class DLKABlockStack:
         for i, blk in enumerate(self.blocks):
             if on_block is not None:
                 on_block(i)
+            if self._prep_pending is not None and i == self._prep_pending:   # the weights of this and the later blocks were prepared on the side stream
+                torch.cuda.current_stream(self.device).wait_event(self._ev_prep2)
+                self._prep_pending = None
             H, W, D = blk.dims
             rc = self.lib.dlka_lka3d_attention_tokens_forward_prepared(L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.y), L.ptr(blk.saved),
                                                                 blk.saved_bytes, L.ptr(self.ws), self.ws_bytes, self.B, blk.C, H, W, D,

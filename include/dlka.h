@@ -300,6 +300,8 @@ size_t dlka_lka3d_tokens_prepare_plan_bytes(int nblocks);
 int dlka_lka3d_tokens_prepare_plan(int nblocks, const dlka_lka3d_params *params, void *const *saved, const size_t *saved_bytes,
                                    const int *dims5, int dtype, void *plan_host, size_t plan_bytes);
 int dlka_lka3d_tokens_prepare_run(const void *plan_device, const void *plan_host, int nblocks, void *stream);
+/* the same for blocks [block_lo, block_hi) only: a caller can prepare the first blocks, start their forward passes, and prepare the rest on another stream */
+int dlka_lka3d_tokens_prepare_run_range(const void *plan_device, const void *plan_host, int nblocks, int block_lo, int block_hi, void *stream);
 int dlka_lka3d_attention_tokens_forward_prepared(const void *x, const dlka_lka3d_params *p, void *y,
                                                  void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes,
                                                  int B, int C, int D, int H, int W, int dtype, void *stream);
