@@ -850,7 +850,7 @@ def main():
             "config": {"workload": "3D D-LKA Former Synapse 64x128x128 patch: fwd+bwd of its 21 D-LKA attention blocks "
                                    "(6x(32,32^3)+6x(64,16^3)+6x(128,8^3)+3x(256,4^3)) + grad all-reduce + SGD update",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "block_params": stack.num_params(), "hipgraph": graph is not None,
+                       "block_params": stack.num_params(), "hipgraph": graph is not None, "weight_gradients_on_side_stream": bool(getattr(stack, "_overlap", False)),
                        "allreduce_overlap": bool(step is step_overlapped), "allreduce_split_block": int(split),
                        "offset_std_voxels_stage0": health["offset_std"][0], "offset_std_voxels_by_stage": health["offset_std"]},
         }
