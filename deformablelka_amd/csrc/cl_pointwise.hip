@@ -12,15 +12,19 @@
 
 namespace dlka {
 
-template <typename T>   // activation storage: float, or bf16_t (fp32 arithmetic either way; weights / bias are fp32)
-__global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
+// KW > 1 (small M, wide C — the C = 128 / 256 stages): KW waves share an output tile, wave w contracts the channel chunks w, w + KW, ..., the partial tiles
+// meet in LDS and wave 0 runs the epilogue.  With one wave per tile a 128 x 256 x 256 product is 32 waves of two load round trips and 128 dependent
+// MFMAs (11.4 us, of which 3.4 us is the MFMA chain); four waves: one round trip and 32 MFMAs each.  No atomics, no zero fill, same epilogues; the sum
+// of the chunk products is formed in a different order (rounding only).
+template <typename T, int KW = 1>   // T: activation storage: float, or bf16_t (fp32 arithmetic either way; weights / bias are fp32)
+__global__ __launch_bounds__(64 * KW, 2) void cl_pointwise_kernel(IgemmArgs p)
 {
     constexpr unsigned SB = sizeof(T);
     const T *auxp = reinterpret_cast<const T *>(p.aux), *aux2p = reinterpret_cast<const T *>(p.aux2);
     T *outp = reinterpret_cast<T *>(p.out), *out2p = reinterpret_cast<T *>(p.out2);
-    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x & 63, kwave = KW > 1 ? (int)(threadIdx.x >> 6) : 0, i = lane & 31, h = lane >> 5;
     if (p.zero_xblocks && (int)blockIdx.x >= (int)gridDim.x - p.zero_xblocks) {   // riding zero fills (IgemmArgs::zero): the workgroups behind the row tiles
-        zero_batch_block(p.zero, (blockIdx.x - (gridDim.x - p.zero_xblocks)) * gridDim.y + blockIdx.y, lane, 64);
+        if (kwave == 0) zero_batch_block(p.zero, (blockIdx.x - (gridDim.x - p.zero_xblocks)) * gridDim.y + blockIdx.y, lane, 64);
         return;
     }
     const int mbase = blockIdx.x * 32, n0 = blockIdx.y * 32;
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
         x0 = __uint_as_float(odd ? (oth & 0xffff0000u) : (own << 16));
         x1 = __uint_as_float(odd ? (own & 0xffff0000u) : (oth << 16));
     };
-    if (p.epi >= 2) {   // uniform
+    if (p.epi >= 2 && kwave == 0) {   // uniform
         if (B16) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
@@ -72,14 +76,15 @@ __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
         }
     }
     const int nchunk = p.CinP / 32;
-    for (int c0 = 0; c0 < nchunk; c0 += 4) {
+    for (int c0 = 0; c0 * KW + kwave < nchunk; c0 += 4) {   // this wave's chunks: kwave, kwave + KW, ...
         f32x4 a[4][4];
         float b[4][16];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (c0 + u >= nchunk) break;   // uniform
-            const unsigned ao = abase + (unsigned)(c0 + u) * 32u * SB;
-            const unsigned bo = bbase + (unsigned)(c0 + u) * 32u * bstep;
+            const int ck = (c0 + u) * KW + kwave;
+            if (ck >= nchunk) break;   // uniform per wave
+            const unsigned ao = abase + (unsigned)ck * 32u * SB;
+            const unsigned bo = bbase + (unsigned)ck * 32u * bstep;
             if (B16) {   // 16 channels = 32 bytes: two 16-byte loads
                 buf_load_bf16x8(rin, ao, a[u][0], a[u][1]);
                 buf_load_bf16x8(rin, ao == DLKA_OOB ? DLKA_OOB : ao + 16u, a[u][2], a[u][3]);
@@ -92,10 +97,27 @@ __global__ __launch_bounds__(64, 2) void cl_pointwise_kernel(IgemmArgs p)
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (c0 + u >= nchunk) break;
+            if ((c0 + u) * KW + kwave >= nchunk) break;
 #pragma unroll
             for (int s = 0; s < 16; ++s) acc = mfma_32x32x2(a[u][s >> 2][s & 3], b[u][s], acc);
         }
+    }
+    if (KW > 1) {   // fold the KW partial tiles: waves 1 .. KW-1 hand theirs over through LDS, wave 0 goes on to the epilogue
+        __shared__ __attribute__((aligned(16))) float red[(KW > 1 ? KW - 1 : 1) * 16 * 64];
+        if (kwave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 4)
+                *reinterpret_cast<f32x4 *>(&red[((kwave - 1) * 16 + r) * 64 + 4 * lane]) = f32x4{acc[r], acc[r + 1], acc[r + 2], acc[r + 3]};
+        }
+        __syncthreads();
+        if (kwave > 0) return;
+#pragma unroll
+        for (int w = 0; w < KW - 1; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                const f32x4 o = *reinterpret_cast<const f32x4 *>(&red[(w * 16 + r) * 64 + 4 * lane]);
+                acc[r] += o[0]; acc[r + 1] += o[1]; acc[r + 2] += o[2]; acc[r + 3] += o[3];
+            }
     }
     // ---- epilogue: D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); same menu as cl_igemm_kernel ----
     if (n >= p.Cout) return;   // (whole waves: Cout % 32 == 0 on the bf16 path, so the lane exchanges below stay complete)
@@ -353,7 +375,14 @@ int launch_cl_pointwise(const IgemmArgs &a, hipStream_t st)
         ax.zero_xblocks = (int)cdiv((int)blk, (int)grid.y);
         grid.x += ax.zero_xblocks;
     }
-    if (a.act_bf16) { auto k = cl_pointwise_kernel<bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, ax); }
+    // few row tiles and a long contraction (C = 128 / 256 at 8^3 / 4^3): four waves per tile split the channel chunks (see the kernel)
+    const char *ekw = getenv("DLKA_PW_KW");   // (not cached: a parity test compares both forms)
+    const bool kw4 = ekw ? atoi(ekw) == 4 : ((long)cdiv(a.M, 32) * (a.NP / 32) <= 256 && a.CinP >= 128);
+    if (kw4) {
+        block = dim3(256);
+        if (a.act_bf16) { auto k = cl_pointwise_kernel<bf16_t, 4>; DLKA_LAUNCH(k, grid, block, 0, st, ax); }
+        else { auto k = cl_pointwise_kernel<float, 4>; DLKA_LAUNCH(k, grid, block, 0, st, ax); }
+    } else if (a.act_bf16) { auto k = cl_pointwise_kernel<bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, ax); }
     else { auto k = cl_pointwise_kernel<float>; DLKA_LAUNCH(k, grid, block, 0, st, ax); }
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;

@@ -287,6 +287,18 @@ def test_stack_with_hoisted_weight_preparation_equals_per_block_calls():
         assert torch.allclose(y, y_ref, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("kw", ["1", "4"])
+def test_lka3d_tokens_pointwise_kernel_with_split_contraction(kw):
+    """cl_pointwise_kernel<T, 4> (four waves share an output tile and split the channel chunks: the C = 128 / 256 stages on the GPU) and the
+    one-wave form on the same block — both against the oracle, fp32 and bf16 storage, ragged M."""
+    os.environ["DLKA_PW_KW"] = kw
+    try:
+        parity.check_lka3d_tokens("cpu", 1, 128, (3, 3, 5))
+        parity.check_lka3d_tokens_bf16("cpu", 1, 64, (3, 4, 3))
+    finally:
+        del os.environ["DLKA_PW_KW"]
+
+
 def test_stack_step_level_weight_gradient_finalisation_equals_per_block_launches():
     """DLKABlockStack lets every block's weight-gradient partial sums land in a block-private area and folds them all with ONE table-driven
     launch (dlka_wgrad_finalize_run) — per slice of the backward pass when it is cut for the overlapped all-reduce.  The job table is recorded
