@@ -141,6 +141,7 @@ struct PrepBatch {
     PrepJob j[PREP_MAX_JOBS];
     int njobs;
     long total;
+    int first[PREP_MAX_JOBS + 1];   // set by launch_cl_prep_batch: first workgroup of job k (a workgroup covers PREP_TABLE_CHUNK elements of ONE job)
 };
 
 // one weight-gradient finalisation: fold the row-chunk partials (kind 0) or re-lay a depthwise [tap][c] buffer (kind 1)

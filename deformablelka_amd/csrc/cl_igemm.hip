@@ -271,32 +271,33 @@ int launch_cl_prep_weight(const float *w, float *wp, int Cout, int Cin, int K, i
 }
 
 // All weight re-layouts of one D-LKA block in ONE launch (the per-conv prep launches were ~17 x 5 us per block).
-// job.mode 0/1/2: cl_prep_weight_kernel's modes; 3: depthwise W[c][tap] -> Wp[tap][c]; 4: the same with flipped taps.
-__global__ __launch_bounds__(256) void cl_prep_batch_kernel(PrepBatch b)
+// job.mode 0/1/2: cl_prep_weight_kernel's modes; 3: depthwise W[c][tap] -> Wp[tap][c]; 4: the same with flipped taps; 5: zero fill.
+// A workgroup covers PREP_TABLE_CHUNK elements of ONE job (b.first[k] = first workgroup of job k): the job is found once per workgroup — the first
+// version searched the job list linearly for EVERY element of a grid-stride loop (21 us average per launch in the nn.Module path of the full net).
+constexpr int PREP_TABLE_CHUNK = 2048;
+__device__ __forceinline__ void prep_job_chunk(const PrepJob &j, long l0)
 {
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < b.total; e += (long)gridDim.x * blockDim.x) {
-        int ji = 0;
-        long lo = 0;
-        while (ji + 1 < b.njobs && e >= lo + b.j[ji].n) { lo += b.j[ji].n; ++ji; }
-        const PrepJob &j = b.j[ji];
-        const long l = e - lo;
-        float val = 0.f;
+    for (long l = l0 + threadIdx.x; l < l0 + PREP_TABLE_CHUNK && l < j.n; l += 256) {
         if (j.mode == 5) { j.dst[l] = 0.f; continue; }   // a zero fill riding along (split outputs of the forward pass)
         if (j.mode == 3 || j.mode == 4) {
             const int c = (int)(l % j.Cin), tap = (int)(l / j.Cin);
-            val = j.src[(long)c * j.K + (j.mode == 4 ? j.K - 1 - tap : tap)];
+            j.dst[l] = j.src[(long)c * j.K + (j.mode == 4 ? j.K - 1 - tap : tap)];
         } else {
             const int n = (int)(l % j.NP), k = (int)((l / j.NP) % j.KP), tp = (int)(l / j.NP / j.KP);
             prep_store(j.dst, j.KP, j.NP, j.mode, tp, k, n, prep_value(j.src, j.Cout, j.Cin, j.K, j.mode, tp, k, n));
-            continue;
         }
-        j.dst[l] = val;
     }
+}
+
+__global__ __launch_bounds__(256) void cl_prep_batch_kernel(PrepBatch b)
+{
+    int ji = 0;
+    while (ji + 1 < b.njobs && (int)blockIdx.x >= b.first[ji + 1]) ++ji;   // (njobs <= PREP_MAX_JOBS, wave-uniform)
+    prep_job_chunk(b.j[ji], (long)((int)blockIdx.x - b.first[ji]) * PREP_TABLE_CHUNK);
 }
 
 // The same re-layouts for MANY blocks in one launch: the job table lives in device memory (built once per model, the pointers do not
 // change), `first[j]` = first workgroup of job j; a workgroup finds its job by bisection and covers PREP_TABLE_CHUNK elements of it.
-constexpr int PREP_TABLE_CHUNK = 2048;
 // (this launch covers jobs [job_lo, job_hi); its workgroup 0 is workgroup first[job_lo] of the whole table)
 __global__ __launch_bounds__(256) void cl_prep_table_kernel(const PrepJob *__restrict__ jobs, const int *__restrict__ first, int job_lo, int job_hi)
 {
@@ -307,16 +308,7 @@ __global__ __launch_bounds__(256) void cl_prep_table_kernel(const PrepJob *__res
         if (first[mid] <= wg) lo = mid; else hi = mid - 1;
     }
     const PrepJob j = jobs[lo];
-    const long l0 = (long)(wg - first[lo]) * PREP_TABLE_CHUNK;
-    for (long l = l0 + threadIdx.x; l < l0 + PREP_TABLE_CHUNK && l < j.n; l += 256) {
-        if (j.mode == 3 || j.mode == 4) {
-            const int c = (int)(l % j.Cin), tap = (int)(l / j.Cin);
-            j.dst[l] = j.src[(long)c * j.K + (j.mode == 4 ? j.K - 1 - tap : tap)];
-        } else {
-            const int n = (int)(l % j.NP), k = (int)((l / j.NP) % j.KP), tp = (int)(l / j.NP / j.KP);
-            prep_store(j.dst, j.KP, j.NP, j.mode, tp, k, n, prep_value(j.src, j.Cout, j.Cin, j.K, j.mode, tp, k, n));
-        }
-    }
+    prep_job_chunk(j, (long)(wg - first[lo]) * PREP_TABLE_CHUNK);
 }
 
 int cl_prep_table_blocks(long n) { return (int)cdivl(n, PREP_TABLE_CHUNK); }
@@ -329,12 +321,18 @@ int launch_cl_prep_table(const PrepJob *jobs_dev, const int *first_dev, int job_
     return DLKA_OK;
 }
 
-int launch_cl_prep_batch(const PrepBatch &b, hipStream_t st)
+int launch_cl_prep_batch(const PrepBatch &b_, hipStream_t st)
 {
-    if (b.njobs <= 0) return DLKA_OK;
-    long blocks = cdivl(b.total, 256);
-    if (blocks > 4096) blocks = 4096;
-    DLKA_LAUNCH(cl_prep_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+    if (b_.njobs <= 0) return DLKA_OK;
+    PrepBatch b = b_;
+    int blk = 0;
+    for (int k = 0; k < b.njobs; ++k) {
+        b.first[k] = blk;
+        blk += (int)cdivl(b.j[k].n, PREP_TABLE_CHUNK);
+    }
+    b.first[b.njobs] = blk;
+    if (blk <= 0) return DLKA_OK;
+    DLKA_LAUNCH(cl_prep_batch_kernel, dim3((unsigned)blk), dim3(256), 0, st, b);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
