@@ -156,7 +156,7 @@ struct FinalizeJob {
     long block0;         // first workgroup of this job
 };
 struct FinalizeBatch {
-    FinalizeJob j[8];
+    FinalizeJob j[12];   // (a D-LKA block has 8; the wrapper block appends its 3 so that one launch folds both)
     int njobs;
     long nblocks;
 };

@@ -1127,7 +1127,8 @@ size_t fin_first_off() { return sizeof(FinPlanHeader); }
 size_t fin_jobs_off(int nb) { return align256(sizeof(FinPlanHeader) + (size_t)(nb + 1) * sizeof(int)); }
 int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void *gy_, const void *saved, size_t saved_bytes, void *gx_,
                          const dlka_lka3d_grads *gr, void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant,
-                         void *stream, void *partials, size_t partials_bytes, FinalizeJob *jobs_out, int *njobs_out, int phase = 0);
+                         void *stream, void *partials, size_t partials_bytes, FinalizeJob *jobs_out, int *njobs_out, int phase = 0,
+                         const FinalizeBatch *extra = nullptr);
 }  // namespace
 
 size_t dlka_lka3d_tokens_partials_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant)
@@ -1266,7 +1267,7 @@ namespace {
 // returned in jobs_out / njobs_out for dlka_wgrad_finalize_run
 int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void *gy_, const void *saved, size_t saved_bytes, void *gx_,
                          const dlka_lka3d_grads *gr, void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant,
-                         void *stream, void *partials, size_t partials_bytes, FinalizeJob *jobs_out, int *njobs_out, int phase)
+                         void *stream, void *partials, size_t partials_bytes, FinalizeJob *jobs_out, int *njobs_out, int phase, const FinalizeBatch *extra)
 {
     if (!x_ || !p || !gy_ || !saved || !gx_ || !gr || !workspace) return DLKA_ERR_NULL;
     if (phase < 0 || phase > 2) return DLKA_ERR_SHAPE;
@@ -1411,6 +1412,10 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
         *njobs_out = fb.njobs;
     } else {
         if (phase != 0) return DLKA_ERR_UNSUPPORTED;   // the split passes need the deferred finalisation (block-private partial sums)
+        if (extra) {   // the caller's own folds (the wrapper block's three conv weight gradients) ride in this launch
+            if (fb.njobs + extra->njobs > (int)(sizeof(fb.j) / sizeof(fb.j[0]))) return DLKA_ERR_UNSUPPORTED;
+            for (int k = 0; k < extra->njobs; ++k) fb.j[fb.njobs++] = extra->j[k];
+        }
         DLKA_TRY(launch_cl_wgrad_finalize(fb, ws_));
     }
     DLKA_P1(dense_backward_data(G.pw, gh, 0, N0, gx, PW.pw_b[0], 3, gy, st, nullptr, nullptr, true));
@@ -1726,12 +1731,13 @@ int dlka_tblock3d_backward_v(const dlka_tblock3d_params *p, const dlka_lka3d_par
                               (float *)gr->conv51_norm1_b, M, N, C, slope, training, st, true));
     // conv1:  g_attn = W1^T g_c1 + g_skip
     DLKA_TRY(dense_backward_weight(G.c3, S.attn, g_c1, 0, (float *)gr->conv51_conv1_w, nullptr, part1, st, &fb.j[fb.njobs++]));
-    DLKA_TRY(launch_cl_wgrad_finalize(fb, st));
+    // (the fold of the three conv weight gradients above rides in the D-LKA block's finalize launch below: one dependent launch less per block)
     DLKA_TRY(dense_backward_data(G.c3, g_c1, 0, nullptr, g_attn, S.w1_b, 3, g_skip, st, nullptr, nullptr, true));
     // attn = xt + gamma * e
     DLKA_TRY(launch_cl_scale_residual_bwd(g_attn, S.e, (const float *)p->gamma, g_e, (float *)gr->gamma, M, C, st, true));
     // epa_block
-    DLKA_TRY(dlka_lka3d_attention_tokens_backward_v(S.xn, lka, g_e, S.lka, S.lka_bytes, g_xn, glka, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, variant, stream));
+    DLKA_TRY(tokens_backward_impl(S.xn, lka, g_e, S.lka, S.lka_bytes, g_xn, glka, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, variant, stream, nullptr, 0, nullptr,
+                                  nullptr, 0, &fb));
     // LayerNorm (+ the residual branch g_attn), pos_embed
     DLKA_TRY(launch_cl_layernorm_bwd(g_xn, g_attn, S.xt, S.lnstats, (const float *)p->norm_w, (float *)grad_x, (float *)gr->norm_w, (float *)gr->norm_b,
                                      (float *)gr->pos_embed, B, (int)N, C, st, true));
