@@ -141,7 +141,7 @@ class InstanceNorm3d(nn.InstanceNorm3d):
 
     def forward(self, x):
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and not self.affine and not self.track_running_stats
-                and not torch.is_autocast_enabled()):
+                and not torch.is_autocast_enabled() and x.shape[0] * x.shape[1] <= 65535):   # (one grid row per (b, c) plane)
             return super().forward(x)
         from . import nn_ops
         B, C = x.shape[:2]
@@ -157,7 +157,7 @@ class BatchNorm3d(nn.BatchNorm3d):
 
     def forward(self, x):
         if not (self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and not torch.is_autocast_enabled()
-                and (self.weight is None or self.weight.dtype == torch.float32)):
+                and (self.weight is None or self.weight.dtype == torch.float32) and x.shape[0] * x.shape[1] <= 65535):
             return super().forward(x)
         from . import nn_ops
         y, stats = nn_ops.batch_norm_train(x.contiguous(), self.weight, self.bias, self.eps)
