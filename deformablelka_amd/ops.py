@@ -327,7 +327,7 @@ def batchnorm_planar_backward(g, x, weight, stats, affine=True):
 def pointwise_planar_supported(x, weight, need_weight_grad=True) -> bool:
     Cout, Cin = weight.shape[:2]
     return (x.dtype == torch.float32 and weight.dtype == torch.float32 and Cin in PLANAR_PW_CIN and Cout <= (16 if need_weight_grad else 64)
-            and x[0, 0].numel() % 4 == 0 and (not need_weight_grad or Cout in PLANAR_PW_CIN))
+            and x[0, 0].numel() % 4 == 0 and x.shape[0] <= 65535 and (not need_weight_grad or Cout in PLANAR_PW_CIN))
 
 
 def pointwise_planar_forward(x, weight, bias=None):
