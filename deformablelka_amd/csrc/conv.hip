@@ -156,10 +156,97 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(const float *__restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same op for rows of W <= 128 voxels (W % 8 == 0: the net's 128-wide full-resolution rows), with the row held in registers: lane (j, kg) owns the
+// EIGHT consecutive voxels 8 j .. 8 j + 7 of the row (two 16-byte loads per input row and k-step) and the wave runs eight 16x16x4 tiles, tile q = the voxels
+// {8 j + q}.  The tap_w = -1 / +1 operands of tile q are the registers of tile q - 1 / q + 1 of the SAME lane; only tile 0's left and tile 7's right neighbour
+// come from the adjacent lane — one DPP row shift each, whose out-of-row zero IS the padding.  Two 16-byte loads and two DPP moves feed 24 MFMAs (the kernel
+// above: 24 dword loads); loads run one k-step ahead of the MFMAs; rows outside the volume are loaded as zeros (buffer range check), so the 36 steps of a row are
+// straight-line code.  Per row 864 MFMAs = 27.6 k cycles of the SIMD's matrix pipe: 184 us for 2 x 16 x 64 x 128 x 128 with every pipe busy.
+// ---------------------------------------------------------------------------------------------
+template <bool FLIP>
+__global__ __launch_bounds__(256, 2) void conv3_row_mfma_kernel(const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ bias,
+                                                               float *__restrict__ out, Geom g, int rows_per_wave)
+{
+    const int lane = threadIdx.x & 63, j = lane & 15, kg = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int CI = FLIP ? g.Cout : g.C, CO = FLIP ? g.C : g.Cout;
+    float areg[27][4];   // as conv3_mfma_kernel
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int i = j, k = 4 * s4 + kg;
+            float v = 0.f;
+            if (i < CO && k < CI) v = FLIP ? w[((long)k * g.C + i) * 27 + (26 - t)] : w[((long)i * g.C + k) * 27 + t];
+            areg[t][s4] = v;
+        }
+    const long nrows = (long)g.B * g.D * g.H;
+    const long r0 = (long)wave * rows_per_wave, r1 = r0 + rows_per_wave < nrows ? r0 + rows_per_wave : nrows;
+    const unsigned plane = (unsigned)(g.D * g.H * g.W);
+    const bool jok = 8 * j < g.W;
+    const BufRsrc rin = make_rsrc(in, (size_t)g.B * CI * plane * 4), rout = make_rsrc(out, (size_t)g.B * CO * plane * 4);
+    unsigned lane_off[4];   // channel plane + position in the row, bytes
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) lane_off[s4] = (jok && 4 * s4 + kg < CI) ? ((unsigned)(4 * s4 + kg) * plane + 8u * j) * 4u : DLKA_OOB;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!FLIP && bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = 4 * kg + r < CO ? bias[4 * kg + r] : 0.f;
+    }
+    for (long r = r0; r < r1; ++r) {
+        const int h = (int)(r % g.H), d = (int)((r / g.H) % g.D), b = (int)(r / ((long)g.H * g.D));
+        const unsigned in_b = (unsigned)b * (unsigned)CI * plane * 4u;
+        f32x4 acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = f32x4{bv[0], bv[1], bv[2], bv[3]};
+        f32x4 lo, hi, nlo, nhi;
+        auto request = [&](int step, f32x4 &a, f32x4 &c) {
+            const int td = step / 12, th = (step / 4) % 3, s4 = step & 3;
+            const int zd = d + td - 1, zh = h + th - 1;
+            const bool ok = zd >= 0 && zd < g.D && zh >= 0 && zh < g.H;   // uniform
+            const unsigned off = ok ? lane_off[s4] + in_b + (unsigned)((zd * g.H + zh) * g.W) * 4u : DLKA_OOB;
+            a = buf_load_f32x4(rin, off);
+            c = buf_load_f32x4(rin, off + 16u);
+        };
+        request(0, lo, hi);
+#pragma unroll
+        for (int step = 0; step < 36; ++step) {
+            if (step + 1 < 36) request(step + 1, nlo, nhi);
+            const int t0 = (step / 4) * 3, s4 = step & 3;
+            const float xv[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const float el = row_shr1(xv[7]), er = row_shl1(xv[0]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = mfma_16x16x4(areg[t0][s4], q ? xv[q ? q - 1 : 0] : el, acc[q]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = mfma_16x16x4(areg[t0 + 1][s4], xv[q], acc[q]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = mfma_16x16x4(areg[t0 + 2][s4], q < 7 ? xv[q < 7 ? q + 1 : 7] : er, acc[q]);
+            lo = nlo; hi = nhi;
+        }
+        const unsigned row = (unsigned)((d * g.H + h) * g.W);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int i = 4 * kg + r4;
+            const unsigned off = (jok && i < CO) ? (((unsigned)b * CO + i) * plane + row + 8u * j) * 4u : DLKA_OOB;
+            buf_store_f32x4(rout, off, f32x4{acc[0][r4], acc[1][r4], acc[2][r4], acc[3][r4]});
+            buf_store_f32x4(rout, off == DLKA_OOB ? DLKA_OOB : off + 16u, f32x4{acc[4][r4], acc[5][r4], acc[6][r4], acc[7][r4]});
+        }
+    }
+}
+
 static bool conv3_mfma_shape(const Geom &g)
 {
     return g.group == 1 && g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 1 && g.ph == 1 && g.pw == 1 && g.dd == 1 &&
            g.dh == 1 && g.dw == 1 && g.C <= 16 && g.Cout <= 16;
+}
+// rows in registers: W <= 128 in whole groups of 8, at least 8 contraction channels (fewer: three quarters of the MFMA k-steps would multiply zeros), and
+// 32-bit byte offsets in both tensors
+static bool conv3_row_mfma_shape(const Geom &g, bool flip)
+{
+    const int CI = flip ? g.Cout : g.C;
+    const size_t big = (size_t)g.B * 16 * g.D * g.H * g.W * 4;
+    return conv3_mfma_shape(g) && g.W % 8 == 0 && g.W <= 128 && CI >= 8 && big < ((size_t)1 << 31);
 }
 static int conv3_mfma_rows_per_wave(const Geom &g, long &waves)
 {
@@ -175,6 +262,16 @@ int launch_conv_fwd(const T *x, const T *w, const T *bias, T *out, float *wt, co
 {
     // (conv3_mfma_kernel<false> serves this shape too, but measured SLOWER than the kernel above at 2 x 16 x 64x128x128: 627 vs 513 us — per 16 voxels it
     //  issues 108 dword loads with their address arithmetic for 108 MFMAs; the data gradient, whose thread-per-voxel form is slower, gains: 617 vs 776 us)
+    if constexpr (sizeof(T) == 4) {
+        if (conv3_row_mfma_shape(g, false)) {
+            long waves;
+            const int rpw = conv3_mfma_rows_per_wave(g, waves);
+            DLKA_LAUNCH(conv3_row_mfma_kernel<false>, dim3((unsigned)cdivl(waves, 4)), dim3(256), 0, st, reinterpret_cast<const float *>(x),
+                        reinterpret_cast<const float *>(w), reinterpret_cast<const float *>(bias), reinterpret_cast<float *>(out), g, rpw);
+            DLKA_CHECK_LAUNCH();
+            return DLKA_OK;
+        }
+    }
     const int cob = pick_pow2_upto32(g.Og);
     const int OgP = round_up(g.Og, cob);
     int rc = launch_relayout_weight<T>(w, wt, g.group, g.Og, g.Cg, g.K, OgP, st);
@@ -252,6 +349,14 @@ template <typename T>
 int launch_conv_bwd_data(const T *gout, const T *w, T *gx, float *wb, const Geom &g, hipStream_t st)
 {
     if constexpr (sizeof(T) == 4) {
+        if (conv3_row_mfma_shape(g, true)) {
+            long waves;
+            const int rpw = conv3_mfma_rows_per_wave(g, waves);
+            DLKA_LAUNCH(conv3_row_mfma_kernel<true>, dim3((unsigned)cdivl(waves, 4)), dim3(256), 0, st, reinterpret_cast<const float *>(gout),
+                        reinterpret_cast<const float *>(w), (const float *)nullptr, reinterpret_cast<float *>(gx), g, rpw);
+            DLKA_CHECK_LAUNCH();
+            return DLKA_OK;
+        }
         if (conv3_mfma_shape(g) && g.Cout >= 4) {
             long waves;
             const int rpw = conv3_mfma_rows_per_wave(g, waves);

@@ -63,6 +63,19 @@ __device__ __forceinline__ float sum4(float x)
     x += hipemu::shfl_any(x, (hipemu::F().lin & 63) ^ 2);
     return x;
 }
+// the value of lane - 1 / lane + 1 inside each row of 16 lanes; 0 in the first / last lane of a row (every lane of the wave must call them)
+__device__ __forceinline__ float row_shr1(float x)
+{
+    const int l = hipemu::F().lin & 63;
+    const float v = hipemu::shfl_any(x, (l & 15) ? l - 1 : l);
+    return (l & 15) ? v : 0.f;
+}
+__device__ __forceinline__ float row_shl1(float x)
+{
+    const int l = hipemu::F().lin & 63;
+    const float v = hipemu::shfl_any(x, (l & 15) != 15 ? l + 1 : l);
+    return (l & 15) != 15 ? v : 0.f;
+}
 // buffer resource: loads at a byte offset >= the buffer size return 0 (the hardware range check of buffer_load)
 struct BufRsrc { const unsigned char *base; unsigned bytes; };
 __device__ __forceinline__ BufRsrc make_rsrc(const void *p, size_t bytes) { return BufRsrc{(const unsigned char *)p, (unsigned)bytes}; }
@@ -216,6 +229,10 @@ __device__ __forceinline__ float sum4(float x)
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));
     return x;
 }
+// the value of lane - 1 / lane + 1 inside each row of 16 lanes, 0 in the first / last lane of a row: one DPP move (row_shr:1 = 0x111, row_shl:1 = 0x101,
+// bound_ctrl: lanes without a source read 0)
+__device__ __forceinline__ float row_shr1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xF, 0xF, true)); }
+__device__ __forceinline__ float row_shl1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x101, 0xF, 0xF, true)); }
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 __device__ __forceinline__ BufRsrc make_rsrc(const void *p, size_t bytes)
 {

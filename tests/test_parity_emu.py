@@ -61,6 +61,10 @@ CONV = [
     (2, 16, 16, (5, 6, 20), 3, 1, 1, 1, 1),     # the full net's plumbing convs: weight gradient on the matrix cores (conv3_bwd_weight_mfma_kernel), W % 16 != 0
     (1, 1, 16, (4, 9, 8), 3, 1, 1, 1, 1),       # encoder1.conv1: one input channel
     (2, 5, 14, (3, 3, 32), 3, 1, 1, 1, 1),      # ragged channel counts
+    (2, 16, 16, (3, 4, 24), 3, 1, 1, 1, 1),     # rows of W % 8 == 0 <= 128 voxels held in registers (conv3_row_mfma_kernel): forward and data gradient
+    (1, 12, 16, (4, 3, 128), 3, 1, 1, 1, 1),    # ... the full 128-wide row, ragged input channels
+    (1, 16, 9, (2, 5, 8), 3, 1, 1, 1, 1),       # ... one lane group per row, ragged output channels
+    (2, 8, 5, (1, 1, 16), 3, 1, 1, 1, 1),       # ... a single row per sample: every neighbour row is padding
 ]
 
 

@@ -67,6 +67,9 @@ CONV = [
     (1, 8, 12, (7, 6, 5), 3, 2, 1, 1, 2),                     # strided grouped
     (2, 96, 50, (1, 20, 20), (1, 5, 5), 1, (0, 2, 2), 1, 1),  # 2-D offset net 5x5 -> 50
     (1, 96, 98, (1, 20, 20), (1, 7, 7), 1, (0, 9, 9), (1, 3, 3), 1),  # 2-D offset net 7x7 dil 3 -> 98
+    (2, 16, 16, (6, 9, 128), 3, 1, 1, 1, 1),                  # the net's full-resolution plumbing convs: 128-wide rows in registers (conv3_row_mfma_kernel)
+    (1, 12, 16, (5, 4, 40), 3, 1, 1, 1, 1),                   # ... partial lane groups, ragged channels
+    (1, 16, 16, (4, 5, 36), 3, 1, 1, 1, 1),                   # W % 8 != 0: the per-voxel-tile MFMA kernel / thread-per-voxel forward
 ]
 
 
@@ -482,6 +485,38 @@ def test_instancenorm_planar_full_resolution_vs_torch():
         ya.backward(gy); yb.backward(gy)
         assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)
         assert torch.allclose(xa.grad, xb.grad, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups,shape", [(1, (2, 32, 32, 32, 32)), (2, (3, 8, 16, 64, 64)), (32, (2, 64, 16, 16, 16))])
+def test_groupnorm_long_rows_vs_torch(groups, shape):
+    """network.GroupNorm (the stem's one-group norm over 2 x 32 x 32^3: planar statistics kernels + affine; the short-row case stays on the stock
+    layer) against nn.GroupNorm with the same parameters: output, input gradient, affine gradients."""
+    import torch.nn as nn
+    from deformablelka_amd.network import GroupNorm
+    torch.manual_seed(0)
+    C = shape[1]
+    a, b = GroupNorm(groups, C).cuda(), nn.GroupNorm(groups, C).cuda()
+    with torch.no_grad():
+        a.weight.copy_(torch.randn(C) * 0.3 + 1.0); a.bias.copy_(torch.randn(C) * 0.2)
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(*shape, device="cuda") * 1.7 + 0.4
+    x[:, 0] += 30.0                      # a channel far from the group's mean
+    gy = torch.randn_like(x)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = a(xa), b(xb)
+    ya.backward(gy); yb.backward(gy)
+    # fp64 restatement as the arbiter of both
+    xd = x.double().view(shape[0], groups, -1)
+    xh = ((xd - xd.mean(-1, keepdim=True)) / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + a.eps)).view(shape)
+    wv = a.weight.detach().double().view(1, C, 1, 1, 1)
+    yr = xh * wv + a.bias.detach().double().view(1, C, 1, 1, 1)
+    assert torch.allclose(ya.double(), yr, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=2e-4)
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-3, atol=2e-5)
+    gw = (gy.double() * xh).sum((0, 2, 3, 4))
+    assert torch.allclose(a.weight.grad.double(), gw, rtol=1e-4, atol=1e-2)
+    assert torch.allclose(a.bias.grad, b.bias.grad, rtol=1e-4, atol=1e-2)
 
 
 @pytest.mark.gpu
