@@ -459,6 +459,56 @@ __global__ __launch_bounds__(DLKA_THREADS) void conv_bwd_weight_kernel(
     }
 }
 
+// Epilogue of the MFMA weight-gradient kernels: the four waves of the workgroup fold their 27 tiles through LDS, one atomic per element and WORKGROUP.
+// With `part` the workgroup's folded tile goes to part[blockIdx.x][27][64][4] as plain 16-byte stores and conv3_wgrad_reduce_kernel adds the tiles up: 512
+// workgroups x 6912 atomics on 6912 addresses took ~400 us of the 580 us kernel at 2 x 16 x 64 x 128 x 128.
+__device__ __forceinline__ void conv3_wgrad_fold_and_add(f32x4 (&acc)[27], float *__restrict__ gw, const Geom &g, int lane, int i, int kg, bool ci_ok,
+                                                         float *__restrict__ part = nullptr)
+{
+    // the four waves of the workgroup fold their tiles through LDS first (waves 2, 3 -> 0, 1; then 1 -> 0): every output element is hit by one
+    // atomic per WORKGROUP — with one per wave, 2048 waves queued on the same 6912 addresses and the atomics were most of the kernel's time
+    __shared__ __attribute__((aligned(16))) float red[2][27 * 64 * 4];
+    const int wv = threadIdx.x >> 6;
+    if (wv >= 2) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) *reinterpret_cast<f32x4 *>(&red[wv - 2][(t * 64 + lane) * 4]) = acc[t];
+    }
+    __syncthreads();
+    if (wv < 2) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const f32x4 o = *reinterpret_cast<const f32x4 *>(&red[wv][(t * 64 + lane) * 4]);
+            acc[t][0] += o[0]; acc[t][1] += o[1]; acc[t][2] += o[2]; acc[t][3] += o[3];
+        }
+    }
+    __syncthreads();
+    if (wv == 1) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) *reinterpret_cast<f32x4 *>(&red[0][(t * 64 + lane) * 4]) = acc[t];
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    if (part) {
+        float *dst = part + (size_t)blockIdx.x * (27 * 256);
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const f32x4 o = *reinterpret_cast<const f32x4 *>(&red[0][(t * 64 + lane) * 4]);
+            *reinterpret_cast<f32x4 *>(dst + (t * 64 + lane) * 4) = f32x4{acc[t][0] + o[0], acc[t][1] + o[1], acc[t][2] + o[2], acc[t][3] + o[3]};
+        }
+        return;
+    }
+    // D layout: column j = lane & 15 = ci, rows 4 kg + r = co
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        const f32x4 o = *reinterpret_cast<const f32x4 *>(&red[0][(t * 64 + lane) * 4]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = 4 * kg + r;
+            if (ci_ok && co < g.Cout) atomicAdd(gw + ((long)co * g.C + i) * 27 + t, acc[t][r] + o[r]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The same weight gradient for the full net's full-resolution plumbing convs (3^3, stride 1, padding 1, <= 16 -> <= 16 channels at
 // 2 x 64 x 128 x 128: encoder1 / decoder2, d_lka_former_synapse.py:89-133) on the matrix cores.  The thread-per-voxel kernel above needs 1.6 ms per
@@ -515,52 +565,133 @@ __global__ __launch_bounds__(256, 2) void conv3_bwd_weight_mfma_kernel(const flo
             }
         }
     }
-    // the four waves of the workgroup fold their tiles through LDS first (waves 2, 3 -> 0, 1; then 1 -> 0): every output element is hit by one
-    // atomic per WORKGROUP — with one per wave, 2048 waves queued on the same 6912 addresses and the atomics were most of the kernel's time
-    __shared__ __attribute__((aligned(16))) float red[2][27 * 64 * 4];
-    const int wv = threadIdx.x >> 6;
-    if (wv >= 2) {
+    conv3_wgrad_fold_and_add(acc, gw, g, lane, i, kg, ci_ok);
+}
+
+// part[nwg][27][64][4] -> gw: grid (27, splits); thread = (lane, r) of tap blockIdx.x, sums its share of the workgroup tiles, one atomic per thread
+__global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw, int nwg, int C, int Cout)
+{
+    const int t = blockIdx.x, e = threadIdx.x, lane = e >> 2, r = e & 3, i = lane & 15, kg = lane >> 4;
+    const int per = (nwg + gridDim.y - 1) / gridDim.y, lo = blockIdx.y * per, hi = lo + per < nwg ? lo + per : nwg;
+    float a = 0.f;
+    for (int wg = lo; wg < hi; ++wg) a += part[(size_t)wg * (27 * 256) + t * 256 + e];
+    const int co = 4 * kg + r;
+    if (lo < hi && i < C && co < Cout) atomicAdd(gw + ((long)co * C + i) * 27 + t, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same weight gradient with 32-voxel segments (lane (i, kg) owns the EIGHT voxels 32 seg + 8 kg .. + 7: two 16-byte loads + the two neighbours per
+// (tap_d, tap_h) feed 24 MFMAs) and straight-line code: rows outside the volume are loaded as zeros through the buffer range check instead of being
+// branched around, and every step's loads are issued one step ahead of its MFMAs — across segments and rows too (the kernel above waits for its loads
+// at every (tap_d, tap_h): 730 us at 2 x 16 x 64 x 128 x 128 for 184 us of matrix-pipe time).  W % 8 == 0, byte offsets < 2^31.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv3_bwd_weight_row_mfma_kernel(const float *__restrict__ x, const float *__restrict__ gout, float *__restrict__ gw,
+                                                                           Geom g, int rows_per_wave, float *__restrict__ part)
+{
+    const int lane = threadIdx.x & 63, i = lane & 15, kg = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nrows = (long)g.B * g.D * g.H;
+    const long r0 = (long)wave * rows_per_wave, r1 = r0 + rows_per_wave < nrows ? r0 + rows_per_wave : nrows;
+    f32x4 acc[27];
 #pragma unroll
-        for (int t = 0; t < 27; ++t) *reinterpret_cast<f32x4 *>(&red[wv - 2][(t * 64 + lane) * 4]) = acc[t];
-    }
-    __syncthreads();
-    if (wv < 2) {
+    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool co_ok = i < g.Cout, ci_ok = i < g.C;
+    const unsigned plane = (unsigned)(g.D * g.H * g.W);
+    const int nseg = (g.W + 31) >> 5;
+    const BufRsrc rx = make_rsrc(x, (size_t)g.B * g.C * plane * 4), rg = make_rsrc(gout, (size_t)g.B * g.Cout * plane * 4);
+    struct XStep { f32x4 lo, hi; float lft, rgt; };
+    // the x operands of step (tap_d, tap_h) of unit (row r, segment seg)
+    auto request_x = [&](long r, int seg, int step, XStep &o) {
+        const int td = step / 3, th = step % 3;
+        const int h = (int)(r % g.H), d = (int)((r / g.H) % g.D), b = (int)(r / ((long)g.H * g.D));
+        const int zd = d + td - 1, zh = h + th - 1, w0 = 32 * seg + 8 * kg;
+        const bool ok = r < r1 && zd >= 0 && zd < g.D && zh >= 0 && zh < g.H && ci_ok && w0 < g.W;
+        const unsigned off = ok ? (((unsigned)b * g.C + i) * plane + (unsigned)((zd * g.H + zh) * g.W + w0)) * 4u : DLKA_OOB;
+        o.lo = buf_load_f32x4(rx, off);
+        o.hi = buf_load_f32x4(rx, off + 16u);
+        o.lft = buf_load_f32(rx, (ok && w0 > 0) ? off - 4u : DLKA_OOB);
+        o.rgt = buf_load_f32(rx, (ok && w0 + 8 < g.W) ? off + 32u : DLKA_OOB);
+    };
+    auto request_g = [&](long r, int seg, f32x4 &lo, f32x4 &hi) {
+        const int h = (int)(r % g.H), d = (int)((r / g.H) % g.D), b = (int)(r / ((long)g.H * g.D));
+        const int w0 = 32 * seg + 8 * kg;
+        const bool ok = r < r1 && co_ok && w0 < g.W;
+        const unsigned off = ok ? (((unsigned)b * g.Cout + i) * plane + (unsigned)((d * g.H + h) * g.W + w0)) * 4u : DLKA_OOB;
+        lo = buf_load_f32x4(rg, off);
+        hi = buf_load_f32x4(rg, off + 16u);
+    };
+    long r = r0;
+    int seg = 0;
+    f32x4 qnl, qnh;
+    XStep nx;
+    request_g(r, seg, qnl, qnh);
+    request_x(r, seg, 0, nx);
+    while (r < r1) {   // wave-uniform
+        const float q[8] = {qnl[0], qnl[1], qnl[2], qnl[3], qnh[0], qnh[1], qnh[2], qnh[3]};
+        int sn = seg + 1;
+        long rn = r;
+        if (sn == nseg) { sn = 0; rn = r + 1; }
 #pragma unroll
-        for (int t = 0; t < 27; ++t) {
-            const f32x4 o = *reinterpret_cast<const f32x4 *>(&red[wv][(t * 64 + lane) * 4]);
-            acc[t][0] += o[0]; acc[t][1] += o[1]; acc[t][2] += o[2]; acc[t][3] += o[3];
+        for (int step = 0; step < 9; ++step) {
+            const XStep cx = nx;
+            if (step < 8) request_x(r, seg, step + 1, nx);
+            else { request_g(rn, sn, qnl, qnh); request_x(rn, sn, 0, nx); }
+            const float c[8] = {cx.lo[0], cx.lo[1], cx.lo[2], cx.lo[3], cx.hi[0], cx.hi[1], cx.hi[2], cx.hi[3]};
+            const int t0 = step * 3;
+            // tap_w = 0: x[w - 1], 1: x[w], 2: x[w + 1] for the lane's voxel w = w0 + e
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                acc[t0] = mfma_16x16x4(q[e], e ? c[e ? e - 1 : 0] : cx.lft, acc[t0]);
+                acc[t0 + 1] = mfma_16x16x4(q[e], c[e], acc[t0 + 1]);
+                acc[t0 + 2] = mfma_16x16x4(q[e], e < 7 ? c[e < 7 ? e + 1 : 7] : cx.rgt, acc[t0 + 2]);
+            }
         }
+        r = rn; seg = sn;
     }
-    __syncthreads();
-    if (wv == 1) {
-#pragma unroll
-        for (int t = 0; t < 27; ++t) *reinterpret_cast<f32x4 *>(&red[0][(t * 64 + lane) * 4]) = acc[t];
-    }
-    __syncthreads();
-    if (wv != 0) return;
-    // D layout: column j = lane & 15 = ci, rows 4 kg + r = co
-#pragma unroll
-    for (int t = 0; t < 27; ++t) {
-        const f32x4 o = *reinterpret_cast<const f32x4 *>(&red[0][(t * 64 + lane) * 4]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = 4 * kg + r;
-            if (ci_ok && co < g.Cout) atomicAdd(gw + ((long)co * g.C + i) * 27 + t, acc[t][r] + o[r]);
-        }
-    }
+    conv3_wgrad_fold_and_add(acc, gw, g, lane, i, kg, ci_ok, part);
+}
+
+static bool conv3_wgrad_mfma_shape(const Geom &g)
+{
+    return g.group == 1 && g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 1 && g.ph == 1 && g.pw == 1 && g.dd == 1 &&
+           g.dh == 1 && g.dw == 1 && g.C <= 16 && g.Cout <= 16 && (g.W & 3) == 0;
+}
+static bool conv3_wgrad_row_shape(const Geom &g) { return conv3_wgrad_mfma_shape(g) && g.W % 8 == 0 && (size_t)g.B * 16 * g.D * g.H * g.W * 4 < ((size_t)1 << 31); }
+static long conv3_wgrad_waves(const Geom &g, int &rpw)
+{
+    const long nrows = (long)g.B * g.D * g.H;
+    rpw = (int)cdivl(nrows, 2048);   // ~2 waves per SIMD over the chip
+    if (rpw < 8) rpw = 8;
+    return cdivl(nrows, rpw);
+}
+size_t conv_bwd_weight_part_floats(const Geom &g, size_t elem_bytes)
+{
+    if (elem_bytes != 4 || !conv3_wgrad_row_shape(g)) return 0;
+    int rpw;
+    const long nwg = cdivl(conv3_wgrad_waves(g, rpw), 4);
+    return nwg >= 8 ? (size_t)nwg * 27 * 256 : 0;   // (few workgroups: their atomics are cheap)
 }
 
 template <typename T>
-int launch_conv_bwd_weight(const T *x, const T *gout, float *gw32, const Geom &g, hipStream_t st)
+int launch_conv_bwd_weight(const T *x, const T *gout, float *gw32, const Geom &g, hipStream_t st, float *part)
 {
     if constexpr (sizeof(T) == 4) {
-        if (g.group == 1 && g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 1 && g.ph == 1 && g.pw == 1 && g.dd == 1 &&
-            g.dh == 1 && g.dw == 1 && g.C <= 16 && g.Cout <= 16 && (g.W & 3) == 0) {
-            const long nrows = (long)g.B * g.D * g.H;
-            int rpw = (int)cdivl(nrows, 2048);   // ~2 waves per SIMD over the chip
-            if (rpw < 8) rpw = 8;
-            const long waves = cdivl(nrows, rpw);
-            DLKA_LAUNCH(conv3_bwd_weight_mfma_kernel, dim3((unsigned)cdivl(waves, 4)), dim3(256), 0, st, reinterpret_cast<const float *>(x),
+        if (conv3_wgrad_mfma_shape(g)) {
+            int rpw;
+            const long waves = conv3_wgrad_waves(g, rpw);
+            const int nwg = (int)cdivl(waves, 4);
+            if (conv3_wgrad_row_shape(g)) {
+                if (part && conv_bwd_weight_part_floats(g, 4) == 0) part = nullptr;
+                DLKA_LAUNCH(conv3_bwd_weight_row_mfma_kernel, dim3((unsigned)nwg), dim3(256), 0, st, reinterpret_cast<const float *>(x),
+                            reinterpret_cast<const float *>(gout), gw32, g, rpw, part);
+                DLKA_CHECK_LAUNCH();
+                if (part) {
+                    DLKA_LAUNCH(conv3_wgrad_reduce_kernel, dim3(27, (unsigned)(nwg >= 256 ? 16 : 4)), dim3(256), 0, st, (const float *)part, gw32, nwg, g.C, g.Cout);
+                    DLKA_CHECK_LAUNCH();
+                }
+                return DLKA_OK;
+            }
+            DLKA_LAUNCH(conv3_bwd_weight_mfma_kernel, dim3((unsigned)nwg), dim3(256), 0, st, reinterpret_cast<const float *>(x),
                         reinterpret_cast<const float *>(gout), gw32, g, rpw);
             DLKA_CHECK_LAUNCH();
             return DLKA_OK;
@@ -595,7 +726,7 @@ int launch_conv_bwd_weight(const T *x, const T *gout, float *gw32, const Geom &g
 #define DLKA_INST(T)                                                                                        \
     template int launch_conv_fwd<T>(const T *, const T *, const T *, T *, float *, const Geom &, hipStream_t); \
     template int launch_conv_bwd_data<T>(const T *, const T *, T *, float *, const Geom &, hipStream_t);      \
-    template int launch_conv_bwd_weight<T>(const T *, const T *, float *, const Geom &, hipStream_t);
+    template int launch_conv_bwd_weight<T>(const T *, const T *, float *, const Geom &, hipStream_t, float *);
 DLKA_INST(float)
 DLKA_INST(bf16_t)
 #undef DLKA_INST

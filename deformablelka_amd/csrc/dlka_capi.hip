@@ -135,6 +135,7 @@ size_t conv_bwd_ws(const Geom &g, int dtype)
 {
     size_t n = align256((size_t)conv_bwd_wb_floats(g) * 4);
     if (dtype != DLKA_F32) n += align256((size_t)g.Cout * g.Cg * g.K * 4);
+    n += align256(conv_bwd_weight_part_floats(g, dtype == DLKA_F32 ? 4 : 2) * 4);
     return n;
 }
 
@@ -156,11 +157,13 @@ int conv_backward_t(const void *x, const void *w, const void *gout, void *gx, vo
     const size_t nw = (size_t)g.Cout * g.Cg * g.K;
     float *gw32 = nullptr;
     if (gw) gw32 = (dtype == DLKA_F32) ? (float *)gw : (float *)cv.take(nw * 4);
+    const size_t npart = conv_bwd_weight_part_floats(g, sizeof(T));
+    float *part = npart ? (float *)cv.take(npart * 4) : nullptr;
     if (!cv.ok() || !wb) return DLKA_ERR_WORKSPACE;
     if (gx) DLKA_TRY(launch_conv_bwd_data<T>((const T *)gout, (const T *)w, (T *)gx, wb, g, st));
     if (gw) {
         if (launch_zero(gw32, nw * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
-        DLKA_TRY(launch_conv_bwd_weight<T>((const T *)x, (const T *)gout, gw32, g, st));
+        DLKA_TRY(launch_conv_bwd_weight<T>((const T *)x, (const T *)gout, gw32, g, st, part));
         if (dtype != DLKA_F32) DLKA_TRY(launch_cast_from_f32<T>(gw32, (T *)gw, (long)nw, st));
     }
     if (gb) DLKA_TRY(launch_bias_grad<T>((const T *)gout, (T *)gb, g.B, g.Cout, g.No, st));

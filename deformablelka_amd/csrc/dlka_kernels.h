@@ -33,8 +33,11 @@ template <typename T>
 int launch_conv_fwd(const T *x, const T *w, const T *bias, T *out, float *wt, const Geom &g, hipStream_t st);
 template <typename T>
 int launch_conv_bwd_data(const T *gout, const T *w, T *gx, float *wb, const Geom &g, hipStream_t st);
+// `part` (conv_bwd_weight_part_floats(g, sizeof(T)) floats; may be null): per-workgroup tiles of the MFMA weight gradient, folded by a second launch
+// instead of one atomic per element and workgroup
+size_t conv_bwd_weight_part_floats(const Geom &g, size_t elem_bytes);
 template <typename T>
-int launch_conv_bwd_weight(const T *x, const T *gout, float *gw32, const Geom &g, hipStream_t st);
+int launch_conv_bwd_weight(const T *x, const T *gout, float *gw32, const Geom &g, hipStream_t st, float *part = nullptr);
 
 // ---- eltwise.hip -------------------------------------------------------------------------------------------
 int launch_zero(void *ptr, size_t bytes, hipStream_t st);

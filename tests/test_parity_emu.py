@@ -65,6 +65,7 @@ CONV = [
     (1, 12, 16, (4, 3, 128), 3, 1, 1, 1, 1),    # ... the full 128-wide row, ragged input channels
     (1, 16, 9, (2, 5, 8), 3, 1, 1, 1, 1),       # ... one lane group per row, ragged output channels
     (2, 8, 5, (1, 1, 16), 3, 1, 1, 1, 1),       # ... a single row per sample: every neighbour row is padding
+    (1, 9, 8, (16, 17, 8), 3, 1, 1, 1, 1),      # ... enough rows for the weight gradient's per-workgroup tiles + fold launch (conv3_wgrad_reduce_kernel)
 ]
 
 
