@@ -26,9 +26,21 @@ def initialize_network(input_channels: int = 1, num_classes: int = 14, crop_size
     return net
 
 
-def initialize_optimizer(net: nn.Module, initial_lr: float = 1e-2, weight_decay: float = 3e-5):
-    """:200-205: SGD, momentum 0.99, Nesterov; the reference drives the learning rate with nnU-Net's poly schedule."""
-    return torch.optim.SGD(net.parameters(), initial_lr, weight_decay=weight_decay, momentum=0.99, nesterov=True)
+def initialize_optimizer(net: nn.Module, initial_lr: float = 1e-2, weight_decay: float = 3e-5, fused=None):
+    """:200-205: SGD, momentum 0.99, Nesterov; the reference drives the learning rate with nnU-Net's poly schedule.
+    ``fused`` (default: on when every parameter is a floating-point GPU tensor) selects torch.optim.SGD's single-pass implementation — the same update,
+    weight decay, momentum, Nesterov step and parameter write in one kernel per tensor list instead of the four ``_foreach`` passes over the 42 M parameters
+    (0.9 ms of a 30 ms iteration)."""
+    params = list(net.parameters())
+    if fused is None:
+        fused = bool(params) and all(p.is_cuda and p.is_floating_point() for p in params)
+    kw = dict(weight_decay=weight_decay, momentum=0.99, nesterov=True)
+    if fused:
+        try:
+            return torch.optim.SGD(params, initial_lr, fused=True, **kw)
+        except (RuntimeError, TypeError, ValueError):   # a torch build without the fused implementation for this device
+            pass
+    return torch.optim.SGD(params, initial_lr, **kw)
 
 
 def wrap_data_parallel(net: nn.Module, device, find_unused_parameters: bool = False, bucket_cap_mb: int = 25) -> nn.Module:
