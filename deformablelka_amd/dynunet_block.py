@@ -30,16 +30,33 @@ def bn_eval_stats(bn: nn.BatchNorm3d):
     return torch.cat([bn.running_mean, torch.rsqrt(bn.running_var + bn.eps), bn.running_var]).float().contiguous()
 
 
-def bn_update_running(bn: nn.BatchNorm3d, stats):
-    """nn.BatchNorm training-mode bookkeeping from the kernel's {mean, rstd, unbiased var}."""
-    if not bn.track_running_stats or bn.running_mean is None:
-        return
-    C = bn.num_features
+def bn_update_running(*pairs):
+    """nn.BatchNorm training-mode bookkeeping from the kernel's {mean, rstd, unbiased var}: ``bn_update_running(bn, stats)`` or, for several layers at
+    once, ``bn_update_running((bn1, stats1), (bn2, stats2), ...)``.  All layers with a fixed momentum go through ONE ``_foreach_lerp_`` launch (running
+    <- running + m (batch - running)) and one ``_foreach_add_`` for the step counters: the two norms of a wrapper block cost 2 launches instead of 10 —
+    210 launches per trainer iteration of the full net otherwise, ~4 us each."""
+    if len(pairs) == 2 and isinstance(pairs[0], nn.Module):
+        pairs = (pairs,)
+    by_m, counters = {}, []
     with torch.no_grad():
-        bn.num_batches_tracked += 1
-        m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-        bn.running_mean.mul_(1 - m).add_(stats[:C], alpha=m)
-        bn.running_var.mul_(1 - m).add_(stats[2 * C:3 * C], alpha=m)
+        for bn, stats in pairs:
+            if not bn.track_running_stats or bn.running_mean is None:
+                continue
+            C = bn.num_features
+            if bn.momentum is None:   # cumulative average: the factor depends on the counter (a device value)
+                bn.num_batches_tracked += 1
+                m = 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - m).add_(stats[:C], alpha=m)
+                bn.running_var.mul_(1 - m).add_(stats[2 * C:3 * C], alpha=m)
+                continue
+            counters.append(bn.num_batches_tracked)
+            dst, src = by_m.setdefault(float(bn.momentum), ([], []))
+            dst += [bn.running_mean, bn.running_var]
+            src += [stats[:C], stats[2 * C:3 * C]]
+        if counters:
+            torch._foreach_add_(counters, 1)
+        for m, (dst, src) in by_m.items():
+            torch._foreach_lerp_(dst, src, m)
 
 
 class _UnetResBlockFn(Function):
@@ -102,6 +119,5 @@ class UnetResBlock(nn.Module):
         out = _UnetResBlockFn.apply(inp, training, st1, st2, (self.norm1.eps, self.norm2.eps), self.conv1.conv.weight, self.norm1.weight,
                                     self.norm1.bias, self.conv2.conv.weight, self.norm2.weight, self.norm2.bias)
         if training:
-            bn_update_running(self.norm1, st1)
-            bn_update_running(self.norm2, st2)
+            bn_update_running((self.norm1, st1), (self.norm2, st2))
         return out

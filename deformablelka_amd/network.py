@@ -187,9 +187,12 @@ class BatchNorm3d(nn.BatchNorm3d):
         if self.track_running_stats and self.running_mean is not None:
             with torch.no_grad():
                 self.num_batches_tracked += 1
-                m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
-                self.running_mean.mul_(1.0 - m).add_(stats[0], alpha=m)
-                self.running_var.mul_(1.0 - m).add_(stats[2], alpha=m)
+                if self.momentum is not None:
+                    torch._foreach_lerp_([self.running_mean, self.running_var], [stats[0], stats[2]], float(self.momentum))
+                else:
+                    m = 1.0 / float(self.num_batches_tracked)
+                    self.running_mean.mul_(1.0 - m).add_(stats[0], alpha=m)
+                    self.running_var.mul_(1.0 - m).add_(stats[2], alpha=m)
         return y
 
 

@@ -221,8 +221,7 @@ class TransformerBlock_3D_single_deform_LKA(nn.Module):
         y = _TBlock3dFn.apply(xin, planar, (H, W, D), mask, training, stats, (self.norm.eps, c.norm1.eps), v, *self.wrapper_params(),
                               *self.epa_block.block_params())
         if training:
-            bn_update_running(c.norm1, stats[:3 * C])
-            bn_update_running(c.norm2, stats[3 * C:])
+            bn_update_running((c.norm1, stats[:3 * C]), (c.norm2, stats[3 * C:]))
         y = y.view(B, H, W, D, C).permute(0, 4, 1, 2, 3)
         keep = self.keep_channels_last if keep_channels_last is None else keep_channels_last
         return y if keep else y.contiguous()

@@ -200,3 +200,26 @@ def test_ddp_trainer_hook_two_ranks_equals_one_process_on_both_shards(tmp_path, 
     training.run_iteration(net, opt, torch.cat(xs), torch.cat(ts), loss_fn=lambda o, t: ((o - t) ** 2).mean(), clip_norm=1e9, forward=lambda t: net(t, 4, 5))
     for k, v in net.state_dict().items():
         assert torch.allclose(got["params"][k], v, rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.parametrize("momentum", [0.1, 0.3, None])
+def test_bn_running_statistics_bookkeeping_equals_torchs(momentum):
+    """dynunet_block.bn_update_running (the wrapper block's two norms in one foreach launch) against nn.BatchNorm3d's own training-mode bookkeeping
+    (running mean / unbiased variance / step counter), single and grouped call forms, over three steps."""
+    import torch.nn as nn
+    from deformablelka_amd.dynunet_block import bn_update_running
+    torch.manual_seed(0)
+    mine = [nn.BatchNorm3d(6, momentum=momentum) for _ in range(3)]
+    ref = [nn.BatchNorm3d(6, momentum=momentum).train() for _ in range(3)]
+    for step in range(3):
+        xs = [torch.randn(3, 6, 2, 3, 4) * (1 + k) + step for k in range(3)]
+        stats = []
+        for k, x in enumerate(xs):
+            ref[k](x)
+            stats.append(torch.cat([x.mean((0, 2, 3, 4)), torch.zeros(6), x.var((0, 2, 3, 4), unbiased=True)]))
+        bn_update_running(mine[0], stats[0])
+        bn_update_running((mine[1], stats[1]), (mine[2], stats[2]))
+    for a, b in zip(mine, ref):
+        assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 3
+        assert torch.allclose(a.running_mean, b.running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(a.running_var, b.running_var, rtol=1e-5, atol=1e-6)
