@@ -25,6 +25,10 @@ for f in ("bench_f32","bench_bf16","bench_extras"):
           "fullnet:", (d.get("fullnet") or {}).get("value"), "lka2d:", (d.get("lka2d") or {}).get("value"), "inf:", (d.get("inference") or {}).get("value"))
 PY
 fi
+if [ "${SKIP_PROFILES:-0}" = 1 ]; then   # (block-stack kernels unchanged since the last profile set: only the full net's table)
+  bash $R/scripts/gpu_netprof.sh $TAG/netprof | tail -3
+  exit 0
+fi
 cd /tmp
 echo "== rocprof of the bench command (as timed: the weight gradients of a block overlap the next block's data chain on a second stream — concurrent kernels stretch each other)"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bench -o t -- python $R/bench.py --no-cpu-baseline --no-tblock --no-companion > $R/$OUT/prof_bench.log 2>&1
