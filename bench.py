@@ -377,7 +377,7 @@ def tblock_metric(batch, steps, warmup, dev):
 
 def fullnet_metric(batch, steps, dev, bf16=False):
     """Third metric (SURVEY §8d iii / §8f-2): the WHOLE D_LKA_Former (42.35 M parameters; its 21 D-LKA transformer blocks on this repo's kernels,
-    the conv / norm plumbing around them as GEMM re-expressions, HIP 3^3 convs and torch norms), one trainer iteration per step — forward, deep-supervision loss, backward,
+    the conv / norm plumbing around them as GEMM re-expressions, HIP 3^3 convs and planar HIP norms), one trainer iteration per step — forward, deep-supervision loss, backward,
     clip_grad_norm_(12), SGD(momentum 0.99, nesterov) — on a synthetic 64x128x128 patch batch (d_lka_former_trainer_synapse.py:259-309)."""
     from deformablelka_amd import training
     from deformablelka_amd.stack import _offset_std_for
@@ -422,7 +422,8 @@ def fullnet_metric(batch, steps, dev, bf16=False):
             "hipgraph": graphed,
             "ms_per_step": round(dt * 1e3, 2), "params": sum(p.numel() for p in net.parameters()), "loss": round(float(loss), 4),
             "path": "nn.Module + autograd, eager; D-LKA blocks = HIP kernels; plumbing: stride == kernel convs = patchify / depth-to-space GEMMs (rocBLAS), 3^3 and 1x1x1 convs "
-                    "and Instance / BatchNorm3d = HIP kernels (weight gradients on the matrix cores), GroupNorm / loss / optimizer = torch" +
+                    "and Instance / Batch / long-row GroupNorm = HIP kernels (the full-resolution 3^3 convs on the matrix cores in all three directions), loss and "
+                    "optimizer (single-pass SGD) = torch" +
                     ("; torch.autocast(bf16) around forward + loss: torch layers only — the transformer blocks and the conv re-expressions stay on their fp32 paths" if bf16 else "")}
 
 

@@ -374,6 +374,31 @@ def test_lka3d_tokens_pointwise_pair_equals_two_launches(dims, dtype):
 
 
 # ---- planar (NCDHW) plumbing of the full net (csrc/planar_ops.hip) against torch's own CPU ops --------------------------------------
+@pytest.mark.parametrize("groups,shape", [(1, (2, 6, 3, 4, 5)), (3, (2, 6, 2, 3, 8)), (4, (1, 4, 2, 2, 2))])
+def test_groupnorm_on_the_planar_statistics_kernels(groups, shape):
+    """network.GroupNorm.planar_forward (the stem's one-group norm of the full net: rows of (C / G) x voxels through dlka_batchnorm_planar_* with B x G
+    single-row channels, then the per-channel affine) against nn.GroupNorm with the same parameters (model_components.py:27-34): output and all gradients."""
+    import torch.nn as nn
+    from deformablelka_amd.network import GroupNorm
+    torch.manual_seed(0)
+    C = shape[1]
+    a, b = GroupNorm(groups, C), nn.GroupNorm(groups, C)
+    with torch.no_grad():
+        a.weight.copy_(torch.randn(C) * 0.3 + 1.0); a.bias.copy_(torch.randn(C) * 0.2)
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(*shape) * 1.7 + 0.4
+    x[:, 0] += 30.0
+    gy = torch.randn(*shape)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = a.planar_forward(xa), b(xb)
+    ya.backward(gy); yb.backward(gy)
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-3, atol=1e-5)
+    assert torch.allclose(a.weight.grad, b.weight.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(a.bias.grad, b.bias.grad, rtol=1e-4, atol=1e-4)
+    assert torch.equal(a(x), b(x))             # short rows / CPU tensors: the stock layer
+
+
 @pytest.mark.parametrize("shape,affine", [((2, 16, 3, 8, 12), True), ((3, 5, 2, 3, 7), True), ((1, 4, 4, 4, 8), False)])
 def test_batchnorm_planar_training_mode(shape, affine):
     """dlka_batchnorm_planar_*: batch statistics (with |mean| >> std in one channel), normalisation, all three gradients, the unbiased variance
