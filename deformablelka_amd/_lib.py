@@ -92,6 +92,7 @@ SIGNATURES = {
     "dlka_lka2d_attention_backward": (c_int, [c_void_p, POINTER(Lka2dPtrs), c_void_p, c_void_p, c_size_t, c_void_p,
                                               POINTER(Lka2dPtrs), c_void_p, c_size_t] + [c_int] * 5 + [c_void_p]),
     "dlka_lka2d_force_general": (c_int, [c_int]),
+    "dlka_lka2d_saved_offsets": (c_int, [c_int] * 5 + [POINTER(c_size_t), POINTER(c_int)]),
     "dlka_conv3d_cl_workspace": (c_size_t, [_G, c_int, c_int]),
     "dlka_conv3d_forward_cl": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_size_t, _G, c_int, c_void_p]),
     "dlka_conv3d_backward_cl": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 4 + [c_size_t, _G, c_int, c_void_p]),

@@ -776,6 +776,22 @@ int dlka_lka2d_attention_forward(const void *x, const dlka_lka2d_params *p, void
                          lka2d_forward_t<bf16_t>(x, p, y, saved, saved_bytes, workspace, workspace_bytes, B, C, H, W, st));
 }
 
+int dlka_lka2d_saved_offsets(int B, int C, int H, int W, int dtype, size_t byte_offsets[2], int *elem_bytes)
+{
+    if (!byte_offsets || !elem_bytes) return DLKA_ERR_NULL;
+    DLKA_TRY(check_block(B, C, 1, H, W));
+    if (lka2d_cl_supported(B, C, H, W, dtype) && !lka2d_general())
+        return lka2d_cl_saved_offsets(B, C, H, W, dtype, byte_offsets, elem_bytes);
+    if (dtype == DLKA_BF16) return DLKA_ERR_UNSUPPORTED;
+    // lka2d_forward_t: h, a, o5, t1, o7, ...
+    Lka2dGeoms G(B, C, H, W);
+    const size_t e = esz(dtype);
+    byte_offsets[0] = 2 * align256(G.E * e);
+    byte_offsets[1] = 3 * align256(G.E * e) + align256(G.Off5 * e);
+    *elem_bytes = (int)e;
+    return DLKA_OK;
+}
+
 int dlka_lka2d_attention_backward(const void *x, const dlka_lka2d_params *p, const void *grad_y, const void *saved, size_t saved_bytes,
                                   void *grad_x, const dlka_lka2d_grads *grads, void *workspace, size_t workspace_bytes,
                                   int B, int C, int H, int W, int dtype, void *stream)

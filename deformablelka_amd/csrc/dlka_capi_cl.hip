@@ -621,6 +621,16 @@ size_t lka2d_cl_saved_bytes(int B, int C, int H, int W, int dtype)
 
 // (the nine gradient buffers keep their fp32 size on the bf16 path: the two grad_input accumulators ARE fp32, two more serve as the forward
 //  pass's fp32 chain tensors and as landing zones of tap-split sums)
+// (diagnostics) the offset tensors inside `saved`: lka2d_cl_forward carves xt, h, a, t1, t2, g1, m, spare, then o5, o7 (fp32 on both paths)
+int lka2d_cl_saved_offsets(int B, int C, int H, int W, int dtype, size_t byte_offsets[2], int *elem_bytes)
+{
+    Lka2dCl G(B, C, H, W, dtype);
+    byte_offsets[0] = 8 * align256(G.E * G.SB);
+    byte_offsets[1] = byte_offsets[0] + align256(G.O5 * 4);
+    *elem_bytes = 4;
+    return DLKA_OK;
+}
+
 size_t lka2d_cl_workspace_bytes(int B, int C, int H, int W, int dtype)
 {
     Lka2dCl G(B, C, H, W, dtype);

@@ -93,6 +93,7 @@ int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st);
 // the 2-D D-LKA block on the channels-last kernels (dlka_capi_cl.hip); NCHW in / out, transposed inside
 int lka2d_cl_supported(int B, int C, int H, int W, int dtype);
 size_t lka2d_cl_saved_bytes(int B, int C, int H, int W, int dtype);
+int lka2d_cl_saved_offsets(int B, int C, int H, int W, int dtype, size_t byte_offsets[2], int *elem_bytes);
 size_t lka2d_cl_workspace_bytes(int B, int C, int H, int W, int dtype);
 int lka2d_cl_forward(const void *x, const dlka_lka2d_params *p, void *y, void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes, int B,
                      int C, int H, int W, int dtype, hipStream_t st);

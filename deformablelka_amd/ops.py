@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C-ABI.  PyTorch is used for device memory and streams only."""
 from __future__ import annotations
 
+import ctypes
 from ctypes import byref
 from typing import Optional, Sequence, Tuple
 
@@ -432,6 +433,23 @@ def lka2d_attention_forward(x, params: Sequence[torch.Tensor]):
                                           L.stream_ptr(x))
     L.check(rc, "lka2d_attention_forward")
     return y, saved
+
+
+def lka2d_saved_offsets(saved, x):
+    """The two predicted offset tensors ([B, 50, H, W] of conv0, [B, 98, H, W] of conv_spatial; torchvision's planar layout) inside the opaque
+    ``saved`` buffer of ``lka2d_attention_forward(x, ...)`` — for the path such a call takes now (``dlka_lka2d_saved_offsets``).  Diagnostics:
+    the parity tests' cell-flip analysis reads them."""
+    B, C, H, W = (int(v) for v in x.shape)
+    lib = L.get_lib()
+    offs = (ctypes.c_size_t * 2)()
+    eb = ctypes.c_int(0)
+    L.check(lib.dlka_lka2d_saved_offsets(B, C, H, W, L.dtype_code(x), offs, byref(eb)), "lka2d_saved_offsets")
+    dt = torch.float32 if eb.value == 4 else torch.bfloat16
+    out = []
+    for o, ch in zip(offs, (50, 98)):
+        n = B * ch * H * W * eb.value
+        out.append(saved[int(o):int(o) + n].view(dt).view(B, ch, H, W))
+    return out
 
 
 def lka2d_attention_backward(x, params, grad_y, saved):

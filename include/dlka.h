@@ -235,6 +235,11 @@ int dlka_lka2d_attention_forward(const void *x, const dlka_lka2d_params *p, void
  * value: 1 iff the environment variable DLKA_LKA2D_GENERAL is set when the first 2-D block call is made.  For A/B runs and the parity test of
  * one path against the other; the size queries return the maximum over both paths, so a switch never under-sizes a buffer. */
 int dlka_lka2d_force_general(int on);
+/* Diagnostics (bench health check, the parity tests' cell-flip analysis): where inside the opaque `saved` buffer of a forward call the two
+ * predicted offset tensors live — conv0's [B][50][H][W] and conv_spatial's [B][98][H][W], planar as torchvision lays them out — for the path a
+ * call with these arguments takes NOW (fast / general, see dlka_lka2d_force_general).  byte_offsets[0..1]: byte offsets from `saved`;
+ * *elem_bytes: 4 (fp32; always on the channels-last path) or 2 (general path with bf16 tensors). */
+int dlka_lka2d_saved_offsets(int B, int C, int H, int W, int dtype, size_t byte_offsets[2], int *elem_bytes);
 int dlka_lka2d_attention_backward(const void *x, const dlka_lka2d_params *p, const void *grad_y,
                                   const void *saved, size_t saved_bytes,
                                   void *grad_x, const dlka_lka2d_grads *grads,

@@ -94,27 +94,34 @@ def transformer_block_3d(x, P, training=False, drop_mask=None, offsets_override=
     return skip + F.conv3d(a, P["conv8.1.weight"], P["conv8.1.bias"])            # :628
 
 
-def deform_conv_2d_pack(x, P, prefix, k, pad, dil, groups, sample_store=None):
+def deform_conv_2d_pack(x, P, prefix, k, pad, dil, groups, sample_store=None, offset_override=None, offsets_out=None):
     """2-D ``DeformConv.forward`` — 2D/deformable_LKA/deformable_LKA.py:27-30.  sample_store: rounding applied to the tensor the deformable conv
-    SAMPLES (the offset net always reads x as it is)."""
+    SAMPLES (the offset net always reads x as it is).  offset_override / offsets_out: as in ``lka3d_attention_volume``."""
     off = F.conv2d(x, P[prefix + "offset_net.weight"], P[prefix + "offset_net.bias"], padding=pad, dilation=dil)
+    if offset_override is not None:   # another implementation's offset VALUES, gradient path unchanged (straight through)
+        off = off + (offset_override - off).detach()
+    if offsets_out is not None:
+        offsets_out.append(off.detach().clone())
     xs = x if sample_store is None else sample_store(x)
     return oracle.DeformConv2dFunction.apply(xs, off, P[prefix + "deform_conv.weight"], None, 1, pad, dil)
 
 
-def lka2d_attention(x, P, store=None):
+def lka2d_attention(x, P, store=None, offsets_override=None, offsets_out=None):
     """deformable_LKA_Attention.forward — deformable_LKA.py:133-140 with deformable_LKA.forward :98-104.
     store: None = the reference's fp32 block; ``bf16_storage`` = the model of the DLKA_BF16 2-D path: every activation that path writes to HBM as
     bf16 is rounded where it is written; the chain that decides the sampling cells (a -> offset net 5 -> t1 = DDW5(a) -> offset net 7) stays fp32
-    there (dlka_capi_cl.hip, Lka2dCl) and is not rounded here either."""
+    there (dlka_capi_cl.hip, Lka2dCl) and is not rounded here either.
+    offsets_override: (conv0's offsets, conv_spatial's offsets) VALUES from another implementation's forward pass (straight through, see
+    ``lka3d_attention_volume``); offsets_out: list that receives the two offset tensors this run samples with."""
     st = store if store is not None else (lambda t: t)
+    ov = offsets_override if offsets_override is not None else (None, None)
     C = x.shape[1]
     shortcut = x.clone()
     a = F.gelu(F.conv2d(x, P["proj_1.weight"], P["proj_1.bias"]))
     u = st(a)
     s = "spatial_gating_unit."
-    attn = deform_conv_2d_pack(a, P, s + "conv0.", 5, 2, 1, C)                   # :93   fp32 in, fp32 out (t1_32)
-    attn = st(deform_conv_2d_pack(attn, P, s + "conv_spatial.", 7, 9, 3, C))     # :94   samples the fp32 t1, t2 stored as bf16
+    attn = deform_conv_2d_pack(a, P, s + "conv0.", 5, 2, 1, C, offset_override=ov[0], offsets_out=offsets_out)   # :93   fp32 in, fp32 out (t1_32)
+    attn = st(deform_conv_2d_pack(attn, P, s + "conv_spatial.", 7, 9, 3, C, offset_override=ov[1], offsets_out=offsets_out))   # :94   samples the fp32 t1, t2 stored as bf16
     attn = F.conv2d(attn, P[s + "conv1.weight"], P[s + "conv1.bias"])
     y = F.conv2d(st(u * attn), P["proj_2.weight"], P["proj_2.bias"])
     return st(y + shortcut)

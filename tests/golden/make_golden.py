@@ -193,6 +193,15 @@ def main():
     gold["DeformConvPack_Depth"] = _run(m, [torch.randn(1, 4, 5, 5, 6)], 15)
     gold["DeformConvPack_Depth"]["ctor"] = dict(in_channels=4, out_channels=4, kernel_size=(3, 3, 3), stride=1, padding=1)
 
+    # (5b) DeformConvPack_experimental (3D/dcn/modules/deform_conv.py:103-139): 1x1x1 channel_adjust C -> 3K, then a DEPTHWISE conv_offset on 3K channels
+    torch.manual_seed(55)
+    m = dcn_mod.DeformConvPack_experimental(4, 6, kernel_size=(3, 3, 3), stride=1, padding=1)
+    with torch.no_grad():
+        m.conv_offset.weight.normal_(0, 0.15)
+        m.conv_offset.bias.normal_(0, 0.05)
+    gold["DeformConvPack_experimental"] = _run(m, [torch.randn(2, 4, 5, 6, 4)], 155)
+    gold["DeformConvPack_experimental"]["ctor"] = dict(in_channels=4, out_channels=6, kernel_size=(3, 3, 3), stride=1, padding=1)
+
     # (6) LKA3d_deform and the full LKA_Attention3d_deform on tokens (transformerblock.py:634-673)
     torch.manual_seed(6)
     m = tb.LKA3d_deform(4)

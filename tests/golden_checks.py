@@ -29,6 +29,8 @@ def gold_nets():
 def build(name, case):
     if name.startswith("DeformConvPack_d_"):
         return dk.DeformConvPack_d(**case["ctor"])
+    if name == "DeformConvPack_experimental":
+        return dk.DeformConvPack_experimental(**case["ctor"])
     if name == "DeformConvPack_Depth":
         return dk.DeformConvPack_Depth(**case["ctor"])
     if name.startswith("DeformConvPack_"):

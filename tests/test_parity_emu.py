@@ -86,7 +86,7 @@ def test_gelu():
 
 
 GOLDEN = ["DeformConvPack_k3", "DeformConvPack_k5_dw_zero", "DeformConv_g2_dg2_nobias", "DeformConvPack_d_TW",
-          "DeformConvPack_d_HW", "DeformConvPack_d_H", "DeformConvPack_Depth", "LKA3d_deform", "LKA_Attention3d_deform",
+          "DeformConvPack_d_HW", "DeformConvPack_d_H", "DeformConvPack_Depth", "DeformConvPack_experimental", "LKA3d_deform", "LKA_Attention3d_deform",
           "DeformConv2d_k5_dw", "deformable_LKA_Attention", "TransformerBlock_3D_single_deform_LKA_train",
           "TransformerBlock_3D_single_deform_LKA_eval", "UnetResBlock_train"]
 
@@ -243,6 +243,18 @@ def test_lka3d_tokens_bf16(C, dims, autocast):
 def test_lka2d_attention_channels_last_fast_path(C, H, W):
     """2-D D-LKA block on the channels-last kernels (cl_ddw2d.hip + MFMA offset nets) vs the oracle block."""
     parity.check_lka2d_attention("cpu", 2, C, H, W, report=True)
+
+
+@pytest.mark.parametrize("B,C,dims", [(2, 32, (4, 5, 6)), (1, 8, (4, 5, 6))])
+def test_lka3d_block_volume_entry_point(B, C, dims):
+    """``forward_volume`` = the NCDHW entry point dlka_lka3d_attention_forward / _backward (general per-op kernels) at the contract's tolerances,
+    flips counted + same-cells rerun (what tests/test_parity_gpu.py::test_lka3d_block_vs_oracle runs at the real widths)."""
+    parity.check_lka3d_tokens("cpu", B, C, dims, volume=True)
+
+
+def test_lka2d_attention_general_path_contract_tolerances():
+    """A width outside the channels-last menu (C % 32 != 0): the general NCHW kernels, offsets read back through dlka_lka2d_saved_offsets."""
+    parity.check_lka2d_attention("cpu", 2, 12, 7, 9, report=True)
 
 
 @pytest.mark.parametrize("C,dims", [(32, (3, 5, 6)), (128, (2, 4, 3)), (256, (2, 3, 3))])

@@ -79,7 +79,7 @@ def test_conv3d_vs_aten_cpu(case):
 
 
 GOLDEN = ["DeformConvPack_k3", "DeformConvPack_k5_dw_zero", "DeformConv_g2_dg2_nobias", "DeformConvPack_d_TW",
-          "DeformConvPack_d_HW", "DeformConvPack_d_H", "DeformConvPack_Depth", "LKA3d_deform", "LKA_Attention3d_deform",
+          "DeformConvPack_d_HW", "DeformConvPack_d_H", "DeformConvPack_Depth", "DeformConvPack_experimental", "LKA3d_deform", "LKA_Attention3d_deform",
           "DeformConv2d_k5_dw", "deformable_LKA_Attention", "TransformerBlock_3D_single_deform_LKA_train",
           "TransformerBlock_3D_single_deform_LKA_eval", "UnetResBlock_train"]
 
@@ -92,30 +92,10 @@ def test_reference_module_golden(name):
 
 @pytest.mark.parametrize("C,dims", [(32, (16, 16, 16)), (64, (8, 8, 8)), (256, (4, 4, 4))])
 def test_lka3d_block_vs_oracle(C, dims):
-    """Whole fused block (one C-ABI call per direction) vs the oracle block on a real stage channel count."""
-    import deformablelka_amd as dk
-    from oracle import blocks
-    torch.manual_seed(0)
-    B = 2
-    m = dk.LKA_Attention3d_deform(C)
-    blocks.randomize_offsets_(m, std=0.02)
-    H, W, D = dims
-    x = torch.randn(B, C, H, W, D)
-    gy = torch.randn(B, C, H, W, D)
-    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
-    xr = x.clone().requires_grad_(True)
-    yr = blocks.lka3d_attention_volume(xr, P)
-    yr.backward(gy)
-    m = m.to(DEV)
-    xd = x.to(DEV).requires_grad_(True)
-    y = m.forward_volume(xd)
-    y.backward(gy.to(DEV))
-    parity.assert_close("block y", y, yr.detach(), atol=2e-4)
-    parity.assert_close("block gx", xd.grad, xr.grad, rtol=2e-3)
-    for k, p in m.named_parameters():
-        g = P[k].grad
-        if g is not None and g.abs().max() > 0:
-            parity.assert_close("block grad " + k, p.grad, g, rtol=2e-3)
+    """Whole fused block on the NCDHW entry point (``forward_volume``: one C-ABI call per direction, general per-op kernels) vs the oracle block
+    on a real stage channel count — at the CONTRACT's tolerances (forward 1e-4 abs, gradients 1e-3 rel), with the cell-flip residual counted and
+    the same-cells rerun, exactly as the token-layout test does (parity.check_lka3d_tokens)."""
+    parity.check_lka3d_tokens(DEV, 2, C, dims, volume=True, report_offsets=True)
 
 
 def test_full_size_stage0_properties():
@@ -251,6 +231,11 @@ def test_lka2d_attention_real_shapes_vs_oracle(C, hw):
     """The three decoder shapes of the 224^2 2-D net (B = 2 here, 24 in training): the channels-last 2-D block — MFMA offset nets,
     gather-layout depthwise deformable convs (cl_ddw2d.hip) — forward and every gradient against the oracle block."""
     parity.check_lka2d_attention(DEV, 2, C, hw, hw, report=True)
+
+
+def test_lka2d_attention_config2_batch24_vs_oracle():
+    """BASELINE.json config 2's own batch (B = 24) at the widest-image decoder shape (96, 56^2): contract tolerances, flips counted, same-cells rerun."""
+    parity.check_lka2d_attention(DEV, 24, 96, 56, 56, report=True)
 
 
 @pytest.mark.parametrize("C,hw", [(384, 14), (192, 28), (96, 56)])
