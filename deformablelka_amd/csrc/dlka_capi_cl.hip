@@ -1595,6 +1595,27 @@ size_t dlka_tblock3d_saved_bytes_v(int B, int C, int D, int H, int W, int dtype,
            align256(dlka_lka3d_tokens_saved_bytes_v(B, C, D, H, W, dtype, variant));
 }
 
+int dlka_lka3d_tokens_saved_offsets_v(int B, int C, int D, int H, int W, int dtype, int variant, size_t *byte_offset)
+{
+    if (!byte_offset) return DLKA_ERR_NULL;
+    if (!dlka_lka3d_tokens_supported_v(B, C, D, H, W, dtype, variant)) return DLKA_ERR_UNSUPPORTED;
+    TokGeoms G(B, C, D, H, W, dtype, variant);
+    *byte_offset = 4 * align256(G.E * G.SB);   // tokens_forward_impl carves h, a, t1, t, then the offsets
+    return DLKA_OK;
+}
+
+int dlka_tblock3d_saved_offsets_v(int B, int C, int D, int H, int W, int dtype, int variant, size_t *byte_offset)
+{
+    if (!byte_offset) return DLKA_ERR_NULL;
+    if (!dlka_tblock3d_supported_v(B, C, D, H, W, dtype, variant)) return DLKA_ERR_UNSUPPORTED;
+    TBlockGeoms G(B, C, D, H, W);
+    size_t inner = 0;
+    DLKA_TRY(dlka_lka3d_tokens_saved_offsets_v(B, C, D, H, W, DLKA_F32, variant, &inner));
+    // carve_tblock_saved: eight activation tensors, the LayerNorm statistics, six prepared weight forms, then the D-LKA block's own `saved`
+    *byte_offset = 8 * align256(G.E * 4) + align256(G.M * 2 * 4) + 4 * align256(dense_wp_floats(G.c3) * 4) + 2 * align256(dense_wp_floats(G.pw) * 4) + inner;
+    return DLKA_OK;
+}
+
 size_t dlka_tblock3d_workspace_bytes(int B, int C, int D, int H, int W, int dtype) { return dlka_tblock3d_workspace_bytes_v(B, C, D, H, W, dtype, DLKA_LKA3D_SYNAPSE); }
 size_t dlka_tblock3d_workspace_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant)
 {

@@ -601,16 +601,28 @@ def lka3d_attention_tokens_forward(x, params, dims, variant=0):
     return y, saved
 
 
-def lka3d_tokens_saved_offsets(saved, B, C, dims, act_dtype=torch.float32):
+def lka3d_tokens_saved_offsets(saved, B, C, dims, act_dtype=torch.float32, variant=0):
     """The predicted sampling offsets [B, 81, D, H, W] (fp32, the reference's planar layout) inside the opaque ``saved`` buffer of a token-layout
-    forward call (include/dlka.h: h, a, t1, t — one activation-sized tensor each, 256-byte aligned — then the offsets).  Diagnostics: bench.py's
-    health check and the cell-flip analysis of the parity tests read them."""
+    forward call (``dlka_lka3d_tokens_saved_offsets_v``; the NCDHW entry point's fp32 ``saved`` starts with the same four tensors).  Diagnostics:
+    bench.py's health check and the cell-flip analysis of the parity tests read them."""
     D, H, W = (int(v) for v in dims)
-    n = D * H * W
-    sb = 4 if act_dtype == torch.float32 else 2
-    a256 = lambda v: (v + 255) & ~255
-    o = 4 * a256(B * C * n * sb)
-    return saved[o:o + B * 81 * n * 4].view(torch.float32).view(B, 81, D, H, W)
+    off = ctypes.c_size_t(0)
+    dt = L.DLKA_F32 if act_dtype == torch.float32 else L.DLKA_BF16
+    lib = L.get_lib()
+    if lib.dlka_lka3d_tokens_saved_offsets_v(B, C, D, H, W, dt, int(variant), byref(off)) != 0:   # widths outside the token path (general NCDHW entry)
+        sb = 4 if act_dtype == torch.float32 else 2
+        off = ctypes.c_size_t(4 * ((B * C * D * H * W * sb + 255) & ~255))
+    o = int(off.value)
+    return saved[o:o + B * 81 * D * H * W * 4].view(torch.float32).view(B, 81, D, H, W)
+
+
+def tblock3d_saved_offsets(saved, B, C, dims, variant=0):
+    """The same tensor inside the ``saved`` buffer of a wrapper-block forward call (``tblock3d_forward``)."""
+    D, H, W = (int(v) for v in dims)
+    off = ctypes.c_size_t(0)
+    L.check(L.get_lib().dlka_tblock3d_saved_offsets_v(B, C, D, H, W, L.DLKA_F32, int(variant), byref(off)), "tblock3d_saved_offsets")
+    o = int(off.value)
+    return saved[o:o + B * 81 * D * H * W * 4].view(torch.float32).view(B, 81, D, H, W)
 
 
 def lka3d_attention_tokens_backward(x, params, grad_y, saved, dims, variant=0):

@@ -478,6 +478,11 @@ int dlka_lka3d_attention_tokens_backward_v(const void *x, const dlka_lka3d_param
                                            int B, int C, int D, int H, int W, int dtype, int variant, void *stream);
 int    dlka_tblock3d_supported_v(int B, int C, int D, int H, int W, int dtype, int variant);
 size_t dlka_tblock3d_saved_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
+/* Diagnostics (bench health check, the parity tests' cell-flip analysis): byte offset, inside the opaque `saved` buffer of a token-layout
+ * forward call / of a wrapper-block forward call, of the predicted sampling offsets [B][81][D][H][W] (fp32 on both dtypes, the reference's planar
+ * layout, deform_im2col_cuda.cuh:237-243). */
+int dlka_lka3d_tokens_saved_offsets_v(int B, int C, int D, int H, int W, int dtype, int variant, size_t *byte_offset);
+int dlka_tblock3d_saved_offsets_v(int B, int C, int D, int H, int W, int dtype, int variant, size_t *byte_offset);
 size_t dlka_tblock3d_workspace_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
 int dlka_tblock3d_forward_v(const void *x, int x_planar, const dlka_tblock3d_params *p, const dlka_lka3d_params *lka,
                             const void *drop_mask, int training, void *bn_stats, void *y, void *saved, size_t saved_bytes,

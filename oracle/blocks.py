@@ -77,7 +77,7 @@ def unet_res_block(x, P, prefix, training, stats_out=None):
     return F.leaky_relu(out + x, 0.01)                                           # :77-79
 
 
-def transformer_block_3d(x, P, training=False, drop_mask=None, offsets_override=None):
+def transformer_block_3d(x, P, training=False, drop_mask=None, offsets_override=None, offsets_out=None):
     """TransformerBlock_3D_single_deform_LKA.forward — transformerblock.py:617-630.  drop_mask: the (B, C) multipliers of
     conv8[0] = Dropout3d(0.1) (None = eval / no dropout)."""
     B, C, H, W, D = x.shape
@@ -86,7 +86,7 @@ def transformer_block_3d(x, P, training=False, drop_mask=None, offsets_override=
         t = t + P["pos_embed"]                                                   # :622-623
     n = F.layer_norm(t, (C,), P["norm.weight"], P["norm.bias"], 1e-5)
     lka = {k[len("epa_block."):]: v for k, v in P.items() if k.startswith("epa_block.")}
-    attn = t + P["gamma"] * lka3d_attention_tokens(n, lka, B, C, H, W, D, offsets_override=offsets_override)        # :624
+    attn = t + P["gamma"] * lka3d_attention_tokens(n, lka, B, C, H, W, D, offsets_override=offsets_override, offsets_out=offsets_out)        # :624
     skip = attn.reshape(B, H, W, D, C).permute(0, 4, 1, 2, 3)                    # :626
     a = unet_res_block(skip, P, "conv51.", training)                             # :627
     if drop_mask is not None:

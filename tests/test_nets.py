@@ -60,6 +60,27 @@ def emu_backend():
     _lib._set_backend_for_tests(None)
 
 
+def test_assembled_net_with_real_dlka_blocks_vs_oracle_assembled_net(emu_backend):
+    """D_LKA_Former(trans_block=TransformerBlock_3D_single_deform_LKA) — the 21 real D-LKA blocks, kernel sources on the emulator — against the
+    oracle-assembled net (tests/netoracle.py: same assembly, every block = oracle.blocks.transformer_block_3d) on the smallest image the Synapse stem
+    admits (16x32x32 -> stages 8^3 / 4^3 / 2^3 / 1^3): logits of all three heads, argmax of the full-resolution head, the deep-supervision loss and
+    EVERY parameter gradient (d_lka_former_synapse.py:144-167, model_components.py:52-66).  Evaluation-mode normalisation: at this size the
+    deepest stage holds ONE voxel per sample, and batch statistics over two values are not a well-conditioned comparison (train mode runs at
+    32x64x64 on the GPU, tests/test_nets_gpu.py)."""
+    from tests import netoracle
+    res = netoracle.run_pair("cpu", (16, 32, 32), B=1, training=False)
+    s = netoracle.summarize(res)
+    print({k: v for k, v in s.items() if not k.endswith("grad_errs")})
+    for tag in ("ref", "same"):
+        assert max(s[tag + "_logit_abs"]) <= 1e-4, s[tag + "_logit_abs"]
+        assert s[tag + "_argmax_agree"] >= 0.999
+        assert s[tag + "_loss_abs"] <= 1e-5
+    assert len(s["same_grad_errs"]) > 500   # (every parameter of the net with a non-zero gradient: 21 blocks x 26 + the plumbing)
+    lim = 1e-3 if s["flipped"] == 0 else 8e-3
+    assert all(v <= lim for v in s["ref_grad_errs"].values()), s["ref_grad_worst"]
+    assert all(v <= 1e-3 for v in s["same_grad_errs"].values()), s["same_grad_worst"]   # identical sampling cells: the contract's 1e-3, no exception
+
+
 @pytest.mark.parametrize("name", ["deformableLKABlock", "MyDecoderLayer", "MyDecoderLayer_last", "MyDecoderLayer_noskip"])
 def test_decoder2d_golden_on_emulator(name, emu_backend):
     golden_checks.replay(name, "cpu")
