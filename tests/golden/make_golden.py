@@ -27,7 +27,15 @@ from oracle.blocks import randomize_offsets_  # noqa: E402
 
 
 # ---- stubs for the native leaves and for absent third-party packages --------------------------------------
-def _install_stubs():
+def _install_stubs(native=True):
+    """native=False: only the absent THIRD-PARTY packages (fvcore, MONAI) are stubbed — the native leaves (D3D, torchvision.ops) are left to the
+    caller (tests/test_reference_import_paths.py routes them to the product's HIP kernels with install_reference_aliases)."""
+    if native:
+        _install_native_stubs()
+    _install_third_party_stubs()
+
+
+def _install_native_stubs():
     d3d = types.ModuleType("D3D")
 
     def fwd(input, weight, bias, offset, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw, group, dg, step):
@@ -64,6 +72,8 @@ def _install_stubs():
     sys.modules["torchvision"] = tv
     sys.modules["torchvision.ops"] = tv_ops
 
+
+def _install_third_party_stubs():
     fv = types.ModuleType("fvcore")
     fvnn = types.ModuleType("fvcore.nn")
     fvnn.FlopCountAnalysis = object

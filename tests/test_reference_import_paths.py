@@ -125,3 +125,116 @@ def test_reference_constructed_block_state_dict_loads_strictly():
     parity.assert_close("block eval y", y, yr.detach(), atol=1e-4)
     y.view(1, -1)          # a downstream .view() must work, as it does on the reference's output
     """)
+
+
+@needs_ref
+def test_reference_synapse_transformerblock_runs_unmodified_on_the_hip_path():
+    """INTEGRATION.md §2a for the NETS: the reference's own 3D/d_lka_former/network_architecture/synapse/transformerblock.py — imported from
+    /root/reference, not edited — finds ``DeformConvPack`` where it imports it from (``d_lka_former.network_architecture.synapse.deform_conv``,
+    transformerblock.py:568) = this package's module, which runs the HIP kernel sources (emulator here).  Only the absent third-party packages
+    (MONAI factories, fvcore) are restated; ``import torchvision`` (:421) is served by the opt-in stand-in.  The reference's
+    LKA_Attention3d_deform and its whole TransformerBlock_3D_single_deform_LKA are compared with the oracle."""
+    out = _run("""
+    import types, importlib
+    sys.path.insert(0, "tests/golden")
+    import make_golden
+    make_golden._install_stubs(native=False)                     # MONAI / fvcore only — NOT the oracle-backed D3D / torchvision stubs
+    dk.install_reference_aliases(names=("D3D",) + dk.NET_ALIASES, torchvision_ops=True)
+    sys.path.insert(0, REF + "/3D")
+    for name in ("d_lka_former", "d_lka_former.network_architecture", "d_lka_former.network_architecture.synapse"):
+        m = types.ModuleType(name)                               # (the package's real __init__ star-imports the trainers: nnU-Net, batchgenerators ...)
+        m.__path__ = [REF + "/3D/" + name.replace(".", "/")]
+        sys.modules[name] = m
+    tb = importlib.import_module("d_lka_former.network_architecture.synapse.transformerblock")
+    assert tb.__file__.startswith(REF)
+    assert tb.DeformConvPack is dk.DeformConvPack, "the reference's transformerblock.py did not pick up the HIP-backed DeformConvPack"
+    from oracle import blocks
+    torch.manual_seed(0)
+    B, C, H, W, D = 2, 32, 4, 5, 6
+    m = tb.LKA_Attention3d_deform(C)                             # the REFERENCE's class
+    blocks.randomize_offsets_(m, std=0.05)
+    x = torch.randn(B, H * W * D, C)
+    gy = torch.randn(B, H * W * D, C)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    yr = blocks.lka3d_attention_tokens(xr, P, B, C, H, W, D)
+    yr.backward(gy)
+    xs = x.clone().requires_grad_(True)
+    y = m(xs, B, C, H, W, D)
+    y.backward(gy)
+    parity.assert_close("ref LKA_Attention3d_deform y", y, yr.detach(), atol=1e-4)
+    parity.assert_close("ref LKA_Attention3d_deform gx", xs.grad, xr.grad, rtol=1e-3)
+    for k, p in m.named_parameters():
+        if P[k].grad is not None and P[k].grad.abs().max() > 0:
+            parity.assert_close("ref LKA_Attention3d_deform grad " + k, p.grad, P[k].grad, rtol=1e-3)
+    print("lka3d ok")
+    blk = tb.TransformerBlock_3D_single_deform_LKA(input_size=H * W * D, hidden_size=C, proj_size=C, num_heads=4, dropout_rate=0.1, pos_embed=True)
+    blocks.randomize_offsets_(blk, std=0.05)
+    with torch.no_grad():
+        blk.gamma.normal_(0.5, 0.2)
+    blk.eval()
+    xv = torch.randn(1, C, H, W, D)
+    Pb = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    parity.assert_close("ref wrapper block y", blk(xv), blocks.transformer_block_3d(xv, Pb, False, None), atol=1e-4)
+    print("tblock ok")
+    """)
+    assert "lka3d ok" in out and "tblock ok" in out
+
+
+@needs_ref
+def test_reference_2d_deformable_lka_runs_unmodified_on_the_hip_path():
+    """2D/deformable_LKA/deformable_LKA.py — the reference's file, not edited — with ``torchvision.ops.DeformConv2d`` (:18, torchvision is not
+    installed here) served by install_reference_aliases(torchvision_ops=True): its deformable_LKA_Attention against the oracle block."""
+    out = _run("""
+    sys.path.insert(0, "tests/golden")
+    import make_golden
+    make_golden._install_third_party_stubs()                     # fvcore (a FLOP counter the file imports at :160) is not installed; nothing native
+    dk.install_reference_aliases(names=(), torchvision_ops=True)
+    import torchvision
+    assert torchvision.ops.DeformConv2d is dk.DeformConv2d
+    sys.path.insert(0, REF + "/2D/deformable_LKA")
+    import deformable_LKA as ref2d
+    assert ref2d.__file__.startswith(REF)
+    from oracle import blocks
+    torch.manual_seed(0)
+    B, C, H, W = 2, 32, 9, 8
+    m = ref2d.deformable_LKA_Attention(C)                        # the REFERENCE's class
+    blocks.randomize_offsets_(m, std=0.03)
+    x = torch.randn(B, C, H, W)
+    gy = torch.randn(B, C, H, W)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    yr = blocks.lka2d_attention(xr, P)
+    yr.backward(gy)
+    xs = x.clone().requires_grad_(True)
+    y = m(xs)
+    y.backward(gy)
+    parity.assert_close("ref deformable_LKA_Attention y", y, yr.detach(), atol=1e-4)
+    parity.assert_close("ref deformable_LKA_Attention gx", xs.grad, xr.grad, rtol=1e-3)
+    for k, p in m.named_parameters():
+        if P[k].grad is not None and P[k].grad.abs().max() > 0:
+            parity.assert_close("ref deformable_LKA_Attention grad " + k, p.grad, P[k].grad, rtol=1e-3)
+    print("lka2d ok")
+    """)
+    assert "lka2d ok" in out
+
+
+def test_net_alias_names_resolve_to_this_package():
+    """The pancreas net's path (3D/pancreas_code/networks/d_lka_former/transformerblock.py:569) and the Synapse / ACDC one resolve to this package's
+    modules once registered; an unknown path is an error, not a silent no-op."""
+    _run("""
+    dk.install_reference_aliases(names=dk.NET_ALIASES)
+    import importlib
+    for n in dk.NET_ALIASES:
+        m = importlib.import_module(n)
+        assert m.__name__.startswith("deformablelka_amd."), (n, m.__name__)
+    from networks.d_lka_former.deform_conv import DeformConvPack, DeformConvPack_Depth
+    from d_lka_former.network_architecture.synapse.deform_conv_func import DeformConvFunction
+    assert DeformConvPack is dk.DeformConvPack and DeformConvFunction is dk.DeformConvFunction
+    try:
+        dk.install_reference_aliases(names=("no.such.module",))
+    except KeyError:
+        pass
+    else:
+        raise AssertionError("unknown alias accepted")
+    """)
