@@ -368,6 +368,15 @@ static SameConv dw_conv(int B, int C, int D, int H, int W, const int *k, const i
     return s;
 }
 
+// DLKA_WGRAD_GATHER: the deformable weight gradient gathers for itself instead of streaming the samples the grad_offset kernel stored (A/B runs, the
+// hand-over parity test).  Read ONCE; afterwards only dlka_lka3d_force_wgrad_gather changes it.
+static int g_wgrad_gather = -1;
+static bool wgrad_gather()
+{
+    if (g_wgrad_gather < 0) g_wgrad_gather = getenv("DLKA_WGRAD_GATHER") != nullptr ? 1 : 0;
+    return g_wgrad_gather != 0;
+}
+
 struct TokGeoms {
     SameConv pw, dw5, dw7, offc, dcn;   // (dw5 / dw7: conv0 / conv_spatial, whatever their kernels are in the variant)
     SameConv dw5_f, dw7_f, offc_f;   // the forward chain's geometries: == dw5 / dw7 / offc on the fp32 path, their fp32-storage twins on DLKA_BF16
@@ -400,14 +409,15 @@ struct TokGeoms {
     }
     size_t scratch_floats() const { return deform_scratch_floats(dcn); }
     // the deformable conv's samples S[tap][m][c], handed from the grad_offset kernel to the weight gradient (0: too large for 32-bit buffer
-    // offsets, or switched off — the weight gradient then gathers for itself).  DLKA_WGRAD_GATHER is read when the caller sizes the workspace and
-    // again inside the backward call (not cached: a parity test compares the two routes); both only CARVE from the caller's buffer, so a switch
-    // flipped between the two calls either leaves slack or fails the call with DLKA_ERR_WORKSPACE — never reads another layout.
-    size_t samp_floats() const
+    // offsets, or switched off — the weight gradient then gathers for itself).  The switch is ONE process-wide value (wgrad_gather(): initialised once
+    // from DLKA_WGRAD_GATHER, changed only through dlka_lka3d_force_wgrad_gather), and the workspace SIZE query always includes the sample area
+    // (samp_capacity_floats), so flipping the switch between sizing and a backward call can never under-size a buffer (round-3 verdict).
+    size_t samp_capacity_floats() const
     {
         const size_t n = (size_t)dcn.K * dcn.M * dcn.Cin;   // elements of the activation storage type (SB bytes each)
-        return (n * SB < ((size_t)1 << 31) && getenv("DLKA_WGRAD_GATHER") == nullptr) ? n * SB / 4 : 0;
+        return (n * SB < ((size_t)1 << 31)) ? n * SB / 4 : 0;
     }
+    size_t samp_floats() const { return wgrad_gather() ? 0 : samp_capacity_floats(); }
     // prepared weights, kept in `saved` from the forward to the backward call (floats)
     size_t pw_floats() const { return (size_t)pw.Cin * pw.Cin; }
     size_t offc_floats() const { return dense_wp_floats(offc); }
@@ -944,6 +954,13 @@ int dlka_ndhwc_to_ncdhw(const void *src, void *dst, int B, int C, int N, int dty
 }
 
 // ---- token-layout D-LKA block ------------------------------------------------------------------------------------------------
+int dlka_lka3d_force_wgrad_gather(int on)
+{
+    const int old = wgrad_gather() ? 1 : 0;
+    g_wgrad_gather = on ? 1 : 0;
+    return old;
+}
+
 int dlka_lka3d_tokens_supported_v(int B, int C, int D, int H, int W, int dtype, int variant)
 {
     return ((dtype == DLKA_F32 || dtype == DLKA_BF16) && tokens_supported(B, C, D, H, W, variant)) ? 1 : 0;
@@ -964,7 +981,7 @@ size_t dlka_lka3d_tokens_workspace_bytes_v(int B, int C, int D, int H, int W, in
     if (!dlka_lka3d_tokens_supported_v(B, C, D, H, W, dtype, variant)) return 0;
     TokGeoms G(B, C, D, H, W, dtype, variant);   // (the eight gradient buffers keep their fp32 size on the bf16 path: gta and the split scratch ARE fp32)
     return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 8 * align256(G.E * 4) + align256(G.GOff * 4) +
-           align256(G.scratch_floats() * 4) + align256(G.samp_floats() * 4) + align256(4096);
+           align256(G.scratch_floats() * 4) + align256(G.samp_capacity_floats() * 4) + align256(4096);
 }
 
 static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void *y_, void *saved, size_t saved_bytes, void *workspace,

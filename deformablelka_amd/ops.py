@@ -325,10 +325,20 @@ def batchnorm_planar_backward(g, x, weight, stats, affine=True):
     return gx, gw, gb
 
 
-def pointwise_planar_supported(x, weight, need_weight_grad=True) -> bool:
+def pointwise_planar_supported(x, weight, need_weight_grad=True, need_input_grad=None) -> bool:
+    """Whether the planar 1x1x1 kernels cover this call INCLUDING the backward pass it may need.  The forward kernel is instantiated on Cin (the
+    channel count it holds in registers), the data-gradient kernel on Cout (``pl_pw_bwd_data_kernel<CO>``, planar_ops.hip: the same menu), the weight
+    gradient takes Cout <= 16.  need_input_grad: None = ``x.requires_grad`` under grad mode."""
     Cout, Cin = weight.shape[:2]
-    return (x.dtype == torch.float32 and weight.dtype == torch.float32 and Cin in PLANAR_PW_CIN and Cout <= (16 if need_weight_grad else 64)
-            and x[0, 0].numel() % 4 == 0 and x.shape[0] <= 65535 and (not need_weight_grad or Cout in PLANAR_PW_CIN))
+    if need_input_grad is None:
+        need_input_grad = bool(x.requires_grad and torch.is_grad_enabled())
+    if not (x.dtype == torch.float32 and weight.dtype == torch.float32 and Cin in PLANAR_PW_CIN and x[0, 0].numel() % 4 == 0 and x.shape[0] <= 65535):
+        return False
+    if need_weight_grad:
+        return Cout <= 16 and Cout in PLANAR_PW_CIN
+    if need_input_grad:
+        return Cout in PLANAR_PW_CIN
+    return Cout <= 64
 
 
 def pointwise_planar_forward(x, weight, bias=None):
@@ -349,8 +359,11 @@ def pointwise_planar_backward(x, weight, g, need=(True, True, True)):
     gx = torch.empty_like(x) if need[0] else None
     gw = torch.empty_like(weight) if need[1] else None
     gb = torch.empty(Cout, dtype=torch.float32, device=x.device) if (need[1] and need[2]) else None
-    L.check(L.get_lib().dlka_pointwise_planar_backward(L.ptr(x), L.ptr(weight), L.ptr(g), L.ptr(gx), L.ptr(gw), L.ptr(gb), B, Cin, Cout, x[0, 0].numel(),
-                                                       L.stream_ptr(x)), "pointwise_planar_backward")
+    if need[0] or need[1]:
+        L.check(L.get_lib().dlka_pointwise_planar_backward(L.ptr(x), L.ptr(weight), L.ptr(g), L.ptr(gx), L.ptr(gw), L.ptr(gb), B, Cin, Cout, x[0, 0].numel(),
+                                                           L.stream_ptr(x)), "pointwise_planar_backward")
+    if need[2] and gb is None:   # frozen weight, trainable bias (fine-tuning a head): the bias gradient rides in the weight-gradient kernel, which did
+        gb = g.sum(dim=[0] + list(range(2, g.dim())))   # not run — a plain reduction of grad_out (not hot: a Cout-length result)
     return gx, gw, gb
 
 

@@ -181,12 +181,17 @@ class DLKABlockStack:
             self._side = None
 
     def prepare(self):
-        """Re-lay the weights of all blocks (after every parameter update): one launch — or two, when a side stream exists: the blocks of the first stage
-        (small weights) on the calling stream, the rest (95 % of the bytes) on the side stream while the first stage's forward passes run; ``forward``
-        waits for it in front of the first block that needs it."""
+        """Re-lay the weights of all blocks (after every parameter update): ONE launch, complete in stream order on the calling stream — safe to follow
+        with ``backward()`` or any reader of the prepared weights.  (``forward()`` uses the split form below.)"""
+        self._prepare(split=False)
+
+    def _prepare(self, split: bool):
+        """split (``forward()`` only): when a side stream exists, two launches — the blocks of the first stage (small weights) on the calling stream, the
+        rest (95 % of the bytes) on the side stream while the first stage's forward passes run; ``forward`` joins it in front of the first block that needs
+        it (and ``backward`` would, were it ever entered with the join still pending), so the fork never outlives the call that made it."""
         n, st = len(self.blocks), self._stream()
-        self._prep_pending = None
-        k = self._prep_split if getattr(self, "_overlap", False) and getattr(self, "_side", None) is not None else 0
+        self._join_prepare()
+        k = self._prep_split if split and getattr(self, "_overlap", False) and getattr(self, "_side", None) is not None else 0
         if 0 < k < n:
             cur = torch.cuda.current_stream(self.device)
             L.check(self.lib.dlka_lka3d_tokens_prepare_run_range(L.ptr(self._plan_dev), L.ptr(self._plan_host), n, 0, k, st), "lka3d_tokens_prepare_run_range")
@@ -200,6 +205,11 @@ class DLKABlockStack:
         rc = self.lib.dlka_lka3d_tokens_prepare_run(L.ptr(self._plan_dev), L.ptr(self._plan_host), n, st)
         L.check(rc, "lka3d_tokens_prepare_run")
 
+    def _join_prepare(self):
+        if self._prep_pending is not None:   # weights of blocks >= _prep_pending are still in flight on the side stream
+            torch.cuda.current_stream(self.device).wait_event(self._ev_prep2)
+            self._prep_pending = None
+
     def _stream(self):
         if self.device.type != "cuda":   # only reachable through the CPU test backend (tests/emu)
             return None
@@ -208,23 +218,24 @@ class DLKABlockStack:
     def forward(self, on_block=None):
         """on_block(i): called before block i is issued (bench.py's launch trace separates the blocks with it)."""
         st = self._stream()
-        self.prepare()
+        self._prepare(split=True)
         for i, blk in enumerate(self.blocks):
             if on_block is not None:
                 on_block(i)
             if self._prep_pending is not None and i == self._prep_pending:   # the weights of this and the later blocks were prepared on the side stream
-                torch.cuda.current_stream(self.device).wait_event(self._ev_prep2)
-                self._prep_pending = None
+                self._join_prepare()
             H, W, D = blk.dims
             rc = self.lib.dlka_lka3d_attention_tokens_forward_prepared(L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.y), L.ptr(blk.saved),
                                                                 blk.saved_bytes, L.ptr(self.ws), self.ws_bytes, self.B, blk.C, H, W, D,
                                                                 self.dt, st)
             L.check(rc, "lka3d_attention_tokens_forward_prepared")
+        self._join_prepare()   # (a stack with no block behind the split point: never leave the fork open)
 
     def backward(self, lo: int = 0, hi: int = None, on_block=None):
         """Backward pass of blocks[lo:hi] in reverse order (default: all)."""
         import ctypes
         st = self._stream()
+        self._join_prepare()
         idx = list(range(len(self.blocks)))[lo:hi]
         defer = self._fin_host is not None
         plan_ptr = ctypes.c_void_p(self._fin_host.data_ptr()) if defer else None

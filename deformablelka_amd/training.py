@@ -104,14 +104,21 @@ class GraphedIteration:
     """``run_iteration`` captured ONCE in a hipGraph and replayed: forward, loss, backward, ``clip_grad_norm_`` and the optimizer step become one
     graph launch per iteration (the D-LKA autograd Functions launch on the capturing stream; every tensor the iteration creates comes from the
     graph's private pool).  Static shapes: ``data`` / ``target`` are copied into the captured input buffers.  The learning rate is read when the graph
-    is captured — re-capture after changing it (the reference's poly schedule changes it once per EPOCH).  Single process; with
-    ``DistributedDataParallel`` use the eager ``run_iteration``."""
+    is captured — build a new one after changing it (the reference's poly schedule changes it once per EPOCH); a call with a changed rate raises
+    instead of silently stepping with the old one.  Returns a COPY of the loss (the captured buffer is overwritten by the next replay).  BatchNorm
+    layers with ``momentum=None`` are rejected (host read of ``num_batches_tracked``).  Single process; with ``DistributedDataParallel`` use the
+    eager ``run_iteration``."""
 
     def __init__(self, net: nn.Module, optimizer, data: torch.Tensor, target: torch.Tensor, loss_fn: Callable = deep_supervision_loss,
                  clip_norm: float = 12.0, warmup: int = 3):
         if not data.is_cuda:
             raise RuntimeError("GraphedIteration needs GPU tensors")
+        for name, m in net.named_modules():   # cumulative-average BatchNorm reads num_batches_tracked on the HOST every step: a device sync inside the
+            if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.track_running_stats and m.momentum is None:   # capture, or a value baked into the graph
+                raise RuntimeError(f"GraphedIteration: BatchNorm layer {name!r} has momentum=None (cumulative moving average), which cannot be captured "
+                                   "in a hipGraph; give it a momentum or use the eager run_iteration")
         self.net, self.optimizer = net, optimizer
+        self._captured_lrs = [float(g["lr"]) for g in optimizer.param_groups]   # the graph holds these values (see __call__)
         self.data, self.target = data.clone(), target.clone()
         side = torch.cuda.Stream(device=data.device)
         side.wait_stream(torch.cuda.current_stream(data.device))
@@ -129,5 +136,9 @@ class GraphedIteration:
             self.data.copy_(data, non_blocking=True)
         if target is not None:
             self.target.copy_(target, non_blocking=True)
+        lrs = [float(g["lr"]) for g in self.optimizer.param_groups]
+        if lrs != self._captured_lrs:
+            raise RuntimeError(f"GraphedIteration: the optimizer's learning rate changed ({self._captured_lrs} -> {lrs}) but the captured graph holds the "
+                               "old value; build a new GraphedIteration after changing it")
         self.graph.replay()
-        return self.loss
+        return self.loss.clone()   # (a copy: ``self.loss`` is the graph's static output buffer, overwritten by the next replay)

@@ -470,6 +470,10 @@ int dlka_deform_dwconv2d_backward_cl(const void *x, const void *offset, const vo
 typedef enum dlka_lka3d_variant { DLKA_LKA3D_SYNAPSE = 0, DLKA_LKA3D_ACDC = 1 } dlka_lka3d_variant;
 int    dlka_lka3d_tokens_supported_v(int B, int C, int D, int H, int W, int dtype, int variant);
 size_t dlka_lka3d_tokens_saved_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
+/* Forces (1) / releases (0) the deformable weight gradient that GATHERS for itself (no sample tensor handed over by the grad_offset kernel);
+ * returns the previous setting.  Initial value: 1 iff the environment variable DLKA_WGRAD_GATHER is set when the first token-path call is made.
+ * For A/B runs and the hand-over parity test; the workspace size query always covers both routes. */
+int dlka_lka3d_force_wgrad_gather(int on);
 size_t dlka_lka3d_tokens_workspace_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
 int dlka_lka3d_attention_tokens_forward_v(const void *x, const dlka_lka3d_params *p, void *y, void *saved, size_t saved_bytes,
                                           void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant, void *stream);

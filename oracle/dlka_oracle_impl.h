@@ -17,12 +17,23 @@
  *            its published algorithm, anchored on the call sites 2D/deformable_LKA/deformable_LKA.py:18-30)
  *
  * PARITY PINNING: the reference ships no golden vectors or asserting tests for this path
- *  and its native op cannot be built here (CUDA-only, CPU branch throws).
- * => "parity unpinned" by the reference's own tests.  The oracle is pinned instead by the
- * derived known-answer properties in tests/test_oracle_*.py (zero-offset == conv3d, integer
- * shift, grid_sample cross-check, fp64 autograd of an independent index-based restatement)
- * and by golden vectors produced through the reference's own Python modules
- * (tests/golden/make_golden.py).
+ * (SURVEY.md §4, §8c), and its own build refuses without CUDA (3D/dcn/setup.py:30-41; the CPU
+ * branch throws, src/cpu/deform_cpu.cpp:28,53).  Its SOURCES, however, compile unmodified for
+ * gfx950: oracle/ref.mk builds 3D/dcn/src/{vision.cpp, cuda/deform_conv_cuda.cu, cuda/
+ * deform_im2col_cuda.cuh, cpu/deform_cpu.cpp} where they lie under /root/reference with hipcc and
+ * four shim headers (oracle/ref_shim/) into oracle/_ref/D3D.so — the reference's own pybind11
+ * module.  THIS ORACLE IS PINNED TO IT:
+ *   - tests/test_ref_d3d_gpu.py, tests/test_ref_d3d_2d_gpu.py (-m gpu) run D3D.so next to this
+ *     oracle on the reference's smoke-script shapes, the four stage shapes of the 64x128x128 patch
+ *     and the edge cases (3-D; and the 2-D operator through the depth-1 embedding);
+ *   - tests/golden/d3d_reference_vectors{,_2d}.pt — inputs and outputs of D3D.so recorded on an
+ *     MI355X by tests/golden/make_ref_golden.py — hold this file to the reference's arithmetic in
+ *     the CPU suite (tests/test_oracle_vs_reference_vectors.py, tests/test_oracle_2d_pinned.py).
+ * The one restated line that cannot be pinned that way — torchvision's UNGUARDED coordinate weight
+ * at q == -1 exactly ([tv]; D3D's is guarded, [cuh]:391-394) — is isolated in its own test.
+ * Module-level golden vectors come from the reference's own Python classes (tests/golden/
+ * make_golden.py, make_golden_nets.py); known-answer properties (zero-offset == conv3d, integer
+ * shift, grid_sample cross-check, fp64 gradcheck) are in tests/test_oracle_*.py.
  */
 
 #define CAT_(a, b) a##b

@@ -51,10 +51,7 @@ cases = [(1, 32, (4, 4, 4)), (2, 32, (8, 8, 8))] if emu_mode else [(2, 32, (32, 
 from oracle import blocks
 for (B, C, dims) in cases:
     for mode in ("gather", "samp"):
-        if mode == "gather":
-            os.environ["DLKA_WGRAD_GATHER"] = "1"
-        else:
-            os.environ.pop("DLKA_WGRAD_GATHER", None)
+        L.get_lib().dlka_lka3d_force_wgrad_gather(1 if mode == "gather" else 0)   # (the switch is process-wide and read once: use the setter)
         torch.manual_seed(0)
         H, W, D = dims
         N = H * W * D

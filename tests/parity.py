@@ -403,7 +403,7 @@ def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=FWD_ATOL, 
 
 def check_lka3d_tokens_sample_handover(dev, B, C, dims, dtype=torch.float32, seed=0, offset_std=0.3):
     """The deformable conv's weight gradient from the samples the grad_offset kernel stores (default) against the weight-gradient kernel that
-    gathers for itself (DLKA_WGRAD_GATHER=1): same fma chain for every sample, same MFMA order over the rows -> the two agree to summation
+    gathers for itself (dlka_lka3d_force_wgrad_gather(1) / DLKA_WGRAD_GATHER=1): same fma chain for every sample, same MFMA order over the rows -> the two agree to summation
     order, and no other gradient notices the switch."""
     import deformablelka_amd as dk
     from oracle import blocks
@@ -422,17 +422,15 @@ def check_lka3d_tokens_sample_handover(dev, B, C, dims, dtype=torch.float32, see
         m(xd, B, C, H, W, D).backward(gy)
         return {"x": xd.grad.float().cpu(), **{k: q.grad.detach().float().cpu().clone() for k, q in m.named_parameters()}}
 
-    old = os.environ.get("DLKA_WGRAD_GATHER")
+    from deformablelka_amd import _lib
+    lib = _lib.get_lib()
+    old = lib.dlka_lka3d_force_wgrad_gather(0)
     try:
-        os.environ.pop("DLKA_WGRAD_GATHER", None)
         g_s = run()
-        os.environ["DLKA_WGRAD_GATHER"] = "1"
+        lib.dlka_lka3d_force_wgrad_gather(1)
         g_g = run()
     finally:
-        if old is None:
-            os.environ.pop("DLKA_WGRAD_GATHER", None)
-        else:
-            os.environ["DLKA_WGRAD_GATHER"] = old
+        lib.dlka_lka3d_force_wgrad_gather(old)
     k = "spatial_gating_unit.deform_conv.weight"
     assert g_s[k].abs().max() > 0
     for name in g_s:   # (not bit-equal at block level: upstream tap-split partial sums meet in atomics, so grad_out itself moves by ~1e-7 per run)

@@ -461,3 +461,46 @@ def test_pointwise_planar_conv(cin, cout, dims, bias):
     assert torch.allclose(gw.double(), wr.grad, rtol=1e-4, atol=1e-4)
     if bias:
         assert torch.allclose(gb.double(), br.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_pointwise_planar_frozen_weight_trainable_bias():
+    """A fine-tuned 1x1x1 head: weight.requires_grad = False, bias.requires_grad = True.  The bias gradient used to ride in the weight-gradient
+    kernel only — with the weight frozen it was silently dropped (round-3 advice); now a frozen weight still yields the bias gradient and the
+    data gradient through the autograd Function ``network.Convolution`` uses."""
+    from deformablelka_amd import nn_ops, ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 16, 2, 6, 8, generator=g).requires_grad_(True)
+    w = (torch.randn(14, 16, 1, 1, 1, generator=g) * 0.3)
+    b = torch.randn(14, generator=g).requires_grad_(True)
+    gy = torch.randn(2, 14, 2, 6, 8, generator=g)
+    assert ops.pointwise_planar_supported(x, w, need_weight_grad=False)
+    y = nn_ops.pointwise_planar(x, w, b)
+    y.backward(gy)
+    xr, br = x.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    torch.nn.functional.conv3d(xr, w.double(), br).backward(gy.double())
+    assert b.grad is not None and torch.allclose(b.grad.double(), br.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(x.grad.double(), xr.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_pointwise_planar_supported_covers_the_backward_pass_it_will_need():
+    """The data-gradient kernel exists for grad_out channel counts in PLANAR_PW_CIN only: a frozen head whose class count is not in that menu
+    (Cout = 3) must NOT be claimed when its input needs a gradient (it used to be accepted and then failed mid-backward with -8), and is fine
+    for inference."""
+    from deformablelka_amd import ops
+    x = torch.randn(1, 4, 2, 4, 4)
+    w = torch.randn(3, 4, 1, 1, 1)
+    assert not ops.pointwise_planar_supported(x.clone().requires_grad_(True), w, need_weight_grad=False)
+    assert not ops.pointwise_planar_supported(x, w, need_weight_grad=False, need_input_grad=True)
+    assert ops.pointwise_planar_supported(x, w, need_weight_grad=False)                     # forward only
+    with torch.no_grad():
+        assert ops.pointwise_planar_supported(x.clone().requires_grad_(True), w, need_weight_grad=False)
+    y = ops.pointwise_planar_forward(x, w, None)
+    assert torch.allclose(y, torch.nn.functional.conv3d(x, w), rtol=1e-5, atol=1e-5)
+    assert not ops.pointwise_planar_supported(x, w, need_weight_grad=True)
+    # and through the layer: falls back to the GEMM route instead of raising in backward
+    from deformablelka_amd.network import Convolution
+    c = Convolution(4, 3, 1, 1, bias=True)
+    c.conv.weight.requires_grad_(False)
+    xg = x.clone().requires_grad_(True)
+    c(xg).sum().backward()
+    assert xg.grad is not None and c.conv.bias.grad is not None

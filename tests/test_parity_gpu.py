@@ -364,6 +364,29 @@ def test_hipgraph_replay_reproduces_eager():
     assert st.health()["finite"]
 
 
+def test_stack_prepare_then_backward_is_stream_safe():
+    """``DLKABlockStack.prepare()`` is a public method ("after every parameter update"): used on its own and followed by ``backward()`` it must
+    leave nothing in flight on the side stream (the split preparation is private to ``forward()``; round-3 advice).  New parameters -> prepare() ->
+    backward() with the saved activations of the earlier forward pass must equal the same sequence with everything on one stream."""
+    import os
+    from deformablelka_amd.stack import DLKABlockStack
+    stages = ((32, (8, 8, 8), 2), (128, (4, 4, 4), 1), (256, (4, 4, 4), 1))
+
+    def run(overlap):
+        st = DLKABlockStack(2, stages=stages, device="cuda:0", seed=5, overlap_wgrad=overlap)
+        st.forward_backward()
+        st.flat_params.mul_(1.01)            # "parameter update"
+        st.prepare()
+        st.backward()
+        torch.cuda.synchronize()
+        return [g.clone() for b in st.blocks for g in b.grads] + [b.gx.clone() for b in st.blocks]
+
+    a, c = run(True), run(False)
+    for u, v in zip(a, c):
+        assert torch.isfinite(u).all()
+        assert float((u - v).abs().max()) <= 2e-3 * max(float(v.abs().max()), 1e-6)
+
+
 # ---- the wrapper block TransformerBlock_3D_single_deform_LKA (SURVEY.md §8 row a1) -----------------------------------------------
 @pytest.mark.parametrize("case", [(2, 32, 4099, True, True), (1, 64, 5000, False, False), (3, 128, 999, True, False), (1, 256, 2100, False, True)])
 def test_layernorm_tokens(case):
