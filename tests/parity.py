@@ -543,7 +543,11 @@ def check_lka2d_attention(dev, B, C, H, W, seed=0, offset_std=0.03, atol=FWD_ATO
               f"{max((a - b).abs().max().item() for a, b in zip(off_hip, off_ref)):.2e}")
         print("    own offsets: " + " ".join(f"{short(k)}={v:.1e}" for k, v in errs.items()))
         print("    same cells:  " + " ".join(f"{short(k)}={v:.1e}" for k, v in errs2.items()))
-    flip_rtol = rtol if flipped == 0 else 8 * rtol
+    # One flipped sample changes ITS grad_offset entry by O(|Col|); relative to a gradient's max norm that is 1e-3 .. 1e-2 per flip depending on how
+    # many samples the tensor sums (measured on the MI355X at B = 24, (96, 56^2): 9 flips of 5.6 M -> conv_spatial.offset_net.weight 1.3e-2 on the oracle's
+    # own offsets, 6e-6 on identical cells).  With flips counted, comparison (1) therefore only keeps a sanity bound for the exposed gradients; the
+    # statement of record is comparison (2): identical cells, every gradient inside the contract's 1e-3.
+    flip_rtol = rtol if flipped == 0 else max(8 * rtol, 5e-2)
     # what collects grad_offset: the offset nets directly, and everything upstream of either deformable conv's input
     exposed = ("offset_net", "conv0.deform_conv", "proj_1.")
     assert errs["y_abs"] <= atol and errs2["y_abs"] <= atol, (errs["y_abs"], errs2["y_abs"])
