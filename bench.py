@@ -49,6 +49,7 @@ def parse():
                     "(SURVEY §8d secondary metrics; ~1 min)")
     ap.add_argument("--no-companion", action="store_true", help="skip the same step measured with the other activation dtype (N = 1 only)")
     ap.add_argument("--no-tblock", action="store_true", help="skip the second metric (wrapper-block stack through nn.Module/autograd)")
+    ap.add_argument("--no-lka2d", action="store_true", help="skip the 2-D block metric (BASELINE.json config 2: bf16, batch 24; ~0.15 s of GPU time)")
     ap.add_argument("--cpu-sample", default="stage", choices=["stage", "tiny"])
     return ap.parse_args()
 
@@ -892,6 +893,13 @@ def main():
             except Exception as e:
                 log("tblock metric failed:", repr(e))
                 out["tblock"] = None
+        if not args.no_lka2d and world == 1 and dtype == torch.float32:   # BASELINE.json config 2 AS WRITTEN (bf16, B = 24) in the DEFAULT line, so that the
+            try:                                                           # driver times it (round-3 verdict); its host companion stays in --extras
+                out["lka2d"] = lka2d_metric(5, dev, torch.bfloat16, with_cpu=False)
+            except Exception as e:
+                log("lka2d metric failed:", repr(e))
+                out["lka2d"] = None
+            torch.cuda.empty_cache()
         if args.extras and world == 1:
             for key, fn in (("fullnet", lambda: fullnet_metric(args.batch, 5, dev, bf16=(dtype == torch.bfloat16))),
                             ("lka2d", lambda: lka2d_metric(5, dev, torch.bfloat16, with_cpu=not args.no_cpu_baseline)),   # BASELINE.json config 2: bf16, B=24

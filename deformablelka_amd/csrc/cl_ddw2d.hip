@@ -257,6 +257,211 @@ __global__ __launch_bounds__(256) void cl_ddw2d_gx_kernel(Ddw2dArgs p, int TH, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// grad_input, second generation (round 4): INPUT-pixel tiles, lane = channel, no atomics.
+// The window kernel above gives a workgroup a tile of OUTPUT pixels and a 4-channel slice: its window has to hold the tile plus the kernel
+// reach (9 pixels for the 7x7 dilation-3 conv: at 56^2 the window IS the image), the sampling description of every (pixel, tap) is recomputed by
+// each of the C / 4 slices, and every corner costs 4 ds_add_f64 — 1.18 ms at (96, 56^2, B = 24), 1.3 % of the vector roof.
+// Depthwise = no contraction over channels, and all channels of a pixel share one sampling position.  So here
+//   * a wave owns an 8 x 4 tile of INPUT pixels and 128 channels (lane = a channel pair): its window is the tile itself, [cell][channel],
+//     16 KB of fp32 — the halo is in the ENUMERATION, not in LDS: per tap, the samples that can touch the tile are those whose base position
+//     lies within the tile +- (margin + 1), 15 x 11 candidates;
+//   * description with lane = candidate (64 at once: offsets, the one sampling rule sample_cell2, guard, per-corner validity against image AND
+//     tile), then __ballot packs the hits and the wave walks them with lane = CHANNEL: one coalesced row read of grad_out, the tap weight, and up
+//     to four read-add-write updates of window cells that only this wave touches and that lie in 64 consecutive banks — exact fp32, fixed order
+//     (deterministic), no atomics of any kind, every element of grad_input written exactly once by plain stores (no zero fill needed);
+//   * samples with |offset| > margin on either axis ("far", ~0.5 % at 1-pixel offsets) are left out here — a tile cannot know about them without
+//     scanning the whole image — and added by cl_ddw2d_gx_far_kernel afterwards (thread = (pixel, tap), global fp32 atomics, rare).
+// The split near / far is decided on the offset VALUES alone, so every tile that enumerates a sample takes the same decision.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int GX3_TY = 8, GX3_TX = 4;                 // tile (input pixels): 32 cells x 128 channels x 4 B = 16 KB of LDS per wave -> 9 waves per CU
+constexpr int GX3_MG = 3;                             // offset margin: |dy|, |dx| <= GX3_MG are "near"
+constexpr int GX3_NBY = GX3_TY + 2 * GX3_MG + 1, GX3_NBX = GX3_TX + 2 * GX3_MG + 1;   // candidate base positions per axis
+constexpr int GX3_CW = 128;                           // channels per wave: lane = a PAIR of channels (8-byte LDS and grad_out accesses)
+constexpr int GX3_NH = 6;                             // hits per group = grad_out row requests in flight per register set
+
+__device__ __forceinline__ bool gx3_near(float oy, float ox) { return (fabsf(oy) <= (float)GX3_MG) & (fabsf(ox) <= (float)GX3_MG); }
+
+struct f32x2_t { float x, y; };
+__device__ __forceinline__ f32x2_t gx3_load2(const float *p, long i) { const float2 v = *reinterpret_cast<const float2 *>(p + i); return f32x2_t{v.x, v.y}; }
+__device__ __forceinline__ f32x2_t gx3_load2(const bf16_t *p, long i)
+{
+    const unsigned w = *reinterpret_cast<const unsigned *>(p + i);   // two bf16: element i in the low half
+    return f32x2_t{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+}
+
+template <typename T>   // T: storage of grad_out `g`
+__global__ __launch_bounds__(64) void cl_ddw2d_gx3_kernel(Ddw2dArgs p, int ntx, int nty, int xcd_nx)
+{
+    constexpr int NCELL = GX3_TY * GX3_TX, TRASH = NCELL;   // cell TRASH: where the corners a hit does NOT own are "added" (weight 0), so that the four
+    __shared__ __attribute__((aligned(8))) f32x2_t Win[(NCELL + 1) * 64];   // updates of a hit are straight-line code; [cell][lane = channel pair]
+    const T *gin = reinterpret_cast<const T *>(p.g);
+    const int lane = threadIdx.x;
+    int t = DLKA_XCD_BX(xcd_nx);   // an XCD owns a contiguous range of tiles (whole images): the grad_out rows its tiles re-read stay in its L2
+    if (t < 0) return;
+    const int tx = t % ntx; t /= ntx;
+    const int ty = t % nty; const int b = t / nty;
+    const int c = blockIdx.y * GX3_CW + 2 * lane;
+    const bool cok = c < p.C;
+    const int cc = cok ? c : 0;   // (lanes beyond C run the same instruction stream on channels 0, 1 and store nothing)
+    const int ty0 = ty * GX3_TY, tx0 = tx * GX3_TX;
+#pragma unroll
+    for (int e = 0; e <= NCELL; ++e) Win[e * 64 + lane] = f32x2_t{0.f, 0.f};   // (each lane only ever touches its own column: no barrier anywhere)
+    constexpr int NCT = GX3_NBY * GX3_NBX;   // candidates per tap
+    const int ncand = p.K * NCT;
+    // The candidates of batch k + 1 are decoded and their two offsets REQUESTED before the hits of batch k are walked (a batch otherwise begins with an
+    // exposed L2 round trip that nothing hides: measured 830 us -> see DESIGN 4.14).  Decoded state of the batch in flight: by / bx / n (n < 0: no candidate).
+    int nby = 0, nbx = 0, nn = -1, ntap = 0;
+    float nfy = 0.f, nfx = 0.f;
+    f32x2_t nwA = {0.f, 0.f}, nwB = {0.f, 0.f};
+    auto decode_and_request = [&](int base) {
+        const int tapA = base / NCT;   // the (at most two) taps of a batch — candidates are tap-major — and their weights for this lane's channels
+        const int tapB = min(tapA + 1, p.K - 1);
+        nwA = gx3_load2(p.wp, (long)min(tapA, p.K - 1) * p.C + cc);
+        nwB = gx3_load2(p.wp, (long)tapB * p.C + cc);
+        const int id = base + lane;
+        nn = -1;
+        ntap = tapA;
+        nfy = nfx = 0.f;
+        if (id < ncand) {
+            const int tap = id / NCT;
+            const int r = id - tap * NCT;
+            const int cy = r / GX3_NBX, cx = r - cy * GX3_NBX;
+            const int ti = tap / p.kw, tj = tap - ti * p.kw;
+            nby = ty0 - GX3_MG - 1 + cy; nbx = tx0 - GX3_MG - 1 + cx;                   // base = output pixel - pad + tap * dilation
+            const int oy = nby + p.ph - ti * p.dh, ox = nbx + p.pw - tj * p.dw;         // the output pixel this (tap, base) belongs to
+            ntap = tap;
+            if (((unsigned)oy < (unsigned)p.H) & ((unsigned)ox < (unsigned)p.W)) {
+                nn = oy * p.W + ox;
+                const float *offp = p.off + ((long)b * 2 * p.K + 2 * tap) * p.N + nn;
+                nfy = offp[0]; nfx = offp[p.N];
+            }
+        }
+    };
+    decode_and_request(0);
+    for (int base = 0; base < ncand; base += 64) {
+        // ---- finish the description of this batch's 64 candidates: lane = (tap, base position) ----
+        const int tapA = base / NCT;
+        const f32x2_t wA = nwA, wB = nwB;
+        int m = 0, cell = 0, vm = 0;
+        const int isB = ntap != tapA;
+        float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+        if (nn >= 0) {
+            {
+                const int n = nn, by = nby, bx = nbx;
+                const float fy = nfy, fx = nfx;
+                int y0, x0;
+                float ly, lx;
+                bool reach;
+                const bool inside = sample_cell2(fy, fx, by, bx, p.H, p.W, y0, x0, ly, lx, reach);   // the one sampling rule (deform_sample.h)
+                if (inside & gx3_near(fy, fx)) {
+                    const int ry = y0 - ty0, rx = x0 - tx0;
+                    const bool vy0 = (y0 >= 0) & (ry >= 0) & (ry < GX3_TY), vy1 = (y0 + 1 <= p.H - 1) & (ry + 1 >= 0) & (ry + 1 < GX3_TY);
+                    const bool vx0 = (x0 >= 0) & (rx >= 0) & (rx < GX3_TX), vx1 = (x0 + 1 <= p.W - 1) & (rx + 1 >= 0) & (rx + 1 < GX3_TX);
+                    vm = (vy0 & vx0 ? 1 : 0) | (vy0 & vx1 ? 2 : 0) | (vy1 & vx0 ? 4 : 0) | (vy1 & vx1 ? 8 : 0);
+                    const float hy = 1.f - ly, hx = 1.f - lx;
+                    w00 = (vm & 1) ? hy * hx : 0.f; w01 = (vm & 2) ? hy * lx : 0.f; w10 = (vm & 4) ? ly * hx : 0.f; w11 = (vm & 8) ? ly * lx : 0.f;
+                    cell = ry * GX3_TX + rx;   // (of the low corner; may be "negative": only the corners in vm are addressed)
+                    m = b * p.N + n;
+                }
+            }
+        }
+        if (base + 64 < ncand) decode_and_request(base + 64);   // in flight while this batch's hits are applied
+        const int key = (cell << 5) | (isB << 4) | vm;   // one broadcast for the three small integers (cell in [-TX - 1, NCELL - 1])
+        // ---- walk the hits with lane = channel pair, GX3_NH at a time: the grad_out rows of the NEXT group are requested before the current group is
+        //      applied (two fixed register sets: no value has to be moved — and therefore waited for — while its load is in flight) ----
+        unsigned long long mask = __ballot(vm != 0);
+        int la[GX3_NH], va[GX3_NH], lb[GX3_NH], vb[GX3_NH];
+        f32x2_t ga[GX3_NH], gb[GX3_NH];
+#define DLKA_GX3_LOAD(G, L, V)                                                               \
+        _Pragma("unroll") for (int q = 0; q < GX3_NH; ++q) {                                 \
+            V[q] = mask != 0;                                                                \
+            L[q] = V[q] ? __builtin_ctzll(mask) : 0;                                         \
+            mask = V[q] ? (mask & (mask - 1)) : 0;                                           \
+            G[q] = gx3_load2(gin, (long)lane_bcast(m, L[q]) * p.C + cc);                     \
+        }
+#define DLKA_GX3_APPLY(G, L, V)                                                              \
+        _Pragma("unroll") for (int q = 0; q < GX3_NH; ++q) {                                 \
+            const int skey = V[q] ? lane_bcast(key, L[q]) : 0;   /* no hit: every corner -> TRASH with weight 0 */ \
+            const int scell = skey >> 5, svm = skey & 15;                                    \
+            const f32x2_t wt = (skey & 16) ? wB : wA;                                        \
+            const float cx_ = G[q].x * wt.x, cy_ = G[q].y * wt.y;   /* d loss / d sample */  \
+            const int a0 = ((svm & 1) ? scell : TRASH) * 64 + lane, a1 = ((svm & 2) ? scell + 1 : TRASH) * 64 + lane;                          \
+            const int a2 = ((svm & 4) ? scell + GX3_TX : TRASH) * 64 + lane, a3 = ((svm & 8) ? scell + GX3_TX + 1 : TRASH) * 64 + lane;        \
+            const float s00 = V[q] ? lane_bcast(w00, L[q]) : 0.f, s01 = V[q] ? lane_bcast(w01, L[q]) : 0.f;                                    \
+            const float s10 = V[q] ? lane_bcast(w10, L[q]) : 0.f, s11 = V[q] ? lane_bcast(w11, L[q]) : 0.f;                                    \
+            const f32x2_t v0 = Win[a0], v1 = Win[a1], v2 = Win[a2], v3 = Win[a3];            \
+            Win[a0] = f32x2_t{fmaf(s00, cx_, v0.x), fmaf(s00, cy_, v0.y)};                   \
+            Win[a1] = f32x2_t{fmaf(s01, cx_, v1.x), fmaf(s01, cy_, v1.y)};                   \
+            Win[a2] = f32x2_t{fmaf(s10, cx_, v2.x), fmaf(s10, cy_, v2.y)};                   \
+            Win[a3] = f32x2_t{fmaf(s11, cx_, v3.x), fmaf(s11, cy_, v3.y)};                   \
+        }
+        DLKA_GX3_LOAD(ga, la, va)
+        while (va[0]) {
+            DLKA_GX3_LOAD(gb, lb, vb)
+            DLKA_GX3_APPLY(ga, la, va)
+            if (!vb[0]) break;
+            DLKA_GX3_LOAD(ga, la, va)
+            DLKA_GX3_APPLY(gb, lb, vb)
+        }
+#undef DLKA_GX3_LOAD
+#undef DLKA_GX3_APPLY
+    }
+    if (!cok) return;
+#pragma unroll 4
+    for (int e = 0; e < NCELL; ++e) {
+        const int yy = ty0 + e / GX3_TX, xx = tx0 + e % GX3_TX;
+        if (yy < p.H && xx < p.W) {
+            const f32x2_t v = Win[e * 64 + lane];
+            *reinterpret_cast<float2 *>(p.gx + ((long)b * p.N + yy * p.W + xx) * p.C + c) = make_float2(v.x, v.y);
+        }
+    }
+}
+
+// the far samples (|offset| > GX3_MG on either axis) of the kernel above: lane = (output pixel, tap) for the test, then the wave walks the far ones
+// it found with lane = channel — coalesced global fp32 atomics, four corner rows per sample.
+template <typename T>
+__global__ __launch_bounds__(256) void cl_ddw2d_gx_far_kernel(Ddw2dArgs p)
+{
+    const T *gin = reinterpret_cast<const T *>(p.g);
+    const int lane = threadIdx.x & 63;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;   // [b][tap][n]: consecutive threads read consecutive offsets
+    int n = 0, tap = 0, b = 0, y0 = 0, x0 = 0;
+    float ly = 0.f, lx = 0.f;
+    bool far = false;
+    if (id < (long)p.M * p.K) {
+        n = (int)(id % p.N);
+        tap = (int)((id / p.N) % p.K);
+        b = (int)(id / ((long)p.N * p.K));
+        const float *offp = p.off + ((long)b * 2 * p.K + 2 * tap) * p.N + n;
+        const float fy = offp[0], fx = offp[p.N];
+        if (!gx3_near(fy, fx)) {
+            const int oy = n / p.W, ox = n - oy * p.W;
+            const int ti = tap / p.kw, tj = tap - ti * p.kw;
+            bool reach;
+            far = sample_cell2(fy, fx, oy - p.ph + ti * p.dh, ox - p.pw + tj * p.dw, p.H, p.W, y0, x0, ly, lx, reach);
+        }
+    }
+    unsigned long long mask = __ballot(far);
+    while (mask) {
+        const int l = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const int sn = lane_bcast(n, l), stap = lane_bcast(tap, l), sb = lane_bcast(b, l), sy0 = lane_bcast(y0, l), sx0 = lane_bcast(x0, l);
+        const float sly = lane_bcast(ly, l), slx = lane_bcast(lx, l);
+        const float wy[2] = {1.f - sly, sly}, wx[2] = {1.f - slx, slx};
+        const long grow = ((long)sb * p.N + sn) * p.C;
+        for (int c = lane; c < p.C; c += 64) {
+            const float col = act_load1(gin, grow + c) * p.wp[(long)stap * p.C + c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int yy = sy0 + (q >> 1), xx = sx0 + (q & 1);
+                if (((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W))   // uniform
+                    atomicAdd(p.gx + ((long)sb * p.N + yy * p.W + xx) * p.C + c, col * (wy[q >> 1] * wx[q & 1]));
+            }
+        }
+    }
+}
+
 // gw[c][tap] (reference layout [C][1][kh][kw]) = sum_blocks part[block][tap][c]
 __global__ __launch_bounds__(256) void cl_ddw2d_fold_kernel(const float *__restrict__ part, float *__restrict__ gw, int nblocks, int K, int C)
 {
@@ -341,6 +546,29 @@ int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st)
     DLKA_CHECK_LAUNCH();
     DLKA_LAUNCH(cl_ddw2d_fold_kernel, dim3(cdiv(a.K * a.C, 256)), dim3(256), 0, st, (const float *)a.part, gw, nblocks, a.K, a.C);
     DLKA_CHECK_LAUNCH();
+    // Second generation where the image gives it enough tiles to fill the chip (one wave per (tile, 128 channels): 2352 waves at (96, 56^2, B = 24));
+    // the smaller decoder shapes keep the window kernel (measured, profiles/r05_notes.md: 575 vs 478 us at (192, 28^2), 346 vs ~300 at (384, 14^2)).
+    // DLKA_DDW2D_GX=window | tiles forces one of them (A/B runs, parity tests of both).
+    const char *gxsel = getenv("DLKA_DDW2D_GX");
+    const long gx3_waves = (long)a.B * cdiv(a.H, GX3_TY) * cdiv(a.W, GX3_TX) * cdiv(a.C, GX3_CW);
+    const bool use_gx3 = (a.C & 1) == 0 && (gxsel ? gxsel[0] == 't' : gx3_waves >= 2048);
+    if (use_gx3) {   // grad_input, second generation: input-pixel tiles, lane = channel pair (the first generation stays for A/B runs)
+        const int ntx = cdiv(a.W, GX3_TX), nty = cdiv(a.H, GX3_TY);
+        const int ntiles = a.B * nty * ntx;
+        dim3 ggrid(ntiles, cdiv(a.C, GX3_CW));
+        int xcd_nx = 0;
+        if (xcd_swizzle_enabled() && ntiles >= xcd_min_blocks()) { xcd_nx = ntiles; ggrid.x = xcd_grid(ntiles); }
+        const dim3 fgrid((unsigned)(((long)a.M * a.K + 255) / 256));
+        if (d.act_bf16) {
+            auto k = cl_ddw2d_gx3_kernel<bf16_t>; DLKA_LAUNCH(k, ggrid, dim3(64), 0, st, a, ntx, nty, xcd_nx);
+            auto f = cl_ddw2d_gx_far_kernel<bf16_t>; DLKA_LAUNCH(f, fgrid, dim3(256), 0, st, a);
+        } else {
+            auto k = cl_ddw2d_gx3_kernel<float>; DLKA_LAUNCH(k, ggrid, dim3(64), 0, st, a, ntx, nty, xcd_nx);
+            auto f = cl_ddw2d_gx_far_kernel<float>; DLKA_LAUNCH(f, fgrid, dim3(256), 0, st, a);
+        }
+        DLKA_CHECK_LAUNCH();
+        return DLKA_OK;
+    }
     {   // grad_input: LDS-window scatter
         const int reach_y = a.ph > (a.kh - 1) * a.dh - a.ph ? a.ph : (a.kh - 1) * a.dh - a.ph;   // |base - output pixel| <= reach
         const int reach_x = a.pw > (a.kw - 1) * a.dw - a.pw ? a.pw : (a.kw - 1) * a.dw - a.pw;

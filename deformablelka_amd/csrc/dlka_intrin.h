@@ -42,6 +42,9 @@ __device__ __forceinline__ float bf16_value(unsigned short h) { return hipemu::h
 __device__ __forceinline__ void wave_sync() { (void)hipemu::shfl_any(0, 0); }
 // a value the caller guarantees to be equal in all active lanes of the wave (moves it to a scalar register on the GPU)
 __device__ __forceinline__ int wave_uniform(int x) { return x; }
+// the value lane `l` holds (l wave-uniform; every lane of the wave must call it): v_readlane_b32 on the GPU
+__device__ __forceinline__ int lane_bcast(int x, int l) { return hipemu::shfl_any(x, l); }
+__device__ __forceinline__ float lane_bcast(float x, int l) { return hipemu::shfl_any(x, l); }
 // the value of lane ^ 1 (every lane of the wave must call it)
 __device__ __forceinline__ unsigned lane_xor1(unsigned x) { return hipemu::shfl_any(x, (hipemu::F().lin & 63) ^ 1); }
 __device__ __forceinline__ int rint_i32(float x) { return (int)lrintf(x); }
@@ -207,6 +210,9 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // a value the caller guarantees to be equal in all active lanes of the wave: into a scalar register, so that pointers / buffer
 // descriptors derived from it are built by the scalar unit
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// the value lane `l` holds, as a scalar (l must be wave-uniform: v_readlane_b32)
+__device__ __forceinline__ int lane_bcast(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ float lane_bcast(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 // the value of lane ^ 1: one DPP move (quad_perm [1, 0, 3, 2])
 __device__ __forceinline__ unsigned lane_xor1(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false); }
 __device__ __forceinline__ int rint_i32(float x) { return __float2int_rn(x); }

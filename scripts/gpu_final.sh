@@ -9,7 +9,7 @@ echo "== smoke"; timeout 600 python -c 'import __graft_entry__ as g; g.smoke()' 
 echo "== bench (default)"; timeout 900 python bench.py > $OUT/bench_f32.json 2> $OUT/bench_f32.err; echo "exit $?"
 echo "== bench --dtype bf16"; timeout 900 python bench.py --dtype bf16 --no-cpu-baseline > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err; echo "exit $?"
 echo "== bench under torch.distributed.run (1 rank, nccl), overlapped all-reduce schedule forced"
-DLKA_BENCH_FORCE_SPLIT=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-tblock --no-companion --no-roofline > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err; echo "exit $?"; python -c "
+DLKA_BENCH_FORCE_SPLIT=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-tblock --no-companion --no-lka2d --no-roofline > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err; echo "exit $?"; python -c "
 import json; d=json.load(open('$OUT/bench_dist1.json')); print('dist1', d['value'], d['ms_per_step'], d['config']['allreduce_overlap'], d['config']['allreduce_split_block'])"
 if [ "${EXTRAS:-1}" = 1 ]; then echo "== bench --extras"; timeout 1200 python bench.py --extras --no-cpu-baseline --no-companion > $OUT/bench_extras.json 2> $OUT/bench_extras.err; echo "exit $?"; fi
 python - <<PY
@@ -31,10 +31,10 @@ if [ "${SKIP_PROFILES:-0}" = 1 ]; then   # (block-stack kernels unchanged since 
 fi
 cd /tmp
 echo "== rocprof of the bench command (as timed: the weight gradients of a block overlap the next block's data chain on a second stream — concurrent kernels stretch each other)"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bench -o t -- python $R/bench.py --no-cpu-baseline --no-tblock --no-companion > $R/$OUT/prof_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bench -o t -- python $R/bench.py --no-cpu-baseline --no-tblock --no-companion --no-lka2d > $R/$OUT/prof_bench.log 2>&1
 F=$(find $R/$OUT/prof_bench -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" $R/$OUT/bench_kernel_stats.csv && head -6 $R/$OUT/bench_kernel_stats.csv | cut -c1-150
 echo "== rocprof of the bench command on ONE stream (DLKA_STACK_WGRAD_OVERLAP=0): the per-kernel durations the roofline block's launch trace must agree with"
-DLKA_STACK_WGRAD_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bench1 -o t -- python $R/bench.py --no-cpu-baseline --no-tblock --no-companion > $R/$OUT/prof_bench1.log 2>&1
+DLKA_STACK_WGRAD_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bench1 -o t -- python $R/bench.py --no-cpu-baseline --no-tblock --no-companion --no-lka2d > $R/$OUT/prof_bench1.log 2>&1
 F=$(find $R/$OUT/prof_bench1 -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" $R/$OUT/bench_one_stream_kernel_stats.csv && head -6 $R/$OUT/bench_one_stream_kernel_stats.csv | cut -c1-150
 export DLKA_STACK_WGRAD_OVERLAP=0   # (one block per stage below: nothing to overlap with)
 for dt in f32 bf16; do for s in 0 1 2 3; do

@@ -504,3 +504,16 @@ def test_pointwise_planar_supported_covers_the_backward_pass_it_will_need():
     xg = x.clone().requires_grad_(True)
     c(xg).sum().backward()
     assert xg.grad is not None and c.conv.bias.grad is not None
+
+
+@pytest.mark.parametrize("sel", ["tiles", "window"])
+def test_lka2d_grad_input_both_generations(sel, monkeypatch):
+    """grad_input of the depthwise deformable convs: the launcher picks the input-tile kernel (lane = channel pair, no atomics; cl_ddw2d_gx3_kernel +
+    cl_ddw2d_gx_far_kernel) where the image gives it enough tiles and the fp64-window kernel elsewhere; DLKA_DDW2D_GX forces one, so that
+    emulator-sized shapes reach both — block parity at the contract tolerances, incl. an image of several tiles with offsets far beyond the margin
+    (the far-sample kernel) and a width that is not a multiple of the 128-channel wave."""
+    monkeypatch.setenv("DLKA_DDW2D_GX", sel)
+    parity.check_lka2d_attention("cpu", 2, 32, 7, 6)
+    parity.check_lka2d_attention("cpu", 1, 96, 9, 11, seed=3)
+    parity.check_lka2d_attention("cpu", 1, 32, 40, 72, seed=1, offset_std=0.2)
+    parity.check_lka2d_attention_bf16("cpu", 2, 64, 6, 10)

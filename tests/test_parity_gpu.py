@@ -233,6 +233,13 @@ def test_lka2d_attention_real_shapes_vs_oracle(C, hw):
     parity.check_lka2d_attention(DEV, 2, C, hw, hw, report=True)
 
 
+@pytest.mark.parametrize("sel,C,hw", [("tiles", 192, 28), ("tiles", 384, 14), ("window", 96, 56)])
+def test_lka2d_grad_input_forced_generation_real_shapes(sel, C, hw, monkeypatch):
+    """The grad_input kernel the launcher would NOT pick at this shape (DLKA_DDW2D_GX): both generations hold the contract at all three decoder shapes."""
+    monkeypatch.setenv("DLKA_DDW2D_GX", sel)
+    parity.check_lka2d_attention(DEV, 2, C, hw, hw)
+
+
 def test_lka2d_attention_config2_batch24_vs_oracle():
     """BASELINE.json config 2's own batch (B = 24) at the widest-image decoder shape (96, 56^2): contract tolerances, flips counted, same-cells rerun."""
     parity.check_lka2d_attention(DEV, 24, 96, 56, 56, report=True)
