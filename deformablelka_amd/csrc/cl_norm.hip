@@ -34,11 +34,20 @@ __device__ __forceinline__ float half_sum(float v)
 }
 }  // namespace
 
+// The tensors that cross into / out of the D-LKA attention block (xn, e, g_e, g_xn) are bf16 storage when the wrapper block runs its attention in
+// DLKA_BF16 (`lo` != 0; include/dlka.h: dlka_tblock3d_*, dtype = DLKA_BF16); everything else of the wrapper is fp32.
+__device__ __forceinline__ float ld_lo(const float *p, long i, int lo) { return lo ? act_load1(reinterpret_cast<const bf16_t *>(p), i) : p[i]; }
+__device__ __forceinline__ void st_lo(float *p, long i, float v, int lo)
+{
+    if (lo) act_store1(reinterpret_cast<bf16_t *>(p), i, v);
+    else p[i] = v;
+}
+
 // One wave per token row: x (planar [B][C][N] — the NCDHW tensor the block receives — or channels-last [M][C]) (+ pos[N][C])
 // -> xt[M][C]; xn = (xt - mean) * rstd * w + b; stats[m] = {mean, rstd}.   Biased variance, eps inside the sqrt (nn.LayerNorm).
 __global__ __launch_bounds__(NT) void cl_layernorm_fwd_kernel(const float *__restrict__ x, int x_planar, const float *__restrict__ pos,
                                                               const float *__restrict__ w, const float *__restrict__ b, float *__restrict__ xt,
-                                                              float *__restrict__ xn, float *__restrict__ stats, int B, int N, int C, float eps)
+                                                              float *__restrict__ xn, float *__restrict__ stats, int B, int N, int C, float eps, int lo)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long M = (long)B * N;
@@ -58,7 +67,7 @@ __global__ __launch_bounds__(NT) void cl_layernorm_fwd_kernel(const float *__res
             const float var = fmaxf(half_sum(val * val) / C - mean * mean, 0.f);
             const float rstd = 1.f / sqrtf(var + eps);
             if (ok) {
-                xn[m * C + c] = (val - mean) * rstd * w[c] + b[c];
+                st_lo(xn, m * C + c, (val - mean) * rstd * w[c] + b[c], lo);
                 if (c == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
             }
         }
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(NT) void cl_layernorm_fwd_kernel(const float *__res
         const float mean = s / C;
         const float var = fmaxf(s2 / C - mean * mean, 0.f);
         const float rstd = 1.f / sqrtf(var + eps);
-        for (int c = lane; c < C; c += 64) xn[m * C + c] = (xt[m * C + c] - mean) * rstd * w[c] + b[c];
+        for (int c = lane; c < C; c += 64) st_lo(xn, m * C + c, (xt[m * C + c] - mean) * rstd * w[c] + b[c], lo);
         if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
     }
 }
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(NT) void cl_layernorm_fwd_kernel(const float *__res
 // gpos[v][c] += gxt[m][c]                     (zero-initialised; optional)
 __global__ __launch_bounds__(NT) void cl_layernorm_bwd_kernel(const float *__restrict__ g, const float *__restrict__ g_res, const float *__restrict__ xt,
                                                               const float *__restrict__ stats, const float *__restrict__ w, float *__restrict__ gxt,
-                                                              float *__restrict__ gw, float *__restrict__ gb, float *__restrict__ gpos, int B, int N, int C)
+                                                              float *__restrict__ gw, float *__restrict__ gb, float *__restrict__ gpos, int B, int N, int C, int lo)
 {
     DLKA_DYN_SMEM(float, red);   // [waves][2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(NT) void cl_layernorm_bwd_kernel(const float *__res
             const bool ok = m < M && c < C;
             float xh = 0.f, dxh = 0.f, rstd = 0.f;
             if (ok) {
-                const float gv = g[m * C + c];
+                const float gv = ld_lo(g, m * C + c, lo);
                 rstd = stats[2 * m + 1];
                 xh = (xt[m * C + c] - stats[2 * m]) * rstd;
                 dxh = gv * w[c];
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(NT) void cl_layernorm_bwd_kernel(const float *__res
             const int c = lane + 64 * k;
             xh[k] = 0.f; dxh[k] = 0.f;
             if (c < C) {
-                const float gv = g[m * C + c];
+                const float gv = ld_lo(g, m * C + c, lo);
                 xh[k] = (xt[m * C + c] - mean) * rstd;
                 dxh[k] = gv * w[c];
                 s1 += dxh[k];
@@ -179,15 +188,15 @@ __global__ __launch_bounds__(NT) void cl_layernorm_bwd_kernel(const float *__res
 
 // out = xt + gamma[c] * e
 __global__ __launch_bounds__(NT) void cl_scale_residual_fwd_kernel(const float *__restrict__ xt, const float *__restrict__ e, const float *__restrict__ gamma,
-                                                                   float *__restrict__ out, long M, int C)
+                                                                   float *__restrict__ out, long M, int C, int lo)
 {
     const long n = M * C;
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) out[i] = fmaf(gamma[i % C], e[i], xt[i]);
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) out[i] = fmaf(gamma[i % C], ld_lo(e, i, lo), xt[i]);
 }
 
 // ge = gamma[c] * g;  ggamma[c] += sum_m g * e   (zero-initialised)
 __global__ __launch_bounds__(NT) void cl_scale_residual_bwd_kernel(const float *__restrict__ g, const float *__restrict__ e, const float *__restrict__ gamma,
-                                                                   float *__restrict__ ge, float *__restrict__ ggamma, long M, int C)
+                                                                   float *__restrict__ ge, float *__restrict__ ggamma, long M, int C, int lo)
 {
     DLKA_DYN_SMEM(float, red);   // [C]
     for (int c = threadIdx.x; c < C; c += NT) red[c] = 0.f;
@@ -201,8 +210,8 @@ __global__ __launch_bounds__(NT) void cl_scale_residual_bwd_kernel(const float *
             const float gm = gamma[c];
             for (long m = (long)blockIdx.x * rpb + r_in; m < M; m += (long)gridDim.x * rpb) {
                 const float gv = g[m * C + c];
-                ge[m * C + c] = gm * gv;
-                acc = fmaf(gv, e[m * C + c], acc);
+                st_lo(ge, m * C + c, gm * gv, lo);
+                acc = fmaf(gv, ld_lo(e, m * C + c, lo), acc);
             }
             atomicAdd(&red[c], acc);
         }
@@ -363,16 +372,16 @@ static unsigned grid_for(long work_items, long per_block, long cap = 2048)
 }
 
 int launch_cl_layernorm_fwd(const float *x, int x_planar, const float *pos, const float *w, const float *b, float *xt, float *xn, float *stats, int B, int N,
-                            int C, float eps, hipStream_t st)
+                            int C, float eps, hipStream_t st, int lo)
 {
     if (C > 64 * KMAX) return DLKA_ERR_UNSUPPORTED;
-    DLKA_LAUNCH(cl_layernorm_fwd_kernel, dim3(grid_for((long)B * N, NT / 64, 4096)), dim3(NT), 0, st, x, x_planar, pos, w, b, xt, xn, stats, B, N, C, eps);
+    DLKA_LAUNCH(cl_layernorm_fwd_kernel, dim3(grid_for((long)B * N, NT / 64, 4096)), dim3(NT), 0, st, x, x_planar, pos, w, b, xt, xn, stats, B, N, C, eps, lo);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
 
 int launch_cl_layernorm_bwd(const float *g, const float *g_res, const float *xt, const float *stats, const float *w, float *gxt, float *gw, float *gb,
-                            float *gpos, int B, int N, int C, hipStream_t st, bool zeroed)
+                            float *gpos, int B, int N, int C, hipStream_t st, bool zeroed, int lo)
 {
     if (C > 64 * KMAX) return DLKA_ERR_UNSUPPORTED;
     if (!zeroed) {   // (the fused block zero-fills every accumulation target of a direction with one launch)
@@ -381,23 +390,23 @@ int launch_cl_layernorm_bwd(const float *g, const float *g_res, const float *xt,
         if (gpos) DLKA_TRY_LAUNCH(launch_zero(gpos, (size_t)N * C * 4, st));
     }
     DLKA_LAUNCH(cl_layernorm_bwd_kernel, dim3(grid_for((long)B * N, NT / 64, 1024)), dim3(NT), (NT / 64) * 2 * C * sizeof(float), st, g, g_res, xt, stats, w, gxt, gw, gb,
-                       gpos, B, N, C);
+                       gpos, B, N, C, lo);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
 
-int launch_cl_scale_residual_fwd(const float *xt, const float *e, const float *gamma, float *out, long M, int C, hipStream_t st)
+int launch_cl_scale_residual_fwd(const float *xt, const float *e, const float *gamma, float *out, long M, int C, hipStream_t st, int lo)
 {
-    DLKA_LAUNCH(cl_scale_residual_fwd_kernel, dim3(grid_for(M * C, NT)), dim3(NT), 0, st, xt, e, gamma, out, M, C);
+    DLKA_LAUNCH(cl_scale_residual_fwd_kernel, dim3(grid_for(M * C, NT)), dim3(NT), 0, st, xt, e, gamma, out, M, C, lo);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }
 
-int launch_cl_scale_residual_bwd(const float *g, const float *e, const float *gamma, float *ge, float *ggamma, long M, int C, hipStream_t st, bool zeroed)
+int launch_cl_scale_residual_bwd(const float *g, const float *e, const float *gamma, float *ge, float *ggamma, long M, int C, hipStream_t st, bool zeroed, int lo)
 {
     if (!zeroed) DLKA_TRY_LAUNCH(launch_zero(ggamma, (size_t)C * 4, st));
     const int rpb = NT / (C < NT ? C : NT);
-    DLKA_LAUNCH(cl_scale_residual_bwd_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), C * sizeof(float), st, g, e, gamma, ge, ggamma, M, C);
+    DLKA_LAUNCH(cl_scale_residual_bwd_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), C * sizeof(float), st, g, e, gamma, ge, ggamma, M, C, lo);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }

@@ -1585,7 +1585,7 @@ struct TBlockSaved {
     size_t lka_bytes;
 };
 
-bool carve_tblock_saved(Carver &sv, const TBlockGeoms &G, int B, int C, int D, int H, int W, TBlockSaved &S, int variant = DLKA_LKA3D_SYNAPSE)
+bool carve_tblock_saved(Carver &sv, const TBlockGeoms &G, int B, int C, int D, int H, int W, TBlockSaved &S, int variant = DLKA_LKA3D_SYNAPSE, int dtype = DLKA_F32)
 {
     S.xt = (float *)sv.take(G.E * 4); S.xn = (float *)sv.take(G.E * 4); S.e = (float *)sv.take(G.E * 4); S.attn = (float *)sv.take(G.E * 4);
     S.c1 = (float *)sv.take(G.E * 4); S.a1 = (float *)sv.take(G.E * 4); S.c2 = (float *)sv.take(G.E * 4); S.rd = (float *)sv.take(G.E * 4);
@@ -1593,14 +1593,20 @@ bool carve_tblock_saved(Carver &sv, const TBlockGeoms &G, int B, int C, int D, i
     S.w1_f = (float *)sv.take(dense_wp_floats(G.c3) * 4); S.w1_b = (float *)sv.take(dense_wp_floats(G.c3) * 4);
     S.w2_f = (float *)sv.take(dense_wp_floats(G.c3) * 4); S.w2_b = (float *)sv.take(dense_wp_floats(G.c3) * 4);
     S.w8_f = (float *)sv.take(dense_wp_floats(G.pw) * 4); S.w8_b = (float *)sv.take(dense_wp_floats(G.pw) * 4);
-    S.lka_bytes = dlka_lka3d_tokens_saved_bytes_v(B, C, D, H, W, DLKA_F32, variant);
+    S.lka_bytes = dlka_lka3d_tokens_saved_bytes_v(B, C, D, H, W, dtype, variant);
     S.lka = sv.take(S.lka_bytes);
     return sv.ok();
 }
 
 }  // namespace
 
-int dlka_tblock3d_supported_v(int B, int C, int D, int H, int W, int dtype, int variant) { return (dtype == DLKA_F32 && tblock_supported(B, C, D, H, W, variant)) ? 1 : 0; }
+// dtype = DLKA_BF16 on the wrapper block is MIXED precision: x, y, the residual stream, LayerNorm / BatchNorm statistics, the 3^3 convs of UnetResBlock and
+// every wrapper gradient stay fp32 (pointers are fp32 on both dtypes); the D-LKA attention inside (transformerblock.py:624) runs DLKA_BF16 — its input xn, output
+// e and their gradients are bf16 storage, with the mixed-precision rule of the token path (fp32 offset-determining chain, fp32 parameters / accumulation).
+int dlka_tblock3d_supported_v(int B, int C, int D, int H, int W, int dtype, int variant)
+{
+    return ((dtype == DLKA_F32 || dtype == DLKA_BF16) && tblock_supported(B, C, D, H, W, variant)) ? 1 : 0;
+}
 int dlka_tblock3d_supported(int B, int C, int D, int H, int W, int dtype) { return dlka_tblock3d_supported_v(B, C, D, H, W, dtype, DLKA_LKA3D_SYNAPSE); }
 
 size_t dlka_tblock3d_saved_bytes(int B, int C, int D, int H, int W, int dtype) { return dlka_tblock3d_saved_bytes_v(B, C, D, H, W, dtype, DLKA_LKA3D_SYNAPSE); }
@@ -1627,7 +1633,7 @@ int dlka_tblock3d_saved_offsets_v(int B, int C, int D, int H, int W, int dtype, 
     if (!dlka_tblock3d_supported_v(B, C, D, H, W, dtype, variant)) return DLKA_ERR_UNSUPPORTED;
     TBlockGeoms G(B, C, D, H, W);
     size_t inner = 0;
-    DLKA_TRY(dlka_lka3d_tokens_saved_offsets_v(B, C, D, H, W, DLKA_F32, variant, &inner));
+    DLKA_TRY(dlka_lka3d_tokens_saved_offsets_v(B, C, D, H, W, dtype, variant, &inner));
     // carve_tblock_saved: eight activation tensors, the LayerNorm statistics, six prepared weight forms, then the D-LKA block's own `saved`
     *byte_offset = 8 * align256(G.E * 4) + align256(G.M * 2 * 4) + 4 * align256(dense_wp_floats(G.c3) * 4) + 2 * align256(dense_wp_floats(G.pw) * 4) + inner;
     return DLKA_OK;
@@ -1663,7 +1669,7 @@ int dlka_tblock3d_forward_v(const void *x, int x_planar, const dlka_tblock3d_par
     TBlockGeoms G(B, C, D, H, W);
     Carver sv(saved, saved_bytes), cv(workspace, workspace_bytes);
     TBlockSaved S;
-    if (!carve_tblock_saved(sv, G, B, C, D, H, W, S, variant)) return DLKA_ERR_WORKSPACE;
+    if (!carve_tblock_saved(sv, G, B, C, D, H, W, S, variant, dtype)) return DLKA_ERR_WORKSPACE;
     const size_t lka_ws_bytes = dlka_lka3d_tokens_workspace_bytes_v(B, C, D, H, W, dtype, variant);
     void *lka_ws = cv.take(lka_ws_bytes);
     float *wp = (float *)cv.take(G.wp_floats() * 4);
@@ -1672,6 +1678,7 @@ int dlka_tblock3d_forward_v(const void *x, int x_planar, const dlka_tblock3d_par
     const long M = (long)G.M, N = G.c3.N;
     float *st1 = (float *)bn_stats, *st2 = st1 + 3 * C;
     const float slope = 0.01f;   // UnetResBlock's act_name default (dynunet_block.py:41)
+    const int lo = dtype == DLKA_BF16 ? 1 : 0;   // the D-LKA attention runs DLKA_BF16: xn / e are bf16 storage
     (void)wp;
     // ONE launch prepares the wrapper's six weight forms (kept in `saved` for the backward call) and zero-fills what this direction accumulates
     // into with atomics (BatchNorm sums, tap-split conv outputs)
@@ -1693,11 +1700,11 @@ int dlka_tblock3d_forward_v(const void *x, int x_planar, const dlka_tblock3d_par
     }
     // tokens (+ pos_embed) and LayerNorm (:620-624)
     DLKA_TRY(launch_cl_layernorm_fwd((const float *)x, x_planar, (const float *)p->pos_embed, (const float *)p->norm_w, (const float *)p->norm_b, S.xt, S.xn,
-                                     S.lnstats, B, (int)N, C, ln_eps, st));
+                                     S.lnstats, B, (int)N, C, ln_eps, st, lo));
     // epa_block = the D-LKA block (:624)
     DLKA_TRY(dlka_lka3d_attention_tokens_forward_v(S.xn, lka, S.e, S.lka, S.lka_bytes, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, variant, stream));
     // attn = x + gamma * epa (:624); attn IS attn_skip in channels-last memory (:626 is a view here)
-    DLKA_TRY(launch_cl_scale_residual_fwd(S.xt, S.e, (const float *)p->gamma, S.attn, M, C, st));
+    DLKA_TRY(launch_cl_scale_residual_fwd(S.xt, S.e, (const float *)p->gamma, S.attn, M, C, st, lo));
     // conv51 = UnetResBlock (dynunet_block.py:66-80)
     DLKA_TRY(dense_forward(G.c3, S.attn, nullptr, nullptr, S.c1, 0, S.w1_f, 0, nullptr, nullptr, st, true));
     if (training) DLKA_TRY(launch_cl_bn_stats(S.c1, sums, st1, M, C, bn_eps, st, true));
@@ -1734,7 +1741,7 @@ int dlka_tblock3d_backward_v(const dlka_tblock3d_params *p, const dlka_lka3d_par
     TBlockGeoms G(B, C, D, H, W);
     Carver sv((void *)saved, saved_bytes), cv(workspace, workspace_bytes);
     TBlockSaved S;
-    if (!carve_tblock_saved(sv, G, B, C, D, H, W, S, variant)) return DLKA_ERR_WORKSPACE;
+    if (!carve_tblock_saved(sv, G, B, C, D, H, W, S, variant, dtype)) return DLKA_ERR_WORKSPACE;
     const size_t lka_ws_bytes = dlka_lka3d_tokens_workspace_bytes_v(B, C, D, H, W, dtype, variant);
     void *lka_ws = cv.take(lka_ws_bytes);
     (void)cv.take(G.wp_floats() * 4);   // (layout kept: the forward call carves the same region)
@@ -1748,6 +1755,7 @@ int dlka_tblock3d_backward_v(const dlka_tblock3d_params *p, const dlka_lka3d_par
     const float *st1 = (const float *)bn_stats, *st2 = st1 + 3 * C;
     const float *gy = (const float *)grad_y, *mask = (const float *)drop_mask;
     const float slope = 0.01f;
+    const int lo = dtype == DLKA_BF16 ? 1 : 0;   // g_e / g_xn are bf16 storage (the D-LKA attention ran DLKA_BF16)
     float *g_rd = b0, *g_c2 = b1, *g_skip = b2, *g_attn = b3, *g_a1 = b4, *g_c1 = b1, *g_e = b4, *g_xn = b5;
     // everything this direction accumulates into with atomics, zero-filled by ONE launch; the weight re-layouts were done by the forward call;
     // the three weight-gradient folds are ONE launch
@@ -1782,13 +1790,13 @@ int dlka_tblock3d_backward_v(const dlka_tblock3d_params *p, const dlka_lka3d_par
     // (the fold of the three conv weight gradients above rides in the D-LKA block's finalize launch below: one dependent launch less per block)
     DLKA_TRY(dense_backward_data(G.c3, g_c1, 0, nullptr, g_attn, S.w1_b, 3, g_skip, st, nullptr, nullptr, true));
     // attn = xt + gamma * e
-    DLKA_TRY(launch_cl_scale_residual_bwd(g_attn, S.e, (const float *)p->gamma, g_e, (float *)gr->gamma, M, C, st, true));
+    DLKA_TRY(launch_cl_scale_residual_bwd(g_attn, S.e, (const float *)p->gamma, g_e, (float *)gr->gamma, M, C, st, true, lo));
     // epa_block
     DLKA_TRY(tokens_backward_impl(S.xn, lka, g_e, S.lka, S.lka_bytes, g_xn, glka, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, variant, stream, nullptr, 0, nullptr,
                                   nullptr, 0, &fb));
     // LayerNorm (+ the residual branch g_attn), pos_embed
     DLKA_TRY(launch_cl_layernorm_bwd(g_xn, g_attn, S.xt, S.lnstats, (const float *)p->norm_w, (float *)grad_x, (float *)gr->norm_w, (float *)gr->norm_b,
-                                     (float *)gr->pos_embed, B, (int)N, C, st, true));
+                                     (float *)gr->pos_embed, B, (int)N, C, st, true, lo));
     return DLKA_OK;
 }
 

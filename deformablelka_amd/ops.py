@@ -629,11 +629,11 @@ def lka3d_tokens_saved_offsets(saved, B, C, dims, act_dtype=torch.float32, varia
     return saved[o:o + B * 81 * D * H * W * 4].view(torch.float32).view(B, 81, D, H, W)
 
 
-def tblock3d_saved_offsets(saved, B, C, dims, variant=0):
+def tblock3d_saved_offsets(saved, B, C, dims, variant=0, lka_bf16=False):
     """The same tensor inside the ``saved`` buffer of a wrapper-block forward call (``tblock3d_forward``)."""
     D, H, W = (int(v) for v in dims)
     off = ctypes.c_size_t(0)
-    L.check(L.get_lib().dlka_tblock3d_saved_offsets_v(B, C, D, H, W, L.DLKA_F32, int(variant), byref(off)), "tblock3d_saved_offsets")
+    L.check(L.get_lib().dlka_tblock3d_saved_offsets_v(B, C, D, H, W, L.DLKA_BF16 if lka_bf16 else L.DLKA_F32, int(variant), byref(off)), "tblock3d_saved_offsets")
     o = int(off.value)
     return saved[o:o + B * 81 * D * H * W * 4].view(torch.float32).view(B, 81, D, H, W)
 
@@ -667,6 +667,11 @@ def tblock3d_supported(x, B, C, D, H, W, variant=0) -> bool:
     return bool(L.get_lib().dlka_tblock3d_supported_v(B, C, D, H, W, L.DLKA_F32, int(variant)))
 
 
+def tblock3d_lka_bf16_supported(B, C, D, H, W, variant=0) -> bool:
+    """The wrapper block's MIXED mode (include/dlka.h: dtype = DLKA_BF16 on dlka_tblock3d_*): fp32 wrapper tensors, the D-LKA attention inside on bf16 activations."""
+    return bool(L.get_lib().dlka_tblock3d_supported_v(B, C, D, H, W, L.DLKA_BF16, int(variant)))
+
+
 def _opt_ptr_struct(cls, fields, tensors):
     st = cls()
     for f, t in zip(fields, tensors):
@@ -674,9 +679,10 @@ def _opt_ptr_struct(cls, fields, tensors):
     return st
 
 
-def tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_stats, dims, ln_eps=1e-5, bn_eps=1e-5, variant=0):
-    """x: [B, C, N...] contiguous NCDHW (x_planar) or [B, N, C] tokens; dims = the reference's (H, W, D).
-    Returns (y tokens [B, N, C], saved).  bn_stats [6*C] is written (training) or read (eval)."""
+def tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_stats, dims, ln_eps=1e-5, bn_eps=1e-5, variant=0, lka_bf16=False):
+    """x: [B, C, N...] contiguous NCDHW (x_planar) or [B, N, C] tokens (fp32); dims = the reference's (H, W, D).
+    Returns (y tokens [B, N, C], saved).  bn_stats [6*C] is written (training) or read (eval).
+    lka_bf16: the MIXED mode — the D-LKA attention inside runs on bf16 activations (DLKA_BF16), the wrapper's own tensors stay fp32."""
     L.require_device(x, bn_stats, drop_mask, *[t for t in tparams if t is not None], *lka_params)
     assert x.is_contiguous() and bn_stats.is_contiguous()
     tparams = [None if t is None else t.contiguous() for t in tparams]
@@ -687,7 +693,9 @@ def tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_s
     C = int(x.shape[1] if x_planar else x.shape[-1])
     assert x.numel() == B * N * C
     lib = L.get_lib()
-    dt = L.dtype_code(x)
+    if x.dtype != torch.float32:
+        raise RuntimeError("tblock3d_forward: the wrapper block takes float32 tensors (lka_bf16 selects bf16 activations for the D-LKA attention inside)")
+    dt = L.DLKA_BF16 if lka_bf16 else L.DLKA_F32
     v = int(variant)
     sb, wb = lib.dlka_tblock3d_saved_bytes_v(B, C, D, H, W, dt, v), lib.dlka_tblock3d_workspace_bytes_v(B, C, D, H, W, dt, v)
     if sb == 0:
@@ -702,7 +710,7 @@ def tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_s
     return y, saved
 
 
-def tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, grad_y, saved, dims, variant=0):
+def tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, grad_y, saved, dims, variant=0, lka_bf16=False):
     """Returns (grad_x tokens [B, N, C], grads of tparams (None where the parameter is None), grads of lka_params)."""
     L.require_device(grad_y, saved, bn_stats)
     grad_y = grad_y.contiguous()
@@ -711,7 +719,8 @@ def tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, grad_y
     B, N, C = (int(v) for v in grad_y.shape)
     D, H, W = (int(v) for v in dims)
     lib = L.get_lib()
-    dt = L.dtype_code(grad_y)
+    dt = L.DLKA_BF16 if lka_bf16 else L.DLKA_F32
+    grad_y = grad_y.float()
     wb = lib.dlka_tblock3d_workspace_bytes_v(B, C, D, H, W, dt, int(variant))
     ws = L.scratch(wb, grad_y)
     gx = torch.empty_like(grad_y)

@@ -79,11 +79,9 @@ def run_iteration(net: nn.Module, optimizer, data: torch.Tensor, target, loss_fn
                   clip_norm: float = 12.0, bf16_autocast: bool = False, forward: Callable = None):
     """:259-309: zero_grad, forward, loss, backward, clip_grad_norm_(12), step.  ``bf16_autocast`` wraps forward + loss in
     ``torch.autocast(dtype=bfloat16)`` (bf16 needs no gradient scaler — the reference's fp16 branch does, :281-290).  What that changes HERE: torch's own
-    layers (norms, activations, the loss) follow autocast; the 21 ``TransformerBlock_3D_single_deform_LKA`` wrappers keep their fused fp32 path — their
-    LayerNorm / BatchNorm statistics and residual stream are fp32 by design, and a bf16 tensor reaching one is widened explicitly — and the conv
-    re-expressions of ``network.Convolution`` stay fp32 GEMMs.  The bf16-ACTIVATION kernels are the block-level entry points
-    (``LKA_Attention3d_deform`` / ``deformable_LKA_Attention`` under autocast, ``DLKABlockStack(dtype=bfloat16)``), which is what ``bench.py --dtype
-    bf16`` measures."""
+    layers (norms, activations, the loss) follow autocast; each of the 21 ``TransformerBlock_3D_single_deform_LKA`` wrappers runs MIXED — its D-LKA
+    attention on bf16 activations (``dlka_tblock3d_*`` with dtype = DLKA_BF16: the token kernels' bf16 path), its own residual stream, LayerNorm /
+    BatchNorm statistics and UnetResBlock convs in fp32 — and the conv re-expressions of ``network.Convolution`` stay fp32 GEMMs."""
     fwd = forward if forward is not None else net      # (modules whose forward takes more than the data tensor)
     optimizer.zero_grad()
     if bf16_autocast:

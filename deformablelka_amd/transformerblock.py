@@ -132,21 +132,22 @@ class _TBlock3dFn(Function):
 
     @staticmethod
     def forward(ctx, x, x_planar, dims, drop_mask, training, bn_stats, eps, variant, *params):
+        variant, lka_bf16 = variant if isinstance(variant, tuple) else (variant, False)
         tparams, lka_params = params[:12], params[12:]
-        y, saved = ops.tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_stats, dims, eps[0], eps[1], variant)
-        ctx.cfg = (x_planar, dims, training, tuple(x.shape), [p is not None for p in tparams], variant)
+        y, saved = ops.tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_stats, dims, eps[0], eps[1], variant, lka_bf16)
+        ctx.cfg = (x_planar, dims, training, tuple(x.shape), [p is not None for p in tparams], (variant, lka_bf16))
         ctx.save_for_backward(saved, bn_stats, drop_mask, *[p for p in params if p is not None])
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x_planar, dims, training, xshape, present, variant = ctx.cfg
+        x_planar, dims, training, xshape, present, (variant, lka_bf16) = ctx.cfg
         saved, bn_stats, drop_mask, *ps = ctx.saved_tensors
         it = iter(ps)
         tparams = [next(it) if here else None for here in present]
         lka_params = list(it)
-        gx, tg, lg = ops.tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, gy, saved, dims, variant)
+        gx, tg, lg = ops.tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, gy, saved, dims, variant, lka_bf16)
         if x_planar:   # gradient w.r.t. the NCDHW input: tokens -> NCDHW.  A contiguous tensor, not the permuted view: the producer of x is a
             # torch layer whose backward (MIOpen) falls to its naive "nonpacked" kernels on a strided grad_output (profiles/r03e: 61 % of a
             # full-net step)
@@ -197,11 +198,15 @@ class TransformerBlock_3D_single_deform_LKA(nn.Module):
     def forward(self, x, keep_channels_last=None):
         """keep_channels_last: None = the module attribute; True / False = this call only (``network._chain`` passes it per call)."""
         B, C, H, W, D = x.shape
-        if x.dtype == torch.bfloat16:
-            # The wrapper block (LayerNorm, UnetResBlock's BatchNorm statistics, the gamma residual) runs in fp32 on this path: a bf16 tensor
-            # reaching it — e.g. from a torch layer inside torch.autocast — is widened here, explicitly (no silent dtype mismatch further down).
-            x = x.float()
+        # Autocast policy (the reference registers none): inside torch.autocast(dtype=bfloat16) — or handed a bf16 tensor — the block runs MIXED: the D-LKA
+        # attention on bf16 activations (DLKA_BF16: the token kernels' bf16 path, fp32 offset-determining chain), the wrapper itself — residual stream,
+        # LayerNorm / BatchNorm statistics, UnetResBlock's convs — in fp32 (include/dlka.h, dlka_tblock3d_*: dtype = DLKA_BF16).  A bf16 input is widened
+        # here, explicitly; the output is fp32.
         v = self.epa_block.variant
+        lka_bf16 = (x.dtype == torch.bfloat16 or ops.autocast_activation_dtype(x) == torch.bfloat16) and self.norm.weight.dtype == torch.float32 \
+            and ops.tblock3d_lka_bf16_supported(B, C, H, W, D, v)
+        if x.dtype == torch.bfloat16:
+            x = x.float()
         if not ops.tblock3d_supported(x, B, C, H, W, D, v):
             raise NotImplementedError(f"TransformerBlock_3D_single_deform_LKA on the HIP path needs float32 and hidden_size in {{32, 64, 128, 256}}; "
                                       f"got {x.dtype}, C={C}")
@@ -218,7 +223,7 @@ class TransformerBlock_3D_single_deform_LKA(nn.Module):
             stats = torch.empty(6 * C, dtype=torch.float32, device=x.device)
         else:
             stats = torch.cat([bn_eval_stats(c.norm1), bn_eval_stats(c.norm2)])
-        y = _TBlock3dFn.apply(xin, planar, (H, W, D), mask, training, stats, (self.norm.eps, c.norm1.eps), v, *self.wrapper_params(),
+        y = _TBlock3dFn.apply(xin, planar, (H, W, D), mask, training, stats, (self.norm.eps, c.norm1.eps), (v, bool(lka_bf16)), *self.wrapper_params(),
                               *self.epa_block.block_params())
         if training:
             bn_update_running((c.norm1, stats[:3 * C]), (c.norm2, stats[3 * C:]))

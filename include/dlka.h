@@ -481,6 +481,10 @@ int dlka_lka3d_attention_tokens_backward_v(const void *x, const dlka_lka3d_param
                                            void *grad_x, const dlka_lka3d_grads *grads, void *workspace, size_t workspace_bytes,
                                            int B, int C, int D, int H, int W, int dtype, int variant, void *stream);
 int    dlka_tblock3d_supported_v(int B, int C, int D, int H, int W, int dtype, int variant);
+/* dtype on the wrapper-block entry points: DLKA_F32, or DLKA_BF16 = MIXED precision — x, y, grad_y, grad_x, the residual stream, LayerNorm / BatchNorm
+ * statistics, the 3^3 convs of UnetResBlock and all parameter gradients stay fp32 (the pointers are fp32 tensors on both dtypes); the D-LKA attention
+ * inside (transformerblock.py:624) runs DLKA_BF16: its input, output and their gradients are bf16 storage, with the token path's rule (the chain that
+ * decides the sampling cells fp32, fp32 parameters / offsets / accumulation).  What torch.autocast(bfloat16) selects for the module. */
 size_t dlka_tblock3d_saved_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
 /* Diagnostics (bench health check, the parity tests' cell-flip analysis): byte offset, inside the opaque `saved` buffer of a token-layout
  * forward call / of a wrapper-block forward call, of the predicted sampling offsets [B][81][D][H][W] (fp32 on both dtypes, the reference's planar

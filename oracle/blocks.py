@@ -77,16 +77,19 @@ def unet_res_block(x, P, prefix, training, stats_out=None):
     return F.leaky_relu(out + x, 0.01)                                           # :77-79
 
 
-def transformer_block_3d(x, P, training=False, drop_mask=None, offsets_override=None, offsets_out=None):
+def transformer_block_3d(x, P, training=False, drop_mask=None, offsets_override=None, offsets_out=None, lka_store=None):
     """TransformerBlock_3D_single_deform_LKA.forward — transformerblock.py:617-630.  drop_mask: the (B, C) multipliers of
-    conv8[0] = Dropout3d(0.1) (None = eval / no dropout)."""
+    conv8[0] = Dropout3d(0.1) (None = eval / no dropout).  lka_store: ``bf16_storage`` = the model of the wrapper block's MIXED mode (the D-LKA
+    attention on bf16 activations: its input, every tensor it stores and its output rounded where they are written; the wrapper itself fp32)."""
     B, C, H, W, D = x.shape
     t = x.reshape(B, C, H * W * D).permute(0, 2, 1)                              # :620
     if "pos_embed" in P and P["pos_embed"] is not None:
         t = t + P["pos_embed"]                                                   # :622-623
     n = F.layer_norm(t, (C,), P["norm.weight"], P["norm.bias"], 1e-5)
+    if lka_store is not None:
+        n = lka_store(n)
     lka = {k[len("epa_block."):]: v for k, v in P.items() if k.startswith("epa_block.")}
-    attn = t + P["gamma"] * lka3d_attention_tokens(n, lka, B, C, H, W, D, offsets_override=offsets_override, offsets_out=offsets_out)        # :624
+    attn = t + P["gamma"] * lka3d_attention_tokens(n, lka, B, C, H, W, D, store=lka_store, offsets_override=offsets_override, offsets_out=offsets_out)        # :624
     skip = attn.reshape(B, H, W, D, C).permute(0, 4, 1, 2, 3)                    # :626
     a = unet_res_block(skip, P, "conv51.", training)                             # :627
     if drop_mask is not None:

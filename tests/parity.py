@@ -828,3 +828,81 @@ def check_tblock3d(dev, B, C, dims, training, pos, seed=0, offset_std=0.02, atol
             if e > lim:
                 bad.append(f"{k} rel {e:.3e} > {lim}")
     assert not bad, "tblock: " + "; ".join(bad)
+
+
+def check_tblock3d_mixed_bf16(dev, B, C, dims, training=True, seed=0, offset_std=0.3, rtol=BF16_RTOL, via_autocast=True, report=False):
+    """The wrapper block in its MIXED mode (dlka_tblock3d_*, dtype = DLKA_BF16: fp32 wrapper, the D-LKA attention inside on bf16 activations) — selected by
+    torch.autocast(bfloat16) or by a bf16 input — against the fp32 oracle block and against the bf16-storage model of that mode
+    (oracle.blocks.transformer_block_3d(lka_store=bf16_storage)): output and every gradient within 2e-2 of max |reference|."""
+    import deformablelka_amd as dk
+    from deformablelka_amd import ops as _ops
+    from oracle import blocks
+    torch.manual_seed(seed)
+    H, W, D = dims
+    m = dk.TransformerBlock_3D_single_deform_LKA(H * W * D, C, C, 4, dropout_rate=0.1, pos_embed=True)
+    blocks.randomize_offsets_(m, std=offset_std)
+    with torch.no_grad():
+        m.gamma.normal_(0.5, 0.2)
+        m.pos_embed.normal_(0, 0.5)
+        for bn in (m.conv51.norm1, m.conv51.norm2):
+            bn.weight.normal_(1.0, 0.2)
+            # LeakyReLU has a kink at 0 and bf16 rounding moves ~1e-3 of the pre-activations across it: each such element changes ITS gradient term by a
+            # factor 100, i.e. a relative error of ~sqrt(flipped fraction) ~ 3 - 6 % in every gradient upstream of the activation — a property of bf16
+            # activations in front of a kink (any framework), not of these kernels, and unrelated to what this test is for (the bf16 hand-over tensors
+            # xn / e / g_e / g_xn of the mixed mode).  The biases keep both activations on their linear side here; the kink itself is covered in fp32
+            # by check_tblock3d.
+            bn.bias.fill_(6.0)
+    m.train(training)
+    x = torch.randn(B, C, H, W, D)
+    if not via_autocast:
+        x = x.bfloat16().float()   # (the block is handed a bf16 tensor: both sides see the rounded input)
+    gy = torch.randn(B, C, H, W, D)
+    mask = torch.nn.functional.dropout3d(torch.ones(B, C, 1, 1, 1), 0.1, True).view(B, C) if training else None
+    m0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    def run_oracle(store):
+        Pr = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.detach().clone()) for k, v in m0.items()}
+        xr = x.detach().clone().requires_grad_(True)
+        yr = blocks.transformer_block_3d(xr, Pr, training, mask, lka_store=store)
+        yr.backward(gy)
+        return yr.detach(), xr.grad, {k: v.grad for k, v in Pr.items() if torch.is_tensor(v) and v.requires_grad}
+
+    y32, gx32, g32 = run_oracle(None)
+    y16, gx16, g16 = run_oracle(blocks.bf16_storage)
+    m = m.to(dev)
+    m._draw_drop_mask = lambda B_, C_, dtype, device: mask.to(device)
+    flags = []
+    orig = _ops.tblock3d_forward
+
+    def spy(*a, **k):
+        flags.append(bool(a[11]) if len(a) > 11 else bool(k.get("lka_bf16", False)))
+        return orig(*a, **k)
+
+    _ops.tblock3d_forward = spy
+    try:
+        if via_autocast:
+            xd = x.to(dev).requires_grad_(True)
+            with torch.autocast(torch.device(dev).type, dtype=torch.bfloat16):
+                y = m(xd)
+        else:
+            xd = x.to(dev).bfloat16().requires_grad_(True)
+            y = m(xd)
+    finally:
+        _ops.tblock3d_forward = orig
+    assert flags == [True], f"the wrapper block did not select its mixed bf16 mode: {flags}"
+    assert y.dtype == torch.float32
+    y.backward(gy.to(dev))
+    errs = {"y": rel_err(y, y32), "gx": rel_err(xd.grad, gx32)}
+    errs16 = {"y": rel_err(y, y16), "gx": rel_err(xd.grad, gx16)}
+    for k, p_ in m.named_parameters():
+        assert p_.grad is not None and p_.grad.dtype == torch.float32, k
+        if g32.get(k) is not None and g32[k].abs().max() > 0:
+            errs[k] = rel_err(p_.grad, g32[k])
+            errs16[k] = rel_err(p_.grad, g16[k])
+    if report or os.environ.get("DLKA_PARITY_VERBOSE"):
+        worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+        print(f"[tblock mixed bf16 C={C} dims={dims}] worst vs fp32 oracle: " + " ".join(f"{k.split('.')[-2:]}={v:.1e}" for k, v in worst))
+    for k in errs:
+        assert errs[k] <= rtol, f"tblock mixed bf16 {k}: rel err vs fp32 oracle {errs[k]:.3e} > {rtol}"
+        assert errs16[k] <= rtol, f"tblock mixed bf16 {k}: rel err vs the bf16-storage model {errs16[k]:.3e} > {rtol}"
+    return errs

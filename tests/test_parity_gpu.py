@@ -422,6 +422,13 @@ def test_tblock3d_vs_oracle(C, dims, training, pos):
     parity.check_tblock3d(DEV, 2, C, dims, training, pos)
 
 
+@pytest.mark.parametrize("C,dims", [(32, (32, 32, 32)), (64, (16, 16, 16)), (128, (8, 8, 8)), (256, (4, 4, 4))])
+def test_tblock3d_mixed_bf16_real_shapes(C, dims):
+    """The wrapper block under torch.autocast(bfloat16) at the four stage shapes of the 64x128x128 patch: fp32 wrapper, DLKA_BF16 attention inside
+    (dlka_tblock3d_* dtype = DLKA_BF16) — output and every gradient within 2e-2 of the fp32 oracle block and of the bf16-storage model."""
+    parity.check_tblock3d_mixed_bf16(DEV, 2, C, dims, report=True)
+
+
 def test_tblock3d_chain():
     parity.check_tblock3d(DEV, 1, 32, (6, 8, 10), True, True, chain=True)
 
