@@ -166,6 +166,8 @@ struct DeformBwdArgs {
     const float *off;   // [B][3K][N] planar
     const float *g;     // [M][Cout] channels-last grad_out
     const float *wp;    // [K][CoutP][C]: wp[tap][co][ci] = W[co][ci][tap], rows co >= Cout are zero
+    const float *wp16;  // optional (act_bf16): the same weights as two-term bf16 records (prep mode 2 | 8: unit (tap, co / 32) = [part][mf][h][C][8], k = co) — the
+                        //   grad_offset kernels then form Col on v_mfma_f32_32x32x16_bf16 and read no LDS weight tile; null = fp32-input MFMA from wp
     float *gx;          // [B][N][C] fp32, zero-initialised (atomics)
     float *goff;        // [B][3K][N] planar
     float *samp;        // optional [K][M][C], fp32 (bf16 when act_bf16): the grad_offset kernel also stores the trilinear samples S(m, tap, c) it has the corners of —

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64) void cl_ddw2d_gx3_kernel(Ddw2dArgs p, int ntx, 
                     const int ry = y0 - ty0, rx = x0 - tx0;
                     const bool vy0 = (y0 >= 0) & (ry >= 0) & (ry < GX3_TY), vy1 = (y0 + 1 <= p.H - 1) & (ry + 1 >= 0) & (ry + 1 < GX3_TY);
                     const bool vx0 = (x0 >= 0) & (rx >= 0) & (rx < GX3_TX), vx1 = (x0 + 1 <= p.W - 1) & (rx + 1 >= 0) & (rx + 1 < GX3_TX);
-                    vm = (vy0 & vx0 ? 1 : 0) | (vy0 & vx1 ? 2 : 0) | (vy1 & vx0 ? 4 : 0) | (vy1 & vx1 ? 8 : 0);
+                    vm = ((vy0 & vx0) ? 1 : 0) | ((vy0 & vx1) ? 2 : 0) | ((vy1 & vx0) ? 4 : 0) | ((vy1 & vx1) ? 8 : 0);
                     const float hy = 1.f - ly, hx = 1.f - lx;
                     w00 = (vm & 1) ? hy * hx : 0.f; w01 = (vm & 2) ? hy * lx : 0.f; w10 = (vm & 4) ? ly * hx : 0.f; w11 = (vm & 8) ? ly * lx : 0.f;
                     cell = ry * GX3_TX + rx;   // (of the low corner; may be "negative": only the corners in vm are addressed)

@@ -52,13 +52,18 @@ constexpr int TG = 8;     // taps per MFMA row group (TG * CS = 32 MFMA rows)
 //  ran one wave per SIMD and was no faster than the first kernel.)
 // ---------------------------------------------------------------------------------------------------------------------
 // SAMP: also store the samples S[tap][m][c] (DeformBwdArgs::samp) for the weight gradient (the launcher picks NKC_REG by measurement).
-template <int NKC_REG, typename T = float, bool SAMP = false>   // T: storage of `in` and `g` (channels-last); offsets / grad_offset are fp32 planar
+// B16 (T = bf16_t, p.wp16 set): Col on the bf16 matrix cores.  The grad_out row of a voxel is bf16 in memory, 16 contiguous bytes ARE the MFMA B operand of a
+// k-group (channels 16 h + 8 mf .. + 7: raw words, no conversion); the weights come as two-term bf16 records (hi + lo) that each lane reads from L2 with 16-byte
+// loads — no LDS weight tile, no workgroup barrier per (tap, chunk) stage; 4 v_mfma_f32_32x32x16_bf16 per stage instead of 16 v_mfma_f32_32x32x2_f32
+// (128 against 1024 matrix-pipe cycles).  The D layout is the same, so everything behind the contraction is unchanged.
+template <int NKC_REG, typename T = float, bool SAMP = false, bool B16 = false>   // T: storage of `in` and `g` (channels-last); offsets / grad_offset are fp32 planar
 __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p, int taps_per_block)
 {
+    static_assert(!B16 || sizeof(T) == 2, "B16 needs bf16 activations");
     constexpr unsigned XB = sizeof(T);
     const T *gin = reinterpret_cast<const T *>(p.g);
     constexpr int SROW = 36;
-    __shared__ __attribute__((aligned(16))) float Bs2[2][32 * 32];          // W[tap][co chunk][ci chunk], double buffered
+    __shared__ __attribute__((aligned(16))) float Bs2[B16 ? 1 : 2][B16 ? 4 : 32 * 32];          // W[tap][co chunk][ci chunk], double buffered (fp32-input MFMA only)
     __shared__ __attribute__((aligned(16))) float Tsm[4][3][32 * SROW];     // per wave: derivative-sample tiles (d, h, w)
     __shared__ __attribute__((aligned(16))) float Dsm[4][32 * GATHER_DESC_WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -90,8 +95,23 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
         float *dst = p.goff + ((long)b * p.goff_cpad + 3 * p.K) * p.N + v;
         for (int c = 3 * p.K; c < p.goff_cpad; ++c, dst += p.N) *dst = 0.f;
     }
-    float greg[NKC_REG > 0 ? NKC_REG : 1][16];
-    if (NKC_REG > 0) {
+    // B16: this lane's grad_out operands as raw words — [kc][mf] = channels kc * 32 + 16 h + 8 mf .. + 7 of voxel j
+    f32x4 graw[(B16 && NKC_REG > 0) ? NKC_REG : 1][2];
+    auto load_graw = [&](int kc, f32x4 out[2]) {
+        const bool okg = row_ok && kc < nkc && kc * 32 + 16 * h < p.Cout;
+        const bf16_t *gp_ = reinterpret_cast<const bf16_t *>(p.g) + (okg ? (long)m * p.Cout + kc * 32 + 16 * h : 0);
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(gp_ + 8 * mf);
+            out[mf][0] = okg ? t[0] : 0.f; out[mf][1] = okg ? t[1] : 0.f; out[mf][2] = okg ? t[2] : 0.f; out[mf][3] = okg ? t[3] : 0.f;
+        }
+    };
+    if (B16 && NKC_REG > 0) {
+#pragma unroll
+        for (int kc = 0; kc < NKC_REG; ++kc) load_graw(kc, graw[kc]);
+    }
+    float greg[(NKC_REG > 0 && !B16) ? NKC_REG : 1][16];
+    if (NKC_REG > 0 && !B16) {
 #pragma unroll
         for (int kc = 0; kc < NKC_REG; ++kc) {
             const bool okg = row_ok && kc < nkc && kc * 32 + 16 * h < p.Cout;
@@ -137,11 +157,18 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
     // weight tile of stage s = (tap, cc, kc) in flight in a register while the previous stage computes
     const int nstage = (tap_hi - tap_lo) * ncb * nkc;
     f32x4 wreg;
+    f32x4 wrec[B16 ? 4 : 1];   // B16: this lane's four records (hi / lo x k-group) of the stage in flight: [part * 2 + mf]
     auto load_w = [&](int s) {
         int kc, ccr;
         const int sq = divmod_fast(s, nkc, kc);
         const int tq = divmod_fast(sq, ncb, ccr);
         const int cc = cc_lo + ccr, tap = tap_lo + tq;
+        if (B16) {
+            const float *src = p.wp16 + ((long)tap * p.CoutP + kc * 32) * p.C;   // unit (tap, kc): [part][mf][h][C][8 bf16]
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wrec[q] = *reinterpret_cast<const f32x4 *>(src + ((long)(q * 2 + h) * p.C + cc * 32 + j) * 4);
+            return;
+        }
         const int rr = tid >> 3, c4 = tid & 7;
         wreg = *(reinterpret_cast<const f32x4 *>(p.wp + ((long)tap * p.CoutP + kc * 32 + rr) * p.C + cc * 32) + c4);
     };
@@ -162,6 +189,24 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll 1
             for (int kc = 0; kc < nkc; ++kc) {
+                if (B16) {
+                    bf16x8 wa[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float w4[4] = {wrec[q][0], wrec[q][1], wrec[q][2], wrec[q][3]}; wa[q] = bf16x8_from_words(w4); }
+                    ++stage;
+                    if (stage < nstage) load_w(stage);
+                    f32x4 gl2[2];
+                    if (NKC_REG == 0) load_graw(kc, gl2);
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf) {
+                        const f32x4 gsel = NKC_REG == 0 ? gl2[mf] : (NKC_REG == 1 ? graw[0][mf] : (kc == 0 ? graw[0][mf] : graw[NKC_REG > 1 ? 1 : 0][mf]));
+                        const float g4[4] = {gsel[0], gsel[1], gsel[2], gsel[3]};
+                        const bf16x8 gb = bf16x8_from_words(g4);
+                        acc = mfma_32x32x16_bf16(wa[mf], gb, acc);        // hi term of the weights
+                        acc = mfma_32x32x16_bf16(wa[2 + mf], gb, acc);    // lo term
+                    }
+                    continue;
+                }
                 float *Bs = Bs2[stage & 1];
                 reinterpret_cast<f32x4 *>(Bs)[tid] = wreg;
                 ++stage;
@@ -1224,11 +1269,20 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         else if (a.samp) { auto k = cl_deform_goff2_kernel<0, TT, true>; DLKA_LAUNCH(k, grid, block, 0, st, ag, tpb); }       \
         else { auto k = cl_deform_goff2_kernel<NK, TT, false>; DLKA_LAUNCH(k, grid, block, 0, st, ag, tpb); }                 \
     }
-            if (a.act_bf16) {
+#define DLKA_GOFF2_B16(NK)                                                                                                           \
+    {                                                                                                                                \
+        if (a.samp) { auto k = cl_deform_goff2_kernel<NK, bf16_t, true, true>; DLKA_LAUNCH(k, grid, block, 0, st, ag, tpb); }        \
+        else { auto k = cl_deform_goff2_kernel<NK, bf16_t, false, true>; DLKA_LAUNCH(k, grid, block, 0, st, ag, tpb); }              \
+    }
+            if (a.act_bf16 && a.wp16) {   // Col on the bf16 matrix cores (two-term weight records, raw grad_out words)
+                if (nkc == 1) DLKA_GOFF2_B16(1) else if (nkc == 2) DLKA_GOFF2_B16(2) else DLKA_GOFF2_B16(0)
+            }
+            else if (a.act_bf16) {
                 if (nkc == 1) DLKA_GOFF2(1, bf16_t) else if (nkc == 2) DLKA_GOFF2(2, bf16_t) else DLKA_GOFF2(0, bf16_t)
             }
             else if (nkc == 1) DLKA_GOFF2(1, float) else if (nkc == 2) DLKA_GOFF2(2, float) else DLKA_GOFF2(0, float)
 #undef DLKA_GOFF2
+#undef DLKA_GOFF2_B16
         }
         DLKA_CHECK_LAUNCH();
     }

@@ -348,6 +348,178 @@ __global__ __launch_bounds__(512, 4) void cl_deform_fwd16_kernel(IgemmArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// DLKA_BF16 with the contraction on the bf16 matrix cores (round 4).  The kernels above feed v_mfma_f32_32x32x2_f32 / 16x16x4_f32 also when the
+// activations are bf16: 16 (resp. 8) MFMAs of 64 cycles per (32-row tile, tap, 32-channel chunk), i.e. the fp32-input rate — 1/16 of what a bf16
+// operand is entitled to.  Here
+//   * the interpolated sample tile goes into the wave's LDS tile AS bf16 (one 8-byte store per 4 channels: half the LDS bytes) and comes back as the
+//     MFMA A operand in ONE 16-byte read per k-group (lane (i, h), group mf: channels 16 h + 8 mf .. + 7 — the k order is permuted identically on
+//     both operands);
+//   * the weights are prepared as two-term bf16 records (cl_igemm.hip prep_store, mode | 8: w = hi + lo to 2^-17; [part][mf][h][n][8]) and read by
+//     each lane straight from L2 with 16-byte loads — the B operand needs no LDS tile, hence no workgroup barrier per unit; the next unit's records
+//     are requested before the current unit's MFMAs;
+//   * per unit and 32-column tile: 4 v_mfma_f32_32x32x16_bf16 (hi and lo term for two k-groups) = 128 matrix-pipe cycles instead of 1024.
+// Accumulation, bias and epilogue as above (fp32).  Same sampling rule, same fmaf order of the interpolation; the sample is rounded to bf16 once (it
+// is a bf16-STORED activation's interpolation — the rounding is inside the 2e-2 contract of the bf16 path, measured with the parity tests).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void cl_deform_fwd_b16_kernel(IgemmArgs p)
+{
+    using T = bf16_t;
+    constexpr unsigned SB = 2;
+    constexpr int SROWW = 20;   // sample-tile row in 32-bit words: 32 bf16 = 16 words + 4 of padding (80 bytes: 16-byte aligned rows)
+    __shared__ __attribute__((aligned(16))) unsigned Ssm[4][32 * SROWW];
+    __shared__ __attribute__((aligned(16))) float Dsm[4][32 * GATHER_DESCW_WORDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;      // MFMA roles
+    using GG = GatherGeom<T>;
+    const int gr = lane >> GG::PSHIFT, gp = lane & ((1 << GG::PSHIFT) - 1);   // gather roles: row gr of each group of RPI, 16-byte piece gp
+    const int bx = DLKA_XCD_BX(p.xcd_nx);
+    if (bx < 0) return;
+    const int mbase = (bx * 4 + wave) * 32;
+    const int m = mbase + i;
+    const bool row_ok = m < p.M;
+    const int b = row_ok ? m / p.N : 0;
+    const int v = row_ok ? m - b * p.N : 0;
+    const int w0 = v % p.W, h0 = (v / p.W) % p.H, d0 = v / (p.W * p.H);
+    const int n0 = blockIdx.z * NT * 32;
+    const int HW = p.H * p.W, rowbytes = p.Cin * SB;
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * SB);
+    unsigned *S = Ssm[wave];
+    float *Dt = Dsm[wave];
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int nchunk = p.CinP / 32;
+    const int unit_lo = blockIdx.y * p.units_per_split;
+    const int unit_hi = min(p.K * nchunk, unit_lo + p.units_per_split);
+
+    // weight records of a unit (tap, chunk): 32 * NP floats = [part (hi, lo)][mf][h][NP][8 bf16]
+    f32x4 breg[NT][4];   // [t][part * 2 + mf]: this lane's records of the NEXT unit, in flight
+    auto load_b = [&](int unit) {
+        const float *src = p.wp + (long)unit * 32 * p.NP;   // (unit = tap * nchunk + chunk: the prepared layout's own unit order)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) breg[t][q] = *reinterpret_cast<const f32x4 *>(src + ((long)(q * 2 + h) * p.NP + n0 + 32 * t + i) * 4);
+    };
+    GatherPiece<T> xr[GG::NG][8];   // gathered corner pieces of the next unit, in flight
+    int cur_tap = -1;
+    float onx[3] = {0.f, 0.f, 0.f};
+    const int tap_first = unit_lo / nchunk, tap_last = (unit_hi - 1) / nchunk;
+    auto load_offsets = [&](int tap) {
+        if (h == 0 && row_ok && tap <= tap_last) {
+            const float *op = p.off + ((long)b * 3 * p.K + 3 * tap) * p.N + v;
+            onx[0] = op[0]; onx[1] = op[p.N]; onx[2] = op[2 * (long)p.N];
+        }
+    };
+    if (unit_lo < unit_hi) load_offsets(tap_first);
+    auto issue = [&](int unit) {
+        int ck;
+        const int tap = divmod_fast(unit, nchunk, ck);
+        if (tap != cur_tap) {   // uniform
+            cur_tap = tap;
+            int ti, tj, tk;
+            tap_decode(tap, p.kw, p.kh, ti, tj, tk);
+            wave_sync();        // every lane has consumed the previous table
+            if (h == 0) {
+                RowDesc r;
+                r.base = 0; r.okm = 0; r.ld = r.lh = r.lw = 0.f;
+                if (row_ok)
+                    r = gather_describe3(onx[0], onx[1], onx[2], p.N, b, d0 + ti * p.dd - p.pd, h0 + tj * p.dh - p.ph, w0 + tk * p.dw - p.pw, p.D, p.H, p.W);
+                gather_publish_w(Dt, i, r, rowbytes);
+            }
+            load_offsets(tap + 1);
+            wave_sync();
+        }
+        const unsigned cbyte = (unsigned)(ck * 32 + GG::PE * gp) * SB;
+#pragma unroll
+        for (int g = 0; g < GG::NG; ++g) {
+            const RowLook r = gather_lookup_d(Dt, GG::RPI * g + gr);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xr[g][q] = gather_load<T>(rin, gather_offset(r, q, HW, p.W, rowbytes, cbyte));
+        }
+    };
+    // interpolate (fp32), round once, store the tile as bf16, read this lane's two A operands back
+    auto finish = [&](bf16x8 a[2]) {
+        wave_sync();   // previous tile consumed
+#pragma unroll
+        for (int g = 0; g < GG::NG; ++g) {
+            float wq[8];
+            gather_lookup_weights(Dt, GG::RPI * g + gr, wq);
+#pragma unroll
+            for (int vv = 0; vv < GG::PE / 4; ++vv) {
+                f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f32x4 x4 = xr[g][q].get(vv);
+                    s4[0] = fmaf(wq[q], x4[0], s4[0]); s4[1] = fmaf(wq[q], x4[1], s4[1]);
+                    s4[2] = fmaf(wq[q], x4[2], s4[2]); s4[3] = fmaf(wq[q], x4[3], s4[3]);
+                }
+                const unsigned long long pk = (unsigned long long)((unsigned)bf16_bits(s4[0]) | ((unsigned)bf16_bits(s4[1]) << 16)) |
+                                              ((unsigned long long)((unsigned)bf16_bits(s4[2]) | ((unsigned)bf16_bits(s4[3]) << 16)) << 32);
+                *reinterpret_cast<unsigned long long *>(S + (GG::RPI * g + gr) * SROWW + (GG::PE * gp + 4 * vv) / 2) = pk;   // (8-byte aligned: even word index)
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(S + i * SROWW + 8 * h + 4 * mf);   // channels 16 h + 8 mf .. + 7
+            const float w4[4] = {t[0], t[1], t[2], t[3]};
+            a[mf] = bf16x8_from_words(w4);
+        }
+    };
+
+    if (unit_lo < unit_hi) {
+        load_b(unit_lo);
+        issue(unit_lo);
+    }
+    for (int unit = unit_lo; unit < unit_hi; ++unit) {
+        bf16x8 a_cur[2];
+        finish(a_cur);      // consumes xr (the loads issued one iteration ago)
+        bf16x8 bcur[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float w4[4] = {breg[t][q][0], breg[t][q][1], breg[t][q][2], breg[t][q][3]};
+                bcur[t][q] = bf16x8_from_words(w4);
+            }
+        if (unit + 1 < unit_hi) {
+            load_b(unit + 1);
+            issue(unit + 1);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                acc[t] = mfma_32x32x16_bf16(a_cur[mf], bcur[t][mf], acc[t]);       // hi term
+                acc[t] = mfma_32x32x16_bf16(a_cur[mf], bcur[t][2 + mf], acc[t]);   // lo term
+            }
+    }
+
+    // ---- epilogue: D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
+    const bool split = gridDim.y > 1;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + t * 32 + i;
+        if (n >= p.Cout) continue;
+        const float bv = (p.bias && blockIdx.y == 0) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = mbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (mr >= p.M) continue;
+            const float val = acc[t][r] + bv;
+            if (split) atomicAdd(p.out + (long)mr * p.Cout + n, val);   // fp32 accumulation buffer (the launcher's caller casts it)
+            else act_store1(reinterpret_cast<T *>(p.out), (long)mr * p.Cout + n, val);
+        }
+    }
+}
+
 int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
 {
     if ((long)a.M * a.Cin * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
@@ -369,6 +541,19 @@ int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
     else if (a.M <= 2048 && NT_total == 4) NT = 2;
     constexpr int nt_env = 0;
     if (nt_env == 1 || nt_env == 2 || nt_env == 4) { if (NT_total % nt_env == 0 && nt_env <= NT_total) NT = nt_env; }
+    if (a.act_bf16 && a.split_bf16 == 2) {   // weights in two-term bf16 records: the contraction runs on the bf16 matrix cores (all stages)
+        dim3 gridb(mblocks, splits, NT_total / NT), blockb(256);
+        a.xcd_nx = 0;
+        if (xcd_swizzle_enabled() && mblocks >= (unsigned)xcd_min_blocks()) { a.xcd_nx = mblocks; gridb.x = xcd_grid(mblocks); }
+        switch (NT) {
+            case 1: { auto k = cl_deform_fwd_b16_kernel<1>; DLKA_LAUNCH(k, gridb, blockb, 0, st, a); } break;
+            case 2: { auto k = cl_deform_fwd_b16_kernel<2>; DLKA_LAUNCH(k, gridb, blockb, 0, st, a); } break;
+            case 4: { auto k = cl_deform_fwd_b16_kernel<4>; DLKA_LAUNCH(k, gridb, blockb, 0, st, a); } break;
+            default: return DLKA_ERR_UNSUPPORTED;
+        }
+        DLKA_CHECK_LAUNCH();
+        return DLKA_OK;
+    }
     // 16-row waves where the 32-row tiling leaves the chip at two waves per SIMD and the output is one 32-column tile (stage 0: C = 32)
     {
         // Measured (profiles/r04_notes.md): 81 vs 94 us at C = 32 / 32^3 (fp32; 75 vs 86 bf16); no gain at the smaller stages with the

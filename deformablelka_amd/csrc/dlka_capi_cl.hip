@@ -230,15 +230,27 @@ int dw_backward_weight(const SameConv &s, const float *x, const float *gout, flo
 }
 
 // ---- deformable (groups = deformable_groups = 1) ---------------------------------------------------------------------
+// DLKA_BF16: the deformable conv's contractions on v_mfma_f32_32x32x16_bf16 (round 4).  ONE process-wide switch, read once: DLKA_DEFORM_B16=0 keeps the
+// fp32-input MFMA of rounds 2 - 3 (A/B runs).  It decides the layout of the prepared weights AND the kernel that reads them, so it must not change between
+// a weight preparation and its use — hence cached.
+static bool deform_b16()
+{
+    static const bool on = [] { const char *e = getenv("DLKA_DEFORM_B16"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 bool deform_supported(const SameConv &s) { return s.group == 1 && s.Cin % 32 == 0 && s.Cout % 32 == 0 && nt_ok(s.Cout) && nt_ok(s.Cin); }
 
 // bf16 storage with a tap split: `acc32` (fp32 [M][Cout], ZEROED by the caller) receives the partial sums and is converted into `out`
 int deform_forward(const SameConv &s, const float *x, const float *off, const float *w, const float *bias, float *out, float *wp, hipStream_t st,
                    bool zeroed = false, float *acc32 = nullptr)
 {
-    if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, s.Cout, 0, st));
+    // DLKA_BF16: the contraction runs on the bf16 matrix cores — weights as two-term bf16 records (prep mode | 8; deform_b16() = 0 keeps the fp32-input MFMA)
+    const int b16 = (s.act_bf16 && deform_b16()) ? 1 : 0;
+    if (w) DLKA_TRY(launch_cl_prep_weight(w, wp, s.Cout, s.Cin, s.K, s.Cin, s.Cout, b16 ? 8 : 0, st));
     IgemmArgs a;
     fill_igemm(a, s);
+    a.split_bf16 = b16 ? 2 : 0;
     a.in = x; a.off = off; a.wp = wp; a.bias = bias; a.out = out; a.epi = 0; a.out_zeroed = zeroed ? 1 : 0;
     a.Cin = s.Cin; a.CinReal = s.Cin; a.CinP = s.Cin; a.Cout = s.Cout; a.NP = s.Cout;
     const int splits = dense_forward_splits(s, 0);
@@ -279,7 +291,7 @@ int deform_bwd_variant() { return 0; }   // (two earlier generations — one fus
 
 int deform_backward(const SameConv &s, const float *x, const float *off, const float *w, const float *gout, float *gx, float *goff,
                     float *gw, float *gb, float *wp, float *part, float *scratch, hipStream_t st, FinalizeJob *defer = nullptr, bool gx_zeroed = false,
-                    bool goff_zeroed = false, int goff_cpad = 0, float *samp = nullptr)
+                    bool goff_zeroed = false, int goff_cpad = 0, float *samp = nullptr, const float *wp16 = nullptr)
 {
     // samp ([K][M][C] fp32): a grad_offset call stores the trilinear samples there, a weight-gradient call reads them instead of gathering again
     if (gx || goff) {
@@ -288,6 +300,7 @@ int deform_backward(const SameConv &s, const float *x, const float *off, const f
         fill_deform_bwd(a, s);
         a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff; a.gx_zeroed = gx_zeroed ? 1 : 0; a.goff_zeroed = goff_zeroed ? 1 : 0; a.goff_cpad = goff_cpad;
         a.samp = goff ? samp : nullptr;
+        a.wp16 = (s.act_bf16 && deform_b16()) ? wp16 : nullptr;   // (prepared by the caller: two-term bf16 records, mode 2 | 8)
         DLKA_TRY(launch_cl_deform_bwd2(a, scratch, st));
     }
     if (gw) {
@@ -424,7 +437,7 @@ struct TokGeoms {
     size_t dcn_floats() const { return dense_wp_floats(dcn); }
     size_t dw5_floats() const { return (size_t)dw5.K * dw5.Cin; }
     size_t dw7_floats() const { return (size_t)dw7.K * dw7.Cin; }
-    size_t prep_floats() const { return 6 * pw_floats() + 2 * offc_floats() + 2 * dcn_floats() + 2 * dw5_floats() + 2 * dw7_floats() + 16 * 64; }
+    size_t prep_floats() const { return 6 * pw_floats() + 2 * offc_floats() + 3 * dcn_floats() + 2 * dw5_floats() + 2 * dw7_floats() + 17 * 64; }
     // weight-gradient partials: every gradient of the block has its own area (folded by one fused launch at the end)
     size_t part_pw() const { return (cl_wgrad_part_floats_mode(pw.M, 1, pw.Cin, pw.Cin, 0) + 63) & ~(size_t)63; }
     size_t part_off() const { return (cl_wgrad_part_floats_mode(pw.M, 27, 81, pw.Cin, 0) + 63) & ~(size_t)63; }
@@ -437,6 +450,7 @@ struct TokGeoms {
 struct TokPrep {
     float *pw_f[3], *pw_b[3];   // proj_1, conv1, proj_2: forward (mode 0) / data-gradient (mode 1) layouts
     float *off_f, *off_b, *dcn_f, *dcn_b, *dw5_f, *dw5_b, *dw7_f, *dw7_b;
+    float *dcn_b16;   // bf16 path: the deformable conv's column-matrix weights as two-term bf16 records (grad_offset / grad_input on the bf16 matrix cores)
 };
 
 void add_job(PrepBatch &pb, const void *src, float *dst, int Cout, int Cin, int K, int KP, int NP, int mode)
@@ -457,6 +471,7 @@ int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_para
     t.dcn_f = take(G.dcn_floats()); t.dcn_b = take(G.dcn_floats());
     t.dw5_f = take(G.dw5_floats()); t.dw5_b = take(G.dw5_floats());
     t.dw7_f = take(G.dw7_floats()); t.dw7_b = take(G.dw7_floats());
+    t.dcn_b16 = take(G.dcn_floats());
     if (!fill) return DLKA_OK;
     PrepBatch pb;
     memset(&pb, 0, sizeof(pb));
@@ -468,8 +483,9 @@ int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_para
     }
     add_job(pb, p->offset_w, t.off_f, 81, C, 27, C, 96, split_mode_flag(use_split(G.offc_f, true)));   // (fp32 A operand on both paths)
     add_job(pb, p->offset_w, t.off_b, 81, C, 27, 96, C, use_split(G.offc, false) ? 9 : 1);
-    add_job(pb, p->deform_w, t.dcn_f, C, C, 27, C, C, 0);
+    add_job(pb, p->deform_w, t.dcn_f, C, C, 27, C, C, (G.dcn.act_bf16 && deform_b16()) ? 8 : 0);   // bf16 path: two-term records for cl_deform_fwd_b16_kernel
     add_job(pb, p->deform_w, t.dcn_b, C, C, 27, C, C, 2);
+    if (G.dcn.act_bf16 && deform_b16()) add_job(pb, p->deform_w, t.dcn_b16, C, C, 27, C, C, 2 | 8);
     add_job(pb, p->conv0_w, t.dw5_f, C, C, G.dw5.K, 0, 0, 3);
     add_job(pb, p->conv0_w, t.dw5_b, C, C, G.dw5.K, 0, 0, 4);
     add_job(pb, p->conv_spatial_w, t.dw7_f, C, C, G.dw7.K, 0, 0, 3);
@@ -1402,7 +1418,7 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
     if (!samp)
         DLKA_P2(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
                                 &fb.j[fb.njobs++]));
-    DLKA_P1(deform_backward(G.dcn, t, off, N0, gf, nullptr, goff, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, false, true, goff_cpad, samp));
+    DLKA_P1(deform_backward(G.dcn, t, off, N0, gf, nullptr, goff, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, false, true, goff_cpad, samp, PW.dcn_b16));
     DLKA_TRY(publish());
     if (samp)
         DLKA_P2(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
