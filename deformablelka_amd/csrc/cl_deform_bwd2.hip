@@ -333,9 +333,14 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
 // Same arithmetic per (voxel, tap, channel) as the kernel above (same separable interpolation, same sample stored for the weight gradient); the
 // order of the channel sum differs (rounding only).
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, bool SAMP, int WAVES, int OCC>   // WAVES per workgroup (4 | 8), OCC = waves per SIMD the register budget is set for
+// B16 (T = bf16_t, p.wp16 set): Col on v_mfma_f32_16x16x32_bf16 — ONE instruction contracts all 32 grad_out channels of a 16 x 16 tile.  A = the weights'
+// two-term bf16 records (prep mode 2 | 8; the records of ci = 2 i and 2 i + 1 are adjacent: one 32-byte read per term), read by every lane from L2 — no LDS
+// weight tile, no workgroup barrier per tap; B = the 16 bytes of the voxel's bf16 grad_out row that hold channels 8 g4 .. 8 g4 + 7, as loaded.  4 MFMAs per tap
+// instead of 16; the D layout is that of v_mfma_f32_16x16x4_f32, so everything behind the contraction is unchanged.
+template <typename T, bool SAMP, int WAVES, int OCC, bool B16 = false>   // WAVES per workgroup (4 | 8), OCC = waves per SIMD the register budget is set for
 __global__ __launch_bounds__(64 * WAVES, OCC) void cl_deform_goff16_kernel(DeformBwdArgs p)
 {
+    static_assert(!B16 || sizeof(T) == 2, "B16 needs bf16 activations");
     constexpr unsigned XB = sizeof(T);
     constexpr int TGRP = 4;
     constexpr int PE = 16 / XB;            // channels per 16-byte piece: 4 (fp32) | 8 (bf16)
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void cl_deform_goff16_kernel(Defor
     constexpr int TP = CPP / 16;           // 16-row MFMA tiles per pass: 1 | 2
     constexpr int SROW = CPP + 4;          // padded Col tile row (floats)
     const T *gin = reinterpret_cast<const T *>(p.g);
-    __shared__ __attribute__((aligned(16))) float Bs2[2][32 * 32];                          // W[tap][co][ci], double buffered
+    __shared__ __attribute__((aligned(16))) float Bs2[B16 ? 1 : 2][B16 ? 4 : 32 * 32];      // W[tap][co][ci], double buffered (fp32-input MFMA only)
     __shared__ __attribute__((aligned(16))) float Csm[WAVES][16 * SROW];                    // per wave: Col[row][channel of the pass]
     __shared__ __attribute__((aligned(16))) float Dsm[WAVES][TGRP * 16 * GATHER_DESC_WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -359,14 +364,21 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void cl_deform_goff16_kernel(Defor
     const BufRsrc rgoff = make_rsrc(p.goff, (size_t)p.B * 3 * p.K * p.N * 4);
     float *Ct = Csm[wave], *Dt = Dsm[wave];
 
-    // B operand of all taps' MFMAs: grad_out[voxel i][co = 8 g4 + s]
+    // B operand of all taps' MFMAs: grad_out[voxel i][co = 8 g4 + s]   (B16: the same eight channels as the four raw words of the bf16 row)
     float greg[8];
+    bf16x8 graw;
     {
         const bool okr = mbase + i < p.M;
         const long gi = okr ? (long)(mbase + i) * p.Cout + 8 * g4 : 0;
-        const f32x4 t0 = act_load4(gin, gi), t1 = act_load4(gin, gi + 4);
+        if (B16) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const bf16_t *>(p.g) + gi);
+            const float w4[4] = {okr ? t[0] : 0.f, okr ? t[1] : 0.f, okr ? t[2] : 0.f, okr ? t[3] : 0.f};
+            graw = bf16x8_from_words(w4);
+        } else {
+            const f32x4 t0 = act_load4(gin, gi), t1 = act_load4(gin, gi + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { greg[e] = okr ? t0[e] : 0.f; greg[4 + e] = okr ? t1[e] : 0.f; }
+            for (int e = 0; e < 4; ++e) { greg[e] = okr ? t0[e] : 0.f; greg[4 + e] = okr ? t1[e] : 0.f; }
+        }
     }
     // where the row this lane reduces (gather role, piece 0) goes: grad_offset is planar, [b][3 K][N]; byte offset of plane 0, DLKA_OOB = no store
     unsigned gbyte = DLKA_OOB;
@@ -414,8 +426,19 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void cl_deform_goff16_kernel(Defor
         for (int q = 0; q < 8; ++q) xr[q] = gather_load<T>(rin, gather_offset(r, q, HW, p.W, rowbytes, cbyte));
     };
     f32x4 wreg = {0.f, 0.f, 0.f, 0.f};
+    f32x4 wrec[B16 ? 4 : 1];   // B16: [part * 2 + t] = the record of (term part, ci = 2 i + t, k-group g4) of the tap in flight
     const bool wload = tid < 256;   // a tap's 32 x 32 weight tile: one 16-byte piece per thread of the first four waves
     auto load_w = [&](int tap) {
+        if (B16) {   // unit (tap, co chunk 0) = [part][mf][h][C = 32][8 bf16], co = 16 h + 8 mf + e = 8 g4 + e  <=>  h = g4 >> 1, mf = g4 & 1
+            const float *src = p.wp16 + (long)tap * p.CoutP * p.C;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const f32x4 *rec = reinterpret_cast<const f32x4 *>(src + ((long)((part * 2 + (g4 & 1)) * 2 + (g4 >> 1)) * p.C + 2 * i) * 4);
+                wrec[part * 2] = rec[0];
+                wrec[part * 2 + 1] = rec[1];
+            }
+            return;
+        }
         if (wload) wreg = *(reinterpret_cast<const f32x4 *>(p.wp + ((long)tap * p.CoutP + (tid >> 3)) * p.C) + (tid & 7));
     };
 
@@ -426,9 +449,15 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void cl_deform_goff16_kernel(Defor
     }
 #pragma unroll 1
     for (int tap = 0; tap < p.K; ++tap) {
-        float *Bs = Bs2[tap & 1];
-        if (wload) reinterpret_cast<f32x4 *>(Bs)[tid] = wreg;
-        __syncthreads();   // this tap's tile staged; the other buffer (read one tap ago) is free for the next
+        float *Bs = Bs2[B16 ? 0 : (tap & 1)];
+        bf16x8 wa[B16 ? 4 : 1];
+        if (B16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float w4[4] = {wrec[q][0], wrec[q][1], wrec[q][2], wrec[q][3]}; wa[q] = bf16x8_from_words(w4); }
+        } else {
+            if (wload) reinterpret_cast<f32x4 *>(Bs)[tid] = wreg;
+            __syncthreads();   // this tap's tile staged; the other buffer (read one tap ago) is free for the next
+        }
         if (tap + 1 < p.K) load_w(tap + 1);
         const RowLook rdg = gather_lookup(Dt + (tap & (TGRP - 1)) * 16 * GATHER_DESC_WORDS, gr);
         float gd = 0.f, gh = 0.f, gw = 0.f;
@@ -438,7 +467,13 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void cl_deform_goff16_kernel(Defor
             f32x4 acc[TP];
 #pragma unroll
             for (int t = 0; t < TP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            {
+            if (B16) {   // tile t <-> ci = 2 i + t (as below); hi and lo term of the weights
+#pragma unroll
+                for (int t = 0; t < TP; ++t) {
+                    acc[t] = mfma_16x16x32_bf16(wa[t], graw, acc[t]);
+                    acc[t] = mfma_16x16x32_bf16(wa[2 + t], graw, acc[t]);
+                }
+            } else {
                 // A[row][k = co = 8 g4 + s].  One tile per pass (fp32): row i <-> ci = 16 pass + i, the lane ends up with channels 4 g4 .. 4 g4 + 3 of
                 // the pass.  Two tiles (bf16): one 8-byte read feeds both, tile t <-> ci = 2 i + t, the lane ends up with channels 8 g4 .. 8 g4 + 7.
                 const float *arow = Bs + (8 * g4) * 32 + (TP == 2 ? 2 * i : CPP * pass + i);
@@ -841,21 +876,32 @@ __device__ __forceinline__ void gx_drain_far(const DeformBwdArgs &p, const float
     wave_sync();   // the queue may be refilled
 }
 
-template <int SW, int SH, int SD, typename T = float, int NKC = 0>   // NKC: 32-channel chunks of a grad_out row known at compile time (1, 2), 0 = up to 4
+// B16 (T = bf16_t): Col on v_mfma_f32_32x32x16_bf16.  The weight tiles of the slice are staged in LDS as bf16 — two terms (hi, lo: w to 2^-17), TRANSPOSED:
+// Bh[grp][term][row (t8, c4)][co], rows padded by 16 bytes — so that the A operand of a k-group is ONE 16-byte LDS read (channels 16 h + 8 mf .. + 7 of
+// the lane's row); the B operand is the 16 bytes of the voxel's bf16 grad_out row with those channels, as loaded (no conversion, half the row registers).
+// 4 MFMAs per (tile, tap group, 32-channel chunk) instead of 16; same D layout, the scatter behind it is unchanged.  gx3_b16_wbytes() = the LDS bytes of the tiles.
+__host__ __device__ __forceinline__ int gx3_b16_rowh(int CoutP) { return CoutP + 8; }   // halfwords per padded row
+__host__ __device__ __forceinline__ size_t gx3_b16_wbytes(int ngroups, int CoutP) { return (size_t)ngroups * 2 * 32 * gx3_b16_rowh(CoutP) * 2; }
+
+template <int SW, int SH, int SD, typename T = float, int NKC = 0, bool B16 = false>   // NKC: 32-channel chunks of a grad_out row known at compile time (1, 2), 0 = up to 4
 __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs p, GxGeom gg, float *__restrict__ scratch)
 {
+    static_assert(!B16 || sizeof(T) == 2, "B16 needs bf16 activations");
     constexpr int PS = SD * SH * SW;   // cells per channel-pair plane
     const T *gin = reinterpret_cast<const T *>(p.g);
     DLKA_DYN_SMEM(unsigned char, smem0);
     unsigned *smax = reinterpret_cast<unsigned *>(smem0);
     unsigned long long *WinI = reinterpret_cast<unsigned long long *>(smem0 + 16);                  // [CS / 2][SD][SH][SW]
-    float *Bs = reinterpret_cast<float *>(smem0 + 16 + (size_t)PS * (CS / 2) * sizeof(double));     // [ngroups][CoutP][32]
+    float *Bs = reinterpret_cast<float *>(smem0 + 16 + (size_t)PS * (CS / 2) * sizeof(double));     // [ngroups][CoutP][32]   (B16: Bh, see above)
+    unsigned short *Bh = reinterpret_cast<unsigned short *>(Bs);
+    const int RH = gx3_b16_rowh(p.CoutP);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     // per-wave queue of the rare samples that leave window + guard ("far"): record = {packed floor cell, ld, lh, lw, Col[4]}.  Handling them on
     // the spot — a divergent branch with 32 global atomics behind it — cost more than the whole regular scatter (311 vs 179 us at 32^3 with
     // ~1-voxel offsets: some lane of most waves is far); queued, they are drained with all 64 lanes busy (lane = (record, corner, channel)).
-    float *Qw = Bs + (size_t)gg.ngroups * p.CoutP * 32 + (size_t)wave * GX_QW * 8;
+    float *Qw = (B16 ? reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(Bs) + gx3_b16_wbytes(gg.ngroups, p.CoutP)) : Bs + (size_t)gg.ngroups * p.CoutP * 32) +
+                (size_t)wave * GX_QW * 8;
     int qcount = 0;   // wave-uniform
     const int bk = DLKA_XCD_BX(gg.xcd_nx);
     if (bk < 0) return;
@@ -885,7 +931,16 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
             const int co = e / TG, t8 = e - co * TG, tap = grp * TG + t8;
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
             if (tap < p.K) val = *reinterpret_cast<const f32x4 *>(p.wp + ((long)tap * p.CoutP + co) * p.C + slice * CS);
-            reinterpret_cast<f32x4 *>(dstB)[e] = val;
+            if (B16) {   // Bh[grp][term][t8*4 + c4][co]: hi and lo term of each weight
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const unsigned short hi = bf16_bits(val[c4]), lo = bf16_bits(val[c4] - bf16_value(hi));
+                    Bh[((size_t)(grp * 2 + 0) * 32 + t8 * 4 + c4) * RH + co] = hi;
+                    Bh[((size_t)(grp * 2 + 1) * 32 + t8 * 4 + c4) * RH + co] = lo;
+                }
+            } else {
+                reinterpret_cast<f32x4 *>(dstB)[e] = val;
+            }
         }
     }
     if (tid < 2) smax[tid] = 0u;
@@ -896,9 +951,14 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
     {
         float wm = 0.f;
         if (tid < gg.ngroups * 32) {
-            const float *col = Bs + (size_t)(tid >> 5) * p.CoutP * 32 + (tid & 31);
             float ss = 0.f;
-            for (int co = 0; co < p.CoutP; ++co) ss = fmaf(col[co * 32], col[co * 32], ss);
+            if (B16) {   // (of the weights the MFMAs will see: hi + lo)
+                const unsigned short *r0 = Bh + ((size_t)((tid >> 5) * 2 + 0) * 32 + (tid & 31)) * RH, *r1 = r0 + (size_t)32 * RH;
+                for (int co = 0; co < p.CoutP; ++co) { const float w = bf16_value(r0[co]) + bf16_value(r1[co]); ss = fmaf(w, w, ss); }
+            } else {
+                const float *col = Bs + (size_t)(tid >> 5) * p.CoutP * 32 + (tid & 31);
+                for (int co = 0; co < p.CoutP; ++co) ss = fmaf(col[co * 32], col[co * 32], ss);
+            }
             wm = sqrtf(ss);
         }
         // largest grad_out row norm of the brick.  One row per THREAD — eight dependent 16-byte loads from 64 different rows per wave instruction —
@@ -966,7 +1026,22 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
     // (loaded at the top of the tile they cost an exposed round trip per tile: 7.6 k of a workgroup's 190 k ticks, twice) — as raw words; the
     // "row outside the brick / chunk beyond Cout" zeroing happens when the tile starts.
     constexpr bool AHEAD = NKC == 1;   // (with more chunks the raw words do not fit next to the scatter's registers: 53 spilled at two chunks)
-    f32x4 graw[AHEAD ? KCMAX : 1][4];
+    f32x4 graw[(AHEAD && !B16) ? KCMAX : 1][4];
+    // B16: the row's MFMA operands as raw words, [kc][mf] = channels kc * 32 + 16 h + 8 mf .. + 7 (always requested a tile ahead when NKC == 1)
+    f32x4 grb[B16 ? KCMAX : 1][2];
+    auto load_rows_b16 = [&](bool ok, int v) {
+#pragma unroll
+        for (int kc = 0; kc < KCMAX; ++kc) {
+            if (kc >= nkc) break;
+            const bool okg = ok && kc * 32 + 16 * h < p.Cout;
+            const bf16_t *gp_ = reinterpret_cast<const bf16_t *>(p.g) + (okg ? ((long)b * p.N + v) * p.Cout + kc * 32 + 16 * h : 0);
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(gp_ + 8 * mf);
+                grb[kc][mf][0] = okg ? t[0] : 0.f; grb[kc][mf][1] = okg ? t[1] : 0.f; grb[kc][mf][2] = okg ? t[2] : 0.f; grb[kc][mf][3] = okg ? t[3] : 0.f;
+            }
+        }
+    };
     auto request_rows = [&](int tile) {
         const int row = tile * 32 + j;
         int rw, rh;
@@ -975,6 +1050,7 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
         const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
         const bool ok = row < R && vd < p.D && vh < p.H && vw < p.W;
         const int v = ok ? (vd * p.H + vh) * p.W + vw : 0;
+        if (B16) { load_rows_b16(ok, v); return; }
 #pragma unroll
         for (int kc = 0; kc < (AHEAD ? KCMAX : 1); ++kc) {
             const bool okg = ok && kc * 32 + 16 * h < p.Cout;
@@ -992,9 +1068,19 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
         const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
         const bool ok = row < R && vd < p.D && vh < p.H && vw < p.W;
         const int v = ok ? (vd * p.H + vh) * p.W + vw : 0;
-        float gl[KCMAX][16];   // this voxel's grad_out row (16 of each 32-channel chunk), loaded once for all tap groups
+        float gl[B16 ? 1 : KCMAX][16];   // this voxel's grad_out row (16 of each 32-channel chunk), loaded once for all tap groups
+        bf16x8 gbo[B16 ? KCMAX : 1][2];   // B16: the same as MFMA operands
+        if (B16) {
+            if (!AHEAD) load_rows_b16(ok, v);
 #pragma unroll
-        for (int kc = 0; kc < KCMAX; ++kc) {
+            for (int kc = 0; kc < KCMAX; ++kc) {
+                if (kc >= nkc) break;
+#pragma unroll
+                for (int mf = 0; mf < 2; ++mf) { const float w4[4] = {grb[kc][mf][0], grb[kc][mf][1], grb[kc][mf][2], grb[kc][mf][3]}; gbo[kc][mf] = bf16x8_from_words(w4); }
+            }
+        }
+#pragma unroll
+        for (int kc = 0; kc < (B16 ? 0 : KCMAX); ++kc) {
             if (kc >= nkc) break;
             const bool okg = ok && kc * 32 + 16 * h < p.Cout;
             const long gi = okg ? ((long)b * p.N + v) * p.Cout + kc * 32 + 16 * h : 0;
@@ -1024,6 +1110,17 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
 #pragma unroll
             for (int kc = 0; kc < KCMAX; ++kc) {
                 if (kc >= nkc) break;
+                if (B16) {
+                    const unsigned short *a0 = Bh + ((size_t)(grp * 2) * 32 + j) * RH + kc * 32 + 16 * h;   // row j = (t8, c4), hi term; lo term 32 rows on
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf) {
+                        const f32x4 th = *reinterpret_cast<const f32x4 *>(a0 + 8 * mf), tl = *reinterpret_cast<const f32x4 *>(a0 + (size_t)32 * RH + 8 * mf);
+                        const float h4[4] = {th[0], th[1], th[2], th[3]}, l4[4] = {tl[0], tl[1], tl[2], tl[3]};
+                        acc = mfma_32x32x16_bf16(bf16x8_from_words(h4), gbo[kc][mf], acc);
+                        acc = mfma_32x32x16_bf16(bf16x8_from_words(l4), gbo[kc][mf], acc);
+                    }
+                    continue;
+                }
                 const float *arow = Bg + (kc * 32 + 16 * h) * 32 + j;   // A[i = (t8, c4) = j][k = co]
 #pragma unroll
                 for (int st = 0; st < 16; ++st) acc = mfma_32x32x2(arow[st * 32], gl[kc][st], acc);
@@ -1249,9 +1346,12 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
                 ag.xcd_nx = 0;
                 if (xcd_swizzle_enabled() && mb16 >= xcd_min_blocks()) { ag.xcd_nx = mb16; grid16.x = xcd_grid(mb16); }
 #define DLKA_G16(TT, SS) { auto k = cl_deform_goff16_kernel<TT, SS, WV, 3>; DLKA_LAUNCH(k, grid16, block16, 0, st, ag); }
-                if (a.act_bf16) { if (a.samp) DLKA_G16(bf16_t, true) else DLKA_G16(bf16_t, false) }
+#define DLKA_G16B(SS) { auto k = cl_deform_goff16_kernel<bf16_t, SS, WV, 3, true>; DLKA_LAUNCH(k, grid16, block16, 0, st, ag); }
+                if (a.act_bf16 && a.wp16) { if (a.samp) DLKA_G16B(true) else DLKA_G16B(false) }   // Col on the bf16 matrix cores
+                else if (a.act_bf16) { if (a.samp) DLKA_G16(bf16_t, true) else DLKA_G16(bf16_t, false) }
                 else { if (a.samp) DLKA_G16(float, true) else DLKA_G16(float, false) }
 #undef DLKA_G16
+#undef DLKA_G16B
                 DLKA_CHECK_LAUNCH();
                 done16 = true;
             }
@@ -1321,13 +1421,13 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         if (hipGetDevice(&dev) != hipSuccess) return DLKA_ERR_LAUNCH;
         const uint64_t bit = 1ull << (dev & 63);
         if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-#define DLKA_FX2_FNS(SWv, SHv, SDv, NK) reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float, NK>), reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, NK>)
-            const void *fns[16] = {reinterpret_cast<const void *>(cl_deform_gx_kernel<false>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true>),
+#define DLKA_FX2_FNS(SWv, SHv, SDv, NK) reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float, NK>), reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, NK>), reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, NK, true>)
+            const void *fns[22] = {reinterpret_cast<const void *>(cl_deform_gx_kernel<false>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true>),
                                    reinterpret_cast<const void *>(cl_deform_gx_kernel<false, bf16_t>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true, bf16_t>),
                                    DLKA_FX2_FNS(18, 10, 14, 0), DLKA_FX2_FNS(18, 10, 14, 1), DLKA_FX2_FNS(18, 10, 14, 2),
                                    DLKA_FX2_FNS(34, 10, 10, 0), DLKA_FX2_FNS(34, 10, 10, 1), DLKA_FX2_FNS(34, 10, 10, 2)};
 #undef DLKA_FX2_FNS
-            for (int f = 0; f < 16; ++f)
+            for (int f = 0; f < 22; ++f)
                 if (hipFuncSetAttribute(fns[f], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DLKA_ERR_LAUNCH;
             attr_done.fetch_or(bit, std::memory_order_release);
         }
@@ -1348,13 +1448,18 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         if (fixed && gl_.resident && !item_grid && !(fx_env && atoi(fx_env) == 2)) {
             auto ext2 = [](int bs, int size) { const int a = size + 2, b = bs + 2 * HALO; return a < b ? a : b; };   // window + guard cells, worst brick
             const int nd = ext2(g.bd, a.D), nh = ext2(g.bh, a.H), nw = ext2(g.bw, a.W);
-            const size_t wbytes = (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
+            const bool b16 = a.act_bf16 && a.wp16 != nullptr;   // (wp16 itself is not read here: the kernel stages its own bf16 tiles from wp)
+            const size_t wbytes = b16 ? gx3_b16_wbytes(g.ngroups, a.CoutP) : (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
             const size_t qbytes = (size_t)8 * GX_QW * 8 * sizeof(float);   // 8 waves x GX_QW far-sample records
 #define DLKA_GX2(SWv, SHv, SDv)                                                                                                    \
     if (nw <= SWv && nh <= SHv && nd <= SDv && 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes + qbytes <= 150 * 1024) {       \
         const size_t lds2 = 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes + qbytes;                                         \
         const int nk_ = a.CoutP / 32;                                                                                              \
-        if (a.act_bf16) {                                                                                                          \
+        if (b16) {                                                                                                                 \
+            if (nk_ == 1) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, 1, true>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }      \
+            else if (nk_ == 2) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, 2, true>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); } \
+            else { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, 0, true>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }               \
+        } else if (a.act_bf16) {                                                                                                   \
             if (nk_ == 1) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, 1>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }      \
             else if (nk_ == 2) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, 2>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); } \
             else { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, 0>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }               \

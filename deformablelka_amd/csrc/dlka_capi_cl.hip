@@ -1425,7 +1425,7 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
                                 &fb.j[fb.njobs++], false, false, 0, samp));
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
     DLKA_P2(dense_backward_weight(G.offc, t, goff, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, ws_, &fb.j[fb.njobs++], goff_cpad));
-    DLKA_P1(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, true));
+    DLKA_P1(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, true, false, 0, nullptr, PW.dcn_b16));
     DLKA_P1(dense_backward_data(G.offc, goff, 1, N0, gt, PW.off_b, 3, gta, st, nullptr, nullptr, true, goff_cpad != 0, true, ga2));
     DLKA_TRY(publish());
     // depthwise 7^3 dil 3:  t = DW7 t1

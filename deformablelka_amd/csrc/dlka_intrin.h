@@ -14,6 +14,7 @@ __device__ __forceinline__ f32x4 mfma_16x16x4(float a, float b, f32x4 c) { retur
 __device__ __forceinline__ int readfirstlane(int v) { return hipemu::readfirstlane(v); }
 typedef hipemu::hipemu_bf16x8 bf16x8;
 __device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return hipemu::mfma_f32_32x32x16bf16(a, b, c); }
+__device__ __forceinline__ f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) { return hipemu::mfma_f32_16x16x32bf16(a, b, c); }
 // a[e] = hi[e] + lo[e] + O(2^-18 |a[e]|): two-term bf16 split of 8 fp32 values
 __device__ __forceinline__ void split_bf16x8(const float *a, bf16x8 &hi, bf16x8 &lo)
 {
@@ -175,6 +176,9 @@ __device__ __forceinline__ int readfirstlane(int v) { return __builtin_amdgcn_re
 // to ~3 * 2^-18 relative (1.1e-5 worst case) at 3/16 of the fp32-input MFMA cost.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+// v_mfma_f32_16x16x32_bf16 (gfx950): lane (i = l&15, g = l>>4) holds A[i][8g..8g+7] and B[8g..8g+7][j = l&15]; D: col = l&15, row = 4 (l>>4) + r — one
+// instruction contracts a whole 32-channel chunk of a 16 x 16 tile.
+__device__ __forceinline__ f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ void split_bf16x8(const float *a, bf16x8 &hi, bf16x8 &lo)
 {
 #pragma unroll

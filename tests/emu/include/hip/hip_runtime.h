@@ -380,6 +380,30 @@ inline hipemu_f32x16 mfma_f32_32x32x16bf16(hipemu_bf16x8 a, hipemu_bf16x8 bv, hi
     return d;
 }
 
+// v_mfma_f32_16x16x32_bf16 (gfx950): lane (i = l&15, g = l>>4) holds A[i][8g .. 8g+7] and B[8g .. 8g+7][j = l&15]; D: col=l&15, row=(l>>4)*4+r
+inline hipemu_f32x4 mfma_f32_16x16x32bf16(hipemu_bf16x8 a, hipemu_bf16x8 bv, hipemu_f32x4 c) {
+    Fiber &f = F(); Block &b = B();
+    const int w0 = (f.lin / WAVE) * WAVE, l = f.lin - w0;
+    unsigned short ab[16];
+    memcpy(ab, a.v, 16); memcpy(ab + 8, bv.v, 16);
+    memcpy(b.xchg[0][f.lin].b, ab, sizeof(ab));
+    f.state = WAVEOP; yield_to_sched();
+    hipemu_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = (l >> 4) * 4 + r, col = l & 15;
+        float acc = c[r];
+        for (int g = 0; g < 4; ++g) {
+            unsigned short A[16], Bm[16];
+            memcpy(A, b.xchg[0][w0 + row + 16 * g].b, sizeof(A));
+            memcpy(Bm, b.xchg[0][w0 + col + 16 * g].b, sizeof(Bm));
+            for (int e = 0; e < 8; ++e) acc += hipemu_bf16_to_f32(A[e]) * hipemu_bf16_to_f32(Bm[8 + e]);
+        }
+        d[r] = acc;
+    }
+    f.state = WAVEOP; yield_to_sched();
+    return d;
+}
+
 // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D: col=l&15, row=(l>>4)*4+r
 inline hipemu_f32x4 mfma_f32_16x16x4f32(float a, float bv, hipemu_f32x4 c) {
     Fiber &f = F(); Block &b = B();
