@@ -56,10 +56,14 @@ constexpr int TG = 8;     // taps per MFMA row group (TG * CS = 32 MFMA rows)
 // k-group (channels 16 h + 8 mf .. + 7: raw words, no conversion); the weights come as two-term bf16 records (hi + lo) that each lane reads from L2 with 16-byte
 // loads — no LDS weight tile, no workgroup barrier per (tap, chunk) stage; 4 v_mfma_f32_32x32x16_bf16 per stage instead of 16 v_mfma_f32_32x32x2_f32
 // (128 against 1024 matrix-pipe cycles).  The D layout is the same, so everything behind the contraction is unchanged.
+// B16 with T = float (round 4): the same on fp32 activations with a TWO-TERM split of the grad_out row (g = hi + lo, formed once per tile in registers — the
+// row is reused by every tap) and the products  W_hi G_hi + W_lo G_hi + W_hi G_lo : each bf16 x bf16 product is exact in fp32, the accumulator is fp32, so Col
+// is reproduced to ~3 * 2^-18 (1.1e-5 worst case, zero-mean) — the rule DESIGN 4.7 applies to the offset conv's gradient contractions; 6 MFMAs of 32 cycles
+// per stage instead of 16 of 64.  Gradients are held to 1e-3; the forward pass keeps the exact fp32-input MFMA.
 template <int NKC_REG, typename T = float, bool SAMP = false, bool B16 = false>   // T: storage of `in` and `g` (channels-last); offsets / grad_offset are fp32 planar
 __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p, int taps_per_block)
 {
-    static_assert(!B16 || sizeof(T) == 2, "B16 needs bf16 activations");
+    constexpr bool SPL = B16 && sizeof(T) == 4;   // fp32 activations, two-term split of grad_out
     constexpr unsigned XB = sizeof(T);
     const T *gin = reinterpret_cast<const T *>(p.g);
     constexpr int SROW = 36;
@@ -95,10 +99,27 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
         float *dst = p.goff + ((long)b * p.goff_cpad + 3 * p.K) * p.N + v;
         for (int c = 3 * p.K; c < p.goff_cpad; ++c, dst += p.N) *dst = 0.f;
     }
-    // B16: this lane's grad_out operands as raw words — [kc][mf] = channels kc * 32 + 16 h + 8 mf .. + 7 of voxel j
-    f32x4 graw[(B16 && NKC_REG > 0) ? NKC_REG : 1][2];
-    auto load_graw = [&](int kc, f32x4 out[2]) {
+    // B16: this lane's grad_out operands — [kc][mf] = channels kc * 32 + 16 h + 8 mf .. + 7 of voxel j: the raw words of a bf16 row, or (SPL) the
+    // hi term of an fp32 row with the lo term in graw_lo
+    f32x4 graw[(B16 && NKC_REG > 0) ? NKC_REG : 1][2], graw_lo[(SPL && NKC_REG > 0) ? NKC_REG : 1][2];
+    auto load_graw = [&](int kc, f32x4 out[2], f32x4 out_lo[2]) {
         const bool okg = row_ok && kc < nkc && kc * 32 + 16 * h < p.Cout;
+        if (SPL) {
+            const float *gp_ = reinterpret_cast<const float *>(p.g) + (okg ? (long)m * p.Cout + kc * 32 + 16 * h : 0);
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                const f32x4 t0 = *reinterpret_cast<const f32x4 *>(gp_ + 8 * mf), t1 = *reinterpret_cast<const f32x4 *>(gp_ + 8 * mf + 4);
+                const float v8[8] = {okg ? t0[0] : 0.f, okg ? t0[1] : 0.f, okg ? t0[2] : 0.f, okg ? t0[3] : 0.f, okg ? t1[0] : 0.f, okg ? t1[1] : 0.f, okg ? t1[2] : 0.f, okg ? t1[3] : 0.f};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned short h0 = bf16_bits(v8[2 * w]), h1 = bf16_bits(v8[2 * w + 1]);
+                    const unsigned short l0 = bf16_bits(v8[2 * w] - bf16_value(h0)), l1 = bf16_bits(v8[2 * w + 1] - bf16_value(h1));
+                    out[mf][w] = __uint_as_float((unsigned)h0 | ((unsigned)h1 << 16));
+                    out_lo[mf][w] = __uint_as_float((unsigned)l0 | ((unsigned)l1 << 16));
+                }
+            }
+            return;
+        }
         const bf16_t *gp_ = reinterpret_cast<const bf16_t *>(p.g) + (okg ? (long)m * p.Cout + kc * 32 + 16 * h : 0);
 #pragma unroll
         for (int mf = 0; mf < 2; ++mf) {
@@ -108,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
     };
     if (B16 && NKC_REG > 0) {
 #pragma unroll
-        for (int kc = 0; kc < NKC_REG; ++kc) load_graw(kc, graw[kc]);
+        for (int kc = 0; kc < NKC_REG; ++kc) load_graw(kc, graw[kc], graw_lo[SPL ? kc : 0]);
     }
     float greg[(NKC_REG > 0 && !B16) ? NKC_REG : 1][16];
     if (NKC_REG > 0 && !B16) {
@@ -195,8 +216,8 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
                     for (int q = 0; q < 4; ++q) { const float w4[4] = {wrec[q][0], wrec[q][1], wrec[q][2], wrec[q][3]}; wa[q] = bf16x8_from_words(w4); }
                     ++stage;
                     if (stage < nstage) load_w(stage);
-                    f32x4 gl2[2];
-                    if (NKC_REG == 0) load_graw(kc, gl2);
+                    f32x4 gl2[2], gl2_lo[2];
+                    if (NKC_REG == 0) load_graw(kc, gl2, gl2_lo);
 #pragma unroll
                     for (int mf = 0; mf < 2; ++mf) {
                         const f32x4 gsel = NKC_REG == 0 ? gl2[mf] : (NKC_REG == 1 ? graw[0][mf] : (kc == 0 ? graw[0][mf] : graw[NKC_REG > 1 ? 1 : 0][mf]));
@@ -204,6 +225,11 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
                         const bf16x8 gb = bf16x8_from_words(g4);
                         acc = mfma_32x32x16_bf16(wa[mf], gb, acc);        // hi term of the weights
                         acc = mfma_32x32x16_bf16(wa[2 + mf], gb, acc);    // lo term
+                        if (SPL) {                                        // ... and W_hi x the lo term of grad_out
+                            const f32x4 lsel = NKC_REG == 0 ? gl2_lo[mf] : (NKC_REG == 1 ? graw_lo[0][mf] : (kc == 0 ? graw_lo[0][mf] : graw_lo[(SPL && NKC_REG > 1) ? 1 : 0][mf]));
+                            const float l4[4] = {lsel[0], lsel[1], lsel[2], lsel[3]};
+                            acc = mfma_32x32x16_bf16(wa[mf], bf16x8_from_words(l4), acc);
+                        }
                     }
                     continue;
                 }
@@ -337,6 +363,9 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
 // two-term bf16 records (prep mode 2 | 8; the records of ci = 2 i and 2 i + 1 are adjacent: one 32-byte read per term), read by every lane from L2 — no LDS
 // weight tile, no workgroup barrier per tap; B = the 16 bytes of the voxel's bf16 grad_out row that hold channels 8 g4 .. 8 g4 + 7, as loaded.  4 MFMAs per tap
 // instead of 16; the D layout is that of v_mfma_f32_16x16x4_f32, so everything behind the contraction is unchanged.
+// (The two-term split of fp32 rows that cl_deform_goff2_kernel / cl_deform_gx_fx2_kernel use does NOT pay here: 148 against 139 us at stage 0 — two passes of
+// three MFMAs plus four record loads per tap push the kernel over its 168-register budget, and a spilled register costs a vmcnt(0) per reload.  fp32 keeps
+// v_mfma_f32_16x16x4_f32.)
 template <typename T, bool SAMP, int WAVES, int OCC, bool B16 = false>   // WAVES per workgroup (4 | 8), OCC = waves per SIMD the register budget is set for
 __global__ __launch_bounds__(64 * WAVES, OCC) void cl_deform_goff16_kernel(DeformBwdArgs p)
 {
@@ -433,7 +462,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void cl_deform_goff16_kernel(Defor
             const float *src = p.wp16 + (long)tap * p.CoutP * p.C;
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
-                const f32x4 *rec = reinterpret_cast<const f32x4 *>(src + ((long)((part * 2 + (g4 & 1)) * 2 + (g4 >> 1)) * p.C + 2 * i) * 4);
+                const f32x4 *rec = reinterpret_cast<const f32x4 *>(src + ((long)((part * 2 + (g4 & 1)) * 2 + (g4 >> 1)) * p.C + 2 * i) * 4);   // tiles t = 0, 1: ci = 2 i + t
                 wrec[part * 2] = rec[0];
                 wrec[part * 2 + 1] = rec[1];
             }
@@ -883,10 +912,11 @@ __device__ __forceinline__ void gx_drain_far(const DeformBwdArgs &p, const float
 __host__ __device__ __forceinline__ int gx3_b16_rowh(int CoutP) { return CoutP + 8; }   // halfwords per padded row
 __host__ __device__ __forceinline__ size_t gx3_b16_wbytes(int ngroups, int CoutP) { return (size_t)ngroups * 2 * 32 * gx3_b16_rowh(CoutP) * 2; }
 
+// B16 with T = float: fp32 grad_out rows, split in two bf16 terms once per tile (W_hi G_hi + W_lo G_hi + W_hi G_lo, see cl_deform_goff2_kernel).
 template <int SW, int SH, int SD, typename T = float, int NKC = 0, bool B16 = false>   // NKC: 32-channel chunks of a grad_out row known at compile time (1, 2), 0 = up to 4
 __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs p, GxGeom gg, float *__restrict__ scratch)
 {
-    static_assert(!B16 || sizeof(T) == 2, "B16 needs bf16 activations");
+    constexpr bool SPL = B16 && sizeof(T) == 4;
     constexpr int PS = SD * SH * SW;   // cells per channel-pair plane
     const T *gin = reinterpret_cast<const T *>(p.g);
     DLKA_DYN_SMEM(unsigned char, smem0);
@@ -1026,9 +1056,9 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
     // (loaded at the top of the tile they cost an exposed round trip per tile: 7.6 k of a workgroup's 190 k ticks, twice) — as raw words; the
     // "row outside the brick / chunk beyond Cout" zeroing happens when the tile starts.
     constexpr bool AHEAD = NKC == 1;   // (with more chunks the raw words do not fit next to the scatter's registers: 53 spilled at two chunks)
-    f32x4 graw[(AHEAD && !B16) ? KCMAX : 1][4];
-    // B16: the row's MFMA operands as raw words, [kc][mf] = channels kc * 32 + 16 h + 8 mf .. + 7 (always requested a tile ahead when NKC == 1)
-    f32x4 grb[B16 ? KCMAX : 1][2];
+    f32x4 graw[(AHEAD && (!B16 || SPL)) ? KCMAX : 1][4];
+    // B16 (bf16 rows): the row's MFMA operands as raw words, [kc][mf] = channels kc * 32 + 16 h + 8 mf .. + 7 (requested a tile ahead when NKC == 1)
+    f32x4 grb[(B16 && !SPL) ? KCMAX : 1][2];
     auto load_rows_b16 = [&](bool ok, int v) {
 #pragma unroll
         for (int kc = 0; kc < KCMAX; ++kc) {
@@ -1050,7 +1080,7 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
         const int vd = bd0 + rd, vh = bh0 + rh, vw = bw0 + rw;
         const bool ok = row < R && vd < p.D && vh < p.H && vw < p.W;
         const int v = ok ? (vd * p.H + vh) * p.W + vw : 0;
-        if (B16) { load_rows_b16(ok, v); return; }
+        if (B16 && !SPL) { load_rows_b16(ok, v); return; }
 #pragma unroll
         for (int kc = 0; kc < (AHEAD ? KCMAX : 1); ++kc) {
             const bool okg = ok && kc * 32 + 16 * h < p.Cout;
@@ -1069,14 +1099,32 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
         const bool ok = row < R && vd < p.D && vh < p.H && vw < p.W;
         const int v = ok ? (vd * p.H + vh) * p.W + vw : 0;
         float gl[B16 ? 1 : KCMAX][16];   // this voxel's grad_out row (16 of each 32-channel chunk), loaded once for all tap groups
-        bf16x8 gbo[B16 ? KCMAX : 1][2];   // B16: the same as MFMA operands
-        if (B16) {
+        bf16x8 gbo[B16 ? KCMAX : 1][2], gbo_lo[SPL ? KCMAX : 1][2];   // B16: the same as MFMA operands (SPL: hi and lo term)
+        if (B16 && !SPL) {
             if (!AHEAD) load_rows_b16(ok, v);
 #pragma unroll
             for (int kc = 0; kc < KCMAX; ++kc) {
                 if (kc >= nkc) break;
 #pragma unroll
                 for (int mf = 0; mf < 2; ++mf) { const float w4[4] = {grb[kc][mf][0], grb[kc][mf][1], grb[kc][mf][2], grb[kc][mf][3]}; gbo[kc][mf] = bf16x8_from_words(w4); }
+            }
+        }
+        if (SPL) {
+#pragma unroll
+            for (int kc = 0; kc < KCMAX; ++kc) {
+                if (kc >= nkc) break;
+                const bool okg = ok && kc * 32 + 16 * h < p.Cout;
+                const long gi = okg ? ((long)b * p.N + v) * p.Cout + kc * 32 + 16 * h : 0;
+                float v16[16];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f32x4 t;
+                    if constexpr (AHEAD) t = graw[kc][e];
+                    else t = act_load4(gin, gi + 4 * e);
+                    v16[4 * e] = okg ? t[0] : 0.f; v16[4 * e + 1] = okg ? t[1] : 0.f; v16[4 * e + 2] = okg ? t[2] : 0.f; v16[4 * e + 3] = okg ? t[3] : 0.f;
+                }
+                split_bf16x8(v16, gbo[kc][0], gbo_lo[kc][0]);
+                split_bf16x8(v16 + 8, gbo[kc][1], gbo_lo[kc][1]);
             }
         }
 #pragma unroll
@@ -1118,6 +1166,7 @@ __global__ __launch_bounds__(512, 4) void cl_deform_gx_fx2_kernel(DeformBwdArgs 
                         const float h4[4] = {th[0], th[1], th[2], th[3]}, l4[4] = {tl[0], tl[1], tl[2], tl[3]};
                         acc = mfma_32x32x16_bf16(bf16x8_from_words(h4), gbo[kc][mf], acc);
                         acc = mfma_32x32x16_bf16(bf16x8_from_words(l4), gbo[kc][mf], acc);
+                        if (SPL) acc = mfma_32x32x16_bf16(bf16x8_from_words(h4), gbo_lo[kc][mf], acc);
                     }
                     continue;
                 }
@@ -1374,8 +1423,16 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         if (a.samp) { auto k = cl_deform_goff2_kernel<NK, bf16_t, true, true>; DLKA_LAUNCH(k, grid, block, 0, st, ag, tpb); }        \
         else { auto k = cl_deform_goff2_kernel<NK, bf16_t, false, true>; DLKA_LAUNCH(k, grid, block, 0, st, ag, tpb); }              \
     }
+#define DLKA_GOFF2_SPL(NK)                                                                                                           \
+    {                                                                                                                                \
+        if (a.samp) { auto k = cl_deform_goff2_kernel<NK, float, true, true>; DLKA_LAUNCH(k, grid, block, 0, st, ag, tpb); }         \
+        else { auto k = cl_deform_goff2_kernel<NK, float, false, true>; DLKA_LAUNCH(k, grid, block, 0, st, ag, tpb); }               \
+    }
             if (a.act_bf16 && a.wp16) {   // Col on the bf16 matrix cores (two-term weight records, raw grad_out words)
                 if (nkc == 1) DLKA_GOFF2_B16(1) else if (nkc == 2) DLKA_GOFF2_B16(2) else DLKA_GOFF2_B16(0)
+            }
+            else if (a.wp16) {            // ... fp32 rows, two-term split (rows in registers at one chunk only: the split doubles them)
+                if (nkc == 1) DLKA_GOFF2_SPL(1) else DLKA_GOFF2_SPL(0)
             }
             else if (a.act_bf16) {
                 if (nkc == 1) DLKA_GOFF2(1, bf16_t) else if (nkc == 2) DLKA_GOFF2(2, bf16_t) else DLKA_GOFF2(0, bf16_t)
@@ -1383,6 +1440,7 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
             else if (nkc == 1) DLKA_GOFF2(1, float) else if (nkc == 2) DLKA_GOFF2(2, float) else DLKA_GOFF2(0, float)
 #undef DLKA_GOFF2
 #undef DLKA_GOFF2_B16
+#undef DLKA_GOFF2_SPL
         }
         DLKA_CHECK_LAUNCH();
     }
@@ -1421,13 +1479,13 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         if (hipGetDevice(&dev) != hipSuccess) return DLKA_ERR_LAUNCH;
         const uint64_t bit = 1ull << (dev & 63);
         if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-#define DLKA_FX2_FNS(SWv, SHv, SDv, NK) reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float, NK>), reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, NK>), reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, NK, true>)
-            const void *fns[22] = {reinterpret_cast<const void *>(cl_deform_gx_kernel<false>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true>),
+#define DLKA_FX2_FNS(SWv, SHv, SDv, NK) reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float, NK>), reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, NK>), reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, NK, true>), reinterpret_cast<const void *>(cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float, NK, true>)
+            const void *fns[28] = {reinterpret_cast<const void *>(cl_deform_gx_kernel<false>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true>),
                                    reinterpret_cast<const void *>(cl_deform_gx_kernel<false, bf16_t>), reinterpret_cast<const void *>(cl_deform_gx_kernel<true, bf16_t>),
                                    DLKA_FX2_FNS(18, 10, 14, 0), DLKA_FX2_FNS(18, 10, 14, 1), DLKA_FX2_FNS(18, 10, 14, 2),
                                    DLKA_FX2_FNS(34, 10, 10, 0), DLKA_FX2_FNS(34, 10, 10, 1), DLKA_FX2_FNS(34, 10, 10, 2)};
 #undef DLKA_FX2_FNS
-            for (int f = 0; f < 22; ++f)
+            for (int f = 0; f < 28; ++f)
                 if (hipFuncSetAttribute(fns[f], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DLKA_ERR_LAUNCH;
             attr_done.fetch_or(bit, std::memory_order_release);
         }
@@ -1448,14 +1506,18 @@ int launch_cl_deform_bwd2(const DeformBwdArgs &a, float *scratch, hipStream_t st
         if (fixed && gl_.resident && !item_grid && !(fx_env && atoi(fx_env) == 2)) {
             auto ext2 = [](int bs, int size) { const int a = size + 2, b = bs + 2 * HALO; return a < b ? a : b; };   // window + guard cells, worst brick
             const int nd = ext2(g.bd, a.D), nh = ext2(g.bh, a.H), nw = ext2(g.bw, a.W);
-            const bool b16 = a.act_bf16 && a.wp16 != nullptr;   // (wp16 itself is not read here: the kernel stages its own bf16 tiles from wp)
+            const bool b16 = a.wp16 != nullptr;   // (wp16 itself is not read here: the kernel stages its own bf16 tiles from wp) — bf16 rows, or fp32 rows split in two terms
             const size_t wbytes = b16 ? gx3_b16_wbytes(g.ngroups, a.CoutP) : (size_t)g.ngroups * a.CoutP * 32 * sizeof(float);
             const size_t qbytes = (size_t)8 * GX_QW * 8 * sizeof(float);   // 8 waves x GX_QW far-sample records
 #define DLKA_GX2(SWv, SHv, SDv)                                                                                                    \
     if (nw <= SWv && nh <= SHv && nd <= SDv && 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes + qbytes <= 150 * 1024) {       \
         const size_t lds2 = 16 + (size_t)SDv * SHv * SWv * (CS / 2) * 8 + wbytes + qbytes;                                         \
         const int nk_ = a.CoutP / 32;                                                                                              \
-        if (b16) {                                                                                                                 \
+        if (b16 && !a.act_bf16) {                                                                                                  \
+            if (nk_ == 1) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float, 1, true>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }       \
+            else if (nk_ == 2) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float, 2, true>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }  \
+            else { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, float, 0, true>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }                \
+        } else if (b16) {                                                                                                          \
             if (nk_ == 1) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, 1, true>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }      \
             else if (nk_ == 2) { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, 2, true>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); } \
             else { auto k = cl_deform_gx_fx2_kernel<SWv, SHv, SDv, bf16_t, 0, true>; DLKA_LAUNCH(k, gx_grid, dim3(512), lds2, st, a, gl_, scratch); }               \

@@ -230,8 +230,9 @@ int dw_backward_weight(const SameConv &s, const float *x, const float *gout, flo
 }
 
 // ---- deformable (groups = deformable_groups = 1) ---------------------------------------------------------------------
-// DLKA_BF16: the deformable conv's contractions on v_mfma_f32_32x32x16_bf16 (round 4).  ONE process-wide switch, read once: DLKA_DEFORM_B16=0 keeps the
-// fp32-input MFMA of rounds 2 - 3 (A/B runs).  It decides the layout of the prepared weights AND the kernel that reads them, so it must not change between
+// The deformable conv's contractions on the bf16 matrix cores (round 4): with DLKA_BF16 activations all of them (forward, Col of grad_offset / grad_input); with
+// fp32 activations the two BACKWARD ones, grad_out split in two bf16 terms (fp32-equivalent to 1e-5; the forward pass keeps the exact fp32-input MFMA).  ONE
+// process-wide switch, read once: DLKA_DEFORM_B16=0 keeps the fp32-input MFMA of rounds 2 - 3 everywhere (A/B runs).  It decides the layout of the prepared weights AND the kernel that reads them, so it must not change between
 // a weight preparation and its use — hence cached.
 static bool deform_b16()
 {
@@ -300,7 +301,7 @@ int deform_backward(const SameConv &s, const float *x, const float *off, const f
         fill_deform_bwd(a, s);
         a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff; a.gx_zeroed = gx_zeroed ? 1 : 0; a.goff_zeroed = goff_zeroed ? 1 : 0; a.goff_cpad = goff_cpad;
         a.samp = goff ? samp : nullptr;
-        a.wp16 = (s.act_bf16 && deform_b16()) ? wp16 : nullptr;   // (prepared by the caller: two-term bf16 records, mode 2 | 8)
+        a.wp16 = deform_b16() ? wp16 : nullptr;   // (prepared by the caller: two-term bf16 records, mode 2 | 8) — both dtypes: bf16 rows as they are, fp32 rows split
         DLKA_TRY(launch_cl_deform_bwd2(a, scratch, st));
     }
     if (gw) {
@@ -485,7 +486,7 @@ int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_para
     add_job(pb, p->offset_w, t.off_b, 81, C, 27, 96, C, use_split(G.offc, false) ? 9 : 1);
     add_job(pb, p->deform_w, t.dcn_f, C, C, 27, C, C, (G.dcn.act_bf16 && deform_b16()) ? 8 : 0);   // bf16 path: two-term records for cl_deform_fwd_b16_kernel
     add_job(pb, p->deform_w, t.dcn_b, C, C, 27, C, C, 2);
-    if (G.dcn.act_bf16 && deform_b16()) add_job(pb, p->deform_w, t.dcn_b16, C, C, 27, C, C, 2 | 8);
+    if (deform_b16()) add_job(pb, p->deform_w, t.dcn_b16, C, C, 27, C, C, 2 | 8);   // (both dtypes: the backward contractions of the deformable conv)
     add_job(pb, p->conv0_w, t.dw5_f, C, C, G.dw5.K, 0, 0, 3);
     add_job(pb, p->conv0_w, t.dw5_b, C, C, G.dw5.K, 0, 0, 4);
     add_job(pb, p->conv_spatial_w, t.dw7_f, C, C, G.dw7.K, 0, 0, 3);
