@@ -236,7 +236,7 @@ int dw_backward_weight(const SameConv &s, const float *x, const float *gout, flo
 // a weight preparation and its use — hence cached.
 static bool deform_b16()
 {
-    static const bool on = [] { const char *e = getenv("DLKA_DEFORM_B16"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char *e = getenv("DLKA_DEFORM_B16"); return !(e && e[0] == '0') && getenv("DLKA_EXACT_FP32") == nullptr; }();   // (DLKA_EXACT_FP32: every contraction on the fp32-input MFMA)
     return on;
 }
 

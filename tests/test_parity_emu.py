@@ -245,7 +245,7 @@ def test_lka2d_attention_channels_last_fast_path(C, H, W):
     parity.check_lka2d_attention("cpu", 2, C, H, W, report=True)
 
 
-@pytest.mark.parametrize("B,C,dims", [(2, 32, (4, 5, 6)), (1, 8, (4, 5, 6))])
+@pytest.mark.parametrize("B,C,dims", [(1, 32, (3, 4, 5)), (1, 8, (4, 5, 6))])
 def test_lka3d_block_volume_entry_point(B, C, dims):
     """``forward_volume`` = the NCDHW entry point dlka_lka3d_attention_forward / _backward (general per-op kernels) at the contract's tolerances,
     flips counted + same-cells rerun (what tests/test_parity_gpu.py::test_lka3d_block_vs_oracle runs at the real widths)."""
@@ -254,7 +254,7 @@ def test_lka3d_block_volume_entry_point(B, C, dims):
 
 def test_lka2d_attention_general_path_contract_tolerances():
     """A width outside the channels-last menu (C % 32 != 0): the general NCHW kernels, offsets read back through dlka_lka2d_saved_offsets."""
-    parity.check_lka2d_attention("cpu", 2, 12, 7, 9, report=True)
+    parity.check_lka2d_attention("cpu", 1, 12, 6, 7, report=True)
 
 
 @pytest.mark.parametrize("C,dims", [(32, (3, 5, 6)), (128, (2, 4, 3)), (256, (2, 3, 3))])
@@ -506,16 +506,15 @@ def test_pointwise_planar_supported_covers_the_backward_pass_it_will_need():
     assert xg.grad is not None and c.conv.bias.grad is not None
 
 
-@pytest.mark.parametrize("sel", ["tiles", "window"])
-def test_lka2d_grad_input_both_generations(sel, monkeypatch):
+def test_lka2d_grad_input_tile_kernel(monkeypatch):
     """grad_input of the depthwise deformable convs: the launcher picks the input-tile kernel (lane = channel pair, no atomics; cl_ddw2d_gx3_kernel +
-    cl_ddw2d_gx_far_kernel) where the image gives it enough tiles and the fp64-window kernel elsewhere; DLKA_DDW2D_GX forces one, so that
-    emulator-sized shapes reach both — block parity at the contract tolerances, incl. an image of several tiles with offsets far beyond the margin
-    (the far-sample kernel) and a width that is not a multiple of the 128-channel wave."""
-    monkeypatch.setenv("DLKA_DDW2D_GX", sel)
+    cl_ddw2d_gx_far_kernel) where the image gives it enough tiles and the fp64-window kernel elsewhere — i.e. for every other 2-D test of this file;
+    DLKA_DDW2D_GX=tiles forces it, so that emulator-sized shapes reach it: block parity at the contract tolerances, incl. an image of several tiles
+    with offsets far beyond the margin (the far-sample kernel), a width that is not a multiple of the 128-channel wave, and bf16 activations."""
+    monkeypatch.setenv("DLKA_DDW2D_GX", "tiles")
     parity.check_lka2d_attention("cpu", 2, 32, 7, 6)
     parity.check_lka2d_attention("cpu", 1, 96, 9, 11, seed=3)
-    parity.check_lka2d_attention("cpu", 1, 32, 40, 72, seed=1, offset_std=0.2)
+    parity.check_lka2d_attention("cpu", 1, 32, 20, 36, seed=1, offset_std=0.2)
     parity.check_lka2d_attention_bf16("cpu", 2, 64, 6, 10)
 
 
@@ -527,12 +526,14 @@ def test_tblock3d_mixed_bf16_mode(C, dims, autocast):
 
 
 def test_full_net_under_autocast_runs_every_dlka_block_in_bf16(monkeypatch):
-    """run_iteration(bf16_autocast=True) on D_LKA_Former: all 21 wrapper blocks hand their D-LKA attention DLKA_BF16 (dlka_tblock3d_* dtype = DLKA_BF16),
-    every parameter gets a finite fp32 gradient."""
+    """run_iteration(bf16_autocast=True) on D_LKA_Former (one block per stage here: 7 instead of 21, the emulator runs every work-item as a fiber): every
+    wrapper block hands its D-LKA attention DLKA_BF16 (dlka_tblock3d_* dtype = DLKA_BF16), every parameter gets a finite fp32 gradient; without autocast
+    the same blocks run fp32."""
     import deformablelka_amd as dk
     from deformablelka_amd import ops, training
     torch.manual_seed(0)
-    net = dk.D_LKA_Former(in_channels=1, out_channels=3, img_size=[16, 32, 32], feature_size=16, num_heads=4, depths=[3, 3, 3, 3], dims=[32, 64, 128, 256], do_ds=True)
+    net = dk.D_LKA_Former(in_channels=1, out_channels=3, img_size=[16, 32, 32], feature_size=16, num_heads=4, depths=[1, 1, 1, 1], dims=[32, 64, 128, 256], do_ds=True)
+    nblk = len(net.dlka_blocks())
     flags = []
     orig = ops.tblock3d_forward
 
@@ -545,11 +546,26 @@ def test_full_net_under_autocast_runs_every_dlka_block_in_bf16(monkeypatch):
     x = torch.randn(2, 1, 16, 32, 32)
     tgt = torch.randint(0, 3, (2, 16, 32, 32))
     loss = training.run_iteration(net, opt, x, tgt, bf16_autocast=True)
-    assert flags == [True] * 21, flags
+    assert nblk >= 7 and flags == [True] * nblk, flags
     assert bool(torch.isfinite(loss))
     for blk in net.dlka_blocks():
         for k, p_ in blk.named_parameters():
             assert p_.grad is not None and p_.grad.dtype == torch.float32 and bool(torch.isfinite(p_.grad).all()), k
     flags.clear()
-    training.run_iteration(net, opt, x, tgt, bf16_autocast=False)
-    assert flags == [False] * 21
+    with torch.no_grad():
+        net.dlka_blocks()[0](torch.randn(2, 32, 8, 8, 8))
+    assert flags == [False]
+
+
+@pytest.mark.parametrize("C,dims", [(128, (2, 3, 3)), (256, (2, 2, 3))])
+def test_lka3d_tokens_bf16_wide_stages(C, dims):
+    """DLKA_BF16 at the two wide stage widths (round 4: the deformable conv's contractions on the bf16 matrix cores — `cl_deform_fwd_b16_kernel` with several
+    column tiles / gridDim.z, the 32-row grad_offset kernel with grad_out rows re-read per chunk (NKC_REG = 0), the fp64-window grad_input kernel)."""
+    parity.check_lka3d_tokens_bf16("cpu", 1, C, dims, report=True)
+
+
+@pytest.mark.parametrize("C,dims", [(64, (3, 4, 5)), (128, (2, 3, 3))])
+def test_lka3d_tokens_fp32_split_backward_contractions(C, dims):
+    """fp32 activations: Col of grad_offset / grad_input as a two-term bf16 split of the grad_out row (default since round 4) — the block test at the contract's
+    tolerances at two-chunk and four-chunk widths (rows in registers / re-read per chunk)."""
+    parity.check_lka3d_tokens("cpu", 2, C, dims, offset_std=0.3)

@@ -238,3 +238,20 @@ def test_net_alias_names_resolve_to_this_package():
     else:
         raise AssertionError("unknown alias accepted")
     """)
+
+
+def test_deform_b16_switch_off_keeps_the_fp32_input_mfma_kernels_correct():
+    """DLKA_DEFORM_B16=0 (read once per process: hence a subprocess) restores the round-3 kernels — fp32-input MFMA in the deformable conv's forward and
+    backward contractions for both activation types.  They are the A/B reference of profiles/r05_notes.md; this keeps them under test."""
+    env_body = """
+    import os
+    assert os.environ.get("DLKA_DEFORM_B16") == "0"
+    parity.check_lka3d_tokens("cpu", 1, 32, (3, 4, 5), offset_std=0.3)
+    parity.check_lka3d_tokens("cpu", 1, 64, (2, 3, 4), offset_std=0.3)
+    parity.check_lka3d_tokens_bf16("cpu", 1, 32, (4, 4, 8))
+    print("b16 off ok")
+    """
+    env = dict(os.environ, PYTHONPATH=ROOT, DLKA_DEFORM_B16="0")
+    code = textwrap.dedent(PRELUDE) + textwrap.dedent(env_body)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "b16 off ok" in r.stdout, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
