@@ -368,6 +368,8 @@ static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st
 
 int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st)
 {
+    const int e = launch_cl_dwconv_lds(a, kw, dil_w, st);   // the LDS-brick kernel where the volume is large enough for it
+    if (e != DLKA_ERR_UNSUPPORTED) return e;
     return a.act_bf16 ? launch_cl_dwconv_t<bf16_t>(a, kw, dil_w, st) : launch_cl_dwconv_t<float>(a, kw, dil_w, st);
 }
 

@@ -569,3 +569,31 @@ def test_lka3d_tokens_fp32_split_backward_contractions(C, dims):
     """fp32 activations: Col of grad_offset / grad_input as a two-term bf16 split of the grad_out row (default since round 4) — the block test at the contract's
     tolerances at two-chunk and four-chunk widths (rows in registers / re-read per chunk)."""
     parity.check_lka3d_tokens("cpu", 2, C, dims, offset_std=0.3)
+
+
+def test_depthwise_lds_brick_kernel(monkeypatch):
+    """cl_dwconv_lds_kernel (dw 5^3 and dw 7^3 dilation 3 from an LDS brick in residue space; forward AND data gradient) takes the large-volume
+    stages on its own; DLKA_DW_LDS=2 sends emulator-sized volumes through it wherever its geometry fits.  Block parity at the contract tolerances with:
+    residue rows of 7 outputs (the 11-wide variant) and two 5^3 bricks along one axis with a ragged tail; the 8-channel / 6-wide variant with residue classes of
+    different sizes (7 = 3 + 2 + 2); bf16 activations.  The launch counter proves which kernel ran."""
+    from deformablelka_amd import _lib
+    lib = _lib.get_lib()
+    monkeypatch.setenv("DLKA_DW_LDS", "2")
+    n0 = lib.dlka_dwconv_lds_launch_count()
+    parity.check_lka3d_tokens("cpu", 1, 32, (4, 5, 20), offset_std=0.3)
+    n1 = lib.dlka_dwconv_lds_launch_count()
+    assert n1 - n0 >= 4, (n0, n1)   # dw 5^3, dw 7^3 and their data gradients
+    parity.check_lka3d_tokens("cpu", 2, 32, (7, 8, 9))
+    parity.check_lka3d_tokens("cpu", 1, 64, (19, 4, 5), seed=2)
+    n2 = lib.dlka_dwconv_lds_launch_count()
+    assert n2 - n1 >= 8
+    parity.check_lka3d_tokens_bf16("cpu", 1, 32, (4, 4, 8))
+    assert lib.dlka_dwconv_lds_launch_count() - n2 >= 4
+    monkeypatch.setenv("DLKA_DW_LDS_TH", "2")   # the 11-wide variant with row PAIRS per work-item (the default is single rows)
+    n3 = lib.dlka_dwconv_lds_launch_count()
+    parity.check_lka3d_tokens("cpu", 1, 32, (20, 5, 4), seed=4, offset_std=0.3)
+    assert lib.dlka_dwconv_lds_launch_count() - n3 >= 4
+    monkeypatch.setenv("DLKA_DW_LDS", "0")
+    n3 = lib.dlka_dwconv_lds_launch_count()
+    parity.check_lka3d_tokens("cpu", 1, 32, (4, 5, 6))
+    assert lib.dlka_dwconv_lds_launch_count() == n3
