@@ -100,6 +100,12 @@ struct DwArgs {
     int B, D, H, W, C;
     int act_bf16;          // 1: in / out / gelu_x / gelu_add are bf16 storage
     int kd, kh, pd, ph, pw, dd, dh;   // kw / dw are template parameters
+    // LDS-brick kernels (cl_dwconv_lds.hip); blk == null: never taken
+    float *blk;            // scratch for the class-blocked fp32 copy of `in` (blk_floats floats available)
+    size_t blk_floats;
+    int in_blocked;        // 1: blk already holds the blocked input (a preceding LDS-brick conv wrote it through ITS out_blk)
+    float *out_blk;        // also write the result class-blocked (fp32) for a following depthwise conv of dilation out_blk_dil; null: no
+    int out_blk_dil;
 };
 
 // channels-last 2-D depthwise deformable conv (cl_ddw2d.hip): forward uses in / off / wp / out; backward in / off / wp / g / gx / goff / part

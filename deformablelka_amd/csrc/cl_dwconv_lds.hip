@@ -3,22 +3,27 @@
 //
 // Why: cl_dwconv_rowsN_kernel (cl_dwconv.hip) reads every input row segment through the vector L1 — one 256-byte wave load per segment element,
 // 1.7 GB per launch at (32 channels, 32^3, 7^3 dilation 3) — and that launch's 42 us ARE those bytes at the L1's 64 bytes / clock / CU; its 720 M
-// FMAs would take 9 us.  Register tiles cannot buy the missing reuse (more outputs per work-item = one wave per SIMD; measured slower, r01o).
+// FMAs take 9 us as packed fp32.  Register tiles cannot buy the missing reuse (more outputs per work-item = one wave per SIMD; measured slower, r01o).
 //
-// Here a workgroup stages the input brick of its outputs ONCE (global -> LDS, CG channels of every cell: 16- or 32-byte pieces) and every tap reads
-// LDS (128 bytes / clock / CU, and only the brick travels through L1 / L2).  A DILATED conv decomposes into DIL^3 independent dense convs: outputs
-// with coordinates = (rd, rh, rw) mod DIL only read inputs of the same residue class, so the brick lives in "residue space" (cell q <-> voxel
-// r + DIL q), where the 7^3 dilation-3 conv is a dense 7^3 conv with halo 3 on an (D / 3)^3 sub-volume — 11^3 outputs + halo = 17^3 cells at 32^3:
-// with 4 channels per workgroup the WHOLE class fits in 78.6 KB, two workgroups per CU.  Zero padding is stored (cells outside the volume = 0), the
-// tap loops are branch-free.
+// Here a workgroup stages the input brick of its outputs ONCE into LDS (4 channels of every cell) and every tap reads LDS.  A DILATED conv
+// decomposes into DIL^3 independent dense convs: outputs with coordinates = (rd, rh, rw) mod DIL only read inputs of the same residue class, so the
+// brick lives in "residue space" (cell q <-> voxel r + DIL q), where the 7^3 dilation-3 conv is a dense 7^3 conv with halo 3 on a (D / 3)^3
+// sub-volume — 11^3 outputs + halo = 17^3 cells at 32^3: with 4 channels per workgroup the WHOLE class fits in 78.6 KB, two workgroups per CU.
+// Zero padding is stored (cells outside the volume = 0), the tap loops are branch-free.
 //
-// Work-item = (channel c of the group, W-run of TW outputs, TH consecutive h rows, one d) in residue space: per input row NR = KW + TH - 1 rows x
-// SEG = TW + KW - 1 LDS reads feed TH * KW * TW FMAs (7.9 FMAs per 4-byte read at 7^3, TW = 11, TH = 2); lanes run c-fastest, rows are an ODD number
-// of cells apart so that the 64 lanes of a read hit 64 different banks.  The KW x KW tap weights of a d-plane sit in registers, the next plane's are
-// loaded at the top of the plane; row r + 1 is read from LDS while row r is multiplied.  Same kernel = forward and data gradient (flipped taps);
-// epilogues as cl_dwconv_rowsN_kernel.  Compiled with -fno-slp-vectorize (Makefile): left alone, the SLP vectoriser pairs the FMAs of neighbouring
-// outputs into v_pk_fma_f32, whose operand pairs need shifted copies of the row segment — 168 registers plus scratch instead of 113, and packed fp32
-// is no faster than two plain FMAs on this chip (MI355X_MICROARCH.md: v_fma_f32 issues in 2 cycles per wave).
+// The first version staged straight from the channels-last tensor: 16 bytes of every 128-byte line per workgroup, the other 112 fetched and dropped
+// — 272 MB of L2 -> L1 fills per launch, all workgroups in phase at the start: 40 us, no better than the register-row kernel (profiles/r05l).  So
+// the brick's source is a CLASS-BLOCKED copy of the input, blk[b][channel quad][residue class][qd][qh][qw][4] fp32, in which a brick row is one
+// contiguous run.  The copy is written by cl_dw_block_kernel (one pass over the tensor) or — between two consecutive depthwise convs (5^3 -> 7^3
+// forward, 7^3 -> 5^3 in the data-gradient chain) — by the producing conv's epilogue (DwArgs::out_blk).
+//
+// Work-item = (channel PAIR, W-run of TW outputs, TH consecutive h rows, one d) in residue space: acc / row segment / tap weights are 2-vectors over
+// the pair and every multiply-add is one v_pk_fma_f32 (two fp32 FMAs per lane and issue slot — unpacked, this kernel is bound by FMA issue at half
+// the rate); per input row SEG = TW + KW - 1 eight-byte LDS reads feed TH * KW * TW packed FMAs.  Rows are an ODD number of cells apart (bank
+// spread).  The KW x KW tap weights of a d-plane sit in registers, the first two tap rows of the next plane are requested a plane ahead; row r + 1
+// is read from LDS while row r is multiplied.  Same kernel = forward and data gradient (flipped taps); epilogues as cl_dwconv_rowsN_kernel.
+// Compiled with -fno-slp-vectorize (Makefile): the packing is explicit, and the SLP vectoriser's own pairing of neighbouring OUTPUTS needs
+// shifted copies of the row segment (168 registers plus scratch).
 #include <stdlib.h>
 
 #include <atomic>
@@ -28,22 +33,56 @@
 
 namespace dlka {
 
+typedef f32x2 dwv2;
+
+constexpr int DWL_CG = 4;   // channels per workgroup = one 16-byte piece of the blocked layout
+
 struct DwLdsGeom {
     int bd, bh, bw;      // outputs per brick along d, h, w (residue space)
     int nbd, nbh, nbw;   // bricks per residue class (sized for the largest class)
     int SD, SH, SW;      // cells of the LDS brick: bd + KW - 1, rows_h * TH + KW - 1, runs_w * TW + KW - 1 rounded up to odd
-    int rows_h, runs_w;  // work-items per (c, d): ceil(bh / TH) row groups x ceil(bw / TW) runs
-    int ncg;             // channel groups (C / CG)
+    int rows_h, runs_w;  // work-items per (channel pair, d): ceil(bh / TH) row groups x ceil(bw / TW) runs
+    int ncg;             // channel quads (C / 4)
+    int Dr, Hr, Wr;      // cells per residue class in the blocked source: ceil(D / DIL), ...
     int nitems, xcd_nx;  // work items = B * DIL^3 * nbd * nbh * nbw * ncg; xcd_nx > 0: blockIdx.x is mapped through xcd_item()
+    int oDr, oHr, oWr;   // DwArgs::out_blk: cells per class of the blocked OUTPUT copy (dilation out_blk_dil)
 };
 
-template <typename T, int KW, int DIL, int CG, int TW, int TH>
-__global__ __launch_bounds__(512, 3) void cl_dwconv_lds_kernel(DwArgs p, DwLdsGeom g)
+__host__ __device__ __forceinline__ size_t dw_blk_floats(int B, int C, int D, int H, int W, int dil)
 {
-    constexpr int R = (KW - 1) / 2, SEG = TW + KW - 1, NR = KW + TH - 1, KH = KW;
-    static_assert(CG % 4 == 0, "channel groups are loaded in 4-channel pieces");
+    return (size_t)B * C * dil * dil * dil * cdiv(D, dil) * cdiv(H, dil) * cdiv(W, dil);
+}
+
+// float index of (b, channel quad cg, voxel (d, h, w)) in the class-blocked layout of dilation dil (Dr, Hr, Wr = cells per class)
+__device__ __forceinline__ long dw_blk_index(int b, int cg, int ncg, int d, int h, int w, int dil, int Dr, int Hr, int Wr)
+{
+    const int cls = ((d % dil) * dil + h % dil) * dil + w % dil;
+    return ((((((long)b * ncg + cg) * (dil * dil * dil) + cls) * Dr + d / dil) * Hr + h / dil) * Wr + w / dil) * DWL_CG;
+}
+
+// in [B][D][H][W][C] (T) -> blk (fp32, class-blocked); one 16-byte piece per work-item, reads coalesced
+template <typename T>
+__global__ __launch_bounds__(256) void cl_dw_block_kernel(const float *__restrict__ in_, float *__restrict__ blk, int B, int D, int H, int W, int C, int dil)
+{
+    const T *in = reinterpret_cast<const T *>(in_);
+    const int ncg = C / DWL_CG, Dr = cdiv(D, dil), Hr = cdiv(H, dil), Wr = cdiv(W, dil);
+    const long n = (long)B * D * H * W * ncg;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const int cg = (int)(e % ncg);
+        long v = e / ncg;
+        const int w = (int)(v % W); v /= W;
+        const int h = (int)(v % H); v /= H;
+        const int d = (int)(v % D), b = (int)(v / D);
+        *reinterpret_cast<f32x4 *>(blk + dw_blk_index(b, cg, ncg, d, h, w, dil, Dr, Hr, Wr)) = act_load4(in, e * DWL_CG);
+    }
+}
+
+template <typename T, int KW, int DIL, int TW, int TH>
+__global__ __launch_bounds__(512, 2) void cl_dwconv_lds_kernel(DwArgs p, DwLdsGeom g)
+{
+    constexpr int R = (KW - 1) / 2, SEG = TW + KW - 1, NR = KW + TH - 1, KH = KW, CG = DWL_CG;
     DLKA_DYN_SMEM(float, Ws);   // [SD][SH][SW][CG]
-    const T *inp = reinterpret_cast<const T *>(p.in), *gxp = reinterpret_cast<const T *>(p.gelu_x), *gap = reinterpret_cast<const T *>(p.gelu_add);
+    const T *gxp = reinterpret_cast<const T *>(p.gelu_x), *gap = reinterpret_cast<const T *>(p.gelu_add);
     T *outp = reinterpret_cast<T *>(p.out);
     const int tid = threadIdx.x;
     int item = g.xcd_nx > 0 ? xcd_item((int)blockIdx.x, g.xcd_nx) : (int)blockIdx.x;
@@ -57,32 +96,30 @@ __global__ __launch_bounds__(512, 3) void cl_dwconv_lds_kernel(DwArgs p, DwLdsGe
     const int od = bdi * g.bd, oh = bhi * g.bh, ow = bwi * g.bw;   // first output of the brick (residue space)
     if (rd + DIL * od >= p.D || rh + DIL * oh >= p.H || rw + DIL * ow >= p.W) return;   // smaller residue classes have fewer bricks (uniform)
 
-    // ---- stage the brick: cell (zd, zh, zw) <-> voxel r + DIL * (o + z - R); zeros outside the volume ----
-    const int cells = g.SD * g.SH * g.SW, c0 = cg * CG;
+    // ---- stage the brick from the blocked copy: cell (zd, zh, zw) <-> class cell o + z - R; zeros outside the volume ----
+    const int cells = g.SD * g.SH * g.SW;
+    const int cd = cdiv(p.D - rd, DIL), ch = cdiv(p.H - rh, DIL), cw = cdiv(p.W - rw, DIL);   // cells of THIS class
+    const float *src = p.blk + ((((long)b * g.ncg + cg) * (DIL * DIL * DIL) + cls) * g.Dr) * g.Hr * g.Wr * CG;
     for (int e = tid; e < cells; e += blockDim.x) {
         const int zw = e % g.SW, zh = (e / g.SW) % g.SH, zd = e / (g.SW * g.SH);
         const int qd = od + zd - R, qh = oh + zh - R, qw = ow + zw - R;
-        const int vd = rd + DIL * qd, vh = rh + DIL * qh, vw = rw + DIL * qw;
-        const bool ok = qd >= 0 && qh >= 0 && qw >= 0 && vd < p.D && vh < p.H && vw < p.W;
-        const long gi = ok ? ((((long)b * p.D + vd) * p.H + vh) * p.W + vw) * p.C + c0 : 0;
-#pragma unroll
-        for (int q = 0; q < CG / 4; ++q) {
-            f32x4 v = act_load4(inp, gi + 4 * q);
-            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4 *>(Ws + (long)e * CG + 4 * q) = v;
-        }
+        const bool ok = (unsigned)qd < (unsigned)cd && (unsigned)qh < (unsigned)ch && (unsigned)qw < (unsigned)cw;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4 *>(src + (((long)qd * g.Hr + qh) * g.Wr + qw) * CG);
+        *reinterpret_cast<f32x4 *>(Ws + (long)e * CG) = v;
     }
     __syncthreads();
 
-    // ---- this work-item's outputs ----
-    const int c = tid % CG;
-    int q = tid / CG;
+    // ---- this work-item's outputs: channels cch, cch + 1 ----
+    const int pr = tid % 2;
+    int q = tid / 2;
     const int run = q % g.runs_w; q /= g.runs_w;
     const int hq = q % g.rows_h, dq = q / g.rows_h;
     if (dq >= g.bd) return;   // (no barrier below)
-    const int cch = c0 + c;
-    float acc[TH][TW];
-    const float bv = p.bias ? p.bias[cch] : 0.f;
+    const int cch = cg * CG + 2 * pr;
+    dwv2 acc[TH][TW];
+    dwv2 bv = {0.f, 0.f};
+    if (p.bias) bv = dwv2{p.bias[cch], p.bias[cch + 1]};
 #pragma unroll
     for (int o = 0; o < TH; ++o)
 #pragma unroll
@@ -90,36 +127,35 @@ __global__ __launch_bounds__(512, 3) void cl_dwconv_lds_kernel(DwArgs p, DwLdsGe
 
     const BufRsrc rwt = make_rsrc(p.wp, (size_t)KW * KH * KW * p.C * 4);
     const unsigned cv = (unsigned)cch * 4u, cbw = (unsigned)p.C * 4u;
-    // tap weights of plane i in registers; the first two tap rows of the NEXT plane are requested a plane ahead (the rest is needed from input row 2 on:
-    // a full second buffer does not fit the 168-register budget of three waves per SIMD)
-    float wv[KH][KW], wp[2][KW];
+    // tap weights of plane i in registers; the first two tap rows of the NEXT plane are requested a plane ahead (a full second buffer costs 2 KW KH registers)
+    dwv2 wv[KH][KW], wp[2][KW];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int k = 0; k < KW; ++k) wp[j][k] = buf_load_f32_s(rwt, cv, (unsigned)(j * KW + k) * cbw);
-    const float *base = Ws + ((long)(dq * g.SH + hq * TH) * g.SW + run * TW) * CG + c;
+        for (int k = 0; k < KW; ++k) wp[j][k] = buf_load_f32x2_s(rwt, cv, (unsigned)(j * KW + k) * cbw);
+    const float *base = Ws + ((long)(dq * g.SH + hq * TH) * g.SW + run * TW) * CG + 2 * pr;
     const int rowst = g.SW * CG, planest = g.SH * g.SW * CG;
 #pragma unroll 1
     for (int i = 0; i < KW; ++i) {
 #pragma unroll
         for (int j = 0; j < KH; ++j)
 #pragma unroll
-            for (int k = 0; k < KW; ++k) wv[j][k] = j < 2 ? wp[j][k] : buf_load_f32_s(rwt, cv, (unsigned)((i * KH + j) * KW + k) * cbw);
+            for (int k = 0; k < KW; ++k) wv[j][k] = j < 2 ? wp[j][k] : buf_load_f32x2_s(rwt, cv, (unsigned)((i * KH + j) * KW + k) * cbw);
         if (i + 1 < KW) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int k = 0; k < KW; ++k) wp[j][k] = buf_load_f32_s(rwt, cv, (unsigned)(((i + 1) * KH + j) * KW + k) * cbw);
+                for (int k = 0; k < KW; ++k) wp[j][k] = buf_load_f32x2_s(rwt, cv, (unsigned)(((i + 1) * KH + j) * KW + k) * cbw);
         }
         const float *pl = base + (long)i * planest;
-        float seg[2][SEG];   // row r + 1 is read from LDS while row r is multiplied (the scheduling fences keep the compiler from hoisting ALL rows' reads)
+        dwv2 seg[2][SEG];   // (the scheduling fences keep the compiler from hoisting ALL rows' reads)
 #pragma unroll
-        for (int e = 0; e < SEG; ++e) seg[0][e] = pl[e * CG];
+        for (int e = 0; e < SEG; ++e) seg[0][e] = *reinterpret_cast<const dwv2 *>(pl + e * CG);
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (r + 1 < NR) {
 #pragma unroll
-                for (int e = 0; e < SEG; ++e) seg[(r + 1) & 1][e] = pl[(r + 1) * rowst + e * CG];
+                for (int e = 0; e < SEG; ++e) seg[(r + 1) & 1][e] = *reinterpret_cast<const dwv2 *>(pl + (r + 1) * rowst + e * CG);
             }
 #pragma unroll
             for (int o = 0; o < TH; ++o) {
@@ -127,7 +163,7 @@ __global__ __launch_bounds__(512, 3) void cl_dwconv_lds_kernel(DwArgs p, DwLdsGe
 #pragma unroll
                 for (int k = 0; k < KW; ++k)
 #pragma unroll
-                    for (int t = 0; t < TW; ++t) acc[o][t] = fmaf(wv[r - o][k], seg[r & 1][t + k], acc[o][t]);
+                    for (int t = 0; t < TW; ++t) acc[o][t] = pk_fma(wv[r - o][k], seg[r & 1][t + k], acc[o][t]);
             }
             sched_fence();
         }
@@ -144,40 +180,46 @@ __global__ __launch_bounds__(512, 3) void cl_dwconv_lds_kernel(DwArgs p, DwLdsGe
             const int lw = run * TW + t, vw = rw + DIL * (ow + lw);
             if (lw >= g.bw || vw >= p.W) continue;
             const long o_ = ((((long)b * p.D + vd) * p.H + vh) * p.W + vw) * p.C + cch;
-            if (p.gelu_x) act_store1(outp, o_, (acc[o][t] + act_load1(gap, o_)) * dgelu_f(act_load1(gxp, o_)));   // (uniform: see cl_dwconv_kernel)
-            else {
-                act_store1(outp, o_, acc[o][t]);
-                if (sizeof(T) == 4 && p.out_lo) act_store1(reinterpret_cast<bf16_t *>(p.out_lo), o_, acc[o][t]);
+            dwv2 r_ = acc[o][t];
+            if (p.gelu_x) {   // (uniform: see cl_dwconv_kernel)
+                r_[0] = (r_[0] + act_load1(gap, o_)) * dgelu_f(act_load1(gxp, o_));
+                r_[1] = (r_[1] + act_load1(gap, o_ + 1)) * dgelu_f(act_load1(gxp, o_ + 1));
             }
+            act_store2(outp, o_, r_[0], r_[1]);
+            if (sizeof(T) == 4 && p.out_lo && !p.gelu_x) act_store2(reinterpret_cast<bf16_t *>(p.out_lo), o_, r_[0], r_[1]);
+            if (p.out_blk)   // the following depthwise conv's blocked source (fp32 whatever T is)
+                *reinterpret_cast<dwv2 *>(p.out_blk + dw_blk_index(b, cg, g.ncg, vd, vh, vw, p.out_blk_dil, g.oDr, g.oHr, g.oWr) + 2 * pr) = r_;
         }
     }
 }
 
-// Brick geometry for one launch; false = shape not worth / not able (the caller keeps cl_dwconv_rowsN_kernel).
-template <int KW, int DIL, int CG, int TW, int TH>
+// Brick geometry for one launch; false = shape not able (the caller keeps cl_dwconv_rowsN_kernel).
+template <int KW, int DIL, int TW, int TH>
 static bool dw_lds_plan(const DwArgs &a, int bd_max, int bh_max, int bw_max, DwLdsGeom &g, size_t &lds, int &threads)
 {
-    if (a.C % CG != 0) return false;
-    const int Dr = cdiv(a.D, DIL), Hr = cdiv(a.H, DIL), Wr = cdiv(a.W, DIL);
-    g.bd = Dr < bd_max ? Dr : bd_max; g.bh = Hr < bh_max ? Hr : bh_max; g.bw = Wr < bw_max ? Wr : bw_max;
-    g.nbd = cdiv(Dr, g.bd); g.nbh = cdiv(Hr, g.bh); g.nbw = cdiv(Wr, g.bw);
+    if (a.C % DWL_CG != 0) return false;
+    g.Dr = cdiv(a.D, DIL); g.Hr = cdiv(a.H, DIL); g.Wr = cdiv(a.W, DIL);
+    g.bd = g.Dr < bd_max ? g.Dr : bd_max; g.bh = g.Hr < bh_max ? g.Hr : bh_max; g.bw = g.Wr < bw_max ? g.Wr : bw_max;
+    g.nbd = cdiv(g.Dr, g.bd); g.nbh = cdiv(g.Hr, g.bh); g.nbw = cdiv(g.Wr, g.bw);
     g.rows_h = cdiv(g.bh, TH); g.runs_w = cdiv(g.bw, TW);
     g.SD = g.bd + KW - 1; g.SH = g.rows_h * TH + KW - 1; g.SW = (g.runs_w * TW + KW - 1) | 1;
-    g.ncg = a.C / CG;
+    g.ncg = a.C / DWL_CG;
     const long items = (long)a.B * DIL * DIL * DIL * g.nbd * g.nbh * g.nbw * g.ncg;
     if (items > (1l << 30)) return false;
     g.nitems = (int)items; g.xcd_nx = 0;
-    lds = (size_t)g.SD * g.SH * g.SW * CG * 4;
-    threads = round_up(CG * g.runs_w * g.rows_h * g.bd, 64);
+    g.oDr = g.oHr = g.oWr = 0;
+    if (a.out_blk) { g.oDr = cdiv(a.D, a.out_blk_dil); g.oHr = cdiv(a.H, a.out_blk_dil); g.oWr = cdiv(a.W, a.out_blk_dil); }
+    lds = (size_t)g.SD * g.SH * g.SW * DWL_CG * 4;
+    threads = round_up(2 * g.runs_w * g.rows_h * g.bd, 64);
     return lds <= 156 * 1024 && threads <= 512 && threads >= 64;
 }
 
 static std::atomic<long> g_dw_lds_launches{0};   // dlka_dwconv_lds_launch_count (include/dlka.h): diagnostics
 
-template <typename T, int KW, int DIL, int CG, int TW, int TH>
+template <typename T, int KW, int DIL, int TW, int TH>
 static int dw_lds_launch(const DwArgs &a, DwLdsGeom g, size_t lds, int threads, hipStream_t st)
 {
-    auto k = cl_dwconv_lds_kernel<T, KW, DIL, CG, TW, TH>;
+    auto k = cl_dwconv_lds_kernel<T, KW, DIL, TW, TH>;
 #if !defined(HIPEMU)
     static std::atomic<uint64_t> attr_done{0};   // dynamic LDS above 64 KB: per function and per device
     int dev = 0;
@@ -188,6 +230,14 @@ static int dw_lds_launch(const DwArgs &a, DwLdsGeom g, size_t lds, int threads, 
         attr_done.fetch_or(bit, std::memory_order_release);
     }
 #endif
+    if (!a.in_blocked) {   // the class-blocked copy of the input (DwArgs::blk); a preceding LDS-brick conv may have written it already
+        const long pieces = (long)a.B * a.D * a.H * a.W * (a.C / DWL_CG);
+        long blocks = cdivl(pieces, 256);
+        if (blocks > 8192) blocks = 8192;
+        if (a.act_bf16) { auto kb = cl_dw_block_kernel<bf16_t>; DLKA_LAUNCH(kb, dim3((unsigned)blocks), dim3(256), 0, st, a.in, a.blk, a.B, a.D, a.H, a.W, a.C, DIL); }
+        else { auto kb = cl_dw_block_kernel<float>; DLKA_LAUNCH(kb, dim3((unsigned)blocks), dim3(256), 0, st, a.in, a.blk, a.B, a.D, a.H, a.W, a.C, DIL); }
+        DLKA_CHECK_LAUNCH();
+    }
     DwArgs ax = a;
     dim3 grid((unsigned)g.nitems);
     if (xcd_swizzle_enabled() && g.nitems >= xcd_min_blocks()) { g.xcd_nx = g.nitems; grid.x = xcd_grid(g.nitems); }
@@ -205,47 +255,62 @@ static int dw_lds_mode()
     return e ? atoi(e) : 1;
 }
 
+// variant of the launch: 0 = not this kernel; 1 = 7^3 dil 3, classes of up to 11^3 (rows of 11); 2 = 7^3 dil 3, classes of up to 6^3; 3 = 5^3
+template <typename T>
+static int dw_lds_select(const DwArgs &a, int kw, int dil_w, DwLdsGeom &g, size_t &lds, int &threads)
+{
+    const int mode = dw_lds_mode();
+    if (mode == 0 || !a.blk) return 0;
+    const bool cubic = a.kd == kw && a.kh == kw && a.dd == dil_w && a.dh == dil_w;
+    const int pad = dil_w * (kw - 1) / 2;
+    if (!cubic || a.pd != pad || a.ph != pad || a.pw != pad) return 0;
+    if (dw_blk_floats(a.B, a.C, a.D, a.H, a.W, dil_w) > a.blk_floats) return 0;
+    const long outs = (long)a.B * a.D * a.H * a.W * a.C;
+    if (kw == 7 && dil_w == 3) {
+        // whole residue classes of up to 11^3 outputs: 17^3 cells = 78.6 KB, two workgroups of four waves per CU (stage 0: 432 workgroups)
+        if (cdiv(a.W, 3) > 6 && dw_lds_plan<7, 3, 11, 1>(a, 11, 11, 11, g, lds, threads) && (mode == 2 || (outs >= (1l << 21) && g.nitems >= 256))) return 1;
+        // <= 6^3 outputs per class (16^3 volumes): 12 x 12 x 13 cells = 30 KB
+        if (cdiv(a.W, 3) <= 6 && dw_lds_plan<7, 3, 6, 1>(a, 6, 6, 6, g, lds, threads) && (mode == 2 || (outs >= (1l << 19) && g.nitems >= 256))) return 2;
+        return 0;
+    }
+    if (kw == 5 && dil_w == 1) {
+        // bricks of 8 x 8 x 16 outputs: 12 x 12 x 21 cells = 48 KB, three workgroups of four waves per CU
+        if (dw_lds_plan<5, 1, 8, 1>(a, a.D >= 32 ? 8 : 4, 8, 16, g, lds, threads) && (mode == 2 || (outs >= (1l << 19) && g.nitems >= 256))) return 3;
+        return 0;
+    }
+    return 0;
+}
+
 // Returns DLKA_ERR_UNSUPPORTED when this launch should stay on cl_dwconv_rowsN_kernel.
 template <typename T>
 static int launch_cl_dwconv_lds_t(const DwArgs &a, int kw, int dil_w, hipStream_t st)
 {
-    const int mode = dw_lds_mode();
-    if (mode == 0) return DLKA_ERR_UNSUPPORTED;
-    const bool cubic = a.kd == kw && a.kh == kw && a.dd == dil_w && a.dh == dil_w;
-    const int pad = dil_w * (kw - 1) / 2;
-    if (!cubic || a.pd != pad || a.ph != pad || a.pw != pad) return DLKA_ERR_UNSUPPORTED;
     DwLdsGeom g;
     size_t lds = 0;
     int threads = 0;
-    const long outs = (long)a.B * a.D * a.H * a.W * a.C;
-    if (kw == 7 && dil_w == 3) {
-        // whole residue classes of up to 11^3 outputs, 4 channels: 17^3 cells = 78.6 KB, two workgroups per CU (stage 0: 432 workgroups of 5 waves)
-        // Row pairs (TH = 2) halve the LDS reads per FMA but give 66 work-items per channel = 5 waves per workgroup, 10 per CU: three on two of the SIMDs;
-        // single rows (TH = 1) give 121 = 8 waves, 16 per CU, four per SIMD.  DLKA_DW_LDS_TH=2 selects the pairs (A/B, profiles/r05_notes.md).
-        const char *th_env = getenv("DLKA_DW_LDS_TH");
-        const bool pairs = th_env && atoi(th_env) == 2;
-        if (cdiv(a.W, 3) > 6 && !pairs && dw_lds_plan<7, 3, 4, 11, 1>(a, 11, 11, 11, g, lds, threads) && (mode == 2 || (outs >= (1l << 21) && g.nitems >= 256)))
-            return dw_lds_launch<T, 7, 3, 4, 11, 1>(a, g, lds, threads, st);
-        if (cdiv(a.W, 3) > 6 && dw_lds_plan<7, 3, 4, 11, 2>(a, 11, 12, 11, g, lds, threads) && (mode == 2 || (outs >= (1l << 21) && g.nitems >= 256)))
-            return dw_lds_launch<T, 7, 3, 4, 11, 2>(a, g, lds, threads, st);
-        // <= 6^3 outputs per class (16^3 volumes), 8 channels: 12 x 12 x 13 cells = 60 KB
-        if (cdiv(a.W, 3) <= 6 && dw_lds_plan<7, 3, 8, 6, 2>(a, 6, 6, 6, g, lds, threads) && (mode == 2 || (outs >= (1l << 19) && g.nitems >= 256)))
-            return dw_lds_launch<T, 7, 3, 8, 6, 2>(a, g, lds, threads, st);
-        return DLKA_ERR_UNSUPPORTED;
+    switch (dw_lds_select<T>(a, kw, dil_w, g, lds, threads)) {
+    case 1: return dw_lds_launch<T, 7, 3, 11, 1>(a, g, lds, threads, st);
+    case 2: return dw_lds_launch<T, 7, 3, 6, 1>(a, g, lds, threads, st);
+    case 3: return dw_lds_launch<T, 5, 1, 8, 1>(a, g, lds, threads, st);
+    default: return DLKA_ERR_UNSUPPORTED;
     }
-    if (kw == 5 && dil_w == 1) {
-        // bricks of 8 x 8 x 16 outputs, 4 channels: 12 x 12 x 21 cells = 48 KB, three workgroups per CU
-        if (dw_lds_plan<5, 1, 4, 8, 2>(a, a.D >= 32 ? 8 : 4, 8, 16, g, lds, threads) && (mode == 2 || (outs >= (1l << 19) && g.nitems >= 256)))
-            return dw_lds_launch<T, 5, 1, 4, 8, 2>(a, g, lds, threads, st);
-        return DLKA_ERR_UNSUPPORTED;
-    }
-    return DLKA_ERR_UNSUPPORTED;
 }
 
 int launch_cl_dwconv_lds(const DwArgs &a, int kw, int dil_w, hipStream_t st)
 {
     return a.act_bf16 ? launch_cl_dwconv_lds_t<bf16_t>(a, kw, dil_w, st) : launch_cl_dwconv_lds_t<float>(a, kw, dil_w, st);
 }
+
+// would launch_cl_dwconv take the LDS-brick kernel for this conv?  (the token path asks before it lets the PREVIOUS conv write the blocked copy)
+bool cl_dwconv_lds_selected(const DwArgs &a, int kw, int dil_w)
+{
+    DwLdsGeom g;
+    size_t lds = 0;
+    int threads = 0;
+    return dw_lds_select<float>(a, kw, dil_w, g, lds, threads) != 0;
+}
+
+size_t cl_dwconv_blk_floats(int B, int C, int D, int H, int W, int dil) { return dw_blk_floats(B, C, D, H, W, dil); }
 
 }  // namespace dlka
 

@@ -193,18 +193,49 @@ void fill_pw_wgrad(WgradArgs &a, const SameConv &s, const float *x, const float 
 }
 
 // ---- depthwise ------------------------------------------------------------------------------------------------------
-int dw_forward(const SameConv &s, const float *x, const float *w, const float *bias, float *out, float *wp, int flip, hipStream_t st,
-               const float *gelu_x = nullptr, const float *gelu_add = nullptr, float *out_lo = nullptr)
+// The LDS-brick kernels (cl_dwconv_lds.hip) read a class-blocked fp32 copy of the input: `blk` = scratch for it (null: those kernels are never taken),
+// `chain` = the depthwise conv that consumes THIS conv's output next (null: none) with `chain_blk` = scratch for ITS blocked input — when both convs take
+// the LDS-brick kernel this one's epilogue writes that copy, and *chained tells the caller to pass in_blocked = true to the next call.
+struct DwBlk {
+    float *blk = nullptr;
+    size_t blk_floats = 0;
+    bool in_blocked = false;
+    const SameConv *chain = nullptr;
+    float *chain_blk = nullptr;
+    bool *chained = nullptr;
+};
+
+static void fill_dw_args(DwArgs &a, const SameConv &s, int flip)
 {
-    if (w) DLKA_TRY(launch_cl_dw_prep_weight(w, wp, s.Cin, s.K, flip, st));
-    if (out_lo && s.act_bf16) return DLKA_ERR_UNSUPPORTED;   // (the bf16 copy rides in the fp32 kernels only)
-    DwArgs a;
-    a.in = x; a.wp = wp; a.bias = bias; a.out = out; a.out_lo = out_lo; a.gelu_x = gelu_x; a.gelu_add = gelu_add;
+    memset(&a, 0, sizeof(a));
     a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.C = s.Cin;
     a.act_bf16 = s.act_bf16; a.xcd_nx = 0;
     a.kd = s.kd; a.kh = s.kh; a.dd = s.dd; a.dh = s.dh;
     if (flip) { a.pd = s.dd * (s.kd - 1) - s.pd; a.ph = s.dh * (s.kh - 1) - s.ph; a.pw = s.dw * (s.kw - 1) - s.pw; }
     else { a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; }
+}
+
+int dw_forward(const SameConv &s, const float *x, const float *w, const float *bias, float *out, float *wp, int flip, hipStream_t st,
+               const float *gelu_x = nullptr, const float *gelu_add = nullptr, float *out_lo = nullptr, const DwBlk *bk = nullptr)
+{
+    if (w) DLKA_TRY(launch_cl_dw_prep_weight(w, wp, s.Cin, s.K, flip, st));
+    if (out_lo && s.act_bf16) return DLKA_ERR_UNSUPPORTED;   // (the bf16 copy rides in the fp32 kernels only)
+    DwArgs a;
+    fill_dw_args(a, s, flip);
+    a.in = x; a.wp = wp; a.bias = bias; a.out = out; a.out_lo = out_lo; a.gelu_x = gelu_x; a.gelu_add = gelu_add;
+    if (bk && bk->blk) {
+        a.blk = bk->blk; a.blk_floats = bk->blk_floats; a.in_blocked = bk->in_blocked ? 1 : 0;
+        if (bk->chained) *bk->chained = false;
+        if (bk->chain && bk->chain_blk && cl_dwconv_lds_selected(a, s.kw, s.dw)) {
+            DwArgs n;
+            fill_dw_args(n, *bk->chain, flip);
+            n.blk = bk->chain_blk; n.blk_floats = bk->blk_floats;
+            if (cl_dwconv_lds_selected(n, bk->chain->kw, bk->chain->dw)) {
+                a.out_blk = bk->chain_blk; a.out_blk_dil = bk->chain->dw;
+                if (bk->chained) *bk->chained = true;
+            }
+        }
+    }
     return launch_cl_dwconv(a, s.kw, s.dw, st);
 }
 
@@ -422,6 +453,12 @@ struct TokGeoms {
         return m;
     }
     size_t scratch_floats() const { return deform_scratch_floats(dcn); }
+    // class-blocked fp32 copy of a depthwise conv's input (cl_dwconv_lds.hip): two of them, so that one conv's epilogue can write the next one's
+    size_t blk_floats() const
+    {
+        const size_t a5 = cl_dwconv_blk_floats(dw5.B, dw5.Cin, dw5.D, dw5.H, dw5.W, dw5.dw), a7 = cl_dwconv_blk_floats(dw7.B, dw7.Cin, dw7.D, dw7.H, dw7.W, dw7.dw);
+        return ((a5 > a7 ? a5 : a7) + 63) & ~(size_t)63;
+    }
     // the deformable conv's samples S[tap][m][c], handed from the grad_offset kernel to the weight gradient (0: too large for 32-bit buffer
     // offsets, or switched off — the weight gradient then gathers for itself).  The switch is ONE process-wide value (wgrad_gather(): initialised once
     // from DLKA_WGRAD_GATHER, changed only through dlka_lka3d_force_wgrad_gather), and the workspace SIZE query always includes the sample area
@@ -998,7 +1035,7 @@ size_t dlka_lka3d_tokens_workspace_bytes_v(int B, int C, int D, int H, int W, in
     if (!dlka_lka3d_tokens_supported_v(B, C, D, H, W, dtype, variant)) return 0;
     TokGeoms G(B, C, D, H, W, dtype, variant);   // (the eight gradient buffers keep their fp32 size on the bf16 path: gta and the split scratch ARE fp32)
     return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 8 * align256(G.E * 4) + align256(G.GOff * 4) +
-           align256(G.scratch_floats() * 4) + align256(G.samp_capacity_floats() * 4) + align256(4096);
+           align256(G.scratch_floats() * 4) + align256(G.samp_capacity_floats() * 4) + 2 * align256(G.blk_floats() * 4) + align256(4096);
 }
 
 static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void *y_, void *saved, size_t saved_bytes, void *workspace,
@@ -1024,6 +1061,7 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     float *acc32 = (float *)cv.take(G.E * 4);   // bf16 path: fp32 landing zone of a tap-split deformable conv (small stages)
     // bf16 path: the fp32 offset-determining chain (TokGeoms): a32, t1_32, t_32 — the next three of the backward pass's gradient buffers
     float *a32 = (float *)cv.take(G.E * 4), *t1_32 = (float *)cv.take(G.E * 4), *t_32 = (float *)cv.take(G.E * 4);
+    float *blkA = (float *)cv.take(G.blk_floats() * 4), *blkB = (float *)cv.take(G.blk_floats() * 4);   // blocked inputs of the LDS-brick depthwise convs
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const bool bf = dtype == DLKA_BF16;
     const float *x = (const float *)x_;
@@ -1049,8 +1087,12 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     // depthwise 5^3 then 7^3 dilation 3 (:646-647)   (bf16: fp32 in / out, the bf16 copies t1 / t ride in the same kernels)
     const float *a_in = bf ? a32 : a;
     float *t1_out = bf ? t1_32 : t1, *t_out = bf ? t_32 : t;
-    DLKA_TRY(dw_forward(G.dw5_f, a_in, N0, (const float *)p->conv0_b, t1_out, PW.dw5_f, 0, st, nullptr, nullptr, bf ? t1 : nullptr));
-    DLKA_TRY(dw_forward(G.dw7_f, t1_out, N0, (const float *)p->conv_spatial_b, t_out, PW.dw7_f, 0, st, nullptr, nullptr, bf ? t : nullptr));
+    bool chained = false;
+    DwBlk bk5, bk7;
+    bk5.blk = blkA; bk5.blk_floats = G.blk_floats(); bk5.chain = &G.dw7_f; bk5.chain_blk = blkB; bk5.chained = &chained;
+    DLKA_TRY(dw_forward(G.dw5_f, a_in, N0, (const float *)p->conv0_b, t1_out, PW.dw5_f, 0, st, nullptr, nullptr, bf ? t1 : nullptr, &bk5));
+    bk7.blk = blkB; bk7.blk_floats = G.blk_floats(); bk7.in_blocked = chained;
+    DLKA_TRY(dw_forward(G.dw7_f, t1_out, N0, (const float *)p->conv_spatial_b, t_out, PW.dw7_f, 0, st, nullptr, nullptr, bf ? t : nullptr, &bk7));
     // offset-predict conv C -> 81 (synapse/deform_conv.py:94) on the fp32 t; offsets stay in the reference's planar layout
     DLKA_TRY(dense_forward(G.offc_f, t_out, N0, (const float *)p->offset_b, off, 1, PW.off_f, 0, nullptr, nullptr, st, true));
     // deformable 3^3 conv (deform_conv.py:95-105)   (bf16: samples the bf16 copy of t)
@@ -1343,6 +1385,7 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
     float *goff = (float *)cv.take(G.GOff * 4);
     float *scratch = (float *)cv.take(G.scratch_floats() * 4);
     float *samp = G.samp_floats() ? (float *)cv.take(G.samp_floats() * 4) : nullptr;
+    float *blkA = (float *)cv.take(G.blk_floats() * 4), *blkB = (float *)cv.take(G.blk_floats() * 4);   // blocked inputs of the LDS-brick depthwise convs
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const float *x = (const float *)x_, *gy = (const float *)gy_;
     float *gx = (float *)gx_;
@@ -1431,13 +1474,17 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
     DLKA_TRY(publish());
     // depthwise 7^3 dil 3:  t = DW7 t1
     DLKA_P2(dw_backward_weight(G.dw7, t1, gt, (float *)gr->conv_spatial_w, (float *)gr->conv_spatial_b, stage7, ws_, &fb.j[fb.njobs++]));
-    DLKA_P1(dw_forward(G.dw7, gt, N0, nullptr, gt1, PW.dw7_b, 1, st));
+    bool chained = false;
+    DwBlk bk7, bk5;
+    bk7.blk = blkA; bk7.blk_floats = G.blk_floats(); bk7.chain = &G.dw5; bk7.chain_blk = blkB; bk7.chained = &chained;
+    DLKA_P1(dw_forward(G.dw7, gt, N0, nullptr, gt1, PW.dw7_b, 1, st, nullptr, nullptr, nullptr, &bk7));
     DLKA_TRY(publish());
     // depthwise 5^3:  t1 = DW5 a
     DLKA_P2(dw_backward_weight(G.dw5, a, gt1, (float *)gr->conv0_w, (float *)gr->conv0_b, stage5, ws_, &fb.j[fb.njobs++]));
     // ... with the GELU backward in its epilogue:  a = GELU(h),  gh = (ga1 + DW5^T gt1) * gelu'(h)
     (void)E;
-    DLKA_P1(dw_forward(G.dw5, gt1, N0, nullptr, gh, PW.dw5_b, 1, st, h, ga1));
+    bk5.blk = blkB; bk5.blk_floats = G.blk_floats(); bk5.in_blocked = chained;
+    DLKA_P1(dw_forward(G.dw5, gt1, N0, nullptr, gh, PW.dw5_b, 1, st, h, ga1, nullptr, &bk5));
     DLKA_TRY(publish());
     // proj_1:  h = P1 x ;  gx = P1^T gh + gy (shortcut)
     if (phase != 1) {

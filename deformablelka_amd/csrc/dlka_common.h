@@ -67,6 +67,12 @@ __device__ __forceinline__ float act_load1(const float *p, long i) { return p[i]
 __device__ __forceinline__ float act_load1(const bf16_t *p, long i) { return __uint_as_float((unsigned)p[i].v << 16); }
 __device__ __forceinline__ void act_store1(float *p, long i, float v) { p[i] = v; }
 __device__ __forceinline__ void act_store1(bf16_t *p, long i, float v) { p[i].v = bf16_bits(v); }
+// two consecutive elements (i even)
+__device__ __forceinline__ void act_store2(float *p, long i, float v0, float v1) { *reinterpret_cast<f32x2 *>(p + i) = f32x2{v0, v1}; }
+__device__ __forceinline__ void act_store2(bf16_t *p, long i, float v0, float v1)
+{
+    *reinterpret_cast<unsigned *>(p + i) = (unsigned)bf16_bits(v0) | ((unsigned)bf16_bits(v1) << 16);
+}
 
 // ---------------------------------------------------------------------------------------------
 // geometry with the derived sizes every kernel needs

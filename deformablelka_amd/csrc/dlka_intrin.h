@@ -102,6 +102,15 @@ __device__ __forceinline__ float buf_load_f32_s(BufRsrc r, unsigned voff, unsign
     if (!(voff < r.bytes)) return 0.f;
     return buf_load_f32(r, voff + soff);
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 buf_load_f32x2_s(BufRsrc r, unsigned voff, unsigned soff)
+{
+    f32x2 v = {0.f, 0.f};
+    if (!(voff < r.bytes)) return v;
+    v[0] = buf_load_f32(r, voff + soff); v[1] = buf_load_f32(r, voff + soff + 4u);
+    return v;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { f32x2 d; d[0] = fmaf(a[0], b[0], c[0]); d[1] = fmaf(a[1], b[1], c[1]); return d; }
 // 4-byte store, dropped when the offset is out of range (DLKA_OOB)
 __device__ __forceinline__ void buf_store_f32(BufRsrc r, unsigned off, float v)
 {
@@ -256,6 +265,13 @@ __device__ __forceinline__ float buf_load_f32_s(BufRsrc r, unsigned voff, unsign
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 buf_load_f32x2_s(BufRsrc r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+// v_pk_fma_f32: two fp32 FMAs per lane in one issue slot (each half rounds like fmaf)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 // No wave-uniform (SGPR) offset variant for stores, on purpose.  Measured on the MI355X (scripts/debug_samp.py, round 2): with an SGPR soffset the
 // compiler (ROCm 7.2 clang) assumes the "VALU overwrites the data registers of a > 64-bit VMEM store" hazard away and schedules such a VALU
 // write directly behind buffer_store_dwordx4 — lanes 8-15 / 24-31 / 40-47 / 56-63 then stored the NEW register contents.  With the whole offset
