@@ -271,7 +271,11 @@ __device__ __forceinline__ f32x2 buf_load_f32x2_s(BufRsrc r, unsigned voff, unsi
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
 // v_pk_fma_f32: two fp32 FMAs per lane in one issue slot (each half rounds like fmaf)
+#if defined(DLKA_NO_PK)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { f32x2 d; d[0] = fmaf(a[0], b[0], c[0]); d[1] = fmaf(a[1], b[1], c[1]); return d; }
+#else
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
 // No wave-uniform (SGPR) offset variant for stores, on purpose.  Measured on the MI355X (scripts/debug_samp.py, round 2): with an SGPR soffset the
 // compiler (ROCm 7.2 clang) assumes the "VALU overwrites the data registers of a > 64-bit VMEM store" hazard away and schedules such a VALU
 // write directly behind buffer_store_dwordx4 — lanes 8-15 / 24-31 / 40-47 / 56-63 then stored the NEW register contents.  With the whole offset
