@@ -1,29 +1,34 @@
-// Channels-last depthwise 3-D convolution through an LDS brick (round 4) — the large-volume stages of the D-LKA block
-// (5^3 pad 2 and 7^3 dilation 3 pad 9: 3D/d_lka_former/network_architecture/synapse/transformerblock.py:637-638; cuDNN in the reference).
+// Channels-last depthwise 3-D convolution through an LDS brick (round 4) — an OPT-IN alternative (DLKA_DW_LDS=1) to cl_dwconv_rowsN_kernel for the
+// large-volume stages of the D-LKA block (5^3 pad 2 and 7^3 dilation 3 pad 9: 3D/d_lka_former/network_architecture/synapse/transformerblock.py:637-638;
+// cuDNN in the reference).  MEASURED NO FASTER than the register-row kernel (profiles/r05_notes.md: 40 - 45 us against 42 at (32 channels, 32^3, 7^3
+// dilation 3)), hence not selected by default; kept, tested, as the record of what bounds this conv on the MI355X:
 //
-// Why: cl_dwconv_rowsN_kernel (cl_dwconv.hip) reads every input row segment through the vector L1 — one 256-byte wave load per segment element,
-// 1.7 GB per launch at (32 channels, 32^3, 7^3 dilation 3) — and that launch's 42 us ARE those bytes at the L1's 64 bytes / clock / CU; its 720 M
-// FMAs take 9 us as packed fp32.  Register tiles cannot buy the missing reuse (more outputs per work-item = one wave per SIMD; measured slower, r01o).
+// cl_dwconv_rowsN_kernel reads every input row segment through the vector L1 — one 256-byte wave load per segment element, 1.7 GB per launch at
+// that shape, 42 us at the L1's 64 bytes / clock / CU.  Here a workgroup stages the input brick of its outputs ONCE into LDS (4 channels of every
+// cell) and every tap reads LDS.  A DILATED conv decomposes into DIL^3 independent dense convs: outputs with coordinates = (rd, rh, rw) mod DIL only
+// read inputs of the same residue class, so the brick lives in "residue space" (cell q <-> voxel r + DIL q), where the 7^3 dilation-3 conv is a dense
+// 7^3 conv with halo 3 on a (D / 3)^3 sub-volume — 11^3 outputs + halo = 17^3 cells at 32^3: with 4 channels per workgroup the WHOLE class fits in
+// 78.6 KB, two workgroups per CU.  Zero padding is stored (cells outside the volume = 0), the tap loops are branch-free: per input row, 77 FMAs per
+// lane against 9 LDS read instructions and one address add (ISA count).
 //
-// Here a workgroup stages the input brick of its outputs ONCE into LDS (4 channels of every cell) and every tap reads LDS.  A DILATED conv
-// decomposes into DIL^3 independent dense convs: outputs with coordinates = (rd, rh, rw) mod DIL only read inputs of the same residue class, so the
-// brick lives in "residue space" (cell q <-> voxel r + DIL q), where the 7^3 dilation-3 conv is a dense 7^3 conv with halo 3 on a (D / 3)^3
-// sub-volume — 11^3 outputs + halo = 17^3 cells at 32^3: with 4 channels per workgroup the WHOLE class fits in 78.6 KB, two workgroups per CU.
-// Zero padding is stored (cells outside the volume = 0), the tap loops are branch-free.
+// What the three versions measured (r5l, r5m, r5n; us per launch at the shape above, the register-row kernel 42):
+//   1. lane = one channel, brick staged straight from the channels-last tensor (16 bytes of every 128-byte line; the other 112 fetched and dropped),
+//      plain v_fma_f32: 40.0 with single rows per work-item (4 waves per SIMD), 68.8 with row pairs (66 work-items per channel = 5 waves per workgroup,
+//      three on two of the SIMDs);
+//   2. (this file) brick staged from a CLASS-BLOCKED fp32 copy of the input, blk[b][channel quad][residue class][qd][qh][qw][4], in which a brick row is
+//      one contiguous run — written by cl_dw_block_kernel or, between two consecutive depthwise convs, by the producing conv's epilogue
+//      (DwArgs::out_blk) — and lane = channel PAIR on v_pk_fma_f32: 42.7;  3. the same with two v_fma_f32 per pair (-DDLKA_NO_PK): 45.4.
+// I.e. the time is the FMA issue itself: a wave64 v_fma_f32 occupies its 16-lane SIMD for 4 cycles and v_pk_fma_f32 for 8 (no gain from packing:
+// the same A/B over the whole library, built with and without the SLP vectoriser's packed fp32, moved no kernel by more than 8 % either way), so the
+// chip does 64 fp32 FMA lanes per clock and CU: 720 M FMAs (+ 16 % of lane and row padding here) = 21 - 25 us at the 2.1 - 2.4 GHz the clocks settle at,
+// before staging, the per-plane weight loads and the tail of a 432-workgroup launch on 512 slots.  A depthwise conv has no contraction to put on the
+// matrix cores (a banded Toeplitz product would spend 7x the useful FLOPs), so ~25 us is this conv's floor and both kernels sit at 1.7x of it.
 //
-// The first version staged straight from the channels-last tensor: 16 bytes of every 128-byte line per workgroup, the other 112 fetched and dropped
-// — 272 MB of L2 -> L1 fills per launch, all workgroups in phase at the start: 40 us, no better than the register-row kernel (profiles/r05l).  So
-// the brick's source is a CLASS-BLOCKED copy of the input, blk[b][channel quad][residue class][qd][qh][qw][4] fp32, in which a brick row is one
-// contiguous run.  The copy is written by cl_dw_block_kernel (one pass over the tensor) or — between two consecutive depthwise convs (5^3 -> 7^3
-// forward, 7^3 -> 5^3 in the data-gradient chain) — by the producing conv's epilogue (DwArgs::out_blk).
-//
-// Work-item = (channel PAIR, W-run of TW outputs, TH consecutive h rows, one d) in residue space: acc / row segment / tap weights are 2-vectors over
-// the pair and every multiply-add is one v_pk_fma_f32 (two fp32 FMAs per lane and issue slot — unpacked, this kernel is bound by FMA issue at half
-// the rate); per input row SEG = TW + KW - 1 eight-byte LDS reads feed TH * KW * TW packed FMAs.  Rows are an ODD number of cells apart (bank
-// spread).  The KW x KW tap weights of a d-plane sit in registers, the first two tap rows of the next plane are requested a plane ahead; row r + 1
-// is read from LDS while row r is multiplied.  Same kernel = forward and data gradient (flipped taps); epilogues as cl_dwconv_rowsN_kernel.
-// Compiled with -fno-slp-vectorize (Makefile): the packing is explicit, and the SLP vectoriser's own pairing of neighbouring OUTPUTS needs
-// shifted copies of the row segment (168 registers plus scratch).
+// Work-item = (channel pair, W-run of TW outputs, TH consecutive h rows, one d) in residue space; rows are an ODD number of cells apart (bank spread).
+// The KW x KW tap weights of a d-plane sit in registers, the first two tap rows of the next plane are requested a plane ahead; row r + 1 is read from
+// LDS while row r is multiplied.  Same kernel = forward and data gradient (flipped taps); epilogues as cl_dwconv_rowsN_kernel.  Compiled with
+// -fno-slp-vectorize (Makefile): the packing is explicit, and the SLP vectoriser's own pairing of neighbouring OUTPUTS needs shifted copies of the
+// row segment (168 registers plus scratch).
 #include <stdlib.h>
 
 #include <atomic>
@@ -247,12 +252,12 @@ static int dw_lds_launch(const DwArgs &a, DwLdsGeom g, size_t lds, int threads, 
     return DLKA_OK;
 }
 
-// DLKA_DW_LDS: unset / "1" = per-shape selection below, "0" = never (the A/B switch of profiles/r05_notes.md), "2" = wherever the geometry fits
-// (emulator tests reach the kernel at small shapes with it).  Read per launch, like DLKA_DDW2D_GX.
+// DLKA_DW_LDS: unset / "0" = never (the default: see the header), "1" = per-shape selection below (the A/B runs of profiles/r05_notes.md), "2" = wherever
+// the geometry fits (emulator tests reach the kernel at small shapes with it).  Read per launch, like DLKA_DDW2D_GX.
 static int dw_lds_mode()
 {
     const char *e = getenv("DLKA_DW_LDS");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 0;
 }
 
 // variant of the launch: 0 = not this kernel; 1 = 7^3 dil 3, classes of up to 11^3 (rows of 11); 2 = 7^3 dil 3, classes of up to 6^3; 3 = 5^3

@@ -474,9 +474,9 @@ size_t dlka_lka3d_tokens_saved_bytes_v(int B, int C, int D, int H, int W, int dt
  * returns the previous setting.  Initial value: 1 iff the environment variable DLKA_WGRAD_GATHER is set when the first token-path call is made.
  * For A/B runs and the hand-over parity test; the workspace size query always covers both routes. */
 int dlka_lka3d_force_wgrad_gather(int on);
-/* Diagnostics: launches so far (this process) of the LDS-brick depthwise kernel (csrc/cl_dwconv_lds.hip) — the dw 5^3 / 7^3 dilation-3 convs of the
- * block and their data gradients take it where the volume is large enough (DLKA_DW_LDS=0: never, =2: wherever its geometry fits); the tests use it
- * to assert WHICH kernel produced the result they compare. */
+/* Diagnostics: launches so far (this process) of the opt-in LDS-brick depthwise kernel (csrc/cl_dwconv_lds.hip; DLKA_DW_LDS=1: the dw 5^3 / 7^3
+ * dilation-3 convs of the block and their data gradients take it where the volume is large enough, =2: wherever its geometry fits; default: never —
+ * it measured no faster than the register-row kernel); the tests use it to assert WHICH kernel produced the result they compare. */
 long dlka_dwconv_lds_launch_count(void);
 size_t dlka_lka3d_tokens_workspace_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
 int dlka_lka3d_attention_tokens_forward_v(const void *x, const dlka_lka3d_params *p, void *y, void *saved, size_t saved_bytes,
