@@ -11,6 +11,8 @@ from __future__ import annotations
 from ctypes import byref
 from typing import List, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -175,6 +177,7 @@ class DLKABlockStack:
             self._ev_data = [torch.cuda.Event() for _ in range(2)]
             self._ev_wg = [torch.cuda.Event() for _ in range(2)]
             self._ev_prep, self._ev_prep2 = torch.cuda.Event(), torch.cuda.Event()
+            self._ev_fin = torch.cuda.Event()
             c0 = self.blocks[0].C
             self._prep_split = sum(1 for b in self.blocks if b.C == c0)   # blocks of the first stage
         else:
@@ -242,6 +245,19 @@ class DLKABlockStack:
         overlap = defer and getattr(self, "_overlap", False)
         side = self._side if overlap else None
         used = [False, False]   # workspace k has weight gradients in flight on the side stream
+        # Sealed plan + side stream: the folds of a block's partial sums follow its weight gradients ON THE SIDE STREAM, a few blocks per launch, instead
+        # of one launch for the whole pass after the join (330 us exposed at the end of every step, profiles/r04s): that stream has the slack (the weight
+        # gradients are ~40 % of a block's backward work) and only the last group's fold is left behind the last block.  DLKA_STACK_FINALIZE_GROUP=0:
+        # the single launch at the end (A/B).
+        fin_group = int(os.environ.get("DLKA_STACK_FINALIZE_GROUP", "3"))
+        side_fin = bool(overlap and side is not None and self._fin_sealed and fin_group > 0)
+        pending = []   # blocks (descending) whose weight gradients are issued and whose folds are not
+
+        def fold_pending():
+            rc = self.lib.dlka_wgrad_finalize_run(L.ptr(self._fin_dev), plan_ptr, pending[-1], pending[0] + 1, side.cuda_stream)
+            L.check(rc, "wgrad_finalize_run (side stream)")
+            pending.clear()
+
         for n, i in enumerate(reversed(idx)):
             blk = self.blocks[i]
             if on_block is not None:
@@ -264,6 +280,10 @@ class DLKABlockStack:
                             "backward phase 2")
                     self._ev_wg[k].record(side)
                     used[k] = True
+                    if side_fin:
+                        pending.append(i)
+                        if len(pending) >= fin_group:
+                            fold_pending()
                 else:
                     L.check(self.lib.dlka_lka3d_attention_tokens_backward_phase_v(*args, plan_ptr if record else None, i, 2, *dims7, st), "backward phase 2")
                 if record:
@@ -292,7 +312,12 @@ class DLKABlockStack:
             for k in range(2):
                 if used[k]:
                     torch.cuda.current_stream(self.device).wait_event(self._ev_wg[k])
-        if defer and idx:
+        if side_fin:
+            if pending:
+                fold_pending()
+            self._ev_fin.record(side)
+            torch.cuda.current_stream(self.device).wait_event(self._ev_fin)   # the gradients are complete for whatever follows the pass
+        elif defer and idx:
             if self._fin_sealed:
                 rc = self.lib.dlka_wgrad_finalize_run(L.ptr(self._fin_dev), plan_ptr, idx[0], idx[-1] + 1, st)
                 L.check(rc, "wgrad_finalize_run")
