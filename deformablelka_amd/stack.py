@@ -248,8 +248,8 @@ class DLKABlockStack:
         # Sealed plan + side stream: the folds of a block's partial sums follow its weight gradients ON THE SIDE STREAM, a few blocks per launch, instead
         # of one launch for the whole pass after the join (330 us exposed at the end of every step, profiles/r04s): that stream has the slack (the weight
         # gradients are ~40 % of a block's backward work) and only the last group's fold is left behind the last block.  DLKA_STACK_FINALIZE_GROUP=0:
-        # the single launch at the end (A/B).
-        fin_group = int(os.environ.get("DLKA_STACK_FINALIZE_GROUP", "3"))
+        # the single launch at the end.  Measured (profiles/r05_notes.md, ms per step): 0 -> 11.135, 1 -> 11.044, 2 -> 11.008, 3 -> 11.09, 5 -> 11.09.
+        fin_group = int(os.environ.get("DLKA_STACK_FINALIZE_GROUP", "2"))
         side_fin = bool(overlap and side is not None and self._fin_sealed and fin_group > 0)
         pending = []   # blocks (descending) whose weight gradients are issued and whose folds are not
 
