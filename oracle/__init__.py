@@ -36,9 +36,15 @@ _lib = None
 def build(force: bool = False) -> str:
     """Compile the C oracle with gcc (idempotent)."""
     src = [os.path.join(_HERE, f) for f in ("dlka_oracle.c", "dlka_oracle_impl.h", "Makefile")]
-    stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
-    if stale:
-        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    def stale():
+        return not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
+
+    if force or stale():
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lk:   # several test processes (pytest-xdist workers, spawned ranks) may get here at once
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if force or stale():
+                subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
 
 

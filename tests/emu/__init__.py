@@ -16,9 +16,21 @@ def build(force=False):
     srcs = sorted(glob.glob(os.path.join(ROOT, "deformablelka_amd", "csrc", "*.hip")))
     deps = srcs + glob.glob(os.path.join(ROOT, "deformablelka_amd", "csrc", "*.h")) + [
         os.path.join(ROOT, "include", "dlka.h"), os.path.join(_HERE, "include", "hip", "hip_runtime.h")]
-    if not force and os.path.exists(SO) and all(os.path.getmtime(d) <= os.path.getmtime(SO) for d in deps):
+    def fresh():
+        return os.path.exists(SO) and all(os.path.getmtime(d) <= os.path.getmtime(SO) for d in deps)
+
+    if not force and fresh():
         return SO
     os.makedirs(os.path.dirname(SO), exist_ok=True)
+    import fcntl
+    with open(os.path.join(_HERE, "_build", ".lock"), "w") as lk:   # pytest-xdist workers / spawned ranks: ONE of them builds, the others wait
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not force and fresh():
+            return SO
+        return _build_locked(srcs)
+
+
+def _build_locked(srcs):
     cxx = CLANG if os.path.exists(CLANG) else "clang++"
     objs = []
     procs = []
@@ -31,7 +43,9 @@ def build(force=False):
     for p in procs:
         if p.wait() != 0:
             raise RuntimeError("emulator build failed")
-    subprocess.check_call([cxx, "-shared", "-o", SO] + objs + ["-lpthread"])
+    tmp = SO + ".tmp%d" % os.getpid()   # linked aside, then renamed: a process that has the old library mapped keeps its (unlinked) file
+    subprocess.check_call([cxx, "-shared", "-o", tmp] + objs + ["-lpthread"])
+    os.replace(tmp, SO)
     return SO
 
 
