@@ -386,8 +386,11 @@ int cl_igemm_pick_splits(int M, int units, int epi, int K)
     // contention instead of chasing block count.
     static int cap = -1;
     if (cap < 0) cap = 32;
-    static int want = -1;   // workgroups to aim for (tuning knob)
-    if (want < 0) want = 512;
+    static int want = -1;   // workgroups to aim for (tuning knob; -DDLKA_SPLIT_WANT=n builds a variant for scripts/build_variant.sh)
+#ifndef DLKA_SPLIT_WANT
+#define DLKA_SPLIT_WANT 512
+#endif
+    if (want < 0) want = DLKA_SPLIT_WANT;
     int splits = 1;
     while (mblocks * splits < want && splits < units && splits < cap) ++splits;
     const int ups = cdiv(units, splits);

@@ -168,6 +168,9 @@ class DLKABlockStack:
         if enable is None:   # default: on (measured 11.95 -> 11.47 ms per step under hipGraph replay); DLKA_STACK_WGRAD_OVERLAP=0 = one stream
             enable = os.environ.get("DLKA_STACK_WGRAD_OVERLAP", "1") != "0"
         self._overlap = bool(enable) and self._fin_host is not None
+        # blocks narrower than this run their weight gradients IN LINE on the calling stream (A/B knob: at the widest-volume stage the data chain fills
+        # the chip by itself, so the side stream's kernels mostly stretch it; profiles/r05_notes.md has the measurement behind the default)
+        self._overlap_min_c = int(os.environ.get("DLKA_STACK_WGRAD_OVERLAP_MIN_C", "0"))
         self._prep_pending, self._prep_split = None, 0
         if not self._overlap:
             return
@@ -273,7 +276,17 @@ class DLKABlockStack:
                 if side is not None and used[k]:
                     torch.cuda.current_stream(self.device).wait_event(self._ev_wg[k])   # the weight gradients that last read this workspace are done
                 L.check(self.lib.dlka_lka3d_attention_tokens_backward_phase_v(*args, None, i, 1, *dims7, st), "backward phase 1")
-                if side is not None:
+                if side is not None and blk.C < self._overlap_min_c:
+                    # this block's weight gradients in line; the side stream (which folds the partial sums) continues behind them
+                    L.check(self.lib.dlka_lka3d_attention_tokens_backward_phase_v(*args, plan_ptr if record else None, i, 2, *dims7, st), "backward phase 2")
+                    used[k] = False   # (whatever read this workspace on the side stream was waited for in front of phase 1)
+                    if side_fin:
+                        self._ev_data[k].record(torch.cuda.current_stream(self.device))
+                        side.wait_event(self._ev_data[k])
+                        pending.append(i)
+                        if len(pending) >= fin_group:
+                            fold_pending()
+                elif side is not None:
                     self._ev_data[k].record(torch.cuda.current_stream(self.device))
                     side.wait_event(self._ev_data[k])
                     L.check(self.lib.dlka_lka3d_attention_tokens_backward_phase_v(*args, plan_ptr if record else None, i, 2, *dims7, side.cuda_stream),
