@@ -150,6 +150,7 @@ SIGNATURES = {
     "dlka_deform_dwconv2d_backward_cl": (c_int, [c_void_p] * 8 + [c_size_t, _G, c_int, c_void_p]),
     "dlka_lka3d_force_wgrad_gather": (c_int, [c_int]),
     "dlka_dwconv_lds_launch_count": (ctypes.c_long, []),
+    "dlka_conv_brick_launch_count": (ctypes.c_long, []),
     "dlka_lka3d_tokens_supported_v": (c_int, [c_int] * 7),
     "dlka_lka3d_tokens_saved_bytes_v": (c_size_t, [c_int] * 7),
     "dlka_lka3d_tokens_workspace_bytes_v": (c_size_t, [c_int] * 7),

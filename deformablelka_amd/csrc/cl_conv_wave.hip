@@ -55,11 +55,21 @@ __global__ __launch_bounds__(256) void cl_conv_wave_kernel(IgemmArgs p)
     float abuf[DEPTH][16];
     f32x4 bbuf[DEPTH][NB];   // [(part * 2 + mf) * NT + t]
     // A rows and B records of one unit into a register set (all loads unconditional buffer loads)
+#ifndef DLKA_ABLW   // -DDLKA_ABLW=bits: TIMING-ONLY ablations of the planar-input two-term kernel (wrong results): 1 no split arithmetic, 2 one MFMA per
+#define DLKA_ABLW 0  // k-half instead of three, 4 no A fetch in the loop, 8 no weight-record fetch in the loop
+#endif
+    constexpr int ABL = (AMODE == 2 && SPLIT == 2 && NT == 1) ? DLKA_ABLW : 0;
+    bool first_issue = true;
     auto issue = [&](int unit, float *ad, f32x4 *bd) {
-        int ck;
-        const int tap = divmod_fast(unit, nchunk, ck);
-        arow.fetch(p, rin, tap, ck, h, row_ok, b, v, d0, h0, w0, ad);
-        const unsigned ub = (unsigned)unit * unit_bytes + blane;
+        int ck, tap;
+#ifdef DLKA_CK_OUTER
+        if (AMODE == 2) { ck = unit / p.K; tap = unit - ck * p.K; }   // planar input: plane chunks OUTER, taps inner (see the launcher)
+        else
+#endif
+        tap = divmod_fast(unit, nchunk, ck);
+        if (!(ABL & 4) || first_issue) arow.fetch(p, rin, tap, ck, h, row_ok, b, v, d0, h0, w0, ad);
+        const unsigned ub = (unsigned)(tap * nchunk + ck) * unit_bytes + blane;
+        if (!(ABL & 8) || first_issue) {
 #pragma unroll
         for (int part = 0; part < SPLIT; ++part)
 #pragma unroll
@@ -67,8 +77,14 @@ __global__ __launch_bounds__(256) void cl_conv_wave_kernel(IgemmArgs p)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     bd[(part * 2 + mf) * NT + t] = buf_load_f32x4(rw, ub + (unsigned)((part * 2 + mf) * 2) * seg_bytes + (unsigned)t * 512u);
+        }
+        if (ABL) first_issue = false;
     };
     auto compute = [&](const float *a_cur, const f32x4 *b_cur) {
+#ifdef DLKA_IGLP
+        __builtin_amdgcn_iglp_opt(DLKA_IGLP);   // (experiment: scripts/build_variant.sh NAME -DDLKA_IGLP=0|1)
+#endif
+
 #pragma unroll
         for (int mf = 0; mf < 2; ++mf) {
             if (SPLIT == 3) {
@@ -89,11 +105,13 @@ __global__ __launch_bounds__(256) void cl_conv_wave_kernel(IgemmArgs p)
                 bf16x8 ahi, alo;
                 if (A16) ahi = alo = bf16x8_from_words(a_cur + 4 * mf);   // raw bf16 rows (ARow): their own high term, no low term
                 else if (AMODE == 2 && p.a_packed) unpack_split2x8(a_cur + 8 * mf, ahi, alo);
+                else if (ABL & 1) { ahi = bf16x8_from_words(a_cur + 8 * mf); alo = bf16x8_from_words(a_cur + 8 * mf + 4); }
                 else split_bf16x8(a_cur + 8 * mf, ahi, alo);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const bf16x8 bhi = __builtin_bit_cast(bf16x8, b_cur[(0 * 2 + mf) * NT + t]), blo = __builtin_bit_cast(bf16x8, b_cur[(1 * 2 + mf) * NT + t]);
                     if (!A16) acc[t] = mfma_32x32x16_bf16(alo, bhi, acc[t]);
+                    if (ABL & 2) continue;
                     acc[t] = mfma_32x32x16_bf16(ahi, blo, acc[t]);
                     acc[t] = mfma_32x32x16_bf16(ahi, bhi, acc[t]);
                 }

@@ -96,29 +96,58 @@ __global__ __launch_bounds__(256) void cl_igemm_kernel(IgemmArgs p)
 #pragma unroll
         for (int e = 0; e < 16; ++e) a_cur[e] = a_nxt[e];
         __syncthreads();   // Bs[buf] staged; Bs[buf^1] (read two iterations ago) is free again
+#ifndef DLKA_ABL   // -DDLKA_ABL=bits builds a TIMING-ONLY ablation of the three-term kernel (wrong results): 1 no split arithmetic, 2 one MFMA per
+#define DLKA_ABL 0  // tile instead of six, 4 no A fetch in the loop, 8 no weight fetch in the loop
+#endif
         if (unit + 1 < unit_hi) {
-            DLKA_LOAD_B(unit + 1)
+            if (!(SPLIT == 3 && (DLKA_ABL & 8))) DLKA_LOAD_B(unit + 1)
             int ck;
             const int tap = divmod_fast(unit + 1, nchunk, ck);
-            arow.fetch(p, rin, tap, ck, h, row_ok, b, v, d0, h0, w0, a_nxt);
+            if (!(SPLIT == 3 && (DLKA_ABL & 4))) arow.fetch(p, rin, tap, ck, h, row_ok, b, v, d0, h0, w0, a_nxt);
         }
+#ifdef DLKA_IGLP
+        __builtin_amdgcn_iglp_opt(DLKA_IGLP);   // (experiment: scripts/build_variant.sh NAME -DDLKA_IGLP=0|1)
+#endif
         if (SPLIT == 3) {
             const bf16x8 *B16 = reinterpret_cast<const bf16x8 *>(Bs[buf]);   // [(part*2 + mf)*2 + h][NPB] records of 8 bf16, part = hi, mid, lo
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) {
                 bf16x8 ahi, amid, alo;
-                split3_bf16x8(a_cur + 8 * mf, ahi, amid, alo);
+                if (DLKA_ABL & 1) { ahi = bf16x8_from_words(a_cur + 8 * mf); amid = bf16x8_from_words(a_cur + 8 * mf + 4); alo = ahi; }
+                else split3_bf16x8(a_cur + 8 * mf, ahi, amid, alo);
+#ifdef DLKA_MFMA_PM   // (experiment: product-major, tile-minor — consecutive MFMAs on different accumulators)
+                bf16x8 bhi[NT], bmid[NT], blo[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    bhi[t] = B16[((0 * 2 + mf) * 2 + h) * NPB + t * 32 + i]; bmid[t] = B16[((1 * 2 + mf) * 2 + h) * NPB + t * 32 + i];
+                    blo[t] = B16[((2 * 2 + mf) * 2 + h) * NPB + t * 32 + i];
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x16_bf16(alo, bhi[t], acc[t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x16_bf16(ahi, blo[t], acc[t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x16_bf16(amid, bmid[t], acc[t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x16_bf16(amid, bhi[t], acc[t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x16_bf16(ahi, bmid[t], acc[t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x16_bf16(ahi, bhi[t], acc[t]);
+#else
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const bf16x8 bhi = B16[((0 * 2 + mf) * 2 + h) * NPB + t * 32 + i], bmid = B16[((1 * 2 + mf) * 2 + h) * NPB + t * 32 + i],
                                  blo = B16[((2 * 2 + mf) * 2 + h) * NPB + t * 32 + i];
                     acc[t] = mfma_32x32x16_bf16(alo, bhi, acc[t]);   // small terms first
+                    if (DLKA_ABL & 2) continue;
                     acc[t] = mfma_32x32x16_bf16(ahi, blo, acc[t]);
                     acc[t] = mfma_32x32x16_bf16(amid, bmid, acc[t]);
                     acc[t] = mfma_32x32x16_bf16(amid, bhi, acc[t]);
                     acc[t] = mfma_32x32x16_bf16(ahi, bmid, acc[t]);
                     acc[t] = mfma_32x32x16_bf16(ahi, bhi, acc[t]);
                 }
+#endif
             }
         } else if (SPLIT) {
             const bf16x8 *B16 = reinterpret_cast<const bf16x8 *>(Bs[buf]);   // [(part*2 + mf)*2 + h][NPB] records of 8 bf16
@@ -410,6 +439,10 @@ int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t s
     if (a.zero.n > 0) {   // only the pointwise kernel carries riding zero fills: anything else gets them as a launch of their own
         if (launch_zero_batch(a.zero, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         a.zero.n = 0;
+    }
+    if (amode == 2 && omode == 0 && splits == 1 && a.split_bf16 == 2) {   // the offset conv's data gradient at the wide stage: LDS-brick kernel
+        const int rc = launch_cl_conv_brick(a, st);
+        if (rc != DLKA_ERR_UNSUPPORTED) return rc;
     }
     if (splits > 1 && !a.out_zeroed) {
         const long n = (long)a.M * a.Cout;

@@ -152,7 +152,8 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
     }
     a.aux_f32 = aux_f32 ? 1 : 0;
     if (ride) a.zero = *ride;
-    const int splits = dense_backward_data_splits(s, epi);
+    int splits = dense_backward_data_splits(s, epi);
+    if (gout_planar && cl_conv_brick_supported(a)) splits = 1;   // (cl_conv_brick.hip writes every output itself: no tap split, whatever the row count)
     if (s.act_bf16 && splits > 1) {
         if (!acc32) return DLKA_ERR_WORKSPACE;
         a.out = acc32; a.out_zeroed = 1;

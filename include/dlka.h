@@ -478,6 +478,8 @@ int dlka_lka3d_force_wgrad_gather(int on);
  * dilation-3 convs of the block and their data gradients take it where the volume is large enough, =2: wherever its geometry fits; default: never —
  * it measured no faster than the register-row kernel); the tests use it to assert WHICH kernel produced the result they compare. */
 long dlka_dwconv_lds_launch_count(void);
+/* launches so far of the LDS-brick data gradient of the offset-predict conv (csrc/cl_conv_brick.hip): parity tests assert which kernel ran */
+long dlka_conv_brick_launch_count(void);
 size_t dlka_lka3d_tokens_workspace_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
 int dlka_lka3d_attention_tokens_forward_v(const void *x, const dlka_lka3d_params *p, void *y, void *saved, size_t saved_bytes,
                                           void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant, void *stream);

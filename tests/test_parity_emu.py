@@ -593,3 +593,28 @@ def test_depthwise_lds_brick_kernel(monkeypatch):
     n3 = lib.dlka_dwconv_lds_launch_count()
     parity.check_lka3d_tokens("cpu", 1, 32, (4, 5, 6))
     assert lib.dlka_dwconv_lds_launch_count() == n3
+
+
+@pytest.mark.parametrize("case", [(1, 32, (2, 16, 16)), (2, 32, (3, 8, 32)), (1, 64, (2, 32, 8))])
+def test_conv_brick_data_gradient(case, monkeypatch):
+    """cl_conv_brick_kernel (the offset-predict conv's data gradient from an LDS brick: planar grad_out staged once per 32-plane chunk, split into its bf16 terms
+    while being staged, 27 taps read from LDS) against the fp64 conv — and against the kernel it replaces at the wide stage (same products, other summation order).
+    DLKA_CONV_BRICK_MIN_WG=1 lets emulator-sized volumes take it (real use: >= 128 workgroups of 256 voxels); the launch counter proves which kernel ran.
+    Cases: one 16 x 16 plane per workgroup; W = 32 with 8-row tiles (the stage-0 geometry) across a batch; two output column tiles with W = 8."""
+    from deformablelka_amd import _lib, ops
+    B, C, dims = case
+    lib = _lib.get_lib()
+    monkeypatch.setenv("DLKA_CONV_BRICK_MIN_WG", "1")
+    n0 = lib.dlka_conv_brick_launch_count()
+    parity.check_conv3d_cl("cpu", B, C, 81, dims, 3, 1, 1, 1, planar=True, seed=3)
+    assert lib.dlka_conv_brick_launch_count() == n0 + 1
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B, *dims, C, generator=gen)
+    w = torch.randn(81, C, 3, 3, 3, generator=gen) * 0.05
+    go = torch.randn(B, 81, *dims, generator=gen)
+    g_brick = ops.conv3d_backward_cl(x, w, go, 1, 1, 1, grad_out_planar=True)[0]
+    monkeypatch.setenv("DLKA_CONV_BRICK", "0")
+    n1 = lib.dlka_conv_brick_launch_count()
+    g_wave = ops.conv3d_backward_cl(x, w, go, 1, 1, 1, grad_out_planar=True)[0]
+    assert lib.dlka_conv_brick_launch_count() == n1
+    assert (g_brick - g_wave).abs().max().item() <= 2e-5 * g_wave.abs().max().item()
