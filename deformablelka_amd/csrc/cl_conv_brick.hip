@@ -23,37 +23,49 @@ namespace dlka {
 constexpr int BRICK_ROW = 144;   // bytes per brick voxel
 static std::atomic<long> g_conv_brick_launches{0};   // dlka_conv_brick_launch_count (include/dlka.h): diagnostics
 
-template <int NT, typename T>   // NT = Cout / 32 column tiles per wave; T = storage of `out` (float | bf16_t); `aux` is fp32 when p.aux_f32 or T = float
-__global__ __launch_bounds__(512) void cl_conv_brick_kernel(IgemmArgs p, int TH)
+template <int NT, typename T, int WAVES, int MT = 1>   // NT = Cout / 32 column tiles per wave; T = storage of `out` (float | bf16_t; `aux` is fp32 when p.aux_f32 or T = float);
+__global__ __launch_bounds__(64 * WAVES) void cl_conv_brick_kernel(IgemmArgs p, int TD, int TH)   // MT row tiles of 32 per wave (one weight-record fetch feeds all of them): WAVES x MT x 32 rows = a TD x TH x W tile
 {
     DLKA_DYN_SMEM(unsigned char, brick);
+    constexpr int NTHR = 64 * WAVES;
+    constexpr int MAXI = MT == 2 ? 17 : 9;   // fill items (brick voxel, group of 8 planes) per thread: 4 * brick voxels <= MAXI * NTHR (checked by the launcher)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int W = p.W, BW = W + 2, BH = TH + 2, nvox = 3 * BH * BW;
-    const int hblocks = p.H / TH;
+    const int W = p.W, BW = W + 2, BH = TH + 2, BD = TD + 2, nvox = BD * BH * BW;
+    const int hblocks = p.H / TH, dblocks = p.D / TD;
+    const int lgW = __builtin_ctz((unsigned)W), lgTH = __builtin_ctz((unsigned)TH);
     int bi = blockIdx.x;
     const int hb = bi % hblocks; bi /= hblocks;
-    const int d0 = bi % p.D;
-    const int b = bi / p.D;
-    const int h0 = hb * TH;
-    const long mbase = (long)b * p.N + ((long)d0 * p.H + h0) * W;   // first of this workgroup's 256 rows
+    const int db = bi % dblocks;
+    const int b = bi / dblocks;
+    const int d0 = db * TD, h0 = hb * TH;
     const int nchunk = p.CinP / 32;
     const BufRsrc rin = make_rsrc(p.in, (size_t)p.B * p.CinReal * p.N * 4);
     const BufRsrc rw = make_rsrc(p.wp, (size_t)p.K * nchunk * 32 * p.NP * 4);
     const unsigned unit_bytes = (unsigned)(32 * p.NP) * 4u, seg_bytes = (unsigned)p.NP * 16u;
     const unsigned blane = (unsigned)(h * p.NP + i) * 16u;   // this lane's record inside segment (part, mf), column tile 0
 
-    // this lane's A row: voxel r of the workgroup's 256, at brick position (1, hl + 1, wl + 1) for the centre tap
-    const int r = 32 * wave + i, hl = r / W, wl = r - hl * W;
-    const unsigned abase = (unsigned)((hl * BW + wl) * BRICK_ROW + 32 * h);   // + tap offset + 16 mf (+ 64 for the low term)
-
-    f32x16 acc[NT];
+    // this lane's A row: voxel r of the tile, at brick position (dl + 1, hl + 1, wl + 1) for the centre tap
+    unsigned abase[MT];   // + tap offset + 16 mf (+ 64 for the low term)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    for (int u = 0; u < MT; ++u) {
+        const int r = 32 * (MT * wave + u) + i, dl = r >> (lgW + lgTH), hl = (r >> lgW) & (TH - 1), wl = r & (W - 1);   // (W, TH: powers of two, launcher)
+        abase[u] = (unsigned)(((dl * BH + hl) * BW + wl) * BRICK_ROW + 32 * h);
+    }
 
-    f32x4 bcur[4 * NT], bnxt[4 * NT];   // [(part * 2 + mf) * NT + t]
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int u = 0; u < MT; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[u][t][q] = 0.f;
+
+#ifndef DLKA_BRICK_DEPTH
+#define DLKA_BRICK_DEPTH 4
+#endif
+    constexpr int DEPTH = DLKA_BRICK_DEPTH;   // register ring of weight records: while tap t computes, taps t+1 .. t+DEPTH-1 are in flight (a tap is only
+    f32x4 bring[DEPTH][4 * NT];               // 6 NT MFMAs = 192 NT cycles against an L2 round trip of several hundred)   [(part * 2 + mf) * NT + t]
     auto load_b = [&](int tap, int ck, f32x4 *bd) {
         const unsigned ub = (unsigned)(tap * nchunk + ck) * unit_bytes + blane;
 #pragma unroll
@@ -63,49 +75,78 @@ __global__ __launch_bounds__(512) void cl_conv_brick_kernel(IgemmArgs p, int TH)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) bd[(part * 2 + mf) * NT + t] = buf_load_f32x4(rw, ub + (unsigned)((part * 2 + mf) * 2) * seg_bytes + (unsigned)t * 512u);
     };
-
-    const int nitems = nvox * 4;   // (brick voxel, group of 8 planes)
-    for (int ck = 0; ck < nchunk; ++ck) {
-        load_b(0, ck, bcur);
-        // ---- fill: brick voxels x 4 plane groups; consecutive threads = consecutive brick voxels of one plane group (coalesced along w) ----
-        for (int it = tid; it < nitems; it += 512) {
-            const int pg = it / nvox, vx = it - pg * nvox;
-            const int dz = vx / (BH * BW), rem = vx - dz * (BH * BW);
-            const int hy = rem / BW, wx = rem - hy * BW;
-            const int zd = d0 + dz - 1, zh = h0 + hy - 1, zw = wx - 1;
-            const bool ok = ((unsigned)zd < (unsigned)p.D) & ((unsigned)zh < (unsigned)p.H) & ((unsigned)zw < (unsigned)W);
-            const int plane0 = ck * 32 + pg * 8;
-            const unsigned voff = ok ? (unsigned)(((long)b * p.CinReal + plane0) * p.N + ((long)zd * p.H + zh) * W + zw) * 4u : DLKA_OOB;
-            float a[8];
+    auto compute = [&](int tap, const f32x4 *bcur) {
+        const int ti = tap / 9, tj = (tap - ti * 9) / 3, tk = tap - ti * 9 - tj * 3;
+        const unsigned toff = (unsigned)(((ti * BH + tj) * BW + tk) * BRICK_ROW);
 #pragma unroll
-            for (int e = 0; e < 8; ++e)   // (planes beyond CinReal: padding of the contraction, read as zero)
-                a[e] = buf_load_f32(rin, (voff != DLKA_OOB && plane0 + e < p.CinReal) ? voff + (unsigned)e * (unsigned)p.N * 4u : DLKA_OOB);
-            bf16x8 hi, lo;
-            split_bf16x8(a, hi, lo);
-            unsigned char *dst = brick + (size_t)vx * BRICK_ROW + pg * 16;
-            *reinterpret_cast<bf16x8 *>(dst) = hi;
-            *reinterpret_cast<bf16x8 *>(dst + 64) = lo;
-        }
-        __syncthreads();
-        // ---- 27 taps from the brick ----
-#pragma unroll 1
-        for (int tap = 0; tap < p.K; ++tap) {
-            if (tap + 1 < p.K) load_b(tap + 1, ck, bnxt);
-            const int ti = tap / 9, tj = (tap - ti * 9) / 3, tk = tap - ti * 9 - tj * 3;
-            const unsigned char *ap = brick + abase + (unsigned)(((ti * BH + tj) * BW + tk) * BRICK_ROW);
+        for (int mf = 0; mf < 2; ++mf) {
 #pragma unroll
-            for (int mf = 0; mf < 2; ++mf) {
+            for (int u = 0; u < MT; ++u) {
+                const unsigned char *ap = brick + abase[u] + toff;
                 const bf16x8 ahi = *reinterpret_cast<const bf16x8 *>(ap + 16 * mf), alo = *reinterpret_cast<const bf16x8 *>(ap + 64 + 16 * mf);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const bf16x8 bhi = __builtin_bit_cast(bf16x8, bcur[(0 * 2 + mf) * NT + t]), blo = __builtin_bit_cast(bf16x8, bcur[(1 * 2 + mf) * NT + t]);
-                    acc[t] = mfma_32x32x16_bf16(alo, bhi, acc[t]);   // small terms first
-                    acc[t] = mfma_32x32x16_bf16(ahi, blo, acc[t]);
-                    acc[t] = mfma_32x32x16_bf16(ahi, bhi, acc[t]);
+                    acc[u][t] = mfma_32x32x16_bf16(alo, bhi, acc[u][t]);   // small terms first
+                    acc[u][t] = mfma_32x32x16_bf16(ahi, blo, acc[u][t]);
+                    acc[u][t] = mfma_32x32x16_bf16(ahi, bhi, acc[u][t]);
                 }
             }
+        }
+    };
+
+    // fill items of this thread, described once (the same for every plane chunk): consecutive threads = consecutive brick voxels of one group of 8
+    // planes, i.e. coalesced along w.  src = byte offset of plane (8 pg) of the voxel inside batch b (DLKA_OOB: zero padding), dst = LDS byte offset.
+    const float r_nvox = 1.0f / (float)nvox, r_plane = 1.0f / (float)(BH * BW), r_bw = 1.0f / (float)BW;
+    unsigned fsrc[MAXI], fdst[MAXI];
+    int fpg[MAXI];
 #pragma unroll
-            for (int q = 0; q < 4 * NT; ++q) bcur[q] = bnxt[q];
+    for (int j = 0; j < MAXI; ++j) {
+        const int it = tid + j * NTHR;
+        // (small non-negative integers: quotient by reciprocal multiply — (x + 0.5) / n never comes within 0.5 / n of an integer, far outside float error here)
+        const int pg = (int)(((float)it + 0.5f) * r_nvox), vx = it - pg * nvox;
+        const int dz = (int)(((float)vx + 0.5f) * r_plane), rem = vx - dz * (BH * BW);
+        const int hy = (int)(((float)rem + 0.5f) * r_bw), wx = rem - hy * BW;
+        const int zd = d0 + dz - 1, zh = h0 + hy - 1, zw = wx - 1;
+        const bool ok = (pg < 4) & ((unsigned)zd < (unsigned)p.D) & ((unsigned)zh < (unsigned)p.H) & ((unsigned)zw < (unsigned)W);
+        fsrc[j] = ok ? (unsigned)(((long)b * p.CinReal + 8 * pg) * p.N + ((long)zd * p.H + zh) * W + zw) * 4u : DLKA_OOB;
+        fdst[j] = pg < 4 ? (unsigned)(vx * BRICK_ROW + pg * 16) : DLKA_OOB;
+        fpg[j] = 8 * pg;
+    }
+    const unsigned plane_bytes = (unsigned)p.N * 4u;
+
+#ifndef DLKA_BRICK_ABL   // TIMING-ONLY ablations (wrong results): 1 no fill, 2 no tap loop
+#define DLKA_BRICK_ABL 0
+#endif
+    for (int ck = 0; ck < nchunk; ++ck) {
+#pragma unroll
+        for (int s = 0; s < DEPTH - 1; ++s)
+            if (s < p.K) load_b(s, ck, bring[s]);
+        // ---- fill (split into the two bf16 terms on the way) ----
+#pragma unroll
+        for (int j = 0; j < ((DLKA_BRICK_ABL & 1) ? 0 : MAXI); ++j) {
+            if (fdst[j] == DLKA_OOB) continue;
+            float a[8];
+            const unsigned s0 = fsrc[j] == DLKA_OOB ? DLKA_OOB : fsrc[j] + (unsigned)(ck * 32) * plane_bytes;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)   // (planes beyond CinReal: padding of the contraction, read as zero)
+                a[e] = buf_load_f32(rin, (s0 != DLKA_OOB && ck * 32 + fpg[j] + e < p.CinReal) ? s0 + (unsigned)e * plane_bytes : DLKA_OOB);
+            bf16x8 hi, lo;
+            split_bf16x8(a, hi, lo);
+            *reinterpret_cast<bf16x8 *>(brick + fdst[j]) = hi;
+            *reinterpret_cast<bf16x8 *>(brick + fdst[j] + 64) = lo;
+        }
+        __syncthreads();
+        // ---- 27 taps from the brick ----
+#pragma unroll 1
+        for (int tap = 0; tap < ((DLKA_BRICK_ABL & 2) ? 0 : p.K); tap += DEPTH) {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                if (tap + s < p.K) {   // uniform
+                    if (tap + s + DEPTH - 1 < p.K) load_b(tap + s + DEPTH - 1, ck, bring[(s + DEPTH - 1) % DEPTH]);
+                    compute(tap + s, bring[s]);
+                }
+            }
         }
         __syncthreads();   // every wave is done with this chunk's brick
     }
@@ -114,18 +155,52 @@ __global__ __launch_bounds__(512) void cl_conv_brick_kernel(IgemmArgs p, int TH)
     T *outp = reinterpret_cast<T *>(p.out);
     const T *auxp = reinterpret_cast<const T *>(p.aux);
 #pragma unroll
+    for (int u = 0; u < MT; ++u)
+#pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = t * 32 + i;
         if (n >= p.Cout) continue;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const long mr = mbase + 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * h;
+            const int rr = 32 * (MT * wave + u) + (q & 3) + 8 * (q >> 2) + 4 * h;   // tile row -> voxel
+            const int rd = rr >> (lgW + lgTH), rh = (rr >> lgW) & (TH - 1), rwv = rr & (W - 1);
+            const long mr = (long)b * p.N + ((long)(d0 + rd) * p.H + h0 + rh) * W + rwv;
             const long o = mr * p.Cout + n;
-            float val = acc[t][q];
+            float val = acc[u][t][q];
             if (p.epi == 3) val += (sizeof(T) == 4 || p.aux_f32) ? p.aux[o] : act_load1(auxp, o);
             act_store1(outp, o, val);
         }
     }
+}
+
+// The tile a launch uses: 4-wave workgroups of 2 x TH x W = 128 voxels when their brick leaves room for TWO workgroups per CU (one stages its next chunk
+// while the other runs its taps: measured against one 8-wave workgroup per CU in profiles/r06_notes.md), else 8 waves on 1 x TH x W = 256 voxels.
+struct BrickTile { int waves, mt, TD, TH; size_t lds; };
+#ifndef DLKA_BRICK_DEFAULT_CAND
+#define DLKA_BRICK_DEFAULT_CAND 1   // 0: 4 waves (2 x TH x W tiles, two workgroups per CU), 1: 8 waves, 2: 4 waves of two row tiles
+#endif
+static bool brick_tile(const IgemmArgs &a, BrickTile &bt)
+{
+    if (a.W > 32 || a.W < 8 || 256 % a.W) return false;
+    const char *force = getenv("DLKA_CONV_BRICK_WAVES");   // (A/B: 4 | 8 | 42 = 4 waves of two row tiles)
+    const int fw = force ? atoi(force) : 0;
+    for (int k = 0; k < 3; ++k) {
+        const int cand = (DLKA_BRICK_DEFAULT_CAND + k) % 3;   // the default first, then whatever else fits the volume
+        const int waves = cand == 1 ? 8 : 4, mt = cand == 2 ? 2 : 1;
+        if (fw && fw != (mt == 2 ? 42 : waves)) continue;
+        const char *etd = getenv("DLKA_CONV_BRICK_TD");   // (A/B: depth of the 8-wave tile)
+        const int TD = (waves == 4 && mt == 1) ? 2 : (waves == 8 ? (etd ? atoi(etd) : ((a.D & 1) ? 1 : 2)) : 1), rows = 32 * waves * mt;   // (2 x 4 x 32: a fifth less halo than 1 x 8 x 32)
+        if (TD < 1 || (TD & (TD - 1))) continue;
+        if (rows % (TD * a.W)) continue;
+        const int TH = rows / (TD * a.W);
+        if (TH < 1 || (TH & (TH - 1)) || (a.W & (a.W - 1)) || a.H % TH || a.D % TD) continue;
+        const size_t lds = (size_t)(TD + 2) * (TH + 2) * (a.W + 2) * BRICK_ROW;
+        if (lds > ((waves == 4 && mt == 1) ? 80u : 160u) * 1024) continue;
+        if (4 * (TD + 2) * (TH + 2) * (a.W + 2) > 17 * 64 * waves) continue;   // MAXI fill items per thread
+        bt.waves = waves; bt.mt = mt; bt.TD = TD; bt.TH = TH; bt.lds = lds;
+        return true;
+    }
+    return false;
 }
 
 // Planar input, channels-last output, 3^3 / stride 1 / padding 1 / dilation 1, two-term weights, epilogues 0 and 3, no tap split, volumes whose rows
@@ -138,12 +213,10 @@ bool cl_conv_brick_supported(const IgemmArgs &a)
     if (a.K != 27 || a.kd != 3 || a.kh != 3 || a.kw != 3 || a.pd != 1 || a.ph != 1 || a.pw != 1 || a.dd != 1 || a.dh != 1 || a.dw != 1) return false;
     if (a.split_bf16 != 2 || a.a_packed || (a.epi != 0 && a.epi != 3) || a.bias || a.CinP % 32 || a.NP % 32 || a.Cout != a.NP) return false;
     if (a.NP != 32 && a.NP != 64) return false;
-    if (a.W > 32 || a.W < 8 || 256 % a.W) return false;
-    const int TH = 256 / a.W;
-    if (a.H % TH) return false;
+    BrickTile bt;
+    if (!brick_tile(a, bt)) return false;
     const char *mw = getenv("DLKA_CONV_BRICK_MIN_WG");
-    if (a.B * a.D * (a.H / TH) < (mw ? atoi(mw) : 128)) return false;   // (a workgroup per CU is what the kernel is built around)
-    if ((size_t)3 * (TH + 2) * (a.W + 2) * BRICK_ROW > 160 * 1024) return false;
+    if ((long)a.M / (32 * bt.waves * bt.mt) < (mw ? atoi(mw) : 128)) return false;   // (enough workgroups to fill the chip; smaller volumes split the taps instead)
     if ((size_t)a.B * a.CinReal * a.N * 4 >= (1ull << 31) || (long)a.K * (a.CinP / 32) * 32 * a.NP * 4 >= (1l << 31)) return false;   // 32-bit buffer offsets
     return true;
 }
@@ -152,30 +225,36 @@ bool cl_conv_brick_supported(const IgemmArgs &a)
 int launch_cl_conv_brick(const IgemmArgs &a, hipStream_t st)
 {
     if (!cl_conv_brick_supported(a)) return DLKA_ERR_UNSUPPORTED;
-    const int NT = a.NP / 32, TH = 256 / a.W;
-    const int nwg = a.B * a.D * (a.H / TH);
-    const size_t lds = (size_t)3 * (TH + 2) * (a.W + 2) * BRICK_ROW;
+    BrickTile bt;
+    if (!brick_tile(a, bt)) return DLKA_ERR_UNSUPPORTED;
+    const int NT = a.NP / 32;
+    const int nwg = a.B * (a.D / bt.TD) * (a.H / bt.TH);
+    const size_t lds = bt.lds;
 #if !defined(HIPEMU)
     static std::atomic<uint64_t> attr_done{0};   // dynamic LDS above 64 KB: per function AND per device (cl_deform_bwd2.hip has the same pattern)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return DLKA_ERR_LAUNCH;
     const uint64_t bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-        const void *fns[4] = {reinterpret_cast<const void *>(cl_conv_brick_kernel<1, float>), reinterpret_cast<const void *>(cl_conv_brick_kernel<2, float>),
-                              reinterpret_cast<const void *>(cl_conv_brick_kernel<1, bf16_t>), reinterpret_cast<const void *>(cl_conv_brick_kernel<2, bf16_t>)};
-        for (int f = 0; f < 4; ++f)
+#define DLKA_BRICK_FNS(WV, MTV) reinterpret_cast<const void *>(cl_conv_brick_kernel<1, float, WV, MTV>), reinterpret_cast<const void *>(cl_conv_brick_kernel<2, float, WV, MTV>), \
+                           reinterpret_cast<const void *>(cl_conv_brick_kernel<1, bf16_t, WV, MTV>), reinterpret_cast<const void *>(cl_conv_brick_kernel<2, bf16_t, WV, MTV>)
+        const void *fns[12] = {DLKA_BRICK_FNS(4, 1), DLKA_BRICK_FNS(8, 1), DLKA_BRICK_FNS(4, 2)};
+#undef DLKA_BRICK_FNS
+        for (int f = 0; f < 12; ++f)
             if (hipFuncSetAttribute(fns[f], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DLKA_ERR_LAUNCH;
         attr_done.fetch_or(bit, std::memory_order_release);
     }
 #endif
-    dim3 grid(nwg), block(512);
-    if (a.act_bf16) {
-        if (NT == 1) { auto k = cl_conv_brick_kernel<1, bf16_t>; DLKA_LAUNCH(k, grid, block, lds, st, a, TH); }
-        else { auto k = cl_conv_brick_kernel<2, bf16_t>; DLKA_LAUNCH(k, grid, block, lds, st, a, TH); }
-    } else {
-        if (NT == 1) { auto k = cl_conv_brick_kernel<1, float>; DLKA_LAUNCH(k, grid, block, lds, st, a, TH); }
-        else { auto k = cl_conv_brick_kernel<2, float>; DLKA_LAUNCH(k, grid, block, lds, st, a, TH); }
+    dim3 grid(nwg), block(64 * bt.waves);
+#define DLKA_BRICK_GO(NTV, TT)                                                                                                   \
+    {                                                                                                                            \
+        if (bt.mt == 2) { auto k = cl_conv_brick_kernel<NTV, TT, 4, 2>; DLKA_LAUNCH(k, grid, block, lds, st, a, bt.TD, bt.TH); }      \
+        else if (bt.waves == 4) { auto k = cl_conv_brick_kernel<NTV, TT, 4>; DLKA_LAUNCH(k, grid, block, lds, st, a, bt.TD, bt.TH); } \
+        else { auto k = cl_conv_brick_kernel<NTV, TT, 8>; DLKA_LAUNCH(k, grid, block, lds, st, a, bt.TD, bt.TH); }               \
     }
+    if (a.act_bf16) { if (NT == 1) DLKA_BRICK_GO(1, bf16_t) else DLKA_BRICK_GO(2, bf16_t) }
+    else { if (NT == 1) DLKA_BRICK_GO(1, float) else DLKA_BRICK_GO(2, float) }
+#undef DLKA_BRICK_GO
     DLKA_CHECK_LAUNCH();
     g_conv_brick_launches.fetch_add(1, std::memory_order_relaxed);
     return DLKA_OK;

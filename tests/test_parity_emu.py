@@ -595,16 +595,19 @@ def test_depthwise_lds_brick_kernel(monkeypatch):
     assert lib.dlka_dwconv_lds_launch_count() == n3
 
 
-@pytest.mark.parametrize("case", [(1, 32, (2, 16, 16)), (2, 32, (3, 8, 32)), (1, 64, (2, 32, 8))])
+@pytest.mark.parametrize("case", [(1, 32, (2, 16, 16), None), (1, 32, (2, 16, 16), "8"), (2, 32, (3, 8, 32), None), (1, 64, (2, 32, 8), None), (1, 32, (4, 4, 32), "4"), (1, 32, (2, 8, 32), "42")])
 def test_conv_brick_data_gradient(case, monkeypatch):
     """cl_conv_brick_kernel (the offset-predict conv's data gradient from an LDS brick: planar grad_out staged once per 32-plane chunk, split into its bf16 terms
     while being staged, 27 taps read from LDS) against the fp64 conv — and against the kernel it replaces at the wide stage (same products, other summation order).
     DLKA_CONV_BRICK_MIN_WG=1 lets emulator-sized volumes take it (real use: >= 128 workgroups of 256 voxels); the launch counter proves which kernel ran.
-    Cases: one 16 x 16 plane per workgroup; W = 32 with 8-row tiles (the stage-0 geometry) across a batch; two output column tiles with W = 8."""
+    Cases: 4-wave workgroups on 2 x 4 x 16 tiles; the same volume on 8-wave workgroups (one 16 x 16 plane each); an odd depth (8-wave tiles of 8 rows of 32, two
+    volumes); two output column tiles with W = 8; the stage-0 tiling (4 waves, 2 x 2 x 32); 4 waves of two row tiles each (8 rows of 32)."""
     from deformablelka_amd import _lib, ops
-    B, C, dims = case
+    B, C, dims, waves = case
     lib = _lib.get_lib()
     monkeypatch.setenv("DLKA_CONV_BRICK_MIN_WG", "1")
+    if waves:
+        monkeypatch.setenv("DLKA_CONV_BRICK_WAVES", waves)
     n0 = lib.dlka_conv_brick_launch_count()
     parity.check_conv3d_cl("cpu", B, C, 81, dims, 3, 1, 1, 1, planar=True, seed=3)
     assert lib.dlka_conv_brick_launch_count() == n0 + 1

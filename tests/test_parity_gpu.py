@@ -616,3 +616,27 @@ def test_pmc_traffic_file_names_the_step_kernels():
         mine = [n for n in names if n.startswith(frag)]
         assert mine, (frag, sorted(names))
         assert all(n in have for n in mine), f"profiles/pmc_traffic_block.json is stale: {mine} not in {sorted(k for k in have if k.startswith(frag))} — re-run scripts/pmc_block.sh"
+
+
+@pytest.mark.parametrize("waves", [None, "4", "8", "42"])
+def test_conv_brick_data_gradient_stage0(waves, monkeypatch):
+    """cl_conv_brick_kernel at the shape it exists for — the offset-predict conv's data gradient at (32, 32^3), B = 2, planar grad_out — against the fp64 conv
+    (1e-3 relative) and against cl_conv_wave_kernel (same products, another summation order), for the default tile and each alternative (DLKA_CONV_BRICK_WAVES);
+    the launch counter proves which kernel produced the result."""
+    from deformablelka_amd import _lib, ops
+    lib = _lib.get_lib()
+    if waves:
+        monkeypatch.setenv("DLKA_CONV_BRICK_WAVES", waves)
+    n0 = lib.dlka_conv_brick_launch_count()
+    parity.check_conv3d_cl(DEV, 2, 32, 81, (32, 32, 32), 3, 1, 1, 1, planar=True, seed=11)
+    assert lib.dlka_conv_brick_launch_count() == n0 + 1
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 32, 32, 32, generator=gen).to(DEV)
+    w = (torch.randn(81, 32, 3, 3, 3, generator=gen) * 0.05).to(DEV)
+    go = torch.randn(2, 81, 32, 32, 32, generator=gen).to(DEV)
+    g_brick = ops.conv3d_backward_cl(x, w, go, 1, 1, 1, grad_out_planar=True)[0]
+    monkeypatch.setenv("DLKA_CONV_BRICK", "0")
+    n1 = lib.dlka_conv_brick_launch_count()
+    g_wave = ops.conv3d_backward_cl(x, w, go, 1, 1, 1, grad_out_planar=True)[0]
+    assert lib.dlka_conv_brick_launch_count() == n1
+    assert (g_brick - g_wave).abs().max().item() <= 2e-5 * g_wave.abs().max().item()
