@@ -84,6 +84,7 @@ struct WgradArgs {
     int act_bf16;        // 1: `in` (and a channels-last `g`) are bf16 storage; a planar `g` (grad_offset) stays fp32
     int CT;              // Cin / 32
     int w16;             // set by the launcher: W % 16 == 0 (fast row addressing in cl_wgrad_dense_kernel)
+    int no_win3;         // set by the launcher: DLKA_WGRAD_WIN3=0 (A/B switch: the three w-taps of a wave load their rows separately, as before round 4)
     int xcd_ny, xcd_nz, xcd_total;   // set by the launcher: > 0 = 1-D XCD-swizzled grid over (chunk, y, z) work items, see xcd_item()
     int g_cpad;          // GMODE 1 only, > 0: g holds pack_split2() words with g_cpad channel planes per batch (see DeformBwdArgs::goff_cpad)
 };

@@ -292,6 +292,12 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
     const int m_hi = min(p.M, m_lo + p.rows_per_chunk);
 
     float ga_n[COT][16], bv_n[TPW][16];
+    // TPW == kw == 3 with the fast row addressing below: the wave's three taps are the three w-neighbours of one (kd, kh), so their 3 x 16 rows are 18 DISTINCT
+    // rows (w_ - 1 .. w_ + 16) — loaded once into xr_n, tap t's operand row s is xr[s + t].  (Ablation, profiles/r06_notes.md: 43 of this kernel's 79 us at
+    // 32^3 were its operand fetch, 48 of the 60 loads per step these rows.)
+    constexpr bool WIN3 = TPW == 3 && N16;
+    float xr_n[WIN3 ? 18 : 1];
+    const bool win3 = WIN3 && p.K > 1 && p.w16 && p.kw == 3 && p.dw == 1 && p.pw == 1 && p.no_win3 == 0;
     const int gcp = (GMODE == 1 && p.g_cpad) ? p.g_cpad : p.Cout;   // channel planes per batch of a planar g
     const BufRsrc rg = make_rsrc(p.g, (size_t)p.B * p.N * gcp * GB), rx = make_rsrc(p.in, (size_t)p.M * p.Cin * XB);
     // operands of the 32-row step starting at mbase: rows m = mbase + 16h + s.  Every load is an unconditional buffer
@@ -339,6 +345,16 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
             const int w_ = v0 % p.W, hh = (v0 / p.W) % p.H, d_ = v0 / (p.W * p.H);
             const unsigned base = (mrow0 < m_hi) ? (unsigned)((b0 * p.N + v0) * p.Cin + ci) * XB : DLKA_OOB;
             const unsigned rs = (unsigned)p.Cin * XB;
+            if (WIN3 && win3) {   // uniform
+                const int zd = d_ + od[1], zh = hh + oh[1];   // (the three taps share kd, kh; tap 1 is the centre column)
+                const bool ok = (tap0 + 2 < p.K) & (base != DLKA_OOB) & ((unsigned)zd < (unsigned)p.D) & ((unsigned)zh < (unsigned)p.H);
+                const int doff = ((od[1] * p.H + oh[1]) * p.W) * p.Cin * (int)XB;
+                const unsigned tc = ok ? base + (unsigned)doff : DLKA_OOB;
+                xr_n[0] = act_buf_load1<T>(rx, (tc != DLKA_OOB && w_ >= 1) ? tc - rs : DLKA_OOB);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) xr_n[1 + s] = act_buf_load1<T>(rx, tc == DLKA_OOB ? DLKA_OOB : tc + (unsigned)s * rs);
+                xr_n[WIN3 ? 17 : 0] = act_buf_load1<T>(rx, (tc != DLKA_OOB && w_ + 16 < p.W) ? tc + 16u * rs : DLKA_OOB);
+            } else
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const int zd = d_ + od[t], zh = hh + oh[t];
@@ -395,6 +411,10 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
         }
     };
 
+#ifndef DLKA_ABLG   // -DDLKA_ABLG=bits: TIMING-ONLY ablations of the split dense weight gradient (wrong results): 1 no split arithmetic, 2 one MFMA per
+#define DLKA_ABLG 0  // (co-tile, tap) and k-half instead of three, 4 no operand fetch in the loop
+#endif
+    constexpr int ABLG = (SPLIT && GMODE == 1 && COT == 3 && TPW == 3) ? DLKA_ABLG : 0;
     if (m_lo < m_hi) load_step(m_lo);
     for (int mbase = m_lo; mbase < m_hi; mbase += 32) {
         float ga[COT][16], bv[TPW][16];
@@ -402,11 +422,18 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
         for (int c = 0; c < COT; ++c)
 #pragma unroll
             for (int s = 0; s < 16; ++s) ga[c][s] = ga_n[c][s];
+        if (WIN3 && win3) {   // uniform
 #pragma unroll
-        for (int t = 0; t < TPW; ++t)
+            for (int t = 0; t < TPW; ++t)
 #pragma unroll
-            for (int s = 0; s < 16; ++s) bv[t][s] = bv_n[t][s];
-        if (mbase + 32 < m_hi) load_step(mbase + 32);   // in flight under the MFMAs below
+                for (int s = 0; s < 16; ++s) bv[t][s] = xr_n[WIN3 ? s + t : 0];
+        } else {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) bv[t][s] = bv_n[t][s];
+        }
+        if (mbase + 32 < m_hi && !(ABLG & 4)) load_step(mbase + 32);   // in flight under the MFMAs below
         const bool gpk = GMODE == 1 && SPLIT && p.g_cpad;   // uniform: g arrives as pack_split2() words
         if (want_bias) {
 #pragma unroll
@@ -426,15 +453,20 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
 #pragma unroll
                 for (int c = 0; c < COT; ++c) {
                     if (gpk) unpack_split2x8(ga[c] + 8 * mf, ahi[c], alo[c]);
+                    else if (ABLG & 1) { ahi[c] = bf16x8_from_words(ga[c] + 8 * mf); alo[c] = bf16x8_from_words(ga[c] + 8 * mf + 4); }
                     else split_bf16x8(ga[c] + 8 * mf, ahi[c], alo[c]);
                 }
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) split_bf16x8(bv[t] + 8 * mf, bhi[t], blo[t]);
+                for (int t = 0; t < TPW; ++t) {
+                    if (ABLG & 1) { bhi[t] = bf16x8_from_words(bv[t] + 8 * mf); blo[t] = bf16x8_from_words(bv[t] + 8 * mf + 4); }
+                    else split_bf16x8(bv[t] + 8 * mf, bhi[t], blo[t]);
+                }
 #pragma unroll
                 for (int c = 0; c < COT; ++c)
 #pragma unroll
                     for (int t = 0; t < TPW; ++t) {
                         acc[c][t] = mfma_32x32x16_bf16(alo[c], bhi[t], acc[c][t]);
+                        if (ABLG & 2) continue;
                         if (!B16) acc[c][t] = mfma_32x32x16_bf16(ahi[c], blo[t], acc[c][t]);   // a bf16 `in` has no low term
                         acc[c][t] = mfma_32x32x16_bf16(ahi[c], bhi[t], acc[c][t]);
                     }
@@ -581,6 +613,7 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
     a.CT = a.Cin / 32;
     constexpr bool slow_addr = false;
     a.w16 = (!slow_addr && (a.W & 15) == 0) ? 1 : 0;
+    { const char *e = getenv("DLKA_WGRAD_WIN3"); a.no_win3 = (e && e[0] == '0') ? 1 : 0; }   // (read per launch: a parity test toggles it)
     const int OT = a.CoutP / 32;
     if ((long)a.M * a.Cin * 4 >= (1l << 31) || (long)a.M * a.Cout * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     a.bpart = gb ? a.part + (size_t)nchunks * a.K * a.CoutP * a.Cin : nullptr;

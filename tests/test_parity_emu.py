@@ -621,3 +621,21 @@ def test_conv_brick_data_gradient(case, monkeypatch):
     g_wave = ops.conv3d_backward_cl(x, w, go, 1, 1, 1, grad_out_planar=True)[0]
     assert lib.dlka_conv_brick_launch_count() == n1
     assert (g_brick - g_wave).abs().max().item() <= 2e-5 * g_wave.abs().max().item()
+
+
+@pytest.mark.parametrize("case", [(1, 32, 32, (2, 3, 16), False), (2, 32, 81, (2, 2, 16), True), (1, 64, 81, (3, 2, 32), True)])
+def test_wgrad_dense_shared_row_window(case, monkeypatch):
+    """Dense 3^3 weight gradient, fast row addressing (W % 16 == 0): the three w-taps of a wave take their 3 x 16 operand rows from ONE 18-row window (default) —
+    against the fp64 conv, and bit for bit against the per-tap loads it replaces (DLKA_WGRAD_WIN3=0: same values into the same MFMAs).  Cases: W = 16 (both edge rows of
+    every run are padding or the neighbouring run), a planar grad_out across a batch, W = 32 with two input chunks."""
+    from deformablelka_amd import ops
+    B, C, Cout, dims, planar = case
+    parity.check_conv3d_cl("cpu", B, C, Cout, dims, 3, 1, 1, 1, planar=planar, seed=7)
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(B, *dims, C, generator=gen)
+    w = torch.randn(Cout, C, 3, 3, 3, generator=gen) * 0.05
+    go = torch.randn(B, Cout, *dims, generator=gen) if planar else torch.randn(B, *dims, Cout, generator=gen)
+    gw_win = ops.conv3d_backward_cl(x, w, go, 1, 1, 1, grad_out_planar=planar)[1]
+    monkeypatch.setenv("DLKA_WGRAD_WIN3", "0")
+    gw_tap = ops.conv3d_backward_cl(x, w, go, 1, 1, 1, grad_out_planar=planar)[1]
+    assert torch.equal(gw_win, gw_tap)
