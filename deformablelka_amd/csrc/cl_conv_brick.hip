@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64 * WAVES) void cl_conv_brick_kernel(IgemmArgs p, 
             for (int q = 0; q < 16; ++q) acc[u][t][q] = 0.f;
 
 #ifndef DLKA_BRICK_DEPTH
-#define DLKA_BRICK_DEPTH 4
+#define DLKA_BRICK_DEPTH 3
 #endif
     constexpr int DEPTH = DLKA_BRICK_DEPTH;   // register ring of weight records: while tap t computes, taps t+1 .. t+DEPTH-1 are in flight (a tap is only
     f32x4 bring[DEPTH][4 * NT];               // 6 NT MFMAs = 192 NT cycles against an L2 round trip of several hundred)   [(part * 2 + mf) * NT + t]
@@ -120,8 +120,7 @@ __global__ __launch_bounds__(64 * WAVES) void cl_conv_brick_kernel(IgemmArgs p, 
 #endif
     for (int ck = 0; ck < nchunk; ++ck) {
 #pragma unroll
-        for (int s = 0; s < DEPTH - 1; ++s)
-            if (s < p.K) load_b(s, ck, bring[s]);
+        for (int s = 0; s < DEPTH - 1; ++s) load_b(s, ck, bring[s]);
         // ---- fill (split into the two bf16 terms on the way) ----
 #pragma unroll
         for (int j = 0; j < ((DLKA_BRICK_ABL & 1) ? 0 : MAXI); ++j) {
@@ -138,14 +137,13 @@ __global__ __launch_bounds__(64 * WAVES) void cl_conv_brick_kernel(IgemmArgs p, 
         }
         __syncthreads();
         // ---- 27 taps from the brick ----
+        // (K = 27 is a multiple of DEPTH; unconditional ring loads — see cl_conv_brick3_kernel)
 #pragma unroll 1
         for (int tap = 0; tap < ((DLKA_BRICK_ABL & 2) ? 0 : p.K); tap += DEPTH) {
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s) {
-                if (tap + s < p.K) {   // uniform
-                    if (tap + s + DEPTH - 1 < p.K) load_b(tap + s + DEPTH - 1, ck, bring[(s + DEPTH - 1) % DEPTH]);
-                    compute(tap + s, bring[s]);
-                }
+                load_b(min(tap + s + DEPTH - 1, p.K - 1), ck, bring[(s + DEPTH - 1) % DEPTH]);
+                compute(tap + s, bring[s]);
             }
         }
         __syncthreads();   // every wave is done with this chunk's brick
@@ -219,6 +217,205 @@ bool cl_conv_brick_supported(const IgemmArgs &a)
     if ((long)a.M / (32 * bt.waves * bt.mt) < (mw ? atoi(mw) : 128)) return false;   // (enough workgroups to fill the chip; smaller volumes split the taps instead)
     if ((size_t)a.B * a.CinReal * a.N * 4 >= (1ull << 31) || (long)a.K * (a.CinP / 32) * 32 * a.NP * 4 >= (1l << 31)) return false;   // 32-bit buffer offsets
     return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The FORWARD offset-predict conv (C -> 81, channels-last fp32 in, planar out + bias, THREE-term split: its output decides floor() of the sampling
+// positions) from the same kind of brick.  cl_igemm_kernel<0, 1, 3, 3> stages the weights of every (tap, chunk) unit through LDS behind a workgroup
+// barrier and re-splits its A rows for every tap; its ablations (profiles/r06_notes.md) show the parts of a unit ADDING UP at two waves per SIMD: 26 us
+// of MFMA + 13 A fetch + 9 weight fetch + 7 split arithmetic + a 26 us skeleton of staging, barriers and the transposing epilogue.  Here the three
+// bf16 terms of the tile's halo are formed ONCE per element and live in LDS — a pass covers the 16 channels one MFMA k-step contracts (channels
+// 8 mf .. 8 mf + 7 and 16 + 8 mf .. 16 + 8 mf + 7 of a 32-channel chunk, the k order of the prepared records):
+//     brick[voxel][ hi: 16 x bf16 | mid | lo | 16 bytes of padding ]          112 bytes per voxel
+// — and the tap loop is three 16-byte LDS reads, 3 NT record loads (register ring, two taps ahead) and 6 NT MFMAs, with no barrier inside a pass.
+// Same six products per (term pair) and the same fp32 accumulation as the kernel it replaces; summation order: (chunk, k-half) outer, taps inner.
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+constexpr int BRICK3_ROW = 112;
+
+// Work split inside a workgroup (256 rows x NT column tiles): a wave owns ONE column tile and MT row tiles — wave = (row group, column tile) — so that a
+// tap's weight records are fetched once per 32 MT rows: with every wave on all NT tiles the eight waves pulled 72 KB of records per tap round through the L1
+// (1152 clocks at 64 B / clk against 1152 of MFMA: 70 us, profiles/r06_notes.md); here 8 / MT x NT waves pull 3 KB each.
+template <int NT, int MT>
+__global__ __launch_bounds__(64 * (8 / MT) * NT) void cl_conv_brick3_kernel(IgemmArgs p, int TD, int TH)
+{
+    DLKA_DYN_SMEM(unsigned char, brick);
+    constexpr int WAVES = (8 / MT) * NT, NTHR = 64 * WAVES, MAXI = 5;   // fill items (brick voxel, 8-channel half) per thread: 2 * brick voxels <= MAXI * NTHR (launcher)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tcol = wave % NT, rg = wave / NT;   // this wave's column tile and row group
+    const int i = lane & 31, h = lane >> 5;
+    const int W = p.W, BW = W + 2, BH = TH + 2, BD = TD + 2, nvox = BD * BH * BW;
+    const int hblocks = p.H / TH, dblocks = p.D / TD;
+    const int lgW = __builtin_ctz((unsigned)W), lgTH = __builtin_ctz((unsigned)TH);
+    int bi = blockIdx.x;
+    const int hb = bi % hblocks; bi /= hblocks;
+    const int db = bi % dblocks;
+    const int b = bi / dblocks;
+    const int d0 = db * TD, h0 = hb * TH;
+    const int nchunk = p.CinP / 32;
+    const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.Cin * 4);
+    const BufRsrc rw = make_rsrc(p.wp, (size_t)p.K * nchunk * 48 * p.NP * 4);
+    const unsigned unit_bytes = (unsigned)(48 * p.NP) * 4u, seg_bytes = (unsigned)p.NP * 16u;
+    const unsigned blane = (unsigned)(h * p.NP + tcol * 32 + i) * 16u;
+    unsigned abase[MT];   // + tap offset + 32 * term
+    long vox[MT];         // the row as a voxel of volume b (epilogue)
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+        const int r = 32 * (MT * rg + u) + i, dl = r >> (lgW + lgTH), hl = (r >> lgW) & (TH - 1), wl = r & (W - 1);
+        abase[u] = (unsigned)(((dl * BH + hl) * BW + wl) * BRICK3_ROW + 16 * h);
+        vox[u] = ((long)(d0 + dl) * p.H + h0 + hl) * W + wl;
+    }
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int u = 0; u < MT; ++u)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[u][q] = 0.f;
+
+    constexpr int DEPTH = 3;
+    f32x4 bring[DEPTH][3];   // [part]: the pass's k-half, this wave's column tile
+    auto load_b = [&](int tap, int ck, int mf, f32x4 *bd) {
+        const unsigned ub = (unsigned)(tap * nchunk + ck) * unit_bytes + blane;
+#pragma unroll
+        for (int part = 0; part < 3; ++part) bd[part] = buf_load_f32x4(rw, ub + (unsigned)((part * 2 + mf) * 2) * seg_bytes);
+    };
+    auto compute = [&](int tap, const f32x4 *bcur) {
+        const int ti = tap / 9, tj = (tap - ti * 9) / 3, tk = tap - ti * 9 - tj * 3;
+        const unsigned toff = (unsigned)(((ti * BH + tj) * BW + tk) * BRICK3_ROW);
+        const bf16x8 bhi = __builtin_bit_cast(bf16x8, bcur[0]), bmid = __builtin_bit_cast(bf16x8, bcur[1]), blo = __builtin_bit_cast(bf16x8, bcur[2]);
+        bf16x8 ahi[MT], amid[MT], alo[MT];
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+            const unsigned char *ap = brick + abase[u] + toff;
+            ahi[u] = *reinterpret_cast<const bf16x8 *>(ap); amid[u] = *reinterpret_cast<const bf16x8 *>(ap + 32); alo[u] = *reinterpret_cast<const bf16x8 *>(ap + 64);
+        }
+        // product-major, row-tile-minor: consecutive MFMAs go to different accumulators; per accumulator the order is cl_igemm_kernel's (small terms first)
+#pragma unroll
+        for (int u = 0; u < MT; ++u) acc[u] = mfma_32x32x16_bf16(alo[u], bhi, acc[u]);
+#pragma unroll
+        for (int u = 0; u < MT; ++u) acc[u] = mfma_32x32x16_bf16(ahi[u], blo, acc[u]);
+#pragma unroll
+        for (int u = 0; u < MT; ++u) acc[u] = mfma_32x32x16_bf16(amid[u], bmid, acc[u]);
+#pragma unroll
+        for (int u = 0; u < MT; ++u) acc[u] = mfma_32x32x16_bf16(amid[u], bhi, acc[u]);
+#pragma unroll
+        for (int u = 0; u < MT; ++u) acc[u] = mfma_32x32x16_bf16(ahi[u], bmid, acc[u]);
+#pragma unroll
+        for (int u = 0; u < MT; ++u) acc[u] = mfma_32x32x16_bf16(ahi[u], bhi, acc[u]);
+    };
+
+    // fill items, described once: (brick voxel, half hh): 8 channels 16 hh + 8 mf .. of the voxel's row -> the voxel's three terms at k positions 8 hh ..
+    const float r_nvox = 1.0f / (float)nvox, r_plane = 1.0f / (float)(BH * BW), r_bw = 1.0f / (float)BW;
+    unsigned fsrc[MAXI], fdst[MAXI];
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) {
+        const int it = tid + j * NTHR;
+        const int hh = (int)(((float)it + 0.5f) * r_nvox), vx = it - hh * nvox;
+        const int dz = (int)(((float)vx + 0.5f) * r_plane), rem = vx - dz * (BH * BW);
+        const int hy = (int)(((float)rem + 0.5f) * r_bw), wx = rem - hy * BW;
+        const int zd = d0 + dz - 1, zh = h0 + hy - 1, zw = wx - 1;
+        const bool ok = (hh < 2) & ((unsigned)zd < (unsigned)p.D) & ((unsigned)zh < (unsigned)p.H) & ((unsigned)zw < (unsigned)W);
+        fsrc[j] = ok ? (unsigned)((((long)b * p.N + ((long)zd * p.H + zh) * W + zw) * p.Cin + 16 * hh) * 4) : DLKA_OOB;
+        fdst[j] = hh < 2 ? (unsigned)(vx * BRICK3_ROW + hh * 16) : DLKA_OOB;
+    }
+
+    for (int ck = 0; ck < nchunk; ++ck)
+        for (int mf = 0; mf < 2; ++mf) {
+#pragma unroll
+            for (int s = 0; s < DEPTH - 1; ++s) load_b(s, ck, mf, bring[s]);
+#ifndef DLKA_BRICK3_ABL   // TIMING-ONLY ablations (wrong results): 1 no fill, 2 no tap loop, 4 no output stores
+#define DLKA_BRICK3_ABL 0
+#endif
+#pragma unroll
+            for (int j = 0; j < ((DLKA_BRICK3_ABL & 1) ? 0 : MAXI); ++j) {
+                if (fdst[j] == DLKA_OOB) continue;
+                const unsigned s0 = fsrc[j] == DLKA_OOB ? DLKA_OOB : fsrc[j] + (unsigned)(ck * 32 + 8 * mf) * 4u;
+                const f32x4 v0 = buf_load_f32x4(rin, s0), v1 = buf_load_f32x4(rin, s0 == DLKA_OOB ? DLKA_OOB : s0 + 16u);
+                const float a[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                bf16x8 hi, mid, lo;
+                split3_bf16x8(a, hi, mid, lo);
+                *reinterpret_cast<bf16x8 *>(brick + fdst[j]) = hi;
+                *reinterpret_cast<bf16x8 *>(brick + fdst[j] + 32) = mid;
+                *reinterpret_cast<bf16x8 *>(brick + fdst[j] + 64) = lo;
+            }
+            __syncthreads();
+            // (K = 27 is a multiple of DEPTH and the ring's loads are UNCONDITIONAL — behind the last tap they re-read it: a conditional load into the ring
+            //  made the compiler merge the two paths with register copies behind s_waitcnt vmcnt(0), i.e. wait for the records it had just requested)
+#pragma unroll 1
+            for (int tap = 0; tap < ((DLKA_BRICK3_ABL & 2) ? 0 : p.K); tap += DEPTH) {
+#pragma unroll
+                for (int s = 0; s < DEPTH; ++s) {
+                    load_b(min(tap + s + DEPTH - 1, p.K - 1), ck, mf, bring[(s + DEPTH - 1) % DEPTH]);
+                    compute(tap + s, bring[s]);
+                }
+            }
+            __syncthreads();   // every wave is done with this pass's brick
+        }
+
+    // ---- epilogue: planar output [B][Cout][N] (+ bias).  Each 32 x 32 tile goes through a wave-private LDS tile (the brick is free now) so that lanes run
+    // over the tile's 32 rows — one W-run of voxels or several: 128 contiguous bytes of one plane per store at W = 32 ----
+    float *Tt = reinterpret_cast<float *>(brick) + wave * (32 * 33);
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Tt[((q & 3) + 8 * (q >> 2) + 4 * h) * 33 + i] = acc[u][q];
+        wave_sync();
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            const int col = 2 * cc + h, n = tcol * 32 + col;
+            if (n >= p.Cout) continue;   // uniform per half-wave
+            float val = Tt[i * 33 + col];
+            if (p.bias) val += p.bias[n];
+            if (!(DLKA_BRICK3_ABL & 4) || val == 123.456f) p.out[((long)b * p.Cout + n) * p.N + vox[u]] = val;
+        }
+    }
+}
+
+bool cl_conv_brick3_supported(const IgemmArgs &a)
+{
+    const char *e = getenv("DLKA_CONV_BRICK");
+    if (e && (e[0] == '0' || e[0] == '2')) return false;   // 0: both brick kernels off, 2: the data gradient's only
+    if (a.K != 27 || a.kd != 3 || a.kh != 3 || a.kw != 3 || a.pd != 1 || a.ph != 1 || a.pw != 1 || a.dd != 1 || a.dh != 1 || a.dw != 1) return false;
+    if (a.split_bf16 != 3 || a.act_bf16 || a.epi != 0 || a.Cin % 32 || a.CinP != a.Cin || a.NP % 32 || a.NP > 96) return false;
+    if (a.W > 32 || a.W < 8 || (a.W & (a.W - 1))) return false;
+    const int TD = (a.D & 1) ? 1 : 2;
+    if (256 % (TD * a.W)) return false;
+    const int TH = 256 / (TD * a.W);
+    if (TH < 1 || (TH & (TH - 1)) || a.H % TH) return false;
+    const size_t nvox = (size_t)(TD + 2) * (TH + 2) * (a.W + 2);
+    const int nt = a.NP / 32, mt = nt == 1 ? 1 : 2, waves = (8 / mt) * nt;
+    if (nvox * BRICK3_ROW > 160 * 1024 || nvox * BRICK3_ROW < (size_t)waves * 32 * 33 * 4 || 2 * nvox > (size_t)5 * 64 * waves) return false;
+    const char *mw = getenv("DLKA_CONV_BRICK_MIN_WG");
+    if ((long)a.M / 256 < (mw ? atoi(mw) : 128)) return false;
+    if ((size_t)a.M * a.Cin * 4 >= (1ull << 31) || (long)a.K * (a.CinP / 32) * 48 * a.NP * 4 >= (1l << 31)) return false;   // 32-bit buffer offsets
+    return true;
+}
+
+int launch_cl_conv_brick3(const IgemmArgs &a, hipStream_t st)
+{
+    if (!cl_conv_brick3_supported(a)) return DLKA_ERR_UNSUPPORTED;
+    const int TD = (a.D & 1) ? 1 : 2, TH = 256 / (TD * a.W), NT = a.NP / 32;
+    const size_t lds = (size_t)(TD + 2) * (TH + 2) * (a.W + 2) * BRICK3_ROW;
+#if !defined(HIPEMU)
+    static std::atomic<uint64_t> attr_done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return DLKA_ERR_LAUNCH;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+        const void *fns[3] = {reinterpret_cast<const void *>(cl_conv_brick3_kernel<1, 1>), reinterpret_cast<const void *>(cl_conv_brick3_kernel<2, 2>),
+                              reinterpret_cast<const void *>(cl_conv_brick3_kernel<3, 2>)};
+        for (int f = 0; f < 3; ++f)
+            if (hipFuncSetAttribute(fns[f], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DLKA_ERR_LAUNCH;
+        attr_done.fetch_or(bit, std::memory_order_release);
+    }
+#endif
+    dim3 grid(a.B * (a.D / TD) * (a.H / TH));
+    if (NT == 1) { auto k = cl_conv_brick3_kernel<1, 1>; DLKA_LAUNCH(k, grid, dim3(512), lds, st, a, TD, TH); }
+    else if (NT == 2) { auto k = cl_conv_brick3_kernel<2, 2>; DLKA_LAUNCH(k, grid, dim3(512), lds, st, a, TD, TH); }
+    else { auto k = cl_conv_brick3_kernel<3, 2>; DLKA_LAUNCH(k, grid, dim3(768), lds, st, a, TD, TH); }
+    DLKA_CHECK_LAUNCH();
+    g_conv_brick_launches.fetch_add(1, std::memory_order_relaxed);
+    return DLKA_OK;
 }
 
 // DLKA_ERR_UNSUPPORTED: the caller takes cl_conv_wave_kernel / cl_igemm_kernel.

@@ -127,7 +127,11 @@ __global__ __launch_bounds__(256) void cl_conv_wave_kernel(IgemmArgs p)
 #pragma unroll
         for (int s = 0; s < DEPTH; ++s) {
             if (unit + s < unit_hi) {   // uniform
+#ifdef DLKA_CW_UNCOND   // (experiment: unconditional ring loads — behind the last unit they re-read it — instead of a conditional load merged by register copies)
+                issue(min(unit + s + DEPTH - 1, unit_hi - 1), abuf[(s + DEPTH - 1) % DEPTH], bbuf[(s + DEPTH - 1) % DEPTH]);
+#else
                 if (unit + s + DEPTH - 1 < unit_hi) issue(unit + s + DEPTH - 1, abuf[(s + DEPTH - 1) % DEPTH], bbuf[(s + DEPTH - 1) % DEPTH]);
+#endif
                 compute(abuf[s], bbuf[s]);
             }
         }

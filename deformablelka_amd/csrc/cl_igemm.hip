@@ -440,6 +440,10 @@ int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t s
         if (launch_zero_batch(a.zero, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         a.zero.n = 0;
     }
+    if (amode == 0 && omode == 1 && splits == 1 && a.split_bf16 == 3) {   // the offset conv's forward at the wide stage: LDS-brick kernel
+        const int rc = launch_cl_conv_brick3(a, st);
+        if (rc != DLKA_ERR_UNSUPPORTED) return rc;
+    }
     if (amode == 2 && omode == 0 && splits == 1 && a.split_bf16 == 2) {   // the offset conv's data gradient at the wide stage: LDS-brick kernel
         const int rc = launch_cl_conv_brick(a, st);
         if (rc != DLKA_ERR_UNSUPPORTED) return rc;

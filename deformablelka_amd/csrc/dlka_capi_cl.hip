@@ -119,7 +119,8 @@ int dense_forward(const SameConv &s, const float *x, const float *w, const float
     a.in = x; a.wp = wp; a.bias = bias; a.out = out; a.out2 = out2; a.aux = aux; a.epi = epi; a.out_zeroed = zeroed ? 1 : 0;
     a.Cin = s.Cin; a.CinReal = s.Cin; a.CinP = s.Cin; a.Cout = s.Cout; a.NP = NP;
     if (ride) a.zero = *ride;
-    const int splits = dense_forward_splits(s, epi);
+    int splits = dense_forward_splits(s, epi);
+    if (out_planar && cl_conv_brick3_supported(a)) splits = 1;   // (cl_conv_brick.hip writes every output itself)
     if (out2_f32) {   // only the pointwise kernel's bf16 GELU epilogue carries the fp32 side output
         if (!(s.act_bf16 && epi == 1 && s.K == 1 && splits == 1 && !split && !out_planar)) return DLKA_ERR_UNSUPPORTED;
         a.out2_f32 = out2_f32;

@@ -606,6 +606,7 @@ def test_conv_brick_data_gradient(case, monkeypatch):
     B, C, dims, waves = case
     lib = _lib.get_lib()
     monkeypatch.setenv("DLKA_CONV_BRICK_MIN_WG", "1")
+    monkeypatch.setenv("DLKA_CONV_BRICK", "2")   # the data gradient's brick kernel only (the forward's has its own test below)
     if waves:
         monkeypatch.setenv("DLKA_CONV_BRICK_WAVES", waves)
     n0 = lib.dlka_conv_brick_launch_count()
@@ -639,3 +640,28 @@ def test_wgrad_dense_shared_row_window(case, monkeypatch):
     monkeypatch.setenv("DLKA_WGRAD_WIN3", "0")
     gw_tap = ops.conv3d_backward_cl(x, w, go, 1, 1, 1, grad_out_planar=planar)[1]
     assert torch.equal(gw_win, gw_tap)
+
+
+@pytest.mark.parametrize("case", [(1, 32, 81, (2, 8, 16)), (2, 32, 81, (3, 8, 32)), (1, 64, 50, (2, 16, 8))])
+def test_conv_brick_forward_three_term(case, monkeypatch):
+    """cl_conv_brick3_kernel (the offset-predict conv's FORWARD from an LDS brick: the three bf16 terms of the tile's halo formed once per element, a pass per MFMA k-step of 16
+    channels, planar output + bias through the transposing epilogue) against the fp64 conv at the forward contract (1e-4) — and against cl_igemm_kernel<0,1,3,3>, whose six
+    products per term pair it repeats in another summation order.  Cases: 2 x 8 x 16 tiles; odd depth (1 x 8 x 32 tiles) over two volumes; two input chunks, two column tiles
+    (50 output channels: a partial tile) with W = 8."""
+    from deformablelka_amd import _lib, ops
+    B, C, Cout, dims = case
+    lib = _lib.get_lib()
+    monkeypatch.setenv("DLKA_CONV_BRICK_MIN_WG", "1")
+    n0 = lib.dlka_conv_brick_launch_count()
+    parity.check_conv3d_cl("cpu", B, C, Cout, dims, 3, 1, 1, 1, planar=True, seed=4)
+    assert lib.dlka_conv_brick_launch_count() == n0 + 2   # forward and data gradient
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(B, *dims, C, generator=gen)
+    w = torch.randn(Cout, C, 3, 3, 3, generator=gen) * 0.05
+    bias = torch.randn(Cout, generator=gen)
+    y_brick = ops.conv3d_forward_cl(x, w, bias, 1, 1, 1, out_planar=True)
+    monkeypatch.setenv("DLKA_CONV_BRICK", "0")
+    n1 = lib.dlka_conv_brick_launch_count()
+    y_igemm = ops.conv3d_forward_cl(x, w, bias, 1, 1, 1, out_planar=True)
+    assert lib.dlka_conv_brick_launch_count() == n1
+    assert (y_brick - y_igemm).abs().max().item() <= 2e-6 * y_igemm.abs().max().item()

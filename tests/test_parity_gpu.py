@@ -627,6 +627,7 @@ def test_conv_brick_data_gradient_stage0(waves, monkeypatch):
     lib = _lib.get_lib()
     if waves:
         monkeypatch.setenv("DLKA_CONV_BRICK_WAVES", waves)
+    monkeypatch.setenv("DLKA_CONV_BRICK", "2")   # the data gradient's brick kernel only
     n0 = lib.dlka_conv_brick_launch_count()
     parity.check_conv3d_cl(DEV, 2, 32, 81, (32, 32, 32), 3, 1, 1, 1, planar=True, seed=11)
     assert lib.dlka_conv_brick_launch_count() == n0 + 1
@@ -640,3 +641,24 @@ def test_conv_brick_data_gradient_stage0(waves, monkeypatch):
     g_wave = ops.conv3d_backward_cl(x, w, go, 1, 1, 1, grad_out_planar=True)[0]
     assert lib.dlka_conv_brick_launch_count() == n1
     assert (g_brick - g_wave).abs().max().item() <= 2e-5 * g_wave.abs().max().item()
+
+
+def test_conv_brick_forward_stage0(monkeypatch):
+    """cl_conv_brick3_kernel at the shape it exists for — the offset-predict conv's FORWARD at (32, 32^3), B = 2, planar output — against the fp64 conv at the forward
+    contract (1e-4; check_conv3d_cl also holds the data / weight gradients, so the data gradient's brick kernel runs in the same call) and against
+    cl_igemm_kernel<0,1,3,3> (same six products per term pair, another summation order); the launch counter proves which kernels ran."""
+    from deformablelka_amd import _lib, ops
+    lib = _lib.get_lib()
+    n0 = lib.dlka_conv_brick_launch_count()
+    parity.check_conv3d_cl(DEV, 2, 32, 81, (32, 32, 32), 3, 1, 1, 1, planar=True, seed=12)
+    assert lib.dlka_conv_brick_launch_count() == n0 + 2
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 32, 32, 32, 32, generator=gen).to(DEV)
+    w = (torch.randn(81, 32, 3, 3, 3, generator=gen) * 0.05).to(DEV)
+    bias = torch.randn(81, generator=gen).to(DEV)
+    y_brick = ops.conv3d_forward_cl(x, w, bias, 1, 1, 1, out_planar=True)
+    monkeypatch.setenv("DLKA_CONV_BRICK", "0")
+    n1 = lib.dlka_conv_brick_launch_count()
+    y_igemm = ops.conv3d_forward_cl(x, w, bias, 1, 1, 1, out_planar=True)
+    assert lib.dlka_conv_brick_launch_count() == n1
+    assert (y_brick - y_igemm).abs().max().item() <= 2e-6 * y_igemm.abs().max().item()
