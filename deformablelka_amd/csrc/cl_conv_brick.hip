@@ -278,16 +278,24 @@ __global__ __launch_bounds__(64 * (8 / MT) * NT) void cl_conv_brick3_kernel(Igem
 #pragma unroll
         for (int part = 0; part < 3; ++part) bd[part] = buf_load_f32x4(rw, ub + (unsigned)((part * 2 + mf) * 2) * seg_bytes);
     };
-    auto compute = [&](int tap, const f32x4 *bcur) {
+    // A operands (three terms per row tile) are read from the brick ONE TAP AHEAD, behind the current tap's MFMAs in program order, so that the LDS latency is
+    // covered by them instead of opening every tap (the compiler does not move LDS reads across the loop's back edge)
+    bf16x8 a_nxt[MT][3];
+    auto read_a = [&](int tap) {
         const int ti = tap / 9, tj = (tap - ti * 9) / 3, tk = tap - ti * 9 - tj * 3;
         const unsigned toff = (unsigned)(((ti * BH + tj) * BW + tk) * BRICK3_ROW);
-        const bf16x8 bhi = __builtin_bit_cast(bf16x8, bcur[0]), bmid = __builtin_bit_cast(bf16x8, bcur[1]), blo = __builtin_bit_cast(bf16x8, bcur[2]);
-        bf16x8 ahi[MT], amid[MT], alo[MT];
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
             const unsigned char *ap = brick + abase[u] + toff;
-            ahi[u] = *reinterpret_cast<const bf16x8 *>(ap); amid[u] = *reinterpret_cast<const bf16x8 *>(ap + 32); alo[u] = *reinterpret_cast<const bf16x8 *>(ap + 64);
+            a_nxt[u][0] = *reinterpret_cast<const bf16x8 *>(ap); a_nxt[u][1] = *reinterpret_cast<const bf16x8 *>(ap + 32); a_nxt[u][2] = *reinterpret_cast<const bf16x8 *>(ap + 64);
         }
+    };
+    auto compute = [&](int tap, const f32x4 *bcur) {
+        const bf16x8 bhi = __builtin_bit_cast(bf16x8, bcur[0]), bmid = __builtin_bit_cast(bf16x8, bcur[1]), blo = __builtin_bit_cast(bf16x8, bcur[2]);
+        bf16x8 ahi[MT], amid[MT], alo[MT];
+#pragma unroll
+        for (int u = 0; u < MT; ++u) { ahi[u] = a_nxt[u][0]; amid[u] = a_nxt[u][1]; alo[u] = a_nxt[u][2]; }
+        read_a(min(tap + 1, p.K - 1));   // (behind the last tap: re-reads it)
         // product-major, row-tile-minor: consecutive MFMAs go to different accumulators; per accumulator the order is cl_igemm_kernel's (small terms first)
 #pragma unroll
         for (int u = 0; u < MT; ++u) acc[u] = mfma_32x32x16_bf16(alo[u], bhi, acc[u]);
@@ -338,6 +346,7 @@ __global__ __launch_bounds__(64 * (8 / MT) * NT) void cl_conv_brick3_kernel(Igem
                 *reinterpret_cast<bf16x8 *>(brick + fdst[j] + 64) = lo;
             }
             __syncthreads();
+            read_a(0);
             // (K = 27 is a multiple of DEPTH and the ring's loads are UNCONDITIONAL — behind the last tap they re-read it: a conditional load into the ring
             //  made the compiler merge the two paths with register copies behind s_waitcnt vmcnt(0), i.e. wait for the records it had just requested)
 #pragma unroll 1
