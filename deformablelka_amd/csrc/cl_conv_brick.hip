@@ -118,7 +118,10 @@ __global__ __launch_bounds__(64 * WAVES) void cl_conv_brick_kernel(IgemmArgs p, 
 #ifndef DLKA_BRICK_ABL   // TIMING-ONLY ablations (wrong results): 1 no fill, 2 no tap loop
 #define DLKA_BRICK_ABL 0
 #endif
-    for (int ck = 0; ck < nchunk; ++ck) {
+    // gridDim.y > 1: the plane chunks are split over blockIdx.y (volumes too small to fill the chip with one workgroup per tile); the partial sums meet in
+    // fp32 atomics on a ZEROED `out` (the caller's business, as for the tap-split kernels) and `aux` enters once
+    const int cpw = (nchunk + (int)gridDim.y - 1) / (int)gridDim.y, ck_lo = (int)blockIdx.y * cpw, ck_hi = min(nchunk, ck_lo + cpw);
+    for (int ck = ck_lo; ck < ck_hi; ++ck) {
 #pragma unroll
         for (int s = 0; s < DEPTH - 1; ++s) load_b(s, ck, bring[s]);
         // ---- fill (split into the two bf16 terms on the way) ----
@@ -143,6 +146,9 @@ __global__ __launch_bounds__(64 * WAVES) void cl_conv_brick_kernel(IgemmArgs p, 
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s) {
                 load_b(min(tap + s + DEPTH - 1, p.K - 1), ck, bring[(s + DEPTH - 1) % DEPTH]);
+#ifdef DLKA_BRICK_FENCE
+                sched_fence();
+#endif
                 compute(tap + s, bring[s]);
             }
         }
@@ -165,15 +171,16 @@ __global__ __launch_bounds__(64 * WAVES) void cl_conv_brick_kernel(IgemmArgs p, 
             const long mr = (long)b * p.N + ((long)(d0 + rd) * p.H + h0 + rh) * W + rwv;
             const long o = mr * p.Cout + n;
             float val = acc[u][t][q];
-            if (p.epi == 3) val += (sizeof(T) == 4 || p.aux_f32) ? p.aux[o] : act_load1(auxp, o);
-            act_store1(outp, o, val);
+            if (p.epi == 3 && blockIdx.y == 0) val += (sizeof(T) == 4 || p.aux_f32) ? p.aux[o] : act_load1(auxp, o);
+            if (gridDim.y > 1) atomicAdd(p.out + o, val);   // (T = float by construction)
+            else act_store1(outp, o, val);
         }
     }
 }
 
 // The tile a launch uses: 4-wave workgroups of 2 x TH x W = 128 voxels when their brick leaves room for TWO workgroups per CU (one stages its next chunk
 // while the other runs its taps: measured against one 8-wave workgroup per CU in profiles/r06_notes.md), else 8 waves on 1 x TH x W = 256 voxels.
-struct BrickTile { int waves, mt, TD, TH; size_t lds; };
+struct BrickTile { int waves, mt, TD, TH, csplit; size_t lds; };
 #ifndef DLKA_BRICK_DEFAULT_CAND
 #define DLKA_BRICK_DEFAULT_CAND 1   // 0: 4 waves (2 x TH x W tiles, two workgroups per CU), 1: 8 waves, 2: 4 waves of two row tiles
 #endif
@@ -194,8 +201,20 @@ static bool brick_tile(const IgemmArgs &a, BrickTile &bt)
         if (TH < 1 || (TH & (TH - 1)) || (a.W & (a.W - 1)) || a.H % TH || a.D % TD) continue;
         const size_t lds = (size_t)(TD + 2) * (TH + 2) * (a.W + 2) * BRICK_ROW;
         if (lds > ((waves == 4 && mt == 1) ? 80u : 160u) * 1024) continue;
-        if (4 * (TD + 2) * (TH + 2) * (a.W + 2) > 17 * 64 * waves) continue;   // MAXI fill items per thread
-        bt.waves = waves; bt.mt = mt; bt.TD = TD; bt.TH = TH; bt.lds = lds;
+        if (4 * (TD + 2) * (TH + 2) * (a.W + 2) > (mt == 2 ? 17 : 9) * 64 * waves) continue;   // MAXI fill items per thread
+        // enough workgroups to fill the chip (DLKA_CONV_BRICK_MIN_WG lowers the bar for tests): one per tile, else — 4-wave tiles only — one per (tile, plane chunk)
+        const char *mw = getenv("DLKA_CONV_BRICK_MIN_WG");
+        const long need = mw ? atoi(mw) : 128, tiles = (long)a.M / rows, nchunk = a.CinP / 32;
+        // The plane-chunk split (4-wave tiles, one workgroup per (tile, chunk)) exists for volumes below `need` tiles and is OFF by default: at (64, 16^3) it
+        // measured 37.9 us against cl_igemm_kernel's 37.1 (profiles/r06_notes.md).  DLKA_CONV_BRICK_CSPLIT=2 switches it on (tests keep it alive).
+        const char *fs = getenv("DLKA_CONV_BRICK_CSPLIT");
+        const bool allow_split = fs && atoi(fs) > 1 && waves == 4 && mt == 1;
+        int csplit = 1;
+        if (tiles < need) {
+            if (!allow_split || tiles * nchunk < need) continue;
+            csplit = (int)nchunk;
+        } else if (allow_split) csplit = (int)nchunk;
+        bt.waves = waves; bt.mt = mt; bt.TD = TD; bt.TH = TH; bt.lds = lds; bt.csplit = csplit;
         return true;
     }
     return false;
@@ -213,8 +232,6 @@ bool cl_conv_brick_supported(const IgemmArgs &a)
     if (a.NP != 32 && a.NP != 64) return false;
     BrickTile bt;
     if (!brick_tile(a, bt)) return false;
-    const char *mw = getenv("DLKA_CONV_BRICK_MIN_WG");
-    if ((long)a.M / (32 * bt.waves * bt.mt) < (mw ? atoi(mw) : 128)) return false;   // (enough workgroups to fill the chip; smaller volumes split the taps instead)
     if ((size_t)a.B * a.CinReal * a.N * 4 >= (1ull << 31) || (long)a.K * (a.CinP / 32) * 32 * a.NP * 4 >= (1l << 31)) return false;   // 32-bit buffer offsets
     return true;
 }
@@ -354,6 +371,9 @@ __global__ __launch_bounds__(64 * (8 / MT) * NT) void cl_conv_brick3_kernel(Igem
 #pragma unroll
                 for (int s = 0; s < DEPTH; ++s) {
                     load_b(min(tap + s + DEPTH - 1, p.K - 1), ck, mf, bring[(s + DEPTH - 1) % DEPTH]);
+#ifdef DLKA_BRICK3_FENCE
+                    sched_fence();   // (experiment: the record loads stay in front of the tap's MFMAs)
+#endif
                     compute(tap + s, bring[s]);
                 }
             }
@@ -427,6 +447,13 @@ int launch_cl_conv_brick3(const IgemmArgs &a, hipStream_t st)
     return DLKA_OK;
 }
 
+// plane-chunk split the brick kernel would use for this conv (1 = none; > 1: fp32 atomics into a zeroed `out`), 0 if it does not take it
+int cl_conv_brick_split(const IgemmArgs &a)
+{
+    BrickTile bt;
+    return (cl_conv_brick_supported(a) && brick_tile(a, bt)) ? bt.csplit : 0;
+}
+
 // DLKA_ERR_UNSUPPORTED: the caller takes cl_conv_wave_kernel / cl_igemm_kernel.
 int launch_cl_conv_brick(const IgemmArgs &a, hipStream_t st)
 {
@@ -451,14 +478,15 @@ int launch_cl_conv_brick(const IgemmArgs &a, hipStream_t st)
         attr_done.fetch_or(bit, std::memory_order_release);
     }
 #endif
-    dim3 grid(nwg), block(64 * bt.waves);
+    dim3 grid(nwg, bt.csplit), block(64 * bt.waves);
+    if (bt.csplit > 1 && !a.out_zeroed && launch_zero(a.out, (size_t)a.M * a.Cout * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
 #define DLKA_BRICK_GO(NTV, TT)                                                                                                   \
     {                                                                                                                            \
         if (bt.mt == 2) { auto k = cl_conv_brick_kernel<NTV, TT, 4, 2>; DLKA_LAUNCH(k, grid, block, lds, st, a, bt.TD, bt.TH); }      \
         else if (bt.waves == 4) { auto k = cl_conv_brick_kernel<NTV, TT, 4>; DLKA_LAUNCH(k, grid, block, lds, st, a, bt.TD, bt.TH); } \
         else { auto k = cl_conv_brick_kernel<NTV, TT, 8>; DLKA_LAUNCH(k, grid, block, lds, st, a, bt.TD, bt.TH); }               \
     }
-    if (a.act_bf16) { if (NT == 1) DLKA_BRICK_GO(1, bf16_t) else DLKA_BRICK_GO(2, bf16_t) }
+    if (a.act_bf16 && bt.csplit == 1) { if (NT == 1) DLKA_BRICK_GO(1, bf16_t) else DLKA_BRICK_GO(2, bf16_t) }   // (split: `out` is the caller's fp32 accumulation buffer)
     else { if (NT == 1) DLKA_BRICK_GO(1, float) else DLKA_BRICK_GO(2, float) }
 #undef DLKA_BRICK_GO
     DLKA_CHECK_LAUNCH();

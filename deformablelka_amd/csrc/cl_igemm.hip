@@ -444,7 +444,7 @@ int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t s
         const int rc = launch_cl_conv_brick3(a, st);
         if (rc != DLKA_ERR_UNSUPPORTED) return rc;
     }
-    if (amode == 2 && omode == 0 && splits == 1 && a.split_bf16 == 2) {   // the offset conv's data gradient at the wide stage: LDS-brick kernel
+    if (amode == 2 && omode == 0 && a.split_bf16 == 2 && (splits == 1) == (cl_conv_brick_split(a) == 1)) {   // the offset conv's data gradient: LDS-brick kernel
         const int rc = launch_cl_conv_brick(a, st);
         if (rc != DLKA_ERR_UNSUPPORTED) return rc;
     }

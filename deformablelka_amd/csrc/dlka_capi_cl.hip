@@ -154,7 +154,10 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
     a.aux_f32 = aux_f32 ? 1 : 0;
     if (ride) a.zero = *ride;
     int splits = dense_backward_data_splits(s, epi);
-    if (gout_planar && cl_conv_brick_supported(a)) splits = 1;   // (cl_conv_brick.hip writes every output itself: no tap split, whatever the row count)
+    // cl_conv_brick.hip: no tap split; volumes too small for a workgroup per tile split the plane chunks instead (fp32 atomics into a zeroed buffer, like a tap split)
+    const int bsplit = gout_planar ? cl_conv_brick_split(a) : 0;
+    if (bsplit == 1) splits = 1;
+    else if (bsplit > 1 && splits <= 1) splits = 2;   // (only its being > 1 matters below: the zero-fill / fp32-accumulation route)
     if (s.act_bf16 && splits > 1) {
         if (!acc32) return DLKA_ERR_WORKSPACE;
         a.out = acc32; a.out_zeroed = 1;

@@ -60,6 +60,7 @@ int launch_cl_pointwise(const IgemmArgs &a, hipStream_t st);
 int launch_cl_pointwise_pair(const PwPairArgs &a, hipStream_t st);   // two dependent pointwise convs in one launch (C = 32 / 64)
 int launch_cl_conv_wave(int amode, int omode, const IgemmArgs &a, int splits, hipStream_t st);
 bool cl_conv_brick_supported(const IgemmArgs &a);
+int cl_conv_brick_split(const IgemmArgs &a);
 bool cl_conv_brick3_supported(const IgemmArgs &a);
 int launch_cl_conv_brick3(const IgemmArgs &a, hipStream_t st);   // the forward offset conv (three-term) from an LDS brick
 int launch_cl_conv_brick(const IgemmArgs &a, hipStream_t st);   // cl_conv_brick.hip: planar-input 3^3 data gradient from an LDS brick

@@ -595,18 +595,21 @@ def test_depthwise_lds_brick_kernel(monkeypatch):
     assert lib.dlka_dwconv_lds_launch_count() == n3
 
 
-@pytest.mark.parametrize("case", [(1, 32, (2, 16, 16), None), (1, 32, (2, 16, 16), "8"), (2, 32, (3, 8, 32), None), (1, 64, (2, 32, 8), None), (1, 32, (4, 4, 32), "4"), (1, 32, (2, 8, 32), "42")])
+@pytest.mark.parametrize("case", [(1, 32, (2, 16, 16), None), (1, 32, (2, 16, 16), "8"), (2, 32, (3, 8, 32), None), (1, 64, (2, 32, 8), None), (1, 32, (4, 4, 32), "4"), (1, 32, (2, 8, 32), "42"), (2, 64, (2, 8, 16), "4s")])
 def test_conv_brick_data_gradient(case, monkeypatch):
     """cl_conv_brick_kernel (the offset-predict conv's data gradient from an LDS brick: planar grad_out staged once per 32-plane chunk, split into its bf16 terms
     while being staged, 27 taps read from LDS) against the fp64 conv — and against the kernel it replaces at the wide stage (same products, other summation order).
     DLKA_CONV_BRICK_MIN_WG=1 lets emulator-sized volumes take it (real use: >= 128 workgroups of 256 voxels); the launch counter proves which kernel ran.
     Cases: 4-wave workgroups on 2 x 4 x 16 tiles; the same volume on 8-wave workgroups (one 16 x 16 plane each); an odd depth (8-wave tiles of 8 rows of 32, two
-    volumes); two output column tiles with W = 8; the stage-0 tiling (4 waves, 2 x 2 x 32); 4 waves of two row tiles each (8 rows of 32)."""
+    volumes); two output column tiles with W = 8; the stage-0 tiling (4 waves, 2 x 2 x 32); 4 waves of two row tiles each (8 rows of 32); 4-wave tiles with the chunk split, two column tiles, two volumes."""
     from deformablelka_amd import _lib, ops
     B, C, dims, waves = case
     lib = _lib.get_lib()
     monkeypatch.setenv("DLKA_CONV_BRICK_MIN_WG", "1")
     monkeypatch.setenv("DLKA_CONV_BRICK", "2")   # the data gradient's brick kernel only (the forward's has its own test below)
+    if waves == "4s":   # 4-wave tiles with the plane chunks split over workgroups (fp32 atomics into a zeroed output): what volumes below 128 tiles get
+        waves = "4"
+        monkeypatch.setenv("DLKA_CONV_BRICK_CSPLIT", "2")
     if waves:
         monkeypatch.setenv("DLKA_CONV_BRICK_WAVES", waves)
     n0 = lib.dlka_conv_brick_launch_count()
@@ -665,3 +668,22 @@ def test_conv_brick_forward_three_term(case, monkeypatch):
     y_igemm = ops.conv3d_forward_cl(x, w, bias, 1, 1, 1, out_planar=True)
     assert lib.dlka_conv_brick_launch_count() == n1
     assert (y_brick - y_igemm).abs().max().item() <= 2e-6 * y_igemm.abs().max().item()
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_lka3d_tokens_block_through_brick_kernels(split, monkeypatch):
+    """The whole token-path block with the offset conv's forward and data gradient on the LDS-brick kernels (emulator-sized volume let in by DLKA_CONV_BRICK_MIN_WG=1), fp32 and
+    bf16 activations — and, split = True, with the data gradient's plane chunks split over workgroups: fp32 atomics into the zero-filled gradient (fp32) / into the fp32
+    accumulation buffer that is converted afterwards (bf16).  The launch counter proves the kernels ran."""
+    from deformablelka_amd import _lib
+    lib = _lib.get_lib()
+    monkeypatch.setenv("DLKA_CONV_BRICK_MIN_WG", "1")
+    if split:
+        monkeypatch.setenv("DLKA_CONV_BRICK_WAVES", "4")
+        monkeypatch.setenv("DLKA_CONV_BRICK_CSPLIT", "2")
+    n0 = lib.dlka_conv_brick_launch_count()
+    parity.check_lka3d_tokens("cpu", 1, 64 if split else 32, (2, 8, 16), offset_std=0.3, seed=3)
+    n1 = lib.dlka_conv_brick_launch_count()
+    assert n1 - n0 >= 2, (n0, n1)   # forward + data gradient
+    parity.check_lka3d_tokens_bf16("cpu", 1, 64 if split else 32, (2, 8, 16))
+    assert lib.dlka_conv_brick_launch_count() - n1 >= 2
