@@ -266,6 +266,120 @@ __global__ __launch_bounds__(256, WL ? 3 : 1) void cl_dwconv_rowsN_kernel(DwArgs
     }
 }
 
+// ... and with TWO output planes per work-item as well (d0 and d0 + DIL, on top of the two rows h0 and h0 + DIL): the kernel above sits exactly on the L1 return
+// path (1.7 GB of wave loads per 7^3 launch at 32^3 = 42 us at 64 bytes / clock / CU, and it measures 42; the vector units are NOT the limit: independent fp32 FMAs
+// issue at ~110 - 125 lanes per clock and CU, scripts/ubench/fma_rate.hip), and output planes DIL apart share KD - 1 of their KD input planes exactly as the rows do:
+// KD + 1 planes of (KH + 1) segment rows feed 2 x 2 x KH x KW x TW products — 7.5 instead of 3.8 FMAs per loaded element at 7^3.
+// Tap weights in LDS as in the WL variant above, plus ONE all-zero tap plane: the first / last input plane of a pair serves only one of the two outputs, and the
+// other output multiplies it with zeros instead of branching (the FMAs are not what this kernel waits for).  C = 32 (one 32-channel group per workgroup).
+#ifndef DLKA_TD2_OCC
+#define DLKA_TD2_OCC 2   // (3: 168 registers with 14 - 19 spilled at 7^3; measured 60 against 51 us)
+#endif
+template <typename T, int KW, int DIL, int TW>
+__global__ __launch_bounds__(256, DLKA_TD2_OCC) void cl_dwconv_rows2d_kernel(DwArgs p)
+{
+    constexpr int KH = KW, KD = KW, TH = 2, TD = 2;
+    constexpr int SB = sizeof(T);
+    const T *inp = reinterpret_cast<const T *>(p.in), *gxp = reinterpret_cast<const T *>(p.gelu_x), *gap = reinterpret_cast<const T *>(p.gelu_add);
+    T *outp = reinterpret_cast<T *>(p.out);
+    constexpr int SEG = TW + (KW - 1) * DIL;
+    constexpr int NR = KH + TH - 1, NP = KD + TD - 1;        // input rows per plane, input planes per work-item
+    constexpr int cpb = 32, rpb = 8;
+    constexpr int PLANE = KH * KW * 32;                      // floats of one tap plane in LDS
+    __shared__ __attribute__((aligned(16))) float Wl[(KD + 1) * PLANE];   // [tap plane (KD = zeros)][tap row][tap col][channel of the workgroup]
+    {
+        const int n4 = KD * KH * KW * 8;   // 16-byte pieces: 8 per tap
+        for (int e = threadIdx.x; e < n4 + KH * KW * 8; e += 256) {
+            const int tap = e >> 3, q = e & 7;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < n4) v = *reinterpret_cast<const f32x4 *>(p.wp + (long)tap * p.C + blockIdx.z * 32 + 4 * q);
+            reinterpret_cast<f32x4 *>(Wl)[e] = v;
+        }
+        __syncthreads();
+    }
+    const int c = blockIdx.z * cpb + threadIdx.x % cpb, cl = threadIdx.x % cpb;
+    const int bx = DLKA_XCD_BX(p.xcd_nx);
+    if (bx < 0) return;
+    const int run = bx * rpb + threadIdx.x / cpb;
+    const int runs_per_row = cdiv(p.W, TW);
+    const int hgroups = DIL * cdiv(p.H, TH * DIL), dgroups = DIL * cdiv(p.D, TD * DIL);   // h0 = r + TH*DIL*q, d0 = r' + TD*DIL*q'  (r, r' < DIL)
+    const long total = (long)p.B * dgroups * hgroups * runs_per_row;
+    if (run >= total || c >= p.C) return;
+    const int w0 = (run % runs_per_row) * TW;
+    const int gidx = wave_uniform(run / runs_per_row);
+    const int hg = gidx % hgroups, dg = (gidx / hgroups) % dgroups, b = gidx / (hgroups * dgroups);
+    const int h0 = (hg % DIL) + (hg / DIL) * TH * DIL, d0 = (dg % DIL) + (dg / DIL) * TD * DIL;
+    if (h0 >= p.H || d0 >= p.D) return;                      // scalar
+    const bool second = d0 + DIL < p.D;                      // the pair's second output plane exists
+
+    float acc[TD][TH][TW];
+    const float bv = p.bias ? p.bias[c] : 0.f;
+#pragma unroll
+    for (int od = 0; od < TD; ++od)
+#pragma unroll
+        for (int o = 0; o < TH; ++o)
+#pragma unroll
+            for (int t = 0; t < TW; ++t) acc[od][o][t] = bv;
+
+    const int cb = p.C * SB;
+    const unsigned rowbytes = (unsigned)(p.W * cb);
+    const int vbase = (w0 - p.pw) * cb + c * SB;
+#pragma unroll 1
+    for (int ip = 0; ip < NP; ++ip) {
+        const int zd = d0 - p.pd + ip * DIL;
+        if (zd < 0 || zd >= p.D) continue;                   // scalar
+        const float *wl0 = Wl + (ip < KD ? ip : KD) * PLANE + cl;                         // output plane d0: tap plane ip
+        const float *wl1 = Wl + ((ip >= 1 && second) ? ip - 1 : KD) * PLANE + cl;         // output plane d0 + DIL: tap plane ip - 1
+        const T *plane = inp + ((long)(b * p.D + zd) * p.H) * p.W * p.C;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {                       // input row h0 - ph + r*DIL: tap row r - o of output row o
+            const int zh = h0 - p.ph + r * DIL;
+            if (zh < 0 || zh >= p.H) continue;               // scalar
+            const BufRsrc rr = make_rsrc(plane + (long)zh * p.W * p.C, rowbytes);
+            float seg[SEG];
+#pragma unroll
+            for (int e = 0; e < SEG; ++e) seg[e] = act_buf_load1<T>(rr, (unsigned)(vbase + e * cb));
+#pragma unroll
+            for (int o = 0; o < TH; ++o) {
+                if (r - o < 0 || r - o >= KH) continue;      // compile time
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    const float wk0 = wl0[((r - o) * KW + k) * 32], wk1 = wl1[((r - o) * KW + k) * 32];
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) {
+                        acc[0][o][t] = fmaf(wk0, seg[t + k * DIL], acc[0][o][t]);
+                        acc[1][o][t] = fmaf(wk1, seg[t + k * DIL], acc[1][o][t]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int od = 0; od < TD; ++od) {
+        if (d0 + od * DIL >= p.D) break;                     // scalar
+#pragma unroll
+        for (int o = 0; o < TH; ++o) {
+            if (h0 + o * DIL >= p.H) break;                  // scalar
+            const long obase = (((long)(b * p.D + d0 + od * DIL) * p.H + h0 + o * DIL) * p.W + w0) * p.C + c;
+            if (p.gelu_x) {
+#pragma unroll
+                for (int t = 0; t < TW; ++t)
+                    if (w0 + t < p.W) act_store1(outp, obase + (long)t * p.C, (acc[od][o][t] + act_load1(gap, obase + (long)t * p.C)) * dgelu_f(act_load1(gxp, obase + (long)t * p.C)));
+            } else {
+#pragma unroll
+                for (int t = 0; t < TW; ++t)
+                    if (w0 + t < p.W) act_store1(outp, obase + (long)t * p.C, acc[od][o][t]);
+                if (sizeof(T) == 4 && p.out_lo) {   // uniform: bf16 copy (see cl_args.h: DwArgs::out_lo)
+                    bf16_t *lo = reinterpret_cast<bf16_t *>(p.out_lo);
+#pragma unroll
+                    for (int t = 0; t < TW; ++t)
+                        if (w0 + t < p.W) act_store1(lo, obase + (long)t * p.C, acc[od][o][t]);
+                }
+            }
+        }
+    }
+}
+
 // reference layout W[c][1][kd][kh][kw] -> Wp[tap][c]; flip = 1 reverses the taps (data gradient)
 __global__ void cl_dw_prep_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int C, int K, int flip)
 {
@@ -323,6 +437,23 @@ static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st
                 else { auto k = cl_dwconv_rowsN_kernel<T, 5, 1, 4, 2>; DLKA_LAUNCH(k, grid4, block, 0, st, ax); }
                 DLKA_CHECK_LAUNCH();
                 return DLKA_OK;
+            }
+            // two output planes per work-item (cl_dwconv_rows2d_kernel): OPT-IN, DLKA_DW_TD2=1 (read per launch).  Measured SLOWER at (32, 32^3): 7^3 60 us (51 at two waves
+            // per SIMD, without its 14 spilled registers) against 45, 5^3 33 against 28; stage-0 stack 5.67 against 5.49 ms (profiles/r06_notes.md) — half the loads per
+            // output did not pay for half the workgroups, twice the LDS weight reads and the longer per-wave stream: these convs are not simply L1-bound.
+            {
+                const char *e2 = getenv("DLKA_DW_TD2");
+                const bool td2 = (e2 && e2[0] == '1') && th == 2 && cpb == 32 && a.C == 32 && a.D >= 4 * dil_w && a.pd == (kw - 1) / 2 * dil_w && !a.out_blk;
+                if (td2) {
+                    const long runs3 = (long)a.B * dil_w * cdiv(a.D, 2 * dil_w) * dil_w * cdiv(a.H, th * dil_w) * cdiv(a.W, TW);
+                    dim3 grid3((unsigned)cdivl(runs3, rpb), 1, 1);
+                    ax.xcd_nx = 0;   // (swz(grid2) above may have set it for the one-plane grid)
+                    swz(grid3);
+                    if (kw == 7) { auto k = cl_dwconv_rows2d_kernel<T, 7, 3, TW>; DLKA_LAUNCH(k, grid3, block, 0, st, ax); }
+                    else { auto k = cl_dwconv_rows2d_kernel<T, 5, 1, TW>; DLKA_LAUNCH(k, grid3, block, 0, st, ax); }
+                    DLKA_CHECK_LAUNCH();
+                    return DLKA_OK;
+                }
             }
             constexpr bool no_wl = false;   // (measured: 54.3 -> 45.0 us at 32 channels / 32^3, profiles/r04_notes.md)
             if (kw == 7 && th == 2 && cpb == 32 && a.kd == 7 && !no_wl) { auto k = cl_dwconv_rowsN_kernel<T, 7, 3, TW, 2, true>; DLKA_LAUNCH(k, grid2, block, 0, st, ax); }

@@ -687,3 +687,23 @@ def test_lka3d_tokens_block_through_brick_kernels(split, monkeypatch):
     assert n1 - n0 >= 2, (n0, n1)   # forward + data gradient
     parity.check_lka3d_tokens_bf16("cpu", 1, 64 if split else 32, (2, 8, 16))
     assert lib.dlka_conv_brick_launch_count() - n1 >= 2
+
+
+@pytest.mark.parametrize("case", [(1, 32, (13, 7, 9), 7, 9, 3), (2, 32, (5, 6, 9), 5, 2, 1), (1, 32, (12, 6, 8), 7, 9, 3)])
+def test_dwconv_two_output_planes(case, monkeypatch):
+    """cl_dwconv_rows2d_kernel (depthwise 5^3 / 7^3 dilation 3 with two output planes AND two output rows per work-item, tap weights + one zero tap plane in LDS; 32 channels)
+    against the fp64 conv (forward, data gradient through the same kernel with flipped taps, weight gradient untouched) — and bit for bit against the one-plane kernel it
+    stands beside (default: one plane; the same FMA chain per output, zero products added at the pair's outer planes).  Cases: odd depth / height / width (an unpaired
+    last plane, ragged rows and runs); 5^3 across a batch; even sizes."""
+    from deformablelka_amd import ops
+    B, C, dims, k, p, d = case
+    monkeypatch.setenv("DLKA_DW_TD2", "1")   # opt-in: measured slower than the one-plane kernel on the MI355X (cl_dwconv.hip)
+    parity.check_conv3d_cl("cpu", B, C, C, dims, k, p, d, C, planar=False, seed=8)
+    gen = torch.Generator().manual_seed(10)
+    x = torch.randn(B, *dims, C, generator=gen)
+    w = torch.randn(C, 1, k, k, k, generator=gen) * 0.1
+    bias = torch.randn(C, generator=gen)
+    y2 = ops.conv3d_forward_cl(x, w, bias, p, d, C)
+    monkeypatch.delenv("DLKA_DW_TD2")
+    y1 = ops.conv3d_forward_cl(x, w, bias, p, d, C)
+    assert torch.equal(y1, y2)
