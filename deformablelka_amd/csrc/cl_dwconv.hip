@@ -429,7 +429,11 @@ static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st
             const long waves8 = runs2 * cpb / 64 * cdiv(a.C, cpb);
             constexpr bool no_tw4 = false;
             // (measured at the stage shapes, us, 4 vs 8 wide: 5^3 13.3 / 17.9 at 16^3, 12.7 / 17.4 at 8^3, 11.0 / 12.4 at 4^3; 7^3 19.0 / 18.5 at 16^3, 8.8 / 9.5 at 8^3)
-            if (!no_tw4 && th == 2 && waves8 < (kw == 5 ? 1024 : 384) && a.W % 4 == 0 && cdiv(a.W, 4) % wpr == 0) {
+            #ifndef DLKA_DW_TW4_5
+#define DLKA_DW_TW4_5 1024   // (waves of the 8-wide grid below which the 4-wide one is taken: 5^3 / 7^3; -D... for scripts/build_variant.sh)
+#define DLKA_DW_TW4_7 384
+#endif
+            if (!no_tw4 && th == 2 && waves8 < (kw == 5 ? DLKA_DW_TW4_5 : DLKA_DW_TW4_7) && a.W % 4 == 0 && cdiv(a.W, 4) % wpr == 0) {
                 const long runs4 = (long)a.B * a.D * dil_w * cdiv(a.H, th * dil_w) * cdiv(a.W, 4);
                 dim3 grid4((unsigned)cdivl(runs4, rpb), 1, cdiv(a.C, cpb));
                 swz(grid4);
