@@ -570,6 +570,43 @@ SideCtx &side_ctx()
     return c;
 }
 
+// grad_input of the deformable conv BESIDE grad_offset: the two kernels are independent (both read grad_out, the offsets and the column weights; one scatters into
+// gta, the other writes goff and the samples), and they are the two largest of the block.  Measured per stage (profiles/r06_notes.md, `r7d`): at the 32^3 stage the
+// pair gains 35 us per block (stage-0 stack 5.377 -> 5.166 ms: the LDS-window scatter kernel runs two workgroups per CU at 128 registers, the gather kernel three waves
+// per SIMD with little LDS — they fill each other's holes), at the smaller stages the fork / join costs more than it gains (2.645 -> 2.651, 1.994 -> 2.014, 0.888 ->
+// 0.905 ms) when a stage is timed ALONE — but in the whole 21-block step, which is the metric, forking EVERY block measured best on three boxes (fp32 10.616 / 10.597 /
+// 10.518 ms for never / wide stage only / always; bf16 9.920 / 9.864 / 9.755): the default is always.  DLKA_GX_FORK_MIN_ROWS (read per call) = row count from which a call
+// forks; a huge value = never.  (Round 3 measured a fork for all stages with that round's kernels and lost, profiles/r04_notes.md.)  One internal stream + two events; under hipGraph capture the pattern becomes a fork / join
+// inside the block.  The first use must not be inside a capture (stream creation): every caller here warms up eagerly.
+struct AuxCtx {
+    hipStream_t s;
+    hipEvent_t fork, join;
+    bool ok;
+};
+AuxCtx &aux_ctx()
+{
+    static AuxCtx c = [] {
+        AuxCtx x;
+        memset(&x, 0, sizeof(x));
+        x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+        return x;
+    }();
+    return c;
+}
+// (phase 0 = the one-call backward of the nn.Module path: there the fork measured SLOWER — wrapper-block stack 100.5 against 102.5 volumes/s, full net 68.8 against 69.8 — so by
+//  default only the stack engine's data-chain pass, phase 1, forks; the environment variable, when set, rules both)
+bool gx_fork_wanted(long rows, int phase)
+{
+#if defined(HIPEMU)
+    return false;   // (no streams on the CPU test backend)
+#else
+    const char *e = getenv("DLKA_GX_FORK_MIN_ROWS");
+    if (!e) return phase == 1;
+    return rows >= atol(e);
+#endif
+}
+
 bool tokens_supported(int B, int C, int D, int H, int W, int variant = DLKA_LKA3D_SYNAPSE)
 {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return false;
@@ -1467,6 +1504,15 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
     if (!samp)
         DLKA_P2(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
                                 &fb.j[fb.njobs++]));
+    bool gx_forked = false;
+    if (phase != 2 && gx_fork_wanted((long)G.dcn.M, phase)) {   // grad_input on the internal stream, beside grad_offset (see aux_ctx)
+        AuxCtx &ax = aux_ctx();
+        if (ax.ok && hipEventRecord(ax.fork, st) == hipSuccess && hipStreamWaitEvent(ax.s, ax.fork, 0) == hipSuccess) {
+            DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, ax.s, nullptr, true, false, 0, nullptr, PW.dcn_b16));
+            if (hipEventRecord(ax.join, ax.s) != hipSuccess) return DLKA_ERR_LAUNCH;
+            gx_forked = true;
+        }
+    }
     DLKA_P1(deform_backward(G.dcn, t, off, N0, gf, nullptr, goff, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, false, true, goff_cpad, samp, PW.dcn_b16));
     DLKA_TRY(publish());
     if (samp)
@@ -1474,7 +1520,10 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
                                 &fb.j[fb.njobs++], false, false, 0, samp));
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
     DLKA_P2(dense_backward_weight(G.offc, t, goff, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, ws_, &fb.j[fb.njobs++], goff_cpad));
-    DLKA_P1(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, true, false, 0, nullptr, PW.dcn_b16));
+    if (gx_forked) {   // join: the offset conv's data gradient adds gta
+        if (hipStreamWaitEvent(st, aux_ctx().join, 0) != hipSuccess) return DLKA_ERR_LAUNCH;
+    } else
+        DLKA_P1(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, true, false, 0, nullptr, PW.dcn_b16));
     DLKA_P1(dense_backward_data(G.offc, goff, 1, N0, gt, PW.off_b, 3, gta, st, nullptr, nullptr, true, goff_cpad != 0, true, ga2));
     DLKA_TRY(publish());
     // depthwise 7^3 dil 3:  t = DW7 t1
