@@ -740,7 +740,7 @@ int lka2d_cl_saved_offsets(int B, int C, int H, int W, int dtype, size_t byte_of
 size_t lka2d_cl_workspace_bytes(int B, int C, int H, int W, int dtype)
 {
     Lka2dCl G(B, C, H, W, dtype);
-    return 9 * align256(G.E * 4) + align256(G.O7 * 4) + align256(G.part_floats() * 4) + align256(4096);
+    return 9 * align256(G.E * 4) + align256(G.O7 * 4) + align256(G.O5 * 4) + align256(G.part_floats() * 4) + align256(4096);   // (O5: the second conv's grad_offset, see lka2d_cl_backward)
 }
 
 int lka2d_cl_forward(const void *x_, const dlka_lka2d_params *p, void *y_, void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes, int B,
@@ -796,11 +796,26 @@ int lka2d_cl_backward(const void *x_, const dlka_lka2d_params *p, const void *gy
     float *gta = (float *)cv.take(G.E * 4), *gt1 = (float *)cv.take(G.E * 4), *gaa = (float *)cv.take(G.E * 4), *gab = (float *)cv.take(G.E * 4);
     float *gh = (float *)cv.take(G.E * 4);
     float *goff = (float *)cv.take(G.O7 * 4);
+    float *goff5 = (float *)cv.take(G.O5 * 4);   // the 5x5 conv's grad_offset in a buffer of its own: the 7x7 offset net's weight gradient may still be reading `goff`
     float *part = (float *)cv.take(G.part_floats() * 4);
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const float *N0 = nullptr;
     Prep2d PW;
     DLKA_TRY(carve_prep2d(G, prep, PW, p, st, false));
+    // The two offset nets' WEIGHT gradients (the largest kernels of this pass after grad_input: C -> 98 / 50 channels over 49 / 25 taps) only read grad_offset and a saved
+    // activation, and nothing before the finalisation reads their partial sums: they run on the library's internal stream (aux_ctx) beside the data chain — fork behind
+    // each depthwise deformable conv's backward, one join in front of the finalisation.  DLKA_LKA2D_FORK=0: one stream (A/B; read per call).  Measured in
+    // profiles/r06_notes.md.
+    bool fork2d = false;
+#if !defined(HIPEMU)
+    { const char *e = getenv("DLKA_LKA2D_FORK"); fork2d = !(e && e[0] == '0') && aux_ctx().ok; }
+#endif
+    hipStream_t wst = fork2d ? aux_ctx().s : st;
+    auto fork_to_aux = [&]() -> int {
+        if (!fork2d) return DLKA_OK;
+        AuxCtx &ax = aux_ctx();
+        return (hipEventRecord(ax.fork, st) == hipSuccess && hipStreamWaitEvent(ax.s, ax.fork, 0) == hipSuccess) ? DLKA_OK : DLKA_ERR_LAUNCH;
+    };
     float *part_p2 = part, *part_c1 = part_p2 + G.part_pw(), *part_p1 = part_c1 + G.part_pw(), *part_o5 = part_p1 + G.part_pw();
     float *part_o7 = part_o5 + G.part_o5(), *part_dw = part_o7 + G.part_o7();
     FinalizeBatch fb;
@@ -826,16 +841,18 @@ int lka2d_cl_backward(const void *x_, const dlka_lka2d_params *p, const void *gy
     d.act_bf16 = bf;
     d.in = t1; d.off = o7; d.wp = PW.dw7; d.g = gt2; d.gx = gta; d.goff = goff; d.part = part_dw;
     DLKA_TRY(launch_cl_ddw2d_bwd(d, (float *)gr->conv_spatial_w, st));
-    DLKA_TRY(dense_backward_weight(G.off7, t1, goff, 1, (float *)gr->conv_spatial_offset_w, (float *)gr->conv_spatial_offset_b, part_o7, st, &fb.j[fb.njobs++]));
+    DLKA_TRY(fork_to_aux());
+    DLKA_TRY(dense_backward_weight(G.off7, t1, goff, 1, (float *)gr->conv_spatial_offset_w, (float *)gr->conv_spatial_offset_b, part_o7, wst, &fb.j[fb.njobs++]));
     DLKA_TRY(dense_backward_data(G.off7, goff, 1, N0, gt1, PW.o7_b, 3, gta, st, nullptr, nullptr, bf && split7, false, bf != 0, bf ? gh : nullptr));   // gt1 = gta + offnet7^T goff
     // conv0 = DeformConv(5x5): t1 = DDW5(a, o5 = offnet5(a))
     fill_ddw(d, G, 5, 2, 1);
     d.act_bf16 = bf;
-    d.in = a; d.off = o5; d.wp = PW.dw5; d.g = gt1; d.gx = gaa; d.goff = goff; d.part = part_dw;
+    d.in = a; d.off = o5; d.wp = PW.dw5; d.g = gt1; d.gx = gaa; d.goff = goff5; d.part = part_dw;
     DLKA_TRY(launch_cl_ddw2d_bwd(d, (float *)gr->conv0_w, st));
-    DLKA_TRY(dense_backward_weight(G.off5, a, goff, 1, (float *)gr->conv0_offset_w, (float *)gr->conv0_offset_b, part_o5, st, &fb.j[fb.njobs++]));
+    DLKA_TRY(fork_to_aux());
+    DLKA_TRY(dense_backward_weight(G.off5, a, goff5, 1, (float *)gr->conv0_offset_w, (float *)gr->conv0_offset_b, part_o5, wst, &fb.j[fb.njobs++]));
     if (bf && split5) DLKA_TRY(launch_zero(gh, G.E * 4, st));
-    DLKA_TRY(dense_backward_data(G.off5, goff, 1, N0, gab, PW.o5_b, 3, gaa, st, nullptr, nullptr, bf && split5, false, bf != 0, bf ? gh : nullptr));   // gab = gaa + offnet5^T goff
+    DLKA_TRY(dense_backward_data(G.off5, goff5, 1, N0, gab, PW.o5_b, 3, gaa, st, nullptr, nullptr, bf && split5, false, bf != 0, bf ? gh : nullptr));   // gab = gaa + offnet5^T goff
     // a = GELU(h) feeds the gate and conv0: gh = (ga1 + gab) * gelu'(h)
     if (bf) DLKA_TRY(launch_gelu_bwd_sum<bf16_t>((const bf16_t *)h, (const bf16_t *)ga1, (const bf16_t *)gab, (bf16_t *)gh, (long)G.E, st));
     else DLKA_TRY(launch_gelu_bwd_sum<float>(h, ga1, gab, gh, (long)G.E, st));
@@ -848,6 +865,10 @@ int lka2d_cl_backward(const void *x_, const dlka_lka2d_params *p, const void *gy
         float *const gbs[3] = {(float *)gr->proj_2_b, (float *)gr->conv1_b, (float *)gr->proj_1_b};
         DLKA_TRY(launch_cl_wgrad_pw3(jobs, gws, gbs, st, &fb.j[fb.njobs]));
         fb.njobs += 3;
+    }
+    if (fork2d) {   // join: the folds read the offset nets' partial sums
+        AuxCtx &ax = aux_ctx();
+        if (hipEventRecord(ax.join, ax.s) != hipSuccess || hipStreamWaitEvent(st, ax.join, 0) != hipSuccess) return DLKA_ERR_LAUNCH;
     }
     DLKA_TRY(launch_cl_wgrad_finalize(fb, st));
     DLKA_TRY(dense_backward_data(G.pw, gh, 0, N0, gxt, PW.pw_b[0], 3, gyt, st));                                                // gx = P1^T gh + gy
