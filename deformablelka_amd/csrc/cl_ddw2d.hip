@@ -526,8 +526,11 @@ int launch_cl_ddw2d_fwd(const DwArgs2d &d, hipStream_t st)
 }
 
 // gx must be zero-filled by the caller; gw receives the folded weight gradient in the reference layout
-int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st)
+// gx_st: stream of the grad_input kernels (null = st).  They are independent of the grad_offset / weight-gradient kernel: a caller that has forked gx_st behind st's
+// producers (and joins it in front of grad_input's consumer) runs the two beside each other (lka2d_cl_backward).
+int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st, hipStream_t gx_st)
 {
+    hipStream_t gst = gx_st ? gx_st : st;
     const int nch = ddw2d_nch(d.C);
     if (!nch) return DLKA_ERR_UNSUPPORTED;
     Ddw2dArgs a;
@@ -560,11 +563,11 @@ int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st)
         if (xcd_swizzle_enabled() && ntiles >= xcd_min_blocks()) { xcd_nx = ntiles; ggrid.x = xcd_grid(ntiles); }
         const dim3 fgrid((unsigned)(((long)a.M * a.K + 255) / 256));
         if (d.act_bf16) {
-            auto k = cl_ddw2d_gx3_kernel<bf16_t>; DLKA_LAUNCH(k, ggrid, dim3(64), 0, st, a, ntx, nty, xcd_nx);
-            auto f = cl_ddw2d_gx_far_kernel<bf16_t>; DLKA_LAUNCH(f, fgrid, dim3(256), 0, st, a);
+            auto k = cl_ddw2d_gx3_kernel<bf16_t>; DLKA_LAUNCH(k, ggrid, dim3(64), 0, gst, a, ntx, nty, xcd_nx);
+            auto f = cl_ddw2d_gx_far_kernel<bf16_t>; DLKA_LAUNCH(f, fgrid, dim3(256), 0, gst, a);
         } else {
-            auto k = cl_ddw2d_gx3_kernel<float>; DLKA_LAUNCH(k, ggrid, dim3(64), 0, st, a, ntx, nty, xcd_nx);
-            auto f = cl_ddw2d_gx_far_kernel<float>; DLKA_LAUNCH(f, fgrid, dim3(256), 0, st, a);
+            auto k = cl_ddw2d_gx3_kernel<float>; DLKA_LAUNCH(k, ggrid, dim3(64), 0, gst, a, ntx, nty, xcd_nx);
+            auto f = cl_ddw2d_gx_far_kernel<float>; DLKA_LAUNCH(f, fgrid, dim3(256), 0, gst, a);
         }
         DLKA_CHECK_LAUNCH();
         return DLKA_OK;
@@ -599,8 +602,8 @@ int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st)
 #endif
         const int ntx = cdiv(a.W, TW), nty = cdiv(a.H, TH);
         dim3 ggrid(a.B * nty * ntx, a.C / GX2_CS);
-        if (d.act_bf16) { auto k = cl_ddw2d_gx_kernel<bf16_t>; DLKA_LAUNCH(k, ggrid, dim3(256), lds, st, a, TH, TW, ntx, nty, reach_y, reach_x); }
-        else { auto k = cl_ddw2d_gx_kernel<float>; DLKA_LAUNCH(k, ggrid, dim3(256), lds, st, a, TH, TW, ntx, nty, reach_y, reach_x); }
+        if (d.act_bf16) { auto k = cl_ddw2d_gx_kernel<bf16_t>; DLKA_LAUNCH(k, ggrid, dim3(256), lds, gst, a, TH, TW, ntx, nty, reach_y, reach_x); }
+        else { auto k = cl_ddw2d_gx_kernel<float>; DLKA_LAUNCH(k, ggrid, dim3(256), lds, gst, a, TH, TW, ntx, nty, reach_y, reach_x); }
         DLKA_CHECK_LAUNCH();
     }
     return DLKA_OK;

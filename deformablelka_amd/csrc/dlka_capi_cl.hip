@@ -579,8 +579,8 @@ SideCtx &side_ctx()
 // forks; a huge value = never.  (Round 3 measured a fork for all stages with that round's kernels and lost, profiles/r04_notes.md.)  One internal stream + two events; under hipGraph capture the pattern becomes a fork / join
 // inside the block.  The first use must not be inside a capture (stream creation): every caller here warms up eagerly.
 struct AuxCtx {
-    hipStream_t s;
-    hipEvent_t fork, join;
+    hipStream_t s, s2;               // s2: the 2-D block's grad_input stream (lka2d_cl_backward)
+    hipEvent_t fork, join, fork2, join2;
     bool ok;
 };
 AuxCtx &aux_ctx()
@@ -589,7 +589,8 @@ AuxCtx &aux_ctx()
         AuxCtx x;
         memset(&x, 0, sizeof(x));
         x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+               hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess && hipStreamCreateWithFlags(&x.s2, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&x.fork2, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&x.join2, hipEventDisableTiming) == hipSuccess;
         return x;
     }();
     return c;
@@ -810,6 +811,23 @@ int lka2d_cl_backward(const void *x_, const dlka_lka2d_params *p, const void *gy
 #if !defined(HIPEMU)
     { const char *e = getenv("DLKA_LKA2D_FORK"); fork2d = !(e && e[0] == '0') && aux_ctx().ok; }
 #endif
+    // ... and each depthwise deformable conv's grad_input (the pass's largest kernel) beside its grad_offset / weight-gradient kernel on a second internal stream:
+    // fork in front of the pair, join in front of the offset net's data gradient, which adds grad_input (DLKA_LKA2D_FORK=1: the weight gradients only)
+    bool forkgx = fork2d;
+#if !defined(HIPEMU)
+    { const char *e = getenv("DLKA_LKA2D_FORK"); if (e && e[0] == '1') forkgx = false; }
+#endif
+    hipStream_t gst = forkgx ? aux_ctx().s2 : nullptr;
+    auto fork_gx = [&]() -> int {
+        if (!forkgx) return DLKA_OK;
+        AuxCtx &ax = aux_ctx();
+        return (hipEventRecord(ax.fork2, st) == hipSuccess && hipStreamWaitEvent(ax.s2, ax.fork2, 0) == hipSuccess) ? DLKA_OK : DLKA_ERR_LAUNCH;
+    };
+    auto join_gx = [&]() -> int {
+        if (!forkgx) return DLKA_OK;
+        AuxCtx &ax = aux_ctx();
+        return (hipEventRecord(ax.join2, ax.s2) == hipSuccess && hipStreamWaitEvent(st, ax.join2, 0) == hipSuccess) ? DLKA_OK : DLKA_ERR_LAUNCH;
+    };
     hipStream_t wst = fork2d ? aux_ctx().s : st;
     auto fork_to_aux = [&]() -> int {
         if (!fork2d) return DLKA_OK;
@@ -840,17 +858,21 @@ int lka2d_cl_backward(const void *x_, const dlka_lka2d_params *p, const void *gy
     fill_ddw(d, G, 7, 9, 3);
     d.act_bf16 = bf;
     d.in = t1; d.off = o7; d.wp = PW.dw7; d.g = gt2; d.gx = gta; d.goff = goff; d.part = part_dw;
-    DLKA_TRY(launch_cl_ddw2d_bwd(d, (float *)gr->conv_spatial_w, st));
+    DLKA_TRY(fork_gx());
+    DLKA_TRY(launch_cl_ddw2d_bwd(d, (float *)gr->conv_spatial_w, st, gst));
     DLKA_TRY(fork_to_aux());
     DLKA_TRY(dense_backward_weight(G.off7, t1, goff, 1, (float *)gr->conv_spatial_offset_w, (float *)gr->conv_spatial_offset_b, part_o7, wst, &fb.j[fb.njobs++]));
+    DLKA_TRY(join_gx());
     DLKA_TRY(dense_backward_data(G.off7, goff, 1, N0, gt1, PW.o7_b, 3, gta, st, nullptr, nullptr, bf && split7, false, bf != 0, bf ? gh : nullptr));   // gt1 = gta + offnet7^T goff
     // conv0 = DeformConv(5x5): t1 = DDW5(a, o5 = offnet5(a))
     fill_ddw(d, G, 5, 2, 1);
     d.act_bf16 = bf;
     d.in = a; d.off = o5; d.wp = PW.dw5; d.g = gt1; d.gx = gaa; d.goff = goff5; d.part = part_dw;
-    DLKA_TRY(launch_cl_ddw2d_bwd(d, (float *)gr->conv0_w, st));
+    DLKA_TRY(fork_gx());
+    DLKA_TRY(launch_cl_ddw2d_bwd(d, (float *)gr->conv0_w, st, gst));
     DLKA_TRY(fork_to_aux());
     DLKA_TRY(dense_backward_weight(G.off5, a, goff5, 1, (float *)gr->conv0_offset_w, (float *)gr->conv0_offset_b, part_o5, wst, &fb.j[fb.njobs++]));
+    DLKA_TRY(join_gx());
     if (bf && split5) DLKA_TRY(launch_zero(gh, G.E * 4, st));
     DLKA_TRY(dense_backward_data(G.off5, goff5, 1, N0, gab, PW.o5_b, 3, gaa, st, nullptr, nullptr, bf && split5, false, bf != 0, bf ? gh : nullptr));   // gab = gaa + offnet5^T goff
     // a = GELU(h) feeds the gate and conv0: gh = (ga1 + gab) * gelu'(h)

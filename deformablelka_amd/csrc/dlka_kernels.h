@@ -97,7 +97,7 @@ int cl_deform_goff_ccsplit(const DeformBwdArgs &a);
 int cl_ddw2d_supported(int C);
 size_t cl_ddw2d_part_floats(int M, int K, int C);
 int launch_cl_ddw2d_fwd(const DwArgs2d &d, hipStream_t st);
-int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st);
+int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st, hipStream_t gx_st = nullptr);
 // the 2-D D-LKA block on the channels-last kernels (dlka_capi_cl.hip); NCHW in / out, transposed inside
 int lka2d_cl_supported(int B, int C, int H, int W, int dtype);
 size_t lka2d_cl_saved_bytes(int B, int C, int H, int W, int dtype);
