@@ -662,3 +662,59 @@ def test_conv_brick_forward_stage0(monkeypatch):
     y_igemm = ops.conv3d_forward_cl(x, w, bias, 1, 1, 1, out_planar=True)
     assert lib.dlka_conv_brick_launch_count() == n1
     assert (y_brick - y_igemm).abs().max().item() <= 2e-6 * y_igemm.abs().max().item()
+
+
+def test_stack_grad_input_fork_equals_one_stream(monkeypatch):
+    """DLKABlockStack's data-chain pass runs the deformable conv's grad_input on the library's internal stream beside grad_offset (fork / join inside the block, also under
+    hipGraph capture).  Same kernels, same inputs: every gradient of a three-stage stack equals the one-stream run (DLKA_GX_FORK_MIN_ROWS=huge) up to the order of the few
+    fp32 global atomics (far samples) — eager and replayed from a graph."""
+    from deformablelka_amd.stack import DLKABlockStack
+    stages = ((32, (8, 8, 8), 3), (64, (4, 4, 4), 2), (128, (4, 4, 4), 2))
+    res = {}
+    for mode, val in (("one", "1000000000"), ("fork", "0")):
+        monkeypatch.setenv("DLKA_GX_FORK_MIN_ROWS", val)
+        st = DLKABlockStack(2, stages=stages, device="cuda:0", seed=5)
+        for _ in range(3):
+            st.forward_backward()
+        torch.cuda.synchronize()
+        res[mode] = [g.clone() for b in st.blocks for g in b.grads] + [b.gx.clone() for b in st.blocks]
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            st.forward_backward()
+        g.replay()
+        torch.cuda.synchronize()
+        res[mode + "_graph"] = [g_.clone() for b in st.blocks for g_ in b.grads] + [b.gx.clone() for b in st.blocks]
+    for mode in ("fork", "one_graph", "fork_graph"):
+        for a_, c_ in zip(res["one"], res[mode]):
+            assert torch.isfinite(c_).all()
+            scale = max(float(a_.abs().max()), 1e-6)
+            assert float((a_ - c_).abs().max()) <= 2e-3 * scale, mode   # atomics order only
+
+
+@pytest.mark.parametrize("C,hw", [(96, 56), (192, 28)])
+def test_lka2d_backward_forks_equal_one_stream(C, hw, monkeypatch):
+    """The 2-D block's backward with its two internal streams (each depthwise deformable conv's grad_input beside its grad_offset kernel; the offset nets' weight gradients
+    beside the data chain) against the same pass on one stream (DLKA_LKA2D_FORK=0): every gradient equal up to atomics order — at a shape of each grad_input generation."""
+    import deformablelka_amd as dk
+    from oracle import blocks
+    torch.manual_seed(3)
+    m = dk.deformable_LKA_Attention(C)
+    blocks.randomize_offsets_(m, std=0.03)
+    m = m.to(DEV)
+    x = torch.randn(4, C, hw, hw, device=DEV, requires_grad=True)
+    gy = torch.randn(4, C, hw, hw, device=DEV)
+    y = m(x)   # ONE forward pass: the three backward passes below share its saved offsets (a second forward could flip a sampling cell through atomics order)
+    leaves = [x] + list(m.parameters())
+    res = {}
+    for mode in ("0", "1", None):
+        if mode is None:
+            monkeypatch.delenv("DLKA_LKA2D_FORK", raising=False)
+        else:
+            monkeypatch.setenv("DLKA_LKA2D_FORK", mode)
+        res[mode] = [g.clone() for g in torch.autograd.grad(y, leaves, gy, retain_graph=True)]
+        torch.cuda.synchronize()
+    for mode in ("1", None):
+        for a_, c_ in zip(res["0"], res[mode]):
+            assert torch.isfinite(c_).all()
+            scale = max(float(a_.abs().max()), 1e-6)
+            assert float((a_ - c_).abs().max()) <= 2e-3 * scale, mode
