@@ -5,14 +5,16 @@
 // Why a kernel of its own.  cl_conv_wave_kernel<2, 0, 1, 2, 2> fetches its A operand — 16 dwords from 16 planes per lane and (tap, chunk) unit — from
 // global memory 27 times over, once per tap: in-situ ablations of that kernel (profiles/r06_notes.md) put 45 of its 91 us at 32^3 on that fetch
 // alone (split arithmetic 9, the matrix cores 6, the weight records 7), the planar layout being the better of two bad choices (a channels-last copy
-// needs a quarter of the load instructions and four times the cache lines, profiles/r04_notes.md).  Here a workgroup owns 256 consecutive voxels
-// (TH rows of W at one depth) and stages their 3 x (TH + 2) x (W + 2) halo ONCE per 32-plane chunk in LDS — read coalesced along the planes' voxels,
-// split into its two bf16 terms there and then (once per element instead of once per tap), zero padding written as zeros — as
+// needs a quarter of the load instructions and four times the cache lines, profiles/r04_notes.md).  Here a workgroup owns a TD x TH x W tile of one
+// volume (8 waves: 2 x 4 x 32 voxels at the 32^3 stage) and stages the tile's (TD + 2) x (TH + 2) x (W + 2) halo ONCE per 32-plane chunk in LDS — read
+// coalesced along the planes' voxels, split into its two bf16 terms there and then (once per element instead of once per tap), zero padding written as
+// zeros — as
 //     brick[voxel][ hi: 32 x bf16 | lo: 32 x bf16 | 16 bytes of padding ]          144 bytes per voxel
 // so that the A operand of v_mfma_f32_32x32x16_bf16 for ANY tap is one 16-byte LDS read per term at a tap-dependent constant offset: no address
 // arithmetic, no bounds code, no conversion in the 27-tap loop (the 144-byte row pitch spreads eight lanes' 16-byte accesses over all banks).
-// The weights come as the two-term records cl_conv_wave_kernel reads (prep mode 1 | 8), one tap ahead, straight from L2.
+// The weights come as the two-term records cl_conv_wave_kernel reads (prep mode 1 | 8), through a register ring three taps deep, straight from L2.
 // Same products and the same fp32 accumulation as the kernel it replaces; the order of the sum over (tap, chunk) differs (chunks outer): rounding only.
+// Measured (one box, profiles/r06_notes.md): 91 -> 53 us, step 11.04 -> 10.72 ms.  The file also holds the FORWARD conv's brick kernel (cl_conv_brick3_kernel, below).
 #include <atomic>
 
 #include "cl_args.h"
