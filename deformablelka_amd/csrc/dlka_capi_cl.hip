@@ -560,7 +560,7 @@ SideCtx &side_ctx()
     static SideCtx c = [] {
         SideCtx x;
         memset(&x, 0, sizeof(x));
-        x.ok = false;   // a side stream for the weight gradients measured slower under graph replay at EVERY stage (fork / join cost): 1.70 vs 1.61 ms
+        x.ok = getenv("DLKA_SIDE_STREAM") != nullptr;   // (opt-in) a side stream for the weight gradients measured slower under graph replay at EVERY stage (fork / join cost): 1.70 vs 1.61 ms
                         // per block at stage 0 (r01), 0.479 vs 0.414 ms at stage 2 and 0.433 vs 0.381 ms at stage 3 (r03); the code path stays for reference
         if (x.ok && hipStreamCreateWithFlags(&x.side, hipStreamNonBlocking) != hipSuccess) x.ok = false;
         for (int k = 0; k < 8 && x.ok; ++k)
