@@ -591,6 +591,7 @@ AuxCtx &aux_ctx()
         x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
                hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess && hipStreamCreateWithFlags(&x.s2, hipStreamNonBlocking) == hipSuccess &&
                hipEventCreateWithFlags(&x.fork2, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&x.join2, hipEventDisableTiming) == hipSuccess;
+        if (!x.ok) (void)hipGetLastError();   // (e.g. first use inside a stream capture: no fork then, and no stale error for the next launch check to find)
         return x;
     }();
     return c;
