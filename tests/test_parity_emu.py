@@ -595,13 +595,13 @@ def test_depthwise_lds_brick_kernel(monkeypatch):
     assert lib.dlka_dwconv_lds_launch_count() == n3
 
 
-@pytest.mark.parametrize("case", [(1, 32, (2, 16, 16), None), (1, 32, (2, 16, 16), "8"), (2, 32, (3, 8, 32), None), (1, 64, (2, 32, 8), None), (1, 32, (4, 4, 32), "4"), (1, 32, (2, 8, 32), "42"), (2, 64, (2, 8, 16), "4s")])
+@pytest.mark.parametrize("case", [(1, 32, (2, 8, 16), None), (1, 32, (2, 8, 16), "4"), (1, 32, (3, 8, 32), None), (1, 64, (2, 32, 8), None), (1, 32, (4, 2, 32), "4"), (1, 32, (2, 8, 32), "42"), (2, 64, (2, 4, 16), "4s")])
 def test_conv_brick_data_gradient(case, monkeypatch):
     """cl_conv_brick_kernel (the offset-predict conv's data gradient from an LDS brick: planar grad_out staged once per 32-plane chunk, split into its bf16 terms
     while being staged, 27 taps read from LDS) against the fp64 conv — and against the kernel it replaces at the wide stage (same products, other summation order).
     DLKA_CONV_BRICK_MIN_WG=1 lets emulator-sized volumes take it (real use: >= 128 workgroups of 256 voxels); the launch counter proves which kernel ran.
-    Cases: 4-wave workgroups on 2 x 4 x 16 tiles; the same volume on 8-wave workgroups (one 16 x 16 plane each); an odd depth (8-wave tiles of 8 rows of 32, two
-    volumes); two output column tiles with W = 8; the stage-0 tiling (4 waves, 2 x 2 x 32); 4 waves of two row tiles each (8 rows of 32); 4-wave tiles with the chunk split, two column tiles, two volumes."""
+    Cases: the default 8-wave workgroups on a 2 x 8 x 16 tile; the same volume on 4-wave workgroups (2 x 4 x 16 tiles); an odd depth (8-wave tiles of 1 x 8 x 32);
+    two output column tiles with W = 8; the stage-0 4-wave tiling (2 x 2 x 32); 4 waves of two row tiles each (8 rows of 32); 4-wave tiles with the chunk split, two column tiles, two volumes."""
     from deformablelka_amd import _lib, ops
     B, C, dims, waves = case
     lib = _lib.get_lib()
