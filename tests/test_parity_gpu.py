@@ -666,24 +666,31 @@ def test_conv_brick_forward_stage0(monkeypatch):
 
 def test_stack_grad_input_fork_equals_one_stream(monkeypatch):
     """DLKABlockStack's data-chain pass runs the deformable conv's grad_input on the library's internal stream beside grad_offset (fork / join inside the block, also under
-    hipGraph capture).  Same kernels, same inputs: every gradient of a three-stage stack equals the one-stream run (DLKA_GX_FORK_MIN_ROWS=huge) up to the order of the few
-    fp32 global atomics (far samples) — eager and replayed from a graph."""
+    hipGraph capture).  Same kernels, same saved activations — ONE forward pass, so that no sampling cell can move between the runs —: every gradient of a three-stage stack
+    equals the one-stream backward pass (DLKA_GX_FORK_MIN_ROWS=huge) up to the order of the few fp32 global atomics (far samples), eager and replayed from a graph."""
     from deformablelka_amd.stack import DLKABlockStack
     stages = ((32, (8, 8, 8), 3), (64, (4, 4, 4), 2), (128, (4, 4, 4), 2))
+    st = DLKABlockStack(2, stages=stages, device="cuda:0", seed=5)
+    for _ in range(3):   # the first pass records the fold plan; the later ones run it sealed
+        st.forward_backward()
+    st.forward()
+    torch.cuda.synchronize()
     res = {}
+
+    def grads():
+        return [g.clone() for b in st.blocks for g in b.grads] + [b.gx.clone() for b in st.blocks]
+
     for mode, val in (("one", "1000000000"), ("fork", "0")):
         monkeypatch.setenv("DLKA_GX_FORK_MIN_ROWS", val)
-        st = DLKABlockStack(2, stages=stages, device="cuda:0", seed=5)
-        for _ in range(3):
-            st.forward_backward()
+        st.backward()
         torch.cuda.synchronize()
-        res[mode] = [g.clone() for b in st.blocks for g in b.grads] + [b.gx.clone() for b in st.blocks]
+        res[mode] = grads()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            st.forward_backward()
+            st.backward()
         g.replay()
         torch.cuda.synchronize()
-        res[mode + "_graph"] = [g_.clone() for b in st.blocks for g_ in b.grads] + [b.gx.clone() for b in st.blocks]
+        res[mode + "_graph"] = grads()
     for mode in ("fork", "one_graph", "fork_graph"):
         for a_, c_ in zip(res["one"], res[mode]):
             assert torch.isfinite(c_).all()
