@@ -4,6 +4,9 @@
 // general NCDHW entry points (dlka_capi.hip) instead — still HIP, never a CPU fallback.
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "cl_args.h"
 #include "dlka_kernels.h"
 
@@ -583,18 +586,35 @@ struct AuxCtx {
     hipEvent_t fork, join, fork2, join2;
     bool ok;
 };
-AuxCtx &aux_ctx()
+// Created at the first call that wants a fork and is NOT inside a stream capture (creating streams there is not allowed and would invalidate the capture: such a call
+// simply keeps everything on the caller's stream, and a later eager call creates the context).  aux_ready(st) == true <=> aux_ctx() is usable.
+static AuxCtx g_aux;
+static std::atomic<int> g_aux_state{0};   // 0: not tried yet, 1: usable, -1: creation failed (no forks in this process)
+static std::mutex g_aux_mu;
+AuxCtx &aux_ctx() { return g_aux; }
+bool aux_ready(hipStream_t st)
 {
-    static AuxCtx c = [] {
-        AuxCtx x;
+#if defined(HIPEMU)
+    (void)st;
+    return false;   // (no streams on the CPU test backend)
+#else
+    const int s0 = g_aux_state.load(std::memory_order_acquire);
+    if (s0) return s0 > 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (cs != hipStreamCaptureStatusNone) return false;
+    std::lock_guard<std::mutex> lk(g_aux_mu);
+    if (g_aux_state.load(std::memory_order_acquire) == 0) {
+        AuxCtx &x = g_aux;
         memset(&x, 0, sizeof(x));
         x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
                hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess && hipStreamCreateWithFlags(&x.s2, hipStreamNonBlocking) == hipSuccess &&
                hipEventCreateWithFlags(&x.fork2, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&x.join2, hipEventDisableTiming) == hipSuccess;
-        if (!x.ok) (void)hipGetLastError();   // (e.g. first use inside a stream capture: no fork then, and no stale error for the next launch check to find)
-        return x;
-    }();
-    return c;
+        if (!x.ok) (void)hipGetLastError();   // (no stale error for the next launch check to find)
+        g_aux_state.store(x.ok ? 1 : -1, std::memory_order_release);
+    }
+    return g_aux_state.load(std::memory_order_acquire) > 0;
+#endif
 }
 // (phase 0 = the one-call backward of the nn.Module path: there the fork measured SLOWER — wrapper-block stack 100.5 against 102.5 volumes/s, full net 68.8 against 69.8 — so by
 //  default only the stack engine's data-chain pass, phase 1, forks; the environment variable, when set, rules both)
@@ -810,7 +830,7 @@ int lka2d_cl_backward(const void *x_, const dlka_lka2d_params *p, const void *gy
     // profiles/r06_notes.md.
     bool fork2d = false;
 #if !defined(HIPEMU)
-    { const char *e = getenv("DLKA_LKA2D_FORK"); fork2d = !(e && e[0] == '0') && aux_ctx().ok; }
+    { const char *e = getenv("DLKA_LKA2D_FORK"); fork2d = !(e && e[0] == '0') && aux_ready(st); }
 #endif
     // ... and each depthwise deformable conv's grad_input (the pass's largest kernel) beside its grad_offset / weight-gradient kernel on a second internal stream:
     // fork in front of the pair, join in front of the offset net's data gradient, which adds grad_input (DLKA_LKA2D_FORK=1: the weight gradients only)
@@ -1549,9 +1569,9 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
         DLKA_P2(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
                                 &fb.j[fb.njobs++]));
     bool gx_forked = false;
-    if (phase != 2 && gx_fork_wanted((long)G.dcn.M, phase)) {   // grad_input on the internal stream, beside grad_offset (see aux_ctx)
+    if (phase != 2 && gx_fork_wanted((long)G.dcn.M, phase) && aux_ready(st)) {   // grad_input on the internal stream, beside grad_offset (see aux_ctx)
         AuxCtx &ax = aux_ctx();
-        if (ax.ok && hipEventRecord(ax.fork, st) == hipSuccess && hipStreamWaitEvent(ax.s, ax.fork, 0) == hipSuccess) {
+        if (hipEventRecord(ax.fork, st) == hipSuccess && hipStreamWaitEvent(ax.s, ax.fork, 0) == hipSuccess) {
             DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, ax.s, nullptr, true, false, 0, nullptr, PW.dcn_b16));
             if (hipEventRecord(ax.join, ax.s) != hipSuccess) return DLKA_ERR_LAUNCH;
             gx_forked = true;
