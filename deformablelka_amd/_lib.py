@@ -149,6 +149,8 @@ SIGNATURES = {
     "dlka_deform_dwconv2d_forward_cl": (c_int, [c_void_p] * 5 + [c_size_t, _G, c_int, c_void_p]),
     "dlka_deform_dwconv2d_backward_cl": (c_int, [c_void_p] * 8 + [c_size_t, _G, c_int, c_void_p]),
     "dlka_lka3d_force_wgrad_gather": (c_int, [c_int]),
+    "dlka_fork_stats": (c_int, [c_int, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64)]),
+    "dlka_env_refresh": (None, []),
     "dlka_dwconv_lds_launch_count": (ctypes.c_long, []),
     "dlka_conv_brick_launch_count": (ctypes.c_long, []),
     "dlka_lka3d_tokens_supported_v": (c_int, [c_int] * 7),
@@ -237,6 +239,11 @@ def require_device(*tensors) -> None:
 def stream_ptr(t: torch.Tensor):
     if _test_backend:
         return None
+    # The library launches on the CURRENT device (HIP's rule) with the handles of that device (include/dlka.h: fork contexts are per device): a tensor of
+    # another device is a caller error that must not reach a launch.  nn.DataParallel replicas and autograd's device threads run with their device current.
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"deformablelka_amd: tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()} — "
+                           f"call under torch.cuda.device({t.device.index})")
     return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 

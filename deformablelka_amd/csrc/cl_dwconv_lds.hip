@@ -316,6 +316,7 @@ bool cl_dwconv_lds_selected(const DwArgs &a, int kw, int dil_w)
 }
 
 size_t cl_dwconv_blk_floats(int B, int C, int D, int H, int W, int dil) { return dw_blk_floats(B, C, D, H, W, dil); }
+int cl_dwconv_lds_mode() { return dw_lds_mode(); }
 
 }  // namespace dlka
 

@@ -28,6 +28,15 @@ struct Carver {
         used += n;
         return r;
     }
+    // optional area: nullptr (and the carver stays valid) when `want` is false or the buffer has no room for it
+    void *take_opt(size_t n, bool want)
+    {
+        n = align256(n);
+        if (!want || !base || used > cap || used + n > cap) return nullptr;
+        void *r = base + used;
+        used += n;
+        return r;
+    }
     bool ok() const { return used <= cap; }
 };
 
@@ -159,13 +168,19 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
     int splits = dense_backward_data_splits(s, epi);
     // cl_conv_brick.hip: no tap split; volumes too small for a workgroup per tile split the plane chunks instead (fp32 atomics into a zeroed buffer, like a tap split)
     const int bsplit = gout_planar ? cl_conv_brick_split(a) : 0;
+    bool brick_only = false;   // the chunk split alone made this an accumulating launch: the caller's zero-fill decision (dense_backward_data_splits) does not know
     if (bsplit == 1) splits = 1;
-    else if (bsplit > 1 && splits <= 1) splits = 2;   // (only its being > 1 matters below: the zero-fill / fp32-accumulation route)
+    else if (bsplit > 1 && splits <= 1) { splits = 2; brick_only = true; }   // (only its being > 1 matters below: the zero-fill / fp32-accumulation route)
     if (s.act_bf16 && splits > 1) {
         if (!acc32) return DLKA_ERR_WORKSPACE;
+        if (brick_only) DLKA_TRY(launch_zero(acc32, (size_t)s.M * s.Cin * 4, st));
         a.out = acc32; a.out_zeroed = 1;
         DLKA_TRY(launch_cl_igemm(gout_planar ? 2 : 0, 0, a, splits, st));
         return launch_cast_from_f32<bf16_t>(acc32, reinterpret_cast<bf16_t *>(gx), (long)s.M * s.Cin, st);
+    }
+    if (brick_only) {   // fp32 atomics into `gx`: zero it here, whatever the caller said
+        DLKA_TRY(launch_zero(gx, (size_t)s.M * s.Cin * 4, st));
+        a.out_zeroed = 1;
     }
     return launch_cl_igemm(gout_planar ? 2 : 0, 0, a, splits, st);
 }
@@ -423,11 +438,15 @@ static SameConv dw_conv(int B, int C, int D, int H, int W, const int *k, const i
 
 // DLKA_WGRAD_GATHER: the deformable weight gradient gathers for itself instead of streaming the samples the grad_offset kernel stored (A/B runs, the
 // hand-over parity test).  Read ONCE; afterwards only dlka_lka3d_force_wgrad_gather changes it.
-static int g_wgrad_gather = -1;
+static std::atomic<int> g_wgrad_gather{-1};
 static bool wgrad_gather()
 {
-    if (g_wgrad_gather < 0) g_wgrad_gather = getenv("DLKA_WGRAD_GATHER") != nullptr ? 1 : 0;
-    return g_wgrad_gather != 0;
+    int v = g_wgrad_gather.load(std::memory_order_acquire);
+    if (v < 0) {
+        int want = getenv("DLKA_WGRAD_GATHER") != nullptr ? 1 : 0;
+        if (g_wgrad_gather.compare_exchange_strong(v, want, std::memory_order_acq_rel)) v = want;   // (lost the race: v holds the winner's value)
+    }
+    return v != 0;
 }
 
 struct TokGeoms {
@@ -476,7 +495,6 @@ struct TokGeoms {
         const size_t n = (size_t)dcn.K * dcn.M * dcn.Cin;   // elements of the activation storage type (SB bytes each)
         return (n * SB < ((size_t)1 << 31)) ? n * SB / 4 : 0;
     }
-    size_t samp_floats() const { return wgrad_gather() ? 0 : samp_capacity_floats(); }
     // prepared weights, kept in `saved` from the forward to the backward call (floats)
     size_t pw_floats() const { return (size_t)pw.Cin * pw.Cin; }
     size_t offc_floats() const { return dense_wp_floats(offc); }
@@ -548,84 +566,238 @@ int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_para
     return launch_cl_prep_batch(pb, st);
 }
 
-// ---- fork / join of the backward pass ------------------------------------------------------------------------------------
-// The weight gradients of a block only READ what the data-gradient chain produces; they run on an internal side stream,
-// forked and joined with events, so that the two chains overlap (also under hipGraph capture, where the event pattern
-// becomes a fork / join in the graph).  Opt-in with DLKA_SIDE_STREAM=1.
-struct SideCtx {
-    hipStream_t side;
-    hipEvent_t ev[8];
-    bool ok;
+// ---- fork / join inside the backward passes -----------------------------------------------------------------------------
+// Three places let independent kernels of ONE call run beside each other on library-internal streams (events fork from and join back into the caller's stream; under
+// hipGraph capture the pattern becomes a fork / join in the graph):
+//   * grad_input of the 3-D deformable conv beside grad_offset (stream `s`; the stack engine's data-chain pass, see gx_fork_wanted),
+//   * the 2-D block's offset-net weight gradients (`s`) and its depthwise deformable convs' grad_input (`s2`) beside the data chain (lka2d_cl_backward),
+//   * (opt-in, DLKA_SIDE_STREAM=1) the 3-D block's weight gradients on `side` in the one-call backward — measured slower under graph replay at EVERY stage (fork / join
+//     cost): 1.70 vs 1.61 ms per block at stage 0 (r01), 0.479 vs 0.414 ms at stage 2 and 0.433 vs 0.381 ms at stage 3 (r03); the code path stays for reference.
+// Why the pairs pay (profiles/r06_notes.md, `r7d`, `r7h`, `r7i`): at the 32^3 stage grad_input beside grad_offset gains 35 us per block (the LDS-window scatter kernel runs
+// two workgroups per CU at 128 registers, the gather kernel three waves per SIMD with little LDS — they fill each other's holes); forking EVERY block measured best in the
+// whole step on three boxes (fp32 10.616 / 10.597 / 10.518 ms for never / wide stage only / always).
+//
+// CONTRACT.  The streams and events a call forks onto are a ForkCtx LEASED for the duration of that call from a per-DEVICE pool:
+//   * per device: a context is created on the device the caller's stream belongs to (== the current device, or the call does not fork at all), so a call under
+//     nn.DataParallel on device k never touches a handle of device 0 (2D/trainer_MaxViT_deform_LKA.py:107-108 wraps the model so);
+//   * per caller: two host threads (each on its own stream) inside the library at the same time hold DIFFERENT contexts — no event is shared between concurrent calls;
+//     a context returns to the pool when its call returns (everything it forked has been joined into the caller's stream by then, so stream order carries the
+//     dependency on to whoever leases it next);
+//   * capture: contexts are never CREATED inside a stream capture (a capturing call finds one in the pool or keeps everything on the caller's stream); a context whose
+//     streams were pulled into a capture is handed only to calls of that same capture until the capture has ended;
+//   * errors: a lease that has forked and is destroyed without its join (early return on a failed launch) still joins its streams into the caller's, so neither
+//     an eager caller nor a capture is left with an unjoined stream.
+#if !defined(HIPEMU)
+struct ForkCtx {
+    int dev;
+    hipStream_t s, s2, side;
+    hipEvent_t fork, join, fork2, join2;
+    hipEvent_t ev[8];                 // `side` only
+    unsigned long long cap_id;        // != 0: last used inside the stream capture with this id
+    ForkCtx *next;
 };
+constexpr int FORK_MAX_DEV = 64;
+static std::mutex g_fork_mu;
+static ForkCtx *g_fork_free[FORK_MAX_DEV];
+static std::atomic<int> g_fork_failed{0};      // creation failed once: no forks in this process
+static std::atomic<long> g_fork_created_dev[FORK_MAX_DEV], g_fork_leases_dev[FORK_MAX_DEV];   // diagnostics (dlka_fork_stats)
 
-SideCtx &side_ctx()
+static ForkCtx *fork_ctx_create(int dev, bool with_side)
 {
-    static SideCtx c = [] {
-        SideCtx x;
-        memset(&x, 0, sizeof(x));
-        x.ok = getenv("DLKA_SIDE_STREAM") != nullptr;   // (opt-in) a side stream for the weight gradients measured slower under graph replay at EVERY stage (fork / join cost): 1.70 vs 1.61 ms
-                        // per block at stage 0 (r01), 0.479 vs 0.414 ms at stage 2 and 0.433 vs 0.381 ms at stage 3 (r03); the code path stays for reference
-        if (x.ok && hipStreamCreateWithFlags(&x.side, hipStreamNonBlocking) != hipSuccess) x.ok = false;
-        for (int k = 0; k < 8 && x.ok; ++k)
-            if (hipEventCreateWithFlags(&x.ev[k], hipEventDisableTiming) != hipSuccess) x.ok = false;
-        return x;
-    }();
+    ForkCtx *c = new ForkCtx();
+    memset(c, 0, sizeof(*c));
+    c->dev = dev;
+    bool ok = hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&c->s2, hipStreamNonBlocking) == hipSuccess;
+    hipEvent_t *evs[] = {&c->fork, &c->join, &c->fork2, &c->join2};
+    for (hipEvent_t *e : evs) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    if (ok && with_side) {
+        ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; k < 8 && ok; ++k) ok = hipEventCreateWithFlags(&c->ev[k], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {   // (no stale error for the next launch check to find; the handles created so far are released)
+        (void)hipGetLastError();
+        if (c->s) (void)hipStreamDestroy(c->s);
+        if (c->s2) (void)hipStreamDestroy(c->s2);
+        if (c->side) (void)hipStreamDestroy(c->side);
+        for (hipEvent_t *e : evs) if (*e) (void)hipEventDestroy(*e);
+        for (int k = 0; k < 8; ++k) if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
+        (void)hipGetLastError();
+        delete c;
+        return nullptr;
+    }
+    g_fork_created_dev[dev].fetch_add(1, std::memory_order_relaxed);
     return c;
 }
 
-// grad_input of the deformable conv BESIDE grad_offset: the two kernels are independent (both read grad_out, the offsets and the column weights; one scatters into
-// gta, the other writes goff and the samples), and they are the two largest of the block.  Measured per stage (profiles/r06_notes.md, `r7d`): at the 32^3 stage the
-// pair gains 35 us per block (stage-0 stack 5.377 -> 5.166 ms: the LDS-window scatter kernel runs two workgroups per CU at 128 registers, the gather kernel three waves
-// per SIMD with little LDS — they fill each other's holes), at the smaller stages the fork / join costs more than it gains (2.645 -> 2.651, 1.994 -> 2.014, 0.888 ->
-// 0.905 ms) when a stage is timed ALONE — but in the whole 21-block step, which is the metric, forking EVERY block measured best on three boxes (fp32 10.616 / 10.597 /
-// 10.518 ms for never / wide stage only / always; bf16 9.920 / 9.864 / 9.755): the default is always.  DLKA_GX_FORK_MIN_ROWS (read per call) = row count from which a call
-// forks; a huge value = never.  (Round 3 measured a fork for all stages with that round's kernels and lost, profiles/r04_notes.md.)  One internal stream + two events; under hipGraph capture the pattern becomes a fork / join
-// inside the block.  The first use must not be inside a capture (stream creation): every caller here warms up eagerly.
-struct AuxCtx {
-    hipStream_t s, s2;               // s2: the 2-D block's grad_input stream (lka2d_cl_backward)
-    hipEvent_t fork, join, fork2, join2;
-    bool ok;
-};
-// Created at the first call that wants a fork and is NOT inside a stream capture (creating streams there is not allowed and would invalidate the capture: such a call
-// simply keeps everything on the caller's stream, and a later eager call creates the context).  aux_ready(st) == true <=> aux_ctx() is usable.
-static AuxCtx g_aux;
-static std::atomic<int> g_aux_state{0};   // 0: not tried yet, 1: usable, -1: creation failed (no forks in this process)
-static std::mutex g_aux_mu;
-AuxCtx &aux_ctx() { return g_aux; }
-bool aux_ready(hipStream_t st)
+static bool side_stream_wanted()
 {
-#if defined(HIPEMU)
-    (void)st;
-    return false;   // (no streams on the CPU test backend)
-#else
-    const int s0 = g_aux_state.load(std::memory_order_acquire);
-    if (s0) return s0 > 0;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (cs != hipStreamCaptureStatusNone) return false;
-    std::lock_guard<std::mutex> lk(g_aux_mu);
-    if (g_aux_state.load(std::memory_order_acquire) == 0) {
-        AuxCtx &x = g_aux;
-        memset(&x, 0, sizeof(x));
-        x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess && hipStreamCreateWithFlags(&x.s2, hipStreamNonBlocking) == hipSuccess &&
-               hipEventCreateWithFlags(&x.fork2, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&x.join2, hipEventDisableTiming) == hipSuccess;
-        if (!x.ok) (void)hipGetLastError();   // (no stale error for the next launch check to find)
-        g_aux_state.store(x.ok ? 1 : -1, std::memory_order_release);
+    static const bool on = getenv("DLKA_SIDE_STREAM") != nullptr;
+    return on;
+}
+
+// RAII lease of one ForkCtx for one library call on the caller's stream `st`.  ok() == false: the call keeps everything on `st`.
+class ForkLease {
+    ForkCtx *c_ = nullptr;
+    hipStream_t st_;
+    unsigned long long cap_ = 0;
+    bool open1_ = false, open2_ = false, open_side_ = false;
+    int nev_ = 0;
+
+    static bool capture_of(hipStream_t s, unsigned long long *id)
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        unsigned long long i = 0;
+        if (hipStreamGetCaptureInfo(s, &cs, &i) != hipSuccess) { (void)hipGetLastError(); *id = 0; return false; }
+        *id = cs == hipStreamCaptureStatusActive ? (i ? i : ~0ull) : 0;
+        return cs == hipStreamCaptureStatusNone || cs == hipStreamCaptureStatusActive;
     }
-    return g_aux_state.load(std::memory_order_acquire) > 0;
+
+public:
+    ForkLease(hipStream_t st, bool want) : st_(st)
+    {
+        if (!want || g_fork_failed.load(std::memory_order_acquire)) return;
+        int dev = -1, sdev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FORK_MAX_DEV) { (void)hipGetLastError(); return; }
+        if (st && hipStreamGetDevice(st, &sdev) == hipSuccess && sdev != dev) return;   // a foreign stream: the launches themselves will say so; no fork
+        (void)hipGetLastError();
+        if (!capture_of(st, &cap_)) return;
+        const bool with_side = side_stream_wanted();
+        {
+            std::lock_guard<std::mutex> lk(g_fork_mu);
+            ForkCtx **pp = &g_fork_free[dev];
+            while (*pp) {
+                ForkCtx *c = *pp;
+                bool usable = true;
+                if (c->cap_id) {   // pulled into a capture by an earlier call: is that capture over by now, or is it this very capture?
+                    unsigned long long i1 = 0, i2 = 0, i3 = 0;
+                    const bool q = capture_of(c->s, &i1) && capture_of(c->s2, &i2) && (!c->side || capture_of(c->side, &i3));
+                    if (q && !i1 && !i2 && !i3) c->cap_id = 0;
+                    else usable = q && cap_ != 0 && cap_ == c->cap_id;
+                }
+                if (usable) { *pp = c->next; c->next = nullptr; c_ = c; break; }
+                pp = &c->next;
+            }
+        }
+        if (!c_ && cap_ == 0) {   // none free for this device: create one — never inside a capture
+            c_ = fork_ctx_create(dev, with_side);
+            if (!c_) g_fork_failed.store(1, std::memory_order_release);
+        }
+        if (c_) g_fork_leases_dev[dev].fetch_add(1, std::memory_order_relaxed);
+    }
+    ForkLease(const ForkLease &) = delete;
+    ForkLease &operator=(const ForkLease &) = delete;
+    ~ForkLease()
+    {
+        if (!c_) return;
+        // an early return between a fork and its join: join now, whatever the streams hold (best effort; the call is failing anyway)
+        if (open1_) (void)join(1);
+        if (open2_) (void)join(2);
+        if (open_side_) (void)side_join();
+        (void)hipGetLastError();
+        if (cap_) c_->cap_id = cap_;
+        std::lock_guard<std::mutex> lk(g_fork_mu);
+        c_->next = g_fork_free[c_->dev];
+        g_fork_free[c_->dev] = c_;
+    }
+    bool ok() const { return c_ != nullptr; }
+    // which: 1 = stream s (events fork / join), 2 = stream s2 (fork2 / join2).  fork() may be repeated before one join() (the stream then also sees the later work).
+    hipStream_t stream(int which) const { return !c_ ? st_ : which == 2 ? c_->s2 : c_->s; }
+    hipStream_t side() const { return c_ && c_->side ? c_->side : st_; }
+    bool has_side() const { return c_ && c_->side; }
+    int fork(int which)   // the internal stream may use what the caller's stream has produced so far
+    {
+        if (!c_) return DLKA_OK;
+        hipEvent_t e = which == 2 ? c_->fork2 : c_->fork;
+        if (hipEventRecord(e, st_) != hipSuccess || hipStreamWaitEvent(stream(which), e, 0) != hipSuccess) return DLKA_ERR_LAUNCH;
+        (which == 2 ? open2_ : open1_) = true;
+        return DLKA_OK;
+    }
+    int join(int which)   // the caller's stream waits for everything issued on the internal stream so far
+    {
+        if (!c_) return DLKA_OK;
+        bool &open = which == 2 ? open2_ : open1_;
+        if (!open) return DLKA_OK;
+        open = false;
+        hipEvent_t e = which == 2 ? c_->join2 : c_->join;
+        if (hipEventRecord(e, stream(which)) != hipSuccess || hipStreamWaitEvent(st_, e, 0) != hipSuccess) return DLKA_ERR_LAUNCH;
+        return DLKA_OK;
+    }
+    // `side` (DLKA_SIDE_STREAM): may use what the caller's stream has produced so far (up to 7 times per call)
+    int side_publish()
+    {
+        if (!has_side()) return DLKA_OK;
+        if (nev_ >= 7) return DLKA_ERR_UNSUPPORTED;
+        if (hipEventRecord(c_->ev[nev_], st_) != hipSuccess || hipStreamWaitEvent(c_->side, c_->ev[nev_], 0) != hipSuccess) return DLKA_ERR_LAUNCH;
+        ++nev_;
+        open_side_ = true;
+        return DLKA_OK;
+    }
+    int side_join()
+    {
+        if (!has_side() || !open_side_) return DLKA_OK;
+        open_side_ = false;
+        if (hipEventRecord(c_->ev[7], c_->side) != hipSuccess || hipStreamWaitEvent(st_, c_->ev[7], 0) != hipSuccess) return DLKA_ERR_LAUNCH;
+        return DLKA_OK;
+    }
+};
+
+#else   // HIPEMU: no streams on the CPU test backend — every lease is empty and the call stays on the caller's stream
+constexpr int FORK_MAX_DEV = 64;
+static std::atomic<long> g_fork_created_dev[FORK_MAX_DEV], g_fork_leases_dev[FORK_MAX_DEV];
+static bool side_stream_wanted() { return false; }
+class ForkLease {
+    hipStream_t st_;
+public:
+    ForkLease(hipStream_t st, bool) : st_(st) {}
+    bool ok() const { return false; }
+    hipStream_t stream(int) const { return st_; }
+    hipStream_t side() const { return st_; }
+    bool has_side() const { return false; }
+    int fork(int) { return DLKA_OK; }
+    int join(int) { return DLKA_OK; }
+    int side_publish() { return DLKA_OK; }
+    int side_join() { return DLKA_OK; }
+};
 #endif
+
+// Environment switches of the fork decisions, read ONCE (dlka_env_refresh() re-reads: tests and the A/B scripts toggle them in-process).
+struct ForkEnv {
+    bool gx_rows_set;
+    long gx_rows;       // DLKA_GX_FORK_MIN_ROWS
+    int lka2d_fork;     // DLKA_LKA2D_FORK: 0 = one stream, 1 = the offset nets' weight gradients only, 2 (unset) = + grad_input beside grad_offset
+};
+static std::mutex g_fork_env_mu;
+static ForkEnv g_fork_env;
+static std::atomic<int> g_fork_env_loaded{0};
+static void fork_env_load()
+{
+    std::lock_guard<std::mutex> lk(g_fork_env_mu);
+    ForkEnv e;
+    const char *r = getenv("DLKA_GX_FORK_MIN_ROWS");
+    e.gx_rows_set = r != nullptr;
+    e.gx_rows = r ? atol(r) : 0;
+    const char *f = getenv("DLKA_LKA2D_FORK");
+    e.lka2d_fork = !f ? 2 : f[0] == '0' ? 0 : f[0] == '1' ? 1 : 2;
+    g_fork_env = e;
+    g_fork_env_loaded.store(1, std::memory_order_release);
+}
+static ForkEnv fork_env()
+{
+    if (!g_fork_env_loaded.load(std::memory_order_acquire)) fork_env_load();
+    std::lock_guard<std::mutex> lk(g_fork_env_mu);
+    return g_fork_env;
 }
 // (phase 0 = the one-call backward of the nn.Module path: there the fork measured SLOWER — wrapper-block stack 100.5 against 102.5 volumes/s, full net 68.8 against 69.8 — so by
-//  default only the stack engine's data-chain pass, phase 1, forks; the environment variable, when set, rules both)
+//  default only the stack engine's data-chain pass, phase 1, forks; DLKA_GX_FORK_MIN_ROWS = row count from which a call forks (a huge value = never), when set, rules both)
 bool gx_fork_wanted(long rows, int phase)
 {
 #if defined(HIPEMU)
+    (void)rows; (void)phase;
     return false;   // (no streams on the CPU test backend)
 #else
-    const char *e = getenv("DLKA_GX_FORK_MIN_ROWS");
-    if (!e) return phase == 1;
-    return rows >= atol(e);
+    const ForkEnv e = fork_env();
+    if (!e.gx_rows_set) return phase == 1;
+    return rows >= e.gx_rows;
 #endif
 }
 
@@ -828,33 +1000,20 @@ int lka2d_cl_backward(const void *x_, const dlka_lka2d_params *p, const void *gy
     // activation, and nothing before the finalisation reads their partial sums: they run on the library's internal stream (aux_ctx) beside the data chain — fork behind
     // each depthwise deformable conv's backward, one join in front of the finalisation.  DLKA_LKA2D_FORK=0: one stream (A/B; read per call).  Measured in
     // profiles/r06_notes.md.
-    bool fork2d = false;
+    int fork_mode = 0;
 #if !defined(HIPEMU)
-    { const char *e = getenv("DLKA_LKA2D_FORK"); fork2d = !(e && e[0] == '0') && aux_ready(st); }
+    fork_mode = fork_env().lka2d_fork;
 #endif
+    ForkLease lease(st, fork_mode != 0);   // (joins whatever is still forked when a DLKA_TRY below returns early)
+    const bool fork2d = lease.ok();
     // ... and each depthwise deformable conv's grad_input (the pass's largest kernel) beside its grad_offset / weight-gradient kernel on a second internal stream:
     // fork in front of the pair, join in front of the offset net's data gradient, which adds grad_input (DLKA_LKA2D_FORK=1: the weight gradients only)
-    bool forkgx = fork2d;
-#if !defined(HIPEMU)
-    { const char *e = getenv("DLKA_LKA2D_FORK"); if (e && e[0] == '1') forkgx = false; }
-#endif
-    hipStream_t gst = forkgx ? aux_ctx().s2 : nullptr;
-    auto fork_gx = [&]() -> int {
-        if (!forkgx) return DLKA_OK;
-        AuxCtx &ax = aux_ctx();
-        return (hipEventRecord(ax.fork2, st) == hipSuccess && hipStreamWaitEvent(ax.s2, ax.fork2, 0) == hipSuccess) ? DLKA_OK : DLKA_ERR_LAUNCH;
-    };
-    auto join_gx = [&]() -> int {
-        if (!forkgx) return DLKA_OK;
-        AuxCtx &ax = aux_ctx();
-        return (hipEventRecord(ax.join2, ax.s2) == hipSuccess && hipStreamWaitEvent(st, ax.join2, 0) == hipSuccess) ? DLKA_OK : DLKA_ERR_LAUNCH;
-    };
-    hipStream_t wst = fork2d ? aux_ctx().s : st;
-    auto fork_to_aux = [&]() -> int {
-        if (!fork2d) return DLKA_OK;
-        AuxCtx &ax = aux_ctx();
-        return (hipEventRecord(ax.fork, st) == hipSuccess && hipStreamWaitEvent(ax.s, ax.fork, 0) == hipSuccess) ? DLKA_OK : DLKA_ERR_LAUNCH;
-    };
+    const bool forkgx = fork2d && fork_mode == 2;
+    hipStream_t gst = forkgx ? lease.stream(2) : nullptr;
+    auto fork_gx = [&]() -> int { return forkgx ? lease.fork(2) : DLKA_OK; };
+    auto join_gx = [&]() -> int { return forkgx ? lease.join(2) : DLKA_OK; };
+    hipStream_t wst = fork2d ? lease.stream(1) : st;
+    auto fork_to_aux = [&]() -> int { return fork2d ? lease.fork(1) : DLKA_OK; };
     float *part_p2 = part, *part_c1 = part_p2 + G.part_pw(), *part_p1 = part_c1 + G.part_pw(), *part_o5 = part_p1 + G.part_pw();
     float *part_o7 = part_o5 + G.part_o5(), *part_dw = part_o7 + G.part_o7();
     FinalizeBatch fb;
@@ -909,10 +1068,7 @@ int lka2d_cl_backward(const void *x_, const dlka_lka2d_params *p, const void *gy
         DLKA_TRY(launch_cl_wgrad_pw3(jobs, gws, gbs, st, &fb.j[fb.njobs]));
         fb.njobs += 3;
     }
-    if (fork2d) {   // join: the folds read the offset nets' partial sums
-        AuxCtx &ax = aux_ctx();
-        if (hipEventRecord(ax.join, ax.s) != hipSuccess || hipStreamWaitEvent(st, ax.join, 0) != hipSuccess) return DLKA_ERR_LAUNCH;
-    }
+    if (fork2d) DLKA_TRY(lease.join(1));   // the folds read the offset nets' partial sums
     DLKA_TRY(launch_cl_wgrad_finalize(fb, st));
     DLKA_TRY(dense_backward_data(G.pw, gh, 0, N0, gxt, PW.pw_b[0], 3, gyt, st));                                                // gx = P1^T gh + gy
     return launch_cl_transpose(gxt, (float *)gx_, B, C, G.pw.N, 0, st, bf);
@@ -1113,11 +1269,27 @@ int dlka_ndhwc_to_ncdhw(const void *src, void *dst, int B, int C, int N, int dty
     return launch_cl_transpose((const float *)src, (float *)dst, B, C, N, 0, (hipStream_t)stream);
 }
 
+// ---- fork contexts: diagnostics and the cached switches ---------------------------------------------------------------------------
+void dlka_env_refresh(void)
+{
+#if !defined(HIPEMU)
+    fork_env_load();
+#endif
+}
+
+int dlka_fork_stats(int device, int64_t *contexts, int64_t *leases)
+{
+    if (device < 0 || device >= FORK_MAX_DEV) return DLKA_ERR_SHAPE;
+    if (contexts) *contexts = g_fork_created_dev[device].load(std::memory_order_relaxed);
+    if (leases) *leases = g_fork_leases_dev[device].load(std::memory_order_relaxed);
+    return DLKA_OK;
+}
+
 // ---- token-layout D-LKA block ------------------------------------------------------------------------------------------------
 int dlka_lka3d_force_wgrad_gather(int on)
 {
     const int old = wgrad_gather() ? 1 : 0;
-    g_wgrad_gather = on ? 1 : 0;
+    g_wgrad_gather.store(on ? 1 : 0, std::memory_order_release);
     return old;
 }
 
@@ -1141,7 +1313,7 @@ size_t dlka_lka3d_tokens_workspace_bytes_v(int B, int C, int D, int H, int W, in
     if (!dlka_lka3d_tokens_supported_v(B, C, D, H, W, dtype, variant)) return 0;
     TokGeoms G(B, C, D, H, W, dtype, variant);   // (the eight gradient buffers keep their fp32 size on the bf16 path: gta and the split scratch ARE fp32)
     return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 8 * align256(G.E * 4) + align256(G.GOff * 4) +
-           align256(G.scratch_floats() * 4) + align256(G.samp_capacity_floats() * 4) + 2 * align256(G.blk_floats() * 4) + align256(4096);
+           align256(G.scratch_floats() * 4) + align256(G.samp_capacity_floats() * 4) + (cl_dwconv_lds_mode() ? 2 * align256(G.blk_floats() * 4) : 0) + align256(4096);
 }
 
 static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void *y_, void *saved, size_t saved_bytes, void *workspace,
@@ -1167,7 +1339,11 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     float *acc32 = (float *)cv.take(G.E * 4);   // bf16 path: fp32 landing zone of a tap-split deformable conv (small stages)
     // bf16 path: the fp32 offset-determining chain (TokGeoms): a32, t1_32, t_32 — the next three of the backward pass's gradient buffers
     float *a32 = (float *)cv.take(G.E * 4), *t1_32 = (float *)cv.take(G.E * 4), *t_32 = (float *)cv.take(G.E * 4);
-    float *blkA = (float *)cv.take(G.blk_floats() * 4), *blkB = (float *)cv.take(G.blk_floats() * 4);   // blocked inputs of the LDS-brick depthwise convs
+    // blocked inputs of the opt-in LDS-brick depthwise convs (DLKA_DW_LDS): sized and carved only when that mode is on — and only when both fit, so a mode
+    // switched on between the size query and this call keeps the register-row kernels instead of overrunning the workspace
+    const bool want_blk = cl_dwconv_lds_mode() != 0;
+    float *blkA = (float *)cv.take_opt(G.blk_floats() * 4, want_blk), *blkB = (float *)cv.take_opt(G.blk_floats() * 4, want_blk && blkA);
+    if (!blkB) blkA = nullptr;
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const bool bf = dtype == DLKA_BF16;
     const float *x = (const float *)x_;
@@ -1490,8 +1666,12 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
     float *gt = (float *)cv.take(G.E * 4), *gt1 = (float *)cv.take(G.E * 4), *ga2 = (float *)cv.take(G.E * 4), *gh = (float *)cv.take(G.E * 4);
     float *goff = (float *)cv.take(G.GOff * 4);
     float *scratch = (float *)cv.take(G.scratch_floats() * 4);
-    float *samp = G.samp_floats() ? (float *)cv.take(G.samp_floats() * 4) : nullptr;
-    float *blkA = (float *)cv.take(G.blk_floats() * 4), *blkB = (float *)cv.take(G.blk_floats() * 4);   // blocked inputs of the LDS-brick depthwise convs
+    // the sample area is ALWAYS carved at its capacity (the layout behind it does not depend on the gather switch, which is read once here)
+    float *samp = G.samp_capacity_floats() ? (float *)cv.take(G.samp_capacity_floats() * 4) : nullptr;
+    if (wgrad_gather()) samp = nullptr;
+    const bool want_blk = cl_dwconv_lds_mode() != 0;   // (see the forward pass)
+    float *blkA = (float *)cv.take_opt(G.blk_floats() * 4, want_blk), *blkB = (float *)cv.take_opt(G.blk_floats() * 4, want_blk && blkA);
+    if (!blkB) blkA = nullptr;
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const float *x = (const float *)x_, *gy = (const float *)gy_;
     float *gx = (float *)gx_;
@@ -1505,17 +1685,13 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
     FinalizeBatch fb;
     memset(&fb, 0, sizeof(fb));
 
-    SideCtx &sc = side_ctx();
-    const bool fork = sc.ok;
-    hipStream_t ws_ = fork ? sc.side : st;   // stream of the weight gradients
-    int nev = 0;
+    // one lease for the call: `side` (opt-in) for the weight gradients, `s` for grad_input beside grad_offset
+    const bool want_gx_fork = phase != 2 && gx_fork_wanted((long)G.dcn.M, phase);
+    ForkLease lease(st, want_gx_fork || side_stream_wanted());
+    const bool fork = lease.has_side();
+    hipStream_t ws_ = lease.side();   // stream of the weight gradients (== st without the side stream)
     // `ws_` may use what the main stream has produced so far
-    auto publish = [&]() -> int {
-        if (!fork) return DLKA_OK;
-        if (hipEventRecord(sc.ev[nev], st) != hipSuccess || hipStreamWaitEvent(ws_, sc.ev[nev], 0) != hipSuccess) return DLKA_ERR_LAUNCH;
-        ++nev;
-        return DLKA_OK;
-    };
+    auto publish = [&]() -> int { return fork ? lease.side_publish() : DLKA_OK; };
     // everything that is accumulated into with atomics, zero-filled by ONE launch: the depthwise weight-gradient staging, the
     // deformable conv's grad_input (halo overflow of the LDS windows) and the outputs of tap-split data gradients
     ZeroBatch zb;
@@ -1569,13 +1745,10 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
         DLKA_P2(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
                                 &fb.j[fb.njobs++]));
     bool gx_forked = false;
-    if (phase != 2 && gx_fork_wanted((long)G.dcn.M, phase) && aux_ready(st)) {   // grad_input on the internal stream, beside grad_offset (see aux_ctx)
-        AuxCtx &ax = aux_ctx();
-        if (hipEventRecord(ax.fork, st) == hipSuccess && hipStreamWaitEvent(ax.s, ax.fork, 0) == hipSuccess) {
-            DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, ax.s, nullptr, true, false, 0, nullptr, PW.dcn_b16));
-            if (hipEventRecord(ax.join, ax.s) != hipSuccess) return DLKA_ERR_LAUNCH;
-            gx_forked = true;
-        }
+    if (want_gx_fork && lease.ok()) {   // grad_input on the internal stream, beside grad_offset (see ForkCtx)
+        DLKA_TRY(lease.fork(1));
+        DLKA_TRY(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, lease.stream(1), nullptr, true, false, 0, nullptr, PW.dcn_b16));
+        gx_forked = true;
     }
     DLKA_P1(deform_backward(G.dcn, t, off, N0, gf, nullptr, goff, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, false, true, goff_cpad, samp, PW.dcn_b16));
     DLKA_TRY(publish());
@@ -1584,9 +1757,8 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
                                 &fb.j[fb.njobs++], false, false, 0, samp));
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
     DLKA_P2(dense_backward_weight(G.offc, t, goff, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, ws_, &fb.j[fb.njobs++], goff_cpad));
-    if (gx_forked) {   // join: the offset conv's data gradient adds gta
-        if (hipStreamWaitEvent(st, aux_ctx().join, 0) != hipSuccess) return DLKA_ERR_LAUNCH;
-    } else
+    if (gx_forked) DLKA_TRY(lease.join(1));   // the offset conv's data gradient adds gta
+    else
         DLKA_P1(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, true, false, 0, nullptr, PW.dcn_b16));
     DLKA_P1(dense_backward_data(G.offc, goff, 1, N0, gt, PW.off_b, 3, gta, st, nullptr, nullptr, true, goff_cpad != 0, true, ga2));
     DLKA_TRY(publish());
@@ -1630,9 +1802,7 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
     DLKA_P1(dense_backward_data(G.pw, gh, 0, N0, gx, PW.pw_b[0], 3, gy, st, nullptr, nullptr, true));
 #undef DLKA_P1
 #undef DLKA_P2
-    if (fork) {   // join
-        if (hipEventRecord(sc.ev[nev], ws_) != hipSuccess || hipStreamWaitEvent(st, sc.ev[nev], 0) != hipSuccess) return DLKA_ERR_LAUNCH;
-    }
+    if (fork) DLKA_TRY(lease.side_join());
     return DLKA_OK;
 }
 }  // namespace

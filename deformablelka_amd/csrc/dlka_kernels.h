@@ -85,6 +85,7 @@ int launch_cl_dw_prep_weight(const float *w, float *wp, int C, int K, int flip, 
 int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st);
 int launch_cl_dwconv_lds(const DwArgs &a, int kw, int dil_w, hipStream_t st);
 bool cl_dwconv_lds_selected(const DwArgs &a, int kw, int dil_w);   // would launch_cl_dwconv take the LDS-brick kernel?
+int cl_dwconv_lds_mode();   // DLKA_DW_LDS (0 = never: no blocked copies are sized or carved)
 size_t cl_dwconv_blk_floats(int B, int C, int D, int H, int W, int dil);   // floats of the class-blocked copy (DwArgs::blk)   // cl_dwconv_lds.hip: DLKA_ERR_UNSUPPORTED = keep the register-row kernels
 int launch_cl_dwconv_wgrad(DwWgradArgs a, int kw, int dil_w, hipStream_t st, bool zero_init = true);
 template <typename T> int launch_cl_dw_unprep(const float *gwp, T *gw, int C, int K, hipStream_t st);

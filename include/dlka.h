@@ -474,6 +474,16 @@ size_t dlka_lka3d_tokens_saved_bytes_v(int B, int C, int D, int H, int W, int dt
  * returns the previous setting.  Initial value: 1 iff the environment variable DLKA_WGRAD_GATHER is set when the first token-path call is made.
  * For A/B runs and the hand-over parity test; the workspace size query always covers both routes. */
 int dlka_lka3d_force_wgrad_gather(int on);
+/* Fork contexts.  Some backward entry points run independent kernels of ONE call on library-internal streams, forked from and
+ * joined back into the caller's stream inside the call (dlka_lka2d_attention_backward; the data-chain pass of the block-stack engine).  The streams and
+ * events of a call are a context leased from a per-DEVICE pool for the duration of that call: a call issued with device k current uses handles of device k
+ * only (nn.DataParallel replicas, 2D/trainer_MaxViT_deform_LKA.py:107-108), two host threads inside the library at once hold different contexts, contexts
+ * are never created inside a stream capture, and an error return joins what was forked.  dlka_fork_stats: contexts created on / leases handed out for
+ * `device` so far in this process (tests: no handle of device 0 is touched by a call on device 1; two concurrent callers got two contexts).
+ * dlka_env_refresh: the switches DLKA_GX_FORK_MIN_ROWS and DLKA_LKA2D_FORK are read once per process; this re-reads them (tests and A/B scripts that
+ * change them in-process call it afterwards). */
+int  dlka_fork_stats(int device, int64_t *contexts, int64_t *leases);
+void dlka_env_refresh(void);
 /* Diagnostics: launches so far (this process) of the opt-in LDS-brick depthwise kernel (csrc/cl_dwconv_lds.hip; DLKA_DW_LDS=1: the dw 5^3 / 7^3
  * dilation-3 convs of the block and their data gradients take it where the volume is large enough, =2: wherever its geometry fits; default: never —
  * it measured no faster than the register-row kernel); the tests use it to assert WHICH kernel produced the result they compare. */

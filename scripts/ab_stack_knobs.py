@@ -50,6 +50,10 @@ def main():
         else:
             from deformablelka_amd import _lib as L
             L._lib = None   # (the default library again)
+        try:
+            L.get_lib().dlka_env_refresh()   # (the library caches its fork switches; builds older than round 5 have no such export)
+        except AttributeError:
+            pass
         st = DLKABlockStack(2, device=dev, dtype=dtype, seed=1234, data_seed=4321, **kw)
         st.forward_backward()
         st.forward_backward()

@@ -20,6 +20,18 @@ def hip_backend(oracle):
     yield
 
 
+def _refresh_env():
+    from deformablelka_amd import _lib
+    _lib.get_lib().dlka_env_refresh()
+
+
+@pytest.fixture(autouse=True)
+def _fork_switches_follow_monkeypatch():
+    """monkeypatch restores the environment when a test ends; the library's cached fork switches follow it."""
+    yield
+    _refresh_env()
+
+
 D3 = [
     # reference smoke-script shapes (SURVEY §4 / §8c) and the four 3-D stage shapes, shrunk where the CPU oracle is slow
     (2, 32, 32, (12, 12, 12), 3, 1, 1, 1, 1, 1, "normal"),     # stage-0 config (3D/dcn/test_deform_conv_speed.py:155)
@@ -682,6 +694,7 @@ def test_stack_grad_input_fork_equals_one_stream(monkeypatch):
 
     for mode, val in (("one", "1000000000"), ("fork", "0")):
         monkeypatch.setenv("DLKA_GX_FORK_MIN_ROWS", val)
+        _refresh_env()   # (the fork switches are read once per process)
         st.backward()
         torch.cuda.synchronize()
         res[mode] = grads()
@@ -718,6 +731,7 @@ def test_lka2d_backward_forks_equal_one_stream(C, hw, monkeypatch):
             monkeypatch.delenv("DLKA_LKA2D_FORK", raising=False)
         else:
             monkeypatch.setenv("DLKA_LKA2D_FORK", mode)
+        _refresh_env()   # (the fork switches are read once per process)
         res[mode] = [g.clone() for g in torch.autograd.grad(y, leaves, gy, retain_graph=True)]
         torch.cuda.synchronize()
     for mode in ("1", None):
@@ -725,3 +739,137 @@ def test_lka2d_backward_forks_equal_one_stream(C, hw, monkeypatch):
             assert torch.isfinite(c_).all()
             scale = max(float(a_.abs().max()), 1e-6)
             assert float((a_ - c_).abs().max()) <= 2e-3 * scale, mode
+
+
+# ---- fork contexts: per device, per caller (include/dlka.h) --------------------------------------------------------------------
+def _fork_stats(dev=0):
+    import ctypes
+    from deformablelka_amd import _lib
+    c, l = ctypes.c_int64(0), ctypes.c_int64(0)
+    assert _lib.get_lib().dlka_fork_stats(dev, ctypes.byref(c), ctypes.byref(l)) == 0
+    return c.value, l.value
+
+
+def _close(a_, c_, bitwise):
+    if bitwise:
+        return torch.equal(a_, c_)
+    scale = max(float(a_.abs().max()), 1e-6)
+    return float((a_ - c_).abs().max()) <= 2e-3 * scale
+
+
+def test_fork_contexts_two_threads_two_streams(monkeypatch):
+    """Two host threads, each on its own torch.cuda.Stream, inside the library AT THE SAME TIME — one in the 2-D block's backward (two internal streams), the other in the
+    3-D token block's backward with grad_input forked beside grad_offset — reproduce what each pass gives alone: bit for bit wherever the pass is bitwise reproducible
+    alone (everything that involves no floating-point global atomics), to atomics order elsewhere.  The calls go straight through the ops layer (ctypes releases the GIL
+    for the duration of a C call; autograd would serialise both on the device's one backward thread).  Every call leases its own context from the device's pool."""
+    import threading
+    import deformablelka_amd as dk
+    from deformablelka_amd import ops
+    from oracle import blocks
+    monkeypatch.setenv("DLKA_GX_FORK_MIN_ROWS", "0")   # the one-call 3-D backward forks too
+    monkeypatch.delenv("DLKA_LKA2D_FORK", raising=False)
+    _refresh_env()
+    torch.manual_seed(11)
+    # problem A: the 2-D block at the shape of its tile grad_input kernel
+    m2 = dk.deformable_LKA_Attention(96)
+    blocks.randomize_offsets_(m2, std=0.03)
+    m2 = m2.to(DEV)
+    params2 = [p.detach() for p in m2.block_params()]
+    x2 = torch.randn(4, 96, 56, 56, device=DEV)
+    g2 = torch.randn(4, 96, 56, 56, device=DEV)
+    # problem B: the 3-D token block, stage-1 shape
+    m3 = dk.LKA_Attention3d_deform(64)
+    blocks.randomize_offsets_(m3, std=0.05)
+    m3 = m3.to(DEV)
+    params3 = [p.detach() for p in m3.block_params()]
+    x3 = torch.randn(2, 16 * 16 * 16, 64, device=DEV)
+    g3 = torch.randn(2, 16 * 16 * 16, 64, device=DEV)
+    y2, saved2 = ops.lka2d_attention_forward(x2, params2)
+    y3, saved3 = ops.lka3d_attention_tokens_forward(x3, params3, (16, 16, 16))
+    torch.cuda.synchronize()
+
+    def run2():
+        gx, gs = ops.lka2d_attention_backward(x2, params2, g2, saved2)
+        return [gx] + list(gs)
+
+    def run3():
+        gx, gs = ops.lka3d_attention_tokens_backward(x3, params3, g3, saved3, (16, 16, 16))
+        return [gx] + list(gs)
+
+    # alone, twice: the reference results and which tensors are bitwise reproducible
+    ref = {}
+    for name, fn in (("2d", run2), ("3d", run3)):
+        a = [t.clone() for t in fn()]
+        torch.cuda.synchronize()
+        b = [t.clone() for t in fn()]
+        torch.cuda.synchronize()
+        ref[name] = (a, [torch.equal(u, v) for u, v in zip(a, b)])
+        assert all(torch.isfinite(t).all() for t in a)
+    c0, l0 = _fork_stats(0)
+    iters = 24
+    bar = threading.Barrier(2)
+    out = {"2d": [], "3d": []}
+    err = []
+
+    def worker(name, fn):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(iters):
+                    bar.wait()
+                    out[name].append([t.clone() for t in fn()])
+                s.synchronize()
+        except Exception as e:   # noqa: BLE001
+            err.append(repr(e))
+            bar.abort()
+
+    ts = [threading.Thread(target=worker, args=("2d", run2)), threading.Thread(target=worker, args=("3d", run3))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert not err, err
+    for name in ("2d", "3d"):
+        a, bitwise = ref[name]
+        assert len(out[name]) == iters
+        for it, res in enumerate(out[name]):
+            for k, (u, v) in enumerate(zip(a, res)):
+                assert _close(u, v, bitwise[k]), (name, it, k, bitwise[k], float((u - v).abs().max()))
+    c1, l1 = _fork_stats(0)
+    assert l1 - l0 == 2 * iters          # every call forked
+    assert c1 >= 2                        # ... and two calls that overlapped held two different contexts
+
+
+def test_fork_contexts_follow_the_device():
+    """A backward call issued with device 1 current (an nn.DataParallel replica: 2D/trainer_MaxViT_deform_LKA.py:107-108) takes its streams and events from device 1's
+    pool — device 0's counters do not move — and computes what device 0 computes."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the 1-GPU box cannot exercise it; the 8-GPU node runs it)")
+    import deformablelka_amd as dk
+    from deformablelka_amd import ops
+    from oracle import blocks
+    torch.manual_seed(12)
+    m2 = dk.deformable_LKA_Attention(96)
+    blocks.randomize_offsets_(m2, std=0.03)
+    x = torch.randn(2, 96, 56, 56)
+    g = torch.randn(2, 96, 56, 56)
+    res = {}
+    for d in (0, 1):
+        with torch.cuda.device(d):
+            dev = f"cuda:{d}"
+            md = m2.to(dev)
+            params = [p.detach() for p in md.block_params()]
+            before = (_fork_stats(0), _fork_stats(1))
+            y, saved = ops.lka2d_attention_forward(x.to(dev), params)
+            gx, gs = ops.lka2d_attention_backward(x.to(dev), params, g.to(dev), saved)
+            torch.cuda.synchronize()
+            after = (_fork_stats(0), _fork_stats(1))
+            assert after[d][1] == before[d][1] + 1 and after[1 - d] == before[1 - d], (d, before, after)
+            res[d] = [t.cpu() for t in [y, gx] + list(gs)]
+    for u, v in zip(res[0], res[1]):
+        assert _close(u, v, False)
+    # a tensor of another device than the current one never reaches a launch
+    with torch.cuda.device(0):
+        with pytest.raises(RuntimeError, match="current device"):
+            ops.lka2d_attention_forward(x.to("cuda:1"), [p.detach() for p in m2.to("cuda:1").block_params()])
