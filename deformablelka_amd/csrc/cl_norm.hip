@@ -47,8 +47,9 @@ __device__ __forceinline__ void st_lo(float *p, long i, float v, int lo)
 // -> xt[M][C]; xn = (xt - mean) * rstd * w + b; stats[m] = {mean, rstd}.   Biased variance, eps inside the sqrt (nn.LayerNorm).
 __global__ __launch_bounds__(NT) void cl_layernorm_fwd_kernel(const float *__restrict__ x, int x_planar, const float *__restrict__ pos,
                                                               const float *__restrict__ w, const float *__restrict__ b, float *__restrict__ xt,
-                                                              float *__restrict__ xn, float *__restrict__ stats, int B, int N, int C, float eps, int lo)
-{
+                                                              float *__restrict__ xn, float *__restrict__ stats, int B, int N, int C, float eps, int lo,
+                                                              float *__restrict__ xn32)
+{   // xn32 (optional, with lo): the UNROUNDED LayerNorm output, fp32 — what the mixed mode's offset-determining chain starts from (dlka_tblock3d_forward_v)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long M = (long)B * N;
     if (C <= 32) {   // two token rows per wave: lanes 0-31 / 32-63 (a 32-channel row would leave half the wave idle)
@@ -67,7 +68,9 @@ __global__ __launch_bounds__(NT) void cl_layernorm_fwd_kernel(const float *__res
             const float var = fmaxf(half_sum(val * val) / C - mean * mean, 0.f);
             const float rstd = 1.f / sqrtf(var + eps);
             if (ok) {
-                st_lo(xn, m * C + c, (val - mean) * rstd * w[c] + b[c], lo);
+                const float o = (val - mean) * rstd * w[c] + b[c];
+                st_lo(xn, m * C + c, o, lo);
+                if (xn32) xn32[m * C + c] = o;
                 if (c == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
             }
         }
@@ -88,7 +91,11 @@ __global__ __launch_bounds__(NT) void cl_layernorm_fwd_kernel(const float *__res
         const float mean = s / C;
         const float var = fmaxf(s2 / C - mean * mean, 0.f);
         const float rstd = 1.f / sqrtf(var + eps);
-        for (int c = lane; c < C; c += 64) st_lo(xn, m * C + c, (xt[m * C + c] - mean) * rstd * w[c] + b[c], lo);
+        for (int c = lane; c < C; c += 64) {
+            const float o = (xt[m * C + c] - mean) * rstd * w[c] + b[c];
+            st_lo(xn, m * C + c, o, lo);
+            if (xn32) xn32[m * C + c] = o;
+        }
         if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
     }
 }
@@ -372,10 +379,10 @@ static unsigned grid_for(long work_items, long per_block, long cap = 2048)
 }
 
 int launch_cl_layernorm_fwd(const float *x, int x_planar, const float *pos, const float *w, const float *b, float *xt, float *xn, float *stats, int B, int N,
-                            int C, float eps, hipStream_t st, int lo)
+                            int C, float eps, hipStream_t st, int lo, float *xn32)
 {
     if (C > 64 * KMAX) return DLKA_ERR_UNSUPPORTED;
-    DLKA_LAUNCH(cl_layernorm_fwd_kernel, dim3(grid_for((long)B * N, NT / 64, 4096)), dim3(NT), 0, st, x, x_planar, pos, w, b, xt, xn, stats, B, N, C, eps, lo);
+    DLKA_LAUNCH(cl_layernorm_fwd_kernel, dim3(grid_for((long)B * N, NT / 64, 4096)), dim3(NT), 0, st, x, x_planar, pos, w, b, xt, xn, stats, B, N, C, eps, lo, xn32);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }

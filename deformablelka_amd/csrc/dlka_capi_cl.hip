@@ -451,7 +451,7 @@ static bool wgrad_gather()
 
 struct TokGeoms {
     SameConv pw, dw5, dw7, offc, dcn;   // (dw5 / dw7: conv0 / conv_spatial, whatever their kernels are in the variant)
-    SameConv dw5_f, dw7_f, offc_f;   // the forward chain's geometries: == dw5 / dw7 / offc on the fp32 path, their fp32-storage twins on DLKA_BF16
+    SameConv dw5_f, dw7_f, offc_f, pw_f;   // the forward chain's geometries: == dw5 / dw7 / offc / pw on the fp32 path, their fp32-storage twins on DLKA_BF16
     size_t E, Off, GOff;   // GOff: the backward's internal grad_offset buffer, 96 channel planes per batch (packed layout, DeformBwdArgs::goff_cpad)
     size_t SB;             // bytes per activation element (4, or 2 on the DLKA_BF16 path)
     TokGeoms(int B, int C, int D, int H, int W, int dtype = DLKA_F32, int variant = DLKA_LKA3D_SYNAPSE)
@@ -468,6 +468,7 @@ struct TokGeoms {
         dw5_f = dw_conv(B, C, D, H, W, dc.k0, dc.p0, dc.d0, 0);
         dw7_f = dw_conv(B, C, D, H, W, dc.k1, dc.p1, dc.d1, 0);
         offc_f = block_conv(B, C, 81, D, H, W, 3, 1, 1, 1, 0);
+        pw_f = block_conv(B, C, C, D, H, W, 1, 0, 1, 1, 0);
         E = (size_t)B * C * D * H * W;
         Off = (size_t)B * 81 * D * H * W;
         GOff = (size_t)B * 96 * D * H * W;
@@ -1316,9 +1317,12 @@ size_t dlka_lka3d_tokens_workspace_bytes_v(int B, int C, int D, int H, int W, in
            align256(G.scratch_floats() * 4) + align256(G.samp_capacity_floats() * 4) + (cl_dwconv_lds_mode() ? 2 * align256(G.blk_floats() * 4) : 0) + align256(4096);
 }
 
+// x_f32 (DLKA_BF16 only, optional): the caller's UNROUNDED fp32 twin of the bf16 input x.  The chain that decides where the deformable conv samples then starts
+// from it (a32 = GELU(proj_1 x_f32) by one extra fp32 pointwise launch) instead of from the bf16 tensor: the wrapper block's mixed mode rounds LayerNorm's output
+// INSIDE the block, and 2^-9 of input rounding in front of floor() would flip sampling cells against the fp32 block (tests/parity.py::check_tblock3d_mixed_bf16).
 static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void *y_, void *saved, size_t saved_bytes, void *workspace,
                                size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, void *stream, bool prepared,
-                               int variant = DLKA_LKA3D_SYNAPSE)
+                               int variant = DLKA_LKA3D_SYNAPSE, const float *x_f32 = nullptr)
 {
     if (!x_ || !p || !y_ || !saved || !workspace) return DLKA_ERR_NULL;
     const void *const *pp = (const void *const *)p;
@@ -1365,7 +1369,12 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
         DLKA_TRY(carve_prep(G, prep, PW, p, st, true, &zb));
     }
     // proj_1 + GELU (transformerblock.py:667-668): h kept for the GELU gradient, a = GELU(h)   (bf16: + the unrounded a for the fp32 chain)
-    DLKA_TRY(dense_forward(G.pw, x, N0, (const float *)p->proj_1_b, h, 0, PW.pw_f[0], 1, nullptr, a, st, false, ride, bf ? a32 : nullptr));
+    if (bf && x_f32) {   // (t_32 is free until the dilated conv writes it: the fp32 pre-activation lands there and is never read)
+        DLKA_TRY(dense_forward(G.pw_f, x_f32, N0, (const float *)p->proj_1_b, t_32, 0, PW.pw_f[0], 1, nullptr, a32, st, false, ride));
+        ride = nullptr;
+        DLKA_TRY(dense_forward(G.pw, x, N0, (const float *)p->proj_1_b, h, 0, PW.pw_f[0], 1, nullptr, a, st));
+    } else
+        DLKA_TRY(dense_forward(G.pw, x, N0, (const float *)p->proj_1_b, h, 0, PW.pw_f[0], 1, nullptr, a, st, false, ride, bf ? a32 : nullptr));
     // depthwise 5^3 then 7^3 dilation 3 (:646-647)   (bf16: fp32 in / out, the bf16 copies t1 / t ride in the same kernels)
     const float *a_in = bf ? a32 : a;
     float *t1_out = bf ? t1_32 : t1, *t_out = bf ? t_32 : t;
@@ -2026,11 +2035,14 @@ int dlka_tblock3d_forward_v(const void *x, int x_planar, const dlka_tblock3d_par
     void *lka_ws = cv.take(lka_ws_bytes);
     float *wp = (float *)cv.take(G.wp_floats() * 4);
     float *sums = (float *)cv.take(4096);
+    const int lo = dtype == DLKA_BF16 ? 1 : 0;   // the D-LKA attention runs DLKA_BF16: xn / e are bf16 storage
+    // mixed mode: LayerNorm's unrounded output, for the offset-determining chain of the attention (in the region the backward call uses for its six gradient buffers)
+    static const bool xn32_on = [] { const char *e = getenv("DLKA_MIXED_XN32"); return !(e && e[0] == '0'); }();   // (A/B: 0 = the chain starts from the bf16 tensor, as in round 4)
+    float *xn32 = (lo && xn32_on) ? (float *)cv.take(G.E * 4) : nullptr;
     if (!cv.ok()) return DLKA_ERR_WORKSPACE;
     const long M = (long)G.M, N = G.c3.N;
     float *st1 = (float *)bn_stats, *st2 = st1 + 3 * C;
     const float slope = 0.01f;   // UnetResBlock's act_name default (dynunet_block.py:41)
-    const int lo = dtype == DLKA_BF16 ? 1 : 0;   // the D-LKA attention runs DLKA_BF16: xn / e are bf16 storage
     (void)wp;
     // ONE launch prepares the wrapper's six weight forms (kept in `saved` for the backward call) and zero-fills what this direction accumulates
     // into with atomics (BatchNorm sums, tap-split conv outputs)
@@ -2052,9 +2064,9 @@ int dlka_tblock3d_forward_v(const void *x, int x_planar, const dlka_tblock3d_par
     }
     // tokens (+ pos_embed) and LayerNorm (:620-624)
     DLKA_TRY(launch_cl_layernorm_fwd((const float *)x, x_planar, (const float *)p->pos_embed, (const float *)p->norm_w, (const float *)p->norm_b, S.xt, S.xn,
-                                     S.lnstats, B, (int)N, C, ln_eps, st, lo));
+                                     S.lnstats, B, (int)N, C, ln_eps, st, lo, xn32));
     // epa_block = the D-LKA block (:624)
-    DLKA_TRY(dlka_lka3d_attention_tokens_forward_v(S.xn, lka, S.e, S.lka, S.lka_bytes, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, variant, stream));
+    DLKA_TRY(tokens_forward_impl(S.xn, lka, S.e, S.lka, S.lka_bytes, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, stream, false, variant, xn32));
     // attn = x + gamma * epa (:624); attn IS attn_skip in channels-last memory (:626 is a view here)
     DLKA_TRY(launch_cl_scale_residual_fwd(S.xt, S.e, (const float *)p->gamma, S.attn, M, C, st, lo));
     // conv51 = UnetResBlock (dynunet_block.py:66-80)

@@ -111,7 +111,7 @@ int lka2d_cl_backward(const void *x, const dlka_lka2d_params *p, const void *gy,
 
 // ---- cl_norm.hip: the non-convolutional pieces of TransformerBlock_3D_single_deform_LKA ---------------------------------
 int launch_cl_layernorm_fwd(const float *x, int x_planar, const float *pos, const float *w, const float *b, float *xt, float *xn, float *stats, int B, int N,
-                            int C, float eps, hipStream_t st, int lo = 0);   // lo: the tensor that crosses into the D-LKA block (xn / g / e / ge) is bf16 storage
+                            int C, float eps, hipStream_t st, int lo = 0, float *xn32 = nullptr);   // lo: the tensor that crosses into the D-LKA block (xn / g / e / ge) is bf16 storage; xn32: + its unrounded fp32 twin
 int launch_cl_layernorm_bwd(const float *g, const float *g_res, const float *xt, const float *stats, const float *w, float *gxt, float *gw, float *gb,
                             float *gpos, int B, int N, int C, hipStream_t st, bool zeroed = false, int lo = 0);
 int launch_cl_scale_residual_fwd(const float *xt, const float *e, const float *gamma, float *out, long M, int C, hipStream_t st, int lo = 0);

@@ -17,7 +17,7 @@ def bf16_storage(t):
     return t + (t.bfloat16().float() - t).detach()
 
 
-def lka3d_attention_volume(x, P, store=None, chain_store=None, offsets_override=None, offsets_out=None):
+def lka3d_attention_volume(x, P, store=None, chain_store=None, offsets_override=None, offsets_out=None, x_chain=None):
     """LKA_Attention3d_deform on an NCDHW volume — 3D/d_lka_former/network_architecture/synapse/transformerblock.py:664-673
     (minus the token permutes), LKA3d_deform.forward :644-652, DeformConvPack.forward synapse/deform_conv.py:93-105.
     store: None = the reference's fp32 block; ``bf16_storage`` = the model of the DLKA_BF16 path: the same arithmetic with every activation
@@ -25,13 +25,18 @@ def lka3d_attention_volume(x, P, store=None, chain_store=None, offsets_override=
     conv_spatial -> conv_offset — stays fp32 there (deformablelka_amd/csrc/dlka_capi_cl.hip, TokGeoms), so it is not rounded here either; the
     gate and the deformable conv's SAMPLES read the bf16 copies of a and t.
     chain_store: rounding applied to the chain tensors a / t1 / t as the offset-determining convs READ them (None = fp32, what the product does;
-    ``bf16_storage`` = the round-2 design with every activation in bf16 — kept so that tests/test_oracle_bf16_model.py can show why it was dropped)."""
+    ``bf16_storage`` = the round-2 design with every activation in bf16 — kept so that tests/test_oracle_bf16_model.py can show why it was dropped).
+    x_chain: the UNROUNDED twin of a bf16-rounded x (the wrapper block's mixed mode hands the attention LayerNorm's fp32 output beside its bf16 copy,
+    dlka_tblock3d_forward_v): the offset-determining chain — and with it the tensor t whose bf16 copy the deformable conv samples — then starts from it;
+    the gate, the shortcut and proj_1's saved activations read x."""
     st = store if store is not None else (lambda t: t)
     cs = chain_store if chain_store is not None else (lambda t: t)
     C = x.shape[1]
     shortcut = x.clone()                                                         # :666
     a = F.gelu(F.conv3d(x, P["proj_1.weight"], P["proj_1.bias"]))                # :667-668
     u = st(a)                                                                    # :645 (the gate's copy)
+    if x_chain is not None:
+        a = F.gelu(F.conv3d(x_chain, P["proj_1.weight"], P["proj_1.bias"]))
     s = "spatial_gating_unit."
     # the depthwise pair by its weight shapes: Synapse 5^3 p2 + 7^3 dil 3 p9 (:637-638); ACDC (acdc/transformerblock.py:213-237) (5,7,7) dil 3
     # p (6,9,9) / (3,5,5) dil (1,3,3) p (1,6,6) / 3^3 p1 after 5^3 p2 / 3^3 p1 — "same" padding with dilation 3 on every axis whose kernel > 3
@@ -54,10 +59,12 @@ def lka3d_attention_volume(x, P, store=None, chain_store=None, offsets_override=
     return st(y + shortcut)                                                      # :671
 
 
-def lka3d_attention_tokens(x, P, B, C, H, W, D, store=None, chain_store=None, offsets_override=None, offsets_out=None):
+def lka3d_attention_tokens(x, P, B, C, H, W, D, store=None, chain_store=None, offsets_override=None, offsets_out=None, x_chain=None):
     """The full forward(x, B, C, H, W, D) on (B, N, C) tokens, :664-673."""
     v = x.permute(0, 2, 1).reshape(B, C, H, W, D)
-    v = lka3d_attention_volume(v, P, store, chain_store, offsets_override, offsets_out)
+    if x_chain is not None:
+        x_chain = x_chain.permute(0, 2, 1).reshape(B, C, H, W, D)
+    v = lka3d_attention_volume(v, P, store, chain_store, offsets_override, offsets_out, x_chain)
     return v.reshape(B, C, H * W * D).permute(0, 2, 1)
 
 
@@ -77,7 +84,7 @@ def unet_res_block(x, P, prefix, training, stats_out=None):
     return F.leaky_relu(out + x, 0.01)                                           # :77-79
 
 
-def transformer_block_3d(x, P, training=False, drop_mask=None, offsets_override=None, offsets_out=None, lka_store=None):
+def transformer_block_3d(x, P, training=False, drop_mask=None, offsets_override=None, offsets_out=None, lka_store=None, lka_chain_fp32=True):
     """TransformerBlock_3D_single_deform_LKA.forward — transformerblock.py:617-630.  drop_mask: the (B, C) multipliers of
     conv8[0] = Dropout3d(0.1) (None = eval / no dropout).  lka_store: ``bf16_storage`` = the model of the wrapper block's MIXED mode (the D-LKA
     attention on bf16 activations: its input, every tensor it stores and its output rounded where they are written; the wrapper itself fp32)."""
@@ -86,10 +93,12 @@ def transformer_block_3d(x, P, training=False, drop_mask=None, offsets_override=
     if "pos_embed" in P and P["pos_embed"] is not None:
         t = t + P["pos_embed"]                                                   # :622-623
     n = F.layer_norm(t, (C,), P["norm.weight"], P["norm.bias"], 1e-5)
-    if lka_store is not None:
-        n = lka_store(n)
+    n32 = None
+    if lka_store is not None:   # the attention's bf16 input, and (round 5) its unrounded twin for the offset-determining chain
+        n32, n = (n if lka_chain_fp32 else None), lka_store(n)
     lka = {k[len("epa_block."):]: v for k, v in P.items() if k.startswith("epa_block.")}
-    attn = t + P["gamma"] * lka3d_attention_tokens(n, lka, B, C, H, W, D, store=lka_store, offsets_override=offsets_override, offsets_out=offsets_out)        # :624
+    attn = t + P["gamma"] * lka3d_attention_tokens(n, lka, B, C, H, W, D, store=lka_store, offsets_override=offsets_override, offsets_out=offsets_out,
+                                                   x_chain=n32)        # :624
     skip = attn.reshape(B, H, W, D, C).permute(0, 4, 1, 2, 3)                    # :626
     a = unet_res_block(skip, P, "conv51.", training)                             # :627
     if drop_mask is not None:

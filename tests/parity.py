@@ -830,7 +830,7 @@ def check_tblock3d(dev, B, C, dims, training, pos, seed=0, offset_std=0.02, atol
     assert not bad, "tblock: " + "; ".join(bad)
 
 
-def check_tblock3d_mixed_bf16(dev, B, C, dims, training=True, seed=0, offset_std=0.3, rtol=BF16_RTOL, via_autocast=True, report=False):
+def check_tblock3d_mixed_bf16(dev, B, C, dims, training=True, seed=0, offset_std=0.3, rtol=BF16_RTOL, via_autocast=True, report=False, bn_bias=6.0):
     """The wrapper block in its MIXED mode (dlka_tblock3d_*, dtype = DLKA_BF16: fp32 wrapper, the D-LKA attention inside on bf16 activations) — selected by
     torch.autocast(bfloat16) or by a bf16 input — against the fp32 oracle block and against the bf16-storage model of that mode
     (oracle.blocks.transformer_block_3d(lka_store=bf16_storage)): output and every gradient within 2e-2 of max |reference|."""
@@ -851,7 +851,7 @@ def check_tblock3d_mixed_bf16(dev, B, C, dims, training=True, seed=0, offset_std
             # activations in front of a kink (any framework), not of these kernels, and unrelated to what this test is for (the bf16 hand-over tensors
             # xn / e / g_e / g_xn of the mixed mode).  The biases keep both activations on their linear side here; the kink itself is covered in fp32
             # by check_tblock3d.
-            bn.bias.fill_(6.0)
+            bn.bias.fill_(bn_bias)
     m.train(training)
     x = torch.randn(B, C, H, W, D)
     if not via_autocast:
@@ -860,14 +860,15 @@ def check_tblock3d_mixed_bf16(dev, B, C, dims, training=True, seed=0, offset_std
     mask = torch.nn.functional.dropout3d(torch.ones(B, C, 1, 1, 1), 0.1, True).view(B, C) if training else None
     m0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
 
-    def run_oracle(store, override=None):
+    def run_oracle(store, override=None, offsets_out=None):
         Pr = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.detach().clone()) for k, v in m0.items()}
         xr = x.detach().clone().requires_grad_(True)
-        yr = blocks.transformer_block_3d(xr, Pr, training, mask, lka_store=store, offsets_override=override)
+        yr = blocks.transformer_block_3d(xr, Pr, training, mask, lka_store=store, offsets_override=override, offsets_out=offsets_out)
         yr.backward(gy)
         return yr.detach(), xr.grad, {k: v.grad for k, v in Pr.items() if torch.is_tensor(v) and v.requires_grad}
 
-    y32, gx32, g32 = run_oracle(None)
+    offs32 = []
+    y32, gx32, g32 = run_oracle(None, offsets_out=offs32)
     m = m.to(dev)
     m._draw_drop_mask = lambda B_, C_, dtype, device: mask.to(device)
     flags, saved_log = [], []
@@ -893,30 +894,48 @@ def check_tblock3d_mixed_bf16(dev, B, C, dims, training=True, seed=0, offset_std
     assert flags == [True], f"the wrapper block did not select its mixed bf16 mode: {flags}"
     assert y.dtype == torch.float32
     y.backward(gy.to(dev))
-    # the bf16-storage model of the mode, on the kernels' own sampling cells (their predicted offsets, read back from `saved`): LayerNorm's output is
-    # rounded to bf16 INSIDE the block, two correct fp32 LayerNorms differ in the last bit, and an element on a bf16 rounding boundary then differs by a
-    # whole bf16 ulp between them — enough to move a sample across a cell boundary (measured: conv_offset.weight 4e-2 at (64, 16^3) on own offsets)
+    # (1) The sampling cells.  Round 5: the chain that decides them starts from LayerNorm's UNROUNDED fp32 output (dlka_tblock3d_forward_v hands the attention an fp32
+    # twin of its bf16 input), so the predicted offsets agree with the fp32 block's to fp32 rounding: the cells that differ are counted and must be (almost) none.  Round 4
+    # started the chain from the bf16 tensor: 2^-9 in front of floor() flipped ~1e-3 of the cells and moved conv_offset.weight.grad by 5 - 10 %.
     off_hip = _ops.tblock3d_saved_offsets(saved_log[0], B, C, dims, 0, lka_bf16=True).cpu().clone()
+    flips = int((torch.floor(off_hip) != torch.floor(offs32[0].reshape(off_hip.shape))).sum()) if via_autocast else 0
+    nsamp = off_hip.numel()
+    # (2) three CPU runs on the kernels' OWN cells (their predicted offsets, read back from `saved`): the fp32 oracle, and the bf16-storage MODEL of the mode (same
+    # arithmetic, every hand-over tensor rounded where the kernels round it, the chain from the unrounded LayerNorm output)
+    y32c, gx32c, g32c = run_oracle(None, off_hip)
     y16, gx16, g16 = run_oracle(blocks.bf16_storage, off_hip)
-    errs = {"y": rel_err(y, y32), "gx": rel_err(xd.grad, gx32)}
-    errs16 = {"y": rel_err(y, y16), "gx": rel_err(xd.grad, gx16)}
+    errs = {"y": rel_err(y, y32c), "gx": rel_err(xd.grad, gx32c)}           # kernels vs fp32 oracle
+    errs16 = {"y": rel_err(y, y16), "gx": rel_err(xd.grad, gx16)}           # kernels vs the model
+    model = {"y": rel_err(y16, y32c), "gx": rel_err(gx16, gx32c)}           # the model vs fp32 oracle: what bf16 storage itself costs
     for k, p_ in m.named_parameters():
         assert p_.grad is not None and p_.grad.dtype == torch.float32, k
-        if g32.get(k) is not None and g32[k].abs().max() > 0:
-            errs[k] = rel_err(p_.grad, g32[k])
+        if g32c.get(k) is not None and g32c[k].abs().max() > 0:
+            errs[k] = rel_err(p_.grad, g32c[k])
             errs16[k] = rel_err(p_.grad, g16[k])
+            model[k] = rel_err(g16[k], g32c[k])
     if report or os.environ.get("DLKA_PARITY_VERBOSE"):
         worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
         worst16 = sorted(errs16.items(), key=lambda kv: -kv[1])[:5]
-        print(f"[tblock mixed bf16 C={C} dims={dims}] worst vs fp32 oracle: " + " ".join(f"{k.split('.')[-2:]}={v:.1e}" for k, v in worst))
-        print(f"[tblock mixed bf16 C={C} dims={dims}] worst vs bf16-storage model (same cells): " + " ".join(f"{k.split('.')[-2:]}={v:.1e}" for k, v in worst16))
-    # The statement of record is the comparison with the bf16-storage MODEL of the mode on identical sampling cells: same arithmetic with the hand-over
-    # tensors rounded where the kernels round them.  Against the fp32 oracle only the OUTPUT is held to 2e-2: in this mode the D-LKA attention's INPUT (LayerNorm's output) is a
-    # bf16 tensor, so the predicted offsets differ from the fp32 block's by ~2^-9 of the activations feeding them, samples near a cell boundary change
-    # cell, and every gradient that collects grad_offset moves by O(1) per flipped sample (measured at the four stage shapes on the MI355X: conv_offset.weight
-    # 5 - 10 %, grad_x up to 20 %) — the same discontinuity check_lka3d_tokens documents for fp32, here with a perturbation 2^15 times larger.  The token
-    # path's own bf16 test feeds the oracle the SAME rounded input and is therefore free of it; a wrapper cannot be, its rounding happens inside.
-    assert errs["y"] <= rtol, f"tblock mixed bf16 y: rel err vs fp32 oracle {errs['y']:.3e} > {rtol}"
-    for k in errs16:
-        assert errs16[k] <= rtol, f"tblock mixed bf16 {k}: rel err vs the bf16-storage model {errs16[k]:.3e} > {rtol}"
+        worstm = sorted(model.items(), key=lambda kv: -kv[1])[:3]
+        tag = f"[tblock mixed bf16 C={C} dims={dims} bn bias {bn_bias}]"
+        print(f"{tag} cells that differ from the fp32 block's: {flips} of {nsamp}; y vs fp32 oracle (own cells) {rel_err(y, y32):.1e}")
+        print(f"{tag} worst vs fp32 oracle (same cells): " + " ".join(f"{k.split('.')[-2:]}={v:.1e}" for k, v in worst))
+        print(f"{tag} worst vs bf16-storage model (same cells): " + " ".join(f"{k.split('.')[-2:]}={v:.1e}" for k, v in worst16))
+        print(f"{tag} the MODEL vs fp32 oracle (same cells): " + " ".join(f"{k.split('.')[-2:]}={v:.1e}" for k, v in worstm))
+    assert rel_err(y, y32) <= rtol, f"tblock mixed bf16 y: rel err vs fp32 oracle {rel_err(y, y32):.3e} > {rtol}"
+    assert flips <= max(3, int(2e-5 * nsamp)), f"tblock mixed bf16: {flips} of {nsamp} sampling cells differ from the fp32 block's"
+    # (3) The kernels implement the MODEL: every output / gradient within 2e-2 of it (max norm), with BatchNorm bias 6 (both LeakyReLUs on their linear side) AND 0 (the
+    # regime a freshly initialised net trains in).  Shapes below ~1000 voxels are exempt at bias 0: two correct implementations of the same bf16 arithmetic put the few
+    # pre-activations within rounding of 0 on different sides of LeakyReLU's kink, and ONE such element moves a gradient by ~1 / sqrt(voxels).
+    if bn_bias >= 3.0 or B * H * W * D >= 1000:
+        for k in errs16:
+            assert errs16[k] <= rtol, f"tblock mixed bf16 {k} (bn bias {bn_bias}): rel err vs the bf16-storage model {errs16[k]:.3e} > {rtol}"
+    # (4) ... and against the fp32 oracle ("bf16 path vs fp32 oracle <= 2e-2"): 2e-2 wherever bf16 STORAGE ITSELF allows it, i.e. every tensor is within
+    # max(2e-2, twice the distance of the model from the fp32 oracle).  What the model cannot reach no implementation of bf16 hand-over tensors can: a bf16 tensor
+    # (the attention's output e) in front of a LeakyReLU flips the side of the pre-activations within 2^-9 of 0, each flipped element changes ITS gradient term by
+    # a factor 100 (slope 1 | 0.01) — isolated elements of grad_x / pos_embed.grad even at bias 6 (the second LeakyReLU adds the residual stream, which reaches -6),
+    # and 2 - 5 % of conv51's parameter gradients at bias 0 (measured on the CPU model: conv51.conv2.weight 4.9e-2 at (64, 16^3)).
+    for k in errs:
+        lim = max(rtol, 2.0 * model[k])
+        assert errs[k] <= lim, f"tblock mixed bf16 {k} (bn bias {bn_bias}): rel err vs the fp32 oracle {errs[k]:.3e} > {lim:.3e} (model vs oracle {model[k]:.3e})"
     return errs

@@ -527,6 +527,7 @@ def test_tblock3d_mixed_bf16_mode(C, dims, autocast):
     """TransformerBlock_3D_single_deform_LKA under torch.autocast(bfloat16) / with a bf16 input: fp32 wrapper, DLKA_BF16 attention inside (round-3 verdict,
     missing #3: a bf16 tensor used to be widened and the whole block ran fp32)."""
     parity.check_tblock3d_mixed_bf16("cpu", 2, C, dims, via_autocast=autocast, report=True)
+    parity.check_tblock3d_mixed_bf16("cpu", 2, C, dims, via_autocast=autocast, report=True, bn_bias=0.0)   # the regime a freshly initialised net trains in
 
 
 def test_full_net_under_autocast_runs_every_dlka_block_in_bf16(monkeypatch):

@@ -461,6 +461,7 @@ def test_tblock3d_mixed_bf16_real_shapes(C, dims):
     """The wrapper block under torch.autocast(bfloat16) at the four stage shapes of the 64x128x128 patch: fp32 wrapper, DLKA_BF16 attention inside
     (dlka_tblock3d_* dtype = DLKA_BF16) — output and every gradient within 2e-2 of the fp32 oracle block and of the bf16-storage model."""
     parity.check_tblock3d_mixed_bf16(DEV, 2, C, dims, report=True)
+    parity.check_tblock3d_mixed_bf16(DEV, 2, C, dims, report=True, bn_bias=0.0)   # BatchNorm bias 0: the regime a freshly initialised net trains in
 
 
 def test_tblock3d_chain():
