@@ -274,27 +274,35 @@ __global__ __launch_bounds__(256) void cl_ddw2d_gx_kernel(Ddw2dArgs p, int TH, i
 //     scanning the whole image — and added by cl_ddw2d_gx_far_kernel afterwards (thread = (pixel, tap), global fp32 atomics, rare).
 // The split near / far is decided on the offset VALUES alone, so every tile that enumerates a sample takes the same decision.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int GX3_TY = 8, GX3_TX = 4;                 // tile (input pixels): 32 cells x 128 channels x 4 B = 16 KB of LDS per wave -> 9 waves per CU
+constexpr int GX3_TY = 8, GX3_TX = 4;                 // tile (input pixels)
 constexpr int GX3_MG = 3;                             // offset margin: |dy|, |dx| <= GX3_MG are "near"
 constexpr int GX3_NBY = GX3_TY + 2 * GX3_MG + 1, GX3_NBX = GX3_TX + 2 * GX3_MG + 1;   // candidate base positions per axis
 constexpr int GX3_CW = 128;                           // channels per wave: lane = a PAIR of channels (8-byte LDS and grad_out accesses)
-constexpr int GX3_NH = 6;                             // hits per group = grad_out row requests in flight per register set
+constexpr int GX3_NH = 8;                             // hits per group = grad_out row requests in flight per register set
+// Round 5 — the window carries a one-cell RING around the tile: (TY + 2) x (TX + 2) cells of [lane = channel pair] float2, 30 KB per wave (5 waves per CU).  A hit's
+// 2 x 2 footprint then ALWAYS lies inside the window (a hit has at least one corner in the tile, so its low corner is at most one cell outside), its four cells
+// are ONE base address plus the compile-time offsets {0, 1, WX, WX + 1} (ds_read_b64 / ds_write_b64 with immediate offsets), and corners outside the tile simply
+// land in ring cells that are never stored — no per-corner select, no per-corner address.  Round 4's version kept a tile-sized window (16 KB, 9 waves per CU) and
+// redirected each corner it did not own to a trash cell: ~48 scalar and ~35 vector instructions per hit (ISA loop mix, scripts/isa_loop_mix.py), 110 wave
+// instructions per hit in the PMC counters, 748 us at (96, 56^2, B = 24).  Now a hit is: one readlane of the row index, one of the window base, four of the
+// corner weights, a packed multiply by the tap weight, four 8-byte LDS reads, four packed FMAs, four 8-byte LDS writes.
+constexpr int GX3_WX = GX3_TX + 2, GX3_WY = GX3_TY + 2;
+constexpr int GX3_NCELL = GX3_WX * GX3_WY;
 
-__device__ __forceinline__ bool gx3_near(float oy, float ox) { return (fabsf(oy) <= (float)GX3_MG) & (fabsf(ox) <= (float)GX3_MG); }
+__device__ __forceinline__ bool gx3_near(float oy, float ox) { return (fabsf(oy) <= (float)GX3_MG) && (fabsf(ox) <= (float)GX3_MG); }
 
-struct f32x2_t { float x, y; };
-__device__ __forceinline__ f32x2_t gx3_load2(const float *p, long i) { const float2 v = *reinterpret_cast<const float2 *>(p + i); return f32x2_t{v.x, v.y}; }
-__device__ __forceinline__ f32x2_t gx3_load2(const bf16_t *p, long i)
+typedef float gx3_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gx3_f2 gx3_load2(const float *p, long i) { const float2 v = *reinterpret_cast<const float2 *>(p + i); return gx3_f2{v.x, v.y}; }
+__device__ __forceinline__ gx3_f2 gx3_load2(const bf16_t *p, long i)
 {
     const unsigned w = *reinterpret_cast<const unsigned *>(p + i);   // two bf16: element i in the low half
-    return f32x2_t{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+    return gx3_f2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
 }
 
 template <typename T>   // T: storage of grad_out `g`
 __global__ __launch_bounds__(64) void cl_ddw2d_gx3_kernel(Ddw2dArgs p, int ntx, int nty, int xcd_nx)
 {
-    constexpr int NCELL = GX3_TY * GX3_TX, TRASH = NCELL;   // cell TRASH: where the corners a hit does NOT own are "added" (weight 0), so that the four
-    __shared__ __attribute__((aligned(8))) f32x2_t Win[(NCELL + 1) * 64];   // updates of a hit are straight-line code; [cell][lane = channel pair]
+    __shared__ __attribute__((aligned(8))) gx3_f2 Win[GX3_NCELL * 64];   // [window cell][lane = channel pair]
     const T *gin = reinterpret_cast<const T *>(p.g);
     const int lane = threadIdx.x;
     int t = DLKA_XCD_BX(xcd_nx);   // an XCD owns a contiguous range of tiles (whole images): the grad_out rows its tiles re-read stay in its L2
@@ -306,14 +314,14 @@ __global__ __launch_bounds__(64) void cl_ddw2d_gx3_kernel(Ddw2dArgs p, int ntx, 
     const int cc = cok ? c : 0;   // (lanes beyond C run the same instruction stream on channels 0, 1 and store nothing)
     const int ty0 = ty * GX3_TY, tx0 = tx * GX3_TX;
 #pragma unroll
-    for (int e = 0; e <= NCELL; ++e) Win[e * 64 + lane] = f32x2_t{0.f, 0.f};   // (each lane only ever touches its own column: no barrier anywhere)
+    for (int e = 0; e < GX3_NCELL; ++e) Win[e * 64 + lane] = gx3_f2{0.f, 0.f};   // (each lane only ever touches its own column: no barrier anywhere)
     constexpr int NCT = GX3_NBY * GX3_NBX;   // candidates per tap
     const int ncand = p.K * NCT;
     // The candidates of batch k + 1 are decoded and their two offsets REQUESTED before the hits of batch k are walked (a batch otherwise begins with an
-    // exposed L2 round trip that nothing hides: measured 830 us -> see DESIGN 4.14).  Decoded state of the batch in flight: by / bx / n (n < 0: no candidate).
+    // exposed L2 round trip that nothing hides).  Decoded state of the batch in flight: by / bx / n (n < 0: no candidate).
     int nby = 0, nbx = 0, nn = -1, ntap = 0;
     float nfy = 0.f, nfx = 0.f;
-    f32x2_t nwA = {0.f, 0.f}, nwB = {0.f, 0.f};
+    gx3_f2 nwA = {0.f, 0.f}, nwB = {0.f, 0.f};
     auto decode_and_request = [&](int base) {
         const int tapA = base / NCT;   // the (at most two) taps of a batch — candidates are tap-major — and their weights for this lane's channels
         const int tapB = min(tapA + 1, p.K - 1);
@@ -342,77 +350,76 @@ __global__ __launch_bounds__(64) void cl_ddw2d_gx3_kernel(Ddw2dArgs p, int ntx, 
     for (int base = 0; base < ncand; base += 64) {
         // ---- finish the description of this batch's 64 candidates: lane = (tap, base position) ----
         const int tapA = base / NCT;
-        const f32x2_t wA = nwA, wB = nwB;
-        int m = 0, cell = 0, vm = 0;
-        const int isB = ntap != tapA;
-        float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+        const gx3_f2 wA = nwA, wB = nwB;
+        int m = 0, key = 0;        // key = (window cell of the low corner) << 1 | (second tap of the batch)
+        bool hit = false;
+        float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;   // corner weights; 0 for corners outside the IMAGE (those inside it but outside the tile go to ring cells)
         if (nn >= 0) {
-            {
-                const int n = nn, by = nby, bx = nbx;
-                const float fy = nfy, fx = nfx;
-                int y0, x0;
-                float ly, lx;
-                bool reach;
-                const bool inside = sample_cell2(fy, fx, by, bx, p.H, p.W, y0, x0, ly, lx, reach);   // the one sampling rule (deform_sample.h)
-                if (inside & gx3_near(fy, fx)) {
-                    const int ry = y0 - ty0, rx = x0 - tx0;
-                    const bool vy0 = (y0 >= 0) & (ry >= 0) & (ry < GX3_TY), vy1 = (y0 + 1 <= p.H - 1) & (ry + 1 >= 0) & (ry + 1 < GX3_TY);
-                    const bool vx0 = (x0 >= 0) & (rx >= 0) & (rx < GX3_TX), vx1 = (x0 + 1 <= p.W - 1) & (rx + 1 >= 0) & (rx + 1 < GX3_TX);
-                    vm = ((vy0 & vx0) ? 1 : 0) | ((vy0 & vx1) ? 2 : 0) | ((vy1 & vx0) ? 4 : 0) | ((vy1 & vx1) ? 8 : 0);
+            const float fy = nfy, fx = nfx;
+            int y0, x0;
+            float ly, lx;
+            bool reach;
+            const bool inside = sample_cell2(fy, fx, nby, nbx, p.H, p.W, y0, x0, ly, lx, reach);   // the one sampling rule (deform_sample.h)
+            if (inside & gx3_near(fy, fx)) {
+                const int ry = y0 - ty0, rx = x0 - tx0;   // low corner relative to the tile: a corner is in the tile iff it is in [0, TY) x [0, TX)
+                const bool iy0 = y0 >= 0, iy1 = y0 + 1 <= p.H - 1, ix0 = x0 >= 0, ix1 = x0 + 1 <= p.W - 1;   // ... and counts iff it is in the image
+                const bool ty_0 = (ry >= 0) & (ry < GX3_TY), ty_1 = (ry + 1 >= 0) & (ry + 1 < GX3_TY);
+                const bool tx_0 = (rx >= 0) & (rx < GX3_TX), tx_1 = (rx + 1 >= 0) & (rx + 1 < GX3_TX);
+                hit = (iy0 & ix0 & ty_0 & tx_0) | (iy0 & ix1 & ty_0 & tx_1) | (iy1 & ix0 & ty_1 & tx_0) | (iy1 & ix1 & ty_1 & tx_1);
+                if (hit) {   // => ry in [-1, TY - 1], rx in [-1, TX - 1]: the 2 x 2 footprint lies in the ringed window
                     const float hy = 1.f - ly, hx = 1.f - lx;
-                    w00 = (vm & 1) ? hy * hx : 0.f; w01 = (vm & 2) ? hy * lx : 0.f; w10 = (vm & 4) ? ly * hx : 0.f; w11 = (vm & 8) ? ly * lx : 0.f;
-                    cell = ry * GX3_TX + rx;   // (of the low corner; may be "negative": only the corners in vm are addressed)
-                    m = b * p.N + n;
+                    w00 = (iy0 & ix0) ? hy * hx : 0.f; w01 = (iy0 & ix1) ? hy * lx : 0.f; w10 = (iy1 & ix0) ? ly * hx : 0.f; w11 = (iy1 & ix1) ? ly * lx : 0.f;
+                    key = (((ry + 1) * GX3_WX + (rx + 1)) << 1) | (ntap != tapA ? 1 : 0);
+                    m = b * p.N + nn;
                 }
             }
         }
         if (base + 64 < ncand) decode_and_request(base + 64);   // in flight while this batch's hits are applied
-        const int key = (cell << 5) | (isB << 4) | vm;   // one broadcast for the three small integers (cell in [-TX - 1, NCELL - 1])
         // ---- walk the hits with lane = channel pair, GX3_NH at a time: the grad_out rows of the NEXT group are requested before the current group is
-        //      applied (two fixed register sets: no value has to be moved — and therefore waited for — while its load is in flight) ----
-        unsigned long long mask = __ballot(vm != 0);
-        int la[GX3_NH], va[GX3_NH], lb[GX3_NH], vb[GX3_NH];
-        f32x2_t ga[GX3_NH], gb[GX3_NH];
-#define DLKA_GX3_LOAD(G, L, V)                                                               \
+        //      applied (two fixed register sets: no value has to be moved — and therefore waited for — while its load is in flight).  A slot past the last hit
+        //      takes a lane that is NOT a hit: its weights are 0, its key 0 (window cell 0, a ring corner) and its row index 0, so the slot runs the same
+        //      straight-line code and changes nothing.  Such a lane exists whenever a slot needs one: 64 hits fill GX3_NH | 64 slots exactly. ----
+        unsigned long long mask = __ballot(hit);
+        const int nz = (~mask) ? __builtin_ctzll(~mask) : 0;
+        int la[GX3_NH], lb[GX3_NH];
+        gx3_f2 ga[GX3_NH], gb[GX3_NH];
+        bool more;
+#define DLKA_GX3_LOAD(G, L)                                                                  \
+        more = mask != 0;                                                                    \
         _Pragma("unroll") for (int q = 0; q < GX3_NH; ++q) {                                 \
-            V[q] = mask != 0;                                                                \
-            L[q] = V[q] ? __builtin_ctzll(mask) : 0;                                         \
-            mask = V[q] ? (mask & (mask - 1)) : 0;                                           \
+            L[q] = mask ? __builtin_ctzll(mask) : nz;                                        \
+            mask &= mask - 1;                                                                \
             G[q] = gx3_load2(gin, (long)lane_bcast(m, L[q]) * p.C + cc);                     \
         }
-#define DLKA_GX3_APPLY(G, L, V)                                                              \
+#define DLKA_GX3_APPLY(G, L)                                                                 \
         _Pragma("unroll") for (int q = 0; q < GX3_NH; ++q) {                                 \
-            const int skey = V[q] ? lane_bcast(key, L[q]) : 0;   /* no hit: every corner -> TRASH with weight 0 */ \
-            const int scell = skey >> 5, svm = skey & 15;                                    \
-            const f32x2_t wt = (skey & 16) ? wB : wA;                                        \
-            const float cx_ = G[q].x * wt.x, cy_ = G[q].y * wt.y;   /* d loss / d sample */  \
-            const int a0 = ((svm & 1) ? scell : TRASH) * 64 + lane, a1 = ((svm & 2) ? scell + 1 : TRASH) * 64 + lane;                          \
-            const int a2 = ((svm & 4) ? scell + GX3_TX : TRASH) * 64 + lane, a3 = ((svm & 8) ? scell + GX3_TX + 1 : TRASH) * 64 + lane;        \
-            const float s00 = V[q] ? lane_bcast(w00, L[q]) : 0.f, s01 = V[q] ? lane_bcast(w01, L[q]) : 0.f;                                    \
-            const float s10 = V[q] ? lane_bcast(w10, L[q]) : 0.f, s11 = V[q] ? lane_bcast(w11, L[q]) : 0.f;                                    \
-            const f32x2_t v0 = Win[a0], v1 = Win[a1], v2 = Win[a2], v3 = Win[a3];            \
-            Win[a0] = f32x2_t{fmaf(s00, cx_, v0.x), fmaf(s00, cy_, v0.y)};                   \
-            Win[a1] = f32x2_t{fmaf(s01, cx_, v1.x), fmaf(s01, cy_, v1.y)};                   \
-            Win[a2] = f32x2_t{fmaf(s10, cx_, v2.x), fmaf(s10, cy_, v2.y)};                   \
-            Win[a3] = f32x2_t{fmaf(s11, cx_, v3.x), fmaf(s11, cy_, v3.y)};                   \
+            const int skey = lane_bcast(key, L[q]);                                          \
+            const gx3_f2 col = G[q] * ((skey & 1) ? wB : wA);   /* d loss / d sample */      \
+            const float s00 = lane_bcast(w00, L[q]), s01 = lane_bcast(w01, L[q]), s10 = lane_bcast(w10, L[q]), s11 = lane_bcast(w11, L[q]);  \
+            gx3_f2 *wp_ = Win + ((skey >> 1) * 64 + lane);                                   \
+            const gx3_f2 v0 = wp_[0], v1 = wp_[64], v2 = wp_[GX3_WX * 64], v3 = wp_[(GX3_WX + 1) * 64];      \
+            wp_[0] = __builtin_elementwise_fma(gx3_f2{s00, s00}, col, v0);                   \
+            wp_[64] = __builtin_elementwise_fma(gx3_f2{s01, s01}, col, v1);                  \
+            wp_[GX3_WX * 64] = __builtin_elementwise_fma(gx3_f2{s10, s10}, col, v2);         \
+            wp_[(GX3_WX + 1) * 64] = __builtin_elementwise_fma(gx3_f2{s11, s11}, col, v3);   \
         }
-        DLKA_GX3_LOAD(ga, la, va)
-        while (va[0]) {
-            DLKA_GX3_LOAD(gb, lb, vb)
-            DLKA_GX3_APPLY(ga, la, va)
-            if (!vb[0]) break;
-            DLKA_GX3_LOAD(ga, la, va)
-            DLKA_GX3_APPLY(gb, lb, vb)
+        DLKA_GX3_LOAD(ga, la)
+        while (more) {
+            DLKA_GX3_LOAD(gb, lb)
+            DLKA_GX3_APPLY(ga, la)
+            if (!more) break;
+            DLKA_GX3_LOAD(ga, la)
+            DLKA_GX3_APPLY(gb, lb)
         }
 #undef DLKA_GX3_LOAD
 #undef DLKA_GX3_APPLY
     }
     if (!cok) return;
 #pragma unroll 4
-    for (int e = 0; e < NCELL; ++e) {
+    for (int e = 0; e < GX3_TY * GX3_TX; ++e) {
         const int yy = ty0 + e / GX3_TX, xx = tx0 + e % GX3_TX;
         if (yy < p.H && xx < p.W) {
-            const f32x2_t v = Win[e * 64 + lane];
+            const gx3_f2 v = Win[((e / GX3_TX + 1) * GX3_WX + (e % GX3_TX + 1)) * 64 + lane];
             *reinterpret_cast<float2 *>(p.gx + ((long)b * p.N + yy * p.W + xx) * p.C + c) = make_float2(v.x, v.y);
         }
     }

@@ -321,12 +321,24 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
                     const f32x4 t4 = buf_load_f32x4(rg, off + 16u * e);
                     ga_n[c][4 * e] = t4[0]; ga_n[c][4 * e + 1] = t4[1]; ga_n[c][4 * e + 2] = t4[2]; ga_n[c][4 * e + 3] = t4[3];
                 }
-            } else {
+            } else if ((p.N & 3) == 0) {   // N % 4 == 0 (round 5: the 2-D net's 14 x 14 stage, N = 196): the half-wave's 16 rows start at a multiple of 16, so every
+                // run of 4 rows is 16-byte aligned inside ONE plane — four 16-byte loads as above, only that a run may belong to the next volume.  (The
+                // per-row dword loads this replaces were 32 of the step's 80 load instructions, each touching 64 cache lines.)
+                int b = b0, v = v0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4 t4 = buf_load_f32x4(rg, (mrow0 + 4 * e < m_hi && co < p.Cout) ? (unsigned)((b * gcp + co) * p.N + v) * 4u : DLKA_OOB);
+                    ga_n[c][4 * e] = t4[0]; ga_n[c][4 * e + 1] = t4[1]; ga_n[c][4 * e + 2] = t4[2]; ga_n[c][4 * e + 3] = t4[3];
+                    v += 4;
+                    if (v >= p.N) { v = 0; ++b; }
+                }
+            } else {   // any N: (b, v) walked from the half-wave's first row (one division per step, not one per row)
+                int b = b0, v = v0;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
-                    const int m = mrow0 + s;
-                    const int b = m / p.N, v = m - b * p.N;
-                    ga_n[c][s] = buf_load_f32(rg, (m < m_hi && co < p.Cout) ? (unsigned)((b * gcp + co) * p.N + v) * 4u : DLKA_OOB);
+                    ga_n[c][s] = buf_load_f32(rg, (mrow0 + s < m_hi && co < p.Cout) ? (unsigned)((b * gcp + co) * p.N + v) * 4u : DLKA_OOB);
+                    ++v;
+                    if (v == p.N) { v = 0; ++b; }
                 }
             }
         }
@@ -385,14 +397,17 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
                     if (w_ == p.W) { w_ = 0; ++hh; if (hh == p.H) { hh = 0; ++d_; } }
                 }
             } else {
+                // any N (round 5; the 2-D net's 14 x 14 stage is N = 196): the same walk — rows are consecutive in memory across volumes too (x is [M][Cin]),
+                // only the coordinates start over at a volume's end.  The per-row div / mod chain this replaces made that stage's offset-net weight
+                // gradient 5x slower per FLOP than the 28 x 28 and 56 x 56 stages' (712 us against ~140 at their rate, BENCH_r04 lka2d table).
+                int w_ = v0 % p.W, hh = (v0 / p.W) % p.H, d_ = v0 / (p.W * p.H);
+                const unsigned base = (unsigned)(mrow0 * p.Cin + ci) * XB;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
-                    int v = v0 + s, b = b0;
-                    if (v >= p.N) { v -= p.N; b += 1; }
-                    if (v >= p.N) { b = (mrow0 + s) / p.N; v = (mrow0 + s) - b * p.N; }
-                    const int w_ = v % p.W, hh = (v / p.W) % p.H, d_ = v / (p.W * p.H);
                     crd[s] = (mrow0 + s < m_hi) ? ((d_ << 20) | (hh << 10) | w_) : -1;
-                    rowoff[s] = (unsigned)((b * p.N + v) * p.Cin + ci) * XB;
+                    rowoff[s] = base + (unsigned)(s * p.Cin) * XB;
+                    ++w_;
+                    if (w_ == p.W) { w_ = 0; ++hh; if (hh == p.H) { hh = 0; ++d_; if (d_ == p.D) d_ = 0; } }
                 }
             }
 #pragma unroll
