@@ -6,6 +6,8 @@
 //   Dropout3d's per-(sample, channel) mask (:611)        cl_channel_scale_kernel
 // All of them are HBM-bound streaming / reduction kernels: lanes run over channels (contiguous 128-byte row pieces), rows
 // are strided over the grid; per-channel reductions fold in LDS and finish with one fp32 atomic per channel and workgroup.
+#include <stdint.h>
+
 #include "dlka_kernels.h"
 
 namespace dlka {
@@ -378,10 +380,308 @@ static unsigned grid_for(long work_items, long per_block, long cap = 2048)
     return (unsigned)g;
 }
 
+// =====================================================================================================================================
+// Round 5 — the same operators on 16-BYTE accesses.  The kernels above give a lane ONE channel (dword loads, a modulo per element, 0.5 - 1.6 TB/s at
+// the 32^3 stage: profiles/r05k_tblock_stage0_kernel_stats.csv: cl_bn_stats 16.4 us for 8.4 MB, cl_bn_bwd_reduce 21.4 us, cl_layernorm_bwd 28.5 us);
+// here a lane owns a QUAD of consecutive channels of a row: LPR = C / 4 lanes per row (8 .. 64 for the block's widths 32 .. 256), NT / LPR rows per
+// workgroup pass, the channel quad of a thread never changes (per-channel parameters live in registers, no modulo anywhere), row sums of LayerNorm are
+// xor-shuffles over the LPR lanes of a row, per-channel sums stay in registers over the thread's rows and meet in LDS once per workgroup.
+// Taken for C in {32, 64, 128, 256} and channels-last input; everything else keeps the kernels above.
+// =====================================================================================================================================
+namespace {
+__device__ __forceinline__ bool quad_shape_ok_dev(int C) { return C == 32 || C == 64 || C == 128 || C == 256; }
+__device__ __forceinline__ f32x4 ldq_lo(const float *p, long i, int lo) { return lo ? act_load4(reinterpret_cast<const bf16_t *>(p), i) : act_load4(p, i); }
+__device__ __forceinline__ void stq_lo(float *p, long i, f32x4 v, int lo)
+{
+    if (lo) act_store4(reinterpret_cast<bf16_t *>(p), i, v);
+    else act_store4(p, i, v);
+}
+template <int LPR> __device__ __forceinline__ float row_sum(float v)
+{
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// per-channel partial sums of a workgroup's threads -> one global atomic per channel: red = [NS][C] floats of LDS (zeroed here)
+template <int NS> __device__ __forceinline__ void quad_fold(float *red, const f32x4 *acc, int q, int C, float *const *dst)
+{
+    for (int c = threadIdx.x; c < NS * C; c += NT) red[c] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(&red[k * C + 4 * q + e], acc[k][e]);
+    __syncthreads();
+    for (int c = threadIdx.x; c < NS * C; c += NT) atomicAdd(dst[c / C] + (c % C), red[c]);
+}
+}  // namespace
+
+template <int LPR>
+__global__ __launch_bounds__(NT) void cl_layernorm_fwd_q_kernel(const float *__restrict__ x, const float *__restrict__ pos, const float *__restrict__ w,
+                                                                const float *__restrict__ b, float *__restrict__ xt, float *__restrict__ xn,
+                                                                float *__restrict__ stats, long M, int N, float eps, int lo, float *__restrict__ xn32)
+{
+    constexpr int C = 4 * LPR, RPB = NT / LPR;
+    const int q = threadIdx.x % LPR, r = threadIdx.x / LPR;
+    const f32x4 wq = act_load4(w, 4 * q), bq = act_load4(b, 4 * q);
+    for (int m0 = blockIdx.x * RPB; m0 < (int)M; m0 += gridDim.x * RPB) {   // uniform trip count per workgroup: the row sums are wave collectives (32-bit row
+        const int m = m0 + r;                                               // counters: the launchers take these kernels for M < 2^30 only)
+        const bool ok = m < (int)M;
+        const long i = (long)(ok ? m : 0) * C + 4 * q;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            v = act_load4(x, i);
+            if (pos) { const f32x4 pv = act_load4(pos, (long)(m % N) * C + 4 * q); v[0] += pv[0]; v[1] += pv[1]; v[2] += pv[2]; v[3] += pv[3]; }
+            act_store4(xt, i, v);
+        }
+        const float s = row_sum<LPR>((v[0] + v[1]) + (v[2] + v[3]));
+        const float s2 = row_sum<LPR>(fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3]))));
+        const float mean = s / C;
+        const float var = fmaxf(s2 / C - mean * mean, 0.f);
+        const float rstd = 1.f / sqrtf(var + eps);
+        if (!ok) continue;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * wq[e] + bq[e];
+        stq_lo(xn, i, o, lo);
+        if (xn32) act_store4(xn32, i, o);
+        if (q == 0) { stats[2 * m] = mean; stats[2 * m + 1] = rstd; }
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(NT) void cl_layernorm_bwd_q_kernel(const float *__restrict__ g, const float *__restrict__ g_res, const float *__restrict__ xt,
+                                                                const float *__restrict__ stats, const float *__restrict__ w, float *__restrict__ gxt,
+                                                                float *__restrict__ gw, float *__restrict__ gb, float *__restrict__ gpos, long M, int N, int lo)
+{
+    constexpr int C = 4 * LPR, RPB = NT / LPR;
+    __shared__ float red[2 * C];
+    const int q = threadIdx.x % LPR, r = threadIdx.x / LPR;
+    const f32x4 wq = act_load4(w, 4 * q);
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // gw, gb of this thread's quad over its rows
+    for (int m0 = blockIdx.x * RPB; m0 < (int)M; m0 += gridDim.x * RPB) {   // (uniform trip count: see the forward kernel)
+        const int m = m0 + r;
+        const bool ok = m < (int)M;
+        const long i = (long)(ok ? m : 0) * C + 4 * q;
+        f32x4 gv = {0.f, 0.f, 0.f, 0.f}, xv = gv;
+        float mean = 0.f, rstd = 0.f;
+        if (ok) { gv = ldq_lo(g, i, lo); xv = act_load4(xt, i); mean = stats[2 * m]; rstd = stats[2 * m + 1]; }
+        f32x4 xh, dxh;
+        float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xh[e] = (xv[e] - mean) * rstd;
+            dxh[e] = gv[e] * wq[e];
+            p1 += dxh[e];
+            p2 = fmaf(dxh[e], xh[e], p2);
+            acc[0][e] = fmaf(gv[e], xh[e], acc[0][e]);
+            acc[1][e] += gv[e];
+        }
+        const float s1 = row_sum<LPR>(p1) / C, s2 = row_sum<LPR>(p2) / C;
+        if (!ok) continue;
+        f32x4 val;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = rstd * (dxh[e] - s1 - xh[e] * s2);
+        if (g_res) { const f32x4 rv = act_load4(g_res, i); val[0] += rv[0]; val[1] += rv[1]; val[2] += rv[2]; val[3] += rv[3]; }
+        act_store4(gxt, i, val);
+        if (gpos) {
+            float *gp = gpos + (long)(m % N) * C + 4 * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(gp + e, val[e]);
+        }
+    }
+    float *const dst[2] = {gw, gb};
+    quad_fold<2>(red, acc, q, C, dst);
+}
+
+// out = xt + gamma[c] * e
+template <int LPR>
+__global__ __launch_bounds__(NT) void cl_scale_residual_fwd_q_kernel(const float *__restrict__ xt, const float *__restrict__ e, const float *__restrict__ gamma,
+                                                                     float *__restrict__ out, long M, int lo)
+{
+    constexpr int C = 4 * LPR, RPB = NT / LPR;
+    const int q = threadIdx.x % LPR, r = threadIdx.x / LPR;
+    const f32x4 gq = act_load4(gamma, 4 * q);
+    for (int m = blockIdx.x * RPB + r; m < (int)M; m += gridDim.x * RPB) {   // (32-bit row counters: the launchers take these kernels for M < 2^31 only)
+        const long i = (long)m * C + 4 * q;
+        const f32x4 ev = ldq_lo(e, i, lo), xv = act_load4(xt, i);
+        act_store4(out, i, f32x4{fmaf(gq[0], ev[0], xv[0]), fmaf(gq[1], ev[1], xv[1]), fmaf(gq[2], ev[2], xv[2]), fmaf(gq[3], ev[3], xv[3])});
+    }
+}
+
+// ge = gamma[c] * g;  ggamma[c] += sum_m g * e
+template <int LPR>
+__global__ __launch_bounds__(NT) void cl_scale_residual_bwd_q_kernel(const float *__restrict__ g, const float *__restrict__ e, const float *__restrict__ gamma,
+                                                                     float *__restrict__ ge, float *__restrict__ ggamma, long M, int lo)
+{
+    constexpr int C = 4 * LPR, RPB = NT / LPR;
+    __shared__ float red[C];
+    const int q = threadIdx.x % LPR, r = threadIdx.x / LPR;
+    const f32x4 gq = act_load4(gamma, 4 * q);
+    f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+    for (int m = blockIdx.x * RPB + r; m < (int)M; m += gridDim.x * RPB) {   // (32-bit row counters: the launchers take these kernels for M < 2^31 only)
+        const long i = (long)m * C + 4 * q;
+        const f32x4 gv = act_load4(g, i), ev = ldq_lo(e, i, lo);
+        stq_lo(ge, i, f32x4{gq[0] * gv[0], gq[1] * gv[1], gq[2] * gv[2], gq[3] * gv[3]}, lo);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[0][k] = fmaf(gv[k], ev[k], acc[0][k]);
+    }
+    float *const dst[1] = {ggamma};
+    quad_fold<1>(red, acc, q, C, dst);
+}
+
+// sums[c] += sum_m (x[m][c] - p_c), sums[C + c] += sum_m (x[m][c] - p_c)^2, p_c = x[0][c]   (see cl_bn_stats_kernel)
+template <int LPR>
+__global__ __launch_bounds__(NT) void cl_bn_stats_q_kernel(const float *__restrict__ x, float *__restrict__ sums, long M)
+{
+    constexpr int C = 4 * LPR, RPB = NT / LPR;
+    __shared__ float red[2 * C];
+    const int q = threadIdx.x % LPR, r = threadIdx.x / LPR;
+    const f32x4 pv = act_load4(x, 4 * q);
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int step = gridDim.x * RPB, Mi = (int)M;
+    int m = blockIdx.x * RPB + r;
+    for (; (long)m + 3l * step < M; m += 4 * step) {   // four rows (64 bytes) in flight per work-item
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = act_load4(x, (long)(m + u * step) * C + 4 * q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[u][e] - pv[e]; acc[0][e] += d; acc[1][e] = fmaf(d, d, acc[1][e]); }
+    }
+    for (; m < Mi; m += step) {
+        const f32x4 v = act_load4(x, (long)m * C + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[e] - pv[e]; acc[0][e] += d; acc[1][e] = fmaf(d, d, acc[1][e]); }
+    }
+    float *const dst[2] = {sums, sums + C};
+    quad_fold<2>(red, acc, q, C, dst);
+}
+
+// y = lrelu((x - mean) * rstd * w + b (+ res)) (* mask[b][c])
+template <int LPR>
+__global__ __launch_bounds__(NT) void cl_bn_apply_q_kernel(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ w,
+                                                           const float *__restrict__ b, const float *__restrict__ stats, const float *__restrict__ mask,
+                                                           float *__restrict__ y, long M, long N, float slope)
+{
+    constexpr int C = 4 * LPR, RPB = NT / LPR;
+    const int q = threadIdx.x % LPR, r = threadIdx.x / LPR;
+    const f32x4 mean = act_load4(stats, 4 * q), rstd = act_load4(stats, C + 4 * q), wq = act_load4(w, 4 * q), bq = act_load4(b, 4 * q);
+    for (int m = blockIdx.x * RPB + r; m < (int)M; m += gridDim.x * RPB) {   // (32-bit row counters: the launchers take these kernels for M < 2^31 only)
+        const long i = (long)m * C + 4 * q;
+        const f32x4 xv = act_load4(x, i);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (xv[e] - mean[e]) * rstd[e] * wq[e] + bq[e];   // (the dword kernel's rounding sequence)
+        if (res) { const f32x4 rv = act_load4(res, i); v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : slope * v[e];
+        if (mask) { const f32x4 mk = act_load4(mask, (long)(m / (int)N) * C + 4 * q); v[0] *= mk[0]; v[1] *= mk[1]; v[2] *= mk[2]; v[3] *= mk[3]; }
+        act_store4(y, i, v);
+    }
+}
+
+// gpre = g * lrelu'(y) (* mask);  sums[c] += sum_m gpre, sums[C + c] += sum_m gpre * xhat;  gres = gpre (+ gres_add)   (optional)
+template <int LPR>
+__global__ __launch_bounds__(NT) void cl_bn_bwd_reduce_q_kernel(const float *__restrict__ g, const float *__restrict__ gmask, const float *__restrict__ x,
+                                                                const float *__restrict__ y, const float *__restrict__ stats, float *__restrict__ sums,
+                                                                float *__restrict__ gres, const float *__restrict__ gres_add, long M, long N, float slope)
+{
+    constexpr int C = 4 * LPR, RPB = NT / LPR;
+    __shared__ float red[2 * C];
+    const int q = threadIdx.x % LPR, r = threadIdx.x / LPR;
+    const f32x4 mean = act_load4(stats, 4 * q), rstd = act_load4(stats, C + 4 * q);
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int step = gridDim.x * RPB, Mi = (int)M;
+    int m = blockIdx.x * RPB + r;
+    auto one = [&](int mm, const f32x4 &gv, const f32x4 &yv, const f32x4 &xv) {
+        f32x4 gp;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gp[e] = gv[e] * (yv[e] > 0.f ? 1.f : slope);
+        if (gmask) { const f32x4 mk = act_load4(gmask, (long)(mm / (int)N) * C + 4 * q); gp[0] *= mk[0]; gp[1] *= mk[1]; gp[2] *= mk[2]; gp[3] *= mk[3]; }
+        if (gres) {
+            f32x4 o = gp;
+            if (gres_add) { const f32x4 av = act_load4(gres_add, (long)mm * C + 4 * q); o[0] += av[0]; o[1] += av[1]; o[2] += av[2]; o[3] += av[3]; }
+            act_store4(gres, (long)mm * C + 4 * q, o);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[0][e] += gp[e]; acc[1][e] = fmaf(gp[e], (xv[e] - mean[e]) * rstd[e], acc[1][e]); }
+    };
+    for (; (long)m + step < M; m += 2 * step) {   // two rows (six 16-byte loads) in flight per work-item
+        const long i0 = (long)m * C + 4 * q, i1 = (long)(m + step) * C + 4 * q;
+        const f32x4 g0 = act_load4(g, i0), g1 = act_load4(g, i1), y0 = act_load4(y, i0), y1 = act_load4(y, i1), x0 = act_load4(x, i0), x1 = act_load4(x, i1);
+        one(m, g0, y0, x0);
+        one(m + step, g1, y1, x1);
+    }
+    for (; m < Mi; m += step) {
+        const long i = (long)m * C + 4 * q;
+        one(m, act_load4(g, i), act_load4(y, i), act_load4(x, i));
+    }
+    float *const dst[2] = {sums, sums + C};
+    quad_fold<2>(red, acc, q, C, dst);
+}
+
+// training: gx = rstd * w * (gpre - sums[c]/M - xhat * sums[C+c]/M);  eval: gx = rstd * w * gpre;  gw[c] = sums[C + c], gb[c] = sums[c] (workgroup 0)
+template <int LPR>
+__global__ __launch_bounds__(NT) void cl_bn_bwd_apply_q_kernel(const float *__restrict__ g, const float *__restrict__ gmask, const float *__restrict__ x,
+                                                               const float *__restrict__ y, const float *__restrict__ w, const float *__restrict__ stats,
+                                                               const float *__restrict__ sums, float *__restrict__ gx, float *__restrict__ gw, float *__restrict__ gb,
+                                                               long M, long N, float slope, int training)
+{
+    constexpr int C = 4 * LPR, RPB = NT / LPR;
+    const int q = threadIdx.x % LPR, r = threadIdx.x / LPR;
+    const float invM = 1.f / (float)M;
+    const f32x4 mean = act_load4(stats, 4 * q), rstd = act_load4(stats, C + 4 * q), wq = act_load4(w, 4 * q);
+    const f32x4 s1 = act_load4(sums, 4 * q), s2 = act_load4(sums, C + 4 * q);
+    for (int m = blockIdx.x * RPB + r; m < (int)M; m += gridDim.x * RPB) {   // (32-bit row counters: the launchers take these kernels for M < 2^31 only)
+        const long i = (long)m * C + 4 * q;
+        const f32x4 gv = act_load4(g, i), yv = act_load4(y, i);
+        f32x4 gp;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gp[e] = gv[e] * (yv[e] > 0.f ? 1.f : slope);
+        if (gmask) { const f32x4 mk = act_load4(gmask, (long)(m / (int)N) * C + 4 * q); gp[0] *= mk[0]; gp[1] *= mk[1]; gp[2] *= mk[2]; gp[3] *= mk[3]; }
+        f32x4 v = gp;
+        if (training) {
+            const f32x4 xv = act_load4(x, i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] -= s1[e] * invM + (xv[e] - mean[e]) * rstd[e] * s2[e] * invM;
+        }
+        act_store4(gx, i, f32x4{rstd[0] * wq[0] * v[0], rstd[1] * wq[1] * v[1], rstd[2] * wq[2] * v[2], rstd[3] * wq[3] * v[3]});
+    }
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += NT) { gw[c] = sums[C + c]; gb[c] = sums[c]; }
+}
+
+static bool quad_shape_ok(int C, long M = 0) { return (C == 32 || C == 64 || C == 128 || C == 256) && M < (1l << 30); }
+static bool quad_aligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// rows per workgroup pass at width C; grids of the streaming kernels: ~4 passes per workgroup, at most `cap` workgroups
+static unsigned quad_grid(long M, int C, int passes, long cap)
+{
+    const long rpb = NT / (C / 4);
+    long gsz = (M + rpb * passes - 1) / (rpb * passes);
+    if (gsz > cap) gsz = cap;
+    if (gsz < 1) gsz = 1;
+    return (unsigned)gsz;
+}
+#define DLKA_QUAD_DISPATCH(C_, KERNEL, GRID, ...)                                                              \
+    switch (C_) {                                                                                              \
+    case 32: { auto k_ = KERNEL<8>; DLKA_LAUNCH(k_, dim3(GRID), dim3(NT), 0, st, __VA_ARGS__); } break;        \
+    case 64: { auto k_ = KERNEL<16>; DLKA_LAUNCH(k_, dim3(GRID), dim3(NT), 0, st, __VA_ARGS__); } break;       \
+    case 128: { auto k_ = KERNEL<32>; DLKA_LAUNCH(k_, dim3(GRID), dim3(NT), 0, st, __VA_ARGS__); } break;      \
+    default: { auto k_ = KERNEL<64>; DLKA_LAUNCH(k_, dim3(GRID), dim3(NT), 0, st, __VA_ARGS__); } break;       \
+    }
+
 int launch_cl_layernorm_fwd(const float *x, int x_planar, const float *pos, const float *w, const float *b, float *xt, float *xn, float *stats, int B, int N,
                             int C, float eps, hipStream_t st, int lo, float *xn32)
 {
     if (C > 64 * KMAX) return DLKA_ERR_UNSUPPORTED;
+    if (!x_planar && quad_shape_ok(C, (long)B * N) && quad_aligned(x) && quad_aligned(xt) && quad_aligned(xn) && quad_aligned(pos) && quad_aligned(xn32)) {
+        const long M = (long)B * N;
+        DLKA_QUAD_DISPATCH(C, cl_layernorm_fwd_q_kernel, quad_grid(M, C, 2, 4096), x, pos, w, b, xt, xn, stats, M, N, eps, lo, xn32)
+        DLKA_CHECK_LAUNCH();
+        return DLKA_OK;
+    }
     DLKA_LAUNCH(cl_layernorm_fwd_kernel, dim3(grid_for((long)B * N, NT / 64, 4096)), dim3(NT), 0, st, x, x_planar, pos, w, b, xt, xn, stats, B, N, C, eps, lo, xn32);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
@@ -396,6 +696,12 @@ int launch_cl_layernorm_bwd(const float *g, const float *g_res, const float *xt,
         DLKA_TRY_LAUNCH(launch_zero(gb, (size_t)C * 4, st));
         if (gpos) DLKA_TRY_LAUNCH(launch_zero(gpos, (size_t)N * C * 4, st));
     }
+    if (quad_shape_ok(C, (long)B * N) && quad_aligned(g) && quad_aligned(g_res) && quad_aligned(xt) && quad_aligned(gxt)) {
+        const long M = (long)B * N;
+        DLKA_QUAD_DISPATCH(C, cl_layernorm_bwd_q_kernel, quad_grid(M, C, 4, 1024), g, g_res, xt, stats, w, gxt, gw, gb, gpos, M, N, lo)
+        DLKA_CHECK_LAUNCH();
+        return DLKA_OK;
+    }
     DLKA_LAUNCH(cl_layernorm_bwd_kernel, dim3(grid_for((long)B * N, NT / 64, 1024)), dim3(NT), (NT / 64) * 2 * C * sizeof(float), st, g, g_res, xt, stats, w, gxt, gw, gb,
                        gpos, B, N, C, lo);
     DLKA_CHECK_LAUNCH();
@@ -404,6 +710,11 @@ int launch_cl_layernorm_bwd(const float *g, const float *g_res, const float *xt,
 
 int launch_cl_scale_residual_fwd(const float *xt, const float *e, const float *gamma, float *out, long M, int C, hipStream_t st, int lo)
 {
+    if (quad_shape_ok(C, M) && quad_aligned(xt) && quad_aligned(e) && quad_aligned(out)) {
+        DLKA_QUAD_DISPATCH(C, cl_scale_residual_fwd_q_kernel, quad_grid(M, C, 2, 4096), xt, e, gamma, out, M, lo)
+        DLKA_CHECK_LAUNCH();
+        return DLKA_OK;
+    }
     DLKA_LAUNCH(cl_scale_residual_fwd_kernel, dim3(grid_for(M * C, NT)), dim3(NT), 0, st, xt, e, gamma, out, M, C, lo);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
@@ -412,6 +723,11 @@ int launch_cl_scale_residual_fwd(const float *xt, const float *e, const float *g
 int launch_cl_scale_residual_bwd(const float *g, const float *e, const float *gamma, float *ge, float *ggamma, long M, int C, hipStream_t st, bool zeroed, int lo)
 {
     if (!zeroed) DLKA_TRY_LAUNCH(launch_zero(ggamma, (size_t)C * 4, st));
+    if (quad_shape_ok(C, M) && quad_aligned(g) && quad_aligned(e) && quad_aligned(ge)) {
+        DLKA_QUAD_DISPATCH(C, cl_scale_residual_bwd_q_kernel, quad_grid(M, C, 4, 1024), g, e, gamma, ge, ggamma, M, lo)
+        DLKA_CHECK_LAUNCH();
+        return DLKA_OK;
+    }
     const int rpb = NT / (C < NT ? C : NT);
     DLKA_LAUNCH(cl_scale_residual_bwd_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), C * sizeof(float), st, g, e, gamma, ge, ggamma, M, C, lo);
     DLKA_CHECK_LAUNCH();
@@ -423,7 +739,10 @@ int launch_cl_bn_stats(const float *x, float *sums, float *stats, long M, int C,
 {
     if (!zeroed) DLKA_TRY_LAUNCH(launch_zero(sums, (size_t)2 * C * 4, st));
     const int rpb = NT / (C < NT ? C : NT);
-    DLKA_LAUNCH(cl_bn_stats_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), 2 * C * sizeof(float), st, x, sums, M, C);
+    if (quad_shape_ok(C, M) && quad_aligned(x)) {
+        DLKA_QUAD_DISPATCH(C, cl_bn_stats_q_kernel, quad_grid(M, C, 8, 1024), x, sums, M)
+    } else
+        DLKA_LAUNCH(cl_bn_stats_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), 2 * C * sizeof(float), st, x, sums, M, C);
     DLKA_CHECK_LAUNCH();
     DLKA_LAUNCH(cl_bn_finish_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, x, (const float *)sums, stats, M, C, eps);
     DLKA_CHECK_LAUNCH();
@@ -433,6 +752,11 @@ int launch_cl_bn_stats(const float *x, float *sums, float *stats, long M, int C,
 int launch_cl_bn_apply(const float *x, const float *res, const float *w, const float *b, const float *stats, const float *mask, float *y, long M, long N, int C,
                        float slope, hipStream_t st)
 {
+    if (quad_shape_ok(C, M) && quad_aligned(x) && quad_aligned(res) && quad_aligned(y) && quad_aligned(stats) && quad_aligned(w) && quad_aligned(b) && quad_aligned(mask)) {
+        DLKA_QUAD_DISPATCH(C, cl_bn_apply_q_kernel, quad_grid(M, C, 2, 4096), x, res, w, b, stats, mask, y, M, N, slope)
+        DLKA_CHECK_LAUNCH();
+        return DLKA_OK;
+    }
     DLKA_LAUNCH(cl_bn_apply_kernel, dim3(grid_for(M * C, NT)), dim3(NT), 0, st, x, res, w, b, stats, mask, y, M, N, C, slope);
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
@@ -443,6 +767,14 @@ int launch_cl_bn_bwd(const float *g, const float *gmask, const float *x, const f
 {
     if (!zeroed) DLKA_TRY_LAUNCH(launch_zero(sums, (size_t)2 * C * 4, st));
     const int rpb = NT / (C < NT ? C : NT);
+    if (quad_shape_ok(C, M) && quad_aligned(g) && quad_aligned(x) && quad_aligned(y) && quad_aligned(gx) && quad_aligned(gres) && quad_aligned(gres_add) &&
+        quad_aligned(stats) && quad_aligned(sums) && quad_aligned(w) && quad_aligned(gmask)) {
+        DLKA_QUAD_DISPATCH(C, cl_bn_bwd_reduce_q_kernel, quad_grid(M, C, 4, 1024), g, gmask, x, y, stats, sums, gres, gres_add, M, N, slope)
+        DLKA_CHECK_LAUNCH();
+        DLKA_QUAD_DISPATCH(C, cl_bn_bwd_apply_q_kernel, quad_grid(M, C, 2, 4096), g, gmask, x, y, w, stats, (const float *)sums, gx, gw, gb, M, N, slope, training)
+        DLKA_CHECK_LAUNCH();
+        return DLKA_OK;
+    }
     DLKA_LAUNCH(cl_bn_bwd_reduce_kernel, dim3(grid_for(M, rpb * 16, 1024)), dim3(NT), 2 * C * sizeof(float), st, g, gmask, x, y, stats, sums, gres, gres_add, M, N, C, slope);
     DLKA_CHECK_LAUNCH();
     DLKA_LAUNCH(cl_bn_bwd_apply_kernel, dim3(grid_for(M * C, NT)), dim3(NT), 0, st, g, gmask, x, y, w, stats, (const float *)sums, gx, gw, gb, M, N, C, slope, training);

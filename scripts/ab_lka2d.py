@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""A/B of two builds of the library on the 2-D block metric (bench.lka2d_metric: config 2, bf16, B = 24) in ONE process on ONE box, interleaved rounds
-(box-to-box spread on the pool exceeds most single-kernel changes).  usage: python scripts/ab_lka2d.py OUT.json [alt_lib/libdlka_hip_prev.so]"""
+"""A/B of two builds of the library on the 2-D block metric (bench.lka2d_metric: config 2, bf16, B = 24) — or, with AB_METRIC=tblock, on the wrapper-block stack
+(bench.tblock_metric) — in ONE process on ONE box, interleaved rounds (box-to-box spread on the pool exceeds most single-kernel changes).
+usage: [AB_METRIC=tblock] python scripts/ab_lka2d.py OUT.json [alt_lib/libdlka_hip_prev.so]"""
 import ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,6 +22,10 @@ kern = {}
 for rnd in range(3):
     for name, lib in libs.items():
         L._lib = lib
+        if os.environ.get("AB_METRIC") == "tblock":
+            r = bench.tblock_metric(2, 10, 3, torch.device("cuda", 0))
+            res[name].append((r["value"], r.get("hipgraph", {}).get("value")))
+            continue
         r = bench.lka2d_metric(10, torch.device("cuda", 0), torch.bfloat16)
         res[name].append(r["value"])
         if "roofline" in r:
