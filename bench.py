@@ -50,6 +50,7 @@ def parse():
                     "(SURVEY §8d secondary metrics; ~1 min)")
     ap.add_argument("--no-companion", action="store_true", help="skip the same step measured with the other activation dtype (N = 1 only)")
     ap.add_argument("--no-tblock", action="store_true", help="skip the second metric (wrapper-block stack through nn.Module/autograd)")
+    ap.add_argument("--no-fullnet", action="store_true", help="skip the full-net trainer iteration (SURVEY section 8d metric iii; 5 timed iterations, ~10 s incl. building the net)")
     ap.add_argument("--no-lka2d", action="store_true", help="skip the 2-D block metric (BASELINE.json config 2: bf16, batch 24; ~0.15 s of GPU time)")
     ap.add_argument("--cpu-sample", default="stage", choices=["stage", "tiny"])
     return ap.parse_args()
@@ -706,7 +707,7 @@ def main():
         _lib._set_backend_for_tests(emu.load())
         torch.set_num_threads(1)
         dev = torch.device("cpu")
-        args.no_graph = args.no_roofline = args.no_cpu_baseline = args.no_companion = args.no_tblock = True
+        args.no_graph = args.no_roofline = args.no_cpu_baseline = args.no_companion = args.no_tblock = args.no_fullnet = args.no_lka2d = True
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
@@ -917,12 +918,19 @@ def main():
                 log("lka2d metric failed:", repr(e))
                 out["lka2d"] = None
             torch.cuda.empty_cache()
+        if not args.no_fullnet and world == 1 and dtype == torch.float32:   # SURVEY section 8d metric (iii) in the DEFAULT line (round-4 verdict: the driver never
+            try:                                                             # timed the net: --extras is not in its command)
+                out["fullnet"] = fullnet_metric(args.batch, 5, dev, bf16=False)
+            except Exception as e:
+                log("fullnet metric failed:", repr(e))
+                out["fullnet"] = None
+            torch.cuda.empty_cache()
         if args.extras and world == 1:
-            for key, fn in (("fullnet", lambda: fullnet_metric(args.batch, 5, dev, bf16=(dtype == torch.bfloat16))),
+            for key, fn in (("fullnet_bf16", lambda: fullnet_metric(args.batch, 5, dev, bf16=True)),
                             ("lka2d", lambda: lka2d_metric(5, dev, torch.bfloat16, with_cpu=not args.no_cpu_baseline)),   # BASELINE.json config 2: bf16, B=24
                             ("lka2d_f32", lambda: lka2d_metric(5, dev, torch.float32)), ("inference", lambda: inference_metric(dev)),
                             ("inference_config5", lambda: inference_config5_metric(dev))):
-                if dtype == torch.bfloat16 and key != "fullnet":
+                if dtype == torch.bfloat16:
                     continue
                 try:
                     out[key] = fn()
