@@ -38,6 +38,20 @@ def _offset_std_for(C: int, offset_std_voxels: float = 1.0) -> float:
     return offset_std_voxels * calib * 3.0 / math.sqrt(C * 27)
 
 
+def chain_order(stages: Sequence, order: str = "unet"):
+    """The chains (stage instances of up to CHAIN blocks) of a patch in EXECUTION order.
+
+    "unet" (default): the order D_LKA_Former's own forward pass visits them — the encoder's stage instances from the widest volume to the bottleneck, then the
+    decoder's back up (model_components.py:33-39 the encoder's four stages, :127-131 the decoder's; network_architecture/synapse/d_lka_former_synapse.py chains them):
+    of a stage's chains the first is the encoder's, the others the decoder's.  The backward pass runs it in reverse, i.e. it STARTS with the decoder's 32^3 blocks —
+    whose weight gradients (the largest of the step) then trail on the side stream under the small stages' data chains, which leave most of the chip idle.
+    "stages": stage by stage as the table lists them (rounds 1 - 4; DLKA_STACK_ORDER=stages), small stages first in the backward pass."""
+    per_stage = [[(C, dims, min(CHAIN, n - c0)) for c0 in range(0, n, CHAIN)] for C, dims, n in stages]
+    if order == "stages":
+        return [c for cs in per_stage for c in cs]
+    return [cs[0] for cs in per_stage if cs] + [c for cs in reversed(per_stage) for c in cs[1:]]
+
+
 class _Block:
     __slots__ = ("C", "dims", "params", "grads", "pstruct", "gstruct", "saved", "x", "y", "gx", "gy", "saved_bytes", "partials", "partials_bytes")
 
@@ -51,8 +65,10 @@ class DLKABlockStack:
         self.lib = L.get_lib()
         self.dt = L.DLKA_F32 if dtype == torch.float32 else L.DLKA_BF16
         gen = torch.Generator().manual_seed(seed)
+        self.order = os.environ.get("DLKA_STACK_ORDER", "unet")
+        chain_specs = chain_order(stages, self.order)
         shapes_all = []
-        for C, dims, n in stages:
+        for C, dims, n in chain_specs:
             for _ in range(n):
                 shapes_all.append((C, dims, _param_shapes(C)))
         total = sum(sum(int(torch.Size(s).numel()) for s in sh) for _, _, sh in shapes_all)
@@ -92,18 +108,17 @@ class DLKABlockStack:
         if data_seed is not None:
             gen = torch.Generator().manual_seed(int(data_seed))
         i = 0
-        for C, dims, n in stages:
-            for c0 in range(0, n, CHAIN):
-                chain = self.blocks[i + c0:i + min(c0 + CHAIN, n)]
-                shape = (batch, dims[0] * dims[1] * dims[2], C)   # token layout [B, N, C]
-                acts = [torch.randn(shape, generator=gen).to(self.device, dtype)] + \
-                       [torch.empty(shape, dtype=dtype, device=self.device) for _ in chain]
-                gacts = [torch.empty(shape, dtype=dtype, device=self.device) for _ in chain] + \
-                        [torch.randn(shape, generator=gen).to(self.device, dtype)]
-                for j, blk in enumerate(chain):
-                    blk.x, blk.y = acts[j], acts[j + 1]
-                    blk.gx, blk.gy = gacts[j], gacts[j + 1]
-                self.chains.append(chain)
+        for C, dims, n in chain_specs:
+            chain = self.blocks[i:i + n]
+            shape = (batch, dims[0] * dims[1] * dims[2], C)   # token layout [B, N, C]
+            acts = [torch.randn(shape, generator=gen).to(self.device, dtype)] + \
+                   [torch.empty(shape, dtype=dtype, device=self.device) for _ in chain]
+            gacts = [torch.empty(shape, dtype=dtype, device=self.device) for _ in chain] + \
+                    [torch.randn(shape, generator=gen).to(self.device, dtype)]
+            for j, blk in enumerate(chain):
+                blk.x, blk.y = acts[j], acts[j + 1]
+                blk.gx, blk.gy = gacts[j], gacts[j + 1]
+            self.chains.append(chain)
             i += n
 
     # reference initialisers: nn.Conv3d default (kaiming_uniform a=sqrt(5) + uniform bias), DeformConv weight/bias
@@ -174,15 +189,24 @@ class DLKABlockStack:
         self._prep_pending, self._prep_split = None, 0
         if not self._overlap:
             return
-        self.ws2 = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
+        # Workspaces of the backward pass, used round-robin: block n's data chain writes pool[n % K], its weight gradients read it on the side stream, and the
+        # data chain of block n + K waits for them.  K = 2 (rounds 2 - 4) ties the side stream to the data chain within one block; with the decoder's 32^3 blocks at
+        # the head of the backward pass (chain_order) a deeper pool lets their weight gradients trail under the small stages.  288 GB of HBM: 0.44 GB each.
+        # Measured (profiles/r08_notes.md, `r8e`): a deep ROUND-ROBIN pool is slower (K = 2 / 4 / 8 / 12: 10.50 / 10.71 / 10.86 / 11.03 ms per step) — the small
+        # stages' working sets then rotate through K x their size and fall out of the L2 / Infinity Cache.  So: two alternating workspaces as before, plus
+        # DLKA_STACK_TRAIL private ones for the FIRST blocks of the backward pass (the decoder's 32^3 chain), whose weight gradients may then trail freely.
+        self._trail = max(0, int(os.environ.get("DLKA_STACK_TRAIL", "0")))
+        self._pool_k = 2 + self._trail
+        self._ws_pool = [self.ws] + [torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device) for _ in range(self._pool_k - 1)]
+        self.ws2 = self._ws_pool[1]
         if self.device.type == "cuda":
             self._side = torch.cuda.Stream(device=self.device)
-            self._ev_data = [torch.cuda.Event() for _ in range(2)]
-            self._ev_wg = [torch.cuda.Event() for _ in range(2)]
+            self._ev_data = [torch.cuda.Event() for _ in range(self._pool_k)]
+            self._ev_wg = [torch.cuda.Event() for _ in range(self._pool_k)]
             self._ev_prep, self._ev_prep2 = torch.cuda.Event(), torch.cuda.Event()
             self._ev_fin = torch.cuda.Event()
             c0 = self.blocks[0].C
-            self._prep_split = sum(1 for b in self.blocks if b.C == c0)   # blocks of the first stage
+            self._prep_split = next((i for i, b in enumerate(self.blocks) if b.C != c0), len(self.blocks))   # the leading blocks of the first width
         else:
             self._side = None
 
@@ -247,7 +271,8 @@ class DLKABlockStack:
         plan_ptr = ctypes.c_void_p(self._fin_host.data_ptr()) if defer else None
         overlap = defer and getattr(self, "_overlap", False)
         side = self._side if overlap else None
-        used = [False, False]   # workspace k has weight gradients in flight on the side stream
+        K = self._pool_k if overlap else 2
+        used = [False] * K   # workspace k has weight gradients in flight on the side stream
         # Sealed plan + side stream: the folds of a block's partial sums follow its weight gradients ON THE SIDE STREAM, a few blocks per launch, instead
         # of one launch for the whole pass after the join (330 us exposed at the end of every step, profiles/r04s): that stream has the slack (the weight
         # gradients are ~40 % of a block's backward work) and only the last group's fold is left behind the last block.  DLKA_STACK_FINALIZE_GROUP=0:
@@ -267,8 +292,8 @@ class DLKABlockStack:
                 on_block(i)
             H, W, D = blk.dims
             if overlap:
-                k = n & 1
-                ws = self.ws if k == 0 else self.ws2
+                k = (2 + n) if n < K - 2 else ((n - (K - 2)) & 1)   # the first K - 2 blocks of the pass: a workspace of their own; then two alternate
+                ws = self._ws_pool[k]
                 record = not self._fin_sealed and i not in self._fin_recorded
                 args = (L.ptr(blk.x), byref(blk.pstruct), L.ptr(blk.gy), L.ptr(blk.saved), blk.saved_bytes, L.ptr(blk.gx), byref(blk.gstruct), L.ptr(ws),
                         self.ws_bytes, L.ptr(blk.partials), blk.partials_bytes)
@@ -322,7 +347,7 @@ class DLKABlockStack:
                                                             self.ws_bytes, self.B, blk.C, H, W, D, self.dt, st)
                 L.check(rc, "lka3d_attention_tokens_backward")
         if side is not None:   # join: the finalisation (and whatever follows the pass) is behind every weight gradient
-            for k in range(2):
+            for k in range(K):
                 if used[k]:
                     torch.cuda.current_stream(self.device).wait_event(self._ev_wg[k])
         if side_fin:
@@ -348,15 +373,20 @@ class DLKABlockStack:
         self.backward(on_block=on_block)
 
     def split_index(self, frac: float = 0.8) -> int:
-        """Block index i such that blocks[i:] hold at least `frac` of the gradient bytes and start a stage: the backward pass produces
-        those gradients FIRST (it runs the blocks in reverse), so their all-reduce can overlap the rest of the backward pass.  With the
-        Synapse stages the split falls in front of the C = 128 blocks: 84 % of the bytes after 25 % of the backward time."""
+        """Block index i such that blocks[i:] hold at least `frac` of the gradient bytes and start a chain (stage instance): the backward pass produces
+        those gradients FIRST (it runs the blocks in reverse), so their all-reduce can overlap the rest of the backward pass.  In the network's order
+        (chain_order) the split falls in front of the encoder's C = 128 chain: 92 % of the bytes, with the two widest encoder chains still to run."""
         sizes = [sum(int(p.numel()) for p in b.params) for b in self.blocks]
+        starts = set()
+        i = 0
+        for chain in self.chains:
+            starts.add(i)
+            i += len(chain)
         total, acc = sum(sizes), 0
         best = len(self.blocks)
         for i in range(len(self.blocks) - 1, -1, -1):
             acc += sizes[i]
-            if i == 0 or self.blocks[i].C != self.blocks[i - 1].C:   # stage boundary
+            if i in starts:
                 best = i
                 if acc >= frac * total:
                     break
