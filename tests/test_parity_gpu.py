@@ -358,7 +358,7 @@ def test_tokens_full_size_stage0_matches_general_path():
 
 def test_hipgraph_replay_reproduces_eager():
     """bench.py replays the 21-block step from a hipGraph: every replay must reproduce the eager result (a graph whose
-    zero-fills were hipMemsetAsync nodes did not, from the second replay on — scripts/debug_graph.py)."""
+    zero-fills were hipMemsetAsync nodes did not, from the second replay on — the round-2 investigation, profiles/design_history_r01_r03.md)."""
     from deformablelka_amd.stack import DLKABlockStack
     st = DLKABlockStack(2, stages=((32, (8, 8, 8), 1), (64, (8, 8, 8), 1), (256, (4, 4, 4), 1)), device="cuda:0", seed=3)
     st.forward_backward()
