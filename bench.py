@@ -319,7 +319,7 @@ def step_work(batch, dbytes):
     return fl, by
 
 
-def tblock_metric(batch, steps, warmup, dev):
+def tblock_metric(batch, steps, warmup, dev, overlap=True):
     """Second reported metric: the same 21 blocks INSIDE their wrapper (TransformerBlock_3D_single_deform_LKA: LayerNorm, gamma residual,
     UnetResBlock, conv8 — SURVEY.md §8 rows a1/f1), fwd+bwd through the nn.Module / autograd path, chained per stage instance."""
     import deformablelka_amd as dk
@@ -334,6 +334,7 @@ def tblock_metric(batch, steps, warmup, dev):
                 with torch.no_grad():
                     m.epa_block.spatial_gating_unit.deform_conv.conv_offset.weight.normal_(0, _offset_std_for(C))
                 m.keep_channels_last = True
+                m.wgrad_overlap = overlap   # the weight gradients on a side stream, joined at the end of backward() (transformerblock.WgradOverlap)
                 mods.append(m.to(dev))
             x = torch.randn(batch, H, W, D, C, device=dev).permute(0, 4, 1, 2, 3).requires_grad_(True)
             gy = torch.randn(batch, H, W, D, C, device=dev).permute(0, 4, 1, 2, 3)
@@ -361,7 +362,7 @@ def tblock_metric(batch, steps, warmup, dev):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     out = {"metric": "3D D-LKA transformer-block (wrapper + D-LKA) fwd+bwd volumes/sec (64x128x128)", "value": round(batch / dt, 3),
-           "unit": "volumes/s", "ms_per_step": round(dt * 1e3, 3), "path": "nn.Module + autograd, eager (no hipGraph), training mode",
+           "unit": "volumes/s", "ms_per_step": round(dt * 1e3, 3), "path": "nn.Module + autograd, eager (no hipGraph), training mode" + (", weight gradients on a side stream joined at the end of backward()" if overlap else ""),
            "blocks": sum(len(c[0]) for c in chains)}
     # the same nn.Module step captured in a hipGraph (autograd Functions launch on the capturing stream, outputs come from the graph's pool)
     try:

@@ -169,6 +169,8 @@ SIGNATURES = {
                                         c_void_p, c_size_t] + [c_int] * 5 + [ctypes.c_float, ctypes.c_float, c_int, c_int, c_void_p]),
     "dlka_tblock3d_backward_v": (c_int, [POINTER(TBlock3dPtrs), POINTER(Lka3dPtrs), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
                                          POINTER(TBlock3dPtrs), POINTER(Lka3dPtrs), c_void_p, c_size_t] + [c_int] * 7 + [c_void_p]),
+    "dlka_tblock3d_backward_phase_v": (c_int, [POINTER(TBlock3dPtrs), POINTER(Lka3dPtrs), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                         POINTER(TBlock3dPtrs), POINTER(Lka3dPtrs), c_void_p, c_size_t] + [c_int] * 8 + [c_void_p]),
     "dlka_trace_start": (c_int, [c_int, c_void_p]),
     "dlka_trace_mark": (c_int, [c_void_p]),
     "dlka_trace_stop": (c_int, []),

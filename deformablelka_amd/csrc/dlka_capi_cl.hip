@@ -2006,7 +2006,8 @@ size_t dlka_tblock3d_workspace_bytes_v(int B, int C, int D, int H, int W, int dt
     if (!dlka_tblock3d_supported_v(B, C, D, H, W, dtype, variant)) return 0;
     TBlockGeoms G(B, C, D, H, W);
     return align256(dlka_lka3d_tokens_workspace_bytes_v(B, C, D, H, W, dtype, variant)) + align256(G.wp_floats() * 4) + 2 * align256(G.part_floats() * 4) +
-           align256(cl_wgrad_part_floats(G.pw.M, 1, G.pw.Cout, G.pw.Cin) * 4) + 6 * align256(G.E * 4) + align256(4096);
+           align256(cl_wgrad_part_floats(G.pw.M, 1, G.pw.Cout, G.pw.Cin) * 4) + 6 * align256(G.E * 4) + align256(4096) +
+           align256(dlka_lka3d_tokens_partials_bytes_v(B, C, D, H, W, dtype, variant));   // (the phased backward's partial sums of the attention: dlka_tblock3d_backward_phase_v)
 }
 
 int dlka_tblock3d_forward(const void *x, int x_planar, const dlka_tblock3d_params *p, const dlka_lka3d_params *lka, const void *drop_mask, int training,
@@ -2095,6 +2096,21 @@ int dlka_tblock3d_backward_v(const dlka_tblock3d_params *p, const dlka_lka3d_par
                              const dlka_lka3d_grads *glka, void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant,
                              void *stream)
 {
+    return dlka_tblock3d_backward_phase_v(p, lka, drop_mask, training, bn_stats, grad_y, saved, saved_bytes, grad_x, gr, glka, workspace, workspace_bytes, B, C, D, H, W,
+                                          dtype, variant, 0, stream);
+}
+
+// phase 0: the whole backward pass (dlka_tblock3d_backward_v).  phase 1: the DATA-gradient chain only — grad_x and every gradient a data kernel produces on its
+// way (LayerNorm / BatchNorm affine parameters, gamma, pos_embed) — leaving in `workspace` what phase 2 reads; phase 2: the wrapper's three conv weight gradients, the
+// attention's weight gradients and the fold of their partial sums, reading `workspace` as phase 1 left it.  A caller that issues phase 2 on another stream (behind an
+// event recorded after phase 1, same `workspace`, which must stay untouched until phase 2 has run) lets a block's weight gradients overlap the NEXT block's data
+// chain: what the block-stack engine does for the bare attention (dlka_lka3d_attention_tokens_backward_phase_v), here for the block the trainers call.
+int dlka_tblock3d_backward_phase_v(const dlka_tblock3d_params *p, const dlka_lka3d_params *lka, const void *drop_mask, int training, const void *bn_stats,
+                                   const void *grad_y, const void *saved, size_t saved_bytes, void *grad_x, const dlka_tblock3d_grads *gr,
+                                   const dlka_lka3d_grads *glka, void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant,
+                                   int phase, void *stream)
+{
+    if (phase < 0 || phase > 2) return DLKA_ERR_SHAPE;
     if (!p || !lka || !bn_stats || !grad_y || !saved || !grad_x || !gr || !glka || !workspace) return DLKA_ERR_NULL;
     if (!gr->norm_w || !gr->norm_b || !gr->gamma || !gr->conv51_conv1_w || !gr->conv51_conv2_w || !gr->conv51_norm1_w || !gr->conv51_norm1_b ||
         !gr->conv51_norm2_w || !gr->conv51_norm2_b || !gr->conv8_w || !gr->conv8_b)
@@ -2114,13 +2130,30 @@ int dlka_tblock3d_backward_v(const dlka_tblock3d_params *p, const dlka_lka3d_par
     float *b0 = (float *)cv.take(G.E * 4), *b1 = (float *)cv.take(G.E * 4), *b2 = (float *)cv.take(G.E * 4), *b3 = (float *)cv.take(G.E * 4);
     float *b4 = (float *)cv.take(G.E * 4), *b5 = (float *)cv.take(G.E * 4);
     float *sums = (float *)cv.take(4096);
+    const size_t lka_part_bytes = dlka_lka3d_tokens_partials_bytes_v(B, C, D, H, W, dtype, variant);
+    void *lka_part = cv.take(lka_part_bytes);   // the attention's partial sums when the pass is split (phase 1 / 2): outside its own workspace
     if (!cv.ok()) return DLKA_ERR_WORKSPACE;
     const long M = (long)G.M, N = G.c3.N;
     const float *st1 = (const float *)bn_stats, *st2 = st1 + 3 * C;
     const float *gy = (const float *)grad_y, *mask = (const float *)drop_mask;
     const float slope = 0.01f;
     const int lo = dtype == DLKA_BF16 ? 1 : 0;   // g_e / g_xn are bf16 storage (the D-LKA attention ran DLKA_BF16)
-    float *g_rd = b0, *g_c2 = b1, *g_skip = b2, *g_attn = b3, *g_a1 = b4, *g_c1 = b1, *g_e = b4, *g_xn = b5;
+    // (g_c1 lives in b0 — g_rd is dead by then —, not beside g_c2 in b1: phase 2 reads BOTH g_c2 and g_c1 after the data chain has finished)
+    float *g_rd = b0, *g_c2 = b1, *g_skip = b2, *g_attn = b3, *g_a1 = b4, *g_c1 = b0, *g_e = b4, *g_xn = b5;
+    if (phase == 2) {   // the weight gradients alone, from what phase 1 left in `workspace`
+        FinalizeBatch fb2;
+        memset(&fb2, 0, sizeof(fb2));
+        DLKA_TRY(dense_backward_weight(G.pw, S.rd, gy, 0, (float *)gr->conv8_w, (float *)gr->conv8_b, part8, st, &fb2.j[fb2.njobs++]));
+        DLKA_TRY(dense_backward_weight(G.c3, S.a1, g_c2, 0, (float *)gr->conv51_conv2_w, nullptr, part2, st, &fb2.j[fb2.njobs++]));
+        DLKA_TRY(dense_backward_weight(G.c3, S.attn, g_c1, 0, (float *)gr->conv51_conv1_w, nullptr, part1, st, &fb2.j[fb2.njobs++]));
+        FinalizeJob jobs[FIN_JOBS_PER_BLOCK];
+        int nj = 0;
+        DLKA_TRY(tokens_backward_impl(S.xn, lka, g_e, S.lka, S.lka_bytes, g_xn, glka, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, variant, stream, lka_part,
+                                      lka_part_bytes, jobs, &nj, 2));
+        if (fb2.njobs + nj > (int)(sizeof(fb2.j) / sizeof(fb2.j[0]))) return DLKA_ERR_UNSUPPORTED;
+        for (int k = 0; k < nj; ++k) fb2.j[fb2.njobs++] = jobs[k];
+        return launch_cl_wgrad_finalize(fb2, st);
+    }
     // everything this direction accumulates into with atomics, zero-filled by ONE launch; the weight re-layouts were done by the forward call;
     // the three weight-gradient folds are ONE launch
     {
@@ -2138,26 +2171,32 @@ int dlka_tblock3d_backward_v(const dlka_tblock3d_params *p, const dlka_lka3d_par
     FinalizeBatch fb;
     memset(&fb, 0, sizeof(fb));
     // conv8[1]:  y = W8 rd + b8 + attn
-    DLKA_TRY(dense_backward_weight(G.pw, S.rd, gy, 0, (float *)gr->conv8_w, (float *)gr->conv8_b, part8, st, &fb.j[fb.njobs++]));
+    if (phase == 0) DLKA_TRY(dense_backward_weight(G.pw, S.rd, gy, 0, (float *)gr->conv8_w, (float *)gr->conv8_b, part8, st, &fb.j[fb.njobs++]));
     DLKA_TRY(dense_backward_data(G.pw, gy, 0, nullptr, g_rd, S.w8_b, 0, nullptr, st, nullptr, nullptr, true));
     // Dropout3d + LeakyReLU + (BN2(c2) + attn):  g_c2, and everything that flows into attn so far:  g_skip = gy + g_pre
     DLKA_TRY(launch_cl_bn_bwd(g_rd, mask, S.c2, S.rd, (const float *)p->conv51_norm2_w, st2, sums, g_c2, g_skip, gy, (float *)gr->conv51_norm2_w,
                               (float *)gr->conv51_norm2_b, M, N, C, slope, training, st, true));
     // conv2
-    DLKA_TRY(dense_backward_weight(G.c3, S.a1, g_c2, 0, (float *)gr->conv51_conv2_w, nullptr, part2, st, &fb.j[fb.njobs++]));
+    if (phase == 0) DLKA_TRY(dense_backward_weight(G.c3, S.a1, g_c2, 0, (float *)gr->conv51_conv2_w, nullptr, part2, st, &fb.j[fb.njobs++]));
     DLKA_TRY(dense_backward_data(G.c3, g_c2, 0, nullptr, g_a1, S.w2_b, 0, nullptr, st, nullptr, nullptr, true));
     // LeakyReLU + BN1
     DLKA_TRY(launch_cl_bn_bwd(g_a1, nullptr, S.c1, S.a1, (const float *)p->conv51_norm1_w, st1, sums + 512, g_c1, nullptr, nullptr, (float *)gr->conv51_norm1_w,
                               (float *)gr->conv51_norm1_b, M, N, C, slope, training, st, true));
     // conv1:  g_attn = W1^T g_c1 + g_skip
-    DLKA_TRY(dense_backward_weight(G.c3, S.attn, g_c1, 0, (float *)gr->conv51_conv1_w, nullptr, part1, st, &fb.j[fb.njobs++]));
+    if (phase == 0) DLKA_TRY(dense_backward_weight(G.c3, S.attn, g_c1, 0, (float *)gr->conv51_conv1_w, nullptr, part1, st, &fb.j[fb.njobs++]));
     // (the fold of the three conv weight gradients above rides in the D-LKA block's finalize launch below: one dependent launch less per block)
     DLKA_TRY(dense_backward_data(G.c3, g_c1, 0, nullptr, g_attn, S.w1_b, 3, g_skip, st, nullptr, nullptr, true));
     // attn = xt + gamma * e
     DLKA_TRY(launch_cl_scale_residual_bwd(g_attn, S.e, (const float *)p->gamma, g_e, (float *)gr->gamma, M, C, st, true, lo));
     // epa_block
-    DLKA_TRY(tokens_backward_impl(S.xn, lka, g_e, S.lka, S.lka_bytes, g_xn, glka, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, variant, stream, nullptr, 0, nullptr,
-                                  nullptr, 0, &fb));
+    if (phase == 1) {
+        FinalizeJob jobs[FIN_JOBS_PER_BLOCK];
+        int nj = 0;
+        DLKA_TRY(tokens_backward_impl(S.xn, lka, g_e, S.lka, S.lka_bytes, g_xn, glka, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, variant, stream, lka_part, lka_part_bytes,
+                                      jobs, &nj, 1));
+    } else
+        DLKA_TRY(tokens_backward_impl(S.xn, lka, g_e, S.lka, S.lka_bytes, g_xn, glka, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, variant, stream, nullptr, 0, nullptr,
+                                      nullptr, 0, &fb));
     // LayerNorm (+ the residual branch g_attn), pos_embed
     DLKA_TRY(launch_cl_layernorm_bwd(g_xn, g_attn, S.xt, S.lnstats, (const float *)p->norm_w, (float *)grad_x, (float *)gr->norm_w, (float *)gr->norm_b,
                                      (float *)gr->pos_embed, B, (int)N, C, st, true, lo));

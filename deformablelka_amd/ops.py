@@ -710,8 +710,13 @@ def tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_s
     return y, saved
 
 
-def tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, grad_y, saved, dims, variant=0, lka_bf16=False):
-    """Returns (grad_x tokens [B, N, C], grads of tparams (None where the parameter is None), grads of lka_params)."""
+def tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, grad_y, saved, dims, variant=0, lka_bf16=False, side_stream=None):
+    """Returns (grad_x tokens [B, N, C], grads of tparams (None where the parameter is None), grads of lka_params).
+
+    side_stream (a torch.cuda.Stream, optional): the pass is issued in two parts (``dlka_tblock3d_backward_phase_v``) — the data-gradient chain on the current stream,
+    the weight gradients on ``side_stream`` behind an event — and NOT joined: every returned tensor that phase 2 writes is then complete only once the current stream has
+    waited for ``side_stream`` (the caller's job: ``transformerblock.WgradOverlap`` joins once per backward pass).  The returned fourth element is the list of tensors
+    that must stay alive until that join."""
     L.require_device(grad_y, saved, bn_stats)
     grad_y = grad_y.contiguous()
     tparams = [None if t is None else t.contiguous() for t in tparams]
@@ -730,10 +735,26 @@ def tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, grad_y
     lk = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, lka_params)
     gs = _opt_ptr_struct(L.TBlock3dPtrs, L.TBLOCK3D_FIELDS, tg)
     gl = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, lg)
-    rc = lib.dlka_tblock3d_backward_v(byref(ps), byref(lk), L.ptr(drop_mask), int(bool(training)), L.ptr(bn_stats), L.ptr(grad_y), L.ptr(saved),
-                                      saved.numel(), L.ptr(gx), byref(gs), byref(gl), L.ptr(ws), wb, B, C, D, H, W, dt, int(variant), L.stream_ptr(grad_y))
-    L.check(rc, "tblock3d_backward")
-    return gx, tg, lg
+    args = (byref(ps), byref(lk), L.ptr(drop_mask), int(bool(training)), L.ptr(bn_stats), L.ptr(grad_y), L.ptr(saved),
+            saved.numel(), L.ptr(gx), byref(gs), byref(gl), L.ptr(ws), wb, B, C, D, H, W, dt, int(variant))
+    if side_stream is None:
+        L.check(lib.dlka_tblock3d_backward_v(*args, L.stream_ptr(grad_y)), "tblock3d_backward")
+        return gx, tg, lg
+    if isinstance(side_stream, str):   # "inline": both parts back to back on the current stream (tests: the split pass equals the whole one)
+        L.check(lib.dlka_tblock3d_backward_phase_v(*args, 1, L.stream_ptr(grad_y)), "tblock3d_backward (data chain)")
+        L.check(lib.dlka_tblock3d_backward_phase_v(*args, 2, L.stream_ptr(grad_y)), "tblock3d_backward (weight gradients)")
+        return gx, tg, lg
+    cur = torch.cuda.current_stream(grad_y.device)
+    L.check(lib.dlka_tblock3d_backward_phase_v(*args, 1, L.stream_ptr(grad_y)), "tblock3d_backward (data chain)")
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    side_stream.wait_event(ev)
+    L.check(lib.dlka_tblock3d_backward_phase_v(*args, 2, ctypes.c_void_p(side_stream.cuda_stream)), "tblock3d_backward (weight gradients)")
+    keep = [ws, grad_y, saved, bn_stats, drop_mask, *[t for t in tparams if t is not None], *lka_params, *[t for t in tg if t is not None], *lg]
+    for t in keep:   # the caching allocator must not hand these blocks out again before the side stream is done with them
+        if t is not None:
+            t.record_stream(side_stream)
+    return gx, tg, lg, keep
 
 
 # ---- the wrapper's pieces, one by one (used by UnetResBlock standalone and by the parity tests) ---------------------------

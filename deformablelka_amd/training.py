@@ -16,14 +16,28 @@ from .transformerblock import TransformerBlock_3D_single_deform_LKA
 
 def initialize_network(input_channels: int = 1, num_classes: int = 14, crop_size: Sequence[int] = (64, 128, 128), depths=(3, 3, 3, 3),
                        skip_connections=(True, True, True, True), trans_block=TransformerBlock_3D_single_deform_LKA, device=None,
-                       patch_size=(2, 4, 4)) -> D_LKA_Former:
-    """d_lka_former_trainer_synapse.py:158-185 (the fvcore FLOP count of :186-193 is logging only)."""
+                       patch_size=(2, 4, 4), wgrad_overlap: bool = True) -> D_LKA_Former:
+    """d_lka_former_trainer_synapse.py:158-185 (the fvcore FLOP count of :186-193 is logging only).
+    wgrad_overlap: the D-LKA transformer blocks issue their weight gradients on a side stream joined at the end of ``backward()`` (transformerblock.WgradOverlap: the
+    block-stack engine's schedule for the nn.Module path).  Right for this trainer's loop (``run_iteration``: zero_grad(set_to_none) -> backward -> clip -> step);
+    ``wrap_data_parallel`` switches it off again, DistributedDataParallel reads gradients while the pass is still running."""
     net = D_LKA_Former(in_channels=input_channels, out_channels=num_classes, img_size=crop_size, feature_size=16, num_heads=4, depths=list(depths),
                        dims=[32, 64, 128, 256], do_ds=True, trans_block=trans_block, skip_connections=list(skip_connections), patch_size=patch_size)
     if device is not None:
         net = net.to(device)
     net.inference_apply_nonlin = lambda x: torch.softmax(x, 1)
+    set_wgrad_overlap(net, wgrad_overlap)
     return net
+
+
+def set_wgrad_overlap(net: nn.Module, on: bool) -> int:
+    """Switch the side-stream weight-gradient schedule of every D-LKA transformer block of `net` (see transformerblock.WgradOverlap for its contract); returns how many."""
+    n = 0
+    for m in net.modules():
+        if hasattr(type(m), "wgrad_overlap"):
+            m.wgrad_overlap = bool(on)
+            n += 1
+    return n
 
 
 def initialize_optimizer(net: nn.Module, initial_lr: float = 1e-2, weight_decay: float = 3e-5, fused=None):
@@ -52,6 +66,7 @@ def wrap_data_parallel(net: nn.Module, device, find_unused_parameters: bool = Fa
         return net
     dev = torch.device(device)
     ids = [dev.index] if dev.type == "cuda" else None
+    set_wgrad_overlap(net, False)   # (DDP's bucket hooks read a gradient as soon as autograd hands it over: it must be complete by then)
     return nn.parallel.DistributedDataParallel(net, device_ids=ids, find_unused_parameters=find_unused_parameters, bucket_cap_mb=bucket_cap_mb,
                                                gradient_as_bucket_view=True)
 

@@ -6,6 +6,8 @@ constructor / forward signatures and ``state_dict`` keys of
 offset-predict conv, deformable 3^3 conv, conv1, gate, proj_2, residual) as ONE C-ABI call per direction
 (``dlka_lka3d_attention_forward/backward``).  ``LKA3d_deform`` alone runs through the per-op kernels.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -127,15 +129,56 @@ class LKA_Attention3d_deform(nn.Module):
         return x
 
 
+class WgradOverlap:
+    """The engine's schedule for the path the trainers call (DLKABlockStack does it for the bare attention, stack.py): a wrapper block's backward pass is issued in two
+    parts — the data-gradient chain on the current stream, its weight gradients (conv51's two convs, conv8, the attention's seven) on a side stream behind an event
+    (``dlka_tblock3d_backward_phase_v``) — and the side stream is joined ONCE, at the end of the whole backward pass (``queue_callback``), so that a block's weight
+    gradients run under the NEXT block's data chain instead of in front of it.
+
+    Contract (why it is opt-in, ``module.wgrad_overlap = True``; ``training.initialize_network`` / ``bench.py`` set it for their single-process loops): the parameter
+    gradients a block's backward returns are complete only when ``backward()`` has returned.  Nothing may read them earlier: no DistributedDataParallel / gradient hooks
+    (``training.wrap_data_parallel`` switches it off), and gradients are not accumulated into existing ``.grad`` tensors (a block whose parameters already carry a
+    ``.grad`` takes the one-stream pass for that call).  One instance per device; works under hipGraph capture (the events become a fork / join in the graph)."""
+    _by_device = {}
+
+    @classmethod
+    def get(cls, device):
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        o = cls._by_device.get(key)
+        if o is None:
+            o = cls._by_device[key] = cls(torch.device(*key))
+        return o
+
+    def __init__(self, device):
+        self.device = device
+        self.side = torch.cuda.Stream(device=device)
+        self.pending = []
+        self.armed = False
+
+    def submit(self, keep):
+        self.pending.append(keep)
+        if not self.armed:
+            self.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.join)
+
+    def join(self):
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        torch.cuda.current_stream(self.device).wait_event(ev)
+        self.pending.clear()
+        self.armed = False
+
+
 class _TBlock3dFn(Function):
     """The whole wrapper block: one C-ABI call per direction (``dlka_tblock3d_forward/backward``)."""
 
     @staticmethod
     def forward(ctx, x, x_planar, dims, drop_mask, training, bn_stats, eps, variant, *params):
-        variant, lka_bf16 = variant if isinstance(variant, tuple) else (variant, False)
+        variant, lka_bf16, owner = (tuple(variant) + (False, None))[:3] if isinstance(variant, tuple) else (variant, False, None)
         tparams, lka_params = params[:12], params[12:]
         y, saved = ops.tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_stats, dims, eps[0], eps[1], variant, lka_bf16)
         ctx.cfg = (x_planar, dims, training, tuple(x.shape), [p is not None for p in tparams], (variant, lka_bf16))
+        ctx.owner = owner   # a weak reference to the module when it asked for the side-stream schedule (WgradOverlap), else None
         ctx.save_for_backward(saved, bn_stats, drop_mask, *[p for p in params if p is not None])
         return y
 
@@ -147,7 +190,13 @@ class _TBlock3dFn(Function):
         it = iter(ps)
         tparams = [next(it) if here else None for here in present]
         lka_params = list(it)
-        gx, tg, lg = ops.tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, gy, saved, dims, variant, lka_bf16)
+        mod = ctx.owner() if ctx.owner is not None else None
+        if mod is not None and gy.is_cuda and all(p.grad is None for p in mod.parameters()):
+            ov = WgradOverlap.get(gy.device)
+            gx, tg, lg, keep = ops.tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, gy, saved, dims, variant, lka_bf16, side_stream=ov.side)
+            ov.submit(keep)
+        else:
+            gx, tg, lg = ops.tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, gy, saved, dims, variant, lka_bf16)
         if x_planar:   # gradient w.r.t. the NCDHW input: tokens -> NCDHW.  A contiguous tensor, not the permuted view: the producer of x is a
             # torch layer whose backward (MIOpen) falls to its naive "nonpacked" kernels on a strided grad_output (profiles/r03e: 61 % of a
             # full-net step)
@@ -167,6 +216,7 @@ class TransformerBlock_3D_single_deform_LKA(nn.Module):
     the layout and reads the tokens in place.  ``deformablelka_amd.network`` sets it on the blocks it chains."""
 
     keep_channels_last = False
+    wgrad_overlap = False   # True: the backward pass's weight gradients on a side stream, joined at the end of backward() — see WgradOverlap for the contract
     EPA_BLOCK = LKA_Attention3d_deform
 
     def __init__(self, input_size: int, hidden_size: int, proj_size: int, num_heads: int, dropout_rate: float = 0.0, pos_embed=False) -> None:
@@ -223,7 +273,8 @@ class TransformerBlock_3D_single_deform_LKA(nn.Module):
             stats = torch.empty(6 * C, dtype=torch.float32, device=x.device)
         else:
             stats = torch.cat([bn_eval_stats(c.norm1), bn_eval_stats(c.norm2)])
-        y = _TBlock3dFn.apply(xin, planar, (H, W, D), mask, training, stats, (self.norm.eps, c.norm1.eps), (v, bool(lka_bf16)), *self.wrapper_params(),
+        owner = weakref.ref(self) if (self.wgrad_overlap and x.is_cuda) else None
+        y = _TBlock3dFn.apply(xin, planar, (H, W, D), mask, training, stats, (self.norm.eps, c.norm1.eps), (v, bool(lka_bf16), owner), *self.wrapper_params(),
                               *self.epa_block.block_params())
         if training:
             bn_update_running((c.norm1, stats[:3 * C]), (c.norm2, stats[3 * C:]))

@@ -516,6 +516,14 @@ int dlka_tblock3d_backward_v(const dlka_tblock3d_params *p, const dlka_lka3d_par
                              const void *bn_stats, const void *grad_y, const void *saved, size_t saved_bytes, void *grad_x,
                              const dlka_tblock3d_grads *grads, const dlka_lka3d_grads *lka_grads,
                              void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant, void *stream);
+/* The same pass in two parts (phase 0 = dlka_tblock3d_backward_v).  phase 1: the DATA-gradient chain — grad_x and the gradients its own kernels produce (norm / norm1 /
+ * norm2 affine parameters, gamma, pos_embed) —, leaving in `workspace` what phase 2 reads; phase 2: the weight gradients of conv51.conv1 / conv2, conv8 and of the D-LKA
+ * attention, and the fold of their partial sums.  Issue phase 2 on another stream behind an event recorded after phase 1 (same arguments; `workspace` untouched in
+ * between) and a block's weight gradients overlap the next block's data chain (deformablelka_amd/transformerblock.py: wgrad_overlap). */
+int dlka_tblock3d_backward_phase_v(const dlka_tblock3d_params *p, const dlka_lka3d_params *lka, const void *drop_mask, int training, const void *bn_stats,
+                                   const void *grad_y, const void *saved, size_t saved_bytes, void *grad_x, const dlka_tblock3d_grads *grads,
+                                   const dlka_lka3d_grads *lka_grads, void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype,
+                                   int variant, int phase, void *stream);
 
 /* =======================================================================================
  * Launch trace — measurement aid (no reference counterpart; the reference has no profiling hooks)

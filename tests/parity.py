@@ -957,3 +957,32 @@ def check_tblock3d_mixed_bf16(dev, B, C, dims, training=True, seed=0, offset_std
         lim = max(rtol, 2.0 * model[k])
         assert errs[k] <= lim, f"tblock mixed bf16 {k} (bn bias {bn_bias}): rel err vs the fp32 oracle {errs[k]:.3e} > {lim:.3e} (model vs oracle {model[k]:.3e})"
     return errs
+
+
+def check_tblock3d_phased_backward(dev, B, C, dims, lka_bf16=False, seed=0):
+    """dlka_tblock3d_backward_phase_v: the data chain (phase 1) followed by the weight gradients (phase 2) gives what the one-call pass (phase 0) gives — the same
+    kernels on the same operands; only the order of a few fp32 atomics (tap-split / chunk-split outputs, LayerNorm / BatchNorm channel sums) may differ."""
+    import deformablelka_amd as dk
+    from deformablelka_amd import ops
+    from oracle import blocks
+    torch.manual_seed(seed)
+    H, W, D = dims
+    m = dk.TransformerBlock_3D_single_deform_LKA(H * W * D, C, C, 4, dropout_rate=0.1, pos_embed=True)
+    blocks.randomize_offsets_(m, std=0.3)
+    m = m.to(dev).train()
+    x = torch.randn(B, H * W * D, C, device=dev)
+    gy = torch.randn(B, H * W * D, C, device=dev)
+    tparams = [None if p is None else p.detach() for p in m.wrapper_params()]
+    lparams = [p.detach() for p in m.epa_block.block_params()]
+    stats = torch.empty(6 * C, dtype=torch.float32, device=dev)
+    mask = torch.ones(B, C, device=dev)
+    y, saved = ops.tblock3d_forward(x, False, tparams, lparams, mask, True, stats, dims, 1e-5, 1e-5, 0, lka_bf16)
+    whole = ops.tblock3d_backward(tparams, lparams, mask, True, stats, gy, saved, dims, 0, lka_bf16)
+    split = ops.tblock3d_backward(tparams, lparams, mask, True, stats, gy, saved, dims, 0, lka_bf16, side_stream="inline")
+
+    def flat(r):
+        return [r[0]] + [t for t in r[1] if t is not None] + list(r[2])
+    for k, (a_, b_) in enumerate(zip(flat(whole), flat(split))):
+        assert torch.isfinite(b_).all(), k
+        scale = max(float(a_.abs().max()), 1e-6)
+        assert float((a_.float() - b_.float()).abs().max()) <= 2e-3 * scale, (k, float((a_.float() - b_.float()).abs().max()), scale)

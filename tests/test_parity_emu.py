@@ -712,3 +712,9 @@ def test_dwconv_two_output_planes(case, monkeypatch):
     monkeypatch.delenv("DLKA_DW_TD2")
     y1 = ops.conv3d_forward_cl(x, w, bias, p, d, C)
     assert torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize("C,dims,bf", [(32, (3, 4, 5), False), (64, (2, 4, 3), True)])
+def test_tblock3d_phased_backward_equals_one_call(C, dims, bf):
+    """dlka_tblock3d_backward_phase_v (round 5: the engine's data-chain / weight-gradient split for the wrapper block): phase 1 then phase 2 == phase 0."""
+    parity.check_tblock3d_phased_backward("cpu", 2, C, dims, lka_bf16=bf)

@@ -874,3 +874,73 @@ def test_fork_contexts_follow_the_device():
     with torch.cuda.device(0):
         with pytest.raises(RuntimeError, match="current device"):
             ops.lka2d_attention_forward(x.to("cuda:1"), [p.detach() for p in m2.to("cuda:1").block_params()])
+
+
+@pytest.mark.parametrize("C,dims,bf", [(32, (32, 32, 32), False), (64, (16, 16, 16), True), (128, (8, 8, 8), False), (256, (4, 4, 4), False)])
+def test_tblock3d_phased_backward_equals_one_call(C, dims, bf):
+    parity.check_tblock3d_phased_backward(DEV, 2, C, dims, lka_bf16=bf)
+
+
+def test_tblock3d_wgrad_overlap_equals_one_stream():
+    """``module.wgrad_overlap = True`` (transformerblock.WgradOverlap): a chain of three wrapper blocks whose weight gradients run on the side stream and are joined once,
+    at the end of backward(), against the same chain on one stream — every gradient equal up to atomics order, eager and replayed from a hipGraph; and a block whose
+    parameters already carry a .grad (accumulation) takes the one-stream pass."""
+    import deformablelka_amd as dk
+    from oracle import blocks
+    torch.manual_seed(5)
+    C, (H, W, D) = 64, (16, 16, 16)
+    mods = []
+    for _ in range(3):
+        m = dk.TransformerBlock_3D_single_deform_LKA(H * W * D, C, C, 4, dropout_rate=0.1, pos_embed=True)
+        blocks.randomize_offsets_(m, std=0.3)
+        m.keep_channels_last = True
+        m._draw_drop_mask = lambda B_, C_, dtype, device: torch.ones(B_, C_, dtype=dtype, device=device)   # (the same mask in every run)
+        mods.append(m.to(DEV).train())
+    x = torch.randn(2, H, W, D, C, device=DEV).permute(0, 4, 1, 2, 3).requires_grad_(True)
+    gy = torch.randn(2, H, W, D, C, device=DEV).permute(0, 4, 1, 2, 3)
+    params = [p for m in mods for p in m.parameters()]
+
+    def run(overlap):
+        for m in mods:
+            m.wgrad_overlap = overlap
+        for p in params + [x]:
+            p.grad = None
+        y = x
+        for m in mods:
+            y = m(y)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        return [x.grad.clone()] + [p.grad.clone() for p in params]
+
+    ref = run(False)
+    from deformablelka_amd.transformerblock import WgradOverlap
+    got = run(True)
+    assert WgradOverlap.get(torch.device(DEV)).pending == [] and not WgradOverlap.get(torch.device(DEV)).armed   # joined, nothing kept alive
+    for k, (a_, b_) in enumerate(zip(ref, got)):
+        scale = max(float(a_.abs().max()), 1e-6)
+        assert torch.isfinite(b_).all() and float((a_ - b_).abs().max()) <= 2e-3 * scale, ("eager", k)
+    # replayed from a graph
+    for m in mods:
+        m.wgrad_overlap = True
+    for p in params + [x]:
+        p.grad = None
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y = x
+        for m in mods:
+            y = m(y)
+        y.backward(gy)
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    got = [x.grad.clone()] + [p.grad.clone() for p in params]
+    for k, (a_, b_) in enumerate(zip(ref, got)):
+        scale = max(float(a_.abs().max()), 1e-6)
+        assert torch.isfinite(b_).all() and float((a_ - b_).abs().max()) <= 2e-3 * scale, ("graph", k)
+    # accumulation into existing .grad tensors: the one-stream pass (2 x the gradient afterwards)
+    y = x
+    for m in mods:
+        y = m(y)
+    y.backward(gy)
+    torch.cuda.synchronize()
+    assert float((params[0].grad - 2 * ref[1]).abs().max()) <= 4e-3 * max(float(ref[1].abs().max()), 1e-6)
