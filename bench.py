@@ -319,7 +319,7 @@ def step_work(batch, dbytes):
     return fl, by
 
 
-def tblock_metric(batch, steps, warmup, dev, overlap=True):
+def tblock_metric(batch, steps, warmup, dev, overlap=False):
     """Second reported metric: the same 21 blocks INSIDE their wrapper (TransformerBlock_3D_single_deform_LKA: LayerNorm, gamma residual,
     UnetResBlock, conv8 — SURVEY.md §8 rows a1/f1), fwd+bwd through the nn.Module / autograd path, chained per stage instance."""
     import deformablelka_amd as dk

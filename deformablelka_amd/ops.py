@@ -750,10 +750,11 @@ def tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, grad_y
     ev.record(cur)
     side_stream.wait_event(ev)
     L.check(lib.dlka_tblock3d_backward_phase_v(*args, 2, ctypes.c_void_p(side_stream.cuda_stream)), "tblock3d_backward (weight gradients)")
-    keep = [ws, grad_y, saved, bn_stats, drop_mask, *[t for t in tparams if t is not None], *lka_params, *[t for t in tg if t is not None], *lg]
-    for t in keep:   # the caching allocator must not hand these blocks out again before the side stream is done with them
-        if t is not None:
-            t.record_stream(side_stream)
+    # What phase 2 READS stays referenced until the caller's join: memory released after the join is reused by work that is ordered behind it, so no
+    # record_stream() is needed.  What it WRITES — the parameter gradients — must NOT be referenced: autograd's AccumulateGrad takes ownership of a returned
+    # gradient only while nobody else holds it, and would otherwise COPY it on the current stream, i.e. before the side stream has written it (seen as garbage
+    # gradients, profiles/r08_notes.md); as `.grad` they outlive the join by themselves.
+    keep = [ws, grad_y, saved, bn_stats, drop_mask]
     return gx, tg, lg, keep
 
 

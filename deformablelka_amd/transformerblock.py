@@ -6,6 +6,7 @@ constructor / forward signatures and ``state_dict`` keys of
 offset-predict conv, deformable 3^3 conv, conv1, gate, proj_2, residual) as ONE C-ABI call per direction
 (``dlka_lka3d_attention_forward/backward``).  ``LKA3d_deform`` alone runs through the per-op kernels.
 """
+import os
 import weakref
 
 import torch
@@ -138,8 +139,12 @@ class WgradOverlap:
     Contract (why it is opt-in, ``module.wgrad_overlap = True``; ``training.initialize_network`` / ``bench.py`` set it for their single-process loops): the parameter
     gradients a block's backward returns are complete only when ``backward()`` has returned.  Nothing may read them earlier: no DistributedDataParallel / gradient hooks
     (``training.wrap_data_parallel`` switches it off), and gradients are not accumulated into existing ``.grad`` tensors (a block whose parameters already carry a
-    ``.grad`` takes the one-stream pass for that call).  One instance per device; works under hipGraph capture (the events become a fork / join in the graph)."""
+    ``.grad`` takes the one-stream pass for that call).  It also relies on autograd taking OWNERSHIP of the gradient tensors this Function returns rather than copying them
+    (AccumulateGrad does so for a dense, contiguous, otherwise unreferenced gradient when ``.grad`` is None — which is what is returned); the GPU test
+    ``test_tblock3d_wgrad_overlap_equals_one_stream`` would see a copy as garbage.  One instance per device; works under hipGraph capture (the events become a fork /
+    join in the graph)."""
     _by_device = {}
+    disabled = os.environ.get("DLKA_TBLOCK_WGRAD_OVERLAP", "1") == "0"   # process-wide kill switch (A/B runs; tests compare both passes on ONE forward pass)
 
     @classmethod
     def get(cls, device):
@@ -191,7 +196,7 @@ class _TBlock3dFn(Function):
         tparams = [next(it) if here else None for here in present]
         lka_params = list(it)
         mod = ctx.owner() if ctx.owner is not None else None
-        if mod is not None and gy.is_cuda and all(p.grad is None for p in mod.parameters()):
+        if mod is not None and not WgradOverlap.disabled and gy.is_cuda and all(p.grad is None for p in mod.parameters()):
             ov = WgradOverlap.get(gy.device)
             gx, tg, lg, keep = ops.tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, gy, saved, dims, variant, lka_bf16, side_stream=ov.side)
             ov.submit(keep)

@@ -883,9 +883,11 @@ def test_tblock3d_phased_backward_equals_one_call(C, dims, bf):
 
 def test_tblock3d_wgrad_overlap_equals_one_stream():
     """``module.wgrad_overlap = True`` (transformerblock.WgradOverlap): a chain of three wrapper blocks whose weight gradients run on the side stream and are joined once,
-    at the end of backward(), against the same chain on one stream — every gradient equal up to atomics order, eager and replayed from a hipGraph; and a block whose
-    parameters already carry a .grad (accumulation) takes the one-stream pass."""
+    at the end of backward(), against the same backward pass on one stream (``WgradOverlap.disabled``) — ONE forward pass (a second one could flip a sampling cell
+    through atomics order), every gradient equal up to atomics order, eager and replayed from a hipGraph; and a block whose parameters already carry a .grad
+    (accumulation) takes the one-stream pass."""
     import deformablelka_amd as dk
+    from deformablelka_amd.transformerblock import WgradOverlap
     from oracle import blocks
     torch.manual_seed(5)
     C, (H, W, D) = 64, (16, 16, 16)
@@ -893,54 +895,65 @@ def test_tblock3d_wgrad_overlap_equals_one_stream():
     for _ in range(3):
         m = dk.TransformerBlock_3D_single_deform_LKA(H * W * D, C, C, 4, dropout_rate=0.1, pos_embed=True)
         blocks.randomize_offsets_(m, std=0.3)
+        with torch.no_grad():
+            m.gamma.normal_(0.5, 0.2)
         m.keep_channels_last = True
+        m.wgrad_overlap = True
         m._draw_drop_mask = lambda B_, C_, dtype, device: torch.ones(B_, C_, dtype=dtype, device=device)   # (the same mask in every run)
         mods.append(m.to(DEV).train())
     x = torch.randn(2, H, W, D, C, device=DEV).permute(0, 4, 1, 2, 3).requires_grad_(True)
     gy = torch.randn(2, H, W, D, C, device=DEV).permute(0, 4, 1, 2, 3)
     params = [p for m in mods for p in m.parameters()]
+    names = ["x"] + [f"m{i}.{k}" for i, m in enumerate(mods) for k, _ in m.named_parameters()]
+    ov = WgradOverlap.get(torch.device(DEV))
+    y = x
+    for m in mods:
+        y = m(y)
 
-    def run(overlap):
-        for m in mods:
-            m.wgrad_overlap = overlap
-        for p in params + [x]:
-            p.grad = None
-        y = x
-        for m in mods:
-            y = m(y)
-        y.backward(gy)
-        torch.cuda.synchronize()
+    def backward(disabled):
+        WgradOverlap.disabled = disabled
+        try:
+            for p in params + [x]:
+                p.grad = None
+            y.backward(gy, retain_graph=True)
+            torch.cuda.synchronize()
+        finally:
+            WgradOverlap.disabled = False
         return [x.grad.clone()] + [p.grad.clone() for p in params]
 
-    ref = run(False)
-    from deformablelka_amd.transformerblock import WgradOverlap
-    got = run(True)
-    assert WgradOverlap.get(torch.device(DEV)).pending == [] and not WgradOverlap.get(torch.device(DEV)).armed   # joined, nothing kept alive
-    for k, (a_, b_) in enumerate(zip(ref, got)):
-        scale = max(float(a_.abs().max()), 1e-6)
-        assert torch.isfinite(b_).all() and float((a_ - b_).abs().max()) <= 2e-3 * scale, ("eager", k)
-    # replayed from a graph
-    for m in mods:
-        m.wgrad_overlap = True
+    def same(tag, ref, got):
+        bad = [(n, float((a_ - b_).abs().max()) / max(float(a_.abs().max()), 1e-30)) for n, a_, b_ in zip(names, ref, got)
+               if not bool(torch.isfinite(b_).all()) or float((a_ - b_).abs().max()) > 2e-3 * max(float(a_.abs().max()), 1e-30)]
+        assert not bad, (tag, bad[:8])
+
+    ref = backward(True)
+    for rep in range(3):
+        same(f"eager {rep}", ref, backward(False))
+        assert ov.pending == [] and not ov.armed   # joined, nothing kept alive
+    # accumulation into existing .grad tensors: the one-stream pass (2 x the gradient afterwards)
+    for p in params + [x]:
+        p.grad = None
+    y.backward(gy, retain_graph=True)
+    y.backward(gy)
+    torch.cuda.synchronize()
+    k = names.index("m0.conv8.1.weight")
+    assert float((params[k - 1].grad - 2 * ref[k]).abs().max()) <= 4e-3 * max(float(ref[k].abs().max()), 1e-6)
+    del y   # (capturing a backward pass while an eager autograd graph of the same modules is still retained crashes inside run_backward on this torch / ROCm build,
+    #          with or without the side stream: scripts/debug_overlap3.py, profiles/r08_notes.md)
+    # replayed from a graph (forward + backward captured: the join is the last node of the backward pass)
     for p in params + [x]:
         p.grad = None
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        y = x
+        yy = x
         for m in mods:
-            y = m(y)
-        y.backward(gy)
+            yy = m(yy)
+        yy.backward(gy)
     for _ in range(2):
         g.replay()
     torch.cuda.synchronize()
     got = [x.grad.clone()] + [p.grad.clone() for p in params]
-    for k, (a_, b_) in enumerate(zip(ref, got)):
-        scale = max(float(a_.abs().max()), 1e-6)
-        assert torch.isfinite(b_).all() and float((a_ - b_).abs().max()) <= 2e-3 * scale, ("graph", k)
-    # accumulation into existing .grad tensors: the one-stream pass (2 x the gradient afterwards)
-    y = x
-    for m in mods:
-        y = m(y)
-    y.backward(gy)
-    torch.cuda.synchronize()
-    assert float((params[0].grad - 2 * ref[1]).abs().max()) <= 4e-3 * max(float(ref[1].abs().max()), 1e-6)
+    # (its forward pass is another one: the cells may differ from `ref`'s in a sample or two — measured 2.2e-2 on conv_offset.weight.grad of the middle block; 5e-2 for the gradients that collect grad_offset)
+    for n, a_, b_ in zip(names, ref, got):
+        lim = (5e-2 if any(t in n for t in ("conv0", "conv_spatial", "conv_offset", "proj_1", "norm.", "pos_embed", "x")) else 2e-3) * max(float(a_.abs().max()), 1e-30)
+        assert bool(torch.isfinite(b_).all()) and float((a_ - b_).abs().max()) <= lim, ("graph", n, float((a_ - b_).abs().max()), lim)
