@@ -301,7 +301,11 @@ def cpu_baseline(sample, batch, budget_s=40.0):
             "sample": (f"oracle D-LKA block fwd+bwd at B={batch}, fp32, offsets ~1 voxel, one block of EACH of the 4 stage shapes timed "
                        f"(warm-up, timed repetitions per stage C=32/64/128/256: {reps}; median), 21-block time = 6*t0+6*t1+6*t2+3*t3; "
                        f"bounded to ~{budget_s:.0f} s (BASELINE.md §3 asks 3 warm + 10 timed)" if sample != "tiny" else "TINY shapes (debug only)"),
-            "per_stage_block_s": [round(t, 4) for t in per_stage], "one_thread_block_s": one, "torch": torch.__version__,
+            "per_stage_block_s": [round(t, 4) for t in per_stage], "one_thread_block_s": one,
+            "offline_protocol": ("profiles/r05z_cpu_baseline_protocol.json: the full BASELINE.md section 3 protocol (3 warm + 10 timed per stage, all four single-thread blocks: "
+                                 "16.8 / 4.62 / 1.21 / 0.39 s) run offline on a GPU box's host by scripts/cpu_baseline_protocol.py; the in-run sample above is bounded and leaves "
+                                 "a single-thread figure None where it would not fit"),
+            "torch": torch.__version__,
             "wall_s": round(time.perf_counter() - t_start, 1)}
 
 
@@ -533,7 +537,16 @@ def lka2d_metric(steps, dev, dtype=torch.float32, with_cpu=False):
             ach, peak, unit, bound = fl / t / 1e12, PEAK_F32_TFLOPS, "TFLOP/s", "mfma"
         else:
             ach, peak, unit, bound = by / t / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
-        out["roofline"] = {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5), "traffic": None,
+        traffic, traffic_source = None, "no profiles/pmc_traffic_lka2d.json entry for this kernel and shape (scripts/pmc_lka2d.sh)"
+        try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes over the same block (NOT measured by this run; launches of both convs / nets averaged)
+            blob = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_lka2d.json")))
+            ent = blob.get("stage2d_C%d_bf16" % C, {}).get(name) if dtype == torch.bfloat16 else None
+            if ent:
+                traffic = ent["hbm_bytes_per_launch"]
+                traffic_source = "profiles/pmc_traffic_lka2d.json (%s): committed rocprofv3 --pmc passes, NOT measured by this run" % blob.get("_meta", {}).get("round", "?")
+        except Exception:
+            pass
+        out["roofline"] = {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5), "traffic": traffic, "traffic_source": traffic_source,
                            "kernel": name, "kernel_us": round(t * 1e6, 2), "shape": "C=%d,%dx%d,B=24" % (C, n, n), "algorithmic_flops": fl,
                            "algorithmic_bytes": by, "method": "library launch trace (HIP events behind every launch), one eager step",
                            "kernels": kern}
@@ -633,7 +646,7 @@ def inference_config5_metric(dev):
             "tile_batch": 2, "stage_shapes": "40x56x56 / 20x28x28 / 10x14x14 / 5x7x7"}
 
 
-def companion_metric(batch, steps, warmup, dev, dtype, lr):
+def companion_metric(batch, steps, warmup, dev, dtype, lr, roofline=True):
     """The same stack step (fwd + bwd of the 21 blocks + SGD update, hipGraph replay) with the OTHER activation storage type — reported next to
     the headline so that one default run shows both: fp32 (the reference's arithmetic, 1e-4 parity) and bf16 activations (north_star's target
     dtype; parity against the bf16-storage oracle)."""
@@ -659,8 +672,16 @@ def companion_metric(batch, steps, warmup, dev, dtype, lr):
     h = st.health()
     if not h["finite"]:
         raise RuntimeError(f"non-finite parameters or gradients: {h}")
-    return {"dtype": "bf16" if dtype == torch.bfloat16 else "f32", "value": round(batch * steps / el, 3), "unit": "volumes/s",
-            "ms_per_step": round(el / steps * 1e3, 4), "steps": steps, "offset_std_voxels_by_stage": h["offset_std"]}
+    out = {"dtype": "bf16" if dtype == torch.bfloat16 else "f32", "value": round(batch * steps / el, 3), "unit": "volumes/s",
+           "ms_per_step": round(el / steps * 1e3, 4), "steps": steps, "offset_std_voxels_by_stage": h["offset_std"]}
+    if roofline:   # the same launch-trace roofline block as the headline's, for this dtype's step (round-4 verdict: none existed for the bf16 step)
+        try:
+            r = roofline_report(st, batch, dtype, el / steps * 1e3)
+            r["kernels"] = r["kernels"][:8]
+            out["roofline"] = r
+        except Exception as e:
+            log("companion roofline failed:", repr(e))
+    return out
 
 
 def spawn_ranks(args):
@@ -901,7 +922,8 @@ def main():
                                      "bf16 matrix cores (v_mfma_f32_32x32x16_bf16 / 16x16x32, two-term weight records), the pointwise convs and the stored-sample weight gradient on fp32 MFMA")
         if world == 1 and not args.no_companion:
             try:
-                out["other_dtype"] = companion_metric(args.batch, args.steps, args.warmup, dev, torch.bfloat16 if dtype == torch.float32 else torch.float32, lr)
+                out["other_dtype"] = companion_metric(args.batch, args.steps, args.warmup, dev, torch.bfloat16 if dtype == torch.float32 else torch.float32, lr,
+                                                    roofline=not args.no_roofline)
             except Exception as e:
                 log("companion dtype measurement failed:", repr(e))
                 out["other_dtype"] = None
