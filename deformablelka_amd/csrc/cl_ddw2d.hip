@@ -40,6 +40,10 @@ struct Ddw2dArgs {
     float *part;         // backward: [nblocks][K][C] weight-gradient partials
     int B, H, W, N, M, C, K, kh, kw, ph, pw, dh, dw;
     int px_per_block;    // backward: pixels per workgroup (multiple of 32)
+    int xcd_nx;          // forward / backward kernels: > 0 = gridDim.x is xcd_grid(xcd_nx) and blockIdx.x is mapped through xcd_item() (dlka_common.h): an XCD owns a
+                         // contiguous range of pixel blocks, i.e. whole images, so the corner rows its blocks gather stay in ITS L2.  Round 5: with the plain order
+                         // (block b on XCD b % 8) every XCD walks every image: 1479 MB of L2 misses per launch of the forward kernel at (96, 56^2, B = 24) for
+                         // 73 MB of tensors (profiles/pmc_traffic_lka2d.json), 6 TB/s — the kernel was bound by the fabric, not by its gathers.
 };
 
 // grid (ceil(M / 32), C / (32 * NCH)); block 256 = 4 waves x 8 pixels.  NCH channel chunks of 32 per block.
@@ -48,7 +52,9 @@ __global__ __launch_bounds__(256) void cl_ddw2d_fwd_kernel(Ddw2dArgs p)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane >> 3, pp = lane & 7;
-    const int m = blockIdx.x * 32 + wave * 8 + r;
+    const int bx = DLKA_XCD_BX(p.xcd_nx);
+    if (bx < 0) return;   // (padding block of the swizzled grid; uniform)
+    const int m = bx * 32 + wave * 8 + r;
     const bool ok = m < p.M;
     const int b = ok ? m / p.N : 0, n = ok ? m - b * p.N : 0;
     const int x0 = n % p.W, y0 = n / p.W;
@@ -103,7 +109,9 @@ __global__ __launch_bounds__(256) void cl_ddw2d_bwd_kernel(Ddw2dArgs p)
     const int r = lane >> 3, pp = lane & 7;
     const int rowbytes = p.C * SB;
     const BufRsrc rin = make_rsrc(p.in, (size_t)p.M * p.C * SB), rg = make_rsrc(p.g, (size_t)p.M * p.C * SB), rw = make_rsrc(p.wp, (size_t)p.K * p.C * 4);
-    const int m_lo = blockIdx.x * p.px_per_block, m_hi = min(p.M, m_lo + p.px_per_block);
+    const int bx = DLKA_XCD_BX(p.xcd_nx);
+    if (bx < 0) return;   // (padding block of the swizzled grid; uniform)
+    const int m_lo = bx * p.px_per_block, m_hi = min(p.M, m_lo + p.px_per_block);
     for (int tap = 0; tap < p.K; ++tap) {
         const int ti = tap / p.kw, tj = tap - ti * p.kw;
         f32x4 gwacc[NCH], w4[NCH];
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(256) void cl_ddw2d_bwd_kernel(Ddw2dArgs p)
         }
         __syncthreads();
         for (int e = tid; e < NCH * 32; e += 256)
-            p.part[((long)blockIdx.x * p.K + tap) * p.C + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+            p.part[((long)bx * p.K + tap) * p.C + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     }
 }
 
@@ -522,6 +530,7 @@ int launch_cl_ddw2d_fwd(const DwArgs2d &d, hipStream_t st)
     while (per > 1 && mblocks * (nch / per) < 1024 && per % 2 == 0) per /= 2;
     if (per == 3 && mblocks * (nch / 3) < 512) per = 1;
     dim3 grid(mblocks, nch / per), block(256);
+    if (xcd_swizzle_enabled() && mblocks >= xcd_min_blocks()) { a.xcd_nx = mblocks; grid.x = xcd_grid(mblocks); }
 #define DLKA_DDW_F(N_) case N_: { auto k = cl_ddw2d_fwd_kernel<N_>; DLKA_LAUNCH(k, grid, block, 0, st, a); } break;
     switch (per) {
         DLKA_DDW_F(1) DLKA_DDW_F(2) DLKA_DDW_F(3) DLKA_DDW_F(4) DLKA_DDW_F(6) DLKA_DDW_F(8) DLKA_DDW_F(12)
@@ -546,6 +555,7 @@ int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st, hipStream_
     a.px_per_block = cl_ddw2d_bwd_px_per_block(a.M);
     const int nblocks = cdiv(a.M, a.px_per_block);
     dim3 grid(nblocks), block(256);
+    if (xcd_swizzle_enabled() && nblocks >= xcd_min_blocks()) { a.xcd_nx = nblocks; grid.x = xcd_grid(nblocks); }
 #define DLKA_DDW_B(N_) case N_: { if (d.act_bf16) { auto k = cl_ddw2d_bwd_kernel<N_, bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, a); }   \
                                   else { auto k = cl_ddw2d_bwd_kernel<N_, float>; DLKA_LAUNCH(k, grid, block, 0, st, a); } } break;
     switch (nch) {
