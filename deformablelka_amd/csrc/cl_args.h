@@ -87,6 +87,10 @@ struct WgradArgs {
     int no_win3;         // set by the launcher: DLKA_WGRAD_WIN3=0 (A/B switch: the three w-taps of a wave load their rows separately, as before round 4)
     int xcd_ny, xcd_nz, xcd_total;   // set by the launcher: > 0 = 1-D XCD-swizzled grid over (chunk, y, z) work items, see xcd_item()
     int g_cpad;          // GMODE 1 only, > 0: g holds pack_split2() words with g_cpad channel planes per batch (see DeformBwdArgs::goff_cpad)
+    // Round 5 — the ZERO-PADDED copy of `in` (cl_wgrad.hip, cl_pad_copy_kernel): [B][DP][HP][WP][Cin] with the conv's reach as a halo, so that a tap's row is
+    // "base of the output voxel + a wave-uniform tap offset" with no validity test at all.  pad != null selects the padded kernels.
+    const float *pad;    // or null
+    int DP, HP, WP;      // padded extents: D + (kd - 1) * dd etc.
 };
 
 struct DwArgs {

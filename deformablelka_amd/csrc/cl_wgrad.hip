@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64, 2) void cl_wgrad_samp_kernel(WgradArgs p)
 // of 144 x 64 for the 3 x 3 blocking.
 // T: storage of `in` and of a channels-last `g` (GMODE 0); a planar `g` (GMODE 1: grad_offset) is always fp32.  A bf16 `in` is its own high
 // term, so the split contraction drops the b_lo product.
-template <int GMODE, int COT, int TPW, bool N16, bool SPLIT, typename T>   // N16: N % 16 == 0 (the 16 rows of a half-wave never straddle two volumes)
+template <int GMODE, int COT, int TPW, bool N16, bool SPLIT, typename T, bool PAD = false>   // N16: N % 16 == 0 (the 16 rows of a half-wave never straddle two volumes)
 __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int bz_in)
 {
     constexpr unsigned XB = sizeof(T), GB = GMODE == 0 ? sizeof(T) : 4u;
@@ -295,11 +295,23 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
     // TPW == kw == 3 with the fast row addressing below: the wave's three taps are the three w-neighbours of one (kd, kh), so their 3 x 16 rows are 18 DISTINCT
     // rows (w_ - 1 .. w_ + 16) — loaded once into xr_n, tap t's operand row s is xr[s + t].  (Ablation, profiles/r06_notes.md: 43 of this kernel's 79 us at
     // 32^3 were its operand fetch, 48 of the 60 loads per step these rows.)
-    constexpr bool WIN3 = TPW == 3 && N16;
+    constexpr bool WIN3 = TPW == 3 && N16 && !PAD;
     float xr_n[WIN3 ? 18 : 1];
     const bool win3 = WIN3 && p.K > 1 && p.w16 && p.kw == 3 && p.dw == 1 && p.pw == 1 && p.no_win3 == 0;
     const int gcp = (GMODE == 1 && p.g_cpad) ? p.g_cpad : p.Cout;   // channel planes per batch of a planar g
-    const BufRsrc rg = make_rsrc(p.g, (size_t)p.B * p.N * gcp * GB), rx = make_rsrc(p.in, (size_t)p.M * p.Cin * XB);
+    const BufRsrc rg = make_rsrc(p.g, (size_t)p.B * p.N * gcp * GB);
+    const BufRsrc rx = PAD ? make_rsrc(p.pad, (size_t)p.B * p.DP * p.HP * p.WP * p.Cin * XB) : make_rsrc(p.in, (size_t)p.M * p.Cin * XB);
+    // PAD (round 5): the B rows come from the zero-padded copy.  Row (b, d, h, w) of tap (i, j, k) is element ((b DP + d + i dd) HP + h + j dh) WP + w + k dw of it —
+    // the VOXEL part is a per-row register, the TAP part a wave-uniform scalar that rides in the load's soffset: no coordinate test, no select, no address add per
+    // (tap, row).  The general path below spends ~12 vector instructions on each of them, 576 of a step's ~930 at the 2-D net's 7 x 7 dilation-3 offset net — and
+    // with one wave per SIMD (370 - 500 registers) the kernel is bound by its instruction count (ISA mix; 2.3 us per 32-row step for 24 MFMAs).
+    unsigned soff[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tap = min(tap0 + t, p.K - 1);   // (a tap past K: any in-range address — its tile is never stored)
+        const int ti = tap / (p.kw * p.kh), tj = (tap / p.kw) % p.kh, tk = tap % p.kw;
+        soff[t] = PAD ? (unsigned)(((ti * p.dd * p.HP + tj * p.dh) * p.WP + tk * p.dw) * p.Cin) * XB : 0u;
+    }
     // operands of the 32-row step starting at mbase: rows m = mbase + 16h + s.  Every load is an unconditional buffer
     // load; rows beyond the chunk, channels beyond Cout and zero-padded neighbours read offset DLKA_OOB -> 0.
     auto load_step = [&](int mbase) {
@@ -342,7 +354,44 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
                 }
             }
         }
-        if (p.K == 1) {   // pointwise: the B rows are the A rows
+        if (PAD) {
+            const int w_0 = v0 % p.W, hh_0 = (v0 / p.W) % p.H, d_0 = v0 / (p.W * p.H);
+            const unsigned base0 = (unsigned)((((b0 * p.DP + d_0) * p.HP + hh_0) * p.WP + w_0) * p.Cin + ci) * XB;
+            const unsigned rs = (unsigned)p.Cin * XB;
+            const unsigned jw = (unsigned)(p.WP - p.W) * rs, jh = (unsigned)((p.HP - p.H) * p.WP) * rs, jd = (unsigned)((p.DP - p.D) * p.HP * p.WP) * rs;
+            if (p.W >= 16) {   // uniform.  At most ONE w-row ends inside the half-wave's 16 rows: rows from `sw` on skip the halo once (and with it, when that row also
+                // ends a plane / a volume, the plane's / volume's halo) — one compare and two adds per row, no divergent control flow
+                const int sw = p.W - w_0;
+                const bool eh = hh_0 == p.H - 1, ed = d_0 == p.D - 1;
+                const unsigned J = jw + (eh ? jh + (ed ? jd : 0u) : 0u);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const unsigned b_ = base0 + (unsigned)s * rs + (s >= sw ? J : 0u);
+                    const unsigned vo = (mrow0 + s < m_hi) ? b_ : DLKA_OOB;
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) bv_n[t][s] = act_buf_load1_s<T>(rx, vo, soff[t]);
+                }
+            } else {   // narrow volumes: the general walk, written with selects (the `if` form compiles to a divergent branch per row)
+                unsigned base = base0;
+                int w_ = w_0, hh = hh_0, d_ = d_0;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const unsigned vo = (mrow0 + s < m_hi) ? base : DLKA_OOB;
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) bv_n[t][s] = act_buf_load1_s<T>(rx, vo, soff[t]);
+                    ++w_;
+                    const bool cw = w_ == p.W;
+                    w_ = cw ? 0 : w_;
+                    hh += cw ? 1 : 0;
+                    const bool ch = hh == p.H;
+                    hh = ch ? 0 : hh;
+                    d_ += ch ? 1 : 0;
+                    const bool cd = d_ == p.D;
+                    d_ = cd ? 0 : d_;
+                    base += rs + (cw ? jw : 0u) + (ch ? jh : 0u) + (cd ? jd : 0u);
+                }
+            }
+        } else if (p.K == 1) {   // pointwise: the B rows are the A rows
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int m = mrow0 + s;
@@ -524,6 +573,40 @@ __global__ __launch_bounds__(64) void cl_wgrad_dense_kernel(WgradArgs p)
     wgrad_dense_body<GMODE, COT, TPW, N16, SPLIT, T>(p, blockIdx.z);
 }
 
+// the same from the zero-padded copy of the input (WgradArgs::pad): planar fp32 grad_out, split contraction, three taps per wave
+template <int COT, bool N16, typename T>
+__global__ __launch_bounds__(64) void cl_wgrad_dense_pad_kernel(WgradArgs p)
+{
+    wgrad_dense_body<1, COT, 3, N16, true, T, true>(p, blockIdx.z);
+}
+
+// out[b][d + lo_d][h + lo_h][w + lo_w][c] = in[b][d][h][w][c], zeros around.  One workgroup per OUTPUT w-row (b, dp, hp): the row's coordinates are decoded once
+// (scalar), the threads stream its WP * C * sizeof(T) bytes in 16-byte pieces.  (The first version decoded every piece with three 64-bit divisions: 192 us for the
+// 19 MB of the (384, 14^2, B = 24) copy, profiles/r08_notes.md.)
+template <typename T>
+__global__ __launch_bounds__(256) void cl_pad_copy_kernel(const T *__restrict__ in, T *__restrict__ out, int B, int D, int H, int W, int C, int DP, int HP, int WP,
+                                                          int lo_d, int lo_h, int lo_w)
+{
+    constexpr int PE = 16 / sizeof(T);   // elements per 16 bytes
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    const int pieces = C / PE, rowp = WP * pieces;
+    const int nrows = B * DP * HP;
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const int hp = r % HP, t = r / HP;
+        const int dp = t % DP, b = t / DP;
+        const int hh = hp - lo_h, d = dp - lo_d;
+        const bool row_in = (unsigned)hh < (unsigned)H && (unsigned)d < (unsigned)D;
+        const T *src = in + ((((long)b * D + (row_in ? d : 0)) * H + (row_in ? hh : 0)) * W) * C;
+        u4_t *dst = reinterpret_cast<u4_t *>(out + (long)r * WP * C);
+        const int lo = lo_w * pieces, hi = (lo_w + W) * pieces;   // pieces [lo, hi) of the row are the input's
+        for (int q = threadIdx.x; q < rowp; q += 256) {
+            u4_t val = {0u, 0u, 0u, 0u};
+            if (row_in && q >= lo && q < hi) val = *reinterpret_cast<const u4_t *>(src + (long)(q - lo) * PE);
+            dst[q] = val;
+        }
+    }
+}
+
 // The three pointwise weight gradients of a D-LKA block (proj_2, conv1, proj_1: same geometry, different operands) in ONE
 // launch, blockIdx.z = job: every dependent kernel node costs ~4.5 us inside the graph, and each of these is a ~1 us kernel.
 struct WgradArgs3 { WgradArgs a[3]; };
@@ -617,6 +700,12 @@ size_t cl_wgrad_part_floats(int M, int K, int Cout, int Cin)
     return (size_t)(c0 > c1 ? c0 : c1) * ((size_t)K * round_up(Cout, 32) * Cin + round_up(Cout, 32));
 }
 
+// bytes of the zero-padded copy the padded dense kernels read (WgradArgs::pad): [B][D + (kd-1) dd][H + (kh-1) dh][W + (kw-1) dw][Cin] activation elements
+size_t cl_wgrad_pad_bytes(int B, int D, int H, int W, int Cin, int kd, int kh, int kw, int dd, int dh, int dw, int act_bf16)
+{
+    return (size_t)B * (D + (kd - 1) * dd) * (H + (kh - 1) * dh) * (W + (kw - 1) * dw) * Cin * (act_bf16 ? 2 : 4);
+}
+
 template <typename T>
 int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t st, FinalizeJob *defer)
 {
@@ -668,7 +757,31 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
         else if ((a.N & 15) == 0) { auto k = cl_wgrad_dense_kernel<GM, CO, TP, true>; DLKA_LAUNCH(k, grid, block, 0, st, a); }  \
         else { auto k = cl_wgrad_dense_kernel<GM, CO, TP, false>; DLKA_LAUNCH(k, grid, block, 0, st, a); }              \
     }
-        if (a.act_bf16) {   // DLKA_BF16 token path: only the offset-predict conv's weight gradient comes through here (planar fp32 g, bf16 in)
+        if (a.pad && a.K > 1 && gmode == 1 && split && !a.g_cpad && pl.tpw == 3 && (a.Cin * (a.act_bf16 ? 2 : 4)) % 16 == 0 &&
+            cl_wgrad_pad_bytes(a.B, a.D, a.H, a.W, a.Cin, a.kd, a.kh, a.kw, a.dd, a.dh, a.dw, a.act_bf16) < ((size_t)1 << 31)) {
+            // round 5: the zero-padded copy of the input first (one streaming pass), then the kernels that need no coordinate test
+            a.DP = a.D + (a.kd - 1) * a.dd; a.HP = a.H + (a.kh - 1) * a.dh; a.WP = a.W + (a.kw - 1) * a.dw;
+            const int prow = a.B * a.DP * a.HP;
+            const unsigned pgrid = (unsigned)(prow > 16384 ? 16384 : prow);
+            if (a.act_bf16) {
+                auto k = cl_pad_copy_kernel<bf16_t>;
+                DLKA_LAUNCH(k, dim3(pgrid), dim3(256), 0, st, reinterpret_cast<const bf16_t *>(a.in), reinterpret_cast<bf16_t *>(const_cast<float *>(a.pad)), a.B, a.D, a.H, a.W,
+                            a.Cin, a.DP, a.HP, a.WP, a.pd, a.ph, a.pw);
+            } else {
+                auto k = cl_pad_copy_kernel<float>;
+                DLKA_LAUNCH(k, dim3(pgrid), dim3(256), 0, st, a.in, const_cast<float *>(a.pad), a.B, a.D, a.H, a.W, a.Cin, a.DP, a.HP, a.WP, a.pd, a.ph, a.pw);
+            }
+            DLKA_CHECK_LAUNCH();
+            const bool n16 = (a.N & 15) == 0;
+#define DLKA_WGP(CO, T_)                                                                                                   \
+    {                                                                                                                      \
+        if (n16) { auto k = cl_wgrad_dense_pad_kernel<CO, true, T_>; DLKA_LAUNCH(k, grid, block, 0, st, a); }              \
+        else { auto k = cl_wgrad_dense_pad_kernel<CO, false, T_>; DLKA_LAUNCH(k, grid, block, 0, st, a); }                 \
+    }
+            if (a.act_bf16) { if (pl.cot == 3) DLKA_WGP(3, bf16_t) else if (pl.cot == 2) DLKA_WGP(2, bf16_t) else DLKA_WGP(1, bf16_t) }
+            else { if (pl.cot == 3) DLKA_WGP(3, float) else if (pl.cot == 2) DLKA_WGP(2, float) else DLKA_WGP(1, float) }
+#undef DLKA_WGP
+        } else if (a.act_bf16) {   // DLKA_BF16 token path: only the offset-predict conv's weight gradient comes through here (planar fp32 g, bf16 in)
             if (a.K == 1 || gmode != 1 || !split || a.g_cpad || pl.tpw != 3) return DLKA_ERR_UNSUPPORTED;
 #define DLKA_WGB(CO)                                                                                                                           \
     {                                                                                                                                          \

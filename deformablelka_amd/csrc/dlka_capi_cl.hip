@@ -189,8 +189,16 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
 size_t dense_wp_floats(const SameConv &s) { return (size_t)s.K * round_up(s.Cin, 32) * round_up(s.Cout, 32) * (s.K > 1 ? 3 : 2) / 2; }
 
 // ---- dense conv weight gradient -----------------------------------------------------------------------------------
+// padbuf (optional, dense_wgrad_pad_bytes(s) bytes): scratch for the zero-padded copy of x — selects the padded kernels (cl_wgrad.hip, round 5) where they apply
+size_t dense_wgrad_pad_bytes(const SameConv &s)
+{
+    const char *e = getenv("DLKA_WGRAD_PAD");   // (A/B: 0 = the unpadded kernels of rounds 2 - 4.  Read per call: a workspace sized with the padded copy and used without it, or the
+    if ((e && e[0] == '0') || s.K <= 1 || s.group != 1) return 0;   //  other way round, is safe — the optional carve returns null when there is no room, and null selects the unpadded kernels)
+    const size_t n = cl_wgrad_pad_bytes(s.B, s.D, s.H, s.W, s.Cin, s.kd, s.kh, s.kw, s.dd, s.dh, s.dw, s.act_bf16);
+    return n < ((size_t)1 << 31) ? align256(n) : 0;
+}
 int dense_backward_weight(const SameConv &s, const float *x, const float *gout, int gout_planar, float *gw, float *gb, float *part, hipStream_t st,
-                          FinalizeJob *defer = nullptr, int g_cpad = 0)
+                          FinalizeJob *defer = nullptr, int g_cpad = 0, float *padbuf = nullptr)
 {
     if (s.Cin % 32) return DLKA_ERR_UNSUPPORTED;
     if (s.K != 1 && s.K > 7 * 64) return DLKA_ERR_UNSUPPORTED;
@@ -203,6 +211,7 @@ int dense_backward_weight(const SameConv &s, const float *x, const float *gout, 
     if (g_cpad && (!gout_planar || s.K == 1)) return DLKA_ERR_UNSUPPORTED;
     a.g_cpad = g_cpad;
     a.act_bf16 = s.act_bf16;
+    a.pad = (padbuf && gout_planar && !g_cpad && dense_wgrad_pad_bytes(s)) ? padbuf : nullptr;
     return launch_cl_wgrad<float>(0, gout_planar ? 1 : 0, a, gw, gb, st, defer);
 }
 
@@ -935,7 +944,8 @@ int lka2d_cl_saved_offsets(int B, int C, int H, int W, int dtype, size_t byte_of
 size_t lka2d_cl_workspace_bytes(int B, int C, int H, int W, int dtype)
 {
     Lka2dCl G(B, C, H, W, dtype);
-    return 9 * align256(G.E * 4) + align256(G.O7 * 4) + align256(G.O5 * 4) + align256(G.part_floats() * 4) + align256(4096);   // (O5: the second conv's grad_offset, see lka2d_cl_backward)
+    return 9 * align256(G.E * 4) + align256(G.O7 * 4) + align256(G.O5 * 4) + align256(G.part_floats() * 4) + align256(4096) +   // (O5: the second conv's grad_offset, see lka2d_cl_backward)
+           dense_wgrad_pad_bytes(G.off7) + dense_wgrad_pad_bytes(G.off5);   // the zero-padded copies the offset nets' weight gradients read (round 5)
 }
 
 int lka2d_cl_forward(const void *x_, const dlka_lka2d_params *p, void *y_, void *saved, size_t saved_bytes, void *workspace, size_t workspace_bytes, int B,
@@ -993,6 +1003,9 @@ int lka2d_cl_backward(const void *x_, const dlka_lka2d_params *p, const void *gy
     float *goff = (float *)cv.take(G.O7 * 4);
     float *goff5 = (float *)cv.take(G.O5 * 4);   // the 5x5 conv's grad_offset in a buffer of its own: the 7x7 offset net's weight gradient may still be reading `goff`
     float *part = (float *)cv.take(G.part_floats() * 4);
+    (void)cv.take(4096);
+    float *pad7 = (float *)cv.take_opt(dense_wgrad_pad_bytes(G.off7), dense_wgrad_pad_bytes(G.off7) != 0);   // (own buffers: both weight gradients may be in flight on the
+    float *pad5 = (float *)cv.take_opt(dense_wgrad_pad_bytes(G.off5), dense_wgrad_pad_bytes(G.off5) != 0);   //  internal stream at once)
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const float *N0 = nullptr;
     Prep2d PW;
@@ -1042,7 +1055,7 @@ int lka2d_cl_backward(const void *x_, const dlka_lka2d_params *p, const void *gy
     DLKA_TRY(fork_gx());
     DLKA_TRY(launch_cl_ddw2d_bwd(d, (float *)gr->conv_spatial_w, st, gst));
     DLKA_TRY(fork_to_aux());
-    DLKA_TRY(dense_backward_weight(G.off7, t1, goff, 1, (float *)gr->conv_spatial_offset_w, (float *)gr->conv_spatial_offset_b, part_o7, wst, &fb.j[fb.njobs++]));
+    DLKA_TRY(dense_backward_weight(G.off7, t1, goff, 1, (float *)gr->conv_spatial_offset_w, (float *)gr->conv_spatial_offset_b, part_o7, wst, &fb.j[fb.njobs++], 0, pad7));
     DLKA_TRY(join_gx());
     DLKA_TRY(dense_backward_data(G.off7, goff, 1, N0, gt1, PW.o7_b, 3, gta, st, nullptr, nullptr, bf && split7, false, bf != 0, bf ? gh : nullptr));   // gt1 = gta + offnet7^T goff
     // conv0 = DeformConv(5x5): t1 = DDW5(a, o5 = offnet5(a))
@@ -1052,7 +1065,7 @@ int lka2d_cl_backward(const void *x_, const dlka_lka2d_params *p, const void *gy
     DLKA_TRY(fork_gx());
     DLKA_TRY(launch_cl_ddw2d_bwd(d, (float *)gr->conv0_w, st, gst));
     DLKA_TRY(fork_to_aux());
-    DLKA_TRY(dense_backward_weight(G.off5, a, goff5, 1, (float *)gr->conv0_offset_w, (float *)gr->conv0_offset_b, part_o5, wst, &fb.j[fb.njobs++]));
+    DLKA_TRY(dense_backward_weight(G.off5, a, goff5, 1, (float *)gr->conv0_offset_w, (float *)gr->conv0_offset_b, part_o5, wst, &fb.j[fb.njobs++], 0, pad5));
     DLKA_TRY(join_gx());
     if (bf && split5) DLKA_TRY(launch_zero(gh, G.E * 4, st));
     DLKA_TRY(dense_backward_data(G.off5, goff5, 1, N0, gab, PW.o5_b, 3, gaa, st, nullptr, nullptr, bf && split5, false, bf != 0, bf ? gh : nullptr));   // gab = gaa + offnet5^T goff
@@ -1314,7 +1327,8 @@ size_t dlka_lka3d_tokens_workspace_bytes_v(int B, int C, int D, int H, int W, in
     if (!dlka_lka3d_tokens_supported_v(B, C, D, H, W, dtype, variant)) return 0;
     TokGeoms G(B, C, D, H, W, dtype, variant);   // (the eight gradient buffers keep their fp32 size on the bf16 path: gta and the split scratch ARE fp32)
     return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 8 * align256(G.E * 4) + align256(G.GOff * 4) +
-           align256(G.scratch_floats() * 4) + align256(G.samp_capacity_floats() * 4) + (cl_dwconv_lds_mode() ? 2 * align256(G.blk_floats() * 4) : 0) + align256(4096);
+           align256(G.scratch_floats() * 4) + align256(G.samp_capacity_floats() * 4) + (cl_dwconv_lds_mode() ? 2 * align256(G.blk_floats() * 4) : 0) + align256(4096) +
+           dense_wgrad_pad_bytes(G.offc);   // the zero-padded copy of t the offset conv's weight gradient reads (round 5)
 }
 
 // x_f32 (DLKA_BF16 only, optional): the caller's UNROUNDED fp32 twin of the bf16 input x.  The chain that decides where the deformable conv samples then starts
@@ -1681,6 +1695,7 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
     const bool want_blk = cl_dwconv_lds_mode() != 0;   // (see the forward pass)
     float *blkA = (float *)cv.take_opt(G.blk_floats() * 4, want_blk), *blkB = (float *)cv.take_opt(G.blk_floats() * 4, want_blk && blkA);
     if (!blkB) blkA = nullptr;
+    float *padt = (float *)cv.take_opt(dense_wgrad_pad_bytes(G.offc), dense_wgrad_pad_bytes(G.offc) != 0);   // (null when the workspace was sized without it: the unpadded kernels)
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
     const float *x = (const float *)x_, *gy = (const float *)gy_;
     float *gx = (float *)gx_;
@@ -1765,7 +1780,7 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
         DLKA_P2(deform_backward(G.dcn, t, off, N0, gf, nullptr, nullptr, (float *)gr->deform_w, (float *)gr->deform_b, PW.dcn_b, part_dcn, scratch, ws_,
                                 &fb.j[fb.njobs++], false, false, 0, samp));
     // offset-predict conv:  off = Coff t      (gt = gt_a + Coff^T goff fused in the epilogue)
-    DLKA_P2(dense_backward_weight(G.offc, t, goff, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, ws_, &fb.j[fb.njobs++], goff_cpad));
+    DLKA_P2(dense_backward_weight(G.offc, t, goff, 1, (float *)gr->offset_w, (float *)gr->offset_b, part_off, ws_, &fb.j[fb.njobs++], goff_cpad, padt));
     if (gx_forked) DLKA_TRY(lease.join(1));   // the offset conv's data gradient adds gta
     else
         DLKA_P1(deform_backward(G.dcn, t, off, N0, gf, gta, nullptr, nullptr, nullptr, PW.dcn_b, nullptr, scratch, st, nullptr, true, false, 0, nullptr, PW.dcn_b16));

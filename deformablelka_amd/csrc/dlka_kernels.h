@@ -68,6 +68,7 @@ int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t s
 int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st);
 int cl_wgrad_pick_chunks(int M, int K, int Cout, int Cin, int amode);
 size_t cl_wgrad_part_floats(int M, int K, int Cout, int Cin);
+size_t cl_wgrad_pad_bytes(int B, int D, int H, int W, int Cin, int kd, int kh, int kw, int dd, int dh, int dw, int act_bf16);   // the zero-padded input copy of the padded dense kernels (WgradArgs::pad)
 template <typename T> int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t st, FinalizeJob *defer = nullptr);
 size_t cl_wgrad_part_floats_mode(int M, int K, int Cout, int Cin, int amode);
 int launch_cl_wgrad_finalize(FinalizeBatch &b, hipStream_t st);
