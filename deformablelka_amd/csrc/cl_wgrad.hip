@@ -669,6 +669,8 @@ static WgradPlan wgrad_plan(int M, int K, int Cout, int Cin, int amode)
         static int tpw_env = -1;
         if (tpw_env < 0) tpw_env = 3;
         pl.tpw = tpw_env; pl.cot = (OT % 3 == 0) ? 3 : ((OT % 2 == 0) ? 2 : 1);
+        static const int cot_cap = [] { const char *e = getenv("DLKA_WGRAD_COT"); return e ? atoi(e) : 0; }();   // (A/B knob, read once: fewer co-tiles per wave = fewer registers)
+        if (cot_cap > 0 && pl.cot > cot_cap) pl.cot = cot_cap;
     }
     const int groups = cdiv(OT, pl.cot) * CT * cdiv(K, pl.tpw);
     const int tiles = cdiv(M, 32);

@@ -1099,7 +1099,7 @@ size_t dlka_conv3d_cl_workspace(const dlka_conv_geom *c, int dtype, int backward
     if (dtype != DLKA_F32 || make_same_conv(c, s)) return 0;
     if (is_depthwise(s)) return 2 * align256((size_t)s.K * s.Cin * 4);
     size_t n = align256(dense_wp_floats(s) * 4);
-    if (backward) n += align256(cl_wgrad_part_floats(s.M, s.K, s.Cout, s.Cin) * 4);
+    if (backward) n += align256(cl_wgrad_part_floats(s.M, s.K, s.Cout, s.Cin) * 4) + dense_wgrad_pad_bytes(s);   // (+ the zero-padded input copy of the padded weight gradient)
     return n;
 }
 
@@ -1145,9 +1145,10 @@ int dlka_conv3d_backward_cl(const void *x, const void *weight, const void *grad_
     if (s.group != 1) return DLKA_ERR_UNSUPPORTED;
     float *wp = (float *)cv.take(dense_wp_floats(s) * 4);
     float *part = (float *)cv.take(cl_wgrad_part_floats(s.M, s.K, s.Cout, s.Cin) * 4);
+    float *padb = (float *)cv.take_opt(dense_wgrad_pad_bytes(s), dense_wgrad_pad_bytes(s) != 0);
     if (!cv.ok()) return DLKA_ERR_WORKSPACE;
     if (grad_x) DLKA_TRY(dense_backward_data(s, (const float *)grad_out, grad_out_planar, (const float *)weight, (float *)grad_x, wp, 0, nullptr, st));
-    if (grad_weight) DLKA_TRY(dense_backward_weight(s, (const float *)x, (const float *)grad_out, grad_out_planar, (float *)grad_weight, (float *)grad_bias, part, st));
+    if (grad_weight) DLKA_TRY(dense_backward_weight(s, (const float *)x, (const float *)grad_out, grad_out_planar, (float *)grad_weight, (float *)grad_bias, part, st, nullptr, 0, padb));
     else if (grad_bias) {
         if (grad_out_planar) DLKA_TRY(launch_bias_grad<float>((const float *)grad_out, (float *)grad_bias, s.B, s.Cout, s.N, st));
         else DLKA_TRY(launch_cl_colsum((const float *)grad_out, (float *)grad_bias, s.M, s.Cout, st));
