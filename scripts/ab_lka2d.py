@@ -1,38 +1,40 @@
 #!/usr/bin/env python
-"""A/B of two builds of the library on the 2-D block metric (bench.lka2d_metric: config 2, bf16, B = 24) — or, with AB_METRIC=tblock, on the wrapper-block stack
-(bench.tblock_metric) — in ONE process on ONE box, interleaved rounds (box-to-box spread on the pool exceeds most single-kernel changes).
-usage: [AB_METRIC=tblock] python scripts/ab_lka2d.py OUT.json [alt_lib/libdlka_hip_prev.so]"""
-import ctypes, json, os, sys
+"""A/B of builds of the library on the 2-D block metric (bench.lka2d_metric: config 2, bf16, B = 24) — or, with AB_METRIC=tblock, on the wrapper-block stack — on ONE box:
+every measurement in its OWN process (two libraries bound in one process are not measured alike: the second one bound ran 6 - 9 % slower whichever it was — round 5's first
+version of this script did that and overstated a gain), alternating A B A B.  usage: [AB_METRIC=tblock] python scripts/ab_lka2d.py OUT.json [libA.so libB.so ...]
+(default: the tree's library against alt_lib/libdlka_hip_prev.so)"""
+import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import torch
-import bench
-from deformablelka_amd import _lib as L
-out_path = sys.argv[1]
-alt = sys.argv[2] if len(sys.argv) > 2 else "alt_lib/libdlka_hip_prev.so"
-libs = {"cur": None}
-if os.path.exists(os.path.join(ROOT, alt)):
-    cd = ctypes.CDLL(os.path.join(ROOT, alt))
-    for name, (rs, args) in L.SIGNATURES.items():   # (an older build may lack this round's new exports: bind what it has)
-        if hasattr(cd, name):
-            fn = getattr(cd, name); fn.restype = rs; fn.argtypes = args
-    libs["prev"] = cd
-res = {k: [] for k in libs}
-kern = {}
-for rnd in range(3):
-    for name, lib in libs.items():
-        L._lib = lib
-        if os.environ.get("AB_METRIC") == "tblock":
-            r = bench.tblock_metric(2, 10, 3, torch.device("cuda", 0))
-            res[name].append((r["value"], r.get("hipgraph", {}).get("value")))
-            continue
+if len(sys.argv) > 1 and sys.argv[1] == "--child":
+    sys.path.insert(0, ROOT)
+    import ctypes
+    import torch
+    import bench
+    from deformablelka_amd import _lib as L
+    path = sys.argv[2]
+    if path != "-":
+        cd = ctypes.CDLL(os.path.join(ROOT, path))
+        for name, (rs, args) in L.SIGNATURES.items():   # (an older build may lack this round's new exports: bind what it has)
+            if hasattr(cd, name):
+                fn = getattr(cd, name); fn.restype = rs; fn.argtypes = args
+        L._lib = cd
+    if os.environ.get("AB_METRIC") == "tblock":
+        r = bench.tblock_metric(2, 10, 3, torch.device("cuda", 0))
+        print("RESULT", json.dumps({"value": r["value"], "graph": r.get("hipgraph", {}).get("value")}))
+    else:
         r = bench.lka2d_metric(10, torch.device("cuda", 0), torch.bfloat16)
-        res[name].append(r["value"])
-        if "roofline" in r:
-            kern[name] = {f'{k["kernel"]} {k["shape"]}': k["avg_us"] for k in r["roofline"]["kernels"]}
-L._lib = None
-json.dump({"images_per_s": res, "kernels": kern}, open(out_path, "w"), indent=1)
-for k, v in res.items():
-    print(k, v)
-for k in sorted(set().union(*[set(d) for d in kern.values()]), key=lambda k: -max(d.get(k, 0) for d in kern.values())):
-    print("%-70s %s" % (k[:70], " ".join("%9.1f" % kern[n].get(k, float("nan")) for n in kern)))
+        print("RESULT", json.dumps({"value": r["value"], "per_block_ms": r["ms_per_block_fwd_bwd"]}))
+    sys.exit(0)
+out_path = sys.argv[1]
+libs = sys.argv[2:] or ["-", "alt_lib/libdlka_hip_prev.so"]
+res = {l: [] for l in libs}
+for rnd in range(2):
+    for l in libs:
+        if l != "-" and not os.path.exists(os.path.join(ROOT, l)):
+            continue
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", l], capture_output=True, text=True, timeout=600)
+        line = [x for x in p.stdout.splitlines() if x.startswith("RESULT")]
+        res[l].append(json.loads(line[0][7:]) if line else {"error": p.stderr[-300:]})
+json.dump(res, open(out_path, "w"), indent=1)
+for l, v in res.items():
+    print("tree" if l == "-" else l, v)
