@@ -916,6 +916,11 @@ def main():
             except Exception as e:
                 log("cpu baseline failed:", repr(e))
                 out["cpu_baseline"] = None
+        if dtype == torch.float32:
+            out["config"]["f32"] = ("fp32 storage and accumulation everywhere; contractions: forward deformable conv and pointwise convs on the fp32-input MFMA (exact products), "
+                                    "forward offset conv as a three-term bf16 split (fp32-equivalent: it feeds floor()), BACKWARD contractions of the deformable conv and the "
+                                    "offset conv's data / weight gradients as two-term bf16 splits (three products, fp32 accumulation, ~1e-5 relative, inside the 1e-3 gradient "
+                                    "contract); DLKA_EXACT_FP32=1 puts all of them on the fp32-input MFMA (include/dlka.h)")
         if dtype == torch.bfloat16:
             out["config"]["bf16"] = ("bf16 STORAGE of every activation tensor (x, y, saved, intermediate gradients); fp32 parameters, offsets, "
                                      "grad_offset and accumulation; the offset-predict conv and the deformable conv's contractions (forward, Col of grad_offset / grad_input) on the "

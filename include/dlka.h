@@ -283,7 +283,11 @@ int dlka_ndhwc_to_ncdhw(const void *src, void *dst, int B, int C, int N, int dty
  *   x, y, grad_x, grad_y: [B][N][C] with N = D*H*W voxels in (d,h,w) order of the reference's reshape(B,C,H,W,D)
  *   (its "H,W,D" are just the three spatial extents).  No permute/copy on either side.
  *   Supported: C in {32, 64, 128, 256} (the four D_LKA_Former stage widths); dtype
- *     DLKA_F32   everything fp32 (the parity path: 1e-4 against the reference);
+ *     DLKA_F32   everything fp32 storage and fp32 accumulation (the parity path: 1e-4 forward, 1e-3 gradients against the reference).  ARITHMETIC of the contractions:
+ *                the FORWARD deformable conv and the pointwise convs run on the fp32-input MFMA (exact fp32 products); the forward offset-predict conv as a THREE-term
+ *                bf16 split (six products per fp32 product: fp32-equivalent — its output decides floor()); the BACKWARD contractions of the deformable conv (Col of
+ *                grad_offset / grad_input) and the offset conv's data / weight gradients as TWO-term bf16 splits (three products, fp32 accumulation, ~1e-5 relative:
+ *                inside the 1e-3 gradient contract).  DLKA_EXACT_FP32=1 (environment, read once) puts every contraction on the fp32-input MFMA;
  *     DLKA_BF16  x, y, grad_y, grad_x and every saved / intermediate activation are bf16 STORAGE; parameters (dlka_lka3d_params), their
  *                gradients, the predicted offsets, grad_offset and all accumulation are fp32.  The offset-predict conv runs single bf16
  *                MFMA products against two-term (fp32-exact) weights.  The reference registers no autocast policy and would raise on half
