@@ -478,16 +478,31 @@ __global__ __launch_bounds__(256) void cl_ddw2d_gx_far_kernel(Ddw2dArgs p)
 }
 
 // gw[c][tap] (reference layout [C][1][kh][kw]) = sum_blocks part[block][tap][c]
+// A workgroup folds 32 consecutive (tap, c) outputs: thread (e = tid & 31, slice = tid >> 5) sums the partial blocks slice, slice + 8, ... with four loads in flight, the
+// eight slice sums meet in LDS (fixed order: deterministic).  Round 5 — the first version gave ONE thread all of an output's partials (784 of them at (96, 56^2, B = 24)):
+// a chain of dependent-latency loads on 19 workgroups, 110 - 118 us per launch for 14.7 MB (scripts/time_ddw2d_gx.py), 1.0 ms of the 2-D step's 17.6.
 __global__ __launch_bounds__(256) void cl_ddw2d_fold_kernel(const float *__restrict__ part, float *__restrict__ gw, int nblocks, int K, int C)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;   // (tap, c)
-    if (e >= K * C) return;
-    float a0 = 0.f, a1 = 0.f;
-    int bk = 0;
-    for (; bk + 1 < nblocks; bk += 2) { a0 += part[(long)bk * K * C + e]; a1 += part[(long)(bk + 1) * K * C + e]; }
-    if (bk < nblocks) a0 += part[(long)bk * K * C + e];
-    const int tap = e / C, c = e - tap * C;
-    gw[(long)c * K + tap] = a0 + a1;
+    __shared__ float red[8][33];
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;   // (tap, c)
+    const long stride = (long)K * C;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < K * C) {
+        const float *src = part + e;
+        int bk = sl;
+        for (; bk + 24 < nblocks; bk += 32) {
+            a0 += src[(long)bk * stride]; a1 += src[(long)(bk + 8) * stride]; a2 += src[(long)(bk + 16) * stride]; a3 += src[(long)(bk + 24) * stride];
+        }
+        for (; bk < nblocks; bk += 8) a0 += src[(long)bk * stride];
+    }
+    red[sl][el] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0 && e < K * C) {
+        const float t = ((red[0][el] + red[1][el]) + (red[2][el] + red[3][el])) + ((red[4][el] + red[5][el]) + (red[6][el] + red[7][el]));
+        const int tap = e / C, c = e - tap * C;
+        gw[(long)c * K + tap] = t;
+    }
 }
 
 static int ddw2d_nch(int C)
@@ -564,7 +579,7 @@ int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st, hipStream_
     }
 #undef DLKA_DDW_B
     DLKA_CHECK_LAUNCH();
-    DLKA_LAUNCH(cl_ddw2d_fold_kernel, dim3(cdiv(a.K * a.C, 256)), dim3(256), 0, st, (const float *)a.part, gw, nblocks, a.K, a.C);
+    DLKA_LAUNCH(cl_ddw2d_fold_kernel, dim3(cdiv(a.K * a.C, 32)), dim3(256), 0, st, (const float *)a.part, gw, nblocks, a.K, a.C);
     DLKA_CHECK_LAUNCH();
     // Second generation where the image gives it enough tiles to fill the chip (one wave per (tile, 128 channels): 2352 waves at (96, 56^2, B = 24));
     // the smaller decoder shapes keep the window kernel (measured, profiles/r05_notes.md: 575 vs 478 us at (192, 28^2), 346 vs ~300 at (384, 14^2)).

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """A/B of builds of the library on the 2-D block metric (bench.lka2d_metric: config 2, bf16, B = 24) — or, with AB_METRIC=tblock, on the wrapper-block stack — on ONE box:
 every measurement in its OWN process (two libraries bound in one process are not measured alike: the second one bound ran 6 - 9 % slower whichever it was — round 5's first
-version of this script did that and overstated a gain), alternating A B A B.  usage: [AB_METRIC=tblock] python scripts/ab_lka2d.py OUT.json [libA.so libB.so ...]
+version of this script did that and overstated a gain), alternating A B A B.  usage: [AB_METRIC=tblock] python scripts/ab_lka2d.py OUT.json [libA.so libB.so "-@KEY=VAL" ...]   ("-" = the tree's library, "@K=V,..." = environment of that measurement)
 (default: the tree's library against alt_lib/libdlka_hip_prev.so)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +12,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import bench
     from deformablelka_amd import _lib as L
     path = sys.argv[2]
+    if "@" in path:   # "LIB@KEY=VAL,KEY=VAL": environment of this measurement
+        path, kv = path.split("@", 1)
+        os.environ.update(dict(x.split("=", 1) for x in kv.split(",") if x))
     if path != "-":
         cd = ctypes.CDLL(os.path.join(ROOT, path))
         for name, (rs, args) in L.SIGNATURES.items():   # (an older build may lack this round's new exports: bind what it has)
@@ -30,7 +33,7 @@ libs = sys.argv[2:] or ["-", "alt_lib/libdlka_hip_prev.so"]
 res = {l: [] for l in libs}
 for rnd in range(2):
     for l in libs:
-        if l != "-" and not os.path.exists(os.path.join(ROOT, l)):
+        if l.split("@")[0] != "-" and not os.path.exists(os.path.join(ROOT, l.split("@")[0])):
             continue
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", l], capture_output=True, text=True, timeout=600)
         line = [x for x in p.stdout.splitlines() if x.startswith("RESULT")]
