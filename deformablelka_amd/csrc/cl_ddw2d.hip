@@ -40,6 +40,8 @@ struct Ddw2dArgs {
     float *part;         // backward: [nblocks][K][C] weight-gradient partials
     int B, H, W, N, M, C, K, kh, kw, ph, pw, dh, dw;
     int px_per_block;    // backward: pixels per workgroup (multiple of 32)
+    int tpg;             // backward kernel: taps per blockIdx.y (grad_offset and the weight-gradient partials are per tap: a tap split needs no atomics) — fills the chip at
+                         // the 14 x 14 stage, where the pixels alone give 147 workgroups
     int xcd_nx;          // forward / backward kernels: > 0 = gridDim.x is xcd_grid(xcd_nx) and blockIdx.x is mapped through xcd_item() (dlka_common.h): an XCD owns a
                          // contiguous range of pixel blocks, i.e. whole images, so the corner rows its blocks gather stay in ITS L2.  Round 5: with the plain order
                          // (block b on XCD b % 8) every XCD walks every image: 1479 MB of L2 misses per launch of the forward kernel at (96, 56^2, B = 24) for
@@ -112,7 +114,8 @@ __global__ __launch_bounds__(256) void cl_ddw2d_bwd_kernel(Ddw2dArgs p)
     const int bx = DLKA_XCD_BX(p.xcd_nx);
     if (bx < 0) return;   // (padding block of the swizzled grid; uniform)
     const int m_lo = bx * p.px_per_block, m_hi = min(p.M, m_lo + p.px_per_block);
-    for (int tap = 0; tap < p.K; ++tap) {
+    const int tap_lo = blockIdx.y * p.tpg, tap_hi = min(p.K, tap_lo + p.tpg);
+    for (int tap = tap_lo; tap < tap_hi; ++tap) {
         const int ti = tap / p.kw, tj = tap - ti * p.kw;
         f32x4 gwacc[NCH], w4[NCH];
 #pragma unroll
@@ -570,6 +573,12 @@ int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st, hipStream_
     a.px_per_block = cl_ddw2d_bwd_px_per_block(a.M);
     const int nblocks = cdiv(a.M, a.px_per_block);
     dim3 grid(nblocks), block(256);
+    {   // few pixel blocks (14 x 14: 147; 28 x 28: 588): split the taps over gridDim.y until ~1024 workgroups exist
+        int groups = nblocks >= 1024 ? 1 : cdiv(1024, nblocks);
+        if (groups > a.K) groups = a.K;
+        a.tpg = cdiv(a.K, groups);
+        grid.y = cdiv(a.K, a.tpg);
+    }
     if (xcd_swizzle_enabled() && nblocks >= xcd_min_blocks()) { a.xcd_nx = nblocks; grid.x = xcd_grid(nblocks); }
 #define DLKA_DDW_B(N_) case N_: { if (d.act_bf16) { auto k = cl_ddw2d_bwd_kernel<N_, bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, a); }   \
                                   else { auto k = cl_ddw2d_bwd_kernel<N_, float>; DLKA_LAUNCH(k, grid, block, 0, st, a); } } break;
