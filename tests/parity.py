@@ -986,3 +986,37 @@ def check_tblock3d_phased_backward(dev, B, C, dims, lka_bf16=False, seed=0):
         assert torch.isfinite(b_).all(), k
         scale = max(float(a_.abs().max()), 1e-6)
         assert float((a_.float() - b_.float()).abs().max()) <= 2e-3 * scale, (k, float((a_.float() - b_.float()).abs().max()), scale)
+
+
+def check_wgrad_pad_equals_unpadded(dev, B, Cin, Cout, dims, k, pad, dil, seed=0):
+    """The dense weight gradient from the zero-padded copy of its input (cl_wgrad_dense_pad_kernel, round 5) against the kernels that test every (tap, row)'s coordinates
+    (DLKA_WGRAD_PAD=0): where both contract with the same arithmetic (N % 16 == 0) the same products in the same order — a padding row contributes exact zeros — so the two
+    agree BITWISE; elsewhere to the split's 1e-5.  Both are also held to the fp64 conv.
+    dims = (D, H, W) of a channels-last volume, planar grad_out (the layout the offset tensors keep)."""
+    from deformablelka_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    D, H, W = dims
+    k3, p3, d3 = ops._triple(k), ops._triple(pad), ops._triple(dil)
+    x = torch.randn(B, D, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, *k3, generator=g) * 0.05
+    go = torch.randn(B, Cout, D, H, W, generator=g)
+    old = os.environ.get("DLKA_WGRAD_PAD")
+    res = []
+    try:
+        for mode in ("1", "0"):
+            os.environ["DLKA_WGRAD_PAD"] = mode
+            _, gw, gb = ops.conv3d_backward_cl(x.to(dev), w.to(dev), go.to(dev), p3, d3, 1, grad_out_planar=True)
+            res.append((gw.cpu(), gb.cpu()))
+    finally:
+        if old is None:
+            os.environ.pop("DLKA_WGRAD_PAD", None)
+        else:
+            os.environ["DLKA_WGRAD_PAD"] = old
+    if (D * H * W) % 16 == 0:
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), float((res[0][0] - res[1][0]).abs().max())
+    else:   # N % 16 != 0 with fp32 activations: the unpadded route is the exact fp32-input MFMA there, the padded kernels always contract as two-term bf16 splits (~1e-5)
+        assert rel_err(res[0][0], res[1][0]) <= 1e-4 and rel_err(res[0][1], res[1][1]) <= 1e-4
+    xr = x.permute(0, 4, 1, 2, 3).double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    F.conv3d(xr, wr, None, 1, p3, d3).backward(go.double())
+    assert rel_err(res[0][0], wr.grad) <= 1e-3

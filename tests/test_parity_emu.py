@@ -718,3 +718,11 @@ def test_dwconv_two_output_planes(case, monkeypatch):
 def test_tblock3d_phased_backward_equals_one_call(C, dims, bf):
     """dlka_tblock3d_backward_phase_v (round 5: the engine's data-chain / weight-gradient split for the wrapper block): phase 1 then phase 2 == phase 0."""
     parity.check_tblock3d_phased_backward("cpu", 2, C, dims, lka_bf16=bf)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 81, (3, 4, 5), 3, 1, 1), (1, 32, 98, (1, 9, 20), (1, 7, 7), (0, 9, 9), (1, 3, 3)), (2, 64, 50, (1, 6, 7), (1, 5, 5), (0, 2, 2), 1),
+                                  (1, 32, 81, (2, 3, 16), 3, 1, 1), (1, 32, 98, (1, 4, 20), (1, 7, 7), (0, 9, 9), (1, 3, 3))])
+def test_wgrad_from_padded_copy_equals_unpadded(case):
+    """cl_wgrad_dense_pad_kernel + cl_pad_copy_kernel (round 5): narrow volumes (the select walk), a W >= 16 row (the one-compare walk), the 2-D nets' 7 x 7 dilation 3 and 5 x 5,
+    ragged N — bitwise equal to the unpadded kernels."""
+    parity.check_wgrad_pad_equals_unpadded("cpu", *case)

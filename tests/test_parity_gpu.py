@@ -957,3 +957,11 @@ def test_tblock3d_wgrad_overlap_equals_one_stream():
     for n, a_, b_ in zip(names, ref, got):
         lim = (5e-2 if any(t in n for t in ("conv0", "conv_spatial", "conv_offset", "proj_1", "norm.", "pos_embed", "x")) else 2e-3) * max(float(a_.abs().max()), 1e-30)
         assert bool(torch.isfinite(b_).all()) and float((a_ - b_).abs().max()) <= lim, ("graph", n, float((a_ - b_).abs().max()), lim)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 81, (32, 32, 32), 3, 1, 1), (2, 128, 81, (8, 8, 8), 3, 1, 1), (24, 96, 98, (1, 56, 56), (1, 7, 7), (0, 9, 9), (1, 3, 3)),
+                                  (24, 384, 50, (1, 14, 14), (1, 5, 5), (0, 2, 2), 1), (3, 64, 81, (5, 6, 7), 3, 1, 1)])
+def test_wgrad_from_padded_copy_equals_unpadded(case):
+    """The padded dense weight gradient at the real shapes (3-D offset conv at 32^3 and 8^3, the 2-D offset nets at 56^2 and 14^2) and a ragged one: bitwise equal to the
+    unpadded kernels, 1e-3 of the fp64 conv."""
+    parity.check_wgrad_pad_equals_unpadded(DEV, *case)
