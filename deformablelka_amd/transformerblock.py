@@ -162,11 +162,15 @@ class WgradOverlap:
 
     def submit(self, keep):
         self.pending.append(keep)
-        if not self.armed:
-            self.armed = True
-            torch.autograd.Variable._execution_engine.queue_callback(self.join)
+        # one callback per SUBMIT, not one per pass guarded by a flag: a backward pass that raised after a block's submit never runs its callbacks, and a flag
+        # left set by it would keep every later pass from joining.  The first callback of a pass joins; the others find nothing pending.
+        self.armed = True
+        torch.autograd.Variable._execution_engine.queue_callback(self.join)
 
     def join(self):
+        if not self.pending:
+            self.armed = False
+            return
         ev = torch.cuda.Event()
         ev.record(self.side)
         torch.cuda.current_stream(self.device).wait_event(ev)
