@@ -113,6 +113,20 @@ struct DwArgs {
     int out_blk_dil;
 };
 
+// two chained depthwise convs of a small volume in one launch (cl_dwpair.hip): in -> conv A -> outA -> conv B -> outB
+struct DwPairArgs {
+    const float *in;                 // [B][D][H][W][C], storage T (float | bf16 when act_bf16)
+    const float *wpA, *wpB;          // prepared tap weights [K][C] (launch_cl_dw_prep_weight: forward or flipped form)
+    const float *biasA, *biasB;      // [C] or null
+    float *outA, *outB;              // storage T
+    float *outA_lo, *outB_lo;        // fp32 kernels only: ALSO store the result rounded to bf16 there, or null
+    const float *gelu_x, *gelu_add;  // optional epilogue of conv B: outB = (acc + gelu_add) * gelu'(gelu_x)   (storage T)
+    int B, D, H, W, C;
+    int kA, dA, pA, KA;              // conv A: cubic kernel size, dilation, padding, kA^3
+    int kB, dB, pB, KB;
+    int act_bf16;
+};
+
 // channels-last 2-D depthwise deformable conv (cl_ddw2d.hip): forward uses in / off / wp / out; backward in / off / wp / g / gx / goff / part
 struct DwArgs2d {
     const float *in;     // [B][H][W][C]

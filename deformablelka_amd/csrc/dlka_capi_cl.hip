@@ -271,6 +271,31 @@ int dw_forward(const SameConv &s, const float *x, const float *w, const float *b
     return launch_cl_dwconv(a, s.kw, s.dw, st);
 }
 
+// Two chained depthwise convs of a small volume in ONE launch (cl_dwpair.hip): x -> sa -> outA -> sb -> outB, prepared weights wpA / wpB (already in the wanted form: the
+// flipped one for the data gradients — "same" padding is its own mirror).  DLKA_ERR_UNSUPPORTED: not that shape (or DLKA_DWPAIR=0) — the caller runs them one by one.
+static int dwpair_mode()
+{
+    const char *e = getenv("DLKA_DWPAIR");
+    return (e && e[0] == '0') ? 0 : 1;
+}
+
+int dw_pair(const SameConv &sa, const SameConv &sb, const float *x, const float *wpA, const float *biasA, float *outA, float *outA_lo, const float *wpB, const float *biasB,
+            float *outB, float *outB_lo, const float *gelu_x, const float *gelu_add, hipStream_t st)
+{
+    if (!dwpair_mode()) return DLKA_ERR_UNSUPPORTED;
+    auto cubic = [](const SameConv &s) { return s.kd == s.kw && s.kh == s.kw && s.dd == s.dw && s.dh == s.dw && s.pd == s.pw && s.ph == s.pw; };
+    if (!cubic(sa) || !cubic(sb) || sa.act_bf16 != sb.act_bf16 || sa.Cin != sb.Cin) return DLKA_ERR_UNSUPPORTED;
+    DwPairArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = x; a.wpA = wpA; a.wpB = wpB; a.biasA = biasA; a.biasB = biasB; a.outA = outA; a.outB = outB; a.outA_lo = outA_lo; a.outB_lo = outB_lo;
+    a.gelu_x = gelu_x; a.gelu_add = gelu_add;
+    a.B = sa.B; a.D = sa.D; a.H = sa.H; a.W = sa.W; a.C = sa.Cin;
+    a.kA = sa.kw; a.dA = sa.dw; a.pA = sa.pw; a.KA = sa.K;
+    a.kB = sb.kw; a.dB = sb.dw; a.pB = sb.pw; a.KB = sb.K;
+    a.act_bf16 = sa.act_bf16;
+    return launch_cl_dwpair_small(a, st);
+}
+
 // defer != null: gwp is a zeroed [K + 1][C] staging area (row K collects the bias sums) that the caller's fused
 // finalisation kernel re-lays into gw / gb
 int dw_backward_weight(const SameConv &s, const float *x, const float *gout, float *gw, float *gb, float *gwp, hipStream_t st, FinalizeJob *defer = nullptr)
@@ -1396,9 +1421,14 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     bool chained = false;
     DwBlk bk5, bk7;
     bk5.blk = blkA; bk5.blk_floats = G.blk_floats(); bk5.chain = &G.dw7_f; bk5.chain_blk = blkB; bk5.chained = &chained;
-    DLKA_TRY(dw_forward(G.dw5_f, a_in, N0, (const float *)p->conv0_b, t1_out, PW.dw5_f, 0, st, nullptr, nullptr, bf ? t1 : nullptr, &bk5));
-    bk7.blk = blkB; bk7.blk_floats = G.blk_floats(); bk7.in_blocked = chained;
-    DLKA_TRY(dw_forward(G.dw7_f, t1_out, N0, (const float *)p->conv_spatial_b, t_out, PW.dw7_f, 0, st, nullptr, nullptr, bf ? t : nullptr, &bk7));
+    const int pair = dw_pair(G.dw5_f, G.dw7_f, a_in, PW.dw5_f, (const float *)p->conv0_b, t1_out, bf ? t1 : nullptr, PW.dw7_f, (const float *)p->conv_spatial_b, t_out,
+                             bf ? t : nullptr, nullptr, nullptr, st);   // 8^3 / 4^3 stages: both in one launch
+    if (pair != DLKA_ERR_UNSUPPORTED) DLKA_TRY(pair);
+    else {
+        DLKA_TRY(dw_forward(G.dw5_f, a_in, N0, (const float *)p->conv0_b, t1_out, PW.dw5_f, 0, st, nullptr, nullptr, bf ? t1 : nullptr, &bk5));
+        bk7.blk = blkB; bk7.blk_floats = G.blk_floats(); bk7.in_blocked = chained;
+        DLKA_TRY(dw_forward(G.dw7_f, t1_out, N0, (const float *)p->conv_spatial_b, t_out, PW.dw7_f, 0, st, nullptr, nullptr, bf ? t : nullptr, &bk7));
+    }
     // offset-predict conv C -> 81 (synapse/deform_conv.py:94) on the fp32 t; offsets stay in the reference's planar layout
     DLKA_TRY(dense_forward(G.offc_f, t_out, N0, (const float *)p->offset_b, off, 1, PW.off_f, 0, nullptr, nullptr, st, true));
     // deformable 3^3 conv (deform_conv.py:95-105)   (bf16: samples the bf16 copy of t)
@@ -1792,14 +1822,18 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
     bool chained = false;
     DwBlk bk7, bk5;
     bk7.blk = blkA; bk7.blk_floats = G.blk_floats(); bk7.chain = &G.dw5; bk7.chain_blk = blkB; bk7.chained = &chained;
-    DLKA_P1(dw_forward(G.dw7, gt, N0, nullptr, gt1, PW.dw7_b, 1, st, nullptr, nullptr, nullptr, &bk7));
+    // (8^3 / 4^3 stages: this conv's and the next one's data gradients, GELU' included, in one launch)
+    int pair = DLKA_ERR_UNSUPPORTED;
+    if (phase != 2) pair = dw_pair(G.dw7, G.dw5, gt, PW.dw7_b, nullptr, gt1, nullptr, PW.dw5_b, nullptr, gh, nullptr, h, ga1, st);
+    if (pair != DLKA_ERR_UNSUPPORTED) DLKA_TRY(pair);
+    else DLKA_P1(dw_forward(G.dw7, gt, N0, nullptr, gt1, PW.dw7_b, 1, st, nullptr, nullptr, nullptr, &bk7));
     DLKA_TRY(publish());
     // depthwise 5^3:  t1 = DW5 a
     DLKA_P2(dw_backward_weight(G.dw5, a, gt1, (float *)gr->conv0_w, (float *)gr->conv0_b, stage5, ws_, &fb.j[fb.njobs++]));
     // ... with the GELU backward in its epilogue:  a = GELU(h),  gh = (ga1 + DW5^T gt1) * gelu'(h)
     (void)E;
     bk5.blk = blkB; bk5.blk_floats = G.blk_floats(); bk5.in_blocked = chained;
-    DLKA_P1(dw_forward(G.dw5, gt1, N0, nullptr, gh, PW.dw5_b, 1, st, h, ga1, nullptr, &bk5));
+    if (pair == DLKA_ERR_UNSUPPORTED) DLKA_P1(dw_forward(G.dw5, gt1, N0, nullptr, gh, PW.dw5_b, 1, st, h, ga1, nullptr, &bk5));
     DLKA_TRY(publish());
     // proj_1:  h = P1 x ;  gx = P1^T gh + gy (shortcut)
     if (phase != 1) {

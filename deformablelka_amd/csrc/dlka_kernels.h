@@ -84,6 +84,8 @@ int launch_cl_wgrad_pw3(const WgradArgs *jobs, float *const *gw, float *const *g
 int launch_cl_colsum(const float *g, float *gb32, int M, int Cout, hipStream_t st);
 int launch_cl_dw_prep_weight(const float *w, float *wp, int C, int K, int flip, hipStream_t st);
 int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st);
+bool cl_dwpair_small_supported(const DwPairArgs &a);   // cl_dwpair.hip: two chained depthwise convs of a small volume (N <= 512) in one launch
+int launch_cl_dwpair_small(const DwPairArgs &a, hipStream_t st);   // DLKA_ERR_UNSUPPORTED = run the convs one by one
 int launch_cl_dwconv_lds(const DwArgs &a, int kw, int dil_w, hipStream_t st);
 bool cl_dwconv_lds_selected(const DwArgs &a, int kw, int dil_w);   // would launch_cl_dwconv take the LDS-brick kernel?
 int cl_dwconv_lds_mode();   // DLKA_DW_LDS (0 = never: no blocked copies are sized or carved)

@@ -988,6 +988,48 @@ def check_tblock3d_phased_backward(dev, B, C, dims, lka_bf16=False, seed=0):
         assert float((a_.float() - b_.float()).abs().max()) <= 2e-3 * scale, (k, float((a_.float() - b_.float()).abs().max()), scale)
 
 
+def check_dwpair_equals_unfused(dev, B, C, dims, lka_bf16=False, seed=0):
+    """cl_dwpair.hip (round 5): the small-volume stages run dw 5^3 -> dw 7^3 dil 3 (and, backward, their data gradients + GELU') as ONE launch with the intermediate in
+    LDS.  Against the same block with DLKA_DWPAIR=0 (one launch per conv): the same fp32 FMAs in another order, so every output agrees to rounding (fp32) / to a bf16 ulp
+    of the stored gradients (DLKA_BF16 storage) — and the saved activations t1, t the weight gradients read are the fused kernel's own stores."""
+    import deformablelka_amd as dk
+    from deformablelka_amd import ops
+    from oracle import blocks
+    torch.manual_seed(seed)
+    H, W, D = dims
+    m = dk.TransformerBlock_3D_single_deform_LKA(H * W * D, C, C, 4, dropout_rate=0.1, pos_embed=True)
+    blocks.randomize_offsets_(m, std=0.05)
+    m = m.to(dev).train()
+    x = torch.randn(B, H * W * D, C, device=dev)
+    gy = torch.randn(B, H * W * D, C, device=dev)
+    tparams = [None if p is None else p.detach() for p in m.wrapper_params()]
+    lparams = [p.detach() for p in m.epa_block.block_params()]
+    mask = torch.ones(B, C, device=dev)
+    old = os.environ.get("DLKA_DWPAIR")
+    res = []
+    try:
+        for mode in ("1", "0"):
+            os.environ["DLKA_DWPAIR"] = mode
+            stats = torch.empty(6 * C, dtype=torch.float32, device=dev)
+            y, saved = ops.tblock3d_forward(x, False, tparams, lparams, mask, True, stats, dims, 1e-5, 1e-5, 0, lka_bf16)
+            r = ops.tblock3d_backward(tparams, lparams, mask, True, stats, gy, saved, dims, 0, lka_bf16)
+            res.append([y, r[0]] + [t for t in r[1] if t is not None] + list(r[2]))
+    finally:
+        if old is None:
+            os.environ.pop("DLKA_DWPAIR", None)
+        else:
+            os.environ["DLKA_DWPAIR"] = old
+    tol = 2e-2 if lka_bf16 else 2e-3
+    worst = 0.0
+    for k, (a_, b_) in enumerate(zip(*res)):
+        assert torch.isfinite(a_).all(), k
+        scale = max(float(b_.abs().max()), 1e-6)
+        err = float((a_.float() - b_.float()).abs().max()) / scale
+        worst = max(worst, err)
+        assert err <= tol, (k, err)
+    return worst
+
+
 def check_wgrad_pad_equals_unpadded(dev, B, Cin, Cout, dims, k, pad, dil, seed=0):
     """The dense weight gradient from the zero-padded copy of its input (cl_wgrad_dense_pad_kernel, round 5) against the kernels that test every (tap, row)'s coordinates
     (DLKA_WGRAD_PAD=0): where both contract with the same arithmetic (N % 16 == 0) the same products in the same order — a padding row contributes exact zeros — so the two

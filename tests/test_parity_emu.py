@@ -720,6 +720,12 @@ def test_tblock3d_phased_backward_equals_one_call(C, dims, bf):
     parity.check_tblock3d_phased_backward("cpu", 2, C, dims, lka_bf16=bf)
 
 
+@pytest.mark.parametrize("C,dims,bf", [(32, (4, 4, 4), False), (32, (3, 5, 8), False), (32, (8, 8, 8), False), (64, (2, 3, 4), True), (32, (5, 3, 8), True)])
+def test_dwpair_equals_unfused(C, dims, bf):
+    """cl_dwpair.hip (round 5): both depthwise convs of a small volume in one launch == one launch per conv (DLKA_DWPAIR=0), forward and backward."""
+    parity.check_dwpair_equals_unfused("cpu", 2, C, dims, lka_bf16=bf)
+
+
 @pytest.mark.parametrize("case", [(2, 32, 81, (3, 4, 5), 3, 1, 1), (1, 32, 98, (1, 9, 20), (1, 7, 7), (0, 9, 9), (1, 3, 3)), (2, 64, 50, (1, 6, 7), (1, 5, 5), (0, 2, 2), 1),
                                   (1, 32, 81, (2, 3, 16), 3, 1, 1), (1, 32, 98, (1, 4, 20), (1, 7, 7), (0, 9, 9), (1, 3, 3))])
 def test_wgrad_from_padded_copy_equals_unpadded(case):

@@ -965,3 +965,12 @@ def test_wgrad_from_padded_copy_equals_unpadded(case):
     """The padded dense weight gradient at the real shapes (3-D offset conv at 32^3 and 8^3, the 2-D offset nets at 56^2 and 14^2) and a ragged one: bitwise equal to the
     unpadded kernels, 1e-3 of the fp64 conv."""
     parity.check_wgrad_pad_equals_unpadded(DEV, *case)
+
+
+@pytest.mark.parametrize("C,dims,bf", [(128, (8, 8, 8), False), (256, (4, 4, 4), False), (128, (8, 8, 8), True), (256, (4, 4, 4), True), (64, (5, 3, 8), False),
+                                       (32, (7, 9, 4), True)])
+def test_dwpair_equals_unfused(C, dims, bf):
+    """cl_dwpair.hip (round 5): the 8^3 / 4^3 stages' two depthwise convs (and their data gradients) in ONE launch == one launch per conv (DLKA_DWPAIR=0): the whole
+    wrapper block's outputs and gradients, fp32 and DLKA_BF16 storage, at the real stage shapes and two ragged ones.  (That block is also held to the oracle by the
+    tblock parity tests, which run through the fused kernel at these shapes.)"""
+    parity.check_dwpair_equals_unfused(DEV, 2, C, dims, lka_bf16=bf)
