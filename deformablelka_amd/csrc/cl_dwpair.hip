@@ -16,6 +16,8 @@
 // an fp32 result) and the GELU-backward one, out = (acc + gelu_add) * gelu'(gelu_x).  bf16 storage: conv B reads conv A's result ROUNDED to bf16, as stored.
 // Taken for W in {4, 8}, N = D H W <= 512, C % 4 = 0 and the two cubic "same" shapes of the Synapse block (5 / dil 1 and 7 / dil 3) in either order; anything else
 // stays on the per-conv kernels.
+#include <atomic>
+
 #include "cl_args.h"
 #include "dlka_kernels.h"
 
@@ -183,12 +185,17 @@ static int launch_pair_t(const DwPairArgs &a, hipStream_t st)
     return DLKA_OK;
 }
 
+static std::atomic<long> g_dwpair_launches{0};   // dlka_dwpair_launch_count (include/dlka.h): diagnostics
+
 // DLKA_ERR_UNSUPPORTED: the caller runs the two convs through launch_cl_dwconv
 int launch_cl_dwpair_small(const DwPairArgs &a, hipStream_t st)
 {
     if (!cl_dwpair_small_supported(a)) return DLKA_ERR_UNSUPPORTED;
+    g_dwpair_launches.fetch_add(1, std::memory_order_relaxed);
     if (a.act_bf16) return a.kA == 5 ? launch_pair_t<bf16_t, 5, 1, 7, 3>(a, st) : launch_pair_t<bf16_t, 7, 3, 5, 1>(a, st);
     return a.kA == 5 ? launch_pair_t<float, 5, 1, 7, 3>(a, st) : launch_pair_t<float, 7, 3, 5, 1>(a, st);
 }
 
 }  // namespace dlka
+
+extern "C" long dlka_dwpair_launch_count(void) { return dlka::g_dwpair_launches.load(std::memory_order_relaxed); }

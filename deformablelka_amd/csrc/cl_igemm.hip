@@ -304,8 +304,97 @@ int launch_cl_prep_weight(const float *w, float *wp, int Cout, int Cin, int K, i
 // A workgroup covers PREP_TABLE_CHUNK elements of ONE job (b.first[k] = first workgroup of job k): the job is found once per workgroup — the first
 // version searched the job list linearly for EVERY element of a grid-stride loop (21 us average per launch in the nn.Module path of the full net).
 constexpr int PREP_TABLE_CHUNK = 2048;
-__device__ __forceinline__ void prep_job_chunk(const PrepJob &j, long l0)
+// Dense jobs (modes 0 - 2) with K <= 27 taps go tile by tile through LDS (round 5): a workgroup owns (8 k, 32 n, all K taps) of the prepared tensor.  In the
+// reference layout W[co][ci][tap] that tile is 32 contiguous runs of 8 K floats (mode 0: k = ci) or 8 runs of 32 K floats (modes 1 / 2: n = ci): read as such, re-laid
+// in LDS, and written as 128-byte rows (plain) or 16-byte bf16 records, 512 contiguous bytes per (tap, term) (split layouts: the 8 k of a record are the tile's 8).
+// The element-per-lane form below read 4-byte pieces Cin K 4 (mode 0) or K 4 bytes apart and wrote 2-byte pieces 16 bytes apart: 47 us for the C = 256 block's
+// 28 MB (0.6 TB/s), 16 us at C = 128 (profiles/r08z_tblock_stage3).
+constexpr int PREP_TILE_KMAX = 27;
+struct alignas(16) PrepU4 { unsigned x, y, z, w; };
+__host__ __device__ inline bool prep_job_tiled(const PrepJob &j)
 {
+    return (j.mode & 7) <= 2 && !(j.mode & 32) && j.K >= 8 && j.K <= PREP_TILE_KMAX && j.KP % 32 == 0 && j.NP % 32 == 0 && j.Cin % 32 == 0 &&
+           (long)j.Cout * j.Cin * j.K * 4 < (1l << 31);   // (bit 32: DLKA_PREP_TILED=0)
+}
+__host__ __device__ inline long prep_job_blocks(const PrepJob &j)
+{
+    return prep_job_tiled(j) ? (long)(j.KP / 8) * (j.NP / 32) : (j.n + PREP_TABLE_CHUNK - 1) / PREP_TABLE_CHUNK;
+}
+
+__device__ __forceinline__ void prep_job_tile(const PrepJob &j, int blk, float *tile)
+{
+    const int K = j.K, m = j.mode & 7;
+    const int nbn = j.NP / 32, kb = blk / nbn, nb = blk % nbn;
+    const int k0 = kb * 8, n0 = nb * 32;
+    const int tid = threadIdx.x;
+    // mode 0 (k = ci, n = co): W[n][k0 .. k0 + 8)[tap] = a run of 8 K contiguous floats per n -> tile[nn][kk * K + tap], 32 rows of stride 8 K + 1
+    // modes 1 / 2 (k = co, n = ci): W[k][n0 .. n0 + 32)[tap] = a run of 32 K contiguous floats per k -> tile[kk][nn * K + tap], 8 rows of stride 32 K + 1
+    // (Cin % 32 == 0: a row is wholly inside or wholly outside the tensor.)  Dword loads — parameters carved from a flat buffer are only 4-byte aligned — one
+    // row (mode 0: 8 K <= 216 floats) or a quarter row (32 K <= 4 x 256) per slot, and all 32 slots of a work-item are issued before the first LDS store:
+    // the tile's latency is ONE trip to memory, not one per loop iteration.
+    {
+        const int run = (m == 0 ? 8 : 32) * K;
+        const BufRsrc rs = make_rsrc(j.src, (size_t)j.Cout * j.Cin * K * 4);   // (range-checked loads: an offset of ~0 reads 0 — no branch per slot)
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int row = m == 0 ? u : (u >> 2), r = m == 0 ? tid : (u & 3) * 256 + tid;
+            const bool in = m == 0 ? (n0 + row < j.Cout && k0 < j.Cin) : (k0 + row < j.Cout && n0 < j.Cin);
+            const unsigned s0 = m == 0 ? (unsigned)((n0 + row) * j.Cin + k0) * (unsigned)K : (unsigned)((k0 + row) * j.Cin + n0) * (unsigned)K;
+            v[u] = buf_load_f32(rs, (in && r < run) ? (s0 + (unsigned)r) * 4u : 0xffffffffu);
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int row = m == 0 ? u : (u >> 2), r = m == 0 ? tid : (u & 3) * 256 + tid;
+            if (r < run) tile[row * (run + 1) + r] = v[u];
+        }
+    }
+    __syncthreads();
+    const int h = (k0 >> 4) & 1, mf = (k0 >> 3) & 1;
+    for (int idx = tid; idx < 32 * K; idx += 256) {
+        const int nn = idx & 31, tp = idx >> 5;
+        const int ts = m == 1 ? K - 1 - tp : tp;   // (data gradient: the flipped kernel)
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = m == 0 ? tile[nn * (8 * K + 1) + e * K + ts] : tile[e * (32 * K + 1) + nn * K + ts];
+        const int n = n0 + nn;
+        if (!(j.mode & 24)) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) j.dst[((long)tp * j.KP + k0 + e) * j.NP + n] = v[e];
+            continue;
+        }
+        unsigned hi[4], md[4], lo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned short a[2], b[2], c[2];
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+                const float val = v[2 * q + z];
+                a[z] = bf16_bits(val);
+                const float r1 = val - bf16_value(a[z]);
+                b[z] = bf16_bits(r1);
+                c[z] = bf16_bits(r1 - bf16_value(b[z]));
+            }
+            hi[q] = (unsigned)a[0] | ((unsigned)a[1] << 16); md[q] = (unsigned)b[0] | ((unsigned)b[1] << 16); lo[q] = (unsigned)c[0] | ((unsigned)c[1] << 16);
+        }
+        if (j.mode & 16) {   // three-term records: a unit takes 48 NP floats
+            PrepU4 *u = reinterpret_cast<PrepU4 *>(j.dst + ((long)tp * (j.KP / 32) + (k0 >> 5)) * 48 * j.NP);
+            u[(long)((0 * 2 + mf) * 2 + h) * j.NP + n] = PrepU4{hi[0], hi[1], hi[2], hi[3]};
+            u[(long)((1 * 2 + mf) * 2 + h) * j.NP + n] = PrepU4{md[0], md[1], md[2], md[3]};
+            u[(long)((2 * 2 + mf) * 2 + h) * j.NP + n] = PrepU4{lo[0], lo[1], lo[2], lo[3]};
+        } else {             // two-term records (second term = bf16(val - hi), the three-term form's "mid")
+            PrepU4 *u = reinterpret_cast<PrepU4 *>(j.dst + ((long)tp * j.KP + (k0 & ~31)) * j.NP);
+            u[(long)((0 * 2 + mf) * 2 + h) * j.NP + n] = PrepU4{hi[0], hi[1], hi[2], hi[3]};
+            u[(long)((1 * 2 + mf) * 2 + h) * j.NP + n] = PrepU4{md[0], md[1], md[2], md[3]};
+        }
+    }
+}
+
+__device__ __forceinline__ void prep_job_chunk(const PrepJob &j, long blk)
+{
+    __shared__ float tile[32 * (8 * PREP_TILE_KMAX + 1)];   // >= 8 * (32 * PREP_TILE_KMAX + 1)
+    if (prep_job_tiled(j)) { prep_job_tile(j, (int)blk, tile); return; }
+    const long l0 = blk * PREP_TABLE_CHUNK;
     for (long l = l0 + threadIdx.x; l < l0 + PREP_TABLE_CHUNK && l < j.n; l += 256) {
         if (j.mode == 5) { j.dst[l] = 0.f; continue; }   // a zero fill riding along (split outputs of the forward pass)
         if (j.mode == 3 || j.mode == 4) {
@@ -322,11 +411,11 @@ __global__ __launch_bounds__(256) void cl_prep_batch_kernel(PrepBatch b)
 {
     int ji = 0;
     while (ji + 1 < b.njobs && (int)blockIdx.x >= b.first[ji + 1]) ++ji;   // (njobs <= PREP_MAX_JOBS, wave-uniform)
-    prep_job_chunk(b.j[ji], (long)((int)blockIdx.x - b.first[ji]) * PREP_TABLE_CHUNK);
+    prep_job_chunk(b.j[ji], (long)((int)blockIdx.x - b.first[ji]));
 }
 
 // The same re-layouts for MANY blocks in one launch: the job table lives in device memory (built once per model, the pointers do not
-// change), `first[j]` = first workgroup of job j; a workgroup finds its job by bisection and covers PREP_TABLE_CHUNK elements of it.
+// change), `first[j]` = first workgroup of job j; a workgroup finds its job by bisection and covers one tile / PREP_TABLE_CHUNK elements of it.
 // (this launch covers jobs [job_lo, job_hi); its workgroup 0 is workgroup first[job_lo] of the whole table)
 __global__ __launch_bounds__(256) void cl_prep_table_kernel(const PrepJob *__restrict__ jobs, const int *__restrict__ first, int job_lo, int job_hi)
 {
@@ -337,10 +426,10 @@ __global__ __launch_bounds__(256) void cl_prep_table_kernel(const PrepJob *__res
         if (first[mid] <= wg) lo = mid; else hi = mid - 1;
     }
     const PrepJob j = jobs[lo];
-    prep_job_chunk(j, (long)(wg - first[lo]) * PREP_TABLE_CHUNK);
+    prep_job_chunk(j, (long)(wg - first[lo]));
 }
 
-int cl_prep_table_blocks(long n) { return (int)cdivl(n, PREP_TABLE_CHUNK); }
+int cl_prep_table_blocks(const PrepJob &j) { return (int)prep_job_blocks(j); }
 
 int launch_cl_prep_table(const PrepJob *jobs_dev, const int *first_dev, int job_lo, int job_hi, int nblocks, hipStream_t st)
 {
@@ -357,7 +446,7 @@ int launch_cl_prep_batch(const PrepBatch &b_, hipStream_t st)
     int blk = 0;
     for (int k = 0; k < b.njobs; ++k) {
         b.first[k] = blk;
-        blk += (int)cdivl(b.j[k].n, PREP_TABLE_CHUNK);
+        blk += (int)prep_job_blocks(b.j[k]);
     }
     b.first[b.njobs] = blk;
     if (blk <= 0) return DLKA_OK;

@@ -556,6 +556,9 @@ void add_job(PrepBatch &pb, const void *src, float *dst, int Cout, int Cin, int 
 {
     PrepJob &j = pb.j[pb.njobs++];
     j.src = (const float *)src; j.dst = dst; j.Cout = Cout; j.Cin = Cin; j.K = K; j.KP = KP; j.NP = NP; j.mode = mode;
+    if (const char *e = getenv("DLKA_PREP_TILED")) {   // =0: the element-per-lane re-layout (mode bit 32, cl_igemm.hip); read when the job is made — a test compares the two bitwise
+        if (e[0] == '0' && (mode & 7) <= 2) j.mode |= 32;
+    }
     j.n = (mode == 3 || mode == 4) ? (long)Cin * K : (long)K * KP * NP;
     pb.total += j.n;
 }
@@ -1505,7 +1508,7 @@ int dlka_lka3d_tokens_prepare_plan(int nblocks, const dlka_lka3d_params *params,
         for (int j = 0; j < pb.njobs; ++j) {
             first[nj] = nb;
             jobs[nj] = pb.j[j];
-            nb += cl_prep_table_blocks(pb.j[j].n);
+            nb += cl_prep_table_blocks(pb.j[j]);
             ++nj;
         }
     }

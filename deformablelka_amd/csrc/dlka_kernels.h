@@ -53,7 +53,7 @@ template <typename T> int launch_gelu_bwd_sum(const T *x, const T *g1, const T *
 // ---- channels-last fast path (cl_*.hip) --------------------------------------------------------------------------
 int launch_cl_prep_weight(const float *w, float *wp, int Cout, int Cin, int K, int KP, int NP, int mode, hipStream_t st);
 int launch_cl_prep_batch(const PrepBatch &b, hipStream_t st);
-int cl_prep_table_blocks(long n);
+int cl_prep_table_blocks(const PrepJob &j);   // workgroups job j takes in a prep table / batch launch
 int launch_cl_prep_table(const PrepJob *jobs_dev, const int *first_dev, int job_lo, int job_hi, int nblocks, hipStream_t st);
 int cl_igemm_pick_splits(int M, int units, int epi, int K);
 int launch_cl_pointwise(const IgemmArgs &a, hipStream_t st);

@@ -494,6 +494,9 @@ void dlka_env_refresh(void);
 long dlka_dwconv_lds_launch_count(void);
 /* launches so far of the LDS-brick data gradient of the offset-predict conv (csrc/cl_conv_brick.hip): parity tests assert which kernel ran */
 long dlka_conv_brick_launch_count(void);
+/* launches so far of the fused small-volume depthwise pair (csrc/cl_dwpair.hip: dw 5^3 -> dw 7^3 dil 3, or their data gradients + GELU', of a volume of at most
+ * 512 voxels with W in {4, 8} in ONE launch; DLKA_DWPAIR=0, read per call, keeps one launch per conv): parity tests assert which kernel ran */
+long dlka_dwpair_launch_count(void);
 size_t dlka_lka3d_tokens_workspace_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
 int dlka_lka3d_attention_tokens_forward_v(const void *x, const dlka_lka3d_params *p, void *y, void *saved, size_t saved_bytes,
                                           void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant, void *stream);

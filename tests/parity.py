@@ -1008,12 +1008,16 @@ def check_dwpair_equals_unfused(dev, B, C, dims, lka_bf16=False, seed=0):
     old = os.environ.get("DLKA_DWPAIR")
     res = []
     try:
+        from deformablelka_amd import _lib
+        lib = _lib.get_lib()
         for mode in ("1", "0"):
             os.environ["DLKA_DWPAIR"] = mode
+            n0 = lib.dlka_dwpair_launch_count()
             stats = torch.empty(6 * C, dtype=torch.float32, device=dev)
             y, saved = ops.tblock3d_forward(x, False, tparams, lparams, mask, True, stats, dims, 1e-5, 1e-5, 0, lka_bf16)
             r = ops.tblock3d_backward(tparams, lparams, mask, True, stats, gy, saved, dims, 0, lka_bf16)
             res.append([y, r[0]] + [t for t in r[1] if t is not None] + list(r[2]))
+            assert lib.dlka_dwpair_launch_count() - n0 == (2 if mode == "1" else 0), (mode, n0, lib.dlka_dwpair_launch_count())   # which kernel produced it
     finally:
         if old is None:
             os.environ.pop("DLKA_DWPAIR", None)
@@ -1028,6 +1032,33 @@ def check_dwpair_equals_unfused(dev, B, C, dims, lka_bf16=False, seed=0):
         worst = max(worst, err)
         assert err <= tol, (k, err)
     return worst
+
+
+def check_prep_tiled_equals_elementwise(dev, stages, dtype=torch.float32):
+    """Weight preparation tile by tile through LDS (cl_igemm.hip prep_job_tile, round 5) writes BITWISE what the element-per-lane re-layout writes (DLKA_PREP_TILED=0,
+    decided when the job table is built): every prepared form of every block of a stack — plain fp32, two- and three-term bf16 records, forward / flipped / column
+    orders, zero padding of Cout = 81 to 96 — compared over the blocks' whole `saved` buffers (zeroed first: both forms must also leave the same bytes untouched)."""
+    from deformablelka_amd.stack import DLKABlockStack
+    old = os.environ.get("DLKA_PREP_TILED")
+    bufs = []
+    try:
+        for mode in ("1", "0"):
+            os.environ["DLKA_PREP_TILED"] = mode
+            st = DLKABlockStack(1, stages=stages, device=dev, dtype=dtype, seed=7)
+            for b in st.blocks:
+                b.saved.zero_()
+            st.prepare()
+            if torch.device(dev).type == "cuda":
+                torch.cuda.synchronize()
+            bufs.append([b.saved.clone().cpu() for b in st.blocks])
+    finally:
+        if old is None:
+            os.environ.pop("DLKA_PREP_TILED", None)
+        else:
+            os.environ["DLKA_PREP_TILED"] = old
+    for k, (a_, b_) in enumerate(zip(*bufs)):
+        assert bool(a_.view(torch.uint8).ne(0).any()), k
+        assert torch.equal(a_.view(torch.uint8), b_.view(torch.uint8)), (k, int(a_.view(torch.uint8).ne(b_.view(torch.uint8)).sum()))
 
 
 def check_wgrad_pad_equals_unpadded(dev, B, Cin, Cout, dims, k, pad, dil, seed=0):

@@ -585,6 +585,7 @@ def test_depthwise_lds_brick_kernel(monkeypatch):
     from deformablelka_amd import _lib
     lib = _lib.get_lib()
     monkeypatch.setenv("DLKA_DW_LDS", "2")
+    monkeypatch.setenv("DLKA_DWPAIR", "0")   # (the second volume is small enough for the fused pair, cl_dwpair.hip, which would take both convs)
     n0 = lib.dlka_dwconv_lds_launch_count()
     parity.check_lka3d_tokens("cpu", 1, 32, (4, 5, 20), offset_std=0.3)
     n1 = lib.dlka_dwconv_lds_launch_count()
@@ -718,6 +719,12 @@ def test_dwconv_two_output_planes(case, monkeypatch):
 def test_tblock3d_phased_backward_equals_one_call(C, dims, bf):
     """dlka_tblock3d_backward_phase_v (round 5: the engine's data-chain / weight-gradient split for the wrapper block): phase 1 then phase 2 == phase 0."""
     parity.check_tblock3d_phased_backward("cpu", 2, C, dims, lka_bf16=bf)
+
+
+@pytest.mark.parametrize("bf", [False, True])
+def test_weight_preparation_tiled_equals_elementwise(bf):
+    """cl_igemm.hip prep_job_tile (round 5): the LDS-tiled weight re-layout is bitwise the element-per-lane one, all prepared forms of a two-width stack."""
+    parity.check_prep_tiled_equals_elementwise("cpu", ((32, (2, 3, 4), 1), (64, (2, 2, 2), 1)), torch.bfloat16 if bf else torch.float32)
 
 
 @pytest.mark.parametrize("C,dims,bf", [(32, (4, 4, 4), False), (32, (3, 5, 8), False), (32, (8, 8, 8), False), (64, (2, 3, 4), True), (32, (5, 3, 8), True)])

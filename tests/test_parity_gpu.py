@@ -974,3 +974,9 @@ def test_dwpair_equals_unfused(C, dims, bf):
     wrapper block's outputs and gradients, fp32 and DLKA_BF16 storage, at the real stage shapes and two ragged ones.  (That block is also held to the oracle by the
     tblock parity tests, which run through the fused kernel at these shapes.)"""
     parity.check_dwpair_equals_unfused(DEV, 2, C, dims, lka_bf16=bf)
+
+
+@pytest.mark.parametrize("bf", [False, True])
+def test_weight_preparation_tiled_equals_elementwise(bf):
+    """cl_igemm.hip prep_job_tile (round 5): the LDS-tiled weight re-layout is bitwise the element-per-lane one — every prepared form of one block of each Synapse width."""
+    parity.check_prep_tiled_equals_elementwise(DEV, ((32, (8, 8, 8), 1), (64, (4, 4, 4), 1), (128, (4, 4, 4), 1), (256, (4, 4, 4), 1)), torch.bfloat16 if bf else torch.float32)
