@@ -19,7 +19,12 @@ ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
 ap.add_argument("--trace", action="store_true")
+ap.add_argument("--lib", default=None, help="another build of libdlka_hip.so (scripts/build_variant.sh), path relative to the repo root")
 a = ap.parse_args()
+if a.lib:
+    import ctypes
+    from deformablelka_amd import _lib as _L
+    _L._lib = _L.bind(ctypes.CDLL(os.path.join(ROOT, a.lib)))
 torch.cuda.set_device(0)
 C, dims, n = SYNAPSE_STAGES[a.stage]
 st = DLKABlockStack(a.batch, stages=((C, dims, 1),), device="cuda:0", dtype=torch.float32 if a.dtype == "f32" else torch.bfloat16)
