@@ -276,8 +276,10 @@ class DLKABlockStack:
         # Sealed plan + side stream: the folds of a block's partial sums follow its weight gradients ON THE SIDE STREAM, a few blocks per launch, instead
         # of one launch for the whole pass after the join (330 us exposed at the end of every step, profiles/r04s): that stream has the slack (the weight
         # gradients are ~40 % of a block's backward work) and only the last group's fold is left behind the last block.  DLKA_STACK_FINALIZE_GROUP=0:
-        # the single launch at the end.  Measured (profiles/r05_notes.md, ms per step): 0 -> 11.135, 1 -> 11.044, 2 -> 11.008, 3 -> 11.09, 5 -> 11.09.
-        fin_group = int(os.environ.get("DLKA_STACK_FINALIZE_GROUP", "2"))
+        # the single launch at the end.  Measured (profiles/r05_notes.md, ms per step): 0 -> 11.135, 1 -> 11.044, 2 -> 11.008, 3 -> 11.09, 5 -> 11.09; on round 5's tree
+        # (faster folds and weight gradients: the side stream has more slack) one block per launch is ahead, 10.07 against 10.11 - 10.14 fp32 and 9.32 against 9.36 bf16
+        # (profiles/r09h_ab_fin_*.json, each configuration twice in one process).
+        fin_group = int(os.environ.get("DLKA_STACK_FINALIZE_GROUP", "1"))
         side_fin = bool(overlap and side is not None and self._fin_sealed and fin_group > 0)
         pending = []   # blocks (descending) whose weight gradients are issued and whose folds are not
 

@@ -385,7 +385,7 @@ def test_hipgraph_replay_reproduces_eager():
 
 def test_stack_grouped_folds_on_the_side_stream_equal_the_single_launch(monkeypatch):
     """With a sealed plan and the weight-gradient stream, DLKABlockStack.backward folds the partial sums of every few blocks right behind their weight
-    gradients on the side stream (DLKA_STACK_FINALIZE_GROUP, default 2) instead of one launch after the join (= 0): same folds, same gradients — incl. a
+    gradients on the side stream (DLKA_STACK_FINALIZE_GROUP, default 1) instead of one launch after the join (= 0): same folds, same gradients — incl. a
     ragged last group (7 blocks) and groups of one."""
     from deformablelka_amd.stack import DLKABlockStack
     stages = ((32, (8, 8, 8), 3), (64, (4, 4, 4), 2), (128, (4, 4, 4), 2))
