@@ -503,7 +503,10 @@ int cl_igemm_pick_splits(int M, int units, int epi, int K)
     // splits of the C=256 / 4^3 offset conv cost 130 us, almost all of it same-address serialisation in L2.  Bound the
     // contention instead of chasing block count.
     static int cap = -1;
-    if (cap < 0) cap = 32;
+#ifndef DLKA_SPLIT_CAP
+#define DLKA_SPLIT_CAP 32
+#endif
+    if (cap < 0) cap = DLKA_SPLIT_CAP;
     static int want = -1;   // workgroups to aim for (tuning knob; -DDLKA_SPLIT_WANT=n builds a variant for scripts/build_variant.sh)
 #ifndef DLKA_SPLIT_WANT
 #define DLKA_SPLIT_WANT 512

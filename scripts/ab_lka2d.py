@@ -21,7 +21,31 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
             if hasattr(cd, name):
                 fn = getattr(cd, name); fn.restype = rs; fn.argtypes = args
         L._lib = cd
-    if os.environ.get("AB_METRIC") == "tblock":
+    if os.environ.get("AB_METRIC") == "stack":   # the timed step of bench.py's headline: the 21-block engine, fwd + bwd from a hipGraph + SGD update (AB_DTYPE=bf16, AB_STAGES=2+3)
+        import time
+        from deformablelka_amd import dp
+        from deformablelka_amd.stack import DLKABlockStack, SYNAPSE_STAGES
+        kw = {}
+        if os.environ.get("AB_STAGES"):
+            kw["stages"] = tuple(SYNAPSE_STAGES[int(i)] for i in os.environ["AB_STAGES"].split("+"))
+        st = DLKABlockStack(2, device=torch.device("cuda", 0), dtype=torch.bfloat16 if os.environ.get("AB_DTYPE") == "bf16" else torch.float32, seed=1234, data_seed=4321, **kw)
+        st.forward_backward(); st.forward_backward()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            st.forward_backward()
+        vals = []
+        for _ in range(3):
+            for _ in range(5):
+                dp.step_single(st, 1e-12, 1, None, g.replay)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                dp.step_single(st, 1e-12, 1, None, g.replay)
+            torch.cuda.synchronize()
+            vals.append(round((time.perf_counter() - t0) / 30 * 1e3, 4))
+        print("RESULT", json.dumps({"ms_per_step": sorted(vals)[1], "all": vals, "finite": st.health()["finite"]}))
+    elif os.environ.get("AB_METRIC") == "tblock":
         r = bench.tblock_metric(2, 10, 3, torch.device("cuda", 0))
         print("RESULT", json.dumps({"value": r["value"], "graph": r.get("hipgraph", {}).get("value")}))
     else:
