@@ -19,6 +19,21 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
 
 
+def rel_err_kink(a, b, drop=2):
+    """rel_err with the `drop` worst OUTPUT CHANNELS (dim 0; elements of a 1-D tensor) left out — the metric for gradients right behind a LeakyReLU kink.
+    One pre-activation within rounding of 0 takes slope 1 in one fp32 implementation and 0.01 in the other (the library's atomics make it vary from run to run on
+    the SAME tree: seen at 2.7e-2 on one conv51 weight of an 8^3 stage, 1 / sqrt(1024 voxels) per element, in one of three runs, profiles/r08_notes.md) and the whole
+    difference sits in that element's output channel of conv.weight / norm.weight / norm.bias; a wrong kernel does not confine itself to two channels.  Tensors
+    with fewer than 8 channels along dim 0 (pos_embed [1, N, C], ...) get the plain metric."""
+    a, b = a.double().cpu(), b.double().cpu()
+    d = (a - b).abs()
+    scale = b.abs().max().clamp_min(1e-6)
+    if d.dim() == 0 or d.shape[0] < 8:
+        return (d.max() / scale).item()
+    per = d.reshape(d.shape[0], -1).max(1).values
+    return (per.sort().values[:-drop].max() / scale).item()
+
+
 def assert_close(name, got, ref, atol=None, rtol=None):
     got, ref = got.double().cpu(), ref.double().cpu()
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
@@ -823,10 +838,15 @@ def check_tblock3d(dev, B, C, dims, training, pos, seed=0, offset_std=0.02, atol
     for k, p in m.named_parameters():
         g = P[k].grad
         if g is not None and g.abs().max() > 0:
-            lim = rtol if any(t in k for t in smooth) else 8 * rtol
-            e = rel_err(p.grad, g)
+            is_smooth = any(t in k for t in smooth)
+            lim = rtol if is_smooth else 8 * rtol
+            # kink-exposed tensors: the bound holds with at most two output channels left out (rel_err_kink), and nothing is further off than one flipped
+            # element of ONE channel can put it (~1 / sqrt(B N) of the tensor's scale, with a factor for the element's own size)
+            e = rel_err(p.grad, g) if is_smooth else rel_err_kink(p.grad, g)
             if e > lim:
                 bad.append(f"{k} rel {e:.3e} > {lim}")
+            if not is_smooth and rel_err(p.grad, g) > max(lim, 4.0 / (B * N) ** 0.5):
+                bad.append(f"{k} rel {rel_err(p.grad, g):.3e} > one kink element's reach {max(lim, 4.0 / (B * N) ** 0.5):.3e}")
     assert not bad, "tblock: " + "; ".join(bad)
 
 
