@@ -16,6 +16,9 @@
 // an fp32 result) and the GELU-backward one, out = (acc + gelu_add) * gelu'(gelu_x).  bf16 storage: conv B reads conv A's result ROUNDED to bf16, as stored.
 // Taken for W in {4, 8}, N = D H W <= 512, C % 4 = 0 and the two cubic "same" shapes of the Synapse block (5 / dil 1 and 7 / dil 3) in either order; anything else
 // stays on the per-conv kernels.
+// Measured (profiles/r08_notes.md, r09a / r09d): 11.5 / 12.7 us at 8^3 against 12.6 + 8.8, 8.8 / 8.3 us at 4^3 against 11.0 + 6.1; step 10.40 -> 10.21 ms fp32.  The kernel sits on the
+// ~5 us floor of a launch in a replayed graph plus three barriers (batched staging loads and a prefetched tap loop changed nothing); a W = 16 / two-channel variant for the 16^3
+// stage was SLOWER than the two row kernels (33 + 41 us against 13 + 19: its LDS row reads are 2-way conflicted and a 4096-voxel volume is work, not latency) and is not here.
 #include <atomic>
 
 #include "cl_args.h"
