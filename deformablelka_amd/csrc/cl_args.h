@@ -161,7 +161,7 @@ struct PrepJob {
     int mode;           // 0 fwd, 1 data-grad (flipped), 2 column matrix (| 8 / | 16: bf16 split layouts); 3 depthwise, 4 depthwise flipped; 5 zero fill of dst
     long n;             // elements of dst
 };
-constexpr int PREP_MAX_JOBS = 20;
+constexpr int PREP_MAX_JOBS = 32;   // (the wrapper block's forward pass puts its own six forms, the attention's fifteen and their zero fills in ONE launch)
 struct PrepBatch {
     PrepJob j[PREP_MAX_JOBS];
     int njobs;

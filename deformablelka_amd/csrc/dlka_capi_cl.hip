@@ -563,8 +563,9 @@ void add_job(PrepBatch &pb, const void *src, float *dst, int Cout, int Cin, int 
     pb.total += j.n;
 }
 
+// collect != null: the jobs go into *collect instead of a launch — replacing its contents, or (append) behind the jobs it already holds
 int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_params *p, hipStream_t st, bool fill, const ZeroBatch *zb = nullptr,
-               PrepBatch *collect = nullptr)
+               PrepBatch *collect = nullptr, bool append = false)
 {
     float *q = base;
     auto take = [&](size_t n) { float *r = q; q += (n + 63) & ~(size_t)63; return r; };
@@ -576,7 +577,9 @@ int carve_prep(const TokGeoms &G, float *base, TokPrep &t, const dlka_lka3d_para
     t.dcn_b16 = take(G.dcn_floats());
     if (!fill) return DLKA_OK;
     PrepBatch pb;
-    memset(&pb, 0, sizeof(pb));
+    if (collect && append) pb = *collect;
+    else memset(&pb, 0, sizeof(pb));
+    if (pb.njobs + 15 + (zb ? zb->n : 0) > PREP_MAX_JOBS) return DLKA_ERR_WORKSPACE;
     const int C = G.pw.Cin;
     const void *pw_w[3] = {p->proj_1_w, p->conv1_w, p->proj_2_w};
     for (int k = 0; k < 3; ++k) {
@@ -2114,13 +2117,26 @@ int dlka_tblock3d_forward_v(const void *x, int x_planar, const dlka_tblock3d_par
         add_zero(sums, 1024);
         if (dense_forward_splits(G.c3, 0) > 1) { add_zero(S.c1, G.E); add_zero(S.c2, G.E); }
         if (dense_forward_splits(G.pw, 3) > 1) add_zero((float *)y, G.E);
+        // ... and the attention's own fifteen forms go out with them (round 5: one launch per block less in the path the trainers call; the attention's zero fills ride
+        // in its first kernel, as they do behind the engine's hoisted preparation)
+        const void *const *pp = (const void *const *)lka;
+        for (size_t k = 0; k < sizeof(*lka) / sizeof(void *); ++k) if (!pp[k]) return DLKA_ERR_NULL;
+        TokGeoms TG(B, C, D, H, W, dtype, variant);
+        Carver lsv(S.lka, S.lka_bytes);   // (the layout tokens_forward_impl carves: h, a, t1, t, offsets, f, g1, then the prepared weights)
+        for (int e = 0; e < 4; ++e) (void)lsv.take(TG.E * TG.SB);
+        (void)lsv.take(TG.Off * 4);
+        (void)lsv.take(TG.E * TG.SB); (void)lsv.take(TG.E * TG.SB);
+        float *lprep = (float *)lsv.take(TG.prep_floats() * 4);
+        if (!lsv.ok()) return DLKA_ERR_WORKSPACE;
+        TokPrep PWl;
+        DLKA_TRY(carve_prep(TG, lprep, PWl, lka, st, true, nullptr, &pb, true));
         DLKA_TRY(launch_cl_prep_batch(pb, st));
     }
     // tokens (+ pos_embed) and LayerNorm (:620-624)
     DLKA_TRY(launch_cl_layernorm_fwd((const float *)x, x_planar, (const float *)p->pos_embed, (const float *)p->norm_w, (const float *)p->norm_b, S.xt, S.xn,
                                      S.lnstats, B, (int)N, C, ln_eps, st, lo, xn32));
     // epa_block = the D-LKA block (:624)
-    DLKA_TRY(tokens_forward_impl(S.xn, lka, S.e, S.lka, S.lka_bytes, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, stream, false, variant, xn32));
+    DLKA_TRY(tokens_forward_impl(S.xn, lka, S.e, S.lka, S.lka_bytes, lka_ws, lka_ws_bytes, B, C, D, H, W, dtype, stream, true, variant, xn32));   // (prepared above)
     // attn = x + gamma * epa (:624); attn IS attn_skip in channels-last memory (:626 is a view here)
     DLKA_TRY(launch_cl_scale_residual_fwd(S.xt, S.e, (const float *)p->gamma, S.attn, M, C, st, lo));
     // conv51 = UnetResBlock (dynunet_block.py:66-80)
