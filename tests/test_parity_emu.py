@@ -727,7 +727,8 @@ def test_weight_preparation_tiled_equals_elementwise(bf):
     parity.check_prep_tiled_equals_elementwise("cpu", ((32, (2, 3, 4), 1), (64, (2, 2, 2), 1)), torch.bfloat16 if bf else torch.float32)
 
 
-@pytest.mark.parametrize("C,dims,bf", [(32, (4, 4, 4), False), (32, (3, 5, 8), False), (32, (8, 8, 8), False), (64, (2, 3, 4), True), (32, (5, 3, 8), True)])
+@pytest.mark.parametrize("C,dims,bf", [(32, (4, 4, 4), False), (32, (3, 5, 8), False), (32, (8, 8, 8), False), (64, (2, 3, 4), True), (32, (5, 3, 8), True),
+                                       (32, (1, 1, 4), False), (32, (7, 1, 8), True)])   # (the last two: one w-row per channel, a single plane of rows)
 def test_dwpair_equals_unfused(C, dims, bf):
     """cl_dwpair.hip (round 5): both depthwise convs of a small volume in one launch == one launch per conv (DLKA_DWPAIR=0), forward and backward."""
     parity.check_dwpair_equals_unfused("cpu", 2, C, dims, lka_bf16=bf)
