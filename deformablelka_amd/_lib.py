@@ -163,6 +163,7 @@ SIGNATURES = {
                                                        POINTER(Lka3dPtrs), c_void_p, c_size_t] + [c_int] * 7 + [c_void_p]),
     "dlka_lka3d_tokens_saved_offsets_v": (c_int, [c_int] * 7 + [POINTER(c_size_t)]),
     "dlka_tblock3d_saved_offsets_v": (c_int, [c_int] * 7 + [POINTER(c_size_t)]),
+    "dlka_tblock3d_saved_activations_v": (c_int, [c_int] * 7 + [POINTER(c_size_t)]),
     "dlka_tblock3d_supported_v": (c_int, [c_int] * 7),
     "dlka_tblock3d_saved_bytes_v": (c_size_t, [c_int] * 7),
     "dlka_tblock3d_workspace_bytes_v": (c_size_t, [c_int] * 7),

@@ -676,7 +676,7 @@ int launch_cl_layernorm_fwd(const float *x, int x_planar, const float *pos, cons
                             int C, float eps, hipStream_t st, int lo, float *xn32)
 {
     if (C > 64 * KMAX) return DLKA_ERR_UNSUPPORTED;
-    if (!x_planar && quad_shape_ok(C, (long)B * N) && quad_aligned(x) && quad_aligned(xt) && quad_aligned(xn) && quad_aligned(pos) && quad_aligned(xn32)) {
+    if (!x_planar && quad_shape_ok(C, (long)B * N) && quad_aligned(x) && quad_aligned(xt) && quad_aligned(xn) && quad_aligned(pos) && quad_aligned(xn32) && quad_aligned(w) && quad_aligned(b)) {
         const long M = (long)B * N;
         DLKA_QUAD_DISPATCH(C, cl_layernorm_fwd_q_kernel, quad_grid(M, C, 2, 4096), x, pos, w, b, xt, xn, stats, M, N, eps, lo, xn32)
         DLKA_CHECK_LAUNCH();
@@ -696,7 +696,7 @@ int launch_cl_layernorm_bwd(const float *g, const float *g_res, const float *xt,
         DLKA_TRY_LAUNCH(launch_zero(gb, (size_t)C * 4, st));
         if (gpos) DLKA_TRY_LAUNCH(launch_zero(gpos, (size_t)N * C * 4, st));
     }
-    if (quad_shape_ok(C, (long)B * N) && quad_aligned(g) && quad_aligned(g_res) && quad_aligned(xt) && quad_aligned(gxt)) {
+    if (quad_shape_ok(C, (long)B * N) && quad_aligned(g) && quad_aligned(g_res) && quad_aligned(xt) && quad_aligned(gxt) && quad_aligned(w)) {
         const long M = (long)B * N;
         DLKA_QUAD_DISPATCH(C, cl_layernorm_bwd_q_kernel, quad_grid(M, C, 4, 1024), g, g_res, xt, stats, w, gxt, gw, gb, gpos, M, N, lo)
         DLKA_CHECK_LAUNCH();
@@ -710,7 +710,7 @@ int launch_cl_layernorm_bwd(const float *g, const float *g_res, const float *xt,
 
 int launch_cl_scale_residual_fwd(const float *xt, const float *e, const float *gamma, float *out, long M, int C, hipStream_t st, int lo)
 {
-    if (quad_shape_ok(C, M) && quad_aligned(xt) && quad_aligned(e) && quad_aligned(out)) {
+    if (quad_shape_ok(C, M) && quad_aligned(xt) && quad_aligned(e) && quad_aligned(out) && quad_aligned(gamma)) {
         DLKA_QUAD_DISPATCH(C, cl_scale_residual_fwd_q_kernel, quad_grid(M, C, 2, 4096), xt, e, gamma, out, M, lo)
         DLKA_CHECK_LAUNCH();
         return DLKA_OK;
@@ -723,7 +723,7 @@ int launch_cl_scale_residual_fwd(const float *xt, const float *e, const float *g
 int launch_cl_scale_residual_bwd(const float *g, const float *e, const float *gamma, float *ge, float *ggamma, long M, int C, hipStream_t st, bool zeroed, int lo)
 {
     if (!zeroed) DLKA_TRY_LAUNCH(launch_zero(ggamma, (size_t)C * 4, st));
-    if (quad_shape_ok(C, M) && quad_aligned(g) && quad_aligned(e) && quad_aligned(ge)) {
+    if (quad_shape_ok(C, M) && quad_aligned(g) && quad_aligned(e) && quad_aligned(ge) && quad_aligned(gamma)) {
         DLKA_QUAD_DISPATCH(C, cl_scale_residual_bwd_q_kernel, quad_grid(M, C, 4, 1024), g, e, gamma, ge, ggamma, M, lo)
         DLKA_CHECK_LAUNCH();
         return DLKA_OK;

@@ -188,12 +188,50 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
 // (x 3/2 for K > 1: the three-term bf16 layout of the forward weights takes 48 instead of 32 floats per unit and column)
 size_t dense_wp_floats(const SameConv &s) { return (size_t)s.K * round_up(s.Cin, 32) * round_up(s.Cout, 32) * (s.K > 1 ? 3 : 2) / 2; }
 
+// ---- environment switches, read once (dlka_env_refresh() re-reads) ------------------------------------------------
+struct ForkEnv {
+    bool gx_rows_set;
+    long gx_rows;       // DLKA_GX_FORK_MIN_ROWS
+    int lka2d_fork;     // DLKA_LKA2D_FORK: 0 = one stream, 1 = the offset nets' weight gradients only, 2 (unset) = + grad_input beside grad_offset
+    // A/B switches that used to be read with getenv() on every call (getenv racing with os.environ writes of other Python threads is undefined behaviour, and a
+    // workspace-size query could disagree with the carve that follows it).  Tests that toggle them call dlka_env_refresh().
+    bool wgrad_pad;     // DLKA_WGRAD_PAD != 0: the dense weight gradient from a zero-padded copy (cl_wgrad.hip)
+    bool dwpair;        // DLKA_DWPAIR != 0: both depthwise convs of a small volume in one launch (cl_dwpair.hip)
+    bool prep_tiled;    // DLKA_PREP_TILED != 0: weight preparation tile by tile through LDS (cl_igemm.hip prep_job_tile)
+};
+static std::mutex g_fork_env_mu;
+static ForkEnv g_fork_env;
+static std::atomic<int> g_fork_env_loaded{0};
+static void fork_env_load()
+{
+    std::lock_guard<std::mutex> lk(g_fork_env_mu);
+    ForkEnv e;
+    const char *r = getenv("DLKA_GX_FORK_MIN_ROWS");
+    e.gx_rows_set = r != nullptr;
+    e.gx_rows = r ? atol(r) : 0;
+    const char *f = getenv("DLKA_LKA2D_FORK");
+    e.lka2d_fork = !f ? 2 : f[0] == '0' ? 0 : f[0] == '1' ? 1 : 2;
+    auto off = [](const char *name) { const char *v = getenv(name); return v && v[0] == '0'; };
+    e.wgrad_pad = !off("DLKA_WGRAD_PAD");
+    e.dwpair = !off("DLKA_DWPAIR");
+    e.prep_tiled = !off("DLKA_PREP_TILED");
+    g_fork_env = e;
+    g_fork_env_loaded.store(1, std::memory_order_release);
+}
+static ForkEnv fork_env()
+{
+    if (!g_fork_env_loaded.load(std::memory_order_acquire)) fork_env_load();
+    std::lock_guard<std::mutex> lk(g_fork_env_mu);
+    return g_fork_env;
+}
+
 // ---- dense conv weight gradient -----------------------------------------------------------------------------------
 // padbuf (optional, dense_wgrad_pad_bytes(s) bytes): scratch for the zero-padded copy of x — selects the padded kernels (cl_wgrad.hip, round 5) where they apply
 size_t dense_wgrad_pad_bytes(const SameConv &s)
 {
-    const char *e = getenv("DLKA_WGRAD_PAD");   // (A/B: 0 = the unpadded kernels of rounds 2 - 4.  Read per call: a workspace sized with the padded copy and used without it, or the
-    if ((e && e[0] == '0') || s.K <= 1 || s.group != 1) return 0;   //  other way round, is safe — the optional carve returns null when there is no room, and null selects the unpadded kernels)
+    // (DLKA_WGRAD_PAD=0: the unpadded kernels of rounds 2 - 4.  A workspace sized with the padded copy and used without it, or the other way round, is safe — the optional
+    //  carve returns null when there is no room, and null selects the unpadded kernels)
+    if (!fork_env().wgrad_pad || s.K <= 1 || s.group != 1) return 0;
     const size_t n = cl_wgrad_pad_bytes(s.B, s.D, s.H, s.W, s.Cin, s.kd, s.kh, s.kw, s.dd, s.dh, s.dw, s.act_bf16);
     return n < ((size_t)1 << 31) ? align256(n) : 0;
 }
@@ -275,8 +313,7 @@ int dw_forward(const SameConv &s, const float *x, const float *w, const float *b
 // flipped one for the data gradients — "same" padding is its own mirror).  DLKA_ERR_UNSUPPORTED: not that shape (or DLKA_DWPAIR=0) — the caller runs them one by one.
 static int dwpair_mode()
 {
-    const char *e = getenv("DLKA_DWPAIR");
-    return (e && e[0] == '0') ? 0 : 1;
+    return fork_env().dwpair ? 1 : 0;
 }
 
 int dw_pair(const SameConv &sa, const SameConv &sb, const float *x, const float *wpA, const float *biasA, float *outA, float *outA_lo, const float *wpB, const float *biasB,
@@ -556,9 +593,7 @@ void add_job(PrepBatch &pb, const void *src, float *dst, int Cout, int Cin, int 
 {
     PrepJob &j = pb.j[pb.njobs++];
     j.src = (const float *)src; j.dst = dst; j.Cout = Cout; j.Cin = Cin; j.K = K; j.KP = KP; j.NP = NP; j.mode = mode;
-    if (const char *e = getenv("DLKA_PREP_TILED")) {   // =0: the element-per-lane re-layout (mode bit 32, cl_igemm.hip); read when the job is made — a test compares the two bitwise
-        if (e[0] == '0' && (mode & 7) <= 2) j.mode |= 32;
-    }
+    if (!fork_env().prep_tiled && (mode & 7) <= 2) j.mode |= 32;   // DLKA_PREP_TILED=0: the element-per-lane re-layout (cl_igemm.hip); decided when the job is made — a test compares the two bitwise
     j.n = (mode == 3 || mode == 4) ? (long)Cin * K : (long)K * KP * NP;
     pb.total += j.n;
 }
@@ -802,32 +837,6 @@ public:
 #endif
 
 // Environment switches of the fork decisions, read ONCE (dlka_env_refresh() re-reads: tests and the A/B scripts toggle them in-process).
-struct ForkEnv {
-    bool gx_rows_set;
-    long gx_rows;       // DLKA_GX_FORK_MIN_ROWS
-    int lka2d_fork;     // DLKA_LKA2D_FORK: 0 = one stream, 1 = the offset nets' weight gradients only, 2 (unset) = + grad_input beside grad_offset
-};
-static std::mutex g_fork_env_mu;
-static ForkEnv g_fork_env;
-static std::atomic<int> g_fork_env_loaded{0};
-static void fork_env_load()
-{
-    std::lock_guard<std::mutex> lk(g_fork_env_mu);
-    ForkEnv e;
-    const char *r = getenv("DLKA_GX_FORK_MIN_ROWS");
-    e.gx_rows_set = r != nullptr;
-    e.gx_rows = r ? atol(r) : 0;
-    const char *f = getenv("DLKA_LKA2D_FORK");
-    e.lka2d_fork = !f ? 2 : f[0] == '0' ? 0 : f[0] == '1' ? 1 : 2;
-    g_fork_env = e;
-    g_fork_env_loaded.store(1, std::memory_order_release);
-}
-static ForkEnv fork_env()
-{
-    if (!g_fork_env_loaded.load(std::memory_order_acquire)) fork_env_load();
-    std::lock_guard<std::mutex> lk(g_fork_env_mu);
-    return g_fork_env;
-}
 // (phase 0 = the one-call backward of the nn.Module path: there the fork measured SLOWER — wrapper-block stack 100.5 against 102.5 volumes/s, full net 68.8 against 69.8 — so by
 //  default only the stack engine's data-chain pass, phase 1, forks; DLKA_GX_FORK_MIN_ROWS = row count from which a call forks (a huge value = never), when set, rules both)
 bool gx_fork_wanted(long rows, int phase)
@@ -1318,9 +1327,7 @@ int dlka_ndhwc_to_ncdhw(const void *src, void *dst, int B, int C, int N, int dty
 // ---- fork contexts: diagnostics and the cached switches ---------------------------------------------------------------------------
 void dlka_env_refresh(void)
 {
-#if !defined(HIPEMU)
     fork_env_load();
-#endif
 }
 
 int dlka_fork_stats(int device, int64_t *contexts, int64_t *leases)
@@ -2053,6 +2060,17 @@ int dlka_tblock3d_saved_offsets_v(int B, int C, int D, int H, int W, int dtype, 
     DLKA_TRY(dlka_lka3d_tokens_saved_offsets_v(B, C, D, H, W, dtype, variant, &inner));
     // carve_tblock_saved: eight activation tensors, the LayerNorm statistics, six prepared weight forms, then the D-LKA block's own `saved`
     *byte_offset = 8 * align256(G.E * 4) + align256(G.M * 2 * 4) + 4 * align256(dense_wp_floats(G.c3) * 4) + 2 * align256(dense_wp_floats(G.pw) * 4) + inner;
+    return DLKA_OK;
+}
+
+int dlka_tblock3d_saved_activations_v(int B, int C, int D, int H, int W, int dtype, int variant, size_t byte_offsets[2])
+{
+    if (!byte_offsets) return DLKA_ERR_NULL;
+    if (!dlka_tblock3d_supported_v(B, C, D, H, W, dtype, variant)) return DLKA_ERR_UNSUPPORTED;
+    TBlockGeoms G(B, C, D, H, W);
+    // carve_tblock_saved: xt, xn, e, attn, c1, a1, c2, rd
+    byte_offsets[0] = 5 * align256(G.E * 4);
+    byte_offsets[1] = 7 * align256(G.E * 4);
     return DLKA_OK;
 }
 

@@ -638,6 +638,19 @@ def tblock3d_saved_offsets(saved, B, C, dims, variant=0, lka_bf16=False):
     return saved[o:o + B * 81 * D * H * W * 4].view(torch.float32).view(B, 81, D, H, W)
 
 
+def tblock3d_saved_activation_signs(saved, B, C, dims, variant=0, lka_bf16=False):
+    """(a1 > 0, rd > 0, rd != 0) as bool tensors [B, N, C]: the activation pattern of UnetResBlock's two LeakyReLUs in the forward call that wrote ``saved``
+    (``dlka_tblock3d_saved_activations_v``; rd carries the Dropout3d multipliers: a dropped channel is all zeros, hence the third tensor).  Diagnostics for
+    the parity tests' kink analysis."""
+    D, H, W = (int(v) for v in dims)
+    offs = (ctypes.c_size_t * 2)()
+    L.check(L.get_lib().dlka_tblock3d_saved_activations_v(B, C, D, H, W, L.DLKA_BF16 if lka_bf16 else L.DLKA_F32, int(variant), offs), "tblock3d_saved_activations")
+    n = B * D * H * W * C
+    a1 = saved[int(offs[0]):int(offs[0]) + n * 4].view(torch.float32).view(B, D * H * W, C)
+    rd = saved[int(offs[1]):int(offs[1]) + n * 4].view(torch.float32).view(B, D * H * W, C)
+    return a1 > 0, rd > 0, rd != 0
+
+
 def lka3d_attention_tokens_backward(x, params, grad_y, saved, dims, variant=0):
     L.require_device(x, grad_y, saved, *params)
     x, grad_y = x.contiguous(), grad_y.to(x.dtype).contiguous()

@@ -7,6 +7,7 @@ offset-predict conv, deformable 3^3 conv, conv1, gate, proj_2, residual) as ONE 
 (``dlka_lka3d_attention_forward/backward``).  ``LKA3d_deform`` alone runs through the per-op kernels.
 """
 import os
+import threading
 import weakref
 
 import torch
@@ -157,25 +158,52 @@ class WgradOverlap:
     def __init__(self, device):
         self.device = device
         self.side = torch.cuda.Stream(device=device)
-        self.pending = []
-        self.armed = False
+        self.pending = {}   # (thread, caller stream) -> [keep-alive lists]: two threads running backward on one device join only their own submissions
+
+    def _key(self):
+        return (threading.get_ident(), torch.cuda.current_stream(self.device).cuda_stream)
 
     def submit(self, keep):
-        self.pending.append(keep)
+        key = self._key()
+        self.pending.setdefault(key, []).append(keep)
         # one callback per SUBMIT, not one per pass guarded by a flag: a backward pass that raised after a block's submit never runs its callbacks, and a flag
         # left set by it would keep every later pass from joining.  The first callback of a pass joins; the others find nothing pending.
-        self.armed = True
-        torch.autograd.Variable._execution_engine.queue_callback(self.join)
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: self.join(key))
 
-    def join(self):
-        if not self.pending:
-            self.armed = False
+    def join(self, key=None):
+        key = self._key() if key is None else key
+        if not self.pending.get(key):
+            self.pending.pop(key, None)
             return
         ev = torch.cuda.Event()
-        ev.record(self.side)
+        ev.record(self.side)   # (behind everything submitted so far, by any caller: a superset of this caller's work)
         torch.cuda.current_stream(self.device).wait_event(ev)
-        self.pending.clear()
-        self.armed = False
+        self.pending.pop(key, None)
+
+    @staticmethod
+    def eligible(ctx, mod, params, first_param_arg):
+        """The side-stream pass writes EVERY weight gradient on the side stream and keeps them alive only through autograd's ownership of the returned tensors.  That
+        holds only if autograd keeps each of them until backward() returns, untouched by the main stream: every parameter must require a gradient (autograd drops the
+        gradient of a frozen one at once, and the caching allocator would hand its memory to the next main-stream allocation while the side stream still writes it), carry no
+        ``.grad`` yet (accumulation would read it early), and the block must be applied ONCE in the graph (two applications: the engine adds their gradients on the main
+        stream before the side stream has finished).  Anything else takes the one-stream pass."""
+        if not all(ctx.needs_input_grad[first_param_arg + i] for i, p in enumerate(params) if p is not None):
+            return False
+        if not all(p.requires_grad and p.grad is None for p in mod.parameters()):
+            return False
+        return not ctx.wgrad_shared[0]
+
+
+def _note_application(mod, ctx):
+    """Marks every not-yet-differentiated application of `mod` (incl. this one) as shared when there is more than one: see WgradOverlap.eligible."""
+    live = [r for r in getattr(mod, "_wgrad_live", ()) if r() is not None and not r().wgrad_done[0]]
+    ctx.wgrad_shared, ctx.wgrad_done = [False], [False]
+    if live:
+        ctx.wgrad_shared[0] = True
+        for r in live:
+            r().wgrad_shared[0] = True
+    live.append(weakref.ref(ctx))
+    mod._wgrad_live = live
 
 
 class _TBlock3dFn(Function):
@@ -187,7 +215,10 @@ class _TBlock3dFn(Function):
         tparams, lka_params = params[:12], params[12:]
         y, saved = ops.tblock3d_forward(x, x_planar, tparams, lka_params, drop_mask, training, bn_stats, dims, eps[0], eps[1], variant, lka_bf16)
         ctx.cfg = (x_planar, dims, training, tuple(x.shape), [p is not None for p in tparams], (variant, lka_bf16))
+        ctx.param_args = [p is not None or None for p in params]   # (which of the trailing arguments are tensors: WgradOverlap.eligible reads needs_input_grad for them)
         ctx.owner = owner   # a weak reference to the module when it asked for the side-stream schedule (WgradOverlap), else None
+        if owner is not None and owner() is not None:
+            _note_application(owner(), ctx)
         ctx.save_for_backward(saved, bn_stats, drop_mask, *[p for p in params if p is not None])
         return y
 
@@ -200,7 +231,9 @@ class _TBlock3dFn(Function):
         tparams = [next(it) if here else None for here in present]
         lka_params = list(it)
         mod = ctx.owner() if ctx.owner is not None else None
-        if mod is not None and not WgradOverlap.disabled and gy.is_cuda and all(p.grad is None for p in mod.parameters()):
+        if mod is not None:
+            ctx.wgrad_done[0] = True
+        if mod is not None and not WgradOverlap.disabled and gy.is_cuda and WgradOverlap.eligible(ctx, mod, ctx.param_args, 8):
             ov = WgradOverlap.get(gy.device)
             gx, tg, lg, keep = ops.tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, gy, saved, dims, variant, lka_bf16, side_stream=ov.side)
             ov.submit(keep)

@@ -514,6 +514,10 @@ size_t dlka_tblock3d_saved_bytes_v(int B, int C, int D, int H, int W, int dtype,
  * layout, deform_im2col_cuda.cuh:237-243). */
 int dlka_lka3d_tokens_saved_offsets_v(int B, int C, int D, int H, int W, int dtype, int variant, size_t *byte_offset);
 int dlka_tblock3d_saved_offsets_v(int B, int C, int D, int H, int W, int dtype, int variant, size_t *byte_offset);
+/* Diagnostics (the parity tests' LeakyReLU-kink analysis): byte offsets, inside the `saved` buffer of a wrapper-block forward call, of the two tensors
+ * whose SIGN is the activation pattern of UnetResBlock's two LeakyReLUs (dynunet_block.py:69-70,77-79): byte_offsets[0] = a1 = lrelu(norm1(conv1(x))),
+ * byte_offsets[1] = rd = dropout3d(lrelu(norm2(conv2(a1)) + x)); both fp32 tokens [B][N][C] on both dtypes. */
+int dlka_tblock3d_saved_activations_v(int B, int C, int D, int H, int W, int dtype, int variant, size_t byte_offsets[2]);
 size_t dlka_tblock3d_workspace_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
 int dlka_tblock3d_forward_v(const void *x, int x_planar, const dlka_tblock3d_params *p, const dlka_lka3d_params *lka,
                             const void *drop_mask, int training, void *bn_stats, void *y, void *saved, size_t saved_bytes,

@@ -68,7 +68,23 @@ def lka3d_attention_tokens(x, P, B, C, H, W, D, store=None, chain_store=None, of
     return v.reshape(B, C, H * W * D).permute(0, 2, 1)
 
 
-def unet_res_block(x, P, prefix, training, stats_out=None):
+def leaky_relu_signed(z, sign=None, known=None, pre_out=None, slope=0.01):
+    """LeakyReLU whose activation PATTERN can be taken from another implementation's forward pass: sign (bool, z's shape) = that implementation's
+    `z > 0`, used where `known` (bool; None = everywhere), the own `z > 0` elsewhere.  Two correct fp32 implementations disagree about the pattern only
+    for pre-activations within rounding of 0, and there the slope jumps by a factor 100 — the same role `offsets_override` plays for floor() in the
+    deformable conv.  pre_out: list receiving (z.detach(), pattern used) for the tests' count of such elements."""
+    if sign is None:
+        if pre_out is not None:
+            pre_out.append((z.detach(), z.detach() > 0))
+        return F.leaky_relu(z, slope)
+    pat = sign if known is None else torch.where(known, sign, z.detach() > 0)
+    pat = pat.contiguous()   # (torch 2.10 CPU: the backward of torch.where with a NON-contiguous condition — e.g. a permuted token view at B = 1 — is wrong)
+    if pre_out is not None:
+        pre_out.append((z.detach(), pat))
+    return torch.where(pat, z, slope * z)
+
+
+def unet_res_block(x, P, prefix, training, stats_out=None, act_signs=None, pre_out=None):
     """UnetResBlock(3, C, C, kernel_size=3, stride=1, norm_name="batch").forward — dynunet_block.py:66-80 with MONAI 0.8's
     factories resolved (Convolution conv_only -> Conv3d bias=False padding 1; "batch" -> BatchNorm3d; LeakyReLU 0.01).
     Running statistics are NOT updated in place (the caller's dict stays intact); in training mode batch statistics are used."""
@@ -77,14 +93,16 @@ def unet_res_block(x, P, prefix, training, stats_out=None):
         if training:
             return F.batch_norm(v, None, None, P[prefix + n + ".weight"], P[prefix + n + ".bias"], True, 0.1, 1e-5)
         return F.batch_norm(v, rm, rv, P[prefix + n + ".weight"], P[prefix + n + ".bias"], False, 0.1, 1e-5)
+    s1, s2, k2 = act_signs if act_signs is not None else (None, None, None)      # (another implementation's activation patterns: leaky_relu_signed)
     out = F.conv3d(x, P[prefix + "conv1.conv.weight"], None, padding=1)          # :68
-    out = F.leaky_relu(bn(out, "norm1"), 0.01)                                   # :69-70
+    out = leaky_relu_signed(bn(out, "norm1"), s1, None, pre_out)                 # :69-70
     out = F.conv3d(out, P[prefix + "conv2.conv.weight"], None, padding=1)        # :71
     out = bn(out, "norm2")                                                       # :72
-    return F.leaky_relu(out + x, 0.01)                                           # :77-79
+    return leaky_relu_signed(out + x, s2, k2, pre_out)                           # :77-79
 
 
-def transformer_block_3d(x, P, training=False, drop_mask=None, offsets_override=None, offsets_out=None, lka_store=None, lka_chain_fp32=True):
+def transformer_block_3d(x, P, training=False, drop_mask=None, offsets_override=None, offsets_out=None, lka_store=None, lka_chain_fp32=True,
+                         act_signs=None, pre_out=None):
     """TransformerBlock_3D_single_deform_LKA.forward — transformerblock.py:617-630.  drop_mask: the (B, C) multipliers of
     conv8[0] = Dropout3d(0.1) (None = eval / no dropout).  lka_store: ``bf16_storage`` = the model of the wrapper block's MIXED mode (the D-LKA
     attention on bf16 activations: its input, every tensor it stores and its output rounded where they are written; the wrapper itself fp32)."""
@@ -100,7 +118,7 @@ def transformer_block_3d(x, P, training=False, drop_mask=None, offsets_override=
     attn = t + P["gamma"] * lka3d_attention_tokens(n, lka, B, C, H, W, D, store=lka_store, offsets_override=offsets_override, offsets_out=offsets_out,
                                                    x_chain=n32)        # :624
     skip = attn.reshape(B, H, W, D, C).permute(0, 4, 1, 2, 3)                    # :626
-    a = unet_res_block(skip, P, "conv51.", training)                             # :627
+    a = unet_res_block(skip, P, "conv51.", training, act_signs=act_signs, pre_out=pre_out)   # :627  (act_signs: NCDHW bool (s1, s2, s2_known), leaky_relu_signed)
     if drop_mask is not None:
         a = a * drop_mask.view(B, C, 1, 1, 1)
     return skip + F.conv3d(a, P["conv8.1.weight"], P["conv8.1.bias"])            # :628

@@ -24,6 +24,8 @@ class OracleTransformerBlock(dk.TransformerBlock_3D_single_deform_LKA):
     offsets_in = None
     offsets_log = None
     masks = None
+    signs_in = None    # iterator over per-block (s1, s2, s2_known) NCDHW bool tensors: the kernels' LeakyReLU activation patterns (blocks.leaky_relu_signed)
+    kink_log = None    # list receiving (differing elements, largest |z| / max|z| among them, elements) per LeakyReLU
 
     def forward(self, x, keep_channels_last=None):
         cls = OracleTransformerBlock
@@ -37,11 +39,22 @@ class OracleTransformerBlock(dk.TransformerBlock_3D_single_deform_LKA):
         if drop.training and drop.p > 0:
             mask = next(cls.masks) if cls.masks is not None else self._draw_drop_mask(B, C, x.dtype, x.device)
         override = next(cls.offsets_in) if cls.offsets_in is not None else None
-        used = []
-        y = blocks.transformer_block_3d(x.contiguous(), P, self.conv51.norm1.training, mask, offsets_override=override, offsets_out=used)
+        signs = next(cls.signs_in) if cls.signs_in is not None else None
+        used, pre = [], []
+        y = blocks.transformer_block_3d(x.contiguous(), P, self.conv51.norm1.training, mask, offsets_override=override, offsets_out=used, act_signs=signs,
+                                        pre_out=pre)
         if cls.offsets_log is not None:
             cls.offsets_log.append(used[0])
+        if cls.kink_log is not None:
+            cls.kink_log.extend(kink_stats(z, pat) for z, pat in pre)
         return y.contiguous()
+
+
+def kink_stats(z, pat):
+    """(elements whose activation pattern differs from the own z > 0, the largest |z| / max|z| among them, elements)."""
+    dis = pat != (z > 0)
+    k = int(dis.sum())
+    return k, (float(z[dis].abs().max() / z.abs().max().clamp_min(1e-30)) if k else 0.0), z.numel()
 
 
 def liven_(net, offset_std=0.05, seed=7):
@@ -73,7 +86,8 @@ def segmentation_loss(outs, target):
 
 def run_pair(dev, img_size, B=1, num_classes=14, seed=0, offset_std=0.05, training=True, backward=True):
     """Runs the HIP net and the oracle-assembled net on the same seeded input / parameters / dropout masks.
-    Returns a dict: logits of both (own offsets / the kernels' offsets), losses, gradients, per-block offsets, flip counts."""
+    Returns a dict: logits of both (own offsets / the kernels' offsets AND LeakyReLU activation patterns), losses, gradients, per-block offsets, flip counts,
+    per-LeakyReLU counts of the patterns that differ."""
     import oracle
     torch.manual_seed(seed)
     kw = dict(in_channels=1, out_channels=num_classes, img_size=list(img_size), feature_size=16, num_heads=4, depths=[3, 3, 3, 3],
@@ -96,7 +110,7 @@ def run_pair(dev, img_size, B=1, num_classes=14, seed=0, offset_std=0.05, traini
         it = iter(masks)
         for blk in net.dlka_blocks():
             blk._draw_drop_mask = (lambda B_, C_, dtype, device, _it=it: next(_it).to(device=device, dtype=dtype))
-    saved_log = []
+    saved_log, sign_log = [], []
     orig = ops.tblock3d_forward
 
     def spy(x_, x_planar, tparams, lka_params, drop_mask, training_, bn_stats, dims, *a, **k):
@@ -104,8 +118,14 @@ def run_pair(dev, img_size, B=1, num_classes=14, seed=0, offset_std=0.05, traini
         C_ = int(lka_params[0].shape[0])
         B_ = int(x_.numel() // (C_ * dims[0] * dims[1] * dims[2]))
         saved_log.append(ops.tblock3d_saved_offsets(out[1], B_, C_, dims).cpu().clone())
+        sign_log.append(tuple(t.cpu().permute(0, 2, 1).reshape(B_, C_, *dims) for t in ops.tblock3d_saved_activation_signs(out[1], B_, C_, dims)))
         return out
 
+    # the plumbing's LeakyReLUs (encoder1 / decoder2: network.UnetResBlock.lrelu, called twice per forward): the pattern of every call, by module name
+    plumb_signs, hooks = {}, []
+    for name, mod in net.named_modules():
+        if isinstance(mod, torch.nn.LeakyReLU) and ".conv51." not in name:   # (a block's own UnetResBlock runs inside the fused call: its pattern is in `saved`)
+            hooks.append(mod.register_forward_hook(lambda _m, _i, out, _n=name: plumb_signs.setdefault(_n, []).append((out.detach() > 0).cpu())))
     ops.tblock3d_forward = spy
     try:
         xd = x.to(dev)
@@ -119,17 +139,35 @@ def run_pair(dev, img_size, B=1, num_classes=14, seed=0, offset_std=0.05, traini
             loss = segmentation_loss(outs, target.to(dev))
     finally:
         ops.tblock3d_forward = orig
+        for h in hooks:
+            h.remove()
     assert len(saved_log) == nblk, (len(saved_log), nblk)
     res = {"hip_logits": [o.detach().float().cpu() for o in outs], "hip_loss": float(loss.detach()), "hip_offsets": saved_log,
            "hip_grads": {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters() if p.grad is not None} if backward else {}}
 
     # ---- oracle-assembled net: (1) on its own offsets, (2) on the kernels' offset values (identical sampling cells) ----
-    def run_ref(offsets):
+    def run_ref(offsets, signs=None):
+        """signs: (per-block patterns, per-module plumbing patterns) of the HIP net's forward pass — every LeakyReLU of the oracle net then takes the kernels' side of
+        its kink (tests/parity.py, the kink protocol); the elements where that differs from the oracle's own z > 0 are counted in kink_log."""
         cls = OracleTransformerBlock
         ref.zero_grad(set_to_none=True)
         cls.offsets_in = iter(offsets) if offsets is not None else None
         cls.offsets_log = []
         cls.masks = iter(masks) if training else None
+        cls.signs_in = iter(signs[0]) if signs is not None else None
+        cls.kink_log = []
+        patched = []
+        if signs is not None:
+            for name, mod in ref.named_modules():
+                if isinstance(mod, torch.nn.LeakyReLU) and name in signs[1]:
+                    it = iter(signs[1][name])
+
+                    def fwd(z, _it=it, _slope=mod.negative_slope):
+                        pat = next(_it).contiguous()   # (non-contiguous conditions: see oracle.blocks.leaky_relu_signed)
+                        cls.kink_log.append(kink_stats(z.detach(), pat))
+                        return torch.where(pat, z, _slope * z)
+                    mod.forward = fwd
+                    patched.append(mod)
         try:
             if backward:
                 o = ref(x)
@@ -140,13 +178,17 @@ def run_pair(dev, img_size, B=1, num_classes=14, seed=0, offset_std=0.05, traini
                     o = ref(x)
                 l = segmentation_loss(o, target)
             log = cls.offsets_log
+            run_ref.kinks = cls.kink_log
         finally:
-            cls.offsets_in = cls.offsets_log = cls.masks = None
+            cls.offsets_in = cls.offsets_log = cls.masks = cls.signs_in = cls.kink_log = None
+            for mod in patched:
+                del mod.forward
         return ([t.detach().clone() for t in o], float(l.detach()), log,
                 {k: p.grad.detach().clone() for k, p in ref.named_parameters() if p.grad is not None} if backward else {})
 
     res["ref_logits"], res["ref_loss"], res["ref_offsets"], res["ref_grads"] = run_ref(None)
-    res["same_logits"], res["same_loss"], _, res["same_grads"] = run_ref(saved_log)
+    res["same_logits"], res["same_loss"], _, res["same_grads"] = run_ref(saved_log, (sign_log, plumb_signs))
+    res["kinks"] = run_ref.kinks   # per LeakyReLU of the "same" run: (patterns that differ from the oracle's own, how close to 0 they are, elements)
     k3 = ((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1))
     flips, total = 0, 0
     for oh, orf in zip(res["hip_offsets"], res["ref_offsets"]):
@@ -164,6 +206,10 @@ def summarize(res, top=8):
     relative gradient errors (max-norm) of every parameter — against the oracle net on its own offsets and on identical cells."""
     from tests.parity import rel_err
     out = {"flipped": res["flipped"], "samples": res["samples"]}
+    if "kinks" in res:
+        out["kink_differ"] = sum(k for k, _, _ in res["kinks"])
+        out["kink_worst_rel_z"] = max([r for _, r, _ in res["kinks"]] + [0.0])
+        out["kink_elements"] = sum(n for _, _, n in res["kinks"])
     for tag in ("ref", "same"):
         lg = res[tag + "_logits"]
         out[tag + "_logit_abs"] = [float((a - b).abs().max()) for a, b in zip(res["hip_logits"], lg)]

@@ -19,19 +19,10 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
 
 
-def rel_err_kink(a, b, drop=2):
-    """rel_err with the `drop` worst OUTPUT CHANNELS (dim 0; elements of a 1-D tensor) left out — the metric for gradients right behind a LeakyReLU kink.
-    One pre-activation within rounding of 0 takes slope 1 in one fp32 implementation and 0.01 in the other (the library's atomics make it vary from run to run on
-    the SAME tree: seen at 2.7e-2 on one conv51 weight of an 8^3 stage, 1 / sqrt(1024 voxels) per element, in one of three runs, profiles/r08_notes.md) and the whole
-    difference sits in that element's output channel of conv.weight / norm.weight / norm.bias; a wrong kernel does not confine itself to two channels.  Tensors
-    with fewer than 8 channels along dim 0 (pos_embed [1, N, C], ...) get the plain metric."""
-    a, b = a.double().cpu(), b.double().cpu()
-    d = (a - b).abs()
-    scale = b.abs().max().clamp_min(1e-6)
-    if d.dim() == 0 or d.shape[0] < 8:
-        return (d.max() / scale).item()
-    per = d.reshape(d.shape[0], -1).max(1).values
-    return (per.sort().values[:-drop].max() / scale).item()
+def _refresh_switches():
+    """The library reads its A/B switches once (dlka_env_refresh re-reads): call after every change of DLKA_WGRAD_PAD / DLKA_DWPAIR / DLKA_PREP_TILED / the fork switches."""
+    from deformablelka_amd import _lib
+    _lib.get_lib().dlka_env_refresh()
 
 
 def assert_close(name, got, ref, atol=None, rtol=None):
@@ -352,20 +343,11 @@ def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=FWD_ATOL, 
     gy = torch.randn_like(x)
     m0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
 
-    def run_oracle(override=None):
-        P = {k: v.detach().clone().requires_grad_(True) for k, v in m0.items()}
-        xr = x.detach().clone().requires_grad_(True)   # (detach: on the CPU backend `x.to(dev)` below IS x, and requires_grad_ marks it)
-        used = []
+    def oracle_fn(xr, P, override, used):
         if volume:
-            yr = blocks.lka3d_attention_volume(xr, P, offsets_override=override, offsets_out=used)
-        else:
-            yr = blocks.lka3d_attention_tokens(xr, P, B, C, H, W, D, offsets_override=override, offsets_out=used)
-        yr.backward(gy)
-        run_oracle.offsets = used[0]
-        return yr.detach(), xr.grad, {k: v.grad for k, v in P.items()}
+            return blocks.lka3d_attention_volume(xr, P, offsets_override=override, offsets_out=used)
+        return blocks.lka3d_attention_tokens(xr, P, B, C, H, W, D, offsets_override=override, offsets_out=used)
 
-    yr, gxr, gr = run_oracle()
-    off_ref = run_oracle.offsets   # the offsets THIS oracle run sampled with
     m = m.to(dev)
     xd = x.to(dev).requires_grad_(True)
     # the kernels' predicted offsets come from the `saved` buffer of THE forward call whose gradients are checked (a second, identical call can
@@ -391,32 +373,131 @@ def check_lka3d_tokens(dev, B, C, dims, seed=0, offset_std=0.02, atol=FWD_ATOL, 
     if "saved" not in captured:   # (a path that does not go through the fused token call: general per-op composition)
         _, captured["saved"] = ops.lka3d_attention_tokens_forward(x.detach().to(dev), [p_.detach() for p_ in m.block_params()], dims, variant)
     off_hip = ops.lka3d_tokens_saved_offsets(captured["saved"], B, C, dims).cpu().clone()
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    return compare_lka3d_with_oracle(f"tokens C={C} dims={dims}", oracle_fn, x, gy, m0, dims, y, xd.grad, grads, off_hip, atol=atol, rtol=rtol,
+                                     report=report_offsets)
+
+
+def compare_lka3d_with_oracle(tag, oracle_fn, x, gy, params, dims, y, gx, grads, off_hip, atol=FWD_ATOL, rtol=BWD_RTOL, report=False):
+    """The flips-counted + same-cells protocol (docstring of check_lka3d_tokens) for ANY run of the 3-D block: oracle_fn(x, P, offsets_override, offsets_out) -> y is the
+    oracle block on CPU tensors, params its state_dict-keyed parameters; y / gx / grads (dict by the same keys) / off_hip are what the run under test produced (any device)."""
+    def run_oracle(override=None):
+        P = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+        xr = x.detach().cpu().clone().requires_grad_(True)   # (detach: on the CPU backend `x.to(dev)` IS x, and requires_grad_ marks it)
+        used = []
+        yr = oracle_fn(xr, P, override, used)
+        yr.backward(gy.detach().cpu())
+        run_oracle.offsets = used[0]
+        return yr.detach(), xr.grad, {k: v.grad for k, v in P.items()}
+
+    yr, gxr, gr = run_oracle()
+    off_ref = run_oracle.offsets   # the offsets THIS oracle run sampled with
+    off_hip = off_hip.detach().cpu()
     k3 = ((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1))
     i_h, m_h = oracle.deform_conv3d_sample_index(off_hip, dims, *k3)
     i_r, m_r = oracle.deform_conv3d_sample_index(off_ref, dims, *k3)
     flipped = int(((i_h != i_r).any(-1) | (m_h != m_r)).sum())
     y2, gx2, g2 = run_oracle(off_hip)
-    if report_offsets or os.environ.get("DLKA_PARITY_VERBOSE"):
-        print(f"[tokens C={C} dims={dims}] y abs {(y.detach().cpu() - yr).abs().max().item():.3e} gx rel {rel_err(xd.grad, gxr):.3e}; "
+    if report or os.environ.get("DLKA_PARITY_VERBOSE"):
+        print(f"[{tag}] y abs {(y.detach().cpu() - yr).abs().max().item():.3e} gx rel {rel_err(gx, gxr):.3e}; "
               f"offsets max |hip - oracle| {(off_hip - off_ref).abs().max().item():.2e}, cell-flipped samples {flipped} of {m_r.numel()}")
-        for k, p in m.named_parameters():
+        for k, g in grads.items():
             if gr[k] is not None and gr[k].abs().max() > 0:
-                print(f"    {k:55s} own offsets {rel_err(p.grad, gr[k]):.3e}   same cells {rel_err(p.grad, g2[k]):.3e}")
+                print(f"    {k:55s} own offsets {rel_err(g, gr[k]):.3e}   same cells {rel_err(g, g2[k]):.3e}")
+    # Both caps BEFORE the flip-dependent bound is derived from the count (VERDICT r5): the predicted offsets themselves agree to fp32 rounding of a 27 C-term sum, and
+    # only a handful of samples may sit close enough to a cell boundary for that to move them (the same cap the mixed-bf16 check uses).
+    off_err = (off_hip - off_ref).abs().max().item()
+    assert off_err <= 1e-4, f"{tag}: predicted offsets max |hip - oracle| {off_err:.3e} > 1e-4"
+    assert flipped <= max(3, int(2e-5 * m_r.numel())), f"{tag}: {flipped} of {m_r.numel()} sampling cells differ from the oracle's (cap max(3, 2e-5 n))"
     # own offsets with flips: a flipped sample's grad_offset is O(1) off, and the gradients that collect grad_offset sum ~sqrt(samples) such terms: 8e-3 covers the real
-    # volumes; a SMALL volume needs the 1 / sqrt(samples) term (fuzz, B = 1, 8^3: ONE flipped sample of 13 824 — the library's atomics decide from run to run whether it
-    # flips — put conv_offset.weight.grad at 1.16e-2, profiles/r08_notes.md).  The comparison on identical cells below stays at the contract's 1e-3 regardless.
-    flip_rtol = rtol if flipped == 0 else max(8 * rtol, 3.0 * (flipped / m_r.numel()) ** 0.5)
+    # volumes; a SMALL volume needs the 1 / sqrt(samples) term (fuzz, B = 1, 8^3: ONE flipped sample of 13 824 put conv_offset.weight.grad at 1.16e-2,
+    # profiles/r08_notes.md).  The comparison on identical cells below stays at the contract's 1e-3 regardless.
+    # (per flipped sample: the engine's decoder block with N(0, 1) grad_y and TWO flips measured 8.9e-3 on conv_offset.weight.grad; the count is capped above.)
+    flip_rtol = rtol if flipped == 0 else min(5e-2, max(8 * rtol * flipped, 3.0 * (flipped / m_r.numel()) ** 0.5))
     exposed = ("conv_offset", "conv_spatial.", "conv0.", "proj_1.")
-    assert_close("tokens y", y, yr, atol=atol)
-    assert_close("tokens gx", xd.grad, gxr, rtol=flip_rtol)
-    assert_close("tokens y (same cells)", y, y2, atol=atol)
-    assert_close("tokens gx (same cells)", xd.grad, gx2, rtol=rtol)
-    for k, p in m.named_parameters():
+    assert_close(tag + " y", y, yr, atol=atol)
+    assert_close(tag + " gx", gx, gxr, rtol=flip_rtol)
+    assert_close(tag + " y (same cells)", y, y2, atol=atol)
+    assert_close(tag + " gx (same cells)", gx, gx2, rtol=rtol)
+    for k, g_hip in grads.items():
         g = gr[k]
         if g is not None and g.abs().max() > 0:
-            assert_close("tokens grad " + k, p.grad, g, rtol=flip_rtol if any(e in k for e in exposed) else rtol)
-            assert_close("tokens grad (same cells) " + k, p.grad, g2[k], rtol=rtol)
+            assert_close(f"{tag} grad " + k, g_hip, g, rtol=flip_rtol if any(e in k for e in exposed) else rtol)
+            assert_close(f"{tag} grad (same cells) " + k, g_hip, g2[k], rtol=rtol)
     return flipped
+
+
+STACK_PARAM_NAMES = ("proj_1.weight", "proj_1.bias", "spatial_gating_unit.conv0.weight", "spatial_gating_unit.conv0.bias", "spatial_gating_unit.conv_spatial.weight",
+                     "spatial_gating_unit.conv_spatial.bias", "spatial_gating_unit.deform_conv.conv_offset.weight", "spatial_gating_unit.deform_conv.conv_offset.bias",
+                     "spatial_gating_unit.deform_conv.weight", "spatial_gating_unit.deform_conv.bias", "spatial_gating_unit.conv1.weight", "spatial_gating_unit.conv1.bias",
+                     "proj_2.weight", "proj_2.bias")   # dlka_lka3d_params order (include/dlka.h) = LKA_Attention3d_deform.block_params()
+
+
+def check_stack_step(st, entry_blocks, oracle_blocks, sync=None):
+    """The state a `DLKABlockStack` step left behind (every block's x / y / grad_y / grad_x / saved / gradients are resident) against
+      (1) the per-block entry points (`dlka_lka3d_attention_tokens_forward/backward`: one stream, private scratch, in-call weight preparation and folds) run now on the
+          same x / grad_y, for `entry_blocks`: y, the predicted offsets, grad_x and all 14 parameter gradients — the backward entry both on the ENGINE's saved
+          activations (identical cells: only the order of the few fp32 atomics may differ, 2e-3) and on its own forward pass (cells that differ counted);
+      (2) the CPU oracle block with the flips-counted + same-cells protocol (compare_lka3d_with_oracle), for `oracle_blocks`.
+    The stack must not have been stepped (parameter update) since the pass."""
+    from deformablelka_amd import ops
+    from oracle import blocks
+    sync = sync or (torch.cuda.synchronize if st.device.type == "cuda" else (lambda: None))
+    B = st.B
+    k3 = ((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1))
+    exposed = ("conv_offset", "conv_spatial.", "conv0.", "proj_1.")
+
+    def scaled(a, b):
+        return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-6))
+
+    report = []
+    for bi in entry_blocks:
+        blk = st.blocks[bi]
+        C, dims = blk.C, blk.dims
+        tag = f"block {bi} (C={C}, {dims})"
+        x, gy = blk.x.clone(), blk.gy.clone()
+        params = [p.clone() for p in blk.params]
+        y1, saved1 = ops.lka3d_attention_tokens_forward(x, params, dims, 0)
+        e_y = scaled(blk.y, y1)
+        off_e = ops.lka3d_tokens_saved_offsets(blk.saved, B, C, dims, st.dtype).cpu()
+        off_1 = ops.lka3d_tokens_saved_offsets(saved1, B, C, dims, st.dtype).cpu()
+        e_off = float((off_e - off_1).abs().max())
+        i_e, m_e = oracle.deform_conv3d_sample_index(off_e, dims, *k3)
+        i_1, m_1 = oracle.deform_conv3d_sample_index(off_1, dims, *k3)
+        flipped = int(((i_e != i_1).any(-1) | (m_e != m_1)).sum())
+        gx_a, g_a = ops.lka3d_attention_tokens_backward(x, params, gy, blk.saved, dims, 0)
+        gx_b, g_b = ops.lka3d_attention_tokens_backward(x, params, gy, saved1, dims, 0)
+        sync()
+        errs_a = {"gx": scaled(blk.gx, gx_a), **{n: scaled(g, ga) for n, g, ga in zip(STACK_PARAM_NAMES, blk.grads, g_a) if float(ga.abs().max()) > 0}}
+        errs_b = {"gx": scaled(blk.gx, gx_b), **{n: scaled(g, gb) for n, g, gb in zip(STACK_PARAM_NAMES, blk.grads, g_b) if float(gb.abs().max()) > 0}}
+        report.append((tag, e_y, e_off, flipped, max(errs_a.values()), max(errs_b.values())))
+        ytol = 2e-5 if st.dtype == torch.float32 else 1.6e-2   # (bf16 storage: one ulp of the largest element where an fp32 sum lands on the other side of a rounding boundary)
+        assert e_y <= ytol, f"{tag}: y differs from the per-block entry by {e_y:.3e} of max|y|"
+        assert e_off <= 1e-5, f"{tag}: predicted offsets differ from the per-block entry by {e_off:.3e}"
+        assert flipped <= 3, f"{tag}: {flipped} sampling cells differ between the engine's and the per-block forward pass"
+        gtol = 2e-3 if st.dtype == torch.float32 else 1.6e-2
+        for n, e in errs_a.items():
+            assert e <= gtol, f"{tag}: {n} differs from the per-block backward entry (engine's saved activations) by {e:.3e}"
+        flip_tol = gtol if flipped == 0 else max(8e-3, gtol, 3.0 * (flipped / m_e.numel()) ** 0.5)
+        for n, e in errs_b.items():
+            lim = flip_tol if (n == "gx" or any(t in n for t in exposed)) else gtol
+            assert e <= lim, f"{tag}: {n} differs from the per-block entry (own forward pass, {flipped} cells differ) by {e:.3e} > {lim:.1e}"
+    for r in report:
+        print("[engine vs per-block entry] %s: y %.1e offsets %.1e cells %d  grads (engine's saved) %.1e (own forward) %.1e" % r)
+    for bi in oracle_blocks:
+        assert st.dtype == torch.float32
+        blk = st.blocks[bi]
+        C, dims = blk.C, blk.dims
+        H, W, D = dims
+        P = {n: p.detach().cpu().clone() for n, p in zip(STACK_PARAM_NAMES, blk.params)}
+        grads = {n: g.detach().cpu().clone() for n, g in zip(STACK_PARAM_NAMES, blk.grads)}
+        off_e = ops.lka3d_tokens_saved_offsets(blk.saved, B, C, dims).cpu().clone()
+
+        def oracle_fn(xr, Pr, override, used, _s=(B, C, H, W, D)):
+            return blocks.lka3d_attention_tokens(xr, Pr, *_s, offsets_override=override, offsets_out=used)
+
+        compare_lka3d_with_oracle(f"engine block {bi} C={C} dims={dims}", oracle_fn, blk.x.float().cpu(), blk.gy.float().cpu(), P, dims,
+                                  blk.y.float().cpu(), blk.gx.float().cpu(), grads, off_e, report=True)
 
 
 def check_lka3d_tokens_sample_handover(dev, B, C, dims, dtype=torch.float32, seed=0, offset_std=0.3):
@@ -760,9 +841,43 @@ def check_scale_residual(dev, M, C, seed=0):
     assert_close("channel scale", ops.channel_scale(x3.to(dev), mask.to(dev)), x3 * mask[:, None, :], atol=1e-6)
 
 
+# The LeakyReLU-kink protocol (wrapper block, assembled net).  LeakyReLU's slope jumps from 0.01 to 1 at 0: a pre-activation within fp32 rounding of 0 can sit on
+# different sides in two correct implementations, and ONE such element moves a gradient summed over N voxels by ~1 / sqrt(N) of its scale.  As for floor() in the
+# deformable conv (cells counted, oracle re-run on the kernels' cells) the elements are IDENTIFIED, COUNTED and CAPPED, and the oracle is re-run on the kernels' own
+# activation pattern (read back from `saved`: dlka_tblock3d_saved_activations_v) — after which EVERY element of EVERY gradient is held to the contract's 1e-3.
+KINK_NEAR = 1e-4          # a disagreeing pre-activation must be this close to 0, relative to max |z| of its tensor (fp32 rounding of a 27 C-term sum: ~1e-6)
+KINK_MAX_FRACTION = 2e-5  # ... and at most max(3, this fraction) of a tensor's elements may disagree (expected for z ~ N(0, 1) +- 1e-6: ~1e-6 of them)
+
+
+def tokens_to_volume(t, B, C, dims):
+    """[B, N, C] tokens -> [B, C, *dims] (the reference's permuted view, transformerblock.py:626)."""
+    return t.permute(0, 2, 1).reshape(B, C, *dims)
+
+
+def kink_report(pre_out):
+    """pre_out: [(z, pattern used)] per LeakyReLU (oracle.blocks.leaky_relu_signed).  Returns (number of elements whose pattern differs from the oracle's own z > 0,
+    the largest |z| / max|z| among them, total elements) and asserts the caps above."""
+    n_dis, worst, total = 0, 0.0, 0
+    for z, pat in pre_out:
+        dis = pat != (z > 0)
+        k = int(dis.sum())
+        total += z.numel()
+        if k:
+            rel = float(z[dis].abs().max() / z.abs().max().clamp_min(1e-30))
+            worst = max(worst, rel)
+            assert rel <= KINK_NEAR, f"activation pattern differs at a pre-activation {rel:.2e} of max|z| away from LeakyReLU's kink (> {KINK_NEAR}): not a rounding flip"
+            assert k <= max(3, int(KINK_MAX_FRACTION * z.numel())), f"{k} of {z.numel()} LeakyReLU pre-activations on the other side of the kink"
+        n_dis += k
+    return n_dis, worst, total
+
+
 def check_tblock3d(dev, B, C, dims, training, pos, seed=0, offset_std=0.02, atol=FWD_ATOL, rtol=BWD_RTOL, chain=False, report=False, acdc=False):
-    """The fused wrapper block vs the oracle composition (oracle/blocks.py transformer_block_3d)."""
+    """The fused wrapper block vs the oracle composition (oracle/blocks.py transformer_block_3d): forward 1e-4 abs (north_star), EVERY gradient 1e-3 rel
+    (SURVEY §8c), every element of it — on identical sampling cells (the oracle fed the kernels' predicted offsets, as check_lka3d_tokens does) and on the
+    kernels' activation pattern at UnetResBlock's two LeakyReLUs (kink protocol above: disagreements counted and capped).  chain=True: two applications of the
+    block, each with its own offsets / patterns.  The plain comparison (oracle on its own cells and pattern) is reported and sanity-bounded."""
     import deformablelka_amd as dk
+    from deformablelka_amd import ops as _ops
     from oracle import blocks
     torch.manual_seed(seed)
     H, W, D = dims
@@ -786,70 +901,88 @@ def check_tblock3d(dev, B, C, dims, training, pos, seed=0, offset_std=0.02, atol
     x = torch.randn(B, C, H, W, D)
     gy = torch.randn(B, C, H, W, D)
     mask = torch.nn.functional.dropout3d(torch.ones(B, C, 1, 1, 1), 0.1, True).view(B, C) if training else None
-    def run_oracle(override=None):
+    napp = 2 if chain else 1
+
+    def run_oracle(overrides=None):
+        """overrides: per application (offsets, (s1, s2, s2_known)) from the kernels' forward pass, or None = the oracle's own cells and pattern."""
         Pr = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.detach().clone())
               for k, v in m0.items()}
         xr_ = x.detach().clone().requires_grad_(True)
-        yr_ = blocks.transformer_block_3d(xr_, Pr, training, mask, offsets_override=override)
-        if chain:
-            yr_ = blocks.transformer_block_3d(yr_, Pr, training, mask)
+        pre, offs = [], []
+        yr_ = xr_
+        for a_ in range(napp):
+            o_, s_ = overrides[a_] if overrides is not None else (None, None)
+            yr_ = blocks.transformer_block_3d(yr_, Pr, training, mask, offsets_override=o_, offsets_out=offs, act_signs=s_, pre_out=pre)
         yr_.backward(gy)
-        return yr_, xr_, Pr
+        return yr_.detach(), xr_.grad, {k: v.grad for k, v in Pr.items() if torch.is_tensor(v) and v.requires_grad}, pre, offs
     m0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    yr, xr, P = run_oracle()
+    y0, gx0, g0, _, off0 = run_oracle()
     m = m.to(dev)
     m._draw_drop_mask = lambda B_, C_, dtype, device: mask.to(device)
     xd = x.to(dev).requires_grad_(True)
     m.keep_channels_last = chain
-    y = m(xd)
-    if chain:
-        assert y.permute(0, 2, 3, 4, 1).is_contiguous()   # opt-in: the channels_last_3d view of the token memory
-        y = m(y)                                          # second application reads the tokens in place (x_planar = 0)
-    else:
-        assert y.is_contiguous()                          # default: contiguous NCDHW like the reference (transformerblock.py:626-630)
+    saved_log = []
+    orig = _ops.tblock3d_forward
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        saved_log.append(out[1])
+        return out
+
+    _ops.tblock3d_forward = spy
+    try:
+        y = m(xd)
+        if chain:
+            assert y.permute(0, 2, 3, 4, 1).is_contiguous()   # opt-in: the channels_last_3d view of the token memory
+            y = m(y)                                          # second application reads the tokens in place (x_planar = 0)
+        else:
+            assert y.is_contiguous()                          # default: contiguous NCDHW like the reference (transformerblock.py:626-630)
+    finally:
+        _ops.tblock3d_forward = orig
+    assert len(saved_log) == napp
     y.backward(gy.to(dev))
+    variant = m.epa_block.variant
+    overrides, flipped, nsamp = [], 0, 0
+    k3 = ((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1))
+    for a_, sv in enumerate(saved_log):
+        off_hip = _ops.tblock3d_saved_offsets(sv, B, C, dims, variant).cpu().clone()
+        s1, s2, k2 = (tokens_to_volume(t.cpu(), B, C, dims) for t in _ops.tblock3d_saved_activation_signs(sv, B, C, dims, variant))
+        overrides.append((off_hip, (s1, s2, k2)))
+        i_h, m_h = oracle.deform_conv3d_sample_index(off_hip, dims, *k3)
+        i_r, m_r = oracle.deform_conv3d_sample_index(off0[a_], dims, *k3)
+        flipped += int(((i_h != i_r).any(-1) | (m_h != m_r)).sum())
+        nsamp += m_r.numel()
+    yr, gxr, gr, pre, _ = run_oracle(overrides)
+    n_dis, worst_z, n_act = kink_report(pre)
     if report or os.environ.get("DLKA_PARITY_VERBOSE"):
-        print(f"[tblock C={C} dims={dims}] y abs", (y.detach().cpu() - yr.detach()).abs().max().item(), "of max |y|", yr.detach().abs().max().item(),
-              "gx rel", rel_err(xd.grad, xr.grad))
+        print(f"[tblock C={C} dims={dims}] y abs {(y.detach().cpu() - yr).abs().max().item():.3e} of max |y| {yr.abs().max().item():.3e}; gx rel {rel_err(xd.grad, gxr):.3e} "
+              f"(own cells / pattern: {rel_err(xd.grad, gx0):.3e}); cells that differ {flipped} of {nsamp}; LeakyReLU patterns that differ {n_dis} of {n_act} "
+              f"(|z| <= {worst_z:.1e} of max)")
         for k, p in m.named_parameters():
-            if P[k].grad is not None:
-                print(f"  {k:60s} {rel_err(p.grad, P[k].grad):.3e}")
-    # Contract tolerances: forward 1e-4 abs (north_star), gradients 1e-3 rel for everything that is a smooth function of the inputs —
-    # here: conv51.conv2 / norm2 and conv8, the tail of the block.  The rest of the wrapper's backward pass runs through TWO kinks where two correct
-    # fp32 implementations can land on different sides for the handful of elements within rounding of them: LeakyReLU at 0 (conv51: slope 1 | 0.01)
-    # and the sampling cell of the deformable conv (floor).  A gradient that is a random-sign sum over N voxels has magnitude ~sqrt(N) terms, so ONE
-    # such element moves it by ~1 / sqrt(N) (4e-3 at 32^3): every tensor upstream of conv51's first activation gets 8e-3 against the oracle on the
-    # SAME sampling cells (the oracle is fed the kernels' offset values, read back through the same LayerNorm + block kernels the wrapper launches —
-    # check_lka3d_tokens shows that on identical cells the block itself is inside 1e-3).  All failures are reported at once.
-    smooth = ("conv51.conv2", "conv51.norm2", "conv8.")
-    if not chain:
-        from deformablelka_amd import ops as _ops
-        with torch.no_grad():
-            xin = x.detach().to(dev)
-            pe = m.pos_embed.detach() if m.pos_embed is not None else None
-            _, xn, _ = _ops.layernorm_tokens_forward(xin.contiguous(), True, pe, m.norm.weight.detach(), m.norm.bias.detach(), m.norm.eps)
-            _, sv = _ops.lka3d_attention_tokens_forward(xn, [p_.detach() for p_ in m.epa_block.block_params()], dims, m.epa_block.variant)
-            off_hip = _ops.lka3d_tokens_saved_offsets(sv, B, C, dims).cpu().clone()
-        yr, xr, P = run_oracle(off_hip)
+            if gr.get(k) is not None:
+                print(f"  {k:60s} {rel_err(p.grad, gr[k]):.3e}   (own cells / pattern {rel_err(p.grad, g0[k]):.3e})")
+    assert flipped <= max(3, int(2e-5 * nsamp)), f"tblock: {flipped} of {nsamp} sampling cells differ from the oracle's"
     bad = []
-    e = (y.detach().cpu().double() - yr.detach().double()).abs().max().item()
+    e = (y.detach().cpu().double() - yr.double()).abs().max().item()
     if e > atol:
         bad.append(f"y abs {e:.3e} > {atol}")
-    e = rel_err(xd.grad, xr.grad)
-    if e > 8 * rtol:
-        bad.append(f"gx rel {e:.3e} > {8 * rtol}")
+    e = (y.detach().cpu().double() - y0.double()).abs().max().item()
+    if e > atol:
+        bad.append(f"y abs (oracle on its own cells) {e:.3e} > {atol}")
+    e = rel_err(xd.grad, gxr)
+    if e > rtol:
+        bad.append(f"gx rel {e:.3e} > {rtol}")
+    # the plain comparison: each differing cell / pattern element moves a gradient by at most ~1 / sqrt(voxels) of its scale
+    loose = max(8 * rtol, 4.0 * (flipped + n_dis) / (B * N) ** 0.5) if flipped + n_dis else rtol
     for k, p in m.named_parameters():
-        g = P[k].grad
+        g = gr.get(k)
         if g is not None and g.abs().max() > 0:
-            is_smooth = any(t in k for t in smooth)
-            lim = rtol if is_smooth else 8 * rtol
-            # kink-exposed tensors: the bound holds with at most two output channels left out (rel_err_kink), and nothing is further off than one flipped
-            # element of ONE channel can put it (~1 / sqrt(B N) of the tensor's scale, with a factor for the element's own size)
-            e = rel_err(p.grad, g) if is_smooth else rel_err_kink(p.grad, g)
-            if e > lim:
-                bad.append(f"{k} rel {e:.3e} > {lim}")
-            if not is_smooth and rel_err(p.grad, g) > max(lim, 4.0 / (B * N) ** 0.5):
-                bad.append(f"{k} rel {rel_err(p.grad, g):.3e} > one kink element's reach {max(lim, 4.0 / (B * N) ** 0.5):.3e}")
+            e = rel_err(p.grad, g)
+            if e > rtol:
+                bad.append(f"{k} rel {e:.3e} > {rtol}")
+            e = rel_err(p.grad, g0[k])
+            if e > loose:
+                bad.append(f"{k} rel (oracle on its own cells / pattern) {e:.3e} > {loose:.3e}")
     assert not bad, "tblock: " + "; ".join(bad)
 
 
@@ -1035,6 +1168,7 @@ def check_dwpair_equals_unfused(dev, B, C, dims, lka_bf16=False, seed=0):
         lib = _lib.get_lib()
         for mode in ("1", "0"):
             os.environ["DLKA_DWPAIR"] = mode
+            _refresh_switches()
             n0 = lib.dlka_dwpair_launch_count()
             stats = torch.empty(6 * C, dtype=torch.float32, device=dev)
             y, saved = ops.tblock3d_forward(x, False, tparams, lparams, mask, True, stats, dims, 1e-5, 1e-5, 0, lka_bf16)
@@ -1046,6 +1180,7 @@ def check_dwpair_equals_unfused(dev, B, C, dims, lka_bf16=False, seed=0):
             os.environ.pop("DLKA_DWPAIR", None)
         else:
             os.environ["DLKA_DWPAIR"] = old
+        _refresh_switches()
     tol = 2e-2 if lka_bf16 else 2e-3
     worst = 0.0
     for k, (a_, b_) in enumerate(zip(*res)):
@@ -1067,6 +1202,7 @@ def check_prep_tiled_equals_elementwise(dev, stages, dtype=torch.float32):
     try:
         for mode in ("1", "0"):
             os.environ["DLKA_PREP_TILED"] = mode
+            _refresh_switches()
             st = DLKABlockStack(1, stages=stages, device=dev, dtype=dtype, seed=7)
             for b in st.blocks:
                 b.saved.zero_()
@@ -1079,6 +1215,7 @@ def check_prep_tiled_equals_elementwise(dev, stages, dtype=torch.float32):
             os.environ.pop("DLKA_PREP_TILED", None)
         else:
             os.environ["DLKA_PREP_TILED"] = old
+        _refresh_switches()
     for k, (a_, b_) in enumerate(zip(*bufs)):
         assert bool(a_.view(torch.uint8).ne(0).any()), k
         assert torch.equal(a_.view(torch.uint8), b_.view(torch.uint8)), (k, int(a_.view(torch.uint8).ne(b_.view(torch.uint8)).sum()))
@@ -1101,6 +1238,7 @@ def check_wgrad_pad_equals_unpadded(dev, B, Cin, Cout, dims, k, pad, dil, seed=0
     try:
         for mode in ("1", "0"):
             os.environ["DLKA_WGRAD_PAD"] = mode
+            _refresh_switches()
             _, gw, gb = ops.conv3d_backward_cl(x.to(dev), w.to(dev), go.to(dev), p3, d3, 1, grad_out_planar=True)
             res.append((gw.cpu(), gb.cpu()))
     finally:
@@ -1108,6 +1246,7 @@ def check_wgrad_pad_equals_unpadded(dev, B, Cin, Cout, dims, k, pad, dil, seed=0
             os.environ.pop("DLKA_WGRAD_PAD", None)
         else:
             os.environ["DLKA_WGRAD_PAD"] = old
+        _refresh_switches()
     if (D * H * W) % 16 == 0:
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), float((res[0][0] - res[1][0]).abs().max())
     else:   # N % 16 != 0 with fp32 activations: the unpadded route is the exact fp32-input MFMA there, the padded kernels always contract as two-term bf16 splits (~1e-5)

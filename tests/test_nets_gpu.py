@@ -43,15 +43,16 @@ def test_plumbing_matches_the_reference_at_full_size_on_gpu():
 def test_assembled_net_train_mode_vs_oracle_assembled_net():
     """The assembled net with its 21 REAL D-LKA blocks (HIP) against the oracle-assembled net (tests/netoracle.py) at 32x64x64, B = 2, TRAINING mode
     (batch statistics in every UnetResBlock, the same Dropout3d draws on both sides): logits of the three heads <= 1e-3, argmax agreement of the
-    full-resolution head >= 99.9 %, the deep-supervision loss, and the parameter gradients — on the oracle's own offsets (flips counted) and on
-    identical sampling cells (the oracle blocks fed the kernels' offset values).  Gradient bounds: the contract's 1e-3 for the three output heads (no
-    kink between them and the loss) and for at least 90 % of ALL parameters; 8e-3 for every one of them with at most two output channels of a tensor
-    left out (parity.rel_err_kink; at most four tensors above it in the plain metric) — the wrapper block's kink-aware bound
-    (tests/parity.py check_tblock3d): a LeakyReLU pre-activation within rounding of 0 takes slope 1 in one implementation and 0.01 in the other, and
-    one such element moves a gradient summed over N voxels by ~1 / sqrt(N).  Measured on the MI355X, two runs of the same test: every one of the 573
-    gradients <= 4.0e-4 in one, decoder2's first 3^3 conv weight (2 x 262 144 voxels per element: 1.4e-3 per mismatched element) at 1.05e-3 in the
-    other; logits 1.4e-5 of 18, argmax agreement 99.9996 %, loss equal to the last digit."""
+    full-resolution head >= 99.9 %, the deep-supervision loss, and the parameter gradients.
+
+    Gradients: the net has two kinds of discontinuity — floor() in the 21 deformable convs and LeakyReLU's kink (two per wrapper block, four in the plumbing's
+    UnetResBlocks).  Both are handled the same way (tests/parity.py, the kink protocol): the elements on which the two implementations differ are COUNTED and CAPPED
+    (sampling cells: <= max(3, 2e-5 n); activation patterns: <= max(3, 2e-5 n) per tensor, each within 1e-4 of 0 relative to max|z|), and the oracle net is
+    re-run on the kernels' cells and activation patterns ("same").  On that run EVERY parameter gradient is held to the contract's 1e-3 in the plain max-norm —
+    no channel is left out, no tensor is exempt.  The run on the oracle's own cells / patterns ("ref") is a sanity bound: each differing element can move one
+    gradient by ~4 / sqrt(voxels of its stage)."""
     from tests import netoracle
+    from tests.parity import KINK_NEAR, KINK_MAX_FRACTION
     res = netoracle.run_pair(DEV, (32, 64, 64), B=2, training=True)
     s = netoracle.summarize(res, top=12)
     print({k: v for k, v in s.items() if not k.endswith("grad_errs")})
@@ -59,27 +60,18 @@ def test_assembled_net_train_mode_vs_oracle_assembled_net():
         assert max(s[tag + "_logit_abs"]) <= 1e-3, s[tag + "_logit_abs"]
         assert s[tag + "_argmax_agree"] >= 0.999, s[tag + "_argmax_agree"]
         assert s[tag + "_loss_abs"] <= 1e-4 * max(1.0, abs(res["ref_loss"])), s[tag + "_loss_abs"]
+    assert s["flipped"] <= max(3, int(2e-5 * s["samples"])), (s["flipped"], s["samples"])
+    for k, rel, n in res["kinks"]:
+        assert k <= max(3, int(KINK_MAX_FRACTION * n)), (k, n)
+        assert rel <= KINK_NEAR, rel
     errs = s["same_grad_errs"]
     assert len(errs) > 500
-    tight = [k for k in errs if k.startswith(("out1.", "out2.", "out3."))]
-    assert len(tight) >= 5
-    for k in tight:
-        assert errs[k] <= 1e-3, (k, errs[k])
-    frac = sum(v <= 1e-3 for v in errs.values()) / len(errs)
-    assert frac >= 0.9, (frac, s["same_grad_worst"])
-    # 8e-3 for every parameter — with at most two OUTPUT CHANNELS of a tensor left out (parity.rel_err_kink), and at most four tensors whose plain error is above it.
-    # (Round 5 tried 1e-3 for every parameter, VERDICT r4 weak #1: a run measured 6.9e-3 on decoder3's conv51.norm1.bias — the LeakyReLU kink the bound's name is
-    # about.  Later the SAME tree gave 2.7e-2 on stages.1.2.conv51.conv1.conv.weight in one run of three — at 32x64x64 that stage is 8^3: 1024 voxels, one flipped
-    # element = 1 / sqrt(1024) of ONE output channel (scripts/debug_net_kink.py prints the per-channel errors: one channel, every other at 1e-5) while everything
-    # upstream of it moved by 2.7e-3.  Which element sits within rounding of 0 varies with the order of the library's atomics.)
-    from tests.parity import rel_err_kink
-    kink = {k: rel_err_kink(res["hip_grads"][k], g) for k, g in res["same_grads"].items() if k in errs}
-    assert all(v <= 8e-3 for v in kink.values()), sorted(kink.items(), key=lambda kv: -kv[1])[:6]
-    assert sum(v > 8e-3 for v in errs.values()) <= 4, s["same_grad_worst"]
-    lim = 8e-3 if s["flipped"] == 0 else 5e-2   # (own offsets with flips counted: sanity bound only, as in parity.check_lka2d_attention)
-    ref_kink = {k: rel_err_kink(res["hip_grads"][k], g) for k, g in res["ref_grads"].items() if k in s["ref_grad_errs"]}
-    assert all(v <= lim for v in ref_kink.values()), (s["flipped"], sorted(ref_kink.items(), key=lambda kv: -kv[1])[:6])
-    assert sum(v > lim for v in s["ref_grad_errs"].values()) <= 4, (s["flipped"], s["ref_grad_worst"])
+    worst = max(errs.values())
+    assert worst <= 1e-3, s["same_grad_worst"]
+    # own cells / own patterns: every differing element (they were counted above) moves at most one tensor by ~4 / sqrt(voxels); the smallest stage here is 2 x 2 x 4 x 4
+    differ = s["flipped"] + s["kink_differ"]
+    lim = 1e-3 if differ == 0 else max(8e-3, min(0.5, 4.0 * differ / (2 * 32) ** 0.5))
+    assert max(s["ref_grad_errs"].values()) <= lim, (differ, s["ref_grad_worst"])
 
 
 def test_assembled_net_full_size_forward_vs_oracle_assembled_net():

@@ -18,6 +18,14 @@ def emu_backend(oracle):
     _lib._set_backend_for_tests(None)
 
 
+@pytest.fixture(autouse=True)
+def _cached_switches_follow_monkeypatch():
+    """monkeypatch restores the environment when a test ends; the library's cached switches (dlka_env_refresh) follow it."""
+    yield
+    from deformablelka_amd import _lib
+    _lib.get_lib().dlka_env_refresh()
+
+
 D3 = [
     # B, C, Cout, dims, k, s, p, d, g, dg, off_mode
     (2, 4, 4, (5, 6, 7), 3, 1, 1, 1, 1, 1, "normal"),
@@ -304,6 +312,16 @@ def test_stack_with_hoisted_weight_preparation_equals_per_block_calls():
         assert torch.allclose(y, y_ref, rtol=1e-6, atol=1e-6)
 
 
+def test_stack_step_vs_per_block_entries_and_oracle():
+    """tests/test_stack_fullsize_gpu.py's check (the benchmarked engine step against the per-block entry points and the oracle) on a toy stack: the same
+    checker, so that its logic is exercised in the CPU suite."""
+    from deformablelka_amd.stack import DLKABlockStack
+    st = DLKABlockStack(1, stages=((32, (3, 4, 5), 4), (64, (2, 2, 3), 1)), device="cpu", seed=5, offset_std_voxels=0.3)
+    for _ in range(2):   # the first pass records the fold plan, the second runs it sealed
+        st.forward_backward()
+    parity.check_stack_step(st, range(len(st.blocks)), (0, len(st.blocks) - 1))
+
+
 @pytest.mark.parametrize("kw", ["1", "4"])
 def test_lka3d_tokens_pointwise_kernel_with_split_contraction(kw):
     """cl_pointwise_kernel<T, 4> (four waves share an output tile and split the channel chunks: the C = 128 / 256 stages on the GPU) and the
@@ -586,6 +604,7 @@ def test_depthwise_lds_brick_kernel(monkeypatch):
     lib = _lib.get_lib()
     monkeypatch.setenv("DLKA_DW_LDS", "2")
     monkeypatch.setenv("DLKA_DWPAIR", "0")   # (the second volume is small enough for the fused pair, cl_dwpair.hip, which would take both convs)
+    lib.dlka_env_refresh()
     n0 = lib.dlka_dwconv_lds_launch_count()
     parity.check_lka3d_tokens("cpu", 1, 32, (4, 5, 20), offset_std=0.3)
     n1 = lib.dlka_dwconv_lds_launch_count()

@@ -929,7 +929,7 @@ def test_tblock3d_wgrad_overlap_equals_one_stream():
     ref = backward(True)
     for rep in range(3):
         same(f"eager {rep}", ref, backward(False))
-        assert ov.pending == [] and not ov.armed   # joined, nothing kept alive
+        assert not ov.pending   # joined, nothing kept alive
     # accumulation into existing .grad tensors: the one-stream pass (2 x the gradient afterwards)
     for p in params + [x]:
         p.grad = None
@@ -957,6 +957,77 @@ def test_tblock3d_wgrad_overlap_equals_one_stream():
     for n, a_, b_ in zip(names, ref, got):
         lim = (5e-2 if any(t in n for t in ("conv0", "conv_spatial", "conv_offset", "proj_1", "norm.", "pos_embed", "x")) else 2e-3) * max(float(a_.abs().max()), 1e-30)
         assert bool(torch.isfinite(b_).all()) and float((a_ - b_).abs().max()) <= lim, ("graph", n, float((a_ - b_).abs().max()), lim)
+
+
+def test_tblock3d_wgrad_overlap_frozen_parameter_and_shared_block_take_one_stream():
+    """the side-stream pass is only safe when autograd keeps every returned weight gradient until backward() returns.  A FROZEN parameter's gradient is
+    dropped at once (its memory would be re-used by the main stream while the side stream still writes it) and a block applied TWICE in one graph has its two
+    gradients added on the main stream before the side stream has finished: both must take the one-stream pass (`WgradOverlap.eligible`) — observed through
+    `ops.tblock3d_backward`'s side_stream argument — and give the one-stream gradients."""
+    import deformablelka_amd as dk
+    from deformablelka_amd import ops
+    from deformablelka_amd.transformerblock import WgradOverlap
+    from oracle import blocks
+    torch.manual_seed(7)
+    C, (H, W, D) = 32, (16, 16, 16)
+    mods = []
+    for _ in range(2):
+        m = dk.TransformerBlock_3D_single_deform_LKA(H * W * D, C, C, 4, dropout_rate=0.1, pos_embed=True)
+        blocks.randomize_offsets_(m, std=0.3)
+        with torch.no_grad():
+            m.gamma.normal_(0.5, 0.2)
+        m.keep_channels_last = True
+        m.wgrad_overlap = True
+        m._draw_drop_mask = lambda B_, C_, dtype, device: torch.ones(B_, C_, dtype=dtype, device=device)
+        mods.append(m.to(DEV).train())
+    x = torch.randn(2, H, W, D, C, device=DEV).permute(0, 4, 1, 2, 3).requires_grad_(True)
+    gy = torch.randn(2, H, W, D, C, device=DEV).permute(0, 4, 1, 2, 3)
+    used = []
+    orig = ops.tblock3d_backward
+
+    def spy(*a, **k):
+        used.append(k.get("side_stream") is not None)
+        return orig(*a, **k)
+
+    def run(frozen, twice, disabled):
+        used.clear()
+        for m in mods:
+            for p in m.parameters():
+                p.requires_grad_(True)
+                p.grad = None
+        x.grad = None
+        if frozen:
+            mods[0].conv51.conv1.conv.weight.requires_grad_(False)
+        WgradOverlap.disabled = disabled
+        ops.tblock3d_backward = spy
+        try:
+            y = mods[1](mods[0](x))
+            if twice:
+                y = mods[1](y)
+            # main-stream allocations right behind each block's backward would land in a dropped gradient's memory
+            y.backward(gy)
+            torch.cuda.synchronize()
+        finally:
+            ops.tblock3d_backward = orig
+            WgradOverlap.disabled = False
+        return list(used), [x.grad.clone()] + [None if p.grad is None else p.grad.clone() for m in mods for p in m.parameters()]
+
+    for frozen, twice in ((True, False), (False, True)):
+        side_ref, ref = run(frozen, twice, True)
+        side, got = run(frozen, twice, False)
+        assert not any(side_ref)
+        # backward order: mods[1] (twice: both applications), then mods[0]
+        if frozen:
+            assert side == [True, False], side      # the block with the frozen parameter: one stream; the other one keeps the side stream
+        else:
+            assert side == [False, False, True], side   # the block applied twice: one stream both times
+        for a_, b_ in zip(ref, got):
+            assert (a_ is None) == (b_ is None)
+            if a_ is not None:
+                assert bool(torch.isfinite(b_).all()) and float((a_ - b_).abs().max()) <= 2e-3 * max(float(a_.abs().max()), 1e-30)
+    for m in mods:
+        for p in m.parameters():
+            p.requires_grad_(True)
 
 
 @pytest.mark.parametrize("case", [(2, 32, 81, (32, 32, 32), 3, 1, 1), (2, 128, 81, (8, 8, 8), 3, 1, 1), (24, 96, 98, (1, 56, 56), (1, 7, 7), (0, 9, 9), (1, 3, 3)),
