@@ -684,12 +684,12 @@ def companion_metric(batch, steps, warmup, dev, dtype, lr, roofline=True):
     return out
 
 
-def spawn_ranks(args):
+def spawn_ranks(args, harness=None):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks ourselves (one process per GPU, torch.distributed.run
     = torchrun, rendezvous on 127.0.0.1) with the same arguments; rank 0 of the child job prints the JSON line on the inherited stdout."""
     import socket
     import subprocess
-    if not EMU:
+    if harness is None:
         have = torch.cuda.device_count()
         if have < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
@@ -698,37 +698,31 @@ def spawn_ranks(args):
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]   # (sys.argv[0]: this file, or the test harness that calls main())
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     log("bench.py: spawning", args.gpus, "ranks:", " ".join(cmd))
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-# TEST HOOK (tests/test_bench_spawn.py): DLKA_BENCH_EMU=1 runs the rank logic of this file — self-spawn, process group, shard seeds, barrier
-# + max-over-ranks timing, the JSON line — on CPU tensors, `gloo`, the host emulator build of the kernels and a two-block toy stack.  The line it
-# prints says so in `data`; it is never a measurement.
-EMU = os.environ.get("DLKA_BENCH_EMU") == "1"
-EMU_STAGES = ((32, (2, 2, 3), 1), (64, (2, 2, 2), 1))
-
-
-def main():
+def main(harness=None):
+    """harness: None for every measurement.  tests/bench_emu_harness.py passes a dict {"device", "process_group", "stages", "data", "setup"} to run the RANK LOGIC of this
+    file — self-spawn, process group, shard seeds, barrier + max-over-ranks timing, the JSON line — on CPU tensors and `gloo` with the host emulator build of the kernels and
+    a two-block toy stack (tests/test_bench_spawn.py); the line it prints says so in `data`, it is never a measurement, and nothing in this file imports test code."""
+    EMU = harness is not None
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        spawn_ranks(args)
+        spawn_ranks(args, harness)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch N ranks, or let --gpus N spawn them)")
     if EMU:
-        from deformablelka_amd import _lib
-        from tests import emu
-        _lib._set_backend_for_tests(emu.load())
-        torch.set_num_threads(1)
-        dev = torch.device("cpu")
+        harness["setup"]()
+        dev = harness["device"]
         args.no_graph = args.no_roofline = args.no_cpu_baseline = args.no_companion = args.no_tblock = args.no_fullnet = args.no_lka2d = True
     else:
         if not torch.cuda.is_available():
@@ -743,7 +737,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if EMU:
-            dist.init_process_group("gloo")
+            dist.init_process_group(harness["process_group"])
         else:
             dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm; ranks talk over xGMI
         if dist.get_world_size() != args.gpus:
@@ -752,7 +746,7 @@ def main():
     from deformablelka_amd.stack import DLKABlockStack
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
     # replicas start from the same parameters (seed); every rank gets its own shard of synthetic volumes (data_seed)
-    stack = DLKABlockStack(args.batch, device=dev, dtype=dtype, seed=1234, data_seed=4321 + rank, **({"stages": EMU_STAGES} if EMU else {}))
+    stack = DLKABlockStack(args.batch, device=dev, dtype=dtype, seed=1234, data_seed=4321 + rank, **({"stages": harness["stages"]} if EMU else {}))
     # Synthetic grad_outputs (N(0,1), no loss behind them) make the block gradients huge; a training-sized step would blow
     # the parameters up within a few iterations (offsets -> inf/NaN, every sample dropped, kernels get FASTER: observed,
     # profiles/r01i).  The SGD update is executed in full but with a step small enough that the data distribution the
@@ -889,7 +883,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "repetitions": {"ms_per_step": [round(e / args.steps * 1e3, 4) for e in rep_elapsed], "min": round(min(rep_elapsed) / args.steps * 1e3, 4),
                             "max": round(max(rep_elapsed) / args.steps * 1e3, 4), "reported": "median"},
-            "data": "synthetic" if not EMU else "synthetic (EMULATOR TEST RUN on CPU: exercises the rank logic only, NOT a measurement)",
+            "data": "synthetic" if not EMU else harness["data"],
             "config": {"workload": "3D D-LKA Former Synapse 64x128x128 patch: fwd+bwd of its 21 D-LKA attention blocks "
                                    "(6x(32,32^3)+6x(64,16^3)+6x(128,8^3)+3x(256,4^3)) + grad all-reduce + SGD update",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",

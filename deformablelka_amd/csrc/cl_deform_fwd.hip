@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
             const int mr = mbase + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (mr >= p.M) continue;
             const float val = acc[t][r] + bv;
-            if (split) atomicAdd(p.out + (long)mr * p.Cout + n, val);   // fp32 accumulation buffer (the launcher's caller casts it for bf16)
+            if (split) p.out[((long)blockIdx.y * p.M + mr) * p.Cout + n] = val;   // this tap range's slab (fp32 [splits][M][Cout]): summed in slab order by cl_slab_reduce_kernel
             else act_store1(reinterpret_cast<T *>(p.out), (long)mr * p.Cout + n, val);
         }
     }
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(512, 4) void cl_deform_fwd16_kernel(IgemmArgs p)
             const int mr = mbase + 4 * g4 + r;
             if (mr >= p.M) continue;
             const float val = acc[t][r] + bv;
-            if (split) atomicAdd(p.out + (long)mr * p.Cout + n, val);
+            if (split) p.out[((long)blockIdx.y * p.M + mr) * p.Cout + n] = val;   // this tap range's slab (fp32 [splits][M][Cout]): summed in slab order by cl_slab_reduce_kernel
             else act_store1(reinterpret_cast<T *>(p.out), (long)mr * p.Cout + n, val);
         }
     }
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_b16_kernel(IgemmArgs p)
             const int mr = mbase + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (mr >= p.M) continue;
             const float val = acc[t][r] + bv;
-            if (split) atomicAdd(p.out + (long)mr * p.Cout + n, val);   // fp32 accumulation buffer (the launcher's caller casts it)
+            if (split) p.out[((long)blockIdx.y * p.M + mr) * p.Cout + n] = val;   // this tap range's slab (fp32 [splits][M][Cout]): summed in slab order by cl_slab_reduce_kernel
             else act_store1(reinterpret_cast<T *>(p.out), (long)mr * p.Cout + n, val);
         }
     }
@@ -523,12 +523,11 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_b16_kernel(IgemmArgs p)
 int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
 {
     if ((long)a.M * a.Cin * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
-    // act_bf16 with splits > 1: a.out must be an fp32 [M][Cout] accumulation buffer (the caller converts it afterwards)
+    // splits > 1 (small volumes): the tap ranges' partial tiles go to SLABS, a.out = fp32 [splits][M][Cout], which launch_cl_slab_reduce sums in slab order into the
+    // output (rounds 1 - 5: fp32 atomics on a zero-filled output — the order of arrival decided the last bit; deform_conv_cuda.cu:95-123 is deterministic)
     a.units_per_split = cdiv(a.K * (a.CinP / 32), splits);
     splits = cdiv(a.K * (a.CinP / 32), a.units_per_split);
-    if (splits > 1 && !a.out_zeroed) {
-        if (launch_zero(a.out, (size_t)a.M * a.Cout * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
-    }
+    // (splits > 1: a.out is the slab buffer fp32 [splits][M][Cout] — every element of every slab is written, nothing is zero-filled; round 6)
     const int NT_total = a.NP / 32;
     const int mblocks = cdiv(a.M, 128);
     // all column tiles in one workgroup (the gather is not repeated) up to 4; wider outputs split over gridDim.z
@@ -593,6 +592,45 @@ int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
             default: return DLKA_ERR_UNSUPPORTED;
         }
     }
+    DLKA_CHECK_LAUNCH();
+    return DLKA_OK;
+}
+
+// out[e] = sum_s slab[s][e], s = 0 .. S-1 IN THAT ORDER (the bias rode in slab 0): the deterministic meeting point of the tap-split deformable forward.
+template <typename T>
+__global__ __launch_bounds__(256) void cl_slab_reduce_kernel(const float *__restrict__ slab, int S, long n, T *__restrict__ out)
+{
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= n) return;
+    if (e + 3 < n) {
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(slab + e);
+        for (int s = 1; s < S; ++s) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(slab + (long)s * n + e);
+            acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) act_store1(out, e + k, acc[k]);
+    } else {
+        for (long j = e; j < n; ++j) {
+            float acc = slab[j];
+            for (int s = 1; s < S; ++s) acc += slab[(long)s * n + j];
+            act_store1(out, j, acc);
+        }
+    }
+}
+
+int cl_deform_fwd_actual_splits(int K, int CinP, int splits)
+{
+    const int units = K * (CinP / 32), ups = cdiv(units, splits < 1 ? 1 : splits);
+    return cdiv(units, ups);
+}
+
+int launch_cl_slab_reduce(const float *slab, int S, long n, void *out, int out_bf16, hipStream_t st)
+{
+    if (n % 4) return DLKA_ERR_UNSUPPORTED;   // (16-byte slab rows: M * Cout with Cout % 32 == 0)
+    const unsigned grid = (unsigned)cdiv(n / 4, 256);
+    if (out_bf16) { auto k = cl_slab_reduce_kernel<bf16_t>; DLKA_LAUNCH(k, dim3(grid), dim3(256), 0, st, slab, S, n, reinterpret_cast<bf16_t *>(out)); }
+    else { auto k = cl_slab_reduce_kernel<float>; DLKA_LAUNCH(k, dim3(grid), dim3(256), 0, st, slab, S, n, reinterpret_cast<float *>(out)); }
     DLKA_CHECK_LAUNCH();
     return DLKA_OK;
 }

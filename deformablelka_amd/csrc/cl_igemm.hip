@@ -540,6 +540,12 @@ int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t s
         const int rc = launch_cl_conv_brick(a, st);
         if (rc != DLKA_ERR_UNSUPPORTED) return rc;
     }
+    // small volumes (the row tiling alone would not fill the chip): the contraction splits over the waves of a workgroup, deterministically (cl_conv_kw.hip).  The
+    // C-ABI sequencing code has asked cl_conv_kw_applies() and passes splits = 1 for these (no zero fill, no fp32 staging buffer)
+    if (splits == 1 && a.K > 1 && a.split_bf16 && cl_igemm_pick_splits(a.M, a.K * (a.CinP / 32), a.epi, a.K) > 1) {
+        const int rc = launch_cl_conv_kw(amode, omode, a, st);
+        if (rc != DLKA_ERR_UNSUPPORTED) return rc;
+    }
     if (splits > 1 && !a.out_zeroed) {
         const long n = (long)a.M * a.Cout;
         if (launch_zero(a.out, (size_t)n * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;

@@ -114,8 +114,24 @@ void fill_igemm(IgemmArgs &a, const SameConv &s)
 
 // ---- dense conv forward: out = conv(x) (+ epilogue) ---------------------------------------------------------------
 // wp must hold K * Cin * round_up(Cout,32) floats
-int dense_forward_splits(const SameConv &s, int epi) { return cl_igemm_pick_splits(s.M, s.K * (s.Cin / 32), epi, s.K); }
-int dense_backward_data_splits(const SameConv &s, int epi) { return cl_igemm_pick_splits(s.M, s.K * (round_up(s.Cout, 32) / 32), epi, s.K); }
+// Tap splits of a launch whose partial sums meet in fp32 atomics on a zero-filled output (> 1: the caller zero-fills, and bf16 storage goes through an fp32 staging
+// buffer).  Round 6: the split-operand convs (K > 1) of small volumes split their contraction over the waves of a workgroup instead (cl_conv_kw.hip: deterministic,
+// no atomics) — for those this returns 1.  The deformable conv's forward keeps its own query (deform_forward_splits).
+int deform_forward_splits(const SameConv &s) { return cl_igemm_pick_splits(s.M, s.K * (s.Cin / 32), 0, s.K); }
+int dense_forward_splits(const SameConv &s, int epi)
+{
+    const int sp = cl_igemm_pick_splits(s.M, s.K * (s.Cin / 32), epi, s.K);
+    if (sp > 1 && cl_conv_kw_applies(0, s.act_bf16 ? 1 : 0, use_split(s, true), s.K, epi, round_up(s.Cout, 32), s.act_bf16 != 0, false)) return 1;
+    return sp;
+}
+int dense_backward_data_splits(const SameConv &s, int epi, int gout_planar = -1)
+{
+    const int sp = cl_igemm_pick_splits(s.M, s.K * (round_up(s.Cout, 32) / 32), epi, s.K);
+    // (gout_planar < 0: a query without the layout — bf16 storage reaches here with planar gradients only, fp32 with either)
+    const int amode = gout_planar < 0 ? (s.act_bf16 ? 2 : 0) : (gout_planar ? 2 : 0);
+    if (sp > 1 && cl_conv_kw_applies(amode, 0, use_split(s, false), s.K, epi, s.Cin, s.act_bf16 != 0, false)) return 1;
+    return sp;
+}
 
 // zeroed: the caller has zero-filled `out` (needed when the tap split is > 1; one batched fill per block instead of one per conv)
 // ride: zero fills that go out with this launch (pointwise kernel; any other kernel gets them as a launch of their own, cl_igemm.hip)
@@ -165,7 +181,7 @@ int dense_backward_data(const SameConv &s, const float *gout, int gout_planar, c
     }
     a.aux_f32 = aux_f32 ? 1 : 0;
     if (ride) a.zero = *ride;
-    int splits = dense_backward_data_splits(s, epi);
+    int splits = dense_backward_data_splits(s, epi, gout_planar);
     // cl_conv_brick.hip: no tap split; volumes too small for a workgroup per tile split the plane chunks instead (fp32 atomics into a zeroed buffer, like a tap split)
     const int bsplit = gout_planar ? cl_conv_brick_split(a) : 0;
     bool brick_only = false;   // the chunk split alone made this an accumulating launch: the caller's zero-fill decision (dense_backward_data_splits) does not know
@@ -367,9 +383,17 @@ static bool deform_b16()
 
 bool deform_supported(const SameConv &s) { return s.group == 1 && s.Cin % 32 == 0 && s.Cout % 32 == 0 && nt_ok(s.Cout) && nt_ok(s.Cin); }
 
-// bf16 storage with a tap split: `acc32` (fp32 [M][Cout], ZEROED by the caller) receives the partial sums and is converted into `out`
+// Small volumes split the taps over the grid: the tap ranges' partial tiles go to `slab` (fp32 [splits][M][Cout], deform_fwd_slab_floats(s) floats, every element written)
+// and are summed IN SLAB ORDER by one reduce launch — deterministic, like the reference's im2col + addmm (deform_conv_cuda.cu:95-123); rounds 1 - 5 let them meet in fp32
+// atomics on a zero-filled output (the order of arrival decided the last bit, and the bf16 path needed an fp32 landing zone + a cast launch: the reduce launch replaces it).
+int deform_fwd_actual_splits(const SameConv &s) { return cl_deform_fwd_actual_splits(s.K, s.Cin, deform_forward_splits(s)); }
+size_t deform_fwd_slab_floats(const SameConv &s)
+{
+    const int sp = deform_fwd_actual_splits(s);
+    return sp > 1 ? (size_t)sp * s.M * s.Cout : 0;
+}
 int deform_forward(const SameConv &s, const float *x, const float *off, const float *w, const float *bias, float *out, float *wp, hipStream_t st,
-                   bool zeroed = false, float *acc32 = nullptr)
+                   float *slab = nullptr)
 {
     // DLKA_BF16: the contraction runs on the bf16 matrix cores — weights as two-term bf16 records (prep mode | 8; deform_b16() = 0 keeps the fp32-input MFMA)
     const int b16 = (s.act_bf16 && deform_b16()) ? 1 : 0;
@@ -377,24 +401,21 @@ int deform_forward(const SameConv &s, const float *x, const float *off, const fl
     IgemmArgs a;
     fill_igemm(a, s);
     a.split_bf16 = b16 ? 2 : 0;
-    a.in = x; a.off = off; a.wp = wp; a.bias = bias; a.out = out; a.epi = 0; a.out_zeroed = zeroed ? 1 : 0;
+    a.in = x; a.off = off; a.wp = wp; a.bias = bias; a.out = out; a.epi = 0; a.out_zeroed = 0;
     a.Cin = s.Cin; a.CinReal = s.Cin; a.CinP = s.Cin; a.Cout = s.Cout; a.NP = s.Cout;
-    const int splits = dense_forward_splits(s, 0);
-    if (s.act_bf16) {
-        if (splits > 1) {
-            if (!acc32) return DLKA_ERR_WORKSPACE;
-            a.out = acc32; a.out_zeroed = 1;
-            DLKA_TRY(launch_cl_deform_fwd(a, splits, st));
-            return launch_cast_from_f32<bf16_t>(acc32, reinterpret_cast<bf16_t *>(out), (long)s.M * s.Cout, st);
-        }
-        return launch_cl_deform_fwd(a, splits, st);
-    }
-    constexpr bool old_path = false;
-    if (!old_path) {
+    const int splits = deform_fwd_actual_splits(s);
+    if (splits > 1) {
+        if (!slab) return DLKA_ERR_WORKSPACE;
+        a.out = slab;
         const int rc = launch_cl_deform_fwd(a, splits, st);
-        if (rc != DLKA_ERR_UNSUPPORTED) return rc;
+        if (rc == DLKA_OK) return launch_cl_slab_reduce(slab, splits, (long)s.M * s.Cout, out, s.act_bf16, st);
+        if (rc != DLKA_ERR_UNSUPPORTED || s.act_bf16) return rc;
+        a.out = out;   // (a width the gather kernels do not tile: the first-generation kernel, tap split with atomics on a zero fill of its own)
+        return launch_cl_igemm(1, 0, a, splits, st);
     }
-    return launch_cl_igemm(1, 0, a, splits, st);
+    const int rc = launch_cl_deform_fwd(a, 1, st);
+    if (rc != DLKA_ERR_UNSUPPORTED || s.act_bf16) return rc;
+    return launch_cl_igemm(1, 0, a, 1, st);
 }
 
 void fill_deform_bwd(DeformBwdArgs &a, const SameConv &s)
@@ -1203,6 +1224,7 @@ size_t dlka_deform_conv3d_cl_workspace(const dlka_conv_geom *c, int dtype, int b
     if ((dtype != DLKA_F32 && dtype != DLKA_BF16) || make_same_conv(c, s)) return 0;
     size_t n = align256(dense_wp_floats(s) * 4);
     if (backward) n += align256(cl_wgrad_part_floats(s.M, s.K, s.Cout, s.Cin) * 4) + align256(deform_scratch_floats(s) * 4);
+    else n += align256(deform_fwd_slab_floats(s) * 4);   // small volumes: the tap ranges' slabs (deform_forward)
     return n;
 }
 
@@ -1215,11 +1237,11 @@ int dlka_deform_conv3d_forward_cl(const void *x, const void *offset, const void 
     DLKA_TRY(make_same_conv(c, s));
     if (c->deformable_group != 1 || !deform_supported(s)) return DLKA_ERR_UNSUPPORTED;
     s.act_bf16 = dtype == DLKA_BF16;   // x / out bf16 storage; offsets, weight and bias stay fp32
-    if (s.act_bf16 && dense_forward_splits(s, 0) > 1) return DLKA_ERR_UNSUPPORTED;   // (tap-split stages: token entry points only)
     Carver cv(workspace, workspace_bytes);
     float *wp = (float *)cv.take(dense_wp_floats(s) * 4);
+    float *slab = (float *)cv.take(deform_fwd_slab_floats(s) * 4);
     if (!cv.ok()) return DLKA_ERR_WORKSPACE;
-    return deform_forward(s, (const float *)x, (const float *)offset, (const float *)weight, (const float *)bias, (float *)out, wp, (hipStream_t)stream);
+    return deform_forward(s, (const float *)x, (const float *)offset, (const float *)weight, (const float *)bias, (float *)out, wp, (hipStream_t)stream, slab);
 }
 
 int dlka_deform_conv3d_backward_cl(const void *x, const void *offset, const void *weight, const void *grad_out, void *grad_x, void *grad_offset,
@@ -1367,7 +1389,8 @@ size_t dlka_lka3d_tokens_workspace_bytes_v(int B, int C, int D, int H, int W, in
     TokGeoms G(B, C, D, H, W, dtype, variant);   // (the eight gradient buffers keep their fp32 size on the bf16 path: gta and the split scratch ARE fp32)
     return align256(G.wp_floats() * 4) + align256(G.part_floats() * 4) + 8 * align256(G.E * 4) + align256(G.GOff * 4) +
            align256(G.scratch_floats() * 4) + align256(G.samp_capacity_floats() * 4) + (cl_dwconv_lds_mode() ? 2 * align256(G.blk_floats() * 4) : 0) + align256(4096) +
-           dense_wgrad_pad_bytes(G.offc);   // the zero-padded copy of t the offset conv's weight gradient reads (round 5)
+           dense_wgrad_pad_bytes(G.offc) +   // the zero-padded copy of t the offset conv's weight gradient reads (round 5)
+           align256(deform_fwd_slab_floats(G.dcn) * 4);   // forward pass, small stages: the deformable conv's tap-range slabs, at the END of the workspace (round 6)
 }
 
 // x_f32 (DLKA_BF16 only, optional): the caller's UNROUNDED fp32 twin of the bf16 input x.  The chain that decides where the deformable conv samples then starts
@@ -1393,7 +1416,7 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     float *m = (float *)sv.take(G.E * SB);   // gate output, kept: proj_2's weight gradient needs it
     (void)cv.take(G.wp_floats() * 4);
     (void)cv.take(G.part_floats() * 4);
-    float *acc32 = (float *)cv.take(G.E * 4);   // bf16 path: fp32 landing zone of a tap-split deformable conv (small stages)
+    (void)cv.take(G.E * 4);   // (layout kept: the first of the backward pass's eight gradient buffers)
     // bf16 path: the fp32 offset-determining chain (TokGeoms): a32, t1_32, t_32 — the next three of the backward pass's gradient buffers
     float *a32 = (float *)cv.take(G.E * 4), *t1_32 = (float *)cv.take(G.E * 4), *t_32 = (float *)cv.take(G.E * 4);
     // blocked inputs of the opt-in LDS-brick depthwise convs (DLKA_DW_LDS): sized and carved only when that mode is on — and only when both fit, so a mode
@@ -1402,6 +1425,10 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     float *blkA = (float *)cv.take_opt(G.blk_floats() * 4, want_blk), *blkB = (float *)cv.take_opt(G.blk_floats() * 4, want_blk && blkA);
     if (!blkB) blkA = nullptr;
     if (!sv.ok() || !cv.ok()) return DLKA_ERR_WORKSPACE;
+    // the deformable conv's slabs (small stages) live at the END of the workspace: behind everything either pass carves from the front
+    const size_t slab_bytes = align256(deform_fwd_slab_floats(G.dcn) * 4);
+    if (slab_bytes && workspace_bytes < dlka_lka3d_tokens_workspace_bytes_v(B, C, D, H, W, dtype, variant)) return DLKA_ERR_WORKSPACE;
+    float *slab = slab_bytes ? (float *)((char *)workspace + dlka_lka3d_tokens_workspace_bytes_v(B, C, D, H, W, dtype, variant) - slab_bytes) : nullptr;
     const bool bf = dtype == DLKA_BF16;
     const float *x = (const float *)x_;
     float *y = (float *)y_;
@@ -1411,7 +1438,6 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     ZeroBatch zb;
     memset(&zb, 0, sizeof(zb));
     if (dense_forward_splits(G.offc_f, 0) > 1) zb.add(off, G.Off);
-    if (dense_forward_splits(G.dcn, 0) > 1) zb.add(bf ? acc32 : f, G.E);
     if (dense_forward_splits(G.pw, 3) > 1) zb.add(y, G.E);
     TokPrep PW;
     const ZeroBatch *ride = nullptr;
@@ -1445,7 +1471,7 @@ static int tokens_forward_impl(const void *x_, const dlka_lka3d_params *p, void 
     // offset-predict conv C -> 81 (synapse/deform_conv.py:94) on the fp32 t; offsets stay in the reference's planar layout
     DLKA_TRY(dense_forward(G.offc_f, t_out, N0, (const float *)p->offset_b, off, 1, PW.off_f, 0, nullptr, nullptr, st, true));
     // deformable 3^3 conv (deform_conv.py:95-105)   (bf16: samples the bf16 copy of t)
-    DLKA_TRY(deform_forward(G.dcn, t, off, N0, (const float *)p->deform_b, f, PW.dcn_f, st, true, acc32));
+    DLKA_TRY(deform_forward(G.dcn, t, off, N0, (const float *)p->deform_b, f, PW.dcn_f, st, slab));
     // conv1 + gate u*attn (:650-652): g1 kept, m = a * g1
     // ... and proj_2 + shortcut (:670-671) — one launch at C <= 64 (cl_pointwise_pair_kernel)
     const int prc = pointwise_pair(G.pw, 0, f, PW.pw_f[1], (const float *)p->conv1_b, PW.pw_f[2], (const float *)p->proj_2_b, a, x, g1, m, y, st);

@@ -59,6 +59,8 @@ int cl_igemm_pick_splits(int M, int units, int epi, int K);
 int launch_cl_pointwise(const IgemmArgs &a, hipStream_t st);
 int launch_cl_pointwise_pair(const PwPairArgs &a, hipStream_t st);   // two dependent pointwise convs in one launch (C = 32 / 64)
 int launch_cl_conv_wave(int amode, int omode, const IgemmArgs &a, int splits, hipStream_t st);
+bool cl_conv_kw_applies(int amode, int omode, int split_bf16, int K, int epi, int NP, bool act_bf16, bool a_out_bf16);   // cl_conv_kw.hip: K split over the waves of a workgroup
+int launch_cl_conv_kw(int amode, int omode, const IgemmArgs &a, hipStream_t st);   // deterministic small-volume contraction (no tap split, no atomics, no zero fill)
 bool cl_conv_brick_supported(const IgemmArgs &a);
 int cl_conv_brick_split(const IgemmArgs &a);
 bool cl_conv_brick3_supported(const IgemmArgs &a);
@@ -66,6 +68,8 @@ int launch_cl_conv_brick3(const IgemmArgs &a, hipStream_t st);   // the forward 
 int launch_cl_conv_brick(const IgemmArgs &a, hipStream_t st);   // cl_conv_brick.hip: planar-input 3^3 data gradient from an LDS brick
 int launch_cl_igemm(int amode, int omode, IgemmArgs a, int splits, hipStream_t st);
 int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st);
+int cl_deform_fwd_actual_splits(int K, int CinP, int splits);   // the slab count launch_cl_deform_fwd really uses for a requested tap split
+int launch_cl_slab_reduce(const float *slab, int S, long n, void *out, int out_bf16, hipStream_t st);   // out = sum of the S slabs in slab order (deterministic)
 int cl_wgrad_pick_chunks(int M, int K, int Cout, int Cin, int amode);
 size_t cl_wgrad_part_floats(int M, int K, int Cout, int Cin);
 size_t cl_wgrad_pad_bytes(int B, int D, int H, int W, int Cin, int kd, int kh, int kw, int dd, int dh, int dw, int act_bf16);   // the zero-padded input copy of the padded dense kernels (WgradArgs::pad)

@@ -497,6 +497,10 @@ long dlka_conv_brick_launch_count(void);
 /* launches so far of the fused small-volume depthwise pair (csrc/cl_dwpair.hip: dw 5^3 -> dw 7^3 dil 3, or their data gradients + GELU', of a volume of at most
  * 512 voxels with W in {4, 8} in ONE launch; DLKA_DWPAIR=0, read per call, keeps one launch per conv): parity tests assert which kernel ran */
 long dlka_dwpair_launch_count(void);
+/* Diagnostics: launches of cl_conv_kw_kernel (round 6: the small-volume split-operand convs — offset-predict conv, its data gradient, UnetResBlock's 3^3 convs at the
+ * 16^3 / 8^3 / 4^3 stages — with the contraction split over the waves of ONE workgroup and summed in wave order in LDS: bitwise reproducible, no global atomics;
+ * DLKA_CONV_KW=0 restores the tap split over the grid) and of the deformable forward's workgroup-split variants.  Tests assert which kernel ran. */
+long dlka_conv_kw_launch_count(void);
 size_t dlka_lka3d_tokens_workspace_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
 int dlka_lka3d_attention_tokens_forward_v(const void *x, const dlka_lka3d_params *p, void *y, void *saved, size_t saved_bytes,
                                           void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant, void *stream);

@@ -1,6 +1,6 @@
 """`python bench.py --gpus N` with no WORLD_SIZE must start N ranks itself (VERDICT r2 missing #3).  Runs the real bench.py rank logic —
 self-spawn through torch.distributed.run, process group, per-rank shards, barrier + max-over-ranks timing, one JSON line from rank 0 — on the
-DLKA_BENCH_EMU test hook: CPU tensors, `gloo`, the host emulator build of the kernel sources, a two-block toy stack."""
+test harness tests/bench_emu_harness.py (which calls bench.main with CPU tensors, `gloo`, the host emulator build of the kernel sources, a two-block toy stack)."""
 import json
 import os
 import subprocess
@@ -15,9 +15,9 @@ def _run(extra_env, *argv, timeout=900):
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    env.update(DLKA_BENCH_EMU="1", HIPEMU_THREADS="2", OMP_NUM_THREADS="1")
+    env.update(HIPEMU_THREADS="2", OMP_NUM_THREADS="1")
     env.update(extra_env)
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_emu_harness.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
 
 
 def _json_lines(out):
@@ -52,7 +52,7 @@ def test_world_size_mismatch_is_an_error_not_a_silent_single_rank():
 def test_more_ranks_than_gpus_is_refused_before_spawning():
     # without the test hook: this container has no GPU, so --gpus 2 must refuse instead of measuring one rank and calling it two
     env = dict(os.environ)
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DLKA_BENCH_EMU"):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     import torch
     if torch.cuda.device_count() >= 2:

@@ -312,6 +312,12 @@ def test_stack_with_hoisted_weight_preparation_equals_per_block_calls():
         assert torch.allclose(y, y_ref, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("C,dims,dtype", [(32, (3, 4, 5), torch.float32), (128, (2, 3, 4), torch.float32), (64, (4, 4, 4), torch.bfloat16)])
+def test_forward_is_bitwise_reproducible(C, dims, dtype):
+    """(On the emulator workgroups of a launch run on several OS threads: arrival order varies here too.)"""
+    parity.check_forward_reproducible("cpu", 2, C, dims, dtype, runs=3, expect_kw=True)
+
+
 def test_stack_step_vs_per_block_entries_and_oracle():
     """tests/test_stack_fullsize_gpu.py's check (the benchmarked engine step against the per-block entry points and the oracle) on a toy stack: the same
     checker, so that its logic is exercised in the CPU suite."""

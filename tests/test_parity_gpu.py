@@ -215,6 +215,13 @@ def test_lka3d_tokens_block_headline_shapes_vs_oracle(C, dims, wstd):
 
 # BASELINE.json config 5 as written: 40x224x224 tiles only divide through the ACDC stem (1,4,4) (acdc/model_components.py:21) -> per-tile stage
 # shapes 40x56x56 / 20x28x28 / 10x14x14 / 5x7x7 with the ACDC variant's anisotropic depthwise pair (acdc/transformerblock.py:213-237)
+@pytest.mark.parametrize("C,dims,wstd", HEADLINE)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_forward_is_bitwise_reproducible_at_the_headline_shapes(C, dims, wstd, dtype):
+    """VERDICT r5 #2: forward outputs and predicted offsets bitwise equal across 5 runs, all four config-3 stage shapes, B = 2, ~1-voxel offsets, both dtypes."""
+    parity.check_forward_reproducible(DEV, 2, C, dims, dtype, runs=5, offset_std=wstd, expect_kw=(dims[0] < 32))
+
+
 CONFIG5 = [(32, (40, 56, 56), 0.376), (64, (20, 28, 28), 0.380), (128, (10, 14, 14), 0.490), (256, (5, 7, 7), 0.451)]
 
 
