@@ -18,7 +18,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libdlka_hip.so")
 
-DLKA_F32, DLKA_BF16 = 0, 1
+DLKA_F32, DLKA_BF16, DLKA_F64 = 0, 1, 2
 LKA3D_SYNAPSE, LKA3D_ACDC = 0, 1   # dlka_lka3d_variant (include/dlka.h)
 
 
@@ -220,12 +220,16 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"{what}: {msg} (dlka status {rc})")
 
 
-def dtype_code(t: torch.Tensor) -> int:
+def dtype_code(t: torch.Tensor, allow_f64: bool = False) -> int:
+    """allow_f64: the general NCDHW operators (D3D.deform_conv_forward / backward, the torchvision-style 2-D op, the plain conv3d) also take float64, as the
+    reference's op does (AT_DISPATCH_FLOATING_TYPES: float, double — deform_conv_cuda.cu:96,233); the fused blocks and channels-last fast paths do not."""
     if t.dtype == torch.float32:
         return DLKA_F32
     if t.dtype == torch.bfloat16:
         return DLKA_BF16
-    raise RuntimeError(f"deformablelka_amd supports float32 and bfloat16 tensors, got {t.dtype}")
+    if t.dtype == torch.float64 and allow_f64:
+        return DLKA_F64
+    raise RuntimeError(f"deformablelka_amd supports float32 and bfloat16 tensors (float64: the general deform_conv / conv3d operators only), got {t.dtype}")
 
 
 def require_device(*tensors) -> None:

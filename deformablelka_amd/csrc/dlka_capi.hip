@@ -498,6 +498,7 @@ int dlka_deform_conv3d_forward(const void *x, const void *offset, const void *we
     Geom g;
     DLKA_TRY(make_geom(c, true, g));
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == DLKA_F64) return launch_deform_fwd_f64<3>((const double *)x, (const double *)offset, (const double *)weight, (const double *)bias, (double *)out, g, st);
     return DLKA_DISPATCH(dtype, (deform_forward_t<float, 3>(x, offset, weight, bias, out, workspace, workspace_bytes, g, st)),
                          (deform_forward_t<bf16_t, 3>(x, offset, weight, bias, out, workspace, workspace_bytes, g, st)));
 }
@@ -517,6 +518,9 @@ int dlka_deform_conv3d_backward(const void *x, const void *offset, const void *w
     Geom g;
     DLKA_TRY(make_geom(c, true, g));
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == DLKA_F64)
+        return launch_deform_bwd_f64<3>((const double *)x, (const double *)offset, (const double *)weight, (const double *)grad_out, (double *)grad_x, (double *)grad_offset,
+                                        (double *)grad_weight, (double *)grad_bias, g, st);
     return DLKA_DISPATCH(dtype,
                          (deform_backward_t<float, 3>(x, offset, weight, grad_out, grad_x, grad_offset, grad_weight, grad_bias, workspace, workspace_bytes, g, dtype, st)),
                          (deform_backward_t<bf16_t, 3>(x, offset, weight, grad_out, grad_x, grad_offset, grad_weight, grad_bias, workspace, workspace_bytes, g, dtype, st)));
@@ -561,6 +565,7 @@ int dlka_deform_conv2d_forward(const void *x, const void *offset, const void *we
     Geom g;
     DLKA_TRY(make_geom(c, true, g));
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == DLKA_F64) return launch_deform_fwd_f64<2>((const double *)x, (const double *)offset, (const double *)weight, (const double *)bias, (double *)out, g, st);
     return DLKA_DISPATCH(dtype, (deform_forward_t<float, 2>(x, offset, weight, bias, out, workspace, workspace_bytes, g, st)),
                          (deform_forward_t<bf16_t, 2>(x, offset, weight, bias, out, workspace, workspace_bytes, g, st)));
 }
@@ -581,6 +586,9 @@ int dlka_deform_conv2d_backward(const void *x, const void *offset, const void *w
     Geom g;
     DLKA_TRY(make_geom(c, true, g));
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == DLKA_F64)
+        return launch_deform_bwd_f64<2>((const double *)x, (const double *)offset, (const double *)weight, (const double *)grad_out, (double *)grad_x, (double *)grad_offset,
+                                        (double *)grad_weight, (double *)grad_bias, g, st);
     return DLKA_DISPATCH(dtype,
                          (deform_backward_t<float, 2>(x, offset, weight, grad_out, grad_x, grad_offset, grad_weight, grad_bias, workspace, workspace_bytes, g, dtype, st)),
                          (deform_backward_t<bf16_t, 2>(x, offset, weight, grad_out, grad_x, grad_offset, grad_weight, grad_bias, workspace, workspace_bytes, g, dtype, st)));
@@ -613,6 +621,7 @@ int dlka_conv3d_forward(const void *x, const void *weight, const void *bias, voi
     Geom g;
     DLKA_TRY(make_geom(c, false, g));
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == DLKA_F64) return launch_conv_fwd_f64((const double *)x, (const double *)weight, (const double *)bias, (double *)out, g, st);
     return DLKA_DISPATCH(dtype, conv_forward_t<float>(x, weight, bias, out, workspace, workspace_bytes, g, st),
                          conv_forward_t<bf16_t>(x, weight, bias, out, workspace, workspace_bytes, g, st));
 }
@@ -631,6 +640,8 @@ int dlka_conv3d_backward(const void *x, const void *weight, const void *grad_out
     Geom g;
     DLKA_TRY(make_geom(c, false, g));
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == DLKA_F64)
+        return launch_conv_bwd_f64((const double *)x, (const double *)weight, (const double *)grad_out, (double *)grad_x, (double *)grad_weight, (double *)grad_bias, g, st);
     return DLKA_DISPATCH(dtype, conv_backward_t<float>(x, weight, grad_out, grad_x, grad_weight, grad_bias, workspace, workspace_bytes, g, dtype, st),
                          conv_backward_t<bf16_t>(x, weight, grad_out, grad_x, grad_weight, grad_bias, workspace, workspace_bytes, g, dtype, st));
 }

@@ -26,6 +26,13 @@ int launch_sample_index(const T *off, int32_t *idx, uint8_t *mask, const Geom &g
 template <typename T>
 int launch_sample_index2(const T *off, int32_t *idx, uint8_t *mask, const Geom &g, int path, hipStream_t st);
 
+// ---- deform_conv_f64.hip: DLKA_F64, the general NCDHW path in double (AT_DISPATCH_FLOATING_TYPES' second type, deform_conv_cuda.cu:96,233) -----------------------
+template <int NOFF> int launch_deform_fwd_f64(const double *x, const double *off, const double *w, const double *bias, double *out, const Geom &g, hipStream_t st);
+template <int NOFF> int launch_deform_bwd_f64(const double *x, const double *off, const double *w, const double *gout, double *gx, double *goff, double *gw, double *gb,
+                                              const Geom &g, hipStream_t st);
+int launch_conv_fwd_f64(const double *x, const double *w, const double *bias, double *out, const Geom &g, hipStream_t st);
+int launch_conv_bwd_f64(const double *x, const double *w, const double *gout, double *gx, double *gw, double *gb, const Geom &g, hipStream_t st);
+
 // ---- conv.hip (general grouped convolution: depthwise, dense, pointwise) -----------------------------------
 int conv_fwd_wt_floats(const Geom &g);
 int conv_bwd_wb_floats(const Geom &g);

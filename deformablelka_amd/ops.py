@@ -59,7 +59,7 @@ def deform_conv3d_forward(input, weight, bias, offset, kernel_size, stride, padd
     bias = bias.contiguous()
     lib = L.get_lib()
     g = _geom(input.shape, weight.shape[0], k, s, p, d, group, deformable_groups, im2col_step)
-    dt = L.dtype_code(input)
+    dt = L.dtype_code(input, allow_f64=True)
     Do, Ho, Wo = _out_dims(g)
     if min(Do, Ho, Wo) <= 0:
         L.check(-4, "deform_conv_forward")
@@ -88,7 +88,7 @@ def deform_conv3d_backward(input, weight, bias, offset, grad_output, kernel_size
     grad_output = grad_output.contiguous()  # reference: permute(...).contiguous() copies, deform_conv_cuda.cu:228
     lib = L.get_lib()
     g = _geom(input.shape, weight.shape[0], k, s, p, d, group, deformable_groups, im2col_step)
-    dt = L.dtype_code(input)
+    dt = L.dtype_code(input, allow_f64=True)
     Do, Ho, Wo = _out_dims(g)
     if tuple(grad_output.shape) != (g.B, g.Cout, Do, Ho, Wo):  # deform_conv_cuda.cu:193-200
         raise RuntimeError(f"Input shape and grad_out shape wont match: ({(g.B, g.Cout, Do, Ho, Wo)} vs {tuple(grad_output.shape)}).")
@@ -145,7 +145,7 @@ def deform_conv2d_forward(input, offset, weight, bias=None, stride=1, padding=0,
     bias = None if bias is None else bias.contiguous()
     g = _geom2d(input.shape, weight.shape, s, p, d, offset.shape[1])
     lib = L.get_lib()
-    dt = L.dtype_code(input)
+    dt = L.dtype_code(input, allow_f64=True)
     _, Ho, Wo = _out_dims(g)
     if tuple(offset.shape[2:]) != (Ho, Wo):
         raise RuntimeError(f"offset spatial size {tuple(offset.shape[2:])} does not match output {(Ho, Wo)}")
@@ -165,7 +165,7 @@ def deform_conv2d_backward(input, offset, weight, grad_output, stride=1, padding
     input, offset, weight, grad_output = input.contiguous(), offset.contiguous(), weight.contiguous(), grad_output.contiguous()
     g = _geom2d(input.shape, weight.shape, s, p, d, offset.shape[1])
     lib = L.get_lib()
-    dt = L.dtype_code(input)
+    dt = L.dtype_code(input, allow_f64=True)
     gi = torch.empty_like(input) if need[0] else None
     go = torch.empty_like(offset) if need[1] else None
     gw = torch.empty_like(weight) if need[2] else None
@@ -248,7 +248,7 @@ def conv3d_forward(input, weight, bias=None, stride=1, padding=0, dilation=1, gr
     bias = None if bias is None else bias.contiguous()
     g = _geom(input.shape, weight.shape[0], tuple(weight.shape[2:5]), s, p, d, groups)
     lib = L.get_lib()
-    dt = L.dtype_code(input)
+    dt = L.dtype_code(input, allow_f64=True)
     Do, Ho, Wo = _out_dims(g)
     out = torch.empty((g.B, g.Cout, Do, Ho, Wo), dtype=input.dtype, device=input.device)
     wsb = lib.dlka_conv3d_forward_workspace(byref(g), dt)
@@ -265,7 +265,7 @@ def conv3d_backward(input, weight, grad_output, stride=1, padding=0, dilation=1,
     input, weight, grad_output = input.contiguous(), weight.contiguous(), grad_output.contiguous()
     g = _geom(input.shape, weight.shape[0], tuple(weight.shape[2:5]), s, p, d, groups)
     lib = L.get_lib()
-    dt = L.dtype_code(input)
+    dt = L.dtype_code(input, allow_f64=True)
     gi = torch.empty_like(input) if need[0] else None
     gw = torch.empty_like(weight) if need[1] else None
     gb = torch.empty((g.Cout,), dtype=input.dtype, device=input.device) if need[2] else None

@@ -45,7 +45,10 @@ typedef enum dlka_status {
     DLKA_ERR_LAUNCH = -9        /* hipGetLastError() != hipSuccess after a launch (reference only printf's, cuh:425-429) */
 } dlka_status;
 
-typedef enum dlka_dtype { DLKA_F32 = 0, DLKA_BF16 = 1 } dlka_dtype;
+/* DLKA_F64: the reference's op dispatches float AND double (AT_DISPATCH_FLOATING_TYPES, 3D/dcn/src/cuda/deform_conv_cuda.cu:96,233; its scripts import gradcheck,
+ * 3D/dcn/test.py:9).  Accepted by the GENERAL NCDHW entry points — dlka_deform_conv3d_*, dlka_deform_conv2d_*, dlka_conv3d_* (forward, backward; every tensor double) —
+ * and nowhere else: the fused blocks and the channels-last fast paths return DLKA_ERR_DTYPE / DLKA_ERR_UNSUPPORTED for it. */
+typedef enum dlka_dtype { DLKA_F32 = 0, DLKA_BF16 = 1, DLKA_F64 = 2 } dlka_dtype;
 
 /* Geometry of one (deformable or plain) N-d convolution.  2-D ops use D = kd = sd = dd = 1, pd = 0. */
 typedef struct dlka_conv_geom {

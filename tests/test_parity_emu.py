@@ -765,3 +765,39 @@ def test_wgrad_from_padded_copy_equals_unpadded(case):
     """cl_wgrad_dense_pad_kernel + cl_pad_copy_kernel (round 5): narrow volumes (the select walk), a W >= 16 row (the one-compare walk), the 2-D nets' 7 x 7 dilation 3 and 5 x 5,
     ragged N — bitwise equal to the unpadded kernels."""
     parity.check_wgrad_pad_equals_unpadded("cpu", *case)
+
+
+# ---- DLKA_F64 (round 6): the general NCDHW operators in double — the reference's op dispatches float and double (deform_conv_cuda.cu:96,233) ---------------------
+def test_f64_gradcheck_deform_conv3d():
+    from tests import f64_checks
+    f64_checks.gradcheck_deform_conv3d("cpu")
+
+
+def test_f64_gradcheck_deform_conv2d_and_conv3d():
+    from tests import f64_checks
+    f64_checks.gradcheck_deform_conv2d("cpu")
+    f64_checks.gradcheck_conv3d("cpu")
+
+
+@pytest.mark.parametrize("name", ["k3_normal", "k3_wild", "k3_integer", "g2_dg2_ragged", "dil3", "single_voxel"])
+def test_f64_deform_conv3d_vs_oracle(name):
+    """The double kernels against the C oracle (fp32: 1e-5 is its own rounding) — forward and the four gradients; the GPU suite holds them to 1e-10 of the
+    reference's own op compiled for double (tests/test_f64_gpu.py)."""
+    import oracle
+    from deformablelka_amd import ops
+    from tests import ref_cases
+    t = ref_cases.make(ref_cases.SMALL[name])
+    k3 = tuple(t["w"].shape[2:5])
+    ref = [oracle.deform_conv3d_forward(t["x"], t["w"], t["b"], t["off"], t["s"], t["p"], t["d"], t["g"], t["dg"], t["step"]),
+           *oracle.deform_conv3d_backward(t["x"], t["w"], t["b"], t["off"], t["go"], t["s"], t["p"], t["d"], t["g"], t["dg"], t["step"], q1_literal=False)]
+    x, w, b, off, go = (t[k].double() for k in ("x", "w", "b", "off", "go"))
+    got = [ops.deform_conv3d_forward(x, w, b, off, k3, t["s"], t["p"], t["d"], t["g"], t["dg"], t["step"]),
+           *ops.deform_conv3d_backward(x, w, b, off, go, k3, t["s"], t["p"], t["d"], t["g"], t["dg"], t["step"])]
+    for a_, r_ in zip(got, ref):
+        assert a_.dtype == torch.float64
+        assert float((a_ - r_.double()).abs().max()) <= 2e-5 * max(float(r_.abs().max()), 1e-6)
+
+
+def test_f64_is_refused_by_the_fast_paths():
+    from tests import f64_checks
+    f64_checks.fast_paths_refuse_double("cpu")
