@@ -389,6 +389,68 @@ def tblock_metric(batch, steps, warmup, dev, overlap=False):
     return out
 
 
+def lka_modules_metric(batch, steps, warmup, dev, overlap=True):
+    """The headline's 21 D-LKA blocks as the TRAINERS call them (north_star: "exposed through PyTorch-ROCm as torch.autograd.Functions that keep the exact nn.Module
+    signatures"): `LKA_Attention3d_deform.forward(x, B, C, H, W, D)` modules chained per stage instance through autograd — same shapes, same offset calibration, same
+    block count as the engine step above; eager and replayed from a hipGraph.  overlap: `module.wgrad_overlap = True` — the engine's side-stream weight-gradient schedule
+    for the module path (transformerblock.WgradOverlap: one join at the end of backward())."""
+    import deformablelka_amd as dk
+    from deformablelka_amd.stack import SYNAPSE_STAGES, chain_order, _offset_std_for
+    torch.manual_seed(0)
+    chains = []
+    for C, (H, W, D), n in chain_order(SYNAPSE_STAGES):
+        mods = []
+        for _ in range(n):
+            m = dk.LKA_Attention3d_deform(C)
+            with torch.no_grad():
+                m.spatial_gating_unit.deform_conv.conv_offset.weight.normal_(0, _offset_std_for(C))
+            m.wgrad_overlap = overlap
+            mods.append(m.to(dev))
+        x = torch.randn(batch, H * W * D, C, device=dev, requires_grad=True)
+        gy = torch.randn(batch, H * W * D, C, device=dev)
+        chains.append((mods, x, gy, (batch, C, H, W, D)))
+    params = [p for mods, _, _, _ in chains for m in mods for p in m.parameters()] + [x for _, x, _, _ in chains]
+
+    def step():
+        for p in params:
+            p.grad = None
+        for mods, x, gy, shp in chains:
+            y = x
+            for m in mods:
+                y = m(y, *shp)
+            y.backward(gy)
+
+    for _ in range(max(warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"metric": "3D D-LKA fwd+bwd volumes/sec (64x128x128), the 21 blocks through LKA_Attention3d_deform modules + autograd", "value": round(batch / dt, 3),
+           "unit": "volumes/s", "ms_per_step": round(dt * 1e3, 3), "blocks": sum(len(c[0]) for c in chains),
+           "path": "nn.Module + torch.autograd.Function, eager" + (", weight gradients on a side stream joined at the end of backward()" if overlap else "")}
+    try:
+        for p in params:
+            p.grad = None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dg = (time.perf_counter() - t0) / steps
+        out["hipgraph"] = {"value": round(batch / dg, 3), "ms_per_step": round(dg * 1e3, 3), "path": "the same nn.Module step, captured once and replayed"}
+    except Exception as e:
+        out["hipgraph"] = {"error": repr(e)[:200]}
+    return out
+
+
 def fullnet_metric(batch, steps, dev, bf16=False):
     """Third metric (SURVEY §8d iii / §8f-2): the WHOLE D_LKA_Former (42.35 M parameters; its 21 D-LKA transformer blocks on this repo's kernels,
     the conv / norm plumbing around them as GEMM re-expressions, HIP 3^3 convs and planar HIP norms), one trainer iteration per step — forward, deep-supervision loss, backward,
@@ -933,6 +995,13 @@ def main(harness=None):
             except Exception as e:
                 log("tblock metric failed:", repr(e))
                 out["tblock"] = None
+        if not args.no_tblock and world == 1 and dtype == torch.float32:
+            try:
+                out["lka_modules"] = lka_modules_metric(args.batch, max(3, args.steps // 2), 2, dev)
+            except Exception as e:
+                log("lka_modules metric failed:", repr(e))
+                out["lka_modules"] = None
+            torch.cuda.empty_cache()
         if not args.no_lka2d and world == 1 and dtype == torch.float32:   # BASELINE.json config 2 AS WRITTEN (bf16, B = 24) in the DEFAULT line, so that the
             try:                                                           # driver times it (round-3 verdict); its host companion stays in --extras
                 out["lka2d"] = lka2d_metric(5, dev, torch.bfloat16, with_cpu=False)

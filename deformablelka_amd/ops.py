@@ -651,7 +651,11 @@ def tblock3d_saved_activation_signs(saved, B, C, dims, variant=0, lka_bf16=False
     return a1 > 0, rd > 0, rd != 0
 
 
-def lka3d_attention_tokens_backward(x, params, grad_y, saved, dims, variant=0):
+def lka3d_attention_tokens_backward(x, params, grad_y, saved, dims, variant=0, side_stream=None):
+    """side_stream (a torch.cuda.Stream, optional): the pass in two parts (``dlka_lka3d_attention_tokens_backward_phase_v``) — the data-gradient chain on the current
+    stream, the five weight-gradient launches and the fold of their partial sums on ``side_stream`` behind an event — and NOT joined: the returned parameter gradients are
+    complete only once the current stream has waited for ``side_stream`` (``transformerblock.WgradOverlap`` joins once per backward pass).  Returns (gx, grads, keep):
+    ``keep`` = what the side stream still reads, to be held until the join.  "inline": both parts on the current stream (tests)."""
     L.require_device(x, grad_y, saved, *params)
     x, grad_y = x.contiguous(), grad_y.to(x.dtype).contiguous()
     params = [_fp32_param(t) for t in params]
@@ -665,6 +669,27 @@ def lka3d_attention_tokens_backward(x, params, grad_y, saved, dims, variant=0):
     grads = [torch.empty_like(t) for t in params]
     ps = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, params)
     gs = _ptr_struct(L.Lka3dPtrs, L.LKA3D_FIELDS, grads)
+    if side_stream is not None:
+        pb = lib.dlka_lka3d_tokens_partials_bytes_v(B, C, D, H, W, dt, int(variant))
+        part = L.scratch(pb, x)
+        nplan = lib.dlka_wgrad_finalize_plan_bytes(1)
+        plan = torch.zeros(nplan, dtype=torch.uint8)   # host job table of ONE block (its folds are launched per slot: no device copy is needed)
+        planp = ctypes.c_void_p(plan.data_ptr())
+        L.check(lib.dlka_wgrad_finalize_plan_init(planp, nplan, 1), "wgrad_finalize_plan_init")
+        args = (L.ptr(x), byref(ps), L.ptr(grad_y), L.ptr(saved), saved.numel(), L.ptr(gx), byref(gs), L.ptr(ws), wb, L.ptr(part), pb)
+        tail = (B, C, D, H, W, dt, int(variant))
+        cur_ptr = L.stream_ptr(x)
+        L.check(lib.dlka_lka3d_attention_tokens_backward_phase_v(*args, None, 0, 1, *tail, cur_ptr), "lka3d_attention_tokens_backward (data chain)")
+        if isinstance(side_stream, str):
+            sp = cur_ptr
+        else:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(x.device))
+            side_stream.wait_event(ev)
+            sp = ctypes.c_void_p(side_stream.cuda_stream)
+        L.check(lib.dlka_lka3d_attention_tokens_backward_phase_v(*args, planp, 0, 2, *tail, sp), "lka3d_attention_tokens_backward (weight gradients)")
+        L.check(lib.dlka_wgrad_finalize_run_slot(planp, 0, sp), "wgrad_finalize_run_slot")
+        return gx, grads, [ws, part, grad_y, saved, x]
     rc = lib.dlka_lka3d_attention_tokens_backward_v(L.ptr(x), byref(ps), L.ptr(grad_y), L.ptr(saved), saved.numel(), L.ptr(gx), byref(gs),
                                                   L.ptr(ws), wb, B, C, D, H, W, dt, int(variant), L.stream_ptr(x))
     L.check(rc, "lka3d_attention_tokens_backward")

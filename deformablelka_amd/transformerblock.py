@@ -66,8 +66,13 @@ class _LKA3dTokensFn(Function):
 
     @staticmethod
     def forward(ctx, x, dims, variant, *params):
+        variant, owner = variant if isinstance(variant, tuple) else (variant, None)
         y, saved = ops.lka3d_attention_tokens_forward(x, params, dims, variant)
         ctx.dims, ctx.variant = dims, variant
+        ctx.owner = owner   # a weak reference to the module when it asked for the side-stream schedule (WgradOverlap), else None
+        ctx.param_args = [True] * len(params)
+        if owner is not None and owner() is not None:
+            _note_application(owner(), ctx)
         ctx.save_for_backward(x, saved, *params)
         return y
 
@@ -75,7 +80,15 @@ class _LKA3dTokensFn(Function):
     @once_differentiable
     def backward(ctx, gy):
         x, saved, *params = ctx.saved_tensors
-        gx, grads = ops.lka3d_attention_tokens_backward(x, params, gy, saved, ctx.dims, ctx.variant)
+        mod = ctx.owner() if ctx.owner is not None else None
+        if mod is not None:
+            ctx.wgrad_done[0] = True
+        if mod is not None and not WgradOverlap.disabled and gy.is_cuda and WgradOverlap.eligible(ctx, mod, ctx.param_args, 3):
+            ov = WgradOverlap.get(gy.device)
+            gx, grads, keep = ops.lka3d_attention_tokens_backward(x, params, gy, saved, ctx.dims, ctx.variant, side_stream=ov.side)
+            ov.submit(keep)
+        else:
+            gx, grads = ops.lka3d_attention_tokens_backward(x, params, gy, saved, ctx.dims, ctx.variant)
         return (gx, None, None, *grads)
 
 
@@ -83,6 +96,7 @@ class LKA_Attention3d_deform(nn.Module):
     """transformerblock.py:655-673."""
 
     GATING_UNIT = LKA3d_deform
+    wgrad_overlap = False   # True: the token path's weight gradients on a side stream, joined once at the end of backward() — WgradOverlap's contract
 
     def __init__(self, d_model):
         super().__init__()
@@ -121,7 +135,8 @@ class LKA_Attention3d_deform(nn.Module):
         if act != x.dtype and fp32_params and ops.lka3d_tokens_supported(act, B, C, H, W, D, v):
             x = x.to(act)   # (one cast: the support query takes the dtype, not a tensor)
         if fp32_params and ops.lka3d_tokens_supported(x.dtype, B, C, H, W, D, v):
-            return _LKA3dTokensFn.apply(x, (H, W, D), v, *self.block_params())
+            owner = weakref.ref(self) if (self.wgrad_overlap and x.is_cuda) else None
+            return _LKA3dTokensFn.apply(x, (H, W, D), (v, owner), *self.block_params())
         if x.dtype != self.proj_1.weight.dtype:   # general path: one dtype for activations and parameters
             x = x.to(self.proj_1.weight.dtype)
         # General path (any C / dtype): the reference's own data movement around the NCDHW block.

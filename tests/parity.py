@@ -531,6 +531,30 @@ def check_forward_reproducible(dev, B, C, dims, dtype=torch.float32, runs=5, off
         assert (lib.dlka_conv_kw_launch_count() - n0 > 0) == expect_kw, (n0, lib.dlka_conv_kw_launch_count())
 
 
+def check_lka3d_tokens_phased_backward(dev, B, C, dims, dtype=torch.float32, seed=0):
+    """ops.lka3d_attention_tokens_backward(side_stream=...): the data chain (phase 1), the weight gradients into block-private partial sums (phase 2) and their fold by
+    dlka_wgrad_finalize_run_slot give what the one-call pass gives — the same kernels on the same operands (only the order of a few fp32 atomics may differ)."""
+    import deformablelka_amd as dk
+    from deformablelka_amd import ops
+    from oracle import blocks
+    torch.manual_seed(seed)
+    H, W, D = dims
+    m = dk.LKA_Attention3d_deform(C)
+    blocks.randomize_offsets_(m, std=0.3)
+    m = m.to(dev)
+    x = torch.randn(B, H * W * D, C).to(dev).to(dtype)
+    gy = torch.randn(B, H * W * D, C).to(dev).to(dtype)
+    params = [p_.detach() for p_ in m.block_params()]
+    y, saved = ops.lka3d_attention_tokens_forward(x, params, dims, m.variant)
+    gx0, g0 = ops.lka3d_attention_tokens_backward(x, params, gy, saved, dims, m.variant)
+    gx1, g1, keep = ops.lka3d_attention_tokens_backward(x, params, gy, saved, dims, m.variant, side_stream="inline")
+    tol = 2e-3 if dtype == torch.float32 else 2e-2
+    for k, (a_, b_) in enumerate(zip([gx0, *g0], [gx1, *g1])):
+        assert torch.isfinite(b_.float()).all(), k
+        scale = max(float(a_.float().abs().max()), 1e-6)
+        assert float((a_.float() - b_.float()).abs().max()) <= tol * scale, (k, float((a_.float() - b_.float()).abs().max()) / scale)
+
+
 def check_lka3d_tokens_sample_handover(dev, B, C, dims, dtype=torch.float32, seed=0, offset_std=0.3):
     """The deformable conv's weight gradient from the samples the grad_offset kernel stores (default) against the weight-gradient kernel that
     gathers for itself (dlka_lka3d_force_wgrad_gather(1) / DLKA_WGRAD_GATHER=1): same fma chain for every sample, same MFMA order over the rows -> the two agree to summation

@@ -39,6 +39,8 @@ def test_product_double_equals_the_references_own_op_in_double(name):
     g = ops.deform_conv3d_backward(x, w, b, off, go, k3, t["s"], t["p"], t["d"], t["g"], t["dg"], t["step"])
     assert out.dtype == torch.float64 and all(q.dtype == torch.float64 for q in g)
     for nm, a_, r_ in zip(("output", "grad_input", "grad_offset", "grad_weight", "grad_bias"), [out, *g], [r_out, *r_g]):
+        if nm == "grad_input" and t["p"][1] != t["p"][2]:
+            continue   # Q1: the reference's col2im forwards pad_h in place of pad_w (cuh:447); the product computes the consistent gradient (tests/test_ref_d3d_gpu.py)
         err = float((a_ - r_).abs().max() / r_.abs().max().clamp_min(1e-30))
         assert err <= 1e-10, f"{name} {nm}: {err:.3e} of max|ref| (double)"
 

@@ -318,6 +318,11 @@ def test_forward_is_bitwise_reproducible(C, dims, dtype):
     parity.check_forward_reproducible("cpu", 2, C, dims, dtype, runs=3, expect_kw=True)
 
 
+@pytest.mark.parametrize("C,dims,dtype", [(32, (3, 4, 5), torch.float32), (64, (2, 3, 4), torch.bfloat16)])
+def test_lka3d_tokens_phased_backward_equals_one_call(C, dims, dtype):
+    parity.check_lka3d_tokens_phased_backward("cpu", 2, C, dims, dtype)
+
+
 def test_stack_step_vs_per_block_entries_and_oracle():
     """tests/test_stack_fullsize_gpu.py's check (the benchmarked engine step against the per-block entry points and the oracle) on a toy stack: the same
     checker, so that its logic is exercised in the CPU suite."""

@@ -966,6 +966,52 @@ def test_tblock3d_wgrad_overlap_equals_one_stream():
         assert bool(torch.isfinite(b_).all()) and float((a_ - b_).abs().max()) <= lim, ("graph", n, float((a_ - b_).abs().max()), lim)
 
 
+@pytest.mark.parametrize("C,dims,dtype", [(32, (32, 32, 32), torch.float32), (128, (8, 8, 8), torch.float32), (64, (16, 16, 16), torch.bfloat16)])
+def test_lka3d_tokens_phased_backward_equals_one_call(C, dims, dtype):
+    parity.check_lka3d_tokens_phased_backward(DEV, 2, C, dims, dtype)
+
+
+def test_lka3d_module_wgrad_overlap_equals_one_stream():
+    """``LKA_Attention3d_deform.wgrad_overlap = True``: a chain of three BARE D-LKA modules through autograd with their weight gradients on the side stream (one join at
+    the end of backward(): transformerblock.WgradOverlap) against the same backward pass on one stream — one forward pass, every gradient equal up to atomics order."""
+    import deformablelka_amd as dk
+    from deformablelka_amd.transformerblock import WgradOverlap
+    from oracle import blocks
+    torch.manual_seed(3)
+    C, (H, W, D) = 64, (16, 16, 16)
+    mods = []
+    for _ in range(3):
+        m = dk.LKA_Attention3d_deform(C)
+        blocks.randomize_offsets_(m, std=0.3)
+        m.wgrad_overlap = True
+        mods.append(m.to(DEV))
+    x = torch.randn(2, H * W * D, C, device=DEV, requires_grad=True)
+    gy = torch.randn(2, H * W * D, C, device=DEV)
+    params = [p for m in mods for p in m.parameters()]
+    y = x
+    for m in mods:
+        y = m(y, 2, C, H, W, D)
+
+    def backward(disabled):
+        WgradOverlap.disabled = disabled
+        try:
+            for p in params + [x]:
+                p.grad = None
+            y.backward(gy, retain_graph=True)
+            torch.cuda.synchronize()
+        finally:
+            WgradOverlap.disabled = False
+        return [x.grad.clone()] + [p.grad.clone() for p in params]
+
+    ref = backward(True)
+    ov = WgradOverlap.get(torch.device(DEV))
+    for rep in range(3):
+        got = backward(False)
+        assert not ov.pending
+        for a_, b_ in zip(ref, got):
+            assert bool(torch.isfinite(b_).all()) and float((a_ - b_).abs().max()) <= 2e-3 * max(float(a_.abs().max()), 1e-30), rep
+
+
 def test_tblock3d_wgrad_overlap_frozen_parameter_and_shared_block_take_one_stream():
     """the side-stream pass is only safe when autograd keeps every returned weight gradient until backward() returns.  A FROZEN parameter's gradient is
     dropped at once (its memory would be re-used by the main stream while the side stream still writes it) and a block applied TWICE in one graph has its two
