@@ -73,13 +73,13 @@ def kernel_work(name, B, C, n, dbytes):
         return contr + 27 * M * (16 * C), 2 * E * s + Off * 4
     if "cl_deform_fwd" in name:
         return contr + interp, 2 * E * s + Off * 4
-    if "cl_wgrad_samp_kernel" in name:        # dense stream over the stored samples S[tap][m][c]
-        return contr, (27 * E + E) * s
+    if "cl_wgrad_samp_kernel" in name:        # dense stream over the stored samples S[tap][m][c] (round 6: IEEE halves on the fp32 path too)
+        return contr, 27 * E * 2 + E * s
     if "cl_wgrad_deform_kernel" in name:
         return contr + interp, 2 * E * s + Off * 4
     if "cl_wgrad_dense_kernel" in name:
         return offc, E * s + Off * 4
-    m = re.search(r"cl_(?:igemm|conv_wave)_kernel<(\d+), (\d+)", name)
+    m = re.search(r"cl_(?:igemm|conv_wave|conv_kw)_kernel<(\d+), (\d+)", name)
     if m:                                     # <mode, planar output, ...>: mode 0 = forward conv, 2 = data gradient from a planar grad_out
         return offc, E * s + Off * 4
     m = re.search(r"cl_dwconv_(?:rowsN|rows|wgrad2|wgrad)_kernel<[^,]+, (\d+), (\d+)", name)
@@ -206,7 +206,10 @@ def roofline_report(stack, B, dtype, ms_per_step):
         except Exception:
             traffic = None
     C, (H, W, D), _ = SYNAPSE_STAGES[dom["stage"]]
-    return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5),
+    extra = {}
+    if dbytes == 2 and bound == "mfma":   # the bf16 step's dominant kernel contracts on the bf16 matrix cores — its fraction of THAT pipe as well
+        extra = {"frac_of_bf16_mfma_peak": round(ach / PEAK_BF16_TFLOPS, 5), "bf16_mfma_peak_TFLOPs": PEAK_BF16_TFLOPS}
+    return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5), **extra,
             "traffic": traffic, "traffic_source": traffic_source, "kernel": dom["kernel"], "kernel_us": dom["avg_us"],
             "kernel_us_less_event_cost": round(dom["avg_us"] - ev_us, 2),
             "launches_per_step": dom["launches_per_step"], "step_share": dom["step_share"],

@@ -75,6 +75,7 @@ struct WgradArgs {
     const float *in;    // [B][N][Cin] channels-last
     const float *off;   // AMODE 1: planar offsets [B][3K][N]
     const float *samp;  // AMODE 1, optional: [K][M][Cin] samples (fp32; bf16 when act_bf16) stored by cl_deform_goff2_kernel (DeformBwdArgs::samp) — no gather
+    int samp_f16;       // fp32 activations only: the samples are IEEE halves (DeformBwdArgs::samp_f16)
     float *part;        // [chunks][K][CoutP][Cin] partial weight-gradient tiles, followed by [chunks][CoutP] partial bias sums
     float *bpart;       // = part + chunks*K*CoutP*Cin when the bias gradient is wanted, else null (set by the launcher)
     int B, D, H, W, N, M;
@@ -205,6 +206,10 @@ struct DeformBwdArgs {
     int gx_zeroed;      // 1: the caller has already zero-filled gx
     int goff_zeroed;    // 1: the caller has already zero-filled goff (needed when cl_deform_goff_ccsplit() > 1)
     int act_bf16;       // 1: in / g are bf16 storage (gx, goff stay fp32: atomics / planar)
+    int samp_f16;       // fp32 activations only (round 6): store the samples as IEEE halves — half the bytes of the hand-over in both directions (250 -> 125 MB written per
+                        //   stage-0 launch, the same read back by cl_wgrad_samp_kernel).  A sample is an interpolated activation: rounding it to 11 significant bits moves a
+                        //   weight-gradient element by ~3e-4 of its own magnitude at worst over 65 536 random-sign terms (bf16's 8 bits would sit ON the 1e-3 contract);
+                        //   grad_out and the accumulation stay fp32.  DLKA_SAMP_F16=0 / DLKA_EXACT_FP32 keep fp32 samples
     int goff_cpad;      // > 0: goff is written as pack_split2() words with goff_cpad channel planes per batch (planes >= 3K zero) for the
                         //      split-MFMA consumers (offset-conv data / weight gradient); 0: plain fp32 [B][3K][N]
 };

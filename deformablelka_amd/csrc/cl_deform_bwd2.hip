@@ -310,7 +310,11 @@ __global__ __launch_bounds__(256, 2) void cl_deform_goff2_kernel(DeformBwdArgs p
                     *reinterpret_cast<f32x4 *>(dst) = dd;
                     *reinterpret_cast<f32x4 *>(dst + 32 * SROW) = dh;
                     *reinterpret_cast<f32x4 *>(dst + 2 * 32 * SROW) = dw;
-                    if (SAMP && XB == 4) buf_store_f32x4(rsamp, srow ? samp_v0 + (unsigned)((tap * p.M + GG::RPI * g) * p.C + cc * 32 + 4 * v) * 4u : DLKA_OOB, s4);
+                    if (SAMP && XB == 4) {
+                        const unsigned so = (unsigned)((tap * p.M + GG::RPI * g) * p.C + cc * 32 + 4 * v);   // element offset beyond this lane's (row, piece)
+                        if (p.samp_f16) buf_store_f16x4(rsamp, srow ? (samp_v0 >> 1) + so * 2u : DLKA_OOB, s4);   // (uniform) halves: samp_v0 is a byte offset of fp32 elements
+                        else buf_store_f32x4(rsamp, srow ? samp_v0 + so * 4u : DLKA_OOB, s4);
+                    }
                     if (SAMP && XB == 2) { if (v == 0) s4_lo = s4; else buf_store_bf16x8(rsamp, srow ? samp_v0 + (unsigned)((tap * p.M + GG::RPI * g) * p.C + cc * 32) * 2u : DLKA_OOB, s4_lo, s4); }
                 }
             }
@@ -551,7 +555,9 @@ __global__ __launch_bounds__(64 * WAVES, OCC) void cl_deform_goff16_kernel(Defor
                     sraw[2 * vv + 1] = __uint_as_float((unsigned)bf16_bits(sv[2]) | ((unsigned)bf16_bits(sv[3]) << 16));
                 }
             }
-            if (SAMP) buf_store_f32x4(rsamp, samp_v0 == DLKA_OOB ? DLKA_OOB : samp_v0 + (unsigned)(tap * p.M * p.C + CPP * pass) * XB, sraw);
+            if (SAMP && XB == 4 && p.samp_f16)   // (uniform) the fp32 path's samples as halves: 8 bytes per lane and pass
+                buf_store_f16x4(rsamp, samp_v0 == DLKA_OOB ? DLKA_OOB : (samp_v0 >> 1) + (unsigned)(tap * p.M * p.C + CPP * pass) * 2u, sraw);
+            else if (SAMP) buf_store_f32x4(rsamp, samp_v0 == DLKA_OOB ? DLKA_OOB : samp_v0 + (unsigned)(tap * p.M * p.C + CPP * pass) * XB, sraw);
             // the next unit's corner loads go out now: in flight under the reduction below, the next staging and the next MFMAs
             sched_fence();   // (the scheduler would hoist these loads above the interpolation into a SECOND set of piece registers — and spill)
             if (pass + 1 < NPASS) issue(tap, pass + 1);

@@ -152,10 +152,14 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
 // step's operands are in flight under the current step's 16 * TPW MFMAs.  Same tile / chunk / partial layout as cl_wgrad_deform_kernel,
 // and the same arithmetic: S is produced by the same fma chain, the MFMA order over the rows is the same.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TPW, typename T = float>   // T: storage of the channels-last `g`
+// S16 (T = float only, round 6): the samples are IEEE halves (WgradArgs::samp_f16) — half the bytes this HBM-bound stream reads; grad_out, the products (fp32-input MFMA on the
+// widened sample) and the accumulation stay fp32.
+template <int TPW, typename T = float, bool S16 = false>   // T: storage of the channels-last `g`
 __global__ __launch_bounds__(64, 2) void cl_wgrad_samp_kernel(WgradArgs p)
 {
+    static_assert(!S16 || sizeof(T) == 4, "half samples belong to the fp32 path");
     constexpr unsigned XB = sizeof(T);
+    constexpr unsigned SB = S16 ? 2u : XB;   // bytes of a stored sample
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
     int chunk = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (p.xcd_total) {
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(64, 2) void cl_wgrad_samp_kernel(WgradArgs p)
     const int tap0 = bz * TPW;
     const int co = ot * 32 + i, ci = ct * 32 + i;
     const bool want_bias = p.bpart && ct == 0 && bz == 0;
-    const BufRsrc rg = make_rsrc(p.g, (size_t)p.M * p.Cout * XB), rs = make_rsrc(p.samp, (size_t)p.K * p.M * p.Cin * XB);
+    const BufRsrc rg = make_rsrc(p.g, (size_t)p.M * p.Cout * XB), rs = make_rsrc(p.samp, (size_t)p.K * p.M * p.Cin * SB);
 
     f32x16 acc[TPW];
 #pragma unroll
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(64, 2) void cl_wgrad_samp_kernel(WgradArgs p)
     // (bf16 grad_out / samples: a dword holding the column pair (c & ~1, c | 1); the lane keeps its half)
     constexpr bool G16 = sizeof(T) == 2;
     const unsigned vg = co < p.Cout ? (unsigned)(16 * h * p.Cout + (G16 ? (co & ~1) : co)) * XB : DLKA_OOB;
-    const unsigned vs = (unsigned)(16 * h * p.Cin + (G16 ? (ci & ~1) : ci)) * XB;   // (the samples have the storage type of grad_out)
+    const unsigned vs = (unsigned)(16 * h * p.Cin + ((G16 || S16) ? (ci & ~1) : ci)) * SB;   // (the samples have the storage type of grad_out, or are halves: S16)
     const unsigned gsh = (co & 1) ? 0u : 16u, ssh = (ci & 1) ? 0u : 16u;           // half selection: (word << sh) & 0xffff0000
     unsigned tapbit[TPW];   // 0, or the out-of-range bit for taps past K (uniform)
 #pragma unroll
@@ -198,10 +202,12 @@ __global__ __launch_bounds__(64, 2) void cl_wgrad_samp_kernel(WgradArgs p)
             ga[buf][s] = buf_load_f32_s(rg, vg | rowbit, (unsigned)((mbase + s) * p.Cout) * XB);
 #pragma unroll
             for (int t = 0; t < TPW; ++t)
-                sv[buf][t][s] = buf_load_f32_s(rs, vs | rowbit | tapbit[t], (unsigned)(((tap0 + t) * p.M + mbase + s) * p.Cin) * XB);
+                sv[buf][t][s] = buf_load_f32_s(rs, vs | rowbit | tapbit[t], (unsigned)(((tap0 + t) * p.M + mbase + s) * p.Cin) * SB);
         }
     };
     auto half = [&](float w, unsigned sh) { return G16 ? __uint_as_float((__float_as_uint(w) << sh) & 0xffff0000u) : w; };
+    // S16: the dword holds the halves of columns (ci & ~1, ci | 1); out-of-range loads return 0 = +0.0 in either format
+    auto samp_val = [&](float w) { return S16 ? f16_value((unsigned short)(__float_as_uint(w) >> ((ci & 1) ? 16 : 0))) : half(w, ssh); };
     auto compute = [&](int buf) {
         float g[16];
 #pragma unroll
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(64, 2) void cl_wgrad_samp_kernel(WgradArgs p)
 #pragma unroll
         for (int t = 0; t < TPW; ++t)
 #pragma unroll
-            for (int s = 0; s < 16; ++s) acc[t] = mfma_32x32x2(g[s], half(sv[buf][t][s], ssh), acc[t]);
+            for (int s = 0; s < 16; ++s) acc[t] = mfma_32x32x2(g[s], samp_val(sv[buf][t][s]), acc[t]);
     };
     if (m_lo < m_hi) load_step(0, m_lo);
     for (int mbase = m_lo; mbase < m_hi; mbase += 64) {   // two steps per trip: the register buffers are addressed statically
@@ -735,6 +741,7 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
         if (a.samp) {   // samples stored by the grad_offset kernel: dense stream, no gather
             if (pl.tpw != 3 || (long)a.K * a.M * a.Cin * (a.act_bf16 ? 2 : 4) >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets below DLKA_OOB
             if (a.act_bf16) { auto k = cl_wgrad_samp_kernel<3, bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
+            else if (a.samp_f16) { auto k = cl_wgrad_samp_kernel<3, float, true>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
             else { auto k = cl_wgrad_samp_kernel<3>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
         }
         else if (a.act_bf16) {

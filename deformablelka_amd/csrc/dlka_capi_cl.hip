@@ -434,6 +434,14 @@ size_t deform_scratch_floats(const SameConv &s)
     return cl_deform_bwd2_scratch_floats(a);
 }
 
+// The stored-sample hand-over of the fp32 path keeps its samples as IEEE halves (round 6; DeformBwdArgs::samp_f16 has the reasoning and the error bound): one process-wide
+// switch, read once — the grad_offset kernel that writes them and the weight-gradient kernel that reads them must agree.  DLKA_SAMP_F16=0 or DLKA_EXACT_FP32: fp32 samples.
+static bool samp_f16(const SameConv &s)
+{
+    static const bool on = [] { const char *e = getenv("DLKA_SAMP_F16"); return !(e && e[0] == '0') && getenv("DLKA_EXACT_FP32") == nullptr; }();
+    return on && !s.act_bf16;
+}
+
 int deform_bwd_variant() { return 0; }   // (two earlier generations — one fused kernel with global atomics, an fp32 LDS window — were removed in round 2)
 
 int deform_backward(const SameConv &s, const float *x, const float *off, const float *w, const float *gout, float *gx, float *goff,
@@ -447,6 +455,7 @@ int deform_backward(const SameConv &s, const float *x, const float *off, const f
         fill_deform_bwd(a, s);
         a.in = x; a.off = off; a.g = gout; a.wp = wp; a.gx = gx; a.goff = goff; a.gx_zeroed = gx_zeroed ? 1 : 0; a.goff_zeroed = goff_zeroed ? 1 : 0; a.goff_cpad = goff_cpad;
         a.samp = goff ? samp : nullptr;
+        a.samp_f16 = (a.samp && samp_f16(s)) ? 1 : 0;
         a.wp16 = deform_b16() ? wp16 : nullptr;   // (prepared by the caller: two-term bf16 records, mode 2 | 8) — both dtypes: bf16 rows as they are, fp32 rows split
         DLKA_TRY(launch_cl_deform_bwd2(a, scratch, st));
     }
@@ -454,6 +463,7 @@ int deform_backward(const SameConv &s, const float *x, const float *off, const f
         WgradArgs a;
         memset(&a, 0, sizeof(a));
         a.g = gout; a.in = x; a.off = off; a.part = part; a.samp = samp;
+        a.samp_f16 = (samp && samp_f16(s)) ? 1 : 0;
         a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.Cin = s.Cin; a.Cout = s.Cout;
         a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
         a.act_bf16 = s.act_bf16;

@@ -131,6 +131,22 @@ __device__ __forceinline__ void buf_store_bf16x8(BufRsrc r, unsigned off, f32x4 
     for (int e = 0; e < 4; ++e) { h[e] = hipemu::hipemu_f32_to_bf16(lo[e]); h[4 + e] = hipemu::hipemu_f32_to_bf16(hi[e]); }
     memcpy(const_cast<unsigned char *>(r.base) + off, h, 16);
 }
+// fp16 (IEEE half) <-> float: the stored-sample hand-over of the fp32 path keeps its samples as halves (cl_deform_bwd2.hip / cl_wgrad.hip, round 6); values beyond the
+// half range saturate at +-65504 instead of becoming infinite
+__device__ __forceinline__ unsigned short f16_bits(float x)
+{
+    const float c = fminf(fmaxf(x, -65504.f), 65504.f);
+    return __builtin_bit_cast(unsigned short, (_Float16)c);
+}
+__device__ __forceinline__ float f16_value(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+// 4 floats -> 4 halves (round to nearest even, saturating), one 8-byte store, dropped when the offset is out of range (DLKA_OOB)
+__device__ __forceinline__ void buf_store_f16x4(BufRsrc r, unsigned off, f32x4 v)
+{
+    if (!(off < r.bytes) || (size_t)off + 8 > r.bytes) return;
+    unsigned short h[4];
+    for (int e = 0; e < 4; ++e) h[e] = f16_bits(v[e]);
+    memcpy(const_cast<unsigned char *>(r.base) + off, h, 8);
+}
 // ---- bf16 activation storage (DLKA_BF16 token path): 4 consecutive bf16 -> 4 floats, one 8-byte buffer load ----
 __device__ __forceinline__ f32x4 buf_load_bf16x4(BufRsrc r, unsigned off)
 {
@@ -295,6 +311,24 @@ __device__ __forceinline__ void buf_store_bf16x8(BufRsrc r, unsigned off, f32x4 
     w[0] = (unsigned)bf16_bits(lo[0]) | ((unsigned)bf16_bits(lo[1]) << 16); w[1] = (unsigned)bf16_bits(lo[2]) | ((unsigned)bf16_bits(lo[3]) << 16);
     w[2] = (unsigned)bf16_bits(hi[0]) | ((unsigned)bf16_bits(hi[1]) << 16); w[3] = (unsigned)bf16_bits(hi[2]) | ((unsigned)bf16_bits(hi[3]) << 16);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw128_t, w), r, off, 0, 0);
+}
+// fp16 (IEEE half) <-> float: the stored-sample hand-over of the fp32 path keeps its samples as halves (cl_deform_bwd2.hip / cl_wgrad.hip, round 6); values beyond the
+// half range saturate at +-65504 instead of becoming infinite
+__device__ __forceinline__ unsigned short f16_bits(float x)
+{
+    const float c = fminf(fmaxf(x, -65504.f), 65504.f);
+    return __builtin_bit_cast(unsigned short, (_Float16)c);
+}
+__device__ __forceinline__ float f16_value(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+// 4 floats -> 4 halves (round to nearest even, saturating), one 8-byte store (whole offset in the VGPR: see the note above)
+__device__ __forceinline__ void buf_store_f16x4(BufRsrc r, unsigned off, f32x4 v)
+{
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    typedef decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0)) raw64_t;
+    u2_t w;
+    w[0] = (unsigned)f16_bits(v[0]) | ((unsigned)f16_bits(v[1]) << 16);
+    w[1] = (unsigned)f16_bits(v[2]) | ((unsigned)f16_bits(v[3]) << 16);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(raw64_t, w), r, off, 0, 0);
 }
 // ---- bf16 activation storage (DLKA_BF16 token path): 4 consecutive bf16 -> 4 floats, one 8-byte buffer load ----
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));

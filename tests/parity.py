@@ -588,7 +588,10 @@ def check_lka3d_tokens_sample_handover(dev, B, C, dims, dtype=torch.float32, see
     k = "spatial_gating_unit.deform_conv.weight"
     assert g_s[k].abs().max() > 0
     for name in g_s:   # (not bit-equal at block level: upstream tap-split partial sums meet in atomics, so grad_out itself moves by ~1e-7 per run)
-        assert rel_err(g_s[name], g_g[name]) < (1e-5 if dtype == torch.float32 else 2e-2), (name, rel_err(g_s[name], g_g[name]))
+        # round 6: the fp32 path hands its samples over as IEEE halves (11 significant bits; grad_out, products and accumulation fp32): the deformable conv's weight gradient
+        # agrees with the gathering kernel's to the rounding of the samples — a random-sign sum over M rows keeps its relative error at ~2^-12, 5e-4 of max at the outside
+        tol = 2e-2 if dtype != torch.float32 else (5e-4 if name == k else 1e-5)
+        assert rel_err(g_s[name], g_g[name]) < tol, (name, rel_err(g_s[name], g_g[name]))
 
 
 def check_lka3d_tokens_pointwise_pair(dev, B, dims, dtype=torch.float32, seed=0):
