@@ -149,11 +149,12 @@ __global__ __launch_bounds__(64 * KW) void cl_conv_kw_kernel(IgemmArgs p)
 
 // Would the K split of this contraction run inside the workgroup (cl_conv_kw_kernel)?  The C-ABI sequencing code asks BEFORE it decides on zero fills and fp32
 // staging buffers: a contraction this returns true for is launched with splits = 1 and needs neither.
-bool cl_conv_kw_applies(int amode, int omode, int split_bf16, int K, int epi, int NP, bool act_bf16, bool a_out_bf16)
+// volume: a 3-D volume (D > 1).  The 2-D nets' offset convs (D = 1: 25 / 49 taps, up to 384 columns, 4 704 / 18 816 rows at B = 24) keep the tap split: with this kernel the 2-D
+// block measured 1328 against 1385 images/s (profiles/r10_notes.md) — many column tiles re-fetching "lane = row" A operands.
+bool cl_conv_kw_applies(int amode, int omode, int split_bf16, int K, int epi, int NP, bool act_bf16, bool volume)
 {
     static const bool off = [] { const char *e = getenv("DLKA_CONV_KW"); return e && e[0] == '0'; }();   // (A/B: 0 = the tap split over gridDim.y with fp32 atomics, rounds 1 - 5)
-    if (off || K <= 1 || (epi != 0 && epi != 3) || NP % 32) return false;
-    (void)a_out_bf16;
+    if (off || !volume || K <= 1 || (epi != 0 && epi != 3) || NP % 32) return false;
     if (act_bf16) return split_bf16 == 2 && ((amode == 0 && omode == 1) || (amode == 2 && omode == 0));   // the two 27-tap convs of the bf16 token path
     if (split_bf16 == 3) return amode == 0 && (omode == 0 || omode == 1);
     if (split_bf16 == 2) return (amode == 0 && (omode == 0 || omode == 1)) || (amode == 2 && omode == 0);
@@ -162,7 +163,7 @@ bool cl_conv_kw_applies(int amode, int omode, int split_bf16, int K, int epi, in
 
 int launch_cl_conv_kw(int amode, int omode, const IgemmArgs &a, hipStream_t st)
 {
-    if (!cl_conv_kw_applies(amode, omode, a.split_bf16, a.K, a.epi, a.NP, a.act_bf16 != 0, false)) return DLKA_ERR_UNSUPPORTED;
+    if (!cl_conv_kw_applies(amode, omode, a.split_bf16, a.K, a.epi, a.NP, a.act_bf16 != 0, a.D > 1)) return DLKA_ERR_UNSUPPORTED;
     if ((long)a.K * (a.CinP / 32) * (a.split_bf16 == 3 ? 48 : 32) * a.NP * 4 >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets
     const int nt_total = a.NP / 32, row_tiles = cdiv(a.M, 32);
     // column tiles per workgroup: as many as still leave >= 2048 waves of four-wave workgroups (the A rows are fetched once per workgroup), else one

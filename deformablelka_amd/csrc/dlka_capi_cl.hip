@@ -121,7 +121,7 @@ int deform_forward_splits(const SameConv &s) { return cl_igemm_pick_splits(s.M, 
 int dense_forward_splits(const SameConv &s, int epi)
 {
     const int sp = cl_igemm_pick_splits(s.M, s.K * (s.Cin / 32), epi, s.K);
-    if (sp > 1 && cl_conv_kw_applies(0, s.act_bf16 ? 1 : 0, use_split(s, true), s.K, epi, round_up(s.Cout, 32), s.act_bf16 != 0, false)) return 1;
+    if (sp > 1 && cl_conv_kw_applies(0, s.act_bf16 ? 1 : 0, use_split(s, true), s.K, epi, round_up(s.Cout, 32), s.act_bf16 != 0, s.D > 1)) return 1;
     return sp;
 }
 int dense_backward_data_splits(const SameConv &s, int epi, int gout_planar = -1)
@@ -129,7 +129,7 @@ int dense_backward_data_splits(const SameConv &s, int epi, int gout_planar = -1)
     const int sp = cl_igemm_pick_splits(s.M, s.K * (round_up(s.Cout, 32) / 32), epi, s.K);
     // (gout_planar < 0: a query without the layout — bf16 storage reaches here with planar gradients only, fp32 with either)
     const int amode = gout_planar < 0 ? (s.act_bf16 ? 2 : 0) : (gout_planar ? 2 : 0);
-    if (sp > 1 && cl_conv_kw_applies(amode, 0, use_split(s, false), s.K, epi, s.Cin, s.act_bf16 != 0, false)) return 1;
+    if (sp > 1 && cl_conv_kw_applies(amode, 0, use_split(s, false), s.K, epi, s.Cin, s.act_bf16 != 0, s.D > 1)) return 1;
     return sp;
 }
 

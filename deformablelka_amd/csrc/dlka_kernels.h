@@ -66,7 +66,7 @@ int cl_igemm_pick_splits(int M, int units, int epi, int K);
 int launch_cl_pointwise(const IgemmArgs &a, hipStream_t st);
 int launch_cl_pointwise_pair(const PwPairArgs &a, hipStream_t st);   // two dependent pointwise convs in one launch (C = 32 / 64)
 int launch_cl_conv_wave(int amode, int omode, const IgemmArgs &a, int splits, hipStream_t st);
-bool cl_conv_kw_applies(int amode, int omode, int split_bf16, int K, int epi, int NP, bool act_bf16, bool a_out_bf16);   // cl_conv_kw.hip: K split over the waves of a workgroup
+bool cl_conv_kw_applies(int amode, int omode, int split_bf16, int K, int epi, int NP, bool act_bf16, bool volume);   // cl_conv_kw.hip: K split over the waves of a workgroup
 int launch_cl_conv_kw(int amode, int omode, const IgemmArgs &a, hipStream_t st);   // deterministic small-volume contraction (no tap split, no atomics, no zero fill)
 bool cl_conv_brick_supported(const IgemmArgs &a);
 int cl_conv_brick_split(const IgemmArgs &a);
