@@ -32,7 +32,14 @@ __global__ __launch_bounds__(64 * KW) void cl_conv_kw_kernel(IgemmArgs p)
     constexpr int UF = SPLIT == 3 ? 48 : 32;      // floats of prepared weights per unit and column
     constexpr int NB = 2 * SPLIT * NT;            // B records (16 bytes) per lane and unit: [(part * 2 + mf) * NT + t]
     constexpr int RS = 65;                        // row stride of a wave's partial tile in LDS (floats): register r of lane l at r * RS + l
-    __shared__ float Red[KW][16 * RS];
+    // LF ("line-friendly" A fetch, channels-last fp32 rows): a "lane = row" load (ARow) touches 64 cache lines per instruction — ~256 address-unit cycles per unit and wave,
+    // which is what bounded this kernel with one workgroup per CU (profiles/r10_notes.md).  Here a load instruction covers 8 WHOLE 128-byte rows (lane = (row of 8, 16-byte
+    // piece), as the gather kernels of cl_gather.h do); the pieces go through a wave-private LDS tile [32 rows][36] into the MFMA A layout (lane (i, h): channels 16 h ..
+    // 16 h + 15 of row i).  The tile shares its LDS with the wave's partial tile of the final reduction (used only behind the loop).
+    constexpr bool LF = AMODE == 0 && sizeof(T) == 4;
+    constexpr int AROW = 36;
+    constexpr int WSM = (LF && 32 * AROW > 16 * RS) ? 32 * AROW : 16 * RS;
+    __shared__ __attribute__((aligned(16))) float Red[KW][WSM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int mbase = blockIdx.x * 32;
@@ -62,9 +69,31 @@ __global__ __launch_bounds__(64 * KW) void cl_conv_kw_kernel(IgemmArgs p)
     ARow<AMODE, T> arow;
     float abuf[2][16];
     f32x4 bbuf[2][NB];
+    // LF: this lane's four rows 8 e + rg and its piece pc; their byte offsets for the current tap (formed by "lane = row" and handed round by shuffles)
+    const int rg = lane >> 3, pc = lane & 7;
+    unsigned lf_ro[4] = {DLKA_OOB, DLKA_OOB, DLKA_OOB, DLKA_OOB};
+    int lf_tap = -1;
     auto issue = [&](int unit, float *ad, f32x4 *bd) {
         int ck;
         const int tap = divmod_fast(unit, nchunk, ck);
+        if (LF) {
+            if (tap != lf_tap) {   // wave-uniform
+                lf_tap = tap;
+                int ti, tj, tk;
+                tap_decode(tap, p.kw, p.kh, ti, tj, tk);
+                const int zd = d0 + ti * p.dd - p.pd, zh = h0 + tj * p.dh - p.ph, zw = w0 + tk * p.dw - p.pw;
+                const bool ok = row_ok & ((unsigned)zd < (unsigned)p.D) & ((unsigned)zh < (unsigned)p.H) & ((unsigned)zw < (unsigned)p.W);
+                const unsigned mine = !ok ? DLKA_OOB : (unsigned)((b * p.N + (zd * p.H + zh) * p.W + zw) * p.Cin) * 4u;   // row i = lane & 31 (both half-waves agree)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lf_ro[e] = (unsigned)__shfl((int)mine, 8 * e + rg);
+            }
+            const unsigned cb = (unsigned)(ck * 32 + 4 * pc) * 4u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {   // the raw pieces ride in the ring as 16 floats: [4 e .. 4 e + 3] = the 16 bytes of row 8 e + rg, piece pc
+                const f32x4 t = buf_load_f32x4(rin, lf_ro[e] == DLKA_OOB ? DLKA_OOB : lf_ro[e] + cb);
+                ad[4 * e] = t[0]; ad[4 * e + 1] = t[1]; ad[4 * e + 2] = t[2]; ad[4 * e + 3] = t[3];
+            }
+        } else
         arow.fetch(p, rin, tap, ck, h, row_ok, b, v, d0, h0, w0, ad);
         const unsigned ub = (unsigned)unit * unit_bytes + blane;
 #pragma unroll
@@ -74,7 +103,21 @@ __global__ __launch_bounds__(64 * KW) void cl_conv_kw_kernel(IgemmArgs p)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) bd[(part * 2 + mf) * NT + t] = buf_load_f32x4(rw, ub + (unsigned)((part * 2 + mf) * 2) * seg_bytes + (unsigned)t * 512u);
     };
-    auto compute = [&](const float *a_cur, const f32x4 *b_cur) {
+    auto compute = [&](const float *a_raw, const f32x4 *b_cur) {
+        float a_lf[16];
+        if (LF) {   // pieces -> wave-private tile -> this lane's 16 A values (LDS operations of one wave execute in order: a fence for the compiler is all it takes)
+            float *At = Red[wave];
+            wave_sync();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x4 *>(At + (8 * e + rg) * AROW + 4 * pc) = f32x4{a_raw[4 * e], a_raw[4 * e + 1], a_raw[4 * e + 2], a_raw[4 * e + 3]};
+            wave_sync();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(At + i * AROW + 16 * h + 4 * e);
+                a_lf[4 * e] = t[0]; a_lf[4 * e + 1] = t[1]; a_lf[4 * e + 2] = t[2]; a_lf[4 * e + 3] = t[3];
+            }
+        }
+        const float *a_cur = LF ? a_lf : a_raw;
 #pragma unroll
         for (int mf = 0; mf < 2; ++mf) {
             if (SPLIT == 3) {   // three-term operands, the six products above 2^-24: fp32-equivalent (cl_igemm.hip) — the FORWARD offset conv, whose output feeds floor()
@@ -119,6 +162,7 @@ __global__ __launch_bounds__(64 * KW) void cl_conv_kw_kernel(IgemmArgs p)
 
     // ---- the waves' partial tiles meet in LDS and are summed in WAVE ORDER (D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) ----
     float *mine = Red[wave];
+    wave_sync();   // (LF: the wave's A tile, in the same LDS, has been read)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if (t) __syncthreads();   // the previous tile has been read

@@ -2,7 +2,7 @@
 // reference's dispatch (AT_DISPATCH_FLOATING_TYPES = float, double: 3D/dcn/src/cuda/deform_conv_cuda.cu:96,233; the reference imports gradcheck, 3D/dcn/test.py:9).
 // General NCDHW layout only, any kernel size / stride / padding / dilation / groups / deformable groups; every value, weight, coordinate and accumulator is a double.
 // Not a fast path — one work-item per output element, the contraction in a loop — its purpose is numerical: torch.autograd.gradcheck runs THROUGH the product, and the
-// reference's own op compiled for double (oracle/_ref/D3D.so) is matched to ~1e-12 (tests/test_f64_gpu.py).
+// reference's own op compiled for double is matched to ~1e-12 (tests/test_f64_gpu.py).
 //
 // The sampling rule is deform_sample.h's, restated in double (the coordinate is formed as double(int base) + offset: the reference's `scalar_t` arithmetic,
 // deform_im2col_cuda.cuh:244-247,26-72 with scalar_t = double):
