@@ -814,7 +814,7 @@ def main(harness=None):
     stack = DLKABlockStack(args.batch, device=dev, dtype=dtype, seed=1234, data_seed=4321 + rank, **({"stages": harness["stages"]} if EMU else {}))
     # Synthetic grad_outputs (N(0,1), no loss behind them) make the block gradients huge; a training-sized step would blow
     # the parameters up within a few iterations (offsets -> inf/NaN, every sample dropped, kernels get FASTER: observed,
-    # profiles/r01i).  The SGD update is executed in full but with a step small enough that the data distribution the
+    # profiles/archive/r01i).  The SGD update is executed in full but with a step small enough that the data distribution the
     # kernels see (offset std ~ 1 voxel) is the same in the last timed step as in the first; checked after the run.
     lr = 1e-12
 

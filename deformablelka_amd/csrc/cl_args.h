@@ -5,7 +5,7 @@
 namespace dlka {
 
 // Several zero fills in one launch (every dependent kernel node costs ~4.5 us of dispatch latency inside a hipGraph on
-// MI355X, profiles/r01n): regions are 16-byte aligned float arrays.
+// MI355X, profiles/archive/r01n): regions are 16-byte aligned float arrays.
 struct ZeroBatch {
     int n;
     float *p[8];

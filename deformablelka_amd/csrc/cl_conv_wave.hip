@@ -5,7 +5,7 @@
 // cl_igemm_kernel shares each 32 x NP weight chunk among the 4 waves of a workgroup through LDS: one barrier per (tap, chunk)
 // unit.  With split operands a unit is only 6..36 MFMAs of 32 cycles, and the measured profile of those launches was per-unit
 // latency, not arithmetic (offset-conv data gradient at 32^3: matrix cores 15 % busy, 30 % of wave cycles waiting, 87 us;
-// profiles/r01u_pmc_offc.txt).  Here every wave runs alone: its B operand comes straight from the L2-resident prepared weights —
+// profiles/archive/r01u_pmc_offc.txt).  Here every wave runs alone: its B operand comes straight from the L2-resident prepared weights —
 // the split layout stores, per (unit, part, mf, h), NP records of 8 bf16, i.e. exactly one 16-byte load per MFMA B operand —
 // and the A rows and B records of unit u+1 are in flight while unit u computes.  No LDS in the main loop, no barrier anywhere.
 #include <stdlib.h>
@@ -198,7 +198,7 @@ int launch_cl_conv_wave(int amode, int omode, const IgemmArgs &a, int splits, hi
     int NT = 1, DEPTH = 2;
     if (cfg) { NT = cfg / 10; DEPTH = cfg % 10; }
     else {
-        // Measured (profiles/r01w_conv_wave_cfg.txt, us, this kernel vs cl_igemm_kernel): offset conv forward (three-term, 96 columns) 128 vs 81 at
+        // Measured (profiles/archive/r01w_conv_wave_cfg.txt, us, this kernel vs cl_igemm_kernel): offset conv forward (three-term, 96 columns) 128 vs 81 at
         // C=32/32^3 — one column tile per wave re-reads the A rows three times through the "lane = row" loads, which cost one L1 access per row —
         // but 46 vs 52 at C=64/16^3 and 28 vs 39 at C=128/8^3; data gradient (two-term) 88 vs 104 at C=32/32^3, equal elsewhere.  A deeper
         // register ring (3 stages) changed nothing: these launches are not waiting on latency.

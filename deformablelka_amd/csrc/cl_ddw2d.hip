@@ -189,10 +189,10 @@ __global__ __launch_bounds__(256) void cl_ddw2d_bwd_kernel(Ddw2dArgs p)
 
 // grad_input of the depthwise deformable conv:  gx[b][v][c] = sum over (pixel o, tap) whose sample touches v of  G[o][c] w[c][tap] wt_v.
 // The reference (torchvision deformable_col2im) issues one global fp32 atomicAdd per (pixel, tap, channel, corner); measured here the same
-// scheme in channels-last layout costs 12 ms at C = 96 / 56^2 / B = 24 (1.4e9 atomics on heavily shared rows, profiles/r03e).  As in the
+// scheme in channels-last layout costs 12 ms at C = 96 / 56^2 / B = 24 (1.4e9 atomics on heavily shared rows, profiles/archive/r03e).  As in the
 // 3-D block (cl_deform_bwd2.hip) the scatter therefore goes into an LDS window first: a workgroup owns a tile of OUTPUT pixels and a
 // 4-channel slice, its window = the tile plus the kernel reach plus a 3-pixel offset margin, clipped to the image, in fp64 cells —
-// ds_add_f64 is the fast LDS atomic on gfx950 (6.8 lanes/clk/CU against 0.33 for ds_add_f32, profiles/r01e) and makes the sum
+// ds_add_f64 is the fast LDS atomic on gfx950 (6.8 lanes/clk/CU against 0.33 for ds_add_f32, profiles/archive/r01e) and makes the sum
 // order-independent.  Corners beyond the window (|offset| > 3 pixels outside the reach) go straight to global atomics; the window is
 // flushed with one fp32 atomic per non-zero (cell, channel).
 constexpr int GX2_CS = 4;        // channels per slice

@@ -4,7 +4,7 @@
 // 27*C x B*N buffer in HBM), deformable_col2im_coord_gpu_kernel (grad_offset, deform_im2col_cuda.cuh:336-405) and
 // deformable_col2im_gpu_kernel (grad_input, cuh:267-334: one global fp32 atomicAdd per column element and corner).
 //
-// Measured on MI355X (profiles/r01d_accum_ubench.txt): global fp32 atomics top out at ~3.3e11 lane-atomics/s whatever
+// Measured on MI355X (profiles/archive/r01d_accum_ubench.txt): global fp32 atomics top out at ~3.3e11 lane-atomics/s whatever
 // the locality (1.0-1.6 ms for the 4.5e8 corner updates of one C=32, 32^3, B=2 call), LDS *fp32* atomics (ds_add_f32)
 // are no faster (0.33 lanes/clk/CU), but LDS *fp64* atomics (ds_add_f64) run at 6.7 lanes/clk/CU — 20x.  Hence:
 //
@@ -595,7 +595,7 @@ struct GxGeom {
 
 // MFMA row t8 of tap group grp <-> tap.  The two half-waves scatter rows t8 = 2*r4 and 2*r4 + 1 in the same instruction; with consecutive
 // taps there (tk, tk + 1) lane (j, 1) and lane (j + 1, 0) aim at the SAME window cell whenever their offsets floor alike — the
-// "consecutive + 0/1 jitter" pattern that costs 21 instead of 9.4 cycles per ds_add_f64 in isolation (profiles/r01e_lds_f64_patterns.txt).
+// "consecutive + 0/1 jitter" pattern that costs 21 instead of 9.4 cycles per ds_add_f64 in isolation (profiles/archive/r01e_lds_f64_patterns.txt).
 // tap_far pairs tap x with tap x + 16 instead (another d-plane of the window).  In the real kernel it did NOT pay (390 vs 370 us at 32^3):
 // the LDS unit serves the half-waves in separate passes, and neighbouring taps share offset / window cache lines.  Kept as an A/B knob.
 __device__ __host__ __forceinline__ int gx_tap(int grp, int t8, int tap_far)
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
     if (gg.resident) {
         // all tap groups' weights stay in LDS: a tile's grad_out rows are loaded ONCE (registers) for its 4 groups and the
         // main loop has no workgroup barrier.  (Measured before: grad_out re-read per group and slice = 377 MB of L2->HBM
-        // traffic against 8 MB of data, profiles/r01j_pmc.)
+        // traffic against 8 MB of data, profiles/archive/r01j_pmc.)
         for (int grp = 0; grp < gg.ngroups; ++grp) stage_weights(grp, Bs + (size_t)grp * p.CoutP * 32);
         if (FX && tid < 2) smax[tid] = 0u;
         __syncthreads();   // also: window zeroed
@@ -1355,7 +1355,7 @@ size_t cl_deform_bwd2_scratch_floats(const DeformBwdArgs &a)
 }
 
 // Slices of the input-channel chunks for grad_offset.  At C = 256 / 4^3 the (voxel-block, tap) grid is 27 workgroups, each
-// running 64 chunk GEMMs in sequence (82 us, profiles/r01n); slicing the channel chunks brings it to ~216 workgroups.
+// running 64 chunk GEMMs in sequence (82 us, profiles/archive/r01n); slicing the channel chunks brings it to ~216 workgroups.
 int cl_deform_goff_ccsplit(const DeformBwdArgs &a)
 {
     const int mblocks = cdiv(a.M, 128);

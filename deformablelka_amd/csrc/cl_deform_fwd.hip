@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void cl_deform_fwd_kernel(IgemmArgs p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 16-row waves (round 3).  The kernel above is latency-bound at 2 waves per SIMD (profiles/r03p_pmc_issue_wait_stage0_f32.txt: an instruction of
+// 16-row waves (round 3).  The kernel above is latency-bound at 2 waves per SIMD (profiles/archive/r03p_pmc_issue_wait_stage0_f32.txt: an instruction of
 // any kind issues in 37 % of the resident wave-cycles): 128 VGPRs of corner pieces in flight per 32-row wave, and a 32-row tile count that gives
 // the chip exactly two waves per SIMD at stage 0 (65 536 rows / 32 = 2048 waves on 1024 SIMDs).  Here a wave owns 16 rows: half the corner pieces
 // (64 VGPRs), v_mfma_f32_16x16x4_f32 (same FLOP rate as 32x32x2, MI355X_MICROARCH.md), twice the waves — 4 per SIMD under the 128-register budget.
@@ -535,7 +535,7 @@ int launch_cl_deform_fwd(IgemmArgs a, int splits, hipStream_t st)
     if (NT_total == 8) NT = 4;
     else if (NT_total == 3 || NT_total > 4) return DLKA_ERR_UNSUPPORTED;
     // small volumes: fewer column tiles per workgroup (-> more workgroups) beats not repeating the gather
-    // (C=256 / 4^3: 57.8 -> 36.0 us with NT = 1; C=128 / 8^3: 47.6 -> 41.0 us with NT = 2; profiles/r01s_dfwd_tuning.txt)
+    // (C=256 / 4^3: 57.8 -> 36.0 us with NT = 1; C=128 / 8^3: 47.6 -> 41.0 us with NT = 2; profiles/archive/r01s_dfwd_tuning.txt)
     if (a.M <= 256) NT = 1;
     else if (a.M <= 2048 && NT_total == 4) NT = 2;
     constexpr int nt_env = 0;

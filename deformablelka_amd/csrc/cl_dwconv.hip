@@ -6,7 +6,7 @@
 // work-item owns TW consecutive outputs along W and slides the KW taps over one input row segment held in registers
 // (TW + (KW-1)*DIL loads feed TW*KW FMAs).  Same kernel = forward and data gradient (flipped taps, no bias).
 // (A row-tiled variant — TH output rows spaced DIL apart per work-item, 5 FMA per load instead of 2.15 — was measured SLOWER
-// (72.9 vs 65.5 us at C=32 / 32^3, profiles/r01o_dw_variants.txt): the kernel is bound by instruction issue with too few waves to
+// (72.9 vs 65.5 us at C=32 / 32^3, profiles/archive/r01o_dw_variants.txt): the kernel is bound by instruction issue with too few waves to
 // hide latency, not by the L1 request rate, and bigger per-thread tiles leave ~1 wave per SIMD.)
 #include <stdlib.h>
 
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void cl_dwconv_wgrad_kernel(DwWgradArgs p)
 // over input rows (b, zd, zh); the row segment it loads (SEG values) meets the KH grad_output rows (zd - i*dd + pd, zh - j*dh + ph)
 // that pair with it, KH*KW accumulators in registers: SEG + KH*TW loads feed KH*KW*TW FMAs (4.8 FMA per load for 7^3 dil 3, against
 // 1.65 in the first version, which re-read the input segment for every (i, j) — that kernel was bound by the L1 request rate:
-// 177 us at C=32 / 32^3, profiles/r01n).  grid.y = kd.  The bias gradient rides on the (i, j) = centre-tap pairing, which visits every
+// 177 us at C=32 / 32^3, profiles/archive/r01n).  grid.y = kd.  The bias gradient rides on the (i, j) = centre-tap pairing, which visits every
 // grad_output element exactly once.
 template <typename T, int KW, int DIL, int TW>
 __global__ __launch_bounds__(256) void cl_dwconv_wgrad2_kernel(DwWgradArgs p)
@@ -706,7 +706,7 @@ static int launch_cl_dwconv_wgrad_t(DwWgradArgs a, int kw, int dil_w, hipStream_
     static int xb_env = -1;
     if (xb_env < 0) xb_env = 0;
     // row-chunks: bounded atomics, enough waves to hide latency.  64 chunks, 128 for the large volumes (measured on the block graph:
-    // 1.515 -> 1.462 ms at 32^3 with 128, no change at 16^3, 256 worse at 16^3; profiles/r01p)
+    // 1.515 -> 1.462 ms at 32^3 with 128, no change at 16^3, 256 worse at 16^3; profiles/archive/r01p)
     const int xb_want = xb_env ? xb_env : (rows >= 1024 ? 128 : 64);
     int xb = rows < xb_want ? rows : xb_want;
     a.rows_per_block = cdiv(rows, xb);
@@ -718,8 +718,8 @@ static int launch_cl_dwconv_wgrad_t(DwWgradArgs a, int kw, int dil_w, hipStream_
     constexpr bool v1 = false;
     // the centre tap row must exist for the bias ride-along (odd kernels with "same" padding: always)
     const bool centre = (a.pd % a.dd == 0) && (a.ph % a.dh == 0) && a.pd / a.dd < a.kd && a.ph / a.dh < a.kh;
-    // measured (profiles/r01o_dw_variants.txt): 7^3 dil 3 178 -> 103 us at 32^3, 38 -> 36 us at 16^3; 5^3 72 -> 66 us at 32^3 but 23.5 -> 26 us at 16^3
-    // with row descriptors (profiles/r01y_dww_rows.txt, us, new vs first generation): 7^3 dil 3: 55 vs 188 at 32^3, 31 vs 39 at 16^3, 22 vs 18 at 8^3;
+    // measured (profiles/archive/r01o_dw_variants.txt): 7^3 dil 3 178 -> 103 us at 32^3, 38 -> 36 us at 16^3; 5^3 72 -> 66 us at 32^3 but 23.5 -> 26 us at 16^3
+    // with row descriptors (profiles/archive/r01y_dww_rows.txt, us, new vs first generation): 7^3 dil 3: 55 vs 188 at 32^3, 31 vs 39 at 16^3, 22 vs 18 at 8^3;
     // 5^3: 38 vs 69 at 32^3, equal below
     const bool pays = kw >= 7 ? rows >= 512 : rows >= 1024;
     const int wpr = cpb < 64 ? 64 / cpb : 1;                       // runs per wave: must not straddle rows (row descriptors)

@@ -1,6 +1,6 @@
 // Trilinear gather of channels-last volumes with a line-friendly lane layout.
 //
-// Measured (profiles/r01g_gather_layout_ubench.txt): the vector-memory front end charges per cache line touched per
+// Measured (profiles/archive/r01g_gather_layout_ubench.txt): the vector-memory front end charges per cache line touched per
 // instruction.  A wave that loads "lane = (row i of 32, half h): 64 bytes of row i" touches 32 rows per instruction and
 // gathers at 9.6 TB/s; "lane = (row r of 8, piece p of 8): 16 bytes" covers 8 WHOLE 128-byte rows per instruction and
 // gathers at 33 TB/s.  The deformable kernels therefore gather in the second layout and transpose through LDS into
@@ -140,7 +140,7 @@ __device__ __forceinline__ RowLook gather_lookup_w(const float *tab, int row, fl
 // Lane layout of the gather, by activation storage type.  fp32: a 32-channel chunk of a row is 128 bytes — lane = (row of 8, 16-byte piece
 // of 8), four row groups cover a 32-row tile.  bf16: the chunk is 64 bytes — lane = (row of 16, 16-byte piece of 4), two row groups; the
 // per-lane load is still 16 bytes (8 channels), so a 32-row tile takes HALF the load instructions (8-byte loads in the fp32 layout were
-// measured slower than fp32 itself: 117 vs 102 us for the stage-0 forward, profiles/r03c).
+// measured slower than fp32 itself: 117 vs 102 us for the stage-0 forward, profiles/archive/r03c).
 template <typename T> struct GatherGeom { static constexpr int NG = 4, RPI = 8, PE = 4, PSHIFT = 3; };
 template <> struct GatherGeom<bf16_t> { static constexpr int NG = 2, RPI = 16, PE = 8, PSHIFT = 2; };
 // What one lane holds of one corner row: fp32 = 4 channels; bf16 = 8 channels as the four RAW 32-bit words the load returned — converted

@@ -494,12 +494,12 @@ int cl_igemm_pick_splits(int M, int units, int epi, int K)
 {
     if ((epi != 0 && epi != 3) || units == 1) return 1;   // epilogues 0 and 3 are linear in the accumulator: splittable
     // pointwise convs (K = 1) have C/32 <= 8 units: splitting 2 or 4 ways buys nothing that pays for the zero fill + atomics
-    // (C = 64 / 16^3: 24.6 us split vs 11.8 us unsplit for the same GEMM, profiles/r01n); they run unsplit on cl_pointwise.hip
+    // (C = 64 / 16^3: 24.6 us split vs 11.8 us unsplit for the same GEMM, profiles/archive/r01n); they run unsplit on cl_pointwise.hip
     static int pw_min = -1;
     if (pw_min < 0) pw_min = 99;
     if (K == 1 && units < pw_min) return 1;
     const int mblocks = cdiv(M, 128);
-    // Split partial sums meet in global fp32 atomics on the SAME addresses: measured on MI355X (profiles/r01e), 216-way
+    // Split partial sums meet in global fp32 atomics on the SAME addresses: measured on MI355X (profiles/archive/r01e), 216-way
     // splits of the C=256 / 4^3 offset conv cost 130 us, almost all of it same-address serialisation in L2.  Bound the
     // contention instead of chasing block count.
     static int cap = -1;

@@ -4,7 +4,7 @@
 // The general implicit-GEMM kernel (cl_igemm.hip) tiles 128 rows x all columns per workgroup and walks the C/32 channel chunks
 // one after the other with a one-deep prefetch: right for 27-tap convs, wrong for K = 1, where the whole contraction is 1..8 chunks.
 // At the small stages that left a handful of workgroups on the chip, each paying one global-load latency per chunk in sequence
-// (C = 256 / 4^3: 21.7 us for a 128 x 256 x 256 GEMM; C = 64 / 16^3: 64 workgroups on 256 CUs; profiles/r01n).  Here one wave
+// (C = 256 / 4^3: 21.7 us for a 128 x 256 x 256 GEMM; C = 64 / 16^3: 64 workgroups on 256 CUs; profiles/archive/r01n).  Here one wave
 // owns a 32 x 32 output tile, issues the loads of up to four chunks back to back (A rows straight from the token tensor, B from the
 // L2-resident prepared weights, both already in MFMA operand order), and runs its MFMAs when they land: grid = (M/32) x (C/32) waves.
 #include "cl_args.h"

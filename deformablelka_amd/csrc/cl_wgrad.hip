@@ -408,7 +408,7 @@ __device__ __forceinline__ void wgrad_dense_body(const WgradArgs &p, const int b
             // them the whole tap's validity in d and h — are common to the 16 rows, only w = w_ + s moves, and only s = 0 / s = 15 can
             // step over the row's ends.  One select per tap, two edge selects and one add per row instead of ~12 VALU instructions per
             // (tap, row).  (The general decode below was half of this kernel's VALU time,
-            // and the kernel is VALU-bound: matrix cores 17 % busy, profiles/r01u_pmc_offc.txt.)
+            // and the kernel is VALU-bound: matrix cores 17 % busy, profiles/archive/r01u_pmc_offc.txt.)
             const int w_ = v0 % p.W, hh = (v0 / p.W) % p.H, d_ = v0 / (p.W * p.H);
             const unsigned base = (mrow0 < m_hi) ? (unsigned)((b0 * p.N + v0) * p.Cin + ci) * XB : DLKA_OOB;
             const unsigned rs = (unsigned)p.Cin * XB;
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64) void cl_wgrad_pw3_kernel(WgradArgs3 b)
 // gW[co][ci][tap] (reference layout, storage type T) = sum_chunk part[chunk][tap][co][ci];  gb[co] = sum_chunk bpart[chunk][co]
 // A workgroup folds 32 consecutive outputs: thread (e = tid & 31, cl = tid >> 5) sums chunks cl, cl+8, ... (coalesced
 // 128-byte reads per chunk), the 8 partial sums meet in LDS.  (The first version gave one thread all 128 chunks of an
-// output: 40 us for the 1024 outputs of a pointwise conv, pure dependent-load latency; profiles/r01e.)
+// output: 40 us for the 1024 outputs of a pointwise conv, pure dependent-load latency; profiles/archive/r01e.)
 template <typename T>
 __global__ __launch_bounds__(256) void cl_wgrad_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bpart, T *__restrict__ gw, T *__restrict__ gb,
                                                               int chunks, int K, int CoutP, int Cout, int Cin)
@@ -891,7 +891,7 @@ __device__ __forceinline__ void wgrad_finalize_body(const FinalizeJob &jb, const
         // Few partials, many outputs (the small stages: 27 x 256 x 256 weights, 3 partials): a workgroup owns (co, 32 ci, all K taps).
         // Reads stay 128-byte rows of the [tap][co][ci] partial tiles; the K x 32 results are re-laid through LDS and leave as ONE
         // contiguous run of 32*K floats of gW[co][ci][tap] — the element-per-lane version wrote 4-byte pieces K*4 bytes apart
-        // (67 us for the C = 256 block, profiles/r01n).
+        // (67 us for the C = 256 block, profiles/archive/r01n).
         __shared__ float tile[32 * 28];   // [ci][tap], K <= 27 (+1 padding)
         const int cblocks = jb.Cin / 32;
         const long wblocks = (long)jb.Cout * cblocks;
@@ -927,7 +927,7 @@ __device__ __forceinline__ void wgrad_finalize_body(const FinalizeJob &jb, const
         const float *src = jb.part + ((long)tap * jb.CoutP + co) * jb.Cin + ci;
         int c = cl;
         // 8 independent loads in flight per work-item: with 2048 partials per output (pointwise convs at 32^3) the fold is a
-        // chain of dependent-latency loads otherwise (133 us for the stage-0 batch with two chains, profiles/r01n)
+        // chain of dependent-latency loads otherwise (133 us for the stage-0 batch with two chains, profiles/archive/r01n)
         float a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
         for (; c + 56 < jb.chunks; c += 64) {
             a0 += src[(long)c * stride]; a1 += src[(long)(c + 8) * stride]; a2 += src[(long)(c + 16) * stride]; a3 += src[(long)(c + 24) * stride];

@@ -481,7 +481,7 @@ int pointwise_pair(const SameConv &s, int bwd, const float *in, const float *wp1
                    const float *a, const float *b, float *out1, float *out1b, float *out2, hipStream_t st, const ZeroBatch *ride = nullptr)
 {
     const bool unfused = getenv("DLKA_PW_UNFUSED") != nullptr;   // (not cached: a parity test toggles it)
-    // (C = 64 exists in the kernel but loses: 26 us against 2 x 7.7 + 4.5 us at 16^3 — M / 32 = 256 waves are too few; profiles/r03n notes)
+    // (C = 64 exists in the kernel but loses: 26 us against 2 x 7.7 + 4.5 us at 16^3 — M / 32 = 256 waves are too few; profiles/archive/r03n notes)
     if (unfused || s.Cin != 32 || s.Cin != s.Cout || s.K != 1) return DLKA_ERR_UNSUPPORTED;
     PwPairArgs pa;
     memset(&pa, 0, sizeof(pa));
@@ -1808,7 +1808,7 @@ int tokens_backward_impl(const void *x_, const dlka_lka3d_params *p, const void 
     {
         DeformBwdArgs da;
         fill_deform_bwd(da, G.dcn);
-        // Measured with the workgroup-tiled consumers (profiles/r01v): no gain — they are bound by per-unit latency (barrier + staging per
+        // Measured with the workgroup-tiled consumers (profiles/archive/r01v): no gain — they are bound by per-unit latency (barrier + staging per
         // 192 MFMA cycles), not by the split arithmetic (grad_offset +14 us, weight gradient +18 us, data gradient unchanged at 32^3) — so the
         // packed hand-over is opt-in (DLKA_GOFF_PACKED=1) until the consumers are wave-granular.
         const bool fp32_goff = bf || getenv("DLKA_GOFF_PACKED") == nullptr;   // (not cached: tests toggle it)

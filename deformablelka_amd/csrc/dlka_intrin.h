@@ -234,7 +234,7 @@ __device__ __forceinline__ float bf16_value(unsigned short h) { return __builtin
 // hardware range check returns 0 for offsets >= the buffer size.  The gather kernels use that for zero padding and for
 // corners outside the volume: the offset of a dropped element is DLKA_OOB, so every load is unconditional — no branch
 // around it, no select after it, and the loads of the next tile stay in flight under the MFMAs of the current one
-// (a conditional load compiles to s_cbranch + s_waitcnt vmcnt(0) per element; measured in profiles/r01g).
+// (a conditional load compiles to s_cbranch + s_waitcnt vmcnt(0) per element; measured in profiles/archive/r01g).
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // a value the caller guarantees to be equal in all active lanes of the wave: into a scalar register, so that pointers / buffer
 // descriptors derived from it are built by the scalar unit

@@ -51,7 +51,7 @@ class Convolution(nn.Sequential):
     """``monai.networks.blocks.Convolution(..., conv_only=True)``: a Sequential with ONE child named ``conv`` (the parameters live there, so
     the ``state_dict`` keys are the reference's).
 
-    On the GPU in fp32 the forward does not call MIOpen: measured on the MI355X (scripts/probe_miopen_conv3d.py, profiles/r03f) its fp32 3-D
+    On the GPU in fp32 the forward does not call MIOpen: measured on the MI355X (scripts/probe_miopen_conv3d.py, profiles/archive/r03f) its fp32 3-D
     paths cost 320 ms for ONE 3x3x3 16 -> 16 conv fwd+bwd at 2 x 64x128x128 (weight gradient) and 10 ms for the (2,4,4) transposed conv — a
     1.03 s training step of which the 21 D-LKA blocks are 24 ms.  The four shapes the net uses are instead computed as
       * kernel == stride, no padding (stem, down-sampling):       patchify + one GEMM,

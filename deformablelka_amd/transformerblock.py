@@ -255,7 +255,7 @@ class _TBlock3dFn(Function):
         else:
             gx, tg, lg = ops.tblock3d_backward(tparams, lka_params, drop_mask, training, bn_stats, gy, saved, dims, variant, lka_bf16)
         if x_planar:   # gradient w.r.t. the NCDHW input: tokens -> NCDHW.  A contiguous tensor, not the permuted view: the producer of x is a
-            # torch layer whose backward (MIOpen) falls to its naive "nonpacked" kernels on a strided grad_output (profiles/r03e: 61 % of a
+            # torch layer whose backward (MIOpen) falls to its naive "nonpacked" kernels on a strided grad_output (profiles/archive/r03e: 61 % of a
             # full-net step)
             B, C = xshape[0], xshape[1]
             gx = ops.ndhwc_to_ncdhw(gx.view(B, *xshape[2:], C))

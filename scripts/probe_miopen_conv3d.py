@@ -1,4 +1,4 @@
-"""Which kernels does torch/MIOpen pick for the fp32 3-D convs of the D_LKA_Former plumbing?  (profiles/r03f: naive 'nonpacked' kernels = 61 % of a step)"""
+"""Which kernels does torch/MIOpen pick for the fp32 3-D convs of the D_LKA_Former plumbing?  (profiles/archive/r03f: naive 'nonpacked' kernels = 61 % of a step)"""
 import sys
 import time
 import torch
