@@ -31,10 +31,11 @@ if [ "${SKIP_PROFILES:-0}" = 1 ]; then   # (block-stack kernels unchanged since 
 fi
 cd /tmp
 echo "== rocprof of the bench command (as timed: the weight gradients of a block overlap the next block's data chain on a second stream — concurrent kernels stretch each other)"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bench -o t -- python $R/bench.py --no-cpu-baseline --no-tblock --no-companion --no-lka2d > $R/$OUT/prof_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bench -o t -- python $R/bench.py --no-cpu-baseline --no-tblock --no-companion --no-lka2d --no-fullnet > $R/$OUT/prof_bench.log 2>&1
 F=$(find $R/$OUT/prof_bench -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" $R/$OUT/bench_kernel_stats.csv && head -6 $R/$OUT/bench_kernel_stats.csv | cut -c1-150
 echo "== rocprof of the bench command on ONE stream (DLKA_STACK_WGRAD_OVERLAP=0): the per-kernel durations the roofline block's launch trace must agree with"
-DLKA_STACK_WGRAD_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bench1 -o t -- python $R/bench.py --no-cpu-baseline --no-tblock --no-companion --no-lka2d > $R/$OUT/prof_bench1.log 2>&1
+# (no library-internal forks either, and none of the companion metrics: the nn.Module / full-net loops run the same kernels beside their own side-stream work, which would stretch the averages)
+DLKA_STACK_WGRAD_OVERLAP=0 DLKA_GX_FORK_MIN_ROWS=1000000000 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bench1 -o t -- python $R/bench.py --no-cpu-baseline --no-tblock --no-companion --no-lka2d --no-fullnet --no-roofline > $R/$OUT/prof_bench1.log 2>&1
 F=$(find $R/$OUT/prof_bench1 -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" $R/$OUT/bench_one_stream_kernel_stats.csv && head -6 $R/$OUT/bench_one_stream_kernel_stats.csv | cut -c1-150
 export DLKA_STACK_WGRAD_OVERLAP=0   # (one block per stage below: nothing to overlap with)
 for dt in f32 bf16; do for s in 0 1 2 3; do
@@ -44,6 +45,6 @@ for dt in f32 bf16; do for s in 0 1 2 3; do
 done; done
 cd $R; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete; du -sh $OUT
 echo "== PMC traffic per kernel of the stage-0 / stage-1 blocks (fp32), stage 0 bf16"
-ROUND=${ROUND:-r04} bash scripts/pmc_block.sh $TAG/pmcb "0 1" "f32" > $OUT/pmc_block.log 2>&1; tail -14 $OUT/pmc_block.log
-ROUND=${ROUND:-r04} bash scripts/pmc_block.sh $TAG/pmcb_bf16 "0" "bf16" > $OUT/pmc_block_bf16.log 2>&1; tail -5 $OUT/pmc_block_bf16.log
+ROUND=${ROUND:-r10} bash scripts/pmc_block.sh $TAG/pmcb "0 1" "f32" > $OUT/pmc_block.log 2>&1; tail -14 $OUT/pmc_block.log
+ROUND=${ROUND:-r10} bash scripts/pmc_block.sh $TAG/pmcb_bf16 "0" "bf16" > $OUT/pmc_block_bf16.log 2>&1; tail -5 $OUT/pmc_block_bf16.log
 du -sh $OUT
