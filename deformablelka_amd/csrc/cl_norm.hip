@@ -559,6 +559,67 @@ __global__ __launch_bounds__(NT) void cl_bn_stats_q_kernel(const float *__restri
     quad_fold<2>(red, acc, q, C, dst);
 }
 
+// DETERMINISTIC batch statistics (round 6): the same row walk, but the threads' partial sums meet in LDS in ROW-GROUP ORDER (no LDS atomics) and the workgroup writes its 2C sums
+// to part[blockIdx.x][2C] (no global atomics, no zero fill); cl_bn_finish_stats_det_kernel adds the workgroups' partials in workgroup order.  The wrapper block's training-mode forward
+// is then bitwise reproducible from run to run, as its eval-mode forward and the D-LKA block inside it already are.
+template <int LPR>
+__global__ __launch_bounds__(NT) void cl_bn_stats_det_q_kernel(const float *__restrict__ x, float *__restrict__ part, long M)
+{
+    constexpr int C = 4 * LPR, RPB = NT / LPR;
+    __shared__ __attribute__((aligned(16))) float red[RPB][2 * C];
+    const int q = threadIdx.x % LPR, r = threadIdx.x / LPR;
+    const f32x4 pv = act_load4(x, 4 * q);
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int step = gridDim.x * RPB, Mi = (int)M;
+    int m = blockIdx.x * RPB + r;
+    for (; (long)m + 3l * step < M; m += 4 * step) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = act_load4(x, (long)(m + u * step) * C + 4 * q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[u][e] - pv[e]; acc[0][e] += d; acc[1][e] = fmaf(d, d, acc[1][e]); }
+    }
+    for (; m < Mi; m += step) {
+        const f32x4 v = act_load4(x, (long)m * C + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[e] - pv[e]; acc[0][e] += d; acc[1][e] = fmaf(d, d, acc[1][e]); }
+    }
+    *reinterpret_cast<f32x4 *>(&red[r][4 * q]) = acc[0];
+    *reinterpret_cast<f32x4 *>(&red[r][C + 4 * q]) = acc[1];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += NT) {
+        float t = 0.f;
+        for (int rr = 0; rr < RPB; ++rr) t += red[rr][c];   // fixed order
+        part[(long)blockIdx.x * 2 * C + c] = t;
+    }
+}
+
+// 256 threads = 32 channels x 8 partial groups: group g adds the workgroup partials g, g + 8, ... in that order, the eight group sums meet in LDS and are added in group order —
+// a fixed summation tree, eight loads in flight per channel instead of one dependent chain over all partials (a single thread per channel measured 2.5 % on the wrapper-block stack)
+__global__ __launch_bounds__(256) void cl_bn_finish_stats_det_kernel(const float *__restrict__ x, const float *__restrict__ part, int nparts, float *__restrict__ stats, long M, int C,
+                                                                     float eps)
+{
+    __shared__ float red[8][64];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C)
+        for (int w = g; w < nparts; w += 8) { s1 += part[(long)w * 2 * C + c]; s2 += part[(long)w * 2 * C + C + c]; }
+    red[g][cl] = s1;
+    red[g][32 + cl] = s2;
+    __syncthreads();
+    if (g != 0 || c >= C) return;
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1 += red[k][cl]; s2 += red[k][32 + cl]; }
+    const float dm = s1 / (float)M;
+    const float var = fmaxf(s2 / (float)M - dm * dm, 0.f);
+    stats[c] = x[c] + dm;
+    stats[C + c] = 1.f / sqrtf(var + eps);
+    stats[2 * C + c] = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+}
+
 // y = lrelu((x - mean) * rstd * w + b (+ res)) (* mask[b][c])
 template <int LPR>
 __global__ __launch_bounds__(NT) void cl_bn_apply_q_kernel(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ w,
@@ -735,8 +796,19 @@ int launch_cl_scale_residual_bwd(const float *g, const float *e, const float *ga
 }
 
 // sums: 2C floats of scratch; stats: 3C floats {mean, rstd, unbiased var}
-int launch_cl_bn_stats(const float *x, float *sums, float *stats, long M, int C, float eps, hipStream_t st, bool zeroed)
+int launch_cl_bn_stats(const float *x, float *sums, float *stats, long M, int C, float eps, hipStream_t st, bool zeroed, float *det_part, size_t det_floats)
 {
+    // det_part (optional scratch, det_floats floats): the deterministic form — per-workgroup partial sums added in fixed order, no atomics (round 6)
+    if (det_part && quad_shape_ok(C, M) && quad_aligned(x) && quad_aligned(det_part)) {
+        unsigned nwg = quad_grid(M, C, 8, 256);
+        if ((size_t)nwg * 2 * C <= det_floats) {
+            DLKA_QUAD_DISPATCH(C, cl_bn_stats_det_q_kernel, nwg, x, det_part, M)
+            DLKA_CHECK_LAUNCH();
+            DLKA_LAUNCH(cl_bn_finish_stats_det_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, x, (const float *)det_part, (int)nwg, stats, M, C, eps);
+            DLKA_CHECK_LAUNCH();
+            return DLKA_OK;
+        }
+    }
     if (!zeroed) DLKA_TRY_LAUNCH(launch_zero(sums, (size_t)2 * C * 4, st));
     const int rpb = NT / (C < NT ? C : NT);
     if (quad_shape_ok(C, M) && quad_aligned(x)) {

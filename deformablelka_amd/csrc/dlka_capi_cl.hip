@@ -2195,10 +2195,11 @@ int dlka_tblock3d_forward_v(const void *x, int x_planar, const dlka_tblock3d_par
     DLKA_TRY(launch_cl_scale_residual_fwd(S.xt, S.e, (const float *)p->gamma, S.attn, M, C, st, lo));
     // conv51 = UnetResBlock (dynunet_block.py:66-80)
     DLKA_TRY(dense_forward(G.c3, S.attn, nullptr, nullptr, S.c1, 0, S.w1_f, 0, nullptr, nullptr, st, true));
-    if (training) DLKA_TRY(launch_cl_bn_stats(S.c1, sums, st1, M, C, bn_eps, st, true));
+    // (batch statistics in their deterministic form: the attention's workspace is free again and serves as the per-workgroup partial-sum scratch)
+    if (training) DLKA_TRY(launch_cl_bn_stats(S.c1, sums, st1, M, C, bn_eps, st, true, (float *)lka_ws, lka_ws_bytes / 4));
     DLKA_TRY(launch_cl_bn_apply(S.c1, nullptr, (const float *)p->conv51_norm1_w, (const float *)p->conv51_norm1_b, st1, nullptr, S.a1, M, N, C, slope, st));
     DLKA_TRY(dense_forward(G.c3, S.a1, nullptr, nullptr, S.c2, 0, S.w2_f, 0, nullptr, nullptr, st, true));
-    if (training) DLKA_TRY(launch_cl_bn_stats(S.c2, sums + 512, st2, M, C, bn_eps, st, true));
+    if (training) DLKA_TRY(launch_cl_bn_stats(S.c2, sums + 512, st2, M, C, bn_eps, st, true, (float *)lka_ws, lka_ws_bytes / 4));
     // ... + residual, LeakyReLU, and conv8[0] = Dropout3d folded into the same pass (:611)
     DLKA_TRY(launch_cl_bn_apply(S.c2, S.attn, (const float *)p->conv51_norm2_w, (const float *)p->conv51_norm2_b, st2, (const float *)drop_mask, S.rd, M, N, C, slope, st));
     // x = attn_skip + conv8(attn) (:628)

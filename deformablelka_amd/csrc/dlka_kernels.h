@@ -130,7 +130,7 @@ int launch_cl_layernorm_bwd(const float *g, const float *g_res, const float *xt,
                             float *gpos, int B, int N, int C, hipStream_t st, bool zeroed = false, int lo = 0);
 int launch_cl_scale_residual_fwd(const float *xt, const float *e, const float *gamma, float *out, long M, int C, hipStream_t st, int lo = 0);
 int launch_cl_scale_residual_bwd(const float *g, const float *e, const float *gamma, float *ge, float *ggamma, long M, int C, hipStream_t st, bool zeroed = false, int lo = 0);
-int launch_cl_bn_stats(const float *x, float *sums, float *stats, long M, int C, float eps, hipStream_t st, bool zeroed = false);
+int launch_cl_bn_stats(const float *x, float *sums, float *stats, long M, int C, float eps, hipStream_t st, bool zeroed = false, float *det_part = nullptr, size_t det_floats = 0);
 int launch_cl_bn_apply(const float *x, const float *res, const float *w, const float *b, const float *stats, const float *mask, float *y, long M, long N, int C,
                        float slope, hipStream_t st);
 int launch_cl_bn_bwd(const float *g, const float *gmask, const float *x, const float *y, const float *w, const float *stats, float *sums, float *gx, float *gres,

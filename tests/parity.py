@@ -555,6 +555,41 @@ def check_lka3d_tokens_phased_backward(dev, B, C, dims, dtype=torch.float32, see
         assert float((a_.float() - b_.float()).abs().max()) <= tol * scale, (k, float((a_.float() - b_.float()).abs().max()) / scale)
 
 
+def check_tblock3d_forward_reproducible(dev, B, C, dims, training=True, runs=4, lka_bf16=False):
+    """Round 6: the wrapper block's forward is bitwise reproducible too — also in TRAINING mode, whose BatchNorm batch statistics were fp32 atomic sums until the per-workgroup partial sums
+    were folded in fixed order (cl_bn_stats_det_q_kernel): output, both sets of batch statistics and the activation patterns equal across `runs` identical calls."""
+    import deformablelka_amd as dk
+    from deformablelka_amd import ops
+    from oracle import blocks
+    torch.manual_seed(13)
+    H, W, D = dims
+    m = dk.TransformerBlock_3D_single_deform_LKA(H * W * D, C, C, 4, dropout_rate=0.1, pos_embed=True)
+    blocks.randomize_offsets_(m, std=0.3)
+    with torch.no_grad():
+        m.gamma.normal_(0.5, 0.2)
+    m = m.to(dev).train(training)
+    x = torch.randn(B, H * W * D, C).to(dev)
+    tparams = [None if p is None else p.detach() for p in m.wrapper_params()]
+    lparams = [p.detach() for p in m.epa_block.block_params()]
+    mask = torch.ones(B, C).to(dev)
+    first = None
+    for r in range(runs):
+        stats = torch.zeros(6 * C, dtype=torch.float32).to(dev)
+        if not training:
+            stats[C:2 * C] = 1.0
+            stats[4 * C:5 * C] = 1.0
+        y, saved = ops.tblock3d_forward(x, False, tparams, lparams, mask, training, stats, dims, 1e-5, 1e-5, 0, lka_bf16)
+        # (`saved` itself has alignment gaps of uninitialised memory: compare what it holds — the predicted offsets and the two LeakyReLU activation patterns)
+        cur = (y.clone(), stats.clone(), torch.cat([ops.tblock3d_saved_offsets(saved, B, C, dims, 0, lka_bf16).reshape(-1).clone()] +
+                                                   [t.reshape(-1).float() for t in ops.tblock3d_saved_activation_signs(saved, B, C, dims, 0, lka_bf16)]))
+        if first is None:
+            first = cur
+            continue
+        assert torch.equal(cur[1], first[1]), f"run {r}: batch statistics differ (max {float((cur[1] - first[1]).abs().max()):.3e})"
+        assert torch.equal(cur[0], first[0]), f"run {r}: y differs in {int((cur[0] != first[0]).sum())} elements"
+        assert torch.equal(cur[2], first[2]), f"run {r}: predicted offsets / activation patterns differ in {int((cur[2] != first[2]).sum())} elements"
+
+
 def check_lka3d_tokens_sample_handover(dev, B, C, dims, dtype=torch.float32, seed=0, offset_std=0.3):
     """The deformable conv's weight gradient from the samples the grad_offset kernel stores (default) against the weight-gradient kernel that
     gathers for itself (dlka_lka3d_force_wgrad_gather(1) / DLKA_WGRAD_GATHER=1): same fma chain for every sample, same MFMA order over the rows -> the two agree to summation

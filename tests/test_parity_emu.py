@@ -323,6 +323,11 @@ def test_lka3d_tokens_phased_backward_equals_one_call(C, dims, dtype):
     parity.check_lka3d_tokens_phased_backward("cpu", 2, C, dims, dtype)
 
 
+@pytest.mark.parametrize("C,dims,training", [(32, (3, 4, 5), True), (64, (2, 4, 4), True), (32, (4, 4, 4), False)])
+def test_tblock3d_forward_is_bitwise_reproducible(C, dims, training):
+    parity.check_tblock3d_forward_reproducible("cpu", 2, C, dims, training, runs=3)
+
+
 def test_stack_step_vs_per_block_entries_and_oracle():
     """tests/test_stack_fullsize_gpu.py's check (the benchmarked engine step against the per-block entry points and the oracle) on a toy stack: the same
     checker, so that its logic is exercised in the CPU suite."""

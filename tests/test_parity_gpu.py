@@ -222,6 +222,12 @@ def test_forward_is_bitwise_reproducible_at_the_headline_shapes(C, dims, wstd, d
     parity.check_forward_reproducible(DEV, 2, C, dims, dtype, runs=5, offset_std=wstd, expect_kw=(dims[0] < 32))
 
 
+@pytest.mark.parametrize("C,dims,wstd", HEADLINE)
+def test_tblock3d_forward_is_bitwise_reproducible_at_the_headline_shapes(C, dims, wstd):
+    """The wrapper block (the path the trainers call) in TRAINING mode: output, BatchNorm batch statistics and every saved activation bitwise equal across 4 runs."""
+    parity.check_tblock3d_forward_reproducible(DEV, 2, C, dims, True, runs=4)
+
+
 CONFIG5 = [(32, (40, 56, 56), 0.376), (64, (20, 28, 28), 0.380), (128, (10, 14, 14), 0.490), (256, (5, 7, 7), 0.451)]
 
 

@@ -24,7 +24,7 @@ def hip_backend(oracle):
     yield
 
 
-@pytest.mark.parametrize("dtype", [torch.float32])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_benchmarked_step_full_size_vs_per_block_entry_and_oracle(dtype):
     from deformablelka_amd.stack import DLKABlockStack, SYNAPSE_STAGES
     B = 2
@@ -54,4 +54,5 @@ def test_benchmarked_step_full_size_vs_per_block_entry_and_oracle(dtype):
     # the oracle, on three blocks of the replayed step: the encoder's first 32^3 block (first of the forward pass), the decoder's last 32^3 block (first of the
     # backward pass: its weight gradients are the first on the side stream), and the last block of the 4^3 chain (chain-interior x, tap-split kernels)
     stage3 = next(i_ for i_, b in enumerate(st.blocks) if b.C == 256) + 2
-    parity.check_stack_step(st, picked, (0, len(st.blocks) - 1, stage3))
+    # (bf16 storage: the per-block entry points only — the oracle comparison of the bf16 block is test_lka3d_tokens_bf16_headline_shapes_vs_oracle's)
+    parity.check_stack_step(st, picked, (0, len(st.blocks) - 1, stage3) if dtype == torch.float32 else ())
