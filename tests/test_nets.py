@@ -244,3 +244,27 @@ def test_bn_running_statistics_bookkeeping_equals_torchs(momentum):
         assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 3
         assert torch.allclose(a.running_mean, b.running_mean, rtol=1e-5, atol=1e-6)
         assert torch.allclose(a.running_var, b.running_var, rtol=1e-5, atol=1e-6)
+
+
+def test_eval_reference_checkpoint_helpers(tmp_path):
+    """scripts/eval_reference_checkpoint.py (the "DSC vs ref" half of the metric, runnable once the published weights / data are mounted): an nnU-Net-style checkpoint
+    file with DataParallel prefixes loads into D_LKA_Former with strict key agreement; Dice per class on a hand-made pair."""
+    import importlib.util
+    import numpy as np
+    import deformablelka_amd as dk
+    spec = importlib.util.spec_from_file_location("eval_ref", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "eval_reference_checkpoint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    net = dk.D_LKA_Former(in_channels=1, out_channels=14, img_size=[64, 128, 128], feature_size=16, num_heads=4, depths=[3, 3, 3, 3], dims=[32, 64, 128, 256], do_ds=True)
+    f = str(tmp_path / "model_final_checkpoint.model")
+    torch.save({"state_dict": {"module." + k: v for k, v in net.state_dict().items()}, "epoch": 1000}, f)
+    sd = mod.load_reference_state_dict(f)
+    assert set(sd) == set(net.state_dict()) and len(sd) == 699
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    pred = np.zeros((4, 4, 4), dtype=np.int64)
+    tgt = np.zeros((4, 4, 4), dtype=np.int64)
+    pred[:2] = 1; tgt[:2, :2] = 1          # |P| = 32, |T| = 16, |P & T| = 16 -> 2 * 16 / 48
+    tgt[3] = 2                             # class 2 only in the target -> 0
+    d = mod.dice_per_class(pred, tgt, [1, 2, 3])
+    assert abs(d[1] - 2 * 16 / 48) < 1e-12 and d[2] == 0.0 and 3 not in d
