@@ -154,6 +154,7 @@ SIGNATURES = {
     "dlka_dwconv_lds_launch_count": (ctypes.c_long, []),
     "dlka_conv_brick_launch_count": (ctypes.c_long, []),
     "dlka_dwpair_launch_count": (ctypes.c_long, []),
+    "dlka_dwconv_2p_launch_count": (ctypes.c_long, []),
     "dlka_conv_kw_launch_count": (ctypes.c_long, []),
     "dlka_lka3d_tokens_supported_v": (c_int, [c_int] * 7),
     "dlka_lka3d_tokens_saved_bytes_v": (c_size_t, [c_int] * 7),

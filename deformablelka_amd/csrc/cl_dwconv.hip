@@ -10,6 +10,8 @@
 // hide latency, not by the L1 request rate, and bigger per-thread tiles leave ~1 wave per SIMD.)
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "cl_args.h"
 #include "dlka_kernels.h"
 
@@ -380,6 +382,158 @@ __global__ __launch_bounds__(256, DLKA_TD2_OCC) void cl_dwconv_rows2d_kernel(DwA
     }
 }
 
+// Third attempt at the family (round 6) — OPT-IN (DLKA_DW_2P=1 | 2), measured SLOWER than the row kernel: 7^3 dilation 3 49.5 against 43.4 us, 5^3 21.9 against
+// 20.2 at (32 channels, 32^3); 30.7 against 19.1 / 19.2 against 16.9 at (64, 16^3)  (profiles/r10_notes.md).  What it does:
+//  * input rows go through a RING of register segments; the loads of row r + RING - 1 are issued BEFORE row r computes.  Every load is unconditional (a row outside the
+//    volume gets a zero-sized descriptor: the hardware range check returns 0, no memory is touched) so that the compiler's vmcnt bookkeeping stays exact across the scalar
+//    branches that skip the FMAs of such rows; planes outside the volume are not visited at all.
+//  * the two output ROWS h0 and h0 + DIL of a work-item are the two halves of v_pk_fma_f32: acc.xy += {w[r][k], w[r - 1][k]} * seg.xx — the broadcast is an op_sel of the
+//    instruction and the weight pair is ONE ds_read2_b32 (LDS layout [tap plane][tap column][zero row, tap rows in DEscending order, zero row][channel]: the two tap rows
+//    are 32 floats apart in register order; the zero rows serve the first / last input row), read one row AHEAD of its use: a tap costs one LDS read, one address add and
+//    TW packed FMAs, no v_mov (the row kernels pack along W: 322 v_mov beside 392 v_pk_fma per tap plane at 7^3 dilation 3).  Per output the FMA chain is the row
+//    kernel's (plus zero products): bit-identical to it.
+//  * lane = channel, TW outputs along W, two rows x two planes (d0, d0 + DIL: input plane ip carries tap plane ip for the first, ip - 1 for the second).
+// Why it loses (ablations of this kernel at 7^3, us: as is 49.5 / no weight staging 44.1 / no input loads 38.6 / no FMAs 27.8; scripts/ubench/fma_rate.hip, VGPR operands):
+// ONE wave issues a vector instruction every ~5 - 6 clocks whatever it is (v_fma_f32 115 FMA lanes per ns and CU at one wave per SIMD, 203 at two, 241 at four; v_pk_fma_f32 with
+// three VGPR sources 194 / 253 / 278), so the FMA pipe only fills at three or four waves per SIMD — and a 2 x 2 x 8 register tile with its ring is 232 registers and
+// 1156 waves for the whole stage-0 volume: one or two waves per SIMD, the SIMDs that got two set the time.  4-wide work-items (twice the waves, 144 - 210 registers, 64 KB
+// of LDS per workgroup: still two per SIMD) measured 56 - 60 us.  The family's lever is occupancy at a small instruction count, not reuse per load: the row kernel
+// (three waves per SIMD, 40 % of its vector instructions are register moves and address adds) stays the default.
+template <typename T, int KW, int DIL, int TW, int RING>
+__global__ __launch_bounds__(256, 2) void cl_dwconv_rows2p_kernel(DwArgs p)
+{
+    constexpr int KH = KW, KD = KW, TH = 2;
+    constexpr int SB = sizeof(T);
+    constexpr int SEG = TW + (KW - 1) * DIL;
+    constexpr int NR = KH + TH - 1, NP = KD + 1;             // input rows per plane, input planes per work-item
+    constexpr int PF = RING - 1;                             // rows in flight ahead of the one that computes
+    static_assert(NR % RING == 0, "the ring slot of a row must not depend on the plane");
+    constexpr int KSTR = (KH + 2) * 32, PLANE = KW * KSTR;   // floats of one tap column (KH tap rows between two zero rows) / one tap plane in LDS
+    const T *inp = reinterpret_cast<const T *>(p.in), *gxp = reinterpret_cast<const T *>(p.gelu_x), *gap = reinterpret_cast<const T *>(p.gelu_add);
+    T *outp = reinterpret_cast<T *>(p.out);
+    __shared__ __attribute__((aligned(16))) float Wl[KD * PLANE];   // [tap plane][tap column k][zero row, tap rows KH - 1 .. 0, zero row][channel of the workgroup]
+    {
+#pragma unroll 4
+        for (int e = threadIdx.x; e < KD * PLANE / 4; e += 256) {
+            const int q = e & 7, slot = (e >> 3) % (KH + 2), k = ((e >> 3) / (KH + 2)) % KW, i = (e >> 3) / ((KH + 2) * KW);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (slot >= 1 && slot <= KH) v = *reinterpret_cast<const f32x4 *>(p.wp + (long)((i * KH + KH - slot) * KW + k) * p.C + blockIdx.z * 32 + 4 * q);   // tap row KH - slot
+            reinterpret_cast<f32x4 *>(Wl)[e] = v;
+        }
+        __syncthreads();
+    }
+    const int cl = threadIdx.x % 32, c = blockIdx.z * 32 + cl;
+    const int bx = DLKA_XCD_BX(p.xcd_nx);
+    if (bx < 0) return;
+    const int run = bx * 8 + threadIdx.x / 32;
+    const int runs_per_row = cdiv(p.W, TW);
+    const int hgroups = DIL * cdiv(p.H, TH * DIL), dgroups = DIL * cdiv(p.D, 2 * DIL);   // h0 = r + 2*DIL*q, d0 = r' + 2*DIL*q'  (r, r' < DIL)
+    const long total = (long)p.B * dgroups * hgroups * runs_per_row;
+    if (run >= total) return;
+    const int w0 = (run % runs_per_row) * TW;
+    const int gidx = wave_uniform(run / runs_per_row);
+    const int hg = gidx % hgroups, dg = (gidx / hgroups) % dgroups, b = gidx / (hgroups * dgroups);
+    const int h0 = (hg % DIL) + (hg / DIL) * TH * DIL, d0 = (dg % DIL) + (dg / DIL) * 2 * DIL;
+    if (h0 >= p.H || d0 >= p.D) return;                      // scalar
+
+    f32x2 acc[2][TW];                                        // [output plane d0 + od*DIL][w]; .x: row h0, .y: row h0 + DIL
+    const float bv = p.bias ? p.bias[c] : 0.f;
+#pragma unroll
+    for (int od = 0; od < 2; ++od)
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[od][t] = f32x2{bv, bv};
+
+    const int cb = p.C * SB;
+    const unsigned rowbytes = (unsigned)(p.W * cb);
+    const int vbase = (w0 - p.pw) * cb + c * SB;
+    // input planes zd = d0 - pd + ip*DIL inside the volume: ip in [ip_lo, ip_hi)
+    const int ip_lo = d0 < p.pd ? cdiv(p.pd - d0, DIL) : 0;
+    const int ip_hi = min(NP, cdiv(p.D - d0 + p.pd, DIL));
+    float seg[RING][SEG];
+    // descriptor of input row rr of plane ip (zero-sized outside the volume)
+    auto row_rsrc = [&](int ip, int rr) {
+        const int zd = d0 - p.pd + ip * DIL, zh = h0 - p.ph + rr * DIL;
+        const bool ok = ip < ip_hi && zh >= 0 && zh < p.H;
+        return make_rsrc(inp + ((long)(b * p.D + (ok ? zd : 0)) * p.H + (ok ? zh : 0)) * p.W * p.C, ok ? rowbytes : 0u);
+    };
+#pragma unroll
+    for (int r = 0; r < PF; ++r) {
+        const BufRsrc rr = row_rsrc(ip_lo, r);
+#pragma unroll
+        for (int e = 0; e < SEG; ++e) seg[r % RING][e] = act_buf_load1<T>(rr, (unsigned)(vbase + e * cb));
+    }
+    // tap weights of the row about to compute, read from LDS one row AHEAD (with one or two waves per SIMD nothing else hides the LDS latency: read at the point of
+    // use, every tap cost ~60 stall clocks beside its 32 clocks of FMAs).  wr[od][k] = {w[i][r][k], w[i][r - 1][k]}, i = ip - od clamped into the staged planes (an
+    // output plane that does not take this input plane skips its FMAs by a scalar branch; what was read for it is dropped).
+    f32x2 wr[2][KW];
+    auto load_w = [&](f32x2 (&w)[2][KW], int ip, int r) {
+#pragma unroll
+        for (int od = 0; od < 2; ++od) {
+            const float *wl = Wl + min(max(ip - od, 0), KD - 1) * PLANE + (KH - r) * 32 + cl;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) w[od][k] = f32x2{wl[k * KSTR], wl[k * KSTR + 32]};   // tap rows r (slot KH - r) and r - 1 (the next slot): one ds_read2_b32, in register order
+        }
+    };
+    load_w(wr, ip_lo, 0);
+#pragma unroll 1
+    for (int ip = ip_lo; ip < ip_hi; ++ip) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {                       // input row h0 - ph + r*DIL: tap row r of output row h0, r - 1 of h0 + DIL
+            {                                                // row r + PF (of this plane or the next one) into the slot row r - 1 left
+                const BufRsrc rr = row_rsrc(ip + (r + PF) / NR, (r + PF) % NR);
+#pragma unroll
+                for (int e = 0; e < SEG; ++e) seg[(r + PF) % RING][e] = act_buf_load1<T>(rr, (unsigned)(vbase + e * cb));
+            }
+            f32x2 wn[2][KW];
+            load_w(wn, ip + (r + 1) / NR, (r + 1) % NR);
+            const int zh = h0 - p.ph + r * DIL;
+            if (zh >= 0 && zh < p.H) {                       // scalar (else: the row's segment is zeros, nothing to add)
+#pragma unroll
+                for (int od = 0; od < 2; ++od) {
+                    const int i = ip - od;                   // tap plane of output plane d0 + od*DIL
+                    if (i < 0 || i >= KD) continue;          // scalar
+#pragma unroll
+                    for (int k = 0; k < KW; ++k) {
+#pragma unroll
+                        for (int t = 0; t < TW; ++t) {
+                            const float sv = seg[r % RING][t + k * DIL];
+                            acc[od][t] = pk_fma(wr[od][k], f32x2{sv, sv}, acc[od][t]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int od = 0; od < 2; ++od)
+#pragma unroll
+                for (int k = 0; k < KW; ++k) wr[od][k] = wn[od][k];
+        }
+    }
+#pragma unroll
+    for (int od = 0; od < 2; ++od) {
+        if (d0 + od * DIL >= p.D) break;                     // scalar
+#pragma unroll
+        for (int o = 0; o < TH; ++o) {
+            if (h0 + o * DIL >= p.H) break;                  // scalar
+            const long obase = (((long)(b * p.D + d0 + od * DIL) * p.H + h0 + o * DIL) * p.W + w0) * p.C + c;
+            if (p.gelu_x) {
+#pragma unroll
+                for (int t = 0; t < TW; ++t)
+                    if (w0 + t < p.W) act_store1(outp, obase + (long)t * p.C, (acc[od][t][o] + act_load1(gap, obase + (long)t * p.C)) * dgelu_f(act_load1(gxp, obase + (long)t * p.C)));
+            } else {
+#pragma unroll
+                for (int t = 0; t < TW; ++t)
+                    if (w0 + t < p.W) act_store1(outp, obase + (long)t * p.C, acc[od][t][o]);
+                if (sizeof(T) == 4 && p.out_lo) {   // uniform: bf16 copy (see cl_args.h: DwArgs::out_lo)
+                    bf16_t *lo = reinterpret_cast<bf16_t *>(p.out_lo);
+#pragma unroll
+                    for (int t = 0; t < TW; ++t)
+                        if (w0 + t < p.W) act_store1(lo, obase + (long)t * p.C, acc[od][t][o]);
+                }
+            }
+        }
+    }
+}
+
 // reference layout W[c][1][kd][kh][kw] -> Wp[tap][c]; flip = 1 reverses the taps (data gradient)
 __global__ void cl_dw_prep_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int C, int K, int flip)
 {
@@ -397,6 +551,10 @@ int launch_cl_dw_prep_weight(const float *w, float *wp, int C, int K, int flip, 
     return DLKA_OK;
 }
 
+static std::atomic<long> g_dw2p_launches{0};   // dlka_dwconv_2p_launch_count (include/dlka.h): diagnostics
+#ifndef DLKA_DW_2P_MIN_WAVES
+#define DLKA_DW_2P_MIN_WAVES 1000000000   // (no launch size at which it won: off unless DLKA_DW_2P asks for it)
+#endif
 // kw, dil_w select the instantiation; returns DLKA_ERR_UNSUPPORTED for other shapes (caller falls back to conv.hip)
 template <typename T>
 static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st)
@@ -420,6 +578,27 @@ static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st
         const bool cubic = a.kd == kw && a.kh == kw && a.dd == dil_w && a.dh == dil_w;
         const int th = th_env ? th_env : 2;
         if ((th == 2 || (th == 3 && F32)) && cubic && a.H >= th * dil_w && ((kw == 7 && dil_w == 3) || (kw == 5 && dil_w == 1))) {
+            // Software-pipelined kernel with two output rows on the halves of v_pk_fma_f32 and two output planes per work-item (cl_dwconv_rows2p_kernel): OPT-IN, measured
+            // slower (see its header).  DLKA_DW_2P (read per launch): unset / 0 = never, 1 = wherever its geometry fits (5^3: two rows ahead), 2 = the same with one row ahead.
+            {
+                const char *e3 = getenv("DLKA_DW_2P");
+                const int mode = e3 ? atoi(e3) : -1;
+                const bool ok2p = th == 2 && a.C % 32 == 0 && a.D >= 2 * dil_w && a.pd == (kw - 1) / 2 * dil_w && a.ph == a.pd && !a.out_blk && cdiv(a.W, TW) % 2 == 0;
+                const long runs3 = (long)a.B * dil_w * cdiv(a.D, 2 * dil_w) * dil_w * cdiv(a.H, th * dil_w) * cdiv(a.W, TW);
+                const long waves3 = runs3 / 2 * (a.C / 32);
+                if (ok2p && (mode > 0 || (mode < 0 && waves3 >= DLKA_DW_2P_MIN_WAVES))) {
+                    dim3 grid3((unsigned)cdivl(runs3, 8), 1, a.C / 32);
+                    swz(grid3);
+                    if (kw == 7) { auto k = cl_dwconv_rows2p_kernel<T, 7, 3, TW, 2>; DLKA_LAUNCH(k, grid3, block, 0, st, ax); }   // (a ring of 4 spills: 262 registers' worth)
+                    else {
+                        if (mode == 2) { auto k = cl_dwconv_rows2p_kernel<T, 5, 1, TW, 2>; DLKA_LAUNCH(k, grid3, block, 0, st, ax); }
+                        else { auto k = cl_dwconv_rows2p_kernel<T, 5, 1, TW, 3>; DLKA_LAUNCH(k, grid3, block, 0, st, ax); }
+                    }
+                    DLKA_CHECK_LAUNCH();
+                    g_dw2p_launches.fetch_add(1, std::memory_order_relaxed);
+                    return DLKA_OK;
+                }
+            }
             const long runs2 = (long)a.B * a.D * dil_w * cdiv(a.H, th * dil_w) * cdiv(a.W, TW);
             dim3 grid2((unsigned)cdivl(runs2, rpb), 1, cdiv(a.C, cpb));
             swz(grid2);
@@ -507,6 +686,10 @@ int launch_cl_dwconv(const DwArgs &a, int kw, int dil_w, hipStream_t st)
     if (e != DLKA_ERR_UNSUPPORTED) return e;
     return a.act_bf16 ? launch_cl_dwconv_t<bf16_t>(a, kw, dil_w, st) : launch_cl_dwconv_t<float>(a, kw, dil_w, st);
 }
+
+}   // namespace dlka
+extern "C" long dlka_dwconv_2p_launch_count(void) { return dlka::g_dw2p_launches.load(std::memory_order_relaxed); }
+namespace dlka {
 
 // ---------------------------------------------------------------------------------------------
 // depthwise weight gradient:  gW[c][tap] = sum_{b,d,h,w} G[b,d,h,w][c] * in[b, d+i*dd-pd, h+j*dh-ph, w+k*dw-pw][c]

@@ -504,6 +504,9 @@ long dlka_dwpair_launch_count(void);
  * 16^3 / 8^3 / 4^3 stages — with the contraction split over the waves of ONE workgroup and summed in wave order in LDS: bitwise reproducible, no global atomics;
  * DLKA_CONV_KW=0 restores the tap split over the grid) and of the deformable forward's workgroup-split variants.  Tests assert which kernel ran. */
 long dlka_conv_kw_launch_count(void);
+/* launches so far of the opt-in software-pipelined depthwise kernel (csrc/cl_dwconv.hip: cl_dwconv_rows2p_kernel, round 6; DLKA_DW_2P=1 | 2 sends the dw 5^3 /
+ * 7^3 dilation-3 convs and their data gradients through it wherever its geometry fits; default: never — it measured slower than the row kernel) */
+long dlka_dwconv_2p_launch_count(void);
 size_t dlka_lka3d_tokens_workspace_bytes_v(int B, int C, int D, int H, int W, int dtype, int variant);
 int dlka_lka3d_attention_tokens_forward_v(const void *x, const dlka_lka3d_params *p, void *y, void *saved, size_t saved_bytes,
                                           void *workspace, size_t workspace_bytes, int B, int C, int D, int H, int W, int dtype, int variant, void *stream);

@@ -750,6 +750,31 @@ def test_dwconv_two_output_planes(case, monkeypatch):
     assert torch.equal(y1, y2)
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("case", [(1, 32, (13, 7, 16), 7, 9, 3), (2, 64, (5, 6, 16), 5, 2, 1), (1, 32, (12, 8, 9), 7, 9, 3), (1, 32, (7, 5, 12), 5, 2, 1)])
+def test_dwconv_pipelined_row_pairs(case, mode, monkeypatch):
+    """cl_dwconv_rows2p_kernel (round 6: software-pipelined input rows, the two output rows of a work-item on the two halves of v_pk_fma_f32, two output planes, tap weights with
+    zero rows in LDS) against the fp64 conv (forward, data gradient through the same kernel with flipped taps) — and bit for bit against the row kernel it replaces (the
+    same FMA chain per output, zero products added for the first / last input row).  Cases: odd depth / height (unpaired last plane / row, planes and rows outside the volume),
+    two channel groups across a batch, a ragged last run (W = 9, 12), both ring depths (mode 2: one row ahead)."""
+    from deformablelka_amd import ops
+    B, C, dims, k, p, d = case
+    from deformablelka_amd._lib import get_lib
+    lib = get_lib()
+    monkeypatch.setenv("DLKA_DW_2P", mode)
+    n0 = lib.dlka_dwconv_2p_launch_count()
+    parity.check_conv3d_cl("cpu", B, C, C, dims, k, p, d, C, planar=False, seed=8)
+    assert lib.dlka_dwconv_2p_launch_count() - n0 >= 2, (n0, lib.dlka_dwconv_2p_launch_count())   # forward + data gradient
+    gen = torch.Generator().manual_seed(10)
+    x = torch.randn(B, *dims, C, generator=gen)
+    w = torch.randn(C, 1, k, k, k, generator=gen) * 0.1
+    bias = torch.randn(C, generator=gen)
+    y2 = ops.conv3d_forward_cl(x, w, bias, p, d, C)
+    monkeypatch.setenv("DLKA_DW_2P", "0")
+    y1 = ops.conv3d_forward_cl(x, w, bias, p, d, C)
+    assert torch.equal(y1, y2)
+
+
 @pytest.mark.parametrize("C,dims,bf", [(32, (3, 4, 5), False), (64, (2, 4, 3), True)])
 def test_tblock3d_phased_backward_equals_one_call(C, dims, bf):
     """dlka_tblock3d_backward_phase_v (round 5: the engine's data-chain / weight-gradient split for the wrapper block): phase 1 then phase 2 == phase 0."""
