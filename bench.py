@@ -557,14 +557,29 @@ def lka2d_metric(steps, dev, dtype=torch.float32, with_cpu=False):
             torch.cuda._sleep(int(60e6))
         except Exception:
             pass
-        L.check(lib.dlka_trace_start(8192, st), "trace_start")
+        # ONE stream for the traced pass (DLKA_LKA2D_FORK=0): with the library's internal fork streams on, the events behind a launch bracket whatever else runs beside it
+        # and are not the kernel's duration; `value` above was timed with the forks on
+        prev_fork = os.environ.get("DLKA_LKA2D_FORK")
+        os.environ["DLKA_LKA2D_FORK"] = "0"
+        lib.dlka_env_refresh()
         try:
-            for i, (m, x, gy) in enumerate(zip(mods, xs, gys)):
-                L.check(lib.dlka_trace_mark(st), "trace_mark")
-                m(x).backward(gy)
+            m0, x0, gy0 = mods[0], xs[0], gys[0]
+            m0(x0).backward(gy0)   # (the one-stream path's first call outside the trace)
+            torch.cuda.synchronize()
+            L.check(lib.dlka_trace_start(8192, st), "trace_start")
+            try:
+                for i, (m, x, gy) in enumerate(zip(mods, xs, gys)):
+                    L.check(lib.dlka_trace_mark(st), "trace_mark")
+                    m(x).backward(gy)
+            finally:
+                rc = lib.dlka_trace_stop()
+            L.check(rc, "trace_stop")
         finally:
-            rc = lib.dlka_trace_stop()
-        L.check(rc, "trace_stop")
+            if prev_fork is None:
+                os.environ.pop("DLKA_LKA2D_FORK", None)
+            else:
+                os.environ["DLKA_LKA2D_FORK"] = prev_fork
+            lib.dlka_env_refresh()
         buf, ms, acc, blk, total = create_string_buffer(512), c_float(), {}, -1, 0.0
         for i in range(lib.dlka_trace_count()):
             L.check(lib.dlka_trace_get(i, buf, 512, byref(ms)), "trace_get")
@@ -613,8 +628,10 @@ def lka2d_metric(steps, dev, dtype=torch.float32, with_cpu=False):
             pass
         out["roofline"] = {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 5), "traffic": traffic, "traffic_source": traffic_source,
                            "kernel": name, "kernel_us": round(t * 1e6, 2), "shape": "C=%d,%dx%d,B=24" % (C, n, n), "algorithmic_flops": fl,
-                           "algorithmic_bytes": by, "method": "library launch trace (HIP events behind every launch), one eager step",
+                           "algorithmic_bytes": by, "method": "library launch trace (HIP events behind every launch), one eager step on ONE stream (DLKA_LKA2D_FORK=0): the durations are the kernels' own",
                            "kernels": kern}
+        if bound == "mfma" and dtype == torch.bfloat16:   # the offset nets' contractions run on bf16 MFMA (three-term operands) in this mode
+            out["roofline"].update({"frac_of_bf16_mfma_peak": round(ach / PEAK_BF16_TFLOPS, 5), "bf16_mfma_peak_TFLOPs": PEAK_BF16_TFLOPS})
     except Exception as e:
         log("lka2d launch trace failed:", repr(e))
     if with_cpu:

@@ -285,12 +285,19 @@ __global__ __launch_bounds__(256) void cl_ddw2d_gx_kernel(Ddw2dArgs p, int TH, i
 //     scanning the whole image — and added by cl_ddw2d_gx_far_kernel afterwards (thread = (pixel, tap), global fp32 atomics, rare).
 // The split near / far is decided on the offset VALUES alone, so every tile that enumerates a sample takes the same decision.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int GX3_TY = 8, GX3_TX = 4;                 // tile (input pixels)
+#ifndef DLKA_GX3_TY
+#define DLKA_GX3_TY 4   // (-D... for scripts/build_variant.sh).  Round 6: 4 x 4 instead of 8 x 4 — a 6 x 6 window is 18 KB per wave, EIGHT waves per CU instead of five, and one wave
+#define DLKA_GX3_TX 4   // issues a vector instruction only every ~5 clocks (scripts/ubench/fma_rate.hip): 906 -> 767 us (7x7) / 507 -> 446 (5x5) at (96, 56^2, B = 24) although a tile
+#endif                  // now walks 1.56 hits per pixel instead of 1.41; 4x3 465 / 781, 3x4 470, 4x2 498, 2x4 499, 6x4 498, 2x2 588, 8x2 484 / 849, 4x8 491 / 888, 16x2 648 / 1140
+#ifndef DLKA_GX3_MIN_WAVES
+#define DLKA_GX3_MIN_WAVES 1024   // launches with fewer waves keep the first-generation window kernel (with 4 x 4 tiles — us, window kernel / this one: (192, 28^2) 383 / 260 (5x5), 588 / 427 (7x7);
+#endif                            // (384, 14^2) 173 / 164, 210 / 194: profiles/r10_notes.md)
+constexpr int GX3_TY = DLKA_GX3_TY, GX3_TX = DLKA_GX3_TX;   // tile (input pixels)
 constexpr int GX3_MG = 3;                             // offset margin: |dy|, |dx| <= GX3_MG are "near"
 constexpr int GX3_NBY = GX3_TY + 2 * GX3_MG + 1, GX3_NBX = GX3_TX + 2 * GX3_MG + 1;   // candidate base positions per axis
 constexpr int GX3_CW = 128;                           // channels per wave: lane = a PAIR of channels (8-byte LDS and grad_out accesses)
 constexpr int GX3_NH = 8;                             // hits per group = grad_out row requests in flight per register set
-// Round 5 — the window carries a one-cell RING around the tile: (TY + 2) x (TX + 2) cells of [lane = channel pair] float2, 30 KB per wave (5 waves per CU).  A hit's
+// Round 5 — the window carries a one-cell RING around the tile: (TY + 2) x (TX + 2) cells of [lane = channel pair] float2 (30 KB per wave = 5 waves per CU with round 5's 8 x 4 tile; 18 KB = 8 waves with 4 x 4).  A hit's
 // 2 x 2 footprint then ALWAYS lies inside the window (a hit has at least one corner in the tile, so its low corner is at most one cell outside), its four cells
 // are ONE base address plus the compile-time offsets {0, 1, WX, WX + 1} (ds_read_b64 / ds_write_b64 with immediate offsets), and corners outside the tile simply
 // land in ring cells that are never stored — no per-corner select, no per-corner address.  Round 4's version kept a tile-sized window (16 KB, 9 waves per CU) and
@@ -595,7 +602,7 @@ int launch_cl_ddw2d_bwd(const DwArgs2d &d, float *gw, hipStream_t st, hipStream_
     // DLKA_DDW2D_GX=window | tiles forces one of them (A/B runs, parity tests of both).
     const char *gxsel = getenv("DLKA_DDW2D_GX");
     const long gx3_waves = (long)a.B * cdiv(a.H, GX3_TY) * cdiv(a.W, GX3_TX) * cdiv(a.C, GX3_CW);
-    const bool use_gx3 = (a.C & 1) == 0 && (gxsel ? gxsel[0] == 't' : gx3_waves >= 2048);
+    const bool use_gx3 = (a.C & 1) == 0 && (gxsel ? gxsel[0] == 't' : gx3_waves >= DLKA_GX3_MIN_WAVES);
     if (use_gx3) {   // grad_input, second generation: input-pixel tiles, lane = channel pair (the first generation stays for A/B runs)
         const int ntx = cdiv(a.W, GX3_TX), nty = cdiv(a.H, GX3_TY);
         const int ntiles = a.B * nty * ntx;

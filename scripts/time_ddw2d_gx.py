@@ -17,13 +17,15 @@ lib = L.get_lib()
 dev = "cuda:0"
 st = torch.cuda.current_stream(torch.device(dev)).cuda_stream
 torch.manual_seed(0)
-for dt in (torch.float32,):
-    for std in (0.3, 1.0):
+SHAPES = [tuple(int(v) for v in sh.split("x")) for sh in os.environ.get("GX_SHAPES", "96x56").split(",")]   # C x n, e.g. GX_SHAPES=96x56,192x28,384x14
+for dt in ((torch.bfloat16,) if os.environ.get("GX_BF16") else (torch.float32,)):
+  for C, n in SHAPES:
+    for std in (0.3,):
         for k, pad, dil in ((5, 2, 1), (7, 9, 3)):
-            x = torch.randn(24, 56, 56, 96, device=dev).to(dt)
-            g = torch.randn(24, 56, 56, 96, device=dev).to(dt)
-            off = torch.randn(24, 2 * k * k, 56, 56, device=dev) * std
-            w = torch.randn(96, 1, k, k, device=dev) * 0.1
+            x = torch.randn(24, n, n, C, device=dev).to(dt)
+            g = torch.randn(24, n, n, C, device=dev).to(dt)
+            off = torch.randn(24, 2 * k * k, n, n, device=dev) * std
+            w = torch.randn(C, 1, k, k, device=dev) * 0.1
             for _ in range(2):
                 ops.deform_dwconv2d_backward_cl(x, off, w, g, pad, dil)
             torch.cuda.synchronize()
@@ -34,6 +36,6 @@ for dt in (torch.float32,):
             buf, ms, acc = create_string_buffer(512), c_float(), {}
             for i in range(lib.dlka_trace_count()):
                 L.check(lib.dlka_trace_get(i, buf, 512, byref(ms)), "get")
-                n = buf.value.decode().replace("void dlka::", "").split("(")[0].replace("cl_ddw2d_", "")
-                acc[n] = acc.get(n, 0.0) + ms.value / 3
-            print(("bf16" if dt == torch.bfloat16 else "f32 "), "std", std, "k", k, " ".join(f"{n[:22]} {v*1e3:.0f}" for n, v in acc.items()))
+                kn = buf.value.decode().replace("void dlka::", "").split("(")[0].replace("cl_ddw2d_", "")
+                acc[kn] = acc.get(kn, 0.0) + ms.value / 3
+            print(("bf16" if dt == torch.bfloat16 else "f32 "), "C", C, "n", n, "std", std, "k", k, " ".join(f"{n[:22]} {v*1e3:.0f}" for n, v in acc.items()))
