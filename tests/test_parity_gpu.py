@@ -1106,6 +1106,33 @@ def test_dwpair_equals_unfused(C, dims, bf):
     parity.check_dwpair_equals_unfused(DEV, 2, C, dims, lka_bf16=bf)
 
 
+@pytest.mark.parametrize("case", [(2, 32, (32, 32, 32), 7, 9, 3), (2, 32, (32, 32, 32), 5, 2, 1), (2, 64, (16, 16, 16), 7, 9, 3), (1, 32, (13, 7, 9), 7, 9, 3), (2, 64, (5, 6, 16), 5, 2, 1)])
+def test_dwconv_pipelined_row_pairs_equal_row_kernel(case, monkeypatch):
+    """cl_dwconv_rows2p_kernel (round 6, opt-in DLKA_DW_2P: software-pipelined rows, output rows on the halves of v_pk_fma_f32, two output planes) at the stage-0 / stage-1
+    shapes and two ragged ones: bit for bit the row kernel's result (same FMA chain per output), forward and data gradient, and the fp64 conv's to 1e-4."""
+    from deformablelka_amd import ops
+    from deformablelka_amd._lib import get_lib
+    lib = get_lib()
+    B, C, dims, k, p, d = case
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(B, *dims, C, generator=gen).to(DEV)
+    g = torch.randn(B, *dims, C, generator=gen).to(DEV)
+    w = (torch.randn(C, 1, k, k, k, generator=gen) * 0.1).to(DEV)
+    bias = torch.randn(C, generator=gen).to(DEV)
+    res = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("DLKA_DW_2P", mode)
+        n0 = lib.dlka_dwconv_2p_launch_count()
+        y = ops.conv3d_forward_cl(x, w, bias, p, d, C)
+        gi = ops.conv3d_backward_cl(x, w, g, p, d, C)[0]
+        assert (lib.dlka_dwconv_2p_launch_count() - n0 >= 2) == (mode != "0"), (mode, n0, lib.dlka_dwconv_2p_launch_count())
+        res[mode] = (y, gi)
+    for mode in ("1", "2"):
+        assert torch.equal(res["0"][0], res[mode][0]) and torch.equal(res["0"][1], res[mode][1]), mode
+    ref = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3).double().cpu(), w.double().cpu(), bias.double().cpu(), padding=p, dilation=d, groups=C).permute(0, 2, 3, 4, 1)
+    assert float((res["1"][0].double().cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("bf", [False, True])
 def test_weight_preparation_tiled_equals_elementwise(bf):
     """cl_igemm.hip prep_job_tile (round 5): the LDS-tiled weight re-layout is bitwise the element-per-lane one — every prepared form of one block of each Synapse width."""
