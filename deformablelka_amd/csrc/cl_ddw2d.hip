@@ -67,24 +67,42 @@ __global__ __launch_bounds__(256) void cl_ddw2d_fwd_kernel(Ddw2dArgs p)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float *offp = p.off + (long)b * 2 * p.K * p.N + n;
-    for (int tap = 0; tap < p.K; ++tap) {
-        const int ti = tap / p.kw, tj = tap - ti * p.kw;
-        Tap2 s;
-        const float oy = ok ? offp[(long)(2 * tap) * p.N] : 0.f, ox = ok ? offp[(long)(2 * tap + 1) * p.N] : 0.f;
-        describe2(s, oy, ox, b, y0 - p.ph + ti * p.dh, x0 - p.pw + tj * p.dw, p.H, p.W, p.N, rowbytes);
-        if (!ok) s.off[0] = s.off[1] = s.off[2] = s.off[3] = DLKA_OOB;
+    // A wave's timeline was K x (offset round trip -> description -> corner round trip -> FMAs) with nothing of tap t + 1 in flight while tap t computes (waves parked 49 % of
+    // their time, issue-stalled 38 %, active 13 %: profiles/r10_sq_counters_lka2d_C96_56.csv).  Round 6: the two offsets of a tap are requested PF taps ahead, which takes
+    // the first of the two round trips off the chain: 246 -> 239 us (7x7), 133 -> 130 (5x5) at (96, 56^2, B = 24), bit-identical — small, because the kernel is NOT
+    // latency-bound: its 4 corner rows per (pixel, tap) are 5.7 GB of L1 reads per 7x7 launch = 24 TB/s, 60 % of the L1's 64 bytes per clock and CU.  (Corner rows + weights
+    // of tap t + 1 in a second register set as well: 234 registers at three chunks instead of 66 — two waves per SIMD instead of seven; not kept.)
+    constexpr int PF = 4;
+    float oyn[PF], oxn[PF];   // offsets of taps t .. t + PF - 1, slot = tap % PF
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const unsigned cb = (unsigned)(c0 + 32 * c) * 4u;
-            f32x4 x4[4];
+    for (int u = 0; u < PF; ++u) {
+        oyn[u] = (ok && u < p.K) ? offp[(long)(2 * u) * p.N] : 0.f;
+        oxn[u] = (ok && u < p.K) ? offp[(long)(2 * u + 1) * p.N] : 0.f;
+    }
+    for (int tap0 = 0; tap0 < p.K; tap0 += PF) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) x4[q] = buf_load_f32x4(rin, s.off[q] == DLKA_OOB ? DLKA_OOB : s.off[q] + cb);
-            const f32x4 w4 = buf_load_f32x4(rw, (unsigned)(tap * p.C) * 4u + cb);
+        for (int u = 0; u < PF; ++u) {
+            const int tap = tap0 + u;
+            if (tap >= p.K) break;   // uniform
+            const int ti = tap / p.kw, tj = tap - ti * p.kw;
+            Tap2 s;
+            describe2(s, oyn[u], oxn[u], b, y0 - p.ph + ti * p.dh, x0 - p.pw + tj * p.dw, p.H, p.W, p.N, rowbytes);
+            if (!ok) s.off[0] = s.off[1] = s.off[2] = s.off[3] = DLKA_OOB;
+            oyn[u] = (ok && tap + PF < p.K) ? offp[(long)(2 * (tap + PF)) * p.N] : 0.f;
+            oxn[u] = (ok && tap + PF < p.K) ? offp[(long)(2 * (tap + PF) + 1) * p.N] : 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float sv = s.wt[0] * x4[0][e];
-                sv = fmaf(s.wt[1], x4[1][e], sv); sv = fmaf(s.wt[2], x4[2][e], sv); sv = fmaf(s.wt[3], x4[3][e], sv);
-                acc[c][e] = fmaf(w4[e], sv, acc[c][e]);
+            for (int c = 0; c < NCH; ++c) {
+                const unsigned cb = (unsigned)(c0 + 32 * c) * 4u;
+                f32x4 x4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x4[q] = buf_load_f32x4(rin, s.off[q] == DLKA_OOB ? DLKA_OOB : s.off[q] + cb);
+                const f32x4 w4 = buf_load_f32x4(rw, (unsigned)(tap * p.C) * 4u + cb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float sv = s.wt[0] * x4[0][e];
+                    sv = fmaf(s.wt[1], x4[1][e], sv); sv = fmaf(s.wt[2], x4[2][e], sv); sv = fmaf(s.wt[3], x4[3][e], sv);
+                    acc[c][e] = fmaf(w4[e], sv, acc[c][e]);
+                }
             }
         }
     }
