@@ -594,7 +594,7 @@ def lka2d_metric(steps, dev, dtype=torch.float32, with_cpu=False):
         rows = sorted(((v[1], k, v[0]) for k, v in acc.items()), reverse=True)
         dbytes = 2 if dtype == torch.bfloat16 else 4
         kern = []
-        for tot, (si, name), cnt in rows[:10]:
+        for tot, (si, name), cnt in rows[:int(os.environ.get("DLKA_BENCH_2D_ROWS", "10"))]:
             kern.append({"kernel": name, "shape": "C=%d,%dx%d" % (shapes[si][0], shapes[si][1], shapes[si][1]), "launches_per_step": cnt,
                          "avg_us": round(tot / cnt * 1e3, 2), "step_share": round(tot / total, 4)})
         tot, (si, name), cnt = rows[0]

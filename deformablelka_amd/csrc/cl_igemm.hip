@@ -462,11 +462,21 @@ static int launch_igemm_nt(const IgemmArgs &a, int splits, hipStream_t st)
     // column tiles per block: all of them when there are plenty of row blocks, fewer (-> gridDim.z) for small M
     int NT = NT_total;
     const int mblocks = cdiv(a.M, 128);
-    if (NT_total == 6) NT = 3;          // 192 / 384 columns (the 2-D block's offset-net data gradients): 3 / 4 tiles per workgroup
-    else if (NT_total == 12) NT = 4;
+    if (NT_total == 6) NT = 2;          // 192 / 384 columns (the 2-D block's offset-net data gradients at 28^2 / 14^2: 147 / 37 row blocks): two tiles per workgroup
+    else if (NT_total == 12) NT = 2;    // (round 6; three / four tiles measured 184 against 160 us and 144 against 129: more, smaller workgroups balance the chip)
     else if (NT_total == 8 && mblocks * splits < 256) NT = (mblocks * splits * 2 < 256) ? 2 : 4;
     else if (NT_total == 4 && mblocks * splits < 256) NT = (mblocks * splits * 2 < 256) ? 1 : 2;
+    // Round 6: 128 columns in ONE workgroup only where the row blocks alone balance the chip.  The 2-D block's 7x7 offset net at 56^2 (588 row blocks, 98 -> 128 columns) was 2.3
+    // workgroups per CU, three resident: the CUs that took three set the time, the matrix pipe 44 % busy and 1.3 resident waves per SIMD on average (profiles/r10_notes.md);
+    // two column halves = 1176 workgroups of half the LDS: 560 -> ~508 us per launch, the 2-D step 17.10 -> 16.74 ms.  (One tile per workgroup: slower — 471 against 339 us averaged
+    // over the two nets — the A rows are fetched and split four times.)
+    else if (NT_total == 4 && mblocks * splits < 1024) NT = 2;
     else if (NT_total == 2 && mblocks * splits < 128) NT = 1;
+    {   // A/B runs: DLKA_IGEMM_NT=n (read per launch) forces n column tiles per workgroup where n divides the tile count
+        const char *e = getenv("DLKA_IGEMM_NT");
+        const int n = e ? atoi(e) : 0;
+        if (n > 0 && NT_total % n == 0 && a.K > 1) NT = n;
+    }
     dim3 grid(mblocks, splits, NT_total / NT), block(256);
     IgemmArgs ax = a;
     ax.xcd_nx = 0;
