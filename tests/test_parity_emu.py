@@ -775,6 +775,25 @@ def test_dwconv_pipelined_row_pairs(case, mode, monkeypatch):
     assert torch.equal(y1, y2)
 
 
+def test_dwconv_pipelined_row_pairs_in_the_bf16_block(monkeypatch):
+    """The bf16-storage instantiation of cl_dwconv_rows2p_kernel, reached through the token block (DLKA_BF16, DLKA_DW_2P=1): the block's parity against the oracle holds and its
+    output equals the default row kernels' bit for bit (volume 7 x 6 x 16: both depthwise convs and both data gradients fit the kernel's geometry)."""
+    import deformablelka_amd as dk
+    from deformablelka_amd._lib import get_lib
+    lib = get_lib()
+    monkeypatch.setenv("DLKA_DW_2P", "1")
+    n0 = lib.dlka_dwconv_2p_launch_count()
+    parity.check_lka3d_tokens_bf16("cpu", 1, 32, (7, 6, 16))
+    assert lib.dlka_dwconv_2p_launch_count() - n0 >= 4, (n0, lib.dlka_dwconv_2p_launch_count())   # dw 5^3, dw 7^3 dil 3 and their data gradients
+    torch.manual_seed(3)
+    m = dk.LKA_Attention3d_deform(32)
+    x = torch.randn(1, 6 * 16 * 7, 32).bfloat16()
+    y2 = m(x, 1, 32, 7, 6, 16)
+    monkeypatch.setenv("DLKA_DW_2P", "0")
+    y1 = m(x, 1, 32, 7, 6, 16)
+    assert torch.equal(y1, y2)
+
+
 @pytest.mark.parametrize("C,dims,bf", [(32, (3, 4, 5), False), (64, (2, 4, 3), True)])
 def test_tblock3d_phased_backward_equals_one_call(C, dims, bf):
     """dlka_tblock3d_backward_phase_v (round 5: the engine's data-chain / weight-gradient split for the wrapper block): phase 1 then phase 2 == phase 0."""
