@@ -161,6 +161,18 @@ __global__ __launch_bounds__(256) void cl_dwconv_rows_kernel(DwArgs p)
     }
 }
 
+// Row groups of the TH-row kernels (shared by the kernel and its launcher): `regular` groups h0 = r + TH*DIL*q (r < DIL) over the full blocks of TH*DIL rows and, where 1 .. DIL
+// rows remain behind them (TH == 2), tail groups of two consecutive rows from tail_row0 on; otherwise the remainder is one more (partly empty) block of regular groups.
+struct DwRowGroups { int groups, regular, tail_row0; };
+__host__ __device__ __forceinline__ DwRowGroups dw_row_groups(int H, int TH, int DIL)
+{
+    const int blk = TH * DIL, full = H / blk, rem = H - full * blk;
+    DwRowGroups g;
+    if (TH == 2 && full >= 1 && rem >= 1 && rem <= DIL) { g.regular = full * DIL; g.tail_row0 = full * blk; g.groups = g.regular + (rem + 1) / 2; }
+    else { g.regular = DIL * ((H + blk - 1) / blk); g.tail_row0 = H; g.groups = g.regular; }
+    return g;
+}
+
 // ... and with TH output rows per work-item, h0, h0 + DIL, ...: with the loads lean, the kernel sits on the L1 return path (one 256-byte
 // wave load per segment element: 1.7 GB per launch at 32^3 for 7^3 dil 3), and output rows DIL apart share KH - 1 of their KH input
 // rows — KH + TH - 1 segment loads per tap plane feed TH * KH row products.  The tap plane's KH*KW weights sit in registers for all.
@@ -193,27 +205,34 @@ __global__ __launch_bounds__(256, WL ? 3 : 1) void cl_dwconv_rowsN_kernel(DwArgs
     if (bx < 0) return;
     const int run = bx * rpb + threadIdx.x / cpb;
     const int runs_per_row = cdiv(p.W, TW);
-    const int groups = DIL * cdiv(p.H, TH * DIL);            // row groups per (b, d) plane: h0 = r + TH*DIL*q, r < DIL
+    // row groups per (b, d) plane: h0 = r + TH*DIL*q, r < DIL — and (round 6) the 1 .. DIL rows that remain behind the last full block of TH*DIL rows as TAIL groups of two
+    // rows each, walked one after the other by the same work-item: 32 rows at dilation 3 are 15 + 1 = 16 groups instead of 18 slots, i.e. 2048 waves for the stage-0 volume
+    // instead of 2304 — two per SIMD instead of 2.25 (the SIMDs that took three set the time: scripts/time_dw_quant.py, 43.8 us at H = 32 and 48.3 at H = 48).
+    const DwRowGroups rg = dw_row_groups(p.H, TH, DIL);
+    const int groups = rg.groups;
     const long total = (long)p.B * p.D * groups * runs_per_row;
     if (run >= total || c >= p.C) return;
     const int w0 = (run % runs_per_row) * TW;
     const int gidx = wave_uniform(run / runs_per_row);
     const int grp = gidx % groups, d0 = (gidx / groups) % p.D, b = gidx / (groups * p.D);
-    const int h0 = (grp % DIL) + (grp / DIL) * TH * DIL;
+    const bool tail = grp >= rg.regular;                     // scalar
+    int h0 = tail ? rg.tail_row0 + 2 * (grp - rg.regular) : (grp % DIL) + (grp / DIL) * TH * DIL;
     if (h0 >= p.H) return;                                   // scalar
-
-    float acc[TH][TW];
-    const float bv = p.bias ? p.bias[c] : 0.f;
-#pragma unroll
-    for (int o = 0; o < TH; ++o)
-#pragma unroll
-        for (int t = 0; t < TW; ++t) acc[o][t] = bv;
+    const int npass = tail ? min(2, p.H - h0) : 1;
 
     const int cb = p.C * SB, cbw = p.C * 4;
     const unsigned rowbytes = (unsigned)(p.W * cb);
     const int vbase = (w0 - p.pw) * cb + c * SB;
     const BufRsrc rwt = make_rsrc(p.wp, (size_t)p.kd * KH * KW * cbw);
     const unsigned cv = (unsigned)c * 4u;
+    const float bv = p.bias ? p.bias[c] : 0.f;
+  for (int pass = 0; pass < npass; ++pass, ++h0) {           // (a tail work-item: its two rows, each as a single output row)
+    float acc[TH][TW];
+#pragma unroll
+    for (int o = 0; o < TH; ++o)
+#pragma unroll
+        for (int t = 0; t < TW; ++t) acc[o][t] = bv;
+
     for (int i = 0; i < p.kd; ++i) {
         const int zd = d0 + i * p.dd - p.pd;
         if (zd < 0 || zd >= p.D) continue;                   // scalar
@@ -229,7 +248,7 @@ __global__ __launch_bounds__(256, WL ? 3 : 1) void cl_dwconv_rowsN_kernel(DwArgs
 #pragma unroll
         for (int r = 0; r < NR; ++r) {                       // input row h0 - ph + r*DIL: tap row r - o of output row o
             const int zh = h0 - p.ph + r * DIL;
-            if (zh < 0 || zh >= p.H) continue;               // scalar
+            if (zh < 0 || zh >= p.H || (tail && r >= KH)) continue;   // scalar (a tail pass has no second output row: the rows beyond KH - 1 feed nothing)
             const BufRsrc rr = make_rsrc(plane + (long)zh * p.W * p.C, rowbytes);
             float seg[SEG];
 #pragma unroll
@@ -237,6 +256,7 @@ __global__ __launch_bounds__(256, WL ? 3 : 1) void cl_dwconv_rowsN_kernel(DwArgs
 #pragma unroll
             for (int o = 0; o < TH; ++o) {
                 if (r - o < 0 || r - o >= KH) continue;      // compile time
+                if (o > 0 && tail) continue;                 // scalar
 #pragma unroll
                 for (int k = 0; k < KW; ++k) {
                     const float wk = WL ? wl[((r - o) * KW + k) * 32] : wv[WL ? 0 : r - o][k];
@@ -248,7 +268,7 @@ __global__ __launch_bounds__(256, WL ? 3 : 1) void cl_dwconv_rowsN_kernel(DwArgs
     }
 #pragma unroll
     for (int o = 0; o < TH; ++o) {
-        if (h0 + o * DIL >= p.H) break;                      // scalar
+        if (h0 + o * DIL >= p.H || (o > 0 && tail)) break;   // scalar
         const long obase = (((long)(b * p.D + d0) * p.H + h0 + o * DIL) * p.W + w0) * p.C + c;
         if (p.gelu_x) {
 #pragma unroll
@@ -266,6 +286,7 @@ __global__ __launch_bounds__(256, WL ? 3 : 1) void cl_dwconv_rowsN_kernel(DwArgs
             }
         }
     }
+  }
 }
 
 // ... and with TWO output planes per work-item as well (d0 and d0 + DIL, on top of the two rows h0 and h0 + DIL): the kernel above sits exactly on the L1 return
@@ -599,7 +620,7 @@ static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st
                     return DLKA_OK;
                 }
             }
-            const long runs2 = (long)a.B * a.D * dil_w * cdiv(a.H, th * dil_w) * cdiv(a.W, TW);
+            const long runs2 = (long)a.B * a.D * dw_row_groups(a.H, th, dil_w).groups * cdiv(a.W, TW);
             dim3 grid2((unsigned)cdivl(runs2, rpb), 1, cdiv(a.C, cpb));
             swz(grid2);
             // Small volumes: with 8 outputs along W per work-item the launch is a fraction of a wave per SIMD (16^3 x 64 channels: 576 waves) and the
@@ -613,7 +634,7 @@ static int launch_cl_dwconv_t(const DwArgs &a, int kw, int dil_w, hipStream_t st
 #define DLKA_DW_TW4_7 384
 #endif
             if (!no_tw4 && th == 2 && waves8 < (kw == 5 ? DLKA_DW_TW4_5 : DLKA_DW_TW4_7) && a.W % 4 == 0 && cdiv(a.W, 4) % wpr == 0) {
-                const long runs4 = (long)a.B * a.D * dil_w * cdiv(a.H, th * dil_w) * cdiv(a.W, 4);
+                const long runs4 = (long)a.B * a.D * dw_row_groups(a.H, th, dil_w).groups * cdiv(a.W, 4);
                 dim3 grid4((unsigned)cdivl(runs4, rpb), 1, cdiv(a.C, cpb));
                 swz(grid4);
                 if (kw == 7) { auto k = cl_dwconv_rowsN_kernel<T, 7, 3, 4, 2>; DLKA_LAUNCH(k, grid4, block, 0, st, ax); }

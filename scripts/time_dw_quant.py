@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Wave quantisation of the depthwise row kernel: dw 7^3 dilation 3 / 5^3 at (B = 2, C = 32, D = 32, W = 32) for a sweep of H — waves = B D 3 ceil(H / 6) 4 / 2 (7^3).
+"""Wave quantisation of the depthwise row kernel: dw 7^3 dilation 3 / 5^3 at (B = 2, C = 32, D = 32, W = 32) for a sweep of H — waves = B D groups(H) 4 / 2.
 usage: python scripts/time_dw_quant.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,6 +23,8 @@ for (k, p, d) in ((7, 9, 3), (5, 2, 1)):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 40 * 1e3
-        groups = d * ((H + 2 * d - 1) // (2 * d))
+        blk, full = 2 * d, H // (2 * d)
+        rem = H - full * blk
+        groups = full * d + (rem + 1) // 2 if (full >= 1 and 1 <= rem <= d) else d * ((H + blk - 1) // blk)   # dw_row_groups (cl_dwconv.hip): tail groups since round 6
         waves = 2 * 32 * groups * 4 // 2
         print(f"k {k} H {H:3d}: {us:7.1f} us  waves {waves:5d} = {waves / 1024:.2f} per SIMD   us per 1024 waves {us / (waves / 1024):6.1f}   us per output row-plane {us / H:6.2f}")
