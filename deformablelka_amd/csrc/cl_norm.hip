@@ -721,6 +721,7 @@ __global__ __launch_bounds__(NT) void cl_bn_bwd_apply_q_kernel(const float *__re
 static bool quad_shape_ok(int C, long M = 0) { return (C == 32 || C == 64 || C == 128 || C == 256) && M < (1l << 30); }
 static bool quad_aligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // rows per workgroup pass at width C; grids of the streaming kernels: ~4 passes per workgroup, at most `cap` workgroups
+constexpr long FOLD_WGS = 256;   // grid cap of the quad kernels that end in a workgroup fold + atomics on per-channel sums (see launch_cl_bn_bwd)
 static unsigned quad_grid(long M, int C, int passes, long cap)
 {
     const long rpb = NT / (C / 4);
@@ -764,7 +765,7 @@ int launch_cl_layernorm_bwd(const float *g, const float *g_res, const float *xt,
     }
     if (quad) {
         const long M = (long)B * N;
-        DLKA_QUAD_DISPATCH(C, cl_layernorm_bwd_q_kernel, quad_grid(gpos ? (long)N : M, C, gpos ? 2 : 4, 1024), g, g_res, xt, stats, w, gxt, gw, gb, gpos, M, N, lo)
+        DLKA_QUAD_DISPATCH(C, cl_layernorm_bwd_q_kernel, quad_grid(gpos ? (long)N : M, C, gpos ? 2 : 4, FOLD_WGS), g, g_res, xt, stats, w, gxt, gw, gb, gpos, M, N, lo)
         DLKA_CHECK_LAUNCH();
         return DLKA_OK;
     }
@@ -790,7 +791,7 @@ int launch_cl_scale_residual_bwd(const float *g, const float *e, const float *ga
 {
     if (!zeroed) DLKA_TRY_LAUNCH(launch_zero(ggamma, (size_t)C * 4, st));
     if (quad_shape_ok(C, M) && quad_aligned(g) && quad_aligned(e) && quad_aligned(ge) && quad_aligned(gamma)) {
-        DLKA_QUAD_DISPATCH(C, cl_scale_residual_bwd_q_kernel, quad_grid(M, C, 4, 1024), g, e, gamma, ge, ggamma, M, lo)
+        DLKA_QUAD_DISPATCH(C, cl_scale_residual_bwd_q_kernel, quad_grid(M, C, 4, FOLD_WGS), g, e, gamma, ge, ggamma, M, lo)
         DLKA_CHECK_LAUNCH();
         return DLKA_OK;
     }
@@ -846,7 +847,9 @@ int launch_cl_bn_bwd(const float *g, const float *gmask, const float *x, const f
     const int rpb = NT / (C < NT ? C : NT);
     if (quad_shape_ok(C, M) && quad_aligned(g) && quad_aligned(x) && quad_aligned(y) && quad_aligned(gx) && quad_aligned(gres) && quad_aligned(gres_add) &&
         quad_aligned(stats) && quad_aligned(sums) && quad_aligned(w) && quad_aligned(gmask)) {
-        DLKA_QUAD_DISPATCH(C, cl_bn_bwd_reduce_q_kernel, quad_grid(M, C, 4, 1024), g, gmask, x, y, stats, sums, gres, gres_add, M, N, slope)
+        // At most FOLD_WGS workgroups: every workgroup ends in 2 C fp32 atomics on the same 2 C addresses, which serialise — us at (2, 32^3, 32) for 2048 / 1024 / 512 / 256 / 128
+        // workgroups: 58.0 / 33.2 / 22.0 / 15.0 / 14.7 (round 6; 512 until then)
+        DLKA_QUAD_DISPATCH(C, cl_bn_bwd_reduce_q_kernel, quad_grid(M, C, 4, FOLD_WGS), g, gmask, x, y, stats, sums, gres, gres_add, M, N, slope)
         DLKA_CHECK_LAUNCH();
         DLKA_QUAD_DISPATCH(C, cl_bn_bwd_apply_q_kernel, quad_grid(M, C, 2, 4096), g, gmask, x, y, w, stats, (const float *)sums, gx, gw, gb, M, N, slope, training)
         DLKA_CHECK_LAUNCH();
