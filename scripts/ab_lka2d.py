@@ -46,6 +46,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
             vals.append(round((time.perf_counter() - t0) / 30 * 1e3, 4))
         print("RESULT", json.dumps({"ms_per_step": sorted(vals)[1], "all": vals, "finite": st.health()["finite"]}))
     elif os.environ.get("AB_METRIC") == "tblock":
+        if os.environ.get("AB_OLD_MASK") == "1":   # (round 6 A/B: the Dropout3d multipliers as dropout3d(ones) — four launches per block instead of two)
+            import deformablelka_amd as dk
+            dk.TransformerBlock_3D_single_deform_LKA._draw_drop_mask = lambda self, B, C, dtype, device: torch.nn.functional.dropout3d(
+                torch.ones(B, C, 1, 1, 1, dtype=dtype, device=device), self.conv8[0].p, True).view(B, C)
         r = bench.tblock_metric(2, 10, 3, torch.device("cuda", 0))
         print("RESULT", json.dumps({"value": r["value"], "graph": r.get("hipgraph", {}).get("value")}))
     else:

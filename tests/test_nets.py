@@ -246,6 +246,28 @@ def test_bn_running_statistics_bookkeeping_equals_torchs(momentum):
         assert torch.allclose(a.running_var, b.running_var, rtol=1e-5, atol=1e-6)
 
 
+def _drop_mask_equals_dropout3d(device):
+    """TransformerBlock_3D_single_deform_LKA._draw_drop_mask (bernoulli_ + div_ on an empty tensor: two launches) makes the draw F.dropout3d makes for its
+    (B, C, 1, 1, 1) noise tensor — same values AND the same generator state afterwards, so a net that mixes both stays in step with the reference's
+    (transformerblock.py:598 conv8 = Dropout3d(0.1) + 1x1x1 conv)."""
+    import torch.nn.functional as F
+    import deformablelka_amd as dk
+    m = dk.TransformerBlock_3D_single_deform_LKA(8, 32, 32, 4, dropout_rate=0.1, pos_embed=True)
+    for seed, (B, C) in enumerate([(2, 32), (2, 256), (3, 64), (24, 128)]):
+        torch.manual_seed(seed)
+        ref = F.dropout3d(torch.ones(B, C, 1, 1, 1, device=device), 0.1, True).view(B, C)
+        ref_next = torch.rand(4, device=device)
+        torch.manual_seed(seed)
+        mine = m._draw_drop_mask(B, C, torch.float32, torch.device(device))
+        mine_next = torch.rand(4, device=device)
+        assert torch.equal(ref, mine) and torch.equal(ref_next, mine_next), (seed, B, C)
+        assert set(mine.unique().tolist()) <= {0.0, float(torch.tensor(1.0) / torch.tensor(0.9))}
+
+
+def test_drop_mask_draw_equals_dropout3d():
+    _drop_mask_equals_dropout3d("cpu")
+
+
 def test_eval_reference_checkpoint_helpers(tmp_path):
     """scripts/eval_reference_checkpoint.py (the "DSC vs ref" half of the metric, runnable once the published weights / data are mounted): an nnU-Net-style checkpoint
     file with DataParallel prefixes loads into D_LKA_Former with strict key agreement; Dice per class on a hand-made pair."""

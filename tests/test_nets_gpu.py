@@ -150,3 +150,9 @@ def test_graphed_trainer_iteration_follows_the_eager_one():
     assert all(abs(a - b) <= 2e-2 * abs(a) for a, b in zip(eager[3:], graphed)), (eager, graphed)
     x2 = torch.randn_like(x) * 3
     assert abs(float(it(x2, tgt)) - graphed[-1]) > 0 and torch.equal(it.data, x2)
+
+
+def test_drop_mask_draw_equals_dropout3d_on_device():
+    """The wrapper block's Dropout3d multipliers drawn in two launches are the draw F.dropout3d(ones) makes from the device generator (values and generator state)."""
+    from tests.test_nets import _drop_mask_equals_dropout3d
+    _drop_mask_equals_dropout3d(DEV)
