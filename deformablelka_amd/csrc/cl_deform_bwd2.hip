@@ -885,7 +885,10 @@ __global__ __launch_bounds__(512, FX ? 4 : 2) void cl_deform_gx_kernel(DeformBwd
 // Same MFMA phase and scale (Cauchy-Schwarz bound, see cl_deform_gx_kernel); every contribution is rounded to nearest-even once, from the exact
 // product (the first generation rounds the fp32 product): the window sums agree with the first generation's to a few quanta.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int GX_QW = 24;   // far-sample records per wave (8 floats each)
+#ifndef DLKA_GX_QW
+#define DLKA_GX_QW 24
+#endif
+constexpr int GX_QW = DLKA_GX_QW;   // far-sample records per wave (8 floats each)
 
 // Drains a wave's far-sample queue: lane = (record r0 + (lane >> 5), corner (lane >> 2) & 7, channel lane & 3): every in-volume corner of a
 // queued sample adds Col * weight to grad_input with a global fp32 atomic (grad_input is zero-initialised by the caller).
