@@ -585,6 +585,11 @@ __global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(const float *__
 // branched around, and every step's loads are issued one step ahead of its MFMAs — across segments and rows too (the kernel above waits for its loads
 // at every (tap_d, tap_h): 730 us at 2 x 16 x 64 x 128 x 128 for 184 us of matrix-pipe time).  W % 8 == 0, byte offsets < 2^31.
 // ---------------------------------------------------------------------------------------------
+// B16 (round 6, default): the contraction on the bf16 matrix cores with both operands as two bf16 terms — a lane's EIGHT voxels are exactly the eight k-values it supplies to
+// v_mfma_f32_16x16x32_bf16, so one instruction contracts the whole 32-voxel segment: gout_hi x_hi + gout_lo x_hi + gout_hi x_lo = 3 instructions of 16 cycles per tap where the
+// fp32 form needs 8 of 32 (each product exact in the fp32 accumulator; the dropped lo x lo term is 2^-18 of the product: ~1e-5 on the gradient, the rule the D-LKA block's own
+// weight gradients follow — DESIGN 4.1).  DLKA_EXACT_FP32 keeps the fp32-input MFMAs.
+template <bool B16>
 __global__ __launch_bounds__(256, 2) void conv3_bwd_weight_row_mfma_kernel(const float *__restrict__ x, const float *__restrict__ gout, float *__restrict__ gw,
                                                                            Geom g, int rows_per_wave, float *__restrict__ part)
 {
@@ -620,33 +625,157 @@ __global__ __launch_bounds__(256, 2) void conv3_bwd_weight_row_mfma_kernel(const
         lo = buf_load_f32x4(rg, off);
         hi = buf_load_f32x4(rg, off + 16u);
     };
+    // The operand loads run PD (tap_d, tap_h) steps ahead of their MFMAs, across segments and rows (9 % PD == 0: the ring slot of a step is known at compile time).  Timing-only
+    // ablations of the one-step version (-DDLKA_ABLC): 361 us as built, 338 with the loads alone, 56 with the split + MFMAs alone — the kernel waits for its loads, two waves per
+    // SIMD with four load instructions each in flight are too few for the ~2 us a line takes to arrive under load (profiles/r10_notes.md).
+#ifndef DLKA_WGRAD_PD
+#define DLKA_WGRAD_PD 3
+#endif
+    constexpr int PD = DLKA_WGRAD_PD;
+    static_assert(9 % PD == 0 && PD < 9, "ring slots must be static");
     long r = r0;
     int seg = 0;
-    f32x4 qnl, qnh;
-    XStep nx;
-    request_g(r, seg, qnl, qnh);
-    request_x(r, seg, 0, nx);
+    f32x4 qcl, qch, qnl, qnh;
+    XStep ring[PD];
+    request_g(r, seg, qcl, qch);
+#pragma unroll
+    for (int s0 = 0; s0 < PD; ++s0) request_x(r, seg, s0, ring[s0]);
     while (r < r1) {   // wave-uniform
-        const float q[8] = {qnl[0], qnl[1], qnl[2], qnl[3], qnh[0], qnh[1], qnh[2], qnh[3]};
+        const float q[8] = {qcl[0], qcl[1], qcl[2], qcl[3], qch[0], qch[1], qch[2], qch[3]};
+        bf16x8 qh, ql;
+        if (B16) split_bf16x8(q, qh, ql);
         int sn = seg + 1;
         long rn = r;
         if (sn == nseg) { sn = 0; rn = r + 1; }
 #pragma unroll
         for (int step = 0; step < 9; ++step) {
-            const XStep cx = nx;
-            if (step < 8) request_x(r, seg, step + 1, nx);
-            else { request_g(rn, sn, qnl, qnh); request_x(rn, sn, 0, nx); }
+            const XStep cx = ring[step % PD];
+#ifndef DLKA_ABLC   // -DDLKA_ABLC=bits: TIMING-ONLY ablations (wrong results): 1 no operand loads in the loop, 2 no split / MFMAs in the loop
+#define DLKA_ABLC 0
+#endif
+            if (!(DLKA_ABLC & 1)) {
+                if (step + PD < 9) request_x(r, seg, step + PD, ring[step % PD]);
+                else {
+                    if (step + PD == 9) request_g(rn, sn, qnl, qnh);
+                    request_x(rn, sn, step + PD - 9, ring[step % PD]);
+                }
+            }
             const float c[8] = {cx.lo[0], cx.lo[1], cx.lo[2], cx.lo[3], cx.hi[0], cx.hi[1], cx.hi[2], cx.hi[3]};
             const int t0 = step * 3;
             // tap_w = 0: x[w - 1], 1: x[w], 2: x[w + 1] for the lane's voxel w = w0 + e
+            if (DLKA_ABLC & 2) { acc[t0][0] += c[0] + cx.lft + cx.rgt + c[7] + q[0]; }
+            else if (B16) {
+                const float xm[10] = {cx.lft, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], cx.rgt};   // x[w0 - 1 .. w0 + 8]
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                acc[t0] = mfma_16x16x4(q[e], e ? c[e ? e - 1 : 0] : cx.lft, acc[t0]);
-                acc[t0 + 1] = mfma_16x16x4(q[e], c[e], acc[t0 + 1]);
-                acc[t0 + 2] = mfma_16x16x4(q[e], e < 7 ? c[e < 7 ? e + 1 : 7] : cx.rgt, acc[t0 + 2]);
+                for (int tw = 0; tw < 3; ++tw) {
+                    bf16x8 bh, bl;
+                    split_bf16x8(xm + tw, bh, bl);
+                    acc[t0 + tw] = mfma_16x16x32_bf16(qh, bh, acc[t0 + tw]);
+                    acc[t0 + tw] = mfma_16x16x32_bf16(ql, bh, acc[t0 + tw]);
+                    acc[t0 + tw] = mfma_16x16x32_bf16(qh, bl, acc[t0 + tw]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    acc[t0] = mfma_16x16x4(q[e], e ? c[e ? e - 1 : 0] : cx.lft, acc[t0]);
+                    acc[t0 + 1] = mfma_16x16x4(q[e], c[e], acc[t0 + 1]);
+                    acc[t0 + 2] = mfma_16x16x4(q[e], e < 7 ? c[e < 7 ? e + 1 : 7] : cx.rgt, acc[t0 + 2]);
+                }
             }
         }
+        qcl = qnl; qch = qnh;
         r = rn; seg = sn;
+    }
+    conv3_wgrad_fold_and_add(acc, gw, g, lane, i, kg, ci_ok, part);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 6 — the same weight gradient, INPUT-row stationary.  The kernel above is bound by its operand loads (timing-only ablations at 2 x 16 x 64 x 128 x 128: 361 us as built, 338 with
+// the loads alone, 56 with the split + MFMAs alone; a three-step prefetch ring changes nothing: 373) — every x row is requested nine times per output row, once per (tap_d, tap_h).
+// Here a wave that owns `rows` consecutive h-rows of one (b, d) plane walks the rows + 2 INPUT rows zh of each of the three d-planes once per segment: x row (d + td - 1, zh) is the
+// tap_h = 0 / 1 / 2 operand of the output rows zh + 1 / zh / zh - 1, whose grad_out rows sit in registers as bf16 pairs (a ring of three, split once per row): 3 (rows + 2) x-row
+// requests per segment instead of 9 rows (30 instead of 72 at rows = 8), each feeding up to 27 MFMAs.  Same products and accumulators as the B16 form above (sums in another order).
+// Needs H % rows == 0 (a wave's rows in one plane); the launcher falls back otherwise.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv3_bwd_weight_rows_b16_kernel(const float *__restrict__ x, const float *__restrict__ gout, float *__restrict__ gw, Geom g,
+                                                                           int rows, float *__restrict__ part)
+{
+    const int lane = threadIdx.x & 63, i = lane & 15, kg = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nrows = (long)g.B * g.D * g.H;
+    const long r0 = (long)wave * rows;
+    const int nrw = r0 < nrows ? rows : 0;   // (H % rows == 0: whole groups only; a wave beyond the volume walks nothing and still joins the fold)
+    f32x4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool co_ok = i < g.Cout, ci_ok = i < g.C;
+    const unsigned plane = (unsigned)(g.D * g.H * g.W);
+    const int nseg = (g.W + 31) >> 5;
+    const BufRsrc rx = make_rsrc(x, (size_t)g.B * g.C * plane * 4), rg = make_rsrc(gout, (size_t)g.B * g.Cout * plane * 4);
+    const int h0 = (int)(r0 % g.H), d = (int)((r0 / g.H) % g.D), b = nrw ? (int)(r0 / ((long)g.H * g.D)) : 0;
+    struct XStep { f32x4 lo, hi; float lft, rgt; };
+    // x row (d + td - 1, zh = h0 - 1 + zi) of segment seg: the lane's eight voxels and their two neighbours
+    auto request_x = [&](int seg, int zi, int td, XStep &o) {
+        const int zd = d + td - 1, zh = h0 - 1 + zi, w0 = 32 * seg + 8 * kg;
+        const bool ok = zi < nrw + 2 && zd >= 0 && zd < g.D && zh >= 0 && zh < g.H && ci_ok && w0 < g.W;
+        const unsigned off = ok ? (((unsigned)b * g.C + i) * plane + (unsigned)((zd * g.H + zh) * g.W + w0)) * 4u : DLKA_OOB;
+        o.lo = buf_load_f32x4(rx, off);
+        o.hi = buf_load_f32x4(rx, off + 16u);
+        o.lft = buf_load_f32(rx, (ok && w0 > 0) ? off - 4u : DLKA_OOB);
+        o.rgt = buf_load_f32(rx, (ok && w0 + 8 < g.W) ? off + 32u : DLKA_OOB);
+    };
+    // grad_out row h0 + k of the wave (zeros outside its range: those rows belong to other waves)
+    auto request_g = [&](int seg, int k, f32x4 &lo, f32x4 &hi) {
+        const int w0 = 32 * seg + 8 * kg;
+        const bool ok = k >= 0 && k < nrw && co_ok && w0 < g.W;
+        const unsigned off = ok ? (((unsigned)b * g.Cout + i) * plane + (unsigned)((d * g.H + h0 + k) * g.W + w0)) * 4u : DLKA_OOB;
+        lo = buf_load_f32x4(rg, off);
+        hi = buf_load_f32x4(rg, off + 16u);
+    };
+    auto split_row = [&](const f32x4 &lo, const f32x4 &hi, bf16x8 &qh, bf16x8 &ql) {
+        const float q[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        split_bf16x8(q, qh, ql);
+    };
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int seg = 0; seg < (nrw ? nseg : 0); ++seg) {   // wave-uniform
+        // grad_out ring: rows zh - 1, zh, zh + 1 of the current input row zh = h0 - 1 + zi, i.e. wave rows zi - 2, zi - 1, zi
+        bf16x8 gmh, gml, g0h, g0l, gph, gpl;
+        split_row(z4, z4, gmh, gml);
+        split_row(z4, z4, g0h, g0l);
+        f32x4 nl, nh;
+        request_g(seg, 0, nl, nh);
+        XStep nx;
+        request_x(seg, 0, 0, nx);
+        split_row(nl, nh, gph, gpl);
+        request_g(seg, 1, nl, nh);
+        for (int zi = 0; zi < nrw + 2; ++zi) {
+#pragma unroll
+            for (int td = 0; td < 3; ++td) {
+                const XStep cx = nx;
+                if (td < 2) request_x(seg, zi, td + 1, nx);
+                else request_x(seg, zi + 1, 0, nx);   // (zi + 1 == nrw + 2: zeros, no traffic)
+                const float xm[10] = {cx.lft, cx.lo[0], cx.lo[1], cx.lo[2], cx.lo[3], cx.hi[0], cx.hi[1], cx.hi[2], cx.hi[3], cx.rgt};   // x[w0 - 1 .. w0 + 8]
+                bf16x8 bh[3], bl[3];
+#pragma unroll
+                for (int tw = 0; tw < 3; ++tw) split_bf16x8(xm + tw, bh[tw], bl[tw]);
+                // tap_h = th: output row zh + 1 - th = wave row zi - th
+#pragma unroll
+                for (int th = 0; th < 3; ++th) {
+                    if ((unsigned)(zi - th) >= (unsigned)nrw) continue;   // (uniform) that output row is another wave's
+                    const bf16x8 qh = th == 0 ? gph : (th == 1 ? g0h : gmh), ql = th == 0 ? gpl : (th == 1 ? g0l : gml);
+                    const int t0 = (td * 3 + th) * 3;
+#pragma unroll
+                    for (int tw = 0; tw < 3; ++tw) {
+                        acc[t0 + tw] = mfma_16x16x32_bf16(qh, bh[tw], acc[t0 + tw]);
+                        acc[t0 + tw] = mfma_16x16x32_bf16(ql, bh[tw], acc[t0 + tw]);
+                        acc[t0 + tw] = mfma_16x16x32_bf16(qh, bl[tw], acc[t0 + tw]);
+                    }
+                }
+            }
+            gmh = g0h; gml = g0l; g0h = gph; g0l = gpl;
+            split_row(nl, nh, gph, gpl);          // wave row zi + 1 (zeros beyond the wave's rows)
+            request_g(seg, zi + 2, nl, nh);
+        }
     }
     conv3_wgrad_fold_and_add(acc, gw, g, lane, i, kg, ci_ok, part);
 }
@@ -682,8 +811,18 @@ int launch_conv_bwd_weight(const T *x, const T *gout, float *gw32, const Geom &g
             const int nwg = (int)cdivl(waves, 4);
             if (conv3_wgrad_row_shape(g)) {
                 if (part && conv_bwd_weight_part_floats(g, 4) == 0) part = nullptr;
-                DLKA_LAUNCH(conv3_bwd_weight_row_mfma_kernel, dim3((unsigned)nwg), dim3(256), 0, st, reinterpret_cast<const float *>(x),
-                            reinterpret_cast<const float *>(gout), gw32, g, rpw, part);
+                static const bool exact = getenv("DLKA_EXACT_FP32") != nullptr;
+                static const bool rows_off = [] { const char *e = getenv("DLKA_CONV3_WGRAD_ROWS"); return e && e[0] == '0'; }();   // (A/B: 0 = the output-row form)
+                if (!exact && !rows_off && g.H % rpw == 0) {
+                    DLKA_LAUNCH(conv3_bwd_weight_rows_b16_kernel, dim3((unsigned)nwg), dim3(256), 0, st, reinterpret_cast<const float *>(x),
+                                reinterpret_cast<const float *>(gout), gw32, g, rpw, part);
+                } else if (exact) {
+                    DLKA_LAUNCH(conv3_bwd_weight_row_mfma_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, st, reinterpret_cast<const float *>(x),
+                                reinterpret_cast<const float *>(gout), gw32, g, rpw, part);
+                } else {
+                    DLKA_LAUNCH(conv3_bwd_weight_row_mfma_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, st, reinterpret_cast<const float *>(x),
+                                reinterpret_cast<const float *>(gout), gw32, g, rpw, part);
+                }
                 DLKA_CHECK_LAUNCH();
                 if (part) {
                     DLKA_LAUNCH(conv3_wgrad_reduce_kernel, dim3(27, (unsigned)(nwg >= 256 ? 16 : 4)), dim3(256), 0, st, (const float *)part, gw32, nwg, g.C, g.Cout);

@@ -45,6 +45,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
             torch.cuda.synchronize()
             vals.append(round((time.perf_counter() - t0) / 30 * 1e3, 4))
         print("RESULT", json.dumps({"ms_per_step": sorted(vals)[1], "all": vals, "finite": st.health()["finite"]}))
+    elif os.environ.get("AB_METRIC") == "fullnet":   # the whole D_LKA_Former trainer iteration (bench.fullnet_metric, eager)
+        r = bench.fullnet_metric(2, 8, torch.device("cuda", 0))
+        print("RESULT", json.dumps({"value": r["value"], "ms_per_step": r["ms_per_step"], "loss": r.get("loss")}))
     elif os.environ.get("AB_METRIC") == "tblock":
         if os.environ.get("AB_OLD_MASK") == "1":   # (round 6 A/B: the Dropout3d multipliers as dropout3d(ones) — four launches per block instead of two)
             import deformablelka_amd as dk

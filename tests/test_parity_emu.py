@@ -74,6 +74,9 @@ CONV = [
     (1, 16, 9, (2, 5, 8), 3, 1, 1, 1, 1),       # ... one lane group per row, ragged output channels
     (2, 8, 5, (1, 1, 16), 3, 1, 1, 1, 1),       # ... a single row per sample: every neighbour row is padding
     (1, 9, 8, (16, 17, 8), 3, 1, 1, 1, 1),      # ... enough rows for the weight gradient's per-workgroup tiles + fold launch (conv3_wgrad_reduce_kernel)
+    (2, 16, 16, (3, 8, 40), 3, 1, 1, 1, 1),     # H % 8 == 0: the input-row-stationary weight gradient (conv3_bwd_weight_rows_b16_kernel), two segments, the second ragged
+    (1, 5, 14, (2, 16, 32), 3, 1, 1, 1, 1),     # ... two waves per plane (their border rows belong to each other), ragged channel counts
+    (1, 16, 16, (1, 24, 128), 3, 1, 1, 1, 1),   # ... one plane (both d-neighbours are padding), four segments
 ]
 
 

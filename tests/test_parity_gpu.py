@@ -82,6 +82,8 @@ CONV = [
     (2, 16, 16, (6, 9, 128), 3, 1, 1, 1, 1),                  # the net's full-resolution plumbing convs: 128-wide rows in registers (conv3_row_mfma_kernel)
     (1, 12, 16, (5, 4, 40), 3, 1, 1, 1, 1),                   # ... partial lane groups, ragged channels
     (1, 16, 16, (4, 5, 36), 3, 1, 1, 1, 1),                   # W % 8 != 0: the per-voxel-tile MFMA kernel / thread-per-voxel forward
+    (2, 16, 16, (5, 32, 128), 3, 1, 1, 1, 1),                 # H % 8 == 0: the input-row-stationary weight gradient (conv3_bwd_weight_rows_b16_kernel), full 128-wide rows, four waves per plane
+    (1, 5, 14, (2, 16, 40), 3, 1, 1, 1, 1),                   # ... ragged channels, a ragged second segment
 ]
 
 
