@@ -212,8 +212,12 @@ __global__ __launch_bounds__(256, 2) void conv3_row_mfma_kernel(const float *__r
         request(0, lo, hi);
 #pragma unroll
         for (int step = 0; step < 36; ++step) {
-            if (step + 1 < 36) request(step + 1, nlo, nhi);
+#ifndef DLKA_ABLR   // -DDLKA_ABLR=bits: TIMING-ONLY ablations (wrong results): 1 no operand loads in the loop, 2 no MFMAs in the loop
+#define DLKA_ABLR 0
+#endif
+            if (step + 1 < 36 && !(DLKA_ABLR & 1)) request(step + 1, nlo, nhi);
             const int t0 = (step / 4) * 3, s4 = step & 3;
+            if (DLKA_ABLR & 2) { acc[0][0] += lo[0] + hi[3]; lo = nlo; hi = nhi; continue; }
             const float xv[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             const float el = row_shr1(xv[7]), er = row_shl1(xv[0]);
 #pragma unroll

@@ -47,6 +47,35 @@ def get_output_padding(kernel_size, stride, padding):
     return o if len(o) > 1 else o[0]
 
 
+class _RowsMatmul(torch.autograd.Function):
+    """``y = a @ w`` for a tall ``a`` [M, K] (M = voxels of a batch, K <= a few hundred) and a small ``w`` [K, N] — the GEMM behind the kernel == stride convolutions below.
+    autograd's own weight gradient ``a^T @ gy`` is ONE GEMM with a 65 536-long contraction and a 32 x 512 (or 32 x 32) result: rocBLAS runs it at 225 - 240 us at the net's
+    full-resolution layers (the stem and the last up-sampling), a fifth of the iteration's rocBLAS time.  Here the rows are cut into chunks of 1024, the chunk products are one
+    batched GEMM and their sum one reduction: 47 us (``scripts/time_upconv_gemms.py``).  Same products; the row sum is formed in another order (fp32 rounding only)."""
+
+    CHUNK = 1024
+
+    @staticmethod
+    def forward(ctx, a, w):
+        ctx.save_for_backward(a, w)
+        return torch.mm(a, w)
+
+    @staticmethod
+    def backward(ctx, gy):
+        a, w = ctx.saved_tensors
+        ga = gw = None
+        if ctx.needs_input_grad[0]:
+            ga = torch.mm(gy, w.t())
+        if ctx.needs_input_grad[1]:
+            M, c = a.shape[0], _RowsMatmul.CHUNK
+            gy = gy.contiguous()
+            if M >= 16 * c and M % c == 0 and a.is_contiguous():
+                gw = torch.bmm(a.view(M // c, c, -1).transpose(1, 2), gy.view(M // c, c, -1)).sum(0)
+            else:
+                gw = torch.mm(a.t(), gy)
+        return ga, gw
+
+
 class Convolution(nn.Sequential):
     """``monai.networks.blocks.Convolution(..., conv_only=True)``: a Sequential with ONE child named ``conv`` (the parameters live there, so
     the ``state_dict`` keys are the reference's).
@@ -89,7 +118,7 @@ class Convolution(nn.Sequential):
             if k == s and p == (0, 0, 0) and tuple(c.output_padding) == (0, 0, 0) and c.groups == 1:
                 D, H, W = x.shape[2:]
                 Cout = c.weight.shape[1]
-                y = torch.matmul(x.permute(0, 2, 3, 4, 1).reshape(-1, Cin), c.weight.reshape(Cin, -1))            # (B D H W, Cout kd kh kw)
+                y = _RowsMatmul.apply(x.permute(0, 2, 3, 4, 1).reshape(-1, Cin), c.weight.reshape(Cin, -1))       # (B D H W, Cout kd kh kw)
                 y = y.reshape(B, D, H, W, Cout, *k).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(B, Cout, D * k[0], H * k[1], W * k[2])
                 return y if c.bias is None else y + c.bias.view(1, -1, 1, 1, 1)
             return c(x)
@@ -106,7 +135,7 @@ class Convolution(nn.Sequential):
         if k == s and p == (0, 0, 0) and all(n % kk == 0 for n, kk in zip(x.shape[2:], k)):
             D, H, W = (n // kk for n, kk in zip(x.shape[2:], k))
             cols = x.reshape(B, Cin, D, k[0], H, k[1], W, k[2]).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * D * H * W, -1)   # patches
-            y = torch.matmul(cols, c.weight.reshape(Cout, -1).t()).reshape(B, D, H, W, Cout).permute(0, 4, 1, 2, 3).contiguous()
+            y = _RowsMatmul.apply(cols, c.weight.reshape(Cout, -1).t()).reshape(B, D, H, W, Cout).permute(0, 4, 1, 2, 3).contiguous()
             return y if c.bias is None else y + c.bias.view(1, -1, 1, 1, 1)
         if s == (1, 1, 1):
             from . import nn_ops

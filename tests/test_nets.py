@@ -268,6 +268,29 @@ def test_drop_mask_draw_equals_dropout3d():
     _drop_mask_equals_dropout3d("cpu")
 
 
+def test_rows_matmul_chunked_weight_gradient():
+    """network._RowsMatmul (the GEMM behind the kernel == stride convs: weight gradient as a batched GEMM over 1024-row chunks + a sum) against plain matmul autograd, fp64:
+    chunked sizes, a size below the threshold, a size that is not a multiple of the chunk."""
+    from deformablelka_amd.network import _RowsMatmul
+    torch.manual_seed(0)
+    for M, K, N in ((16384, 32, 48), (20480, 8, 16), (4096, 32, 64), (16384 + 512, 16, 8)):
+        a = torch.randn(M, K, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(K, N, dtype=torch.float64, requires_grad=True)
+        gy = torch.randn(M, N, dtype=torch.float64)
+        y = _RowsMatmul.apply(a, w)
+        y.backward(gy)
+        a2, w2 = a.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+        y2 = a2 @ w2
+        y2.backward(gy)
+        assert torch.equal(y, y2) and torch.equal(a.grad, a2.grad)
+        assert (w.grad - w2.grad).abs().max().item() <= 1e-12 * w2.grad.abs().max().item()
+    a = torch.randn(16384, 4, dtype=torch.float64)   # a frozen weight: no weight gradient is formed
+    w = torch.randn(4, 4, dtype=torch.float64)
+    a.requires_grad_(True)
+    _RowsMatmul.apply(a, w).sum().backward()
+    assert a.grad is not None
+
+
 def test_eval_reference_checkpoint_helpers(tmp_path):
     """scripts/eval_reference_checkpoint.py (the "DSC vs ref" half of the metric, runnable once the published weights / data are mounted): an nnU-Net-style checkpoint
     file with DataParallel prefixes loads into D_LKA_Former with strict key agreement; Dice per class on a hand-made pair."""

@@ -156,3 +156,29 @@ def test_drop_mask_draw_equals_dropout3d_on_device():
     """The wrapper block's Dropout3d multipliers drawn in two launches are the draw F.dropout3d(ones) makes from the device generator (values and generator state)."""
     from tests.test_nets import _drop_mask_equals_dropout3d
     _drop_mask_equals_dropout3d(DEV)
+
+
+@pytest.mark.parametrize("kind", ["down", "up"])
+def test_kernel_equals_stride_convs_gemm_path_vs_torch_layers(kind):
+    """network.Convolution's GEMM re-expressions of the kernel == stride convs (stem / down-sampling: patchify + GEMM; up-sampling: GEMM + depth-to-space; weight gradient through
+    the chunked batched GEMM of network._RowsMatmul: >= 16 384 rows) against the stock torch layers: output and all gradients."""
+    from deformablelka_amd.network import Convolution
+    torch.manual_seed(0)
+    if kind == "down":
+        m = Convolution(4, 32, (2, 4, 4), (2, 4, 4)).to(DEV)
+        x = torch.randn(2, 4, 32, 128, 128, device=DEV, requires_grad=True)     # 2 x 16 x 32 x 32 = 32 768 rows
+    else:
+        m = Convolution(32, 16, (2, 4, 4), (2, 4, 4), is_transposed=True).to(DEV)
+        x = torch.randn(2, 32, 16, 32, 32, device=DEV, requires_grad=True)      # 32 768 rows
+    y = m(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    gx, gw = x.grad.clone(), m.conv.weight.grad.clone()
+    x.grad = None
+    m.conv.weight.grad = None
+    m.gemm_path = False
+    y2 = m(x)
+    y2.backward(gy)
+    assert (y - y2).abs().max().item() <= 1e-4 * y2.abs().max().item()
+    assert (gx - x.grad).abs().max().item() <= 1e-3 * x.grad.abs().max().item()
+    assert (gw - m.conv.weight.grad).abs().max().item() <= 1e-3 * m.conv.weight.grad.abs().max().item()
