@@ -182,8 +182,7 @@ class GroupNorm(nn.GroupNorm):
         """The long-row path (any device the library runs on: the CPU tests call it on the emulator build)."""
         from . import nn_ops
         B, C, G = x.shape[0], x.shape[1], self.num_groups
-        y, _ = nn_ops.batch_norm_train(x.contiguous().view(1, B * G, -1), None, None, self.eps)
-        y = y.view_as(x)
+        y, _ = nn_ops.batch_norm_train(x.contiguous(), None, None, self.eps, planes=(B * G,))   # (y in x's shape, not a view of the op's output: see nn_ops)
         if self.weight is not None:
             shape = (1, C) + (1,) * (x.dim() - 2)
             y = torch.addcmul(self.bias.view(shape), y, self.weight.view(shape))
@@ -202,8 +201,8 @@ class InstanceNorm3d(nn.InstanceNorm3d):
             return super().forward(x)
         from . import nn_ops
         B, C = x.shape[:2]
-        y, _ = nn_ops.batch_norm_train(x.contiguous().view(1, B * C, *x.shape[2:]), None, None, self.eps)
-        return y.view_as(x)
+        y, _ = nn_ops.batch_norm_train(x.contiguous(), None, None, self.eps, planes=(B * C,))   # (y in x's shape, not a view of the op's output: see nn_ops)
+        return y
 
 
 class BatchNorm3d(nn.BatchNorm3d):

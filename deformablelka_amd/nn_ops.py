@@ -59,8 +59,18 @@ class _BatchNormPlanarFn(Function):
     (mean, unbiased variance) the module folds into its running estimates."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
-        y, stats = ops.batchnorm_planar_forward(x, weight, bias, eps)
+    def forward(ctx, x, weight, bias, eps, planes=None):
+        # planes = (rows,): x (any shape, contiguous) is normalised as the tensor [1, rows, numel / rows] — InstanceNorm / GroupNorm rows — and y comes back in x's OWN
+        # shape.  The reshape happens inside the Function on purpose: a caller-side ``y.view_as(x)`` makes y a view of this Function's output, and the in-place
+        # LeakyReLU / ``out += residual`` that follow in UnetResBlock then run their backward through CopySlices + AsStridedBackward — four extra full-resolution
+        # copies per site (0.4 ms of the full net's iteration, scripts/prof_net_copies.py).
+        ctx.shape = None
+        out = None
+        if planes is not None:
+            ctx.shape = tuple(x.shape)
+            out = torch.empty_like(x)            # (y is allocated in x's shape and handed to the kernel: a ``.view()`` of the op's result would again be a view)
+            x = x.view(1, int(planes[0]), -1)
+        y, stats = ops.batchnorm_planar_forward(x, weight, bias, eps, out=out)
         ctx.save_for_backward(x, weight, stats)
         ctx.affine = weight is not None
         ctx.mark_non_differentiable(stats)
@@ -70,12 +80,15 @@ class _BatchNormPlanarFn(Function):
     @once_differentiable
     def backward(ctx, gy, _gstats):
         x, weight, stats = ctx.saved_tensors
-        gx, gw, gb = ops.batchnorm_planar_backward(gy.contiguous(), x, weight, stats, ctx.affine)
-        return gx, gw, gb, None
+        gy = gy.contiguous()
+        if ctx.shape is not None:
+            gy = gy.view(x.shape)
+        gx, gw, gb = ops.batchnorm_planar_backward(gy, x, weight, stats, ctx.affine)
+        return (gx if ctx.shape is None else gx.view(ctx.shape)), gw, gb, None, None
 
 
-def batch_norm_train(x, weight, bias, eps=1e-5):
-    return _BatchNormPlanarFn.apply(x, weight, bias, eps)
+def batch_norm_train(x, weight, bias, eps=1e-5, planes=None):
+    return _BatchNormPlanarFn.apply(x, weight, bias, eps, planes)
 
 
 class _PointwisePlanarFn(Function):

@@ -299,12 +299,17 @@ def gelu_backward(x, gy):
 PLANAR_PW_CIN = (1, 2, 4, 8, 14, 16, 32)
 
 
-def batchnorm_planar_forward(x, weight, bias, eps=1e-5):
-    """x (B, C, *spatial) fp32 contiguous -> y, stats (4, C) = mean, rstd, unbiased variance, mean - pivot (batch statistics)."""
+def batchnorm_planar_forward(x, weight, bias, eps=1e-5, out=None):
+    """x (B, C, *spatial) fp32 contiguous -> y, stats (4, C) = mean, rstd, unbiased variance, mean - pivot (batch statistics).
+    out: a contiguous fp32 tensor of x's element count (any shape) that receives y instead of a fresh tensor of x's shape."""
     L.require_device(x)
     B, C = x.shape[:2]
     N = x[0, 0].numel()
-    y = torch.empty_like(x)
+    if out is None:
+        y = torch.empty_like(x)
+    else:
+        assert out.is_contiguous() and out.numel() == x.numel() and out.dtype == x.dtype and out.device == x.device
+        y = out
     stats = torch.empty(4, C, dtype=torch.float32, device=x.device)
     scratch = torch.empty(2 * C, dtype=torch.float32, device=x.device)
     L.check(L.get_lib().dlka_batchnorm_planar_forward(L.ptr(x), L.ptr(weight), L.ptr(bias), L.ptr(stats), L.ptr(y), L.ptr(scratch), B, C, N, float(eps),

@@ -38,3 +38,15 @@ for ev in prof.events():
         a = acc.setdefault(ev.name, [0, 0.0]); a[0] += 1; a[1] += ev.device_time
 for k, v in acc.items():
     print(k, v)
+print("== large copies / adds and the op chain that issued them (cpu_parent names, innermost first)")
+seen = {}
+for ev in prof.events():
+    if ev.name in ("aten::copy_", "aten::clone", "aten::add", "aten::add_", "aten::contiguous") and ev.device_time_total > 25.0:
+        chain, p = [], ev.cpu_parent
+        while p is not None and len(chain) < 6:
+            chain.append(p.name[:60])
+            p = p.cpu_parent
+        key = (ev.name, str(ev.input_shapes)[:60], " <- ".join(chain))
+        a = seen.setdefault(key, [0, 0.0]); a[0] += 1; a[1] += ev.device_time_total
+for (n, shp, ch), (c, t) in sorted(seen.items(), key=lambda kv: -kv[1][1])[:40]:
+    print(f"{n:16s} n={c:3d} dev={t:8.1f} us  {shp}  {ch}")

@@ -560,6 +560,31 @@ def test_instancenorm_planar_full_resolution_vs_torch():
 
 
 @pytest.mark.gpu
+def test_instancenorm_followed_by_inplace_ops_vs_torch():
+    """UnetResBlock's pattern around the planar InstanceNorm3d (dynunet_block.py:55-68): in-place LeakyReLU on the norm's output, ``out += residual``, in-place LeakyReLU
+    again.  The norm returns its result in x's own shape from inside its autograd Function (no caller-side view of the op's output), so the in-place ops neither fail nor
+    detour through CopySlices; output and both input gradients against the stock layers."""
+    import torch.nn as nn
+    from deformablelka_amd.network import InstanceNorm3d
+    torch.manual_seed(0)
+    x = torch.randn(2, 16, 16, 32, 32, device="cuda") * 1.3 + 0.2
+    res = torch.randn_like(x)
+    gy = torch.randn_like(x)
+    outs = []
+    for norm in (InstanceNorm3d(16).cuda(), nn.InstanceNorm3d(16).cuda()):
+        act = nn.LeakyReLU(0.01, inplace=True)
+        xa, ra = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        out = act(norm(xa * 1.0))
+        out = norm(out * 1.0)
+        out += ra * 1.0
+        out = act(out)
+        out.backward(gy)
+        outs.append((out.detach(), xa.grad, ra.grad))
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("groups,shape", [(1, (2, 32, 32, 32, 32)), (2, (3, 8, 16, 64, 64)), (32, (2, 64, 16, 16, 16))])
 def test_groupnorm_long_rows_vs_torch(groups, shape):
     """network.GroupNorm (the stem's one-group norm over 2 x 32 x 32^3: planar statistics kernels + affine; the short-row case stays on the stock
