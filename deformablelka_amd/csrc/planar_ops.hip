@@ -256,6 +256,26 @@ __global__ __launch_bounds__(PL_THREADS) void pl_pw_bwd_weight_kernel(const floa
             for (int s = 0; s < 4; ++s) acc[t] = mfma_16x16x4(q[s], xv[s], acc[t]);
         }
     }
+    // the workgroup's waves fold their tiles through LDS: one atomic per output and WORKGROUP (round 6: the run per workgroup went from 16 384 to 4096 voxels — 128 workgroups
+    // left half the chip idle at 2 x 64 x 128 x 128 — and one atomic per wave would then be 460 k atomics on 224 addresses)
+    constexpr int NW = PL_THREADS / 64;
+    __shared__ __attribute__((aligned(16))) float red[NW - 1][NCT * 64 * 4 + 64];
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) *reinterpret_cast<f32x4 *>(&red[wave - 1][(t * 64 + lane) * 4]) = acc[t];
+        red[wave - 1][NCT * 256 + lane] = sb;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) {
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) {
+            const f32x4 o = *reinterpret_cast<const f32x4 *>(&red[w][(t * 64 + lane) * 4]);
+            acc[t][0] += o[0]; acc[t][1] += o[1]; acc[t][2] += o[2]; acc[t][3] += o[3];
+        }
+        sb += red[w][NCT * 256 + lane];
+    }
     // D layout: column j = lane & 15 (ci within the tile), rows 4 kg + r (co)
 #pragma unroll
     for (int t = 0; t < NCT; ++t) {
@@ -303,7 +323,10 @@ int launch_pl_pw_backward(const float *x, const float *w, const float *g, float 
         if (CO > 16 || CI > 64) return DLKA_ERR_UNSUPPORTED;
         if (launch_zero(gw, (size_t)CO * CI * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
         if (gb && launch_zero(gb, (size_t)CO * 4, st) != DLKA_OK) return DLKA_ERR_LAUNCH;
-        const int chunk = 16384;   // voxels per workgroup: 4096 per wave (a multiple of 16)
+        // voxels per workgroup (a multiple of 16 per wave): the longest run that still gives the chip a workgroup per CU (16 384 left 128 workgroups at
+        // 2 x 64 x 128 x 128 and 16 at the 32 -> 14 head's 2 x 32 x 64 x 64: 144 / 150 us; now 78 / see notes)
+        int chunk = 16384;
+        while (chunk > 1024 && cdivl(N, chunk) * B < 256) chunk /= 4;
         const dim3 grid((unsigned)cdivl(N, chunk), B);
         const int nct = cdiv(CI, 16);
         if (nct == 1) { auto k = pl_pw_bwd_weight_kernel<1>; DLKA_LAUNCH(k, grid, dim3(PL_THREADS), 0, st, g, x, gw, gb, CO, CI, N, chunk); }
