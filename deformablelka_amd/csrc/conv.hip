@@ -239,6 +239,100 @@ __global__ __launch_bounds__(256, 2) void conv3_row_mfma_kernel(const float *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 6 — the DATA gradient of the same conv on the bf16 matrix cores with both operands as two bf16 terms (the rule the D-LKA block's own gradients follow, DESIGN 4.1: ~1e-5
+// against the 1e-3 gradient contract; the forward pass keeps the fp32-input MFMAs above).  Timing-only ablations of conv3_row_mfma_kernel at 2 x 16 x 64 x 128 x 128 said it is
+// bound by its 864 fp32 MFMAs per row (288 us as built, 295 without the loads, 162 with the loads alone).  Here a lane's FOUR contraction channels 4 s + kg are half of the eight
+// k-values it supplies to v_mfma_f32_16x16x32_bf16 and the other half carries a second term:  A = [w_hi | w_lo] (one 16-byte operand per tap, built once),
+// B1 = [g_hi | g_hi], B2 = [g_lo | g_lo]:  A B1 + A B2 = (w_hi + w_lo)(g_hi + g_lo) — two instructions of 16 cycles per (tile, tap) instead of four of 32.  The B operands of
+// position p (voxel 8 j + p, p = -1 .. 8) are built when the walk reaches it and serve the tiles p + 1, p, p - 1 (tap_w = 0, 1, 2).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv3_row_dgrad_b16_kernel(const float *__restrict__ in, const float *__restrict__ w, float *__restrict__ out, Geom g, int rows_per_wave)
+{
+    const int lane = threadIdx.x & 63, j = lane & 15, kg = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int CI = g.Cout, CO = g.C;   // (the data gradient contracts the conv's OUTPUT channels)
+    bf16x8 areg[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        float v[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int i = j, k = 4 * s4 + kg;
+            v[s4] = (i < CO && k < CI) ? w[((long)k * g.C + i) * 27 + (26 - t)] : 0.f;
+        }
+        // [w_hi | w_lo]: the high terms of (w, w - bf16(w))
+        const float a8[8] = {v[0], v[1], v[2], v[3], v[0] - bf16_value(bf16_bits(v[0])), v[1] - bf16_value(bf16_bits(v[1])), v[2] - bf16_value(bf16_bits(v[2])),
+                             v[3] - bf16_value(bf16_bits(v[3]))};
+        bf16x8 unused;
+        split_bf16x8(a8, areg[t], unused);
+    }
+    const long nrows = (long)g.B * g.D * g.H;
+    const long r0 = (long)wave * rows_per_wave, r1 = r0 + rows_per_wave < nrows ? r0 + rows_per_wave : nrows;
+    const unsigned plane = (unsigned)(g.D * g.H * g.W);
+    const bool jok = 8 * j < g.W;
+    const BufRsrc rin = make_rsrc(in, (size_t)g.B * CI * plane * 4), rout = make_rsrc(out, (size_t)g.B * CO * plane * 4);
+    unsigned lane_off[4];   // channel plane + position in the row, bytes
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) lane_off[s4] = (jok && 4 * s4 + kg < CI) ? ((unsigned)(4 * s4 + kg) * plane + 8u * j) * 4u : DLKA_OOB;
+    struct Raw { f32x4 lo[4], hi[4]; };   // the lane's eight voxels of its four channels
+    for (long r = r0; r < r1; ++r) {
+        const int h = (int)(r % g.H), d = (int)((r / g.H) % g.D), b = (int)(r / ((long)g.H * g.D));
+        const unsigned in_b = (unsigned)b * (unsigned)CI * plane * 4u;
+        f32x4 acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto request = [&](int step, Raw &o) {
+            const int td = step / 3, th = step % 3;
+            const int zd = d + td - 1, zh = h + th - 1;
+            const bool ok = zd >= 0 && zd < g.D && zh >= 0 && zh < g.H;   // uniform
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const unsigned off = (ok && lane_off[s4] != DLKA_OOB) ? lane_off[s4] + in_b + (unsigned)((zd * g.H + zh) * g.W) * 4u : DLKA_OOB;
+                o.lo[s4] = buf_load_f32x4(rin, off);
+                o.hi[s4] = buf_load_f32x4(rin, off == DLKA_OOB ? DLKA_OOB : off + 16u);
+            }
+        };
+        Raw cur, nxt;
+        request(0, cur);
+#pragma unroll
+        for (int step = 0; step < 9; ++step) {
+            if (step + 1 < 9) request(step + 1, nxt);
+            const int t0 = step * 3;
+            float el[4], er[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) { el[s4] = row_shr1(cur.hi[s4][3]); er[s4] = row_shl1(cur.lo[s4][0]); }
+#pragma unroll
+            for (int p = -1; p <= 8; ++p) {
+                float v8[8];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const float v = p < 0 ? el[s4] : (p > 7 ? er[s4] : (p < 4 ? cur.lo[s4][p < 4 && p >= 0 ? p : 0] : cur.hi[s4][p >= 4 && p < 8 ? p - 4 : 0]));
+                    v8[s4] = v; v8[4 + s4] = v;
+                }
+                bf16x8 b1, b2;   // [g_hi | g_hi], [g_lo | g_lo]  (A b2 = w_hi g_lo + w_lo g_lo: the fourth term of the product rides along)
+                split_bf16x8(v8, b1, b2);
+#pragma unroll
+                for (int tw = 0; tw < 3; ++tw) {
+                    const int q = p + 1 - tw;
+                    if (q < 0 || q > 7) continue;
+                    acc[q] = mfma_16x16x32_bf16(areg[t0 + tw], b1, acc[q]);
+                    acc[q] = mfma_16x16x32_bf16(areg[t0 + tw], b2, acc[q]);
+                }
+            }
+            cur = nxt;
+        }
+        const unsigned row = (unsigned)((d * g.H + h) * g.W);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int i = 4 * kg + r4;
+            const unsigned off = (jok && i < CO) ? (((unsigned)b * CO + i) * plane + row + 8u * j) * 4u : DLKA_OOB;
+            buf_store_f32x4(rout, off, f32x4{acc[0][r4], acc[1][r4], acc[2][r4], acc[3][r4]});
+            buf_store_f32x4(rout, off == DLKA_OOB ? DLKA_OOB : off + 16u, f32x4{acc[4][r4], acc[5][r4], acc[6][r4], acc[7][r4]});
+        }
+    }
+}
+
 static bool conv3_mfma_shape(const Geom &g)
 {
     return g.group == 1 && g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 1 && g.ph == 1 && g.pw == 1 && g.dd == 1 &&
@@ -356,8 +450,15 @@ int launch_conv_bwd_data(const T *gout, const T *w, T *gx, float *wb, const Geom
         if (conv3_row_mfma_shape(g, true)) {
             long waves;
             const int rpw = conv3_mfma_rows_per_wave(g, waves);
-            DLKA_LAUNCH(conv3_row_mfma_kernel<true>, dim3((unsigned)cdivl(waves, 4)), dim3(256), 0, st, reinterpret_cast<const float *>(gout),
-                        reinterpret_cast<const float *>(w), (const float *)nullptr, reinterpret_cast<float *>(gx), g, rpw);
+            static const bool exact = getenv("DLKA_EXACT_FP32") != nullptr;
+            static const bool b16_off = [] { const char *e = getenv("DLKA_CONV3_DGRAD_B16"); return e && e[0] == '0'; }();   // (A/B: 0 = fp32-input MFMAs)
+            if (!exact && !b16_off) {
+                DLKA_LAUNCH(conv3_row_dgrad_b16_kernel, dim3((unsigned)cdivl(waves, 4)), dim3(256), 0, st, reinterpret_cast<const float *>(gout),
+                            reinterpret_cast<const float *>(w), reinterpret_cast<float *>(gx), g, rpw);
+            } else {
+                DLKA_LAUNCH(conv3_row_mfma_kernel<true>, dim3((unsigned)cdivl(waves, 4)), dim3(256), 0, st, reinterpret_cast<const float *>(gout),
+                            reinterpret_cast<const float *>(w), (const float *)nullptr, reinterpret_cast<float *>(gx), g, rpw);
+            }
             DLKA_CHECK_LAUNCH();
             return DLKA_OK;
         }
