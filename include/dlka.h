@@ -146,7 +146,11 @@ size_t dlka_conv3d_forward_workspace(const dlka_conv_geom *g, int dtype);
 int dlka_conv3d_forward(const void *x, const void *weight, const void *bias, void *out,
                         void *workspace, size_t workspace_bytes,
                         const dlka_conv_geom *g, int dtype, void *stream);
-/* grad_x / grad_weight / grad_bias may each be NULL to skip. All are fully overwritten. */
+/* grad_x / grad_weight / grad_bias may each be NULL to skip. All are fully overwritten.
+ * Arithmetic (DLKA_F32): fp32 products and sums — except the shape the assembled net's full-resolution plumbing uses (3^3, stride 1, padding 1, group 1, <= 16 -> <= 16
+ * channels, W % 8 == 0): its grad_x (W <= 128, >= 8 output channels) and grad_weight contract on the bf16 matrix cores with BOTH operands as two bf16 terms and fp32
+ * accumulation (~1e-5 of max|gradient|, inside the 1e-3 gradient contract; the rule of the token-layout block's gradients, see dlka_lka3d_attention_tokens_backward).
+ * DLKA_EXACT_FP32=1 keeps fp32-input MFMAs there too. */
 size_t dlka_conv3d_backward_workspace(const dlka_conv_geom *g, int dtype);
 int dlka_conv3d_backward(const void *x, const void *weight, const void *grad_out,
                          void *grad_x, void *grad_weight, void *grad_bias,
