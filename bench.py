@@ -1011,7 +1011,9 @@ def main(harness=None):
             torch.cuda.empty_cache()
         if not args.no_tblock and world == 1 and dtype == torch.float32:
             try:
-                out["tblock"] = tblock_metric(args.batch, max(3, args.steps // 2), 2, dev)
+                # the side-stream weight-gradient schedule ON, as `training.initialize_network` configures the blocks for the reference trainer (and as `lka_modules` /
+                # `fullnet` below run): on round 6's final tree it measures 118.8 - 119.4 against 116.9 - 117.3 volumes/s with one stream (same box, alternating)
+                out["tblock"] = tblock_metric(args.batch, max(3, args.steps // 2), 2, dev, overlap=True)
             except Exception as e:
                 log("tblock metric failed:", repr(e))
                 out["tblock"] = None
