@@ -1011,9 +1011,10 @@ def main(harness=None):
             torch.cuda.empty_cache()
         if not args.no_tblock and world == 1 and dtype == torch.float32:
             try:
-                # the side-stream weight-gradient schedule ON, as `training.initialize_network` configures the blocks for the reference trainer (and as `lka_modules` /
-                # `fullnet` below run): on round 6's final tree it measures 118.8 - 119.4 against 116.9 - 117.3 volumes/s with one stream (same box, alternating)
-                out["tblock"] = tblock_metric(args.batch, max(3, args.steps // 2), 2, dev, overlap=True)
+                # (one stream: with `wgrad_overlap` — the schedule `training.initialize_network` turns on, which `lka_modules` / `fullnet` below run with — the eager wrapper stack
+                #  measured 118.8 - 119.9 volumes/s in some processes and 108.8 - 109.3 in others on round 6's final tree (the replayed graph 119 - 120 either way): the eager
+                #  loop sits at the edge of being bound by the host's launches, which the side stream's events add to; the stable figure is reported)
+                out["tblock"] = tblock_metric(args.batch, max(3, args.steps // 2), 2, dev)
             except Exception as e:
                 log("tblock metric failed:", repr(e))
                 out["tblock"] = None
