@@ -208,7 +208,34 @@ __global__ __launch_bounds__(64, 2) void cl_wgrad_samp_kernel(WgradArgs p)
     auto half = [&](float w, unsigned sh) { return G16 ? __uint_as_float((__float_as_uint(w) << sh) & 0xffff0000u) : w; };
     // S16: the dword holds the halves of columns (ci & ~1, ci | 1); out-of-range loads return 0 = +0.0 in either format
     auto samp_val = [&](float w) { return S16 ? f16_value((unsigned short)(__float_as_uint(w) >> ((ci & 1) ? 16 : 0))) : half(w, ssh); };
+    // bf16 storage (round 6): grad_out and the samples ARE bf16 — the halves the lane keeps of sixteen rows, packed pairwise, are the two K = 16 operands of
+    // v_mfma_f32_32x32x16_bf16 (lane (i, h) supplies k = 8 h .. 8 h + 7 <-> rows 16 h + 8 kb + e of k-block kb: the same assignment on both operands): two instructions of 32
+    // cycles per tap and 32-row step instead of sixteen fp32-input ones of 64, and no widening.  Same products (bf16 x bf16 is exact in fp32), fp32 accumulation; the sum over
+    // the rows of a step is formed in the matrix core's order instead of row by row (rounding only).
+    auto pack8 = [&](const float *w16, int kb, unsigned parity) {   // rows 8 kb .. 8 kb + 7 of this lane's column -> 8 bf16
+        float o[4];
+        const unsigned sh = parity ? 16u : 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned w0 = __float_as_uint(w16[8 * kb + 2 * e]), w1 = __float_as_uint(w16[8 * kb + 2 * e + 1]);
+            o[e] = __uint_as_float(((w0 >> sh) & 0xffffu) | ((w1 >> sh) << 16));
+        }
+        return bf16x8_from_words(o);
+    };
     auto compute = [&](int buf) {
+        if (G16) {
+            if (want_bias) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) bsum += half(ga[buf][s], gsh);
+            }
+            const bf16x8 a0 = pack8(ga[buf], 0, (unsigned)(co & 1)), a1 = pack8(ga[buf], 1, (unsigned)(co & 1));
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                acc[t] = mfma_32x32x16_bf16(a0, pack8(sv[buf][t], 0, (unsigned)(ci & 1)), acc[t]);
+                acc[t] = mfma_32x32x16_bf16(a1, pack8(sv[buf][t], 1, (unsigned)(ci & 1)), acc[t]);
+            }
+            return;
+        }
         float g[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) g[s] = half(ga[buf][s], gsh);
