@@ -76,6 +76,7 @@ struct WgradArgs {
     const float *off;   // AMODE 1: planar offsets [B][3K][N]
     const float *samp;  // AMODE 1, optional: [K][M][Cin] samples (fp32; bf16 when act_bf16) stored by cl_deform_goff2_kernel (DeformBwdArgs::samp) — no gather
     int samp_f16;       // fp32 activations only: the samples are IEEE halves (DeformBwdArgs::samp_f16)
+    int samp_b16mfma;   // ... and the contraction runs on the bf16 matrix cores with two-term operands (DLKA_SAMP_B16MFMA, A/B)
     float *part;        // [chunks][K][CoutP][Cin] partial weight-gradient tiles, followed by [chunks][CoutP] partial bias sums
     float *bpart;       // = part + chunks*K*CoutP*Cin when the bias gradient is wanted, else null (set by the launcher)
     int B, D, H, W, N, M;

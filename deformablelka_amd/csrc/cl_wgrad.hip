@@ -154,9 +154,10 @@ __global__ __launch_bounds__(64) void cl_wgrad_deform_kernel(WgradArgs p)
 // ---------------------------------------------------------------------------------------------------------------------
 // S16 (T = float only, round 6): the samples are IEEE halves (WgradArgs::samp_f16) — half the bytes this HBM-bound stream reads; grad_out, the products (fp32-input MFMA on the
 // widened sample) and the accumulation stay fp32.
-template <int TPW, typename T = float, bool S16 = false>   // T: storage of the channels-last `g`
+template <int TPW, typename T = float, bool S16 = false, bool B16M = false>   // T: storage of the channels-last `g`; B16M (S16 only): the contraction on the bf16 matrix cores
 __global__ __launch_bounds__(64, 2) void cl_wgrad_samp_kernel(WgradArgs p)
 {
+    static_assert(!B16M || S16, "B16M is a variant of the half-sample kernel");
     static_assert(!S16 || sizeof(T) == 4, "half samples belong to the fp32 path");
     constexpr unsigned XB = sizeof(T);
     constexpr unsigned SB = S16 ? 2u : XB;   // bytes of a stored sample
@@ -242,6 +243,26 @@ __global__ __launch_bounds__(64, 2) void cl_wgrad_samp_kernel(WgradArgs p)
         if (want_bias) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) bsum += g[s];
+        }
+        if (B16M) {   // fp32 grad_out x half samples on the bf16 matrix cores: both as two bf16 terms (a half's 11 significant bits are EXACTLY hi + lo)
+            bf16x8 gh[2], gl[2];
+            split_bf16x8(g, gh[0], gl[0]);
+            split_bf16x8(g + 8, gh[1], gl[1]);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                float sf[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) sf[s] = samp_val(sv[buf][t][s]);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    bf16x8 sh, sl;
+                    split_bf16x8(sf + 8 * kb, sh, sl);
+                    acc[t] = mfma_32x32x16_bf16(gl[kb], sh, acc[t]);
+                    acc[t] = mfma_32x32x16_bf16(gh[kb], sl, acc[t]);
+                    acc[t] = mfma_32x32x16_bf16(gh[kb], sh, acc[t]);
+                }
+            }
+            return;
         }
 #pragma unroll
         for (int t = 0; t < TPW; ++t)
@@ -768,6 +789,7 @@ int launch_cl_wgrad(int amode, int gmode, WgradArgs a, T *gw, T *gb, hipStream_t
         if (a.samp) {   // samples stored by the grad_offset kernel: dense stream, no gather
             if (pl.tpw != 3 || (long)a.K * a.M * a.Cin * (a.act_bf16 ? 2 : 4) >= (1l << 31)) return DLKA_ERR_UNSUPPORTED;   // 32-bit buffer offsets below DLKA_OOB
             if (a.act_bf16) { auto k = cl_wgrad_samp_kernel<3, bf16_t>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
+            else if (a.samp_f16 && a.samp_b16mfma) { auto k = cl_wgrad_samp_kernel<3, float, true, true>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
             else if (a.samp_f16) { auto k = cl_wgrad_samp_kernel<3, float, true>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
             else { auto k = cl_wgrad_samp_kernel<3>; DLKA_LAUNCH(k, grid, block, 0, st, a); }
         }

@@ -464,6 +464,10 @@ int deform_backward(const SameConv &s, const float *x, const float *off, const f
         memset(&a, 0, sizeof(a));
         a.g = gout; a.in = x; a.off = off; a.part = part; a.samp = samp;
         a.samp_f16 = (samp && samp_f16(s)) ? 1 : 0;
+        {   // DLKA_SAMP_B16MFMA=0: the half samples widened onto fp32-input MFMAs (round 6's first form); read once
+            static const bool b16 = [] { const char *e = getenv("DLKA_SAMP_B16MFMA"); return !(e && e[0] == '0'); }();
+            a.samp_b16mfma = (a.samp_f16 && b16) ? 1 : 0;
+        }
         a.B = s.B; a.D = s.D; a.H = s.H; a.W = s.W; a.N = s.N; a.M = s.M; a.Cin = s.Cin; a.Cout = s.Cout;
         a.kd = s.kd; a.kh = s.kh; a.kw = s.kw; a.pd = s.pd; a.ph = s.ph; a.pw = s.pw; a.dd = s.dd; a.dh = s.dh; a.dw = s.dw; a.K = s.K;
         a.act_bf16 = s.act_bf16;
