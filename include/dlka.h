@@ -293,8 +293,9 @@ int dlka_ndhwc_to_ncdhw(const void *src, void *dst, int B, int C, int N, int dty
  *     DLKA_F32   everything fp32 storage and fp32 accumulation (the parity path: 1e-4 forward, 1e-3 gradients against the reference).  ARITHMETIC of the contractions:
  *                the FORWARD deformable conv and the pointwise convs run on the fp32-input MFMA (exact fp32 products); the forward offset-predict conv as a THREE-term
  *                bf16 split (six products per fp32 product: fp32-equivalent — its output decides floor()); the BACKWARD contractions of the deformable conv (Col of
- *                grad_offset / grad_input) and the offset conv's data / weight gradients as TWO-term bf16 splits (three products, fp32 accumulation, ~1e-5 relative:
- *                inside the 1e-3 gradient contract).  DLKA_EXACT_FP32=1 (environment, read once) puts every contraction on the fp32-input MFMA;
+ *                grad_offset / grad_input), its WEIGHT gradient (fp32 grad_out x the samples grad_offset handed over as IEEE halves — a half is exactly two bf16 terms)
+ *                and the offset conv's data / weight gradients as TWO-term bf16 splits (three products, fp32 accumulation, ~1e-5 relative: inside the 1e-3 gradient
+ *                contract).  DLKA_EXACT_FP32=1 (environment, read once) puts every contraction on the fp32-input MFMA (and keeps the samples fp32);
  *     DLKA_BF16  x, y, grad_y, grad_x and every saved / intermediate activation are bf16 STORAGE; parameters (dlka_lka3d_params), their
  *                gradients, the predicted offsets, grad_offset and all accumulation are fp32.  The offset-predict conv runs single bf16
  *                MFMA products against two-term (fp32-exact) weights.  The reference registers no autocast policy and would raise on half
